@@ -1,0 +1,286 @@
+/* mjpcx.h -- C ABI of the MI355X rollout-and-evaluate library (libmjpcx.so).
+ *
+ * This is the drop-in boundary for the batched rollout hot path of
+ * google-deepmind/mujoco_mpc: everything the reference does between
+ * `SamplingPlanner::Rollouts` (mjpc/planners/sampling/planner.cc:355-393) and
+ * the `partial_sort` on total_return (planner.cc:184-188), i.e. N x
+ * `Trajectory::Rollout` (mjpc/trajectory.cc:92-210) + `UpdateReturn`
+ * (trajectory.cc:312-326), runs behind these entry points on one gfx950 GPU.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success, a negative MJPCX_E* code otherwise;
+ *     no exceptions cross the boundary; `mjpcx_error_string` maps codes.
+ *   - the caller owns all host buffers; the library owns device buffers inside
+ *     the opaque context and deep-copies model/task at create time.
+ *   - calls on ONE context are serialised by the caller (the planning thread,
+ *     cf. mjpc/agent.cc:283-357); different contexts are independent.
+ *   - all host-side reals are fp64 (mjtNum=double in the reference), whatever
+ *     precision the device kernels compute in.
+ */
+#ifndef MJPCX_H_
+#define MJPCX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJPCX_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+enum {
+  MJPCX_OK = 0,
+  MJPCX_EINVAL = -1,       /* bad argument / size mismatch                   */
+  MJPCX_EUNSUPPORTED = -2, /* model feature / size has no device kernel      */
+  MJPCX_EDEVICE = -3,      /* HIP runtime error (see mjpcx_last_hip_error)   */
+  MJPCX_ENOMEM = -4,       /* host or device allocation failed               */
+  MJPCX_ESTATE = -5,       /* call out of order (e.g. fetch before rollout)  */
+};
+
+/* ---- enums shared with the reference ------------------------------------ */
+/* mjtJoint (MuJoCo) */
+enum { MJPCX_JNT_FREE = 0, MJPCX_JNT_BALL = 1, MJPCX_JNT_SLIDE = 2, MJPCX_JNT_HINGE = 3 };
+/* mjtIntegrator (MuJoCo): only Euler (with implicit joint damping) and RK4 */
+enum { MJPCX_INT_EULER = 0, MJPCX_INT_RK4 = 1 };
+/* mjpc::spline::SplineInterpolation, mjpc/spline/spline.h:29-33 */
+enum { MJPCX_SPLINE_ZERO = 0, MJPCX_SPLINE_LINEAR = 1, MJPCX_SPLINE_CUBIC = 2 };
+/* mjpc::NormType, mjpc/norm.h:24-35 */
+enum {
+  MJPCX_NORM_NULL = -1, MJPCX_NORM_QUADRATIC = 0, MJPCX_NORM_L22 = 1, MJPCX_NORM_L2 = 2,
+  MJPCX_NORM_COSH = 3, MJPCX_NORM_POWER_LOSS = 5, MJPCX_NORM_SMOOTH_ABS = 6,
+  MJPCX_NORM_SMOOTH_ABS2 = 7, MJPCX_NORM_RECTIFY = 8,
+};
+/* actuator gain / bias types (mjtGain / mjtBias subset) */
+enum { MJPCX_GAIN_FIXED = 0 };
+enum { MJPCX_BIAS_NONE = 0, MJPCX_BIAS_AFFINE = 1 };
+/* opt.disableflags bits used by the hot path (MuJoCo mjtDisableBit subset) */
+enum {
+  MJPCX_DSBL_CONSTRAINT = 1 << 0, MJPCX_DSBL_LIMIT = 1 << 3, MJPCX_DSBL_CONTACT = 1 << 4,
+  MJPCX_DSBL_PASSIVE = 1 << 5, MJPCX_DSBL_GRAVITY = 1 << 6, MJPCX_DSBL_CLAMPCTRL = 1 << 7,
+  MJPCX_DSBL_ACTUATION = 1 << 10, MJPCX_DSBL_REFSAFE = 1 << 11, MJPCX_DSBL_EULERDAMP = 1 << 14,
+};
+
+/* Device residual functions = the `ResidualFn::Residual` overrides of the
+ * reference tasks, resolved to an id at task-bake time. */
+enum {
+  MJPCX_RESIDUAL_PARTICLE = 1,      /* mjpc/test/testdata/particle_residual.h:33-43   */
+  MJPCX_RESIDUAL_PARTICLE_COPY = 2, /* mjpc/test/agent/rollout_test.cc:37-42          */
+  MJPCX_RESIDUAL_CARTPOLE = 3,      /* mjpc/tasks/cartpole/cartpole.cc:36-49          */
+};
+
+/* ---- flat model ("mjModel" subset, compiled) ----
+ * Array sizes are given next to each pointer. All arrays are host memory,
+ * row-major, and are deep-copied by mjpcx_create. */
+typedef struct mjpcx_model {
+  /* sizes */
+  int32_t nq, nv, nu, na, nbody, njnt, nsite, nmocap, nuserdata;
+  /* options (mjOption) */
+  double timestep;
+  double gravity[3];
+  int32_t integrator;   /* MJPCX_INT_*                                        */
+  int32_t disableflags; /* MJPCX_DSBL_* bits                                  */
+  int32_t solver_iterations; /* opt.iterations (default 100)                  */
+  double solver_tolerance;   /* opt.tolerance (default 1e-8)                  */
+  double meaninertia;        /* stat.meaninertia                              */
+  /* bodies (nbody, body 0 = world) */
+  const int32_t* body_parentid; /* nbody */
+  const int32_t* body_rootid;   /* nbody */
+  const int32_t* body_jntnum;   /* nbody */
+  const int32_t* body_jntadr;   /* nbody (-1: none) */
+  const int32_t* body_dofnum;   /* nbody */
+  const int32_t* body_dofadr;   /* nbody (-1: none) */
+  const int32_t* body_mocapid;  /* nbody (-1: not mocap) */
+  const double* body_pos;       /* nbody x 3 */
+  const double* body_quat;      /* nbody x 4 */
+  const double* body_ipos;      /* nbody x 3 */
+  const double* body_iquat;     /* nbody x 4 */
+  const double* body_mass;      /* nbody */
+  const double* body_inertia;   /* nbody x 3 */
+  /* joints (njnt) */
+  const int32_t* jnt_type;    /* njnt */
+  const int32_t* jnt_qposadr; /* njnt */
+  const int32_t* jnt_dofadr;  /* njnt */
+  const int32_t* jnt_bodyid;  /* njnt */
+  const int32_t* jnt_limited; /* njnt */
+  const double* jnt_pos;      /* njnt x 3 */
+  const double* jnt_axis;     /* njnt x 3 */
+  const double* jnt_stiffness;/* njnt */
+  const double* jnt_range;    /* njnt x 2 */
+  const double* jnt_margin;   /* njnt */
+  const double* jnt_solref;   /* njnt x 2 */
+  const double* jnt_solimp;   /* njnt x 5 */
+  /* dofs (nv) */
+  const int32_t* dof_bodyid;   /* nv */
+  const int32_t* dof_jntid;    /* nv */
+  const int32_t* dof_parentid; /* nv (-1: none) */
+  const double* dof_armature;  /* nv */
+  const double* dof_damping;   /* nv */
+  const double* dof_frictionloss; /* nv */
+  const double* dof_invweight0;   /* nv */
+  /* reference configuration */
+  const double* qpos0;       /* nq */
+  const double* qpos_spring; /* nq */
+  /* sites (nsite) */
+  const int32_t* site_bodyid; /* nsite */
+  const double* site_pos;     /* nsite x 3 */
+  const double* site_quat;    /* nsite x 4 */
+  /* actuators (nu): joint transmission only */
+  const int32_t* actuator_trnid;      /* nu: joint id */
+  const int32_t* actuator_gaintype;   /* nu */
+  const int32_t* actuator_biastype;   /* nu */
+  const int32_t* actuator_ctrllimited;  /* nu */
+  const int32_t* actuator_forcelimited; /* nu */
+  const double* actuator_gear;       /* nu (gear[0]) */
+  const double* actuator_gainprm;    /* nu x 3 */
+  const double* actuator_biasprm;    /* nu x 3 */
+  const double* actuator_ctrlrange;  /* nu x 2 */
+  const double* actuator_forcerange; /* nu x 2 */
+} mjpcx_model;
+
+/* ---- task / cost specification (mjpc::Task after Task::Reset,
+ * mjpc/task.cc:147-248, plus the frozen ResidualFn copy of agent.cc:319) ---- */
+#define MJPCX_MAX_COST_TERMS 128 /* kMaxCostTerms, mjpc/task.h:31 */
+typedef struct mjpcx_task {
+  int32_t residual_id;  /* MJPCX_RESIDUAL_*                                   */
+  int32_t num_residual; /* Task::num_residual                                 */
+  int32_t num_term;     /* Task::num_term                                     */
+  int32_t num_trace;    /* Task::num_trace                                    */
+  int32_t num_parameter;/* Task::parameters.size()                            */
+  const int32_t* dim_norm_residual;  /* num_term */
+  const int32_t* norm;               /* num_term, MJPCX_NORM_* */
+  const int32_t* num_norm_parameter; /* num_term */
+  const double* weight;              /* num_term */
+  const double* norm_parameter;      /* sum(num_norm_parameter) */
+  const double* parameters;          /* num_parameter (residual_* numerics) */
+  const int32_t* trace_site;         /* num_trace: site id of sensor "trace%i" */
+  double risk;                       /* Task::risk */
+} mjpcx_task;
+
+/* ---- outputs ---------------------------------------------------------------
+ * One candidate trajectory in the reference's own layout (mjpc::Trajectory,
+ * mjpc/trajectory.h:74-86): row-major by time. Any pointer may be NULL to skip
+ * that buffer. */
+typedef struct mjpcx_traj_view {
+  int32_t horizon;   /* in: capacity in steps; out: trajectory length         */
+  double* states;    /* horizon x dim_state                                   */
+  double* actions;   /* horizon x nu                                          */
+  double* times;     /* horizon                                               */
+  double* residual;  /* horizon x num_residual                                */
+  double* costs;     /* horizon                                               */
+  double* trace;     /* horizon x 3*num_trace                                 */
+  double total_return; /* out */
+  int32_t failure;     /* out */
+} mjpcx_traj_view;
+
+/* Noise specification for device-side candidate generation: the counter-based
+ * replacement of the function-local absl::BitGen in
+ * SamplingPlanner::AddNoiseToPolicy (sampling/planner.cc:326-352) and
+ * CrossEntropyPlanner::AddNoiseToPolicy (cross_entropy/planner.cc:351-385).
+ * Philox4x32-10, key = (seed_lo, seed_hi), counter = (i, c, iteration, stream)
+ * for global candidate i. stream 0: the four words of counter c give two 53-bit
+ * uniforms u1,u2 in (0,1) and Box-Muller gives z0 = sqrt(-2 ln u1) cos(2 pi u2),
+ * z1 = ... sin(...); parameter j = node*nu + actuator uses pair c = j/2, z(j%2).
+ * stream 1, c = 0: u1 < 0.2 is the per-candidate Bernoulli choosing std1. */
+enum {
+  /* sigma(k) = 0.5*(ctrlrange_hi-lo)(k) * std, std = std0, or std1 w.p. 0.2 per
+   * candidate when std1 > 0 (sampling/planner.cc:331-345) */
+  MJPCX_NOISE_SAMPLING = 0,
+  /* sigma(j) = max(sqrt(param_variance[j]), floor), floor = std0 (std_initial)
+   * for global candidates < explore_count, else std1 (std_min); not scaled by
+   * ctrlrange (cross_entropy/planner.cc:351-385, 399-405) */
+  MJPCX_NOISE_CROSS_ENTROPY = 1,
+};
+typedef struct mjpcx_noise_spec {
+  uint64_t seed;
+  uint32_t iteration;        /* plan-iteration counter                          */
+  int32_t mode;              /* MJPCX_NOISE_*                                   */
+  int32_t candidate_offset;  /* global index of local candidate 0 (rank sharding) */
+  int32_t nominal_candidate; /* global candidate left un-noised (PS: 0, planner.cc:374); -1: none (CE) */
+  int32_t explore_count;     /* CE only                                         */
+  double std0;
+  double std1;
+  const double* param_variance; /* CE only: P*nu                                */
+} mjpcx_noise_spec;
+
+typedef struct mjpcx_ctx mjpcx_ctx;
+
+/* ---- lifecycle --------------------------------------------------------------
+ * precision: 64 (fp64, the reference's mjtNum) or 32. Replaces
+ * Planner::Initialize/Allocate/ResizeMjData (planners/planner.cc:23-33). */
+int mjpcx_create(const mjpcx_model* model, const mjpcx_task* task, int device,
+                 int precision, mjpcx_ctx** out);
+void mjpcx_destroy(mjpcx_ctx* ctx);
+const char* mjpcx_create_error(void); /* detail of the calling thread's last failed mjpcx_create */
+const char* mjpcx_error_string(int code);
+const char* mjpcx_last_error(const mjpcx_ctx* ctx); /* detail of last failure */
+const char* mjpcx_kernel_name(const mjpcx_ctx* ctx); /* rollout kernel variant */
+
+/* Planner::SetState (sampling/planner.cc:150-153, State::CopyTo
+ * states/state.cc:128-135): state = [qpos,qvel,act], mocap = 7*nmocap. */
+int mjpcx_set_state(mjpcx_ctx* ctx, const double* state, double time,
+                    const double* mocap, const double* userdata);
+
+/* Per-plan frozen copy of weights/parameters (BaseResidualFn::Update,
+ * task.cc:112-123). Any pointer may be NULL to keep the current value. */
+int mjpcx_set_task_params(mjpcx_ctx* ctx, const double* weight,
+                          const double* norm_parameter, const double* parameters,
+                          double risk);
+
+/* ---- the hot path -----------------------------------------------------------
+ * Roll out N candidate spline policies for `horizon` steps from the state set
+ * by mjpcx_set_state and evaluate their returns. Equivalent to N x
+ * Trajectory::Rollout + UpdateReturn with SamplingPolicy::Action
+ * (sampling/policy.cc:52-59) as the policy. Asynchronous on the context's
+ * stream; results are read with the getters below (which synchronise).
+ *   node_times : P                (shared by all candidates)
+ *   node_values: N x P x nu       (candidate-major, each block = the reference's
+ *                                  TimeSpline values, already noised+clamped) */
+int mjpcx_rollout_splines(mjpcx_ctx* ctx, int num_candidates, int horizon,
+                          int num_nodes, int interpolation, const double* node_times,
+                          const double* node_values);
+
+/* Same, but candidates are generated on the device: nominal spline (P x nu)
+ * + clamped Gaussian noise per mjpcx_noise_spec. */
+int mjpcx_rollout_noise(mjpcx_ctx* ctx, int num_candidates, int horizon,
+                        int num_nodes, int interpolation, const double* node_times,
+                        const double* nominal_values, const mjpcx_noise_spec* noise);
+
+/* Block until everything queued on the context's stream has finished. */
+int mjpcx_sync(mjpcx_ctx* ctx);
+
+/* total_return[N], failure[N] (Trajectory::total_return / failure). */
+int mjpcx_get_returns(mjpcx_ctx* ctx, double* total_return, int32_t* failure);
+
+/* Device-side selection replacing std::partial_sort (sampling/planner.cc:184):
+ * indices and returns of the k best candidates, ascending, ties by index. */
+int mjpcx_topk(mjpcx_ctx* ctx, int k, int32_t* index, double* total_return);
+
+/* Gather one candidate into the reference's Trajectory layout. */
+int mjpcx_fetch_trajectory(mjpcx_ctx* ctx, int candidate, mjpcx_traj_view* out);
+
+/* The (noised, clamped) spline values of one candidate: P x nu. This is
+ * candidate_policy[i].plan of the reference (sampling/planner.cc:534-543). */
+int mjpcx_fetch_spline(mjpcx_ctx* ctx, int candidate, double* node_values);
+
+/* ---- measurement --------------------------------------------------------------
+ * HIP-event timing of the rollout kernel on the context's own stream.
+ * mjpcx_timing_reset zeroes the accumulators; mjpcx_timing_read synchronises and
+ * returns the summed kernel time [ms] and launch count since the reset. */
+int mjpcx_timing_reset(mjpcx_ctx* ctx);
+int mjpcx_timing_read(mjpcx_ctx* ctx, double* kernel_ms, int64_t* launches);
+
+/* Algorithmic bytes of one candidate rollout:
+ * w*[H*(dim_state+nu+1+nr+3*ntrace+1) + P*nu + P + 2]. */
+int64_t mjpcx_algorithmic_bytes(const mjpcx_ctx* ctx, int horizon, int num_nodes);
+
+/* Raw device pointers (for zero-copy wrapping, e.g. torch tensors feeding an
+ * RCCL collective). which: 0 = total_return (N x fp64), 1 = failure (N x i32). */
+int mjpcx_device_buffer(mjpcx_ctx* ctx, int which, void** ptr, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJPCX_H_ */

@@ -1,0 +1,224 @@
+"""ctypes binding of the C ABI (include/mjpcx.h) exported by libmjpcx.so.
+
+There is no fallback: if the HIP library is missing or fails to load, importing
+the binding raises. The library is built in-tree by `__graft_entry__.build()` /
+`mujoco_mpc_amd.build.build_native()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .cstructs import (MjpcxModel, MjpcxNoiseSpec, MjpcxTask, MjpcxTrajView, PackedModel, PackedTask, as_f64p,
+                       as_i32p, c_f64p, c_i32p)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmjpcx.so")
+
+SPLINE_ZERO, SPLINE_LINEAR, SPLINE_CUBIC = 0, 1, 2
+NOISE_SAMPLING, NOISE_CROSS_ENTROPY = 0, 1
+
+# every symbol include/mjpcx.h declares
+EXPORTS = [
+    "mjpcx_create", "mjpcx_destroy", "mjpcx_create_error", "mjpcx_error_string", "mjpcx_last_error",
+    "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_rollout_splines",
+    "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_topk", "mjpcx_fetch_trajectory",
+    "mjpcx_fetch_spline", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
+    "mjpcx_device_buffer",
+]
+
+_LIB = None
+
+
+class MjpcxError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__(f"mjpcx error {code} ({lib().mjpcx_error_string(code).decode()}): {detail}")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build the HIP library first "
+                              "(python -c 'import __graft_entry__ as g; g.build()')")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.mjpcx_create.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), C.c_int, C.c_int, C.POINTER(vp)]
+        L.mjpcx_destroy.argtypes = [vp]
+        L.mjpcx_destroy.restype = None
+        for f in ("mjpcx_create_error",):
+            getattr(L, f).restype = C.c_char_p
+            getattr(L, f).argtypes = []
+        L.mjpcx_error_string.restype = C.c_char_p
+        L.mjpcx_error_string.argtypes = [C.c_int]
+        L.mjpcx_last_error.restype = C.c_char_p
+        L.mjpcx_last_error.argtypes = [vp]
+        L.mjpcx_kernel_name.restype = C.c_char_p
+        L.mjpcx_kernel_name.argtypes = [vp]
+        L.mjpcx_set_state.argtypes = [vp, c_f64p, C.c_double, c_f64p, c_f64p]
+        L.mjpcx_set_task_params.argtypes = [vp, c_f64p, c_f64p, c_f64p, C.c_double]
+        L.mjpcx_rollout_splines.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p]
+        L.mjpcx_rollout_noise.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.POINTER(MjpcxNoiseSpec)]
+        L.mjpcx_sync.argtypes = [vp]
+        L.mjpcx_get_returns.argtypes = [vp, c_f64p, c_i32p]
+        L.mjpcx_topk.argtypes = [vp, C.c_int, c_i32p, c_f64p]
+        L.mjpcx_fetch_trajectory.argtypes = [vp, C.c_int, C.POINTER(MjpcxTrajView)]
+        L.mjpcx_fetch_spline.argtypes = [vp, C.c_int, c_f64p]
+        L.mjpcx_timing_reset.argtypes = [vp]
+        L.mjpcx_timing_read.argtypes = [vp, c_f64p, C.POINTER(C.c_int64)]
+        L.mjpcx_algorithmic_bytes.restype = C.c_int64
+        L.mjpcx_algorithmic_bytes.argtypes = [vp, C.c_int, C.c_int]
+        L.mjpcx_device_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        _LIB = L
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def make_noise_spec(seed=0, iteration=0, mode=NOISE_SAMPLING, candidate_offset=0, nominal_candidate=0,
+                    explore_count=0, std0=0.1, std1=0.0, param_variance=None):
+    ns = MjpcxNoiseSpec()
+    ns.seed, ns.iteration, ns.mode = int(seed), int(iteration), int(mode)
+    ns.candidate_offset, ns.nominal_candidate, ns.explore_count = int(candidate_offset), int(nominal_candidate), int(explore_count)
+    ns.std0, ns.std1 = float(std0), float(std1)
+    keep = None
+    if param_variance is not None:
+        keep = _f(param_variance).reshape(-1)
+        ns.param_variance = as_f64p(keep)
+    ns._keep = keep
+    return ns
+
+
+class Trajectory:
+    """mjpc::Trajectory buffers in the reference layout (mjpc/trajectory.h:74-86)."""
+
+    def __init__(self, dim_state, nu, nr, ntrace, horizon):
+        self.horizon = horizon
+        self.dim_state, self.dim_action, self.dim_residual, self.dim_trace = dim_state, nu, nr, 3 * ntrace
+        self.states = np.zeros((horizon, dim_state))
+        self.actions = np.zeros((horizon, nu))
+        self.times = np.zeros(horizon)
+        self.residual = np.zeros((horizon, nr))
+        self.costs = np.zeros(horizon)
+        self.trace = np.zeros((horizon, 3 * ntrace))
+        self.total_return = 0.0
+        self.failure = False
+
+
+class Context:
+    """One (model, task, device) rollout context = `mjpcx_ctx`."""
+
+    def __init__(self, packed_model: PackedModel, packed_task: PackedTask, device=0, precision=64):
+        self._pm, self._pt = packed_model, packed_task
+        self.handle = C.c_void_p()
+        rc = lib().mjpcx_create(packed_model.ptr, packed_task.ptr, int(device), int(precision), C.byref(self.handle))
+        if rc != 0:
+            raise MjpcxError(rc, lib().mjpcx_create_error().decode())
+        m, t = packed_model.struct, packed_task.struct
+        self.nq, self.nv, self.nu, self.na = m.nq, m.nv, m.nu, m.na
+        self.dim_state = m.nq + m.nv + m.na
+        self.num_residual, self.num_trace = t.num_residual, t.num_trace
+        self.precision = precision
+        self.device = device
+        self.N = self.H = self.P = 0
+
+    def close(self):
+        if self.handle:
+            lib().mjpcx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MjpcxError(rc, lib().mjpcx_last_error(self.handle).decode())
+
+    @property
+    def kernel_name(self):
+        return lib().mjpcx_kernel_name(self.handle).decode()
+
+    def set_state(self, state, time=0.0, mocap=None, userdata=None):
+        st = _f(state)
+        assert st.size == self.dim_state
+        mc = None if mocap is None else as_f64p(_f(mocap))
+        ud = None if userdata is None else as_f64p(_f(userdata))
+        self._chk(lib().mjpcx_set_state(self.handle, as_f64p(st), float(time), mc, ud))
+
+    def set_task_params(self, weight=None, norm_parameter=None, parameters=None, risk=0.0):
+        w = None if weight is None else as_f64p(_f(weight))
+        n = None if norm_parameter is None else as_f64p(_f(norm_parameter))
+        p = None if parameters is None else as_f64p(_f(parameters))
+        self._chk(lib().mjpcx_set_task_params(self.handle, w, n, p, float(risk)))
+
+    def rollout_splines(self, horizon, interp, node_times, node_values):
+        nt = _f(node_times)
+        nv = _f(node_values)
+        P = nt.size
+        N = nv.size // (P * self.nu)
+        assert nv.size == N * P * self.nu
+        self._chk(lib().mjpcx_rollout_splines(self.handle, N, int(horizon), P, int(interp), as_f64p(nt), as_f64p(nv)))
+        self.N, self.H, self.P = N, int(horizon), P
+
+    def rollout_noise(self, num_candidates, horizon, interp, node_times, nominal, noise_spec):
+        nt, nom = _f(node_times), _f(nominal)
+        P = nt.size
+        assert nom.size == P * self.nu
+        self._chk(lib().mjpcx_rollout_noise(self.handle, int(num_candidates), int(horizon), P, int(interp),
+                                            as_f64p(nt), as_f64p(nom), C.byref(noise_spec)))
+        self.N, self.H, self.P = int(num_candidates), int(horizon), P
+
+    def sync(self):
+        self._chk(lib().mjpcx_sync(self.handle))
+
+    def returns(self):
+        ret = np.zeros(self.N)
+        fl = np.zeros(self.N, np.int32)
+        self._chk(lib().mjpcx_get_returns(self.handle, as_f64p(ret), as_i32p(fl)))
+        return ret, fl
+
+    def topk(self, k):
+        idx = np.zeros(k, np.int32)
+        ret = np.zeros(k)
+        self._chk(lib().mjpcx_topk(self.handle, int(k), as_i32p(idx), as_f64p(ret)))
+        return idx, ret
+
+    def fetch_trajectory(self, candidate) -> Trajectory:
+        tr = Trajectory(self.dim_state, self.nu, self.num_residual, self.num_trace, self.H)
+        v = MjpcxTrajView()
+        v.horizon = self.H
+        v.states, v.actions, v.times = as_f64p(tr.states), as_f64p(tr.actions), as_f64p(tr.times)
+        v.residual, v.costs, v.trace = as_f64p(tr.residual), as_f64p(tr.costs), as_f64p(tr.trace)
+        self._chk(lib().mjpcx_fetch_trajectory(self.handle, int(candidate), C.byref(v)))
+        tr.total_return, tr.failure = v.total_return, bool(v.failure)
+        return tr
+
+    def fetch_spline(self, candidate):
+        out = np.zeros((self.P, self.nu))
+        self._chk(lib().mjpcx_fetch_spline(self.handle, int(candidate), as_f64p(out)))
+        return out
+
+    def timing_reset(self):
+        self._chk(lib().mjpcx_timing_reset(self.handle))
+
+    def timing_read(self):
+        ms = C.c_double()
+        n = C.c_int64()
+        self._chk(lib().mjpcx_timing_read(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def algorithmic_bytes(self, horizon, num_nodes):
+        return lib().mjpcx_algorithmic_bytes(self.handle, int(horizon), int(num_nodes))
+
+    def device_buffer(self, which):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._chk(lib().mjpcx_device_buffer(self.handle, int(which), C.byref(p), C.byref(n)))
+        return p.value, n.value

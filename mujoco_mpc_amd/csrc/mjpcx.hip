@@ -1,0 +1,775 @@
+// mjpcx.hip -- implementation of the C ABI in include/mjpcx.h for gfx950.
+//
+// Host side of the drop-in boundary: validates the flat model, selects the rollout kernel
+// instantiation whose static topology matches it, owns all device buffers, and exposes
+// results in the reference's Trajectory layout. No CPU fallback exists: if no kernel
+// matches the model, mjpcx_create fails with MJPCX_EUNSUPPORTED.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mjpcx.h"
+#include "rollout_lane.h"
+
+using namespace mjpcx;
+
+// ===================================================================== kernel registry
+namespace {
+
+constexpr uint64_t pack4() { return 0; }
+template <typename... R> constexpr uint64_t pack4(int a, R... r) { return (uint64_t)(a & 15) | (pack4(r...) << 4); }
+constexpr uint64_t pack2() { return 0; }
+template <typename... R> constexpr uint64_t pack2(int a, R... r) { return (uint64_t)(a & 3) | (pack2(r...) << 2); }
+
+// Cart-pole (mjpc/tasks/cartpole): world -> cart[slide x, limited] -> pole_1[hinge y]; site tip on pole
+using TopoCartpole = Topo</*NB*/3, /*NV*/2, /*NU*/1, /*NSITE*/1, /*NMOCAP*/0,
+                          /*parent*/pack4(0, 0, 1), /*mocap*/pack4(15, 15, 15), /*jtype*/pack2(kJntSlide, kJntHinge),
+                          /*jbody*/pack4(1, 2), /*jlimited*/0x1, /*actj*/pack4(0), /*siteb*/pack4(2)>;
+using TaskCartpole = TaskTopo<MJPCX_RESIDUAL_CARTPOLE, 4, 4, pack4(1, 1, 1, 1), 1, pack4(0)>;
+// Particle (mjpc/test/testdata/particle.xml): world -> goal[mocap]; world -> pointmass[slide x, slide y]
+using TopoParticle = Topo<3, 2, 2, 1, 1, pack4(0, 0, 0), pack4(15, 0, 15), pack2(kJntSlide, kJntSlide),
+                          pack4(2, 2), 0x3, pack4(0, 1), pack4(2)>;
+using TaskParticle = TaskTopo<MJPCX_RESIDUAL_PARTICLE, 4, 2, pack4(2, 2), 1, pack4(0)>;
+using TaskParticleCopy = TaskTopo<MJPCX_RESIDUAL_PARTICLE_COPY, 4, 2, pack4(2, 2), 1, pack4(0)>;
+
+struct TopoKey {
+  int nb, nv, nu, nsite, nmocap;
+  uint64_t parent, mocap, jtype, jbody, jlimited, actj, siteb;
+  bool operator==(const TopoKey& o) const {
+    return nb == o.nb && nv == o.nv && nu == o.nu && nsite == o.nsite && nmocap == o.nmocap && parent == o.parent &&
+           mocap == o.mocap && jtype == o.jtype && jbody == o.jbody && jlimited == o.jlimited && actj == o.actj &&
+           siteb == o.siteb;
+  }
+};
+struct TaskKey {
+  int rid, nr, nterm, ntrace;
+  uint64_t termdim, tracesite;
+  bool operator==(const TaskKey& o) const {
+    return rid == o.rid && nr == o.nr && nterm == o.nterm && ntrace == o.ntrace && termdim == o.termdim &&
+           tracesite == o.tracesite;
+  }
+};
+template <class TP> constexpr TopoKey topo_key() {
+  return {TP::NB, TP::NV, TP::NU, TP::NSITE, TP::NMOCAP, TP::kParent, TP::kMocap, TP::kJtype,
+          TP::kJbody, TP::kJlimited, TP::kActj, TP::kSiteb};
+}
+template <class TK> constexpr TaskKey task_key() {
+  return {TK::RID, TK::NR, TK::NTERM, TK::NTRACE, TK::kTermDim, TK::kTraceSite};
+}
+
+template <class TP, class TK, typename T>
+hipError_t launch_lane(const RolloutArgs<T>& a, hipStream_t s) {
+  const int blocks = (a.N + 63) / 64;
+  const size_t shmem = (size_t)a.P * TP::NU * 64 * sizeof(T);
+  hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T>), dim3(blocks), dim3(64), shmem, s, a);
+  return hipGetLastError();
+}
+
+struct KernelEntry {
+  const char* name;
+  TopoKey topo;
+  TaskKey task;
+  hipError_t (*launch64)(const RolloutArgs<double>&, hipStream_t);
+  hipError_t (*launch32)(const RolloutArgs<float>&, hipStream_t);
+};
+#define MJPCX_LANE_ENTRY(TP, TK) \
+  { "rollout_lane<" #TP "," #TK ">", topo_key<TP>(), task_key<TK>(), &launch_lane<TP, TK, double>, &launch_lane<TP, TK, float> }
+const KernelEntry kKernels[] = {
+    MJPCX_LANE_ENTRY(TopoCartpole, TaskCartpole),
+    MJPCX_LANE_ENTRY(TopoParticle, TaskParticle),
+    MJPCX_LANE_ENTRY(TopoParticle, TaskParticleCopy),
+};
+
+// ===================================================================== small kernels
+// argmin / top-k over total_return: replaces std::partial_sort (sampling/planner.cc:184-188).
+// Keys are (return, index) with ties broken by index, so the result is deterministic.
+struct RetIdx { double r; int i; };
+__device__ __forceinline__ bool less_ri(const RetIdx& a, const RetIdx& b) {
+  // NaN returns sort last (the reference's operator< would make the order unspecified)
+  const bool an = a.r != a.r, bn = b.r != b.r;
+  if (an != bn) return bn;
+  if (a.r != b.r && !an) return a.r < b.r;
+  return a.i < b.i;
+}
+__global__ __launch_bounds__(1024) void argmin_kernel(const double* __restrict__ ret, int n, RetIdx* out) {
+  __shared__ RetIdx sm[16];
+  RetIdx best{INFINITY, 0x7fffffff};
+  best.r = ret[0] != ret[0] ? ret[0] : INFINITY;  // keep NaN ordering consistent when everything is NaN
+  best.i = 0x7fffffff;
+  bool have = false;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    RetIdx c{ret[i], i};
+    if (!have || less_ri(c, best)) { best = c; have = true; }
+  }
+  if (!have) { best.r = NAN; best.i = 0x7fffffff; }
+  // wave-level reduction over 64 lanes
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    RetIdx o;
+    o.r = __shfl_down(best.r, off, 64);
+    o.i = __shfl_down(best.i, off, 64);
+    if (less_ri(o, best)) best = o;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sm[wave] = best;
+  __syncthreads();
+  if (wave == 0) {
+    const int nw = blockDim.x >> 6;
+    best = lane < nw ? sm[lane] : RetIdx{NAN, 0x7fffffff};
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      RetIdx o;
+      o.r = __shfl_down(best.r, off, 64);
+      o.i = __shfl_down(best.i, off, 64);
+      if (less_ri(o, best)) best = o;
+    }
+    if (lane == 0) out[0] = best;
+  }
+}
+// single-workgroup bitonic sort of (return, index) pairs in global memory (n2 = pow2 >= n)
+__global__ __launch_bounds__(1024) void sort_kernel(const double* __restrict__ ret, int n, int n2, RetIdx* buf) {
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) buf[i] = i < n ? RetIdx{ret[i], i} : RetIdx{NAN, 0x7fffffff};
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          RetIdx a = buf[i], b = buf[l];
+          if (less_ri(b, a) == up) { buf[i] = b; buf[l] = a; }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+}
+
+// gather one candidate out of the [t][field][candidate] SoA into a packed row-major staging
+// buffer: [states H*DS | actions H*NU | times H | residual H*NR | costs H | trace H*3*NTR]
+template <typename T>
+__global__ void gather_traj_kernel(const T* states, const T* actions, const T* times, const T* residual,
+                                   const T* costs, const T* trace, int N, int H, int ds, int nu, int nr, int ntr3,
+                                   int cand, double* out) {
+  const int row = ds + nu + 1 + nr + 1 + ntr3;
+  const int total = H * row;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    // i indexes the packed output
+    int o = i;
+    const T* src; int width;
+    if (o < H * ds) { src = states; width = ds; }
+    else if ((o -= H * ds) < H * nu) { src = actions; width = nu; }
+    else if ((o -= H * nu) < H) { src = times; width = 1; }
+    else if ((o -= H) < H * nr) { src = residual; width = nr; }
+    else if ((o -= H * nr) < H) { src = costs; width = 1; }
+    else { o -= H; src = trace; width = ntr3; }
+    out[i] = (double)src[(size_t)o * N + cand];  // o = t*width + k  ->  [(t*width+k)*N + cand]
+    (void)width;
+  }
+}
+template <typename T>
+__global__ void gather_spline_kernel(const T* nodes, int N, int np, int cand, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np) out[i] = (double)nodes[(size_t)i * N + cand];
+}
+template <typename T>
+__global__ void scatter_nodes_kernel(const double* __restrict__ in, T* nodes, int N, int np) {
+  // in: candidate-major [N][np] (the reference's per-candidate TimeSpline values) -> [np][N]
+  const size_t total = (size_t)N * np;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t j = i / N, c = i % N;
+    nodes[i] = (T)in[c * np + j];
+  }
+}
+
+}  // namespace
+
+// ===================================================================== context
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct mjpcx_ctx {
+  int device = 0, precision = 64;
+  const KernelEntry* kernel = nullptr;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  // model/task dims
+  int nq = 0, nv = 0, nu = 0, na = 0, nmocap = 0, nr = 0, nterm = 0, ntrace = 0, nparam = 0;
+  std::vector<int> num_norm_parameter;
+  std::vector<double> ctrlrange;
+  // host mirrors of the device structs (both precisions kept; only one uploaded)
+  LaneModel<double> hm64{}; LaneModel<float> hm32{};
+  LaneTask<double> ht64{}; LaneTask<float> ht32{};
+  bool task_dirty = true;
+  DevBuf d_model, d_task;
+  // rollout buffers
+  DevBuf d_node_times, d_nodes, d_nominal, d_variance, d_in_nodes;
+  DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
+  int N = 0, H = 0, P = 0;  // shape of the last rollout
+  bool have_rollout = false;
+  std::vector<double> h_stage;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+namespace {
+int fail(mjpcx_ctx* c, int code, const std::string& msg) {
+  if (c) c->last_error = msg;
+  return code;
+}
+#define HIPCHK(c, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess)                                                                   \
+      return fail(c, e__ == hipErrorOutOfMemory ? MJPCX_ENOMEM : MJPCX_EDEVICE,              \
+                  std::string(#expr) + ": " + hipGetErrorString(e__));                       \
+  } while (0)
+
+size_t esize(const mjpcx_ctx* c) { return c->precision == 64 ? 8 : 4; }
+
+template <typename T>
+void fill_model(LaneModel<T>& d, const mjpcx_model* m) {
+  std::memset(&d, 0, sizeof d);
+  d.timestep = (T)m->timestep;
+  for (int k = 0; k < 3; k++) d.gravity[k] = (T)m->gravity[k];
+  d.solver_tolerance = (T)m->solver_tolerance;
+  d.meaninertia = (T)m->meaninertia;
+  d.disableflags = m->disableflags;
+  d.solver_iterations = m->solver_iterations;
+  std::vector<double> sub(m->nbody);
+  for (int b = 0; b < m->nbody; b++) sub[b] = m->body_mass[b];
+  for (int b = m->nbody - 1; b > 0; b--) sub[m->body_parentid[b]] += sub[b];
+  for (int b = 0; b < m->nbody; b++) {
+    for (int k = 0; k < 3; k++) {
+      d.body_pos[b][k] = (T)m->body_pos[3 * b + k];
+      d.body_ipos[b][k] = (T)m->body_ipos[3 * b + k];
+      d.body_inertia[b][k] = (T)m->body_inertia[3 * b + k];
+    }
+    for (int k = 0; k < 4; k++) {
+      d.body_quat[b][k] = (T)m->body_quat[4 * b + k];
+      d.body_iquat[b][k] = (T)m->body_iquat[4 * b + k];
+    }
+    d.body_mass[b] = (T)m->body_mass[b];
+    d.root_invmass[b] = (T)(sub[b] > kMinVal ? 1.0 / sub[b] : 0.0);
+  }
+  d.any_damping = 0;
+  for (int j = 0; j < m->njnt; j++) {
+    for (int k = 0; k < 3; k++) { d.jnt_pos[j][k] = (T)m->jnt_pos[3 * j + k]; d.jnt_axis[j][k] = (T)m->jnt_axis[3 * j + k]; }
+    d.jnt_stiffness[j] = (T)m->jnt_stiffness[j];
+    d.jnt_range[j][0] = (T)m->jnt_range[2 * j]; d.jnt_range[j][1] = (T)m->jnt_range[2 * j + 1];
+    d.jnt_margin[j] = (T)m->jnt_margin[j];
+    d.jnt_solref[j][0] = (T)m->jnt_solref[2 * j]; d.jnt_solref[j][1] = (T)m->jnt_solref[2 * j + 1];
+    for (int k = 0; k < 5; k++) d.jnt_solimp[j][k] = (T)m->jnt_solimp[5 * j + k];
+    d.qpos0[j] = (T)m->qpos0[j]; d.qpos_spring[j] = (T)m->qpos_spring[j];
+    d.dof_armature[j] = (T)m->dof_armature[j]; d.dof_damping[j] = (T)m->dof_damping[j];
+    d.dof_invweight0[j] = (T)m->dof_invweight0[j];
+    if (m->dof_damping[j] > 0) d.any_damping = 1;
+  }
+  for (int s = 0; s < m->nsite; s++)
+    for (int k = 0; k < 3; k++) d.site_pos[s][k] = (T)m->site_pos[3 * s + k];
+  for (int u = 0; u < m->nu; u++) {
+    d.act_gear[u] = (T)m->actuator_gear[u];
+    d.act_gain[u] = (T)m->actuator_gainprm[3 * u];
+    for (int k = 0; k < 3; k++) d.act_bias[u][k] = (T)m->actuator_biasprm[3 * u + k];
+    for (int k = 0; k < 2; k++) {
+      d.act_ctrlrange[u][k] = (T)m->actuator_ctrlrange[2 * u + k];
+      d.act_forcerange[u][k] = (T)m->actuator_forcerange[2 * u + k];
+    }
+    d.act_biastype[u] = m->actuator_biastype[u];
+    d.act_ctrllimited[u] = m->actuator_ctrllimited[u];
+    d.act_forcelimited[u] = m->actuator_forcelimited[u];
+  }
+}
+
+template <typename TD, typename TS>
+void convert_task(LaneTask<TD>& d, const LaneTask<TS>& s) {
+  for (int k = 0; k < kLaneMaxTerm; k++) {
+    d.norm[k] = s.norm[k]; d.weight[k] = (TD)s.weight[k]; d.norm_p[k] = (TD)s.norm_p[k]; d.norm_q[k] = (TD)s.norm_q[k];
+  }
+  for (int k = 0; k < kLaneMaxParam; k++) d.parameters[k] = (TD)s.parameters[k];
+  d.risk = (TD)s.risk;
+  for (int k = 0; k < kLaneMaxDof; k++) { d.qpos[k] = (TD)s.qpos[k]; d.qvel[k] = (TD)s.qvel[k]; }
+  d.time = (TD)s.time;
+  for (int i = 0; i < kLaneMaxMocap; i++) {
+    for (int k = 0; k < 3; k++) d.mocap_pos[i][k] = (TD)s.mocap_pos[i][k];
+    for (int k = 0; k < 4; k++) d.mocap_quat[i][k] = (TD)s.mocap_quat[i][k];
+  }
+}
+
+int upload_task(mjpcx_ctx* c) {
+  if (!c->task_dirty) return MJPCX_OK;
+  if (c->precision == 64) {
+    HIPCHK(c, hipMemcpyAsync(c->d_task.p, &c->ht64, sizeof c->ht64, hipMemcpyHostToDevice, c->stream));
+  } else {
+    convert_task(c->ht32, c->ht64);
+    HIPCHK(c, hipMemcpyAsync(c->d_task.p, &c->ht32, sizeof c->ht32, hipMemcpyHostToDevice, c->stream));
+  }
+  // the host structs are members of the ctx and outlive the copy; still, serialise so that a
+  // following mjpcx_set_* cannot overwrite them while the DMA is in flight
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->task_dirty = false;
+  return MJPCX_OK;
+}
+
+void set_norm_params(mjpcx_ctx* c, const double* norm_parameter) {
+  int shift = 0;
+  for (int k = 0; k < c->nterm; k++) {
+    const int np = c->num_norm_parameter[k];
+    c->ht64.norm_p[k] = np > 0 ? norm_parameter[shift] : 0.0;
+    c->ht64.norm_q[k] = np > 1 ? norm_parameter[shift + 1] : 0.0;
+    shift += np;
+  }
+}
+}  // namespace
+
+namespace {
+int reserve_rollout(mjpcx_ctx* c, int N, int H, int P) {
+  const size_t w = esize(c);
+  const size_t ds = c->nq + c->nv + c->na;
+  HIPCHK(c, c->d_node_times.reserve((size_t)P * w));
+  HIPCHK(c, c->d_nodes.reserve((size_t)N * P * c->nu * w));
+  HIPCHK(c, c->d_nominal.reserve((size_t)P * c->nu * w));
+  HIPCHK(c, c->d_variance.reserve((size_t)P * c->nu * 8));
+  HIPCHK(c, c->d_states.reserve((size_t)N * H * ds * w));
+  HIPCHK(c, c->d_actions.reserve((size_t)N * H * c->nu * w));
+  HIPCHK(c, c->d_times.reserve((size_t)N * H * w));
+  HIPCHK(c, c->d_residual.reserve((size_t)N * H * c->nr * w));
+  HIPCHK(c, c->d_costs.reserve((size_t)N * H * w));
+  HIPCHK(c, c->d_trace.reserve((size_t)N * H * 3 * std::max(c->ntrace, 1) * w));
+  HIPCHK(c, c->d_ret.reserve((size_t)N * 8));
+  HIPCHK(c, c->d_fail.reserve((size_t)N * 4));
+  return MJPCX_OK;
+}
+
+template <typename T>
+int upload_converted(mjpcx_ctx* c, DevBuf& dst, const double* src, size_t n) {
+  if (sizeof(T) == 8) {
+    HIPCHK(c, hipMemcpyAsync(dst.p, src, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // pageable source: make reuse by the caller safe
+  } else {
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = (float)src[i];
+    HIPCHK(c, hipMemcpyAsync(dst.p, tmp.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return MJPCX_OK;
+}
+
+template <typename T>
+int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node_times,
+                      const double* node_values, const double* nominal, const mjpcx_noise_spec* ns) {
+  int rc;
+  if ((rc = reserve_rollout(c, N, H, P)) != MJPCX_OK) return rc;
+  if ((rc = upload_task(c)) != MJPCX_OK) return rc;
+  if ((rc = upload_converted<T>(c, c->d_node_times, node_times, P)) != MJPCX_OK) return rc;
+  const int np = P * c->nu;
+  RolloutArgs<T> a{};
+  a.model = (const LaneModel<T>*)c->d_model.p;
+  a.task = (const LaneTask<T>*)c->d_task.p;
+  a.N = N; a.H = H; a.P = P; a.interp = interp;
+  a.node_times = (const T*)c->d_node_times.p;
+  a.nodes = (T*)c->d_nodes.p;
+  a.nominal = (const T*)c->d_nominal.p;
+  a.noise.mode = -1;
+  if (node_values) {
+    // candidate-major host splines -> [node][actuator][candidate] on the device
+    HIPCHK(c, c->d_in_nodes.reserve((size_t)N * np * 8));
+    HIPCHK(c, hipMemcpyAsync(c->d_in_nodes.p, node_values, (size_t)N * np * 8, hipMemcpyHostToDevice, c->stream));
+    const size_t total = (size_t)N * np;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL((scatter_nodes_kernel<T>), dim3(blocks), dim3(256), 0, c->stream,
+                       (const double*)c->d_in_nodes.p, (T*)c->d_nodes.p, N, np);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  } else {
+    if ((rc = upload_converted<T>(c, c->d_nominal, nominal, np)) != MJPCX_OK) return rc;
+    a.noise.mode = ns->mode;
+    a.noise.seed = ns->seed; a.noise.iteration = ns->iteration;
+    a.noise.candidate_offset = ns->candidate_offset; a.noise.nominal_candidate = ns->nominal_candidate;
+    a.noise.explore_count = ns->explore_count; a.noise.std0 = ns->std0; a.noise.std1 = ns->std1;
+    a.noise.param_variance = nullptr;
+    if (ns->mode == MJPCX_NOISE_CROSS_ENTROPY) {
+      if (!ns->param_variance) return fail(c, MJPCX_EINVAL, "cross-entropy noise needs param_variance");
+      HIPCHK(c, hipMemcpyAsync(c->d_variance.p, ns->param_variance, (size_t)np * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      a.noise.param_variance = (const double*)c->d_variance.p;
+    }
+  }
+  a.states = (T*)c->d_states.p; a.actions = (T*)c->d_actions.p; a.times = (T*)c->d_times.p;
+  a.residual = (T*)c->d_residual.p; a.costs = (T*)c->d_costs.p; a.trace = (T*)c->d_trace.p;
+  a.total_return = (double*)c->d_ret.p; a.failure = (int*)c->d_fail.p;
+
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->timing) {
+    if (c->events_used == c->events.size()) {
+      hipEvent_t x, y;
+      HIPCHK(c, hipEventCreate(&x));
+      HIPCHK(c, hipEventCreate(&y));
+      c->events.emplace_back(x, y);
+    }
+    e0 = c->events[c->events_used].first; e1 = c->events[c->events_used].second;
+    c->events_used++;
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+  }
+  hipError_t le;
+  if constexpr (sizeof(T) == 8) le = c->kernel->launch64(a, c->stream);
+  else le = c->kernel->launch32(a, c->stream);
+  if (le != hipSuccess) return fail(c, MJPCX_EDEVICE, std::string("rollout kernel launch: ") + hipGetErrorString(le));
+  if (c->timing) HIPCHK(c, hipEventRecord(e1, c->stream));
+  c->N = N; c->H = H; c->P = P;
+  c->have_rollout = true;
+  return MJPCX_OK;
+}
+
+int check_rollout_args(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node_times) {
+  if (!c || !node_times) return fail(c, MJPCX_EINVAL, "null argument");
+  if (N < 1 || H < 1 || P < 1) return fail(c, MJPCX_EINVAL, "num_candidates, horizon and num_nodes must be >= 1");
+  if (interp < 0 || interp > 2) return fail(c, MJPCX_EINVAL, "unknown interpolation");
+  for (int p = 1; p < P; p++)
+    if (!(node_times[p] > node_times[p - 1])) return fail(c, MJPCX_EINVAL, "node_times must be strictly increasing");
+  const size_t shmem = (size_t)P * c->nu * 64 * esize(c);
+  if (shmem > 64 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "num_nodes * nu too large for the LDS spline stage");
+  if (hipSetDevice(c->device) != hipSuccess) return fail(c, MJPCX_EDEVICE, "hipSetDevice failed");
+  return MJPCX_OK;
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+extern "C" {
+
+const char* mjpcx_error_string(int code) {
+  switch (code) {
+    case MJPCX_OK: return "ok";
+    case MJPCX_EINVAL: return "invalid argument";
+    case MJPCX_EUNSUPPORTED: return "model or task not supported by any device kernel";
+    case MJPCX_EDEVICE: return "HIP runtime error";
+    case MJPCX_ENOMEM: return "out of memory";
+    case MJPCX_ESTATE: return "call out of order";
+    default: return "unknown error";
+  }
+}
+const char* mjpcx_last_error(const mjpcx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char* mjpcx_kernel_name(const mjpcx_ctx* ctx) { return ctx && ctx->kernel ? ctx->kernel->name : ""; }
+
+static thread_local std::string g_create_error;
+const char* mjpcx_create_error(void) { return g_create_error.c_str(); }
+
+int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int precision, mjpcx_ctx** out) {
+  g_create_error.clear();
+  auto bad = [&](int code, const std::string& msg) { g_create_error = msg; return code; };
+  if (!m || !t || !out) return bad(MJPCX_EINVAL, "null argument");
+  *out = nullptr;
+  if (precision != 64 && precision != 32) return bad(MJPCX_EINVAL, "precision must be 64 or 32");
+  // ---- features the device kernels cover today
+  if (m->na != 0) return bad(MJPCX_EUNSUPPORTED, "actuator activations (na > 0) unsupported");
+  if (m->integrator != MJPCX_INT_EULER) return bad(MJPCX_EUNSUPPORTED, "only the Euler integrator is implemented");
+  if (m->nq != m->nv || m->njnt != m->nv) return bad(MJPCX_EUNSUPPORTED, "only slide/hinge joints are implemented (nq == nv == njnt)");
+  if (m->nbody > kLaneMaxBody || m->nv > kLaneMaxDof || m->nu > kLaneMaxAct || m->nsite > kLaneMaxSite ||
+      m->nmocap > kLaneMaxMocap || t->num_term > kLaneMaxTerm || t->num_parameter > kLaneMaxParam)
+    return bad(MJPCX_EUNSUPPORTED, "model exceeds the small-model kernel capacity");
+  for (int j = 0; j < m->njnt; j++) {
+    if (m->jnt_type[j] != MJPCX_JNT_SLIDE && m->jnt_type[j] != MJPCX_JNT_HINGE)
+      return bad(MJPCX_EUNSUPPORTED, "only slide/hinge joints are implemented");
+    if (m->jnt_dofadr[j] != j || m->jnt_qposadr[j] != j) return bad(MJPCX_EINVAL, "joint/dof addressing is not 1:1");
+    if (m->dof_frictionloss[j] > 0) return bad(MJPCX_EUNSUPPORTED, "joint frictionloss unsupported");
+    if (m->jnt_limited[j] && !(m->jnt_range[2 * j + 1] - m->jnt_range[2 * j] > 2 * m->jnt_margin[j]))
+      return bad(MJPCX_EUNSUPPORTED, "joint range narrower than twice its margin");
+  }
+  if (!(m->disableflags & MJPCX_DSBL_CONTACT)) return bad(MJPCX_EUNSUPPORTED, "contacts are not implemented: the model must disable them");
+  for (int u = 0; u < m->nu; u++)
+    if (m->actuator_trnid[u] < 0 || m->actuator_trnid[u] >= m->njnt) return bad(MJPCX_EINVAL, "actuator transmission out of range");
+
+  // ---- static-topology key of the runtime model
+  TopoKey tk{m->nbody, m->nv, m->nu, m->nsite, m->nmocap, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < m->nbody; b++) {
+    tk.parent |= (uint64_t)(m->body_parentid[b] & 15) << (4 * b);
+    tk.mocap |= (uint64_t)((m->body_mocapid[b] < 0 ? 15 : m->body_mocapid[b]) & 15) << (4 * b);
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    tk.jtype |= (uint64_t)(m->jnt_type[j] & 3) << (2 * j);
+    tk.jbody |= (uint64_t)(m->jnt_bodyid[j] & 15) << (4 * j);
+    tk.jlimited |= (uint64_t)(m->jnt_limited[j] ? 1 : 0) << j;
+  }
+  for (int u = 0; u < m->nu; u++) tk.actj |= (uint64_t)(m->actuator_trnid[u] & 15) << (4 * u);
+  for (int s = 0; s < m->nsite; s++) tk.siteb |= (uint64_t)(m->site_bodyid[s] & 15) << (4 * s);
+  TaskKey kk{t->residual_id, t->num_residual, t->num_term, t->num_trace, 0, 0};
+  for (int k = 0; k < t->num_term; k++) kk.termdim |= (uint64_t)(t->dim_norm_residual[k] & 15) << (4 * k);
+  for (int k = 0; k < t->num_trace; k++) kk.tracesite |= (uint64_t)(t->trace_site[k] & 15) << (4 * k);
+  const KernelEntry* entry = nullptr;
+  for (const KernelEntry& e : kKernels)
+    if (e.topo == tk && e.task == kk) { entry = &e; break; }
+  if (!entry) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf,
+                  "no rollout kernel is instantiated for this model/task topology: Topo<%d,%d,%d,%d,%d,0x%llx,0x%llx,0x%llx,"
+                  "0x%llx,0x%llx,0x%llx,0x%llx> TaskTopo<%d,%d,%d,0x%llx,%d,0x%llx> (add it to kKernels in csrc/mjpcx.hip)",
+                  tk.nb, tk.nv, tk.nu, tk.nsite, tk.nmocap, (unsigned long long)tk.parent, (unsigned long long)tk.mocap,
+                  (unsigned long long)tk.jtype, (unsigned long long)tk.jbody, (unsigned long long)tk.jlimited,
+                  (unsigned long long)tk.actj, (unsigned long long)tk.siteb, kk.rid, kk.nr, kk.nterm,
+                  (unsigned long long)kk.termdim, kk.ntrace, (unsigned long long)kk.tracesite);
+    return bad(MJPCX_EUNSUPPORTED, buf);
+  }
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad(MJPCX_EDEVICE, "no HIP device available");
+  if (device < 0 || device >= ndev) return bad(MJPCX_EINVAL, "device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return bad(MJPCX_EDEVICE, "hipSetDevice failed");
+
+  mjpcx_ctx* c = new (std::nothrow) mjpcx_ctx();
+  if (!c) return bad(MJPCX_ENOMEM, "host allocation failed");
+  c->device = device; c->precision = precision; c->kernel = entry;
+  c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap;
+  c->nr = t->num_residual; c->nterm = t->num_term; c->ntrace = t->num_trace; c->nparam = t->num_parameter;
+  c->num_norm_parameter.assign(t->num_norm_parameter, t->num_norm_parameter + t->num_term);
+  c->ctrlrange.assign(m->actuator_ctrlrange, m->actuator_ctrlrange + 2 * m->nu);
+  fill_model(c->hm64, m);
+  fill_model(c->hm32, m);
+  std::memset(&c->ht64, 0, sizeof c->ht64);
+  for (int k = 0; k < t->num_term; k++) { c->ht64.norm[k] = t->norm[k]; c->ht64.weight[k] = t->weight[k]; }
+  set_norm_params(c, t->norm_parameter);
+  for (int k = 0; k < t->num_parameter; k++) c->ht64.parameters[k] = t->parameters[k];
+  c->ht64.risk = t->risk;
+  for (int j = 0; j < m->nq; j++) c->ht64.qpos[j] = m->qpos0[j];
+  for (int b = 0; b < m->nbody; b++)
+    if (m->body_mocapid[b] >= 0) {
+      for (int k = 0; k < 3; k++) c->ht64.mocap_pos[m->body_mocapid[b]][k] = m->body_pos[3 * b + k];
+      for (int k = 0; k < 4; k++) c->ht64.mocap_quat[m->body_mocapid[b]][k] = m->body_quat[4 * b + k];
+    }
+  auto cleanup = [&](int code, const std::string& msg) { mjpcx_destroy(c); return bad(code, msg); };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(MJPCX_EDEVICE, "hipStreamCreate failed");
+  const size_t msz = precision == 64 ? sizeof c->hm64 : sizeof c->hm32;
+  const size_t tsz = precision == 64 ? sizeof c->ht64 : sizeof c->ht32;
+  if (c->d_model.reserve(msz) != hipSuccess || c->d_task.reserve(tsz) != hipSuccess) return cleanup(MJPCX_ENOMEM, "device allocation failed");
+  const void* src = precision == 64 ? (const void*)&c->hm64 : (const void*)&c->hm32;
+  if (hipMemcpy(c->d_model.p, src, msz, hipMemcpyHostToDevice) != hipSuccess) return cleanup(MJPCX_EDEVICE, "model upload failed");
+  c->task_dirty = true;
+  *out = c;
+  return MJPCX_OK;
+}
+
+void mjpcx_destroy(mjpcx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  DevBuf* bufs[] = {&c->d_model, &c->d_task, &c->d_node_times, &c->d_nodes, &c->d_nominal, &c->d_variance, &c->d_in_nodes,
+                    &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
+                    &c->d_fail, &c->d_sort, &c->d_stage};
+  for (DevBuf* b : bufs) b->release();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mjpcx_set_state(mjpcx_ctx* c, const double* state, double time, const double* mocap, const double* userdata) {
+  if (!c || !state) return fail(c, MJPCX_EINVAL, "null argument");
+  (void)userdata;  // nuserdata == 0 for every supported model
+  for (int j = 0; j < c->nq; j++) c->ht64.qpos[j] = state[j];
+  for (int j = 0; j < c->nv; j++) c->ht64.qvel[j] = state[c->nq + j];
+  c->ht64.time = time;
+  if (mocap)
+    for (int i = 0; i < c->nmocap; i++) {  // trajectory.cc:121-124
+      for (int k = 0; k < 3; k++) c->ht64.mocap_pos[i][k] = mocap[7 * i + k];
+      for (int k = 0; k < 4; k++) c->ht64.mocap_quat[i][k] = mocap[7 * i + 3 + k];
+    }
+  c->task_dirty = true;
+  return MJPCX_OK;
+}
+
+int mjpcx_set_task_params(mjpcx_ctx* c, const double* weight, const double* norm_parameter,
+                          const double* parameters, double risk) {
+  if (!c) return MJPCX_EINVAL;
+  if (weight) for (int k = 0; k < c->nterm; k++) c->ht64.weight[k] = weight[k];
+  if (norm_parameter) set_norm_params(c, norm_parameter);
+  if (parameters) for (int k = 0; k < c->nparam; k++) c->ht64.parameters[k] = parameters[k];
+  c->ht64.risk = risk;
+  c->task_dirty = true;
+  return MJPCX_OK;
+}
+
+int mjpcx_rollout_splines(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node_times,
+                          const double* node_values) {
+  int rc = check_rollout_args(c, N, H, P, interp, node_times);
+  if (rc != MJPCX_OK) return rc;
+  if (!node_values) return fail(c, MJPCX_EINVAL, "null node_values");
+  return c->precision == 64 ? do_rollout<double>(c, N, H, P, interp, node_times, node_values, nullptr, nullptr)
+                            : do_rollout<float>(c, N, H, P, interp, node_times, node_values, nullptr, nullptr);
+}
+
+int mjpcx_rollout_noise(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node_times,
+                        const double* nominal, const mjpcx_noise_spec* ns) {
+  int rc = check_rollout_args(c, N, H, P, interp, node_times);
+  if (rc != MJPCX_OK) return rc;
+  if (!nominal || !ns) return fail(c, MJPCX_EINVAL, "null argument");
+  if (ns->mode != MJPCX_NOISE_SAMPLING && ns->mode != MJPCX_NOISE_CROSS_ENTROPY) return fail(c, MJPCX_EINVAL, "unknown noise mode");
+  return c->precision == 64 ? do_rollout<double>(c, N, H, P, interp, node_times, nullptr, nominal, ns)
+                            : do_rollout<float>(c, N, H, P, interp, node_times, nullptr, nominal, ns);
+}
+
+int mjpcx_sync(mjpcx_ctx* c) {
+  if (!c) return MJPCX_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+
+int mjpcx_get_returns(mjpcx_ctx* c, double* total_return, int32_t* failure) {
+  if (!c) return MJPCX_EINVAL;
+  if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (total_return) HIPCHK(c, hipMemcpyAsync(total_return, c->d_ret.p, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+  if (failure) HIPCHK(c, hipMemcpyAsync(failure, c->d_fail.p, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+
+int mjpcx_topk(mjpcx_ctx* c, int k, int32_t* index, double* total_return) {
+  if (!c || !index) return fail(c, MJPCX_EINVAL, "null argument");
+  if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");
+  if (k < 1 || k > c->N) return fail(c, MJPCX_EINVAL, "k out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  int n2 = 1;
+  while (n2 < c->N) n2 <<= 1;
+  HIPCHK(c, c->d_sort.reserve((size_t)n2 * sizeof(RetIdx)));
+  if (k == 1) {
+    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)c->d_ret.p, c->N, (RetIdx*)c->d_sort.p);
+  } else {
+    hipLaunchKernelGGL(sort_kernel, dim3(1), dim3(1024), 0, c->stream, (const double*)c->d_ret.p, c->N, n2, (RetIdx*)c->d_sort.p);
+  }
+  HIPCHK(c, hipGetLastError());
+  std::vector<RetIdx> h(k);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_sort.p, (size_t)k * sizeof(RetIdx), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < k; i++) {
+    index[i] = h[i].i;
+    if (total_return) total_return[i] = h[i].r;
+  }
+  return MJPCX_OK;
+}
+
+int mjpcx_fetch_trajectory(mjpcx_ctx* c, int cand, mjpcx_traj_view* out) {
+  if (!c || !out) return fail(c, MJPCX_EINVAL, "null argument");
+  if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");
+  if (cand < 0 || cand >= c->N) return fail(c, MJPCX_EINVAL, "candidate out of range");
+  if (out->horizon < c->H) return fail(c, MJPCX_EINVAL, "trajectory view too short");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = c->H, ds = c->nq + c->nv + c->na, nu = c->nu, nr = c->nr, ntr3 = 3 * c->ntrace;
+  const int row = ds + nu + 1 + nr + 1 + ntr3;
+  const size_t total = (size_t)H * row;
+  HIPCHK(c, c->d_stage.reserve((total + 2) * 8));
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 1024);
+  if (c->precision == 64)
+    hipLaunchKernelGGL((gather_traj_kernel<double>), dim3(blocks), dim3(256), 0, c->stream, (const double*)c->d_states.p,
+                       (const double*)c->d_actions.p, (const double*)c->d_times.p, (const double*)c->d_residual.p,
+                       (const double*)c->d_costs.p, (const double*)c->d_trace.p, c->N, H, ds, nu, nr, ntr3, cand,
+                       (double*)c->d_stage.p);
+  else
+    hipLaunchKernelGGL((gather_traj_kernel<float>), dim3(blocks), dim3(256), 0, c->stream, (const float*)c->d_states.p,
+                       (const float*)c->d_actions.p, (const float*)c->d_times.p, (const float*)c->d_residual.p,
+                       (const float*)c->d_costs.p, (const float*)c->d_trace.p, c->N, H, ds, nu, nr, ntr3, cand,
+                       (double*)c->d_stage.p);
+  HIPCHK(c, hipGetLastError());
+  c->h_stage.resize(total);
+  double ret = 0; int32_t fl = 0;
+  HIPCHK(c, hipMemcpyAsync(c->h_stage.data(), c->d_stage.p, total * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&ret, (const double*)c->d_ret.p + cand, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&fl, (const int*)c->d_fail.p + cand, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const double* s = c->h_stage.data();
+  if (out->states) std::memcpy(out->states, s, sizeof(double) * H * ds);
+  s += (size_t)H * ds;
+  if (out->actions) std::memcpy(out->actions, s, sizeof(double) * H * nu);
+  s += (size_t)H * nu;
+  if (out->times) std::memcpy(out->times, s, sizeof(double) * H);
+  s += H;
+  if (out->residual) std::memcpy(out->residual, s, sizeof(double) * H * nr);
+  s += (size_t)H * nr;
+  if (out->costs) std::memcpy(out->costs, s, sizeof(double) * H);
+  s += H;
+  if (out->trace && ntr3) std::memcpy(out->trace, s, sizeof(double) * H * ntr3);
+  out->horizon = H;
+  out->total_return = ret;
+  out->failure = fl;
+  return MJPCX_OK;
+}
+
+int mjpcx_fetch_spline(mjpcx_ctx* c, int cand, double* node_values) {
+  if (!c || !node_values) return fail(c, MJPCX_EINVAL, "null argument");
+  if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");
+  if (cand < 0 || cand >= c->N) return fail(c, MJPCX_EINVAL, "candidate out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int np = c->P * c->nu;
+  HIPCHK(c, c->d_stage.reserve((size_t)np * 8));
+  if (c->precision == 64)
+    hipLaunchKernelGGL((gather_spline_kernel<double>), dim3((np + 63) / 64), dim3(64), 0, c->stream,
+                       (const double*)c->d_nodes.p, c->N, np, cand, (double*)c->d_stage.p);
+  else
+    hipLaunchKernelGGL((gather_spline_kernel<float>), dim3((np + 63) / 64), dim3(64), 0, c->stream,
+                       (const float*)c->d_nodes.p, c->N, np, cand, (double*)c->d_stage.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(node_values, c->d_stage.p, (size_t)np * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+
+int mjpcx_timing_reset(mjpcx_ctx* c) {
+  if (!c) return MJPCX_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->events_used = 0;
+  c->timing = true;
+  return MJPCX_OK;
+}
+
+int mjpcx_timing_read(mjpcx_ctx* c, double* kernel_ms, int64_t* launches) {
+  if (!c) return MJPCX_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double total = 0;
+  for (size_t i = 0; i < c->events_used; i++) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second));
+    total += ms;
+  }
+  if (kernel_ms) *kernel_ms = total;
+  if (launches) *launches = (int64_t)c->events_used;
+  c->timing = false;
+  return MJPCX_OK;
+}
+
+int64_t mjpcx_algorithmic_bytes(const mjpcx_ctx* c, int H, int P) {
+  if (!c) return 0;
+  const int64_t w = c->precision == 64 ? 8 : 4;
+  const int64_t ds = c->nq + c->nv + c->na;
+  return w * ((int64_t)H * (ds + c->nu + 1 + c->nr + 3 * c->ntrace + 1) + (int64_t)P * c->nu + P + 2);
+}
+
+int mjpcx_device_buffer(mjpcx_ctx* c, int which, void** ptr, size_t* bytes) {
+  if (!c || !ptr) return MJPCX_EINVAL;
+  if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");
+  if (which == 0) { *ptr = c->d_ret.p; if (bytes) *bytes = (size_t)c->N * 8; }
+  else if (which == 1) { *ptr = c->d_fail.p; if (bytes) *bytes = (size_t)c->N * 4; }
+  else return fail(c, MJPCX_EINVAL, "unknown buffer");
+  return MJPCX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+/* oracle.h -- CPU fp64 restatement of the MJPC rollout-and-evaluate hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing in the product (mujoco_mpc_amd/, the C-ABI
+ * library, bench.py's timed GPU leg) may import, link or execute this code; it
+ * is the checker for tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg.
+ *
+ * Parity status
+ *   - mjpc-owned arithmetic (TimeSpline, Norm, CostTerms/CostValue, Trajectory
+ *     bookkeeping, sampling-planner update, iLQG Riccati step) is PINNED against
+ *     the reference's own known-answer tests (tests/test_oracle_*.py cite them).
+ *   - the rigid-body physics (`mj_step`/`mj_forward`, MuJoCo @ 088079ef, a
+ *     third-party dependency that is absent from /root/reference and from this
+ *     image) is restated from MuJoCo's documented pipeline: PARITY UNPINNED
+ *     against MuJoCo itself. It is validated by analytic checks (closed-form
+ *     cart-pole dynamics, energy conservation, free fall, pendulum period) and
+ *     the reference's behavioural tests (rollout_test.cc).
+ */
+#ifndef MJPC_ORACLE_H_
+#define MJPC_ORACLE_H_
+
+#include <stdint.h>
+#include "../include/mjpcx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- TimeSpline (mjpc/spline/spline.{h,cc}) ------------------ */
+typedef struct OSpline {
+  int dim, interp, size, cap;
+  double* times;  /* size, sorted            */
+  double* values; /* size x dim, time order  */
+} OSpline;
+void ospline_init(OSpline* s, int dim, int interp);
+void ospline_free(OSpline* s);
+void ospline_clear(OSpline* s);
+void ospline_copy(OSpline* dst, const OSpline* src);
+void ospline_set_interpolation(OSpline* s, int interp);
+/* returns node index, or -1 when `time` falls strictly inside the node range
+ * (spline.cc:217-219 CHECKs that) */
+int ospline_add_node(OSpline* s, double time, const double* values);
+void ospline_sample(const OSpline* s, double time, double* out);
+int ospline_discard_before(OSpline* s, double time);
+void ospline_shift_time(OSpline* s, double start_time);
+
+/* ---------------- Norm (mjpc/norm.cc) ------------------------------------- */
+int onorm_parameter_dimension(int type);
+double onorm(double* g, double* H, const double* x, const double* params, int n, int type);
+
+/* ---------------- cost (mjpc/task.cc:71-110) ------------------------------ */
+void ocost_terms(const mjpcx_task* task, const double* residual, double* terms, int weighted);
+double ocost_value(const mjpcx_task* task, const double* residual);
+
+/* ---------------- counter-based noise (replaces absl::BitGen) --- */
+void ophilox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void ogaussian_pair(uint64_t seed, uint32_t candidate, uint32_t pair, uint32_t iteration, double z[2]);
+/* candidate spline values = clamp(nominal + noise): sampling/planner.cc:326-352 */
+void onoise_candidate(const mjpcx_model* m, const mjpcx_noise_spec* ns, int num_nodes,
+                      const double* nominal, int global_candidate, double* out_values);
+
+/* ---------------- physics (MuJoCo pipeline restatement) ------------------- */
+typedef struct OData OData;
+OData* odata_new(const mjpcx_model* m);
+void odata_free(OData* d);
+void odata_set_state(OData* d, const double* state, double time, const double* mocap,
+                     const double* userdata);
+void odata_set_ctrl(OData* d, const double* ctrl);
+void o_forward(OData* d);           /* mj_forward */
+void o_step(OData* d);              /* mj_step    */
+/* same, with the task residual evaluated at the sensor-callback point */
+void o_forward_task(OData* d, const mjpcx_task* task, double* residual);
+void o_step_task(OData* d, const mjpcx_task* task, double* residual);
+const double* odata_site_xpos(const OData* d);
+int odata_warning(const OData* d);  /* !=0: BADQPOS/BADQVEL/BADQACC/BADCTRL seen */
+/* introspection for tests: name in {"qpos","qvel","qacc","qacc_smooth","M",
+ * "xpos","xquat","xmat","xipos","site_xpos","subtree_com","qfrc_bias",
+ * "qfrc_passive","qfrc_actuator","qfrc_constraint","actuator_force","time",
+ * "efc_force","nefc","energy"}; returns count written (<= cap), -1 unknown. */
+int odata_get(const OData* d, const char* name, double* out, int cap);
+
+/* residual dispatch (the ResidualFn::Residual overrides) */
+void oresidual(const mjpcx_task* task, const OData* d, double* residual);
+
+/* ---------------- Trajectory::Rollout (mjpc/trajectory.cc:92-210) --------- */
+/* policy = SamplingPolicy::Action over `spline` (sampling/policy.cc:52-59). */
+int orollout_spline(const mjpcx_model* m, const mjpcx_task* task, OData* d,
+                    const double* state, double time, const double* mocap,
+                    const double* userdata, int horizon, const OSpline* spline,
+                    mjpcx_traj_view* out);
+/* policy = PD feedback of rollout_test.cc:84-103 (particle), for the ported test */
+int orollout_pd(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state,
+                double time, const double* mocap, int horizon, const double* pos_goal,
+                const double* vel_goal, double P, double D, mjpcx_traj_view* out);
+
+/* ---------------- batched rollouts over a thread pool --------------------- */
+/* The reference's fan-out (sampling/planner.cc:355-393): one task per candidate,
+ * one physics arena per worker. node_values: N x P x nu. Outputs: returns[N],
+ * failure[N]; optional full trajectories in reference layout, candidate-major
+ * (NULL to skip). Returns 0. */
+typedef struct OBatchOut {
+  double* total_return; /* N */
+  int32_t* failure;     /* N */
+  double* states;   /* N x H x dim_state or NULL */
+  double* actions;  /* N x H x nu or NULL */
+  double* times;    /* N x H or NULL */
+  double* residual; /* N x H x nr or NULL */
+  double* costs;    /* N x H or NULL */
+  double* trace;    /* N x H x 3*ntrace or NULL */
+} OBatchOut;
+int orollout_batch(const mjpcx_model* m, const mjpcx_task* task, const double* state,
+                   double time, const double* mocap, const double* userdata, int N, int H,
+                   int P, int interp, const double* node_times, const double* node_values,
+                   int num_threads, OBatchOut* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

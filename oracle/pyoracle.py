@@ -1,0 +1,284 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+never by the product package (mujoco_mpc_amd/)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from mujoco_mpc_amd.cstructs import (MjpcxModel, MjpcxNoiseSpec, MjpcxTask, MjpcxTrajView, as_f64p, as_i32p,
+                                     c_f64p, c_i32p)
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_DIR, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _DIR, "-s", "liboracle.so"] + (["-B"] if force else []))
+    return so
+
+
+class OSpline(C.Structure):
+    _fields_ = [("dim", C.c_int), ("interp", C.c_int), ("size", C.c_int), ("cap", C.c_int),
+                ("times", c_f64p), ("values", c_f64p)]
+
+
+class OBatchOut(C.Structure):
+    _fields_ = [("total_return", c_f64p), ("failure", c_i32p), ("states", c_f64p), ("actions", c_f64p),
+                ("times", c_f64p), ("residual", c_f64p), ("costs", c_f64p), ("trace", c_f64p)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.odata_new.restype = C.c_void_p
+        L.odata_new.argtypes = [C.POINTER(MjpcxModel)]
+        L.odata_free.argtypes = [C.c_void_p]
+        L.odata_set_state.argtypes = [C.c_void_p, c_f64p, C.c_double, c_f64p, c_f64p]
+        L.odata_set_ctrl.argtypes = [C.c_void_p, c_f64p]
+        L.o_forward.argtypes = [C.c_void_p]
+        L.o_step.argtypes = [C.c_void_p]
+        L.odata_warning.argtypes = [C.c_void_p]
+        L.odata_get.argtypes = [C.c_void_p, C.c_char_p, c_f64p, C.c_int]
+        L.onorm.restype = C.c_double
+        L.onorm.argtypes = [c_f64p, c_f64p, c_f64p, c_f64p, C.c_int, C.c_int]
+        L.ocost_value.restype = C.c_double
+        L.ocost_value.argtypes = [C.POINTER(MjpcxTask), c_f64p]
+        L.ocost_terms.argtypes = [C.POINTER(MjpcxTask), c_f64p, c_f64p, C.c_int]
+        L.ospline_init.argtypes = [C.POINTER(OSpline), C.c_int, C.c_int]
+        L.ospline_free.argtypes = [C.POINTER(OSpline)]
+        L.ospline_clear.argtypes = [C.POINTER(OSpline)]
+        L.ospline_copy.argtypes = [C.POINTER(OSpline), C.POINTER(OSpline)]
+        L.ospline_set_interpolation.argtypes = [C.POINTER(OSpline), C.c_int]
+        L.ospline_add_node.argtypes = [C.POINTER(OSpline), C.c_double, c_f64p]
+        L.ospline_sample.argtypes = [C.POINTER(OSpline), C.c_double, c_f64p]
+        L.ospline_discard_before.argtypes = [C.POINTER(OSpline), C.c_double]
+        L.ospline_shift_time.argtypes = [C.POINTER(OSpline), C.c_double]
+        L.ophilox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.ogaussian_pair.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, c_f64p]
+        L.onoise_candidate.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxNoiseSpec), C.c_int, c_f64p, C.c_int, c_f64p]
+        L.orollout_spline.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), C.c_void_p, c_f64p, C.c_double,
+                                      c_f64p, c_f64p, C.c_int, C.POINTER(OSpline), C.POINTER(MjpcxTrajView)]
+        L.orollout_pd.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), C.c_void_p, c_f64p, C.c_double,
+                                  c_f64p, C.c_int, c_f64p, c_f64p, C.c_double, C.c_double, C.POINTER(MjpcxTrajView)]
+        L.orollout_batch.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, c_f64p,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_int, C.POINTER(OBatchOut)]
+        if hasattr(L, "oriccati"):
+            L.oriccati.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [c_f64p] * 14
+        _LIB = L
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Spline:
+    """mjpc::spline::TimeSpline restatement."""
+
+    def __init__(self, dim, interp=0):
+        self.s = OSpline()
+        lib().ospline_init(C.byref(self.s), dim, interp)
+        self.dim = dim
+
+    def __del__(self):
+        try:
+            lib().ospline_free(C.byref(self.s))
+        except Exception:
+            pass
+
+    def size(self):
+        return self.s.size
+
+    def set_interpolation(self, interp):
+        lib().ospline_set_interpolation(C.byref(self.s), interp)
+
+    def clear(self):
+        lib().ospline_clear(C.byref(self.s))
+
+    def add_node(self, time, values=None):
+        v = None if values is None else as_f64p(_f(values))
+        r = lib().ospline_add_node(C.byref(self.s), float(time), v)
+        if r < 0:
+            raise ValueError("Adding nodes to the middle of the spline isn't supported.")
+        return r
+
+    def sample(self, time):
+        out = np.zeros(max(self.dim, 1))
+        lib().ospline_sample(C.byref(self.s), float(time), as_f64p(out))
+        return out[:self.dim]
+
+    def discard_before(self, time):
+        return lib().ospline_discard_before(C.byref(self.s), float(time))
+
+    def shift_time(self, t):
+        lib().ospline_shift_time(C.byref(self.s), float(t))
+
+    def copy(self):
+        o = Spline(self.dim)
+        lib().ospline_copy(C.byref(o.s), C.byref(self.s))
+        return o
+
+    def node_times(self):
+        return np.array([self.s.times[i] for i in range(self.s.size)])
+
+    def node_values(self):
+        return np.array([self.s.values[i] for i in range(self.s.size * self.dim)]).reshape(self.s.size, self.dim)
+
+    def set_node_values(self, idx, values):
+        for k, v in enumerate(values):
+            self.s.values[idx * self.dim + k] = float(v)
+
+
+def norm(x, params, norm_type, grad=False, hess=False):
+    x = _f(x)
+    n = x.size
+    p = _f(list(params) + [0.0, 0.0])
+    g = np.zeros(n) if (grad or hess) else None
+    H = np.zeros(n * n) if hess else None
+    y = lib().onorm(as_f64p(g) if g is not None else None, as_f64p(H) if H is not None else None,
+                    as_f64p(x), as_f64p(p), n, int(norm_type))
+    return (y, g, None if H is None else H.reshape(n, n))
+
+
+class Physics:
+    """One physics arena (mjData analogue) bound to a packed model."""
+
+    def __init__(self, packed_model):
+        self.pm = packed_model
+        self.m = packed_model.struct
+        self.d = lib().odata_new(packed_model.ptr)
+        if not self.d:
+            raise NotImplementedError("model uses features outside the oracle's physics subset")
+
+    def __del__(self):
+        try:
+            lib().odata_free(self.d)
+        except Exception:
+            pass
+
+    def set_state(self, qpos, qvel, time=0.0, mocap=None):
+        st = _f(np.concatenate([qpos, qvel]))
+        mc = None if mocap is None else as_f64p(_f(mocap))
+        lib().odata_set_state(self.d, as_f64p(st), float(time), mc, None)
+
+    def set_ctrl(self, ctrl):
+        lib().odata_set_ctrl(self.d, as_f64p(_f(ctrl)))
+
+    def forward(self):
+        lib().o_forward(self.d)
+
+    def step(self):
+        lib().o_step(self.d)
+
+    def warning(self):
+        return lib().odata_warning(self.d)
+
+    def get(self, name, cap=4096):
+        out = np.zeros(cap)
+        n = lib().odata_get(self.d, name.encode(), as_f64p(out), cap)
+        if n < 0:
+            raise KeyError(name)
+        return out[:n].copy()
+
+
+def cost_value(packed_task, residual):
+    return lib().ocost_value(packed_task.ptr, as_f64p(_f(residual)))
+
+
+def cost_terms(packed_task, residual, weighted=True):
+    out = np.zeros(packed_task.struct.num_term)
+    lib().ocost_terms(packed_task.ptr, as_f64p(_f(residual)), as_f64p(out), int(weighted))
+    return out
+
+
+class Trajectory:
+    """mjpc::Trajectory buffers (mjpc/trajectory.h:74-86), reference layout."""
+
+    def __init__(self, dim_state, nu, nr, ntrace, horizon):
+        self.horizon = horizon
+        self.states = np.zeros((horizon, dim_state))
+        self.actions = np.zeros((horizon, nu))
+        self.times = np.zeros(horizon)
+        self.residual = np.zeros((horizon, nr))
+        self.costs = np.zeros(horizon)
+        self.trace = np.zeros((horizon, 3 * ntrace))
+        self.total_return = 0.0
+        self.failure = False
+
+    def view(self):
+        v = MjpcxTrajView()
+        v.horizon = self.horizon
+        v.states, v.actions, v.times = as_f64p(self.states), as_f64p(self.actions), as_f64p(self.times)
+        v.residual, v.costs, v.trace = as_f64p(self.residual), as_f64p(self.costs), as_f64p(self.trace)
+        return v
+
+    def take(self, v):
+        self.total_return = v.total_return
+        self.failure = bool(v.failure)
+
+
+def rollout_spline(pm, pt, physics, state, time, mocap, horizon, spline: Spline):
+    m = pm.struct
+    tr = Trajectory(m.nq + m.nv + m.na, m.nu, pt.struct.num_residual, pt.struct.num_trace, horizon)
+    v = tr.view()
+    mc = None if mocap is None else as_f64p(_f(mocap))
+    lib().orollout_spline(pm.ptr, pt.ptr, physics.d, as_f64p(_f(state)), float(time), mc, None, horizon,
+                          C.byref(spline.s), C.byref(v))
+    tr.take(v)
+    return tr
+
+
+def rollout_pd(pm, pt, physics, state, time, mocap, horizon, pos_goal, vel_goal, P, D):
+    m = pm.struct
+    tr = Trajectory(m.nq + m.nv + m.na, m.nu, pt.struct.num_residual, pt.struct.num_trace, horizon)
+    v = tr.view()
+    lib().orollout_pd(pm.ptr, pt.ptr, physics.d, as_f64p(_f(state)), float(time), as_f64p(_f(mocap)), horizon,
+                      as_f64p(_f(pos_goal)), as_f64p(_f(vel_goal)), float(P), float(D), C.byref(v))
+    tr.take(v)
+    return tr
+
+
+def rollout_batch(pm, pt, state, time, mocap, N, H, P, interp, node_times, node_values, num_threads=1, full=True):
+    """N x Trajectory::Rollout over a worker pool. Returns dict of arrays (candidate-major)."""
+    m = pm.struct
+    ds, nu, nr, ntr = m.nq + m.nv + m.na, m.nu, pt.struct.num_residual, pt.struct.num_trace
+    out = dict(total_return=np.zeros(N), failure=np.zeros(N, np.int32))
+    o = OBatchOut()
+    o.total_return, o.failure = as_f64p(out["total_return"]), as_i32p(out["failure"])
+    if full:
+        out.update(states=np.zeros((N, H, ds)), actions=np.zeros((N, H, nu)), times=np.zeros((N, H)),
+                   residual=np.zeros((N, H, nr)), costs=np.zeros((N, H)), trace=np.zeros((N, H, 3 * ntr)))
+        o.states, o.actions, o.times = as_f64p(out["states"]), as_f64p(out["actions"]), as_f64p(out["times"])
+        o.residual, o.costs, o.trace = as_f64p(out["residual"]), as_f64p(out["costs"]), as_f64p(out["trace"])
+    nt, nvv = _f(node_times), _f(node_values)
+    assert nvv.size == N * P * nu
+    mc = None if mocap is None else as_f64p(_f(mocap))
+    lib().orollout_batch(pm.ptr, pt.ptr, as_f64p(_f(state)), float(time), mc, None, N, H, P, interp,
+                         as_f64p(nt), as_f64p(nvv), int(num_threads), C.byref(o))
+    return out
+
+
+def noise_candidates(pm, noise_spec: MjpcxNoiseSpec, P, nominal, candidates):
+    """clamp(nominal + noise) for each global candidate index in `candidates`: (len, P, nu)."""
+    nu = pm.struct.nu
+    nom = _f(nominal).reshape(-1)
+    out = np.zeros((len(candidates), P, nu))
+    for k, gi in enumerate(candidates):
+        lib().onoise_candidate(pm.ptr, C.byref(noise_spec), P, as_f64p(nom), int(gi), as_f64p(out[k]))
+    return out
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().ophilox4x32_10(c, k, o)
+    return list(o)
