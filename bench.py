@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate-trajectory rollouts/sec of the MI355X rollout-and-evaluate path.
+
+A "step" is one pass of the hot path over one batch of synthetic input: one Predictive
+Sampling plan iteration's timed span in the reference (`rollouts_compute_time`,
+mjpc/planners/sampling/planner.cc:169-191) = candidate noise + N rollouts of H steps +
+selection of the best candidate, followed by the policy update that feeds the next step.
+
+Workload at --gpus 1 = BASELINE.json configs[1]: Cartpole, Predictive Sampling,
+4096 candidates, horizon 128, fp64, 10 cubic spline points. With --gpus N every rank
+rolls out its own 4096 candidates of a global batch of N*4096 (weak scaling) and the
+ranks exchange (best cost, index) + the winner's spline over RCCL.
+
+Prints ONE JSON line (rank 0) with the fields of the driver contract plus `roofline`
+and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--task", default="Cartpole")
+    ap.add_argument("--candidates", type=int, default=4096, help="candidates per GPU")
+    ap.add_argument("--horizon", type=int, default=128)
+    ap.add_argument("--precision", type=int, default=64, choices=[32, 64])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call):
+    """Times the CPU oracle (a port, NOT MuJoCo) driven through the reference's fan-out
+    structure (one task per candidate, one arena per worker) on all host cores."""
+    from mujoco_mpc_amd import capi
+    from oracle import pyoracle
+    pm, pt = task.packed_model(), task.packed()
+    cores = os.cpu_count() or 1
+    dt = task.model.get_number("agent_timestep", task.model.timestep)
+    times = np.array([k * (horizon - 1) * dt / (num_nodes - 1) for k in range(num_nodes)])
+    rng = np.random.default_rng(0)
+    nodes = np.clip(rng.normal(0, 0.5, (n_per_call, num_nodes, task.model.nu)), -1, 1)
+    pyoracle.rollout_batch(pm, pt, state, 0.0, None, min(256, n_per_call), horizon, num_nodes,
+                           capi.SPLINE_CUBIC, times, nodes[:min(256, n_per_call)], num_threads=cores, full=False)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        pyoracle.rollout_batch(pm, pt, state, 0.0, None, n_per_call, horizon, num_nodes, capi.SPLINE_CUBIC,
+                               times, nodes, num_threads=cores, full=False)
+        done += n_per_call
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return dict(value=done / el, unit="rollouts/s", cores=cores, kind="port",
+                sample=f"{done} rollouts of H={horizon} ({el:.1f} s) through the C oracle's ThreadPool-style fan-out, "
+                       f"{cores} threads; CPU restatement, not MuJoCo")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    import torch
+    from mujoco_mpc_amd import capi
+    from mujoco_mpc_amd.planners import GpuSamplingPlanner, State
+    from mujoco_mpc_amd.task import load_task
+
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        from mujoco_mpc_amd.distributed import RankGroup
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        group = RankGroup(dist, torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    task = load_task(args.task)
+    model = task.model
+    planner = GpuSamplingPlanner(device=local_rank, precision=args.precision, seed=0, group=group)
+    planner.initialize(model, task)
+    planner.num_trajectory_ = args.candidates * world  # lifts kMaxTrajectory=128
+    planner.allocate()
+    H = args.horizon
+    planner.reset(H)
+    P = planner.policy.num_spline_points
+
+    # synthetic initial condition: the task's home keyframe
+    state = State(model)
+    home = model.keyframes.get("home")
+    qpos = home["qpos"] if home else model.qpos0
+    qvel = home["qvel"] if home else np.zeros(model.nv)
+    state.set(qpos, qvel, time=0.0)
+    planner.set_state(state)
+
+    def step():
+        planner.optimize_policy(H)
+
+    def fence():
+        if group is not None:
+            group.barrier()
+        planner.ctx.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    planner.ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = planner.ctx.timing_read()
+    if group is not None:
+        elapsed = group.max_scalar(elapsed)
+
+    total_rollouts = args.candidates * world * args.steps
+    value = total_rollouts / elapsed
+    if rank == 0:
+        bytes_per_rollout = planner.ctx.algorithmic_bytes(H, P)
+        bytes_per_launch = bytes_per_rollout * args.candidates
+        avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
+        achieved = bytes_per_launch / avg_kernel_s / 1e9
+        out = {
+            "metric": "candidate-trajectory rollouts/sec (fixed horizon)",
+            "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.task} Predictive Sampling, {args.candidates} candidates/GPU, horizon {H}, "
+                                   f"{P} cubic spline points, fp{args.precision} (BASELINE.json configs[1])",
+                       "candidates_per_gpu": args.candidates, "horizon": H, "spline_points": P,
+                       "parallelism": f"candidates sharded over {world} rank(s)", "kernel": planner.ctx.kernel_name},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": avg_kernel_s * 1e3, "bytes_per_launch": bytes_per_launch,
+                         "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time on the context's stream; "
+                                 "the kernel is fp64-latency-bound at this batch size, see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline:
+            st = np.concatenate([qpos, qvel])
+            out["cpu_baseline"] = cpu_baseline(task, st, H, P, args.cpu_seconds, args.candidates)
+        print(json.dumps(out), flush=True)
+    if group is not None:
+        group.barrier()
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -254,6 +254,10 @@ int mjpcx_sync(mjpcx_ctx* ctx);
 /* total_return[N], failure[N] (Trajectory::total_return / failure). */
 int mjpcx_get_returns(mjpcx_ctx* ctx, double* total_return, int32_t* failure);
 
+/* total_return / failure of one candidate (e.g. trajectory[0], the nominal,
+ * for `improvement`, sampling/planner.cc:207-208). */
+int mjpcx_get_return_at(mjpcx_ctx* ctx, int candidate, double* total_return, int32_t* failure);
+
 /* Device-side selection replacing std::partial_sort (sampling/planner.cc:184):
  * indices and returns of the k best candidates, ascending, ties by index. */
 int mjpcx_topk(mjpcx_ctx* ctx, int k, int32_t* index, double* total_return);

@@ -23,7 +23,7 @@ NOISE_SAMPLING, NOISE_CROSS_ENTROPY = 0, 1
 EXPORTS = [
     "mjpcx_create", "mjpcx_destroy", "mjpcx_create_error", "mjpcx_error_string", "mjpcx_last_error",
     "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_rollout_splines",
-    "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_topk", "mjpcx_fetch_trajectory",
+    "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_topk", "mjpcx_fetch_trajectory",
     "mjpcx_fetch_spline", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
     "mjpcx_device_buffer",
 ]
@@ -63,6 +63,7 @@ def lib():
         L.mjpcx_rollout_noise.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.POINTER(MjpcxNoiseSpec)]
         L.mjpcx_sync.argtypes = [vp]
         L.mjpcx_get_returns.argtypes = [vp, c_f64p, c_i32p]
+        L.mjpcx_get_return_at.argtypes = [vp, C.c_int, C.POINTER(C.c_double), c_i32p]
         L.mjpcx_topk.argtypes = [vp, C.c_int, c_i32p, c_f64p]
         L.mjpcx_fetch_trajectory.argtypes = [vp, C.c_int, C.POINTER(MjpcxTrajView)]
         L.mjpcx_fetch_spline.argtypes = [vp, C.c_int, c_f64p]
@@ -183,6 +184,11 @@ class Context:
         fl = np.zeros(self.N, np.int32)
         self._chk(lib().mjpcx_get_returns(self.handle, as_f64p(ret), as_i32p(fl)))
         return ret, fl
+
+    def return_of(self, candidate):
+        r = C.c_double()
+        self._chk(lib().mjpcx_get_return_at(self.handle, int(candidate), C.byref(r), None))
+        return r.value
 
     def topk(self, k):
         idx = np.zeros(k, np.int32)

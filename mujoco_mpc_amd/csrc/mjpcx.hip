@@ -642,6 +642,17 @@ int mjpcx_get_returns(mjpcx_ctx* c, double* total_return, int32_t* failure) {
   return MJPCX_OK;
 }
 
+int mjpcx_get_return_at(mjpcx_ctx* c, int cand, double* total_return, int32_t* failure) {
+  if (!c) return MJPCX_EINVAL;
+  if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");
+  if (cand < 0 || cand >= c->N) return fail(c, MJPCX_EINVAL, "candidate out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (total_return) HIPCHK(c, hipMemcpyAsync(total_return, (const double*)c->d_ret.p + cand, 8, hipMemcpyDeviceToHost, c->stream));
+  if (failure) HIPCHK(c, hipMemcpyAsync(failure, (const int*)c->d_fail.p + cand, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+
 int mjpcx_topk(mjpcx_ctx* c, int k, int32_t* index, double* total_return) {
   if (!c || !index) return fail(c, MJPCX_EINVAL, "null argument");
   if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");

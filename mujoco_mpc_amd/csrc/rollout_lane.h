@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
     bool bad = false;
     if (!last) {
 #pragma unroll
-      for (int i = 0; i < NV; i++) bad |= is_bad(qpos[i]) | is_bad(qvel[i]);
+      for (int i = 0; i < NV; i++) bad |= is_bad(qpos[i]) || is_bad(qvel[i]);
 #pragma unroll
       for (int k = 0; k < NU; k++) bad |= is_bad(ctrl[k]);  // mjWARN_BADCTRL
     }

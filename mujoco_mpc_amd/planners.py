@@ -1,0 +1,316 @@
+"""Host-side planners over the C ABI: drop-in mirrors of the reference's
+`mjpc::SamplingPlanner` (mjpc/planners/sampling/planner.{h,cc}) and
+`mjpc::SamplingPolicy` (sampling/policy.{h,cc}).
+
+Only `Rollouts(...)` (planner.cc:355-393) and the sort (planner.cc:184-188) are
+replaced by device work; nominal resampling, policy copy and `ActionFromPolicy`
+stay host-side with the reference's semantics. Differences, both forced by
+SURVEY.md findings: the 128-candidate cap of kMaxTrajectory is lifted (F5) and
+noise comes from a seedable counter-based generator (F4).
+"""
+from __future__ import annotations
+
+import threading
+import time as _time
+
+import numpy as np
+
+from . import capi
+from .spline import CUBIC, LINEAR, ZERO, TimeSpline
+from .task import Task
+
+K_MAX_TRAJECTORY_HORIZON = 512  # mjpc/trajectory.h:27
+
+
+def clamp(x, bounds):
+    """Clamp, mjpc/utilities.cc:112-116 (mju_clip = max(lo, min(hi, x)))."""
+    b = np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
+    np.maximum(b[:, 0], np.minimum(b[:, 1], x), out=x)
+    return x
+
+
+class State:
+    """mjpc::State (mjpc/states/state.{h,cc}): the snapshot handed to Planner::SetState."""
+
+    def __init__(self, model):
+        self._lock = threading.RLock()
+        self.state = np.zeros(model.nq + model.nv + model.na)
+        self.mocap = np.zeros(7 * model.nmocap)
+        self.userdata = np.zeros(model.nuserdata)
+        self.time = 0.0
+        # mocap bodies start at their model pose
+        for b in range(model.nbody):
+            i = int(model.body_mocapid[b])
+            if i >= 0:
+                self.mocap[7 * i:7 * i + 3] = model.body_pos[b]
+                self.mocap[7 * i + 3:7 * i + 7] = model.body_quat[b]
+
+    def set(self, qpos, qvel, act=(), mocap_pos=None, mocap_quat=None, userdata=None, time=0.0):
+        with self._lock:
+            self.state[:] = np.concatenate([np.asarray(qpos, float), np.asarray(qvel, float), np.asarray(act, float)])
+            if mocap_pos is not None:
+                mp, mq = np.asarray(mocap_pos, float).reshape(-1, 3), np.asarray(mocap_quat, float).reshape(-1, 4)
+                for i in range(mp.shape[0]):
+                    self.mocap[7 * i:7 * i + 3], self.mocap[7 * i + 3:7 * i + 7] = mp[i], mq[i]
+            if userdata is not None:
+                self.userdata[:] = userdata
+            self.time = float(time)
+
+    def copy_to(self):
+        with self._lock:
+            return self.state.copy(), self.mocap.copy(), self.userdata.copy(), self.time
+
+
+class SamplingPolicy:
+    """mjpc::SamplingPolicy (sampling/policy.{h,cc})."""
+
+    def __init__(self):
+        self.model = None
+        self.plan = TimeSpline(0)
+        self.num_spline_points = 0
+
+    def allocate(self, model, task, horizon):
+        self.model = model
+        self.num_spline_points = int(model.get_number("sampling_spline_points", K_MAX_TRAJECTORY_HORIZON))
+        self.plan = TimeSpline(model.nu)
+        self.plan.reserve(self.num_spline_points)
+
+    def reset(self, horizon, initial_repeated_action=None):
+        self.plan.clear()
+        if initial_repeated_action is not None:
+            self.plan.add_node(0, initial_repeated_action)
+
+    def action(self, action, state, time):
+        self.plan.sample(time, action)
+        return clamp(action, self.model.actuator_ctrlrange)
+
+    def copy_from(self, policy, horizon=None):
+        self.model = policy.model
+        self.plan = policy.plan.copy()
+        self.num_spline_points = policy.num_spline_points
+
+
+class GpuSamplingPlanner:
+    """mjpc::SamplingPlanner with the candidate fan-out on the GPU.
+
+    `group`: optional rank group (see distributed.py) sharding the candidates over
+    GPUs; every rank keeps an identical host policy."""
+
+    def __init__(self, device=0, precision=64, seed=0, group=None, backend_factory=None):
+        self.device, self.precision, self.seed = device, precision, seed
+        self.group = group
+        self._backend_factory = backend_factory
+        self.model = None
+        self.task = None
+        self.ctx = None
+        self.mtx_ = threading.RLock()
+        self.noise_exploration = [0.0, 0.0]
+        self.iteration = 0
+        self.winner = 0
+        self.improvement = 0.0
+        self.noise_compute_time = 0.0
+        self.rollouts_compute_time = 0.0
+        self.policy_update_compute_time = 0.0
+        self.trajectory_order = []
+        self._scores = []
+
+    # ---- Planner::Initialize, planner.cc:41-77
+    def initialize(self, model, task: Task):
+        self.model, self.task = model, task
+        self.noise_exploration[0] = model.get_number("sampling_exploration", 0.1)
+        se = model.numeric.get("sampling_exploration")
+        self.noise_exploration[1] = float(se[1]) if se is not None and len(se) > 1 else 0.0
+        self.num_trajectory_ = int(model.get_number("sampling_trajectories", 10))
+        self.interpolation_ = int(model.get_number("sampling_representation", CUBIC))
+        self.sliding_plan_ = int(model.get_number("sampling_sliding_plan", 0))
+        self.winner = 0
+
+    # ---- Planner::Allocate, planner.cc:80-107
+    def allocate(self):
+        m = self.model
+        self.state = np.zeros(m.nq + m.nv + m.na)
+        self.mocap = np.zeros(7 * m.nmocap)
+        self.userdata = np.zeros(m.nuserdata)
+        self.time = 0.0
+        self.policy, self.previous_policy = SamplingPolicy(), SamplingPolicy()
+        self.policy.allocate(m, self.task, K_MAX_TRAJECTORY_HORIZON)
+        self.previous_policy.allocate(m, self.task, K_MAX_TRAJECTORY_HORIZON)
+        self.winner_policy = SamplingPolicy()  # candidate_policy[winner]
+        self.winner_policy.allocate(m, self.task, K_MAX_TRAJECTORY_HORIZON)
+        self.plan_scratch = TimeSpline(m.nu)
+        self._best = None
+        if self._backend_factory is not None:
+            self.ctx = self._backend_factory(self.task)
+        else:
+            self.ctx = capi.Context(self.task.packed_model(), self.task.packed(), self.device, self.precision)
+
+    # ---- Planner::Reset, planner.cc:110-147
+    def reset(self, horizon, initial_repeated_action=None):
+        self.state[:] = 0
+        self.mocap[:] = 0
+        self.userdata[:] = 0
+        self.time = 0.0
+        with self.mtx_:
+            self.policy.reset(horizon, initial_repeated_action)
+            self.previous_policy.reset(horizon, initial_repeated_action)
+        self.winner_policy.reset(horizon, initial_repeated_action)
+        self.plan_scratch.clear()
+        self.improvement = 0.0
+        self.winner = 0
+        self._best = None
+
+    # ---- Planner::SetState, planner.cc:150-153
+    def set_state(self, state: State):
+        self.state, self.mocap, self.userdata, self.time = state.copy_to()
+
+    # ---- UpdateNominalPolicy, planner.cc:240-323
+    def update_nominal_policy(self, horizon):
+        num_spline_points = self.winner_policy.num_spline_points
+        nominal_time = self.time
+        time_horizon = (horizon - 1) * self._timestep()
+        if self.sliding_plan_:
+            extra = {ZERO: 1, LINEAR: 2, CUBIC: 4}[self.interpolation_]
+            if num_spline_points > extra:
+                time_shift = max(time_horizon / (num_spline_points - extra), 1.0e-5)
+            else:
+                time_shift = time_horizon
+            with self.mtx_:
+                plan = self.policy.plan
+                if plan.size() and plan.node_at(0)[0] > nominal_time:
+                    plan.shift_time(nominal_time)
+                    self.previous_policy.plan.shift_time(nominal_time)
+                plan.discard_before(nominal_time)
+                if plan.size() == 0:
+                    plan.add_node(nominal_time)
+                while plan.size() < num_spline_points:
+                    t_last, v_last = plan.node_at(plan.size() - 1)
+                    plan.add_node(t_last + time_shift, v_last.copy())
+        else:
+            if self.interpolation_ == ZERO:
+                time_shift = max(time_horizon / num_spline_points, 1.0e-5)
+            else:
+                time_shift = max(time_horizon / (num_spline_points - 1), 1.0e-5)
+            self.plan_scratch.clear()
+            self.plan_scratch.set_interpolation(self.interpolation_)
+            for _ in range(num_spline_points):
+                node = self.plan_scratch.add_node(nominal_time)
+                self.winner_policy.action(node, None, nominal_time)
+                nominal_time += time_shift
+            with self.mtx_:
+                self.policy.plan = self.plan_scratch.copy()
+
+    def _timestep(self):
+        return self.model.get_number("agent_timestep", self.model.timestep)
+
+    # ---- Rollouts, planner.cc:355-393: the device fan-out
+    def rollouts(self, num_trajectory, horizon):
+        plan = self.policy.plan
+        rank, world = (self.group.rank, self.group.world) if self.group else (0, 1)
+        # candidates [rank*n, (rank+1)*n) of the global batch; candidate 0 is the un-noised nominal
+        n_local = num_trajectory // world
+        offset = rank * n_local
+        if rank == world - 1:
+            n_local = num_trajectory - offset
+        ns = capi.make_noise_spec(seed=self.seed, iteration=self.iteration, mode=capi.NOISE_SAMPLING,
+                                  candidate_offset=offset, nominal_candidate=0,
+                                  std0=self.noise_exploration[0], std1=self.noise_exploration[1])
+        self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
+        self.ctx.rollout_noise(n_local, horizon, plan.interpolation(), plan.times(), plan.values(), ns)
+        self._offset, self._n_local = offset, n_local
+
+    # ---- OptimizePolicyCandidates, planner.cc:155-194
+    def optimize_policy_candidates(self, ncandidates, horizon, pool=None):
+        self.update_nominal_policy(horizon)
+        num_trajectory = self.num_trajectory_
+        ncandidates = min(ncandidates, num_trajectory)
+        t0 = _time.perf_counter()
+        self.policy.plan.set_interpolation(self.interpolation_)
+        self.rollouts(num_trajectory, horizon)
+        k = min(ncandidates, self._n_local)
+        idx, ret = self.ctx.topk(k)  # device selection replaces std::partial_sort
+        idx = idx + self._offset
+        if self.group and self.group.world > 1:
+            idx, ret = self.group.merge_topk(idx, ret, ncandidates)
+        self.trajectory_order = [int(i) for i in idx]
+        self._scores = [float(r) for r in ret]
+        self.rollouts_compute_time = (_time.perf_counter() - t0) * 1e6
+        self.iteration += 1
+        return len(self.trajectory_order)
+
+    # ---- OptimizePolicy, planner.cc:197-212
+    def optimize_policy(self, horizon, pool=None):
+        self.optimize_policy_candidates(1, horizon, pool)
+        t0 = _time.perf_counter()
+        nominal_return = self._nominal_return()
+        self.copy_candidate_to_policy(0)
+        self.improvement = max(nominal_return - self._scores[0], 0.0)
+        self.policy_update_compute_time = (_time.perf_counter() - t0) * 1e6
+
+    def _nominal_return(self):
+        """trajectory[0].total_return: global candidate 0 lives on rank 0."""
+        val = None
+        if self._offset == 0:
+            val = float(self.ctx.return_of(0))
+        if self.group and self.group.world > 1:
+            val = self.group.broadcast_scalar(val, src=0)
+        return val
+
+    # ---- NominalTrajectory, planner.cc:215-227
+    def nominal_trajectory(self, horizon, pool=None):
+        plan = self.winner_policy.plan if self.winner_policy.plan.size() else self.policy.plan
+        self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
+        if plan.size() == 0:
+            times, values = np.array([self.time]), np.zeros((1, 1, self.model.nu))
+        else:
+            times, values = plan.times(), plan.values()[None]
+        self.ctx.rollout_splines(horizon, plan.interpolation(), times, values)
+        self._best = self.ctx.fetch_trajectory(0)
+        return self._best
+
+    # ---- ActionFromPolicy, planner.cc:230-238: never touches the GPU
+    def action_from_policy(self, action, state, time, use_previous=False):
+        with self.mtx_:
+            return (self.previous_policy if use_previous else self.policy).action(action, state, time)
+
+    # ---- BestTrajectory, planner.cc:396-398
+    def best_trajectory(self):
+        return self._best
+
+    def num_parameters(self):
+        return self.policy.num_spline_points * self.model.nu
+
+    # ---- RankedPlanner quartet, planner.cc:520-543
+    def candidate_score(self, candidate):
+        return self._scores[candidate]
+
+    def action_from_candidate_policy(self, action, candidate, state, time):
+        p = SamplingPolicy()
+        p.copy_from(self.policy)
+        self._load_candidate_plan(p, self.trajectory_order[candidate])
+        return p.action(action, state, time)
+
+    def _load_candidate_plan(self, policy, global_idx):
+        """candidate_policy[i].plan: fetched from the rank that rolled it out."""
+        local = global_idx - self._offset
+        values = None
+        owner = 0
+        if 0 <= local < self._n_local:
+            values = self.ctx.fetch_spline(local)
+        if self.group and self.group.world > 1:
+            owner = self.group.owner_of(global_idx, self.num_trajectory_)
+            values = self.group.broadcast_array(values, (self.ctx.P, self.model.nu), src=owner)
+        times = self.policy.plan.times()
+        policy.plan = TimeSpline(self.model.nu, self.policy.plan.interpolation())
+        for t, v in zip(times, values):
+            policy.plan.add_node(t, v)
+
+    def copy_candidate_to_policy(self, candidate):
+        self.winner = self.trajectory_order[candidate]
+        self.winner_policy.num_spline_points = self.policy.num_spline_points
+        self._load_candidate_plan(self.winner_policy, self.winner)
+        local = self.winner - self._offset
+        if 0 <= local < self._n_local and not (self.group and self.group.world > 1):
+            self._best = self.ctx.fetch_trajectory(local)
+        with self.mtx_:
+            self.previous_policy.copy_from(self.policy)
+            self.policy.copy_from(self.winner_policy)

@@ -44,6 +44,7 @@ struct OData {
   double *efc_J; /* OMAXEFC x nv */
   double efc_pos[OMAXEFC], efc_margin[OMAXEFC], efc_R[OMAXEFC], efc_aref[OMAXEFC];
   double efc_b[OMAXEFC], efc_force[OMAXEFC];
+  double *scratch_minvjt, *scratch_qacc, *scratch_A; /* preallocated work arrays */
   int warning;
 };
 
@@ -181,6 +182,7 @@ OData* odata_new(const mjpcx_model* m) {
   d->qfrc_smooth = dalloc(nv); d->qacc_smooth = dalloc(nv); d->qfrc_constraint = dalloc(nv);
   d->qacc = dalloc(nv); d->actuator_force = dalloc(nu);
   d->efc_J = dalloc(OMAXEFC * nv);
+  d->scratch_minvjt = dalloc(OMAXEFC * nv); d->scratch_qacc = dalloc(nv); d->scratch_A = dalloc(2 * nv * nv);
   /* subtree masses are model constants */
   for (int i = 0; i < nb; i++) d->subtree_mass[i] = m->body_mass[i];
   for (int i = nb - 1; i > 0; i--) d->subtree_mass[m->body_parentid[i]] += d->subtree_mass[i];
@@ -200,7 +202,8 @@ void odata_free(OData* d) {
                   &d->site_xpos, &d->site_xmat, &d->subtree_com, &d->subtree_mass, &d->cinert,
                   &d->crb, &d->cdof, &d->cdof_dot, &d->cvel, &d->cacc, &d->cfrc, &d->M, &d->L,
                   &d->qfrc_passive, &d->qfrc_bias, &d->qfrc_actuator, &d->qfrc_smooth,
-                  &d->qacc_smooth, &d->qfrc_constraint, &d->qacc, &d->actuator_force, &d->efc_J};
+                  &d->qacc_smooth, &d->qfrc_constraint, &d->qacc, &d->actuator_force, &d->efc_J,
+                  &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
   free(d);
 }
@@ -563,7 +566,7 @@ static void o_constraint(OData* d) {
   memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
   if (ne == 0) return;
   double AR[OMAXEFC * OMAXEFC];
-  double* MinvJt = (double*)malloc(sizeof(double) * ne * nv);
+  double* MinvJt = d->scratch_minvjt;
   for (int r = 0; r < ne; r++) {
     int j = d->efc_jnt[r];
     const double* solref = m->jnt_solref + 2 * j;
@@ -621,7 +624,6 @@ static void o_constraint(OData* d) {
       d->qfrc_constraint[c] += d->efc_J[r * nv + c] * d->efc_force[r];
       d->qacc[c] += MinvJt[r * nv + c] * d->efc_force[r];
     }
-  free(MinvJt);
 }
 
 void o_forward(OData* d) {
@@ -647,17 +649,16 @@ static void o_euler(OData* d) {
   const mjpcx_model* m = d->m;
   int nv = m->nv;
   double h = m->timestep;
-  double* qacc = (double*)malloc(sizeof(double) * nv);
+  double* qacc = d->scratch_qacc;
   int damped = 0;
   for (int i = 0; i < nv; i++) damped |= m->dof_damping[i] > 0;
   if (damped && !(m->disableflags & MJPCX_DSBL_EULERDAMP)) {
-    double* A = (double*)malloc(sizeof(double) * nv * nv * 2);
+    double* A = d->scratch_A;
     memcpy(A, d->M, sizeof(double) * nv * nv);
     for (int i = 0; i < nv; i++) A[i * nv + i] += h * m->dof_damping[i];
     for (int i = 0; i < nv; i++) qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
     if (chol_factor(A + nv * nv, A, nv)) chol_solve(qacc, A + nv * nv, qacc, nv);
     else memcpy(qacc, d->qacc, sizeof(double) * nv);
-    free(A);
   } else {
     memcpy(qacc, d->qacc, sizeof(double) * nv);
   }
@@ -685,7 +686,6 @@ static void o_euler(OData* d) {
     }
   }
   d->time += h;
-  free(qacc);
 }
 
 void o_forward_task(OData* d, const mjpcx_task* task, double* r) {

@@ -117,7 +117,6 @@ typedef struct {
   int N, H, P, interp;
   OBatchOut* out;
   int next; /* shared work counter = the FIFO queue of one task per candidate */
-  pthread_mutex_t mu;
 } Batch;
 
 static void* batch_worker(void* arg) {
@@ -128,9 +127,7 @@ static void* batch_worker(void* arg) {
   OSpline sp;
   ospline_init(&sp, nu, b->interp);
   for (;;) {
-    pthread_mutex_lock(&b->mu);
-    int i = b->next++;
-    pthread_mutex_unlock(&b->mu);
+    int i = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
     if (i >= b->N) break;
     ospline_clear(&sp);
     for (int p = 0; p < b->P; p++)
@@ -158,8 +155,7 @@ int orollout_batch(const mjpcx_model* m, const mjpcx_task* task, const double* s
                    const double* mocap, const double* userdata, int N, int H, int P, int interp,
                    const double* node_times, const double* node_values, int num_threads,
                    OBatchOut* out) {
-  Batch b = {m, task, state, mocap, userdata, node_times, node_values, time, N, H, P, interp, out, 0,
-             PTHREAD_MUTEX_INITIALIZER};
+  Batch b = {m, task, state, mocap, userdata, node_times, node_values, time, N, H, P, interp, out, 0};
   if (num_threads < 1) num_threads = 1;
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * num_threads);
   for (int t = 0; t < num_threads; t++) pthread_create(&th[t], NULL, batch_worker, &b);

@@ -1,0 +1,92 @@
+"""CPU-side checks of the drop-in boundary: libmjpcx.so builds (hipcc cross-compiles gfx950 without a
+GPU), loads, and exports every symbol include/mjpcx.h declares; struct layouts agree with the header."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mujoco_mpc_amd import capi, cstructs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mjpcx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mjpcx_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.lib()
+    declared = header_functions()
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mjpcx.h but not exported"
+    assert sorted(capi.EXPORTS) == declared
+
+
+def test_error_strings():
+    lib = capi.lib()
+    assert lib.mjpcx_error_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5):
+        assert lib.mjpcx_error_string(code) not in (b"ok", b"unknown error")
+
+
+def test_struct_layout_matches_header():
+    """Field order / count of the ctypes mirrors vs the C structs (parsed from the header)."""
+    src = open(os.path.join(ROOT, "include", "mjpcx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), src, re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r"^(const\s+)?(u?int\d+_t|double)\s*\*?\s*", "", decl)
+            for n in decl.split(","):
+                names.append(re.sub(r"\[.*\]", "", n.strip().lstrip("*").strip()))
+        return names
+
+    assert fields("mjpcx_model") == [f[0] for f in cstructs.MjpcxModel._fields_]
+    assert fields("mjpcx_task") == [f[0] for f in cstructs.MjpcxTask._fields_]
+    assert fields("mjpcx_traj_view") == [f[0] for f in cstructs.MjpcxTrajView._fields_]
+    assert fields("mjpcx_noise_spec") == [f[0] for f in cstructs.MjpcxNoiseSpec._fields_]
+
+
+def test_create_rejects_bad_arguments(cartpole):
+    """Argument validation happens before any device call, so it is testable without a GPU."""
+    lib = capi.lib()
+    pm, pt = cartpole.packed_model(), cartpole.packed()
+    h = C.c_void_p()
+    assert lib.mjpcx_create(None, pt.ptr, 0, 64, C.byref(h)) == -1
+    assert lib.mjpcx_create(pm.ptr, pt.ptr, 0, 16, C.byref(h)) == -1
+    assert b"precision" in lib.mjpcx_create_error()
+
+
+def test_unsupported_models_fail_loudly(cartpole):
+    import copy
+    lib = capi.lib()
+    t = copy.copy(cartpole)
+    pm = t.packed_model()
+    pm.struct.integrator = 1  # RK4 has no device kernel yet
+    h = C.c_void_p()
+    assert lib.mjpcx_create(pm.ptr, t.packed().ptr, 0, 64, C.byref(h)) == -2
+    assert b"Euler" in lib.mjpcx_create_error()
+    # an unknown topology names the missing instantiation
+    spec = t.spec(); spec["residual_id"] = 99
+    from mujoco_mpc_amd.cstructs import PackedTask
+    assert lib.mjpcx_create(t.packed_model().ptr, PackedTask(spec).ptr, 0, 64, C.byref(h)) == -2
+    assert b"no rollout kernel is instantiated" in lib.mjpcx_create_error()
+
+
+def test_no_cpu_fallback_in_product():
+    """The product package must not import or link the oracle."""
+    pkg = os.path.join(ROOT, "mujoco_mpc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".cc")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and "oracle.h" not in txt, f

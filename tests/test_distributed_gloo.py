@@ -1,0 +1,72 @@
+"""world_size-2 `gloo` test of the candidate sharding + exchange (mujoco_mpc_amd/distributed.py):
+two ranks, each rolling out half of the candidates, must produce the same policy as one rank rolling
+out all of them (the noise is counter-based on the GLOBAL candidate index)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch, torch.distributed as dist
+from mujoco_mpc_amd.distributed import RankGroup
+from mujoco_mpc_amd.planners import GpuSamplingPlanner, State
+from mujoco_mpc_amd.task import load_task
+from oracle_backend import OracleContext
+world = int(os.environ.get("WORLD_SIZE", "1"))
+group = None
+if world > 1:
+    dist.init_process_group(backend="gloo")
+    group = RankGroup(dist, torch.device("cpu"))
+task = load_task("Cartpole")
+p = GpuSamplingPlanner(seed=5, group=group, backend_factory=lambda t: OracleContext(t, threads=1))
+p.initialize(task.model, task); p.num_trajectory_ = 48; p.allocate()
+H = 24
+p.reset(H)
+st = State(task.model); st.set([0.2, 0.6], [0.0, 0.1])
+p.set_state(st)
+log = []
+for it in range(3):
+    p.optimize_policy(H)
+    log.append(dict(winner=int(p.winner), score=p.candidate_score(0), improvement=p.improvement,
+                    plan=p.policy.plan.values().tolist()))
+if group is None or group.rank == 0:
+    print("RESULT " + json.dumps(log))
+if group is not None:
+    # unit checks of the exchange primitives
+    idx, ret = group.merge_topk(np.array([group.rank * 10 + 1, group.rank * 10 + 2]), np.array([1.0 - group.rank, 5.0]), 3)
+    assert list(idx) == [11, 1, 2] and list(ret) == [0.0, 1.0, 5.0], (idx, ret)
+    assert group.broadcast_scalar(3.5 if group.rank == 1 else None, src=1) == 3.5
+    assert group.owner_of(47, 48) == 1 and group.owner_of(0, 48) == 0
+    assert group.max_scalar(float(group.rank)) == 1.0
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def run(world):
+    script = WORKER % dict(root=ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    if world == 1:
+        cmd = [sys.executable, "-c", script]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", "29533", "--no-python", sys.executable, "-c", script]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    import json
+    return json.loads(line[7:])
+
+
+def test_two_ranks_equal_one_rank():
+    one, two = run(1), run(2)
+    assert len(one) == len(two) == 3
+    for a, b in zip(one, two):
+        assert a["winner"] == b["winner"]
+        assert a["score"] == b["score"] and a["improvement"] == b["improvement"]
+        assert np.array_equal(np.array(a["plan"]), np.array(b["plan"]))
