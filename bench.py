@@ -43,8 +43,10 @@ def parse():
 
 
 def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call):
-    """Times the CPU oracle (a port, NOT MuJoCo) driven through the reference's fan-out
-    structure (one task per candidate, one arena per worker) on all host cores."""
+    """Times the CPU oracle (a port, NOT MuJoCo) driven through the reference's fan-out structure
+    (one task per candidate, one physics arena per worker thread; sampling/planner.cc:355-393) on the
+    GPU box's host cores. The thread count is the best of a short probe over {all, 1/2, 1/4, 1/8} of the
+    visible cores (containers often expose more CPUs than their quota lets them run)."""
     from mujoco_mpc_amd import capi
     from oracle import pyoracle
     pm, pt = task.packed_model(), task.packed()
@@ -53,19 +55,30 @@ def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call):
     times = np.array([k * (horizon - 1) * dt / (num_nodes - 1) for k in range(num_nodes)])
     rng = np.random.default_rng(0)
     nodes = np.clip(rng.normal(0, 0.5, (n_per_call, num_nodes, task.model.nu)), -1, 1)
-    pyoracle.rollout_batch(pm, pt, state, 0.0, None, min(256, n_per_call), horizon, num_nodes,
-                           capi.SPLINE_CUBIC, times, nodes[:min(256, n_per_call)], num_threads=cores, full=False)
+
+    def run(n, threads):
+        t0 = time.perf_counter()
+        pyoracle.rollout_batch(pm, pt, state, 0.0, None, n, horizon, num_nodes, capi.SPLINE_CUBIC, times, nodes[:n],
+                               num_threads=threads, full=False)
+        return n / (time.perf_counter() - t0)
+
+    best_threads, best_rate = 1, 0.0
+    for threads in sorted({max(1, cores // d) for d in (1, 2, 4, 8)}):
+        n = min(n_per_call, 64 * threads)
+        run(n, threads)
+        rate = max(run(n, threads), run(n, threads))
+        if rate > best_rate:
+            best_threads, best_rate = threads, rate
     done, t0 = 0, time.perf_counter()
     while True:
-        pyoracle.rollout_batch(pm, pt, state, 0.0, None, n_per_call, horizon, num_nodes, capi.SPLINE_CUBIC,
-                               times, nodes, num_threads=cores, full=False)
+        run(n_per_call, best_threads)
         done += n_per_call
         el = time.perf_counter() - t0
         if el >= seconds:
             break
-    return dict(value=done / el, unit="rollouts/s", cores=cores, kind="port",
+    return dict(value=done / el, unit="rollouts/s", cores=best_threads, kind="port",
                 sample=f"{done} rollouts of H={horizon} ({el:.1f} s) through the C oracle's ThreadPool-style fan-out, "
-                       f"{cores} threads; CPU restatement, not MuJoCo")
+                       f"{best_threads} threads (best of a probe over {cores} visible CPUs); CPU restatement, not MuJoCo")
 
 
 def main():
@@ -155,9 +168,20 @@ def main():
                          "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time on the context's stream; "
                                  "the kernel is fp64-latency-bound at this batch size, see DESIGN.md"},
         }
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # collected in separate --pmc runs as MI355X_MICROARCH.md prescribes); only for the profiled workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            if args.task == "Cartpole" and args.candidates == 4096 and H == 128 and args.precision == 64:
+                out["roofline"]["traffic"] = pmc["n4096"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         if not args.no_cpu_baseline:
             st = np.concatenate([qpos, qvel])
-            out["cpu_baseline"] = cpu_baseline(task, st, H, P, args.cpu_seconds, args.candidates)
+            # same workload (model, horizon, spline), batch enlarged so that every host thread has
+            # >= 64 rollouts per fan-out and thread start-up does not dominate the CPU number
+            n_cpu = max(args.candidates, 64 * (os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(task, st, H, P, args.cpu_seconds, n_cpu)
         print(json.dumps(out), flush=True)
     if group is not None:
         group.barrier()

@@ -262,6 +262,13 @@ int mjpcx_get_return_at(mjpcx_ctx* ctx, int candidate, double* total_return, int
  * indices and returns of the k best candidates, ascending, ties by index. */
 int mjpcx_topk(mjpcx_ctx* ctx, int k, int32_t* index, double* total_return);
 
+/* The reads one Predictive-Sampling policy update needs, fused into one launch and one sync:
+ * argmin over total_return (ties by index) -> *index, *best_return; the winner's spline values
+ * (P x nu, may be NULL); and the return of `ref_candidate` (the nominal, candidate 0; -1: skip)
+ * for `improvement` (sampling/planner.cc:197-212, 534-543). */
+int mjpcx_best(mjpcx_ctx* ctx, int ref_candidate, int32_t* index, double* best_return, double* ref_return,
+               double* spline_values);
+
 /* Gather one candidate into the reference's Trajectory layout. */
 int mjpcx_fetch_trajectory(mjpcx_ctx* ctx, int candidate, mjpcx_traj_view* out);
 

@@ -8,8 +8,11 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libmjpcx.so")
-SOURCES = ["mjpcx.hip"]
-HEADERS = ["device_common.h", "rollout_lane.h", os.path.join("..", "..", "include", "mjpcx.h")]
+# (source, extra flags). lane_static.hip holds the instantiations specialised for compile-time model
+# constants; its flags let exact-zero arithmetic fold (see the file header).
+SOURCES = [("mjpcx.hip", []), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"])]
+HEADERS = ["device_common.h", "rollout_lane.h", "lane_registry.h", os.path.join("generated", "static_models.h"),
+           os.path.join("..", "..", "include", "mjpcx.h")]
 
 
 def _hipcc():
@@ -27,11 +30,27 @@ def _stale(target, deps):
 
 
 def build_native(force=False, verbose=False):
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    from . import codegen
+    codegen.main([])  # regenerate generated/static_models.h if the model XMLs changed
+    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS]
     if not force and not _stale(LIB, deps):
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    objdir = os.path.join(PKG_DIR, "build")
+    os.makedirs(objdir, exist_ok=True)
+    common = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    objs, procs = [], []
+    for src, flags in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, deps):
+            cmd = common + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -23,7 +23,7 @@ NOISE_SAMPLING, NOISE_CROSS_ENTROPY = 0, 1
 EXPORTS = [
     "mjpcx_create", "mjpcx_destroy", "mjpcx_create_error", "mjpcx_error_string", "mjpcx_last_error",
     "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_rollout_splines",
-    "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_topk", "mjpcx_fetch_trajectory",
+    "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_fetch_trajectory",
     "mjpcx_fetch_spline", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
     "mjpcx_device_buffer",
 ]
@@ -64,6 +64,7 @@ def lib():
         L.mjpcx_sync.argtypes = [vp]
         L.mjpcx_get_returns.argtypes = [vp, c_f64p, c_i32p]
         L.mjpcx_get_return_at.argtypes = [vp, C.c_int, C.POINTER(C.c_double), c_i32p]
+        L.mjpcx_best.argtypes = [vp, C.c_int, c_i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_f64p]
         L.mjpcx_topk.argtypes = [vp, C.c_int, c_i32p, c_f64p]
         L.mjpcx_fetch_trajectory.argtypes = [vp, C.c_int, C.POINTER(MjpcxTrajView)]
         L.mjpcx_fetch_spline.argtypes = [vp, C.c_int, c_f64p]
@@ -189,6 +190,15 @@ class Context:
         r = C.c_double()
         self._chk(lib().mjpcx_get_return_at(self.handle, int(candidate), C.byref(r), None))
         return r.value
+
+    def best(self, ref_candidate=0, with_spline=True):
+        """argmin + winner spline + reference candidate's return in one launch / one sync."""
+        idx = np.zeros(1, np.int32)
+        br, rr = C.c_double(), C.c_double()
+        sp = np.zeros((self.P, self.nu)) if with_spline else None
+        self._chk(lib().mjpcx_best(self.handle, int(ref_candidate), as_i32p(idx), C.byref(br), C.byref(rr),
+                                   as_f64p(sp) if with_spline else None))
+        return int(idx[0]), br.value, rr.value, sp
 
     def topk(self, k):
         idx = np.zeros(k, np.int32)

@@ -14,12 +14,15 @@ constexpr double kMaxVal = 1e10;   // mjMAXVAL
 constexpr double kMaxReturn = 1.0e6;  // kMaxReturnValue, mjpc/trajectory.cc:29
 
 // Capacity of the lane-per-candidate ("small model") kernel family.
-constexpr int kLaneMaxBody = 8, kLaneMaxDof = 8, kLaneMaxAct = 8, kLaneMaxSite = 8;
-constexpr int kLaneMaxMocap = 4, kLaneMaxTerm = 16, kLaneMaxParam = 16;
+// LaneModel + LaneTask travel BY VALUE in the kernel-argument segment (<= 4 KiB), so the
+// capacities are sized to keep sizeof(LaneModel<double>) + sizeof(LaneTask<double>) ~ 3 KiB.
+constexpr int kLaneMaxBody = 6, kLaneMaxDof = 6, kLaneMaxAct = 6, kLaneMaxSite = 4;
+constexpr int kLaneMaxMocap = 2, kLaneMaxTerm = 8, kLaneMaxParam = 8;
 
-// Model constants of a slide/hinge tree, in the compute precision T. One instance lives
-// in device global memory; kernels read it through a wave-uniform pointer with constant
-// offsets, so every access is an s_load from the scalar cache (no VGPRs, no LDS).
+// Model constants of a slide/hinge tree, in the compute precision T. Passed by value as a
+// kernel argument: the kernarg segment is constant address space, so every access is an
+// s_load through the scalar cache into SGPRs (no VGPRs, no LDS, no aliasing with the
+// kernel's own global stores -- which is what forces vector re-loads through a pointer).
 template <typename T>
 struct LaneModel {
   T timestep, gravity[3], solver_tolerance, meaninertia;
@@ -129,9 +132,16 @@ template <typename T> __device__ __forceinline__ void cross_force(T (&res)[6], c
 template <typename T> __device__ __forceinline__ T dot6(const T (&a)[6], const T (&b)[6]) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
-// mju_isBad without relying on NaN comparison semantics
-template <typename T> __device__ __forceinline__ bool is_bad(T x) {
-  return !(x <= T(kMaxVal) && x >= T(-kMaxVal));
+// mju_isBad (NaN, or |x| > mjMAXVAL) as an integer test on the bit pattern: for non-negative
+// IEEE values the bit patterns order like the values, and Inf/NaN patterns are above every
+// finite one. Immune to the compiler's floating-point assumptions (finite-math TUs).
+__device__ __forceinline__ bool is_bad(double x) {
+  const uint64_t mag = (uint64_t)__double_as_longlong(x) & 0x7fffffffffffffffull;
+  return mag > 0x4202A05F20000000ull;  // bits of 1e10
+}
+__device__ __forceinline__ bool is_bad(float x) {
+  const uint32_t mag = (uint32_t)__float_as_int(x) & 0x7fffffffu;
+  return mag > 0x501502F9u;  // bits of 1e10f
 }
 __device__ __forceinline__ void sincos_t(double x, double& s, double& c) { sincos(x, &s, &c); }
 __device__ __forceinline__ void sincos_t(float x, float& s, float& c) { sincosf(x, &s, &c); }

@@ -1,0 +1,44 @@
+// lane_registry.h -- the registered static topologies of the lane-per-candidate kernel family and
+// the launchers of the specialised (compile-time model constants) instantiations, which live in
+// their own translation unit (lane_static.hip) built with -fno-signed-zeros -ffinite-math-only so
+// that arithmetic on exact-zero model constants folds away.
+#pragma once
+#include "../../include/mjpcx.h"
+#include "generated/static_models.h"
+#include "rollout_lane.h"
+
+namespace mjpcx {
+
+constexpr uint64_t pack4() { return 0; }
+template <typename... R> constexpr uint64_t pack4(int a, R... r) { return (uint64_t)(a & 15) | (pack4(r...) << 4); }
+constexpr uint64_t pack2() { return 0; }
+template <typename... R> constexpr uint64_t pack2(int a, R... r) { return (uint64_t)(a & 3) | (pack2(r...) << 2); }
+
+// Cart-pole (mjpc/tasks/cartpole): world -> cart[slide x, limited] -> pole_1[hinge y]; site tip on pole
+using TopoCartpole = Topo</*NB*/3, /*NV*/2, /*NU*/1, /*NSITE*/1, /*NMOCAP*/0,
+                          /*parent*/pack4(0, 0, 1), /*mocap*/pack4(15, 15, 15), /*jtype*/pack2(kJntSlide, kJntHinge),
+                          /*jbody*/pack4(1, 2), /*jlimited*/0x1, /*actj*/pack4(0), /*siteb*/pack4(2)>;
+using TaskCartpole = TaskTopo<MJPCX_RESIDUAL_CARTPOLE, 4, 4, pack4(1, 1, 1, 1), 1, pack4(0)>;
+// Particle (mjpc/test/testdata/particle.xml): world -> goal[mocap]; world -> pointmass[slide x, slide y]
+using TopoParticle = Topo<3, 2, 2, 1, 1, pack4(0, 0, 0), pack4(15, 0, 15), pack2(kJntSlide, kJntSlide),
+                          pack4(2, 2), 0x3, pack4(0, 1), pack4(2)>;
+using TaskParticle = TaskTopo<MJPCX_RESIDUAL_PARTICLE, 4, 2, pack4(2, 2), 1, pack4(0)>;
+using TaskParticleCopy = TaskTopo<MJPCX_RESIDUAL_PARTICLE_COPY, 4, 2, pack4(2, 2), 1, pack4(0)>;
+
+template <class TP, class TK, typename T, class MC>
+hipError_t launch_lane_impl(const LaneModel<T>& m, const LaneTask<T>& tk, const RolloutArgs<T>& a, hipStream_t s) {
+  static_assert(sizeof(LaneModel<T>) + sizeof(LaneTask<T>) + sizeof(RolloutArgs<T>) <= 4096, "kernarg segment is 4 KiB");
+  const int blocks = (a.N + 63) / 64;
+  const size_t shmem = ((size_t)a.P * TP::NU * 64 + a.P) * sizeof(T);
+  hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
+  return hipGetLastError();
+}
+
+#define MJPCX_DECLARE_STATIC(FN)                                                                             \
+  hipError_t FN##_f64(const LaneModel<double>&, const LaneTask<double>&, const RolloutArgs<double>&, hipStream_t); \
+  hipError_t FN##_f32(const LaneModel<float>&, const LaneTask<float>&, const RolloutArgs<float>&, hipStream_t);
+MJPCX_DECLARE_STATIC(launch_static_cartpole)
+MJPCX_DECLARE_STATIC(launch_static_particle)
+MJPCX_DECLARE_STATIC(launch_static_particle_copy)
+
+}  // namespace mjpcx

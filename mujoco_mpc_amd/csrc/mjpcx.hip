@@ -16,27 +16,12 @@
 
 #include "../../include/mjpcx.h"
 #include "rollout_lane.h"
+#include "lane_registry.h"
 
 using namespace mjpcx;
 
 // ===================================================================== kernel registry
 namespace {
-
-constexpr uint64_t pack4() { return 0; }
-template <typename... R> constexpr uint64_t pack4(int a, R... r) { return (uint64_t)(a & 15) | (pack4(r...) << 4); }
-constexpr uint64_t pack2() { return 0; }
-template <typename... R> constexpr uint64_t pack2(int a, R... r) { return (uint64_t)(a & 3) | (pack2(r...) << 2); }
-
-// Cart-pole (mjpc/tasks/cartpole): world -> cart[slide x, limited] -> pole_1[hinge y]; site tip on pole
-using TopoCartpole = Topo</*NB*/3, /*NV*/2, /*NU*/1, /*NSITE*/1, /*NMOCAP*/0,
-                          /*parent*/pack4(0, 0, 1), /*mocap*/pack4(15, 15, 15), /*jtype*/pack2(kJntSlide, kJntHinge),
-                          /*jbody*/pack4(1, 2), /*jlimited*/0x1, /*actj*/pack4(0), /*siteb*/pack4(2)>;
-using TaskCartpole = TaskTopo<MJPCX_RESIDUAL_CARTPOLE, 4, 4, pack4(1, 1, 1, 1), 1, pack4(0)>;
-// Particle (mjpc/test/testdata/particle.xml): world -> goal[mocap]; world -> pointmass[slide x, slide y]
-using TopoParticle = Topo<3, 2, 2, 1, 1, pack4(0, 0, 0), pack4(15, 0, 15), pack2(kJntSlide, kJntSlide),
-                          pack4(2, 2), 0x3, pack4(0, 1), pack4(2)>;
-using TaskParticle = TaskTopo<MJPCX_RESIDUAL_PARTICLE, 4, 2, pack4(2, 2), 1, pack4(0)>;
-using TaskParticleCopy = TaskTopo<MJPCX_RESIDUAL_PARTICLE_COPY, 4, 2, pack4(2, 2), 1, pack4(0)>;
 
 struct TopoKey {
   int nb, nv, nu, nsite, nmocap;
@@ -64,23 +49,29 @@ template <class TK> constexpr TaskKey task_key() {
 }
 
 template <class TP, class TK, typename T>
-hipError_t launch_lane(const RolloutArgs<T>& a, hipStream_t s) {
-  const int blocks = (a.N + 63) / 64;
-  const size_t shmem = (size_t)a.P * TP::NU * 64 * sizeof(T);
-  hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T>), dim3(blocks), dim3(64), shmem, s, a);
-  return hipGetLastError();
+hipError_t launch_lane(const LaneModel<T>& m, const LaneTask<T>& tk, const RolloutArgs<T>& a, hipStream_t s) {
+  return launch_lane_impl<TP, TK, T, RuntimeModel>(m, tk, a, s);
 }
 
 struct KernelEntry {
   const char* name;
   TopoKey topo;
   TaskKey task;
-  hipError_t (*launch64)(const RolloutArgs<double>&, hipStream_t);
-  hipError_t (*launch32)(const RolloutArgs<float>&, hipStream_t);
+  const LaneModel<double>* static_model;  // non-null: instantiation specialised for exactly these constants
+  hipError_t (*launch64)(const LaneModel<double>&, const LaneTask<double>&, const RolloutArgs<double>&, hipStream_t);
+  hipError_t (*launch32)(const LaneModel<float>&, const LaneTask<float>&, const RolloutArgs<float>&, hipStream_t);
 };
 #define MJPCX_LANE_ENTRY(TP, TK) \
-  { "rollout_lane<" #TP "," #TK ">", topo_key<TP>(), task_key<TK>(), &launch_lane<TP, TK, double>, &launch_lane<TP, TK, float> }
+  { "rollout_lane<" #TP "," #TK ">", topo_key<TP>(), task_key<TK>(), nullptr, &launch_lane<TP, TK, double>, &launch_lane<TP, TK, float> }
+#define MJPCX_STATIC_ENTRY(TP, TK, GEN, FN) \
+  { "rollout_lane<" #TP "," #TK "," #GEN ">", topo_key<TP>(), task_key<TK>(), &kHost##GEN, &FN##_f64, &FN##_f32 }
+const LaneModel<double> kHostStaticCartpole = make_Cartpole<double>();
+const LaneModel<double> kHostStaticParticle = make_Particle<double>();
+// specialised entries first: mjpcx_create takes the first entry whose key (and constants) match
 const KernelEntry kKernels[] = {
+    MJPCX_STATIC_ENTRY(TopoCartpole, TaskCartpole, StaticCartpole, launch_static_cartpole),
+    MJPCX_STATIC_ENTRY(TopoParticle, TaskParticle, StaticParticle, launch_static_particle),
+    MJPCX_STATIC_ENTRY(TopoParticle, TaskParticleCopy, StaticParticle, launch_static_particle_copy),
     MJPCX_LANE_ENTRY(TopoCartpole, TaskCartpole),
     MJPCX_LANE_ENTRY(TopoParticle, TaskParticle),
     MJPCX_LANE_ENTRY(TopoParticle, TaskParticleCopy),
@@ -132,6 +123,56 @@ __global__ __launch_bounds__(1024) void argmin_kernel(const double* __restrict__
     if (lane == 0) out[0] = best;
   }
 }
+// The policy update of Predictive Sampling needs, from one rollout batch: the winner's index
+// and return, its spline values (candidate_policy[winner], sampling/planner.cc:534-543) and the
+// nominal candidate's return (`improvement`, planner.cc:207-208). One launch writes them all
+// into a pinned, device-mapped host record, so the host pays exactly one stream sync per plan step.
+struct BestRecord { double best_return, ref_return; int best_index, ref_failure; double spline[1]; };
+template <typename T>
+__global__ __launch_bounds__(1024) void best_kernel(const double* __restrict__ ret, const int* __restrict__ fail,
+                                                     const T* __restrict__ nodes, int n, int np, int ref, BestRecord* out) {
+  __shared__ RetIdx sm[16];
+  __shared__ int winner;
+  RetIdx best{NAN, 0x7fffffff};
+  bool have = false;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    RetIdx c{ret[i], i};
+    if (!have || less_ri(c, best)) { best = c; have = true; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    RetIdx o;
+    o.r = __shfl_down(best.r, off, 64);
+    o.i = __shfl_down(best.i, off, 64);
+    if (less_ri(o, best)) best = o;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sm[wave] = best;
+  __syncthreads();
+  if (wave == 0) {
+    const int nw = blockDim.x >> 6;
+    best = lane < nw ? sm[lane] : RetIdx{NAN, 0x7fffffff};
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      RetIdx o;
+      o.r = __shfl_down(best.r, off, 64);
+      o.i = __shfl_down(best.i, off, 64);
+      if (less_ri(o, best)) best = o;
+    }
+    if (lane == 0) {
+      winner = best.i;
+      out->best_return = best.r;
+      out->best_index = best.i;
+      out->ref_return = (ref >= 0 && ref < n) ? ret[ref] : NAN;
+      out->ref_failure = (ref >= 0 && ref < n) ? fail[ref] : 0;
+    }
+  }
+  __syncthreads();
+  const int w = winner;
+  if (w >= 0 && w < n)
+    for (int j = threadIdx.x; j < np; j += blockDim.x) out->spline[j] = (double)nodes[(size_t)j * n + w];
+}
+
 // single-workgroup bitonic sort of (return, index) pairs in global memory (n2 = pow2 >= n)
 __global__ __launch_bounds__(1024) void sort_kernel(const double* __restrict__ ret, int n, int n2, RetIdx* buf) {
   for (int i = threadIdx.x; i < n2; i += blockDim.x) buf[i] = i < n ? RetIdx{ret[i], i} : RetIdx{NAN, 0x7fffffff};
@@ -217,10 +258,17 @@ struct mjpcx_ctx {
   // host mirrors of the device structs (both precisions kept; only one uploaded)
   LaneModel<double> hm64{}; LaneModel<float> hm32{};
   LaneTask<double> ht64{}; LaneTask<float> ht32{};
-  bool task_dirty = true;
-  DevBuf d_model, d_task;
+  const void* cur_times = nullptr; const void* cur_nominal = nullptr;  // device views of the last plan inputs
+  // plan inputs (node times, nominal spline, CE variances) go through a small ring of pinned
+  // staging slots: one truly asynchronous H2D copy per rollout, no host sync
+  static constexpr int kSlots = 4;
+  struct Slot { void* host = nullptr; DevBuf dev; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
+  Slot slots[kSlots];
+  int next_slot = 0;
+  // pinned + device-mapped result record of mjpcx_best
+  void* best_host = nullptr; void* best_dev = nullptr; size_t best_cap = 0;
   // rollout buffers
-  DevBuf d_node_times, d_nodes, d_nominal, d_variance, d_in_nodes;
+  DevBuf d_nodes, d_in_nodes;
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
   int N = 0, H = 0, P = 0;  // shape of the last rollout
   bool have_rollout = false;
@@ -300,6 +348,13 @@ void fill_model(LaneModel<T>& d, const mjpcx_model* m) {
   }
 }
 
+bool same_model(const LaneModel<double>& a, const LaneModel<double>& b) {
+  // both objects are fully zero-initialised before being filled, so a byte comparison of the
+  // value representation is exact equality of every constant (the structs have no padding holes
+  // between doubles; the two int members before arrays of doubles are compared as stored)
+  return std::memcmp(&a, &b, sizeof a) == 0;
+}
+
 template <typename TD, typename TS>
 void convert_task(LaneTask<TD>& d, const LaneTask<TS>& s) {
   for (int k = 0; k < kLaneMaxTerm; k++) {
@@ -313,21 +368,6 @@ void convert_task(LaneTask<TD>& d, const LaneTask<TS>& s) {
     for (int k = 0; k < 3; k++) d.mocap_pos[i][k] = (TD)s.mocap_pos[i][k];
     for (int k = 0; k < 4; k++) d.mocap_quat[i][k] = (TD)s.mocap_quat[i][k];
   }
-}
-
-int upload_task(mjpcx_ctx* c) {
-  if (!c->task_dirty) return MJPCX_OK;
-  if (c->precision == 64) {
-    HIPCHK(c, hipMemcpyAsync(c->d_task.p, &c->ht64, sizeof c->ht64, hipMemcpyHostToDevice, c->stream));
-  } else {
-    convert_task(c->ht32, c->ht64);
-    HIPCHK(c, hipMemcpyAsync(c->d_task.p, &c->ht32, sizeof c->ht32, hipMemcpyHostToDevice, c->stream));
-  }
-  // the host structs are members of the ctx and outlive the copy; still, serialise so that a
-  // following mjpcx_set_* cannot overwrite them while the DMA is in flight
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->task_dirty = false;
-  return MJPCX_OK;
 }
 
 void set_norm_params(mjpcx_ctx* c, const double* norm_parameter) {
@@ -345,10 +385,7 @@ namespace {
 int reserve_rollout(mjpcx_ctx* c, int N, int H, int P) {
   const size_t w = esize(c);
   const size_t ds = c->nq + c->nv + c->na;
-  HIPCHK(c, c->d_node_times.reserve((size_t)P * w));
   HIPCHK(c, c->d_nodes.reserve((size_t)N * P * c->nu * w));
-  HIPCHK(c, c->d_nominal.reserve((size_t)P * c->nu * w));
-  HIPCHK(c, c->d_variance.reserve((size_t)P * c->nu * 8));
   HIPCHK(c, c->d_states.reserve((size_t)N * H * ds * w));
   HIPCHK(c, c->d_actions.reserve((size_t)N * H * c->nu * w));
   HIPCHK(c, c->d_times.reserve((size_t)N * H * w));
@@ -360,38 +397,59 @@ int reserve_rollout(mjpcx_ctx* c, int N, int H, int P) {
   return MJPCX_OK;
 }
 
+// Stage [node_times (T) | nominal (T) | variance (f64)] into the next pinned slot and enqueue ONE
+// asynchronous H2D copy. The slot is recycled only after the kernel that reads it has finished.
 template <typename T>
-int upload_converted(mjpcx_ctx* c, DevBuf& dst, const double* src, size_t n) {
-  if (sizeof(T) == 8) {
-    HIPCHK(c, hipMemcpyAsync(dst.p, src, n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // pageable source: make reuse by the caller safe
-  } else {
-    std::vector<float> tmp(n);
-    for (size_t i = 0; i < n; i++) tmp[i] = (float)src[i];
-    HIPCHK(c, hipMemcpyAsync(dst.p, tmp.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+int stage_plan_inputs(mjpcx_ctx* c, int P, const double* node_times, const double* nominal, const double* variance,
+                      const T** d_times, const T** d_nominal, const double** d_variance, mjpcx_ctx::Slot** used) {
+  const int np = P * c->nu;
+  const size_t off_nom = ((size_t)P * sizeof(T) + 15) & ~(size_t)15;
+  const size_t off_var = (off_nom + (size_t)np * sizeof(T) + 15) & ~(size_t)15;
+  const size_t bytes = off_var + (size_t)np * 8;
+  mjpcx_ctx::Slot& s = c->slots[c->next_slot];
+  c->next_slot = (c->next_slot + 1) % mjpcx_ctx::kSlots;
+  if (s.pending) { HIPCHK(c, hipEventSynchronize(s.done)); s.pending = false; }
+  if (!s.done) HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if (bytes > s.cap) {
+    if (s.host) (void)hipHostFree(s.host);
+    s.host = nullptr; s.cap = 0;
+    HIPCHK(c, hipHostMalloc(&s.host, bytes, hipHostMallocDefault));
+    s.cap = bytes;
   }
+  HIPCHK(c, s.dev.reserve(bytes));
+  char* h = (char*)s.host;
+  T* ht = (T*)h;
+  for (int p = 0; p < P; p++) ht[p] = (T)node_times[p];
+  T* hn = (T*)(h + off_nom);
+  if (nominal) for (int j = 0; j < np; j++) hn[j] = (T)nominal[j];
+  if (variance) std::memcpy(h + off_var, variance, (size_t)np * 8);
+  HIPCHK(c, hipMemcpyAsync(s.dev.p, s.host, bytes, hipMemcpyHostToDevice, c->stream));
+  *d_times = (const T*)s.dev.p;
+  *d_nominal = (const T*)((char*)s.dev.p + off_nom);
+  *d_variance = (const double*)((char*)s.dev.p + off_var);
+  *used = &s;
   return MJPCX_OK;
 }
 
 template <typename T>
 int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node_times,
-                      const double* node_values, const double* nominal, const mjpcx_noise_spec* ns) {
+               const double* node_values, const double* nominal, const mjpcx_noise_spec* ns) {
   int rc;
   if ((rc = reserve_rollout(c, N, H, P)) != MJPCX_OK) return rc;
-  if ((rc = upload_task(c)) != MJPCX_OK) return rc;
-  if ((rc = upload_converted<T>(c, c->d_node_times, node_times, P)) != MJPCX_OK) return rc;
   const int np = P * c->nu;
   RolloutArgs<T> a{};
-  a.model = (const LaneModel<T>*)c->d_model.p;
-  a.task = (const LaneTask<T>*)c->d_task.p;
   a.N = N; a.H = H; a.P = P; a.interp = interp;
-  a.node_times = (const T*)c->d_node_times.p;
   a.nodes = (T*)c->d_nodes.p;
-  a.nominal = (const T*)c->d_nominal.p;
   a.noise.mode = -1;
+  const double* d_var = nullptr;
+  mjpcx_ctx::Slot* slot = nullptr;
+  const bool ce = ns && ns->mode == MJPCX_NOISE_CROSS_ENTROPY;
+  if (ce && !ns->param_variance) return fail(c, MJPCX_EINVAL, "cross-entropy noise needs param_variance");
+  if ((rc = stage_plan_inputs<T>(c, P, node_times, nominal, ce ? ns->param_variance : nullptr, &a.node_times,
+                                 &a.nominal, &d_var, &slot)) != MJPCX_OK) return rc;
   if (node_values) {
-    // candidate-major host splines -> [node][actuator][candidate] on the device
+    // candidate-major host splines -> [node][actuator][candidate] on the device (not the hot path:
+    // the planner generates candidates on the device; this entry serves tests and NominalTrajectory)
     HIPCHK(c, c->d_in_nodes.reserve((size_t)N * np * 8));
     HIPCHK(c, hipMemcpyAsync(c->d_in_nodes.p, node_values, (size_t)N * np * 8, hipMemcpyHostToDevice, c->stream));
     const size_t total = (size_t)N * np;
@@ -399,20 +457,13 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     hipLaunchKernelGGL((scatter_nodes_kernel<T>), dim3(blocks), dim3(256), 0, c->stream,
                        (const double*)c->d_in_nodes.p, (T*)c->d_nodes.p, N, np);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // pageable source buffer: make caller reuse safe
   } else {
-    if ((rc = upload_converted<T>(c, c->d_nominal, nominal, np)) != MJPCX_OK) return rc;
     a.noise.mode = ns->mode;
     a.noise.seed = ns->seed; a.noise.iteration = ns->iteration;
     a.noise.candidate_offset = ns->candidate_offset; a.noise.nominal_candidate = ns->nominal_candidate;
     a.noise.explore_count = ns->explore_count; a.noise.std0 = ns->std0; a.noise.std1 = ns->std1;
-    a.noise.param_variance = nullptr;
-    if (ns->mode == MJPCX_NOISE_CROSS_ENTROPY) {
-      if (!ns->param_variance) return fail(c, MJPCX_EINVAL, "cross-entropy noise needs param_variance");
-      HIPCHK(c, hipMemcpyAsync(c->d_variance.p, ns->param_variance, (size_t)np * 8, hipMemcpyHostToDevice, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      a.noise.param_variance = (const double*)c->d_variance.p;
-    }
+    a.noise.param_variance = ce ? d_var : nullptr;
   }
   a.states = (T*)c->d_states.p; a.actions = (T*)c->d_actions.p; a.times = (T*)c->d_times.p;
   a.residual = (T*)c->d_residual.p; a.costs = (T*)c->d_costs.p; a.trace = (T*)c->d_trace.p;
@@ -431,10 +482,16 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
   hipError_t le;
-  if constexpr (sizeof(T) == 8) le = c->kernel->launch64(a, c->stream);
-  else le = c->kernel->launch32(a, c->stream);
+  if constexpr (sizeof(T) == 8) {
+    le = c->kernel->launch64(c->hm64, c->ht64, a, c->stream);
+  } else {
+    convert_task(c->ht32, c->ht64);
+    le = c->kernel->launch32(c->hm32, c->ht32, a, c->stream);
+  }
   if (le != hipSuccess) return fail(c, MJPCX_EDEVICE, std::string("rollout kernel launch: ") + hipGetErrorString(le));
   if (c->timing) HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventRecord(slot->done, c->stream));
+  slot->pending = true;
   c->N = N; c->H = H; c->P = P;
   c->have_rollout = true;
   return MJPCX_OK;
@@ -446,7 +503,7 @@ int check_rollout_args(mjpcx_ctx* c, int N, int H, int P, int interp, const doub
   if (interp < 0 || interp > 2) return fail(c, MJPCX_EINVAL, "unknown interpolation");
   for (int p = 1; p < P; p++)
     if (!(node_times[p] > node_times[p - 1])) return fail(c, MJPCX_EINVAL, "node_times must be strictly increasing");
-  const size_t shmem = (size_t)P * c->nu * 64 * esize(c);
+  const size_t shmem = ((size_t)P * c->nu * 64 + P) * esize(c);
   if (shmem > 64 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "num_nodes * nu too large for the LDS spline stage");
   if (hipSetDevice(c->device) != hipSuccess) return fail(c, MJPCX_EDEVICE, "hipSetDevice failed");
   return MJPCX_OK;
@@ -516,8 +573,13 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
   for (int k = 0; k < t->num_term; k++) kk.termdim |= (uint64_t)(t->dim_norm_residual[k] & 15) << (4 * k);
   for (int k = 0; k < t->num_trace; k++) kk.tracesite |= (uint64_t)(t->trace_site[k] & 15) << (4 * k);
   const KernelEntry* entry = nullptr;
+  LaneModel<double> probe;
+  fill_model(probe, m);
   for (const KernelEntry& e : kKernels)
-    if (e.topo == tk && e.task == kk) { entry = &e; break; }
+    if (e.topo == tk && e.task == kk && (!e.static_model || (!getenv("MJPCX_NO_STATIC") && same_model(*e.static_model, probe)))) {
+      entry = &e;
+      break;
+    }
   if (!entry) {
     char buf[512];
     std::snprintf(buf, sizeof buf,
@@ -557,12 +619,6 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     }
   auto cleanup = [&](int code, const std::string& msg) { mjpcx_destroy(c); return bad(code, msg); };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(MJPCX_EDEVICE, "hipStreamCreate failed");
-  const size_t msz = precision == 64 ? sizeof c->hm64 : sizeof c->hm32;
-  const size_t tsz = precision == 64 ? sizeof c->ht64 : sizeof c->ht32;
-  if (c->d_model.reserve(msz) != hipSuccess || c->d_task.reserve(tsz) != hipSuccess) return cleanup(MJPCX_ENOMEM, "device allocation failed");
-  const void* src = precision == 64 ? (const void*)&c->hm64 : (const void*)&c->hm32;
-  if (hipMemcpy(c->d_model.p, src, msz, hipMemcpyHostToDevice) != hipSuccess) return cleanup(MJPCX_EDEVICE, "model upload failed");
-  c->task_dirty = true;
   *out = c;
   return MJPCX_OK;
 }
@@ -572,7 +628,13 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  DevBuf* bufs[] = {&c->d_model, &c->d_task, &c->d_node_times, &c->d_nodes, &c->d_nominal, &c->d_variance, &c->d_in_nodes,
+  for (auto& sl : c->slots) {
+    if (sl.host) (void)hipHostFree(sl.host);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    sl.dev.release();
+  }
+  if (c->best_host) (void)hipHostFree(c->best_host);
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();
@@ -591,7 +653,6 @@ int mjpcx_set_state(mjpcx_ctx* c, const double* state, double time, const double
       for (int k = 0; k < 3; k++) c->ht64.mocap_pos[i][k] = mocap[7 * i + k];
       for (int k = 0; k < 4; k++) c->ht64.mocap_quat[i][k] = mocap[7 * i + 3 + k];
     }
-  c->task_dirty = true;
   return MJPCX_OK;
 }
 
@@ -602,7 +663,6 @@ int mjpcx_set_task_params(mjpcx_ctx* c, const double* weight, const double* norm
   if (norm_parameter) set_norm_params(c, norm_parameter);
   if (parameters) for (int k = 0; k < c->nparam; k++) c->ht64.parameters[k] = parameters[k];
   c->ht64.risk = risk;
-  c->task_dirty = true;
   return MJPCX_OK;
 }
 
@@ -650,6 +710,36 @@ int mjpcx_get_return_at(mjpcx_ctx* c, int cand, double* total_return, int32_t* f
   if (total_return) HIPCHK(c, hipMemcpyAsync(total_return, (const double*)c->d_ret.p + cand, 8, hipMemcpyDeviceToHost, c->stream));
   if (failure) HIPCHK(c, hipMemcpyAsync(failure, (const int*)c->d_fail.p + cand, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+
+int mjpcx_best(mjpcx_ctx* c, int ref_candidate, int32_t* index, double* best_return, double* ref_return,
+               double* spline_values) {
+  if (!c || !index) return fail(c, MJPCX_EINVAL, "null argument");
+  if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int np = c->P * c->nu;
+  const size_t bytes = sizeof(BestRecord) + (size_t)np * 8;
+  if (bytes > c->best_cap) {
+    if (c->best_host) (void)hipHostFree(c->best_host);
+    c->best_host = nullptr; c->best_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->best_host, bytes, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(&c->best_dev, c->best_host, 0));
+    c->best_cap = bytes;
+  }
+  if (c->precision == 64)
+    hipLaunchKernelGGL((best_kernel<double>), dim3(1), dim3(1024), 0, c->stream, (const double*)c->d_ret.p,
+                       (const int*)c->d_fail.p, (const double*)c->d_nodes.p, c->N, np, ref_candidate, (BestRecord*)c->best_dev);
+  else
+    hipLaunchKernelGGL((best_kernel<float>), dim3(1), dim3(1024), 0, c->stream, (const double*)c->d_ret.p,
+                       (const int*)c->d_fail.p, (const float*)c->d_nodes.p, c->N, np, ref_candidate, (BestRecord*)c->best_dev);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const BestRecord* r = (const BestRecord*)c->best_host;
+  *index = r->best_index;
+  if (best_return) *best_return = r->best_return;
+  if (ref_return) *ref_return = r->ref_return;
+  if (spline_values) std::memcpy(spline_values, r->spline, (size_t)np * 8);
   return MJPCX_OK;
 }
 

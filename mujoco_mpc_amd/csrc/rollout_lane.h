@@ -17,8 +17,10 @@
 //     (xpos, xmat, cinert, cdof, M, ...) lives in VGPRs -- no scratch, no LDS round trips.
 //   * the model's numeric constants (LaneModel) are read through a wave-uniform pointer
 //     with constant offsets: s_load through the scalar cache into SGPRs.
-//   * the candidate's spline nodes are staged once into LDS ([node][actuator][lane],
-//     conflict-free) and touched only when the (wave-uniform) spline segment changes.
+//   * the candidate's spline nodes and the node times are staged once into LDS
+//     ([node][actuator][lane], conflict-free) and touched only when the (wave-uniform) spline
+//     segment changes: there is NO global load inside the time loop, so the per-step stores are
+//     never waited for.
 //   * per-step outputs are written in a [step][field][candidate] SoA layout so that each
 //     store instruction of the wave writes 64 consecutive elements (512 B for fp64).
 #pragma once
@@ -109,8 +111,6 @@ struct NoiseArgs {
 
 template <typename T>
 struct RolloutArgs {
-  const LaneModel<T>* model;
-  const LaneTask<T>* task;
   int N, H, P, interp;
   const T* node_times;  // P
   T* nodes;             // [P][NU][N]
@@ -123,21 +123,39 @@ struct RolloutArgs {
 
 // weighted sum of norms over the (compile-time) term partition of the residual
 template <class TK, typename T, int... K>
-__device__ __forceinline__ T cost_terms(const T (&r)[TK::NR], const LaneTask<T>* __restrict__ tk,
+__device__ __forceinline__ T cost_terms(const T (&r)[TK::NR], const LaneTask<T>& tk,
                                         std::integer_sequence<int, K...>) {
-  return ((tk->weight[K] * norm_value<T, TK::term_dim(K)>(&r[TK::term_off(K)], tk->norm[K], tk->norm_p[K], tk->norm_q[K])) + ... + T(0));
+  return ((tk.weight[K] * norm_value<T, TK::term_dim(K)>(&r[TK::term_off(K)], tk.norm[K], tk.norm_p[K], tk.norm_q[K])) + ... + T(0));
 }
 
+// Where the model's numeric constants come from:
+//   RuntimeModel  - the kernel-argument copy (general path: any model with this topology)
+//   StaticXxx     - a generated constexpr object (generated/static_models.h): every constant is an
+//                   immediate and the compiler folds the arithmetic on exact zeros / ones away.
+struct RuntimeModel {
+  template <typename T> __device__ static __forceinline__ const LaneModel<T>& get(const LaneModel<T>& karg) { return karg; }
+};
+template <class Gen>
+struct StaticModel {  // returns the constexpr object BY VALUE: a local constant the optimiser scalarises
+  template <typename T> __device__ static __forceinline__ constexpr LaneModel<T> get(const LaneModel<T>&) {
+    return Gen::template make<T>();
+  }
+};
+
 // ------------------------------------------------------------------ the kernel
-template <class TP, class TK, typename T>
-__global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a) {
+template <class TP, class TK, typename T, class MC>
+__global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_karg, const LaneTask<T> tk,
+                                                           const RolloutArgs<T> a) {
+  decltype(auto) m = MC::template get<T>(m_karg);
   constexpr int NB = TP::NB, NV = TP::NV, NU = TP::NU, NS = TP::NSITE;
   constexpr int NR = TK::NR, NTR = TK::NTRACE, DS = 2 * NV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lnodes = reinterpret_cast<T*>(smem_raw);  // [P][NU][64]
+  // node times also live in LDS: a global LOAD inside the time loop would need s_waitcnt vmcnt(0),
+  // which also drains the step's 14 outstanding stores (vmcnt retires in order) -- ~1.7k cycles/step
+  T* ltimes = lnodes + (size_t)a.P * NU * 64;  // [P]
+  for (int p = threadIdx.x; p < a.P; p += 64) ltimes[p] = a.node_times[p];
 
-  const LaneModel<T>* __restrict__ m = a.model;
-  const LaneTask<T>* __restrict__ tk = a.task;
   const int lane = threadIdx.x;
   const int cand = blockIdx.x * 64 + lane;
   const bool live = cand < a.N;
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
         const int j = j0 + e;
         if (j < np) {
           const int k = j % NU;
-          const double lo = (double)m->act_ctrlrange[k][0], hi = (double)m->act_ctrlrange[k][1];
+          const double lo = (double)m.act_ctrlrange[k][0], hi = (double)m.act_ctrlrange[k][1];
           double v = (double)a.nominal[j];
           if (noised) {
             double sigma;
@@ -191,11 +209,11 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
   // ---------------- initial condition (Planner::SetState)
   T qpos[NV], qvel[NV], ctrl[NU];
 #pragma unroll
-  for (int i = 0; i < NV; i++) { qpos[i] = tk->qpos[i]; qvel[i] = tk->qvel[i]; }
+  for (int i = 0; i < NV; i++) { qpos[i] = tk.qpos[i]; qvel[i] = tk.qvel[i]; }
 #pragma unroll
   for (int k = 0; k < NU; k++) ctrl[k] = 0;
-  T time = tk->time;
-  const T h = m->timestep;
+  T time = tk.time;
+  const T h = m.timestep;
 
   // spline segment cache
   int up = 0, cached_up = -1;
@@ -209,9 +227,10 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
 
   for (int t = 0; t < H; t++) {
     const bool last = (t == H - 1);
+    bool bad_ctrl = false;
     // ================= policy: TimeSpline::Sample + Clamp (spline.cc:103-156, policy.cc:52-59)
     if (!last) {
-      while (up < P && a.node_times[up] <= time) up++;  // upper_bound; time is wave-uniform
+      while (up < P && ltimes[up] <= time) up++;  // upper_bound; time is wave-uniform
       if (up != cached_up) {
         cached_up = up;
         const int lo = up - 1;
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
 #pragma unroll
           for (int k = 0; k < NU; k++) sp0[k] = lnodes[(n * NU + k) * 64 + lane];
         } else {
-          tl = a.node_times[lo]; tu = a.node_times[up];
+          tl = ltimes[lo]; tu = ltimes[up];
 #pragma unroll
           for (int k = 0; k < NU; k++) {
             sp0[k] = lnodes[(lo * NU + k) * 64 + lane];
@@ -235,13 +254,13 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
                 sm0[k] = fwd;
               } else {
                 const T pv = lnodes[((lo - 1) * NU + k) * 64 + lane];
-                sm0[k] = T(0.5) * (sp1[k] - sp0[k]) / dt_mid + T(0.5) * (sp0[k] - pv) / (tl - a.node_times[lo - 1]);
+                sm0[k] = T(0.5) * (sp1[k] - sp0[k]) / dt_mid + T(0.5) * (sp0[k] - pv) / (tl - ltimes[lo - 1]);
               }
               if (up == P - 1) {
                 sm1[k] = fwd;
               } else {
                 const T nv = lnodes[((up + 1) * NU + k) * 64 + lane];
-                sm1[k] = T(0.5) * (nv - sp1[k]) / (a.node_times[up + 1] - tu) + T(0.5) * (sp1[k] - sp0[k]) / dt_mid;
+                sm1[k] = T(0.5) * (nv - sp1[k]) / (ltimes[up + 1] - tu) + T(0.5) * (sp1[k] - sp0[k]) / dt_mid;
               }
             }
           }
@@ -266,18 +285,19 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
         }
       }
 #pragma unroll
-      for (int k = 0; k < NU; k++) ctrl[k] = clampv(ctrl[k], m->act_ctrlrange[k][0], m->act_ctrlrange[k][1]);
+      for (int k = 0; k < NU; k++) {
+        bad_ctrl |= is_bad(ctrl[k]);  // mjWARN_BADCTRL; tested before Clamp, which may not propagate NaN
+        ctrl[k] = clampv(ctrl[k], m.act_ctrlrange[k][0], m.act_ctrlrange[k][1]);
+      }
     }
     // (last step: mj_forward with the previous control still in data->ctrl; the recorded
     //  action is a copy of the previous one, trajectory.cc:190-198)
 
     // ================= mj_checkPos / mj_checkVel
-    bool bad = false;
+    bool bad = bad_ctrl;
     if (!last) {
 #pragma unroll
       for (int i = 0; i < NV; i++) bad |= is_bad(qpos[i]) || is_bad(qvel[i]);
-#pragma unroll
-      for (int k = 0; k < NU; k++) bad |= is_bad(ctrl[k]);  // mjWARN_BADCTRL
     }
 
     // ================= position stage: kinematics
@@ -288,19 +308,19 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
       T pos[3], quat[4];
       if (TP::mocap(b) != 15) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) pos[c] = tk->mocap_pos[TP::mocap(b)][c];
+        for (int c = 0; c < 3; c++) pos[c] = tk.mocap_pos[TP::mocap(b)][c];
 #pragma unroll
-        for (int c = 0; c < 4; c++) quat[c] = tk->mocap_quat[TP::mocap(b)][c];
+        for (int c = 0; c < 4; c++) quat[c] = tk.mocap_quat[TP::mocap(b)][c];
       } else {
         if (TP::parent(b) == 0) {
 #pragma unroll
-          for (int c = 0; c < 3; c++) pos[c] = m->body_pos[b][c];
+          for (int c = 0; c < 3; c++) pos[c] = m.body_pos[b][c];
 #pragma unroll
-          for (int c = 0; c < 4; c++) quat[c] = m->body_quat[b][c];
+          for (int c = 0; c < 4; c++) quat[c] = m.body_quat[b][c];
         } else {
           const int p = TP::parent(b);
-          T bp[3] = {m->body_pos[b][0], m->body_pos[b][1], m->body_pos[b][2]};
-          T bq[4] = {m->body_quat[b][0], m->body_quat[b][1], m->body_quat[b][2], m->body_quat[b][3]};
+          T bp[3] = {m.body_pos[b][0], m.body_pos[b][1], m.body_pos[b][2]};
+          T bq[4] = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
           mat_vec(pos, xmat[p], bp);
 #pragma unroll
           for (int c = 0; c < 3; c++) pos[c] += xpos[p][c];
@@ -311,13 +331,13 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
           if (TP::jbody(j) == b) {
             T R[9];
             quat_to_mat(R, quat);
-            T jp[3] = {m->jnt_pos[j][0], m->jnt_pos[j][1], m->jnt_pos[j][2]};
-            T ja[3] = {m->jnt_axis[j][0], m->jnt_axis[j][1], m->jnt_axis[j][2]};
+            T jp[3] = {m.jnt_pos[j][0], m.jnt_pos[j][1], m.jnt_pos[j][2]};
+            T ja[3] = {m.jnt_axis[j][0], m.jnt_axis[j][1], m.jnt_axis[j][2]};
             mat_vec(xanchor[j], R, jp);
 #pragma unroll
             for (int c = 0; c < 3; c++) xanchor[j][c] += pos[c];
             mat_vec(xaxis[j], R, ja);
-            const T dq = qpos[j] - m->qpos0[j];
+            const T dq = qpos[j] - m.qpos0[j];
             if (TP::jtype(j) == kJntSlide) {
 #pragma unroll
               for (int c = 0; c < 3; c++) pos[c] += xaxis[j][c] * dq;
@@ -335,14 +355,18 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
           }
         }
       }
-      normalize4(quat);
+      // mj_kinematics renormalises every body quaternion to stop drift of FREE/BALL qpos quaternions.
+      // Here only mocap poses (user input) can be unnormalised: a slide/hinge body's quaternion is a
+      // product of unit quaternions (model constants and axis-angle factors), unit to rounding, so
+      // the sqrt + divide on the per-step dependent chain is skipped for those bodies.
+      if (TP::mocap(b) != 15) normalize4(quat);
 #pragma unroll
       for (int c = 0; c < 3; c++) xpos[b][c] = pos[c];
 #pragma unroll
       for (int c = 0; c < 4; c++) xquat[b][c] = quat[c];
       quat_to_mat(xmat[b], quat);
-      T ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]};
-      T iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
+      T ip[3] = {m.body_ipos[b][0], m.body_ipos[b][1], m.body_ipos[b][2]};
+      T iq[4] = {m.body_iquat[b][0], m.body_iquat[b][1], m.body_iquat[b][2], m.body_iquat[b][3]};
       T v[3], q2[4];
       mat_vec(v, xmat[b], ip);
 #pragma unroll
@@ -354,7 +378,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       const int b = TP::siteb(s);
-      T sp[3] = {m->site_pos[s][0], m->site_pos[s][1], m->site_pos[s][2]};
+      T sp[3] = {m.site_pos[s][0], m.site_pos[s][1], m.site_pos[s][2]};
       if (b == 0) {
 #pragma unroll
         for (int c = 0; c < 3; c++) site_xpos[s][c] = sp[c];
@@ -376,10 +400,10 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
         for (int b = 1; b < NB; b++)
           if (TP::root(b) == r) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc[c] += m->body_mass[b] * xipos[b][c];
+            for (int c = 0; c < 3; c++) acc[c] += m.body_mass[b] * xipos[b][c];
           }
 #pragma unroll
-        for (int c = 0; c < 3; c++) com[r][c] = acc[c] * m->root_invmass[r];
+        for (int c = 0; c < 3; c++) com[r][c] = acc[c] * m.root_invmass[r];
       }
     }
     T cinert[NB][10];
@@ -389,8 +413,8 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
         T off[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) off[c] = xipos[b][c] - com[TP::root(b)][c];
-        T bi[3] = {m->body_inertia[b][0], m->body_inertia[b][1], m->body_inertia[b][2]};
-        inert_com(cinert[b], bi, ximat[b], off, m->body_mass[b]);
+        T bi[3] = {m.body_inertia[b][0], m.body_inertia[b][1], m.body_inertia[b][2]};
+        inert_com(cinert[b], bi, ximat[b], off, m.body_mass[b]);
       }
     }
     T cdof[NV][6];
@@ -429,7 +453,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
     for (int i = 0; i < NV; i++) {
       T buf[6];
       mul_inert_vec(buf, crb[TP::jbody(i)], cdof[i]);
-      M[i][i] = m->dof_armature[i] + dot6(cdof[i], buf);
+      M[i][i] = m.dof_armature[i] + dot6(cdof[i], buf);
 #pragma unroll
       for (int j = 0; j < i; j++) M[i][j] = TP::dof_ancestor(i, j) ? dot6(cdof[j], buf) : T(0);
     }
@@ -461,17 +485,17 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
       for (int c = 0; c < 6; c++) cvel[b][c] = v[c];
     }
     T qfrc[NV];  // becomes qfrc_smooth
-    const bool passive_on = !(m->disableflags & (1 << 5));
+    const bool passive_on = !(m.disableflags & (1 << 5));
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       T f = 0;
-      if (passive_on) f = -m->jnt_stiffness[j] * (qpos[j] - m->qpos_spring[j]) - m->dof_damping[j] * qvel[j];
+      if (passive_on) f = -m.jnt_stiffness[j] * (qpos[j] - m.qpos_spring[j]) - m.dof_damping[j] * qvel[j];
       qfrc[j] = f;
     }
     {
       T cfrc[NB][6];
       T g[3] = {0, 0, 0};
-      if (!(m->disableflags & (1 << 6))) { g[0] = -m->gravity[0]; g[1] = -m->gravity[1]; g[2] = -m->gravity[2]; }
+      if (!(m.disableflags & (1 << 6))) { g[0] = -m.gravity[0]; g[1] = -m.gravity[1]; g[2] = -m.gravity[2]; }
       T cacc[NB][6];
 #pragma unroll
       for (int b = 1; b < NB; b++) {
@@ -507,17 +531,17 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
     }
 
     // ================= actuation (joint transmission)
-    if (!(m->disableflags & (1 << 10))) {
+    if (!(m.disableflags & (1 << 10))) {
 #pragma unroll
       for (int u = 0; u < NU; u++) {
         const int j = TP::actj(u);
         T c = ctrl[u];
-        if (m->act_ctrllimited[u] && !(m->disableflags & (1 << 7))) c = clampv(c, m->act_ctrlrange[u][0], m->act_ctrlrange[u][1]);
-        T force = m->act_gain[u] * c;
-        if (m->act_biastype[u] == 1)
-          force += m->act_bias[u][0] + m->act_bias[u][1] * m->act_gear[u] * qpos[j] + m->act_bias[u][2] * m->act_gear[u] * qvel[j];
-        if (m->act_forcelimited[u]) force = clampv(force, m->act_forcerange[u][0], m->act_forcerange[u][1]);
-        qfrc[j] += m->act_gear[u] * force;
+        if (m.act_ctrllimited[u] && !(m.disableflags & (1 << 7))) c = clampv(c, m.act_ctrlrange[u][0], m.act_ctrlrange[u][1]);
+        T force = m.act_gain[u] * c;
+        if (m.act_biastype[u] == 1)
+          force += m.act_bias[u][0] + m.act_bias[u][1] * m.act_gear[u] * qpos[j] + m.act_bias[u][2] * m.act_gear[u] * qvel[j];
+        if (m.act_forcelimited[u]) force = clampv(force, m.act_forcerange[u][0], m.act_forcerange[u][1]);
+        qfrc[j] += m.act_gear[u] * force;
       }
     }
 
@@ -530,7 +554,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
     T qfrc_c[NV];
 #pragma unroll
     for (int j = 0; j < NV; j++) qfrc_c[j] = 0;
-    if (TP::num_limited() > 0 && !(m->disableflags & ((1 << 0) | (1 << 3)))) {
+    if (TP::num_limited() > 0 && !(m.disableflags & ((1 << 0) | (1 << 3)))) {
       bool act[NV];
       T sgn[NV], dist[NV];
       bool any = false;
@@ -538,9 +562,9 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
       for (int j = 0; j < NV; j++) {
         act[j] = false; sgn[j] = 0; dist[j] = 0;
         if (TP::jlimited(j)) {
-          const T dlo = qpos[j] - m->jnt_range[j][0], dhi = m->jnt_range[j][1] - qpos[j];
-          if (dlo < m->jnt_margin[j]) { act[j] = true; sgn[j] = 1; dist[j] = dlo; }
-          else if (dhi < m->jnt_margin[j]) { act[j] = true; sgn[j] = -1; dist[j] = dhi; }
+          const T dlo = qpos[j] - m.jnt_range[j][0], dhi = m.jnt_range[j][1] - qpos[j];
+          if (dlo < m.jnt_margin[j]) { act[j] = true; sgn[j] = 1; dist[j] = dlo; }
+          else if (dhi < m.jnt_margin[j]) { act[j] = true; sgn[j] = -1; dist[j] = dhi; }
           any |= act[j];
         }
       }
@@ -556,12 +580,12 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
           for (int c = 0; c < NV; c++) e[c] = (c == j) ? T(1) : T(0);
           ldl_solve<NV>(Mi[j], Lm, Dinv, e);
           // impedance / reference (mj_makeImpedance)
-          const T pos = dist[j] - m->jnt_margin[j];
-          T dmin = clampv(m->jnt_solimp[j][0], T(kMinVal), T(1 - kMinVal));
-          T dmax = clampv(m->jnt_solimp[j][1], T(kMinVal), T(1 - kMinVal));
-          const T width = m->jnt_solimp[j][2];
-          T mid = clampv(m->jnt_solimp[j][3], T(kMinVal), T(1 - kMinVal));
-          T power = m->jnt_solimp[j][4] < 1 ? T(1) : m->jnt_solimp[j][4];
+          const T pos = dist[j] - m.jnt_margin[j];
+          T dmin = clampv(m.jnt_solimp[j][0], T(kMinVal), T(1 - kMinVal));
+          T dmax = clampv(m.jnt_solimp[j][1], T(kMinVal), T(1 - kMinVal));
+          const T width = m.jnt_solimp[j][2];
+          T mid = clampv(m.jnt_solimp[j][3], T(kMinVal), T(1 - kMinVal));
+          T power = m.jnt_solimp[j][4] < 1 ? T(1) : m.jnt_solimp[j][4];
           T imp;
           if (dmin == dmax || width <= T(kMinVal)) {
             imp = T(0.5) * (dmin + dmax);
@@ -578,17 +602,17 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
             }
           }
           T kk, bd;
-          if (m->jnt_solref[j][0] > 0) {
-            T tc = m->jnt_solref[j][0];
-            if (!(m->disableflags & (1 << 11)) && tc < 2 * h) tc = 2 * h;
-            kk = T(1) / (dmax * dmax * tc * tc * m->jnt_solref[j][1] * m->jnt_solref[j][1]);
+          if (m.jnt_solref[j][0] > 0) {
+            T tc = m.jnt_solref[j][0];
+            if (!(m.disableflags & (1 << 11)) && tc < 2 * h) tc = 2 * h;
+            kk = T(1) / (dmax * dmax * tc * tc * m.jnt_solref[j][1] * m.jnt_solref[j][1]);
             bd = T(2) / (dmax * tc);
           } else {
-            kk = -m->jnt_solref[j][0] / (dmax * dmax);
-            bd = -m->jnt_solref[j][1] / dmax;
+            kk = -m.jnt_solref[j][0] / (dmax * dmax);
+            bd = -m.jnt_solref[j][1] / dmax;
           }
           const T aref = -bd * (sgn[j] * qvel[j]) - kk * imp * pos;
-          T R = (1 - imp) / imp * m->dof_invweight0[j];
+          T R = (1 - imp) / imp * m.dof_invweight0[j];
           Rr[j] = R < T(kMinVal) ? T(kMinVal) : R;
           bb[j] = sgn[j] * qacc[j] - aref;
           f[j] = 0;
@@ -599,9 +623,9 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
           for (int s = 0; s < NV; s++)
             if (TP::jlimited(r) && TP::jlimited(s)) AR[r][s] = sgn[r] * sgn[s] * Mi[s][r] + (r == s ? Rr[r] : T(0));
         // projected Gauss-Seidel on the dual (MuJoCo PGS), rows in joint order
-        const T scale = T(1) / (m->meaninertia * T(NV > 1 ? NV : 1));
+        const T scale = T(1) / (m.meaninertia * T(NV > 1 ? NV : 1));
         bool done = !any;
-        for (int it = 0; it < m->solver_iterations; it++) {
+        for (int it = 0; it < m.solver_iterations; it++) {
           T improvement = 0;
 #pragma unroll
           for (int r = 0; r < NV; r++) {
@@ -621,7 +645,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
               }
             }
           }
-          done |= improvement * scale < m->solver_tolerance;
+          done |= improvement * scale < m.solver_tolerance;
           if (__all(done)) break;
         }
 #pragma unroll
@@ -644,8 +668,8 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
     // ================= sensor stage: task residual (mjcb_sensor at mjSTAGE_ACC), cost
     T r[NR];
     if (TK::RID == 1) {  // Particle: mjpc/test/testdata/particle_residual.h:33-43
-      r[0] = qpos[0] - tk->mocap_pos[0][0];
-      r[1] = qpos[1] - tk->mocap_pos[0][1];
+      r[0] = qpos[0] - tk.mocap_pos[0][0];
+      r[1] = qpos[1] - tk.mocap_pos[0][1];
       r[2] = qvel[0];
       r[3] = qvel[1];
     } else if (TK::RID == 2) {  // ParticleCopy: mjpc/test/agent/rollout_test.cc:37-42
@@ -653,12 +677,12 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
       for (int i = 0; i < NV; i++) { r[i] = qpos[i]; r[NV + i] = qvel[i]; }
     } else if (TK::RID == 3) {  // Cartpole: mjpc/tasks/cartpole/cartpole.cc:36-49
       r[0] = cos(qpos[1]) - 1;
-      r[1] = qpos[0] - tk->parameters[0];
+      r[1] = qpos[0] - tk.parameters[0];
       r[2] = qvel[1];
       r[3] = ctrl[0];
     }
     T cost = cost_terms<TK, T>(r, tk, std::make_integer_sequence<int, TK::NTERM>{});  // task.cc:71-110
-    if (!(fabs(tk->risk) < T(1.0e-6))) cost = (exp(tk->risk * cost) - T(1)) / tk->risk;
+    if (!(fabs(tk.risk) < T(1.0e-6))) cost = (exp(tk.risk * cost) - T(1)) / tk.risk;
 
     // ================= record step t: coalesced [t][field][candidate] stores
     if (live && !failed) {
@@ -685,13 +709,13 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const RolloutArgs<T> a
 
     // ================= mj_Euler: implicit joint damping, then advance
     T qdd[NV];
-    if (m->any_damping && !(m->disableflags & (1 << 14))) {
+    if (m.any_damping && !(m.disableflags & (1 << 14))) {
       T Mh[NV][NV], L2[NV][NV], D2[NV], rhs[NV];
 #pragma unroll
       for (int i = 0; i < NV; i++) {
 #pragma unroll
         for (int j = 0; j < i; j++) Mh[i][j] = M[i][j];
-        Mh[i][i] = M[i][i] + h * m->dof_damping[i];
+        Mh[i][i] = M[i][i] + h * m.dof_damping[i];
         rhs[i] = qfrc[i] + qfrc_c[i];
       }
       ldl_factor<NV>(L2, D2, Mh);

@@ -47,6 +47,20 @@ class RankGroup:
         keep = keep[keep[:, 1] < 2 ** 52]
         return keep[:, 1].astype(np.int64), keep[:, 0]
 
+    def exchange_best(self, idx, best_ret, nominal_ret, values):
+        """Predictive Sampling exchange: all-gather (best return, global index, nominal return) and
+        broadcast the winner's spline values from its owner. Ties go to the lowest global index."""
+        t = self.torch
+        local = t.tensor([best_ret, float(idx), nominal_ret], dtype=t.float64, device=self.device)
+        gathered = [t.empty_like(local) for _ in range(self.world)]
+        self.dist.all_gather(gathered, local)
+        allp = t.stack(gathered).cpu().numpy()
+        rets = np.where(np.isnan(allp[:, 0]), np.inf, allp[:, 0])
+        owner = int(np.lexsort((allp[:, 1], rets))[0])
+        nominal = float(allp[0, 2])                       # global candidate 0 lives on rank 0
+        vals = self.broadcast_array(values if self.rank == owner else None, np.asarray(values).shape, src=owner)
+        return int(allp[owner, 1]), float(allp[owner, 0]), nominal, vals
+
     def broadcast_scalar(self, value, src=0):
         t = self.torch
         x = t.tensor([0.0 if value is None else float(value)], dtype=t.float64, device=self.device)

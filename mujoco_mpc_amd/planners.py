@@ -239,21 +239,40 @@ class GpuSamplingPlanner:
 
     # ---- OptimizePolicy, planner.cc:197-212
     def optimize_policy(self, horizon, pool=None):
-        self.optimize_policy_candidates(1, horizon, pool)
+        """OptimizePolicyCandidates(1) + CopyCandidateToPolicy(0), with the device selection, the
+        winner's spline and the nominal's return fetched in ONE launch + ONE sync (mjpcx_best)."""
+        self.update_nominal_policy(horizon)
         t0 = _time.perf_counter()
-        nominal_return = self._nominal_return()
-        self.copy_candidate_to_policy(0)
-        self.improvement = max(nominal_return - self._scores[0], 0.0)
+        self.policy.plan.set_interpolation(self.interpolation_)
+        self.rollouts(self.num_trajectory_, horizon)
+        ref = 0 if self._offset == 0 else -1                 # trajectory[0] lives on rank 0
+        idx, best_ret, nominal_ret, values = self.ctx.best(ref)
+        idx += self._offset
+        if self.group and self.group.world > 1:
+            idx, best_ret, nominal_ret, values = self.group.exchange_best(idx, best_ret, nominal_ret, values)
+        self.trajectory_order = [int(idx)]
+        self._scores = [float(best_ret)]
+        self.rollouts_compute_time = (_time.perf_counter() - t0) * 1e6
+        self.iteration += 1
+        t0 = _time.perf_counter()
+        self._set_winner(int(idx), values)
+        self.improvement = max(nominal_ret - best_ret, 0.0)
         self.policy_update_compute_time = (_time.perf_counter() - t0) * 1e6
 
-    def _nominal_return(self):
-        """trajectory[0].total_return: global candidate 0 lives on rank 0."""
-        val = None
-        if self._offset == 0:
-            val = float(self.ctx.return_of(0))
-        if self.group and self.group.world > 1:
-            val = self.group.broadcast_scalar(val, src=0)
-        return val
+    def _set_winner(self, global_idx, values):
+        """CopyCandidateToPolicy, planner.cc:534-543, given candidate_policy[winner]'s spline values."""
+        self.winner = global_idx
+        times = self.policy.plan.times()
+        plan = TimeSpline(self.model.nu, self.policy.plan.interpolation())
+        for t, v in zip(times, np.asarray(values).reshape(len(times), -1)):
+            plan.add_node(t, v)
+        self.winner_policy.model = self.model
+        self.winner_policy.plan = plan
+        self.winner_policy.num_spline_points = self.policy.num_spline_points
+        self._best = None                                        # BestTrajectory() is fetched lazily
+        with self.mtx_:
+            self.previous_policy.copy_from(self.policy)
+            self.policy.copy_from(self.winner_policy)
 
     # ---- NominalTrajectory, planner.cc:215-227
     def nominal_trajectory(self, horizon, pool=None):
@@ -272,8 +291,14 @@ class GpuSamplingPlanner:
         with self.mtx_:
             return (self.previous_policy if use_previous else self.policy).action(action, state, time)
 
-    # ---- BestTrajectory, planner.cc:396-398
+    # ---- BestTrajectory, planner.cc:396-398 (the reference returns &trajectory[winner]; here the
+    # winner's buffers stay on the device until someone asks for them; with several ranks only the
+    # owner of the winner has them)
     def best_trajectory(self):
+        if self._best is None and self.ctx is not None and self.ctx.N > 0:
+            local = self.winner - self._offset
+            if 0 <= local < self._n_local:
+                self._best = self.ctx.fetch_trajectory(local)
         return self._best
 
     def num_parameters(self):
@@ -305,12 +330,6 @@ class GpuSamplingPlanner:
             policy.plan.add_node(t, v)
 
     def copy_candidate_to_policy(self, candidate):
-        self.winner = self.trajectory_order[candidate]
-        self.winner_policy.num_spline_points = self.policy.num_spline_points
-        self._load_candidate_plan(self.winner_policy, self.winner)
-        local = self.winner - self._offset
-        if 0 <= local < self._n_local and not (self.group and self.group.world > 1):
-            self._best = self.ctx.fetch_trajectory(local)
-        with self.mtx_:
-            self.previous_policy.copy_from(self.policy)
-            self.policy.copy_from(self.winner_policy)
+        p = SamplingPolicy()
+        self._load_candidate_plan(p, self.trajectory_order[candidate])
+        self._set_winner(self.trajectory_order[candidate], p.plan.values())

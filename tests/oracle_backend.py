@@ -44,6 +44,11 @@ class OracleContext:
         order = np.lexsort((np.arange(self.N), r))[:k]
         return order.astype(np.int32), r[order]
 
+    def best(self, ref_candidate=0, with_spline=True):
+        idx, ret = self.topk(1)
+        ref = float(self.out["total_return"][ref_candidate]) if ref_candidate >= 0 else float("nan")
+        return int(idx[0]), float(ret[0]), ref, self.nodes[idx[0]].copy()
+
     def fetch_spline(self, i):
         return self.nodes[i].copy()
 

@@ -219,6 +219,20 @@ def test_topk_matches_sorted_returns(cartpole):
     assert ctx.return_of(5) == ret[5]
 
 
+def test_fused_best(cartpole):
+    pm, pt = cartpole.packed_model(), cartpole.packed()
+    ctx = capi.Context(pm, pt, 0, 64)
+    N, H, P = 777, 12, 4
+    ctx.set_state([0, 0.5, 0, 0], 0.0)
+    ctx.rollout_noise(N, H, 2, np.linspace(0, 0.11, P), np.zeros((P, 1)), capi.make_noise_spec(seed=11, std0=0.5))
+    ret, _ = ctx.returns()
+    idx, best, ref, spline = ctx.best(ref_candidate=0)
+    assert idx == int(np.lexsort((np.arange(N), ret))[0]) and best == ret[idx] and ref == ret[0]
+    assert np.array_equal(spline, ctx.fetch_spline(idx))
+    idx2, _, ref2, sp2 = ctx.best(ref_candidate=-1, with_spline=False)
+    assert idx2 == idx and np.isnan(ref2) and sp2 is None
+
+
 def test_api_errors(cartpole):
     pm, pt = cartpole.packed_model(), cartpole.packed()
     ctx = capi.Context(pm, pt, 0, 64)

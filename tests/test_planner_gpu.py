@@ -25,7 +25,7 @@ def test_gpu_planner_converges_on_particle(particle):
     best = p.best_trajectory()
     assert np.abs(best.states[-1, :2] - st.mocap[:2]).max() < 0.1
     assert np.all(np.abs(best.actions) <= 1.0)
-    assert "rollout_lane<TopoParticle,TaskParticle>" == p.ctx.kernel_name
+    assert p.ctx.kernel_name.startswith("rollout_lane<TopoParticle,TaskParticle")
 
 
 def test_gpu_planner_tracks_oracle_planner(cartpole):
