@@ -269,6 +269,13 @@ int mjpcx_topk(mjpcx_ctx* ctx, int k, int32_t* index, double* total_return);
 int mjpcx_best(mjpcx_ctx* ctx, int ref_candidate, int32_t* index, double* best_return, double* ref_return,
                double* spline_values);
 
+/* Cross-Entropy elite statistics (cross_entropy/planner.cc:231-270) over the spline parameters
+ * of `n` local candidates: out[j] = sum_i p_ij when mean == NULL, else sum_i (p_ij - mean[j])^2,
+ * j < P*nu; *sum_return = sum_i total_return_i. The caller divides (n_elite, n_elite - 1) -- and, when
+ * the candidates are sharded, all-reduces the partial sums first. */
+int mjpcx_elite_moments(mjpcx_ctx* ctx, int n, const int32_t* candidates, const double* mean,
+                        double* out, double* sum_return);
+
 /* Gather one candidate into the reference's Trajectory layout. */
 int mjpcx_fetch_trajectory(mjpcx_ctx* ctx, int candidate, mjpcx_traj_view* out);
 

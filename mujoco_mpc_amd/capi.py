@@ -23,7 +23,7 @@ NOISE_SAMPLING, NOISE_CROSS_ENTROPY = 0, 1
 EXPORTS = [
     "mjpcx_create", "mjpcx_destroy", "mjpcx_create_error", "mjpcx_error_string", "mjpcx_last_error",
     "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_rollout_splines",
-    "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_fetch_trajectory",
+    "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
     "mjpcx_fetch_spline", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
     "mjpcx_device_buffer",
 ]
@@ -66,6 +66,7 @@ def lib():
         L.mjpcx_get_return_at.argtypes = [vp, C.c_int, C.POINTER(C.c_double), c_i32p]
         L.mjpcx_best.argtypes = [vp, C.c_int, c_i32p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_f64p]
         L.mjpcx_topk.argtypes = [vp, C.c_int, c_i32p, c_f64p]
+        L.mjpcx_elite_moments.argtypes = [vp, C.c_int, c_i32p, c_f64p, c_f64p, C.POINTER(C.c_double)]
         L.mjpcx_fetch_trajectory.argtypes = [vp, C.c_int, C.POINTER(MjpcxTrajView)]
         L.mjpcx_fetch_spline.argtypes = [vp, C.c_int, c_f64p]
         L.mjpcx_timing_reset.argtypes = [vp]
@@ -205,6 +206,16 @@ class Context:
         ret = np.zeros(k)
         self._chk(lib().mjpcx_topk(self.handle, int(k), as_i32p(idx), as_f64p(ret)))
         return idx, ret
+
+    def elite_moments(self, candidates, mean=None):
+        """(sum over the listed local candidates of p, or of (p - mean)^2) per spline parameter, and sum of returns."""
+        cand = np.ascontiguousarray(candidates, dtype=np.int32).reshape(-1)
+        out = np.zeros(self.P * self.nu)
+        sr = C.c_double()
+        m = None if mean is None else as_f64p(_f(mean).reshape(-1))
+        self._chk(lib().mjpcx_elite_moments(self.handle, cand.size, as_i32p(cand) if cand.size else as_i32p(np.zeros(1, np.int32)),
+                                            m, as_f64p(out), C.byref(sr)))
+        return out.reshape(self.P, self.nu), sr.value
 
     def fetch_trajectory(self, candidate) -> Trajectory:
         tr = Trajectory(self.dim_state, self.nu, self.num_residual, self.num_trace, self.H)

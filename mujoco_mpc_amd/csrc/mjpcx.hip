@@ -173,6 +173,32 @@ __global__ __launch_bounds__(1024) void best_kernel(const double* __restrict__ r
     for (int j = threadIdx.x; j < np; j += blockDim.x) out->spline[j] = (double)nodes[(size_t)j * n + w];
 }
 
+// elite moments: one workgroup per spline parameter j, fixed-shape tree reduction (deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void elite_moments_kernel(const T* __restrict__ nodes, const double* __restrict__ ret,
+                                                            const int* __restrict__ cand, int n, int N, int np,
+                                                            const double* __restrict__ mean, double* out) {
+  __shared__ double sm[256];
+  const int j = blockIdx.x;  // j == np: the return sum
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = cand[i];
+    if (j < np) {
+      const double p = (double)nodes[(size_t)j * N + c];
+      if (mean) { const double d = p - mean[j]; acc += d * d; } else acc += p;
+    } else {
+      acc += ret[c];
+    }
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[j] = sm[0];
+}
+
 // single-workgroup bitonic sort of (return, index) pairs in global memory (n2 = pow2 >= n)
 __global__ __launch_bounds__(1024) void sort_kernel(const double* __restrict__ ret, int n, int n2, RetIdx* buf) {
   for (int i = threadIdx.x; i < n2; i += blockDim.x) buf[i] = i < n ? RetIdx{ret[i], i} : RetIdx{NAN, 0x7fffffff};
@@ -764,6 +790,39 @@ int mjpcx_topk(mjpcx_ctx* c, int k, int32_t* index, double* total_return) {
     index[i] = h[i].i;
     if (total_return) total_return[i] = h[i].r;
   }
+  return MJPCX_OK;
+}
+
+int mjpcx_elite_moments(mjpcx_ctx* c, int n, const int32_t* candidates, const double* mean, double* out,
+                        double* sum_return) {
+  if (!c || !candidates || !out) return fail(c, MJPCX_EINVAL, "null argument");
+  if (!c->have_rollout) return fail(c, MJPCX_ESTATE, "no rollout has been run");
+  if (n < 0) return fail(c, MJPCX_EINVAL, "negative count");
+  for (int i = 0; i < n; i++)
+    if (candidates[i] < 0 || candidates[i] >= c->N) return fail(c, MJPCX_EINVAL, "candidate out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int np = c->P * c->nu;
+  // staging: [cand (n i32) | mean (np f64) | out (np+1 f64)]
+  const size_t off_mean = (((size_t)n * 4) + 15) & ~(size_t)15;
+  const size_t off_out = off_mean + (size_t)np * 8;
+  const size_t bytes = off_out + (size_t)(np + 1) * 8;
+  HIPCHK(c, c->d_stage.reserve(bytes));
+  char* d = (char*)c->d_stage.p;
+  if (n) HIPCHK(c, hipMemcpyAsync(d, candidates, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  if (mean) HIPCHK(c, hipMemcpyAsync(d + off_mean, mean, (size_t)np * 8, hipMemcpyHostToDevice, c->stream));
+  const double* dmean = mean ? (const double*)(d + off_mean) : nullptr;
+  if (c->precision == 64)
+    hipLaunchKernelGGL((elite_moments_kernel<double>), dim3(np + 1), dim3(256), 0, c->stream, (const double*)c->d_nodes.p,
+                       (const double*)c->d_ret.p, (const int*)d, n, c->N, np, dmean, (double*)(d + off_out));
+  else
+    hipLaunchKernelGGL((elite_moments_kernel<float>), dim3(np + 1), dim3(256), 0, c->stream, (const float*)c->d_nodes.p,
+                       (const double*)c->d_ret.p, (const int*)d, n, c->N, np, dmean, (double*)(d + off_out));
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> h(np + 1);
+  HIPCHK(c, hipMemcpyAsync(h.data(), d + off_out, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out, h.data(), (size_t)np * 8);
+  if (sum_return) *sum_return = h[np];
   return MJPCX_OK;
 }
 

@@ -76,6 +76,13 @@ class RankGroup:
         self.dist.broadcast(x, src=src)
         return x.cpu().numpy()
 
+    def sum_array(self, values):
+        """all-reduce(sum) of a small fp64 vector (the CE elite moments)."""
+        t = self.torch
+        x = t.as_tensor(np.ascontiguousarray(values, np.float64), device=self.device).clone()
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
+        return x.cpu().numpy()
+
     def max_scalar(self, value):
         t = self.torch
         x = t.tensor([float(value)], dtype=t.float64, device=self.device)

@@ -333,3 +333,170 @@ class GpuSamplingPlanner:
         p = SamplingPolicy()
         self._load_candidate_plan(p, self.trajectory_order[candidate])
         self._set_winner(self.trajectory_order[candidate], p.plan.values())
+
+
+class GpuCrossEntropyPlanner:
+    """mjpc::CrossEntropyPlanner (mjpc/planners/cross_entropy/planner.{h,cc}) with the candidate
+    fan-out, the sort and the elite statistics on the GPU. Differences forced by SURVEY F4/F5 as for
+    the sampling planner; the extra nominal rollout (planner.cc:435) rides along as one more candidate."""
+
+    def __init__(self, device=0, precision=64, seed=0, group=None, backend_factory=None):
+        self.device, self.precision, self.seed = device, precision, seed
+        self.group = group
+        self._backend_factory = backend_factory
+        self.mtx_ = threading.RLock()
+        self.iteration = 0
+        self.improvement = 0.0
+        self.noise_compute_time = self.rollouts_compute_time = self.policy_update_compute_time = 0.0
+        self.trajectory_order = []
+        self.interpolation_ = ZERO  # member default kZeroSpline, planner.h:141-142 (CE never reads sampling_representation)
+
+    # ---- Initialize, planner.cc:41-74
+    def initialize(self, model, task: Task):
+        self.model, self.task = model, task
+        self.std_initial_ = model.get_number("sampling_exploration", 0.1)
+        self.std_min_ = model.get_number("std_min", 0.01)
+        self.explore_fraction_ = model.get_number("explore_fraction", 0.0)
+        self.num_trajectory_ = int(model.get_number("sampling_trajectories", 10))
+        self.n_elite_ = int(model.get_number("n_elite", max(self.num_trajectory_ // 10, 2)))
+
+    # ---- Allocate, planner.cc:77-119
+    def allocate(self):
+        m = self.model
+        self.state = np.zeros(m.nq + m.nv + m.na)
+        self.mocap = np.zeros(7 * m.nmocap)
+        self.userdata = np.zeros(m.nuserdata)
+        self.time = 0.0
+        self.policy, self.resampled_policy, self.previous_policy = SamplingPolicy(), SamplingPolicy(), SamplingPolicy()
+        for p in (self.policy, self.resampled_policy, self.previous_policy):
+            p.allocate(m, self.task, K_MAX_TRAJECTORY_HORIZON)
+        self.variance = np.zeros(m.nu * K_MAX_TRAJECTORY_HORIZON)
+        self.times_scratch = np.zeros(K_MAX_TRAJECTORY_HORIZON)
+        self.parameters_scratch = np.zeros(m.nu * K_MAX_TRAJECTORY_HORIZON)
+        self._nominal = None
+        if self._backend_factory is not None:
+            self.ctx = self._backend_factory(self.task)
+        else:
+            self.ctx = capi.Context(self.task.packed_model(), self.task.packed(), self.device, self.precision)
+
+    # ---- Reset, planner.cc:122-160
+    def reset(self, horizon, initial_repeated_action=None):
+        self.state[:] = 0
+        self.mocap[:] = 0
+        self.userdata[:] = 0
+        self.time = 0.0
+        for p in (self.policy, self.resampled_policy, self.previous_policy):
+            p.reset(horizon, initial_repeated_action)
+        self.variance[:] = self.std_initial_ ** 2
+        self.improvement = 0.0
+        self._nominal = None
+
+    def set_state(self, state: State):
+        self.state, self.mocap, self.userdata, self.time = state.copy_to()
+
+    def _timestep(self):
+        return self.model.get_number("agent_timestep", self.model.timestep)
+
+    # ---- ResamplePolicy, planner.cc:322-348
+    def resample_policy(self, horizon):
+        P = self.resampled_policy.num_spline_points
+        nu = self.model.nu
+        nominal_time = self.time
+        time_shift = max((horizon - 1) * self._timestep() / (P - 1), 1.0e-5)
+        for t in range(P):
+            self.times_scratch[t] = nominal_time
+            self.resampled_policy.action(self.parameters_scratch[t * nu:(t + 1) * nu], None, nominal_time)
+            nominal_time += time_shift
+        interp = self.policy.plan.interpolation()
+        self.resampled_policy.plan.clear()
+        for t in range(P):
+            self.resampled_policy.plan.add_node(self.times_scratch[t], self.parameters_scratch[t * nu:(t + 1) * nu])
+        self.resampled_policy.plan.set_interpolation(interp)
+
+    # ---- OptimizePolicy, planner.cc:168-291
+    def optimize_policy(self, horizon, pool=None):
+        self.resampled_policy.plan.set_interpolation(self.interpolation_)
+        num_trajectory = self.num_trajectory_
+        self.n_elite_ = min(self.n_elite_, num_trajectory)
+        n_elite = self.n_elite_
+        with self.mtx_:
+            self.resampled_policy.copy_from(self.policy, self.policy.num_spline_points)
+        self.resample_policy(horizon)
+        t0 = _time.perf_counter()
+        P, nu = self.resampled_policy.num_spline_points, self.model.nu
+        np_ = P * nu
+        # ---- Rollouts, planner.cc:388-443: N noised candidates + the nominal as global candidate N
+        rank, world = (self.group.rank, self.group.world) if self.group else (0, 1)
+        n_local = num_trajectory // world
+        offset = rank * n_local
+        if rank == world - 1:
+            n_local = num_trajectory - offset + 1          # the last rank also rolls out the nominal
+        explore_count = int(np.sum(np.arange(num_trajectory) < num_trajectory * self.explore_fraction_))
+        ns = capi.make_noise_spec(seed=self.seed, iteration=self.iteration, mode=capi.NOISE_CROSS_ENTROPY,
+                                  candidate_offset=offset, nominal_candidate=num_trajectory, explore_count=explore_count,
+                                  std0=self.std_initial_, std1=self.std_min_, param_variance=self.variance[:np_])
+        plan = self.resampled_policy.plan
+        self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
+        self.ctx.rollout_noise(n_local, horizon, plan.interpolation(), plan.times(), plan.values(), ns)
+        self._offset, self._n_local = offset, n_local
+        # ---- full sort in the reference (planner.cc:206-211); only the elites matter downstream
+        k = min(n_elite + 1, n_local)
+        idx, ret = self.ctx.topk(k)
+        idx = idx.astype(np.int64) + offset
+        if world > 1:
+            idx, ret = self.group.merge_topk(idx, ret, n_elite + 1)
+        keep = idx != num_trajectory                      # the nominal rollout is not a candidate
+        idx, ret = idx[keep][:n_elite], ret[keep][:n_elite]
+        self.trajectory_order = [int(i) for i in idx]
+        self.rollouts_compute_time = (_time.perf_counter() - t0) * 1e6
+        # ---- elite mean / variance, planner.cc:216-270
+        t0 = _time.perf_counter()
+        mine = np.array([i - offset for i in self.trajectory_order if offset <= i < offset + n_local and i != num_trajectory],
+                        dtype=np.int32)
+        s, sret = self.ctx.elite_moments(mine)
+        if world > 1:
+            tot = self.group.sum_array(np.concatenate([s.reshape(-1), [sret]]))
+            s, sret = tot[:-1].reshape(P, nu), tot[-1]
+        mean = s / n_elite
+        avg_return = sret / n_elite
+        sq, _ = self.ctx.elite_moments(mine, mean)
+        if world > 1:
+            sq = self.group.sum_array(sq.reshape(-1)).reshape(P, nu)
+        self.variance[:] = 0.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            self.variance[:np_] = (sq / (n_elite - 1)).reshape(-1)   # n_elite == 1 -> inf/nan, as the reference
+        self.parameters_scratch[:np_] = mean.reshape(-1)
+        with self.mtx_:
+            self.previous_policy.copy_from(self.policy)
+            self.policy.plan.clear()
+            self.policy.plan.set_interpolation(self.interpolation_)
+            for t in range(P):
+                self.policy.plan.add_node(self.times_scratch[t], mean[t])
+        self.improvement = max(avg_return - float(ret[0]), 0.0)
+        self._nominal = None
+        self.iteration += 1
+        self.policy_update_compute_time = (_time.perf_counter() - t0) * 1e6
+
+    # ---- NominalTrajectory, planner.cc:294-308
+    def nominal_trajectory(self, horizon, pool=None):
+        plan = self.resampled_policy.plan
+        self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
+        self.ctx.rollout_splines(horizon, plan.interpolation(), plan.times(), plan.values()[None])
+        self._nominal = self.ctx.fetch_trajectory(0)
+        self._n_local = 0
+        return self._nominal
+
+    def action_from_policy(self, action, state, time, use_previous=False):
+        with self.mtx_:
+            return (self.previous_policy if use_previous else self.policy).action(action, state, time)
+
+    # ---- BestTrajectory, planner.cc:446-448: the NOMINAL trajectory
+    def best_trajectory(self):
+        if self._nominal is None and self.ctx is not None and getattr(self, "_n_local", 0) > 0:
+            local = self.num_trajectory_ - self._offset
+            if 0 <= local < self._n_local:
+                self._nominal = self.ctx.fetch_trajectory(local)
+        return self._nominal
+
+    def num_parameters(self):
+        return self.policy.num_spline_points * self.model.nu

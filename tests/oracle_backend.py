@@ -49,6 +49,12 @@ class OracleContext:
         ref = float(self.out["total_return"][ref_candidate]) if ref_candidate >= 0 else float("nan")
         return int(idx[0]), float(ret[0]), ref, self.nodes[idx[0]].copy()
 
+    def elite_moments(self, candidates, mean=None):
+        c = np.asarray(candidates, int)
+        p = self.nodes[c]
+        out = p.sum(axis=0) if mean is None else ((p - np.asarray(mean).reshape(1, self.P, self.nu)) ** 2).sum(axis=0)
+        return out.reshape(self.P, self.nu), float(self.out["total_return"][c].sum())
+
     def fetch_spline(self, i):
         return self.nodes[i].copy()
 

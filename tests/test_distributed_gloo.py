@@ -35,6 +35,16 @@ for it in range(3):
     p.optimize_policy(H)
     log.append(dict(winner=int(p.winner), score=p.candidate_score(0), improvement=p.improvement,
                     plan=p.policy.plan.values().tolist()))
+# Cross-Entropy: sharded candidates + all-gathered elites + all-reduced moments
+from mujoco_mpc_amd.planners import GpuCrossEntropyPlanner
+ce = GpuCrossEntropyPlanner(seed=8, group=group, backend_factory=lambda t: OracleContext(t, threads=1))
+ce.initialize(task.model, task); ce.num_trajectory_ = 40; ce.n_elite_ = 6; ce.allocate()
+ce.std_initial_, ce.std_min_, ce.explore_fraction_ = 0.3, 0.05, 0.2
+ce.reset(H); ce.set_state(st)
+for it in range(2):
+    ce.optimize_policy(H)
+    log.append(dict(winner=ce.trajectory_order[0], score=float(ce.improvement), improvement=float(ce.variance[:10].sum()),
+                    plan=ce.policy.plan.values().tolist()))
 if group is None or group.rank == 0:
     print("RESULT " + json.dumps(log))
 if group is not None:
@@ -65,8 +75,12 @@ def run(world):
 
 def test_two_ranks_equal_one_rank():
     one, two = run(1), run(2)
-    assert len(one) == len(two) == 3
-    for a, b in zip(one, two):
+    assert len(one) == len(two) == 5
+    for k, (a, b) in enumerate(zip(one, two)):
         assert a["winner"] == b["winner"]
-        assert a["score"] == b["score"] and a["improvement"] == b["improvement"]
-        assert np.array_equal(np.array(a["plan"]), np.array(b["plan"]))
+        if k < 3:   # Predictive Sampling: bit-identical
+            assert a["score"] == b["score"] and a["improvement"] == b["improvement"]
+            assert np.array_equal(np.array(a["plan"]), np.array(b["plan"]))
+        else:       # Cross-Entropy: sums are re-associated across ranks
+            assert abs(a["score"] - b["score"]) < 1e-12 and abs(a["improvement"] - b["improvement"]) < 1e-12
+            assert np.allclose(np.array(a["plan"]), np.array(b["plan"]), rtol=0, atol=1e-14)
