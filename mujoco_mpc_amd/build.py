@@ -55,3 +55,11 @@ def build_native(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB
+
+
+def build_host(verbose=False):
+    """C++ host layer (namespace mjpc over the C ABI) + its test programs: g++, links libmjpcx.so."""
+    build_native()
+    host = os.path.join(PKG_DIR, "host")
+    subprocess.check_call(["make", "-C", host, "-s", "-j8"], stdout=None if verbose else subprocess.DEVNULL)
+    return os.path.join(host, "build", "libmjpc_host.so")

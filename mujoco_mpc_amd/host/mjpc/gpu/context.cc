@@ -1,0 +1,101 @@
+#include "context.h"
+
+namespace mjpc::gpu {
+
+FlatModel::FlatModel(const mjModel* m, double timestep, int integrator) {
+  mjpcx_model& f = flat_;
+  f.nq = m->nq; f.nv = m->nv; f.nu = m->nu; f.na = m->na; f.nbody = m->nbody; f.njnt = m->njnt;
+  f.nsite = m->nsite; f.nmocap = m->nmocap; f.nuserdata = m->nuserdata;
+  f.timestep = timestep;
+  for (int k = 0; k < 3; k++) f.gravity[k] = m->opt.gravity[k];
+  f.integrator = integrator;
+  f.disableflags = m->opt.disableflags;
+  f.solver_iterations = m->opt.iterations;
+  f.solver_tolerance = m->opt.tolerance;
+  f.meaninertia = m->stat.meaninertia;
+  // arrays that already have the ABI's element type and stride are passed through
+  f.body_parentid = m->body_parentid; f.body_rootid = m->body_rootid; f.body_jntnum = m->body_jntnum;
+  f.body_jntadr = m->body_jntadr; f.body_dofnum = m->body_dofnum; f.body_dofadr = m->body_dofadr;
+  f.body_mocapid = m->body_mocapid;
+  f.body_pos = m->body_pos; f.body_quat = m->body_quat; f.body_ipos = m->body_ipos; f.body_iquat = m->body_iquat;
+  f.body_mass = m->body_mass; f.body_inertia = m->body_inertia;
+  f.jnt_type = m->jnt_type; f.jnt_qposadr = m->jnt_qposadr; f.jnt_dofadr = m->jnt_dofadr; f.jnt_bodyid = m->jnt_bodyid;
+  f.jnt_pos = m->jnt_pos; f.jnt_axis = m->jnt_axis; f.jnt_stiffness = m->jnt_stiffness; f.jnt_range = m->jnt_range;
+  f.jnt_margin = m->jnt_margin; f.jnt_solref = m->jnt_solref; f.jnt_solimp = m->jnt_solimp;
+  f.dof_bodyid = m->dof_bodyid; f.dof_jntid = m->dof_jntid; f.dof_parentid = m->dof_parentid;
+  f.dof_armature = m->dof_armature; f.dof_damping = m->dof_damping; f.dof_frictionloss = m->dof_frictionloss;
+  f.dof_invweight0 = m->dof_invweight0;
+  f.qpos0 = m->qpos0; f.qpos_spring = m->qpos_spring;
+  f.site_bodyid = m->site_bodyid; f.site_pos = m->site_pos; f.site_quat = m->site_quat;
+  f.actuator_gaintype = m->actuator_gaintype; f.actuator_biastype = m->actuator_biastype;
+  f.actuator_ctrlrange = m->actuator_ctrlrange; f.actuator_forcerange = m->actuator_forcerange;
+  // MuJoCo strides / byte flags -> the ABI's compact int32 / [nu x 3] layout
+  jnt_limited_.assign(m->jnt_limited, m->jnt_limited + m->njnt);
+  trnid_.resize(m->nu); ctrllimited_.resize(m->nu); forcelimited_.resize(m->nu);
+  gear_.resize(m->nu); gainprm_.resize(3 * (size_t)m->nu); biasprm_.resize(3 * (size_t)m->nu);
+  for (int u = 0; u < m->nu; u++) {
+    trnid_[u] = m->actuator_trnid[2 * u];
+    ctrllimited_[u] = m->actuator_ctrllimited[u];
+    forcelimited_[u] = m->actuator_forcelimited[u];
+    gear_[u] = m->actuator_gear[6 * u];
+    for (int k = 0; k < 3; k++) {
+      gainprm_[3 * u + k] = m->actuator_gainprm[mjNGAIN * u + k];
+      biasprm_[3 * u + k] = m->actuator_biasprm[mjNBIAS * u + k];
+    }
+  }
+  f.jnt_limited = jnt_limited_.data();
+  f.actuator_trnid = trnid_.data(); f.actuator_ctrllimited = ctrllimited_.data();
+  f.actuator_forcelimited = forcelimited_.data(); f.actuator_gear = gear_.data();
+  f.actuator_gainprm = gainprm_.data(); f.actuator_biasprm = biasprm_.data();
+}
+
+FlatTask::FlatTask(const Task& t) {
+  norm_.assign(t.norm.begin(), t.norm.end());
+  flat_.residual_id = t.DeviceResidualId();
+  flat_.num_residual = t.num_residual;
+  flat_.num_term = t.num_term;
+  flat_.num_trace = t.num_trace;
+  flat_.num_parameter = (int)t.parameters.size();
+  flat_.dim_norm_residual = t.dim_norm_residual.data();
+  flat_.norm = norm_.data();
+  flat_.num_norm_parameter = t.num_norm_parameter.data();
+  flat_.weight = t.weight.data();
+  flat_.norm_parameter = t.norm_parameter.data();
+  flat_.parameters = t.parameters.data();
+  flat_.trace_site = t.trace_site.data();
+  flat_.risk = t.risk;
+}
+
+Context::Context(const mjModel* model, const Task& task, int device, int precision) {
+  // the planning copy runs at agent_timestep / agent_integrator when the model defines them
+  double timestep = model->opt.timestep;
+  int integrator = model->opt.integrator;
+  for (int i = 0; i < model->nnumeric; i++) {
+    const std::string name = model->names + model->name_numericadr[i];
+    if (name == "agent_timestep") timestep = model->numeric_data[model->numeric_adr[i]];
+    if (name == "agent_integrator") integrator = (int)model->numeric_data[model->numeric_adr[i]];
+  }
+  FlatModel fm(model, timestep, integrator);
+  FlatTask ft(task);
+  const int rc = mjpcx_create(fm.get(), ft.get(), device, precision, &ctx_);
+  if (rc != MJPCX_OK) throw Error(rc, std::string(mjpcx_error_string(rc)) + ": " + mjpcx_create_error());
+}
+
+Context::~Context() { mjpcx_destroy(ctx_); }
+
+void Context::Check(int rc) const {
+  if (rc != MJPCX_OK) throw Error(rc, std::string(mjpcx_error_string(rc)) + ": " + mjpcx_last_error(ctx_));
+}
+
+void Context::FetchTrajectory(int index, Trajectory* tr) {
+  mjpcx_traj_view v{};
+  v.horizon = (int)tr->times.size();
+  v.states = tr->states.data(); v.actions = tr->actions.data(); v.times = tr->times.data();
+  v.residual = tr->residual.data(); v.costs = tr->costs.data(); v.trace = tr->trace.data();
+  Check(mjpcx_fetch_trajectory(ctx_, index, &v));
+  tr->horizon = v.horizon;
+  tr->total_return = v.total_return;
+  tr->failure = v.failure != 0;
+}
+
+}  // namespace mjpc::gpu

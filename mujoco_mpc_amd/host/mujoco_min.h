@@ -1,0 +1,71 @@
+// mujoco_min.h -- the slice of MuJoCo's public `mjModel` / `mjData` structs that the MJPC host code on
+// the rollout path touches, with MuJoCo's own field names, element types and array strides
+// (actuator_gear x6, actuator_gainprm/biasprm x mjNGAIN/mjNBIAS, actuator_trnid x2, limited flags as
+// mjtByte). MuJoCo itself is a FetchContent dependency of the reference that is not available in this
+// build environment; inside a real MJPC checkout this header is replaced by
+// <mujoco/mujoco.h> and everything above it compiles unchanged.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+typedef double mjtNum;
+typedef unsigned char mjtByte;
+
+enum { mjNREF = 2, mjNIMP = 5, mjNGAIN = 10, mjNBIAS = 10 };
+enum mjtJoint { mjJNT_FREE = 0, mjJNT_BALL, mjJNT_SLIDE, mjJNT_HINGE };
+enum mjtSensor { mjSENS_USER = 100, mjSENS_FRAMEPOS = 25, mjSENS_OTHER = 0 };
+enum mjtObj { mjOBJ_BODY = 1, mjOBJ_SITE = 6 };
+enum mjtBias { mjBIAS_NONE = 0, mjBIAS_AFFINE = 1 };
+
+struct mjOption {
+  mjtNum timestep;
+  mjtNum gravity[3];
+  mjtNum tolerance;
+  int integrator;
+  int iterations;
+  int disableflags;
+};
+struct mjStatistic {
+  mjtNum meaninertia;
+};
+
+struct mjModel {
+  int nq, nv, nu, na, nbody, njnt, nsite, nmocap, nuserdata, nsensor, nuser_sensor, nnumeric, ntext, nkey;
+  mjOption opt;
+  mjStatistic stat;
+  int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_mocapid;
+  mjtNum *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia;
+  int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
+  mjtByte* jnt_limited;
+  mjtNum *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
+  int *dof_bodyid, *dof_jntid, *dof_parentid;
+  mjtNum *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0;
+  mjtNum *qpos0, *qpos_spring;
+  int* site_bodyid;
+  mjtNum *site_pos, *site_quat;
+  int *actuator_trnid, *actuator_gaintype, *actuator_biastype;
+  mjtByte *actuator_ctrllimited, *actuator_forcelimited;
+  mjtNum *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
+  int *sensor_type, *sensor_objtype, *sensor_objid, *sensor_dim, *sensor_adr;
+  mjtNum* sensor_user;
+  int *numeric_adr, *numeric_size;
+  mjtNum* numeric_data;
+  mjtNum *key_qpos, *key_qvel;
+  int *name_bodyadr, *name_jntadr, *name_siteadr, *name_sensoradr, *name_numericadr, *name_keyadr;
+  char* names;
+};
+
+struct mjData {
+  mjtNum time;
+  mjtNum *qpos, *qvel, *act, *ctrl, *mocap_pos, *mocap_quat, *userdata, *sensordata;
+};
+
+inline void mju_copy(mjtNum* dst, const mjtNum* src, int n) { if (n > 0) std::memcpy(dst, src, sizeof(mjtNum) * n); }
+inline void mju_zero(mjtNum* dst, int n) { if (n > 0) std::memset(dst, 0, sizeof(mjtNum) * n); }
+inline mjtNum mju_max(mjtNum a, mjtNum b) { return a > b ? a : b; }
+inline mjtNum mju_min(mjtNum a, mjtNum b) { return a < b ? a : b; }
+inline mjtNum mju_clip(mjtNum x, mjtNum lo, mjtNum hi) { return mju_max(lo, mju_min(hi, x)); }
+inline mjtNum mju_abs(mjtNum x) { return std::fabs(x); }

@@ -1,0 +1,60 @@
+// mjpc/test/tasks/task_test.cc:49-99 on the compiled particle task (argv[1] = Particle.mjpx, argv[2] = Cartpole.mjpx).
+#include <cmath>
+
+#include "check.h"
+#include "mjpc/tasks/tasks.h"
+#include "mjpc/utilities.h"
+#include "model_io.h"
+using namespace mjpc;
+
+int main(int argc, char** argv) {
+  if (argc < 3) { std::printf("usage: task_test Particle.mjpx Cartpole.mjpx\n"); return 2; }
+  auto storage = ModelStorage::Load(argv[1]);
+  const mjModel* model = storage->model();
+  ParticleTestTask task;
+  task.Reset(model);
+  CHECK_NEAR(task.risk, 1.0, 1e-5);
+  CHECK(task.mode == 0 && task.parameters.size() == 2);
+  CHECK_NEAR(task.parameters[0], 0.05, 1e-5);
+  CHECK_NEAR(task.parameters[1], -0.1, 1e-5);
+  CHECK(task.num_residual == 4 && task.num_term == 2 && task.num_trace == 1);
+  CHECK(task.dim_norm_residual[0] == 2 && task.dim_norm_residual[1] == 2);
+  CHECK(task.num_norm_parameter[0] == 0 && task.num_norm_parameter[1] == 0);
+  CHECK(task.norm[0] == kQuadratic && task.norm[1] == kQuadratic);
+  CHECK_NEAR(task.weight[0], 5.0, 1e-5);
+  CHECK_NEAR(task.weight[1], 0.1, 1e-5);
+  CHECK(task.trace_site.size() == 1 && task.trace_site[0] == 0);
+  double terms[2];
+  const double residual[] = {1.0e-3, 2.0e-3, 3.0e-3, 4.0e-3};
+  task.CostTerms(terms, residual);
+  const double c = 5.0 * 0.5 * (residual[0] * residual[0] + residual[1] * residual[1]) +
+                   0.1 * 0.5 * (residual[2] * residual[2] + residual[3] * residual[3]);
+  CHECK_NEAR(terms[0] + terms[1], c, 1e-12);
+  task.risk = 0.2;
+  task.UpdateResidual();
+  CHECK_NEAR(task.CostValue(residual), (std::exp(0.2 * c) - 1.0) / 0.2, 1e-12);
+  // GetNumberOrDefault (mjpc/test/agent/agent_utilities_test.cc)
+  CHECK_NEAR(GetNumberOrDefault(7.0, model, "test_double"), 0.1, 1e-15);
+  CHECK(GetNumberOrDefault(0, model, "test_int") == 1 && GetNumberOrDefault(3, model, "absent") == 3);
+  CHECK(GetCustomNumericSize(model, "test_doubles") == 2);
+  double xs[3] = {-2.0, 0.5, 2.0};
+  const double bounds[6] = {-1, 1, -1, 1, -1, 1};
+  Clamp(xs, bounds, 3);
+  CHECK(xs[0] == -1.0 && xs[1] == 0.5 && xs[2] == 1.0);
+  CHECK(KeyQPosByName(model, "home") != nullptr && KeyQPosByName(model, "home")[1] == 2.0);
+
+  auto cstorage = ModelStorage::Load(argv[2]);
+  Cartpole cart;
+  cart.Reset(cstorage->model());
+  CHECK(cart.num_term == 4 && cart.norm[0] == kSmoothAbsLoss && cart.norm[2] == kQuadratic);
+  CHECK(cart.norm_parameter.size() == 2 && cart.norm_parameter[0] == 0.01 && cart.norm_parameter[1] == 0.1);
+  // residual function on a hand-built mjData
+  double qpos[2] = {0.3, 1.0}, qvel[2] = {0.1, -0.2}, ctrl[1] = {0.7}, r[4];
+  mjData d{};
+  d.qpos = qpos; d.qvel = qvel; d.ctrl = ctrl;
+  cart.Residual(cstorage->model(), &d, r);
+  CHECK_NEAR(r[0], std::cos(1.0) - 1, 1e-15);
+  CHECK(r[1] == 0.3 && r[2] == -0.2 && r[3] == 0.7);
+  CHECK(GetTasks().size() == 3);
+  TEST_MAIN_END();
+}

@@ -693,3 +693,90 @@ def load_xml(path: str) -> FlatModel:
     root = ET.parse(path).getroot()
     _expand_includes(root, os.path.dirname(path))
     return _Compiler(root, path).compile()
+
+
+# ----------------------------------------------------------------------------- binary blob for the C++ host
+_SENSOR_TYPE = {"user": 100, "framepos": 25}   # mjtSensor values the host code inspects; others -> 0
+_OBJ_TYPE = {"body": 1, "site": 6}             # mjtObj
+
+
+def save_blob(fm: FlatModel, path: str):
+    """Serialise a compiled model for mujoco_mpc_amd/host/model_io.cc (the C++ stand-in for mj_loadXML).
+    Arrays use MuJoCo's mjModel strides (gear x6, gainprm/biasprm x10, trnid x2, limited flags as bytes)."""
+    import struct
+    a, sc = fm.arrays, fm.scalars
+    nu, nsens = sc["nu"], len(fm.sensors)
+    entries = []
+
+    def put_i(name, v):
+        entries.append((name, 0, np.ascontiguousarray(v, dtype=np.int32).reshape(-1)))
+
+    def put_r(name, v):
+        entries.append((name, 1, np.ascontiguousarray(v, dtype=np.float64).reshape(-1)))
+
+    def put_b(name, v):
+        entries.append((name, 2, np.ascontiguousarray(v, dtype=np.uint8).reshape(-1)))
+
+    names = bytearray()
+
+    def name_table(lst):
+        adr = []
+        for n in lst:
+            adr.append(len(names))
+            names.extend(n.encode() + b"\0")
+        return adr
+
+    keys = list(fm.keyframes.items())
+    put_i("sizes", [sc["nq"], sc["nv"], nu, sc["na"], sc["nbody"], sc["njnt"], sc["nsite"], sc["nmocap"],
+                    sc["nuserdata"], nsens, fm.nuser_sensor, len(fm.numeric), len(fm.text), len(keys)])
+    put_r("opt", [sc["timestep"], *sc["gravity"], sc["solver_tolerance"], sc["meaninertia"]])
+    put_i("opt_int", [sc["integrator"], sc["solver_iterations"], sc["disableflags"]])
+    for k in ("body_parentid", "body_rootid", "body_jntnum", "body_jntadr", "body_dofnum", "body_dofadr", "body_mocapid",
+              "jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "dof_bodyid", "dof_jntid", "dof_parentid",
+              "site_bodyid", "actuator_gaintype", "actuator_biastype"):
+        put_i(k, a[k])
+    for k in ("body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia", "jnt_pos", "jnt_axis",
+              "jnt_stiffness", "jnt_range", "jnt_margin", "jnt_solref", "jnt_solimp", "dof_armature", "dof_damping",
+              "dof_frictionloss", "dof_invweight0", "qpos0", "qpos_spring", "site_pos", "site_quat",
+              "actuator_ctrlrange", "actuator_forcerange"):
+        put_r(k, a[k])
+    put_b("jnt_limited", a["jnt_limited"])
+    put_b("actuator_ctrllimited", a["actuator_ctrllimited"])
+    put_b("actuator_forcelimited", a["actuator_forcelimited"])
+    trnid = np.full((nu, 2), -1, np.int32); trnid[:, 0] = a["actuator_trnid"]
+    gear = np.zeros((nu, 6)); gear[:, 0] = a["actuator_gear"]
+    gain = np.zeros((nu, 10)); gain[:, :3] = np.asarray(a["actuator_gainprm"]).reshape(nu, 3)
+    bias = np.zeros((nu, 10)); bias[:, :3] = np.asarray(a["actuator_biasprm"]).reshape(nu, 3)
+    put_i("actuator_trnid", trnid); put_r("actuator_gear", gear); put_r("actuator_gainprm", gain); put_r("actuator_biasprm", bias)
+    # sensors
+    stype, sobjtype, sobjid, sdim, sadr, suser = [], [], [], [], [], np.zeros((nsens, max(fm.nuser_sensor, 1)))
+    adr = 0
+    for i, s in enumerate(fm.sensors):
+        stype.append(_SENSOR_TYPE.get(s["type"], 0))
+        ot = _OBJ_TYPE.get(s["objtype"], 0)
+        sobjtype.append(ot)
+        sobjid.append(fm.name2id(s["objtype"], s["objname"]) if ot else -1)
+        sdim.append(s["dim"]); sadr.append(adr); adr += s["dim"]
+        suser[i, :len(s["user"])] = s["user"]
+    put_i("sensor_type", stype); put_i("sensor_objtype", sobjtype); put_i("sensor_objid", sobjid)
+    put_i("sensor_dim", sdim); put_i("sensor_adr", sadr)
+    put_r("sensor_user", suser[:, :fm.nuser_sensor] if fm.nuser_sensor else np.zeros(0))
+    # custom numerics
+    nadr, nsize, ndata = [], [], []
+    for k, v in fm.numeric.items():
+        nadr.append(len(ndata)); nsize.append(len(v)); ndata += list(v)
+    put_i("numeric_adr", nadr); put_i("numeric_size", nsize); put_r("numeric_data", ndata)
+    put_r("key_qpos", np.array([k[1]["qpos"] for k in keys]) if keys else np.zeros(0))
+    put_r("key_qvel", np.array([k[1]["qvel"] for k in keys]) if keys else np.zeros(0))
+    put_i("name_bodyadr", name_table(fm.names["body"])); put_i("name_jntadr", name_table(fm.names["joint"]))
+    put_i("name_siteadr", name_table(fm.names["site"])); put_i("name_sensoradr", name_table(fm.names["sensor"]))
+    put_i("name_numericadr", name_table(list(fm.numeric.keys()))); put_i("name_keyadr", name_table([k[0] for k in keys]))
+    put_b("names", np.frombuffer(bytes(names) or b"\0", dtype=np.uint8))
+    with open(path, "wb") as f:
+        f.write(b"MJPXBLOB1\n")
+        f.write(struct.pack("<I", len(entries)))
+        for name, kind, arr in entries:
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb))); f.write(nb)
+            f.write(struct.pack("<BQ", kind, arr.size)); f.write(arr.tobytes())
+    return path

@@ -1,0 +1,55 @@
+"""The C++ host layer (mujoco_mpc_amd/host: namespace mjpc mirror of the reference's Planner / Trajectory /
+Task / TimeSpline / State / ThreadPool classes over the C ABI). The test programs are ports of the reference's
+gtest suites (cited in each .cc); this file builds and runs them."""
+import os
+import subprocess
+
+import pytest
+
+from mujoco_mpc_amd import mjcf
+from mujoco_mpc_amd.build import build_host
+from mujoco_mpc_amd.task import load_task
+
+HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mujoco_mpc_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def blobs(tmp_path_factory):
+    build_host()
+    d = tmp_path_factory.mktemp("blobs")
+    for name in ("Cartpole", "Particle"):
+        mjcf.save_blob(load_task(name).model, str(d / f"{name}.mjpx"))
+    return str(d)
+
+
+def run(exe, *args, timeout=300):
+    out = subprocess.run([os.path.join(HOST, "build", exe), *args], capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("exe", ["spline_test", "norm_test", "trajectory_test", "threadpool_test"])
+def test_cpu_suites(blobs, exe):
+    assert "OK" in run(exe)
+
+
+def test_task_and_state_suites(blobs):
+    assert "OK" in run("task_test", os.path.join(blobs, "Particle.mjpx"), os.path.join(blobs, "Cartpole.mjpx"))
+    assert "OK" in run("state_test", os.path.join(blobs, "Particle.mjpx"))
+
+
+def test_host_library_links_the_c_abi(blobs):
+    out = subprocess.run(["ldd", os.path.join(HOST, "build", "libmjpc_host.so")], capture_output=True, text=True).stdout
+    assert "libmjpcx.so" in out
+
+
+@pytest.mark.gpu
+def test_gpu_sampling_planner_cpp(blobs):
+    assert "OK" in run("gpu_planner_test", blobs)
+
+
+@pytest.mark.gpu
+def test_testspeed_app(blobs):
+    out = run("testspeed_app", "--task=Cartpole", "--total_time=0.5", "--steps_per_planning_iteration=4",
+              f"--model_dir={blobs}", "--candidates=4096")
+    assert "Average cost per step" in out
