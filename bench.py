@@ -91,7 +91,7 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     import torch
     from mujoco_mpc_amd import capi
-    from mujoco_mpc_amd.planners import GpuSamplingPlanner, State
+    from mujoco_mpc_amd.hostplanner import HostPlanner
     from mujoco_mpc_amd.task import load_task
 
     group = None
@@ -107,21 +107,20 @@ def main():
 
     task = load_task(args.task)
     model = task.model
-    planner = GpuSamplingPlanner(device=local_rank, precision=args.precision, seed=0, group=group)
-    planner.initialize(model, task)
-    planner.num_trajectory_ = args.candidates * world  # lifts kMaxTrajectory=128
-    planner.allocate()
+    # the C++ mjpc::GpuSamplingPlanner (mujoco_mpc_amd/host) drives the C ABI; Python only lends it
+    # torch.distributed as the transport of the per-step candidate exchange when there are several ranks
     H = args.horizon
+    planner = HostPlanner(task, device=local_rank, precision=args.precision, seed=0,
+                          num_trajectory=args.candidates * world,  # lifts kMaxTrajectory = 128
+                          group=group)
     planner.reset(H)
-    P = planner.policy.num_spline_points
+    P = planner.num_spline_points
 
     # synthetic initial condition: the task's home keyframe
-    state = State(model)
     home = model.keyframes.get("home")
     qpos = home["qpos"] if home else model.qpos0
     qvel = home["qvel"] if home else np.zeros(model.nv)
-    state.set(qpos, qvel, time=0.0)
-    planner.set_state(state)
+    planner.set_state(qpos, qvel, 0.0)
 
     def step():
         planner.optimize_policy(H)
@@ -129,27 +128,27 @@ def main():
     def fence():
         if group is not None:
             group.barrier()
-        planner.ctx.sync()
+        planner.sync()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
-    planner.ctx.timing_reset()
+    planner.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = planner.ctx.timing_read()
+    kernel_ms, launches = planner.timing_read()
     if group is not None:
         elapsed = group.max_scalar(elapsed)
 
     total_rollouts = args.candidates * world * args.steps
     value = total_rollouts / elapsed
     if rank == 0:
-        bytes_per_rollout = planner.ctx.algorithmic_bytes(H, P)
+        bytes_per_rollout = planner.algorithmic_bytes(H, P)
         bytes_per_launch = bytes_per_rollout * args.candidates
         avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
         achieved = bytes_per_launch / avg_kernel_s / 1e9
@@ -161,7 +160,7 @@ def main():
             "config": {"workload": f"{args.task} Predictive Sampling, {args.candidates} candidates/GPU, horizon {H}, "
                                    f"{P} cubic spline points, fp{args.precision} (BASELINE.json configs[1])",
                        "candidates_per_gpu": args.candidates, "horizon": H, "spline_points": P,
-                       "parallelism": f"candidates sharded over {world} rank(s)", "kernel": planner.ctx.kernel_name},
+                       "parallelism": f"candidates sharded over {world} rank(s)", "kernel": planner.kernel_name, "host": "C++ mjpc::GpuSamplingPlanner over the C ABI"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": avg_kernel_s * 1e3, "bytes_per_launch": bytes_per_launch,

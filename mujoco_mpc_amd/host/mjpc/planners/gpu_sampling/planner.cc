@@ -97,21 +97,32 @@ void GpuSamplingPlanner::UpdateNominalPolicy(int horizon) {
   policy.plan = plan_scratch;
 }
 
+void GpuSamplingPlanner::SetSharding(int rank, int world, ExchangeFn exchange, void* user) {
+  rank_ = rank;
+  world_ = std::max(world, 1);
+  exchange_ = exchange;
+  exchange_user_ = user;
+}
+
 // the device fan-out: noise + N rollouts + returns, one launch (sampling/planner.cc:355-393)
 void GpuSamplingPlanner::Rollouts(int num_trajectory, int horizon) {
+  // this rank's slice of the global batch
+  int n_local = num_trajectory / world_;
+  offset_ = rank_ * n_local;
+  if (rank_ == world_ - 1) n_local = num_trajectory - offset_;
   mjpcx_noise_spec ns{};
   ns.seed = seed_;
   ns.iteration = iteration;
   ns.mode = MJPCX_NOISE_SAMPLING;
-  ns.candidate_offset = 0;
+  ns.candidate_offset = offset_;
   ns.nominal_candidate = 0;  // `if (i != 0) AddNoiseToPolicy`: candidate 0 is the nominal
   ns.std0 = noise_exploration[0];
   ns.std1 = noise_exploration[1];
   const TimeSpline& plan = policy.plan;
   ctx_->Check(mjpcx_set_state(ctx_->handle(), state.data(), time, mocap.data(), userdata.data()));
-  ctx_->Check(mjpcx_rollout_noise(ctx_->handle(), num_trajectory, horizon, (int)plan.Size(), (int)plan.Interpolation(),
+  ctx_->Check(mjpcx_rollout_noise(ctx_->handle(), n_local, horizon, (int)plan.Size(), (int)plan.Interpolation(),
                                   plan.times().data(), plan.values().data(), &ns));
-  num_rolled_ = num_trajectory;
+  num_rolled_ = n_local;
   best_valid_ = false;
 }
 
@@ -140,7 +151,18 @@ void GpuSamplingPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
   int32_t index = 0;
   double best_return = 0, nominal_return = 0;
   std::vector<double> values(policy.plan.Size() * (size_t)model->nu);
-  ctx_->Check(mjpcx_best(ctx_->handle(), /*ref_candidate=*/0, &index, &best_return, &nominal_return, values.data()));
+  ctx_->Check(mjpcx_best(ctx_->handle(), /*ref_candidate=*/offset_ == 0 ? 0 : -1, &index, &best_return, &nominal_return,
+                         values.data()));
+  index += offset_;  // global candidate index
+  if (world_ > 1) {
+    if (!exchange_) throw gpu::Error(MJPCX_EINVAL, "sharded planner without an exchange function");
+    double record[3] = {best_return, (double)index, nominal_return};
+    if (exchange_(exchange_user_, record, values.data(), (int)values.size()) != 0)
+      throw gpu::Error(MJPCX_EDEVICE, "candidate exchange failed");
+    best_return = record[0];
+    index = (int32_t)record[1];
+    nominal_return = record[2];
+  }
   trajectory_order.assign(1, index);
   scores_.assign(1, best_return);
   rollouts_compute_time = GetDuration(start);
@@ -185,6 +207,7 @@ void GpuSamplingPlanner::NominalTrajectory(int horizon, ThreadPool& pool) {
                                     times.data(), values.data()));
   num_rolled_ = 1;
   winner = 0;
+  offset_ = 0;
   ctx_->FetchTrajectory(0, &best_);
   best_valid_ = true;
 }
@@ -197,8 +220,9 @@ void GpuSamplingPlanner::ActionFromPolicy(double* action, const double* s, doubl
 // the reference returns &trajectory[winner]; here the winner stays on the device until someone asks
 const Trajectory* GpuSamplingPlanner::BestTrajectory() {
   if (!best_valid_) {
-    if (num_rolled_ == 0 || winner < 0 || winner >= num_rolled_) return nullptr;
-    ctx_->FetchTrajectory(winner, &best_);
+    const int local = winner - offset_;  // only the owner rank holds the winner's buffers
+    if (num_rolled_ == 0 || local < 0 || local >= num_rolled_) return nullptr;
+    ctx_->FetchTrajectory(local, &best_);
     best_valid_ = true;
   }
   return &best_;

@@ -48,6 +48,17 @@ class GpuSamplingPlanner : public RankedPlanner {
   void UpdateNominalPolicy(int horizon);
   void Rollouts(int num_trajectory, int horizon);
 
+  // Multi-GPU: one process per GPU, rank r rolls out global candidates [r*n, (r+1)*n) of num_trajectory_
+  // (noise is keyed on the GLOBAL index, so results do not depend on the rank count). After the local
+  // selection the planner calls `exchange` once per plan step with record = {best return, global index,
+  // nominal return} and the local winner's spline (np values); the callee all-gathers the records, picks
+  // the global winner (lowest return, ties by index), overwrites record and spline with the winner's
+  // (broadcast from its owner) and returns 0. The transport is the caller's: torch.distributed over
+  // RCCL/xGMI in bench.py, gloo in the CPU tests.
+  using ExchangeFn = int (*)(void* user, double record[3], double* spline, int np);
+  void SetSharding(int rank, int world, ExchangeFn exchange, void* user);
+  gpu::Context* context() { return ctx_.get(); }
+
   // ----- members (names as in the reference) ----- //
   mjModel* model = nullptr;
   const Task* task = nullptr;
@@ -75,6 +86,9 @@ class GpuSamplingPlanner : public RankedPlanner {
   void LoadCandidatePlan(int index, SamplingPolicy* out);
   int device_, precision_;
   std::uint64_t seed_;
+  int rank_ = 0, world_ = 1, offset_ = 0;
+  ExchangeFn exchange_ = nullptr;
+  void* exchange_user_ = nullptr;
   std::unique_ptr<gpu::Context> ctx_;
   std::vector<double> scores_;
   Trajectory best_;
