@@ -17,11 +17,32 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-def build(force=False):
-    so = os.path.join(_DIR, "liboracle.so")
+def build(force=False, fast=False):
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    so = os.path.join(_DIR, name)
     if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", _DIR, "-s", "liboracle.so"] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", _DIR, "-s", name] + (["-B"] if force else []))
     return so
+
+
+_FAST = None
+
+
+def rollout_batch_fast(pm, pt, state, time, mocap, N, H, P, interp, node_times, node_values, num_threads=1):
+    """orollout_batch from the -O3 -march=native build (timing only: bench.py's cpu_baseline). Returns total_return."""
+    global _FAST
+    if _FAST is None:
+        _FAST = C.CDLL(build(fast=True))
+        _FAST.orollout_batch.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, c_f64p,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_int, C.POINTER(OBatchOut)]
+    ret, fail = np.zeros(N), np.zeros(N, np.int32)
+    o = OBatchOut()
+    o.total_return, o.failure = as_f64p(ret), as_i32p(fail)
+    nt, nvv = _f(node_times), _f(node_values)
+    mc = None if mocap is None else as_f64p(_f(mocap))
+    _FAST.orollout_batch(pm.ptr, pt.ptr, as_f64p(_f(state)), float(time), mc, None, N, H, P, interp, as_f64p(nt),
+                         as_f64p(nvv), int(num_threads), C.byref(o))
+    return ret
 
 
 class OSpline(C.Structure):
