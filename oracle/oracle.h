@@ -113,6 +113,19 @@ int orollout_batch(const mjpcx_model* m, const mjpcx_task* task, const double* s
                    int P, int interp, const double* node_times, const double* node_values,
                    int num_threads, OBatchOut* out);
 
+/* ---------------- iLQG backward pass (mjpc/planners/ilqg/backward_pass.cc) ---------------- */
+/* box-constrained QP (MuJoCo mju_boxQP): returns the number of free dimensions, -1 if not PD */
+int oboxqp(double* res, double* R, int* index, const double* H, const double* g, int n, const double* lower,
+           const double* upper);
+/* One backward sweep over T steps at regularisation mu. Row-major layouts as in the reference:
+ * A[T*n*n] B[T*n*m] cx[T*n] cu[T*m] cxx[T*n*n] cxu[T*n*m] cuu[T*m*m]; out Vx[T*n] Vxx[T*n*n]
+ * K[T*m*n] (feedback_gain) du[T*m] (action_improvement) dV[2]. reg_type 0 control, 1 state-control,
+ * 2 value. Returns 1 on success, 0 if a step's Quu was not positive definite. */
+int oriccati(int n, int m, int T, double mu, int reg_type, int use_limits, const double* A, const double* B,
+             const double* cx, const double* cu, const double* cxx, const double* cxu, const double* cuu,
+             const double* actions, const double* action_limits, double* Vx, double* Vxx, double* K, double* du,
+             double* dV);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,8 +91,8 @@ def lib():
                                   c_f64p, C.c_int, c_f64p, c_f64p, C.c_double, C.c_double, C.POINTER(MjpcxTrajView)]
         L.orollout_batch.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, c_f64p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_int, C.POINTER(OBatchOut)]
-        if hasattr(L, "oriccati"):
-            L.oriccati.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [c_f64p] * 14
+        L.oriccati.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int] + [c_f64p] * 14
+        L.oboxqp.argtypes = [c_f64p, c_f64p, c_i32p, c_f64p, c_f64p, C.c_int, c_f64p, c_f64p]
         _LIB = L
     return _LIB
 
@@ -303,3 +303,22 @@ def philox(ctr, key):
     o = (C.c_uint32 * 4)()
     lib().ophilox4x32_10(c, k, o)
     return list(o)
+
+
+def riccati(n, m, T, mu, reg_type, use_limits, A, B, cx, cu, cxx, cxu, cuu, actions, limits):
+    """iLQGBackwardPass::Riccati at one regularisation value. Returns dict(ok, Vx, Vxx, K, du, dV)."""
+    Vx, Vxx, K, du, dV = np.zeros(T * n), np.zeros(T * n * n), np.zeros(T * m * n), np.zeros(T * m), np.zeros(2)
+    args = [_f(x).reshape(-1) for x in (A, B, cx, cu, cxx, cxu, cuu, actions, limits)]
+    ok = lib().oriccati(n, m, T, float(mu), int(reg_type), int(use_limits), *[as_f64p(a) for a in args],
+                        as_f64p(Vx), as_f64p(Vxx), as_f64p(K), as_f64p(du), as_f64p(dV))
+    return dict(ok=bool(ok), Vx=Vx.reshape(T, n), Vxx=Vxx.reshape(T, n, n), K=K.reshape(T, m, n), du=du.reshape(T, m), dV=dV)
+
+
+def boxqp(H, g, lower, upper, x0=None):
+    n = len(g)
+    res = np.zeros(n) if x0 is None else _f(x0).copy()
+    R = np.zeros(n * (n + 7))
+    idx = np.zeros(max(n, 1), np.int32)
+    nfree = lib().oboxqp(as_f64p(res), as_f64p(R), as_i32p(idx), as_f64p(_f(H).reshape(-1)), as_f64p(_f(g)), n,
+                         as_f64p(_f(lower)), as_f64p(_f(upper)))
+    return nfree, res, idx[:max(nfree, 0)]
