@@ -283,6 +283,43 @@ int mjpcx_fetch_trajectory(mjpcx_ctx* ctx, int candidate, mjpcx_traj_view* out);
  * candidate_policy[i].plan of the reference (sampling/planner.cc:534-543). */
 int mjpcx_fetch_spline(mjpcx_ctx* ctx, int candidate, double* node_values);
 
+/* ---- iLQG (mjpc/planners/ilqg, model_derivatives.cc, cost_derivatives.cc) -------------------------
+ * All arrays are host fp64, row-major, time-major as in the reference's std::vectors; dim_state = nq+nv,
+ * ndx = 2*nv (state-derivative dimension), nr = num_residual. */
+
+/* N candidate rollouts under a feedback policy built on a shared nominal trajectory of Tn steps.
+ *   mode 0: Trajectory::RolloutDiscrete with the index policy of iLQGPlanner::ActionRollouts
+ *           (ilqg/planner.cc:630-692): u = clamp(actions[t] + alpha_i * improvement[t] + gains[t] (x - states[t]))
+ *   mode 1: Trajectory::Rollout with iLQGPolicy::Action (ilqg/policy.cc:82-161), representation 0/1
+ *           (zero-order / linear interpolation over `times`), feedback scaled by alpha_i, applied iff use_state
+ *           (FeedbackRollouts, ilqg/planner.cc:695-724)
+ * gains: Tn x nu x ndx (feedback_gain), improvement: Tn x nu (action_improvement), alpha: N. */
+int mjpcx_rollout_feedback(mjpcx_ctx* ctx, int num_candidates, int horizon, int mode, int representation,
+                           int use_state, int nominal_horizon, const double* times, const double* states,
+                           const double* actions, const double* gains, const double* improvement,
+                           const double* alpha);
+
+/* ModelDerivatives::Compute (model_derivatives.cc:45-106) = Tn x mjd_transitionFD(eps, centered): A (Tn x ndx x ndx),
+ * B (Tn x ndx x nu) of the next state, C (Tn x nr x ndx), D (Tn x nr x nu) of the residual sensors. Any output may be NULL. */
+int mjpcx_transition_fd(mjpcx_ctx* ctx, int nominal_horizon, const double* times, const double* states,
+                        const double* actions, double eps, int centered, double* A, double* B, double* C, double* D);
+
+/* CostDerivatives::Compute (cost_derivatives.cc:112-230) with the context's current cost specification:
+ * residual (T x nr), C, D as above -> cx (T x ndx), cu (T x nu), cxx, cxu (T x ndx x nu), cuu. */
+int mjpcx_cost_derivatives(mjpcx_ctx* ctx, int T, const double* residual, const double* C, const double* D,
+                           double* cx, double* cu, double* cxx, double* cxu, double* cuu);
+
+/* One Riccati sweep at regularisation mu (iLQGBackwardPass::RiccatiStep for t = T-2..0, backward_pass.cc:65-250;
+ * reg_type 0 control / 1 state-control / 2 value; use_limits: box-QP on ctrlrange `limits` (nu x 2)).
+ * Outputs Vx (T x n), Vxx, K = feedback_gain (T x m x n), du = action_improvement (T x m), dV[2];
+ * *status = 1 on success, 0 if some Quu was not positive definite (the caller scales mu and retries,
+ * ilqg/planner.cc:429-520). n <= 48, m <= 16. kernel_ms (optional): HIP-event time of the kernel. */
+int mjpcx_backward_pass(mjpcx_ctx* ctx, int n, int m, int T, double mu, int reg_type, int use_limits,
+                        const double* A, const double* B, const double* cx, const double* cu, const double* cxx,
+                        const double* cxu, const double* cuu, const double* actions, const double* limits,
+                        double* Vx, double* Vxx, double* K, double* du, double* dV, int32_t* status,
+                        double* kernel_ms);
+
 /* ---- measurement --------------------------------------------------------------
  * HIP-event timing of the rollout kernel on the context's own stream.
  * mjpcx_timing_reset zeroes the accumulators; mjpcx_timing_read synchronises and

@@ -24,7 +24,8 @@ EXPORTS = [
     "mjpcx_create", "mjpcx_destroy", "mjpcx_create_error", "mjpcx_error_string", "mjpcx_last_error",
     "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_rollout_splines",
     "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
-    "mjpcx_fetch_spline", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
+    "mjpcx_fetch_spline", "mjpcx_rollout_feedback", "mjpcx_transition_fd", "mjpcx_cost_derivatives",
+    "mjpcx_backward_pass", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
     "mjpcx_device_buffer",
 ]
 
@@ -69,6 +70,11 @@ def lib():
         L.mjpcx_elite_moments.argtypes = [vp, C.c_int, c_i32p, c_f64p, c_f64p, C.POINTER(C.c_double)]
         L.mjpcx_fetch_trajectory.argtypes = [vp, C.c_int, C.POINTER(MjpcxTrajView)]
         L.mjpcx_fetch_spline.argtypes = [vp, C.c_int, c_f64p]
+        L.mjpcx_rollout_feedback.argtypes = [vp] + [C.c_int] * 6 + [c_f64p] * 6
+        L.mjpcx_transition_fd.argtypes = [vp, C.c_int, c_f64p, c_f64p, c_f64p, C.c_double, C.c_int, c_f64p, c_f64p, c_f64p, c_f64p]
+        L.mjpcx_cost_derivatives.argtypes = [vp, C.c_int] + [c_f64p] * 8
+        L.mjpcx_backward_pass.argtypes = ([vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int] + [c_f64p] * 14 +
+                                          [c_i32p, C.POINTER(C.c_double)])
         L.mjpcx_timing_reset.argtypes = [vp]
         L.mjpcx_timing_read.argtypes = [vp, c_f64p, C.POINTER(C.c_int64)]
         L.mjpcx_algorithmic_bytes.restype = C.c_int64
@@ -231,6 +237,42 @@ class Context:
         out = np.zeros((self.P, self.nu))
         self._chk(lib().mjpcx_fetch_spline(self.handle, int(candidate), as_f64p(out)))
         return out
+
+    # ---- iLQG
+    def rollout_feedback(self, horizon, mode, representation, use_state, times, states, actions, gains, improvement, alpha):
+        arrs = [_f(x).reshape(-1) for x in (times, states, actions, gains, improvement, alpha)]
+        N, Tn = arrs[5].size, arrs[0].size
+        self._chk(lib().mjpcx_rollout_feedback(self.handle, N, int(horizon), int(mode), int(representation), int(use_state),
+                                               Tn, *[as_f64p(a) for a in arrs]))
+        self.N, self.H, self.P = N, int(horizon), 0
+
+    def transition_fd(self, times, states, actions, eps=1e-6, centered=0):
+        T, ndx, nu, nr = len(times), 2 * self.nv, self.nu, self.num_residual
+        A, B, Cm, D = np.zeros((T, ndx, ndx)), np.zeros((T, ndx, nu)), np.zeros((T, nr, ndx)), np.zeros((T, nr, nu))
+        self._chk(lib().mjpcx_transition_fd(self.handle, T, as_f64p(_f(times)), as_f64p(_f(states).reshape(-1)),
+                                            as_f64p(_f(actions).reshape(-1)), float(eps), int(centered), as_f64p(A),
+                                            as_f64p(B), as_f64p(Cm), as_f64p(D)))
+        return A, B, Cm, D
+
+    def cost_derivatives(self, residual, Cm, D):
+        T, ndx, nu = residual.shape[0], 2 * self.nv, self.nu
+        cx, cu = np.zeros((T, ndx)), np.zeros((T, nu))
+        cxx, cxu, cuu = np.zeros((T, ndx, ndx)), np.zeros((T, ndx, nu)), np.zeros((T, nu, nu))
+        self._chk(lib().mjpcx_cost_derivatives(self.handle, T, as_f64p(_f(residual).reshape(-1)), as_f64p(_f(Cm).reshape(-1)),
+                                               as_f64p(_f(D).reshape(-1)), as_f64p(cx), as_f64p(cu), as_f64p(cxx),
+                                               as_f64p(cxu), as_f64p(cuu)))
+        return cx, cu, cxx, cxu, cuu
+
+    def backward_pass(self, mu, reg_type, use_limits, A, B, cx, cu, cxx, cxu, cuu, actions, limits):
+        T, n, m = A.shape[0], A.shape[1], B.shape[2]
+        Vx, Vxx, K, du, dV = np.zeros((T, n)), np.zeros((T, n, n)), np.zeros((T, m, n)), np.zeros((T, m)), np.zeros(2)
+        st = np.zeros(1, np.int32)
+        ms = C.c_double()
+        args = [as_f64p(_f(x).reshape(-1)) for x in (A, B, cx, cu, cxx, cxu, cuu, actions, limits)]
+        self._chk(lib().mjpcx_backward_pass(self.handle, n, m, T, float(mu), int(reg_type), int(use_limits), *args,
+                                            as_f64p(Vx), as_f64p(Vxx), as_f64p(K), as_f64p(du), as_f64p(dV), as_i32p(st),
+                                            C.byref(ms)))
+        return dict(ok=bool(st[0]), Vx=Vx, Vxx=Vxx, K=K, du=du, dV=dV, kernel_ms=ms.value)
 
     def timing_reset(self):
         self._chk(lib().mjpcx_timing_reset(self.handle))

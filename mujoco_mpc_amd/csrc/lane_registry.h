@@ -5,6 +5,7 @@
 #pragma once
 #include "../../include/mjpcx.h"
 #include "generated/static_models.h"
+#include "ilqg_kernels.h"
 #include "rollout_lane.h"
 
 namespace mjpcx {
@@ -34,9 +35,29 @@ hipError_t launch_lane_impl(const LaneModel<T>& m, const LaneTask<T>& tk, const 
   return hipGetLastError();
 }
 
+template <class TP, class TK, typename T, class MC>
+hipError_t launch_feedback_impl(const LaneModel<T>& m, const LaneTask<T>& tk, const RolloutArgs<T>& a,
+                                const FeedbackArgs<T>& fb, hipStream_t s) {
+  static_assert(sizeof(LaneModel<T>) + sizeof(LaneTask<T>) + sizeof(RolloutArgs<T>) + sizeof(FeedbackArgs<T>) <= 4096, "kernarg");
+  const int blocks = (a.N + 63) / 64;
+  const size_t shmem = (size_t)fb.Tn * (1 + 2 * TP::NV + 2 * TP::NU + TP::NU * 2 * TP::NV) * sizeof(T);
+  hipLaunchKernelGGL((rollout_feedback_kernel<TP, TK, T, MC>), dim3(blocks), dim3(64), shmem, s, m, tk, a, fb);
+  return hipGetLastError();
+}
+template <class TP, class TK, typename T, class MC>
+hipError_t launch_fd_impl(const LaneModel<T>& m, const LaneTask<T>& tk, const FdArgs<T>& f, hipStream_t s) {
+  const int items = f.Tn * fd_columns<TP>();
+  hipLaunchKernelGGL((transition_fd_kernel<TP, TK, T, MC>), dim3((items + 63) / 64), dim3(64), 0, s, m, tk, f);
+  return hipGetLastError();
+}
+
 #define MJPCX_DECLARE_STATIC(FN)                                                                             \
   hipError_t FN##_f64(const LaneModel<double>&, const LaneTask<double>&, const RolloutArgs<double>&, hipStream_t); \
-  hipError_t FN##_f32(const LaneModel<float>&, const LaneTask<float>&, const RolloutArgs<float>&, hipStream_t);
+  hipError_t FN##_f32(const LaneModel<float>&, const LaneTask<float>&, const RolloutArgs<float>&, hipStream_t); \
+  hipError_t FN##_fb_f64(const LaneModel<double>&, const LaneTask<double>&, const RolloutArgs<double>&, const FeedbackArgs<double>&, hipStream_t); \
+  hipError_t FN##_fb_f32(const LaneModel<float>&, const LaneTask<float>&, const RolloutArgs<float>&, const FeedbackArgs<float>&, hipStream_t); \
+  hipError_t FN##_fd_f64(const LaneModel<double>&, const LaneTask<double>&, const FdArgs<double>&, hipStream_t); \
+  hipError_t FN##_fd_f32(const LaneModel<float>&, const LaneTask<float>&, const FdArgs<float>&, hipStream_t);
 MJPCX_DECLARE_STATIC(launch_static_cartpole)
 MJPCX_DECLARE_STATIC(launch_static_particle)
 MJPCX_DECLARE_STATIC(launch_static_particle_copy)

@@ -17,6 +17,7 @@
 #include "../../include/mjpcx.h"
 #include "rollout_lane.h"
 #include "lane_registry.h"
+#include "ilqg_dense.h"
 
 using namespace mjpcx;
 
@@ -60,11 +61,25 @@ struct KernelEntry {
   const LaneModel<double>* static_model;  // non-null: instantiation specialised for exactly these constants
   hipError_t (*launch64)(const LaneModel<double>&, const LaneTask<double>&, const RolloutArgs<double>&, hipStream_t);
   hipError_t (*launch32)(const LaneModel<float>&, const LaneTask<float>&, const RolloutArgs<float>&, hipStream_t);
+  hipError_t (*feedback64)(const LaneModel<double>&, const LaneTask<double>&, const RolloutArgs<double>&, const FeedbackArgs<double>&, hipStream_t);
+  hipError_t (*feedback32)(const LaneModel<float>&, const LaneTask<float>&, const RolloutArgs<float>&, const FeedbackArgs<float>&, hipStream_t);
+  hipError_t (*fd64)(const LaneModel<double>&, const LaneTask<double>&, const FdArgs<double>&, hipStream_t);
+  hipError_t (*fd32)(const LaneModel<float>&, const LaneTask<float>&, const FdArgs<float>&, hipStream_t);
 };
+template <class TP, class TK, typename T>
+hipError_t launch_feedback(const LaneModel<T>& m, const LaneTask<T>& tk, const RolloutArgs<T>& a, const FeedbackArgs<T>& fb, hipStream_t s) {
+  return launch_feedback_impl<TP, TK, T, RuntimeModel>(m, tk, a, fb, s);
+}
+template <class TP, class TK, typename T>
+hipError_t launch_fd(const LaneModel<T>& m, const LaneTask<T>& tk, const FdArgs<T>& f, hipStream_t s) {
+  return launch_fd_impl<TP, TK, T, RuntimeModel>(m, tk, f, s);
+}
 #define MJPCX_LANE_ENTRY(TP, TK) \
-  { "rollout_lane<" #TP "," #TK ">", topo_key<TP>(), task_key<TK>(), nullptr, &launch_lane<TP, TK, double>, &launch_lane<TP, TK, float> }
+  { "rollout_lane<" #TP "," #TK ">", topo_key<TP>(), task_key<TK>(), nullptr, &launch_lane<TP, TK, double>, &launch_lane<TP, TK, float>, \
+    &launch_feedback<TP, TK, double>, &launch_feedback<TP, TK, float>, &launch_fd<TP, TK, double>, &launch_fd<TP, TK, float> }
 #define MJPCX_STATIC_ENTRY(TP, TK, GEN, FN) \
-  { "rollout_lane<" #TP "," #TK "," #GEN ">", topo_key<TP>(), task_key<TK>(), &kHost##GEN, &FN##_f64, &FN##_f32 }
+  { "rollout_lane<" #TP "," #TK "," #GEN ">", topo_key<TP>(), task_key<TK>(), &kHost##GEN, &FN##_f64, &FN##_f32, \
+    &FN##_fb_f64, &FN##_fb_f32, &FN##_fd_f64, &FN##_fd_f32 }
 const LaneModel<double> kHostStaticCartpole = make_Cartpole<double>();
 const LaneModel<double> kHostStaticParticle = make_Particle<double>();
 // specialised entries first: mjpcx_create takes the first entry whose key (and constants) match
@@ -279,7 +294,8 @@ struct mjpcx_ctx {
   std::string last_error;
   // model/task dims
   int nq = 0, nv = 0, nu = 0, na = 0, nmocap = 0, nr = 0, nterm = 0, ntrace = 0, nparam = 0;
-  std::vector<int> num_norm_parameter;
+  std::vector<int> num_norm_parameter, dim_norm_residual;
+  std::vector<int> ctrllimited;
   std::vector<double> ctrlrange;
   // host mirrors of the device structs (both precisions kept; only one uploaded)
   LaneModel<double> hm64{}; LaneModel<float> hm32{};
@@ -294,7 +310,7 @@ struct mjpcx_ctx {
   // pinned + device-mapped result record of mjpcx_best
   void* best_host = nullptr; void* best_dev = nullptr; size_t best_cap = 0;
   // rollout buffers
-  DevBuf d_nodes, d_in_nodes;
+  DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out;
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
   int N = 0, H = 0, P = 0;  // shape of the last rollout
   bool have_rollout = false;
@@ -629,6 +645,8 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
   c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap;
   c->nr = t->num_residual; c->nterm = t->num_term; c->ntrace = t->num_trace; c->nparam = t->num_parameter;
   c->num_norm_parameter.assign(t->num_norm_parameter, t->num_norm_parameter + t->num_term);
+  c->dim_norm_residual.assign(t->dim_norm_residual, t->dim_norm_residual + t->num_term);
+  c->ctrllimited.assign(m->actuator_ctrllimited, m->actuator_ctrllimited + m->nu);
   c->ctrlrange.assign(m->actuator_ctrlrange, m->actuator_ctrlrange + 2 * m->nu);
   fill_model(c->hm64, m);
   fill_model(c->hm32, m);
@@ -660,7 +678,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
     sl.dev.release();
   }
   if (c->best_host) (void)hipHostFree(c->best_host);
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();
@@ -929,6 +947,205 @@ int mjpcx_device_buffer(mjpcx_ctx* c, int which, void** ptr, size_t* bytes) {
   if (which == 0) { *ptr = c->d_ret.p; if (bytes) *bytes = (size_t)c->N * 8; }
   else if (which == 1) { *ptr = c->d_fail.p; if (bytes) *bytes = (size_t)c->N * 4; }
   else return fail(c, MJPCX_EINVAL, "unknown buffer");
+  return MJPCX_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ iLQG entry points
+namespace {
+// uploads a list of host fp64 arrays into one device buffer, converting to T; returns device pointers
+template <typename T>
+int upload_arrays(mjpcx_ctx* c, DevBuf& buf, const std::vector<std::pair<const double*, size_t>>& arrays, std::vector<T*>* out) {
+  size_t total = 0;
+  for (auto& a : arrays) total += (a.second + 1) & ~(size_t)1;
+  HIPCHK(c, buf.reserve(total * sizeof(T)));
+  std::vector<T> host(total);
+  size_t off = 0;
+  out->clear();
+  for (auto& a : arrays) {
+    for (size_t i = 0; i < a.second; i++) host[off + i] = (T)a.first[i];
+    out->push_back((T*)buf.p + off);
+    off += (a.second + 1) & ~(size_t)1;
+  }
+  HIPCHK(c, hipMemcpyAsync(buf.p, host.data(), total * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+
+template <typename T>
+int do_feedback(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
+                const double* states, const double* actions, const double* gains, const double* improvement,
+                const double* alpha) {
+  int rc;
+  if ((rc = reserve_rollout(c, N, H, 1)) != MJPCX_OK) return rc;
+  const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu;
+  std::vector<T*> d;
+  if ((rc = upload_arrays<T>(c, c->d_ilqg, {{times, (size_t)Tn}, {states, Tn * ds}, {actions, Tn * nu},
+                                            {gains, Tn * nu * ndx}, {improvement, Tn * nu}, {alpha, (size_t)N}}, &d)) != MJPCX_OK)
+    return rc;
+  RolloutArgs<T> a{};
+  a.N = N; a.H = H; a.P = 0; a.interp = 0;
+  a.nodes = (T*)c->d_nodes.p; a.noise.mode = -1;
+  a.states = (T*)c->d_states.p; a.actions = (T*)c->d_actions.p; a.times = (T*)c->d_times.p;
+  a.residual = (T*)c->d_residual.p; a.costs = (T*)c->d_costs.p; a.trace = (T*)c->d_trace.p;
+  a.total_return = (double*)c->d_ret.p; a.failure = (int*)c->d_fail.p;
+  FeedbackArgs<T> fb{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state};
+  hipError_t le;
+  if constexpr (sizeof(T) == 8) le = c->kernel->feedback64(c->hm64, c->ht64, a, fb, c->stream);
+  else { convert_task(c->ht32, c->ht64); le = c->kernel->feedback32(c->hm32, c->ht32, a, fb, c->stream); }
+  if (le != hipSuccess) return fail(c, MJPCX_EDEVICE, std::string("feedback kernel launch: ") + hipGetErrorString(le));
+  c->N = N; c->H = H; c->P = 0;
+  c->have_rollout = true;
+  return MJPCX_OK;
+}
+
+template <typename T>
+int do_transition_fd(mjpcx_ctx* c, int Tn, const double* times, const double* states, const double* actions, double eps,
+                     int centered, double* A, double* B, double* C, double* D) {
+  int rc;
+  const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu, nr = c->nr;
+  const size_t nc = 1 + 2 * (ndx + nu);
+  std::vector<T*> d;
+  std::vector<double> cr(c->ctrlrange);
+  if ((rc = upload_arrays<T>(c, c->d_ilqg, {{times, (size_t)Tn}, {states, Tn * ds}, {actions, Tn * nu}, {cr.data(), 2 * nu}}, &d)) != MJPCX_OK)
+    return rc;
+  // outputs: next [Tn][nc][ndx] (T), sensor [Tn][nc][nr] (T), ctrllimited (int), then A,B,C,D (f64)
+  const size_t off_sensor = (Tn * nc * ndx * sizeof(T) + 15) & ~(size_t)15;
+  const size_t off_lim = (off_sensor + Tn * nc * nr * sizeof(T) + 15) & ~(size_t)15;
+  const size_t off_A = (off_lim + nu * sizeof(int) + 15) & ~(size_t)15;
+  const size_t nA = Tn * ndx * ndx, nB = Tn * ndx * nu, nC = Tn * nr * ndx, nD = Tn * nr * nu;
+  HIPCHK(c, c->d_ilqg_out.reserve(off_A + (nA + nB + nC + nD) * 8));
+  char* base = (char*)c->d_ilqg_out.p;
+  HIPCHK(c, hipMemcpyAsync(base + off_lim, c->ctrllimited.data(), nu * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  FdArgs<T> f{d[0], d[1], d[2], Tn, (T)eps, (T*)base, (T*)(base + off_sensor)};
+  hipError_t le;
+  if constexpr (sizeof(T) == 8) le = c->kernel->fd64(c->hm64, c->ht64, f, c->stream);
+  else { convert_task(c->ht32, c->ht64); le = c->kernel->fd32(c->hm32, c->ht32, f, c->stream); }
+  if (le != hipSuccess) return fail(c, MJPCX_EDEVICE, std::string("fd kernel launch: ") + hipGetErrorString(le));
+  double* dA = (double*)(base + off_A);
+  double *dB = dA + nA, *dC = dB + nB, *dD = dC + nC;
+  const int total = (int)(Tn * (ndx + nr) * (ndx + nu));
+  hipLaunchKernelGGL((fd_assemble_kernel<T>), dim3(std::min((total + 255) / 256, 1024)), dim3(256), 0, c->stream,
+                     (const T*)base, (const T*)(base + off_sensor), (const T*)d[2], (const T*)d[3],
+                     (const int*)(base + off_lim), Tn, (int)ndx, (int)nu, (int)nr, (T)eps, centered, dA, dB, dC, dD);
+  HIPCHK(c, hipGetLastError());
+  if (A) HIPCHK(c, hipMemcpyAsync(A, dA, nA * 8, hipMemcpyDeviceToHost, c->stream));
+  if (B) HIPCHK(c, hipMemcpyAsync(B, dB, nB * 8, hipMemcpyDeviceToHost, c->stream));
+  if (C) HIPCHK(c, hipMemcpyAsync(C, dC, nC * 8, hipMemcpyDeviceToHost, c->stream));
+  if (D) HIPCHK(c, hipMemcpyAsync(D, dD, nD * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mjpcx_rollout_feedback(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn,
+                           const double* times, const double* states, const double* actions, const double* gains,
+                           const double* improvement, const double* alpha) {
+  if (!c || !times || !states || !actions || !gains || !improvement || !alpha) return fail(c, MJPCX_EINVAL, "null argument");
+  if (N < 1 || H < 1 || Tn < 1) return fail(c, MJPCX_EINVAL, "N, H and Tn must be >= 1");
+  if (mode == 0 && H > Tn) return fail(c, MJPCX_EINVAL, "index policy needs a nominal trajectory at least as long as the horizon");
+  if (mode != 0 && mode != 1) return fail(c, MJPCX_EINVAL, "unknown feedback policy mode");
+  if (mode == 1 && representation != 0 && representation != 1) return fail(c, MJPCX_EUNSUPPORTED, "only zero-order / linear iLQG policy representations are implemented");
+  const size_t shmem = (size_t)Tn * (1 + 2 * c->nv + 2 * c->nu + c->nu * 2 * c->nv) * esize(c);
+  if (shmem > 120 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "nominal trajectory too large for the LDS stage");
+  HIPCHK(c, hipSetDevice(c->device));
+  return c->precision == 64 ? do_feedback<double>(c, N, H, mode, representation, use_state, Tn, times, states, actions, gains, improvement, alpha)
+                            : do_feedback<float>(c, N, H, mode, representation, use_state, Tn, times, states, actions, gains, improvement, alpha);
+}
+
+int mjpcx_transition_fd(mjpcx_ctx* c, int Tn, const double* times, const double* states, const double* actions, double eps,
+                        int centered, double* A, double* B, double* C, double* D) {
+  if (!c || !times || !states || !actions) return fail(c, MJPCX_EINVAL, "null argument");
+  if (Tn < 1 || !(eps > 0)) return fail(c, MJPCX_EINVAL, "bad horizon or epsilon");
+  HIPCHK(c, hipSetDevice(c->device));
+  return c->precision == 64 ? do_transition_fd<double>(c, Tn, times, states, actions, eps, centered, A, B, C, D)
+                            : do_transition_fd<float>(c, Tn, times, states, actions, eps, centered, A, B, C, D);
+}
+
+int mjpcx_cost_derivatives(mjpcx_ctx* c, int T, const double* residual, const double* C, const double* D, double* cx,
+                           double* cu, double* cxx, double* cxu, double* cuu) {
+  if (!c || !residual || !C || !D || !cx || !cu || !cxx || !cxu || !cuu) return fail(c, MJPCX_EINVAL, "null argument");
+  if (T < 1) return fail(c, MJPCX_EINVAL, "T must be >= 1");
+  if (c->nterm > 32) return fail(c, MJPCX_EUNSUPPORTED, "more than 32 cost terms");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t ndx = 2 * (size_t)c->nv, nu = c->nu, nr = c->nr;
+  CostSpec cs{};
+  cs.num_term = c->nterm; cs.num_residual = c->nr; cs.risk = c->ht64.risk;
+  for (int k = 0; k < c->nterm; k++) {
+    if (c->dim_norm_residual[k] > 32) return fail(c, MJPCX_EUNSUPPORTED, "cost term wider than 32 residuals");
+    cs.dim[k] = c->dim_norm_residual[k]; cs.norm[k] = c->ht64.norm[k]; cs.weight[k] = c->ht64.weight[k];
+    cs.p[k] = c->ht64.norm_p[k]; cs.q[k] = c->ht64.norm_q[k];
+  }
+  std::vector<double*> d;
+  int rc;
+  if ((rc = upload_arrays<double>(c, c->d_ilqg, {{residual, T * nr}, {C, T * nr * ndx}, {D, T * nr * nu}}, &d)) != MJPCX_OK) return rc;
+  const size_t n_out = T * (ndx + nu + ndx * ndx + ndx * nu + nu * nu);
+  HIPCHK(c, c->d_ilqg_out.reserve(n_out * 8));
+  double* o = (double*)c->d_ilqg_out.p;
+  double *dcx = o, *dcu = dcx + T * ndx, *dcxx = dcu + T * nu, *dcxu = dcxx + T * ndx * ndx, *dcuu = dcxu + T * ndx * nu;
+  const size_t shmem = (32 + 32 * 32 + 32 * ndx + 32 * nu) * 8;
+  hipLaunchKernelGGL(cost_derivatives_kernel, dim3(T), dim3(64), shmem, c->stream, cs, (const double*)d[0], (const double*)d[1],
+                     (const double*)d[2], T, (int)ndx, (int)nu, dcx, dcu, dcxx, dcxu, dcuu);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(cx, dcx, T * ndx * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cu, dcu, T * nu * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cxx, dcxx, T * ndx * ndx * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cxu, dcxu, T * ndx * nu * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cuu, dcuu, T * nu * nu * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+
+int mjpcx_backward_pass(mjpcx_ctx* c, int n, int m, int T, double mu, int reg_type, int use_limits, const double* A,
+                        const double* B, const double* cx, const double* cu, const double* cxx, const double* cxu,
+                        const double* cuu, const double* actions, const double* limits, double* Vx, double* Vxx, double* K,
+                        double* du, double* dV, int32_t* status, double* kernel_ms) {
+  if (!c || !A || !B || !cx || !cu || !cxx || !cxu || !cuu || !actions || !limits || !Vx || !Vxx || !K || !du || !dV || !status)
+    return fail(c, MJPCX_EINVAL, "null argument");
+  if (n < 1 || n > 48 || m < 1 || m > 16 || T < 2) return fail(c, MJPCX_EUNSUPPORTED, "backward pass kernel covers 1 <= n <= 48, 1 <= m <= 16, T >= 2");
+  if (reg_type < 0 || reg_type > 2) return fail(c, MJPCX_EINVAL, "unknown regularization type");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<double*> d;
+  int rc;
+  const size_t sn = n, sm = m, sT = T;
+  if ((rc = upload_arrays<double>(c, c->d_ilqg, {{A, sT * sn * sn}, {B, sT * sn * sm}, {cx, sT * sn}, {cu, sT * sm}, {cxx, sT * sn * sn},
+                                                 {cxu, sT * sn * sm}, {cuu, sT * sm * sm}, {actions, sT * sm}, {limits, 2 * sm}}, &d)) != MJPCX_OK)
+    return rc;
+  const size_t n_out = sT * (sn + sn * sn + sm * sn + sm) + 2 + 2;
+  HIPCHK(c, c->d_ilqg_out.reserve(n_out * 8));
+  double* o = (double*)c->d_ilqg_out.p;
+  BackwardArgs a{};
+  a.n = n; a.m = m; a.T = T; a.mu = mu; a.reg_type = reg_type; a.use_limits = use_limits;
+  a.A = d[0]; a.B = d[1]; a.cx = d[2]; a.cu = d[3]; a.cxx = d[4]; a.cxu = d[5]; a.cuu = d[6]; a.actions = d[7]; a.limits = d[8];
+  a.Vx = o; a.Vxx = a.Vx + sT * sn; a.K = a.Vxx + sT * sn * sn; a.du = a.K + sT * sm * sn; a.dV = a.du + sT * sm;
+  a.status = (int*)(a.dV + 2);
+  const int NP = (n + 15) & ~15;
+  const size_t lds = (size_t)(5 * NP * NP + 2 * NP + 6 * NP * 16 + 5 * 256 + 16 * 23 + 16 * 12) * 8;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipFuncSetAttribute((const void*)backward_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  hipLaunchKernelGGL(backward_pass_kernel, dim3(1), dim3(64), lds, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipMemcpyAsync(Vx, a.Vx, sT * sn * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(Vxx, a.Vxx, sT * sn * sn * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(K, a.K, sT * sm * sn * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(du, a.du, sT * sm * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dV, a.dV, 16, hipMemcpyDeviceToHost, c->stream));
+  int st = 0;
+  HIPCHK(c, hipMemcpyAsync(&st, a.status, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *status = st;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (kernel_ms) *kernel_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return MJPCX_OK;
 }
 

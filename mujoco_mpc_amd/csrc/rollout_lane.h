@@ -128,6 +128,460 @@ __device__ __forceinline__ T cost_terms(const T (&r)[TK::NR], const LaneTask<T>&
   return ((tk.weight[K] * norm_value<T, TK::term_dim(K)>(&r[TK::term_off(K)], tk.norm[K], tk.norm_p[K], tk.norm_q[K])) + ... + T(0));
 }
 
+// ------------------------------------------------------------------ the per-candidate step engine
+// mj_forward (position, velocity, actuation, acceleration, constraint stages) for ONE candidate held in
+// the calling lane's registers. Shared by the rollout kernels, the finite-difference derivative kernel
+// and anything else that needs "one MuJoCo step" of a registered small-model topology.
+//   out: qacc, qfrc (= qfrc_smooth), qfrc_c (= qfrc_constraint), M (lower triangle), site_xpos
+template <class TP, typename T, class MODEL>
+__device__ __forceinline__ void lane_forward(const MODEL& m, const LaneTask<T>& tk, const T (&qpos)[TP::NV],
+                                             const T (&qvel)[TP::NV], const T (&ctrl)[TP::NU], T (&qacc)[TP::NV],
+                                             T (&qfrc)[TP::NV], T (&qfrc_c)[TP::NV], T (&M)[TP::NV][TP::NV],
+                                             T (&site_xpos)[TP::NSITE > 0 ? TP::NSITE : 1][3]) {
+  constexpr int NB = TP::NB, NV = TP::NV, NU = TP::NU, NS = TP::NSITE;
+  const T h = m.timestep;
+  // ================= position stage: kinematics
+  T xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3], ximat[NB][9];
+  T xanchor[NV][3], xaxis[NV][3];
+#pragma unroll
+  for (int b = 1; b < NB; b++) {
+    T pos[3], quat[4];
+    if (TP::mocap(b) != 15) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) pos[c] = tk.mocap_pos[TP::mocap(b)][c];
+#pragma unroll
+      for (int c = 0; c < 4; c++) quat[c] = tk.mocap_quat[TP::mocap(b)][c];
+    } else {
+      if (TP::parent(b) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) pos[c] = m.body_pos[b][c];
+#pragma unroll
+        for (int c = 0; c < 4; c++) quat[c] = m.body_quat[b][c];
+      } else {
+        const int p = TP::parent(b);
+        T bp[3] = {m.body_pos[b][0], m.body_pos[b][1], m.body_pos[b][2]};
+        T bq[4] = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
+        mat_vec(pos, xmat[p], bp);
+#pragma unroll
+        for (int c = 0; c < 3; c++) pos[c] += xpos[p][c];
+        quat_mul(quat, xquat[p], bq);
+      }
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        if (TP::jbody(j) == b) {
+          T R[9];
+          quat_to_mat(R, quat);
+          T jp[3] = {m.jnt_pos[j][0], m.jnt_pos[j][1], m.jnt_pos[j][2]};
+          T ja[3] = {m.jnt_axis[j][0], m.jnt_axis[j][1], m.jnt_axis[j][2]};
+          mat_vec(xanchor[j], R, jp);
+#pragma unroll
+          for (int c = 0; c < 3; c++) xanchor[j][c] += pos[c];
+          mat_vec(xaxis[j], R, ja);
+          const T dq = qpos[j] - m.qpos0[j];
+          if (TP::jtype(j) == kJntSlide) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) pos[c] += xaxis[j][c] * dq;
+          } else {  // hinge
+            T sn, cs;
+            sincos_t(T(0.5) * dq, sn, cs);
+            T ql[4] = {cs, ja[0] * sn, ja[1] * sn, ja[2] * sn};
+            quat_mul(quat, quat, ql);
+            T R2[9], v[3];
+            quat_to_mat(R2, quat);
+            mat_vec(v, R2, jp);
+#pragma unroll
+            for (int c = 0; c < 3; c++) pos[c] = xanchor[j][c] - v[c];
+          }
+        }
+      }
+    }
+    // mj_kinematics renormalises every body quaternion to stop drift of FREE/BALL qpos quaternions.
+    // Here only mocap poses (user input) can be unnormalised: a slide/hinge body's quaternion is a
+    // product of unit quaternions (model constants and axis-angle factors), unit to rounding, so
+    // the sqrt + divide on the per-step dependent chain is skipped for those bodies.
+    if (TP::mocap(b) != 15) normalize4(quat);
+#pragma unroll
+    for (int c = 0; c < 3; c++) xpos[b][c] = pos[c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) xquat[b][c] = quat[c];
+    quat_to_mat(xmat[b], quat);
+    T ip[3] = {m.body_ipos[b][0], m.body_ipos[b][1], m.body_ipos[b][2]};
+    T iq[4] = {m.body_iquat[b][0], m.body_iquat[b][1], m.body_iquat[b][2], m.body_iquat[b][3]};
+    T v[3], q2[4];
+    mat_vec(v, xmat[b], ip);
+#pragma unroll
+    for (int c = 0; c < 3; c++) xipos[b][c] = pos[c] + v[c];
+    quat_mul(q2, quat, iq);
+    quat_to_mat(ximat[b], q2);
+  }
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int b = TP::siteb(s);
+    T sp[3] = {m.site_pos[s][0], m.site_pos[s][1], m.site_pos[s][2]};
+    if (b == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) site_xpos[s][c] = sp[c];
+    } else {
+      T v[3];
+      mat_vec(v, xmat[b], sp);
+#pragma unroll
+      for (int c = 0; c < 3; c++) site_xpos[s][c] = xpos[b][c] + v[c];
+    }
+  }
+
+  // ================= comPos: subtree com of each moving tree, cinert, cdof
+  T com[NB][3];  // only entries of moving roots are used
+#pragma unroll
+  for (int r = 1; r < NB; r++) {
+    if (TP::parent(r) == 0 && TP::moves(r)) {
+      T acc[3] = {0, 0, 0};
+#pragma unroll
+      for (int b = 1; b < NB; b++)
+        if (TP::root(b) == r) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) acc[c] += m.body_mass[b] * xipos[b][c];
+        }
+#pragma unroll
+      for (int c = 0; c < 3; c++) com[r][c] = acc[c] * m.root_invmass[r];
+    }
+  }
+  T cinert[NB][10];
+#pragma unroll
+  for (int b = 1; b < NB; b++) {
+    if (TP::moves(b)) {
+      T off[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) off[c] = xipos[b][c] - com[TP::root(b)][c];
+      T bi[3] = {m.body_inertia[b][0], m.body_inertia[b][1], m.body_inertia[b][2]};
+      inert_com(cinert[b], bi, ximat[b], off, m.body_mass[b]);
+    }
+  }
+  T cdof[NV][6];
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    if (TP::jtype(j) == kJntSlide) {
+      cdof[j][0] = cdof[j][1] = cdof[j][2] = 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) cdof[j][3 + c] = xaxis[j][c];
+    } else {
+      T off[3], cr[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) off[c] = com[TP::root(TP::jbody(j))][c] - xanchor[j][c];
+      cross3(cr, xaxis[j], off);
+#pragma unroll
+      for (int c = 0; c < 3; c++) { cdof[j][c] = xaxis[j][c]; cdof[j][3 + c] = cr[c]; }
+    }
+  }
+
+  // ================= CRB -> M (lower triangle, static sparsity), LDL' factor
+  T crb[NB][10];
+#pragma unroll
+  for (int b = 1; b < NB; b++)
+    if (TP::moves(b)) {
+#pragma unroll
+      for (int c = 0; c < 10; c++) crb[b][c] = cinert[b][c];
+    }
+#pragma unroll
+  for (int b = NB - 1; b >= 1; b--)
+    if (TP::moves(b) && TP::parent(b) != 0 && TP::moves(TP::parent(b))) {
+#pragma unroll
+      for (int c = 0; c < 10; c++) crb[TP::parent(b)][c] += crb[b][c];
+    }
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    T buf[6];
+    mul_inert_vec(buf, crb[TP::jbody(i)], cdof[i]);
+    M[i][i] = m.dof_armature[i] + dot6(cdof[i], buf);
+#pragma unroll
+    for (int j = 0; j < i; j++) M[i][j] = TP::dof_ancestor(i, j) ? dot6(cdof[j], buf) : T(0);
+  }
+  // M = L D L' (unit lower L, stored in Lm below the diagonal; Dinv = 1/D)
+  T Lm[NV][NV], Dinv[NV];
+  ldl_factor<NV>(Lm, Dinv, M);
+
+  // ================= velocity stage: comVel, passive, RNE bias
+  T cvel[NB][6], cdof_dot[NV][6];
+#pragma unroll
+  for (int b = 1; b < NB; b++) {
+    if (!TP::moves(b)) continue;
+    T v[6];
+    if (TP::parent(b) == 0 || !TP::moves(TP::parent(b))) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) v[c] = 0;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; c++) v[c] = cvel[TP::parent(b)][c];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+      if (TP::jbody(j) == b) {
+        cross_motion(cdof_dot[j], v, cdof[j]);
+#pragma unroll
+        for (int c = 0; c < 6; c++) v[c] += cdof[j][c] * qvel[j];
+      }
+#pragma unroll
+    for (int c = 0; c < 6; c++) cvel[b][c] = v[c];
+  }
+  const bool passive_on = !(m.disableflags & (1 << 5));
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    T f = 0;
+    if (passive_on) f = -m.jnt_stiffness[j] * (qpos[j] - m.qpos_spring[j]) - m.dof_damping[j] * qvel[j];
+    qfrc[j] = f;
+  }
+  {
+    T cfrc[NB][6];
+    T g[3] = {0, 0, 0};
+    if (!(m.disableflags & (1 << 6))) { g[0] = -m.gravity[0]; g[1] = -m.gravity[1]; g[2] = -m.gravity[2]; }
+    T cacc[NB][6];
+#pragma unroll
+    for (int b = 1; b < NB; b++) {
+      if (!TP::moves(b)) continue;
+      if (TP::parent(b) == 0 || !TP::moves(TP::parent(b))) {
+        cacc[b][0] = cacc[b][1] = cacc[b][2] = 0;
+        cacc[b][3] = g[0]; cacc[b][4] = g[1]; cacc[b][5] = g[2];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) cacc[b][c] = cacc[TP::parent(b)][c];
+      }
+#pragma unroll
+      for (int j = 0; j < NV; j++)
+        if (TP::jbody(j) == b) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) cacc[b][c] += cdof_dot[j][c] * qvel[j];
+        }
+      T t1[6], t2[6], t3[6];
+      mul_inert_vec(t1, cinert[b], cacc[b]);
+      mul_inert_vec(t2, cinert[b], cvel[b]);
+      cross_force(t3, cvel[b], t2);
+#pragma unroll
+      for (int c = 0; c < 6; c++) cfrc[b][c] = t1[c] + t3[c];
+    }
+#pragma unroll
+    for (int b = NB - 1; b >= 1; b--)
+      if (TP::moves(b) && TP::parent(b) != 0 && TP::moves(TP::parent(b))) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) cfrc[TP::parent(b)][c] += cfrc[b][c];
+      }
+#pragma unroll
+    for (int j = 0; j < NV; j++) qfrc[j] -= dot6(cdof[j], cfrc[TP::jbody(j)]);  // - qfrc_bias
+  }
+
+  // ================= actuation (joint transmission)
+  if (!(m.disableflags & (1 << 10))) {
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int j = TP::actj(u);
+      T c = ctrl[u];
+      if (m.act_ctrllimited[u] && !(m.disableflags & (1 << 7))) c = clampv(c, m.act_ctrlrange[u][0], m.act_ctrlrange[u][1]);
+      T force = m.act_gain[u] * c;
+      if (m.act_biastype[u] == 1)
+        force += m.act_bias[u][0] + m.act_bias[u][1] * m.act_gear[u] * qpos[j] + m.act_bias[u][2] * m.act_gear[u] * qvel[j];
+      if (m.act_forcelimited[u]) force = clampv(force, m.act_forcerange[u][0], m.act_forcerange[u][1]);
+      qfrc[j] += m.act_gear[u] * force;
+    }
+  }
+
+  // ================= acceleration stage
+  ldl_solve<NV>(qacc, Lm, Dinv, qfrc);  // qacc_smooth
+
+  // joint-limit rows: at most one side per joint can be active (checked at create time);
+  // lanes without an active row are predicated, waves without any skip the solve.
+#pragma unroll
+  for (int j = 0; j < NV; j++) qfrc_c[j] = 0;
+  if (TP::num_limited() > 0 && !(m.disableflags & ((1 << 0) | (1 << 3)))) {
+    bool act[NV];
+    T sgn[NV], dist[NV];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      act[j] = false; sgn[j] = 0; dist[j] = 0;
+      if (TP::jlimited(j)) {
+        const T dlo = qpos[j] - m.jnt_range[j][0], dhi = m.jnt_range[j][1] - qpos[j];
+        if (dlo < m.jnt_margin[j]) { act[j] = true; sgn[j] = 1; dist[j] = dlo; }
+        else if (dhi < m.jnt_margin[j]) { act[j] = true; sgn[j] = -1; dist[j] = dhi; }
+        any |= act[j];
+      }
+    }
+    if (__any(any)) {
+      // Minv columns of the limited dofs, A = J Minv J' + R, b = J qacc_smooth - aref
+      T Mi[NV][NV];  // Mi[j] = Minv e_j (only limited j used)
+      T AR[NV][NV], bb[NV], Rr[NV], f[NV];
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        if (!TP::jlimited(j)) continue;
+        T e[NV];
+#pragma unroll
+        for (int c = 0; c < NV; c++) e[c] = (c == j) ? T(1) : T(0);
+        ldl_solve<NV>(Mi[j], Lm, Dinv, e);
+        // impedance / reference (mj_makeImpedance)
+        const T pos = dist[j] - m.jnt_margin[j];
+        T dmin = clampv(m.jnt_solimp[j][0], T(kMinVal), T(1 - kMinVal));
+        T dmax = clampv(m.jnt_solimp[j][1], T(kMinVal), T(1 - kMinVal));
+        const T width = m.jnt_solimp[j][2];
+        T mid = clampv(m.jnt_solimp[j][3], T(kMinVal), T(1 - kMinVal));
+        T power = m.jnt_solimp[j][4] < 1 ? T(1) : m.jnt_solimp[j][4];
+        T imp;
+        if (dmin == dmax || width <= T(kMinVal)) {
+          imp = T(0.5) * (dmin + dmax);
+        } else {
+          const T x = fabs(pos) / width;
+          if (x >= 1) imp = dmax;
+          else if (x <= 0) imp = dmin;
+          else {
+            T y;
+            if (power == 1) y = x;
+            else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+            else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+            imp = dmin + y * (dmax - dmin);
+          }
+        }
+        T kk, bd;
+        if (m.jnt_solref[j][0] > 0) {
+          T tc = m.jnt_solref[j][0];
+          if (!(m.disableflags & (1 << 11)) && tc < 2 * h) tc = 2 * h;
+          kk = T(1) / (dmax * dmax * tc * tc * m.jnt_solref[j][1] * m.jnt_solref[j][1]);
+          bd = T(2) / (dmax * tc);
+        } else {
+          kk = -m.jnt_solref[j][0] / (dmax * dmax);
+          bd = -m.jnt_solref[j][1] / dmax;
+        }
+        const T aref = -bd * (sgn[j] * qvel[j]) - kk * imp * pos;
+        T R = (1 - imp) / imp * m.dof_invweight0[j];
+        Rr[j] = R < T(kMinVal) ? T(kMinVal) : R;
+        bb[j] = sgn[j] * qacc[j] - aref;
+        f[j] = 0;
+      }
+#pragma unroll
+      for (int r = 0; r < NV; r++)
+#pragma unroll
+        for (int s = 0; s < NV; s++)
+          if (TP::jlimited(r) && TP::jlimited(s)) AR[r][s] = sgn[r] * sgn[s] * Mi[s][r] + (r == s ? Rr[r] : T(0));
+      // projected Gauss-Seidel on the dual (MuJoCo PGS), rows in joint order
+      const T scale = T(1) / (m.meaninertia * T(NV > 1 ? NV : 1));
+      bool done = !any;
+      for (int it = 0; it < m.solver_iterations; it++) {
+        T improvement = 0;
+#pragma unroll
+        for (int r = 0; r < NV; r++) {
+          if (!TP::jlimited(r)) continue;
+          if (act[r]) {
+            T res = bb[r];
+#pragma unroll
+            for (int s = 0; s < NV; s++)
+              if (TP::jlimited(s)) res += act[s] ? AR[r][s] * f[s] : T(0);
+            const T old = f[r];
+            T fn = old - res / AR[r][r];
+            fn = fn < 0 ? T(0) : fn;
+            if (!done) {
+              f[r] = fn;
+              const T delta = fn - old;
+              improvement -= T(0.5) * delta * delta * AR[r][r] + delta * res;
+            }
+          }
+        }
+        done |= improvement * scale < m.solver_tolerance;
+        if (__all(done)) break;
+      }
+#pragma unroll
+      for (int r = 0; r < NV; r++)
+        if (TP::jlimited(r)) {
+          const T fr = act[r] ? f[r] : T(0);
+          qfrc_c[r] += sgn[r] * fr;
+#pragma unroll
+          for (int c = 0; c < NV; c++) qacc[c] += Mi[r][c] * sgn[r] * fr;
+        }
+    }
+  }
+
+}
+
+// the ResidualFn::Residual overrides of the registered tasks (the mjcb_sensor callback at mjSTAGE_ACC)
+template <class TP, class TK, typename T>
+__device__ __forceinline__ void lane_residual(const LaneTask<T>& tk, const T (&qpos)[TP::NV], const T (&qvel)[TP::NV],
+                                              const T (&ctrl)[TP::NU], T (&r)[TK::NR]) {
+  constexpr int NV = TP::NV;
+  if (TK::RID == 1) {  // Particle: mjpc/test/testdata/particle_residual.h:33-43
+    r[0] = qpos[0] - tk.mocap_pos[0][0];
+    r[1] = qpos[1] - tk.mocap_pos[0][1];
+    r[2] = qvel[0];
+    r[3] = qvel[1];
+  } else if (TK::RID == 2) {  // ParticleCopy: mjpc/test/agent/rollout_test.cc:37-42
+#pragma unroll
+    for (int i = 0; i < NV; i++) { r[i] = qpos[i]; r[NV + i] = qvel[i]; }
+  } else if (TK::RID == 3) {  // Cartpole: mjpc/tasks/cartpole/cartpole.cc:36-49
+    r[0] = cos(qpos[1]) - 1;
+    r[1] = qpos[0] - tk.parameters[0];
+    r[2] = qvel[1];
+    r[3] = ctrl[0];
+  }
+}
+
+// BaseResidualFn::CostValue (task.cc:71-110): weighted norms + exponential risk transform
+template <class TK, typename T>
+__device__ __forceinline__ T lane_cost(const LaneTask<T>& tk, const T (&r)[TK::NR]) {
+  T cost = cost_terms<TK, T>(r, tk, std::make_integer_sequence<int, TK::NTERM>{});
+  if (!(fabs(tk.risk) < T(1.0e-6))) cost = (exp(tk.risk * cost) - T(1)) / tk.risk;
+  return cost;
+}
+
+// mj_Euler with implicit joint damping, then mj_advance (slide/hinge: qpos += h qvel)
+template <class TP, typename T, class MODEL>
+__device__ __forceinline__ void lane_euler(const MODEL& m, T (&qpos)[TP::NV], T (&qvel)[TP::NV], const T (&qacc)[TP::NV],
+                                           const T (&qfrc)[TP::NV], const T (&qfrc_c)[TP::NV],
+                                           const T (&M)[TP::NV][TP::NV]) {
+  constexpr int NV = TP::NV;
+  const T h = m.timestep;
+  // ================= mj_Euler: implicit joint damping, then advance
+  T qdd[NV];
+  if (m.any_damping && !(m.disableflags & (1 << 14))) {
+    T Mh[NV][NV], L2[NV][NV], D2[NV], rhs[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+#pragma unroll
+      for (int j = 0; j < i; j++) Mh[i][j] = M[i][j];
+      Mh[i][i] = M[i][i] + h * m.dof_damping[i];
+      rhs[i] = qfrc[i] + qfrc_c[i];
+    }
+    ldl_factor<NV>(L2, D2, Mh);
+    ldl_solve<NV>(qdd, L2, D2, rhs);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; i++) qdd[i] = qacc[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    qvel[i] += h * qdd[i];
+    qpos[i] += h * qvel[i];
+  }
+}
+
+// one step's Trajectory row of this candidate -> [step][field][candidate] SoA (coalesced across the wave)
+template <class TP, class TK, typename T>
+__device__ __forceinline__ void lane_record(const RolloutArgs<T>& a, int t, int cand, const T (&qpos)[TP::NV],
+                                            const T (&qvel)[TP::NV], const T (&ctrl)[TP::NU], T time,
+                                            const T (&r)[TK::NR], const T (&site_xpos)[TP::NSITE > 0 ? TP::NSITE : 1][3],
+                                            T cost, bool bad) {
+  constexpr int NV = TP::NV, NU = TP::NU, NR = TK::NR, NTR = TK::NTRACE, DS = 2 * NV;
+  const size_t N = (size_t)a.N;
+  const size_t base = (size_t)t * N + cand;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    a.states[((size_t)t * DS + i) * N + cand] = qpos[i];
+    a.states[((size_t)t * DS + NV + i) * N + cand] = qvel[i];
+  }
+#pragma unroll
+  for (int k = 0; k < NU; k++) a.actions[((size_t)t * NU + k) * N + cand] = ctrl[k];
+  a.times[base] = time;
+#pragma unroll
+  for (int i = 0; i < NR; i++) a.residual[((size_t)t * NR + i) * N + cand] = r[i];
+#pragma unroll
+  for (int k = 0; k < NTR; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) a.trace[((size_t)t * 3 * NTR + 3 * k + c) * N + cand] = site_xpos[TK::trace_site(k)][c];
+  if (!bad) a.costs[base] = cost;
+}
+
 // Where the model's numeric constants come from:
 //   RuntimeModel  - the kernel-argument copy (general path: any model with this topology)
 //   StaticXxx     - a generated constexpr object (generated/static_models.h): every constant is an
@@ -300,364 +754,10 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
       for (int i = 0; i < NV; i++) bad |= is_bad(qpos[i]) || is_bad(qvel[i]);
     }
 
-    // ================= position stage: kinematics
-    T xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3], ximat[NB][9];
-    T xanchor[NV][3], xaxis[NV][3];
-#pragma unroll
-    for (int b = 1; b < NB; b++) {
-      T pos[3], quat[4];
-      if (TP::mocap(b) != 15) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) pos[c] = tk.mocap_pos[TP::mocap(b)][c];
-#pragma unroll
-        for (int c = 0; c < 4; c++) quat[c] = tk.mocap_quat[TP::mocap(b)][c];
-      } else {
-        if (TP::parent(b) == 0) {
-#pragma unroll
-          for (int c = 0; c < 3; c++) pos[c] = m.body_pos[b][c];
-#pragma unroll
-          for (int c = 0; c < 4; c++) quat[c] = m.body_quat[b][c];
-        } else {
-          const int p = TP::parent(b);
-          T bp[3] = {m.body_pos[b][0], m.body_pos[b][1], m.body_pos[b][2]};
-          T bq[4] = {m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2], m.body_quat[b][3]};
-          mat_vec(pos, xmat[p], bp);
-#pragma unroll
-          for (int c = 0; c < 3; c++) pos[c] += xpos[p][c];
-          quat_mul(quat, xquat[p], bq);
-        }
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-          if (TP::jbody(j) == b) {
-            T R[9];
-            quat_to_mat(R, quat);
-            T jp[3] = {m.jnt_pos[j][0], m.jnt_pos[j][1], m.jnt_pos[j][2]};
-            T ja[3] = {m.jnt_axis[j][0], m.jnt_axis[j][1], m.jnt_axis[j][2]};
-            mat_vec(xanchor[j], R, jp);
-#pragma unroll
-            for (int c = 0; c < 3; c++) xanchor[j][c] += pos[c];
-            mat_vec(xaxis[j], R, ja);
-            const T dq = qpos[j] - m.qpos0[j];
-            if (TP::jtype(j) == kJntSlide) {
-#pragma unroll
-              for (int c = 0; c < 3; c++) pos[c] += xaxis[j][c] * dq;
-            } else {  // hinge
-              T sn, cs;
-              sincos_t(T(0.5) * dq, sn, cs);
-              T ql[4] = {cs, ja[0] * sn, ja[1] * sn, ja[2] * sn};
-              quat_mul(quat, quat, ql);
-              T R2[9], v[3];
-              quat_to_mat(R2, quat);
-              mat_vec(v, R2, jp);
-#pragma unroll
-              for (int c = 0; c < 3; c++) pos[c] = xanchor[j][c] - v[c];
-            }
-          }
-        }
-      }
-      // mj_kinematics renormalises every body quaternion to stop drift of FREE/BALL qpos quaternions.
-      // Here only mocap poses (user input) can be unnormalised: a slide/hinge body's quaternion is a
-      // product of unit quaternions (model constants and axis-angle factors), unit to rounding, so
-      // the sqrt + divide on the per-step dependent chain is skipped for those bodies.
-      if (TP::mocap(b) != 15) normalize4(quat);
-#pragma unroll
-      for (int c = 0; c < 3; c++) xpos[b][c] = pos[c];
-#pragma unroll
-      for (int c = 0; c < 4; c++) xquat[b][c] = quat[c];
-      quat_to_mat(xmat[b], quat);
-      T ip[3] = {m.body_ipos[b][0], m.body_ipos[b][1], m.body_ipos[b][2]};
-      T iq[4] = {m.body_iquat[b][0], m.body_iquat[b][1], m.body_iquat[b][2], m.body_iquat[b][3]};
-      T v[3], q2[4];
-      mat_vec(v, xmat[b], ip);
-#pragma unroll
-      for (int c = 0; c < 3; c++) xipos[b][c] = pos[c] + v[c];
-      quat_mul(q2, quat, iq);
-      quat_to_mat(ximat[b], q2);
-    }
+    // ================= mj_forward for this candidate (lane_forward)
+    T qacc[NV], qfrc[NV], qfrc_c[NV], M[NV][NV];
     T site_xpos[NS > 0 ? NS : 1][3];
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-      const int b = TP::siteb(s);
-      T sp[3] = {m.site_pos[s][0], m.site_pos[s][1], m.site_pos[s][2]};
-      if (b == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) site_xpos[s][c] = sp[c];
-      } else {
-        T v[3];
-        mat_vec(v, xmat[b], sp);
-#pragma unroll
-        for (int c = 0; c < 3; c++) site_xpos[s][c] = xpos[b][c] + v[c];
-      }
-    }
-
-    // ================= comPos: subtree com of each moving tree, cinert, cdof
-    T com[NB][3];  // only entries of moving roots are used
-#pragma unroll
-    for (int r = 1; r < NB; r++) {
-      if (TP::parent(r) == 0 && TP::moves(r)) {
-        T acc[3] = {0, 0, 0};
-#pragma unroll
-        for (int b = 1; b < NB; b++)
-          if (TP::root(b) == r) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) acc[c] += m.body_mass[b] * xipos[b][c];
-          }
-#pragma unroll
-        for (int c = 0; c < 3; c++) com[r][c] = acc[c] * m.root_invmass[r];
-      }
-    }
-    T cinert[NB][10];
-#pragma unroll
-    for (int b = 1; b < NB; b++) {
-      if (TP::moves(b)) {
-        T off[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) off[c] = xipos[b][c] - com[TP::root(b)][c];
-        T bi[3] = {m.body_inertia[b][0], m.body_inertia[b][1], m.body_inertia[b][2]};
-        inert_com(cinert[b], bi, ximat[b], off, m.body_mass[b]);
-      }
-    }
-    T cdof[NV][6];
-#pragma unroll
-    for (int j = 0; j < NV; j++) {
-      if (TP::jtype(j) == kJntSlide) {
-        cdof[j][0] = cdof[j][1] = cdof[j][2] = 0;
-#pragma unroll
-        for (int c = 0; c < 3; c++) cdof[j][3 + c] = xaxis[j][c];
-      } else {
-        T off[3], cr[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) off[c] = com[TP::root(TP::jbody(j))][c] - xanchor[j][c];
-        cross3(cr, xaxis[j], off);
-#pragma unroll
-        for (int c = 0; c < 3; c++) { cdof[j][c] = xaxis[j][c]; cdof[j][3 + c] = cr[c]; }
-      }
-    }
-
-    // ================= CRB -> M (lower triangle, static sparsity), LDL' factor
-    T crb[NB][10];
-#pragma unroll
-    for (int b = 1; b < NB; b++)
-      if (TP::moves(b)) {
-#pragma unroll
-        for (int c = 0; c < 10; c++) crb[b][c] = cinert[b][c];
-      }
-#pragma unroll
-    for (int b = NB - 1; b >= 1; b--)
-      if (TP::moves(b) && TP::parent(b) != 0 && TP::moves(TP::parent(b))) {
-#pragma unroll
-        for (int c = 0; c < 10; c++) crb[TP::parent(b)][c] += crb[b][c];
-      }
-    T M[NV][NV];
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      T buf[6];
-      mul_inert_vec(buf, crb[TP::jbody(i)], cdof[i]);
-      M[i][i] = m.dof_armature[i] + dot6(cdof[i], buf);
-#pragma unroll
-      for (int j = 0; j < i; j++) M[i][j] = TP::dof_ancestor(i, j) ? dot6(cdof[j], buf) : T(0);
-    }
-    // M = L D L' (unit lower L, stored in Lm below the diagonal; Dinv = 1/D)
-    T Lm[NV][NV], Dinv[NV];
-    ldl_factor<NV>(Lm, Dinv, M);
-
-    // ================= velocity stage: comVel, passive, RNE bias
-    T cvel[NB][6], cdof_dot[NV][6];
-#pragma unroll
-    for (int b = 1; b < NB; b++) {
-      if (!TP::moves(b)) continue;
-      T v[6];
-      if (TP::parent(b) == 0 || !TP::moves(TP::parent(b))) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) v[c] = 0;
-      } else {
-#pragma unroll
-        for (int c = 0; c < 6; c++) v[c] = cvel[TP::parent(b)][c];
-      }
-#pragma unroll
-      for (int j = 0; j < NV; j++)
-        if (TP::jbody(j) == b) {
-          cross_motion(cdof_dot[j], v, cdof[j]);
-#pragma unroll
-          for (int c = 0; c < 6; c++) v[c] += cdof[j][c] * qvel[j];
-        }
-#pragma unroll
-      for (int c = 0; c < 6; c++) cvel[b][c] = v[c];
-    }
-    T qfrc[NV];  // becomes qfrc_smooth
-    const bool passive_on = !(m.disableflags & (1 << 5));
-#pragma unroll
-    for (int j = 0; j < NV; j++) {
-      T f = 0;
-      if (passive_on) f = -m.jnt_stiffness[j] * (qpos[j] - m.qpos_spring[j]) - m.dof_damping[j] * qvel[j];
-      qfrc[j] = f;
-    }
-    {
-      T cfrc[NB][6];
-      T g[3] = {0, 0, 0};
-      if (!(m.disableflags & (1 << 6))) { g[0] = -m.gravity[0]; g[1] = -m.gravity[1]; g[2] = -m.gravity[2]; }
-      T cacc[NB][6];
-#pragma unroll
-      for (int b = 1; b < NB; b++) {
-        if (!TP::moves(b)) continue;
-        if (TP::parent(b) == 0 || !TP::moves(TP::parent(b))) {
-          cacc[b][0] = cacc[b][1] = cacc[b][2] = 0;
-          cacc[b][3] = g[0]; cacc[b][4] = g[1]; cacc[b][5] = g[2];
-        } else {
-#pragma unroll
-          for (int c = 0; c < 6; c++) cacc[b][c] = cacc[TP::parent(b)][c];
-        }
-#pragma unroll
-        for (int j = 0; j < NV; j++)
-          if (TP::jbody(j) == b) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) cacc[b][c] += cdof_dot[j][c] * qvel[j];
-          }
-        T t1[6], t2[6], t3[6];
-        mul_inert_vec(t1, cinert[b], cacc[b]);
-        mul_inert_vec(t2, cinert[b], cvel[b]);
-        cross_force(t3, cvel[b], t2);
-#pragma unroll
-        for (int c = 0; c < 6; c++) cfrc[b][c] = t1[c] + t3[c];
-      }
-#pragma unroll
-      for (int b = NB - 1; b >= 1; b--)
-        if (TP::moves(b) && TP::parent(b) != 0 && TP::moves(TP::parent(b))) {
-#pragma unroll
-          for (int c = 0; c < 6; c++) cfrc[TP::parent(b)][c] += cfrc[b][c];
-        }
-#pragma unroll
-      for (int j = 0; j < NV; j++) qfrc[j] -= dot6(cdof[j], cfrc[TP::jbody(j)]);  // - qfrc_bias
-    }
-
-    // ================= actuation (joint transmission)
-    if (!(m.disableflags & (1 << 10))) {
-#pragma unroll
-      for (int u = 0; u < NU; u++) {
-        const int j = TP::actj(u);
-        T c = ctrl[u];
-        if (m.act_ctrllimited[u] && !(m.disableflags & (1 << 7))) c = clampv(c, m.act_ctrlrange[u][0], m.act_ctrlrange[u][1]);
-        T force = m.act_gain[u] * c;
-        if (m.act_biastype[u] == 1)
-          force += m.act_bias[u][0] + m.act_bias[u][1] * m.act_gear[u] * qpos[j] + m.act_bias[u][2] * m.act_gear[u] * qvel[j];
-        if (m.act_forcelimited[u]) force = clampv(force, m.act_forcerange[u][0], m.act_forcerange[u][1]);
-        qfrc[j] += m.act_gear[u] * force;
-      }
-    }
-
-    // ================= acceleration stage
-    T qacc[NV];
-    ldl_solve<NV>(qacc, Lm, Dinv, qfrc);  // qacc_smooth
-
-    // joint-limit rows: at most one side per joint can be active (checked at create time);
-    // lanes without an active row are predicated, waves without any skip the solve.
-    T qfrc_c[NV];
-#pragma unroll
-    for (int j = 0; j < NV; j++) qfrc_c[j] = 0;
-    if (TP::num_limited() > 0 && !(m.disableflags & ((1 << 0) | (1 << 3)))) {
-      bool act[NV];
-      T sgn[NV], dist[NV];
-      bool any = false;
-#pragma unroll
-      for (int j = 0; j < NV; j++) {
-        act[j] = false; sgn[j] = 0; dist[j] = 0;
-        if (TP::jlimited(j)) {
-          const T dlo = qpos[j] - m.jnt_range[j][0], dhi = m.jnt_range[j][1] - qpos[j];
-          if (dlo < m.jnt_margin[j]) { act[j] = true; sgn[j] = 1; dist[j] = dlo; }
-          else if (dhi < m.jnt_margin[j]) { act[j] = true; sgn[j] = -1; dist[j] = dhi; }
-          any |= act[j];
-        }
-      }
-      if (__any(any)) {
-        // Minv columns of the limited dofs, A = J Minv J' + R, b = J qacc_smooth - aref
-        T Mi[NV][NV];  // Mi[j] = Minv e_j (only limited j used)
-        T AR[NV][NV], bb[NV], Rr[NV], f[NV];
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-          if (!TP::jlimited(j)) continue;
-          T e[NV];
-#pragma unroll
-          for (int c = 0; c < NV; c++) e[c] = (c == j) ? T(1) : T(0);
-          ldl_solve<NV>(Mi[j], Lm, Dinv, e);
-          // impedance / reference (mj_makeImpedance)
-          const T pos = dist[j] - m.jnt_margin[j];
-          T dmin = clampv(m.jnt_solimp[j][0], T(kMinVal), T(1 - kMinVal));
-          T dmax = clampv(m.jnt_solimp[j][1], T(kMinVal), T(1 - kMinVal));
-          const T width = m.jnt_solimp[j][2];
-          T mid = clampv(m.jnt_solimp[j][3], T(kMinVal), T(1 - kMinVal));
-          T power = m.jnt_solimp[j][4] < 1 ? T(1) : m.jnt_solimp[j][4];
-          T imp;
-          if (dmin == dmax || width <= T(kMinVal)) {
-            imp = T(0.5) * (dmin + dmax);
-          } else {
-            const T x = fabs(pos) / width;
-            if (x >= 1) imp = dmax;
-            else if (x <= 0) imp = dmin;
-            else {
-              T y;
-              if (power == 1) y = x;
-              else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
-              else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
-              imp = dmin + y * (dmax - dmin);
-            }
-          }
-          T kk, bd;
-          if (m.jnt_solref[j][0] > 0) {
-            T tc = m.jnt_solref[j][0];
-            if (!(m.disableflags & (1 << 11)) && tc < 2 * h) tc = 2 * h;
-            kk = T(1) / (dmax * dmax * tc * tc * m.jnt_solref[j][1] * m.jnt_solref[j][1]);
-            bd = T(2) / (dmax * tc);
-          } else {
-            kk = -m.jnt_solref[j][0] / (dmax * dmax);
-            bd = -m.jnt_solref[j][1] / dmax;
-          }
-          const T aref = -bd * (sgn[j] * qvel[j]) - kk * imp * pos;
-          T R = (1 - imp) / imp * m.dof_invweight0[j];
-          Rr[j] = R < T(kMinVal) ? T(kMinVal) : R;
-          bb[j] = sgn[j] * qacc[j] - aref;
-          f[j] = 0;
-        }
-#pragma unroll
-        for (int r = 0; r < NV; r++)
-#pragma unroll
-          for (int s = 0; s < NV; s++)
-            if (TP::jlimited(r) && TP::jlimited(s)) AR[r][s] = sgn[r] * sgn[s] * Mi[s][r] + (r == s ? Rr[r] : T(0));
-        // projected Gauss-Seidel on the dual (MuJoCo PGS), rows in joint order
-        const T scale = T(1) / (m.meaninertia * T(NV > 1 ? NV : 1));
-        bool done = !any;
-        for (int it = 0; it < m.solver_iterations; it++) {
-          T improvement = 0;
-#pragma unroll
-          for (int r = 0; r < NV; r++) {
-            if (!TP::jlimited(r)) continue;
-            if (act[r]) {
-              T res = bb[r];
-#pragma unroll
-              for (int s = 0; s < NV; s++)
-                if (TP::jlimited(s)) res += act[s] ? AR[r][s] * f[s] : T(0);
-              const T old = f[r];
-              T fn = old - res / AR[r][r];
-              fn = fn < 0 ? T(0) : fn;
-              if (!done) {
-                f[r] = fn;
-                const T delta = fn - old;
-                improvement -= T(0.5) * delta * delta * AR[r][r] + delta * res;
-              }
-            }
-          }
-          done |= improvement * scale < m.solver_tolerance;
-          if (__all(done)) break;
-        }
-#pragma unroll
-        for (int r = 0; r < NV; r++)
-          if (TP::jlimited(r)) {
-            const T fr = act[r] ? f[r] : T(0);
-            qfrc_c[r] += sgn[r] * fr;
-#pragma unroll
-            for (int c = 0; c < NV; c++) qacc[c] += Mi[r][c] * sgn[r] * fr;
-          }
-      }
-    }
+    lane_forward<TP, T>(m, tk, qpos, qvel, ctrl, qacc, qfrc, qfrc_c, M, site_xpos);
 
     // ================= mj_checkAcc
     if (!last) {
@@ -667,68 +767,17 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
 
     // ================= sensor stage: task residual (mjcb_sensor at mjSTAGE_ACC), cost
     T r[NR];
-    if (TK::RID == 1) {  // Particle: mjpc/test/testdata/particle_residual.h:33-43
-      r[0] = qpos[0] - tk.mocap_pos[0][0];
-      r[1] = qpos[1] - tk.mocap_pos[0][1];
-      r[2] = qvel[0];
-      r[3] = qvel[1];
-    } else if (TK::RID == 2) {  // ParticleCopy: mjpc/test/agent/rollout_test.cc:37-42
-#pragma unroll
-      for (int i = 0; i < NV; i++) { r[i] = qpos[i]; r[NV + i] = qvel[i]; }
-    } else if (TK::RID == 3) {  // Cartpole: mjpc/tasks/cartpole/cartpole.cc:36-49
-      r[0] = cos(qpos[1]) - 1;
-      r[1] = qpos[0] - tk.parameters[0];
-      r[2] = qvel[1];
-      r[3] = ctrl[0];
-    }
-    T cost = cost_terms<TK, T>(r, tk, std::make_integer_sequence<int, TK::NTERM>{});  // task.cc:71-110
-    if (!(fabs(tk.risk) < T(1.0e-6))) cost = (exp(tk.risk * cost) - T(1)) / tk.risk;
+    lane_residual<TP, TK, T>(tk, qpos, qvel, ctrl, r);
+    T cost = lane_cost<TK, T>(tk, r);  // task.cc:71-110
 
     // ================= record step t: coalesced [t][field][candidate] stores
-    if (live && !failed) {
-      const size_t base = (size_t)t * N + cand;
-#pragma unroll
-      for (int i = 0; i < NV; i++) {
-        a.states[((size_t)t * DS + i) * N + cand] = qpos[i];
-        a.states[((size_t)t * DS + NV + i) * N + cand] = qvel[i];
-      }
-#pragma unroll
-      for (int k = 0; k < NU; k++) a.actions[((size_t)t * NU + k) * N + cand] = ctrl[k];
-      a.times[base] = time;
-#pragma unroll
-      for (int i = 0; i < NR; i++) a.residual[((size_t)t * NR + i) * N + cand] = r[i];
-#pragma unroll
-      for (int k = 0; k < NTR; k++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) a.trace[((size_t)t * 3 * NTR + 3 * k + c) * N + cand] = site_xpos[TK::trace_site(k)][c];
-      if (!bad) a.costs[base] = cost;
-    }
+    if (live && !failed) lane_record<TP, TK, T>(a, t, cand, qpos, qvel, ctrl, time, r, site_xpos, cost, bad);
     if (bad) failed = true;  // CheckWarnings -> abort (trajectory.cc:169-173)
     total += (double)cost;
     if (last) break;
 
-    // ================= mj_Euler: implicit joint damping, then advance
-    T qdd[NV];
-    if (m.any_damping && !(m.disableflags & (1 << 14))) {
-      T Mh[NV][NV], L2[NV][NV], D2[NV], rhs[NV];
-#pragma unroll
-      for (int i = 0; i < NV; i++) {
-#pragma unroll
-        for (int j = 0; j < i; j++) Mh[i][j] = M[i][j];
-        Mh[i][i] = M[i][i] + h * m.dof_damping[i];
-        rhs[i] = qfrc[i] + qfrc_c[i];
-      }
-      ldl_factor<NV>(L2, D2, Mh);
-      ldl_solve<NV>(qdd, L2, D2, rhs);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NV; i++) qdd[i] = qacc[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      qvel[i] += h * qdd[i];
-      qpos[i] += h * qvel[i];
-    }
+    // ================= mj_Euler (implicit joint damping) + advance
+    lane_euler<TP, T>(m, qpos, qvel, qacc, qfrc, qfrc_c, M);
     time += h;
   }
 

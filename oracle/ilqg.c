@@ -1,0 +1,214 @@
+/* ilqg.c -- oracle restatement of the iLQG planner's derivative and rollout pieces:
+ *   - mjd_transitionFD (MuJoCo @088079ef engine_derivative_fd.c; third-party, restated from its documented
+ *     behaviour: forward/centred differences of the next state and of sensordata w.r.t. state and control,
+ *     control nudges kept inside ctrlrange), as called by ModelDerivatives::Compute
+ *     (mjpc/planners/model_derivatives.cc:75-106)
+ *   - CostDerivatives::DerivativeStep / Compute (mjpc/planners/cost_derivatives.cc:77-230)
+ *   - iLQGPolicy::Action (mjpc/planners/ilqg/policy.cc:82-161) and the index feedback policy of
+ *     iLQGPlanner::ActionRollouts (ilqg/planner.cc:640-668), as policies of Trajectory::Rollout /
+ *     RolloutDiscrete (mjpc/trajectory.cc:92-309)
+ * TEST INFRASTRUCTURE ONLY (see oracle.h). */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+
+/* ---- one perturbed mj_step: next state (nq==nv models: plain difference space) + residual ---- */
+static void fd_step(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state, double time,
+                    const double* ctrl, double* next, double* sensor) {
+  odata_set_state(d, state, time, NULL, NULL);
+  odata_set_ctrl(d, ctrl);
+  o_step_task(d, task, sensor);
+  odata_get(d, "qpos", next, m->nq);
+  odata_get(d, "qvel", next + m->nq, m->nv);
+}
+
+static int in_range(double a, double b, const double* range) {
+  return a >= range[0] && a <= range[1] && b >= range[0] && b <= range[1];
+}
+
+/* A: ndx x ndx, B: ndx x nu, C: nr x ndx, D: nr x nu (row-major); any may be NULL. Slide/hinge models only
+ * (nq == nv), which is all the device path covers. Mocap pose must already be set on `d`. */
+int otransition_fd(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state, double time,
+                   const double* ctrl, double eps, int centered, double* A, double* B, double* C, double* D) {
+  if (m->nq != m->nv) return -1;
+  const int nv = m->nv, nu = m->nu, ndx = 2 * nv, nr = task->num_residual;
+  double* w = (double*)malloc(sizeof(double) * (size_t)(3 * ndx + 3 * nr + ndx + nu));
+  double *y0 = w, *yp = y0 + ndx, *ym = yp + ndx, *s0 = ym + ndx, *sp = s0 + nr, *sm = sp + nr, *x = sm + nr, *u = x + ndx;
+  fd_step(m, task, d, state, time, ctrl, y0, s0);
+  for (int j = 0; j < ndx + nu; j++) {
+    memcpy(x, state, sizeof(double) * ndx);
+    memcpy(u, ctrl, sizeof(double) * nu);
+    int fwd = 1, back = centered != 0;
+    if (j >= ndx) {
+      const int k = j - ndx;
+      if (m->actuator_ctrllimited[k]) {
+        const double* range = m->actuator_ctrlrange + 2 * k;
+        fwd = in_range(ctrl[k], ctrl[k] + eps, range);
+        back = (centered || !fwd) && in_range(ctrl[k] - eps, ctrl[k], range);
+      }
+    }
+    if (fwd) {
+      if (j < ndx) x[j] = state[j] + eps; else u[j - ndx] = ctrl[j - ndx] + eps;
+      fd_step(m, task, d, x, time, u, yp, sp);
+    }
+    if (back) {
+      memcpy(x, state, sizeof(double) * ndx);
+      memcpy(u, ctrl, sizeof(double) * nu);
+      if (j < ndx) x[j] = state[j] - eps; else u[j - ndx] = ctrl[j - ndx] - eps;
+      fd_step(m, task, d, x, time, u, ym, sm);
+    }
+    for (int i = 0; i < ndx + nr; i++) {
+      const double v0 = i < ndx ? y0[i] : s0[i - ndx], vp = i < ndx ? yp[i] : sp[i - ndx], vm = i < ndx ? ym[i] : sm[i - ndx];
+      double dv = 0;
+      if (fwd && back) dv = (vp - vm) / (2 * eps);
+      else if (fwd) dv = (vp - v0) / eps;
+      else if (back) dv = (v0 - vm) / eps;
+      if (i < ndx) {
+        if (j < ndx) { if (A) A[i * ndx + j] = dv; } else if (B) B[i * nu + (j - ndx)] = dv;
+      } else {
+        if (j < ndx) { if (C) C[(i - ndx) * ndx + j] = dv; } else if (D) D[(i - ndx) * nu + (j - ndx)] = dv;
+      }
+    }
+  }
+  free(w);
+  return 0;
+}
+
+/* CostDerivatives::Compute for one timestep t of T (the 1/T weight scaling is the caller's T) */
+void ocost_derivatives(const mjpcx_task* task, int T, int ndx, int nu, const double* r, const double* rx, const double* ru,
+                       double* cx, double* cu, double* cxx, double* cxu, double* cuu) {
+  memset(cx, 0, sizeof(double) * ndx); memset(cu, 0, sizeof(double) * nu);
+  memset(cxx, 0, sizeof(double) * ndx * ndx); memset(cxu, 0, sizeof(double) * ndx * nu); memset(cuu, 0, sizeof(double) * nu * nu);
+  double g[64], H[64 * 64];
+  double* Hrx = (double*)malloc(sizeof(double) * 64 * (size_t)(ndx + nu));
+  double* Hru = Hrx + 64 * ndx;
+  int shift = 0, pshift = 0;
+  double c = 0;
+  for (int k = 0; k < task->num_term; k++) {
+    const int nk = task->dim_norm_residual[k];
+    const double w = task->weight[k] / T;
+    const double* rxk = rx + (size_t)shift * ndx;
+    const double* ruk = ru + (size_t)shift * nu;
+    c += w * onorm(g, H, r + shift, task->norm_parameter + pshift, nk, task->norm[k]);
+    for (int a = 0; a < nk; a++) {
+      for (int j = 0; j < ndx; j++) { double s = 0; for (int b = 0; b < nk; b++) s += H[a * nk + b] * rxk[b * ndx + j]; Hrx[a * ndx + j] = s; }
+      for (int j = 0; j < nu; j++) { double s = 0; for (int b = 0; b < nk; b++) s += H[a * nk + b] * ruk[b * nu + j]; Hru[a * nu + j] = s; }
+    }
+    for (int i = 0; i < ndx; i++) { double s = 0; for (int a = 0; a < nk; a++) s += rxk[a * ndx + i] * g[a]; cx[i] += w * s; }
+    for (int i = 0; i < nu; i++) { double s = 0; for (int a = 0; a < nk; a++) s += ruk[a * nu + i] * g[a]; cu[i] += w * s; }
+    for (int i = 0; i < ndx; i++)
+      for (int j = 0; j < ndx; j++) { double s = 0; for (int a = 0; a < nk; a++) s += Hrx[a * ndx + i] * rxk[a * ndx + j]; cxx[i * ndx + j] += w * s; }
+    for (int i = 0; i < ndx; i++)
+      for (int j = 0; j < nu; j++) { double s = 0; for (int a = 0; a < nk; a++) s += Hrx[a * ndx + i] * ruk[a * nu + j]; cxu[i * nu + j] += w * s; }
+    for (int i = 0; i < nu; i++)
+      for (int j = 0; j < nu; j++) { double s = 0; for (int a = 0; a < nk; a++) s += Hru[a * nu + i] * ruk[a * nu + j]; cuu[i * nu + j] += w * s; }
+    shift += nk;
+    pshift += task->num_norm_parameter[k];
+  }
+  free(Hrx);
+  if (fabs(task->risk) < 1.0e-6) return;
+  /* cost_derivatives.cc:156-226, including its use of the already scaled cx / cu in the rank-one terms */
+  const double s = exp(task->risk * c);
+  for (int i = 0; i < ndx; i++) cx[i] *= s;
+  for (int i = 0; i < nu; i++) cu[i] *= s;
+  for (int i = 0; i < ndx; i++)
+    for (int j = 0; j < ndx; j++) cxx[i * ndx + j] = cxx[i * ndx + j] * s + task->risk * s * cx[i] * cx[j];
+  for (int i = 0; i < ndx; i++)
+    for (int j = 0; j < nu; j++) cxu[i * nu + j] = cxu[i * nu + j] * s + task->risk * s * cx[i] * cu[j];
+  for (int i = 0; i < nu; i++)
+    for (int j = 0; j < nu; j++) cuu[i * nu + j] = cuu[i * nu + j] * s + task->risk * s * cu[i] * cu[j];
+}
+
+/* ---- feedback policies ---- */
+typedef struct {
+  const mjpcx_model* m;
+  int Tn, mode, representation, use_state;
+  const double *times, *states, *actions, *gains, *improvement;
+  double alpha;
+} FbPolicy;
+
+static void find_interval(const double* xs, double v, int length, int* b) { /* utilities.h:124-144 */
+  int up = 0;
+  while (up < length && xs[up] <= v) up++;
+  int lo = up - 1;
+  if (lo < 0) { b[0] = b[1] = 0; }
+  else if (lo > length - 1) { b[0] = b[1] = length - 1; }
+  else { b[0] = lo; b[1] = up < length - 1 ? up : length - 1; }
+}
+static void interp(double* out, double x, const double* xs, const double* ys, int dim, int length, int zero) {
+  int b[2];
+  find_interval(xs, x, length, b);
+  if (zero || b[0] == b[1]) { memcpy(out, ys + dim * b[0], sizeof(double) * dim); return; }
+  const double t = (x - xs[b[0]]) / (xs[b[1]] - xs[b[0]]);
+  for (int i = 0; i < dim; i++) out[i] = ys[dim * b[0] + i] * (1.0 - t) + ys[dim * b[1] + i] * t;
+}
+static void clamp_ctrl(const mjpcx_model* m, double* u) {
+  for (int k = 0; k < m->nu; k++) {
+    const double lo = m->actuator_ctrlrange[2 * k], hi = m->actuator_ctrlrange[2 * k + 1];
+    u[k] = u[k] < lo ? lo : (u[k] > hi ? hi : u[k]);
+  }
+}
+/* action for step index t (mode 0) or time (mode 1) */
+static void fb_action(const FbPolicy* p, double* action, const double* state, double time, int t) {
+  const mjpcx_model* m = p->m;
+  const int nu = m->nu, ds = m->nq + m->nv, ndx = 2 * m->nv;
+  double dx[64], xi[64], K[64 * 16];
+  if (p->mode == 0) {
+    for (int k = 0; k < nu; k++) action[k] = p->actions[t * nu + k] + p->alpha * p->improvement[t * nu + k];
+    for (int j = 0; j < ndx; j++) dx[j] = state[j] - p->states[t * ds + j];
+    for (int k = 0; k < nu; k++) { double s = 0; for (int j = 0; j < ndx; j++) s += p->gains[(t * nu + k) * ndx + j] * dx[j]; action[k] += s; }
+  } else {
+    int b[2];
+    find_interval(p->times, time, p->Tn, b);
+    const int zero = b[0] == b[1] || p->representation == 0;
+    interp(action, time, p->times, p->actions, nu, p->Tn - 1, zero);
+    if (p->use_state) {
+      interp(xi, time, p->times, p->states, ds, p->Tn, zero);
+      interp(K, time, p->times, p->gains, nu * ndx, p->Tn - 1, zero);
+      for (int j = 0; j < ndx; j++) dx[j] = state[j] - xi[j];
+      for (int k = 0; k < nu; k++) { double s = 0; for (int j = 0; j < ndx; j++) s += K[k * ndx + j] * dx[j]; action[k] += p->alpha * s; }
+    }
+  }
+  clamp_ctrl(m, action);
+}
+
+/* N rollouts sharing the nominal trajectory, differing by alpha[i]; outputs candidate-major like orollout_batch */
+int orollout_feedback(const mjpcx_model* m, const mjpcx_task* task, const double* state, double time, const double* mocap,
+                      int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
+                      const double* states, const double* actions, const double* gains, const double* improvement,
+                      const double* alpha, OBatchOut* out) {
+  const int nu = m->nu, ds = m->nq + m->nv, nr = task->num_residual, ntr = task->num_trace;
+  OData* d = odata_new(m);
+  if (!d) return -1;
+  double* r = (double*)malloc(sizeof(double) * (size_t)(nr + nu + ds));
+  double *act = r + nr, *st = act + nu;
+  for (int i = 0; i < N; i++) {
+    FbPolicy p = {m, Tn, mode, representation, use_state, times, states, actions, gains, improvement, alpha[i]};
+    odata_set_state(d, state, time, mocap, NULL);
+    memcpy(st, state, sizeof(double) * ds);
+    double cur = time, total = 0;
+    int failure = 0;
+    for (int t = 0; t < H; t++) {
+      const int last = t == H - 1;
+      if (!last) { fb_action(&p, act, st, cur, t); odata_set_ctrl(d, act); }
+      if (out->states) memcpy(out->states + ((size_t)i * H + t) * ds, st, sizeof(double) * ds);
+      if (out->actions) memcpy(out->actions + ((size_t)i * H + t) * nu, act, sizeof(double) * nu);
+      if (out->times) out->times[(size_t)i * H + t] = cur;
+      if (last) o_forward_task(d, task, r); else o_step_task(d, task, r);
+      if (out->residual) memcpy(out->residual + ((size_t)i * H + t) * nr, r, sizeof(double) * nr);
+      for (int k = 0; k < ntr && out->trace; k++)
+        memcpy(out->trace + (((size_t)i * H + t) * ntr + k) * 3, odata_site_xpos(d) + 3 * task->trace_site[k], 3 * sizeof(double));
+      if (!last && odata_warning(d)) { failure = 1; break; }
+      const double c = ocost_value(task, r);
+      if (out->costs) out->costs[(size_t)i * H + t] = c;
+      total += c;
+      if (!last) { odata_get(d, "qpos", st, m->nq); odata_get(d, "qvel", st + m->nq, m->nv); odata_get(d, "time", &cur, 1); }
+    }
+    out->total_return[i] = failure ? 1.0e6 : total / (H > 1 ? H : 1);
+    out->failure[i] = failure;
+  }
+  free(r);
+  odata_free(d);
+  return 0;
+}

@@ -113,6 +113,16 @@ int orollout_batch(const mjpcx_model* m, const mjpcx_task* task, const double* s
                    int P, int interp, const double* node_times, const double* node_values,
                    int num_threads, OBatchOut* out);
 
+/* ---------------- iLQG derivatives and feedback rollouts (oracle/ilqg.c) ---------------- */
+int otransition_fd(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state, double time,
+                   const double* ctrl, double eps, int centered, double* A, double* B, double* C, double* D);
+void ocost_derivatives(const mjpcx_task* task, int T, int ndx, int nu, const double* r, const double* rx, const double* ru,
+                       double* cx, double* cu, double* cxx, double* cxu, double* cuu);
+int orollout_feedback(const mjpcx_model* m, const mjpcx_task* task, const double* state, double time, const double* mocap,
+                      int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
+                      const double* states, const double* actions, const double* gains, const double* improvement,
+                      const double* alpha, OBatchOut* out);
+
 /* ---------------- iLQG backward pass (mjpc/planners/ilqg/backward_pass.cc) ---------------- */
 /* box-constrained QP (MuJoCo mju_boxQP): returns the number of free dimensions, -1 if not PD */
 int oboxqp(double* res, double* R, int* index, const double* H, const double* g, int n, const double* lower,

@@ -91,6 +91,11 @@ def lib():
                                   c_f64p, C.c_int, c_f64p, c_f64p, C.c_double, C.c_double, C.POINTER(MjpcxTrajView)]
         L.orollout_batch.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, c_f64p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_int, C.POINTER(OBatchOut)]
+        L.otransition_fd.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), C.c_void_p, c_f64p, C.c_double, c_f64p,
+                                     C.c_double, C.c_int, c_f64p, c_f64p, c_f64p, c_f64p]
+        L.ocost_derivatives.argtypes = [C.POINTER(MjpcxTask), C.c_int, C.c_int, C.c_int] + [c_f64p] * 8
+        L.orollout_feedback.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [c_f64p] * 6 + [C.POINTER(OBatchOut)]
         L.oriccati.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int] + [c_f64p] * 14
         L.oboxqp.argtypes = [c_f64p, c_f64p, c_i32p, c_f64p, c_f64p, C.c_int, c_f64p, c_f64p]
         _LIB = L
@@ -322,3 +327,49 @@ def boxqp(H, g, lower, upper, x0=None):
     nfree = lib().oboxqp(as_f64p(res), as_f64p(R), as_i32p(idx), as_f64p(_f(H).reshape(-1)), as_f64p(_f(g)), n,
                          as_f64p(_f(lower)), as_f64p(_f(upper)))
     return nfree, res, idx[:max(nfree, 0)]
+
+
+def transition_fd(pm, pt, states, times, actions, eps=1e-6, centered=0, mocap=None):
+    """ModelDerivatives::Compute: A (T,ndx,ndx), B (T,ndx,nu), C (T,nr,ndx), D (T,nr,nu)."""
+    m = pm.struct
+    T, ndx, nu, nr = len(times), 2 * m.nv, m.nu, pt.struct.num_residual
+    ph = Physics(pm)
+    if mocap is not None:
+        ph.set_state(np.zeros(m.nq), np.zeros(m.nv), 0.0, mocap)
+    A, B, Cm, D = np.zeros((T, ndx, ndx)), np.zeros((T, ndx, nu)), np.zeros((T, nr, ndx)), np.zeros((T, nr, nu))
+    states, actions = _f(states).reshape(T, -1), _f(actions).reshape(T, -1)
+    for t in range(T):
+        rc = lib().otransition_fd(pm.ptr, pt.ptr, ph.d, as_f64p(states[t]), float(times[t]), as_f64p(actions[t]), float(eps),
+                                  int(centered), as_f64p(A[t]), as_f64p(B[t]), as_f64p(Cm[t]), as_f64p(D[t]))
+        assert rc == 0
+    return A, B, Cm, D
+
+
+def cost_derivatives(pt, residual, Cm, D):
+    T, nr = residual.shape
+    ndx, nu = Cm.shape[2], D.shape[2]
+    cx, cu = np.zeros((T, ndx)), np.zeros((T, nu))
+    cxx, cxu, cuu = np.zeros((T, ndx, ndx)), np.zeros((T, ndx, nu)), np.zeros((T, nu, nu))
+    for t in range(T):
+        lib().ocost_derivatives(pt.ptr, T, ndx, nu, as_f64p(_f(residual[t])), as_f64p(_f(Cm[t])), as_f64p(_f(D[t])),
+                                as_f64p(cx[t]), as_f64p(cu[t]), as_f64p(cxx[t]), as_f64p(cxu[t]), as_f64p(cuu[t]))
+    return cx, cu, cxx, cxu, cuu
+
+
+def rollout_feedback(pm, pt, state, time, mocap, H, mode, representation, use_state, times, states, actions, gains,
+                     improvement, alpha):
+    m = pm.struct
+    N, Tn = len(alpha), len(times)
+    ds, nu, nr, ntr = m.nq + m.nv, m.nu, pt.struct.num_residual, pt.struct.num_trace
+    out = dict(total_return=np.zeros(N), failure=np.zeros(N, np.int32), states=np.zeros((N, H, ds)), actions=np.zeros((N, H, nu)),
+               times=np.zeros((N, H)), residual=np.zeros((N, H, nr)), costs=np.zeros((N, H)), trace=np.zeros((N, H, 3 * ntr)))
+    o = OBatchOut()
+    o.total_return, o.failure = as_f64p(out["total_return"]), as_i32p(out["failure"])
+    o.states, o.actions, o.times = as_f64p(out["states"]), as_f64p(out["actions"]), as_f64p(out["times"])
+    o.residual, o.costs, o.trace = as_f64p(out["residual"]), as_f64p(out["costs"]), as_f64p(out["trace"])
+    mc = None if mocap is None else as_f64p(_f(mocap))
+    arrs = [_f(x).reshape(-1) for x in (times, states, actions, gains, improvement, alpha)]
+    rc = lib().orollout_feedback(pm.ptr, pt.ptr, as_f64p(_f(state)), float(time), mc, N, H, int(mode), int(representation),
+                                 int(use_state), Tn, *[as_f64p(a) for a in arrs], C.byref(o))
+    assert rc == 0
+    return out

@@ -1,0 +1,163 @@
+"""-m gpu: device pieces of the iLQG planner vs the CPU oracle.
+   transition_fd   <-> oracle otransition_fd   (mjd_transitionFD restatement)       tol: see below
+   cost_derivatives<-> oracle ocost_derivatives (cost_derivatives.cc restatement)    1e-10 relative
+   backward_pass   <-> oracle oriccati (pinned by backward_pass_test.cc golden)      1e-9
+   rollout_feedback<-> oracle orollout_feedback                                      1e-9
+Finite differences with eps = 1e-6 amplify the ~1e-16 rounding differences between the two step
+implementations by 1/eps, so A,B,C,D agree to ~1e-9 absolute, not 1e-13."""
+import numpy as np
+import pytest
+
+from mujoco_mpc_amd import capi
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.all(np.abs(a - b) <= tol * (1 + np.abs(b)))
+
+
+def nominal(task, H, seed, state, mocap=None):
+    """a nominal trajectory from a random spline rollout on the oracle"""
+    pm, pt = task.packed_model(), task.packed()
+    P = 5
+    times = np.linspace(0, (H - 1) * pm.struct.timestep, P)
+    nodes = np.clip(np.random.default_rng(seed).normal(0, 0.5, (1, P, pm.struct.nu)), -1, 1)
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, 1, H, P, 2, times, nodes)
+    return pm, pt, {k: v[0] for k, v in ref.items()}
+
+
+@pytest.mark.parametrize("centered", [0, 1])
+def test_transition_fd(cartpole, centered):
+    H = 24
+    pm, pt, nom = nominal(cartpole, H, 1, [0.3, 2.0, 0.1, -0.5])
+    nom["actions"][3] = 1.0          # at the upper ctrl limit: forward nudge impossible -> backward difference
+    nom["actions"][4] = -1.0
+    ctx = capi.Context(pm, pt, 0, 64)
+    A, B, C, D = ctx.transition_fd(nom["times"], nom["states"], nom["actions"], 1e-6, centered)
+    Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], 1e-6, centered)
+    for g, o in ((A, Ao), (B, Bo), (C, Co), (D, Do)):
+        assert close(g, o, 2e-8), np.abs(g - o).max()
+    # structure: d(next q)/d(v) ~ h on the diagonal block; control column of the residual "Control" term is 1
+    assert np.allclose(A[:, 0, 2], 0.01, atol=2e-4) and np.allclose(D[:, 3, 0], 1.0, atol=1e-6)
+    assert abs(B[3, 2, 0]) > 0.05     # nudged backward: still a real derivative (h * gear / mass), not 0
+
+
+def test_transition_fd_particle_with_mocap(particle):
+    H = 12
+    mocap = np.array([0.2, -0.1, 0.01, 1, 0, 0, 0.0])
+    pm, pt, nom = nominal(particle, H, 2, [0.05, -0.1, 0.2, 0.1], mocap)
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(nom["states"][0], 0.0, mocap)
+    A, B, C, D = ctx.transition_fd(nom["times"], nom["states"], nom["actions"])
+    Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], mocap=mocap)
+    for g, o in ((A, Ao), (B, Bo), (C, Co), (D, Do)):
+        assert close(g, o, 2e-8)
+    assert np.allclose(C[:, :2, :2], np.eye(2), atol=1e-6)   # residual = qpos - goal
+
+
+@pytest.mark.parametrize("risk", [0.0, 0.7])
+def test_cost_derivatives(cartpole, risk):
+    import copy
+    t2 = copy.copy(cartpole); t2.risk = risk
+    H = 16
+    pm, pt, nom = nominal(t2, H, 3, [0.2, 1.0, 0.0, 0.3])
+    Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"])
+    ctx = capi.Context(pm, pt, 0, 64)
+    got = ctx.cost_derivatives(nom["residual"], Co, Do)
+    ref = pyoracle.cost_derivatives(pt, nom["residual"], Co, Do)
+    for g, o in zip(got, ref):
+        assert close(g, o, 1e-10), np.abs(g - o).max()
+    assert np.allclose(got[2], np.transpose(got[2], (0, 2, 1)), atol=1e-12)     # cxx symmetric
+
+
+def test_cost_derivatives_all_norms(particle):
+    import copy
+    H = 6
+    mocap = np.array([0.1, 0.05, 0.01, 1, 0, 0, 0.0])
+    for ntype, params in [(0, []), (1, [0.1, 2.0]), (2, [0.1]), (3, [0.5]), (5, [2.0]), (6, [0.1]), (7, [0.1, 2.0]), (8, [0.3])]:
+        t2 = copy.copy(particle)
+        t2.norm = [ntype, 6]; t2.num_norm_parameter = [len(params), 1]; t2.norm_parameter = list(params) + [0.2]
+        pm, pt, nom = nominal(t2, H, 4, [0.05, -0.1, 0.3, 0.2], mocap)
+        _, _, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], mocap=mocap)
+        ctx = capi.Context(pm, pt, 0, 64)
+        got = ctx.cost_derivatives(nom["residual"], Co, Do)
+        ref = pyoracle.cost_derivatives(pt, nom["residual"], Co, Do)
+        for g, o in zip(got, ref):
+            assert close(g, o, 1e-10), ntype
+        ctx.close()
+
+
+def random_lq(n, m, T, seed):
+    rng = np.random.default_rng(seed)
+    A = np.eye(n)[None] + 0.1 * rng.normal(size=(T, n, n))
+    B = 0.3 * rng.normal(size=(T, n, m))
+    def spd(k, scale):
+        M = rng.normal(size=(T, k, k))
+        return scale * (M @ np.transpose(M, (0, 2, 1)) / k + 0.5 * np.eye(k))
+    cxx, cuu = spd(n, 1.0), spd(m, 0.5)
+    cxu = 0.05 * rng.normal(size=(T, n, m))
+    cx, cu = rng.normal(size=(T, n)), rng.normal(size=(T, m))
+    actions = rng.uniform(-0.9, 0.9, size=(T, m))
+    limits = np.tile([-1.0, 1.0], (m, 1))
+    return A, B, cx, cu, cxx, cxu, cuu, actions, limits
+
+
+def test_backward_pass_golden_lqr(cartpole):
+    """the reference's golden vectors (backward_pass_test.cc:101-138) through the MFMA kernel"""
+    from test_oracle_riccati import lqr_problem
+    n, m, A, B, cx, cu, cxx, cxu, cuu, actions, x = lqr_problem(3)
+    ctx = capi.Context(cartpole.packed_model(), cartpole.packed(), 0, 64)
+    out = ctx.backward_pass(0.0, 0, 1, A, B, cx, cu, cxx, cxu, cuu, actions, [[-1.0, 1.0]])
+    assert out["ok"]
+    assert np.allclose(out["Vx"], [[0.0, 0.0], [0.5, 1.25], [0.5, 1.0]], atol=1e-5)
+    assert np.allclose(out["Vxx"], [[[2.71428571, 2.0], [2.0, 4.0]], [[2.0, 1.0], [1.0, 2.5]], [[1.0, 0.0], [0.0, 1.0]]], atol=1e-5)
+    assert np.allclose(out["K"][:2], [[[-0.285714285, -1.0]], [[0.0, -0.5]]], atol=1e-5)
+    assert np.allclose(out["du"][:2], [[-0.5], [-0.75]], atol=1e-5)
+
+
+@pytest.mark.parametrize("n,m,T", [(4, 1, 20), (4, 2, 11), (17, 5, 8), (36, 12, 36), (48, 16, 5)])
+@pytest.mark.parametrize("reg_type,limits", [(0, 1), (0, 0), (1, 1), (2, 1)])
+def test_backward_pass_vs_oracle(cartpole, n, m, T, reg_type, limits):
+    """(36, 12, 36) is the Quadruped iLQG shape of BASELINE configs[4]"""
+    prob = random_lq(n, m, T, seed=n * 100 + m)
+    ctx = capi.Context(cartpole.packed_model(), cartpole.packed(), 0, 64)
+    out = ctx.backward_pass(0.3, reg_type, limits, *prob)
+    ref = pyoracle.riccati(n, m, T, 0.3, reg_type, limits, *prob)
+    assert out["ok"] == ref["ok"] == True
+    for k in ("Vx", "Vxx", "K", "du", "dV"):
+        assert close(out[k], ref[k], 1e-9), (k, np.abs(out[k] - ref[k]).max())
+
+
+def test_backward_pass_reports_failure(cartpole):
+    prob = list(random_lq(6, 2, 5, 1))
+    prob[6] = -5.0 * np.abs(prob[6])                     # cuu indefinite
+    ctx = capi.Context(cartpole.packed_model(), cartpole.packed(), 0, 64)
+    assert not ctx.backward_pass(0.0, 0, 0, *prob)["ok"]
+    assert not pyoracle.riccati(6, 2, 5, 0.0, 0, 0, *prob)["ok"]
+
+
+@pytest.mark.parametrize("mode,representation,use_state", [(0, 0, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0)])
+def test_rollout_feedback(cartpole, mode, representation, use_state):
+    H = 30
+    pm, pt, nom = nominal(cartpole, H, 5, [0.1, 2.5, 0.0, 0.2])
+    rng = np.random.default_rng(7)
+    gains = 0.5 * rng.normal(size=(H, 1, 4))
+    improvement = 0.2 * rng.normal(size=(H, 1))
+    alpha = np.concatenate([np.exp(np.linspace(0, np.log(1e-3), 69)), [0.0]])        # LogScale line search, 70 candidates
+    state = [0.12, 2.45, 0.05, 0.15]                                                 # off-nominal start: feedback matters
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(state, 0.0)
+    ctx.rollout_feedback(H, mode, representation, use_state, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_feedback(pm, pt, state, 0.0, None, H, mode, representation, use_state, nom["times"], nom["states"],
+                                    nom["actions"], gains, improvement, alpha)
+    assert np.array_equal(fail, ref["failure"]) and close(ret, ref["total_return"], 1e-9)
+    for c in (0, 33, 69):
+        tr = ctx.fetch_trajectory(c)
+        for name in ("states", "actions", "times", "residual", "costs"):
+            assert close(getattr(tr, name), ref[name][c], 1e-9), (name, c)
+    if use_state:
+        assert np.ptp(ret) > 1e-6
