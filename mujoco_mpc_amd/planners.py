@@ -500,3 +500,309 @@ class GpuCrossEntropyPlanner:
 
     def num_parameters(self):
         return self.policy.num_spline_points * self.model.nu
+
+
+# ====================================================================================== iLQG
+def log_scale(max_value, min_value, steps):
+    """LogScale, mjpc/utilities.cc:819-826 (ascending from min_value to max_value)."""
+    step = (np.log(max_value) - np.log(min_value)) / max(steps - 1, 1)
+    return np.exp(np.log(min_value) + np.arange(steps) * step)
+
+
+def find_interval(xs, value, length):
+    """FindInterval, mjpc/utilities.h:124-144."""
+    up = int(np.searchsorted(np.asarray(xs[:length]), value, side="right"))
+    lo = up - 1
+    if lo < 0:
+        return 0, 0
+    if lo > length - 1:
+        return length - 1, length - 1
+    return lo, min(up, length - 1)
+
+
+class ILQGSettings:
+    """iLQGSettings, mjpc/planners/ilqg/settings.h."""
+    min_linesearch_step = 1.0e-3
+    fd_tolerance = 1.0e-6
+    fd_mode = 0
+    min_regularization = 1.0e-6
+    max_regularization = 1.0e6
+    regularization_type = 0
+    max_regularization_iterations = 5
+    action_limits = 1
+    nominal_feedback_scaling = 1
+    verbose = 0
+
+
+class ILQGPolicy:
+    """iLQGPolicy, mjpc/planners/ilqg/policy.{h,cc}: a nominal trajectory + time-varying linear feedback."""
+
+    def __init__(self, model, task, horizon_cap=K_MAX_TRAJECTORY_HORIZON):
+        self.model = model
+        nu, ds, ndx = model.nu, model.nq + model.nv + model.na, 2 * model.nv + model.na
+        self.trajectory = capi.Trajectory(ds, nu, task.num_residual, task.num_trace, horizon_cap)
+        self.feedback_gain = np.zeros((horizon_cap, nu, ndx))
+        self.action_improvement = np.zeros((horizon_cap, nu))
+        self.feedback_scaling = 1.0
+        self.representation = int(model.get_number("ilqg_representation", 1))
+
+    def reset(self, horizon, initial_repeated_action=None):
+        tr = self.trajectory
+        for a in (tr.states, tr.times, tr.residual, tr.costs, tr.trace):
+            a[...] = 0
+        tr.actions[...] = 0 if initial_repeated_action is None else np.asarray(initial_repeated_action)
+        tr.total_return, tr.failure = 0.0, False
+        self.feedback_gain[:horizon] = 0
+        self.action_improvement[:horizon] = 0
+        self.feedback_scaling = 1.0
+
+    def copy_from(self, other, horizon):
+        import copy
+        self.trajectory = copy.deepcopy(other.trajectory)
+        self.feedback_gain[:horizon] = other.feedback_gain[:horizon]
+        self.action_improvement[:horizon] = other.action_improvement[:horizon]
+
+    @staticmethod
+    def _interp(x, xs, ys, length, zero):
+        b0, b1 = find_interval(xs, x, length)
+        if zero or b0 == b1:
+            return ys[b0].copy()
+        t = (x - xs[b0]) / (xs[b1] - xs[b0])
+        return ys[b0] * (1.0 - t) + ys[b1] * t
+
+    def action(self, action, state, time):
+        """policy.cc:82-161 (zero-order / linear representations)."""
+        tr, H = self.trajectory, self.trajectory.horizon
+        b0, b1 = find_interval(tr.times, time, H)
+        zero = b0 == b1 or self.representation == 0
+        if self.representation == 2 and not zero:
+            raise NotImplementedError("cubic iLQG policy representation")
+        action[:] = self._interp(time, tr.times, tr.actions, H - 1, zero)
+        if state is not None:
+            xi = self._interp(time, tr.times, tr.states, H, zero)
+            K = self._interp(time, tr.times, self.feedback_gain, H - 1, zero)
+            action += self.feedback_scaling * (K @ (np.asarray(state, float) - xi))   # StateDiff with nq == nv
+        return clamp(action, self.model.actuator_ctrlrange)
+
+
+class GpuILQGPlanner:
+    """mjpc::iLQGPlanner (mjpc/planners/ilqg/planner.{h,cc}) with every data-parallel piece on the GPU:
+    feedback / line-search rollouts (mjpcx_rollout_feedback), finite-difference model derivatives
+    (mjpcx_transition_fd), cost derivatives (mjpcx_cost_derivatives) and the Riccati sweep on the matrix
+    cores (mjpcx_backward_pass). Host side: the regularisation schedule, BestRollout, policy bookkeeping."""
+
+    def __init__(self, device=0, precision=64, backend_factory=None):
+        self.device, self.precision = device, precision
+        self._backend_factory = backend_factory
+        self.settings = ILQGSettings()
+        self.mtx_ = threading.RLock()
+
+    def initialize(self, model, task: Task):
+        self.model, self.task = model, task
+        self.dim_state = model.nq + model.nv + model.na
+        self.dim_state_derivative = 2 * model.nv + model.na
+        self.dim_action = model.nu
+        self.num_rollouts_gui_ = int(model.get_number("ilqg_num_rollouts", 10))
+        self.settings.regularization_type = int(model.get_number("ilqg_regularization_type", self.settings.regularization_type))
+        self.num_trajectory_ = self.num_rollouts_gui_
+
+    def allocate(self):
+        m = self.model
+        self.state = np.zeros(self.dim_state)
+        self.mocap = np.zeros(7 * m.nmocap)
+        self.userdata = np.zeros(m.nuserdata)
+        self.time = 0.0
+        self.policy = ILQGPolicy(m, self.task)
+        self.previous_policy = ILQGPolicy(m, self.task)
+        self.candidate0 = ILQGPolicy(m, self.task)          # candidate_policy[0]
+        self.ctx = (self._backend_factory(self.task) if self._backend_factory
+                    else capi.Context(self.task.packed_model(), self.task.packed(), self.device, self.precision))
+
+    def reset(self, horizon, initial_repeated_action=None):
+        self.state[:] = 0; self.mocap[:] = 0; self.userdata[:] = 0
+        self.time = 0.0
+        for p in (self.policy, self.previous_policy, self.candidate0):
+            p.reset(horizon, initial_repeated_action)
+        # iLQGBackwardPass::Reset, backward_pass.cc:50-62
+        self.regularization, self.regularization_rate, self.regularization_factor = 1.0, 1.0, 2.0
+        self.dV = np.zeros(2)
+        self.action_step = self.feedback_scaling = self.improvement = self.expected = self.surprise = 0.0
+        self.derivative_skip_ = int(self.model.get_number("derivative_skip", 0))
+        self.winner = 0
+        self.timers = {}
+
+    def set_state(self, state: State):
+        self.state, self.mocap, self.userdata, self.time = state.copy_to()
+
+    # ---- backward_pass.cc:327-356
+    def scale_regularization(self, factor, reg_min, reg_max):
+        if factor > 1:
+            self.regularization_rate = max(self.regularization_rate * factor, factor)
+        else:
+            self.regularization_rate = min(self.regularization_rate * factor, factor)
+        self.regularization = min(max(self.regularization * self.regularization_rate, reg_min), reg_max)
+
+    def update_regularization(self, reg_min, reg_max, z, s):
+        bad = lambda v: not np.isfinite(v) or abs(v) > 1e10
+        f = self.regularization_factor
+        if bad(z) or bad(s):
+            self.scale_regularization(f * f, reg_min, reg_max)
+        elif z > 0.5 or s > 0.3:
+            self.scale_regularization(1.0 / f, reg_min, reg_max)
+        elif z < 0.1 or s < 0.06:
+            self.scale_regularization(f, reg_min, reg_max)
+
+    def _linesearch_steps(self):
+        n = self.num_trajectory_
+        steps = np.zeros(n)
+        steps[:n - 1] = log_scale(1.0, self.settings.min_linesearch_step, n - 1)
+        steps[n - 1] = 0.0
+        return steps
+
+    @staticmethod
+    def best_rollout(returns, failure):
+        """iLQGPlanner::BestRollout, planner.cc:727-740 (scan from the last index, strict <)."""
+        best, best_return = -1, 0.0
+        for j in range(len(returns) - 1, -1, -1):
+            if failure[j]:
+                continue
+            if best == -1 or returns[j] < best_return:
+                best, best_return = j, returns[j]
+        return best
+
+    # ---- OptimizePolicy, planner.cc:156-164
+    def optimize_policy(self, horizon, pool=None):
+        self.num_trajectory_ = self.num_rollouts_gui_       # the reference clamps to kMaxTrajectory = 128 (lifted)
+        self.nominal_trajectory(horizon)
+        self.iteration(horizon)
+
+    # ---- NominalTrajectory, planner.cc:167-223 + FeedbackRollouts :695-724
+    def nominal_trajectory(self, horizon, pool=None):
+        if self.num_trajectory_ == 0:
+            return
+        t0 = _time.perf_counter()
+        self.policy.trajectory.horizon = horizon
+        steps = self._linesearch_steps()
+        tr = self.policy.trajectory
+        self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
+        self.ctx.rollout_feedback(horizon, 1, self.policy.representation, self.settings.nominal_feedback_scaling,
+                                  tr.times[:horizon], tr.states[:horizon], tr.actions[:horizon],
+                                  self.policy.feedback_gain[:horizon], self.policy.action_improvement[:horizon], steps)
+        ret, fail = self.ctx.returns()
+        best = self.best_rollout(ret, fail)
+        if best == -1:
+            import copy
+            self.candidate0.trajectory = copy.deepcopy(self.policy.trajectory)
+            self.feedback_scaling = 0.0
+        else:
+            self._take_trajectory(self.candidate0, best, horizon)
+            self.feedback_scaling = steps[best]
+        self.candidate0.feedback_gain[:horizon] = self.policy.feedback_gain[:horizon]
+        self.candidate0.action_improvement[:horizon] = self.policy.action_improvement[:horizon]
+        self.candidate0.representation = self.policy.representation
+        self.timers["nominal"] = (_time.perf_counter() - t0) * 1e6
+
+    def _take_trajectory(self, policy, index, horizon):
+        """candidate_policy[0].trajectory = trajectory[index] (buffers keep their allocated capacity)."""
+        got = self.ctx.fetch_trajectory(index)
+        tr = policy.trajectory
+        for name in ("states", "actions", "times", "residual", "costs", "trace"):
+            getattr(tr, name)[:horizon] = getattr(got, name)
+        tr.horizon, tr.total_return, tr.failure = horizon, got.total_return, got.failure
+
+    # ---- ModelDerivatives::Compute incl. skip + interpolation, model_derivatives.cc:45-165
+    def _model_derivatives(self, tr, T):
+        s = self.derivative_skip_ + 1
+        evaluate = [0] + list(range(s, T - s, s)) + [T - 2, T - 1]
+        evaluate = sorted(set(e for e in evaluate if 0 <= e < T))
+        A, B, C, D = self.ctx.transition_fd(tr.times[evaluate], tr.states[evaluate], tr.actions[evaluate],
+                                            self.settings.fd_tolerance, int(self.settings.fd_mode))
+        if len(evaluate) == T:
+            return A, B, C, D
+        full = [np.zeros((T,) + x.shape[1:]) for x in (A, B, C, D)]
+        ev = np.array(evaluate)
+        for t in range(T):
+            k = int(np.searchsorted(ev, t, side="right")) - 1
+            e0 = k
+            e1 = min(k + 1, len(ev) - 1)
+            tt = 0.0 if (ev[e0] == t or e0 == e1) else (t - ev[e0]) / (ev[e1] - ev[e0])
+            for f, x in zip(full, (A, B, C, D)):
+                f[t] = x[e0] * (1.0 - tt) + x[e1] * tt
+        return full
+
+    # ---- Iteration, planner.cc:377-627
+    def iteration(self, horizon, pool=None):
+        st = self.settings
+        c0 = self.candidate0
+        tr = c0.trajectory
+        T, n, m = horizon, self.dim_state_derivative, self.dim_action
+        previous_return = tr.total_return
+        steps = self._linesearch_steps()
+        t0 = _time.perf_counter()
+        A, B, C, D = self._model_derivatives(tr, T)
+        # the last step has no transition (model_derivatives.cc:88-92 computes only C there)
+        A[T - 1] = 0; B[T - 1] = 0; D[T - 1] = 0
+        self.timers["model_derivative"] = (_time.perf_counter() - t0) * 1e6
+        t0 = _time.perf_counter()
+        cx, cu, cxx, cxu, cuu = self.ctx.cost_derivatives(tr.residual[:T], C, D)
+        self.timers["cost_derivative"] = (_time.perf_counter() - t0) * 1e6
+        # ---- backward pass with regularisation retries, planner.cc:429-520
+        t0 = _time.perf_counter()
+        ok, reg_iter = False, 0
+        limits = np.asarray(self.model.actuator_ctrlrange, float).reshape(-1, 2)
+        while reg_iter < st.max_regularization_iterations and not ok:
+            out = self.ctx.backward_pass(self.regularization, st.regularization_type, st.action_limits, A, B, cx, cu, cxx,
+                                         cxu, cuu, tr.actions[:T], limits)
+            ok = out["ok"]
+            if not ok and self.regularization <= st.max_regularization:
+                self.scale_regularization(self.regularization_factor, st.min_regularization, st.max_regularization)
+                reg_iter += 1
+            elif not ok:
+                break
+        self.timers["backward_pass"] = (_time.perf_counter() - t0) * 1e6
+        if not ok:
+            return
+        self.dV = out["dV"]
+        c0.feedback_gain[:T] = out["K"]
+        c0.action_improvement[:T] = out["du"]
+        # ---- ActionRollouts, planner.cc:630-692: line search over the improvement step
+        t0 = _time.perf_counter()
+        self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
+        self.ctx.rollout_feedback(T, 0, 0, 1, tr.times[:T], tr.states[:T], tr.actions[:T], c0.feedback_gain[:T],
+                                  c0.action_improvement[:T], steps)
+        ret, fail = self.ctx.returns()
+        best = self.best_rollout(ret, fail)
+        if best == -1:
+            return
+        self.winner = best
+        # candidate_policy[winner]: the nominal trajectory with actions += step * improvement (NOT re-rolled)
+        import copy
+        winner_policy = ILQGPolicy.__new__(ILQGPolicy)
+        winner_policy.__dict__ = dict(c0.__dict__)
+        winner_policy.trajectory = copy.deepcopy(c0.trajectory)
+        winner_policy.trajectory.actions[:T] = tr.actions[:T] + steps[best] * c0.action_improvement[:T]
+        self._take_trajectory(c0, best, T)
+        if best == 0:
+            winner_policy.trajectory = copy.deepcopy(c0.trajectory)
+        self.action_step = steps[best]
+        self.expected = -1.0 * self.action_step * (self.dV[0] + self.action_step * self.dV[1]) + 1.0e-16
+        self.improvement = previous_return - float(ret[best])
+        self.surprise = min(max(0.0, self.improvement / self.expected), 2.0)
+        self.update_regularization(st.min_regularization, st.max_regularization, self.surprise, self.action_step)
+        self.timers["rollouts"] = (_time.perf_counter() - t0) * 1e6
+        with self.mtx_:
+            self.previous_policy.copy_from(self.policy, T)
+            self.previous_policy.feedback_scaling = self.policy.feedback_scaling
+            self.policy.copy_from(winner_policy, T)
+            self.policy.feedback_scaling = 1.0
+
+    def action_from_policy(self, action, state, time, use_previous=False):
+        with self.mtx_:
+            return (self.previous_policy if use_previous else self.policy).action(action, state, time)
+
+    def best_trajectory(self):
+        with self.mtx_:
+            return self.policy.trajectory
+
+    def num_parameters(self):
+        return self.dim_action * K_MAX_TRAJECTORY_HORIZON

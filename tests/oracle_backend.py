@@ -65,5 +65,21 @@ class OracleContext:
         tr.total_return, tr.failure = float(self.out["total_return"][i]), bool(self.out["failure"][i])
         return tr
 
+    # ---- iLQG
+    def rollout_feedback(self, horizon, mode, representation, use_state, times, states, actions, gains, improvement, alpha):
+        self.N, self.H, self.P = len(alpha), horizon, 0
+        self.out = pyoracle.rollout_feedback(self.pm, self.pt, self.state, self.time, self.mocap, horizon, mode, representation,
+                                             use_state, times, states, actions, gains, improvement, alpha)
+
+    def transition_fd(self, times, states, actions, eps=1e-6, centered=0):
+        return pyoracle.transition_fd(self.pm, self.pt, states, times, actions, eps, centered, mocap=self.mocap)
+
+    def cost_derivatives(self, residual, Cm, D):
+        return pyoracle.cost_derivatives(self.pt, np.asarray(residual), np.asarray(Cm), np.asarray(D))
+
+    def backward_pass(self, mu, reg_type, use_limits, A, B, cx, cu, cxx, cxu, cuu, actions, limits):
+        T, n, m = A.shape[0], A.shape[1], B.shape[2]
+        return pyoracle.riccati(n, m, T, mu, reg_type, use_limits, A, B, cx, cu, cxx, cxu, cuu, actions, limits)
+
     def sync(self):
         pass
