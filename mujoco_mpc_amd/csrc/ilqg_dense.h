@@ -185,24 +185,48 @@ __global__ __launch_bounds__(64) void cost_derivatives_kernel(const CostSpec cs,
 // M, N, K are the LOGICAL sizes; out-of-range operand elements read as zero, out-of-range results are dropped.
 // v_mfma_f64_16x16x4_f64 fragment layout (gfx950): A: lane l holds A[i = l&15][k = l>>4]; B: B[k = l>>4][j = l&15];
 // C/D: 4 regs per lane, reg r -> row (l>>4) + 4r, col l&15.
-__device__ __forceinline__ void wave_gemm(double* Cm, int ldc, const double* Am, int lda, bool transA, const double* Bm,
-                                          int ldb, int M, int N, int K, const double* Dm, int ldd, int lane) {
+// The operands are LDS pointers by TYPE (address space 3): ds_read/ds_write whatever the inliner decides.
+// KSTEPS = ceil(Kmax / 4): ALL operand fragments of an output tile are fetched first (2*KSTEPS independent LDS
+// reads, one wait), then the MFMAs issue back to back; a read pair per MFMA would expose the LDS latency KSTEPS
+// times per tile. Returns the advanced tile counter (16x16 output tiles are dealt round-robin over the waves).
+typedef __attribute__((address_space(3))) double lds_f64;
+#define MJPCX_LDS(p) ((lds_f64*)(p))
+template <int KSTEPS>
+__device__ __forceinline__ int wave_gemm(lds_f64* Cm, int ldc, const lds_f64* Am, int lda, bool transA, const lds_f64* Bm,
+                                         int ldb, int M, int N, int K, const lds_f64* Dm, int ldd, int lane, int wave = 0,
+                                         int nwave = 1, int tile = 0) {
   const int li = lane & 15, lk = lane >> 4;
+  const int astep = transA ? lda : 1;
   for (int ti = 0; ti < M; ti += 16)
     for (int tj = 0; tj < N; tj += 16) {
+      if ((tile++) % nwave != wave) continue;
       v4f64 acc = {0, 0, 0, 0};
-      for (int k0 = 0; k0 < K; k0 += 4) {
-        const int i = ti + li, k = k0 + lk, j = tj + li;
-        const double av = (i < M && k < K) ? (transA ? Am[k * lda + i] : Am[i * lda + k]) : 0.0;
-        const double bv = (k < K && j < N) ? Bm[k * ldb + j] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      const int i = ti + li, j = tj + li;
+      const bool iv = i < M, jv = j < N;
+      const int ic = iv ? i : M - 1, jc = jv ? j : N - 1;  // clamped: every lane reads a valid address
+      const lds_f64* ap = transA ? Am + ic : Am + ic * lda;
+      const lds_f64* bp = Bm + jc;
+      double av[KSTEPS], bv[KSTEPS];
+      int aoff = lk * astep, boff = lk * ldb;
+#pragma unroll
+      for (int u = 0; u < KSTEPS; u++) {
+        const bool kv = 4 * u + lk < K;
+        av[u] = ap[kv ? aoff : 0];
+        bv[u] = bp[kv ? boff : 0];
+        if (!(iv && kv)) av[u] = 0.0;
+        if (!(jv && kv)) bv[u] = 0.0;
+        aoff += 4 * astep; boff += 4 * ldb;
       }
 #pragma unroll
+      for (int u = 0; u < KSTEPS; u++)
+        if (4 * u < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
       for (int rg = 0; rg < 4; rg++) {
-        const int i = ti + lk + 4 * rg, j = tj + li;
-        if (i < M && j < N) Cm[i * ldc + j] = acc[rg] + (Dm ? Dm[i * ldd + j] : 0.0);
+        const int ci = ti + lk + 4 * rg;
+        if (ci < M && jv) Cm[ci * ldc + j] = acc[rg] + (Dm ? Dm[ci * ldd + j] : 0.0);
       }
     }
+  return tile;
 }
 
 // ---------------------------------------------------------------- serial helpers (one lane)
@@ -295,6 +319,305 @@ __device__ inline int boxqp_serial(double* res, double* R, int* index, const dou
   return nfree;
 }
 
+// ---------------------------------------------------------------- wave-cooperative small dense algebra (m <= 16)
+// Matrices live in LDS with leading dimension 16; lane i < m owns ROW i of wave 0; dependent phases are separated
+// by wave_sync() (in-order DS execution within a wave), never by a workgroup barrier.
+// Clamped (box-constrained) coordinates are handled by MASKING instead of compressing: their row/column of the
+// Hessian is replaced by the identity and their right-hand side by zero, which yields exactly the free-subspace
+// solution of mju_boxQP with zeros at the clamped coordinates.
+// LDS ordering point inside ONE wavefront: DS operations of a wave execute in order, so only the compiler has to
+// be stopped from moving LDS accesses across it (no s_barrier: the other waves of the workgroup are not involved)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_sum16(double v, int lane) {  // sum over lanes 0..15 (others contribute 0)
+  v = lane < 16 ? v : 0.0;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+// in-place Cholesky of the masked matrix L (ld 16); returns false if a pivot is not positive
+__device__ __forceinline__ bool coop_chol16(double* L, int m, int lane) {
+  bool ok = true;
+  for (int j = 0; j < m; j++) {
+    if (lane == j) {
+      double s = L[j * 16 + j];
+      for (int k = 0; k < j; k++) s -= L[j * 16 + k] * L[j * 16 + k];
+      L[j * 16 + j] = s > 1e-15 ? sqrt(s) : -1.0;
+    }
+    wave_sync();
+    const double d = L[j * 16 + j];
+    if (d < 0) { ok = false; break; }
+    if (lane > j && lane < m) {
+      double v = L[lane * 16 + j];
+      for (int k = 0; k < j; k++) v -= L[lane * 16 + k] * L[j * 16 + k];
+      L[lane * 16 + j] = v / d;
+    }
+    wave_sync();
+  }
+  return ok;
+}
+// x = (L L')^-1 b for one right-hand side held in LDS (x, length m); lanes 0..m-1 cooperate
+__device__ __forceinline__ void coop_solve16(double* x, const double* L, int m, int lane) {
+  for (int j = 0; j < m; j++) {  // forward
+    if (lane == j) x[j] /= L[j * 16 + j];
+    wave_sync();
+    if (lane > j && lane < m) x[lane] -= L[lane * 16 + j] * x[j];
+    wave_sync();
+  }
+  for (int j = m - 1; j >= 0; j--) {  // backward
+    if (lane == j) x[j] /= L[j * 16 + j];
+    wave_sync();
+    if (lane < j) x[lane] -= L[j * 16 + lane] * x[j];
+    wave_sync();
+  }
+}
+// mju_boxQP (projected Newton), cooperative: res in/out (LDS, m), H (LDS ld 16), g/lower/upper (LDS).
+// On return Lm holds the Cholesky factor of the masked Hessian and free_mask the free set. Returns nfree or -1.
+__device__ __forceinline__ int coop_boxqp16(double* res, double* Lm, unsigned* free_mask, const double* H, const double* g, int m,
+                                             const double* lower, const double* upper, double* work, int lane) {
+  double* search = work;       // [16]
+  double* cand = work + 16;    // [16]
+  int nfree = 0;
+  if (lane < m) res[lane] = fmin(fmax(res[lane], lower[lane]), upper[lane]);
+  wave_sync();
+  double oldvalue = 0;
+  for (int iter = 0; iter < 100; iter++) {
+    double hx = 0, xi = 0, gi = 0;
+    if (lane < m) {
+      xi = res[lane]; gi = g[lane];
+      for (int k = 0; k < m; k++) hx += H[lane * 16 + k] * res[k];
+    }
+    const double value = wave_sum16(0.5 * xi * hx + gi * xi, lane);
+    if (iter > 0 && (oldvalue - value) < 1e-8 * fabs(oldvalue)) break;  // no further relative improvement
+    oldvalue = value;
+    const double grad = hx + gi;
+    const bool clamped = lane < m && ((xi <= lower[lane] && grad > 0) || (xi >= upper[lane] && grad < 0));
+    const bool is_free = lane < m && !clamped;
+    const unsigned long long fm = __ballot(is_free);
+    *free_mask = (unsigned)fm;
+    nfree = __popcll(fm);
+    if (nfree == 0) break;
+    // masked Hessian and its factor
+    if (lane < m)
+      for (int k = 0; k < m; k++) {
+        const bool fk = (fm >> k) & 1;
+        Lm[lane * 16 + k] = (is_free && fk) ? H[lane * 16 + k] : (lane == k ? 1.0 : 0.0);
+      }
+    wave_sync();
+    if (!coop_chol16(Lm, m, lane)) return -1;
+    const double gn = wave_sum16(is_free ? grad * grad : 0.0, lane);
+    if (sqrt(gn) < 1e-16) break;
+    // Newton step in the free subspace: rhs = -(g + H x_clamped) on free rows, 0 on clamped rows
+    if (lane < m) {
+      double s = 0;
+      for (int k = 0; k < m; k++) s += ((fm >> k) & 1) ? 0.0 : H[lane * 16 + k] * res[k];
+      search[lane] = is_free ? -(gi + s) : 0.0;
+    }
+    wave_sync();
+    coop_solve16(search, Lm, m, lane);
+    const double sd = (lane < m && is_free) ? search[lane] - xi : 0.0;
+    const double sdotg = wave_sum16(sd * grad, lane);
+    if (sdotg >= 0) break;
+    double step = 1;
+    bool ok = false;
+    while (step > 1e-22) {
+      if (lane < m) cand[lane] = fmin(fmax(xi + step * sd, lower[lane]), upper[lane]);
+      wave_sync();
+      double hc = 0, ci = 0;
+      if (lane < m) {
+        ci = cand[lane];
+        for (int k = 0; k < m; k++) hc += H[lane * 16 + k] * cand[k];
+      }
+      const double vc = wave_sum16(0.5 * ci * hc + gi * ci, lane);
+      if ((vc - value) / (step * sdotg) >= 0.1) { ok = true; break; }
+      step *= 0.5;
+      wave_sync();
+    }
+    if (!ok) break;
+    wave_sync();
+    if (lane < m) res[lane] = cand[lane];
+    wave_sync();
+  }
+  return nfree;
+}
+
+// ---- register-resident variants (wave 0): lane i < 16 keeps ROW i of the m x m matrix in 16 registers; values of
+// other rows arrive through v_readlane (uniform source lane), so a factorisation costs no LDS round trips at all
+__device__ __forceinline__ double bcast_lane(double v, int src) {  // src must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// in-place Cholesky; on exit row[k], k <= lane, holds L[lane][k]. Same operation order as the left-looking serial
+// algorithm (each entry has its products subtracted for k = 0, 1, ...). Returns false on a non-positive pivot.
+__device__ __forceinline__ bool reg_chol16(double (&row)[16], int m, int lane) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    if (j < m && ok) {
+      const double djj = bcast_lane(row[j], j);
+      if (!(djj > 1e-15)) {
+        ok = false;
+      } else {
+        const double d = sqrt(djj);
+        const double lij = lane == j ? d : row[j] / d;
+        row[j] = lij;
+#pragma unroll
+        for (int k = j + 1; k < 16; k++) {
+          if (k < m) {
+            const double lkj = bcast_lane(lij, k);
+            if (lane >= k) row[k] -= lij * lkj;
+          }
+        }
+      }
+    }
+  }
+  return ok;
+}
+// x = (L L')^-1 b; row[k] = L[lane][k], col[k] = L[k][lane]; b is this lane's right-hand side entry
+__device__ __forceinline__ double reg_solve16(const double (&row)[16], const double (&col)[16], double b, int m, int lane) {
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    if (j < m) {
+      const double yj = bcast_lane(b, j) / bcast_lane(row[j], j);
+      b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
+    }
+  }
+#pragma unroll
+  for (int j = 15; j >= 0; j--) {
+    if (j < m) {
+      const double xj = bcast_lane(b, j) / bcast_lane(row[j], j);
+      b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
+    }
+  }
+  return b;
+}
+// L rows (registers) -> LDS (ld 16) -> L columns (registers)
+__device__ __forceinline__ void reg_transpose16(double (&col)[16], const double (&row)[16], double* lds, int lane) {
+  if (lane < 16) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[lane * 16 + k] = row[k];
+  }
+  wave_sync();
+#pragma unroll
+  for (int k = 0; k < 16; k++) col[k] = lane < 16 ? lds[k * 16 + lane] : 0.0;
+}
+__device__ __forceinline__ double reg_matvec16(const double (&row)[16], double x, int m, int lane) {
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) if (k < m) s += row[k] * bcast_lane(x, k);
+  return lane < m ? s : 0.0;
+}
+// mju_boxQP (projected Newton) with everything in registers. res: this lane's coordinate (in/out, warm start);
+// Hrow: row of H; on return Lrow/Lcol hold the factor of the masked Hessian of the last evaluated free set (also left
+// in Llds, ld 16) and fmask that free set. Returns nfree or -1 (factorisation failed).
+// boxed == false is the unconstrained branch of the backward pass (one factorisation, res = -H^-1 g): it shares this
+// body so that the unrolled Cholesky and triangular solves exist ONCE in the instruction stream.
+__device__ __forceinline__ int reg_boxqp16(double& res, double (&Lrow)[16], unsigned& fmask, const double (&Hrow)[16], double gi,
+                                            int m, double lower, double upper, double* Llds, int lane, bool boxed) {
+  int nfree = 0;
+  if (boxed) res = lane < m ? fmin(fmax(res, lower), upper) : 0.0;
+  double oldvalue = 0;
+  double Lcol[16];
+  unsigned long long prev_fm = 0;
+  for (int iter = 0; iter < 100; iter++) {
+    const double xi = res;
+    double value = 0, grad = 0;
+    bool is_free = lane < m;
+    if (boxed) {
+      const double hx = reg_matvec16(Hrow, xi, m, lane);
+      value = wave_sum16(0.5 * xi * hx + gi * xi, lane);
+      grad = hx + gi;
+      const bool clamped = lane < m && ((xi <= lower && grad > 0) || (xi >= upper && grad < 0));
+      is_free = lane < m && !clamped;
+    }
+    const unsigned long long fm = __ballot(is_free);
+    fmask = (unsigned)fm;
+    nfree = __popcll(fm);
+    if (nfree == 0) break;
+    if (iter == 0 || fm != prev_fm) {  // re-factorise only when the clamped set changed
+#pragma unroll
+      for (int k = 0; k < 16; k++) Lrow[k] = (is_free && ((fm >> k) & 1)) ? Hrow[k] : (lane == k ? 1.0 : 0.0);
+      if (!reg_chol16(Lrow, m, lane)) return -1;
+      wave_sync();
+      reg_transpose16(Lcol, Lrow, Llds, lane);
+      prev_fm = fm;
+    }
+    double rhs = -gi;
+    if (boxed) {
+      if (iter > 0 && (oldvalue - value) < 1e-8 * fabs(oldvalue)) break;  // no further relative improvement
+      oldvalue = value;
+      const double gn = wave_sum16(is_free ? grad * grad : 0.0, lane);
+      if (sqrt(gn) < 1e-16) break;
+      // Newton step in the free subspace: rhs = -(g + H x_clamped) on free rows, 0 on clamped rows
+      double sc = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) if (k < m && !((fm >> k) & 1)) sc += Hrow[k] * bcast_lane(xi, k);
+      rhs = is_free ? -(gi + sc) : 0.0;
+    }
+    const double search = reg_solve16(Lrow, Lcol, rhs, m, lane);
+    if (!boxed) { res = search; break; }
+    const double sd = is_free ? search - xi : 0.0;
+    const double sdotg = wave_sum16(sd * grad, lane);
+    if (sdotg >= 0) break;
+    double step = 1, ci = 0;
+    bool ok = false;
+    while (step > 1e-22) {
+      ci = lane < m ? fmin(fmax(xi + step * sd, lower), upper) : 0.0;
+      const double hc = reg_matvec16(Hrow, ci, m, lane);
+      const double vc = wave_sum16(0.5 * ci * hc + gi * ci, lane);
+      if ((vc - value) / (step * sdotg) >= 0.1) { ok = true; break; }
+      step *= 0.5;
+    }
+    if (!ok) break;
+    res = ci;
+  }
+  return nfree;
+}
+
+// ---- strided global <-> LDS block moves for one wave: no integer division in the loop, four independent
+// global accesses in flight per lane (a one-element-per-iteration loop exposes the full HBM latency each time)
+template <int MODE>  // 0: dst = src, 1: dst += src (global -> LDS); 2: LDS -> global
+__device__ __forceinline__ void wave_block_move(double* lds, int ld, double* glob, int rows, int cols, int lane, int nthr = 64) {
+  const int total = rows * cols;
+  int e = lane, r = lane / cols, c = lane % cols;
+  while (e < total) {
+    double v[4];
+    int rr[4], cc[4], cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (e < total) {
+        rr[u] = r; cc[u] = c; cnt = u + 1;
+        if (MODE != 2) v[u] = glob[e];
+        e += nthr; r += nthr / cols; c += nthr % cols;
+        if (c >= cols) { c -= cols; r++; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (u < cnt) {
+        if (MODE == 0) lds[rr[u] * ld + cc[u]] = v[u];
+        else if (MODE == 1) lds[rr[u] * ld + cc[u]] += v[u];
+        else glob[rr[u] * cols + cc[u]] = lds[rr[u] * ld + cc[u]];
+      }
+    }
+  }
+}
+// f(row, col) over a rows x cols index space, one element per thread per trip, without integer division per element
+template <class F>
+__device__ __forceinline__ void block_for_each(int rows, int cols, int tid, int nthr, F f) {
+  const int total = rows * cols, dr = nthr / cols, dc = nthr % cols;
+  int r = tid / cols, c = tid % cols;
+  for (int e = tid; e < total; e += nthr) {
+    f(r, c);
+    r += dr; c += dc;
+    if (c >= cols) { c -= cols; r++; }
+  }
+}
+
 struct BackwardArgs {
   int n, m, T;
   double mu;
@@ -302,165 +625,234 @@ struct BackwardArgs {
   const double *A, *B, *cx, *cu, *cxx, *cxu, *cuu, *actions, *limits;
   double *Vx, *Vxx, *K, *du, *dV;
   int* status;  // 1 ok, 0 failed (Quu not PD at some step)
+  long long* stamps;  // optional: 16 phase timestamps of the first step (s_memtime), for tuning
 };
 
-// ONE wavefront walks the horizon backwards. LDS carve (doubles), NP = n rounded up to 16 (row stride):
-//   W[NP*NP] Wx[NP] At[NP*NP] Bt[NP*16] tmp[NP*NP] tmp2[16*NP] Qxx[NP*NP] Qxu[NP*16] Quu[256] Qxur[NP*16] Quur[256]
-//   Qx[NP] Qu[16] Kt[16*NP] dut[16] + box-QP scratch
-__global__ __launch_bounds__(64) void backward_pass_kernel(const BackwardArgs a) {
+constexpr int kBackwardWaves = 4;
+constexpr int kBackwardThreads = 64 * kBackwardWaves;
+// contiguous global -> registers -> LDS staging, K elements per thread (total <= K * kBackwardThreads)
+template <int K>
+__device__ __forceinline__ void flat_load(double (&v)[K], const double* g, int total, int tid) {
+#pragma unroll
+  for (int k = 0; k < K; k++) { const int e = tid + k * kBackwardThreads; v[k] = g[e < total ? e : total - 1]; }
+}
+template <int K>
+__device__ __forceinline__ void flat_store(double* l, const double (&v)[K], int total, int tid) {
+#pragma unroll
+  for (int k = 0; k < K; k++) { const int e = tid + k * kBackwardThreads; if (e < total) l[e] = v[k]; }
+}
+
+// ONE workgroup of 4 wavefronts walks the horizon backwards (the recursion is sequential in t). Per step the
+// MFMA tiles of the GEMMs and all element-wise phases are spread over the 256 threads; the m x m (m <= 16)
+// factorisation / box-QP runs register-resident on wave 0 while the others wait at the next barrier. The inputs of
+// step t-1 (A, B, c*) are fetched into registers while step t computes, so HBM latency is off the critical path.
+// All LDS matrices are DENSE (leading dimension = their column count), which makes every staging copy flat:
+//   W[n*n] Wx[n] At[n*n] Bt[n*m] tmp[n*n] tmp2[m*n] Qxx[n*n] Qxu[n*m] Quu[m*m] Quur[m*m] Qx[n] Qu[m]
+//   Kt[m*n] KQ[m*n] dut[m] qsum[m] L[16*16] cxl[n] cul[m] actl[m] lim[2m]      (carved with NP = 16*ceil(n/16), 16)
+__global__ __launch_bounds__(kBackwardThreads) void backward_pass_kernel(const BackwardArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int n = a.n, m = a.m, T = a.T, lane = threadIdx.x;
+  const int n = a.n, m = a.m, T = a.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = kBackwardWaves, NT = kBackwardThreads;
   const int NP = (n + 15) & ~15, MP = 16;
+  const int nn = n * n, nm = n * m, mm = m * m;
   double* W = reinterpret_cast<double*>(smem_raw);
   double* Wx = W + NP * NP; double* At = Wx + NP; double* Bt = At + NP * NP; double* tmp = Bt + NP * MP;
   double* tmp2 = tmp + NP * NP; double* Qxx = tmp2 + MP * NP; double* Qxu = Qxx + NP * NP; double* Quu = Qxu + NP * MP;
   double* Qxur = Quu + MP * MP; double* Quur = Qxur + NP * MP; double* Qx = Quur + MP * MP; double* Qu = Qx + NP;
-  double* Kt = Qu + MP; double* dut = Kt + MP * NP; double* boxres = dut + MP; double* boxR = boxres + MP;
-  double* lo = boxR + MP * (MP + 7); double* hi = lo + MP; double* scratch = hi + MP;  // 5*MP
-  double* Hc = scratch + 5 * MP;  // compact m x m copy of Quu_reg
-  double* KQ = Hc + MP * MP;      // MP x NP: Quu K
-  __shared__ int index[16];
-  __shared__ int nfree_s, ok_s;
+  double* Kt = Qu + MP; double* KQ = Kt + MP * NP; double* dut = KQ + MP * NP; double* qsum = dut + MP;
+  double* Llds = qsum + MP; double* cxl = Llds + MP * MP; double* cul = cxl + NP; double* actl = cul + MP;
+  double* lim = actl + MP;  // 2*MP
+  __shared__ unsigned fmask_s;
+  __shared__ int ok_s;
   __shared__ double dV0, dV1;
-  if (lane == 0) { dV0 = 0; dV1 = 0; ok_s = 1; }
-  for (int i = lane; i < MP; i += 64) boxres[i] = 0;  // BoxQP::res warm start, reset per sweep
+  if (tid == 0) { dV0 = 0; dV1 = 0; ok_s = 1; }
+  double boxres = 0;  // BoxQP::res warm start (wave 0, lane i), reset per sweep
   // terminal condition: V = c at T-1
-  for (int e = lane; e < n * n; e += 64) W[(e / n) * NP + e % n] = a.cxx[(size_t)(T - 1) * n * n + e];
-  for (int i = lane; i < n; i += 64) Wx[i] = a.cx[(size_t)(T - 1) * n + i];
-  for (int e = lane; e < n * n; e += 64) a.Vxx[(size_t)(T - 1) * n * n + e] = a.cxx[(size_t)(T - 1) * n * n + e];
-  for (int i = lane; i < n; i += 64) a.Vx[(size_t)(T - 1) * n + i] = a.cx[(size_t)(T - 1) * n + i];
-  __syncthreads();
+  for (int e = tid; e < nn; e += NT) { const double v = a.cxx[(size_t)(T - 1) * nn + e]; W[e] = v; a.Vxx[(size_t)(T - 1) * nn + e] = v; }
+  for (int i = tid; i < n; i += NT) { const double v = a.cx[(size_t)(T - 1) * n + i]; Wx[i] = v; a.Vx[(size_t)(T - 1) * n + i] = v; }
+  for (int i = tid; i < 2 * m; i += NT) lim[i] = a.limits[i];
+  // register staging of the next step's inputs
+  double rA[9], rB[3], rCxx[9], rCxu[3], rCuu[1], rCx[1], rCu[1], rAct[1];
+  auto prefetch = [&](int t) {
+    flat_load(rA, a.A + (size_t)t * nn, nn, tid);
+    flat_load(rB, a.B + (size_t)t * nm, nm, tid);
+    flat_load(rCxx, a.cxx + (size_t)t * nn, nn, tid);
+    flat_load(rCxu, a.cxu + (size_t)t * nm, nm, tid);
+    flat_load(rCuu, a.cuu + (size_t)t * mm, mm, tid);
+    flat_load(rCx, a.cx + (size_t)t * n, n, tid);
+    flat_load(rCu, a.cu + (size_t)t * m, m, tid);
+    flat_load(rAct, a.actions + (size_t)t * m, m, tid);
+  };
+  prefetch(T - 2);
+#define MJPCX_STAMP(k) do { if (a.stamps && t == T - 3 && tid == 0) a.stamps[k] = (long long)__builtin_readcyclecounter(); } while (0)
   for (int t = T - 2; t >= 0; t--) {
-    const double* Ag = a.A + (size_t)t * n * n; const double* Bg = a.B + (size_t)t * n * m;
-    const double* cxg = a.cx + (size_t)t * n; const double* cug = a.cu + (size_t)t * m;
-    const double* cxxg = a.cxx + (size_t)t * n * n; const double* cxug = a.cxu + (size_t)t * n * m;
-    const double* cuug = a.cuu + (size_t)t * m * m;
-    for (int e = lane; e < n * n; e += 64) At[(e / n) * NP + e % n] = Ag[e];
-    for (int e = lane; e < n * m; e += 64) Bt[(e / m) * MP + e % m] = Bg[e];
+    MJPCX_STAMP(0);
+    // the cost Hessians land directly in the Qxx/Qxu/Quu buffers: they are the "D" operand of the GEMMs below
+    flat_store(At, rA, nn, tid); flat_store(Bt, rB, nm, tid); flat_store(Qxx, rCxx, nn, tid); flat_store(Qxu, rCxu, nm, tid);
+    flat_store(Quu, rCuu, mm, tid); flat_store(cxl, rCx, n, tid); flat_store(cul, rCu, m, tid); flat_store(actl, rAct, m, tid);
     __syncthreads();
-    // tmp = A' W ; Qxx = tmp A + cxx ; Qxu = tmp B + cxu ; tmp2 = B' W ; Quu = tmp2 B + cuu   (matrix cores)
-    wave_gemm(tmp, NP, At, NP, true, W, NP, n, n, n, nullptr, 0, lane);
-    __syncthreads();
-    wave_gemm(Qxx, NP, tmp, NP, false, At, NP, n, n, n, nullptr, 0, lane);
-    wave_gemm(Qxu, MP, tmp, NP, false, Bt, MP, n, m, n, nullptr, 0, lane);
-    wave_gemm(tmp2, NP, Bt, MP, true, W, NP, m, n, n, nullptr, 0, lane);
-    __syncthreads();
-    wave_gemm(Quu, MP, tmp2, NP, false, Bt, MP, m, m, n, nullptr, 0, lane);
-    __syncthreads();
-    for (int e = lane; e < n * n; e += 64) Qxx[(e / n) * NP + e % n] += cxxg[e];
-    for (int e = lane; e < n * m; e += 64) Qxu[(e / m) * MP + e % m] += cxug[e];
-    for (int e = lane; e < m * m; e += 64) Quu[(e / m) * MP + e % m] += cuug[e];
-    for (int i = lane; i < n; i += 64) { double s = cxg[i]; for (int k = 0; k < n; k++) s += At[k * NP + i] * Wx[k]; Qx[i] = s; }
-    for (int i = lane; i < m; i += 64) { double s = cug[i]; for (int k = 0; k < n; k++) s += Bt[k * MP + i] * Wx[k]; Qu[i] = s; }
-    __syncthreads();
-    // ---- regularisation
-    if (a.reg_type == 2) {  // value: recompute with W + mu I
-      for (int i = lane; i < n; i += 64) W[i * NP + i] += a.mu;
-      __syncthreads();
-      wave_gemm(tmp, NP, At, NP, true, W, NP, n, n, n, nullptr, 0, lane);
-      wave_gemm(tmp2, NP, Bt, MP, true, W, NP, m, n, n, nullptr, 0, lane);
-      __syncthreads();
-      wave_gemm(Qxur, MP, tmp, NP, false, Bt, MP, n, m, n, nullptr, 0, lane);
-      wave_gemm(Quur, MP, tmp2, NP, false, Bt, MP, m, m, n, nullptr, 0, lane);
-      __syncthreads();
-      for (int e = lane; e < n * m; e += 64) Qxur[(e / m) * MP + e % m] += cxug[e];
-      for (int e = lane; e < m * m; e += 64) Quur[(e / m) * MP + e % m] += cuug[e];
-      for (int i = lane; i < n; i += 64) W[i * NP + i] -= a.mu;
-    } else {
-      for (int e = lane; e < n * m; e += 64) Qxur[(e / m) * MP + e % m] = Qxu[(e / m) * MP + e % m];
-      for (int e = lane; e < m * m; e += 64) Quur[(e / m) * MP + e % m] = Quu[(e / m) * MP + e % m];
-      __syncthreads();
-      if (a.mu != 0 && a.reg_type == 0) {
-        for (int i = lane; i < m; i += 64) Quur[i * MP + i] += a.mu;
-      } else if (a.mu != 0 && a.reg_type == 1) {
-        wave_gemm(tmp, MP, At, NP, true, Bt, MP, n, m, n, nullptr, 0, lane);   // A'B (n x m) into tmp (ld MP)
-        wave_gemm(tmp2, MP, Bt, MP, true, Bt, MP, m, m, n, nullptr, 0, lane);  // B'B (m x m)
-        __syncthreads();
-        for (int e = lane; e < n * m; e += 64) Qxur[(e / m) * MP + e % m] += a.mu * tmp[(e / m) * MP + e % m];
-        for (int e = lane; e < m * m; e += 64) Quur[(e / m) * MP + e % m] += a.mu * tmp2[(e / m) * MP + e % m];
+    if (t > 0) prefetch(t - 1);
+    MJPCX_STAMP(1);
+    // tmp = A' W ; tmp2 = B' W ; Qxx = tmp A + cxx ; Qxu = tmp B + cxu ; Quu = tmp2 B + cuu   (matrix cores)
+    int tc = 0;
+    tc = wave_gemm<12>(MJPCX_LDS(tmp), n, MJPCX_LDS(At), n, true, MJPCX_LDS(W), n, n, n, n, nullptr, 0, lane, wave, NW, tc);
+    tc = wave_gemm<12>(MJPCX_LDS(tmp2), n, MJPCX_LDS(Bt), m, true, MJPCX_LDS(W), n, m, n, n, nullptr, 0, lane, wave, NW, tc);
+    // Qx = cx + A' Vx ; Qu = cu + B' Vx
+    if (wave == NW - 1) {  // the last wave has the fewest GEMM tiles
+      const int i = lane;  // n + m <= 64
+      if (i < n) {
+        double sx = cxl[i];
+#pragma unroll 4
+        for (int k = 0; k < n; k++) sx += At[k * n + i] * Wx[k];
+        Qx[i] = sx;
+      } else if (i < n + m) {
+        const int u = i - n;
+        double su = cul[u];
+#pragma unroll 4
+        for (int k = 0; k < n; k++) su += Bt[k * m + u] * Wx[k];
+        Qu[u] = su;
       }
     }
     __syncthreads();
-    // ---- du and K
-    for (int e = lane; e < m * n; e += 64) Kt[(e / n) * NP + e % n] = 0;
-    for (int e = lane; e < m * m; e += 64) Hc[e] = Quur[(e / m) * MP + e % m];
+    tc = 0;
+    tc = wave_gemm<12>(MJPCX_LDS(Qxx), n, MJPCX_LDS(tmp), n, false, MJPCX_LDS(At), n, n, n, n, MJPCX_LDS(Qxx), n, lane, wave, NW, tc);
+    tc = wave_gemm<12>(MJPCX_LDS(Qxu), m, MJPCX_LDS(tmp), n, false, MJPCX_LDS(Bt), m, n, m, n, MJPCX_LDS(Qxu), m, lane, wave, NW, tc);
+    tc = wave_gemm<12>(MJPCX_LDS(Quu), m, MJPCX_LDS(tmp2), n, false, MJPCX_LDS(Bt), m, m, m, n, MJPCX_LDS(Quu), m, lane, wave, NW, tc);
     __syncthreads();
-    if (lane == 0) {
-      int ok = 1;
-      if (a.use_limits) {
-        for (int i = 0; i < m; i++) { lo[i] = a.limits[2 * i] - a.actions[(size_t)t * m + i]; hi[i] = a.limits[2 * i + 1] - a.actions[(size_t)t * m + i]; }
-        const int mf = boxqp_serial(boxres, boxR, index, Hc, Qu, m, lo, hi, scratch);
-        if (mf < 0) ok = 0;
-        nfree_s = mf < 0 ? 0 : mf;
-        for (int i = 0; i < m; i++) dut[i] = boxres[i];
-      } else {
-        for (int e = 0; e < m * m; e++) boxR[e] = Hc[e];
-        if (chol_factor_serial(boxR, m) < m) ok = 0;
-        for (int i = 0; i < m; i++) index[i] = i;
-        nfree_s = m;
-        if (ok) { chol_solve_serial(dut, boxR, Qu, m); for (int i = 0; i < m; i++) dut[i] = -dut[i]; }
+    MJPCX_STAMP(2);
+    // ---- regularisation
+    if (a.reg_type == 2) {  // value: recompute with W + mu I
+      for (int i = tid; i < n; i += NT) W[i * n + i] += a.mu;
+      __syncthreads();
+      tc = 0;
+      tc = wave_gemm<12>(MJPCX_LDS(tmp2), n, MJPCX_LDS(Bt), m, true, MJPCX_LDS(W), n, m, n, n, nullptr, 0, lane, wave, NW, tc);
+      __syncthreads();
+      // + cxu / cuu: recovered as (unregularised Q) - (unregularised product) would lose bits; re-read them instead
+      const double* cuug = a.cuu + (size_t)t * mm;
+      for (int e = tid; e < mm; e += NT) Quur[e] = cuug[e];
+      for (int i = tid; i < n; i += NT) W[i * n + i] -= a.mu;
+      __syncthreads();
+      tc = 0;
+      tc = wave_gemm<12>(MJPCX_LDS(Quur), m, MJPCX_LDS(tmp2), n, false, MJPCX_LDS(Bt), m, m, m, n, MJPCX_LDS(Quur), m, lane, wave, NW, tc);
+    } else {
+      for (int e = tid; e < mm; e += NT) Quur[e] = Quu[e];
+      if (a.mu != 0 && a.reg_type == 1) {
+        tc = 0;
+        tc = wave_gemm<12>(MJPCX_LDS(tmp2), m, MJPCX_LDS(Bt), m, true, MJPCX_LDS(Bt), m, m, m, n, nullptr, 0, lane, wave, NW, tc);  // B'B (m x m)
+        __syncthreads();
+        const double mu = a.mu;
+        for (int e = tid; e < mm; e += NT) Quur[e] += mu * tmp2[e];
+      } else if (a.mu != 0 && a.reg_type == 0) {
+        __syncthreads();
+        for (int i = tid; i < m; i += NT) Quur[i * m + i] += a.mu;
       }
-      if (!ok) ok_s = 0;
+    }
+    __syncthreads();
+    MJPCX_STAMP(3);
+    // ---- du (wave 0, register-resident: lane i owns row i of the m x m problem)
+    if (wave == 0) {
+      double Hrow[16], Lrow[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) Hrow[k] = (lane < m && k < m) ? Quur[(lane < m ? lane : 0) * m + (k < m ? k : 0)] : (lane == k ? 1.0 : 0.0);
+      const double qu = lane < m ? Qu[lane] : 0.0;
+      unsigned fmask = (1u << m) - 1u;
+      const bool boxed = a.use_limits != 0;
+      const double act = (boxed && lane < m) ? actl[lane] : 0.0;
+      const double lo = (boxed && lane < m) ? lim[2 * lane] - act : 0.0, hi = (boxed && lane < m) ? lim[2 * lane + 1] - act : 0.0;
+      double x0 = boxed ? boxres : 0.0;
+      const int mf = reg_boxqp16(x0, Lrow, fmask, Hrow, qu, m, lo, hi, Llds, lane, boxed);
+      if (boxed) boxres = x0;
+      const bool ok = mf >= 0;
+      const double du_i = lane < m ? x0 : 0.0;
+      if (ok) {
+        if (mf == 0 && lane < 16) {  // everything clamped: identity factor, K = 0
+#pragma unroll
+          for (int k = 0; k < 16; k++) Llds[lane * 16 + k] = lane == k ? 1.0 : 0.0;
+        }
+        if (lane < m) dut[lane] = du_i;
+        // dV and Quu du + Qu
+        double quu_row[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) quu_row[k] = (lane < m && k < m) ? Quu[(lane < m ? lane : 0) * m + (k < m ? k : 0)] : 0.0;
+        const double qd = reg_matvec16(quu_row, du_i, m, lane);
+        if (lane < m) qsum[lane] = qd + qu;
+        const double d0 = wave_sum16(lane < m ? du_i * qu : 0.0, lane), d1 = wave_sum16(lane < m ? 0.5 * du_i * qd : 0.0, lane);
+        if (lane == 0) { dV0 += d0; dV1 += d1; }
+      }
+      if (lane == 0) { fmask_s = fmask; if (!ok) ok_s = 0; }
     }
     __syncthreads();
     if (!ok_s) break;
-    {  // K_free = -H_ff^-1 Qux_free: one lane per state column j
-      const int mf = nfree_s;
-      for (int j = lane; j < n; j += 64) {
-        double rhs[16], sol[16];
-        for (int i = 0; i < mf; i++) rhs[i] = Qxu[j * MP + index[i]];
-        chol_solve_serial(sol, boxR, rhs, mf);
-        for (int i = 0; i < mf; i++) Kt[index[i] * NP + j] = -sol[i];
+    MJPCX_STAMP(4);
+    {
+      // K = -H_masked^-1 Qux with the UNregularised Qxu, as backward_pass.cc:176-206 does (Qxu_reg is computed there
+      // but never used, so it is not computed here); rows of clamped controls are zero. One thread per state column, unrolled to 16 so
+      // that the per-thread solution vector stays in registers; L is read from LDS (broadcast across lanes)
+      const unsigned fmask = fmask_s;
+      for (int j = tid; j < n; j += NT) {
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = (i < m && ((fmask >> i) & 1)) ? Qxu[j * m + i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          if (i < m) {
+            double v = x[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) v -= Llds[i * 16 + k] * x[k];
+            x[i] = v / Llds[i * 16 + i];
+          }
+        }
+#pragma unroll
+        for (int i = 15; i >= 0; i--) {
+          if (i < m) {
+            double v = x[i];
+#pragma unroll
+            for (int k = i + 1; k < 16; k++) if (k < m) v -= Llds[k * 16 + i] * x[k];
+            x[i] = v / Llds[i * 16 + i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) if (i < m) Kt[i * n + j] = -x[i];
       }
     }
     __syncthreads();
+    MJPCX_STAMP(5);
     // ---- cost-to-go update
-    if (lane == 0) {
-      double d0 = 0, d1 = 0;
-      for (int i = 0; i < m; i++) {
-        double s = 0;
-        for (int k = 0; k < m; k++) s += Quu[i * MP + k] * dut[k];
-        scratch[i] = s + Qu[i];  // Quu du + Qu
-        d0 += dut[i] * Qu[i];
-        d1 += 0.5 * dut[i] * s;
-      }
-      dV0 += d0; dV1 += d1;
-    }
-    wave_gemm(KQ, NP, Quu, MP, false, Kt, NP, m, n, m, nullptr, 0, lane);  // Quu K  (m x n)
-    __syncthreads();
+    tc = 0;
+    tc = wave_gemm<4>(MJPCX_LDS(KQ), n, MJPCX_LDS(Quu), m, false, MJPCX_LDS(Kt), n, m, n, m, nullptr, 0, lane, wave, NW, tc);  // Quu K  (m x n)
+    tc = wave_gemm<4>(MJPCX_LDS(W), n, MJPCX_LDS(Qxu), m, false, MJPCX_LDS(Kt), n, n, n, m, nullptr, 0, lane, wave, NW, tc);   // Qxu K -> W (the old W is dead now)
     // Vx = Qx + K'(Quu du + Qu) + Qxu du
-    for (int i = lane; i < n; i += 64) {
-      double s = Qx[i];
-      for (int k = 0; k < m; k++) s += Kt[k * NP + i] * scratch[k] + Qxu[i * MP + k] * dut[k];
-      Wx[i] = s;
-    }
-    // Vxx = Qxx + K'(Quu K) + Qxu K + (Qxu K)'
-    wave_gemm(tmp, NP, Kt, NP, true, KQ, NP, n, n, m, Qxx, NP, lane);      // Qxx + K' Quu K
-    wave_gemm(W, NP, Qxu, MP, false, Kt, NP, n, n, m, nullptr, 0, lane);   // Qxu K -> W (the old W is dead now)
-    __syncthreads();
-    for (int e = lane; e < n * n; e += 64) {
-      const int i = e / n, j = e % n;
-      tmp[i * NP + j] += W[i * NP + j] + W[j * NP + i];
+    for (int i = tid; i < n; i += NT) {
+      double sv = Qx[i];
+      for (int k = 0; k < m; k++) sv += Kt[k * n + i] * qsum[k] + Qxu[i * m + k] * dut[k];
+      Wx[i] = sv;
     }
     __syncthreads();
-    for (int e = lane; e < n * n; e += 64) {  // mju_symmetrize
-      const int i = e / n, j = e % n;
-      W[i * NP + j] = 0.5 * (tmp[i * NP + j] + tmp[j * NP + i]);
-    }
+    tc = 0;
+    tc = wave_gemm<4>(MJPCX_LDS(tmp), n, MJPCX_LDS(Kt), n, true, MJPCX_LDS(KQ), n, n, n, m, MJPCX_LDS(Qxx), n, lane, wave, NW, tc);      // Qxx + K' Quu K
     __syncthreads();
+    // Vxx = sym(Qxx + K'(Quu K) + Qxu K + (Qxu K)') (mju_symmetrize), written into the Qxx buffer, which then
+    // becomes W for the next step (pointer swap)
+    block_for_each(n, n, tid, NT, [&](int i, int j) {
+      const double tij = tmp[i * n + j] + W[i * n + j] + W[j * n + i], tji = tmp[j * n + i] + W[j * n + i] + W[i * n + j];
+      Qxx[i * n + j] = 0.5 * (tij + tji);
+    });
+    { double* sw = W; W = Qxx; Qxx = sw; }
+    __syncthreads();
+    MJPCX_STAMP(6);
     // ---- write step t
-    for (int e = lane; e < n * n; e += 64) a.Vxx[(size_t)t * n * n + e] = W[(e / n) * NP + e % n];
-    for (int i = lane; i < n; i += 64) a.Vx[(size_t)t * n + i] = Wx[i];
-    for (int e = lane; e < m * n; e += 64) a.K[(size_t)t * m * n + e] = Kt[(e / n) * NP + e % n];
-    for (int i = lane; i < m; i += 64) a.du[(size_t)t * m + i] = dut[i];
-    __syncthreads();
+    for (int e = tid; e < nn; e += NT) a.Vxx[(size_t)t * nn + e] = W[e];
+    for (int i = tid; i < n; i += NT) a.Vx[(size_t)t * n + i] = Wx[i];
+    for (int e = tid; e < nm; e += NT) a.K[(size_t)t * nm + e] = Kt[e];
+    for (int i = tid; i < m; i += NT) a.du[(size_t)t * m + i] = dut[i];
+    MJPCX_STAMP(7);
   }
   __syncthreads();
   if (ok_s && T > 1) {  // backward_pass.cc:297-306: the last index repeats T-2
-    for (int e = lane; e < m * n; e += 64) a.K[(size_t)(T - 1) * m * n + e] = a.K[(size_t)(T - 2) * m * n + e];
-    for (int i = lane; i < m; i += 64) a.du[(size_t)(T - 1) * m + i] = a.du[(size_t)(T - 2) * m + i];
+    for (int e = tid; e < nm; e += NT) a.K[(size_t)(T - 1) * nm + e] = a.K[(size_t)(T - 2) * nm + e];
+    for (int i = tid; i < m; i += NT) a.du[(size_t)(T - 1) * m + i] = a.du[(size_t)(T - 2) * m + i];
   }
-  if (lane == 0) { a.dV[0] = dV0; a.dV[1] = dV1; *a.status = ok_s; }
+  if (tid == 0) { a.dV[0] = dV0; a.dV[1] = dV1; *a.status = ok_s; }
 }
 
 }  // namespace mjpcx

@@ -1114,7 +1114,7 @@ int mjpcx_backward_pass(mjpcx_ctx* c, int n, int m, int T, double mu, int reg_ty
   if ((rc = upload_arrays<double>(c, c->d_ilqg, {{A, sT * sn * sn}, {B, sT * sn * sm}, {cx, sT * sn}, {cu, sT * sm}, {cxx, sT * sn * sn},
                                                  {cxu, sT * sn * sm}, {cuu, sT * sm * sm}, {actions, sT * sm}, {limits, 2 * sm}}, &d)) != MJPCX_OK)
     return rc;
-  const size_t n_out = sT * (sn + sn * sn + sm * sn + sm) + 2 + 2;
+  const size_t n_out = sT * (sn + sn * sn + sm * sn + sm) + 2 + 2 + 16;
   HIPCHK(c, c->d_ilqg_out.reserve(n_out * 8));
   double* o = (double*)c->d_ilqg_out.p;
   BackwardArgs a{};
@@ -1122,6 +1122,7 @@ int mjpcx_backward_pass(mjpcx_ctx* c, int n, int m, int T, double mu, int reg_ty
   a.A = d[0]; a.B = d[1]; a.cx = d[2]; a.cu = d[3]; a.cxx = d[4]; a.cxu = d[5]; a.cuu = d[6]; a.actions = d[7]; a.limits = d[8];
   a.Vx = o; a.Vxx = a.Vx + sT * sn; a.K = a.Vxx + sT * sn * sn; a.du = a.K + sT * sm * sn; a.dV = a.du + sT * sm;
   a.status = (int*)(a.dV + 2);
+  a.stamps = getenv("MJPCX_STAMPS") ? (long long*)(a.dV + 4) : nullptr;
   const int NP = (n + 15) & ~15;
   const size_t lds = (size_t)(5 * NP * NP + 2 * NP + 6 * NP * 16 + 5 * 256 + 16 * 23 + 16 * 12) * 8;
   hipEvent_t e0, e1;
@@ -1129,7 +1130,7 @@ int mjpcx_backward_pass(mjpcx_ctx* c, int n, int m, int T, double mu, int reg_ty
   HIPCHK(c, hipEventCreate(&e1));
   HIPCHK(c, hipFuncSetAttribute((const void*)backward_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(c, hipEventRecord(e0, c->stream));
-  hipLaunchKernelGGL(backward_pass_kernel, dim3(1), dim3(64), lds, c->stream, a);
+  hipLaunchKernelGGL(backward_pass_kernel, dim3(1), dim3(64 * kBackwardWaves), lds, c->stream, a);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipMemcpyAsync(Vx, a.Vx, sT * sn * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1141,6 +1142,12 @@ int mjpcx_backward_pass(mjpcx_ctx* c, int n, int m, int T, double mu, int reg_ty
   HIPCHK(c, hipMemcpyAsync(&st, a.status, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *status = st;
+  if (a.stamps) {
+    long long h[9];
+    (void)hipMemcpy(h, a.stamps, sizeof h, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "backward_pass phase cycles (second step): stage %lld gemm %lld reg %lld du/qp %lld Kcols %lld update %lld write %lld\n",
+                 h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6]);
+  }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
   if (kernel_ms) *kernel_ms = ms;

@@ -81,10 +81,22 @@ int oboxqp(double* res, double* R, int* index, const double* H, const double* g,
   double *search = grad + n, *cand = search + n, *tmp = cand + n, *rhs = tmp + n;
   int nfree = 0;
   for (int i = 0; i < n; i++) res[i] = res[i] < lower[i] ? lower[i] : (res[i] > upper[i] ? upper[i] : res[i]);
+  double oldvalue = 0;
   for (int iter = 0; iter < maxiter; iter++) {
     mat_vec(tmp, H, res, n, n);
     double value = 0;
     for (int i = 0; i < n; i++) { value += 0.5 * res[i] * tmp[i] + g[i] * res[i]; grad[i] = tmp[i] + g[i]; }
+    if (iter > 0 && (oldvalue - value) < 1e-8 * fabs(oldvalue)) { /* minimum relative improvement (boxQP.m) */
+      /* free set of the final point, for the caller's K computation */
+      nfree = 0;
+      for (int i = 0; i < n; i++)
+        if (!((res[i] <= lower[i] && grad[i] > 0) || (res[i] >= upper[i] && grad[i] < 0))) index[nfree++] = i;
+      for (int a = 0; a < nfree; a++)
+        for (int b = 0; b < nfree; b++) R[a * nfree + b] = H[index[a] * n + index[b]];
+      if (nfree && chol_factor(R, nfree) < nfree) { free(grad); return -1; }
+      break;
+    }
+    oldvalue = value;
     nfree = 0;
     for (int i = 0; i < n; i++) {
       int clamped = (res[i] <= lower[i] && grad[i] > 0) || (res[i] >= upper[i] && grad[i] < 0);
