@@ -63,6 +63,8 @@ struct mjData {
   mjtNum *qpos, *qvel, *act, *ctrl, *mocap_pos, *mocap_quat, *userdata, *sensordata;
 };
 
+#define mjMAX(a, b) (((a) > (b)) ? (a) : (b))
+#define mjMIN(a, b) (((a) < (b)) ? (a) : (b))
 inline void mju_copy(mjtNum* dst, const mjtNum* src, int n) { if (n > 0) std::memcpy(dst, src, sizeof(mjtNum) * n); }
 inline void mju_zero(mjtNum* dst, int n) { if (n > 0) std::memset(dst, 0, sizeof(mjtNum) * n); }
 inline mjtNum mju_max(mjtNum a, mjtNum b) { return a > b ? a : b; }

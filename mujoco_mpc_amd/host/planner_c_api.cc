@@ -1,9 +1,12 @@
-// planner_c_api.cc -- a thin extern "C" view of mjpc::GpuSamplingPlanner for non-C++ drivers (bench.py and the
-// pytest suite drive the C++ planner through it with ctypes; the planner logic itself stays in C++).
+// planner_c_api.cc -- a thin extern "C" view of the C++ GPU planners (mjpc::GpuSamplingPlanner,
+// mjpc::GpuCrossEntropyPlanner, mjpc::GpuILQGPlanner) for non-C++ drivers: bench.py and the pytest suite drive the
+// C++ planners through it with ctypes; the planner logic itself stays in C++.
 #include <cstring>
 #include <memory>
 #include <string>
 
+#include "mjpc/planners/gpu_cross_entropy/planner.h"
+#include "mjpc/planners/gpu_ilqg/planner.h"
 #include "mjpc/planners/gpu_sampling/planner.h"
 #include "mjpc/tasks/tasks.h"
 #include "model_io.h"
@@ -12,10 +15,14 @@ namespace {
 struct Handle {
   std::unique_ptr<mjpc::ModelStorage> storage;
   std::shared_ptr<mjpc::Task> task;
-  std::unique_ptr<mjpc::GpuSamplingPlanner> planner;
+  std::unique_ptr<mjpc::Planner> planner;
+  mjpc::GpuSamplingPlanner* ps = nullptr;       // exactly one of these three is set
+  mjpc::GpuCrossEntropyPlanner* ce = nullptr;
+  mjpc::GpuILQGPlanner* ilqg = nullptr;
   mjpc::State state;
   mjpc::ThreadPool pool{1};
   std::string error;
+  mjpc::gpu::Context* context() { return ps ? ps->context() : ce ? ce->context() : ilqg->context(); }
 };
 thread_local std::string g_error;
 }  // namespace
@@ -24,8 +31,9 @@ extern "C" {
 
 const char* mjpc_planner_last_error(void* h) { return h ? static_cast<Handle*>(h)->error.c_str() : g_error.c_str(); }
 
-void* mjpc_planner_create(const char* blob_path, const char* task_name, int device, int precision,
-                          unsigned long long seed, int num_trajectory) {
+// kind: "sampling" | "cross_entropy" | "ilqg". num_trajectory > 0 overrides the model's custom numeric.
+void* mjpc_planner_create_kind(const char* kind, const char* blob_path, const char* task_name, int device, int precision,
+                               unsigned long long seed, int num_trajectory) {
   try {
     auto h = std::make_unique<Handle>();
     h->storage = mjpc::ModelStorage::Load(blob_path);
@@ -33,9 +41,26 @@ void* mjpc_planner_create(const char* blob_path, const char* task_name, int devi
       if (t->Name() == task_name) h->task = t;
     if (!h->task) { g_error = std::string("unknown task ") + task_name; return nullptr; }
     h->task->Reset(h->storage->model());
-    h->planner = std::make_unique<mjpc::GpuSamplingPlanner>(device, precision, seed);
+    const std::string k = kind ? kind : "sampling";
+    if (k == "sampling") {
+      h->ps = new mjpc::GpuSamplingPlanner(device, precision, seed);
+      h->planner.reset(h->ps);
+    } else if (k == "cross_entropy") {
+      h->ce = new mjpc::GpuCrossEntropyPlanner(device, precision, seed);
+      h->planner.reset(h->ce);
+    } else if (k == "ilqg") {
+      h->ilqg = new mjpc::GpuILQGPlanner(device, precision);
+      h->planner.reset(h->ilqg);
+    } else {
+      g_error = "unknown planner kind " + k;
+      return nullptr;
+    }
     h->planner->Initialize(h->storage->model(), *h->task);
-    if (num_trajectory > 0) h->planner->num_trajectory_ = num_trajectory;
+    if (num_trajectory > 0) {
+      if (h->ps) h->ps->num_trajectory_ = num_trajectory;
+      if (h->ce) { h->ce->num_trajectory_ = num_trajectory; h->ce->n_elite_ = std::max(num_trajectory / 10, 2); }
+      if (h->ilqg) h->ilqg->num_rollouts_gui_ = h->ilqg->num_trajectory_ = num_trajectory;
+    }
     h->planner->Allocate();
     h->state.Allocate(h->storage->model());
     h->state.Reset();
@@ -45,6 +70,10 @@ void* mjpc_planner_create(const char* blob_path, const char* task_name, int devi
     return nullptr;
   }
 }
+void* mjpc_planner_create(const char* blob_path, const char* task_name, int device, int precision,
+                          unsigned long long seed, int num_trajectory) {
+  return mjpc_planner_create_kind("sampling", blob_path, task_name, device, precision, seed, num_trajectory);
+}
 void mjpc_planner_destroy(void* h) { delete static_cast<Handle*>(h); }
 
 #define GUARD(h, ...)                                    \
@@ -52,7 +81,11 @@ void mjpc_planner_destroy(void* h) { delete static_cast<Handle*>(h); }
   try { __VA_ARGS__; return 0; } catch (const std::exception& e) { H->error = e.what(); return -1; }
 
 int mjpc_planner_set_sharding(void* h, int rank, int world, mjpc::GpuSamplingPlanner::ExchangeFn fn, void* user) {
-  GUARD(h, H->planner->SetSharding(rank, world, fn, user));
+  GUARD(h, { if (!H->ps) throw std::runtime_error("not a sampling planner"); H->ps->SetSharding(rank, world, fn, user); });
+}
+int mjpc_planner_set_sharding_ce(void* h, int rank, int world, mjpc::GpuCrossEntropyPlanner::MergeTopkFn merge,
+                                 mjpc::GpuCrossEntropyPlanner::SumFn sum, void* user) {
+  GUARD(h, { if (!H->ce) throw std::runtime_error("not a cross-entropy planner"); H->ce->SetSharding(rank, world, merge, sum, user); });
 }
 int mjpc_planner_reset(void* h, int horizon) { GUARD(h, H->planner->Reset(horizon)); }
 int mjpc_planner_set_state(void* h, const double* qpos, const double* qvel, const double* mocap_pos,
@@ -70,17 +103,36 @@ int mjpc_planner_set_state(void* h, const double* qpos, const double* qvel, cons
   });
 }
 int mjpc_planner_optimize(void* h, int horizon) { GUARD(h, H->planner->OptimizePolicy(horizon, H->pool)); }
+int mjpc_planner_nominal(void* h, int horizon) { GUARD(h, H->planner->NominalTrajectory(horizon, H->pool)); }
+// state may be NULL (open-loop action)
 int mjpc_planner_action(void* h, double time, int use_previous, double* action) {
   GUARD(h, H->planner->ActionFromPolicy(action, nullptr, time, use_previous != 0));
 }
-int mjpc_planner_num_spline_points(void* h) { return static_cast<Handle*>(h)->planner->policy.num_spline_points; }
-int mjpc_planner_winner(void* h) { return static_cast<Handle*>(h)->planner->winner; }
-double mjpc_planner_improvement(void* h) { return static_cast<Handle*>(h)->planner->improvement; }
-double mjpc_planner_best_score(void* h) { return static_cast<Handle*>(h)->planner->CandidateScore(0); }
-// policy spline nodes: returns the node count; copies up to `cap` nodes
+int mjpc_planner_action_state(void* h, const double* state, double time, int use_previous, double* action) {
+  GUARD(h, H->planner->ActionFromPolicy(action, state, time, use_previous != 0));
+}
+int mjpc_planner_num_parameters(void* h) { return static_cast<Handle*>(h)->planner->NumParameters(); }
+int mjpc_planner_num_spline_points(void* h) {
+  Handle* H = static_cast<Handle*>(h);
+  return H->ps ? H->ps->policy.num_spline_points : H->ce ? H->ce->policy.num_spline_points : 0;
+}
+int mjpc_planner_winner(void* h) {
+  Handle* H = static_cast<Handle*>(h);
+  return H->ps ? H->ps->winner : H->ilqg ? H->ilqg->winner : (H->ce->trajectory_order.empty() ? -1 : H->ce->trajectory_order[0]);
+}
+double mjpc_planner_improvement(void* h) {
+  Handle* H = static_cast<Handle*>(h);
+  return H->ps ? H->ps->improvement : H->ce ? H->ce->improvement : H->ilqg->improvement;
+}
+double mjpc_planner_best_score(void* h) {
+  Handle* H = static_cast<Handle*>(h);
+  return H->ps ? H->ps->CandidateScore(0) : 0.0;
+}
+// policy spline nodes (sampling / cross-entropy): returns the node count; copies up to `cap` nodes
 int mjpc_planner_policy(void* h, double* times, double* values, int cap) {
   Handle* H = static_cast<Handle*>(h);
-  const auto& plan = H->planner->policy.plan;
+  if (H->ilqg) return 0;
+  const auto& plan = H->ps ? H->ps->policy.plan : H->ce->policy.plan;
   const int n = (int)plan.Size(), nu = H->storage->model()->nu;
   for (int k = 0; k < n && k < cap; k++) {
     times[k] = plan.times()[k];
@@ -88,7 +140,84 @@ int mjpc_planner_policy(void* h, double* times, double* values, int cap) {
   }
   return n;
 }
+// cross-entropy: fitted variance of the P*nu spline parameters, elite indices (global), n_elite
+int mjpc_planner_ce_variance(void* h, double* variance, int n) {
+  Handle* H = static_cast<Handle*>(h);
+  if (!H->ce) return -1;
+  for (int i = 0; i < n && i < (int)H->ce->variance.size(); i++) variance[i] = H->ce->variance[i];
+  return 0;
+}
+int mjpc_planner_ce_elites(void* h, int* index, int cap) {
+  Handle* H = static_cast<Handle*>(h);
+  if (!H->ce) return -1;
+  const int n = (int)H->ce->trajectory_order.size();
+  for (int i = 0; i < n && i < cap; i++) index[i] = H->ce->trajectory_order[i];
+  return n;
+}
+int mjpc_planner_ce_set(void* h, int n_elite, double std_initial, double std_min, double explore_fraction, int interpolation) {
+  Handle* H = static_cast<Handle*>(h);
+  if (!H->ce) return -1;
+  if (n_elite > 0) H->ce->n_elite_ = n_elite;
+  if (std_initial >= 0) H->ce->std_initial_ = std_initial;
+  if (std_min >= 0) H->ce->std_min_ = std_min;
+  if (explore_fraction >= 0) H->ce->explore_fraction_ = explore_fraction;
+  if (interpolation >= 0) H->ce->interpolation_ = (mjpc::spline::SplineInterpolation)interpolation;
+  return 0;
+}
+// iLQG: scalars out[0..9] = {regularization, dV0, dV1, action_step, feedback_scaling, improvement, expected, surprise,
+// winner, policy.trajectory.total_return}
+int mjpc_planner_ilqg_info(void* h, double* out) {
+  Handle* H = static_cast<Handle*>(h);
+  if (!H->ilqg) return -1;
+  auto* p = H->ilqg;
+  const double v[10] = {p->regularization, p->dV[0], p->dV[1], p->action_step, p->feedback_scaling, p->improvement,
+                        p->expected, p->surprise, (double)p->winner, p->policy.trajectory.total_return};
+  std::memcpy(out, v, sizeof v);
+  return 0;
+}
+int mjpc_planner_ilqg_set(void* h, int regularization_type, int action_limits, int fd_mode, int derivative_skip,
+                          int representation) {
+  Handle* H = static_cast<Handle*>(h);
+  if (!H->ilqg) return -1;
+  auto* p = H->ilqg;
+  if (regularization_type >= 0) p->settings.regularization_type = regularization_type;
+  if (action_limits >= 0) p->settings.action_limits = action_limits;
+  if (fd_mode >= 0) p->settings.fd_mode = fd_mode;
+  if (derivative_skip >= 0) p->derivative_skip_ = derivative_skip;
+  if (representation >= 0) p->policy.representation = p->previous_policy.representation = p->candidate_policy0.representation = representation;
+  return 0;
+}
+// iLQG policy arrays for T steps: actions (T x nu), states (T x dim_state), times (T), gains (T x nu x ndx)
+int mjpc_planner_ilqg_policy(void* h, int T, double* times, double* states, double* actions, double* gains) {
+  Handle* H = static_cast<Handle*>(h);
+  if (!H->ilqg) return -1;
+  const auto& p = H->ilqg->policy;
+  const int nu = H->ilqg->dim_action, ds = H->ilqg->dim_state, ndx = H->ilqg->dim_state_derivative;
+  if (times) std::memcpy(times, p.trajectory.times.data(), sizeof(double) * T);
+  if (states) std::memcpy(states, p.trajectory.states.data(), sizeof(double) * T * ds);
+  if (actions) std::memcpy(actions, p.trajectory.actions.data(), sizeof(double) * T * nu);
+  if (gains) std::memcpy(gains, p.feedback_gain.data(), sizeof(double) * T * nu * ndx);
+  return p.trajectory.horizon;
+}
+// BestTrajectory(): horizon or -1; any output may be NULL
+int mjpc_planner_best_trajectory(void* h, double* states, double* actions, double* times, double* costs, double* total_return) {
+  Handle* H = static_cast<Handle*>(h);
+  try {
+    const mjpc::Trajectory* tr = H->planner->BestTrajectory();
+    if (!tr) return -1;
+    const int T = tr->horizon;
+    if (states) std::memcpy(states, tr->states.data(), sizeof(double) * T * tr->dim_state);
+    if (actions) std::memcpy(actions, tr->actions.data(), sizeof(double) * T * tr->dim_action);
+    if (times) std::memcpy(times, tr->times.data(), sizeof(double) * T);
+    if (costs) std::memcpy(costs, tr->costs.data(), sizeof(double) * T);
+    if (total_return) *total_return = tr->total_return;
+    return T;
+  } catch (const std::exception& e) {
+    H->error = e.what();
+    return -1;
+  }
+}
 // the underlying mjpcx context (timing, algorithmic bytes, kernel name)
-mjpcx_ctx* mjpc_planner_ctx(void* h) { return static_cast<Handle*>(h)->planner->context()->handle(); }
+mjpcx_ctx* mjpc_planner_ctx(void* h) { return static_cast<Handle*>(h)->context()->handle(); }
 
 }  // extern "C"

@@ -1,4 +1,5 @@
-"""ctypes view of the C++ `mjpc::GpuSamplingPlanner` (mujoco_mpc_amd/host, planner_c_api.cc).
+"""ctypes view of the C++ planners `mjpc::GpuSamplingPlanner`, `mjpc::GpuCrossEntropyPlanner` and `mjpc::GpuILQGPlanner`
+(mujoco_mpc_amd/host, planner_c_api.cc).
 
 The planner logic (nominal resampling, policy bookkeeping, C-ABI calls) is the C++ host layer; Python
 only drives it, and -- for several ranks -- lends it a transport for the per-step candidate exchange
@@ -17,6 +18,8 @@ from .cstructs import as_f64p, c_f64p
 
 _LIB = None
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+MERGE_TOPK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double))
+SUM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 
 def lib():
@@ -30,6 +33,19 @@ def lib():
         vp = C.c_void_p
         L.mjpc_planner_create.restype = vp
         L.mjpc_planner_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_ulonglong, C.c_int]
+        L.mjpc_planner_create_kind.restype = vp
+        L.mjpc_planner_create_kind.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_ulonglong, C.c_int]
+        L.mjpc_planner_set_sharding_ce.argtypes = [vp, C.c_int, C.c_int, MERGE_TOPK_FN, SUM_FN, vp]
+        L.mjpc_planner_nominal.argtypes = [vp, C.c_int]
+        L.mjpc_planner_action_state.argtypes = [vp, c_f64p, C.c_double, C.c_int, c_f64p]
+        L.mjpc_planner_num_parameters.argtypes = [vp]
+        L.mjpc_planner_ce_variance.argtypes = [vp, c_f64p, C.c_int]
+        L.mjpc_planner_ce_elites.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
+        L.mjpc_planner_ce_set.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.mjpc_planner_ilqg_info.argtypes = [vp, c_f64p]
+        L.mjpc_planner_ilqg_set.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.mjpc_planner_ilqg_policy.argtypes = [vp, C.c_int, c_f64p, c_f64p, c_f64p, c_f64p]
+        L.mjpc_planner_best_trajectory.argtypes = [vp, c_f64p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_double)]
         L.mjpc_planner_destroy.argtypes = [vp]
         L.mjpc_planner_last_error.restype = C.c_char_p
         L.mjpc_planner_last_error.argtypes = [vp]
@@ -52,17 +68,48 @@ def lib():
 
 
 class HostPlanner:
-    def __init__(self, task, device=0, precision=64, seed=0, num_trajectory=0, group=None):
+    def __init__(self, task, device=0, precision=64, seed=0, num_trajectory=0, group=None, kind="sampling"):
         self.task = task
+        self.kind = kind
         self.nu = task.model.nu
         self._blob = tempfile.NamedTemporaryFile(suffix=".mjpx", delete=False).name
         mjcf.save_blob(task.model, self._blob)
-        self.h = lib().mjpc_planner_create(self._blob.encode(), task.name.encode(), device, precision, seed, num_trajectory)
+        self.h = lib().mjpc_planner_create_kind(kind.encode(), self._blob.encode(), task.name.encode(), device, precision, seed,
+                                                num_trajectory)
         if not self.h:
             raise RuntimeError(lib().mjpc_planner_last_error(None).decode())
         self.group = group
         self._cb = None
-        if group is not None and group.world > 1:
+        if group is not None and group.world > 1 and kind == "cross_entropy":
+            def merge(user, k, index, ret):
+                try:
+                    idx = np.ctypeslib.as_array(index, (k,))
+                    r = np.ctypeslib.as_array(ret, (k,))
+                    have = idx >= 0
+                    gi, gr = group.merge_topk(idx[have].copy(), r[have].copy(), k)
+                    idx[:] = -1
+                    r[:] = 1.0e300
+                    idx[:len(gi)] = gi
+                    r[:len(gr)] = gr
+                    return 0
+                except Exception as e:
+                    print("top-k exchange failed:", e, flush=True)
+                    return 1
+
+            def total(user, values, n):
+                try:
+                    v = np.ctypeslib.as_array(values, (n,))
+                    v[:] = group.sum_array(v.copy())
+                    return 0
+                except Exception as e:
+                    print("sum exchange failed:", e, flush=True)
+                    return 1
+            self._cb = (MERGE_TOPK_FN(merge), SUM_FN(total))
+            self._chk(lib().mjpc_planner_set_sharding_ce(self.h, group.rank, group.world, self._cb[0], self._cb[1], None))
+        elif group is not None and group.world > 1:
+            if kind != "sampling":
+                raise ValueError("the iLQG planner is not sharded (replicas only)")
+
             def exchange(user, record, spline, n):
                 try:
                     rec = np.ctypeslib.as_array(record, (3,))
@@ -108,10 +155,59 @@ class HostPlanner:
     def optimize_policy(self, horizon):
         self._chk(lib().mjpc_planner_optimize(self.h, horizon))
 
-    def action(self, time, use_previous=False):
+    def nominal_trajectory(self, horizon):
+        self._chk(lib().mjpc_planner_nominal(self.h, horizon))
+
+    def action(self, time, use_previous=False, state=None):
         a = np.zeros(self.nu)
-        self._chk(lib().mjpc_planner_action(self.h, float(time), int(use_previous), as_f64p(a)))
+        if state is None:
+            self._chk(lib().mjpc_planner_action(self.h, float(time), int(use_previous), as_f64p(a)))
+        else:
+            st = np.ascontiguousarray(state, float)
+            self._chk(lib().mjpc_planner_action_state(self.h, as_f64p(st), float(time), int(use_previous), as_f64p(a)))
         return a
+
+    # ---- cross-entropy
+    def ce_set(self, n_elite=-1, std_initial=-1.0, std_min=-1.0, explore_fraction=-1.0, interpolation=-1):
+        assert lib().mjpc_planner_ce_set(self.h, n_elite, std_initial, std_min, explore_fraction, interpolation) == 0
+
+    def ce_variance(self, n):
+        v = np.zeros(n)
+        assert lib().mjpc_planner_ce_variance(self.h, as_f64p(v), n) == 0
+        return v
+
+    def ce_elites(self, cap=65536):
+        idx = (C.c_int * cap)()
+        n = lib().mjpc_planner_ce_elites(self.h, idx, cap)
+        return np.array(idx[:n], dtype=np.int64)
+
+    # ---- iLQG
+    def ilqg_set(self, regularization_type=-1, action_limits=-1, fd_mode=-1, derivative_skip=-1, representation=-1):
+        assert lib().mjpc_planner_ilqg_set(self.h, regularization_type, action_limits, fd_mode, derivative_skip, representation) == 0
+
+    def ilqg_info(self):
+        v = np.zeros(10)
+        assert lib().mjpc_planner_ilqg_info(self.h, as_f64p(v)) == 0
+        keys = ("regularization", "dV0", "dV1", "action_step", "feedback_scaling", "improvement", "expected", "surprise",
+                "winner", "total_return")
+        return dict(zip(keys, v))
+
+    def ilqg_policy(self, T):
+        m = self.task.model
+        ds, ndx = m.nq + m.nv + m.na, 2 * m.nv + m.na
+        t, x, u, K = np.zeros(T), np.zeros((T, ds)), np.zeros((T, self.nu)), np.zeros((T, self.nu, ndx))
+        lib().mjpc_planner_ilqg_policy(self.h, T, as_f64p(t), as_f64p(x), as_f64p(u), as_f64p(K))
+        return t, x, u, K
+
+    def best_trajectory(self, cap=512):
+        m = self.task.model
+        ds = m.nq + m.nv + m.na
+        x, u, t, c = np.zeros((cap, ds)), np.zeros((cap, self.nu)), np.zeros(cap), np.zeros(cap)
+        ret = C.c_double()
+        T = lib().mjpc_planner_best_trajectory(self.h, as_f64p(x), as_f64p(u), as_f64p(t), as_f64p(c), C.byref(ret))
+        if T < 0:
+            return None
+        return dict(states=x[:T], actions=u[:T], times=t[:T], costs=c[:T], total_return=ret.value)
 
     @property
     def num_spline_points(self):

@@ -28,7 +28,7 @@ def run(exe, *args, timeout=300):
     return out.stdout
 
 
-@pytest.mark.parametrize("exe", ["spline_test", "norm_test", "trajectory_test", "threadpool_test"])
+@pytest.mark.parametrize("exe", ["spline_test", "norm_test", "trajectory_test", "threadpool_test", "utilities_test"])
 def test_cpu_suites(blobs, exe):
     assert "OK" in run(exe)
 

@@ -35,6 +35,65 @@ def test_cpp_planner_equals_python_planner(cartpole):
     assert "StaticCartpole" in cpp.kernel_name
 
 
+def test_cpp_cross_entropy_equals_python_planner(particle):
+    """mjpc::GpuCrossEntropyPlanner (C++) against planners.GpuCrossEntropyPlanner (itself checked against the numpy
+    restatement of cross_entropy/planner.cc and the oracle backend in tests/test_cross_entropy.py)."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.planners import GpuCrossEntropyPlanner, State
+    H, N = 30, 600
+    cpp = HostPlanner(particle, seed=5, num_trajectory=N, kind="cross_entropy")
+    cpp.reset(H)
+    py = GpuCrossEntropyPlanner(seed=5)
+    py.initialize(particle.model, particle); py.num_trajectory_ = N; py.n_elite_ = max(N // 10, 2); py.allocate(); py.reset(H)
+    st = State(particle.model)
+    P, nu = py.policy.num_spline_points, particle.model.nu
+    for k in range(5):
+        q, v, t = [0.02 * k, -0.05], [0.0, 0.1], 0.05 * k
+        st.set(q, v, time=t); py.set_state(st); py.optimize_policy(H)
+        cpp.set_state(q, v, t); cpp.optimize_policy(H)
+        assert list(cpp.ce_elites()) == py.trajectory_order
+        assert cpp.improvement == py.improvement
+        ct, cv = cpp.policy()
+        assert np.array_equal(ct, py.policy.plan.times()) and np.array_equal(cv, py.policy.plan.values())
+        assert np.array_equal(cpp.ce_variance(P * nu), py.variance[:P * nu])
+        a = np.zeros(nu)
+        py.action_from_policy(a, None, t + 0.013)
+        assert np.array_equal(cpp.action(t + 0.013), a)
+    bt, pt = cpp.best_trajectory(), py.best_trajectory()
+    assert bt["total_return"] == pt.total_return and np.array_equal(bt["states"], pt.states[:H])
+
+
+@pytest.mark.parametrize("limits,reg", [(1, 0), (0, 2)])
+def test_cpp_ilqg_equals_python_planner(particle, limits, reg):
+    """mjpc::GpuILQGPlanner (C++) against planners.GpuILQGPlanner (itself checked against the oracle backend in
+    tests/test_ilqg_planner.py): same device calls in the same order => identical policies."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.planners import GpuILQGPlanner, State
+    H = 25
+    cpp = HostPlanner(particle, kind="ilqg")
+    cpp.reset(H)
+    cpp.ilqg_set(regularization_type=reg, action_limits=limits)
+    py = GpuILQGPlanner()
+    py.initialize(particle.model, particle); py.allocate(); py.reset(H)
+    py.settings.regularization_type, py.settings.action_limits = reg, limits
+    st = State(particle.model)
+    for k in range(4):
+        q, v, t = [0.03 * k, -0.04], [0.1, 0.0], 0.05 * k
+        st.set(q, v, time=t); py.set_state(st); py.optimize_policy(H)
+        cpp.set_state(q, v, t); cpp.optimize_policy(H)
+        info = cpp.ilqg_info()
+        assert info["winner"] == py.winner and info["regularization"] == py.regularization
+        assert info["dV0"] == py.dV[0] and info["dV1"] == py.dV[1] and info["improvement"] == py.improvement
+        ct, cx, cu, cK = cpp.ilqg_policy(H)
+        tr = py.policy.trajectory
+        assert np.array_equal(ct, tr.times[:H]) and np.array_equal(cx, tr.states[:H]) and np.array_equal(cu, tr.actions[:H])
+        assert np.array_equal(cK, py.policy.feedback_gain[:H])
+        a = np.zeros(particle.model.nu)
+        x = np.array([0.03 * k + 0.01, -0.03, 0.1, 0.02])
+        py.action_from_policy(a, x, t + 0.013)
+        np.testing.assert_allclose(cpp.action(t + 0.013, state=x), a, rtol=1e-13, atol=1e-15)  # K dx: numpy dot vs C loop
+
+
 WORKER = r'''
 import os, sys, json
 sys.path.insert(0, %(root)r)
@@ -47,8 +106,9 @@ group = None
 if world > 1:
     dist.init_process_group(backend="gloo")
     group = RankGroup(dist, torch.device("cpu"))
+kind = os.environ.get("MJPC_TEST_KIND", "sampling")
 task = load_task("Cartpole")
-p = HostPlanner(task, device=0, seed=7, num_trajectory=1000, group=group)
+p = HostPlanner(task, device=0, seed=7, num_trajectory=1000, group=group, kind=kind)
 H = 32
 p.reset(H)
 log = []
@@ -56,7 +116,11 @@ for k in range(4):
     p.set_state([0.05 * k, 0.3], [0.0, 0.1], 0.04 * k)
     p.optimize_policy(H)
     t, v = p.policy()
-    log.append(dict(winner=p.winner, score=p.best_score, improvement=p.improvement, plan=v.tolist()))
+    rec = dict(winner=p.winner, score=p.best_score, improvement=p.improvement, plan=v.tolist())
+    if kind == "cross_entropy":
+        rec["elites"] = p.ce_elites().tolist()
+        rec["variance"] = p.ce_variance(v.size).tolist()
+    log.append(rec)
 if group is None or group.rank == 0:
     print("RESULT " + json.dumps(log))
 if group is not None:
@@ -64,9 +128,9 @@ if group is not None:
 '''
 
 
-def run(world):
+def run(world, kind="sampling"):
     script = WORKER % dict(root=ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MJPC_TEST_KIND=kind)
     cmd = [sys.executable, "-c", script] if world == 1 else [
         sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
         "127.0.0.1", "--master-port", "29544", "--no-python", sys.executable, "-c", script]
@@ -78,3 +142,13 @@ def run(world):
 def test_two_ranks_on_one_gpu_equal_one_rank():
     one, two = run(1), run(2)
     assert one == two
+
+
+def test_cross_entropy_two_ranks_on_one_gpu_equal_one_rank():
+    """elite set identical; the moments are all-reduced partial sums, so mean/variance agree to rounding"""
+    one, two = run(1, "cross_entropy"), run(2, "cross_entropy")
+    for a, b in zip(one, two):
+        assert a["elites"] == b["elites"]
+        np.testing.assert_allclose(a["plan"], b["plan"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(a["variance"], b["variance"], rtol=1e-10, atol=1e-16)
+        np.testing.assert_allclose(a["improvement"], b["improvement"], rtol=1e-10, atol=1e-14)
