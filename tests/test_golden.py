@@ -1,0 +1,93 @@
+"""Committed fixtures (tests/golden/*.npz, written by tools/make_golden.py from seeded inputs).
+
+CPU leg: the oracle must still reproduce its frozen outputs exactly-ish (1e-12: same code, same compiler flags).
+GPU leg (-m gpu): the HIP path is checked against the SAME committed vectors without running anything under oracle/.
+Tolerance for the GPU leg as in test_gpu_parity.py: |gpu - golden| <= 1e-9 (1 + |golden|), fp64."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.task import load_task
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROLLOUTS = sorted(glob.glob(os.path.join(GOLDEN, "rollout_*.npz")))
+FIELDS = ("states", "actions", "times", "residual", "costs", "trace")
+
+
+def load(path):
+    z = np.load(path)
+    i = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    o = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    return i, o
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.all(np.abs(a - b) <= tol * (1 + np.abs(b)))
+
+
+def test_fixtures_present():
+    assert len(ROLLOUTS) >= 3 and os.path.exists(os.path.join(GOLDEN, "riccati_random_lq.npz"))
+
+
+@pytest.mark.parametrize("path", ROLLOUTS, ids=[os.path.basename(p) for p in ROLLOUTS])
+def test_oracle_reproduces_golden_rollouts(path):
+    from oracle import pyoracle
+    i, o = load(path)
+    task = load_task(str(i["task"]))
+    mocap = i["mocap"] if i["mocap"].size else None
+    ref = pyoracle.rollout_batch(task.packed_model(), task.packed(), i["state"], float(i["time"]), mocap, int(i["N"]), int(i["H"]),
+                                 int(i["P"]), int(i["interp"]), i["times"], i["nodes"], num_threads=2)
+    assert np.array_equal(ref["failure"], o["failure"])
+    for k in FIELDS + ("total_return",):
+        assert close(ref[k], o[k], 1e-12), k
+
+
+def test_oracle_reproduces_golden_riccati():
+    from oracle import pyoracle
+    i, o = load(os.path.join(GOLDEN, "riccati_random_lq.npz"))
+    args = [i[k] for k in ("A", "B", "cx", "cu", "cxx", "cxu", "cuu", "actions", "limits")]
+    for lim in (0, 1):
+        for reg in (0, 1, 2):
+            r = pyoracle.riccati(int(i["n"]), int(i["m"]), int(i["T"]), float(i["mu"]), reg, lim, *args)
+            assert r["ok"]
+            for k in ("Vx", "Vxx", "K", "du", "dV"):
+                assert close(r[k], o[f"lim{lim}_reg{reg}_{k}"], 1e-12), (lim, reg, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ROLLOUTS, ids=[os.path.basename(p) for p in ROLLOUTS])
+def test_gpu_matches_golden_rollouts(path):
+    i, o = load(path)
+    task = load_task(str(i["task"]))
+    ctx = capi.Context(task.packed_model(), task.packed(), 0, 64)
+    ctx.set_state(i["state"], float(i["time"]), i["mocap"] if i["mocap"].size else None)
+    ctx.rollout_splines(int(i["H"]), int(i["interp"]), i["times"], i["nodes"])
+    ret, fail = ctx.returns()
+    assert np.array_equal(fail, o["failure"])
+    assert close(ret, o["total_return"], 1e-9)
+    for c in range(int(i["N"])):
+        tr = ctx.fetch_trajectory(c)
+        for k in FIELDS:
+            assert close(getattr(tr, k), o[k][c], 1e-9), (k, c)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden_riccati(cartpole):
+    i, o = load(os.path.join(GOLDEN, "riccati_random_lq.npz"))
+    args = [i[k] for k in ("A", "B", "cx", "cu", "cxx", "cxu", "cuu", "actions", "limits")]
+    ctx = capi.Context(cartpole.packed_model(), cartpole.packed(), 0, 64)
+    T = int(i["T"])
+    for lim in (0, 1):
+        for reg in (0, 1, 2):
+            r = ctx.backward_pass(float(i["mu"]), reg, lim, *args)
+            assert r["ok"]
+            for k in ("Vx", "Vxx", "dV"):
+                assert close(r[k], o[f"lim{lim}_reg{reg}_{k}"], 1e-9), (lim, reg, k)
+            for k in ("K", "du"):  # the oracle leaves index T-1 as a copy of T-2 too (backward_pass.cc:297-306)
+                assert close(r[k][:T - 1], o[f"lim{lim}_reg{reg}_{k}"][:T - 1], 1e-9), (lim, reg, k)
+    ctx.close()

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/*.npz: seeded inputs and the CPU oracle's outputs for the rollout path and the iLQG pieces.
+
+The reference itself cannot run in this environment (MuJoCo is a fetch-at-configure dependency), so
+these fixtures are NOT reference outputs: they freeze the oracle (whose mjpc-owned arithmetic is pinned by the
+reference's own known-answer tests, see tests/test_spline.py, test_norm_cost.py, test_oracle_riccati.py,
+test_oracle_rollout.py) so that (a) the oracle cannot drift silently and (b) the GPU box can check the HIP path against
+committed vectors without executing anything under oracle/. Re-run after an intentional oracle change:
+    python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from mujoco_mpc_amd import capi  # noqa: E402
+from mujoco_mpc_amd.task import load_task  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+ROLLOUT_CASES = {
+    # name: (task, state, time, mocap, N, H, P, interp, node-time span, seed)
+    "cartpole_cubic": ("Cartpole", [0.3, 2.7, -0.4, 0.9], 0.25, None, 24, 64, 10, capi.SPLINE_CUBIC, 0.63, 11),
+    "cartpole_zero_limit": ("Cartpole", [1.75, 3.0, 1.5, 0.0], 0.0, None, 16, 48, 3, capi.SPLINE_ZERO, 0.47, 12),
+    "particle_linear": ("Particle", [0.05, -0.1, 0.2, 0.0], 0.1, [0.15, -0.1, 0.01, 1, 0, 0, 0], 20, 40, 5, capi.SPLINE_LINEAR, 0.39, 13),
+}
+
+
+def rollout_case(name):
+    tname, state, time, mocap, N, H, P, interp, span, seed = ROLLOUT_CASES[name]
+    task = load_task(tname)
+    rng = np.random.default_rng(seed)
+    times = time + np.arange(P) * (span / max(P - 1, 1))
+    nodes = np.clip(rng.normal(0, 0.6, (N, P, task.model.nu)), -1, 1)
+    ref = pyoracle.rollout_batch(task.packed_model(), task.packed(), state, time, mocap, N, H, P, interp, times, nodes,
+                                 num_threads=1)
+    inputs = dict(task=tname, state=np.asarray(state, float), time=time,
+                  mocap=np.zeros(0) if mocap is None else np.asarray(mocap, float), N=N, H=H, P=P, interp=interp,
+                  times=times, nodes=nodes)
+    return inputs, ref
+
+
+def ilqg_case():
+    from test_gpu_ilqg import random_lq
+    n, m, T = 6, 2, 12
+    prob = random_lq(n, m, T, 5)
+    out = {}
+    for lim in (0, 1):
+        for reg in (0, 1, 2):
+            r = pyoracle.riccati(n, m, T, 0.3, reg, lim, *prob)
+            assert r["ok"]
+            for k in ("Vx", "Vxx", "K", "du", "dV"):
+                out[f"lim{lim}_reg{reg}_{k}"] = r[k]
+    names = ("A", "B", "cx", "cu", "cxx", "cxu", "cuu", "actions", "limits")
+    return dict(n=n, m=m, T=T, mu=0.3, **{k: np.asarray(v) for k, v in zip(names, prob)}), out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    pyoracle.build()
+    for name in ROLLOUT_CASES:
+        inputs, ref = rollout_case(name)
+        np.savez_compressed(os.path.join(OUT, f"rollout_{name}.npz"), **{f"in_{k}": v for k, v in inputs.items()},
+                            **{f"out_{k}": np.asarray(v) for k, v in ref.items()})
+    inputs, out = ilqg_case()
+    np.savez_compressed(os.path.join(OUT, "riccati_random_lq.npz"), **{f"in_{k}": v for k, v in inputs.items()},
+                        **{f"out_{k}": v for k, v in out.items()})
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
