@@ -58,7 +58,7 @@ enum { MJPCX_GAIN_FIXED = 0 };
 enum { MJPCX_BIAS_NONE = 0, MJPCX_BIAS_AFFINE = 1 };
 /* opt.disableflags bits used by the hot path (MuJoCo mjtDisableBit subset) */
 enum {
-  MJPCX_DSBL_CONSTRAINT = 1 << 0, MJPCX_DSBL_LIMIT = 1 << 3, MJPCX_DSBL_CONTACT = 1 << 4,
+  MJPCX_DSBL_CONSTRAINT = 1 << 0, MJPCX_DSBL_FRICTIONLOSS = 1 << 2, MJPCX_DSBL_LIMIT = 1 << 3, MJPCX_DSBL_CONTACT = 1 << 4,
   MJPCX_DSBL_PASSIVE = 1 << 5, MJPCX_DSBL_GRAVITY = 1 << 6, MJPCX_DSBL_CLAMPCTRL = 1 << 7,
   MJPCX_DSBL_ACTUATION = 1 << 10, MJPCX_DSBL_REFSAFE = 1 << 11, MJPCX_DSBL_EULERDAMP = 1 << 14,
 };
@@ -69,6 +69,7 @@ enum {
   MJPCX_RESIDUAL_PARTICLE = 1,      /* mjpc/test/testdata/particle_residual.h:33-43   */
   MJPCX_RESIDUAL_PARTICLE_COPY = 2, /* mjpc/test/agent/rollout_test.cc:37-42          */
   MJPCX_RESIDUAL_CARTPOLE = 3,      /* mjpc/tasks/cartpole/cartpole.cc:36-49          */
+  MJPCX_RESIDUAL_QUADRUPED_FLAT = 4,/* mjpc/tasks/quadruped/quadruped.cc:33-226       */
 };
 
 /* ---- flat model ("mjModel" subset, compiled) ----
@@ -138,7 +139,35 @@ typedef struct mjpcx_model {
   const double* actuator_biasprm;    /* nu x 3 */
   const double* actuator_ctrlrange;  /* nu x 2 */
   const double* actuator_forcerange; /* nu x 2 */
+  /* ---- contacts and constraint options (all zero / NULL for contact-free models) ---- */
+  int32_t ngeom;
+  int32_t nkey;
+  int32_t cone;            /* opt.cone: 0 pyramidal, 1 elliptic                */
+  double impratio;         /* opt.impratio                                     */
+  const int32_t* geom_type;        /* ngeom, MJPCX_GEOM_* (= mjtGeom)          */
+  const int32_t* geom_bodyid;      /* ngeom */
+  const int32_t* geom_contype;     /* ngeom */
+  const int32_t* geom_conaffinity; /* ngeom */
+  const int32_t* geom_condim;      /* ngeom */
+  const int32_t* geom_priority;    /* ngeom */
+  const int32_t* geom_group;       /* ngeom */
+  const double* geom_size;     /* ngeom x 3 */
+  const double* geom_pos;      /* ngeom x 3 (body frame) */
+  const double* geom_quat;     /* ngeom x 4 */
+  const double* geom_friction; /* ngeom x 3 (sliding, torsional, rolling) */
+  const double* geom_solref;   /* ngeom x 2 */
+  const double* geom_solimp;   /* ngeom x 5 */
+  const double* geom_margin;   /* ngeom */
+  const double* geom_gap;      /* ngeom */
+  const double* geom_solmix;   /* ngeom */
+  const double* body_invweight0;  /* nbody x 2 (translational, rotational) */
+  const double* body_subtreemass; /* nbody */
+  const double* dof_solref;       /* nv x 2 (friction loss) */
+  const double* dof_solimp;       /* nv x 5 */
+  const double* key_qpos;         /* nkey x nq (residuals that read keyframes) */
 } mjpcx_model;
+
+enum { MJPCX_GEOM_PLANE = 0, MJPCX_GEOM_SPHERE = 2, MJPCX_GEOM_CAPSULE = 3, MJPCX_GEOM_CYLINDER = 5, MJPCX_GEOM_BOX = 6 };
 
 /* ---- task / cost specification (mjpc::Task after Task::Reset,
  * mjpc/task.cc:147-248, plus the frozen ResidualFn copy of agent.cc:319) ---- */
@@ -157,6 +186,12 @@ typedef struct mjpcx_task {
   const double* parameters;          /* num_parameter (residual_* numerics) */
   const int32_t* trace_site;         /* num_trace: site id of sensor "trace%i" */
   double risk;                       /* Task::risk */
+  /* task-specific frozen ResidualFn state (the members Transition manages and Reset resolves, e.g.
+   * QuadrupedFlat::ResidualFn, quadruped.h:186-246); layout documented per residual in csrc/residuals.h */
+  int32_t num_residual_int;
+  int32_t num_residual_real;
+  const int32_t* residual_int;
+  const double* residual_real;
 } mjpcx_task;
 
 /* ---- outputs ---------------------------------------------------------------

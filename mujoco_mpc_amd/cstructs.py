@@ -29,6 +29,12 @@ _MODEL_FIELDS = (
                              "actuator_ctrllimited", "actuator_forcelimited")]
     + [(n, c_f64p) for n in ("actuator_gear", "actuator_gainprm", "actuator_biasprm",
                              "actuator_ctrlrange", "actuator_forcerange")]
+    + [("ngeom", C.c_int32), ("nkey", C.c_int32), ("cone", C.c_int32), ("impratio", C.c_double)]
+    + [(n, c_i32p) for n in ("geom_type", "geom_bodyid", "geom_contype", "geom_conaffinity", "geom_condim",
+                             "geom_priority", "geom_group")]
+    + [(n, c_f64p) for n in ("geom_size", "geom_pos", "geom_quat", "geom_friction", "geom_solref", "geom_solimp",
+                             "geom_margin", "geom_gap", "geom_solmix", "body_invweight0", "body_subtreemass",
+                             "dof_solref", "dof_solimp", "key_qpos")]
 )
 
 
@@ -43,6 +49,8 @@ class MjpcxTask(C.Structure):
         ("dim_norm_residual", c_i32p), ("norm", c_i32p), ("num_norm_parameter", c_i32p),
         ("weight", c_f64p), ("norm_parameter", c_f64p), ("parameters", c_f64p),
         ("trace_site", c_i32p), ("risk", C.c_double),
+        ("num_residual_int", C.c_int32), ("num_residual_real", C.c_int32),
+        ("residual_int", c_i32p), ("residual_real", c_f64p),
     ]
 
 

@@ -260,6 +260,15 @@ class _Compiler:
         g = dict(name=a.get("name", ""), type=gtype, size=np.array(size), pos=pos, quat=quat,
                  density=float(a.get("density", 1000.0)), mass=float(a["mass"]) if "mass" in a else None,
                  attrib=a)
+        fr = _floats(a.get("friction", "1 0.005 0.0001"))
+        fr = fr + [0.005, 0.0001][len(fr) - 1:] if len(fr) < 3 else fr
+        simp = list(DEFAULT_SOLIMP)
+        if "solimp" in a:
+            v = _floats(a["solimp"]); simp[:len(v)] = v
+        g.update(contype=int(a.get("contype", 1)), conaffinity=int(a.get("conaffinity", 1)), condim=int(a.get("condim", 3)),
+                 priority=int(a.get("priority", 0)), group=int(a.get("group", 0)), friction=np.array(fr[:3]),
+                 solref=np.array(_floats(a.get("solref", "0.02 1"), 2)), solimp=np.array(simp),
+                 margin=float(a.get("margin", 0)), gap=float(a.get("gap", 0)), solmix=float(a.get("solmix", 1)))
         vol, inertia_unit = _geom_volume_inertia(gtype, g["size"])
         if g["mass"] is None:
             g["mass"] = g["density"] * vol
@@ -302,7 +311,9 @@ class _Compiler:
                 self.joints.append(dict(body=bid, attrib=ja))
                 body["joints"].append(len(self.joints) - 1)
             elif child.tag == "geom":
-                body["geoms"].append(self._geom(child, childclass))
+                g = self._geom(child, childclass)
+                if g["type"] != "mesh":  # mesh assets are not available; such geoms are visual-only in the models used
+                    body["geoms"].append(g)
             elif child.tag == "site":
                 sa = self.defaults.resolve("site", child.get("class", childclass))
                 sa.update(child.attrib)
@@ -331,7 +342,9 @@ class _Compiler:
                     gravity=np.array(_floats(opt.get("gravity", "0 0 -9.81"), 3)),
                     integrator=integrator, disableflags=disable,
                     solver_iterations=int(opt.get("iterations", 100)),
-                    solver_tolerance=float(opt.get("tolerance", 1e-8)))
+                    solver_tolerance=float(opt.get("tolerance", 1e-8)),
+                    cone={"pyramidal": 0, "elliptic": 1}[opt.get("cone", "pyramidal")],
+                    impratio=float(opt.get("impratio", 1.0)))
 
         # ---- body tree (world = body 0)
         world = dict(name="world", parent=0, pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]), mocap=False,
@@ -394,6 +407,7 @@ class _Compiler:
         jnt_solimp = np.tile(DEFAULT_SOLIMP, (nj, 1)).astype(float)
         qpos0, qpos_spring = [], []
         dof_bodyid, dof_jntid, dof_parentid, dof_armature, dof_damping, dof_frictionloss = [], [], [], [], [], []
+        dof_solref, dof_solimp = [], []
         body_jntnum = np.zeros(nb, np.int32); body_jntadr = -np.ones(nb, np.int32)
         body_dofnum = np.zeros(nb, np.int32); body_dofadr = -np.ones(nb, np.int32)
         last_dof_of_body = -np.ones(nb, np.int64)
@@ -448,6 +462,11 @@ class _Compiler:
                 dof_armature.append(float(a.get("armature", 0)))
                 dof_damping.append(float(a.get("damping", 0)))
                 dof_frictionloss.append(float(a.get("frictionloss", 0)))
+                dof_solref.append(_floats(a.get("solreffriction", "0.02 1"), 2))
+                fimp = list(DEFAULT_SOLIMP)
+                if "solimpfriction" in a:
+                    v = _floats(a["solimpfriction"]); fimp[:len(v)] = v
+                dof_solimp.append(fimp)
                 last_dof_of_body[b] = d
                 body_dofnum[b] += 1
         nq, nv = len(qpos0), len(dof_bodyid)
@@ -507,7 +526,30 @@ class _Compiler:
                 v = a.get(lim, "auto")
                 A[f"actuator_{key}limited"][i] = 1 if v == "true" else (0 if v == "false" else int(self.autolimits and key + "range" in a))
 
+        _GEOM_TYPE = {"plane": 0, "hfield": 1, "sphere": 2, "capsule": 3, "ellipsoid": 4, "cylinder": 5, "box": 6, "mesh": 7}
+        geoms = [(bi, g) for bi, b in enumerate(self.bodies) for g in b["geoms"]]
+        ng = len(geoms)
+        G = dict(
+            geom_type=np.array([_GEOM_TYPE[g["type"]] for _, g in geoms], np.int32),
+            geom_bodyid=np.array([bi for bi, _ in geoms], np.int32),
+            geom_contype=np.array([g["contype"] for _, g in geoms], np.int32),
+            geom_conaffinity=np.array([g["conaffinity"] for _, g in geoms], np.int32),
+            geom_condim=np.array([g["condim"] for _, g in geoms], np.int32),
+            geom_priority=np.array([g["priority"] for _, g in geoms], np.int32),
+            geom_group=np.array([g["group"] for _, g in geoms], np.int32),
+            geom_size=np.array([g["size"] for _, g in geoms], float).reshape(ng, 3),
+            geom_pos=np.array([g["pos"] for _, g in geoms], float).reshape(ng, 3),
+            geom_quat=np.array([g["quat"] for _, g in geoms], float).reshape(ng, 4),
+            geom_friction=np.array([g["friction"] for _, g in geoms], float).reshape(ng, 3),
+            geom_solref=np.array([g["solref"] for _, g in geoms], float).reshape(ng, 2),
+            geom_solimp=np.array([g["solimp"] for _, g in geoms], float).reshape(ng, 5),
+            geom_margin=np.array([g["margin"] for _, g in geoms], float),
+            geom_gap=np.array([g["gap"] for _, g in geoms], float),
+            geom_solmix=np.array([g["solmix"] for _, g in geoms], float))
+        self.geom_names = [g["name"] for _, g in geoms]
         arrays = dict(
+            **G, dof_solref=np.array(dof_solref, float).reshape(-1, 2), dof_solimp=np.array(dof_solimp, float).reshape(-1, 5),
+            body_invweight0=np.zeros((nb, 2)), body_subtreemass=np.zeros(nb),
             body_parentid=body_parentid, body_rootid=body_rootid, body_jntnum=body_jntnum, body_jntadr=body_jntadr,
             body_dofnum=body_dofnum, body_dofadr=body_dofadr, body_mocapid=body_mocapid,
             body_pos=np.array([b["pos"] for b in self.bodies]), body_quat=np.array([b["quat"] for b in self.bodies]),
@@ -522,7 +564,7 @@ class _Compiler:
             site_bodyid=np.array([s["body"] for s in self.sites], np.int32),
             site_pos=np.array([s["pos"] for s in self.sites], float).reshape(-1, 3),
             site_quat=np.array([s["quat"] for s in self.sites], float).reshape(-1, 4), **A)
-        scal.update(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, nsite=len(self.sites), nmocap=nmocap, nuserdata=0)
+        scal.update(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, nsite=len(self.sites), nmocap=nmocap, nuserdata=0, ngeom=ng)
 
         # ---- custom, sensors, keyframes
         numeric, text = {}, {}
@@ -554,7 +596,11 @@ class _Compiler:
                         k[f] = np.array(_floats(e.get(f)))
                 keyframes[e.get("name", f"key{len(keyframes)}")] = k
 
-        names = dict(body=[b["name"] for b in self.bodies], joint=joint_names,
+        scal["nkey"] = len(keyframes)
+        arrays["key_qpos"] = (np.array([k["qpos"] for k in keyframes.values()], float).reshape(len(keyframes), nq)
+                              if keyframes else np.zeros((0, nq)))
+        names = dict(body=[b["name"] for b in self.bodies], joint=joint_names, geom=self.geom_names,
+                     key=list(keyframes.keys()),
                      site=[s["name"] for s in self.sites], actuator=act_names,
                      sensor=[s["name"] for s in sensors])
         fm = FlatModel(arrays=arrays, scalars=scal, names=names, numeric=numeric, text=text,
@@ -628,8 +674,9 @@ def forward_kinematics(fm: FlatModel, qpos):
     return dict(xpos=xpos, xquat=xquat, xmat=xmat, xipos=xipos, ximat=ximat, xanchor=xanchor, xaxis=xaxis)
 
 
-def mass_matrix(fm: FlatModel, qpos):
-    """Dense joint-space inertia via body Jacobians (independent of the CRB recursion)."""
+def mass_matrix(fm: FlatModel, qpos, jacobians=None):
+    """Dense joint-space inertia via body Jacobians (independent of the CRB recursion). If `jacobians` is a dict it
+    receives body id -> (Jp at the body's centre of mass, Jr)."""
     a = fm.arrays
     k = forward_kinematics(fm, qpos)
     nv, nb = fm.nv, fm.nbody
@@ -665,6 +712,8 @@ def mass_matrix(fm: FlatModel, qpos):
             Jp[:, d] = dof_lin[d] + np.cross(dof_ang[d], k["xipos"][i] - dof_pt[d])
         Iw = k["ximat"][i] @ np.diag(a["body_inertia"][i]) @ k["ximat"][i].T
         M += a["body_mass"][i] * Jp.T @ Jp + Jr.T @ Iw @ Jr
+        if jacobians is not None:
+            jacobians[i] = (Jp, Jr)
     return M
 
 
@@ -674,10 +723,21 @@ def _set_const(fm: FlatModel):
     if nv == 0:
         fm.scalars["meaninertia"] = 1.0
         return
-    M = mass_matrix(fm, fm.arrays["qpos0"])
+    jac = {}
+    M = mass_matrix(fm, fm.arrays["qpos0"], jac)
     Minv = np.linalg.inv(M)
     inv = np.diag(Minv).copy()
     a = fm.arrays
+    # body_invweight0: mean diagonal of J M^-1 J' for the translational (at the body COM) and rotational Jacobians
+    biw = np.zeros((fm.nbody, 2))
+    for i, (Jp, Jr) in jac.items():
+        biw[i, 0] = np.trace(Jp @ Minv @ Jp.T) / 3.0
+        biw[i, 1] = np.trace(Jr @ Minv @ Jr.T) / 3.0
+    a["body_invweight0"] = biw
+    sub = np.array(a["body_mass"], float).copy()
+    for i in range(fm.nbody - 1, 0, -1):
+        sub[a["body_parentid"][i]] += sub[i]
+    a["body_subtreemass"] = sub
     for j in range(fm.njnt):  # free/ball: average over each 3-dof block
         t, d = a["jnt_type"][j], a["jnt_dofadr"][j]
         if t == JNT_FREE:

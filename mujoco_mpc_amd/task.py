@@ -19,7 +19,7 @@ NORM_POWER_LOSS, NORM_SMOOTH_ABS, NORM_SMOOTH_ABS2, NORM_RECTIFY = 5, 6, 7, 8
 K_MAX_COST_TERMS = 128  # task.h:31
 K_MAX_TRACES = 99       # "Number of traces should be less than 100"
 
-RESIDUAL_PARTICLE, RESIDUAL_PARTICLE_COPY, RESIDUAL_CARTPOLE = 1, 2, 3
+RESIDUAL_PARTICLE, RESIDUAL_PARTICLE_COPY, RESIDUAL_CARTPOLE, RESIDUAL_QUADRUPED_FLAT = 1, 2, 3, 4
 
 
 def norm_parameter_dimension(norm_type: int) -> int:
@@ -51,6 +51,16 @@ class Task:
     norm_parameter: list = field(default_factory=list)
     parameters: list = field(default_factory=list)
     trace_site: list = field(default_factory=list)
+    residual_int: list = field(default_factory=list)    # task-specific frozen ResidualFn state (mjpcx_task::residual_int)
+    residual_real: list = field(default_factory=list)
+
+    def parameter_index(self, name: str) -> int:
+        """ParameterIndex, mjpc/utilities.cc:207-223: index among the "residual_" numerics."""
+        keys = [k for k in self.model.numeric if k.startswith("residual_")]
+        return keys.index("residual_" + name)
+
+    def cost_term_by_name(self, name: str) -> int:
+        return self.weight_names.index(name)
 
     def reset(self):
         """Task::Reset, mjpc/task.cc:147-248."""
@@ -114,7 +124,9 @@ class Task:
                     dim_norm_residual=self.dim_norm_residual, norm=self.norm,
                     num_norm_parameter=self.num_norm_parameter, weight=self.weight,
                     norm_parameter=self.norm_parameter, parameters=self.parameters,
-                    trace_site=self.trace_site, risk=float(self.risk))
+                    trace_site=self.trace_site, risk=float(self.risk),
+                    num_residual_int=len(self.residual_int), num_residual_real=len(self.residual_real),
+                    residual_int=self.residual_int, residual_real=self.residual_real)
 
     def packed(self) -> PackedTask:
         return PackedTask(self.spec())
@@ -137,12 +149,102 @@ class Task:
         return int(max(min(horizon / ts + 1, 512), 1))
 
 
+class QuadrupedFlat(Task):
+    """mjpc::QuadrupedFlat (mjpc/tasks/quadruped/quadruped.{h,cc}): ResetLocked (:520-607) resolves the ids and the flip
+    kinematics; `transition` is TransitionLocked (:229-391) for the state it can maintain without sensor feedback
+    (phase clock, manual gait switch, mode); the frozen ResidualFn copy handed to the device is residual_int/real in
+    the layout documented in csrc/residuals.h."""
+    MODE_QUADRUPED, MODE_BIPED, MODE_WALK, MODE_SCRAMBLE, MODE_FLIP = range(5)
+    GAIT_PARAM = [(1, 1, 0, 0, 1, 1), (0.75, 1, 0.03, 0, 1, 1), (0.45, 2, 0.03, 0.2, 1, 1), (0.4, 4, 0.05, 0.03, 0.5, 0.2),
+                  (0.3, 3.5, 0.10, 0.03, 0.2, 0.1)]   # kGaitParam, quadruped.h:99-108
+    K_MAX_HEIGHT, K_LEAP_HEIGHT, K_CROUCH_HEIGHT, K_HEIGHT_QUADRUPED = 0.8, 0.5, 0.15, 0.25
+
+    def reset(self):
+        super().reset()
+        m = self.model
+        self.ids = dict(
+            gait=self.parameter_index("select_Gait"), gait_switch=self.parameter_index("select_Gait switch"),
+            flip_dir=self.parameter_index("select_Flip dir"), biped_type=self.parameter_index("select_Biped type"),
+            cadence=self.parameter_index("Cadence"), amplitude=self.parameter_index("Amplitude"),
+            duty=self.parameter_index("Duty ratio"), arm_posture=self.parameter_index("Arm posture"),
+            heading=self.parameter_index("Heading"),
+            balance=self.cost_term_by_name("Balance"), upright=self.cost_term_by_name("Upright"),
+            height=self.cost_term_by_name("Height"),
+            torso=m.name2id("body", "trunk"), head=m.name2id("site", "head"),
+            goal_mocap=int(m.arrays["body_mocapid"][m.name2id("body", "goal")]),
+            feet=[m.name2id("geom", n) for n in ("FL", "HL", "FR", "HR")],
+            key_home=m.names["key"].index("home"), key_crouch=m.names["key"].index("crouch"))
+        # task state managed by Transition (quadruped.h:186-214)
+        self.current_mode, self.last_transition_time = self.MODE_QUADRUPED, -1.0
+        self.mode_start_time, self.position, self.heading_vec = 0.0, [0.0, 0.0, 0.0], [0.0, 0.0]
+        self.speed, self.angvel, self.ground, self.orientation = 0.0, 0.0, 0.0, [0.0, 0.0, 0.0, 0.0]
+        self.current_gait, self.phase_start, self.phase_start_time, self.phase_velocity = 0, 0.0, 0.0, 0.0
+        # derived kinematic quantities of the flip (quadruped.cc:566-606)
+        g = float(np.linalg.norm(m.gravity))
+        jump_vel = np.sqrt(2 * g * (self.K_MAX_HEIGHT - self.K_LEAP_HEIGHT))
+        flight_time = 2 * jump_vel / g
+        jump_acc = jump_vel * jump_vel / (2 * (self.K_LEAP_HEIGHT - self.K_CROUCH_HEIGHT))
+        crouch_time = np.sqrt(2 * (self.K_HEIGHT_QUADRUPED - self.K_CROUCH_HEIGHT) / jump_acc)
+        leap_time = jump_vel / jump_acc
+        jump_time = crouch_time + leap_time
+        crouch_vel = -jump_acc * crouch_time
+        land_time = 2 * (self.K_LEAP_HEIGHT - self.K_HEIGHT_QUADRUPED) / jump_vel
+        land_acc = jump_vel / land_time
+        flight_rot_vel = 1.25 * np.pi / flight_time
+        jump_rot_vel = np.pi / leap_time - flight_rot_vel
+        jump_rot_acc = (flight_rot_vel - jump_rot_vel) / leap_time
+        land_rot_acc = 2 * (flight_rot_vel * land_time - np.pi / 4) / (land_time * land_time)
+        self.flip = [g, jump_vel, flight_time, jump_acc, crouch_time, leap_time, jump_time, crouch_vel, land_time, land_acc,
+                     flight_rot_vel, jump_rot_vel, jump_rot_acc, land_rot_acc]
+        self._freeze()
+        return self
+
+    def get_phase(self, time):
+        return self.phase_start + (time - self.phase_start_time) * self.phase_velocity
+
+    def transition(self, time, mode=None):
+        """TransitionLocked without the sensor-driven parts (automatic gait switching, Walk goal motion, Flip)."""
+        mode = self.mode if mode is None else mode
+        if time < self.last_transition_time or self.last_transition_time == -1:
+            if mode not in (self.MODE_QUADRUPED, self.MODE_BIPED):
+                mode = self.MODE_QUADRUPED
+            self.last_transition_time = self.phase_start_time = self.phase_start = time
+        if mode != self.current_mode and self.current_mode != self.MODE_QUADRUPED and mode in (self.MODE_WALK, self.MODE_FLIP):
+            mode = self.MODE_QUADRUPED
+        phase_velocity = 2 * np.pi * self.parameters[self.ids["cadence"]]
+        if phase_velocity != self.phase_velocity:
+            self.phase_start = self.get_phase(time)
+            self.phase_start_time = time
+            self.phase_velocity = phase_velocity
+        if mode == self.MODE_BIPED:
+            self.parameters[self.ids["gait"]] = 2.0
+        gait_selection = int(self.parameters[self.ids["gait"]])
+        if gait_selection != self.current_gait:
+            self.current_gait = gait_selection
+            gp = self.GAIT_PARAM[2 if self.current_mode == self.MODE_BIPED else gait_selection]
+            self.parameters[self.ids["duty"]], self.parameters[self.ids["cadence"]], self.parameters[self.ids["amplitude"]] = gp[:3]
+            self.weight[self.ids["balance"]], self.weight[self.ids["upright"]], self.weight[self.ids["height"]] = gp[3:]
+        self.mode = self.current_mode = mode
+        self.last_transition_time = time
+        self._freeze()
+
+    def _freeze(self):
+        i = self.ids
+        self.residual_int = [self.current_mode, i["torso"], i["head"], i["goal_mocap"], *i["feet"], int(self.current_gait),
+                             int(self.parameters[i["flip_dir"]]), int(self.parameters[i["biped_type"]]), i["amplitude"],
+                             i["duty"], i["arm_posture"], i["heading"], i["key_home"], i["key_crouch"]]
+        self.residual_real = [self.mode_start_time, *self.position, *self.heading_vec, self.speed, self.angvel, self.ground,
+                              *self.orientation, self.phase_start, self.phase_start_time, self.phase_velocity, *self.flip]
+
+
 _REGISTRY = {
     # name -> (xml path under models/, residual id)
     "Cartpole": ("cartpole/task.xml", RESIDUAL_CARTPOLE),      # mjpc/tasks/cartpole/cartpole.cc
     "Particle": ("particle/task.xml", RESIDUAL_PARTICLE),      # mjpc/test/testdata/particle_residual.h
     "ParticleCopy": ("particle/task.xml", RESIDUAL_PARTICLE_COPY),  # mjpc/test/agent/rollout_test.cc:28-58
+    "QuadrupedFlat": ("quadruped/task_flat.xml", RESIDUAL_QUADRUPED_FLAT),  # mjpc/tasks/quadruped/quadruped.cc
 }
+_CLASSES = {"QuadrupedFlat": QuadrupedFlat}
 
 
 def task_names():
@@ -152,4 +254,4 @@ def task_names():
 def load_task(name: str) -> Task:
     path, rid = _REGISTRY[name]
     model = mjcf.load_xml(os.path.join(MODELS_DIR, path))
-    return Task(name=name, residual_id=rid, model=model).reset()
+    return _CLASSES.get(name, Task)(name=name, residual_id=rid, model=model).reset()

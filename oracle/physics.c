@@ -26,7 +26,15 @@
 
 #define OMINVAL 1e-15 /* mjMINVAL */
 #define OMAXVAL 1e10  /* mjMAXVAL */
-#define OMAXEFC 64
+#define OMAXEFC 160
+#define OMAXCON 32
+#define OMINMU 1e-5 /* mjMINMU */
+
+typedef struct OContact {
+  int g1, g2, dim, efc;
+  double dist, margin, includemargin, mu;
+  double pos[3], frame[9], friction[5], solref[2], solimp[5];
+} OContact;
 
 struct OData {
   const mjpcx_model* m;
@@ -45,6 +53,15 @@ struct OData {
   double efc_pos[OMAXEFC], efc_margin[OMAXEFC], efc_R[OMAXEFC], efc_aref[OMAXEFC];
   double efc_b[OMAXEFC], efc_force[OMAXEFC];
   double *scratch_minvjt, *scratch_qacc, *scratch_A; /* preallocated work arrays */
+  /* contacts / friction loss / Newton solver (contact.inc) */
+  int full; /* 1: constraint rows beyond joint limits can occur -> Newton path */
+  int ngeom, ncon, solver_iter;
+  int* geom_static;
+  double *geom_xpos, *geom_xmat;
+  OContact con[OMAXCON];
+  int efc_type[OMAXEFC], efc_id[OMAXEFC], efc_zone[OMAXEFC];
+  double efc_D[OMAXEFC], efc_floss[OMAXEFC], efc_vel[OMAXEFC];
+  double *scratch_jac, *nw_jar, *nw_jv, *nw_grad, *nw_search, *nw_Ma, *nw_H, *nw_L;
   int warning;
 };
 
@@ -153,10 +170,9 @@ static int is_bad(double x) { return isnan(x) || x > OMAXVAL || x < -OMAXVAL; }
 void oresidual(const mjpcx_task* task, const OData* d, double* r);
 
 /* ------------------------------------------------------------------ lifetime */
+static int body_is_static(const mjpcx_model* m, int b);
 OData* odata_new(const mjpcx_model* m) {
   /* reject features this restatement does not cover */
-  for (int i = 0; i < m->nv; i++)
-    if (m->dof_frictionloss[i] > 0) return NULL;
   for (int j = 0; j < m->njnt; j++)
     if (m->jnt_limited[j] && (m->jnt_type[j] == MJPCX_JNT_BALL || m->jnt_type[j] == MJPCX_JNT_FREE))
       return NULL;
@@ -183,6 +199,20 @@ OData* odata_new(const mjpcx_model* m) {
   d->qacc = dalloc(nv); d->actuator_force = dalloc(nu);
   d->efc_J = dalloc(OMAXEFC * nv);
   d->scratch_minvjt = dalloc(OMAXEFC * nv); d->scratch_qacc = dalloc(nv); d->scratch_A = dalloc(2 * nv * nv);
+  /* geoms and the Newton solver's work space */
+  d->ngeom = m->ngeom;
+  d->geom_xpos = dalloc(3 * m->ngeom); d->geom_xmat = dalloc(9 * m->ngeom);
+  d->geom_static = (int*)calloc((size_t)(m->ngeom > 0 ? m->ngeom : 1), sizeof(int));
+  d->scratch_jac = dalloc(12 * nv); d->nw_jar = dalloc(OMAXEFC); d->nw_jv = dalloc(OMAXEFC);
+  d->nw_grad = dalloc(nv); d->nw_search = dalloc(nv); d->nw_Ma = dalloc(nv); d->nw_H = dalloc(nv * nv); d->nw_L = dalloc(nv * nv);
+  d->full = 0;
+  for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0 && !(m->disableflags & MJPCX_DSBL_FRICTIONLOSS)) d->full = 1;
+  int nstatic = 0, ndynamic = 0;
+  for (int g = 0; g < m->ngeom; g++) {
+    d->geom_static[g] = body_is_static(m, m->geom_bodyid[g]);
+    if (m->geom_contype[g] || m->geom_conaffinity[g]) { if (d->geom_static[g]) nstatic++; else ndynamic++; }
+  }
+  if (nstatic && ndynamic && !(m->disableflags & MJPCX_DSBL_CONTACT)) d->full = 1;
   /* subtree masses are model constants */
   for (int i = 0; i < nb; i++) d->subtree_mass[i] = m->body_mass[i];
   for (int i = nb - 1; i > 0; i--) d->subtree_mass[m->body_parentid[i]] += d->subtree_mass[i];
@@ -203,8 +233,10 @@ void odata_free(OData* d) {
                   &d->crb, &d->cdof, &d->cdof_dot, &d->cvel, &d->cacc, &d->cfrc, &d->M, &d->L,
                   &d->qfrc_passive, &d->qfrc_bias, &d->qfrc_actuator, &d->qfrc_smooth,
                   &d->qacc_smooth, &d->qfrc_constraint, &d->qacc, &d->actuator_force, &d->efc_J,
-                  &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A};
+                  &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A, &d->geom_xpos, &d->geom_xmat, &d->scratch_jac,
+                  &d->nw_jar, &d->nw_jv, &d->nw_grad, &d->nw_search, &d->nw_Ma, &d->nw_H, &d->nw_L};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
+  free(d->geom_static);
   free(d);
 }
 void odata_set_state(OData* d, const double* state, double time, const double* mocap,
@@ -626,6 +658,8 @@ static void o_constraint(OData* d) {
     }
 }
 
+#include "contact.inc"
+
 void o_forward(OData* d) {
   const mjpcx_model* m = d->m;
   int nv = m->nv;
@@ -633,15 +667,17 @@ void o_forward(OData* d) {
   o_compos(d);
   o_crb(d);
   if (!chol_factor(d->L, d->M, nv)) d->warning |= 16;
-  o_make_constraint(d);
+  if (d->full) { o_geom_kinematics(d); o_collision(d); }
+  else { if (m->ngeom) o_geom_kinematics(d); o_make_constraint(d); }
   o_comvel(d);
+  if (d->full) o_make_constraint_full(d); /* needs qvel-dependent terms only through J qvel: after collision */
   o_passive(d);
   o_rne(d);
   o_actuation(d);
   for (int i = 0; i < nv; i++)
     d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
   chol_solve(d->qacc_smooth, d->L, d->qfrc_smooth, nv);
-  o_constraint(d);
+  if (d->full) o_constraint_newton(d); else o_constraint(d);
 }
 
 /* mj_Euler with implicit joint damping, then mj_advance */
@@ -706,9 +742,32 @@ const double* odata_site_xpos(const OData* d) { return d->site_xpos; }
 
 /* ------------------------------------------------------------------ residuals */
 /* the ResidualFn::Residual overrides of the covered tasks */
+/* linear velocity of the centre of mass of the subtree rooted at `body` (sensor subtreelinvel, mj_subtreeVel) */
+static void o_subtree_linvel(const OData* d, int body, double out[3]) {
+  const mjpcx_model* m = d->m;
+  double mom[3] = {0, 0, 0}, mass = 0;
+  for (int i = body; i < m->nbody; i++) {
+    int p = i, inside = 0;
+    while (p > 0) { if (p == body) { inside = 1; break; } p = m->body_parentid[p]; }
+    if (!inside && i != body) continue;
+    const double* cv = d->cvel + 6 * i; /* [angular, linear at subtree_com[root]] */
+    const double* com = d->subtree_com + 3 * m->body_rootid[i];
+    double off[3], lin[3];
+    for (int k = 0; k < 3; k++) off[k] = d->xipos[3 * i + k] - com[k];
+    cross3(lin, cv, off);
+    for (int k = 0; k < 3; k++) mom[k] += m->body_mass[i] * (cv[3 + k] + lin[k]);
+    mass += m->body_mass[i];
+  }
+  for (int k = 0; k < 3; k++) out[k] = mass > OMINVAL ? mom[k] / mass : 0;
+}
+#include "quadruped.inc"
+
 void oresidual(const mjpcx_task* task, const OData* d, double* r) {
   const mjpcx_model* m = d->m;
   switch (task->residual_id) {
+    case MJPCX_RESIDUAL_QUADRUPED_FLAT:
+      quadruped_residual(task, d, r);
+      break;
     case MJPCX_RESIDUAL_PARTICLE: /* test/testdata/particle_residual.h:33-43 */
       for (int i = 0; i < m->nq; i++) r[i] = d->qpos[i];
       r[0] -= d->mocap_pos[0];
@@ -749,7 +808,27 @@ int odata_get(const OData* d, const char* name, double* out, int cap) {
   F("qfrc_constraint", d->qfrc_constraint, nv); F("actuator_force", d->actuator_force, m->nu);
   F("efc_force", d->efc_force, d->nefc); F("time", &d->time, 1);
   F("cvel", d->cvel, 6 * nb); F("cdof", d->cdof, 6 * nv);
+  F("geom_xpos", d->geom_xpos, 3 * m->ngeom); F("geom_xmat", d->geom_xmat, 9 * m->ngeom);
+  F("efc_J", d->efc_J, d->nefc * nv); F("efc_aref", d->efc_aref, d->nefc); F("efc_R", d->efc_R, d->nefc);
+  F("efc_pos", d->efc_pos, d->nefc);
 #undef F
+  if (!strcmp(name, "ncon")) { double v = d->ncon; return put(out, cap, &v, 1); }
+  if (!strcmp(name, "solver_iter")) { double v = d->solver_iter; return put(out, cap, &v, 1); }
+  if (!strcmp(name, "warning")) { double v = d->warning; return put(out, cap, &v, 1); }
+  if (!strcmp(name, "contact")) { /* per contact: dist, pos[3], normal[3], geom1, geom2, dim, efc address */
+    int n = 0;
+    for (int i = 0; i < d->ncon && n + 11 <= cap; i++) {
+      const OContact* c = d->con + i;
+      out[n++] = c->dist; for (int k = 0; k < 3; k++) out[n++] = c->pos[k]; for (int k = 0; k < 3; k++) out[n++] = c->frame[k];
+      out[n++] = c->g1; out[n++] = c->g2; out[n++] = c->dim; out[n++] = c->efc;
+    }
+    return n;
+  }
+  if (!strcmp(name, "subtree_linvel")) { /* per body */
+    int n = 0;
+    for (int i = 0; i < nb && n + 3 <= cap; i++) { o_subtree_linvel(d, i, out + n); n += 3; }
+    return n;
+  }
   if (!strcmp(name, "nefc")) { double v = d->nefc; return put(out, cap, &v, 1); }
   if (!strcmp(name, "energy")) { /* [potential, kinetic] (mj_energyPos/Vel) */
     double e[2] = {0, 0};

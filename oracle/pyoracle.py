@@ -66,6 +66,8 @@ def lib():
         L.odata_set_ctrl.argtypes = [C.c_void_p, c_f64p]
         L.o_forward.argtypes = [C.c_void_p]
         L.o_step.argtypes = [C.c_void_p]
+        L.o_forward_task.argtypes = [C.c_void_p, C.POINTER(MjpcxTask), c_f64p]
+        L.o_step_task.argtypes = [C.c_void_p, C.POINTER(MjpcxTask), c_f64p]
         L.odata_warning.argtypes = [C.c_void_p]
         L.odata_get.argtypes = [C.c_void_p, C.c_char_p, c_f64p, C.c_int]
         L.onorm.restype = C.c_double
@@ -203,6 +205,12 @@ class Physics:
 
     def step(self):
         lib().o_step(self.d)
+
+    def forward_task(self, packed_task):
+        """mj_forward with the task residual evaluated at the sensor-callback point"""
+        r = np.zeros(packed_task.struct.num_residual)
+        lib().o_forward_task(self.d, packed_task.ptr, as_f64p(r))
+        return r
 
     def warning(self):
         return lib().odata_warning(self.d)

@@ -1,0 +1,139 @@
+"""Oracle contact / friction-loss / Newton-solver restatement (oracle/contact.inc) and the Quadruped residual
+(oracle/quadruped.inc). PARITY UNPINNED against MuJoCo (not available here); these are analytic checks:
+static equilibrium (normal force = weight), Coulomb stick/slip threshold, rolling without slipping, friction-loss
+stiction, and the QuadrupedFlat residual against hand-computed entries (quadruped.cc:33-226)."""
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_mpc_amd import mjcf
+from mujoco_mpc_amd.cstructs import PackedModel
+from mujoco_mpc_amd.task import load_task
+from oracle import pyoracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def scene(gravity=None):
+    fm = mjcf.load_xml(os.path.join(HERE, "models", "ball_plane.xml"))
+    if gravity is not None:
+        fm.scalars["gravity"] = np.asarray(gravity, float)
+    pm = PackedModel(fm)
+    ph = pyoracle.Physics(pm)
+    ph.set_state(fm.arrays["qpos0"].copy(), np.zeros(fm.nv))
+    ph.set_ctrl(np.zeros(0))
+    return fm, pm, ph
+
+
+def test_resting_contacts_carry_the_weight():
+    fm, pm, ph = scene()
+    for _ in range(1500):
+        ph.step()
+    assert np.abs(ph.get("qvel")).max() < 1e-9
+    ph.forward()
+    c = ph.get("contact").reshape(-1, 11)
+    f = ph.get("efc_force")
+    assert len(c) == 5 and int(ph.get("nefc")[0]) == 15 and ph.get("warning")[0] == 0
+    normal = np.array([f[int(a)] for a in c[:, 10]])
+    assert abs(normal[0] - 2 * 9.81) < 1e-6                      # ball: m g
+    assert np.allclose(normal[1:], 9.81 / 4, atol=1e-6)            # box: four corners share m g
+    assert -1e-3 < c[0, 0] < 0 and np.all(c[:, 0] < 0)             # soft contacts rest slightly penetrated
+    assert ph.get("solver_iter")[0] <= 6
+
+
+@pytest.mark.parametrize("deg,slides", [(20, False), (35, True)])
+def test_coulomb_threshold_and_rolling(deg, slides):
+    th = np.radians(deg)
+    fm, pm, ph = scene([9.81 * np.sin(th), 0, -9.81 * np.cos(th)])
+    for _ in range(500):  # 1 s
+        ph.step()
+    v = ph.get("qvel")
+    if slides:   # mu = 0.5 < tan(35 deg): a = g (sin - mu cos)
+        assert abs(v[6] - 9.81 * (np.sin(th) - 0.5 * np.cos(th))) < 0.08
+    else:        # sticks (soft constraint: creeps a little)
+        assert abs(v[6]) < 5e-3
+    # the ball rolls without slipping: a = 5/7 g sin(theta), omega = v / r
+    assert abs(v[0] - 5 / 7 * 9.81 * np.sin(th)) < 0.01
+    assert abs(v[4] * 0.1 - v[0]) < 0.01
+
+
+def test_newton_solver_satisfies_optimality():
+    """at the solution the gradient M (a - a_smooth) - J' f vanishes and every cone force is inside its cone"""
+    fm, pm, ph = scene([2.0, 1.0, -9.81])
+    for _ in range(50):
+        ph.step()
+    ph.forward()
+    nv = fm.nv
+    M = ph.get("M").reshape(nv, nv)
+    J = ph.get("efc_J", 100000).reshape(-1, nv)
+    f = ph.get("efc_force")
+    grad = M @ (ph.get("qacc") - ph.get("qacc_smooth")) - J.T @ f
+    assert np.abs(grad).max() < 1e-9 * max(1.0, np.abs(f).max())
+    for c in ph.get("contact").reshape(-1, 11):
+        a = int(c[10])
+        assert f[a] >= -1e-12 and np.hypot(f[a + 1], f[a + 2]) <= 0.5 * f[a] + 1e-9
+
+
+def test_a1_settles_on_the_floor():
+    t = load_task("QuadrupedFlat")
+    assert (t.model.nq, t.model.nv, t.model.nu, t.num_residual, t.num_term) == (19, 18, 12, 42, 9)
+    assert abs(t.model.arrays["body_mass"][t.model.name2id("body", "trunk"):].sum() - 12.453) < 1e-9
+    ph = pyoracle.Physics(t.packed_model())
+    mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
+    ph.set_state(t.model.keyframes["home"]["qpos"], np.zeros(18), 0.0, mocap)
+    ph.set_ctrl(np.zeros(12))
+    for _ in range(300):
+        ph.step()
+    assert ph.get("warning")[0] == 0 and np.abs(ph.get("qvel")).max() < 0.05
+    ph.forward()
+    c = ph.get("contact").reshape(-1, 11)
+    f = ph.get("efc_force")
+    assert abs(sum(f[int(a)] for a in c[:, 10]) - 12.453 * 9.81) < 1.0     # the floor carries the robot
+
+
+def test_friction_loss_holds_a_joint():
+    """a hinge with frictionloss 0.2 N m and a smaller gravity torque does not move; a larger one does"""
+    t = load_task("QuadrupedFlat")
+    ph = pyoracle.Physics(t.packed_model())
+    q = t.model.keyframes["home"]["qpos"].copy()
+    q[2] = 1.0  # in the air: no contacts
+    mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
+    ph.set_state(q, np.zeros(18), 0.0, mocap)
+    ph.set_ctrl(np.zeros(12))
+    ph.forward()
+    f = ph.get("efc_force")
+    assert int(ph.get("ncon")[0]) == 0 and int(ph.get("nefc")[0]) == 12
+    assert np.all(np.abs(f) <= 0.2 + 1e-12)   # friction-loss rows are box-bounded by dof_frictionloss
+
+
+def test_quadruped_residual_entries():
+    t = load_task("QuadrupedFlat")
+    t.transition(0.0)
+    pm, pt = t.packed_model(), t.packed()
+    ph = pyoracle.Physics(pm)
+    q = t.model.keyframes["home"]["qpos"].copy()
+    mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
+    ph.set_state(q, np.zeros(18), 0.0, mocap)
+    ctrl = np.linspace(-0.5, 0.5, 12)
+    ph.set_ctrl(ctrl)
+    r = ph.forward_task(pt)
+    assert r.shape == (42,)
+    xmat = ph.get("xmat").reshape(-1, 3, 3)[t.ids["torso"]]
+    gx = ph.get("geom_xpos").reshape(-1, 3)
+    feet = gx[t.ids["feet"]]
+    assert np.allclose(r[0:3], [xmat[2, 2] - 1, 0, 0])                                   # Upright
+    xipos = ph.get("xipos").reshape(-1, 3)[t.ids["torso"]]
+    assert np.isclose(r[3], xipos[2] - feet[:, 2].mean() - 0.25)                         # Height
+    head = ph.get("site_xpos").reshape(-1, 3)[t.ids["head"]]
+    assert np.allclose(r[4:7], [head[0] - 0.3, head[1] - 0.0, 0])                        # Position (goal mocap)
+    # Gait: amplitude .06, duty 0, phase 0 at t = 0 -> step = .06 cos(0) for every foot; flat floor at z = -0.01
+    assert np.allclose(r[7:11], feet[:, 2] - (-0.01 + 0.02 + 0.06))
+    com = ph.get("subtree_com").reshape(-1, 3)[t.ids["torso"]]
+    assert np.allclose(r[11:13], com[:2] - feet[:, :2].mean(0))                          # Balance at zero velocity
+    assert np.allclose(r[13:25], 0.02 * 40 * ctrl)                                       # Effort: gainprm 40
+    home = t.model.keyframes["home"]["qpos"]
+    assert np.allclose(r[25:37], 0)                                                      # Posture at home
+    assert np.allclose(r[37:39], [0, 0], atol=1e-12)                                     # Yaw: heading goal 0
+    assert np.allclose(r[39:42], 0)                                                      # "Angmom" = subtree linvel
+    assert pyoracle.cost_value(pt, r) > 0
