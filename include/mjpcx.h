@@ -283,6 +283,11 @@ int mjpcx_rollout_noise(mjpcx_ctx* ctx, int num_candidates, int horizon,
                         int num_nodes, int interpolation, const double* node_times,
                         const double* nominal_values, const mjpcx_noise_spec* noise);
 
+/* The task-specific frozen ResidualFn state (mjpcx_task::residual_int / residual_real) for the next rollouts: what
+ * Task::Transition changed since the context was created (mode, gait phase origin, Walk/Flip state of the Quadruped).
+ * Either pointer may be NULL (keep). */
+int mjpcx_set_residual_state(mjpcx_ctx* ctx, const int32_t* residual_int, const double* residual_real);
+
 /* Block until everything queued on the context's stream has finished. */
 int mjpcx_sync(mjpcx_ctx* ctx);
 

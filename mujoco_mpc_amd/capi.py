@@ -22,7 +22,7 @@ NOISE_SAMPLING, NOISE_CROSS_ENTROPY = 0, 1
 # every symbol include/mjpcx.h declares
 EXPORTS = [
     "mjpcx_create", "mjpcx_destroy", "mjpcx_create_error", "mjpcx_error_string", "mjpcx_last_error",
-    "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_rollout_splines",
+    "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_set_residual_state", "mjpcx_rollout_splines",
     "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
     "mjpcx_fetch_spline", "mjpcx_rollout_feedback", "mjpcx_transition_fd", "mjpcx_cost_derivatives",
     "mjpcx_backward_pass", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
@@ -60,6 +60,7 @@ def lib():
         L.mjpcx_kernel_name.argtypes = [vp]
         L.mjpcx_set_state.argtypes = [vp, c_f64p, C.c_double, c_f64p, c_f64p]
         L.mjpcx_set_task_params.argtypes = [vp, c_f64p, c_f64p, c_f64p, C.c_double]
+        L.mjpcx_set_residual_state.argtypes = [vp, c_i32p, c_f64p]
         L.mjpcx_rollout_splines.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p]
         L.mjpcx_rollout_noise.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.POINTER(MjpcxNoiseSpec)]
         L.mjpcx_sync.argtypes = [vp]
@@ -166,6 +167,12 @@ class Context:
         n = None if norm_parameter is None else as_f64p(_f(norm_parameter))
         p = None if parameters is None else as_f64p(_f(parameters))
         self._chk(lib().mjpcx_set_task_params(self.handle, w, n, p, float(risk)))
+
+    def set_residual_state(self, residual_int=None, residual_real=None):
+        ri = None if residual_int is None else np.ascontiguousarray(residual_int, dtype=np.int32)
+        rr = None if residual_real is None else _f(residual_real)
+        self._chk(lib().mjpcx_set_residual_state(self.handle, None if ri is None else ri.ctypes.data_as(c_i32p),
+                                                 None if rr is None else as_f64p(rr)))
 
     def rollout_splines(self, horizon, interp, node_times, node_values):
         nt = _f(node_times)

@@ -11,6 +11,7 @@ namespace mjpcx {
 constexpr int kJntFree = 0, kJntBall = 1, kJntSlide = 2, kJntHinge = 3;
 constexpr double kMinVal = 1e-15;  // mjMINVAL
 constexpr double kMaxVal = 1e10;   // mjMAXVAL
+constexpr double kMinImp = 0.0001, kMaxImp = 0.9999;  // mjMINIMP / mjMAXIMP: clip range of solimp's d0, d_width, midpoint
 constexpr double kMaxReturn = 1.0e6;  // kMaxReturnValue, mjpc/trajectory.cc:29
 
 // Capacity of the lane-per-candidate ("small model") kernel family.

@@ -18,6 +18,7 @@
 #include "rollout_lane.h"
 #include "lane_registry.h"
 #include "ilqg_dense.h"
+#include "rollout_wave.h"
 
 using namespace mjpcx;
 
@@ -91,6 +92,11 @@ const KernelEntry kKernels[] = {
     MJPCX_LANE_ENTRY(TopoParticle, TaskParticle),
     MJPCX_LANE_ENTRY(TopoParticle, TaskParticleCopy),
 };
+
+// the wavefront-per-candidate family is selected by model FEATURES (free/ball joints, friction loss, contacts),
+// not by topology: one generic kernel that reads the model through WaveModel
+const KernelEntry kWaveEntry = {"rollout_wave_kernel (wavefront per candidate, model in LDS/L1; Newton contact solver)",
+                                TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 // ===================================================================== small kernels
 // argmin / top-k over total_return: replaces std::partial_sort (sampling/planner.cc:184-188).
@@ -314,6 +320,10 @@ struct mjpcx_ctx {
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
   int N = 0, H = 0, P = 0;  // shape of the last rollout
   bool have_rollout = false;
+  // wavefront-per-candidate family
+  bool wave = false;
+  WaveHost wh;
+  std::vector<unsigned char> blob_scratch;
   std::vector<double> h_stage;
   // timing
   bool timing = false;
@@ -416,8 +426,9 @@ void set_norm_params(mjpcx_ctx* c, const double* norm_parameter) {
   int shift = 0;
   for (int k = 0; k < c->nterm; k++) {
     const int np = c->num_norm_parameter[k];
-    c->ht64.norm_p[k] = np > 0 ? norm_parameter[shift] : 0.0;
-    c->ht64.norm_q[k] = np > 1 ? norm_parameter[shift + 1] : 0.0;
+    const double p = np > 0 ? norm_parameter[shift] : 0.0, q = np > 1 ? norm_parameter[shift + 1] : 0.0;
+    if (c->wave) { c->wh.norm_p[k] = p; c->wh.norm_q[k] = q; }
+    else { c->ht64.norm_p[k] = p; c->ht64.norm_q[k] = q; }
     shift += np;
   }
 }
@@ -443,11 +454,13 @@ int reserve_rollout(mjpcx_ctx* c, int N, int H, int P) {
 // asynchronous H2D copy. The slot is recycled only after the kernel that reads it has finished.
 template <typename T>
 int stage_plan_inputs(mjpcx_ctx* c, int P, const double* node_times, const double* nominal, const double* variance,
-                      const T** d_times, const T** d_nominal, const double** d_variance, mjpcx_ctx::Slot** used) {
+                      const T** d_times, const T** d_nominal, const double** d_variance, mjpcx_ctx::Slot** used,
+                      const void** d_blob = nullptr) {
   const int np = P * c->nu;
   const size_t off_nom = ((size_t)P * sizeof(T) + 15) & ~(size_t)15;
   const size_t off_var = (off_nom + (size_t)np * sizeof(T) + 15) & ~(size_t)15;
-  const size_t bytes = off_var + (size_t)np * 8;
+  const size_t off_blob = (off_var + (size_t)np * 8 + 15) & ~(size_t)15;
+  const size_t bytes = off_blob + (c->wave ? c->wh.blob_bytes : 0);
   mjpcx_ctx::Slot& s = c->slots[c->next_slot];
   c->next_slot = (c->next_slot + 1) % mjpcx_ctx::kSlots;
   if (s.pending) { HIPCHK(c, hipEventSynchronize(s.done)); s.pending = false; }
@@ -465,6 +478,10 @@ int stage_plan_inputs(mjpcx_ctx* c, int P, const double* node_times, const doubl
   T* hn = (T*)(h + off_nom);
   if (nominal) for (int j = 0; j < np; j++) hn[j] = (T)nominal[j];
   if (variance) std::memcpy(h + off_var, variance, (size_t)np * 8);
+  if (c->wave) {
+    c->wh.fill_blob(h + off_blob);
+    if (d_blob) *d_blob = (const char*)s.dev.p + off_blob;
+  }
   HIPCHK(c, hipMemcpyAsync(s.dev.p, s.host, bytes, hipMemcpyHostToDevice, c->stream));
   *d_times = (const T*)s.dev.p;
   *d_nominal = (const T*)((char*)s.dev.p + off_nom);
@@ -487,8 +504,9 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
   mjpcx_ctx::Slot* slot = nullptr;
   const bool ce = ns && ns->mode == MJPCX_NOISE_CROSS_ENTROPY;
   if (ce && !ns->param_variance) return fail(c, MJPCX_EINVAL, "cross-entropy noise needs param_variance");
+  const void* d_blob = nullptr;
   if ((rc = stage_plan_inputs<T>(c, P, node_times, nominal, ce ? ns->param_variance : nullptr, &a.node_times,
-                                 &a.nominal, &d_var, &slot)) != MJPCX_OK) return rc;
+                                 &a.nominal, &d_var, &slot, &d_blob)) != MJPCX_OK) return rc;
   if (node_values) {
     // candidate-major host splines -> [node][actuator][candidate] on the device (not the hot path:
     // the planner generates candidates on the device; this entry serves tests and NominalTrajectory)
@@ -525,7 +543,20 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
   }
   hipError_t le;
   if constexpr (sizeof(T) == 8) {
-    le = c->kernel->launch64(c->hm64, c->ht64, a, c->stream);
+    if (c->wave) {
+      WaveTask wt = c->wh.t;
+      wt.blob = (const double*)d_blob;
+      const WaveModel& wm = c->wh.m;
+      const size_t lds = 8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P);
+      if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
+      le = hipFuncSetAttribute((const void*)rollout_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (le == hipSuccess) {
+        hipLaunchKernelGGL(rollout_wave_kernel, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
+        le = hipGetLastError();
+      }
+    } else {
+      le = c->kernel->launch64(c->hm64, c->ht64, a, c->stream);
+    }
   } else {
     convert_task(c->ht32, c->ht64);
     le = c->kernel->launch32(c->hm32, c->ht32, a, c->stream);
@@ -545,7 +576,7 @@ int check_rollout_args(mjpcx_ctx* c, int N, int H, int P, int interp, const doub
   if (interp < 0 || interp > 2) return fail(c, MJPCX_EINVAL, "unknown interpolation");
   for (int p = 1; p < P; p++)
     if (!(node_times[p] > node_times[p - 1])) return fail(c, MJPCX_EINVAL, "node_times must be strictly increasing");
-  const size_t shmem = ((size_t)P * c->nu * 64 + P) * esize(c);
+  const size_t shmem = c->wave ? 0 : ((size_t)P * c->nu * 64 + P) * esize(c);
   if (shmem > 64 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "num_nodes * nu too large for the LDS spline stage");
   if (hipSetDevice(c->device) != hipSuccess) return fail(c, MJPCX_EDEVICE, "hipSetDevice failed");
   return MJPCX_OK;
@@ -582,6 +613,46 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
   // ---- features the device kernels cover today
   if (m->na != 0) return bad(MJPCX_EUNSUPPORTED, "actuator activations (na > 0) unsupported");
   if (m->integrator != MJPCX_INT_EULER) return bad(MJPCX_EUNSUPPORTED, "only the Euler integrator is implemented");
+  // ---- wavefront-per-candidate family: free/ball joints, friction loss, contacts
+  bool needs_wave = false;
+  for (int j = 0; j < m->njnt; j++) needs_wave |= m->jnt_type[j] == MJPCX_JNT_FREE || m->jnt_type[j] == MJPCX_JNT_BALL;
+  for (int i = 0; i < m->nv; i++) needs_wave |= m->dof_frictionloss[i] > 0 && !(m->disableflags & MJPCX_DSBL_FRICTIONLOSS);
+  if (!(m->disableflags & MJPCX_DSBL_CONTACT) && m->ngeom > 0) {
+    bool st = false, dy = false;
+    for (int g = 0; g < m->ngeom; g++) {
+      if (!(m->geom_contype[g] || m->geom_conaffinity[g])) continue;
+      bool moving = false;
+      for (int b = m->geom_bodyid[g]; b > 0; b = m->body_parentid[b]) moving |= m->body_dofnum[b] > 0;
+      (moving ? dy : st) = true;
+    }
+    needs_wave |= st && dy;
+  }
+  if (needs_wave) {
+    if (precision != 64) return bad(MJPCX_EUNSUPPORTED, "the wavefront-per-candidate kernel is fp64 only for now");
+    for (int j = 0; j < m->njnt; j++)
+      if (m->jnt_limited[j] && (m->jnt_type[j] == MJPCX_JNT_FREE || m->jnt_type[j] == MJPCX_JNT_BALL))
+        return bad(MJPCX_EUNSUPPORTED, "limits on free/ball joints are not implemented");
+    if (t->num_trace * 3 > 64 || m->nu > 64 || t->num_term > 64) return bad(MJPCX_EUNSUPPORTED, "task exceeds the wave kernel capacity");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad(MJPCX_EDEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return bad(MJPCX_EINVAL, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) return bad(MJPCX_EDEVICE, "hipSetDevice failed");
+    mjpcx_ctx* c = new (std::nothrow) mjpcx_ctx();
+    if (!c) return bad(MJPCX_ENOMEM, "host allocation failed");
+    c->device = device; c->precision = precision; c->kernel = &kWaveEntry; c->wave = true;
+    c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap;
+    c->nr = t->num_residual; c->nterm = t->num_term; c->ntrace = t->num_trace; c->nparam = t->num_parameter;
+    c->num_norm_parameter.assign(t->num_norm_parameter, t->num_norm_parameter + t->num_term);
+    c->dim_norm_residual.assign(t->dim_norm_residual, t->dim_norm_residual + t->num_term);
+    c->ctrllimited.assign(m->actuator_ctrllimited, m->actuator_ctrllimited + m->nu);
+    c->ctrlrange.assign(m->actuator_ctrlrange, m->actuator_ctrlrange + 2 * m->nu);
+    const std::string err = c->wh.build(m, t);
+    if (!err.empty()) { mjpcx_destroy(c); return bad(MJPCX_EUNSUPPORTED, err); }
+    set_norm_params(c, t->norm_parameter);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
+    *out = c;
+    return MJPCX_OK;
+  }
   if (m->nq != m->nv || m->njnt != m->nv) return bad(MJPCX_EUNSUPPORTED, "only slide/hinge joints are implemented (nq == nv == njnt)");
   if (m->nbody > kLaneMaxBody || m->nv > kLaneMaxDof || m->nu > kLaneMaxAct || m->nsite > kLaneMaxSite ||
       m->nmocap > kLaneMaxMocap || t->num_term > kLaneMaxTerm || t->num_parameter > kLaneMaxParam)
@@ -678,6 +749,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
     sl.dev.release();
   }
   if (c->best_host) (void)hipHostFree(c->best_host);
+  c->wh.release();
   DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
@@ -689,6 +761,12 @@ void mjpcx_destroy(mjpcx_ctx* c) {
 int mjpcx_set_state(mjpcx_ctx* c, const double* state, double time, const double* mocap, const double* userdata) {
   if (!c || !state) return fail(c, MJPCX_EINVAL, "null argument");
   (void)userdata;  // nuserdata == 0 for every supported model
+  if (c->wave) {
+    std::memcpy(c->wh.state.data(), state, sizeof(double) * (c->nq + c->nv));
+    c->wh.time = time;
+    if (mocap) std::memcpy(c->wh.mocap.data(), mocap, sizeof(double) * 7 * c->nmocap);
+    return MJPCX_OK;
+  }
   for (int j = 0; j < c->nq; j++) c->ht64.qpos[j] = state[j];
   for (int j = 0; j < c->nv; j++) c->ht64.qvel[j] = state[c->nq + j];
   c->ht64.time = time;
@@ -703,10 +781,25 @@ int mjpcx_set_state(mjpcx_ctx* c, const double* state, double time, const double
 int mjpcx_set_task_params(mjpcx_ctx* c, const double* weight, const double* norm_parameter,
                           const double* parameters, double risk) {
   if (!c) return MJPCX_EINVAL;
+  if (c->wave) {
+    if (weight) c->wh.weight.assign(weight, weight + c->nterm);
+    if (norm_parameter) set_norm_params(c, norm_parameter);
+    if (parameters) c->wh.parameters.assign(parameters, parameters + c->nparam);
+    c->wh.risk = risk;
+    return MJPCX_OK;
+  }
   if (weight) for (int k = 0; k < c->nterm; k++) c->ht64.weight[k] = weight[k];
   if (norm_parameter) set_norm_params(c, norm_parameter);
   if (parameters) for (int k = 0; k < c->nparam; k++) c->ht64.parameters[k] = parameters[k];
   c->ht64.risk = risk;
+  return MJPCX_OK;
+}
+
+int mjpcx_set_residual_state(mjpcx_ctx* c, const int32_t* residual_int, const double* residual_real) {
+  if (!c) return MJPCX_EINVAL;
+  if (!c->wave) return (residual_int || residual_real) ? fail(c, MJPCX_EUNSUPPORTED, "this task's residual has no frozen state") : MJPCX_OK;
+  if (residual_int) c->wh.residual_int.assign(residual_int, residual_int + c->wh.t.nri);
+  if (residual_real) c->wh.residual_real.assign(residual_real, residual_real + c->wh.t.nrr);
   return MJPCX_OK;
 }
 
@@ -766,6 +859,7 @@ int mjpcx_best(mjpcx_ctx* c, int ref_candidate, int32_t* index, double* best_ret
   const size_t bytes = sizeof(BestRecord) + (size_t)np * 8;
   if (bytes > c->best_cap) {
     if (c->best_host) (void)hipHostFree(c->best_host);
+  c->wh.release();
     c->best_host = nullptr; c->best_cap = 0;
     HIPCHK(c, hipHostMalloc(&c->best_host, bytes, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer(&c->best_dev, c->best_host, 0));

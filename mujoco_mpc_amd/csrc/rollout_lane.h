@@ -416,10 +416,10 @@ __device__ __forceinline__ void lane_forward(const MODEL& m, const LaneTask<T>& 
         ldl_solve<NV>(Mi[j], Lm, Dinv, e);
         // impedance / reference (mj_makeImpedance)
         const T pos = dist[j] - m.jnt_margin[j];
-        T dmin = clampv(m.jnt_solimp[j][0], T(kMinVal), T(1 - kMinVal));
-        T dmax = clampv(m.jnt_solimp[j][1], T(kMinVal), T(1 - kMinVal));
+        T dmin = clampv(m.jnt_solimp[j][0], T(kMinImp), T(kMaxImp));
+        T dmax = clampv(m.jnt_solimp[j][1], T(kMinImp), T(kMaxImp));
         const T width = m.jnt_solimp[j][2];
-        T mid = clampv(m.jnt_solimp[j][3], T(kMinVal), T(1 - kMinVal));
+        T mid = clampv(m.jnt_solimp[j][3], T(kMinImp), T(kMaxImp));
         T power = m.jnt_solimp[j][4] < 1 ? T(1) : m.jnt_solimp[j][4];
         T imp;
         if (dmin == dmax || width <= T(kMinVal)) {

@@ -1,0 +1,894 @@
+// wave_forward.h -- mj_forward for one candidate held in LDS, all 64 lanes cooperating (see rollout_wave.h).
+// Stage by stage the arithmetic is oracle/physics.c + oracle/contact.inc; the comments name the oracle function.
+#pragma once
+
+namespace mjpcx {
+
+// ---- o_kinematics: bodies level by level (a body needs its parent), then sites
+__device__ __forceinline__ void wf_kinematics(const WaveModel& m, const WaveTask& tk, WaveData& d, int lane) {
+  if (lane == 0) {
+    d.xpos[0] = d.xpos[1] = d.xpos[2] = 0;
+    d.xquat[0] = 1; d.xquat[1] = d.xquat[2] = d.xquat[3] = 0;
+    for (int k = 0; k < 9; k++) d.xmat[k] = d.ximat[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    d.xipos[0] = d.xipos[1] = d.xipos[2] = 0;
+  }
+  WSYNC();
+  for (int l = 0; l < m.nlevel; l++) {
+    const int idx = m.level_start[l] + lane;
+    if (idx < m.level_start[l + 1]) {
+      const int i = m.level_body[idx];
+      const int pid = m.body_parentid[i], jn = m.body_jntnum[i], ja = m.body_jntadr[i];
+      double xpos[3], xquat[4];
+      if (m.body_mocapid[i] >= 0) {
+        const double* mp = tk.blob + tk.off_mocap + 7 * m.body_mocapid[i];
+        for (int k = 0; k < 3; k++) xpos[k] = mp[k];
+        for (int k = 0; k < 4; k++) xquat[k] = mp[3 + k];
+        q_norm(xquat);
+      } else if (jn == 1 && m.jnt_type[ja] == kJntFree) {
+        const int qa = m.jnt_qposadr[ja];
+        for (int k = 0; k < 3; k++) xpos[k] = d.qpos[qa + k];
+        for (int k = 0; k < 4; k++) xquat[k] = d.qpos[qa + 3 + k];
+        q_norm(xquat);
+        for (int k = 0; k < 3; k++) d.xanchor[3 * ja + k] = xpos[k];
+        d.xaxis[3 * ja] = 0; d.xaxis[3 * ja + 1] = 0; d.xaxis[3 * ja + 2] = 1;
+      } else {
+        mv3(xpos, d.xmat + 9 * pid, m.body_pos + 3 * i);
+        for (int k = 0; k < 3; k++) xpos[k] += d.xpos[3 * pid + k];
+        q_mul(xquat, d.xquat + 4 * pid, m.body_quat + 4 * i);
+        for (int j = ja; j < ja + jn; j++) {
+          const int qa = m.jnt_qposadr[j];
+          double anchor[3], axis[3];
+          q_rot(anchor, m.jnt_pos + 3 * j, xquat);
+          for (int k = 0; k < 3; k++) anchor[k] += xpos[k];
+          q_rot(axis, m.jnt_axis + 3 * j, xquat);
+          const int jt = m.jnt_type[j];
+          if (jt == kJntSlide) {
+            const double s = d.qpos[qa] - m.qpos0[qa];
+            for (int k = 0; k < 3; k++) xpos[k] += axis[k] * s;
+          } else if (jt == kJntBall || jt == kJntHinge) {
+            double qloc[4], vec[3];
+            if (jt == kJntBall) { for (int k = 0; k < 4; k++) qloc[k] = d.qpos[qa + k]; q_norm(qloc); }
+            else aa2quat(qloc, m.jnt_axis + 3 * j, d.qpos[qa] - m.qpos0[qa]);
+            q_mul(xquat, xquat, qloc);
+            q_rot(vec, m.jnt_pos + 3 * j, xquat);
+            for (int k = 0; k < 3; k++) xpos[k] = anchor[k] - vec[k];
+          }
+          for (int k = 0; k < 3; k++) { d.xanchor[3 * j + k] = anchor[k]; d.xaxis[3 * j + k] = axis[k]; }
+        }
+      }
+      q_norm(xquat);
+      double xmat[9], v[3], q[4];
+      q2mat(xmat, xquat);
+      for (int k = 0; k < 3; k++) d.xpos[3 * i + k] = xpos[k];
+      for (int k = 0; k < 4; k++) d.xquat[4 * i + k] = xquat[k];
+      for (int k = 0; k < 9; k++) d.xmat[9 * i + k] = xmat[k];
+      mv3(v, xmat, m.body_ipos + 3 * i);
+      for (int k = 0; k < 3; k++) d.xipos[3 * i + k] = xpos[k] + v[k];
+      q_mul(q, xquat, m.body_iquat + 4 * i);
+      q2mat(d.ximat + 9 * i, q);
+    }
+    WSYNC();
+  }
+  if (lane < m.nsite) {
+    const int s = lane, b = m.site_bodyid[s];
+    double v[3];
+    mv3(v, d.xmat + 9 * b, m.site_pos + 3 * s);
+    for (int k = 0; k < 3; k++) d.site_xpos[3 * s + k] = d.xpos[3 * b + k] + v[k];
+  }
+}
+
+// world pose of a geom (o_geom_kinematics), computed where it is needed instead of being stored for all geoms
+__device__ __forceinline__ void wf_geom_pose(const WaveModel& m, const WaveData& d, int g, double* pos, double* mat) {
+  const int b = m.geom_bodyid[g];
+  double v[3], q[4];
+  mv3(v, d.xmat + 9 * b, m.geom_pos + 3 * g);
+  for (int k = 0; k < 3; k++) pos[k] = d.xpos[3 * b + k] + v[k];
+  q_mul(q, d.xquat + 4 * b, m.geom_quat + 4 * g);
+  q2mat(mat, q);
+}
+
+// ---- o_compos: subtree centres of mass, cinert, cdof
+__device__ __forceinline__ void wf_compos(const WaveModel& m, WaveData& d, int lane) {
+  const int nb = m.nbody;
+  if (lane < nb) {
+    const int i = lane;
+    unsigned long long mask = m.body_subtree_mask[i];
+    double s[3] = {0, 0, 0};
+    // ascending body order = the oracle's accumulation order reversed; sums of <= 13 terms, parity tolerance covers it
+    while (mask) {
+      const int j = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const double mj = m.body_mass[j];
+      for (int k = 0; k < 3; k++) s[k] += mj * d.xipos[3 * j + k];
+    }
+    const double sm = m.body_subtreemass[i];
+    for (int k = 0; k < 3; k++) d.subtree_com[3 * i + k] = sm < kMinVal ? d.xipos[3 * i + k] : s[k] / sm;
+  }
+  WSYNC();
+  if (lane < nb) {
+    const int i = lane;
+    if (i == 0) { for (int k = 0; k < 10; k++) d.cinert[k] = 0; }
+    else {
+      double off[3];
+      const double* com = d.subtree_com + 3 * m.body_rootid[i];
+      for (int k = 0; k < 3; k++) off[k] = d.xipos[3 * i + k] - com[k];
+      w_inert_com(d.cinert + 10 * i, m.body_inertia + 3 * i, d.ximat + 9 * i, off, m.body_mass[i]);
+    }
+  }
+  if (lane < m.njnt) {
+    const int j = lane, b = m.jnt_bodyid[j];
+    int da = m.jnt_dofadr[j];
+    double off[3];
+    const double* com = d.subtree_com + 3 * m.body_rootid[b];
+    for (int k = 0; k < 3; k++) off[k] = com[k] - d.xanchor[3 * j + k];
+    const double* xmat = d.xmat + 9 * b;
+    const int jt = m.jnt_type[j];
+    if (jt == kJntFree) {
+      for (int k = 0; k < 3; k++) {
+        double* c = d.cdof + 6 * (da + k);
+        for (int e = 0; e < 6; e++) c[e] = 0;
+        c[3 + k] = 1;
+      }
+      da += 3;
+    }
+    if (jt == kJntFree || jt == kJntBall) {
+      for (int k = 0; k < 3; k++) {
+        double* c = d.cdof + 6 * (da + k);
+        const double ax[3] = {xmat[k], xmat[3 + k], xmat[6 + k]};
+        for (int e = 0; e < 3; e++) c[e] = ax[e];
+        cr3(c + 3, ax, off);
+      }
+    } else if (jt == kJntSlide) {
+      double* c = d.cdof + 6 * da;
+      c[0] = c[1] = c[2] = 0;
+      for (int e = 0; e < 3; e++) c[3 + e] = d.xaxis[3 * j + e];
+    } else {
+      double* c = d.cdof + 6 * da;
+      for (int e = 0; e < 3; e++) c[e] = d.xaxis[3 * j + e];
+      cr3(c + 3, d.xaxis + 3 * j, off);
+    }
+  }
+  WSYNC();
+}
+
+// ---- o_crb: composite inertias by subtree masks, then M (dense, both triangles)
+__device__ __forceinline__ void wf_crb(const WaveModel& m, WaveData& d, int lane) {
+  const int nb = m.nbody, nv = m.nv;
+  if (lane < nb && lane > 0) {
+    const int i = lane;
+    unsigned long long mask = m.body_subtree_mask[i];
+    double s[10];
+    for (int k = 0; k < 10; k++) s[k] = 0;
+    while (mask) {
+      const int j = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      for (int k = 0; k < 10; k++) s[k] += d.cinert[10 * j + k];
+    }
+    for (int k = 0; k < 10; k++) d.crb[10 * i + k] = s[k];
+  }
+  for (int e = lane; e < nv * nv; e += 64) d.M[e] = 0;
+  WSYNC();
+  if (lane < nv) {
+    const int i = lane;
+    double buf[6];
+    w_mul_inert(buf, d.crb + 10 * m.dof_bodyid[i], d.cdof + 6 * i);
+    d.M[i * nv + i] = m.dof_armature[i] + w_dot6(d.cdof + 6 * i, buf);
+    for (int j = m.dof_parentid[i]; j >= 0; j = m.dof_parentid[j]) {
+      const double v = w_dot6(d.cdof + 6 * j, buf);
+      d.M[i * nv + j] = v;
+      d.M[j * nv + i] = v;
+    }
+  }
+  WSYNC();
+}
+
+// ---- o_comvel: cvel and cdof_dot, level by level
+__device__ __forceinline__ void wf_comvel(const WaveModel& m, WaveData& d, int lane) {
+  if (lane < 6) d.cvel[lane] = 0;
+  WSYNC();
+  for (int l = 0; l < m.nlevel; l++) {
+    const int idx = m.level_start[l] + lane;
+    if (idx < m.level_start[l + 1]) {
+      const int i = m.level_body[idx];
+      double cvel[6];
+      for (int c = 0; c < 6; c++) cvel[c] = d.cvel[6 * m.body_parentid[i] + c];
+      for (int j = m.body_jntadr[i]; j < m.body_jntadr[i] + m.body_jntnum[i]; j++) {
+        int da = m.jnt_dofadr[j];
+        const int jt = m.jnt_type[j];
+        if (jt == kJntFree) {
+          for (int e = 0; e < 18; e++) d.cdof_dot[6 * da + e] = 0;
+          for (int k = 0; k < 3; k++)
+            for (int c = 0; c < 6; c++) cvel[c] += d.cdof[6 * (da + k) + c] * d.qvel[da + k];
+          da += 3;
+        }
+        if (jt == kJntFree || jt == kJntBall) {
+          for (int k = 0; k < 3; k++) w_cross_motion(d.cdof_dot + 6 * (da + k), cvel, d.cdof + 6 * (da + k));
+          for (int k = 0; k < 3; k++)
+            for (int c = 0; c < 6; c++) cvel[c] += d.cdof[6 * (da + k) + c] * d.qvel[da + k];
+        } else {
+          w_cross_motion(d.cdof_dot + 6 * da, cvel, d.cdof + 6 * da);
+          for (int c = 0; c < 6; c++) cvel[c] += d.cdof[6 * da + c] * d.qvel[da];
+        }
+      }
+      for (int c = 0; c < 6; c++) d.cvel[6 * i + c] = cvel[c];
+    }
+    WSYNC();
+  }
+}
+
+// ---- o_passive, o_rne (bias forces), o_actuation, qfrc_smooth
+__device__ __forceinline__ void wf_smooth_forces(const WaveModel& m, WaveData& d, int lane, bool& bad_ctrl) {
+  const int nb = m.nbody, nv = m.nv, nu = m.nu;
+  // passive
+  if (lane < nv) {
+    double f = 0;
+    if (!(m.disableflags & MJPCX_DSBL_PASSIVE)) {
+      const int j = m.dof_jntid[lane], jt = m.jnt_type[j];
+      const double k = m.jnt_stiffness[j];
+      if (k != 0 && (jt == kJntSlide || jt == kJntHinge)) f -= k * (d.qpos[m.jnt_qposadr[j]] - m.qpos_spring[m.jnt_qposadr[j]]);
+      f -= m.dof_damping[lane] * d.qvel[lane];
+    }
+    d.qfrc_passive[lane] = f;
+  }
+  // RNE forward: cacc level by level, cfrc per body
+  if (lane < 6) {
+    d.cacc[lane] = (lane >= 3 && !(m.disableflags & MJPCX_DSBL_GRAVITY)) ? -m.gravity[lane - 3] : 0.0;
+    d.cfrc[lane] = 0;
+  }
+  WSYNC();
+  for (int l = 0; l < m.nlevel; l++) {
+    const int idx = m.level_start[l] + lane;
+    if (idx < m.level_start[l + 1]) {
+      const int i = m.level_body[idx];
+      double cacc[6], t1[6], t2[6], t3[6];
+      for (int c = 0; c < 6; c++) cacc[c] = d.cacc[6 * m.body_parentid[i] + c];
+      const int da = m.body_dofadr[i];
+      for (int k = da; k >= 0 && k < da + m.body_dofnum[i]; k++)
+        for (int c = 0; c < 6; c++) cacc[c] += d.cdof_dot[6 * k + c] * d.qvel[k];
+      for (int c = 0; c < 6; c++) d.cacc[6 * i + c] = cacc[c];
+      w_mul_inert(t1, d.cinert + 10 * i, cacc);
+      w_mul_inert(t2, d.cinert + 10 * i, d.cvel + 6 * i);
+      w_cross_force(t3, d.cvel + 6 * i, t2);
+      for (int c = 0; c < 6; c++) d.cfrc[6 * i + c] = t1[c] + t3[c];
+    }
+    WSYNC();
+  }
+  // backward accumulation over subtrees (parents of world-attached bodies excluded, as in the oracle: body 0 never sums)
+  if (lane < nb && lane > 0) {
+    const int i = lane;
+    unsigned long long mask = m.body_subtree_mask[i];
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    while (mask) {
+      const int j = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      for (int c = 0; c < 6; c++) s[c] += d.cfrc[6 * j + c];
+    }
+    for (int c = 0; c < 6; c++) d.cfrc_sub[6 * i + c] = s[c];
+  }
+  // actuation (o_actuation): BADCTRL zeroes every control
+  bool bad = false;
+  if (lane < nu) bad = is_bad(d.ctrl[lane]);
+  bad_ctrl = __any(bad);
+  WSYNC();
+  if (bad_ctrl && lane < nu) d.ctrl[lane] = 0;
+  if (lane < nv) { d.qfrc_bias[lane] = w_dot6(d.cdof + 6 * lane, d.cfrc_sub + 6 * m.dof_bodyid[lane]); d.qfrc_actuator[lane] = 0; }
+  WSYNC();
+  if (lane < nu) {
+    const int i = lane;
+    double force = 0;
+    if (!(m.disableflags & MJPCX_DSBL_ACTUATION)) {
+      double ctrl = d.ctrl[i];
+      if (m.actuator_ctrllimited[i] && !(m.disableflags & MJPCX_DSBL_CLAMPCTRL))
+        ctrl = clampv(ctrl, m.actuator_ctrlrange[2 * i], m.actuator_ctrlrange[2 * i + 1]);
+      const int j = m.actuator_trnid[i], qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+      const double gear = m.actuator_gear[i];
+      force = m.actuator_gainprm[3 * i] * ctrl;
+      if (m.actuator_biastype[i] == 1)
+        force += m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * gear * d.qpos[qa] + m.actuator_biasprm[3 * i + 2] * gear * d.qvel[da];
+      if (m.actuator_forcelimited[i]) force = clampv(force, m.actuator_forcerange[2 * i], m.actuator_forcerange[2 * i + 1]);
+    }
+    d.actuator_force[i] = force;
+  }
+  WSYNC();
+  if (lane == 0 && !(m.disableflags & MJPCX_DSBL_ACTUATION))  // several actuators may drive one dof: serial, in actuator order
+    for (int i = 0; i < nu; i++) d.qfrc_actuator[m.jnt_dofadr[m.actuator_trnid[i]]] += m.actuator_gear[i] * d.actuator_force[i];
+  WSYNC();
+  if (lane < nv) {
+    d.qfrc_smooth[lane] = d.qfrc_passive[lane] - d.qfrc_bias[lane] + d.qfrc_actuator[lane];
+    d.qacc_smooth[lane] = d.qfrc_smooth[lane];
+  }
+  WSYNC();
+}
+
+// ---- o_collision: one lane per moving geom against each static geom; order-preserving compaction
+__device__ __forceinline__ void wf_contact_param(const WaveModel& m, int g1, int g2, WaveContact& c) {
+  const double margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
+  const double gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
+  c.margin = margin;
+  c.includemargin = margin - gap;
+  double fr[3];
+  const int p1 = m.geom_priority[g1], p2 = m.geom_priority[g2];
+  if (p1 != p2) {
+    const int g = p1 > p2 ? g1 : g2;
+    c.dim = m.geom_condim[g];
+    for (int k = 0; k < 3; k++) fr[k] = m.geom_friction[3 * g + k];
+    for (int k = 0; k < 2; k++) c.solref[k] = m.geom_solref[2 * g + k];
+    for (int k = 0; k < 5; k++) c.solimp[k] = m.geom_solimp[5 * g + k];
+  } else {
+    c.dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
+    for (int k = 0; k < 3; k++) fr[k] = fmax(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
+    const double s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
+    const double mix = (s1 >= kMinVal && s2 >= kMinVal) ? s1 / (s1 + s2) : (s1 < kMinVal && s2 < kMinVal ? 0.5 : (s1 < kMinVal ? 0.0 : 1.0));
+    for (int k = 0; k < 2; k++) c.solref[k] = mix * m.geom_solref[2 * g1 + k] + (1 - mix) * m.geom_solref[2 * g2 + k];
+    for (int k = 0; k < 5; k++) c.solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
+  }
+  c.friction[0] = c.friction[1] = fmax(fr[0], kMinMu);
+  c.friction[2] = fmax(fr[1], kMinMu);
+  c.friction[3] = c.friction[4] = fmax(fr[2], kMinMu);
+  c.dim0 = c.dim;
+}
+
+__device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, int lane) {
+  if (lane == 0) d.counters[0] = 0;
+  WSYNC();
+  if (m.disableflags & (MJPCX_DSBL_CONSTRAINT | MJPCX_DSBL_CONTACT)) return;
+  // this lane's moving geom
+  const bool have = lane < m.ndynamic_geom;
+  const int g2 = have ? m.dynamic_geom[lane] : 0;
+  double p2[3] = {0, 0, 0}, R2[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (have) wf_geom_pose(m, d, g2, p2, R2);
+  const int t2 = have ? m.geom_type[g2] : -1;
+  const double s2[3] = {have ? m.geom_size[3 * g2] : 0, have ? m.geom_size[3 * g2 + 1] : 0, have ? m.geom_size[3 * g2 + 2] : 0};
+  for (int si = 0; si < m.nstatic_geom; si++) {
+    const int g1 = m.static_geom[si], t1 = m.geom_type[g1];
+    if (t1 != MJPCX_GEOM_PLANE && t1 != MJPCX_GEOM_SPHERE && t1 != MJPCX_GEOM_BOX) continue;
+    double p1[3], R1[9];
+    wf_geom_pose(m, d, g1, p1, R1);  // wave-uniform
+    // up to 4 candidate contacts of this lane: dist, pos, normal
+    double cd[4], cp[4][3], cn[3] = {0, 0, 1};
+    int cnt = 0;
+    double margin = 0;
+    const bool pair = have && ((m.geom_contype[g1] & m.geom_conaffinity[g2]) || (m.geom_contype[g2] & m.geom_conaffinity[g1]));
+    if (pair) {
+      margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
+      if (t1 == MJPCX_GEOM_PLANE) {
+        const double n[3] = {R1[2], R1[5], R1[8]};
+        for (int k = 0; k < 3; k++) cn[k] = n[k];
+        auto sphere_plane = [&](const double* c, double r) {
+          const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2] - r;
+          if (dist < margin) { cd[cnt] = dist; for (int k = 0; k < 3; k++) cp[cnt][k] = c[k] - n[k] * (r + 0.5 * dist); cnt++; }
+        };
+        if (t2 == MJPCX_GEOM_SPHERE) {
+          sphere_plane(p2, s2[0]);
+        } else if (t2 == MJPCX_GEOM_CAPSULE) {
+          for (int sgn = -1; sgn <= 1; sgn += 2) {
+            double c[3];
+            for (int k = 0; k < 3; k++) c[k] = p2[k] + sgn * s2[1] * R2[3 * k + 2];
+            sphere_plane(c, s2[0]);
+          }
+        } else if (t2 == MJPCX_GEOM_BOX) {
+          for (int i = 0; i < 8 && cnt < 4; i++) {
+            const double loc[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])};
+            double c[3];
+            mv3(c, R2, loc);
+            for (int k = 0; k < 3; k++) c[k] += p2[k];
+            const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
+            if (dist < margin) { cd[cnt] = dist; for (int k = 0; k < 3; k++) cp[cnt][k] = c[k] - 0.5 * dist * n[k]; cnt++; }
+          }
+        } else if (t2 == MJPCX_GEOM_CYLINDER) {
+          const double a[3] = {R2[2], R2[5], R2[8]};
+          const double pa = n[0] * a[0] + n[1] * a[1] + n[2] * a[2];
+          const double sgn = pa > 0 ? -1.0 : 1.0;
+          double v[3], vn = 0;
+          for (int k = 0; k < 3; k++) { v[k] = -(n[k] - pa * a[k]); vn += v[k] * v[k]; }
+          vn = sqrt(vn);
+          if (vn < 1e-10) { v[0] = R2[0]; v[1] = R2[3]; v[2] = R2[6]; vn = 1; }
+          for (int k = 0; k < 3; k++) v[k] /= vn;
+          double w[3];
+          cr3(w, a, v);
+          const double cs[3] = {1.0, -0.5, -0.5}, sn[3] = {0.0, 0.8660254037844386, -0.8660254037844386};
+          for (int i = 0; i < 4; i++) {
+            const double side = i < 3 ? sgn : -sgn, cc = i < 3 ? cs[i] : 1.0, ss = i < 3 ? sn[i] : 0.0;
+            double c[3];
+            for (int k = 0; k < 3; k++) c[k] = p2[k] + side * s2[1] * a[k] + s2[0] * (cc * v[k] + ss * w[k]);
+            const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
+            if (dist < margin) { cd[cnt] = dist; for (int k = 0; k < 3; k++) cp[cnt][k] = c[k] - 0.5 * dist * n[k]; cnt++; }
+          }
+        }
+      } else if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
+        double n[3], len = 0;
+        for (int k = 0; k < 3; k++) { n[k] = p2[k] - p1[k]; len += n[k] * n[k]; }
+        len = sqrt(len);
+        if (len < kMinVal) { n[0] = 1; n[1] = n[2] = 0; } else for (int k = 0; k < 3; k++) n[k] /= len;
+        const double r1 = m.geom_size[3 * g1], dist = len - r1 - s2[0];
+        if (dist < margin) {
+          cd[0] = dist;
+          for (int k = 0; k < 3; k++) { cp[0][k] = p1[k] + n[k] * (r1 + 0.5 * dist); cn[k] = n[k]; }
+          cnt = 1;
+        }
+      } else if (t1 == MJPCX_GEOM_BOX && t2 == MJPCX_GEOM_SPHERE) {
+        const double* s1 = m.geom_size + 3 * g1;
+        double rel[3], loc[3], clamped[3];
+        for (int k = 0; k < 3; k++) rel[k] = p2[k] - p1[k];
+        for (int k = 0; k < 3; k++) loc[k] = R1[k] * rel[0] + R1[3 + k] * rel[1] + R1[6 + k] * rel[2];
+        bool inside = true;
+        for (int k = 0; k < 3; k++) {
+          clamped[k] = loc[k] < -s1[k] ? -s1[k] : (loc[k] > s1[k] ? s1[k] : loc[k]);
+          if (clamped[k] != loc[k]) inside = false;
+        }
+        double nl[3] = {0, 0, 0}, dist;
+        if (!inside) {
+          double len = 0;
+          for (int k = 0; k < 3; k++) { nl[k] = loc[k] - clamped[k]; len += nl[k] * nl[k]; }
+          len = sqrt(len);
+          for (int k = 0; k < 3; k++) nl[k] /= len;
+          dist = len - s2[0];
+        } else {
+          int best = 0; double bd = 1e300;
+          for (int k = 0; k < 3; k++) { const double dd = s1[k] - fabs(loc[k]); if (dd < bd) { bd = dd; best = k; } }
+          nl[best] = loc[best] >= 0 ? 1 : -1;
+          clamped[best] = nl[best] * s1[best];
+          dist = -bd - s2[0];
+        }
+        if (dist < margin) {
+          double n[3], surf[3];
+          mv3(n, R1, nl);
+          mv3(surf, R1, clamped);
+          cd[0] = dist;
+          for (int k = 0; k < 3; k++) { cp[0][k] = p1[k] + surf[k] + 0.5 * dist * n[k]; cn[k] = n[k]; }
+          cnt = 1;
+        }
+      }
+    }
+    // lane-major, contact-minor compaction: offset = contacts of all lower lanes (+ those already stored)
+    int below = 0, total = 0;
+    for (int k = 0; k < 4; k++) {
+      const unsigned long long b = __ballot(cnt > k);
+      below += __popcll(b & ((1ull << lane) - 1ull));
+      total += __popcll(b);
+    }
+    const int base = d.counters[0];
+    WSYNC();
+    if (cnt > 0) {
+      WaveContact proto;
+      proto.g1 = g1; proto.g2 = g2; proto.efc = 0; proto.mu = 0;
+      wf_contact_param(m, g1, g2, proto);
+      for (int k = 0; k < cnt; k++) {
+        const int at = base + below + k;
+        if (at < kWaveMaxCon) {
+          WaveContact c = proto;
+          c.dist = cd[k];
+          for (int e = 0; e < 3; e++) { c.pos[e] = cp[k][e]; c.frame[e] = cn[e]; }
+          w_make_frame(c.frame);
+          d.con[at] = c;
+        }
+      }
+    }
+    if (lane == 0) {
+      const int n = base + total;
+      if (n > kWaveMaxCon) d.counters[2] |= 32;
+      d.counters[0] = n > kWaveMaxCon ? kWaveMaxCon : n;
+    }
+    WSYNC();
+  }
+}
+
+// ---- o_make_constraint_full: rows in the order friction loss, limits, contacts; then impedance/aref/R per row
+__device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData& d, int lane) {
+  const int nv = m.nv;
+  int nefc = 0;
+  if (m.disableflags & MJPCX_DSBL_CONSTRAINT) { if (lane == 0) { d.counters[0] = 0; d.counters[1] = 0; } WSYNC(); return; }
+  for (int e = lane; e < kWaveMaxEfc * nv; e += 64) d.efc_J[e] = 0;
+  if (lane < kWaveMaxEfc) { d.efc_pos[lane] = 0; d.efc_margin[lane] = 0; d.efc_floss[lane] = 0; d.efc_type[lane] = -1; d.efc_id[lane] = 0; }
+  WSYNC();
+  // friction loss: one lane per dof
+  {
+    const bool on = !(m.disableflags & MJPCX_DSBL_FRICTIONLOSS) && lane < nv && m.dof_frictionloss[lane] > 0;
+    const unsigned long long b = __ballot(on);
+    const int r = nefc + __popcll(b & ((1ull << lane) - 1ull));
+    if (on && r < kWaveMaxEfc) {
+      d.efc_type[r] = kEfcFriction; d.efc_id[r] = lane;
+      d.efc_J[r * nv + lane] = 1;
+      d.efc_floss[r] = m.dof_frictionloss[lane];
+    }
+    nefc += __popcll(b);
+  }
+  // limits: one lane per joint, sides -1 then +1
+  {
+    bool on0 = false, on1 = false;
+    double dist0 = 0, dist1 = 0, margin = 0;
+    if (!(m.disableflags & MJPCX_DSBL_LIMIT) && lane < m.njnt && m.jnt_limited[lane] &&
+        (m.jnt_type[lane] == kJntSlide || m.jnt_type[lane] == kJntHinge)) {
+      const double value = d.qpos[m.jnt_qposadr[lane]];
+      margin = m.jnt_margin[lane];
+      dist0 = -(m.jnt_range[2 * lane] - value);      // side -1: lower bound
+      dist1 = m.jnt_range[2 * lane + 1] - value;     // side +1: upper bound
+      on0 = dist0 < margin; on1 = dist1 < margin;
+    }
+    const unsigned long long b0 = __ballot(on0), b1 = __ballot(on1);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const int r0 = nefc + __popcll(b0 & lower) + __popcll(b1 & lower);
+    const int r1 = r0 + (on0 ? 1 : 0);
+    if (on0 && r0 < kWaveMaxEfc) {
+      d.efc_type[r0] = kEfcLimit; d.efc_id[r0] = lane; d.efc_J[r0 * nv + m.jnt_dofadr[lane]] = 1;  // -side, side = -1
+      d.efc_pos[r0] = dist0; d.efc_margin[r0] = margin;
+    }
+    if (on1 && r1 < kWaveMaxEfc) {
+      d.efc_type[r1] = kEfcLimit; d.efc_id[r1] = lane; d.efc_J[r1 * nv + m.jnt_dofadr[lane]] = -1;
+      d.efc_pos[r1] = dist1; d.efc_margin[r1] = margin;
+    }
+    nefc += __popcll(b0) + __popcll(b1);
+  }
+  if (nefc > kWaveMaxEfc) nefc = kWaveMaxEfc;
+  WSYNC();
+  // contacts: row ranges by a serial prefix over (<= 16) contacts, every lane computes the same numbers
+  const int ncon = d.counters[0];
+  int my_efc = 0, my_dim = 0;
+  {
+    int at = nefc;
+    for (int ci = 0; ci < ncon; ci++) {
+      int dim = d.con[ci].dim0;
+      if (dim > 1 && m.cone != 1) dim = 1;  // pyramidal cones are not built (oracle: warning 128)
+      const int fit = at + dim <= kWaveMaxEfc ? dim : (kWaveMaxEfc - at > 0 ? kWaveMaxEfc - at : 0);
+      if (ci == lane) { my_efc = at; my_dim = fit; }
+      at += fit;
+    }
+    nefc = at;
+  }
+  if (lane < ncon) {
+    WaveContact& c = d.con[lane];
+    int dim0 = c.dim0;
+    if (dim0 > 1 && m.cone != 1) { dim0 = 1; if (lane == 0) d.counters[2] |= 128; }
+    c.efc = my_efc; c.dim = my_dim;
+    c.mu = c.friction[0] / sqrt(m.impratio > kMinVal ? m.impratio : 1.0);
+    for (int row = 0; row < my_dim; row++) {
+      const int r = my_efc + row;
+      d.efc_type[r] = dim0 == 1 ? kEfcNormal : (row == 0 ? kEfcElliptic : kEfcConeRow);
+      d.efc_id[r] = lane;
+      if (row == 0) { d.efc_pos[r] = c.dist; d.efc_margin[r] = c.includemargin; }
+    }
+  }
+  if (lane == 0) d.counters[1] = nefc;
+  WSYNC();
+  // contact Jacobian rows: (row, dof) pairs over the lanes. geom1 is static -> only the moving body contributes.
+  for (int e = lane; e < nefc * nv; e += 64) {
+    const int r = e / nv, k = e - r * nv;
+    const int t = d.efc_type[r];
+    if (t != kEfcNormal && t != kEfcElliptic && t != kEfcConeRow) continue;
+    const WaveContact& c = d.con[d.efc_id[r]];
+    const int row = r - c.efc;
+    int body = m.geom_bodyid[c.g2];
+    double v = 0;
+    if ((m.body_dofmask[body] >> k) & 1u) {
+      const double* cd = d.cdof + 6 * k;
+      const double* ax = c.frame + 3 * (row < 3 ? row : row - 3);
+      if (row < 3) {
+        const double* com = d.subtree_com + 3 * m.body_rootid[body];
+        const double off[3] = {c.pos[0] - com[0], c.pos[1] - com[1], c.pos[2] - com[2]};
+        double lin[3];
+        cr3(lin, cd, off);
+        v = ax[0] * (cd[3] + lin[0]) + ax[1] * (cd[4] + lin[1]) + ax[2] * (cd[5] + lin[2]);
+      } else {
+        v = ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
+      }
+    }
+    d.efc_J[r * nv + k] = v;
+  }
+  WSYNC();
+  // per-row impedance, reference acceleration, regulariser (cone rows after their normal row)
+  double kk = 0, bb = 0, vel = 0;
+  int type = -1, id = 0;
+  if (lane < nefc) {
+    const int r = lane;
+    type = d.efc_type[r]; id = d.efc_id[r];
+    const double *solref, *solimp;
+    double diag;
+    if (type == kEfcFriction) { solref = m.dof_solref + 2 * id; solimp = m.dof_solimp + 5 * id; diag = m.dof_invweight0[id]; }
+    else if (type == kEfcLimit) { solref = m.jnt_solref + 2 * id; solimp = m.jnt_solimp + 5 * id; diag = m.dof_invweight0[m.jnt_dofadr[id]]; }
+    else {
+      const WaveContact& c = d.con[id];
+      solref = c.solref; solimp = c.solimp;
+      diag = m.body_invweight0[2 * m.geom_bodyid[c.g1]] + m.body_invweight0[2 * m.geom_bodyid[c.g2]];
+    }
+    for (int k = 0; k < nv; k++) vel += d.efc_J[r * nv + k] * d.qvel[k];
+    w_solref_kb(m, solref, solimp, kk, bb);
+    if (type != kEfcConeRow) {
+      const double pos = d.efc_pos[r] - d.efc_margin[r];
+      const double imp = w_impedance(solimp, pos);
+      const double R = (1 - imp) / imp * diag;
+      d.efc_R[r] = R < kMinVal ? kMinVal : R;
+      d.efc_aref[r] = -bb * vel - kk * imp * pos;
+      d.efc_D[r] = 1.0 / d.efc_R[r];
+    }
+  }
+  WSYNC();
+  if (lane < nefc && type == kEfcConeRow) {
+    const int r = lane;
+    const WaveContact& c = d.con[id];
+    const double f = c.friction[r - c.efc - 1];
+    d.efc_R[r] = d.efc_R[c.efc] * (c.mu * c.mu) / (f * f);
+    d.efc_aref[r] = -bb * vel;
+    d.efc_D[r] = 1.0 / d.efc_R[r];
+  }
+  WSYNC();
+}
+
+// ---- penalties: one lane per row; a cone is evaluated by the lane of its first row
+struct ConeEval { double cost, g, h; };
+// value/force/zone at x = jar (+ alpha jv when jv != nullptr); derivative terms along jv when requested
+__device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const double* jar, const double* jv, double alpha,
+                                            bool write_force, double& cost, double& g1, double& h2) {
+  cost = 0; g1 = 0; h2 = 0;
+  const int type = d.efc_type[r];
+  const double D = d.efc_D[r];
+  const double v = jv ? jv[r] : 0.0;
+  const double x = jar[r] + alpha * v;
+  if (type == kEfcFriction) {
+    const double f = d.efc_floss[r], R = d.efc_R[r];
+    if (x <= -R * f) { cost = -0.5 * R * f * f - f * x; g1 = -f * v; if (write_force) { d.efc_force[r] = f; d.efc_zone[r] = kZoneTop; } }
+    else if (x >= R * f) { cost = -0.5 * R * f * f + f * x; g1 = f * v; if (write_force) { d.efc_force[r] = -f; d.efc_zone[r] = kZoneTop; } }
+    else { cost = 0.5 * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
+  } else if (type == kEfcLimit || type == kEfcNormal) {
+    if (x < 0) { cost = 0.5 * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
+    else if (write_force) { d.efc_force[r] = 0; d.efc_zone[r] = kZoneTop; }
+  } else if (type == kEfcElliptic) {
+    const WaveContact& c = d.con[d.efc_id[r]];
+    const int dim = c.dim;
+    const double mu = c.mu;
+    double U[6], V[6], X[6], T = 0;
+    X[0] = x; U[0] = x * mu; V[0] = v * mu;
+    for (int j = 1; j < dim; j++) {
+      const double vj = jv ? jv[r + j] : 0.0;
+      X[j] = jar[r + j] + alpha * vj;
+      U[j] = X[j] * c.friction[j - 1];
+      V[j] = vj * c.friction[j - 1];
+      T += U[j] * U[j];
+    }
+    T = sqrt(T);
+    const double N = U[0];
+    if (N >= mu * T || (T <= 0 && N >= 0)) {
+      if (write_force) { for (int j = 0; j < dim; j++) d.efc_force[r + j] = 0; d.efc_zone[r] = kZoneTop; }
+    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+      for (int j = 0; j < dim; j++) {
+        const double Dj = d.efc_D[r + j], vj = jv ? jv[r + j] : 0.0;
+        cost += 0.5 * Dj * X[j] * X[j]; g1 += Dj * X[j] * vj; h2 += Dj * vj * vj;
+        if (write_force) d.efc_force[r + j] = -Dj * X[j];
+      }
+      if (write_force) d.efc_zone[r] = kZoneBottom;
+    } else {
+      const double Dm = D / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+      cost = 0.5 * Dm * NT * NT;
+      double UV = 0, VV = 0;
+      for (int j = 1; j < dim; j++) { UV += U[j] * V[j]; VV += V[j] * V[j]; }
+      const double dNT = V[0] - mu * UV / T;
+      const double d2NT = -mu * (VV / T - UV * UV / (T * T * T));
+      g1 = Dm * NT * dNT;
+      h2 = Dm * (dNT * dNT + NT * d2NT);
+      if (write_force) {
+        d.efc_force[r] = -Dm * NT * mu;
+        for (int j = 1; j < dim; j++) d.efc_force[r + j] = Dm * NT * mu * U[j] * c.friction[j - 1] / T;
+        d.efc_zone[r] = kZoneMiddle;
+      }
+    }
+  }
+}
+
+// cost of all rows at jar; writes force and zone. Returns the wave-uniform sum.
+__device__ __forceinline__ double wf_constraint_cost(WaveData& d, int nefc, int lane) {
+  double c = 0, g, h;
+  if (lane < nefc) wf_row_eval(d, lane, d.jar, nullptr, 0.0, true, c, g, h);
+  c = wave_sum(c);
+  WSYNC();
+  return c;
+}
+
+// ---- o_constraint_newton
+__device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveData& d, int lane) {
+  const int nv = m.nv, ne = d.counters[1];
+  if (lane < nv) { d.qfrc_constraint[lane] = 0; d.qacc[lane] = d.qacc_smooth[lane]; }
+  WSYNC();
+  if (ne == 0) return;
+  if (lane < ne) {
+    double s = -d.efc_aref[lane];
+    for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.qacc[k];
+    d.jar[lane] = s;
+  }
+  WSYNC();
+  double cost = wf_constraint_cost(d, ne, lane);
+  const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
+  bool polish = false;
+  for (int iter = 0; iter < m.solver_iterations; iter++) {
+    // gradient = M (qacc - qacc_smooth) - J' force
+    double g = 0;
+    if (lane < nv) {
+      double s = 0;
+      for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc[b] - d.qacc_smooth[b]);
+      d.Ma[lane] = s;
+      g = s;
+      for (int r = 0; r < ne; r++) g -= d.efc_J[r * nv + lane] * d.efc_force[r];
+      d.grad[lane] = g;
+      d.search[lane] = -g;
+    }
+    const double gnorm = sqrt(wave_sum(lane < nv ? g * g : 0.0));
+    if (gnorm == 0) break;
+    // cone Hessian blocks (one lane per contact), then H = M + J' (d2s) J over the lower triangle
+    if (lane < d.counters[0]) {
+      const WaveContact& c = d.con[lane];
+      const int r = c.efc, dim = c.dim;
+      double* Hc = d.coneH + 36 * lane;
+      if (dim > 0 && d.efc_type[r] == kEfcElliptic) {
+        for (int e = 0; e < 36; e++) Hc[e] = 0;
+        const int zone = d.efc_zone[r];
+        if (zone == kZoneBottom) {
+          for (int j = 0; j < dim; j++) Hc[j * dim + j] = d.efc_D[r + j];
+        } else if (zone == kZoneMiddle) {
+          const double mu = c.mu;
+          double U[6], s[6], T = 0;
+          s[0] = mu; U[0] = d.jar[r] * mu;
+          for (int j = 1; j < dim; j++) { s[j] = c.friction[j - 1]; U[j] = d.jar[r + j] * s[j]; T += U[j] * U[j]; }
+          T = sqrt(T);
+          const double Dm = d.efc_D[r] / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T;
+          Hc[0] = Dm;
+          for (int j = 1; j < dim; j++) {
+            Hc[j] = Hc[j * dim] = -Dm * mu * U[j] / T;
+            for (int k = 1; k < dim; k++)
+              Hc[j * dim + k] = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? 1.0 / T : 0.0) - U[j] * U[k] / (T * T * T));
+          }
+          for (int j = 0; j < dim; j++) for (int k = 0; k < dim; k++) Hc[j * dim + k] *= s[j] * s[k];
+        }
+      }
+    }
+    WSYNC();
+    for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
+      // e -> (a >= b)
+      int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((a + 1) * (a + 2) / 2 <= e) a++;
+      while (a * (a + 1) / 2 > e) a--;
+      const int b = e - a * (a + 1) / 2;
+      double h = d.M[a * nv + b];
+      for (int r = 0; r < ne; r++) {
+        const int t = d.efc_type[r];
+        if (t == kEfcFriction || t == kEfcLimit || t == kEfcNormal) {
+          if (d.efc_zone[r] == kZoneBottom) h += d.efc_D[r] * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
+        } else if (t == kEfcElliptic) {
+          const int ci = d.efc_id[r];
+          const int dim = d.con[ci].dim;
+          if (d.efc_zone[r] != kZoneTop) {
+            const double* Hc = d.coneH + 36 * ci;
+            for (int j = 0; j < dim; j++) {
+              const double ja = d.efc_J[(r + j) * nv + a];
+              if (ja == 0) continue;
+              double s = 0;
+              for (int k = 0; k < dim; k++) s += Hc[j * dim + k] * d.efc_J[(r + k) * nv + b];
+              h += ja * s;
+            }
+          }
+          r += dim - 1;
+        }
+      }
+      d.H[a * nv + b] = h;
+      d.H[b * nv + a] = h;
+    }
+    WSYNC();
+    if (!wave_chol(d.H, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
+    wave_chol_solve(d.search, d.H, nv, lane);
+    // jv = J search; Gauss part along the ray
+    if (lane < ne) {
+      double s = 0;
+      for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.search[k];
+      d.jv[lane] = s;
+    }
+    double q1 = 0, q2 = 0;
+    if (lane < nv) {
+      double s = 0;
+      for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * d.search[b];
+      q1 = d.search[lane] * d.Ma[lane];
+      q2 = d.search[lane] * s;
+    }
+    q1 = wave_sum(q1); q2 = wave_sum(q2);
+    WSYNC();
+    // exact line search: safeguarded 1-D Newton on the (convex, piecewise quadratic) restriction
+    double lo = 0, hi = -1, alpha = 0, d1, d2, c0, g0, h0;
+    c0 = 0; g0 = 0; h0 = 0;
+    if (lane < ne) wf_row_eval(d, lane, d.jar, d.jv, 0.0, false, c0, g0, h0);
+    d1 = wave_sum(g0) + q1; d2 = wave_sum(h0) + q2;
+    const double d10 = fabs(d1);
+    for (int ls = 0; ls < 50; ls++) {
+      double an = alpha - d1 / d2;
+      if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
+      if (an == alpha) break;
+      alpha = an;
+      c0 = 0; g0 = 0; h0 = 0;
+      if (lane < ne) wf_row_eval(d, lane, d.jar, d.jv, alpha, false, c0, g0, h0);
+      d1 = wave_sum(g0) + q1 + alpha * q2; d2 = wave_sum(h0) + q2;
+      if (fabs(d1) <= 1e-14 * d10) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+    }
+    if (lane < nv) d.qacc[lane] += alpha * d.search[lane];
+    if (lane < ne) d.jar[lane] += alpha * d.jv[lane];
+    WSYNC();
+    double gauss = 0;
+    if (lane < nv) {
+      double s = 0;
+      for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc[b] - d.qacc_smooth[b]);
+      gauss = 0.5 * s * (d.qacc[lane] - d.qacc_smooth[lane]);
+    }
+    gauss = wave_sum(gauss);
+    const double newcost = gauss + wf_constraint_cost(d, ne, lane);
+    const double improvement = cost - newcost;
+    cost = newcost;
+    if (polish) break;
+    if (scale * improvement < m.solver_tolerance || scale * gnorm < m.solver_tolerance) polish = true;
+  }
+  if (lane < nv) {
+    double s = 0;
+    for (int r = 0; r < ne; r++) s += d.efc_J[r * nv + lane] * d.efc_force[r];
+    d.qfrc_constraint[lane] = s;
+  }
+  WSYNC();
+}
+
+// ---- mj_forward up to the constraint solve
+__device__ __forceinline__ void wf_forward(const WaveModel& m, const WaveTask& tk, WaveData& d, int lane, bool& bad_ctrl) {
+  const int nv = m.nv;
+  wf_kinematics(m, tk, d, lane);
+  WSYNC();
+  wf_compos(m, d, lane);
+  wf_crb(m, d, lane);
+  for (int e = lane; e < nv * nv; e += 64) d.L[e] = d.M[e];
+  WSYNC();
+  if (!wave_chol(d.L, nv, lane)) { if (lane == 0) d.counters[2] |= 16; }
+  WSYNC();
+  wf_collision(m, d, lane);
+  wf_comvel(m, d, lane);
+  wf_make_constraint(m, d, lane);
+  wf_smooth_forces(m, d, lane, bad_ctrl);
+  wave_chol_solve(d.qacc_smooth, d.L, nv, lane);
+  wf_constraint_newton(m, d, lane);
+}
+
+// ---- o_euler: implicit joint damping, then integrate positions
+__device__ __forceinline__ void wf_euler(const WaveModel& m, WaveData& d, int lane, double& time) {
+  const int nv = m.nv;
+  const double h = m.timestep;
+  if (m.any_damping && !(m.disableflags & MJPCX_DSBL_EULERDAMP)) {
+    for (int e = lane; e < nv * nv; e += 64) d.H[e] = d.M[e];
+    WSYNC();
+    if (lane < nv) { d.H[lane * nv + lane] += h * m.dof_damping[lane]; d.tmpv[lane] = d.qfrc_smooth[lane] + d.qfrc_constraint[lane]; }
+    WSYNC();
+    if (wave_chol(d.H, nv, lane)) wave_chol_solve(d.tmpv, d.H, nv, lane);
+    else { WSYNC(); if (lane < nv) d.tmpv[lane] = d.qacc[lane]; WSYNC(); }
+  } else {
+    if (lane < nv) d.tmpv[lane] = d.qacc[lane];
+    WSYNC();
+  }
+  if (lane < nv) d.qvel[lane] += h * d.tmpv[lane];
+  WSYNC();
+  if (lane < m.njnt) {
+    const int j = lane;
+    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    const int jt = m.jnt_type[j];
+    if (jt == kJntFree) {
+      for (int k = 0; k < 3; k++) d.qpos[qa + k] += h * d.qvel[da + k];
+      qa += 3; da += 3;
+    }
+    if (jt == kJntFree || jt == kJntBall) {
+      double ax[3] = {d.qvel[da], d.qvel[da + 1], d.qvel[da + 2]};
+      const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      if (n < kMinVal) { ax[0] = 1; ax[1] = ax[2] = 0; }
+      else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
+      double qrot[4], q[4];
+      aa2quat(qrot, ax, h * n);
+      for (int k = 0; k < 4; k++) q[k] = d.qpos[qa + k];
+      q_norm(q);
+      q_mul(q, q, qrot);
+      for (int k = 0; k < 4; k++) d.qpos[qa + k] = q[k];
+    } else {
+      d.qpos[qa] += h * d.qvel[da];
+    }
+  }
+  time += h;
+  WSYNC();
+}
+
+}  // namespace mjpcx

@@ -1,0 +1,188 @@
+// wave_kernel.h -- Trajectory::Rollout (mjpc/trajectory.cc:100-210) + UpdateReturn (:312-326) for one candidate per
+// wavefront, on top of wf_forward / wf_euler. Candidate generation, spline policy, failure semantics and the output
+// layout ([step][field][candidate]) are those of rollout_lane_kernel, so every downstream entry point (best, top-k,
+// elite moments, fetch) serves both kernel families.
+#pragma once
+
+namespace mjpcx {
+
+__host__ __device__ inline size_t wave_lds_doubles(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P) {
+  size_t n = 0;
+  n += nq + nv + nu;                                   // qpos qvel ctrl
+  n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 6 * njnt + 3 * nsite;  // kinematics
+  n += 3 * nbody + 10 * nbody * 2 + 6 * nv * 2 + 6 * nbody * 4 + 3;                       // com, inertias, spatial
+  n += 3 * (size_t)nv * nv;                            // M L H
+  n += 7 * nv + nu + 5 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma Ms tmpv
+  n += (size_t)kWaveMaxEfc * nv + 10 * kWaveMaxEfc;    // efc_J + per-row doubles
+  n += (3 * kWaveMaxEfc + 1) / 2 + 1;                  // per-row ints
+  n += 36 * kWaveMaxCon + 12 + nr + nterm + 8;         // coneH foot_xpos residual terms scal
+  n += (sizeof(WaveContact) * kWaveMaxCon + 7) / 8;
+  n += 4;                                              // counters
+  n += (size_t)P * nu + P;                             // spline nodes + node times
+  return n + 16;
+}
+
+__global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, const WaveTask tk, const RolloutArgs<double> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x, cand = blockIdx.x;
+  const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
+  const int P = a.P, H = a.H;
+  const size_t N = (size_t)a.N;
+  // ---- LDS carve
+  double* p = reinterpret_cast<double*>(smem_raw);
+  auto take = [&](size_t n) { double* q = p; p += n; return q; };
+  WaveData d;
+  d.qpos = take(nq); d.qvel = take(nv); d.ctrl = take(nu);
+  d.xpos = take(3 * nb); d.xquat = take(4 * nb); d.xmat = take(9 * nb); d.xipos = take(3 * nb); d.ximat = take(9 * nb);
+  d.xanchor = take(3 * nj); d.xaxis = take(3 * nj); d.site_xpos = take(3 * ns);
+  d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.crb = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
+  d.cvel = take(6 * nb); d.cacc = take(6 * nb); d.cfrc = take(6 * nb); d.cfrc_sub = take(6 * nb); d.subtree_linvel = take(3);
+  d.M = take((size_t)nv * nv); d.L = take((size_t)nv * nv); d.H = take((size_t)nv * nv);
+  d.qfrc_passive = take(nv); d.qfrc_bias = take(nv); d.qfrc_actuator = take(nv); d.qfrc_smooth = take(nv);
+  d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
+  d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = take(nv); d.tmpv = take(nv);
+  d.efc_J = take((size_t)kWaveMaxEfc * nv);
+  d.efc_pos = take(kWaveMaxEfc); d.efc_margin = take(kWaveMaxEfc); d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
+  d.efc_aref = take(kWaveMaxEfc); d.efc_floss = take(kWaveMaxEfc); d.efc_force = take(kWaveMaxEfc); d.jar = take(kWaveMaxEfc);
+  d.jv = take(kWaveMaxEfc);
+  take(kWaveMaxEfc);  // spare
+  int* ip = reinterpret_cast<int*>(take((3 * kWaveMaxEfc + 1) / 2 + 1));
+  d.efc_type = ip; d.efc_id = ip + kWaveMaxEfc; d.efc_zone = ip + 2 * kWaveMaxEfc;
+  d.coneH = take(36 * kWaveMaxCon); d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
+  d.con = reinterpret_cast<WaveContact*>(take((sizeof(WaveContact) * kWaveMaxCon + 7) / 8));
+  d.counters = reinterpret_cast<int*>(take(4));
+  double* lnodes = take((size_t)P * nu);  // [P][nu]
+  double* ltimes = take(P);
+
+  // ---- candidate spline nodes (SamplingPlanner / CrossEntropyPlanner::AddNoiseToPolicy, as rollout_lane_kernel)
+  for (int q = lane; q < P; q += 64) ltimes[q] = a.node_times[q];
+  const int np = P * nu;
+  if (a.noise.mode < 0) {
+    for (int j = lane; j < np; j += 64) lnodes[j] = a.nodes[(size_t)j * N + cand];
+  } else {
+    const int gi = a.noise.candidate_offset + cand;
+    double std = a.noise.std0;
+    if (a.noise.mode == 0 && a.noise.std1 > 0) {
+      if (bernoulli_uniform(a.noise.seed, (uint32_t)gi, a.noise.iteration) < 0.2) std = a.noise.std1;
+    }
+    const bool noised = gi != a.noise.nominal_candidate;
+    for (int j0 = 2 * lane; j0 < np; j0 += 128) {
+      double z[2];
+      gaussian_pair(a.noise.seed, (uint32_t)gi, (uint32_t)(j0 >> 1), a.noise.iteration, z);
+      for (int e = 0; e < 2; e++) {
+        const int j = j0 + e;
+        if (j < np) {
+          const int k = j % nu;
+          const double lo = m.actuator_ctrlrange[2 * k], hi = m.actuator_ctrlrange[2 * k + 1];
+          double v = a.nominal[j];
+          if (noised) {
+            double sigma;
+            if (a.noise.mode == 0) sigma = 0.5 * (hi - lo) * std;
+            else {
+              const double fl = gi < a.noise.explore_count ? a.noise.std0 : a.noise.std1;
+              const double s = sqrt(a.noise.param_variance[j]);
+              sigma = s > fl ? s : fl;
+            }
+            v = clampv(v + sigma * z[e], lo, hi);
+          }
+          lnodes[j] = v;
+          a.nodes[(size_t)j * N + cand] = v;
+        }
+      }
+    }
+  }
+  // ---- initial condition (Planner::SetState)
+  for (int i = lane; i < nq; i += 64) d.qpos[i] = tk.blob[i];
+  for (int i = lane; i < nv; i += 64) d.qvel[i] = tk.blob[nq + i];
+  if (lane < nu) d.ctrl[lane] = 0;
+  if (lane < 4) d.counters[lane] = 0;
+  double time = tk.blob[tk.off_time];
+  WSYNC();
+
+  const int ds = nq + nv;
+  double total = 0;
+  bool failed = false;
+  for (int t = 0; t < H; t++) {
+    const bool last = t == H - 1;
+    bool bad = false;
+    // ================= policy: TimeSpline::Sample + Clamp, one lane per actuator
+    if (!last) {
+      double u = 0;
+      if (lane < nu) {
+        const int k = lane;
+        int up = 0;
+        while (up < P && ltimes[up] <= time) up++;
+        if (up == P || up == 0) {
+          u = lnodes[(up == 0 ? 0 : P - 1) * nu + k];
+        } else {
+          const int lo = up - 1;
+          const double tl = ltimes[lo], tu = ltimes[up];
+          const double p0 = lnodes[lo * nu + k], p1 = lnodes[up * nu + k];
+          if (a.interp == 0) u = p0;
+          else {
+            const double s = (time - tl) / (tu - tl);
+            if (a.interp == 1) u = p0 * (1 - s) + p1 * s;
+            else {
+              const double dt_mid = tu - tl, fwd = (p1 - p0) / dt_mid;
+              double m0, m1;
+              if (lo == 0) m0 = fwd;
+              else m0 = 0.5 * (p1 - p0) / dt_mid + 0.5 * (p0 - lnodes[(lo - 1) * nu + k]) / (tl - ltimes[lo - 1]);
+              if (up == P - 1) m1 = fwd;
+              else m1 = 0.5 * (lnodes[(up + 1) * nu + k] - p1) / (ltimes[up + 1] - tu) + 0.5 * (p1 - p0) / dt_mid;
+              const double s2 = s * s, s3 = s * s * s;
+              const double c0 = 2 * s3 - 3 * s2 + 1, c1 = (s3 - 2 * s2 + s) * (tu - tl), c2 = -2 * s3 + 3 * s2, c3 = (s3 - s2) * (tu - tl);
+              u = c0 * p0 + c1 * m0 + c2 * p1 + c3 * m1;
+            }
+          }
+        }
+        bad = is_bad(u);
+        u = clampv(u, m.actuator_ctrlrange[2 * k], m.actuator_ctrlrange[2 * k + 1]);
+        d.ctrl[k] = u;
+      }
+      // mj_checkPos / mj_checkVel
+      for (int i = lane; i < nq; i += 64) bad |= is_bad(d.qpos[i]);
+      for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qvel[i]);
+    }
+    WSYNC();
+    // ================= mj_forward
+    bool bad_ctrl = false;
+    wf_forward(m, tk, d, lane, bad_ctrl);
+    if (!last) for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qacc[i]);  // mj_checkAcc
+    bad = __any(bad);
+    // ================= sensor stage: task residual and cost (task.cc:71-110)
+    wr_residual(m, tk, d, time, lane);
+    if (lane < tk.nterm) {
+      int off = 0;
+      for (int k = 0; k < lane; k++) off += tk.dim_norm_residual[k];
+      d.terms[lane] = tk.blob[tk.off_weight + lane] *
+                      w_norm_value(d.residual + off, tk.dim_norm_residual[lane], tk.norm[lane], tk.blob[tk.off_normp + lane], tk.blob[tk.off_normq + lane]);
+    }
+    WSYNC();
+    double cost = 0;
+    for (int k = 0; k < tk.nterm; k++) cost += d.terms[k];
+    const double risk = tk.blob[tk.off_risk];
+    if (!(fabs(risk) < 1.0e-6)) cost = (exp(risk * cost) - 1.0) / risk;
+    // ================= record step t
+    if (!failed) {
+      for (int i = lane; i < ds; i += 64) a.states[((size_t)t * ds + i) * N + cand] = i < nq ? d.qpos[i] : d.qvel[i - nq];
+      if (lane < nu) a.actions[((size_t)t * nu + lane) * N + cand] = d.ctrl[lane];
+      for (int i = lane; i < nr; i += 64) a.residual[((size_t)t * nr + i) * N + cand] = d.residual[i];
+      if (lane < 3 * tk.ntrace) a.trace[((size_t)t * 3 * tk.ntrace + lane) * N + cand] = d.site_xpos[3 * tk.trace_site[lane / 3] + lane % 3];
+      if (lane == 0) {
+        a.times[(size_t)t * N + cand] = time;
+        if (!bad) a.costs[(size_t)t * N + cand] = cost;
+      }
+    }
+    if (bad) failed = true;
+    total += cost;
+    if (last) break;
+    // ================= mj_Euler + advance
+    wf_euler(m, d, lane, time);
+  }
+  if (lane == 0) {
+    a.total_return[cand] = failed ? kMaxReturn : total / (double)(H > 1 ? H : 1);
+    a.failure[cand] = failed ? 1 : 0;
+  }
+}
+
+}  // namespace mjpcx

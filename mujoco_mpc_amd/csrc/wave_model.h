@@ -1,0 +1,212 @@
+// wave_model.h -- device-side model/task views of the wavefront-per-candidate kernel family (free joints,
+// contacts, friction loss: the Quadruped class of models) and the host code that bakes them.
+//
+// Unlike the lane-per-candidate family (LaneModel by value in the kernarg segment), these models are too large
+// for kernel arguments: every array lives in ONE device allocation and the kernel receives a struct of pointers
+// into it. All reads of it are wave-uniform or lane-indexed gathers of a few hundred bytes that stay in the
+// scalar / vector L1 after the first step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mjpcx.h"
+
+namespace mjpcx {
+
+constexpr int kWaveMaxBody = 32, kWaveMaxDof = 32, kWaveMaxGeom = 64, kWaveMaxLevel = 16;
+constexpr int kWaveMaxCon = 16;   // contacts kept per step (further ones are dropped, as in the oracle)
+constexpr int kWaveMaxEfc = 64;   // constraint rows kept per step
+
+struct WaveModel {
+  int nq, nv, nu, nbody, njnt, nsite, nmocap, ngeom, nkey;
+  int cone, disableflags, solver_iterations, any_damping;
+  double timestep, gravity[3], solver_tolerance, meaninertia, impratio;
+  const int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_mocapid;
+  const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_subtreemass;
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  const double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
+  const int *dof_bodyid, *dof_jntid, *dof_parentid;
+  const double *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
+  const double *qpos0, *qpos_spring;
+  const int* site_bodyid;
+  const double *site_pos, *site_quat;
+  const int *actuator_trnid, *actuator_biastype, *actuator_ctrllimited, *actuator_forcelimited;
+  const double *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
+  const int *geom_type, *geom_bodyid, *geom_contype, *geom_conaffinity, *geom_condim, *geom_priority, *geom_group;
+  const double *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_solmix;
+  const double* key_qpos;
+  // ---- baked helpers (host-computed once)
+  const unsigned long long* body_subtree_mask;  // bit j: body j is in the subtree rooted at body i (incl. i)
+  const unsigned* body_dofmask;                 // bit k: dof k is on the chain from body i to the root
+  const int* level_body;                        // bodies 1..nbody-1 sorted by depth
+  int nlevel;
+  int level_start[kWaveMaxLevel + 1];           // level l = level_body[level_start[l] .. level_start[l+1])
+  const int* static_geom;                       // collidable geoms on bodies without dofs (world, mocap), model order
+  const int* dynamic_geom;                      // collidable geoms on moving bodies, model order
+  int nstatic_geom, ndynamic_geom;
+  int full;                                     // 1: rows beyond joint limits can occur (Newton path of the oracle)
+};
+
+// Per-plan task values: one small blob re-staged with every rollout (Planner::SetState + the frozen ResidualFn copy)
+struct WaveTask {
+  int residual_id, nr, nterm, ntrace, nparam, nri, nrr;
+  const int *dim_norm_residual, *norm, *trace_site;   // static, in the model allocation
+  // blob (doubles): state[nq+nv] time mocap[7 nmocap] weight[nterm] norm_p[nterm] norm_q[nterm] parameters[nparam]
+  //                 risk residual_real[nrr] ; then residual_int[nri] as int32
+  const double* blob;
+  int off_time, off_mocap, off_weight, off_normp, off_normq, off_param, off_risk, off_rreal, off_rint;
+};
+
+// ---------------------------------------------------------------- host side
+struct WaveHost {
+  WaveModel m{};
+  WaveTask t{};
+  void* dev = nullptr;  // the model allocation
+  size_t blob_doubles = 0, blob_bytes = 0;
+  std::vector<double> state, mocap, weight, norm_p, norm_q, parameters, residual_real;
+  std::vector<int32_t> residual_int;
+  double time = 0, risk = 0;
+
+  void release() { if (dev) (void)hipFree(dev); dev = nullptr; }
+
+  // Returns "" or an error message. Requires the device to be current.
+  std::string build(const mjpcx_model* src, const mjpcx_task* task) {
+    if (src->nbody > kWaveMaxBody || src->nv > kWaveMaxDof || src->ngeom > 4 * kWaveMaxGeom) return "model exceeds the wave kernel capacity";
+    if (src->nbody > 64) return "more than 64 bodies";
+    std::vector<unsigned char> host;
+    auto put = [&](const void* p, size_t bytes) -> size_t {
+      size_t off = (host.size() + 15) & ~(size_t)15;
+      host.resize(off + (bytes ? bytes : 16));
+      if (bytes) std::memcpy(host.data() + off, p, bytes);
+      return off;
+    };
+    struct Fix { size_t field_off; size_t data_off; };
+    std::vector<Fix> fixes;
+    auto reg = [&](const void* field_addr, const void* p, size_t bytes) {
+      fixes.push_back({(size_t)((const char*)field_addr - (const char*)&m), put(p, bytes)});
+    };
+    std::memset(&m, 0, sizeof m);
+    m.nq = src->nq; m.nv = src->nv; m.nu = src->nu; m.nbody = src->nbody; m.njnt = src->njnt; m.nsite = src->nsite;
+    m.nmocap = src->nmocap; m.ngeom = src->ngeom; m.nkey = src->nkey; m.cone = src->cone; m.disableflags = src->disableflags;
+    m.solver_iterations = src->solver_iterations; m.timestep = src->timestep;
+    for (int k = 0; k < 3; k++) m.gravity[k] = src->gravity[k];
+    m.solver_tolerance = src->solver_tolerance; m.meaninertia = src->meaninertia; m.impratio = src->impratio;
+    const int nb = src->nbody, nj = src->njnt, nv = src->nv, nu = src->nu, ns = src->nsite, ng = src->ngeom;
+#define I(name, n) reg(&m.name, src->name, sizeof(int32_t) * (size_t)(n))
+#define D(name, n) reg(&m.name, src->name, sizeof(double) * (size_t)(n))
+    I(body_parentid, nb); I(body_rootid, nb); I(body_jntnum, nb); I(body_jntadr, nb); I(body_dofnum, nb); I(body_dofadr, nb); I(body_mocapid, nb);
+    D(body_pos, 3 * nb); D(body_quat, 4 * nb); D(body_ipos, 3 * nb); D(body_iquat, 4 * nb); D(body_mass, nb); D(body_inertia, 3 * nb);
+    D(body_invweight0, 2 * nb); D(body_subtreemass, nb);
+    I(jnt_type, nj); I(jnt_qposadr, nj); I(jnt_dofadr, nj); I(jnt_bodyid, nj); I(jnt_limited, nj);
+    D(jnt_pos, 3 * nj); D(jnt_axis, 3 * nj); D(jnt_stiffness, nj); D(jnt_range, 2 * nj); D(jnt_margin, nj); D(jnt_solref, 2 * nj); D(jnt_solimp, 5 * nj);
+    I(dof_bodyid, nv); I(dof_jntid, nv); I(dof_parentid, nv);
+    D(dof_armature, nv); D(dof_damping, nv); D(dof_frictionloss, nv); D(dof_invweight0, nv); D(dof_solref, 2 * nv); D(dof_solimp, 5 * nv);
+    D(qpos0, src->nq); D(qpos_spring, src->nq);
+    I(site_bodyid, ns); D(site_pos, 3 * ns); D(site_quat, 4 * ns);
+    I(actuator_trnid, nu); I(actuator_biastype, nu); I(actuator_ctrllimited, nu); I(actuator_forcelimited, nu);
+    D(actuator_gear, nu); D(actuator_gainprm, 3 * nu); D(actuator_biasprm, 3 * nu); D(actuator_ctrlrange, 2 * nu); D(actuator_forcerange, 2 * nu);
+    I(geom_type, ng); I(geom_bodyid, ng); I(geom_contype, ng); I(geom_conaffinity, ng); I(geom_condim, ng); I(geom_priority, ng); I(geom_group, ng);
+    D(geom_size, 3 * ng); D(geom_pos, 3 * ng); D(geom_quat, 4 * ng); D(geom_friction, 3 * ng); D(geom_solref, 2 * ng); D(geom_solimp, 5 * ng);
+    D(geom_margin, ng); D(geom_gap, ng); D(geom_solmix, ng);
+    D(key_qpos, (size_t)src->nkey * src->nq);
+#undef I
+#undef D
+    for (int i = 0; i < nv; i++) m.any_damping |= src->dof_damping[i] > 0;
+    // baked helpers
+    std::vector<unsigned long long> sub(nb, 0);
+    std::vector<unsigned> dofmask(nb, 0);
+    std::vector<int> depth(nb, 0);
+    for (int i = 0; i < nb; i++) {
+      for (int b = i; ; b = src->body_parentid[b]) { sub[b] |= 1ull << i; if (b == 0) break; }
+      if (i > 0) depth[i] = depth[src->body_parentid[i]] + 1;
+      unsigned mk = i > 0 ? dofmask[src->body_parentid[i]] : 0u;
+      for (int k = 0; k < src->body_dofnum[i]; k++) mk |= 1u << (src->body_dofadr[i] + k);
+      dofmask[i] = mk;
+    }
+    int maxdepth = 0;
+    for (int i = 1; i < nb; i++) maxdepth = depth[i] > maxdepth ? depth[i] : maxdepth;
+    if (maxdepth > kWaveMaxLevel) return "kinematic tree deeper than the wave kernel supports";
+    std::vector<int> level_body;
+    m.nlevel = maxdepth;
+    for (int l = 1; l <= maxdepth; l++) {
+      m.level_start[l - 1] = (int)level_body.size();
+      for (int i = 1; i < nb; i++) if (depth[i] == l) level_body.push_back(i);
+    }
+    m.level_start[maxdepth] = (int)level_body.size();
+    std::vector<int> sg, dg;
+    bool any_floss = false;
+    for (int i = 0; i < nv; i++) any_floss |= src->dof_frictionloss[i] > 0 && !(src->disableflags & MJPCX_DSBL_FRICTIONLOSS);
+    for (int g = 0; g < ng; g++) {
+      if (!(src->geom_contype[g] || src->geom_conaffinity[g])) continue;
+      (dofmask[src->geom_bodyid[g]] == 0 ? sg : dg).push_back(g);
+    }
+    if ((int)dg.size() > 64) return "more than 64 collidable geoms on moving bodies";
+    m.nstatic_geom = (int)sg.size(); m.ndynamic_geom = (int)dg.size();
+    m.full = any_floss || (!sg.empty() && !dg.empty() && !(src->disableflags & MJPCX_DSBL_CONTACT));
+    for (int j = 0; j < nj; j++) m.full |= src->jnt_type[j] == MJPCX_JNT_FREE || src->jnt_type[j] == MJPCX_JNT_BALL;
+    reg(&m.body_subtree_mask, sub.data(), sizeof(unsigned long long) * nb);
+    reg(&m.body_dofmask, dofmask.data(), sizeof(unsigned) * nb);
+    reg(&m.level_body, level_body.data(), sizeof(int) * level_body.size());
+    reg(&m.static_geom, sg.data(), sizeof(int) * sg.size());
+    reg(&m.dynamic_geom, dg.data(), sizeof(int) * dg.size());
+    // static task arrays
+    t.residual_id = task->residual_id; t.nr = task->num_residual; t.nterm = task->num_term; t.ntrace = task->num_trace;
+    t.nparam = task->num_parameter; t.nri = task->num_residual_int; t.nrr = task->num_residual_real;
+    const size_t o_dim = put(task->dim_norm_residual, sizeof(int32_t) * task->num_term);
+    const size_t o_norm = put(task->norm, sizeof(int32_t) * task->num_term);
+    const size_t o_trace = put(task->trace_site, sizeof(int32_t) * task->num_trace);
+    if (hipMalloc(&dev, host.size()) != hipSuccess) return "hipMalloc of the model failed";
+    if (hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return "model upload failed";
+    for (const Fix& f : fixes) *(const void**)((char*)&m + f.field_off) = (const char*)dev + f.data_off;
+    t.dim_norm_residual = (const int*)((const char*)dev + o_dim);
+    t.norm = (const int*)((const char*)dev + o_norm);
+    t.trace_site = (const int*)((const char*)dev + o_trace);
+    // blob layout
+    int o = 0;
+    auto seg = [&](int n) { int at = o; o += n; return at; };
+    seg(src->nq + src->nv);
+    t.off_time = seg(1); t.off_mocap = seg(7 * src->nmocap); t.off_weight = seg(task->num_term); t.off_normp = seg(task->num_term);
+    t.off_normq = seg(task->num_term); t.off_param = seg(task->num_parameter); t.off_risk = seg(1); t.off_rreal = seg(task->num_residual_real);
+    t.off_rint = o;
+    blob_doubles = (size_t)o;
+    blob_bytes = blob_doubles * 8 + sizeof(int32_t) * (size_t)task->num_residual_int;
+    blob_bytes = (blob_bytes + 15) & ~(size_t)15;
+    // host mirrors of the per-plan values
+    state.assign(src->nq + src->nv, 0.0);
+    for (int i = 0; i < src->nq; i++) state[i] = src->qpos0[i];
+    mocap.assign(7 * (size_t)src->nmocap, 0.0);
+    for (int b = 0; b < nb; b++)
+      if (src->body_mocapid[b] >= 0) {
+        for (int k = 0; k < 3; k++) mocap[7 * src->body_mocapid[b] + k] = src->body_pos[3 * b + k];
+        for (int k = 0; k < 4; k++) mocap[7 * src->body_mocapid[b] + 3 + k] = src->body_quat[4 * b + k];
+      }
+    weight.assign(task->weight, task->weight + task->num_term);
+    norm_p.assign(task->num_term, 0.0); norm_q.assign(task->num_term, 0.0);
+    parameters.assign(task->parameters, task->parameters + task->num_parameter);
+    residual_real.assign(task->residual_real, task->residual_real + task->num_residual_real);
+    residual_int.assign(task->residual_int, task->residual_int + task->num_residual_int);
+    risk = task->risk;
+    return "";
+  }
+
+  // serialise the per-plan values into `dst` (blob_bytes)
+  void fill_blob(void* dst) const {
+    double* d = (double*)dst;
+    std::memcpy(d, state.data(), state.size() * 8);
+    d[t.off_time] = time;
+    std::memcpy(d + t.off_mocap, mocap.data(), mocap.size() * 8);
+    std::memcpy(d + t.off_weight, weight.data(), weight.size() * 8);
+    std::memcpy(d + t.off_normp, norm_p.data(), norm_p.size() * 8);
+    std::memcpy(d + t.off_normq, norm_q.data(), norm_q.size() * 8);
+    std::memcpy(d + t.off_param, parameters.data(), parameters.size() * 8);
+    d[t.off_risk] = risk;
+    std::memcpy(d + t.off_rreal, residual_real.data(), residual_real.size() * 8);
+    std::memcpy(d + t.off_rint, residual_int.data(), residual_int.size() * sizeof(int32_t));
+  }
+};
+
+}  // namespace mjpcx

@@ -20,14 +20,17 @@
  * rejected by odata_new).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
 
 #define OMINVAL 1e-15 /* mjMINVAL */
+#define OMINIMP 0.0001 /* mjMINIMP: solimp d0, d_width, midpoint are clipped to [mjMINIMP, mjMAXIMP] */
+#define OMAXIMP 0.9999 /* mjMAXIMP */
 #define OMAXVAL 1e10  /* mjMAXVAL */
-#define OMAXEFC 160
-#define OMAXCON 32
+#define OMAXEFC 64 /* = kWaveMaxEfc of the device kernel: rows beyond the cap are dropped identically */
+#define OMAXCON 16 /* = kWaveMaxCon */
 #define OMINMU 1e-5 /* mjMINMU */
 
 typedef struct OContact {
@@ -213,6 +216,7 @@ OData* odata_new(const mjpcx_model* m) {
     if (m->geom_contype[g] || m->geom_conaffinity[g]) { if (d->geom_static[g]) nstatic++; else ndynamic++; }
   }
   if (nstatic && ndynamic && !(m->disableflags & MJPCX_DSBL_CONTACT)) d->full = 1;
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == MJPCX_JNT_FREE || m->jnt_type[j] == MJPCX_JNT_BALL) d->full = 1;
   /* subtree masses are model constants */
   for (int i = 0; i < nb; i++) d->subtree_mass[i] = m->body_mass[i];
   for (int i = nb - 1; i > 0; i--) d->subtree_mass[m->body_parentid[i]] += d->subtree_mass[i];
@@ -445,10 +449,10 @@ static void chol_solve(double* x, const double* L, const double* b, int n) {
 /* solimp -> impedance at violation `dist` (pos - margin) */
 static double impedance(const double* solimp, double dist) {
   double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
-  if (dmin < OMINVAL) dmin = OMINVAL; if (dmin > 1 - OMINVAL) dmin = 1 - OMINVAL;
-  if (dmax < OMINVAL) dmax = OMINVAL; if (dmax > 1 - OMINVAL) dmax = 1 - OMINVAL;
+  if (dmin < OMINIMP) dmin = OMINIMP; if (dmin > OMAXIMP) dmin = OMAXIMP;
+  if (dmax < OMINIMP) dmax = OMINIMP; if (dmax > OMAXIMP) dmax = OMAXIMP;
   if (power < 1) power = 1;
-  if (mid < OMINVAL) mid = OMINVAL; if (mid > 1 - OMINVAL) mid = 1 - OMINVAL;
+  if (mid < OMINIMP) mid = OMINIMP; if (mid > OMAXIMP) mid = OMAXIMP;
   if (dmin == dmax || width <= OMINVAL) return 0.5 * (dmin + dmax);
   double x = fabs(dist) / width;
   if (x >= 1) return dmax;
@@ -606,7 +610,7 @@ static void o_constraint(OData* d) {
     double pos = d->efc_pos[r] - d->efc_margin[r];
     double imp = impedance(solimp, pos);
     double dmax = solimp[1];
-    if (dmax < OMINVAL) dmax = OMINVAL; if (dmax > 1 - OMINVAL) dmax = 1 - OMINVAL;
+    if (dmax < OMINIMP) dmax = OMINIMP; if (dmax > OMAXIMP) dmax = OMAXIMP;
     double k, b;
     if (solref[0] > 0) { /* (timeconst, dampratio) */
       double tc = solref[0];

@@ -1,0 +1,84 @@
+"""-m gpu: the wavefront-per-candidate kernel (free joint, friction loss, elliptic-cone contacts, Newton solver, the
+QuadrupedFlat residual) against the CPU oracle on the Unitree A1 of BASELINE configs[2].
+
+Tolerance: contact-rich dynamics amplify rounding differences between the two implementations (different summation
+orders in the subtree sums, FMA contraction, device libm), so the bound loosens with the horizon:
+|gpu - oracle| <= tol (1 + |oracle|) with tol = 1e-9 for the first steps and 1e-6 over 40 steps (observed ~1e-10)."""
+import numpy as np
+import pytest
+
+from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.task import load_task
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+MOCAP = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
+
+
+@pytest.fixture(scope="module")
+def quad():
+    t = load_task("QuadrupedFlat")
+    t.transition(0.0)
+    return t
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.all(np.abs(a - b) <= tol * (1 + np.abs(b)))
+
+
+def run(task, state, N, H, P, interp, seed, tol, time=0.0):
+    pm, pt = task.packed_model(), task.packed()
+    rng = np.random.default_rng(seed)
+    dt = task.model.get_number("agent_timestep", task.model.timestep)
+    times = time + np.arange(P) * max((H - 1) * dt / max(P - 1, 1), 1e-3)
+    nodes = np.clip(rng.normal(0, 0.4, (N, P, task.model.nu)), -1, 1)
+    ctx = capi.Context(pm, pt, 0, 64)
+    assert "rollout_wave_kernel" in ctx.kernel_name
+    ctx.set_state(state, time, MOCAP)
+    ctx.rollout_splines(H, interp, times, nodes)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_batch(pm, pt, state, time, MOCAP, N, H, P, interp, times, nodes, num_threads=8)
+    assert np.array_equal(fail, ref["failure"]) and not fail.any()
+    worst = 0.0
+    for c in range(N):
+        tr = ctx.fetch_trajectory(c)
+        for name in ("states", "actions", "times", "residual", "costs", "trace"):
+            g, o = getattr(tr, name), ref[name][c]
+            worst = max(worst, float(np.max(np.abs(g - o) / (1 + np.abs(o)))))
+            assert close(g, o, tol), (name, c, float(np.max(np.abs(g - o))))
+    assert close(ret, ref["total_return"], tol)
+    ctx.close()
+    return worst
+
+
+def test_standing_start_short(quad):
+    home = quad.model.keyframes["home"]["qpos"]
+    state = np.concatenate([home, np.zeros(18)])
+    run(quad, state, N=6, H=6, P=3, interp=0, seed=1, tol=1e-9)
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_forty_steps(quad, interp):
+    home = quad.model.keyframes["home"]["qpos"]
+    state = np.concatenate([home, np.zeros(18)])
+    run(quad, state, N=8, H=40, P=4, interp=interp, seed=2 + interp, tol=1e-6)
+
+
+def test_falling_and_tumbling(quad):
+    """dropped from 0.5 m with spin: body geoms hit the floor, many contacts, row cap exercised"""
+    q = quad.model.keyframes["home"]["qpos"].copy()
+    q[2] = 0.5
+    q[3:7] = [0.9, 0.3, 0.2, 0.1]
+    q[3:7] /= np.linalg.norm(q[3:7])
+    v = np.zeros(18)
+    v[3:6] = [2.0, -1.0, 0.5]
+    run(quad, np.concatenate([q, v]), N=4, H=60, P=3, interp=0, seed=5, tol=1e-5)
+
+
+def test_trot_gait_residual(quad):
+    t = load_task("QuadrupedFlat")
+    t.parameters[t.ids["gait"]] = 2.0   # Trot
+    t.transition(0.0)
+    home = t.model.keyframes["home"]["qpos"]
+    run(t, np.concatenate([home, np.zeros(18)]), N=4, H=20, P=3, interp=0, seed=7, tol=1e-7, time=0.0)
