@@ -546,13 +546,35 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     if (c->wave) {
       WaveTask wt = c->wh.t;
       wt.blob = (const double*)d_blob;
+      wt.stamps = nullptr;
+      if (getenv("MJPCX_STAMPS")) {
+        HIPCHK(c, c->d_stage.reserve(32 * 8));
+        HIPCHK(c, hipMemsetAsync(c->d_stage.p, 0, 32 * 8, c->stream));
+        wt.stamps = (long long*)c->d_stage.p;
+      }
       const WaveModel& wm = c->wh.m;
-      const size_t lds = 8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P);
+      const size_t lds_state = (8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
+      const size_t blob_d = (c->wh.blob_bytes + 7) / 8;
+      const size_t lds = lds_state + (size_t)wm.bytes + blob_d * 8;
+      a.lds_state_bytes = (int)lds_state;
+      a.blob_doubles = (int)blob_d;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
-      le = hipFuncSetAttribute((const void*)rollout_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      auto kern = wm.nv <= 20 ? rollout_wave_kernel<20> : rollout_wave_kernel<32>;
+      le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (le == hipSuccess) {
-        hipLaunchKernelGGL(rollout_wave_kernel, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
+        hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
         le = hipGetLastError();
+      }
+      if (wt.stamps && le == hipSuccess) {
+        long long h[32];
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(h, wt.stamps, sizeof h, hipMemcpyDeviceToHost);
+        static const char* nm[] = {"policy", "kinematics", "compos", "crb", "cholM", "collision", "comvel", "make_constraint", "smooth", "solve",
+                                   "newton", "residual", "cost+record", "euler"};
+        std::fprintf(stderr, "wave kernel phase cycles (step 1, candidate 0; LDS %zu B):", lds);
+        for (int k = 0; k < 14; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k + 1] - h[k]);
+        std::fprintf(stderr, " | newton iters %lld: grad %lld hess %lld chol+solve %lld linesearch %lld\n", h[20], h[21] - h[10], h[22] - h[21],
+                     h[23] - h[22], h[24] - h[23]);
       }
     } else {
       le = c->kernel->launch64(c->hm64, c->ht64, a, c->stream);

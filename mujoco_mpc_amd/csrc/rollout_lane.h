@@ -119,6 +119,7 @@ struct RolloutArgs {
   T *states, *actions, *times, *residual, *costs, *trace;
   double* total_return;
   int* failure;
+  int lds_state_bytes, blob_doubles;  // wave kernel: LDS offset of the staged model, size of the plan blob
 };
 
 // weighted sum of norms over the (compile-time) term partition of the residual

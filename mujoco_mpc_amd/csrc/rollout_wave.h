@@ -36,7 +36,7 @@ struct WaveData {
   double *qpos, *qvel, *ctrl;
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *site_xpos;
   double *subtree_com, *cinert, *crb, *cdof, *cdof_dot, *cvel, *cacc, *cfrc, *cfrc_sub, *subtree_linvel;
-  double *M, *L, *H;
+  double *M, *L, *H, *Ldinv, *dinv;
   double *qfrc_passive, *qfrc_bias, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qacc, *qfrc_constraint;
   double *actuator_force, *grad, *search, *Ma, *Ms, *tmpv;
   double *efc_J, *efc_pos, *efc_margin, *efc_D, *efc_R, *efc_aref, *efc_floss, *efc_force, *jar, *jv;
@@ -148,42 +148,76 @@ __device__ __forceinline__ double w_dot6(const double* a, const double* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
 
-// ------------------------------------------------------------------ dense SPD algebra, lane i owns row i (n <= 32)
-// in-place: on exit the lower triangle of A (ld n) holds L with A = L L'. Returns false if not positive definite.
-__device__ __forceinline__ bool wave_chol(double* A, int n, int lane) {
+// ------------------------------------------------------------------ dense SPD algebra, lane i owns row i (n <= NMAX <= 32)
+// Register-resident: lane i keeps ROW i of the matrix in NMAX registers; values of other rows arrive through
+// v_readlane (uniform source lane), so a factorisation or a triangular solve makes no LDS round trips on its
+// dependent chain. Pivots are applied as reciprocals (one v_rsq-based 1/sqrt per column instead of a sqrt and a
+// division per row), which differs from the oracle's divisions by <= 2 ulp.
+__device__ __forceinline__ double wbcast(double v, int src) {  // src must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// in-place: on exit the lower triangle of A (LDS, ld n) holds L with A = L L', dinv[j] = 1 / L[j][j].
+template <int NMAX>
+__device__ __forceinline__ bool wave_chol(double* A, double* dinv, int n, int lane) {
+  double row[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) row[k] = (lane < n && k <= lane) ? A[lane * n + k] : 0.0;
   bool ok = true;
-  for (int j = 0; j < n; j++) {
-    if (lane == j) {
-      double s = A[j * n + j];
-      for (int k = 0; k < j; k++) s -= A[j * n + k] * A[j * n + k];
-      A[j * n + j] = s > kMinVal ? sqrt(s) : -1.0;
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    if (j < n && ok) {
+      const double djj = wbcast(row[j], j);
+      if (!(djj > kMinVal)) {
+        ok = false;
+      } else {
+        const double inv = rsqrt(djj);
+        const double lij = lane == j ? djj * inv : row[j] * inv;
+        row[j] = lij;
+        if (lane == j) dinv[j] = inv;
+#pragma unroll
+        for (int k = j + 1; k < NMAX; k++) {
+          if (k < n) {
+            const double lkj = wbcast(lij, k);
+            if (lane >= k) row[k] -= lij * lkj;
+          }
+        }
+      }
     }
-    WSYNC();
-    const double d = A[j * n + j];
-    if (d < 0) { ok = false; break; }
-    if (lane > j && lane < n) {
-      double v = A[lane * n + j];
-      for (int k = 0; k < j; k++) v -= A[lane * n + k] * A[j * n + k];
-      A[lane * n + j] = v / d;
-    }
-    WSYNC();
   }
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) if (lane < n && k <= lane) A[lane * n + k] = row[k];
+  WSYNC();
   return ok;
 }
 // x := (L L')^-1 x, x in LDS
-__device__ __forceinline__ void wave_chol_solve(double* x, const double* L, int n, int lane) {
-  for (int j = 0; j < n; j++) {
-    if (lane == j) x[j] /= L[j * n + j];
-    WSYNC();
-    if (lane > j && lane < n) x[lane] -= L[lane * n + j] * x[j];
-    WSYNC();
+template <int NMAX>
+__device__ __forceinline__ void wave_chol_solve(double* x, const double* L, const double* dinv, int n, int lane) {
+  double row[NMAX], col[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) {
+    row[k] = (lane < n && k < lane) ? L[lane * n + k] : 0.0;
+    col[k] = (lane < n && k > lane && k < n) ? L[k * n + lane] : 0.0;
   }
-  for (int j = n - 1; j >= 0; j--) {
-    if (lane == j) x[j] /= L[j * n + j];
-    WSYNC();
-    if (lane < j) x[lane] -= L[j * n + lane] * x[j];
-    WSYNC();
+  double b = lane < n ? x[lane] : 0.0;
+  const double mydinv = lane < n ? dinv[lane] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    if (j < n) {
+      const double yj = wbcast(b, j) * wbcast(mydinv, j);
+      b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
+    }
   }
+#pragma unroll
+  for (int j = NMAX - 1; j >= 0; j--) {
+    if (j < n) {
+      const double xj = wbcast(b, j) * wbcast(mydinv, j);
+      b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
+    }
+  }
+  if (lane < n) x[lane] = b;
+  WSYNC();
 }
 
 // solimp -> impedance at violation `dist` (oracle impedance())

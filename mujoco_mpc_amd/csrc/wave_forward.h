@@ -683,7 +683,8 @@ __device__ __forceinline__ double wf_constraint_cost(WaveData& d, int nefc, int 
 }
 
 // ---- o_constraint_newton
-__device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveData& d, int lane) {
+template <int NMAX>
+__device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveData& d, int lane, long long* stamp = nullptr) {
   const int nv = m.nv, ne = d.counters[1];
   if (lane < nv) { d.qfrc_constraint[lane] = 0; d.qacc[lane] = d.qacc_smooth[lane]; }
   WSYNC();
@@ -711,6 +712,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     }
     const double gnorm = sqrt(wave_sum(lane < nv ? g * g : 0.0));
     if (gnorm == 0) break;
+    if (stamp && lane == 0 && iter == 0) stamp[21] = (long long)__builtin_readcyclecounter();
     // cone Hessian blocks (one lane per contact), then H = M + J' (d2s) J over the lower triangle
     if (lane < d.counters[0]) {
       const WaveContact& c = d.con[lane];
@@ -770,8 +772,10 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       d.H[b * nv + a] = h;
     }
     WSYNC();
-    if (!wave_chol(d.H, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
-    wave_chol_solve(d.search, d.H, nv, lane);
+    if (stamp && lane == 0 && iter == 0) stamp[22] = (long long)__builtin_readcyclecounter();
+    if (!wave_chol<NMAX>(d.H, d.dinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
+    wave_chol_solve<NMAX>(d.search, d.H, d.dinv, nv, lane);
+    if (stamp && lane == 0 && iter == 0) stamp[23] = (long long)__builtin_readcyclecounter();
     // jv = J search; Gauss part along the ray
     if (lane < ne) {
       double s = 0;
@@ -804,6 +808,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       if (fabs(d1) <= 1e-14 * d10) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
     }
+    if (stamp && lane == 0 && iter == 0) stamp[24] = (long long)__builtin_readcyclecounter();
     if (lane < nv) d.qacc[lane] += alpha * d.search[lane];
     if (lane < ne) d.jar[lane] += alpha * d.jv[lane];
     WSYNC();
@@ -817,6 +822,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     const double newcost = gauss + wf_constraint_cost(d, ne, lane);
     const double improvement = cost - newcost;
     cost = newcost;
+    if (stamp && lane == 0) stamp[20] = iter + 1;
     if (polish) break;
     if (scale * improvement < m.solver_tolerance || scale * gnorm < m.solver_tolerance) polish = true;
   }
@@ -829,25 +835,39 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
 }
 
 // ---- mj_forward up to the constraint solve
-__device__ __forceinline__ void wf_forward(const WaveModel& m, const WaveTask& tk, WaveData& d, int lane, bool& bad_ctrl) {
+#define WSTAMP(k) do { if (stamp && lane == 0) stamp[k] = (long long)__builtin_readcyclecounter(); } while (0)
+template <int NMAX>
+__device__ __forceinline__ void wf_forward(const WaveModel& m, const WaveTask& tk, WaveData& d, int lane, bool& bad_ctrl,
+                                           long long* stamp) {
   const int nv = m.nv;
+  WSTAMP(1);
   wf_kinematics(m, tk, d, lane);
   WSYNC();
+  WSTAMP(2);
   wf_compos(m, d, lane);
+  WSTAMP(3);
   wf_crb(m, d, lane);
+  WSTAMP(4);
   for (int e = lane; e < nv * nv; e += 64) d.L[e] = d.M[e];
   WSYNC();
-  if (!wave_chol(d.L, nv, lane)) { if (lane == 0) d.counters[2] |= 16; }
-  WSYNC();
+  if (!wave_chol<NMAX>(d.L, d.Ldinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; }
+  WSTAMP(5);
   wf_collision(m, d, lane);
+  WSTAMP(6);
   wf_comvel(m, d, lane);
+  WSTAMP(7);
   wf_make_constraint(m, d, lane);
+  WSTAMP(8);
   wf_smooth_forces(m, d, lane, bad_ctrl);
-  wave_chol_solve(d.qacc_smooth, d.L, nv, lane);
-  wf_constraint_newton(m, d, lane);
+  WSTAMP(9);
+  wave_chol_solve<NMAX>(d.qacc_smooth, d.L, d.Ldinv, nv, lane);
+  WSTAMP(10);
+  wf_constraint_newton<NMAX>(m, d, lane, stamp);
+  WSTAMP(11);
 }
 
 // ---- o_euler: implicit joint damping, then integrate positions
+template <int NMAX>
 __device__ __forceinline__ void wf_euler(const WaveModel& m, WaveData& d, int lane, double& time) {
   const int nv = m.nv;
   const double h = m.timestep;
@@ -856,8 +876,8 @@ __device__ __forceinline__ void wf_euler(const WaveModel& m, WaveData& d, int la
     WSYNC();
     if (lane < nv) { d.H[lane * nv + lane] += h * m.dof_damping[lane]; d.tmpv[lane] = d.qfrc_smooth[lane] + d.qfrc_constraint[lane]; }
     WSYNC();
-    if (wave_chol(d.H, nv, lane)) wave_chol_solve(d.tmpv, d.H, nv, lane);
-    else { WSYNC(); if (lane < nv) d.tmpv[lane] = d.qacc[lane]; WSYNC(); }
+    if (wave_chol<NMAX>(d.H, d.dinv, nv, lane)) wave_chol_solve<NMAX>(d.tmpv, d.H, d.dinv, nv, lane);
+    else { if (lane < nv) d.tmpv[lane] = d.qacc[lane]; WSYNC(); }
   } else {
     if (lane < nv) d.tmpv[lane] = d.qacc[lane];
     WSYNC();

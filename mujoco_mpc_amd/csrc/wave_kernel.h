@@ -11,7 +11,7 @@ __host__ __device__ inline size_t wave_lds_doubles(int nq, int nv, int nu, int n
   n += nq + nv + nu;                                   // qpos qvel ctrl
   n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 6 * njnt + 3 * nsite;  // kinematics
   n += 3 * nbody + 10 * nbody * 2 + 6 * nv * 2 + 6 * nbody * 4 + 3;                       // com, inertias, spatial
-  n += 3 * (size_t)nv * nv;                            // M L H
+  n += 3 * (size_t)nv * nv + 2 * nv;                   // M L H + reciprocal pivots
   n += 7 * nv + nu + 5 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma Ms tmpv
   n += (size_t)kWaveMaxEfc * nv + 10 * kWaveMaxEfc;    // efc_J + per-row doubles
   n += (3 * kWaveMaxEfc + 1) / 2 + 1;                  // per-row ints
@@ -22,9 +22,34 @@ __host__ __device__ inline size_t wave_lds_doubles(int nq, int nv, int nu, int n
   return n + 16;
 }
 
-__global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, const WaveTask tk, const RolloutArgs<double> a) {
+template <int NMAX>
+__global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_global, const WaveTask tk_global, const RolloutArgs<double> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x, cand = blockIdx.x;
+  // ---- the model allocation and the plan blob are staged into LDS once; every later model read is an LDS read
+  // (thousands of dependent lookups per step would otherwise each pay an L1/L2 round trip)
+  // (pointer arithmetic through integers: one constant LDS->generic cast of smem_raw, no per-pointer null checks --
+  //  the backend mis-selects the aperture compare of a variable-offset LDS->generic cast on gfx950)
+  const uintptr_t lds_generic = reinterpret_cast<uintptr_t>(static_cast<unsigned char*>(smem_raw));
+  unsigned char* lds_model = reinterpret_cast<unsigned char*>(lds_generic + (uintptr_t)a.lds_state_bytes);
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(m_global.base);
+    uint4* dst = reinterpret_cast<uint4*>(lds_model);
+    for (int i = lane; i < m_global.bytes / 16; i += 64) dst[i] = src[i];
+    const double* bsrc = tk_global.blob;
+    double* bdst = reinterpret_cast<double*>(lds_model + m_global.bytes);
+    for (int i = lane; i < a.blob_doubles; i += 64) bdst[i] = bsrc[i];
+  }
+  WaveModel m = m_global;
+  const uintptr_t model_generic = lds_generic + (uintptr_t)a.lds_state_bytes, gbase = reinterpret_cast<uintptr_t>(m_global.base);
+#define MJPCX_REBASE(f) m.f = reinterpret_cast<decltype(m.f)>(model_generic + (reinterpret_cast<uintptr_t>(m_global.f) - gbase));
+  MJPCX_WAVE_MODEL_POINTERS(MJPCX_REBASE)
+#undef MJPCX_REBASE
+  WaveTask tk = tk_global;
+  tk.blob = reinterpret_cast<const double*>(model_generic + (uintptr_t)m_global.bytes);
+  tk.dim_norm_residual = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.dim_norm_residual) - gbase));
+  tk.norm = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.norm) - gbase));
+  tk.trace_site = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.trace_site) - gbase));
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
   const int P = a.P, H = a.H;
   const size_t N = (size_t)a.N;
@@ -37,7 +62,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
   d.xanchor = take(3 * nj); d.xaxis = take(3 * nj); d.site_xpos = take(3 * ns);
   d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.crb = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
   d.cvel = take(6 * nb); d.cacc = take(6 * nb); d.cfrc = take(6 * nb); d.cfrc_sub = take(6 * nb); d.subtree_linvel = take(3);
-  d.M = take((size_t)nv * nv); d.L = take((size_t)nv * nv); d.H = take((size_t)nv * nv);
+  d.M = take((size_t)nv * nv); d.L = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = take(nv);
   d.qfrc_passive = take(nv); d.qfrc_bias = take(nv); d.qfrc_actuator = take(nv); d.qfrc_smooth = take(nv);
   d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
   d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = take(nv); d.tmpv = take(nv);
@@ -146,11 +171,14 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
     WSYNC();
     // ================= mj_forward
     bool bad_ctrl = false;
-    wf_forward(m, tk, d, lane, bad_ctrl);
+    long long* stamp = (tk.stamps && cand == 0 && t == 1) ? tk.stamps : nullptr;
+    WSTAMP(0);
+    wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, stamp);
     if (!last) for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qacc[i]);  // mj_checkAcc
     bad = __any(bad);
     // ================= sensor stage: task residual and cost (task.cc:71-110)
     wr_residual(m, tk, d, time, lane);
+    WSTAMP(12);
     if (lane < tk.nterm) {
       int off = 0;
       for (int k = 0; k < lane; k++) off += tk.dim_norm_residual[k];
@@ -176,8 +204,10 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
     if (bad) failed = true;
     total += cost;
     if (last) break;
+    WSTAMP(13);
     // ================= mj_Euler + advance
-    wf_euler(m, d, lane, time);
+    wf_euler<NMAX>(m, d, lane, time);
+    WSTAMP(14);
   }
   if (lane == 0) {
     a.total_return[cand] = failed ? kMaxReturn : total / (double)(H > 1 ? H : 1);

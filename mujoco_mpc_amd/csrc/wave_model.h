@@ -49,7 +49,24 @@ struct WaveModel {
   const int* dynamic_geom;                      // collidable geoms on moving bodies, model order
   int nstatic_geom, ndynamic_geom;
   int full;                                     // 1: rows beyond joint limits can occur (Newton path of the oracle)
+  const int* ray_geom;                          // geoms of group 0 a downward ray can hit (plane / sphere / box), model order
+  int nray_geom;
+  const unsigned char* base;                    // the single device allocation all pointers above point into
+  int bytes;                                    // its size (a multiple of 16): the kernel stages it into LDS
 };
+
+// every pointer member of WaveModel, for rebasing the struct onto a copy of the allocation (LDS staging)
+#define MJPCX_WAVE_MODEL_POINTERS(X)                                                                                         \
+  X(body_parentid) X(body_rootid) X(body_jntnum) X(body_jntadr) X(body_dofnum) X(body_dofadr) X(body_mocapid) X(body_pos)  \
+  X(body_quat) X(body_ipos) X(body_iquat) X(body_mass) X(body_inertia) X(body_invweight0) X(body_subtreemass) X(jnt_type)  \
+  X(jnt_qposadr) X(jnt_dofadr) X(jnt_bodyid) X(jnt_limited) X(jnt_pos) X(jnt_axis) X(jnt_stiffness) X(jnt_range)          \
+  X(jnt_margin) X(jnt_solref) X(jnt_solimp) X(dof_bodyid) X(dof_jntid) X(dof_parentid) X(dof_armature) X(dof_damping)     \
+  X(dof_frictionloss) X(dof_invweight0) X(dof_solref) X(dof_solimp) X(qpos0) X(qpos_spring) X(site_bodyid) X(site_pos)    \
+  X(site_quat) X(actuator_trnid) X(actuator_biastype) X(actuator_ctrllimited) X(actuator_forcelimited) X(actuator_gear)   \
+  X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange) X(geom_type) X(geom_bodyid)        \
+  X(geom_contype) X(geom_conaffinity) X(geom_condim) X(geom_priority) X(geom_group) X(geom_size) X(geom_pos) X(geom_quat) \
+  X(geom_friction) X(geom_solref) X(geom_solimp) X(geom_margin) X(geom_gap) X(geom_solmix) X(key_qpos)                    \
+  X(body_subtree_mask) X(body_dofmask) X(level_body) X(static_geom) X(dynamic_geom) X(ray_geom)
 
 // Per-plan task values: one small blob re-staged with every rollout (Planner::SetState + the frozen ResidualFn copy)
 struct WaveTask {
@@ -58,6 +75,7 @@ struct WaveTask {
   // blob (doubles): state[nq+nv] time mocap[7 nmocap] weight[nterm] norm_p[nterm] norm_q[nterm] parameters[nparam]
   //                 risk residual_real[nrr] ; then residual_int[nri] as int32
   const double* blob;
+  long long* stamps;  // optional (tuning): s_memtime at the phase boundaries of step 1 of candidate 0
   int off_time, off_mocap, off_weight, off_normp, off_normq, off_param, off_risk, off_rreal, off_rint;
 };
 
@@ -153,18 +171,27 @@ struct WaveHost {
     reg(&m.level_body, level_body.data(), sizeof(int) * level_body.size());
     reg(&m.static_geom, sg.data(), sizeof(int) * sg.size());
     reg(&m.dynamic_geom, dg.data(), sizeof(int) * dg.size());
+    std::vector<int> rg;
+    for (int g = 0; g < ng; g++)
+      if (src->geom_group[g] == 0 && (src->geom_type[g] == MJPCX_GEOM_PLANE || src->geom_type[g] == MJPCX_GEOM_SPHERE || src->geom_type[g] == MJPCX_GEOM_BOX))
+        rg.push_back(g);
+    m.nray_geom = (int)rg.size();
+    reg(&m.ray_geom, rg.data(), sizeof(int) * rg.size());
     // static task arrays
     t.residual_id = task->residual_id; t.nr = task->num_residual; t.nterm = task->num_term; t.ntrace = task->num_trace;
     t.nparam = task->num_parameter; t.nri = task->num_residual_int; t.nrr = task->num_residual_real;
     const size_t o_dim = put(task->dim_norm_residual, sizeof(int32_t) * task->num_term);
     const size_t o_norm = put(task->norm, sizeof(int32_t) * task->num_term);
     const size_t o_trace = put(task->trace_site, sizeof(int32_t) * task->num_trace);
+    host.resize((host.size() + 15) & ~(size_t)15);
     if (hipMalloc(&dev, host.size()) != hipSuccess) return "hipMalloc of the model failed";
     if (hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return "model upload failed";
     for (const Fix& f : fixes) *(const void**)((char*)&m + f.field_off) = (const char*)dev + f.data_off;
     t.dim_norm_residual = (const int*)((const char*)dev + o_dim);
     t.norm = (const int*)((const char*)dev + o_norm);
     t.trace_site = (const int*)((const char*)dev + o_trace);
+    m.base = (const unsigned char*)dev;
+    m.bytes = (int)host.size();
     // blob layout
     int o = 0;
     auto seg = [&](int n) { int at = o; o += n; return at; };

@@ -17,10 +17,9 @@ constexpr double kQPi = 3.14159265358979323846;
 // mj_ray straight down against the geoms of group 0 (plane / sphere / box), as Ground() asks (utilities.cc:556-574)
 __device__ __forceinline__ double wr_ray_down(const WaveModel& m, const WaveData& d, const double* from) {
   double best = -1;
-  for (int g = 0; g < m.ngeom; g++) {
-    if (m.geom_group[g] != 0) continue;
+  for (int gi = 0; gi < m.nray_geom; gi++) {
+    const int g = m.ray_geom[gi];
     const int type = m.geom_type[g];
-    if (type != MJPCX_GEOM_PLANE && type != MJPCX_GEOM_SPHERE && type != MJPCX_GEOM_BOX) continue;
     double p[3], R[9];
     wf_geom_pose(m, d, g, p, R);
     const double* s = m.geom_size + 3 * g;

@@ -17,6 +17,8 @@ ap.add_argument("-n", type=int, default=4096)
 ap.add_argument("--horizon", type=int, default=128)
 ap.add_argument("--launches", type=int, default=20)
 ap.add_argument("--precision", type=int, default=64)
+ap.add_argument("--interp", type=int, default=2)
+ap.add_argument("--std", type=float, default=0.5)
 a = ap.parse_args()
 task = load_task(a.task)
 ctx = capi.Context(task.packed_model(), task.packed(), 0, a.precision)
@@ -25,11 +27,17 @@ dt = task.model.get_number("agent_timestep", task.model.timestep)
 times = np.arange(P) * ((a.horizon - 1) * dt / (P - 1))
 home = task.model.keyframes.get("home")
 state = np.concatenate([home["qpos"], home["qvel"]]) if home else np.zeros(task.model.nq + task.model.nv)
+if hasattr(task, "transition"):
+    task.transition(0.0)
+    ctx.set_task_params(task.weight, task.norm_parameter, task.parameters, task.risk)
+    ctx.set_residual_state(task.residual_int, task.residual_real)
 ctx.set_state(state, 0.0)
 ctx.timing_reset()
 for k in range(a.launches):
-    ctx.rollout_noise(a.n, a.horizon, capi.SPLINE_CUBIC, times, np.zeros((P, task.model.nu)),
-                      capi.make_noise_spec(seed=0, iteration=k, std0=0.5))
+    ctx.rollout_noise(a.n, a.horizon, a.interp, times, np.zeros((P, task.model.nu)),
+                      capi.make_noise_spec(seed=0, iteration=k, std0=a.std))
 ms, n = ctx.timing_read()
-print(f"{ctx.kernel_name}: {n} launches, avg {ms / n * 1e3:.1f} us, "
+ret, fail = ctx.returns()
+print(f"returns: min {ret.min():.4f} median {np.median(ret):.4f} failures {int(fail.sum())}")
+print(f"{ctx.kernel_name}: {n} launches, avg {ms / n * 1e3:.1f} us, {a.n * a.horizon / (ms / n * 1e-3) / 1e6:.2f} M steps/s, "
       f"{ctx.algorithmic_bytes(a.horizon, P) * a.n / (ms / n * 1e-3) / 1e9:.1f} GB/s algorithmic")
