@@ -21,7 +21,16 @@
 
 namespace mjpcx {
 
-#define WSYNC() __syncthreads()  // single-wavefront workgroups: the LDS ordering point between dependent phases
+// Single-wavefront workgroups: the ordering point between dependent LDS phases only has to (a) stop the compiler from
+// moving LDS accesses across it and (b) wait for this wave's outstanding LDS operations -- no s_barrier, and no wait
+// on outstanding global stores (which __syncthreads() would add through its global-memory fence).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only (gfx9 encoding: vmcnt = max, expcnt = max)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#define WSYNC() wave_lds_sync()
 
 struct WaveContact {
   int g1, g2, dim, dim0, efc;
@@ -159,8 +168,9 @@ __device__ __forceinline__ double wbcast(double v, int src) {  // src must be wa
   return __hiloint2double(hi, lo);
 }
 // in-place: on exit the lower triangle of A (LDS, ld n) holds L with A = L L', dinv[j] = 1 / L[j][j].
+// (not inlined: five call sites per step, and the step loop has to stay inside the instruction cache)
 template <int NMAX>
-__device__ __forceinline__ bool wave_chol(double* A, double* dinv, int n, int lane) {
+__device__ __noinline__ bool wave_chol(double* A, double* dinv, int n, int lane) {
   double row[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; k++) row[k] = (lane < n && k <= lane) ? A[lane * n + k] : 0.0;
@@ -193,7 +203,7 @@ __device__ __forceinline__ bool wave_chol(double* A, double* dinv, int n, int la
 }
 // x := (L L')^-1 x, x in LDS
 template <int NMAX>
-__device__ __forceinline__ void wave_chol_solve(double* x, const double* L, const double* dinv, int n, int lane) {
+__device__ __noinline__ void wave_chol_solve(double* x, const double* L, const double* dinv, int n, int lane) {
   double row[NMAX], col[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
@@ -221,7 +231,7 @@ __device__ __forceinline__ void wave_chol_solve(double* x, const double* L, cons
 }
 
 // solimp -> impedance at violation `dist` (oracle impedance())
-__device__ __forceinline__ double w_impedance(const double* solimp, double dist) {
+__device__ __noinline__ double w_impedance(const double* solimp, double dist) {
   double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
   dmin = fmin(fmax(dmin, kMinImp), kMaxImp);
   dmax = fmin(fmax(dmax, kMinImp), kMaxImp);
@@ -262,7 +272,7 @@ __device__ __forceinline__ void w_make_frame(double* frame) {
 constexpr double kMinMu = 1e-5;
 
 // runtime-sized mjpc::Norm value (device_common.h norm_value with a run-time slice length)
-__device__ __forceinline__ double w_norm_value(const double* x, int n, int type, double p, double q) {
+__device__ __noinline__ double w_norm_value(const double* x, int n, int type, double p, double q) {
   double y = 0;
   switch (type) {
     case -1: y = x[0]; break;

@@ -616,9 +616,17 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
 // ---- penalties: one lane per row; a cone is evaluated by the lane of its first row
 struct ConeEval { double cost, g, h; };
 // value/force/zone at x = jar (+ alpha jv when jv != nullptr); derivative terms along jv when requested
-__device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const double* jar, const double* jv, double alpha,
-                                            bool write_force, double& cost, double& g1, double& h2) {
-  cost = 0; g1 = 0; h2 = 0;
+struct RowView {  // by value into the out-of-line row evaluator
+  const int *efc_type, *efc_id;
+  int* efc_zone;
+  const double *efc_D, *efc_R, *efc_floss;
+  double* efc_force;
+  const WaveContact* con;
+};
+struct RowResult { double cost, g1, h2; };
+__device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const double* jar, const double* jv, double alpha,
+                                                   bool write_force) {
+  double cost = 0, g1 = 0, h2 = 0;
   const int type = d.efc_type[r];
   const double D = d.efc_D[r];
   const double v = jv ? jv[r] : 0.0;
@@ -671,6 +679,13 @@ __device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const doub
       }
     }
   }
+  return RowResult{cost, g1, h2};
+}
+__device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const double* jar, const double* jv, double alpha,
+                                            bool write_force, double& cost, double& g1, double& h2) {
+  const RowView v{d.efc_type, d.efc_id, d.efc_zone, d.efc_D, d.efc_R, d.efc_floss, d.efc_force, d.con};
+  const RowResult res = wf_row_eval_impl(v, r, jar, jv, alpha, write_force);
+  cost = res.cost; g1 = res.g1; h2 = res.h2;
 }
 
 // cost of all rows at jar; writes force and zone. Returns the wave-uniform sum.
