@@ -19,6 +19,7 @@
 #include "lane_registry.h"
 #include "ilqg_dense.h"
 #include "rollout_wave.h"
+#include "rollout_simt.h"
 
 using namespace mjpcx;
 
@@ -316,7 +317,7 @@ struct mjpcx_ctx {
   // pinned + device-mapped result record of mjpcx_best
   void* best_host = nullptr; void* best_dev = nullptr; size_t best_cap = 0;
   // rollout buffers
-  DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out;
+  DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out, d_simt;
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
   int N = 0, H = 0, P = 0;  // shape of the last rollout
   bool have_rollout = false;
@@ -547,6 +548,20 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       WaveTask wt = c->wh.t;
       wt.blob = (const double*)d_blob;
       wt.stamps = nullptr;
+      // A second mapping of the same step function exists for experiments: lane per candidate with the per-lane state in
+      // the private segment (MJPCX_CONTACT_KERNEL=simt). Measured 4-10x SLOWER than the wavefront-per-candidate kernel
+      // at N <= 16384 (every state access is a dependent ~1 us memory round trip and there are too few wavefronts to
+      // hide it), so it is never selected automatically.
+      const char* force = getenv("MJPCX_CONTACT_KERNEL");
+      const bool simt = force && std::string(force) == "simt";
+      if (simt) {
+        const SimtLayout lay = simt_layout(c->wh.m.nq, c->wh.m.nv, c->wh.m.nu, c->wh.m.nbody, c->wh.m.njnt, c->wh.m.nsite, wt.nr, P);
+        const int nblk = (N + 63) / 64;
+        if (lay.total > kSimtPrivateDoubles) return fail(c, MJPCX_EUNSUPPORTED, "model state exceeds the lane kernel's private segment");
+        if (!MJPCX_SIMT_PRIVATE) HIPCHK(c, c->d_simt.reserve((size_t)nblk * lay.total * 64 * 8));
+        hipLaunchKernelGGL(rollout_simt_kernel, dim3(nblk), dim3(64), 0, c->stream, c->wh.m, wt, a, lay, (double*)c->d_simt.p);
+        le = hipGetLastError();
+      } else {
       if (getenv("MJPCX_STAMPS")) {
         HIPCHK(c, c->d_stage.reserve(32 * 8));
         HIPCHK(c, hipMemsetAsync(c->d_stage.p, 0, 32 * 8, c->stream));
@@ -554,8 +569,9 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       }
       const WaveModel& wm = c->wh.m;
       const size_t lds_state = (8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
-      const size_t blob_d = (c->wh.blob_bytes + 7) / 8;
-      const size_t lds = lds_state + (size_t)wm.bytes + blob_d * 8;
+      const bool stage = getenv("MJPCX_WAVE_STAGE_MODEL") != nullptr;
+      const size_t blob_d = stage ? (c->wh.blob_bytes + 7) / 8 : 0;
+      const size_t lds = lds_state + (stage ? (size_t)wm.bytes + blob_d * 8 : 0);
       a.lds_state_bytes = (int)lds_state;
       a.blob_doubles = (int)blob_d;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
@@ -575,6 +591,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         for (int k = 0; k < 14; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k + 1] - h[k]);
         std::fprintf(stderr, " | newton iters %lld: grad %lld hess %lld chol+solve %lld linesearch %lld\n", h[20], h[21] - h[10], h[22] - h[21],
                      h[23] - h[22], h[24] - h[23]);
+      }
       }
     } else {
       le = c->kernel->launch64(c->hm64, c->ht64, a, c->stream);
@@ -772,7 +789,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   }
   if (c->best_host) (void)hipHostFree(c->best_host);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_simt,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();

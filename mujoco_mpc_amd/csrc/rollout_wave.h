@@ -47,7 +47,7 @@ struct WaveData {
   double *subtree_com, *cinert, *crb, *cdof, *cdof_dot, *cvel, *cacc, *cfrc, *cfrc_sub, *subtree_linvel;
   double *M, *L, *H, *Ldinv, *dinv;
   double *qfrc_passive, *qfrc_bias, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qacc, *qfrc_constraint;
-  double *actuator_force, *grad, *search, *Ma, *Ms, *tmpv;
+  double *actuator_force, *grad, *search, *Ma, *Ms, *tmpv, *qacc_warm;
   double *efc_J, *efc_pos, *efc_margin, *efc_D, *efc_R, *efc_aref, *efc_floss, *efc_force, *jar, *jv;
   int *efc_type, *efc_id, *efc_zone;
   double* coneH;  // kWaveMaxCon x 36

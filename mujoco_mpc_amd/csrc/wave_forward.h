@@ -699,7 +699,7 @@ __device__ __forceinline__ double wf_constraint_cost(WaveData& d, int nefc, int 
 
 // ---- o_constraint_newton
 template <int NMAX>
-__device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveData& d, int lane, long long* stamp = nullptr) {
+__device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveData& d, int lane, long long* stamp = nullptr, bool have_warm = false) {
   const int nv = m.nv, ne = d.counters[1];
   if (lane < nv) { d.qfrc_constraint[lane] = 0; d.qacc[lane] = d.qacc_smooth[lane]; }
   WSYNC();
@@ -711,6 +711,34 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
   }
   WSYNC();
   double cost = wf_constraint_cost(d, ne, lane);
+  if (have_warm) {  // warm start (mj_fwdConstraint): begin at the previous step's qacc if its cost is lower
+    double jsave = 0, jw = 0, gauss = 0;
+    if (lane < ne) {
+      jsave = d.jar[lane];
+      double s = -d.efc_aref[lane];
+      for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.qacc_warm[k];
+      jw = s;
+    }
+    if (lane < nv) {
+      double s = 0;
+      for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc_warm[b] - d.qacc_smooth[b]);
+      gauss = 0.5 * s * (d.qacc_warm[lane] - d.qacc_smooth[lane]);
+    }
+    gauss = wave_sum(gauss);
+    WSYNC();
+    if (lane < ne) d.jar[lane] = jw;
+    WSYNC();
+    const double cw = gauss + wf_constraint_cost(d, ne, lane);
+    if (cw < cost) {
+      cost = cw;
+      if (lane < nv) d.qacc[lane] = d.qacc_warm[lane];
+      WSYNC();
+    } else {
+      if (lane < ne) d.jar[lane] = jsave;
+      WSYNC();
+      wf_constraint_cost(d, ne, lane);  // restore force / zone of the smooth start
+    }
+  }
   const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
   bool polish = false;
   for (int iter = 0; iter < m.solver_iterations; iter++) {
@@ -853,7 +881,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
 #define WSTAMP(k) do { if (stamp && lane == 0) stamp[k] = (long long)__builtin_readcyclecounter(); } while (0)
 template <int NMAX>
 __device__ __forceinline__ void wf_forward(const WaveModel& m, const WaveTask& tk, WaveData& d, int lane, bool& bad_ctrl,
-                                           long long* stamp) {
+                                           long long* stamp, bool have_warm) {
   const int nv = m.nv;
   WSTAMP(1);
   wf_kinematics(m, tk, d, lane);
@@ -877,7 +905,7 @@ __device__ __forceinline__ void wf_forward(const WaveModel& m, const WaveTask& t
   WSTAMP(9);
   wave_chol_solve<NMAX>(d.qacc_smooth, d.L, d.Ldinv, nv, lane);
   WSTAMP(10);
-  wf_constraint_newton<NMAX>(m, d, lane, stamp);
+  wf_constraint_newton<NMAX>(m, d, lane, stamp, have_warm);
   WSTAMP(11);
 }
 

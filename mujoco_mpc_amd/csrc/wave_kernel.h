@@ -12,7 +12,7 @@ __host__ __device__ inline size_t wave_lds_doubles(int nq, int nv, int nu, int n
   n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 6 * njnt + 3 * nsite;  // kinematics
   n += 3 * nbody + 10 * nbody * 2 + 6 * nv * 2 + 6 * nbody * 4 + 3;                       // com, inertias, spatial
   n += 3 * (size_t)nv * nv + 2 * nv;                   // M L H + reciprocal pivots
-  n += 7 * nv + nu + 5 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma Ms tmpv
+  n += 7 * nv + nu + 6 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma Ms tmpv qacc_warm
   n += (size_t)kWaveMaxEfc * nv + 10 * kWaveMaxEfc;    // efc_J + per-row doubles
   n += (3 * kWaveMaxEfc + 1) / 2 + 1;                  // per-row ints
   n += 36 * kWaveMaxCon + 12 + nr + nterm + 8;         // coneH foot_xpos residual terms scal
@@ -26,30 +26,31 @@ template <int NMAX>
 __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_global, const WaveTask tk_global, const RolloutArgs<double> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x, cand = blockIdx.x;
-  // ---- the model allocation and the plan blob are staged into LDS once; every later model read is an LDS read
-  // (thousands of dependent lookups per step would otherwise each pay an L1/L2 round trip)
   // (pointer arithmetic through integers: one constant LDS->generic cast of smem_raw, no per-pointer null checks --
   //  the backend mis-selects the aperture compare of a variable-offset LDS->generic cast on gfx950)
   const uintptr_t lds_generic = reinterpret_cast<uintptr_t>(static_cast<unsigned char*>(smem_raw));
   unsigned char* lds_model = reinterpret_cast<unsigned char*>(lds_generic + (uintptr_t)a.lds_state_bytes);
-  {
+  WaveModel m = m_global;
+  WaveTask tk = tk_global;
+  // Staging is optional (a.blob_doubles > 0): it removes the L1/L2 round trips of the model reads but costs ~19 KB of
+  // LDS, i.e. 2 instead of 3 candidates per CU; measured it does not shorten the step (issue-bound), so the default
+  // keeps the model in global memory (scalar / vector L1 hits after the first step).
+  if (a.blob_doubles > 0) {
     const uint4* src = reinterpret_cast<const uint4*>(m_global.base);
     uint4* dst = reinterpret_cast<uint4*>(lds_model);
     for (int i = lane; i < m_global.bytes / 16; i += 64) dst[i] = src[i];
     const double* bsrc = tk_global.blob;
     double* bdst = reinterpret_cast<double*>(lds_model + m_global.bytes);
     for (int i = lane; i < a.blob_doubles; i += 64) bdst[i] = bsrc[i];
-  }
-  WaveModel m = m_global;
   const uintptr_t model_generic = lds_generic + (uintptr_t)a.lds_state_bytes, gbase = reinterpret_cast<uintptr_t>(m_global.base);
 #define MJPCX_REBASE(f) m.f = reinterpret_cast<decltype(m.f)>(model_generic + (reinterpret_cast<uintptr_t>(m_global.f) - gbase));
   MJPCX_WAVE_MODEL_POINTERS(MJPCX_REBASE)
 #undef MJPCX_REBASE
-  WaveTask tk = tk_global;
   tk.blob = reinterpret_cast<const double*>(model_generic + (uintptr_t)m_global.bytes);
   tk.dim_norm_residual = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.dim_norm_residual) - gbase));
   tk.norm = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.norm) - gbase));
   tk.trace_site = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.trace_site) - gbase));
+  }
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
   const int P = a.P, H = a.H;
   const size_t N = (size_t)a.N;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_glob
   d.M = take((size_t)nv * nv); d.L = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = take(nv);
   d.qfrc_passive = take(nv); d.qfrc_bias = take(nv); d.qfrc_actuator = take(nv); d.qfrc_smooth = take(nv);
   d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
-  d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = take(nv); d.tmpv = take(nv);
+  d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = take(nv); d.tmpv = take(nv); d.qacc_warm = take(nv);
   d.efc_J = take((size_t)kWaveMaxEfc * nv);
   d.efc_pos = take(kWaveMaxEfc); d.efc_margin = take(kWaveMaxEfc); d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
   d.efc_aref = take(kWaveMaxEfc); d.efc_floss = take(kWaveMaxEfc); d.efc_force = take(kWaveMaxEfc); d.jar = take(kWaveMaxEfc);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_glob
     bool bad_ctrl = false;
     long long* stamp = (tk.stamps && cand == 0 && t == 1) ? tk.stamps : nullptr;
     WSTAMP(0);
-    wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, stamp);
+    wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, stamp, /*have_warm=*/t > 0);
     if (!last) for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qacc[i]);  // mj_checkAcc
     bad = __any(bad);
     // ================= sensor stage: task residual and cost (task.cc:71-110)
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_glob
     total += cost;
     if (last) break;
     WSTAMP(13);
-    // ================= mj_Euler + advance
+    // ================= mj_Euler + advance (qacc is kept as the next step's warm start)
+    if (lane < nv) d.qacc_warm[lane] = d.qacc[lane];
     wf_euler<NMAX>(m, d, lane, time);
     WSTAMP(14);
   }

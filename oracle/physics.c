@@ -65,6 +65,8 @@ struct OData {
   int efc_type[OMAXEFC], efc_id[OMAXEFC], efc_zone[OMAXEFC];
   double efc_D[OMAXEFC], efc_floss[OMAXEFC], efc_vel[OMAXEFC];
   double *scratch_jac, *nw_jar, *nw_jv, *nw_grad, *nw_search, *nw_Ma, *nw_H, *nw_L;
+  double* qacc_warmstart; /* previous step's qacc (mj_advance); valid iff have_warm */
+  int have_warm;
   int warning;
 };
 
@@ -208,6 +210,7 @@ OData* odata_new(const mjpcx_model* m) {
   d->geom_static = (int*)calloc((size_t)(m->ngeom > 0 ? m->ngeom : 1), sizeof(int));
   d->scratch_jac = dalloc(12 * nv); d->nw_jar = dalloc(OMAXEFC); d->nw_jv = dalloc(OMAXEFC);
   d->nw_grad = dalloc(nv); d->nw_search = dalloc(nv); d->nw_Ma = dalloc(nv); d->nw_H = dalloc(nv * nv); d->nw_L = dalloc(nv * nv);
+  d->qacc_warmstart = dalloc(nv); d->have_warm = 0;
   d->full = 0;
   for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0 && !(m->disableflags & MJPCX_DSBL_FRICTIONLOSS)) d->full = 1;
   int nstatic = 0, ndynamic = 0;
@@ -238,7 +241,7 @@ void odata_free(OData* d) {
                   &d->qfrc_passive, &d->qfrc_bias, &d->qfrc_actuator, &d->qfrc_smooth,
                   &d->qacc_smooth, &d->qfrc_constraint, &d->qacc, &d->actuator_force, &d->efc_J,
                   &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A, &d->geom_xpos, &d->geom_xmat, &d->scratch_jac,
-                  &d->nw_jar, &d->nw_jv, &d->nw_grad, &d->nw_search, &d->nw_Ma, &d->nw_H, &d->nw_L};
+                  &d->nw_jar, &d->nw_jv, &d->nw_grad, &d->nw_search, &d->nw_Ma, &d->nw_H, &d->nw_L, &d->qacc_warmstart};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
   free(d->geom_static);
   free(d);
@@ -255,6 +258,7 @@ void odata_set_state(OData* d, const double* state, double time, const double* m
   }
   if (userdata && m->nuserdata) memcpy(d->userdata, userdata, sizeof(double) * m->nuserdata);
   d->warning = 0;
+  d->have_warm = 0; /* a rollout starts without a warm start (the reference inherits whatever the pooled mjData held) */
 }
 void odata_set_ctrl(OData* d, const double* ctrl) { memcpy(d->ctrl, ctrl, sizeof(double) * d->nu); }
 int odata_warning(const OData* d) { return d->warning; }
@@ -702,6 +706,8 @@ static void o_euler(OData* d) {
   } else {
     memcpy(qacc, d->qacc, sizeof(double) * nv);
   }
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv); /* mj_advance: save for the next step's solver */
+  d->have_warm = 1;
   for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
   for (int j = 0; j < m->njnt; j++) { /* mj_integratePos */
     int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
