@@ -47,6 +47,15 @@ FlatModel::FlatModel(const mjModel* m, double timestep, int integrator) {
   f.actuator_trnid = trnid_.data(); f.actuator_ctrllimited = ctrllimited_.data();
   f.actuator_forcelimited = forcelimited_.data(); f.actuator_gear = gear_.data();
   f.actuator_gainprm = gainprm_.data(); f.actuator_biasprm = biasprm_.data();
+  // contacts and constraint options (geom_* keep MuJoCo's strides: size 3, friction 3, solref mjNREF, solimp mjNIMP)
+  f.ngeom = m->ngeom; f.nkey = m->nkey; f.cone = m->opt.cone; f.impratio = m->opt.impratio;
+  f.geom_type = m->geom_type; f.geom_bodyid = m->geom_bodyid; f.geom_contype = m->geom_contype;
+  f.geom_conaffinity = m->geom_conaffinity; f.geom_condim = m->geom_condim; f.geom_priority = m->geom_priority;
+  f.geom_group = m->geom_group; f.geom_size = m->geom_size; f.geom_pos = m->geom_pos; f.geom_quat = m->geom_quat;
+  f.geom_friction = m->geom_friction; f.geom_solref = m->geom_solref; f.geom_solimp = m->geom_solimp;
+  f.geom_margin = m->geom_margin; f.geom_gap = m->geom_gap; f.geom_solmix = m->geom_solmix;
+  f.body_invweight0 = m->body_invweight0; f.body_subtreemass = m->body_subtreemass;
+  f.dof_solref = m->dof_solref; f.dof_solimp = m->dof_solimp; f.key_qpos = m->key_qpos;
 }
 
 FlatTask::FlatTask(const Task& t) {
@@ -64,6 +73,11 @@ FlatTask::FlatTask(const Task& t) {
   flat_.parameters = t.parameters.data();
   flat_.trace_site = t.trace_site.data();
   flat_.risk = t.risk;
+  t.ResidualState(&residual_int_, &residual_real_);
+  flat_.num_residual_int = (int)residual_int_.size();
+  flat_.num_residual_real = (int)residual_real_.size();
+  flat_.residual_int = residual_int_.data();
+  flat_.residual_real = residual_real_.data();
 }
 
 Context::Context(const mjModel* model, const Task& task, int device, int precision) {
@@ -85,6 +99,15 @@ Context::~Context() { mjpcx_destroy(ctx_); }
 
 void Context::Check(int rc) const {
   if (rc != MJPCX_OK) throw Error(rc, std::string(mjpcx_error_string(rc)) + ": " + mjpcx_last_error(ctx_));
+}
+
+// the per-plan frozen task copy (Agent::PlanIteration: residual_fn_ = task->Residual(), agent.cc:319)
+void Context::SyncTask(const Task& t) {
+  Check(mjpcx_set_task_params(ctx_, t.weight.data(), t.norm_parameter.data(), t.parameters.data(), t.risk));
+  std::vector<int32_t> ri;
+  std::vector<double> rr;
+  t.ResidualState(&ri, &rr);
+  if (!ri.empty() || !rr.empty()) Check(mjpcx_set_residual_state(ctx_, ri.empty() ? nullptr : ri.data(), rr.empty() ? nullptr : rr.data()));
 }
 
 void Context::FetchTrajectory(int index, Trajectory* tr) {

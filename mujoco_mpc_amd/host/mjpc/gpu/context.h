@@ -39,7 +39,8 @@ class FlatTask {
 
  private:
   mjpcx_task flat_{};
-  std::vector<int32_t> norm_;
+  std::vector<int32_t> norm_, residual_int_;
+  std::vector<double> residual_real_;
 };
 
 class Context {
@@ -52,6 +53,7 @@ class Context {
   mjpcx_ctx* handle() { return ctx_; }
   std::string KernelName() const { return mjpcx_kernel_name(ctx_); }
   void Check(int rc) const;  // throws gpu::Error with mjpcx_last_error on rc != 0
+  void SyncTask(const Task& task);  // weights, norm/residual parameters, risk and the frozen ResidualFn state
   // gathers candidate `index` into a (pre-allocated) reference-layout Trajectory
   void FetchTrajectory(int index, Trajectory* trajectory);
 

@@ -117,6 +117,7 @@ void GpuCrossEntropyPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
   ns.std1 = std_min_;
   ns.param_variance = variance.data();
   const TimeSpline& plan = resampled_policy.plan;
+  ctx_->SyncTask(*task);  // the per-plan frozen ResidualFn copy (agent.cc:319)
   ctx_->Check(mjpcx_set_state(ctx_->handle(), state.data(), time, mocap.data(), userdata.data()));
   ctx_->Check(mjpcx_rollout_noise(ctx_->handle(), n_local_, horizon, (int)plan.Size(), (int)plan.Interpolation(),
                                   plan.times().data(), plan.values().data(), &ns));

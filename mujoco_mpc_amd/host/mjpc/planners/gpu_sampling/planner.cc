@@ -119,6 +119,7 @@ void GpuSamplingPlanner::Rollouts(int num_trajectory, int horizon) {
   ns.std0 = noise_exploration[0];
   ns.std1 = noise_exploration[1];
   const TimeSpline& plan = policy.plan;
+  ctx_->SyncTask(*task);  // the per-plan frozen ResidualFn copy (agent.cc:319)
   ctx_->Check(mjpcx_set_state(ctx_->handle(), state.data(), time, mocap.data(), userdata.data()));
   ctx_->Check(mjpcx_rollout_noise(ctx_->handle(), n_local, horizon, (int)plan.Size(), (int)plan.Interpolation(),
                                   plan.times().data(), plan.values().data(), &ns));

@@ -2,6 +2,7 @@
 // addition is Task::DeviceResidualId(): the id of the device function that implements the task's
 // ResidualFn::Residual inside the GPU rollout kernels (include/mjpcx.h MJPCX_RESIDUAL_*).
 #pragma once
+#include <cstdint>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -61,6 +62,9 @@ class Task {
   virtual std::string Name() const = 0;
   virtual std::string XmlPath() const = 0;
   virtual int DeviceResidualId() const { return 0; }
+  // the task-specific members of the frozen ResidualFn copy a device residual needs (mjpcx_task::residual_int/real);
+  // layout per residual in csrc/wave_residual.h. Tasks whose residual only reads `parameters` leave them empty.
+  virtual void ResidualState(std::vector<int32_t>* ints, std::vector<double>* reals) const { ints->clear(); reals->clear(); }
 
   int mode = 0;
   int reset = 0, visualize = 0;

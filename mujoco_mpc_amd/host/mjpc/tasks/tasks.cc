@@ -1,5 +1,7 @@
 #include "tasks.h"
 
+#include "quadruped/quadruped.h"
+
 #include <cmath>
 
 #include "../../../../include/mjpcx.h"
@@ -38,7 +40,8 @@ void ParticleCopyTestTask::ResidualFn::Residual(const mjModel* model, const mjDa
 }
 
 std::vector<std::shared_ptr<Task>> GetTasks() {
-  return {std::make_shared<Cartpole>(), std::make_shared<ParticleTestTask>(), std::make_shared<ParticleCopyTestTask>()};
+  return {std::make_shared<Cartpole>(), std::make_shared<ParticleTestTask>(), std::make_shared<ParticleCopyTestTask>(),
+          std::make_shared<QuadrupedFlat>()};
 }
 
 }  // namespace mjpc

@@ -72,8 +72,9 @@ void ModelStorage::Bind() {
   const double* opt = R("opt", 6);
   m.opt.timestep = opt[0]; m.opt.gravity[0] = opt[1]; m.opt.gravity[1] = opt[2]; m.opt.gravity[2] = opt[3];
   m.opt.tolerance = opt[4]; m.stat.meaninertia = opt[5];
-  const int* oi = I("opt_int", 3);
-  m.opt.integrator = oi[0]; m.opt.iterations = oi[1]; m.opt.disableflags = oi[2];
+  const int* oi = I("opt_int", 5);
+  m.opt.integrator = oi[0]; m.opt.iterations = oi[1]; m.opt.disableflags = oi[2]; m.opt.cone = oi[3]; m.ngeom = oi[4];
+  m.opt.impratio = R("opt_impratio", 1)[0];
   const size_t nb = m.nbody, nj = m.njnt, nv = m.nv, nq = m.nq, ns = m.nsite, nu = m.nu;
 #define BI(f, n) m.f = I(#f, n)
 #define BR(f, n) m.f = R(#f, n)
@@ -100,6 +101,13 @@ void ModelStorage::Bind() {
   BR(key_qpos, (size_t)m.nkey * nq); BR(key_qvel, (size_t)m.nkey * nv);
   BI(name_bodyadr, nb); BI(name_jntadr, nj); BI(name_siteadr, ns); BI(name_sensoradr, nsn);
   BI(name_numericadr, m.nnumeric); BI(name_keyadr, m.nkey);
+  const size_t ng = m.ngeom;
+  BR(body_invweight0, 2 * nb); BR(body_subtreemass, nb); BR(dof_solref, mjNREF * nv); BR(dof_solimp, mjNIMP * nv);
+  BI(geom_type, ng); BI(geom_bodyid, ng); BI(geom_contype, ng); BI(geom_conaffinity, ng); BI(geom_condim, ng);
+  BI(geom_priority, ng); BI(geom_group, ng);
+  BR(geom_size, 3 * ng); BR(geom_pos, 3 * ng); BR(geom_quat, 4 * ng); BR(geom_friction, 3 * ng); BR(geom_solref, mjNREF * ng);
+  BR(geom_solimp, mjNIMP * ng); BR(geom_margin, ng); BR(geom_gap, ng); BR(geom_solmix, ng);
+  BI(name_geomadr, ng);
   m.names = reinterpret_cast<char*>(B("names", 1));
 #undef BI
 #undef BR
@@ -110,7 +118,10 @@ int NameToId(const mjModel* m, int objtype, const std::string& name) {
   const int* adr = nullptr;
   int n = 0;
   if (objtype == mjOBJ_BODY) { adr = m->name_bodyadr; n = m->nbody; }
+  else if (objtype == mjOBJ_XBODY) { adr = m->name_bodyadr; n = m->nbody; }
   else if (objtype == mjOBJ_SITE) { adr = m->name_siteadr; n = m->nsite; }
+  else if (objtype == mjOBJ_GEOM) { adr = m->name_geomadr; n = m->ngeom; }
+  else if (objtype == mjOBJ_KEY) { adr = m->name_keyadr; n = m->nkey; }
   for (int i = 0; i < n; i++)
     if (name == m->names + adr[i]) return i;
   return -1;

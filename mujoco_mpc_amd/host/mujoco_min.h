@@ -17,7 +17,8 @@ typedef unsigned char mjtByte;
 enum { mjNREF = 2, mjNIMP = 5, mjNGAIN = 10, mjNBIAS = 10 };
 enum mjtJoint { mjJNT_FREE = 0, mjJNT_BALL, mjJNT_SLIDE, mjJNT_HINGE };
 enum mjtSensor { mjSENS_USER = 100, mjSENS_FRAMEPOS = 25, mjSENS_OTHER = 0 };
-enum mjtObj { mjOBJ_BODY = 1, mjOBJ_SITE = 6 };
+enum mjtObj { mjOBJ_BODY = 1, mjOBJ_XBODY = 2, mjOBJ_GEOM = 5, mjOBJ_SITE = 6, mjOBJ_KEY = 21 };
+enum mjtCone { mjCONE_PYRAMIDAL = 0, mjCONE_ELLIPTIC = 1 };
 enum mjtBias { mjBIAS_NONE = 0, mjBIAS_AFFINE = 1 };
 
 struct mjOption {
@@ -27,22 +28,26 @@ struct mjOption {
   int integrator;
   int iterations;
   int disableflags;
+  int cone;
+  mjtNum impratio;
 };
 struct mjStatistic {
   mjtNum meaninertia;
 };
 
 struct mjModel {
-  int nq, nv, nu, na, nbody, njnt, nsite, nmocap, nuserdata, nsensor, nuser_sensor, nnumeric, ntext, nkey;
+  int nq, nv, nu, na, nbody, njnt, nsite, nmocap, nuserdata, nsensor, nuser_sensor, nnumeric, ntext, nkey, ngeom;
   mjOption opt;
   mjStatistic stat;
   int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_mocapid;
-  mjtNum *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia;
+  mjtNum *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_subtreemass;
   int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
   mjtByte* jnt_limited;
   mjtNum *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
   int *dof_bodyid, *dof_jntid, *dof_parentid;
-  mjtNum *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0;
+  mjtNum *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
+  int *geom_type, *geom_bodyid, *geom_contype, *geom_conaffinity, *geom_condim, *geom_priority, *geom_group;
+  mjtNum *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_solmix;
   mjtNum *qpos0, *qpos_spring;
   int* site_bodyid;
   mjtNum *site_pos, *site_quat;
@@ -54,7 +59,7 @@ struct mjModel {
   int *numeric_adr, *numeric_size;
   mjtNum* numeric_data;
   mjtNum *key_qpos, *key_qvel;
-  int *name_bodyadr, *name_jntadr, *name_siteadr, *name_sensoradr, *name_numericadr, *name_keyadr;
+  int *name_bodyadr, *name_jntadr, *name_siteadr, *name_sensoradr, *name_numericadr, *name_keyadr, *name_geomadr;
   char* names;
 };
 

@@ -102,6 +102,19 @@ int mjpc_planner_set_state(void* h, const double* qpos, const double* qvel, cons
     H->planner->SetState(H->state);
   });
 }
+// Task::Transition at `time` (mode: < 0 keeps the task's current mode); parameters/weights the transition changed
+// reach the device with the next plan
+int mjpc_planner_task_transition(void* h, double time, int mode) {
+  GUARD(h, {
+    mjData d{};
+    d.time = time;
+    if (mode >= 0) H->task->mode = mode;
+    H->task->Transition(H->storage->model(), &d);
+  });
+}
+int mjpc_planner_task_set_parameter(void* h, int index, double value) {
+  GUARD(h, { if (index < 0 || index >= (int)H->task->parameters.size()) throw std::runtime_error("parameter index"); H->task->parameters[index] = value; });
+}
 int mjpc_planner_optimize(void* h, int horizon) { GUARD(h, H->planner->OptimizePolicy(horizon, H->pool)); }
 int mjpc_planner_nominal(void* h, int horizon) { GUARD(h, H->planner->NominalTrajectory(horizon, H->pool)); }
 // state may be NULL (open-loop action)

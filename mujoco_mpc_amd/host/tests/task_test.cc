@@ -55,6 +55,29 @@ int main(int argc, char** argv) {
   cart.Residual(cstorage->model(), &d, r);
   CHECK_NEAR(r[0], std::cos(1.0) - 1, 1e-15);
   CHECK(r[1] == 0.3 && r[2] == -0.2 && r[3] == 0.7);
-  CHECK(GetTasks().size() == 3);
+  CHECK(GetTasks().size() == 4);
+  if (argc > 3) {  // QuadrupedFlat: ResetLocked ids, Transition state and the frozen residual copy (quadruped.cc:229-391, 520-607)
+    auto qstorage = ModelStorage::Load(argv[3]);
+    std::shared_ptr<Task> quad;
+    for (auto& t : GetTasks()) if (t->Name() == "QuadrupedFlat") quad = t;
+    CHECK(quad != nullptr);
+    quad->Reset(qstorage->model());
+    CHECK(quad->num_term == 9 && quad->num_residual == 42 && quad->num_trace == 1 && quad->parameters.size() == 11);
+    std::vector<int32_t> ri; std::vector<double> rr;
+    quad->ResidualState(&ri, &rr);
+    CHECK(ri.size() == 17 && rr.size() == 30);
+    CHECK(ri[0] == 0 && ri[8] == 0 && rr[15] == 0.0);  // Quadruped mode, Stand, phase clock not started
+    mjData d{};
+    d.time = 0.5;
+    quad->parameters[0] = 2;  // select_Gait = Trot
+    quad->Transition(qstorage->model(), &d);
+    quad->ResidualState(&ri, &rr);
+    CHECK(ri[8] == 2);                                  // gait switched
+    CHECK_NEAR(rr[15], 2 * 3.14159265358979323846 * 2, 1e-12);  // phase velocity from the XML cadence (2 Hz) at the first transition
+    CHECK_NEAR(rr[13], 0.5, 0); CHECK_NEAR(rr[14], 0.5, 0);   // phase_start_ / phase_start_time_ = time of the first transition
+    CHECK(quad->parameters[4] == 0.45 && quad->parameters[2] == 2 && quad->parameters[3] == 0.03);  // duty, cadence, amplitude of Trot
+    CHECK(quad->weight[4] == 0.2 && quad->weight[0] == 1 && quad->weight[1] == 1);                   // balance, upright, height
+    CHECK_NEAR(rr[18], 2 * std::sqrt(2 * 9.81 * 0.3) / 9.81, 1e-12);                               // flight_time_
+  }
   TEST_MAIN_END();
 }

@@ -46,6 +46,8 @@ def lib():
         L.mjpc_planner_ilqg_set.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.mjpc_planner_ilqg_policy.argtypes = [vp, C.c_int, c_f64p, c_f64p, c_f64p, c_f64p]
         L.mjpc_planner_best_trajectory.argtypes = [vp, c_f64p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_double)]
+        L.mjpc_planner_task_transition.argtypes = [vp, C.c_double, C.c_int]
+        L.mjpc_planner_task_set_parameter.argtypes = [vp, C.c_int, C.c_double]
         L.mjpc_planner_destroy.argtypes = [vp]
         L.mjpc_planner_last_error.restype = C.c_char_p
         L.mjpc_planner_last_error.argtypes = [vp]
@@ -154,6 +156,12 @@ class HostPlanner:
 
     def optimize_policy(self, horizon):
         self._chk(lib().mjpc_planner_optimize(self.h, horizon))
+
+    def task_transition(self, time, mode=-1):
+        self._chk(lib().mjpc_planner_task_transition(self.h, float(time), int(mode)))
+
+    def task_set_parameter(self, index, value):
+        self._chk(lib().mjpc_planner_task_set_parameter(self.h, int(index), float(value)))
 
     def nominal_trajectory(self, horizon):
         self._chk(lib().mjpc_planner_nominal(self.h, horizon))

@@ -790,7 +790,13 @@ def save_blob(fm: FlatModel, path: str):
     put_i("sizes", [sc["nq"], sc["nv"], nu, sc["na"], sc["nbody"], sc["njnt"], sc["nsite"], sc["nmocap"],
                     sc["nuserdata"], nsens, fm.nuser_sensor, len(fm.numeric), len(fm.text), len(keys)])
     put_r("opt", [sc["timestep"], *sc["gravity"], sc["solver_tolerance"], sc["meaninertia"]])
-    put_i("opt_int", [sc["integrator"], sc["solver_iterations"], sc["disableflags"]])
+    put_i("opt_int", [sc["integrator"], sc["solver_iterations"], sc["disableflags"], sc.get("cone", 0), sc.get("ngeom", 0)])
+    put_r("opt_impratio", [sc.get("impratio", 1.0)])
+    for k in ("geom_type", "geom_bodyid", "geom_contype", "geom_conaffinity", "geom_condim", "geom_priority", "geom_group"):
+        put_i(k, a[k])
+    for k in ("geom_size", "geom_pos", "geom_quat", "geom_friction", "geom_solref", "geom_solimp", "geom_margin", "geom_gap",
+              "geom_solmix", "body_invweight0", "body_subtreemass", "dof_solref", "dof_solimp"):
+        put_r(k, a[k])
     for k in ("body_parentid", "body_rootid", "body_jntnum", "body_jntadr", "body_dofnum", "body_dofadr", "body_mocapid",
               "jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "dof_bodyid", "dof_jntid", "dof_parentid",
               "site_bodyid", "actuator_gaintype", "actuator_biastype"):
@@ -831,6 +837,7 @@ def save_blob(fm: FlatModel, path: str):
     put_i("name_bodyadr", name_table(fm.names["body"])); put_i("name_jntadr", name_table(fm.names["joint"]))
     put_i("name_siteadr", name_table(fm.names["site"])); put_i("name_sensoradr", name_table(fm.names["sensor"]))
     put_i("name_numericadr", name_table(list(fm.numeric.keys()))); put_i("name_keyadr", name_table([k[0] for k in keys]))
+    put_i("name_geomadr", name_table(fm.names.get("geom", [])))
     put_b("names", np.frombuffer(bytes(names) or b"\0", dtype=np.uint8))
     with open(path, "wb") as f:
         f.write(b"MJPXBLOB1\n")

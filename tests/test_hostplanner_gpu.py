@@ -63,6 +63,36 @@ def test_cpp_cross_entropy_equals_python_planner(particle):
     assert bt["total_return"] == pt.total_return and np.array_equal(bt["states"], pt.states[:H])
 
 
+def test_cpp_cross_entropy_on_the_quadruped_equals_python_planner():
+    """BASELINE configs[2] through the C++ host: mjpc::QuadrupedFlat (ResetLocked ids, Transition state, frozen residual
+    copy) + mjpc::GpuCrossEntropyPlanner on the wavefront-per-candidate kernel == the Python mirror, bit for bit."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.planners import GpuCrossEntropyPlanner, State
+    from mujoco_mpc_amd.task import load_task
+    t = load_task("QuadrupedFlat")
+    t.parameters[t.ids["gait"]] = 2.0  # Trot: exercises the gait switch in Transition (weights and parameters change)
+    t.transition(0.0)
+    H, N = 20, 128
+    cpp = HostPlanner(load_task("QuadrupedFlat"), seed=9, num_trajectory=N, kind="cross_entropy")
+    cpp.task_set_parameter(t.ids["gait"], 2.0)
+    cpp.task_transition(0.0)
+    cpp.reset(H)
+    py = GpuCrossEntropyPlanner(seed=9)
+    py.initialize(t.model, t); py.num_trajectory_ = N; py.n_elite_ = max(N // 10, 2); py.allocate(); py.reset(H)
+    st = State(t.model)
+    home = t.model.keyframes["home"]["qpos"]
+    mp = np.array([[0.3, 0, 0.26], [-2.5, 0, 0]]); mq = np.array([[1.0, 0, 0, 0], [1.0, 0, 0, 0]])
+    for k in range(2):
+        tm = 0.01 * k
+        st.set(home, np.zeros(18), mocap_pos=mp, mocap_quat=mq, time=tm); py.set_state(st); py.optimize_policy(H)
+        cpp.set_state(home, np.zeros(18), tm, mocap_pos=mp, mocap_quat=mq); cpp.optimize_policy(H)
+        assert list(cpp.ce_elites()) == py.trajectory_order
+        ct, cv = cpp.policy()
+        assert np.array_equal(ct, py.policy.plan.times()) and np.array_equal(cv, py.policy.plan.values())
+        assert cpp.improvement == py.improvement
+    assert "rollout_wave_kernel" in cpp.kernel_name
+
+
 @pytest.mark.parametrize("limits,reg", [(1, 0), (0, 2)])
 def test_cpp_ilqg_equals_python_planner(particle, limits, reg):
     """mjpc::GpuILQGPlanner (C++) against planners.GpuILQGPlanner (itself checked against the oracle backend in
