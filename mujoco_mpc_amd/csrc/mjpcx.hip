@@ -898,7 +898,6 @@ int mjpcx_best(mjpcx_ctx* c, int ref_candidate, int32_t* index, double* best_ret
   const size_t bytes = sizeof(BestRecord) + (size_t)np * 8;
   if (bytes > c->best_cap) {
     if (c->best_host) (void)hipHostFree(c->best_host);
-  c->wh.release();
     c->best_host = nullptr; c->best_cap = 0;
     HIPCHK(c, hipHostMalloc(&c->best_host, bytes, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer(&c->best_dev, c->best_host, 0));

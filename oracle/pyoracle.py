@@ -20,8 +20,8 @@ _LIB = None
 def build(force=False, fast=False):
     name = "liboracle_fast.so" if fast else "liboracle.so"
     so = os.path.join(_DIR, name)
-    if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", _DIR, "-s", name] + (["-B"] if force else []))
+    # always ask make: it rebuilds only when a source, an .inc or the C-ABI header is newer than the library
+    subprocess.check_call(["make", "-C", _DIR, "-s", name] + (["-B"] if force else []))
     return so
 
 

@@ -93,6 +93,26 @@ def test_cpp_cross_entropy_on_the_quadruped_equals_python_planner():
     assert "rollout_wave_kernel" in cpp.kernel_name
 
 
+def test_cpp_predictive_sampling_replans_on_the_quadruped():
+    """several plan iterations through mjpcx_best on a wave-kernel context (regression: the model allocation must
+    outlive the first policy update) -- the return of the winner keeps improving from a standing start"""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.task import load_task
+    t = load_task("QuadrupedFlat")
+    p = HostPlanner(t, seed=1, num_trajectory=64, kind="sampling")
+    p.task_transition(0.0)
+    H = t.planning_steps()
+    p.reset(H)
+    home = t.model.keyframes["home"]["qpos"]
+    mp = np.array([[0.3, 0, 0.26], [-2.5, 0, 0]]); mq = np.array([[1.0, 0, 0, 0], [1.0, 0, 0, 0]])
+    scores = []
+    for k in range(4):
+        p.set_state(home, np.zeros(18), 0.0, mocap_pos=mp, mocap_quat=mq)
+        p.optimize_policy(H)
+        scores.append(p.best_score)
+    assert all(np.isfinite(scores)) and scores[-1] < scores[0]
+
+
 @pytest.mark.parametrize("limits,reg", [(1, 0), (0, 2)])
 def test_cpp_ilqg_equals_python_planner(particle, limits, reg):
     """mjpc::GpuILQGPlanner (C++) against planners.GpuILQGPlanner (itself checked against the oracle backend in
