@@ -37,12 +37,14 @@ def parse():
     ap.add_argument("--candidates", type=int, default=4096, help="candidates per GPU")
     ap.add_argument("--horizon", type=int, default=128)
     ap.add_argument("--precision", type=int, default=64, choices=[32, 64])
+    ap.add_argument("--planner", default="sampling", choices=["sampling", "cross_entropy"],
+                    help="host planner driving the hot path (cross_entropy: BASELINE configs[2] with --task QuadrupedFlat)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
 
-def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call):
+def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=None, interp=None):
     """Times the CPU oracle (a port, NOT MuJoCo) driven through the reference's fan-out structure
     (one task per candidate, one physics arena per worker thread; sampling/planner.cc:355-393) on the
     GPU box's host cores. The thread count is the best of a short probe over {all, 1/2, 1/4, 1/8} of the
@@ -54,12 +56,12 @@ def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call):
     dt = task.model.get_number("agent_timestep", task.model.timestep)
     times = np.array([k * (horizon - 1) * dt / (num_nodes - 1) for k in range(num_nodes)])
     rng = np.random.default_rng(0)
-    nodes = np.clip(rng.normal(0, 0.5, (n_per_call, num_nodes, task.model.nu)), -1, 1)
+    nodes = np.clip(rng.normal(0, task.model.get_number("sampling_exploration", 0.5), (n_per_call, num_nodes, task.model.nu)), -1, 1)
 
     def run(n, threads):
         t0 = time.perf_counter()
-        pyoracle.rollout_batch_fast(pm, pt, state, 0.0, None, n, horizon, num_nodes, capi.SPLINE_CUBIC, times, nodes[:n],
-                                    num_threads=threads)
+        pyoracle.rollout_batch_fast(pm, pt, state, 0.0, mocap, n, horizon, num_nodes, capi.SPLINE_CUBIC if interp is None else interp,
+                                    times, nodes[:n], num_threads=threads)
         return n / (time.perf_counter() - t0)
 
     run(64, 1)
@@ -115,7 +117,9 @@ def main():
     H = args.horizon
     planner = HostPlanner(task, device=local_rank, precision=args.precision, seed=0,
                           num_trajectory=args.candidates * world,  # lifts kMaxTrajectory = 128
-                          group=group)
+                          group=group, kind=args.planner)
+    if hasattr(task, "transition"):
+        planner.task_transition(0.0)
     planner.reset(H)
     P = planner.num_spline_points
 
@@ -123,7 +127,13 @@ def main():
     home = model.keyframes.get("home")
     qpos = home["qpos"] if home else model.qpos0
     qvel = home["qvel"] if home else np.zeros(model.nv)
-    planner.set_state(qpos, qvel, 0.0)
+    mocap_pos = mocap_quat = None
+    if model.nmocap:  # mocap bodies at their model pose (State::Reset)
+        ids = [b for b in range(model.nbody) if model.arrays["body_mocapid"][b] >= 0]
+        ids.sort(key=lambda b: model.arrays["body_mocapid"][b])
+        mocap_pos = np.array([model.arrays["body_pos"][b] for b in ids])
+        mocap_quat = np.array([model.arrays["body_quat"][b] for b in ids])
+    planner.set_state(qpos, qvel, 0.0, mocap_pos=mocap_pos, mocap_quat=mocap_quat)
 
     def step():
         planner.optimize_policy(H)
@@ -160,10 +170,12 @@ def main():
             "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.task} Predictive Sampling, {args.candidates} candidates/GPU, horizon {H}, "
-                                   f"{P} cubic spline points, fp{args.precision} (BASELINE.json configs[1])",
+            "config": {"workload": (f"{args.task} Predictive Sampling, {args.candidates} candidates/GPU, horizon {H}, "
+                                    f"{P} cubic spline points, fp{args.precision} (BASELINE.json configs[1])") if args.planner == "sampling" else
+                                   (f"{args.task} Cross-Entropy, {args.candidates} candidates/GPU, horizon {H}, {P} zero-order spline "
+                                    f"points, fp{args.precision} (BASELINE.json configs[2] at --task QuadrupedFlat --candidates 16384 --horizon 100)"),
                        "candidates_per_gpu": args.candidates, "horizon": H, "spline_points": P,
-                       "parallelism": f"candidates sharded over {world} rank(s)", "kernel": planner.kernel_name, "host": "C++ mjpc::GpuSamplingPlanner over the C ABI"},
+                       "parallelism": f"candidates sharded over {world} rank(s)", "kernel": planner.kernel_name, "host": ("C++ mjpc::GpuSamplingPlanner" if args.planner == "sampling" else "C++ mjpc::GpuCrossEntropyPlanner") + " over the C ABI"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": avg_kernel_s * 1e3, "bytes_per_launch": bytes_per_launch,
@@ -183,7 +195,9 @@ def main():
             # same workload (model, horizon, spline), batch enlarged so that every host thread has
             # >= 64 rollouts per fan-out and thread start-up does not dominate the CPU number
             n_cpu = max(args.candidates, 64 * (os.cpu_count() or 1))
-            out["cpu_baseline"] = cpu_baseline(task, st, H, P, args.cpu_seconds, n_cpu)
+            out["cpu_baseline"] = cpu_baseline(task, st, H, P, args.cpu_seconds, n_cpu,
+                                               mocap=None if mocap_pos is None else np.hstack([mocap_pos, mocap_quat]).reshape(-1),
+                                               interp=capi.SPLINE_CUBIC if args.planner == "sampling" else capi.SPLINE_ZERO)
         print(json.dumps(out), flush=True)
     if group is not None:
         group.barrier()
