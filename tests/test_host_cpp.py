@@ -50,6 +50,11 @@ def test_gpu_sampling_planner_cpp(blobs):
 
 
 @pytest.mark.gpu
+def test_agent_cpp(blobs):
+    assert "OK" in run("agent_test", blobs)
+
+
+@pytest.mark.gpu
 def test_testspeed_app(blobs):
     out = run("testspeed_app", "--task=Cartpole", "--total_time=0.5", "--steps_per_planning_iteration=4",
               f"--model_dir={blobs}", "--candidates=4096")
