@@ -317,7 +317,7 @@ struct mjpcx_ctx {
   // pinned + device-mapped result record of mjpcx_best
   void* best_host = nullptr; void* best_dev = nullptr; size_t best_cap = 0;
   // rollout buffers
-  DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out, d_simt;
+  DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out, d_simt, d_wblob;
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
   int N = 0, H = 0, P = 0;  // shape of the last rollout
   bool have_rollout = false;
@@ -789,7 +789,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   }
   if (c->best_host) (void)hipHostFree(c->best_host);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_simt,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_simt, &c->d_wblob,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();
@@ -1171,6 +1171,96 @@ int do_transition_fd(mjpcx_ctx* c, int Tn, const double* times, const double* st
 }
 }  // namespace
 
+namespace {
+// per-plan task blob of a wave context on the device (not the Predictive-Sampling hot path: pageable copy)
+int wave_blob(mjpcx_ctx* c, WaveTask* wt) {
+  c->blob_scratch.resize(c->wh.blob_bytes);
+  c->wh.fill_blob(c->blob_scratch.data());
+  HIPCHK(c, c->d_wblob.reserve(c->wh.blob_bytes));
+  HIPCHK(c, hipMemcpyAsync(c->d_wblob.p, c->blob_scratch.data(), c->wh.blob_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *wt = c->wh.t;
+  wt->blob = (const double*)c->d_wblob.p;
+  wt->stamps = nullptr;
+  return MJPCX_OK;
+}
+size_t wave_lds_bytes(const mjpcx_ctx* c, int P) {
+  const WaveModel& wm = c->wh.m;
+  return (8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, c->wh.t.nr, c->wh.t.nterm, P) + 15) & ~(size_t)15;
+}
+
+int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
+                     const double* states, const double* actions, const double* gains, const double* improvement, const double* alpha) {
+  int rc;
+  if ((rc = reserve_rollout(c, N, H, 1)) != MJPCX_OK) return rc;
+  const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu;
+  std::vector<double*> d;
+  if ((rc = upload_arrays<double>(c, c->d_ilqg, {{times, (size_t)Tn}, {states, Tn * ds}, {actions, Tn * nu}, {gains, Tn * nu * ndx},
+                                                 {improvement, Tn * nu}, {alpha, (size_t)N}}, &d)) != MJPCX_OK) return rc;
+  WaveTask wt;
+  if ((rc = wave_blob(c, &wt)) != MJPCX_OK) return rc;
+  RolloutArgs<double> a{};
+  a.N = N; a.H = H; a.P = 1; a.interp = 0; a.nodes = (double*)c->d_nodes.p; a.noise.mode = -1;
+  a.states = (double*)c->d_states.p; a.actions = (double*)c->d_actions.p; a.times = (double*)c->d_times.p;
+  a.residual = (double*)c->d_residual.p; a.costs = (double*)c->d_costs.p; a.trace = (double*)c->d_trace.p;
+  a.total_return = (double*)c->d_ret.p; a.failure = (int*)c->d_fail.p;
+  FeedbackWaveArgs fb{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state};
+  const int Ppolicy = (int)((ndx + 2 * ds + nu - 1) / nu + 1);
+  const size_t lds = wave_lds_bytes(c, Ppolicy);
+  auto kern = c->wh.m.nv <= 20 ? rollout_feedback_wave_kernel<20> : rollout_feedback_wave_kernel<32>;
+  HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, c->wh.m, wt, a, fb);
+  HIPCHK(c, hipGetLastError());
+  c->N = N; c->H = H; c->P = 1;
+  c->have_rollout = true;
+  return MJPCX_OK;
+}
+
+int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const double* states, const double* actions, double eps,
+                          int centered, double* A, double* B, double* C, double* D) {
+  int rc;
+  const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu, nr = c->nr;
+  const size_t nc = 1 + 2 * (ndx + nu);
+  std::vector<double*> d;
+  std::vector<double> cr(c->ctrlrange);
+  if ((rc = upload_arrays<double>(c, c->d_ilqg, {{times, (size_t)Tn}, {states, Tn * ds}, {actions, Tn * nu}, {cr.data(), 2 * nu}}, &d)) != MJPCX_OK)
+    return rc;
+  WaveTask wt;
+  if ((rc = wave_blob(c, &wt)) != MJPCX_OK) return rc;
+  // outputs: raw next [Tn][nc][ds], tangent next [Tn][nc][ndx], sensor [Tn][nc][nr], ctrllimited (int), then A,B,C,D
+  const size_t off_tan = (Tn * nc * ds * 8 + 15) & ~(size_t)15;
+  const size_t off_sensor = (off_tan + Tn * nc * ndx * 8 + 15) & ~(size_t)15;
+  const size_t off_lim = (off_sensor + Tn * nc * nr * 8 + 15) & ~(size_t)15;
+  const size_t off_A = (off_lim + nu * sizeof(int) + 15) & ~(size_t)15;
+  const size_t nA = Tn * ndx * ndx, nB = Tn * ndx * nu, nC = Tn * nr * ndx, nD = Tn * nr * nu;
+  HIPCHK(c, c->d_ilqg_out.reserve(off_A + (nA + nB + nC + nD) * 8));
+  char* base = (char*)c->d_ilqg_out.p;
+  HIPCHK(c, hipMemcpyAsync(base + off_lim, c->ctrllimited.data(), nu * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  FdWaveArgs f{d[0], d[1], d[2], Tn, (int)nc, eps, (double*)base, (double*)(base + off_sensor)};
+  const size_t lds = wave_lds_bytes(c, 1);
+  auto kern = c->wh.m.nv <= 20 ? transition_fd_wave_kernel<20> : transition_fd_wave_kernel<32>;
+  HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(Tn * nc)), dim3(64), lds, c->stream, c->wh.m, wt, f);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(fd_tangent_kernel, dim3((unsigned)std::min<size_t>((Tn * nc + 63) / 64, 1024)), dim3(64), 0, c->stream, c->wh.m,
+                     (const double*)base, (double*)(base + off_tan), Tn, (int)nc);
+  HIPCHK(c, hipGetLastError());
+  double* dA = (double*)(base + off_A);
+  double *dB = dA + nA, *dC = dB + nB, *dD = dC + nC;
+  const int total = (int)(Tn * (ndx + nr) * (ndx + nu));
+  hipLaunchKernelGGL((fd_assemble_kernel<double>), dim3(std::min((total + 255) / 256, 1024)), dim3(256), 0, c->stream,
+                     (const double*)(base + off_tan), (const double*)(base + off_sensor), (const double*)d[2], (const double*)d[3],
+                     (const int*)(base + off_lim), Tn, (int)ndx, (int)nu, (int)nr, eps, centered, dA, dB, dC, dD);
+  HIPCHK(c, hipGetLastError());
+  if (A) HIPCHK(c, hipMemcpyAsync(A, dA, nA * 8, hipMemcpyDeviceToHost, c->stream));
+  if (B) HIPCHK(c, hipMemcpyAsync(B, dB, nB * 8, hipMemcpyDeviceToHost, c->stream));
+  if (C) HIPCHK(c, hipMemcpyAsync(C, dC, nC * 8, hipMemcpyDeviceToHost, c->stream));
+  if (D) HIPCHK(c, hipMemcpyAsync(D, dD, nD * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int mjpcx_rollout_feedback(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn,
@@ -1181,9 +1271,10 @@ int mjpcx_rollout_feedback(mjpcx_ctx* c, int N, int H, int mode, int representat
   if (mode == 0 && H > Tn) return fail(c, MJPCX_EINVAL, "index policy needs a nominal trajectory at least as long as the horizon");
   if (mode != 0 && mode != 1) return fail(c, MJPCX_EINVAL, "unknown feedback policy mode");
   if (mode == 1 && representation != 0 && representation != 1) return fail(c, MJPCX_EUNSUPPORTED, "only zero-order / linear iLQG policy representations are implemented");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->wave) return do_feedback_wave(c, N, H, mode, representation, use_state, Tn, times, states, actions, gains, improvement, alpha);
   const size_t shmem = (size_t)Tn * (1 + 2 * c->nv + 2 * c->nu + c->nu * 2 * c->nv) * esize(c);
   if (shmem > 120 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "nominal trajectory too large for the LDS stage");
-  HIPCHK(c, hipSetDevice(c->device));
   return c->precision == 64 ? do_feedback<double>(c, N, H, mode, representation, use_state, Tn, times, states, actions, gains, improvement, alpha)
                             : do_feedback<float>(c, N, H, mode, representation, use_state, Tn, times, states, actions, gains, improvement, alpha);
 }
@@ -1193,6 +1284,7 @@ int mjpcx_transition_fd(mjpcx_ctx* c, int Tn, const double* times, const double*
   if (!c || !times || !states || !actions) return fail(c, MJPCX_EINVAL, "null argument");
   if (Tn < 1 || !(eps > 0)) return fail(c, MJPCX_EINVAL, "bad horizon or epsilon");
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->wave) return do_transition_fd_wave(c, Tn, times, states, actions, eps, centered, A, B, C, D);
   return c->precision == 64 ? do_transition_fd<double>(c, Tn, times, states, actions, eps, centered, A, B, C, D)
                             : do_transition_fd<float>(c, Tn, times, states, actions, eps, centered, A, B, C, D);
 }
@@ -1205,11 +1297,12 @@ int mjpcx_cost_derivatives(mjpcx_ctx* c, int T, const double* residual, const do
   HIPCHK(c, hipSetDevice(c->device));
   const size_t ndx = 2 * (size_t)c->nv, nu = c->nu, nr = c->nr;
   CostSpec cs{};
-  cs.num_term = c->nterm; cs.num_residual = c->nr; cs.risk = c->ht64.risk;
+  cs.num_term = c->nterm; cs.num_residual = c->nr; cs.risk = c->wave ? c->wh.risk : c->ht64.risk;
   for (int k = 0; k < c->nterm; k++) {
     if (c->dim_norm_residual[k] > 32) return fail(c, MJPCX_EUNSUPPORTED, "cost term wider than 32 residuals");
-    cs.dim[k] = c->dim_norm_residual[k]; cs.norm[k] = c->ht64.norm[k]; cs.weight[k] = c->ht64.weight[k];
-    cs.p[k] = c->ht64.norm_p[k]; cs.q[k] = c->ht64.norm_q[k];
+    cs.dim[k] = c->dim_norm_residual[k];
+    if (c->wave) { cs.norm[k] = c->wh.norm_types[k]; cs.weight[k] = c->wh.weight[k]; cs.p[k] = c->wh.norm_p[k]; cs.q[k] = c->wh.norm_q[k]; }
+    else { cs.norm[k] = c->ht64.norm[k]; cs.weight[k] = c->ht64.weight[k]; cs.p[k] = c->ht64.norm_p[k]; cs.q[k] = c->ht64.norm_q[k]; }
   }
   std::vector<double*> d;
   int rc;

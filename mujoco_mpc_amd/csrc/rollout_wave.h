@@ -294,3 +294,5 @@ __device__ __noinline__ double w_norm_value(const double* x, int n, int type, do
 #include "wave_forward.h"
 #include "wave_residual.h"
 #include "wave_kernel.h"
+#include "ilqg_kernels.h"  // find_interval, fd_assemble_kernel
+#include "wave_ilqg.h"

@@ -22,6 +22,38 @@ __host__ __device__ inline size_t wave_lds_doubles(int nq, int nv, int nu, int n
   return n + 16;
 }
 
+// the LDS layout of one candidate's mjData (shared by the rollout, feedback-rollout and finite-difference kernels)
+__device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WaveModel& m, const WaveTask& tk, int P, double*& lnodes,
+                                               double*& ltimes) {
+  const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
+  double* p = reinterpret_cast<double*>(smem_raw);
+  auto take = [&](size_t n) { double* q = p; p += n; return q; };
+  WaveData d;
+  d.qpos = take(nq); d.qvel = take(nv); d.ctrl = take(nu);
+  d.xpos = take(3 * nb); d.xquat = take(4 * nb); d.xmat = take(9 * nb); d.xipos = take(3 * nb); d.ximat = take(9 * nb);
+  d.xanchor = take(3 * nj); d.xaxis = take(3 * nj); d.site_xpos = take(3 * ns);
+  d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.crb = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
+  d.cvel = take(6 * nb); d.cacc = take(6 * nb); d.cfrc = take(6 * nb); d.cfrc_sub = take(6 * nb); d.subtree_linvel = take(3);
+  d.M = take((size_t)nv * nv); d.L = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = take(nv);
+  d.qfrc_passive = take(nv); d.qfrc_bias = take(nv); d.qfrc_actuator = take(nv); d.qfrc_smooth = take(nv);
+  d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
+  d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = take(nv); d.tmpv = take(nv); d.qacc_warm = take(nv);
+  d.efc_J = take((size_t)kWaveMaxEfc * nv);
+  d.efc_pos = take(kWaveMaxEfc); d.efc_margin = take(kWaveMaxEfc); d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
+  d.efc_aref = take(kWaveMaxEfc); d.efc_floss = take(kWaveMaxEfc); d.efc_force = take(kWaveMaxEfc); d.jar = take(kWaveMaxEfc);
+  d.jv = take(kWaveMaxEfc);
+  take(kWaveMaxEfc);  // spare
+  int* ip = reinterpret_cast<int*>(take((3 * kWaveMaxEfc + 1) / 2 + 1));
+  d.efc_type = ip; d.efc_id = ip + kWaveMaxEfc; d.efc_zone = ip + 2 * kWaveMaxEfc;
+  d.coneH = take(36 * kWaveMaxCon); d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
+  d.con = reinterpret_cast<WaveContact*>(take((sizeof(WaveContact) * kWaveMaxCon + 7) / 8));
+  d.counters = reinterpret_cast<int*>(take(4));
+  lnodes = take((size_t)P * nu);  // [P][nu]
+  ltimes = take(P);
+
+  return d;
+}
+
 template <int NMAX>
 __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_global, const WaveTask tk_global, const RolloutArgs<double> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -55,31 +87,8 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_glob
   const int P = a.P, H = a.H;
   const size_t N = (size_t)a.N;
   // ---- LDS carve
-  double* p = reinterpret_cast<double*>(smem_raw);
-  auto take = [&](size_t n) { double* q = p; p += n; return q; };
-  WaveData d;
-  d.qpos = take(nq); d.qvel = take(nv); d.ctrl = take(nu);
-  d.xpos = take(3 * nb); d.xquat = take(4 * nb); d.xmat = take(9 * nb); d.xipos = take(3 * nb); d.ximat = take(9 * nb);
-  d.xanchor = take(3 * nj); d.xaxis = take(3 * nj); d.site_xpos = take(3 * ns);
-  d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.crb = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
-  d.cvel = take(6 * nb); d.cacc = take(6 * nb); d.cfrc = take(6 * nb); d.cfrc_sub = take(6 * nb); d.subtree_linvel = take(3);
-  d.M = take((size_t)nv * nv); d.L = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = take(nv);
-  d.qfrc_passive = take(nv); d.qfrc_bias = take(nv); d.qfrc_actuator = take(nv); d.qfrc_smooth = take(nv);
-  d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
-  d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = take(nv); d.tmpv = take(nv); d.qacc_warm = take(nv);
-  d.efc_J = take((size_t)kWaveMaxEfc * nv);
-  d.efc_pos = take(kWaveMaxEfc); d.efc_margin = take(kWaveMaxEfc); d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
-  d.efc_aref = take(kWaveMaxEfc); d.efc_floss = take(kWaveMaxEfc); d.efc_force = take(kWaveMaxEfc); d.jar = take(kWaveMaxEfc);
-  d.jv = take(kWaveMaxEfc);
-  take(kWaveMaxEfc);  // spare
-  int* ip = reinterpret_cast<int*>(take((3 * kWaveMaxEfc + 1) / 2 + 1));
-  d.efc_type = ip; d.efc_id = ip + kWaveMaxEfc; d.efc_zone = ip + 2 * kWaveMaxEfc;
-  d.coneH = take(36 * kWaveMaxCon); d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
-  d.con = reinterpret_cast<WaveContact*>(take((sizeof(WaveContact) * kWaveMaxCon + 7) / 8));
-  d.counters = reinterpret_cast<int*>(take(4));
-  double* lnodes = take((size_t)P * nu);  // [P][nu]
-  double* ltimes = take(P);
-
+  double* lnodes; double* ltimes;
+  WaveData d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes);
   // ---- candidate spline nodes (SamplingPlanner / CrossEntropyPlanner::AddNoiseToPolicy, as rollout_lane_kernel)
   for (int q = lane; q < P; q += 64) ltimes[q] = a.node_times[q];
   const int np = P * nu;

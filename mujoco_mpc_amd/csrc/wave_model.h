@@ -86,7 +86,7 @@ struct WaveHost {
   void* dev = nullptr;  // the model allocation
   size_t blob_doubles = 0, blob_bytes = 0;
   std::vector<double> state, mocap, weight, norm_p, norm_q, parameters, residual_real;
-  std::vector<int32_t> residual_int;
+  std::vector<int32_t> residual_int, norm_types;
   double time = 0, risk = 0;
 
   void release() { if (dev) (void)hipFree(dev); dev = nullptr; }
@@ -212,6 +212,7 @@ struct WaveHost {
         for (int k = 0; k < 4; k++) mocap[7 * src->body_mocapid[b] + 3 + k] = src->body_quat[4 * b + k];
       }
     weight.assign(task->weight, task->weight + task->num_term);
+    norm_types.assign(task->norm, task->norm + task->num_term);
     norm_p.assign(task->num_term, 0.0); norm_q.assign(task->num_term, 0.0);
     parameters.assign(task->parameters, task->parameters + task->num_parameter);
     residual_real.assign(task->residual_real, task->residual_real + task->num_residual_real);

@@ -13,7 +13,73 @@
 #include <string.h>
 #include "oracle.h"
 
-/* ---- one perturbed mj_step: next state (nq==nv models: plain difference space) + residual ---- */
+/* ---- quaternion helpers for the tangent-space state difference (mj_differentiatePos / mj_integratePos) ---- */
+static void iq_mul(double* r, const double* a, const double* b) {
+  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+/* res(3) = rotation vector taking qb to qa, expressed in qb's frame (mju_subQuat) */
+static void iq_sub(double* res, const double* qa, const double* qb) {
+  const double qn[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
+  double qd[4];
+  iq_mul(qd, qn, qa);
+  double ax[3] = {qd[1], qd[2], qd[3]};
+  const double s = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  if (s > 1e-15) for (int k = 0; k < 3; k++) ax[k] /= s;
+  double speed = 2 * atan2(s, qd[0]);
+  if (speed > 3.14159265358979323846) speed -= 2 * 3.14159265358979323846;
+  for (int k = 0; k < 3; k++) res[k] = ax[k] * speed;
+}
+/* q <- q * exp(v h / 2) (mju_quatIntegrate) */
+static void iq_integrate(double* q, const double* v, double h) {
+  double ax[3] = {v[0], v[1], v[2]};
+  const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  if (n < 1e-15) { ax[0] = 1; ax[1] = ax[2] = 0; } else for (int k = 0; k < 3; k++) ax[k] /= n;
+  const double a = 0.5 * h * n;
+  const double qr[4] = {cos(a), ax[0] * sin(a), ax[1] * sin(a), ax[2] * sin(a)};
+  double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (nq < 1e-15) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else for (int k = 0; k < 4; k++) q[k] /= nq;
+  iq_mul(q, q, qr);
+}
+/* StateDiff (mjpc/utilities.cc:543-553): dx = (s2 - s1) / h in the tangent space: mj_differentiatePos for the
+ * positions, plain differences for velocities. dx has 2 nv entries. */
+void ostate_diff(const mjpcx_model* m, double* dx, const double* s1, const double* s2, double h) {
+  const int nq = m->nq, nv = m->nv;
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    switch (m->jnt_type[j]) {
+      case MJPCX_JNT_FREE:
+        for (int k = 0; k < 3; k++) dx[da + k] = (s2[qa + k] - s1[qa + k]) / h;
+        qa += 3; da += 3;
+        /* fallthrough */
+      case MJPCX_JNT_BALL: {
+        double r[3];
+        iq_sub(r, s2 + qa, s1 + qa);
+        for (int k = 0; k < 3; k++) dx[da + k] = r[k] / h;
+        break;
+      }
+      default: dx[da] = (s2[qa] - s1[qa]) / h;
+    }
+  }
+  for (int i = 0; i < nv; i++) dx[nv + i] = (s2[nq + i] - s1[nq + i]) / h;
+}
+/* x_out = x with tangent coordinate j (< 2 nv) moved by eps (mj_integratePos for positions) */
+static void state_perturb(const mjpcx_model* m, double* xo, const double* x, int j, double eps) {
+  const int nq = m->nq, nv = m->nv;
+  memcpy(xo, x, sizeof(double) * (nq + nv));
+  if (j >= nv) { xo[nq + j - nv] += eps; return; }
+  const int jn = m->dof_jntid[j], qa = m->jnt_qposadr[jn], da = m->jnt_dofadr[jn], t = m->jnt_type[jn];
+  if (t == MJPCX_JNT_FREE && j - da < 3) xo[qa + (j - da)] += eps;
+  else if (t == MJPCX_JNT_FREE || t == MJPCX_JNT_BALL) {
+    double v[3] = {0, 0, 0};
+    const int qq = t == MJPCX_JNT_FREE ? qa + 3 : qa, k = t == MJPCX_JNT_FREE ? j - da - 3 : j - da;
+    v[k] = 1;
+    iq_integrate(xo + qq, v, eps);
+  } else xo[qa] += eps;
+}
+
+/* ---- one perturbed mj_step: next state + residual ---- */
 static void fd_step(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state, double time,
                     const double* ctrl, double* next, double* sensor) {
   odata_set_state(d, state, time, NULL, NULL);
@@ -27,17 +93,36 @@ static int in_range(double a, double b, const double* range) {
   return a >= range[0] && a <= range[1] && b >= range[0] && b <= range[1];
 }
 
-/* A: ndx x ndx, B: ndx x nu, C: nr x ndx, D: nr x nu (row-major); any may be NULL. Slide/hinge models only
- * (nq == nv), which is all the device path covers. Mocap pose must already be set on `d`. */
+/* A: ndx x ndx, B: ndx x nu, C: nr x ndx, D: nr x nu (row-major, ndx = 2 nv); any may be NULL. Positions are perturbed and
+ * differenced in the tangent space (mj_integratePos / mj_differentiatePos), so quaternion joints are covered.
+ * Mocap pose must already be set on `d`. */
+/* tangent coordinates (2 nv) of a state y for differencing: scalar joints, free-joint translations and velocities keep
+ * their raw values (so differences of them are plain subtractions); a quaternion is represented by its rotation
+ * vector relative to the same joint's quaternion in `y0` (mj_differentiatePos of that joint against y0) */
+static void state_tangent(const mjpcx_model* m, double* z, const double* y, const double* y0) {
+  const int nq = m->nq, nv = m->nv;
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    switch (m->jnt_type[j]) {
+      case MJPCX_JNT_FREE:
+        for (int k = 0; k < 3; k++) z[da + k] = y[qa + k];
+        qa += 3; da += 3;
+        /* fallthrough */
+      case MJPCX_JNT_BALL: iq_sub(z + da, y + qa, y0 + qa); break;
+      default: z[da] = y[qa];
+    }
+  }
+  for (int i = 0; i < nv; i++) z[nv + i] = y[nq + i];
+}
+
 int otransition_fd(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state, double time,
                    const double* ctrl, double eps, int centered, double* A, double* B, double* C, double* D) {
-  if (m->nq != m->nv) return -1;
-  const int nv = m->nv, nu = m->nu, ndx = 2 * nv, nr = task->num_residual;
-  double* w = (double*)malloc(sizeof(double) * (size_t)(3 * ndx + 3 * nr + ndx + nu));
-  double *y0 = w, *yp = y0 + ndx, *ym = yp + ndx, *s0 = ym + ndx, *sp = s0 + nr, *sm = sp + nr, *x = sm + nr, *u = x + ndx;
+  const int nq = m->nq, nv = m->nv, nu = m->nu, ndx = 2 * nv, ds = nq + nv, nr = task->num_residual;
+  double* w = (double*)malloc(sizeof(double) * (size_t)(3 * ds + 3 * nr + nu + 3 * ndx));
+  double *y0 = w, *yq = y0 + ds, *x = yq + ds, *s0 = x + ds, *sp = s0 + nr, *sm = sp + nr, *u = sm + nr, *z0 = u + nu, *zp = z0 + ndx, *zm = zp + ndx;
   fd_step(m, task, d, state, time, ctrl, y0, s0);
+  state_tangent(m, z0, y0, y0);
   for (int j = 0; j < ndx + nu; j++) {
-    memcpy(x, state, sizeof(double) * ndx);
     memcpy(u, ctrl, sizeof(double) * nu);
     int fwd = 1, back = centered != 0;
     if (j >= ndx) {
@@ -49,17 +134,18 @@ int otransition_fd(const mjpcx_model* m, const mjpcx_task* task, OData* d, const
       }
     }
     if (fwd) {
-      if (j < ndx) x[j] = state[j] + eps; else u[j - ndx] = ctrl[j - ndx] + eps;
-      fd_step(m, task, d, x, time, u, yp, sp);
+      if (j < ndx) state_perturb(m, x, state, j, eps); else { memcpy(x, state, sizeof(double) * ds); u[j - ndx] = ctrl[j - ndx] + eps; }
+      fd_step(m, task, d, x, time, u, yq, sp);
+      state_tangent(m, zp, yq, y0);
     }
     if (back) {
-      memcpy(x, state, sizeof(double) * ndx);
       memcpy(u, ctrl, sizeof(double) * nu);
-      if (j < ndx) x[j] = state[j] - eps; else u[j - ndx] = ctrl[j - ndx] - eps;
-      fd_step(m, task, d, x, time, u, ym, sm);
+      if (j < ndx) state_perturb(m, x, state, j, -eps); else { memcpy(x, state, sizeof(double) * ds); u[j - ndx] = ctrl[j - ndx] - eps; }
+      fd_step(m, task, d, x, time, u, yq, sm);
+      state_tangent(m, zm, yq, y0);
     }
     for (int i = 0; i < ndx + nr; i++) {
-      const double v0 = i < ndx ? y0[i] : s0[i - ndx], vp = i < ndx ? yp[i] : sp[i - ndx], vm = i < ndx ? ym[i] : sm[i - ndx];
+      const double v0 = i < ndx ? z0[i] : s0[i - ndx], vp = i < ndx ? zp[i] : sp[i - ndx], vm = i < ndx ? zm[i] : sm[i - ndx];
       double dv = 0;
       if (fwd && back) dv = (vp - vm) / (2 * eps);
       else if (fwd) dv = (vp - v0) / eps;
@@ -156,7 +242,7 @@ static void fb_action(const FbPolicy* p, double* action, const double* state, do
   double dx[64], xi[64], K[64 * 16];
   if (p->mode == 0) {
     for (int k = 0; k < nu; k++) action[k] = p->actions[t * nu + k] + p->alpha * p->improvement[t * nu + k];
-    for (int j = 0; j < ndx; j++) dx[j] = state[j] - p->states[t * ds + j];
+    ostate_diff(m, dx, p->states + (size_t)t * ds, state, 1.0); /* StateDiff(model, dx, states[t], state, 1.0) */
     for (int k = 0; k < nu; k++) { double s = 0; for (int j = 0; j < ndx; j++) s += p->gains[(t * nu + k) * ndx + j] * dx[j]; action[k] += s; }
   } else {
     int b[2];
@@ -166,7 +252,15 @@ static void fb_action(const FbPolicy* p, double* action, const double* state, do
     if (p->use_state) {
       interp(xi, time, p->times, p->states, ds, p->Tn, zero);
       interp(K, time, p->times, p->gains, nu * ndx, p->Tn - 1, zero);
-      for (int j = 0; j < ndx; j++) dx[j] = state[j] - xi[j];
+      for (int j = 0; j < m->njnt; j++) { /* policy.cc:118-125: renormalise interpolated quaternions */
+        const int tj = m->jnt_type[j];
+        if (tj == MJPCX_JNT_FREE || tj == MJPCX_JNT_BALL) {
+          double* q = xi + m->jnt_qposadr[j] + (tj == MJPCX_JNT_FREE ? 3 : 0);
+          double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+          if (n < 1e-15) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else for (int k = 0; k < 4; k++) q[k] /= n;
+        }
+      }
+      ostate_diff(m, dx, xi, state, 1.0);
       for (int k = 0; k < nu; k++) { double s = 0; for (int j = 0; j < ndx; j++) s += K[k * ndx + j] * dx[j]; action[k] += p->alpha * s; }
     }
   }

@@ -114,6 +114,8 @@ int orollout_batch(const mjpcx_model* m, const mjpcx_task* task, const double* s
                    int num_threads, OBatchOut* out);
 
 /* ---------------- iLQG derivatives and feedback rollouts (oracle/ilqg.c) ---------------- */
+/* StateDiff (mjpc/utilities.cc:543-553): (s2 - s1) / h in the tangent space, 2 nv entries */
+void ostate_diff(const mjpcx_model* m, double* dx, const double* s1, const double* s2, double h);
 int otransition_fd(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state, double time,
                    const double* ctrl, double eps, int centered, double* A, double* B, double* C, double* D);
 void ocost_derivatives(const mjpcx_task* task, int T, int ndx, int nu, const double* r, const double* rx, const double* ru,

@@ -110,3 +110,66 @@ def test_cross_entropy_planner_on_the_quadruped(quad):
     nominal = p.best_trajectory()
     assert not nominal.failure and nominal.total_return < 1.5 * best[-1] + 0.05
     assert np.all(np.isfinite(p.policy.plan.values())) and np.all(np.isfinite(p.variance[:36]))
+
+
+# ---------------------------------------------------------------------------------- iLQG pieces on the A1 (configs[4])
+def nominal_quad(task, H, seed):
+    """a nominal trajectory from the oracle (zero-order spline rollout from the home keyframe)"""
+    pm, pt = task.packed_model(), task.packed()
+    rng = np.random.default_rng(seed)
+    home = task.model.keyframes["home"]["qpos"]
+    state = np.concatenate([home, np.zeros(18)])
+    times = np.arange(4) * (H - 1) * 0.01 / 3
+    nodes = np.clip(rng.normal(0, 0.15, (1, 4, 12)), -1, 1)
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, 1, H, 4, 1, times, nodes, num_threads=1)
+    return pm, pt, {k: v[0] for k, v in ref.items() if k not in ("total_return", "failure")}, state
+
+
+@pytest.mark.parametrize("centered", [0, 1])
+def test_transition_fd_on_the_quadruped(quad, centered):
+    """mjd_transitionFD with tangent-space perturbations (free joint) and contacts; the difference quotient amplifies the
+    ~1e-13 agreement of the two step functions by 1/eps = 1e6"""
+    H = 8
+    pm, pt, nom, state = nominal_quad(quad, H, 11)
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(state, 0.0, MOCAP)
+    A, B, C, D = ctx.transition_fd(nom["times"], nom["states"], nom["actions"], 1e-6, centered)
+    Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], 1e-6, centered, mocap=MOCAP)
+    assert A.shape == (H, 36, 36) and B.shape == (H, 36, 12) and C.shape == (H, 42, 36) and D.shape == (H, 42, 12)
+    for g, o in ((A, Ao), (B, Bo), (C, Co), (D, Do)):
+        assert close(g, o, 5e-6), float(np.abs(g - o).max())
+    # structure: d(next position)/d(velocity) = h on the free joint's translation; Effort residual = 0.02 * 40 * ctrl
+    assert np.allclose(A[0, 0:3, 18:21], 0.01 * np.eye(3), atol=1e-3)
+    assert np.allclose(D[0, 13:25, :], 0.8 * np.eye(12), atol=1e-5)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode,representation,use_state", [(0, 0, 1), (1, 1, 1), (1, 0, 0)])
+def test_rollout_feedback_on_the_quadruped(quad, mode, representation, use_state):
+    """RolloutDiscrete / iLQGPolicy::Action with StateDiff on the free joint's quaternion"""
+    H = 20
+    pm, pt, nom, state = nominal_quad(quad, H, 12)
+    rng = np.random.default_rng(13)
+    gains = 0.05 * rng.normal(size=(H, 12, 36))
+    improvement = 0.05 * rng.normal(size=(H, 12))
+    alpha = np.concatenate([np.exp(np.linspace(0, np.log(1e-3), 9)), [0.0]])
+    start = state.copy()
+    start[0:3] += [0.01, -0.005, 0.004]
+    q = start[3:7] + [0.0, 0.02, -0.01, 0.015]
+    start[3:7] = q / np.linalg.norm(q)                                             # off-nominal orientation: quaternion StateDiff matters
+    start[19:] = 0.05 * rng.normal(size=18)
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(start, 0.0, MOCAP)
+    ctx.rollout_feedback(H, mode, representation, use_state, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_feedback(pm, pt, start, 0.0, MOCAP, H, mode, representation, use_state, nom["times"], nom["states"],
+                                    nom["actions"], gains, improvement, alpha)
+    assert np.array_equal(fail, ref["failure"]) and not fail.any()
+    assert close(ret, ref["total_return"], 1e-7)
+    for c in (0, 4, 9):
+        tr = ctx.fetch_trajectory(c)
+        for name in ("states", "actions", "times", "residual", "costs"):
+            assert close(getattr(tr, name), ref[name][c], 1e-7), (name, c, float(np.abs(getattr(tr, name) - ref[name][c]).max()))
+    if use_state:
+        assert np.ptp(ret) > 1e-7
+    ctx.close()
