@@ -81,7 +81,7 @@ def as_i32p(a):
 class PackedModel:
     """Owns contiguous copies of the arrays an MjpcxModel struct points into."""
 
-    def __init__(self, fm, timestep=None, integrator=None):
+    def __init__(self, fm, timestep=None, integrator=None, differentiable=False):
         self.fm = fm
         self.keep = {}
         m = MjpcxModel()
@@ -97,7 +97,9 @@ class PackedModel:
                 self.keep[name] = arr
                 setattr(m, name, as_i32p(arr))
             elif ctype is c_f64p:
-                arr = np.ascontiguousarray(fm.arrays[name], dtype=np.float64).reshape(-1)
+                arr = np.array(fm.arrays[name], dtype=np.float64).reshape(-1)   # private copy
+                if differentiable and name in ("jnt_solimp", "geom_solimp") and arr.size:
+                    arr[0::5] = 0.0   # MakeDifferentiable, mjpc/utilities.cc:60-75: solimp[0] = 0
                 if arr.size == 0:
                     arr = np.zeros(1, np.float64)
                 self.keep[name] = arr

@@ -2,7 +2,7 @@
 
 namespace mjpc::gpu {
 
-FlatModel::FlatModel(const mjModel* m, double timestep, int integrator) {
+FlatModel::FlatModel(const mjModel* m, double timestep, int integrator, bool differentiable) {
   mjpcx_model& f = flat_;
   f.nq = m->nq; f.nv = m->nv; f.nu = m->nu; f.na = m->na; f.nbody = m->nbody; f.njnt = m->njnt;
   f.nsite = m->nsite; f.nmocap = m->nmocap; f.nuserdata = m->nuserdata;
@@ -56,6 +56,14 @@ FlatModel::FlatModel(const mjModel* m, double timestep, int integrator) {
   f.geom_margin = m->geom_margin; f.geom_gap = m->geom_gap; f.geom_solmix = m->geom_solmix;
   f.body_invweight0 = m->body_invweight0; f.body_subtreemass = m->body_subtreemass;
   f.dof_solref = m->dof_solref; f.dof_solimp = m->dof_solimp; f.key_qpos = m->key_qpos;
+  if (differentiable) {
+    jnt_solimp_.assign(m->jnt_solimp, m->jnt_solimp + (size_t)mjNIMP * m->njnt);
+    geom_solimp_.assign(m->geom_solimp, m->geom_solimp + (size_t)mjNIMP * m->ngeom);
+    for (int i = 0; i < m->njnt; i++) jnt_solimp_[(size_t)mjNIMP * i] = 0.0;
+    for (int i = 0; i < m->ngeom; i++) geom_solimp_[(size_t)mjNIMP * i] = 0.0;
+    f.jnt_solimp = jnt_solimp_.data();
+    if (m->ngeom) f.geom_solimp = geom_solimp_.data();
+  }
 }
 
 FlatTask::FlatTask(const Task& t) {
@@ -80,7 +88,7 @@ FlatTask::FlatTask(const Task& t) {
   flat_.residual_real = residual_real_.data();
 }
 
-Context::Context(const mjModel* model, const Task& task, int device, int precision) {
+Context::Context(const mjModel* model, const Task& task, int device, int precision, bool differentiable) {
   // the planning copy runs at agent_timestep / agent_integrator when the model defines them
   double timestep = model->opt.timestep;
   int integrator = model->opt.integrator;
@@ -89,7 +97,7 @@ Context::Context(const mjModel* model, const Task& task, int device, int precisi
     if (name == "agent_timestep") timestep = model->numeric_data[model->numeric_adr[i]];
     if (name == "agent_integrator") integrator = (int)model->numeric_data[model->numeric_adr[i]];
   }
-  FlatModel fm(model, timestep, integrator);
+  FlatModel fm(model, timestep, integrator, differentiable);
   FlatTask ft(task);
   const int rc = mjpcx_create(fm.get(), ft.get(), device, precision, &ctx_);
   if (rc != MJPCX_OK) throw Error(rc, std::string(mjpcx_error_string(rc)) + ": " + mjpcx_create_error());

@@ -23,13 +23,14 @@ class Error : public std::runtime_error {
 class FlatModel {
  public:
   // `timestep` / `integrator`: Agent::PlanIteration's overrides of the planning copy (agent.cc:288-291)
-  FlatModel(const mjModel* m, double timestep, int integrator);
+  // `differentiable`: MakeDifferentiable (utilities.cc:60-75) on the planning copy: solimp[0] = 0 for joints and geoms
+  FlatModel(const mjModel* m, double timestep, int integrator, bool differentiable = false);
   const mjpcx_model* get() const { return &flat_; }
 
  private:
   mjpcx_model flat_{};
   std::vector<int32_t> jnt_limited_, trnid_, ctrllimited_, forcelimited_;
-  std::vector<double> gear_, gainprm_, biasprm_;
+  std::vector<double> gear_, gainprm_, biasprm_, jnt_solimp_, geom_solimp_;
 };
 
 class FlatTask {
@@ -45,7 +46,7 @@ class FlatTask {
 
 class Context {
  public:
-  Context(const mjModel* model, const Task& task, int device, int precision = 64);
+  Context(const mjModel* model, const Task& task, int device, int precision = 64, bool differentiable = false);
   ~Context();
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;

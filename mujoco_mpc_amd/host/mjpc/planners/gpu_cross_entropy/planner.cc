@@ -179,6 +179,7 @@ void GpuCrossEntropyPlanner::NominalTrajectory(int horizon, ThreadPool& pool) {
   const TimeSpline& plan = resampled_policy.plan;
   std::vector<double> times(plan.times()), values(plan.values());
   if (times.empty()) { times.assign(1, time); values.assign(model->nu, 0.0); }
+  ctx_->SyncTask(*task);
   ctx_->Check(mjpcx_set_state(ctx_->handle(), state.data(), time, mocap.data(), userdata.data()));
   ctx_->Check(mjpcx_rollout_splines(ctx_->handle(), 1, horizon, (int)times.size(), (int)plan.Interpolation(),
                                     times.data(), values.data()));

@@ -29,7 +29,9 @@ void GpuILQGPlanner::Allocate() {
   userdata.resize(model->nuserdata);
   for (iLQGPolicy* p : {&policy, &previous_policy, &candidate_policy0, &winner_policy_})
     p->Allocate(model, *task, kMaxTrajectoryHorizon);
-  ctx_ = std::make_unique<gpu::Context>(model, *task, device_, precision_);
+  // gradient-based planners plan on the differentiable model copy unless agent_differentiable says otherwise (agent.cc:156-164)
+  const bool differentiable = GetNumberOrDefault(1, model, "agent_differentiable") != 0;
+  ctx_ = std::make_unique<gpu::Context>(model, *task, device_, precision_, differentiable);
 }
 
 // ilqg/planner.cc:116-153 + iLQGBackwardPass::Reset (backward_pass.cc:50-62)
@@ -104,6 +106,7 @@ void GpuILQGPlanner::NominalTrajectory(int horizon, ThreadPool& pool) {
   policy.trajectory.horizon = horizon;
   LineSearchSteps();
   const Trajectory& tr = policy.trajectory;
+  ctx_->SyncTask(*task);  // the per-plan frozen ResidualFn copy (agent.cc:319)
   ctx_->Check(mjpcx_set_state(ctx_->handle(), state.data(), time, mocap.data(), userdata.data()));
   ctx_->Check(mjpcx_rollout_feedback(ctx_->handle(), num_trajectory_, horizon, /*mode=*/1, policy.representation,
                                      settings.nominal_feedback_scaling, horizon, tr.times.data(), tr.states.data(),
@@ -175,6 +178,7 @@ void GpuILQGPlanner::Iteration(int horizon, ThreadPool& pool) {
   const int T = horizon, n = dim_state_derivative, m = dim_action;
   const double previous_return = tr.total_return;
   LineSearchSteps();
+  ctx_->SyncTask(*task);
 
   auto start = std::chrono::steady_clock::now();
   ModelDerivatives(tr, T);

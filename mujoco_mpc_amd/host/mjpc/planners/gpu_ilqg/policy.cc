@@ -46,6 +46,7 @@ void iLQGPolicy::Action(double* action, const double* state, double time) const 
   interp(action, trajectory.actions.data(), nu, H - 1);
   if (state) {
     interp(state_interp.data(), trajectory.states.data(), ds, H);
+    if (model->nq != model->nv) NormalizeStateQuaternions(model, state_interp.data());
     interp(feedback_gain_scratch.data(), feedback_gain.data(), nu * ndx, H - 1);
     StateDiff(model, state_scratch.data(), state_interp.data(), state, 1.0);
     for (int i = 0; i < nu; i++) {

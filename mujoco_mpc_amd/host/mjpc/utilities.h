@@ -82,10 +82,41 @@ inline void LogScale(double* values, double max_value, double min_value, int ste
   const double step = (std::log(max_value) - std::log(min_value)) / (steps > 1 ? steps - 1 : 1);
   for (int i = 0; i < steps; i++) values[i] = std::exp(std::log(min_value) + i * step);
 }
-// state difference for models without quaternion joints (nq == nv), utilities.cc:543-553
+// StateDiff (utilities.cc:543-553): dx = (s2 - s1) / h in the tangent space: mj_differentiatePos for the positions
+// (free-joint translations and scalar joints subtract; quaternions give the rotation vector of q1^-1 q2), velocities
+// subtract. dx has 2 nv + na entries.
 inline void StateDiff(const mjModel* m, double* dx, const double* s1, const double* s2, double h) {
-  const int n = m->nq + m->nv + m->na;  // == 2 nv + na
-  for (int i = 0; i < n; i++) dx[i] = (s2[i] - s1[i]) / h;
+  const int nq = m->nq, nv = m->nv;
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    const int t = m->jnt_type[j];
+    if (t == mjJNT_FREE) { for (int k = 0; k < 3; k++) dx[da + k] = (s2[qa + k] - s1[qa + k]) / h; qa += 3; da += 3; }
+    if (t == mjJNT_FREE || t == mjJNT_BALL) {  // mju_subQuat + mju_quat2Vel
+      const double* b = s1 + qa; const double* a = s2 + qa;
+      const double n[4] = {b[0], -b[1], -b[2], -b[3]};
+      const double qd[4] = {n[0] * a[0] - n[1] * a[1] - n[2] * a[2] - n[3] * a[3], n[0] * a[1] + n[1] * a[0] + n[2] * a[3] - n[3] * a[2],
+                            n[0] * a[2] - n[1] * a[3] + n[2] * a[0] + n[3] * a[1], n[0] * a[3] + n[1] * a[2] - n[2] * a[1] + n[3] * a[0]};
+      double ax[3] = {qd[1], qd[2], qd[3]};
+      const double sn = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      if (sn > 1e-15) for (double& v : ax) v /= sn;
+      double speed = 2 * std::atan2(sn, qd[0]);
+      if (speed > 3.14159265358979323846) speed -= 2 * 3.14159265358979323846;
+      for (int k = 0; k < 3; k++) dx[da + k] = ax[k] * speed / h;
+    } else {
+      dx[da] = (s2[qa] - s1[qa]) / h;
+    }
+  }
+  for (int i = 0; i < nv + m->na; i++) dx[nv + i] = (s2[nq + i] - s1[nq + i]) / h;
+}
+// mj_normalizeQuat on every quaternion of a qpos-layout vector (ilqg/policy.cc:118-125)
+inline void NormalizeStateQuaternions(const mjModel* m, double* qpos) {
+  for (int j = 0; j < m->njnt; j++) {
+    const int t = m->jnt_type[j];
+    if (t != mjJNT_FREE && t != mjJNT_BALL) continue;
+    double* q = qpos + m->jnt_qposadr[j] + (t == mjJNT_FREE ? 3 : 0);
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n < 1e-15) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else for (int k = 0; k < 4; k++) q[k] /= n;
+  }
 }
 
 }  // namespace mjpc

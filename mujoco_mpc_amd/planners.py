@@ -22,6 +22,15 @@ from .task import Task
 K_MAX_TRAJECTORY_HORIZON = 512  # mjpc/trajectory.h:27
 
 
+def sync_task(ctx, task):
+    """The per-plan frozen ResidualFn copy (Agent::PlanIteration, agent.cc:319): weights, norm / residual parameters,
+    risk and the task-specific residual state reach the device before the plan's rollouts."""
+    if hasattr(ctx, "set_task_params"):
+        ctx.set_task_params(task.weight, task.norm_parameter, task.parameters, task.risk)
+    if hasattr(ctx, "set_residual_state") and (task.residual_int or task.residual_real):
+        ctx.set_residual_state(task.residual_int, task.residual_real)
+
+
 def clamp(x, bounds):
     """Clamp, mjpc/utilities.cc:112-116 (mju_clip = max(lo, min(hi, x)))."""
     b = np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
@@ -214,6 +223,7 @@ class GpuSamplingPlanner:
         ns = capi.make_noise_spec(seed=self.seed, iteration=self.iteration, mode=capi.NOISE_SAMPLING,
                                   candidate_offset=offset, nominal_candidate=0,
                                   std0=self.noise_exploration[0], std1=self.noise_exploration[1])
+        sync_task(self.ctx, self.task)
         self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
         self.ctx.rollout_noise(n_local, horizon, plan.interpolation(), plan.times(), plan.values(), ns)
         self._offset, self._n_local = offset, n_local
@@ -277,6 +287,7 @@ class GpuSamplingPlanner:
     # ---- NominalTrajectory, planner.cc:215-227
     def nominal_trajectory(self, horizon, pool=None):
         plan = self.winner_policy.plan if self.winner_policy.plan.size() else self.policy.plan
+        sync_task(self.ctx, self.task)
         self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
         if plan.size() == 0:
             times, values = np.array([self.time]), np.zeros((1, 1, self.model.nu))
@@ -436,6 +447,7 @@ class GpuCrossEntropyPlanner:
                                   candidate_offset=offset, nominal_candidate=num_trajectory, explore_count=explore_count,
                                   std0=self.std_initial_, std1=self.std_min_, param_variance=self.variance[:np_])
         plan = self.resampled_policy.plan
+        sync_task(self.ctx, self.task)
         self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
         self.ctx.rollout_noise(n_local, horizon, plan.interpolation(), plan.times(), plan.values(), ns)
         self._offset, self._n_local = offset, n_local
@@ -480,6 +492,7 @@ class GpuCrossEntropyPlanner:
     # ---- NominalTrajectory, planner.cc:294-308
     def nominal_trajectory(self, horizon, pool=None):
         plan = self.resampled_policy.plan
+        sync_task(self.ctx, self.task)
         self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
         self.ctx.rollout_splines(horizon, plan.interpolation(), plan.times(), plan.values()[None])
         self._nominal = self.ctx.fetch_trajectory(0)
@@ -518,6 +531,52 @@ def find_interval(xs, value, length):
     if lo > length - 1:
         return length - 1, length - 1
     return lo, min(up, length - 1)
+
+
+def _quat_mul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def state_diff(model, s1, s2, h=1.0):
+    """StateDiff, mjpc/utilities.cc:543-553: (s2 - s1) / h in the tangent space (mj_differentiatePos + velocities)."""
+    nq, nv = model.nq, model.nv
+    if nq == nv:
+        return (np.asarray(s2, float) - np.asarray(s1, float)) / h
+    a = model.arrays
+    dx = np.zeros(2 * nv)
+    for j in range(model.njnt):
+        qa, da, t = int(a["jnt_qposadr"][j]), int(a["jnt_dofadr"][j]), int(a["jnt_type"][j])
+        if t == 0:  # free
+            dx[da:da + 3] = (s2[qa:qa + 3] - s1[qa:qa + 3]) / h
+            qa, da = qa + 3, da + 3
+        if t in (0, 1):  # free / ball: mju_subQuat
+            qb, qa_ = np.asarray(s1[qa:qa + 4], float), np.asarray(s2[qa:qa + 4], float)
+            qd = _quat_mul(np.array([qb[0], -qb[1], -qb[2], -qb[3]]), qa_)
+            ax = qd[1:].copy()
+            sn = np.linalg.norm(ax)
+            if sn > 1e-15:
+                ax /= sn
+            speed = 2 * np.arctan2(sn, qd[0])
+            if speed > np.pi:
+                speed -= 2 * np.pi
+            dx[da:da + 3] = ax * speed / h
+        else:
+            dx[da] = (s2[qa] - s1[qa]) / h
+    dx[nv:] = (np.asarray(s2[nq:], float) - np.asarray(s1[nq:], float)) / h
+    return dx
+
+
+def normalize_state_quaternions(model, x):
+    """mj_normalizeQuat on an interpolated state (ilqg/policy.cc:118-125)."""
+    a = model.arrays
+    for j in range(model.njnt):
+        t = int(a["jnt_type"][j])
+        if t in (0, 1):
+            qa = int(a["jnt_qposadr"][j]) + (3 if t == 0 else 0)
+            n = np.linalg.norm(x[qa:qa + 4])
+            x[qa:qa + 4] = [1, 0, 0, 0] if n < 1e-15 else x[qa:qa + 4] / n
+    return x
 
 
 class ILQGSettings:
@@ -580,8 +639,10 @@ class ILQGPolicy:
         action[:] = self._interp(time, tr.times, tr.actions, H - 1, zero)
         if state is not None:
             xi = self._interp(time, tr.times, tr.states, H, zero)
+            if self.model.nq != self.model.nv:
+                xi = normalize_state_quaternions(self.model, xi)
             K = self._interp(time, tr.times, self.feedback_gain, H - 1, zero)
-            action += self.feedback_scaling * (K @ (np.asarray(state, float) - xi))   # StateDiff with nq == nv
+            action += self.feedback_scaling * (K @ state_diff(self.model, xi, np.asarray(state, float)))
         return clamp(action, self.model.actuator_ctrlrange)
 
 
@@ -615,8 +676,11 @@ class GpuILQGPlanner:
         self.policy = ILQGPolicy(m, self.task)
         self.previous_policy = ILQGPolicy(m, self.task)
         self.candidate0 = ILQGPolicy(m, self.task)          # candidate_policy[0]
-        self.ctx = (self._backend_factory(self.task) if self._backend_factory
-                    else capi.Context(self.task.packed_model(), self.task.packed(), self.device, self.precision))
+        # gradient-based planners plan on the differentiable model copy unless agent_differentiable says otherwise
+        self.differentiable_ = bool(int(m.get_number("agent_differentiable", 1)))
+        self.ctx = (self._backend_factory(self.task) if self._backend_factory   # test backends: see tests/oracle_backend.py
+                    else capi.Context(self.task.packed_model(differentiable=self.differentiable_), self.task.packed(), self.device,
+                                      self.precision))
 
     def reset(self, horizon, initial_repeated_action=None):
         self.state[:] = 0; self.mocap[:] = 0; self.userdata[:] = 0
@@ -684,6 +748,7 @@ class GpuILQGPlanner:
         self.policy.trajectory.horizon = horizon
         steps = self._linesearch_steps()
         tr = self.policy.trajectory
+        sync_task(self.ctx, self.task)
         self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
         self.ctx.rollout_feedback(horizon, 1, self.policy.representation, self.settings.nominal_feedback_scaling,
                                   tr.times[:horizon], tr.states[:horizon], tr.actions[:horizon],
@@ -767,6 +832,7 @@ class GpuILQGPlanner:
         c0.action_improvement[:T] = out["du"]
         # ---- ActionRollouts, planner.cc:630-692: line search over the improvement step
         t0 = _time.perf_counter()
+        sync_task(self.ctx, self.task)
         self.ctx.set_state(self.state, self.time, self.mocap, self.userdata)
         self.ctx.rollout_feedback(T, 0, 0, 1, tr.times[:T], tr.states[:T], tr.actions[:T], c0.feedback_gain[:T],
                                   c0.action_improvement[:T], steps)

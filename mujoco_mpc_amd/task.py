@@ -131,15 +131,16 @@ class Task:
     def packed(self) -> PackedTask:
         return PackedTask(self.spec())
 
-    def packed_model(self, planning=True) -> PackedModel:
+    def packed_model(self, planning=True, differentiable=False) -> PackedModel:
         """The agent plans on its own model copy with opt.timestep=agent_timestep and
-        opt.integrator=agent_integrator (mjpc/agent.cc:97-107, 288-291)."""
+        opt.integrator=agent_integrator (mjpc/agent.cc:97-107, 288-291); gradient-based planners plan on a
+        "differentiable" copy (MakeDifferentiable, agent.cc:156-164, 295-311)."""
         m = self.model
         if not planning:
             return PackedModel(m)
         ts = m.get_number("agent_timestep", m.timestep)
         integ = int(m.get_number("agent_integrator", m.integrator))
-        return PackedModel(m, timestep=ts, integrator=integ)
+        return PackedModel(m, timestep=ts, integrator=integ, differentiable=differentiable)
 
     def planning_steps(self) -> int:
         """steps_ = clamp(horizon/timestep + 1, 1, 512), mjpc/agent.cc:288-293."""

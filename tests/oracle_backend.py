@@ -7,9 +7,9 @@ from oracle import pyoracle
 
 
 class OracleContext:
-    def __init__(self, task, threads=2):
+    def __init__(self, task, threads=2, differentiable=False):
         self.task = task
-        self.pm, self.pt = task.packed_model(), task.packed()
+        self.pm, self.pt = task.packed_model(differentiable=differentiable), task.packed()
         self.nu = self.pm.struct.nu
         self.threads = threads
         self.N = self.H = self.P = 0

@@ -173,3 +173,43 @@ def test_rollout_feedback_on_the_quadruped(quad, mode, representation, use_state
     if use_state:
         assert np.ptp(ret) > 1e-7
     ctx.close()
+
+
+def test_ilqg_planner_on_the_quadruped():
+    """BASELINE configs[4] in miniature: iLQG on the A1 (T = 36, 10 line-search rollouts, forward differences) -- the
+    device sweep (49 perturbed steps per time step), cost derivatives, the MFMA Riccati pass at n = 36, m = 12 and the
+    feedback line search all run; the planned return improves; the C++ planner reproduces the Python mirror."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.planners import GpuILQGPlanner, State
+    t = load_task("QuadrupedFlat")
+    t.transition(0.0)
+    H = t.planning_steps()
+    assert H == 36
+    py = GpuILQGPlanner()
+    py.initialize(t.model, t); py.allocate(); py.reset(H)
+    st = State(t.model)
+    home = t.model.keyframes["home"]["qpos"]
+    mp = MOCAP.reshape(2, 7)[:, :3]; mq = MOCAP.reshape(2, 7)[:, 3:]
+    st.set(home, np.zeros(18), mocap_pos=mp, mocap_quat=mq, time=0.0)
+    py.set_state(st)
+    cpp = HostPlanner(load_task("QuadrupedFlat"), kind="ilqg")
+    cpp.task_transition(0.0)
+    cpp.reset(H)
+    cpp.set_state(home, np.zeros(18), 0.0, mocap_pos=mp, mocap_quat=mq)
+    returns = []
+    for k in range(3):
+        py.optimize_policy(H)
+        cpp.optimize_policy(H)
+        returns.append(py.policy.trajectory.total_return)
+        info = cpp.ilqg_info()
+        assert info["winner"] == py.winner and info["regularization"] == py.regularization
+        ct, cx, cu, cK = cpp.ilqg_policy(H)
+        tr = py.policy.trajectory
+        assert np.array_equal(cx, tr.states[:H]) and np.array_equal(cu, tr.actions[:H]) and np.array_equal(cK, py.policy.feedback_gain[:H])
+    assert np.all(np.isfinite(returns)) and returns[-1] <= returns[0]
+    assert py.policy.feedback_gain[:H - 1].any()      # the backward pass produced gains
+    # ActionFromPolicy with quaternion StateDiff
+    x = np.concatenate([home, np.zeros(18)]); x[0] += 0.01; x[7] += 0.02
+    a = np.zeros(12)
+    py.action_from_policy(a, x, 0.013)
+    np.testing.assert_allclose(cpp.action(0.013, state=x), a, rtol=1e-12, atol=1e-14)

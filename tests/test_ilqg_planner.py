@@ -45,7 +45,7 @@ def test_helpers():
 
 
 def test_ilqg_particle_oracle_backend():
-    p, st, steps, hist = run_particle(lambda t: OracleContext(t), iterations=25)
+    p, st, steps, hist = run_particle(lambda t: OracleContext(t, differentiable=True), iterations=25)
     check_converged(p, st, steps)
     assert hist[-1][0] < hist[0][0]
     a = np.zeros(2)
@@ -66,7 +66,7 @@ def test_ilqg_particle_gpu():
 @pytest.mark.gpu
 def test_ilqg_gpu_tracks_oracle_backend():
     g, _, steps, hg = run_particle(None, iterations=6)
-    o, _, _, ho = run_particle(lambda t: OracleContext(t), iterations=6)
+    o, _, _, ho = run_particle(lambda t: OracleContext(t, differentiable=True), iterations=6)
     for (rg, wg, mg, sg), (ro, wo, mo, so) in zip(hg, ho):
         assert wg == wo and mg == mo and sg == so
         assert abs(rg - ro) < 1e-7 * (1 + abs(ro))
