@@ -566,6 +566,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         HIPCHK(c, c->d_stage.reserve(32 * 8));
         HIPCHK(c, hipMemsetAsync(c->d_stage.p, 0, 32 * 8, c->stream));
         wt.stamps = (long long*)c->d_stage.p;
+        wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
       }
       const WaveModel& wm = c->wh.m;
       const size_t lds_state = (8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
@@ -587,7 +588,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         (void)hipMemcpy(h, wt.stamps, sizeof h, hipMemcpyDeviceToHost);
         static const char* nm[] = {"policy", "kinematics", "compos", "crb", "cholM", "collision", "comvel", "make_constraint", "smooth", "solve",
                                    "newton", "residual", "cost+record", "euler"};
-        std::fprintf(stderr, "wave kernel phase cycles (step 1, candidate 0; LDS %zu B):", lds);
+        std::fprintf(stderr, "wave kernel phase cycles (step %d, candidate 0; LDS %zu B):", wt.stamp_step, lds);
         for (int k = 0; k < 14; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k + 1] - h[k]);
         std::fprintf(stderr, " | newton iters %lld: grad %lld hess %lld chol+solve %lld linesearch %lld\n", h[20], h[21] - h[10], h[22] - h[21],
                      h[23] - h[22], h[24] - h[23]);
@@ -1182,6 +1183,7 @@ int wave_blob(mjpcx_ctx* c, WaveTask* wt) {
   *wt = c->wh.t;
   wt->blob = (const double*)c->d_wblob.p;
   wt->stamps = nullptr;
+  wt->stamp_step = 0;
   return MJPCX_OK;
 }
 size_t wave_lds_bytes(const mjpcx_ctx* c, int P) {

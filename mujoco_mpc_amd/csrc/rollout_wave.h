@@ -34,6 +34,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 struct WaveContact {
   int g1, g2, dim, dim0, efc;
+  unsigned dofmask;  // dofs with a non-zero Jacobian column (the chain of the moving body)
   double dist, margin, includemargin, mu;
   double pos[3], frame[9], friction[5], solref[2], solimp[5];
 };

@@ -540,6 +540,7 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
     int dim0 = c.dim0;
     if (dim0 > 1 && m.cone != 1) { dim0 = 1; if (lane == 0) d.counters[2] |= 128; }
     c.efc = my_efc; c.dim = my_dim;
+    c.dofmask = m.body_dofmask[m.geom_bodyid[c.g2]];
     c.mu = c.friction[0] / sqrt(m.impratio > kMinVal ? m.impratio : 1.0);
     for (int row = 0; row < my_dim; row++) {
       const int r = my_efc + row;
@@ -784,32 +785,55 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       }
     }
     WSYNC();
+    // H = M + J' (d2s) J. Friction-loss and limit rows have a single non-zero Jacobian entry: diagonal updates, one lane
+    // per row (friction rows have distinct dofs; a limit row may share its dof with a friction row -> two passes).
+    // Contact rows: the lower-triangle entries are dealt over the lanes; a contact only touches the dofs on the chain
+    // of its body (dofmask), which skips ~3/4 of the (entry, contact) pairs on a legged robot.
+    for (int e = lane; e < nv * nv; e += 64) d.H[e] = d.M[e];
+    WSYNC();
+    int first_contact = ne;
+    for (int pass = 0; pass < 2; pass++) {
+      if (lane < ne) {
+        const int t = d.efc_type[lane];
+        if (t == (pass == 0 ? kEfcFriction : kEfcLimit) && d.efc_zone[lane] == kZoneBottom) {
+          const int dof = t == kEfcFriction ? d.efc_id[lane] : m.jnt_dofadr[d.efc_id[lane]];
+          d.H[dof * nv + dof] += d.efc_D[lane];
+        }
+      }
+      WSYNC();
+    }
+    {
+      const bool is_contact = lane < ne && d.efc_type[lane] >= kEfcNormal;
+      const unsigned long long b = __ballot(is_contact);
+      first_contact = b ? __ffsll((long long)b) - 1 : ne;
+    }
     for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
       // e -> (a >= b)
       int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
       while ((a + 1) * (a + 2) / 2 <= e) a++;
       while (a * (a + 1) / 2 > e) a--;
       const int b = e - a * (a + 1) / 2;
-      double h = d.M[a * nv + b];
-      for (int r = 0; r < ne; r++) {
+      const unsigned need = (1u << a) | (1u << b);
+      double h = d.H[a * nv + b];
+      for (int r = first_contact; r < ne; r++) {
         const int t = d.efc_type[r];
-        if (t == kEfcFriction || t == kEfcLimit || t == kEfcNormal) {
-          if (d.efc_zone[r] == kZoneBottom) h += d.efc_D[r] * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
-        } else if (t == kEfcElliptic) {
-          const int ci = d.efc_id[r];
-          const int dim = d.con[ci].dim;
-          if (d.efc_zone[r] != kZoneTop) {
+        const int ci = d.efc_id[r];
+        const WaveContact& c = d.con[ci];
+        const int dim = c.dim;
+        if ((c.dofmask & need) == need) {
+          if (t == kEfcNormal) {
+            if (d.efc_zone[r] == kZoneBottom) h += d.efc_D[r] * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
+          } else if (t == kEfcElliptic && d.efc_zone[r] != kZoneTop) {
             const double* Hc = d.coneH + 36 * ci;
             for (int j = 0; j < dim; j++) {
               const double ja = d.efc_J[(r + j) * nv + a];
-              if (ja == 0) continue;
               double s = 0;
               for (int k = 0; k < dim; k++) s += Hc[j * dim + k] * d.efc_J[(r + k) * nv + b];
               h += ja * s;
             }
           }
-          r += dim - 1;
         }
+        r += (dim > 0 ? dim : 1) - 1;
       }
       d.H[a * nv + b] = h;
       d.H[b * nv + a] = h;

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_glob
     WSYNC();
     // ================= mj_forward
     bool bad_ctrl = false;
-    long long* stamp = (tk.stamps && cand == 0 && t == 1) ? tk.stamps : nullptr;
+    long long* stamp = (tk.stamps && cand == 0 && t == tk.stamp_step) ? tk.stamps : nullptr;
     WSTAMP(0);
     wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, stamp, /*have_warm=*/t > 0);
     if (!last) for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qacc[i]);  // mj_checkAcc

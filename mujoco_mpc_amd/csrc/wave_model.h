@@ -75,7 +75,8 @@ struct WaveTask {
   // blob (doubles): state[nq+nv] time mocap[7 nmocap] weight[nterm] norm_p[nterm] norm_q[nterm] parameters[nparam]
   //                 risk residual_real[nrr] ; then residual_int[nri] as int32
   const double* blob;
-  long long* stamps;  // optional (tuning): s_memtime at the phase boundaries of step 1 of candidate 0
+  long long* stamps;  // optional (tuning): s_memtime at the phase boundaries of step `stamp_step` of candidate 0
+  int stamp_step;
   int off_time, off_mocap, off_weight, off_normp, off_normq, off_param, off_risk, off_rreal, off_rint;
 };
 

@@ -42,3 +42,21 @@ t0 = time.perf_counter()
 for _ in range(20):
     ctx.cost_derivatives(res, C, D)
 print(f"cost_derivatives T={H}: {(time.perf_counter() - t0) / 20 * 1e6:.0f} us per call (host-inclusive)")
+
+# ---- BASELINE configs[4]: iLQG on the Quadruped (T = 36, 10 line-search rollouts, forward differences)
+from mujoco_mpc_amd.planners import GpuILQGPlanner, State  # noqa: E402
+qt = load_task("QuadrupedFlat")
+qt.transition(0.0)
+Hq = qt.planning_steps()
+pl = GpuILQGPlanner()
+pl.initialize(qt.model, qt); pl.allocate(); pl.reset(Hq)
+st = State(qt.model)
+home = qt.model.keyframes["home"]["qpos"]
+st.set(home, np.zeros(18), mocap_pos=[[0.3, 0, 0.26], [-2.5, 0, 0]], mocap_quat=[[1, 0, 0, 0], [1, 0, 0, 0]], time=0.0)
+pl.set_state(st)
+for k in range(4):
+    t0 = time.perf_counter()
+    pl.optimize_policy(Hq)
+    el = (time.perf_counter() - t0) * 1e3
+    print(f"quadruped iLQG iteration {k}: {el:.1f} ms total; return {pl.policy.trajectory.total_return:.4f}; " +
+          ", ".join(f"{n} {v / 1e3:.1f} ms" for n, v in pl.timers.items()))
