@@ -51,7 +51,7 @@ struct WaveData {
   double *actuator_force, *grad, *search, *Ma, *Ms, *tmpv, *qacc_warm;
   double *efc_J, *efc_pos, *efc_margin, *efc_D, *efc_R, *efc_aref, *efc_floss, *efc_force, *jar, *jv;
   int *efc_type, *efc_id, *efc_zone;
-  double* coneH;  // kWaveMaxCon x 36
+  double* coneH;  // kWaveMaxCon x 21: lower triangle (j >= k at j (j + 1) / 2 + k) of each cone's symmetric Hessian block
   double* foot_xpos;  // geom_xpos of the geoms the residual reads (4 x 3)
   double* residual;
   double* terms;

@@ -761,8 +761,9 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     if (lane < d.counters[0]) {
       const WaveContact& c = d.con[lane];
       const int r = c.efc, dim = c.dim;
-      double* Hc = d.coneH + 36 * lane;
+      double* Hs = d.coneH + 21 * lane;
       if (dim > 0 && d.efc_type[r] == kEfcElliptic) {
+        double Hc[36];
         for (int e = 0; e < 36; e++) Hc[e] = 0;
         const int zone = d.efc_zone[r];
         if (zone == kZoneBottom) {
@@ -782,6 +783,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
           }
           for (int j = 0; j < dim; j++) for (int k = 0; k < dim; k++) Hc[j * dim + k] *= s[j] * s[k];
         }
+        for (int j = 0; j < dim; j++) for (int k = 0; k <= j; k++) Hs[j * (j + 1) / 2 + k] = Hc[j * dim + k];
       }
     }
     WSYNC();
@@ -824,12 +826,18 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
           if (t == kEfcNormal) {
             if (d.efc_zone[r] == kZoneBottom) h += d.efc_D[r] * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
           } else if (t == kEfcElliptic && d.efc_zone[r] != kZoneTop) {
-            const double* Hc = d.coneH + 36 * ci;
-            for (int j = 0; j < dim; j++) {
-              const double ja = d.efc_J[(r + j) * nv + a];
+            const double* Hs = d.coneH + 21 * ci;
+            double Ja[6], Jb[6], Hl[21];  // fully unrolled with guards: static indices keep these in registers
+#pragma unroll
+            for (int j = 0; j < 6; j++) { Ja[j] = j < dim ? d.efc_J[(r + j) * nv + a] : 0.0; Jb[j] = j < dim ? d.efc_J[(r + j) * nv + b] : 0.0; }
+#pragma unroll
+            for (int e = 0; e < 21; e++) Hl[e] = e < dim * (dim + 1) / 2 ? Hs[e] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {  // row j of the symmetric block from its packed lower triangle
               double s = 0;
-              for (int k = 0; k < dim; k++) s += Hc[j * dim + k] * d.efc_J[(r + k) * nv + b];
-              h += ja * s;
+#pragma unroll
+              for (int k = 0; k < 6; k++) s += Hl[j >= k ? j * (j + 1) / 2 + k : k * (k + 1) / 2 + j] * Jb[k];
+              h += Ja[j] * s;
             }
           }
         }

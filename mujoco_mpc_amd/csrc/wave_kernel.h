@@ -10,12 +10,12 @@ __host__ __device__ inline size_t wave_lds_doubles(int nq, int nv, int nu, int n
   size_t n = 0;
   n += nq + nv + nu;                                   // qpos qvel ctrl
   n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 6 * njnt + 3 * nsite;  // kinematics
-  n += 3 * nbody + 10 * nbody * 2 + 6 * nv * 2 + 6 * nbody * 4 + 3;                       // com, inertias, spatial
-  n += 3 * (size_t)nv * nv + 2 * nv;                   // M L H + reciprocal pivots
-  n += 7 * nv + nu + 6 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma Ms tmpv qacc_warm
-  n += (size_t)kWaveMaxEfc * nv + 10 * kWaveMaxEfc;    // efc_J + per-row doubles
+  n += 3 * nbody + 10 * nbody + 6 * nv * 2 + 6 * nbody * 4 + 3;                           // com, cinert (crb aliases cacc|cfrc), spatial
+  n += 2 * (size_t)nv * nv + 2 * nv;                   // M H (the factor of M lives in H until Newton) + reciprocal pivots
+  n += 7 * nv + nu + 5 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma tmpv qacc_warm
+  n += (size_t)kWaveMaxEfc * nv + 9 * kWaveMaxEfc;     // efc_J + per-row doubles
   n += (3 * kWaveMaxEfc + 1) / 2 + 1;                  // per-row ints
-  n += 36 * kWaveMaxCon + 12 + nr + nterm + 8;         // coneH foot_xpos residual terms scal
+  n += 21 * kWaveMaxCon + 12 + nr + nterm + 8;         // coneH (lower triangles) foot_xpos residual terms scal
   n += (sizeof(WaveContact) * kWaveMaxCon + 7) / 8;
   n += 4;                                              // counters
   n += (size_t)P * nu + P;                             // spline nodes + node times
@@ -32,20 +32,21 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const Wa
   d.qpos = take(nq); d.qvel = take(nv); d.ctrl = take(nu);
   d.xpos = take(3 * nb); d.xquat = take(4 * nb); d.xmat = take(9 * nb); d.xipos = take(3 * nb); d.ximat = take(9 * nb);
   d.xanchor = take(3 * nj); d.xaxis = take(3 * nj); d.site_xpos = take(3 * ns);
-  d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.crb = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
+  d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
   d.cvel = take(6 * nb); d.cacc = take(6 * nb); d.cfrc = take(6 * nb); d.cfrc_sub = take(6 * nb); d.subtree_linvel = take(3);
-  d.M = take((size_t)nv * nv); d.L = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = take(nv);
+  d.crb = d.cacc;  // composite inertias (10 nb) are dead before RNE writes cacc | cfrc (12 nb, contiguous)
+  d.M = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = take(nv);
+  d.L = d.H;       // the factor of M is only needed until qacc_smooth is solved, before Newton builds H
   d.qfrc_passive = take(nv); d.qfrc_bias = take(nv); d.qfrc_actuator = take(nv); d.qfrc_smooth = take(nv);
   d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
-  d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = take(nv); d.tmpv = take(nv); d.qacc_warm = take(nv);
+  d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = nullptr; d.tmpv = take(nv); d.qacc_warm = take(nv);
   d.efc_J = take((size_t)kWaveMaxEfc * nv);
   d.efc_pos = take(kWaveMaxEfc); d.efc_margin = take(kWaveMaxEfc); d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
   d.efc_aref = take(kWaveMaxEfc); d.efc_floss = take(kWaveMaxEfc); d.efc_force = take(kWaveMaxEfc); d.jar = take(kWaveMaxEfc);
   d.jv = take(kWaveMaxEfc);
-  take(kWaveMaxEfc);  // spare
   int* ip = reinterpret_cast<int*>(take((3 * kWaveMaxEfc + 1) / 2 + 1));
   d.efc_type = ip; d.efc_id = ip + kWaveMaxEfc; d.efc_zone = ip + 2 * kWaveMaxEfc;
-  d.coneH = take(36 * kWaveMaxCon); d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
+  d.coneH = take(21 * kWaveMaxCon); d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
   d.con = reinterpret_cast<WaveContact*>(take((sizeof(WaveContact) * kWaveMaxCon + 7) / 8));
   d.counters = reinterpret_cast<int*>(take(4));
   lnodes = take((size_t)P * nu);  // [P][nu]
