@@ -641,41 +641,57 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
     if (x < 0) { cost = 0.5 * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
     else if (write_force) { d.efc_force[r] = 0; d.efc_zone[r] = kZoneTop; }
   } else if (type == kEfcElliptic) {
+    // loops are unrolled to the maximum cone dimension with guards: static indices keep U/V/X in registers (run-time
+    // trip counts would put them in scratch, and this runs for every line-search trial)
     const WaveContact& c = d.con[d.efc_id[r]];
     const int dim = c.dim;
     const double mu = c.mu;
-    double U[6], V[6], X[6], T = 0;
-    X[0] = x; U[0] = x * mu; V[0] = v * mu;
-    for (int j = 1; j < dim; j++) {
-      const double vj = jv ? jv[r + j] : 0.0;
-      X[j] = jar[r + j] + alpha * vj;
-      U[j] = X[j] * c.friction[j - 1];
-      V[j] = vj * c.friction[j - 1];
-      T += U[j] * U[j];
+    double U[6], V[6], X[6], Dj[6], T = 0;
+    X[0] = x; U[0] = x * mu; V[0] = v * mu; Dj[0] = D;
+#pragma unroll
+    for (int j = 1; j < 6; j++) {
+      if (j < dim) {
+        const double vj = jv ? jv[r + j] : 0.0, fj = c.friction[j - 1];
+        X[j] = jar[r + j] + alpha * vj;
+        U[j] = X[j] * fj;
+        V[j] = vj * fj;
+        Dj[j] = d.efc_D[r + j];
+        T += U[j] * U[j];
+      } else { X[j] = U[j] = V[j] = Dj[j] = 0; }
     }
     T = sqrt(T);
     const double N = U[0];
     if (N >= mu * T || (T <= 0 && N >= 0)) {
-      if (write_force) { for (int j = 0; j < dim; j++) d.efc_force[r + j] = 0; d.efc_zone[r] = kZoneTop; }
+      if (write_force) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j < dim) d.efc_force[r + j] = 0;
+        d.efc_zone[r] = kZoneTop;
+      }
     } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-      for (int j = 0; j < dim; j++) {
-        const double Dj = d.efc_D[r + j], vj = jv ? jv[r + j] : 0.0;
-        cost += 0.5 * Dj * X[j] * X[j]; g1 += Dj * X[j] * vj; h2 += Dj * vj * vj;
-        if (write_force) d.efc_force[r + j] = -Dj * X[j];
+      // bottom zone: plain quadratic in every row (vj recovered from jv to keep the oracle's arithmetic)
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        if (j < dim) {
+          const double vj = jv ? jv[r + j] : 0.0;
+          cost += 0.5 * Dj[j] * X[j] * X[j]; g1 += Dj[j] * X[j] * vj; h2 += Dj[j] * vj * vj;
+          if (write_force) d.efc_force[r + j] = -Dj[j] * X[j];
+        }
       }
       if (write_force) d.efc_zone[r] = kZoneBottom;
     } else {
       const double Dm = D / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
       cost = 0.5 * Dm * NT * NT;
       double UV = 0, VV = 0;
-      for (int j = 1; j < dim; j++) { UV += U[j] * V[j]; VV += V[j] * V[j]; }
+#pragma unroll
+      for (int j = 1; j < 6; j++) if (j < dim) { UV += U[j] * V[j]; VV += V[j] * V[j]; }
       const double dNT = V[0] - mu * UV / T;
       const double d2NT = -mu * (VV / T - UV * UV / (T * T * T));
       g1 = Dm * NT * dNT;
       h2 = Dm * (dNT * dNT + NT * d2NT);
       if (write_force) {
         d.efc_force[r] = -Dm * NT * mu;
-        for (int j = 1; j < dim; j++) d.efc_force[r + j] = Dm * NT * mu * U[j] * c.friction[j - 1] / T;
+#pragma unroll
+        for (int j = 1; j < 6; j++) if (j < dim) d.efc_force[r + j] = Dm * NT * mu * U[j] * c.friction[j - 1] / T;
         d.efc_zone[r] = kZoneMiddle;
       }
     }
@@ -763,27 +779,34 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       const int r = c.efc, dim = c.dim;
       double* Hs = d.coneH + 21 * lane;
       if (dim > 0 && d.efc_type[r] == kEfcElliptic) {
-        double Hc[36];
-        for (int e = 0; e < 36; e++) Hc[e] = 0;
+        // lower triangle only, unrolled to dimension 6 with guards (register-resident)
         const int zone = d.efc_zone[r];
-        if (zone == kZoneBottom) {
-          for (int j = 0; j < dim; j++) Hc[j * dim + j] = d.efc_D[r + j];
-        } else if (zone == kZoneMiddle) {
-          const double mu = c.mu;
-          double U[6], s[6], T = 0;
-          s[0] = mu; U[0] = d.jar[r] * mu;
-          for (int j = 1; j < dim; j++) { s[j] = c.friction[j - 1]; U[j] = d.jar[r + j] * s[j]; T += U[j] * U[j]; }
-          T = sqrt(T);
-          const double Dm = d.efc_D[r] / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T;
-          Hc[0] = Dm;
-          for (int j = 1; j < dim; j++) {
-            Hc[j] = Hc[j * dim] = -Dm * mu * U[j] / T;
-            for (int k = 1; k < dim; k++)
-              Hc[j * dim + k] = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? 1.0 / T : 0.0) - U[j] * U[k] / (T * T * T));
-          }
-          for (int j = 0; j < dim; j++) for (int k = 0; k < dim; k++) Hc[j * dim + k] *= s[j] * s[k];
+        const double mu = c.mu;
+        double U[6], sc[6], T = 0;
+        sc[0] = mu; U[0] = d.jar[r] * mu;
+#pragma unroll
+        for (int j = 1; j < 6; j++) {
+          if (j < dim) { sc[j] = c.friction[j - 1]; U[j] = d.jar[r + j] * sc[j]; T += U[j] * U[j]; } else { sc[j] = 0; U[j] = 0; }
         }
-        for (int j = 0; j < dim; j++) for (int k = 0; k <= j; k++) Hs[j * (j + 1) / 2 + k] = Hc[j * dim + k];
+        T = sqrt(T);
+        const double Dm = d.efc_D[r] / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+#pragma unroll
+          for (int k = 0; k <= j; k++) {
+            if (j < dim) {
+              double hjk = 0;
+              if (zone == kZoneBottom) hjk = j == k ? d.efc_D[r + j] : 0.0;
+              else if (zone == kZoneMiddle) {
+                if (j == 0) hjk = Dm;                                   // (0, 0)
+                else if (k == 0) hjk = -Dm * mu * U[j] / T;             // (j, 0)
+                else hjk = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? 1.0 / T : 0.0) - U[j] * U[k] / (T * T * T));
+                hjk *= sc[j] * sc[k];
+              }
+              Hs[j * (j + 1) / 2 + k] = hjk;
+            }
+          }
+        }
       }
     }
     WSYNC();
