@@ -570,11 +570,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       }
       const WaveModel& wm = c->wh.m;
       const size_t lds_state = (8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
-      const bool stage = getenv("MJPCX_WAVE_STAGE_MODEL") != nullptr;
-      const size_t blob_d = stage ? (c->wh.blob_bytes + 7) / 8 : 0;
-      const size_t lds = lds_state + (stage ? (size_t)wm.bytes + blob_d * 8 : 0);
-      a.lds_state_bytes = (int)lds_state;
-      a.blob_doubles = (int)blob_d;
+      const size_t lds = lds_state;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
       auto kern = wm.nv <= 20 ? rollout_wave_kernel<20> : rollout_wave_kernel<32>;
       le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -347,6 +347,16 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
     // up to 4 candidate contacts of this lane: dist, pos, normal
     double cd[4], cp[4][3], cn[3] = {0, 0, 1};
     int cnt = 0;
+    // candidate slots are written through a switch on the count: static indices keep cd / cp in registers
+    auto push = [&](double dist, double px, double py, double pz) {
+      switch (cnt) {
+        case 0: cd[0] = dist; cp[0][0] = px; cp[0][1] = py; cp[0][2] = pz; break;
+        case 1: cd[1] = dist; cp[1][0] = px; cp[1][1] = py; cp[1][2] = pz; break;
+        case 2: cd[2] = dist; cp[2][0] = px; cp[2][1] = py; cp[2][2] = pz; break;
+        default: cd[3] = dist; cp[3][0] = px; cp[3][1] = py; cp[3][2] = pz; break;
+      }
+      cnt++;
+    };
     double margin = 0;
     const bool pair = have && ((m.geom_contype[g1] & m.geom_conaffinity[g2]) || (m.geom_contype[g2] & m.geom_conaffinity[g1]));
     if (pair) {
@@ -356,7 +366,7 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
         for (int k = 0; k < 3; k++) cn[k] = n[k];
         auto sphere_plane = [&](const double* c, double r) {
           const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2] - r;
-          if (dist < margin) { cd[cnt] = dist; for (int k = 0; k < 3; k++) cp[cnt][k] = c[k] - n[k] * (r + 0.5 * dist); cnt++; }
+          if (dist < margin) push(dist, c[0] - n[0] * (r + 0.5 * dist), c[1] - n[1] * (r + 0.5 * dist), c[2] - n[2] * (r + 0.5 * dist));
         };
         if (t2 == MJPCX_GEOM_SPHERE) {
           sphere_plane(p2, s2[0]);
@@ -373,7 +383,7 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
             mv3(c, R2, loc);
             for (int k = 0; k < 3; k++) c[k] += p2[k];
             const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
-            if (dist < margin) { cd[cnt] = dist; for (int k = 0; k < 3; k++) cp[cnt][k] = c[k] - 0.5 * dist * n[k]; cnt++; }
+            if (dist < margin) push(dist, c[0] - 0.5 * dist * n[0], c[1] - 0.5 * dist * n[1], c[2] - 0.5 * dist * n[2]);
           }
         } else if (t2 == MJPCX_GEOM_CYLINDER) {
           const double a[3] = {R2[2], R2[5], R2[8]};
@@ -392,7 +402,7 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
             double c[3];
             for (int k = 0; k < 3; k++) c[k] = p2[k] + side * s2[1] * a[k] + s2[0] * (cc * v[k] + ss * w[k]);
             const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
-            if (dist < margin) { cd[cnt] = dist; for (int k = 0; k < 3; k++) cp[cnt][k] = c[k] - 0.5 * dist * n[k]; cnt++; }
+            if (dist < margin) push(dist, c[0] - 0.5 * dist * n[0], c[1] - 0.5 * dist * n[1], c[2] - 0.5 * dist * n[2]);
           }
         }
       } else if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
@@ -453,9 +463,10 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
       WaveContact proto;
       proto.g1 = g1; proto.g2 = g2; proto.efc = 0; proto.mu = 0;
       wf_contact_param(m, g1, g2, proto);
-      for (int k = 0; k < cnt; k++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
         const int at = base + below + k;
-        if (at < kWaveMaxCon) {
+        if (k < cnt && at < kWaveMaxCon) {
           WaveContact c = proto;
           c.dist = cd[k];
           for (int e = 0; e < 3; e++) { c.pos[e] = cp[k][e]; c.frame[e] = cn[e]; }

@@ -56,34 +56,12 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const Wa
 }
 
 template <int NMAX>
-__global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m_global, const WaveTask tk_global, const RolloutArgs<double> a) {
+__global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, const WaveTask tk, const RolloutArgs<double> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x, cand = blockIdx.x;
-  // (pointer arithmetic through integers: one constant LDS->generic cast of smem_raw, no per-pointer null checks --
-  //  the backend mis-selects the aperture compare of a variable-offset LDS->generic cast on gfx950)
-  const uintptr_t lds_generic = reinterpret_cast<uintptr_t>(static_cast<unsigned char*>(smem_raw));
-  unsigned char* lds_model = reinterpret_cast<unsigned char*>(lds_generic + (uintptr_t)a.lds_state_bytes);
-  WaveModel m = m_global;
-  WaveTask tk = tk_global;
-  // Staging is optional (a.blob_doubles > 0): it removes the L1/L2 round trips of the model reads but costs ~19 KB of
-  // LDS, i.e. 2 instead of 3 candidates per CU; measured it does not shorten the step (issue-bound), so the default
-  // keeps the model in global memory (scalar / vector L1 hits after the first step).
-  if (a.blob_doubles > 0) {
-    const uint4* src = reinterpret_cast<const uint4*>(m_global.base);
-    uint4* dst = reinterpret_cast<uint4*>(lds_model);
-    for (int i = lane; i < m_global.bytes / 16; i += 64) dst[i] = src[i];
-    const double* bsrc = tk_global.blob;
-    double* bdst = reinterpret_cast<double*>(lds_model + m_global.bytes);
-    for (int i = lane; i < a.blob_doubles; i += 64) bdst[i] = bsrc[i];
-  const uintptr_t model_generic = lds_generic + (uintptr_t)a.lds_state_bytes, gbase = reinterpret_cast<uintptr_t>(m_global.base);
-#define MJPCX_REBASE(f) m.f = reinterpret_cast<decltype(m.f)>(model_generic + (reinterpret_cast<uintptr_t>(m_global.f) - gbase));
-  MJPCX_WAVE_MODEL_POINTERS(MJPCX_REBASE)
-#undef MJPCX_REBASE
-  tk.blob = reinterpret_cast<const double*>(model_generic + (uintptr_t)m_global.bytes);
-  tk.dim_norm_residual = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.dim_norm_residual) - gbase));
-  tk.norm = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.norm) - gbase));
-  tk.trace_site = reinterpret_cast<const int*>(model_generic + (reinterpret_cast<uintptr_t>(tk_global.trace_site) - gbase));
-  }
+  // The model and task structs stay in the kernel-argument segment (scalar loads). Staging the model allocation into
+  // LDS was tried: no shorter step, fewer candidates per CU, and a run-time-rebased copy of this struct
+  // ends up in the private segment -- every pointer fetch becomes a scratch load.
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
   const int P = a.P, H = a.H;
   const size_t N = (size_t)a.N;
