@@ -602,6 +602,7 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
       solref = c.solref; solimp = c.solimp;
       diag = m.body_invweight0[2 * m.geom_bodyid[c.g1]] + m.body_invweight0[2 * m.geom_bodyid[c.g2]];
     }
+#pragma unroll 6
     for (int k = 0; k < nv; k++) vel += d.efc_J[r * nv + k] * d.qvel[k];
     w_solref_kb(m, solref, solimp, kk, bb);
     if (type != kEfcConeRow) {
@@ -734,6 +735,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
   if (ne == 0) return;
   if (lane < ne) {
     double s = -d.efc_aref[lane];
+#pragma unroll 6
     for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.qacc[k];
     d.jar[lane] = s;
   }
@@ -744,11 +746,13 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     if (lane < ne) {
       jsave = d.jar[lane];
       double s = -d.efc_aref[lane];
+#pragma unroll 6
       for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.qacc_warm[k];
       jw = s;
     }
     if (lane < nv) {
       double s = 0;
+#pragma unroll 6
       for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc_warm[b] - d.qacc_smooth[b]);
       gauss = 0.5 * s * (d.qacc_warm[lane] - d.qacc_smooth[lane]);
     }
@@ -774,9 +778,11 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     double g = 0;
     if (lane < nv) {
       double s = 0;
+#pragma unroll 6
       for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc[b] - d.qacc_smooth[b]);
       d.Ma[lane] = s;
       g = s;
+#pragma unroll 8
       for (int r = 0; r < ne; r++) g -= d.efc_J[r * nv + lane] * d.efc_force[r];
       d.grad[lane] = g;
       d.search[lane] = -g;
@@ -888,12 +894,14 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     // jv = J search; Gauss part along the ray
     if (lane < ne) {
       double s = 0;
+#pragma unroll 6
       for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.search[k];
       d.jv[lane] = s;
     }
     double q1 = 0, q2 = 0;
     if (lane < nv) {
       double s = 0;
+#pragma unroll 6
       for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * d.search[b];
       q1 = d.search[lane] * d.Ma[lane];
       q2 = d.search[lane] * s;
@@ -924,6 +932,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     double gauss = 0;
     if (lane < nv) {
       double s = 0;
+#pragma unroll 6
       for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc[b] - d.qacc_smooth[b]);
       gauss = 0.5 * s * (d.qacc[lane] - d.qacc_smooth[lane]);
     }
@@ -937,6 +946,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
   }
   if (lane < nv) {
     double s = 0;
+#pragma unroll 8
     for (int r = 0; r < ne; r++) s += d.efc_J[r * nv + lane] * d.efc_force[r];
     d.qfrc_constraint[lane] = s;
   }
