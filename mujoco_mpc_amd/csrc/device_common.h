@@ -12,6 +12,7 @@ constexpr int kJntFree = 0, kJntBall = 1, kJntSlide = 2, kJntHinge = 3;
 constexpr double kMinVal = 1e-15;  // mjMINVAL
 constexpr double kMaxVal = 1e10;   // mjMAXVAL
 constexpr double kMinImp = 0.0001, kMaxImp = 0.9999;  // mjMINIMP / mjMAXIMP: clip range of solimp's d0, d_width, midpoint
+constexpr double kLsTolerance = 0.01;  // mjOption.ls_tolerance default: line-search gradient tolerance relative to the solver tolerance
 constexpr double kMaxReturn = 1.0e6;  // kMaxReturnValue, mjpc/trajectory.cc:29
 
 // Capacity of the lane-per-candidate ("small model") kernel family.

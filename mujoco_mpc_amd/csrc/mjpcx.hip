@@ -563,8 +563,8 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         le = hipGetLastError();
       } else {
       if (getenv("MJPCX_STAMPS")) {
-        HIPCHK(c, c->d_stage.reserve(32 * 8));
-        HIPCHK(c, hipMemsetAsync(c->d_stage.p, 0, 32 * 8, c->stream));
+        HIPCHK(c, c->d_stage.reserve(48 * 8));
+        HIPCHK(c, hipMemsetAsync(c->d_stage.p, 0, 48 * 8, c->stream));
         wt.stamps = (long long*)c->d_stage.p;
         wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
       }
@@ -579,7 +579,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         le = hipGetLastError();
       }
       if (wt.stamps && le == hipSuccess) {
-        long long h[32];
+        long long h[48];
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemcpy(h, wt.stamps, sizeof h, hipMemcpyDeviceToHost);
         static const char* nm[] = {"policy", "kinematics", "compos", "crb", "cholM", "collision", "comvel", "make_constraint", "smooth", "solve",
@@ -588,6 +588,8 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         for (int k = 0; k < 14; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k + 1] - h[k]);
         std::fprintf(stderr, " | newton iters %lld: grad %lld hess %lld chol+solve %lld linesearch %lld\n", h[20], h[21] - h[10], h[22] - h[21],
                      h[23] - h[22], h[24] - h[23]);
+        std::fprintf(stderr, "  newton totals over iterations: grad %lld coneblocks %lld hess %lld chol+solve %lld jv+q %lld linesearch %lld (%lld trials) update+cost %lld\n",
+                     h[32], h[33], h[34], h[35], h[36], h[37], h[39], h[38]);
       }
       }
     } else {

@@ -808,14 +808,17 @@ __device__ __forceinline__ void simt_newton(const WaveModel& m, const SimtData& 
     simt_rows<false, true>(d, ne, 0.0, d1, d2);
     d1 += q1; d2 += q2;
     const double d10 = fabs(d1);
-    for (int ls = 0; ls < 50; ls++) {
+    double snorm = 0;
+    for (int a = 0; a < nv; a++) snorm += d.at(o.search, a) * d.at(o.search, a);
+    const double gtol = m.solver_tolerance * kLsTolerance * sqrt(snorm) / scale;
+    for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
       double an = alpha - d1 / d2;
       if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
       if (an == alpha) break;
       alpha = an;
       simt_rows<false, true>(d, ne, alpha, d1, d2);
       d1 += q1 + alpha * q2; d2 += q2;
-      if (fabs(d1) <= 1e-14 * d10) break;
+      if (fabs(d1) < gtol) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
     }
     for (int a = 0; a < nv; a++) d.at(o.qacc, a) += alpha * d.at(o.search, a);

@@ -773,7 +773,10 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
   }
   const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
   bool polish = false;
+  long long tacc = 0;
+#define WACC(k) do { if (stamp && lane == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); stamp[k] += now_ - tacc; tacc = now_; } } while (0)
   for (int iter = 0; iter < m.solver_iterations; iter++) {
+    if (stamp && lane == 0) tacc = (long long)__builtin_readcyclecounter();
     // gradient = M (qacc - qacc_smooth) - J' force
     double g = 0;
     if (lane < nv) {
@@ -790,6 +793,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     const double gnorm = sqrt(wave_sum(lane < nv ? g * g : 0.0));
     if (gnorm == 0) break;
     if (stamp && lane == 0 && iter == 0) stamp[21] = (long long)__builtin_readcyclecounter();
+    WACC(32);
     // cone Hessian blocks (one lane per contact), then H = M + J' (d2s) J over the lower triangle
     if (lane < d.counters[0]) {
       const WaveContact& c = d.con[lane];
@@ -827,6 +831,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       }
     }
     WSYNC();
+    WACC(33);
     // H = M + J' (d2s) J. Friction-loss and limit rows have a single non-zero Jacobian entry: diagonal updates, one lane
     // per row (friction rows have distinct dofs; a limit row may share its dof with a friction row -> two passes).
     // Contact rows: the lower-triangle entries are dealt over the lanes; a contact only touches the dofs on the chain
@@ -888,9 +893,11 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     }
     WSYNC();
     if (stamp && lane == 0 && iter == 0) stamp[22] = (long long)__builtin_readcyclecounter();
+    WACC(34);
     if (!wave_chol<NMAX>(d.H, d.dinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
     wave_chol_solve<NMAX>(d.search, d.H, d.dinv, nv, lane);
     if (stamp && lane == 0 && iter == 0) stamp[23] = (long long)__builtin_readcyclecounter();
+    WACC(35);
     // jv = J search; Gauss part along the ray
     if (lane < ne) {
       double s = 0;
@@ -908,13 +915,16 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     }
     q1 = wave_sum(q1); q2 = wave_sum(q2);
     WSYNC();
+    WACC(36);
     // exact line search: safeguarded 1-D Newton on the (convex, piecewise quadratic) restriction
     double lo = 0, hi = -1, alpha = 0, d1, d2, c0, g0, h0;
     c0 = 0; g0 = 0; h0 = 0;
     if (lane < ne) wf_row_eval(d, lane, d.jar, d.jv, 0.0, false, c0, g0, h0);
     d1 = wave_sum(g0) + q1; d2 = wave_sum(h0) + q2;
     const double d10 = fabs(d1);
-    for (int ls = 0; ls < 50; ls++) {
+    // termination as in MuJoCo's PrimalSearch: |derivative| < tolerance * ls_tolerance * |search| / scale
+    const double gtol = m.solver_tolerance * kLsTolerance * sqrt(wave_sum(lane < nv ? d.search[lane] * d.search[lane] : 0.0)) / scale;
+    for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
       double an = alpha - d1 / d2;
       if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
       if (an == alpha) break;
@@ -922,9 +932,11 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       c0 = 0; g0 = 0; h0 = 0;
       if (lane < ne) wf_row_eval(d, lane, d.jar, d.jv, alpha, false, c0, g0, h0);
       d1 = wave_sum(g0) + q1 + alpha * q2; d2 = wave_sum(h0) + q2;
-      if (fabs(d1) <= 1e-14 * d10) break;
+      if (fabs(d1) < gtol) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
+      if (stamp && lane == 0) stamp[39]++;
     }
+    WACC(37);
     if (stamp && lane == 0 && iter == 0) stamp[24] = (long long)__builtin_readcyclecounter();
     if (lane < nv) d.qacc[lane] += alpha * d.search[lane];
     if (lane < ne) d.jar[lane] += alpha * d.jv[lane];
@@ -940,6 +952,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     const double newcost = gauss + wf_constraint_cost(d, ne, lane);
     const double improvement = cost - newcost;
     cost = newcost;
+    WACC(38);
     if (stamp && lane == 0) stamp[20] = iter + 1;
     if (polish) break;
     if (scale * improvement < m.solver_tolerance || scale * gnorm < m.solver_tolerance) polish = true;

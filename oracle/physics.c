@@ -28,6 +28,7 @@
 #define OMINVAL 1e-15 /* mjMINVAL */
 #define OMINIMP 0.0001 /* mjMINIMP: solimp d0, d_width, midpoint are clipped to [mjMINIMP, mjMAXIMP] */
 #define OMAXIMP 0.9999 /* mjMAXIMP */
+#define OLS_TOLERANCE 0.01 /* mjOption.ls_tolerance default (not carried by mjpcx_model) */
 #define OMAXVAL 1e10  /* mjMAXVAL */
 #define OMAXEFC 64 /* = kWaveMaxEfc of the device kernel: rows beyond the cap are dropped identically */
 #define OMAXCON 16 /* = kWaveMaxCon */
