@@ -70,6 +70,7 @@ enum {
   MJPCX_RESIDUAL_PARTICLE_COPY = 2, /* mjpc/test/agent/rollout_test.cc:37-42          */
   MJPCX_RESIDUAL_CARTPOLE = 3,      /* mjpc/tasks/cartpole/cartpole.cc:36-49          */
   MJPCX_RESIDUAL_QUADRUPED_FLAT = 4,/* mjpc/tasks/quadruped/quadruped.cc:33-226       */
+  MJPCX_RESIDUAL_HUMANOID_TRACK = 5,/* mjpc/tasks/humanoid/tracking/tracking.cc:94-216 */
 };
 
 /* ---- flat model ("mjModel" subset, compiled) ----
@@ -165,8 +166,27 @@ typedef struct mjpcx_model {
   const double* dof_solref;       /* nv x 2 (friction loss) */
   const double* dof_solimp;       /* nv x 5 */
   const double* key_qpos;         /* nkey x nq (residuals that read keyframes) */
+  /* ---- fixed tendons (limits only), body-pair collision filter, mocap keyframes: the Humanoid class of models.
+   * All zero / NULL for models without them. Spatial tendons are not supported (mjpcx_create: MJPCX_EUNSUPPORTED). */
+  int32_t ntendon;
+  int32_t nwrap;
+  int32_t nexclude;
+  const int32_t* tendon_adr;        /* ntendon: first wrap entry                                   */
+  const int32_t* tendon_num;        /* ntendon: number of wrap entries                             */
+  const int32_t* tendon_limited;    /* ntendon                                                     */
+  const int32_t* wrap_objid;        /* nwrap: joint id (mjWRAP_JOINT entries only)                 */
+  const double* wrap_prm;           /* nwrap: coefficient                                          */
+  const double* tendon_range;       /* ntendon x 2                                                 */
+  const double* tendon_margin;      /* ntendon                                                     */
+  const double* tendon_solref_lim;  /* ntendon x 2                                                 */
+  const double* tendon_solimp_lim;  /* ntendon x 5                                                 */
+  const double* tendon_invweight0;  /* ntendon                                                     */
+  const int32_t* exclude_signature; /* nexclude: (body1 << 16) + body2, body1 < body2 (mjModel)    */
+  const int32_t* body_weldid;       /* nbody: the body this one is welded to (mjModel.body_weldid) */
+  const double* key_mpos;           /* nkey x nmocap x 3 (Humanoid tracking residual)              */
 } mjpcx_model;
 
+/* moving-geom pairs (self-collision) are built for sphere and capsule geoms; other pairs are skipped */
 enum { MJPCX_GEOM_PLANE = 0, MJPCX_GEOM_SPHERE = 2, MJPCX_GEOM_CAPSULE = 3, MJPCX_GEOM_CYLINDER = 5, MJPCX_GEOM_BOX = 6 };
 
 /* ---- task / cost specification (mjpc::Task after Task::Reset,

@@ -555,6 +555,8 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       const char* force = getenv("MJPCX_CONTACT_KERNEL");
       const bool simt = force && std::string(force) == "simt";
       if (simt) {
+        if (c->wh.m.ntendon > 0 || c->wh.m.npair > 0 || c->wh.m.cone != 1)
+          return fail(c, MJPCX_EUNSUPPORTED, "the lane-per-candidate experiment covers elliptic cones and static-vs-moving contacts only");
         const SimtLayout lay = simt_layout(c->wh.m.nq, c->wh.m.nv, c->wh.m.nu, c->wh.m.nbody, c->wh.m.njnt, c->wh.m.nsite, wt.nr, P);
         const int nblk = (N + 63) / 64;
         if (lay.total > kSimtPrivateDoubles) return fail(c, MJPCX_EUNSUPPORTED, "model state exceeds the lane kernel's private segment");
@@ -665,6 +667,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     }
     needs_wave |= st && dy;
   }
+  for (int k = 0; k < m->ntendon; k++) needs_wave |= m->tendon_limited[k] != 0;
   if (needs_wave) {
     if (precision != 64) return bad(MJPCX_EUNSUPPORTED, "the wavefront-per-candidate kernel is fp64 only for now");
     for (int j = 0; j < m->njnt; j++)
@@ -692,6 +695,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     return MJPCX_OK;
   }
   if (m->nq != m->nv || m->njnt != m->nv) return bad(MJPCX_EUNSUPPORTED, "only slide/hinge joints are implemented (nq == nv == njnt)");
+  if (m->ntendon > 0) return bad(MJPCX_EUNSUPPORTED, "tendons are only implemented in the wavefront-per-candidate kernel (limited fixed tendons)");
   if (m->nbody > kLaneMaxBody || m->nv > kLaneMaxDof || m->nu > kLaneMaxAct || m->nsite > kLaneMaxSite ||
       m->nmocap > kLaneMaxMocap || t->num_term > kLaneMaxTerm || t->num_parameter > kLaneMaxParam)
     return bad(MJPCX_EUNSUPPORTED, "model exceeds the small-model kernel capacity");

@@ -34,11 +34,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 struct WaveContact {
   int g1, g2, dim, dim0, efc;
-  unsigned dofmask;  // dofs with a non-zero Jacobian column (the chain of the moving body)
+  int nrow;          // rows built: dim (frictionless / elliptic) or up to 2 (dim0 - 1) pyramid edges
+  unsigned dofmask;  // dofs with a non-zero Jacobian column (the chains of the two bodies, minus their common part)
   double dist, margin, includemargin, mu;
   double pos[3], frame[9], friction[5], solref[2], solimp[5];
 };
-enum { kEfcFriction = 0, kEfcLimit = 1, kEfcNormal = 2, kEfcElliptic = 3, kEfcConeRow = 4 };
+enum { kEfcFriction = 0, kEfcLimit = 1, kEfcNormal = 2, kEfcElliptic = 3, kEfcConeRow = 4, kEfcTendon = 5, kEfcPyramid = 6 };
 enum { kZoneTop = 0, kZoneMiddle = 1, kZoneBottom = 2 };
 
 // LDS state of one candidate ("mjData")

@@ -461,7 +461,7 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
     WSYNC();
     if (cnt > 0) {
       WaveContact proto;
-      proto.g1 = g1; proto.g2 = g2; proto.efc = 0; proto.mu = 0;
+      proto.g1 = g1; proto.g2 = g2; proto.efc = 0; proto.mu = 0; proto.nrow = 0;
       wf_contact_param(m, g1, g2, proto);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -470,6 +470,106 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
           WaveContact c = proto;
           c.dist = cd[k];
           for (int e = 0; e < 3; e++) { c.pos[e] = cp[k][e]; c.frame[e] = cn[e]; }
+          w_make_frame(c.frame);
+          d.con[at] = c;
+        }
+      }
+    }
+    if (lane == 0) {
+      const int n = base + total;
+      if (n > kWaveMaxCon) d.counters[2] |= 32;
+      d.counters[0] = n > kWaveMaxCon ? kWaveMaxCon : n;
+    }
+    WSYNC();
+  }
+  // moving-geom pairs (sphere | capsule; oracle: pair_collide): one lane per baked pair, up to two contacts each
+  for (int p0 = 0; p0 < m.npair; p0 += 64) {
+    const bool on = p0 + lane < m.npair;
+    const int g1 = on ? m.pair_g1[p0 + lane] : 0, g2 = on ? m.pair_g2[p0 + lane] : 0;
+    double cd[2] = {0, 0}, cp[2][3] = {{0, 0, 0}, {0, 0, 0}}, cn[2][3] = {{1, 0, 0}, {1, 0, 0}};
+    int cnt = 0;
+    if (on) {
+      double p1[3], R1[9], p2[3], R2[9];
+      wf_geom_pose(m, d, g1, p1, R1);
+      wf_geom_pose(m, d, g2, p2, R2);
+      const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+      const double r1 = m.geom_size[3 * g1], r2 = m.geom_size[3 * g2];
+      const double margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
+      auto spheres = [&](const double* c1, const double* c2) {
+        double n[3], len = 0;
+        for (int k = 0; k < 3; k++) { n[k] = c2[k] - c1[k]; len += n[k] * n[k]; }
+        len = sqrt(len);
+        if (len < kMinVal) { n[0] = 1; n[1] = n[2] = 0; } else for (int k = 0; k < 3; k++) n[k] /= len;
+        const double dist = len - r1 - r2;
+        if (dist < margin) {
+          if (cnt == 0) { cd[0] = dist; for (int k = 0; k < 3; k++) { cp[0][k] = c1[k] + n[k] * (r1 + 0.5 * dist); cn[0][k] = n[k]; } }
+          else { cd[1] = dist; for (int k = 0; k < 3; k++) { cp[1][k] = c1[k] + n[k] * (r1 + 0.5 * dist); cn[1][k] = n[k]; } }
+          cnt++;
+        }
+      };
+      auto seg = [&](const double* p, const double* a, double h, const double* c) {
+        const double x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
+        return x < -h ? -h : (x > h ? h : x);
+      };
+      if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
+        spheres(p1, p2);
+      } else if (t1 == MJPCX_GEOM_SPHERE) {
+        const double a2[3] = {R2[2], R2[5], R2[8]};
+        const double x = seg(p2, a2, m.geom_size[3 * g2 + 1], p1);
+        const double c2[3] = {p2[0] + x * a2[0], p2[1] + x * a2[1], p2[2] + x * a2[2]};
+        spheres(p1, c2);
+      } else {
+        const double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
+        const double h1 = m.geom_size[3 * g1 + 1], h2 = m.geom_size[3 * g2 + 1];
+        const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+        const double mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
+        const double u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
+        const double v = a2[0] * dif[0] + a2[1] * dif[1] + a2[2] * dif[2];
+        const double det = 1.0 - mb * mb;
+        double c1[3], c2[3];
+        if (fabs(det) >= kMinVal) {
+          double x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
+          if (x1 > h1) { x1 = h1; x2 = v - mb * x1; } else if (x1 < -h1) { x1 = -h1; x2 = v - mb * x1; }
+          if (x2 > h2) { x2 = h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
+          else if (x2 < -h2) { x2 = -h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
+          for (int k = 0; k < 3; k++) { c1[k] = p1[k] + x1 * a1[k]; c2[k] = p2[k] + x2 * a2[k]; }
+          spheres(c1, c2);
+        } else {
+          for (int e = 0; e < 4 && cnt < 2; e++) {
+            const double sgn = (e & 1) ? -1.0 : 1.0;
+            if (e < 2) {
+              for (int k = 0; k < 3; k++) c1[k] = p1[k] + sgn * h1 * a1[k];
+              const double x2 = seg(p2, a2, h2, c1);
+              for (int k = 0; k < 3; k++) c2[k] = p2[k] + x2 * a2[k];
+            } else {
+              for (int k = 0; k < 3; k++) c2[k] = p2[k] + sgn * h2 * a2[k];
+              const double x1 = seg(p1, a1, h1, c2);
+              for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k];
+            }
+            spheres(c1, c2);
+          }
+        }
+      }
+    }
+    int below = 0, total = 0;
+    for (int k = 0; k < 2; k++) {
+      const unsigned long long b = __ballot(cnt > k);
+      below += __popcll(b & ((1ull << lane) - 1ull));
+      total += __popcll(b);
+    }
+    const int base = d.counters[0];
+    WSYNC();
+    if (cnt > 0) {
+      WaveContact proto;
+      proto.g1 = g1; proto.g2 = g2; proto.efc = 0; proto.mu = 0; proto.nrow = 0;
+      wf_contact_param(m, g1, g2, proto);
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int at = base + below + k;
+        if (k < cnt && at < kWaveMaxCon) {
+          WaveContact c = proto;
+          c.dist = cd[k];
+          for (int e = 0; e < 3; e++) { c.pos[e] = cp[k][e]; c.frame[e] = cn[k][e]; }
           w_make_frame(c.frame);
           d.con[at] = c;
         }
@@ -530,59 +630,100 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
     }
     nefc += __popcll(b0) + __popcll(b1);
   }
+  // fixed-tendon limits: one lane per tendon (constant Jacobian = the wrap coefficients)
+  {
+    bool on0 = false, on1 = false;
+    double dist0 = 0, dist1 = 0, margin = 0;
+    if (!(m.disableflags & MJPCX_DSBL_LIMIT) && lane < m.ntendon && m.tendon_limited[lane]) {
+      double value = 0;
+      for (int w = m.tendon_adr[lane]; w < m.tendon_adr[lane] + m.tendon_num[lane]; w++) value += m.wrap_prm[w] * d.qpos[m.jnt_qposadr[m.wrap_objid[w]]];
+      margin = m.tendon_margin[lane];
+      dist0 = -(m.tendon_range[2 * lane] - value);
+      dist1 = m.tendon_range[2 * lane + 1] - value;
+      on0 = dist0 < margin; on1 = dist1 < margin;
+    }
+    const unsigned long long b0 = __ballot(on0), b1 = __ballot(on1);
+    if (b0 | b1) {
+      const unsigned long long lower = (1ull << lane) - 1ull;
+      const int r0 = nefc + __popcll(b0 & lower) + __popcll(b1 & lower);
+      const int r1 = r0 + (on0 ? 1 : 0);
+      for (int side = 0; side < 2; side++) {
+        const int r = side ? r1 : r0;
+        if ((side ? on1 : on0) && r < kWaveMaxEfc) {
+          d.efc_type[r] = kEfcTendon; d.efc_id[r] = lane;
+          for (int w = m.tendon_adr[lane]; w < m.tendon_adr[lane] + m.tendon_num[lane]; w++)
+            d.efc_J[r * nv + m.jnt_dofadr[m.wrap_objid[w]]] = side ? -m.wrap_prm[w] : m.wrap_prm[w];
+          d.efc_pos[r] = side ? dist1 : dist0; d.efc_margin[r] = margin;
+        }
+      }
+      nefc += __popcll(b0) + __popcll(b1);
+    }
+  }
   if (nefc > kWaveMaxEfc) nefc = kWaveMaxEfc;
   WSYNC();
   // contacts: row ranges by a serial prefix over (<= 16) contacts, every lane computes the same numbers
   const int ncon = d.counters[0];
-  int my_efc = 0, my_dim = 0;
+  const bool pyramidal = m.cone != 1;
+  int my_efc = 0, my_rows = 0;
   {
     int at = nefc;
     for (int ci = 0; ci < ncon; ci++) {
-      int dim = d.con[ci].dim0;
-      if (dim > 1 && m.cone != 1) dim = 1;  // pyramidal cones are not built (oracle: warning 128)
-      const int fit = at + dim <= kWaveMaxEfc ? dim : (kWaveMaxEfc - at > 0 ? kWaveMaxEfc - at : 0);
-      if (ci == lane) { my_efc = at; my_dim = fit; }
+      const int dim = d.con[ci].dim0;
+      const int rows = (dim > 1 && pyramidal) ? 2 * (dim - 1) : dim;
+      const int fit = at + rows <= kWaveMaxEfc ? rows : (kWaveMaxEfc - at > 0 ? kWaveMaxEfc - at : 0);
+      if (ci == lane) { my_efc = at; my_rows = fit; }
       at += fit;
     }
     nefc = at;
   }
   if (lane < ncon) {
     WaveContact& c = d.con[lane];
-    int dim0 = c.dim0;
-    if (dim0 > 1 && m.cone != 1) { dim0 = 1; if (lane == 0) d.counters[2] |= 128; }
-    c.efc = my_efc; c.dim = my_dim;
-    c.dofmask = m.body_dofmask[m.geom_bodyid[c.g2]];
-    c.mu = c.friction[0] / sqrt(m.impratio > kMinVal ? m.impratio : 1.0);
-    for (int row = 0; row < my_dim; row++) {
+    const int dim0 = c.dim0;
+    const bool pyr = dim0 > 1 && pyramidal;
+    c.efc = my_efc; c.nrow = my_rows;
+    c.dim = pyr ? dim0 : my_rows;
+    c.dofmask = m.body_dofmask[m.geom_bodyid[c.g1]] ^ m.body_dofmask[m.geom_bodyid[c.g2]];  // common ancestors cancel exactly
+    c.mu = pyr ? c.friction[0] : c.friction[0] / sqrt(m.impratio > kMinVal ? m.impratio : 1.0);
+    for (int row = 0; row < my_rows; row++) {
       const int r = my_efc + row;
-      d.efc_type[r] = dim0 == 1 ? kEfcNormal : (row == 0 ? kEfcElliptic : kEfcConeRow);
+      d.efc_type[r] = pyr ? kEfcPyramid : (dim0 == 1 ? kEfcNormal : (row == 0 ? kEfcElliptic : kEfcConeRow));
       d.efc_id[r] = lane;
-      if (row == 0) { d.efc_pos[r] = c.dist; d.efc_margin[r] = c.includemargin; }
+      if (row == 0 || pyr) { d.efc_pos[r] = c.dist; d.efc_margin[r] = c.includemargin; }
     }
   }
   if (lane == 0) d.counters[1] = nefc;
   WSYNC();
-  // contact Jacobian rows: (row, dof) pairs over the lanes. geom1 is static -> only the moving body contributes.
+  // contact Jacobian rows: (row, dof) pairs over the lanes; J = J(body of geom2) - J(body of geom1) at the contact point
   for (int e = lane; e < nefc * nv; e += 64) {
     const int r = e / nv, k = e - r * nv;
     const int t = d.efc_type[r];
-    if (t != kEfcNormal && t != kEfcElliptic && t != kEfcConeRow) continue;
+    if (t != kEfcNormal && t != kEfcElliptic && t != kEfcConeRow && t != kEfcPyramid) continue;
     const WaveContact& c = d.con[d.efc_id[r]];
     const int row = r - c.efc;
-    int body = m.geom_bodyid[c.g2];
     double v = 0;
-    if ((m.body_dofmask[body] >> k) & 1u) {
+    if ((c.dofmask >> k) & 1u) {
+      const int b2 = m.geom_bodyid[c.g2];
+      const bool second = (m.body_dofmask[b2] >> k) & 1u;   // the dof is on exactly one of the two chains
+      const int body = second ? b2 : m.geom_bodyid[c.g1];
       const double* cd = d.cdof + 6 * k;
-      const double* ax = c.frame + 3 * (row < 3 ? row : row - 3);
-      if (row < 3) {
-        const double* com = d.subtree_com + 3 * m.body_rootid[body];
-        const double off[3] = {c.pos[0] - com[0], c.pos[1] - com[1], c.pos[2] - com[2]};
-        double lin[3];
-        cr3(lin, cd, off);
-        v = ax[0] * (cd[3] + lin[0]) + ax[1] * (cd[4] + lin[1]) + ax[2] * (cd[5] + lin[2]);
+      const double* com = d.subtree_com + 3 * m.body_rootid[body];
+      const double off[3] = {c.pos[0] - com[0], c.pos[1] - com[1], c.pos[2] - com[2]};
+      double lin[3];
+      cr3(lin, cd, off);
+      // axis j of the contact frame on the translational (j < 3) or rotational Jacobian of the point
+      auto along = [&](int j) {
+        const double* ax = c.frame + 3 * (j < 3 ? j : j - 3);
+        return j < 3 ? ax[0] * (cd[3] + lin[0]) + ax[1] * (cd[4] + lin[1]) + ax[2] * (cd[5] + lin[2])
+                     : ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
+      };
+      if (t == kEfcPyramid) {
+        const int j = 1 + row / 2;
+        const double f = (row & 1) ? -c.friction[j - 1] : c.friction[j - 1];
+        v = along(0) + f * along(j);
       } else {
-        v = ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
+        v = along(row);
       }
+      if (!second) v = -v;
     }
     d.efc_J[r * nv + k] = v;
   }
@@ -597,10 +738,17 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
     double diag;
     if (type == kEfcFriction) { solref = m.dof_solref + 2 * id; solimp = m.dof_solimp + 5 * id; diag = m.dof_invweight0[id]; }
     else if (type == kEfcLimit) { solref = m.jnt_solref + 2 * id; solimp = m.jnt_solimp + 5 * id; diag = m.dof_invweight0[m.jnt_dofadr[id]]; }
+    else if (type == kEfcTendon) { solref = m.tendon_solref_lim + 2 * id; solimp = m.tendon_solimp_lim + 5 * id; diag = m.tendon_invweight0[id]; }
     else {
       const WaveContact& c = d.con[id];
       solref = c.solref; solimp = c.solimp;
-      diag = m.body_invweight0[2 * m.geom_bodyid[c.g1]] + m.body_invweight0[2 * m.geom_bodyid[c.g2]];
+      const int b1 = m.geom_bodyid[c.g1], b2 = m.geom_bodyid[c.g2];
+      diag = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+      if (type == kEfcPyramid) {  // mj_diagApprox: tran + friction^2 * (tran | rot)
+        const int j = 1 + (r - c.efc) / 2;
+        const double f = c.friction[j - 1];
+        diag += f * f * (j < 3 ? diag : m.body_invweight0[2 * b1 + 1] + m.body_invweight0[2 * b2 + 1]);
+      }
     }
 #pragma unroll 6
     for (int k = 0; k < nv; k++) vel += d.efc_J[r * nv + k] * d.qvel[k];
@@ -615,6 +763,7 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
     }
   }
   WSYNC();
+  double Rpy = 0;
   if (lane < nefc && type == kEfcConeRow) {
     const int r = lane;
     const WaveContact& c = d.con[id];
@@ -622,7 +771,13 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
     d.efc_R[r] = d.efc_R[c.efc] * (c.mu * c.mu) / (f * f);
     d.efc_aref[r] = -bb * vel;
     d.efc_D[r] = 1.0 / d.efc_R[r];
+  } else if (lane < nefc && type == kEfcPyramid) {  // every edge: Rpy = 2 mu^2 R of the first edge (read, sync, then write)
+    const WaveContact& c = d.con[id];
+    Rpy = 2 * c.mu * c.mu * d.efc_R[c.efc];
+    if (Rpy < kMinVal) Rpy = kMinVal;
   }
+  WSYNC();
+  if (lane < nefc && type == kEfcPyramid) { d.efc_R[lane] = Rpy; d.efc_D[lane] = 1.0 / Rpy; }
   WSYNC();
 }
 
@@ -649,7 +804,7 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
     if (x <= -R * f) { cost = -0.5 * R * f * f - f * x; g1 = -f * v; if (write_force) { d.efc_force[r] = f; d.efc_zone[r] = kZoneTop; } }
     else if (x >= R * f) { cost = -0.5 * R * f * f + f * x; g1 = f * v; if (write_force) { d.efc_force[r] = -f; d.efc_zone[r] = kZoneTop; } }
     else { cost = 0.5 * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
-  } else if (type == kEfcLimit || type == kEfcNormal) {
+  } else if (type == kEfcLimit || type == kEfcNormal || type == kEfcTendon || type == kEfcPyramid) {
     if (x < 0) { cost = 0.5 * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
     else if (write_force) { d.efc_force[r] = 0; d.efc_zone[r] = kZoneTop; }
   } else if (type == kEfcElliptic) {
@@ -799,7 +954,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       const WaveContact& c = d.con[lane];
       const int r = c.efc, dim = c.dim;
       double* Hs = d.coneH + 21 * lane;
-      if (dim > 0 && d.efc_type[r] == kEfcElliptic) {
+      if (c.nrow > 0 && dim > 0 && d.efc_type[r] == kEfcElliptic) {
         // lower triangle only, unrolled to dimension 6 with guards (register-resident)
         const int zone = d.efc_zone[r];
         const double mu = c.mu;
@@ -865,12 +1020,15 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       for (int r = first_contact; r < ne; r++) {
         const int t = d.efc_type[r];
         const int ci = d.efc_id[r];
+        if (t != kEfcElliptic) {  // simple inequality rows: frictionless contact, pyramid edge, tendon limit
+          const unsigned mask = t == kEfcTendon ? m.tendon_dofmask[ci] : d.con[ci].dofmask;
+          if ((mask & need) == need && d.efc_zone[r] == kZoneBottom) h += d.efc_D[r] * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
+          continue;
+        }
         const WaveContact& c = d.con[ci];
         const int dim = c.dim;
         if ((c.dofmask & need) == need) {
-          if (t == kEfcNormal) {
-            if (d.efc_zone[r] == kZoneBottom) h += d.efc_D[r] * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
-          } else if (t == kEfcElliptic && d.efc_zone[r] != kZoneTop) {
+          if (d.efc_zone[r] != kZoneTop) {
             const double* Hs = d.coneH + 21 * ci;
             double Ja[6], Jb[6], Hl[21];  // fully unrolled with guards: static indices keep these in registers
 #pragma unroll

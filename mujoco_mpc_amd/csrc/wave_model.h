@@ -17,7 +17,7 @@
 
 namespace mjpcx {
 
-constexpr int kWaveMaxBody = 32, kWaveMaxDof = 32, kWaveMaxGeom = 64, kWaveMaxLevel = 16;
+constexpr int kWaveMaxBody = 64, kWaveMaxDof = 32, kWaveMaxGeom = 64, kWaveMaxLevel = 16;
 constexpr int kWaveMaxCon = 16;   // contacts kept per step (further ones are dropped, as in the oracle)
 constexpr int kWaveMaxEfc = 64;   // constraint rows kept per step
 
@@ -39,6 +39,11 @@ struct WaveModel {
   const int *geom_type, *geom_bodyid, *geom_contype, *geom_conaffinity, *geom_condim, *geom_priority, *geom_group;
   const double *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_solmix;
   const double* key_qpos;
+  const double* key_mpos;                       // nkey x nmocap x 3 (Humanoid tracking residual); stays in HBM / L2
+  int ntendon;                                  // fixed tendons (limits)
+  const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
+  const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
+  const unsigned* tendon_dofmask;               // baked: dofs a tendon's Jacobian touches
   // ---- baked helpers (host-computed once)
   const unsigned long long* body_subtree_mask;  // bit j: body j is in the subtree rooted at body i (incl. i)
   const unsigned* body_dofmask;                 // bit k: dof k is on the chain from body i to the root
@@ -48,6 +53,8 @@ struct WaveModel {
   const int* static_geom;                       // collidable geoms on bodies without dofs (world, mocap), model order
   const int* dynamic_geom;                      // collidable geoms on moving bodies, model order
   int nstatic_geom, ndynamic_geom;
+  const int *pair_g1, *pair_g2;                 // moving-geom pairs that pass MuJoCo's body filters (oracle: bake_pairs)
+  int npair;
   int full;                                     // 1: rows beyond joint limits can occur (Newton path of the oracle)
   const int* ray_geom;                          // geoms of group 0 a downward ray can hit (plane / sphere / box), model order
   int nray_geom;
@@ -65,7 +72,9 @@ struct WaveModel {
   X(site_quat) X(actuator_trnid) X(actuator_biastype) X(actuator_ctrllimited) X(actuator_forcelimited) X(actuator_gear)   \
   X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange) X(geom_type) X(geom_bodyid)        \
   X(geom_contype) X(geom_conaffinity) X(geom_condim) X(geom_priority) X(geom_group) X(geom_size) X(geom_pos) X(geom_quat) \
-  X(geom_friction) X(geom_solref) X(geom_solimp) X(geom_margin) X(geom_gap) X(geom_solmix) X(key_qpos)                    \
+  X(geom_friction) X(geom_solref) X(geom_solimp) X(geom_margin) X(geom_gap) X(geom_solmix) X(key_qpos) X(key_mpos)        \
+  X(tendon_adr) X(tendon_num) X(tendon_limited) X(wrap_objid) X(wrap_prm) X(tendon_range) X(tendon_margin)                \
+  X(tendon_solref_lim) X(tendon_solimp_lim) X(tendon_invweight0) X(tendon_dofmask) X(pair_g1) X(pair_g2)                  \
   X(body_subtree_mask) X(body_dofmask) X(level_body) X(static_geom) X(dynamic_geom) X(ray_geom)
 
 // Per-plan task values: one small blob re-staged with every rollout (Planner::SetState + the frozen ResidualFn copy)
@@ -132,6 +141,11 @@ struct WaveHost {
     D(geom_size, 3 * ng); D(geom_pos, 3 * ng); D(geom_quat, 4 * ng); D(geom_friction, 3 * ng); D(geom_solref, 2 * ng); D(geom_solimp, 5 * ng);
     D(geom_margin, ng); D(geom_gap, ng); D(geom_solmix, ng);
     D(key_qpos, (size_t)src->nkey * src->nq);
+    if (src->key_mpos) D(key_mpos, (size_t)src->nkey * src->nmocap * 3); else reg(&m.key_mpos, nullptr, 0);
+    const int nt = src->ntendon, nw = src->nwrap;
+    m.ntendon = nt;
+    I(tendon_adr, nt); I(tendon_num, nt); I(tendon_limited, nt); I(wrap_objid, nw);
+    D(wrap_prm, nw); D(tendon_range, 2 * nt); D(tendon_margin, nt); D(tendon_solref_lim, 2 * nt); D(tendon_solimp_lim, 5 * nt); D(tendon_invweight0, nt);
 #undef I
 #undef D
     for (int i = 0; i < nv; i++) m.any_damping |= src->dof_damping[i] > 0;
@@ -166,6 +180,36 @@ struct WaveHost {
     if ((int)dg.size() > 64) return "more than 64 collidable geoms on moving bodies";
     m.nstatic_geom = (int)sg.size(); m.ndynamic_geom = (int)dg.size();
     m.full = any_floss || (!sg.empty() && !dg.empty() && !(src->disableflags & MJPCX_DSBL_CONTACT));
+    std::vector<unsigned> tmask(nt > 0 ? nt : 1, 0u);
+    for (int t = 0; t < nt; t++) {
+      m.full |= src->tendon_limited[t] != 0;
+      for (int w = src->tendon_adr[t]; w < src->tendon_adr[t] + src->tendon_num[t]; w++) tmask[t] |= 1u << src->jnt_dofadr[src->wrap_objid[w]];
+    }
+    reg(&m.tendon_dofmask, tmask.data(), sizeof(unsigned) * (size_t)nt);
+    // moving-geom pairs (sphere | capsule) after MuJoCo's body filters; canonical order = lower geom type first
+    std::vector<int> pg1, pg2;
+    if (src->body_weldid)
+      for (int a = 0; a < ng; a++)
+        for (int b = a + 1; b < ng; b++) {
+          if (dofmask[src->geom_bodyid[a]] == 0 || dofmask[src->geom_bodyid[b]] == 0) continue;
+          const int ta = src->geom_type[a], tb = src->geom_type[b];
+          if ((ta != MJPCX_GEOM_SPHERE && ta != MJPCX_GEOM_CAPSULE) || (tb != MJPCX_GEOM_SPHERE && tb != MJPCX_GEOM_CAPSULE)) continue;
+          if (!((src->geom_contype[a] & src->geom_conaffinity[b]) || (src->geom_contype[b] & src->geom_conaffinity[a]))) continue;
+          const int b1 = src->geom_bodyid[a], b2 = src->geom_bodyid[b];
+          const int w1 = src->body_weldid[b1], w2 = src->body_weldid[b2];
+          if (w1 == w2) continue;
+          const int pw1 = src->body_weldid[src->body_parentid[w1]], pw2 = src->body_weldid[src->body_parentid[w2]];
+          if (w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
+          const int sig = ((b1 < b2 ? b1 : b2) << 16) + (b1 < b2 ? b2 : b1);
+          bool excluded = false;
+          for (int e = 0; e < src->nexclude; e++) excluded |= src->exclude_signature[e] == sig;
+          if (excluded) continue;
+          pg1.push_back(ta > tb ? b : a);
+          pg2.push_back(ta > tb ? a : b);
+        }
+    m.npair = (int)pg1.size();
+    reg(&m.pair_g1, pg1.data(), sizeof(int) * pg1.size());
+    reg(&m.pair_g2, pg2.data(), sizeof(int) * pg2.size());
     for (int j = 0; j < nj; j++) m.full |= src->jnt_type[j] == MJPCX_JNT_FREE || src->jnt_type[j] == MJPCX_JNT_BALL;
     reg(&m.body_subtree_mask, sub.data(), sizeof(unsigned long long) * nb);
     reg(&m.body_dofmask, dofmask.data(), sizeof(unsigned) * nb);

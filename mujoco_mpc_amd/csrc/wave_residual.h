@@ -259,8 +259,60 @@ __device__ __forceinline__ void wr_quadruped(const WaveModel& m, const WaveTask&
   WSYNC();
 }
 
+// ---- mjpc::humanoid::Tracking::ResidualFn::Residual (mjpc/tasks/humanoid/tracking/tracking.cc:94-216; oracle/humanoid.inc).
+// residual_int = [first key, last key, 16 tracking-site ids, 16 mocap ids], residual_real = [reference_time].
+// Lanes 0..15: one marker each (interpolated keyframe position, site position and linear velocity); the averages are
+// wave reductions in the oracle's summation order (serial over the 16 markers).
+__device__ __forceinline__ void wr_humanoid_track(const WaveModel& m, const WaveTask& tk, WaveData& d, double time, int lane) {
+  const int* ri = reinterpret_cast<const int*>(tk.blob + tk.off_rint);
+  const double ref_time = tk.blob[tk.off_rreal];
+  const int start = ri[0], last = ri[1];
+  const double kFps = 30.0;
+  const double index = (time - ref_time) * kFps + start;
+  const double clamped = index < 0.0 ? 0.0 : (index > (double)last ? (double)last : index);
+  const int k0 = (int)floor(clamped);
+  const int k1 = k0 + 1 < last ? k0 + 1 : last;
+  const double w1 = clamped - k0, w0 = 1.0 - w1;
+  double* r = d.residual;
+  const int nj = m.nv - 6;
+  if (lane < nj) r[lane] = d.qvel[6 + lane];
+  if (lane < m.nu) r[nj + lane] = d.ctrl[lane];
+  double mp[3] = {0, 0, 0}, sp[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+  if (lane < 16) {
+    const int site = ri[2 + lane], mc = ri[18 + lane];
+    const double* key0 = m.key_mpos + ((size_t)m.nmocap * k0 + mc) * 3;
+    const double* key1 = m.key_mpos + ((size_t)m.nmocap * k1 + mc) * 3;
+    const int body = m.site_bodyid[site];
+    const double* cv = d.cvel + 6 * body;
+    const double* com = d.subtree_com + 3 * m.body_rootid[body];
+    double off[3], lin[3];
+    for (int k = 0; k < 3; k++) { sp[k] = d.site_xpos[3 * site + k]; off[k] = sp[k] - com[k]; }
+    cr3(lin, cv, off);
+    for (int k = 0; k < 3; k++) {
+      double v = key0[k] * w0;
+      v += key1[k] * w1;
+      mp[k] = v;
+      dv[k] = (key1[k] - key0[k]) * kFps - (cv[3 + k] + lin[k]);
+    }
+  }
+  // averages: serial sums over the 16 markers, as the reference accumulates them
+  double am[3] = {0, 0, 0}, as[3] = {0, 0, 0};
+  for (int b = 0; b < 16; b++)
+    for (int k = 0; k < 3; k++) { am[k] += __shfl(mp[k], b, 64); as[k] += __shfl(sp[k], b, 64); }
+  for (int k = 0; k < 3; k++) { am[k] *= 1.0 / 16; as[k] *= 1.0 / 16; }
+  const int c = nj + m.nu;
+  if (lane < 3) r[c + lane] = am[lane] - as[lane];
+  if (lane < 16)
+    for (int k = 0; k < 3; k++) {
+      r[c + 3 + 3 * lane + k] = (mp[k] - am[k]) - (sp[k] - as[k]);
+      r[c + 51 + 3 * lane + k] = dv[k];
+    }
+  WSYNC();
+}
+
 __device__ __forceinline__ void wr_residual(const WaveModel& m, const WaveTask& tk, WaveData& d, double time, int lane) {
   if (tk.residual_id == MJPCX_RESIDUAL_QUADRUPED_FLAT) { wr_quadruped(m, tk, d, time, lane); return; }
+  if (tk.residual_id == MJPCX_RESIDUAL_HUMANOID_TRACK) { wr_humanoid_track(m, tk, d, time, lane); return; }
   for (int i = lane; i < tk.nr; i += 64) d.residual[i] = 0;
   WSYNC();
 }

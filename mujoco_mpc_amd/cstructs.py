@@ -35,6 +35,11 @@ _MODEL_FIELDS = (
     + [(n, c_f64p) for n in ("geom_size", "geom_pos", "geom_quat", "geom_friction", "geom_solref", "geom_solimp",
                              "geom_margin", "geom_gap", "geom_solmix", "body_invweight0", "body_subtreemass",
                              "dof_solref", "dof_solimp", "key_qpos")]
+    + [(n, C.c_int32) for n in ("ntendon", "nwrap", "nexclude")]
+    + [(n, c_i32p) for n in ("tendon_adr", "tendon_num", "tendon_limited", "wrap_objid")]
+    + [(n, c_f64p) for n in ("wrap_prm", "tendon_range", "tendon_margin", "tendon_solref_lim", "tendon_solimp_lim",
+                             "tendon_invweight0")]
+    + [("exclude_signature", c_i32p), ("body_weldid", c_i32p), ("key_mpos", c_f64p)]
 )
 
 

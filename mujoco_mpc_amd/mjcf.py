@@ -566,6 +566,53 @@ class _Compiler:
             site_quat=np.array([s["quat"] for s in self.sites], float).reshape(-1, 4), **A)
         scal.update(nq=nq, nv=nv, nu=nu, na=0, nbody=nb, njnt=nj, nsite=len(self.sites), nmocap=nmocap, nuserdata=0, ngeom=ng)
 
+        # ---- fixed tendons (joint wraps only), contact excludes, weld ids
+        tend = []
+        for sec in root.findall("tendon"):
+            for e in sec:
+                if e.tag != "fixed":
+                    raise NotImplementedError(f"tendon <{e.tag}> (only fixed tendons are supported)")
+                ta = self.defaults.resolve("tendon", e.get("class"))
+                ta.update(e.attrib)
+                wraps = [(joint_names.index(w.get("joint")), float(w.get("coef"))) for w in e.findall("joint")]
+                tend.append((ta, wraps))
+        nt = len(tend)
+        T = dict(tendon_adr=np.zeros(nt, np.int32), tendon_num=np.zeros(nt, np.int32), tendon_limited=np.zeros(nt, np.int32),
+                 wrap_objid=[], wrap_prm=[], tendon_range=np.zeros((nt, 2)), tendon_margin=np.zeros(nt),
+                 tendon_solref_lim=np.tile(DEFAULT_SOLREF, (nt, 1)).astype(float).reshape(nt, 2),
+                 tendon_solimp_lim=np.tile(DEFAULT_SOLIMP, (nt, 1)).astype(float).reshape(nt, 5),
+                 tendon_invweight0=np.zeros(nt))
+        tendon_names = []
+        for i, (ta, wraps) in enumerate(tend):
+            tendon_names.append(ta.get("name", ""))
+            T["tendon_adr"][i] = len(T["wrap_objid"]); T["tendon_num"][i] = len(wraps)
+            for jid, coef in wraps:
+                T["wrap_objid"].append(jid); T["wrap_prm"].append(coef)
+            if "range" in ta:
+                T["tendon_range"][i] = _floats(ta["range"], 2)
+            lim = ta.get("limited", "auto")
+            T["tendon_limited"][i] = 1 if lim == "true" else (0 if lim == "false" else int(self.autolimits and "range" in ta))
+            T["tendon_margin"][i] = float(ta.get("margin", 0))
+            if "solreflimit" in ta:
+                T["tendon_solref_lim"][i] = _floats(ta["solreflimit"], 2)
+            if "solimplimit" in ta:
+                v = _floats(ta["solimplimit"]); T["tendon_solimp_lim"][i, :len(v)] = v
+        T["wrap_objid"] = np.array(T["wrap_objid"], np.int32); T["wrap_prm"] = np.array(T["wrap_prm"], float)
+        body_names = [b["name"] for b in self.bodies]
+        excl = []
+        for sec in root.findall("contact"):
+            for e in sec:
+                if e.tag == "exclude":
+                    b1, b2 = body_names.index(e.get("body1")), body_names.index(e.get("body2"))
+                    excl.append((min(b1, b2) << 16) + max(b1, b2))
+                elif e.tag == "pair":
+                    raise NotImplementedError("explicit contact pairs")
+        weld = np.zeros(nb, np.int32)
+        for i in range(1, nb):
+            weld[i] = i if body_dofnum[i] > 0 else weld[body_parentid[i]]
+        arrays.update(T, exclude_signature=np.array(excl, np.int32), body_weldid=weld)
+        scal.update(ntendon=nt, nwrap=len(T["wrap_objid"]), nexclude=len(excl))
+
         # ---- custom, sensors, keyframes
         numeric, text = {}, {}
         for sec in root.findall("custom"):
@@ -599,8 +646,12 @@ class _Compiler:
         scal["nkey"] = len(keyframes)
         arrays["key_qpos"] = (np.array([k["qpos"] for k in keyframes.values()], float).reshape(len(keyframes), nq)
                               if keyframes else np.zeros((0, nq)))
+        arrays["key_qvel"] = (np.array([k["qvel"] for k in keyframes.values()], float).reshape(len(keyframes), nv)
+                              if keyframes else np.zeros((0, nv)))
+        arrays["key_mpos"] = (np.array([k.get("mpos", np.zeros(3 * nmocap)) for k in keyframes.values()], float).reshape(len(keyframes), 3 * nmocap)
+                              if keyframes and nmocap else np.zeros((0, 3 * nmocap)))
         names = dict(body=[b["name"] for b in self.bodies], joint=joint_names, geom=self.geom_names,
-                     key=list(keyframes.keys()),
+                     key=list(keyframes.keys()), tendon=tendon_names,
                      site=[s["name"] for s in self.sites], actuator=act_names,
                      sensor=[s["name"] for s in sensors])
         fm = FlatModel(arrays=arrays, scalars=scal, names=names, numeric=numeric, text=text,
@@ -746,6 +797,26 @@ def _set_const(fm: FlatModel):
             inv[d:d + 3] = inv[d:d + 3].mean()
     a["dof_invweight0"] = inv
     fm.scalars["meaninertia"] = float(np.mean(np.diag(M)))
+    # tendon_invweight0 = J M^-1 J' with the (constant) Jacobian of a fixed tendon
+    for t in range(fm.scalars.get("ntendon", 0)):
+        J = np.zeros(nv)
+        for w in range(a["tendon_adr"][t], a["tendon_adr"][t] + a["tendon_num"][t]):
+            J[a["jnt_dofadr"][a["wrap_objid"][w]]] = a["wrap_prm"][w]
+        a["tendon_invweight0"][t] = float(J @ Minv @ J)
+
+
+def attach_keyframes(fm: FlatModel, names, qpos, qvel, mpos):
+    """Keyframes that do not come from the XML (large tables converted to npz): same arrays a <keyframe> section fills."""
+    n = len(names)
+    fm.scalars["nkey"] = n
+    fm.arrays["key_qpos"] = np.asarray(qpos, float).reshape(n, fm.nq)
+    fm.arrays["key_qvel"] = np.asarray(qvel, float).reshape(n, fm.nv)
+    fm.arrays["key_mpos"] = np.asarray(mpos, float).reshape(n, 3 * fm.nmocap)
+    fm.names["key"] = list(names)
+    fm.keyframes.clear()
+    for i, k in enumerate(names):
+        fm.keyframes[k] = dict(qpos=fm.arrays["key_qpos"][i], qvel=fm.arrays["key_qvel"][i], ctrl=np.zeros(fm.nu),
+                               mpos=fm.arrays["key_mpos"][i])
 
 
 def load_xml(path: str) -> FlatModel:
@@ -788,7 +859,7 @@ def save_blob(fm: FlatModel, path: str):
 
     keys = list(fm.keyframes.items())
     put_i("sizes", [sc["nq"], sc["nv"], nu, sc["na"], sc["nbody"], sc["njnt"], sc["nsite"], sc["nmocap"],
-                    sc["nuserdata"], nsens, fm.nuser_sensor, len(fm.numeric), len(fm.text), len(keys)])
+                    sc["nuserdata"], nsens, fm.nuser_sensor, len(fm.numeric), len(fm.text), int(sc["nkey"])])
     put_r("opt", [sc["timestep"], *sc["gravity"], sc["solver_tolerance"], sc["meaninertia"]])
     put_i("opt_int", [sc["integrator"], sc["solver_iterations"], sc["disableflags"], sc.get("cone", 0), sc.get("ngeom", 0)])
     put_r("opt_impratio", [sc.get("impratio", 1.0)])
@@ -832,8 +903,12 @@ def save_blob(fm: FlatModel, path: str):
     for k, v in fm.numeric.items():
         nadr.append(len(ndata)); nsize.append(len(v)); ndata += list(v)
     put_i("numeric_adr", nadr); put_i("numeric_size", nsize); put_r("numeric_data", ndata)
-    put_r("key_qpos", np.array([k[1]["qpos"] for k in keys]) if keys else np.zeros(0))
-    put_r("key_qvel", np.array([k[1]["qvel"] for k in keys]) if keys else np.zeros(0))
+    put_r("key_qpos", a["key_qpos"]); put_r("key_qvel", a["key_qvel"]); put_r("key_mpos", a["key_mpos"])
+    put_i("tendon_sizes", [sc.get("ntendon", 0), sc.get("nwrap", 0), sc.get("nexclude", 0)])
+    for k in ("tendon_adr", "tendon_num", "tendon_limited", "wrap_objid", "exclude_signature", "body_weldid"):
+        put_i(k, a[k])
+    for k in ("wrap_prm", "tendon_range", "tendon_margin", "tendon_solref_lim", "tendon_solimp_lim", "tendon_invweight0"):
+        put_r(k, a[k])
     put_i("name_bodyadr", name_table(fm.names["body"])); put_i("name_jntadr", name_table(fm.names["joint"]))
     put_i("name_siteadr", name_table(fm.names["site"])); put_i("name_sensoradr", name_table(fm.names["sensor"]))
     put_i("name_numericadr", name_table(list(fm.numeric.keys()))); put_i("name_keyadr", name_table([k[0] for k in keys]))

@@ -19,7 +19,7 @@ NORM_POWER_LOSS, NORM_SMOOTH_ABS, NORM_SMOOTH_ABS2, NORM_RECTIFY = 5, 6, 7, 8
 K_MAX_COST_TERMS = 128  # task.h:31
 K_MAX_TRACES = 99       # "Number of traces should be less than 100"
 
-RESIDUAL_PARTICLE, RESIDUAL_PARTICLE_COPY, RESIDUAL_CARTPOLE, RESIDUAL_QUADRUPED_FLAT = 1, 2, 3, 4
+RESIDUAL_PARTICLE, RESIDUAL_PARTICLE_COPY, RESIDUAL_CARTPOLE, RESIDUAL_QUADRUPED_FLAT, RESIDUAL_HUMANOID_TRACK = 1, 2, 3, 4, 5
 
 
 def norm_parameter_dimension(norm_type: int) -> int:
@@ -88,9 +88,10 @@ class Task:
         self.trace_site = []
         for i in range(self.num_trace):
             s = next((s for s in sensors if s["name"] == f"trace{i}"), None)
-            if s is None or s["type"] != "framepos" or s["objtype"] != "site":
-                raise TaskError(f"trace{i}: only framepos site sensors are supported")
-            self.trace_site.append(m.name2id("site", s["objname"]))
+            if s is None or s["type"] != "framepos" or s["objtype"] not in ("site", "body"):
+                raise TaskError(f"trace{i}: only framepos site / body sensors are supported")
+            # site id, or -1 - body id for a body frame (mjpcx_task::trace_site)
+            self.trace_site.append(m.name2id("site", s["objname"]) if s["objtype"] == "site" else -1 - m.name2id("body", s["objname"]))
         self.num_residual = 0
         self.dim_norm_residual, self.num_norm_parameter, self.norm = [], [], []
         self.weight, self.weight_names, self.norm_parameter = [], [], []
@@ -238,14 +239,75 @@ class QuadrupedFlat(Task):
                               *self.orientation, self.phase_start, self.phase_start_time, self.phase_velocity, *self.flip]
 
 
+class HumanoidTrack(Task):
+    """mjpc::humanoid::Tracking (mjpc/tasks/humanoid/tracking/tracking.{h,cc}): the residual follows CMU mocap keyframes
+    (`model.key_mpos`, 30 fps, linear interpolation); `transition` is TransitionLocked (:219-264). Frozen ResidualFn
+    state for the device: residual_int = [first key, last key, 16 tracking-site ids, 16 mocap ids], residual_real =
+    [reference_time] (csrc/wave_residual.h)."""
+    K_FPS = 30.0
+    MOTION_LENGTHS = [121, 154, 115, 78, 145, 188, 260, 279, 39, 510]   # kMotionLengths, tracking.cc:45-56
+    BODY_NAMES = ["pelvis", "head", "ltoe", "rtoe", "lheel", "rheel", "lknee", "rknee", "lhand", "rhand", "lelbow",
+                  "relbow", "lshoulder", "rshoulder", "lhip", "rhip"]           # tracking.cc:71-75
+
+    def reset(self):
+        super().reset()
+        m = self.model
+        if m.scalars["nkey"] == 0:   # the keyframe table travels as a compact npz next to the task XML
+            kf = np.load(os.path.join(os.path.dirname(m.source), "tracking_keyframes.npz"))
+            qpos = np.where(np.isnan(kf["qpos"]), np.asarray(m.arrays["qpos0"], float)[None, :], kf["qpos"])
+            mjcf.attach_keyframes(m, [str(n) for n in kf["names"]], qpos, kf["qvel"], kf["mpos"])
+        self.site_ids = [m.name2id("site", f"tracking[{n}]") for n in self.BODY_NAMES]
+        self.mocap_ids = [int(m.arrays["body_mocapid"][m.name2id("body", f"mocap[{n}]")]) for n in self.BODY_NAMES]
+        self.current_mode, self.reference_time = 0, 0.0
+        self._freeze()
+        return self
+
+    def motion_start(self, mode):
+        return int(sum(self.MOTION_LENGTHS[:mode]))
+
+    @staticmethod
+    def interpolation_values(index, max_index):
+        """ComputeInterpolationValues, tracking.cc:29-38."""
+        c = min(max(index, 0.0), float(max_index))
+        i0 = int(np.floor(c))
+        i1 = min(i0 + 1, max_index)
+        w1 = c - i0
+        return i0, i1, 1.0 - w1, w1
+
+    def transition(self, time, mode=None):
+        """TransitionLocked: returns the simulation-state edits the reference applies to mjData: always `mocap_pos`
+        [16, 3]; on a motion switch or at time 0 also `qpos` / `qvel` of the motion's first keyframe."""
+        mode = self.mode if mode is None else mode
+        m = self.model
+        start, length = self.motion_start(mode), self.MOTION_LENGTHS[mode]
+        edits = {}
+        if self.current_mode != mode or time == 0.0:
+            self.current_mode = mode
+            self.reference_time = time
+            edits["qpos"] = np.array(m.arrays["key_qpos"][start], float)
+            edits["qvel"] = np.array(m.arrays["key_qvel"][start], float)
+        self.mode = mode
+        i0, i1, w0, w1 = self.interpolation_values((time - self.reference_time) * self.K_FPS + start, start + length - 1)
+        mpos = np.asarray(m.arrays["key_mpos"], float)
+        edits["mocap_pos"] = (mpos[i0] * w0 + mpos[i1] * w1).reshape(-1, 3)
+        self._freeze()
+        return edits
+
+    def _freeze(self):
+        start = self.motion_start(self.current_mode)
+        self.residual_int = [start, start + self.MOTION_LENGTHS[self.current_mode] - 1, *self.site_ids, *self.mocap_ids]
+        self.residual_real = [self.reference_time]
+
+
 _REGISTRY = {
     # name -> (xml path under models/, residual id)
     "Cartpole": ("cartpole/task.xml", RESIDUAL_CARTPOLE),      # mjpc/tasks/cartpole/cartpole.cc
     "Particle": ("particle/task.xml", RESIDUAL_PARTICLE),      # mjpc/test/testdata/particle_residual.h
     "ParticleCopy": ("particle/task.xml", RESIDUAL_PARTICLE_COPY),  # mjpc/test/agent/rollout_test.cc:28-58
     "QuadrupedFlat": ("quadruped/task_flat.xml", RESIDUAL_QUADRUPED_FLAT),  # mjpc/tasks/quadruped/quadruped.cc
+    "HumanoidTrack": ("humanoid/tracking/task.xml", RESIDUAL_HUMANOID_TRACK),  # mjpc/tasks/humanoid/tracking/tracking.cc
 }
-_CLASSES = {"QuadrupedFlat": QuadrupedFlat}
+_CLASSES = {"QuadrupedFlat": QuadrupedFlat, "HumanoidTrack": HumanoidTrack}
 
 
 def task_names():

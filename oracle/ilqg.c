@@ -292,7 +292,7 @@ int orollout_feedback(const mjpcx_model* m, const mjpcx_task* task, const double
       if (last) o_forward_task(d, task, r); else o_step_task(d, task, r);
       if (out->residual) memcpy(out->residual + ((size_t)i * H + t) * nr, r, sizeof(double) * nr);
       for (int k = 0; k < ntr && out->trace; k++)
-        memcpy(out->trace + (((size_t)i * H + t) * ntr + k) * 3, odata_site_xpos(d) + 3 * task->trace_site[k], 3 * sizeof(double));
+        memcpy(out->trace + (((size_t)i * H + t) * ntr + k) * 3, odata_trace_point(d, task->trace_site[k]), 3 * sizeof(double));
       if (!last && odata_warning(d)) { failure = 1; break; }
       const double c = ocost_value(task, r);
       if (out->costs) out->costs[(size_t)i * H + t] = c;

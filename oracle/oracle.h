@@ -72,6 +72,7 @@ void o_step(OData* d);              /* mj_step    */
 void o_forward_task(OData* d, const mjpcx_task* task, double* residual);
 void o_step_task(OData* d, const mjpcx_task* task, double* residual);
 const double* odata_site_xpos(const OData* d);
+const double* odata_trace_point(const OData* d, int id);
 int odata_warning(const OData* d);  /* !=0: BADQPOS/BADQVEL/BADQACC/BADCTRL seen */
 /* introspection for tests: name in {"qpos","qvel","qacc","qacc_smooth","M",
  * "xpos","xquat","xmat","xipos","site_xpos","subtree_com","qfrc_bias",

@@ -36,6 +36,7 @@
 
 typedef struct OContact {
   int g1, g2, dim, efc;
+  int nrow; /* rows built: dim for a frictionless / elliptic contact, 2 (dim - 1) pyramid edges otherwise */
   double dist, margin, includemargin, mu;
   double pos[3], frame[9], friction[5], solref[2], solimp[5];
 } OContact;
@@ -61,6 +62,7 @@ struct OData {
   int full; /* 1: constraint rows beyond joint limits can occur -> Newton path */
   int ngeom, ncon, solver_iter;
   int* geom_static;
+  int npair; int *pair_g1, *pair_g2; /* moving-geom pairs that pass the body filters (baked once) */
   double *geom_xpos, *geom_xmat;
   OContact con[OMAXCON];
   int efc_type[OMAXEFC], efc_id[OMAXEFC], efc_zone[OMAXEFC];
@@ -177,6 +179,7 @@ void oresidual(const mjpcx_task* task, const OData* d, double* r);
 
 /* ------------------------------------------------------------------ lifetime */
 static int body_is_static(const mjpcx_model* m, int b);
+static void bake_pairs(OData* d);
 OData* odata_new(const mjpcx_model* m) {
   /* reject features this restatement does not cover */
   for (int j = 0; j < m->njnt; j++)
@@ -220,6 +223,8 @@ OData* odata_new(const mjpcx_model* m) {
     if (m->geom_contype[g] || m->geom_conaffinity[g]) { if (d->geom_static[g]) nstatic++; else ndynamic++; }
   }
   if (nstatic && ndynamic && !(m->disableflags & MJPCX_DSBL_CONTACT)) d->full = 1;
+  for (int t = 0; t < m->ntendon; t++) if (m->tendon_limited[t]) d->full = 1;
+  bake_pairs(d);
   for (int j = 0; j < m->njnt; j++) if (m->jnt_type[j] == MJPCX_JNT_FREE || m->jnt_type[j] == MJPCX_JNT_BALL) d->full = 1;
   /* subtree masses are model constants */
   for (int i = 0; i < nb; i++) d->subtree_mass[i] = m->body_mass[i];
@@ -244,7 +249,7 @@ void odata_free(OData* d) {
                   &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A, &d->geom_xpos, &d->geom_xmat, &d->scratch_jac,
                   &d->nw_jar, &d->nw_jv, &d->nw_grad, &d->nw_search, &d->nw_Ma, &d->nw_H, &d->nw_L, &d->qacc_warmstart};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
-  free(d->geom_static);
+  free(d->geom_static); free(d->pair_g1); free(d->pair_g2);
   free(d);
 }
 void odata_set_state(OData* d, const double* state, double time, const double* mocap,
@@ -750,6 +755,8 @@ void o_step_task(OData* d, const mjpcx_task* task, double* r) {
 }
 void o_step(OData* d) { o_step_task(d, NULL, NULL); }
 const double* odata_site_xpos(const OData* d) { return d->site_xpos; }
+/* GetTraces (utilities.cc:268-286): framepos of a site (id >= 0) or of a body frame (id = -1 - body) */
+const double* odata_trace_point(const OData* d, int id) { return id >= 0 ? d->site_xpos + 3 * id : d->xpos + 3 * (-1 - id); }
 
 /* ------------------------------------------------------------------ residuals */
 /* the ResidualFn::Residual overrides of the covered tasks */
@@ -772,12 +779,16 @@ static void o_subtree_linvel(const OData* d, int body, double out[3]) {
   for (int k = 0; k < 3; k++) out[k] = mass > OMINVAL ? mom[k] / mass : 0;
 }
 #include "quadruped.inc"
+#include "humanoid.inc"
 
 void oresidual(const mjpcx_task* task, const OData* d, double* r) {
   const mjpcx_model* m = d->m;
   switch (task->residual_id) {
     case MJPCX_RESIDUAL_QUADRUPED_FLAT:
       quadruped_residual(task, d, r);
+      break;
+    case MJPCX_RESIDUAL_HUMANOID_TRACK:
+      humanoid_track_residual(task, d, r);
       break;
     case MJPCX_RESIDUAL_PARTICLE: /* test/testdata/particle_residual.h:33-43 */
       for (int i = 0; i < m->nq; i++) r[i] = d->qpos[i];

@@ -40,7 +40,7 @@ static int rollout_core(const mjpcx_model* m, const mjpcx_task* task, OData* d, 
     o_step_task(d, task, r);
     if (out->residual) memcpy(out->residual + t * nr, r, sizeof(double) * nr);
     for (int k = 0; k < ntr && out->trace; k++) /* GetTraces, utilities.cc:268-286 */
-      memcpy(out->trace + (t * ntr + k) * 3, odata_site_xpos(d) + 3 * task->trace_site[k], 3 * sizeof(double));
+      memcpy(out->trace + (t * ntr + k) * 3, odata_trace_point(d, task->trace_site[k]), 3 * sizeof(double));
     if (odata_warning(d)) { /* CheckWarnings, trajectory.cc:169-173 */
       out->total_return = KMAX_RETURN;
       out->failure = 1;
@@ -65,7 +65,7 @@ static int rollout_core(const mjpcx_model* m, const mjpcx_task* task, OData* d, 
   o_forward_task(d, task, r);
   if (out->residual) memcpy(out->residual + (horizon - 1) * nr, r, sizeof(double) * nr);
   for (int k = 0; k < ntr && out->trace; k++)
-    memcpy(out->trace + ((horizon - 1) * ntr + k) * 3, odata_site_xpos(d) + 3 * task->trace_site[k], 3 * sizeof(double));
+    memcpy(out->trace + ((horizon - 1) * ntr + k) * 3, odata_trace_point(d, task->trace_site[k]), 3 * sizeof(double));
   double c = ocost_value(task, r);
   if (out->costs) out->costs[horizon - 1] = c;
   total += c;
