@@ -851,6 +851,11 @@ int odata_get(const OData* d, const char* name, double* out, int cap) {
     for (int i = 0; i < nb && n + 3 <= cap; i++) { o_subtree_linvel(d, i, out + n); n += 3; }
     return n;
   }
+  if (!strcmp(name, "pairs")) { /* baked moving-geom pairs: geom1, geom2 */
+    int n = 0;
+    for (int i = 0; i < d->npair && 2 * i + 1 < cap; i++) { out[2 * i] = d->pair_g1[i]; out[2 * i + 1] = d->pair_g2[i]; n = 2 * i + 2; }
+    return n;
+  }
   if (!strcmp(name, "nefc")) { double v = d->nefc; return put(out, cap, &v, 1); }
   if (!strcmp(name, "energy")) { /* [potential, kinetic] (mj_energyPos/Vel) */
     double e[2] = {0, 0};

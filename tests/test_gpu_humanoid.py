@@ -78,3 +78,37 @@ def test_later_frames_of_the_motion(walk):
     e = t.transition(0.4133, mode=8)   # between keys
     q = np.array(t.model.arrays["key_qpos"][t.motion_start(8)], float)
     run(t, np.concatenate([q, np.zeros(27)]), mocap7(e["mocap_pos"]), N=3, H=12, P=4, interp=1, seed=11, tol=1e-8, time=0.4133)
+
+
+def test_contact_feature_scene():
+    """tests/models/capsules_tendon.xml on the device: pyramidal sphere-plane contact, crossed and exactly parallel free
+    capsules (the two-contact branch), a limited fixed tendon; null residual (the cost is a dummy term)."""
+    import os
+    from mujoco_mpc_amd import mjcf
+    from mujoco_mpc_amd.task import Task
+    fm = mjcf.load_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "capsules_tendon.xml"))
+    task = Task(name="scene", residual_id=0, model=fm).reset()
+    q = fm.arrays["qpos0"].copy()
+    v = np.zeros(fm.nv)
+    q[14 + 2] = 1.0 + 0.0995      # rod_b just into rod_a
+    v[12 + 2] = -0.5
+    q[fm.nq - 2] = 0.6            # tendon beyond its upper limit
+    v[0] = 0.3                    # the puck slides/rolls
+    pm, pt = task.packed_model(), task.packed()
+    ctx = capi.Context(pm, pt, 0, 64)
+    assert "rollout_wave_kernel" in ctx.kernel_name
+    state = np.concatenate([q, v])
+    H, P, N = 60, 2, 2
+    times = np.array([0.0, 1.0])
+    nodes = np.zeros((N, P, 1))
+    nodes[1] = 0.5
+    ctx.set_state(state, 0.0, np.zeros(0))
+    ctx.rollout_splines(H, 0, times, nodes)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, np.zeros(0), N, H, P, 0, times, nodes, num_threads=2)
+    assert not fail.any() and not ref["failure"].any()
+    tr = ctx.fetch_trajectory(1)
+    assert close(tr.states, ref["states"][1], 1e-7), float(np.max(np.abs(tr.states - ref["states"][1])))
+    # something happened: the rods exchanged momentum and the tendon pushed the arm back
+    assert tr.states[-1, fm.nq + 6 + 2] < -0.05 and tr.states[-1, fm.nq - 2] < 0.6
+    ctx.close()
