@@ -118,21 +118,25 @@ def main():
     planner = HostPlanner(task, device=local_rank, precision=args.precision, seed=0,
                           num_trajectory=args.candidates * world,  # lifts kMaxTrajectory = 128
                           group=group, kind=args.planner)
-    if hasattr(task, "transition"):
-        planner.task_transition(0.0)
-    planner.reset(H)
-    P = planner.num_spline_points
-
     # synthetic initial condition: the task's home keyframe
     home = model.keyframes.get("home")
-    qpos = home["qpos"] if home else model.qpos0
-    qvel = home["qvel"] if home else np.zeros(model.nv)
+    qpos = np.array(home["qpos"] if home else model.qpos0, float)
+    qvel = np.array(home["qvel"] if home else np.zeros(model.nv), float)
     mocap_pos = mocap_quat = None
     if model.nmocap:  # mocap bodies at their model pose (State::Reset)
         ids = [b for b in range(model.nbody) if model.arrays["body_mocapid"][b] >= 0]
         ids.sort(key=lambda b: model.arrays["body_mocapid"][b])
-        mocap_pos = np.array([model.arrays["body_pos"][b] for b in ids])
-        mocap_quat = np.array([model.arrays["body_quat"][b] for b in ids])
+        mocap_pos = np.array([model.arrays["body_pos"][b] for b in ids], float)
+        mocap_quat = np.array([model.arrays["body_quat"][b] for b in ids], float)
+    if args.task == "HumanoidTrack":
+        # Task::Transition edits the simulation state: first keyframe of the motion, interpolated marker positions
+        mode = 9   # Walk
+        planner.task_transition_state(0.0, mode, qpos, qvel, mocap_pos.reshape(-1))
+        task.transition(0.0, mode)   # the Python mirror keeps the frozen residual state for the cpu_baseline leg
+    elif hasattr(task, "transition"):
+        planner.task_transition(0.0)
+    planner.reset(H)
+    P = planner.num_spline_points
     planner.set_state(qpos, qvel, 0.0, mocap_pos=mocap_pos, mocap_quat=mocap_quat)
 
     def step():
@@ -171,7 +175,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": (f"{args.task} Predictive Sampling, {args.candidates} candidates/GPU, horizon {H}, "
-                                    f"{P} cubic spline points, fp{args.precision} (BASELINE.json configs[1])") if args.planner == "sampling" else
+                                    f"{P} cubic spline points, fp{args.precision} " +
+                                    {"Cartpole": "(BASELINE.json configs[1])", "HumanoidTrack": "(BASELINE.json configs[3]: one GPU's 8192-candidate share, fp64 instead of fp32)"}.get(args.task, "")) if args.planner == "sampling" else
                                    (f"{args.task} Cross-Entropy, {args.candidates} candidates/GPU, horizon {H}, {P} zero-order spline "
                                     f"points, fp{args.precision} (BASELINE.json configs[2] at --task QuadrupedFlat --candidates 16384 --horizon 100)"),
                        "candidates_per_gpu": args.candidates, "horizon": H, "spline_points": P,

@@ -204,7 +204,7 @@ typedef struct mjpcx_task {
   const double* weight;              /* num_term */
   const double* norm_parameter;      /* sum(num_norm_parameter) */
   const double* parameters;          /* num_parameter (residual_* numerics) */
-  const int32_t* trace_site;         /* num_trace: site id of sensor "trace%i" */
+  const int32_t* trace_site;         /* num_trace: site id of sensor "trace%i", or -1 - body id for a body frame */
   double risk;                       /* Task::risk */
   /* task-specific frozen ResidualFn state (the members Transition manages and Reset resolves, e.g.
    * QuadrupedFlat::ResidualFn, quadruped.h:186-246); layout documented per residual in csrc/residuals.h */

@@ -56,6 +56,17 @@ FlatModel::FlatModel(const mjModel* m, double timestep, int integrator, bool dif
   f.geom_margin = m->geom_margin; f.geom_gap = m->geom_gap; f.geom_solmix = m->geom_solmix;
   f.body_invweight0 = m->body_invweight0; f.body_subtreemass = m->body_subtreemass;
   f.dof_solref = m->dof_solref; f.dof_solimp = m->dof_solimp; f.key_qpos = m->key_qpos;
+  // fixed tendons (mjWRAP_JOINT entries only), contact excludes, weld ids, mocap keyframes
+  f.ntendon = m->ntendon; f.nwrap = m->nwrap; f.nexclude = m->nexclude;
+  for (int w = 0; w < m->nwrap; w++)
+    if (m->wrap_type[w] != mjWRAP_JOINT) throw Error(MJPCX_EUNSUPPORTED, "spatial tendons are not supported by the device path");
+  tendon_limited_.assign(m->tendon_limited, m->tendon_limited + m->ntendon);
+  if (tendon_limited_.empty()) tendon_limited_.resize(1);
+  f.tendon_adr = m->tendon_adr; f.tendon_num = m->tendon_num; f.tendon_limited = tendon_limited_.data();
+  f.wrap_objid = m->wrap_objid; f.wrap_prm = m->wrap_prm; f.tendon_range = m->tendon_range; f.tendon_margin = m->tendon_margin;
+  f.tendon_solref_lim = m->tendon_solref_lim; f.tendon_solimp_lim = m->tendon_solimp_lim;
+  f.tendon_invweight0 = m->tendon_invweight0;
+  f.exclude_signature = m->exclude_signature; f.body_weldid = m->body_weldid; f.key_mpos = m->key_mpos;
   if (differentiable) {
     jnt_solimp_.assign(m->jnt_solimp, m->jnt_solimp + (size_t)mjNIMP * m->njnt);
     geom_solimp_.assign(m->geom_solimp, m->geom_solimp + (size_t)mjNIMP * m->ngeom);

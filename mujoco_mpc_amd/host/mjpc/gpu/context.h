@@ -29,7 +29,7 @@ class FlatModel {
 
  private:
   mjpcx_model flat_{};
-  std::vector<int32_t> jnt_limited_, trnid_, ctrllimited_, forcelimited_;
+  std::vector<int32_t> jnt_limited_, trnid_, ctrllimited_, forcelimited_, tendon_limited_;
   std::vector<double> gear_, gainprm_, biasprm_, jnt_solimp_, geom_solimp_;
 };
 

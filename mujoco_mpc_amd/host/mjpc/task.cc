@@ -107,8 +107,10 @@ void Task::Reset(const mjModel* model) {
     const char* name = model->names + model->name_sensoradr[i];
     if (!StartsWith(name, "trace")) continue;
     const int k = std::atoi(name + 5);
-    if (k >= 0 && k < num_trace && model->sensor_type[i] == mjSENS_FRAMEPOS && model->sensor_objtype[i] == mjOBJ_SITE)
-      trace_site[k] = model->sensor_objid[i];
+    if (k < 0 || k >= num_trace || model->sensor_type[i] != mjSENS_FRAMEPOS) continue;
+    // site id, or -1 - body id for the frame of a body (mjpcx_task::trace_site)
+    if (model->sensor_objtype[i] == mjOBJ_SITE) trace_site[k] = model->sensor_objid[i];
+    else if (model->sensor_objtype[i] == mjOBJ_BODY || model->sensor_objtype[i] == mjOBJ_XBODY) trace_site[k] = -1 - model->sensor_objid[i];
   }
   num_residual = 0;
   dim_norm_residual.assign(num_term, 0);

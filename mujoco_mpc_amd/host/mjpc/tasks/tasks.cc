@@ -1,5 +1,6 @@
 #include "tasks.h"
 
+#include "humanoid/tracking/tracking.h"
 #include "quadruped/quadruped.h"
 
 #include <cmath>
@@ -41,7 +42,7 @@ void ParticleCopyTestTask::ResidualFn::Residual(const mjModel* model, const mjDa
 
 std::vector<std::shared_ptr<Task>> GetTasks() {
   return {std::make_shared<Cartpole>(), std::make_shared<ParticleTestTask>(), std::make_shared<ParticleCopyTestTask>(),
-          std::make_shared<QuadrupedFlat>()};
+          std::make_shared<QuadrupedFlat>(), std::make_shared<humanoid::Tracking>()};
 }
 
 }  // namespace mjpc

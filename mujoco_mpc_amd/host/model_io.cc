@@ -108,6 +108,21 @@ void ModelStorage::Bind() {
   BR(geom_size, 3 * ng); BR(geom_pos, 3 * ng); BR(geom_quat, 4 * ng); BR(geom_friction, 3 * ng); BR(geom_solref, mjNREF * ng);
   BR(geom_solimp, mjNIMP * ng); BR(geom_margin, ng); BR(geom_gap, ng); BR(geom_solmix, ng);
   BI(name_geomadr, ng);
+  const int* ts = I("tendon_sizes", 3);
+  m.ntendon = ts[0]; m.nwrap = ts[1]; m.nexclude = ts[2];
+  const size_t nt = m.ntendon, nw = m.nwrap;
+  BI(tendon_adr, nt); BI(tendon_num, nt); BI(wrap_objid, nw); BI(exclude_signature, m.nexclude); BI(body_weldid, nb);
+  BR(wrap_prm, nw); BR(tendon_range, 2 * nt); BR(tendon_margin, nt); BR(tendon_solref_lim, mjNREF * nt);
+  BR(tendon_solimp_lim, mjNIMP * nt); BR(tendon_invweight0, nt);
+  {  // byte flags / wrap types as mjModel stores them (the blob carries int32 limited flags, joint wraps only)
+    const int* lim = I("tendon_limited", nt);
+    auto& lb = bytes_["tendon_limited"]; lb.assign(nt ? nt : 1, 0);
+    for (size_t i = 0; i < nt; i++) lb[i] = (unsigned char)lim[i];
+    m.tendon_limited = lb.data();
+    auto& wt = ints_["wrap_type"]; wt.assign(nw ? nw : 1, mjWRAP_JOINT);
+    m.wrap_type = wt.data();
+  }
+  BR(key_mpos, (size_t)m.nkey * 3 * m.nmocap);
   m.names = reinterpret_cast<char*>(B("names", 1));
 #undef BI
 #undef BR

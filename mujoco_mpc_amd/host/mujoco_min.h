@@ -19,6 +19,7 @@ enum mjtJoint { mjJNT_FREE = 0, mjJNT_BALL, mjJNT_SLIDE, mjJNT_HINGE };
 enum mjtSensor { mjSENS_USER = 100, mjSENS_FRAMEPOS = 25, mjSENS_OTHER = 0 };
 enum mjtObj { mjOBJ_BODY = 1, mjOBJ_XBODY = 2, mjOBJ_GEOM = 5, mjOBJ_SITE = 6, mjOBJ_KEY = 21 };
 enum mjtCone { mjCONE_PYRAMIDAL = 0, mjCONE_ELLIPTIC = 1 };
+enum mjtWrap { mjWRAP_NONE = 0, mjWRAP_JOINT = 1 };
 enum mjtBias { mjBIAS_NONE = 0, mjBIAS_AFFINE = 1 };
 
 struct mjOption {
@@ -37,9 +38,10 @@ struct mjStatistic {
 
 struct mjModel {
   int nq, nv, nu, na, nbody, njnt, nsite, nmocap, nuserdata, nsensor, nuser_sensor, nnumeric, ntext, nkey, ngeom;
+  int ntendon, nwrap, nexclude;
   mjOption opt;
   mjStatistic stat;
-  int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_mocapid;
+  int *body_parentid, *body_rootid, *body_weldid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_mocapid;
   mjtNum *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_subtreemass;
   int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid;
   mjtByte* jnt_limited;
@@ -58,7 +60,10 @@ struct mjModel {
   mjtNum* sensor_user;
   int *numeric_adr, *numeric_size;
   mjtNum* numeric_data;
-  mjtNum *key_qpos, *key_qvel;
+  mjtNum *key_qpos, *key_qvel, *key_mpos;
+  int *tendon_adr, *tendon_num, *wrap_type, *wrap_objid, *exclude_signature;
+  mjtByte* tendon_limited;
+  mjtNum *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
   int *name_bodyadr, *name_jntadr, *name_siteadr, *name_sensoradr, *name_numericadr, *name_keyadr, *name_geomadr;
   char* names;
 };

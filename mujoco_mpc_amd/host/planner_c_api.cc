@@ -38,7 +38,7 @@ void* mjpc_planner_create_kind(const char* kind, const char* blob_path, const ch
     auto h = std::make_unique<Handle>();
     h->storage = mjpc::ModelStorage::Load(blob_path);
     for (auto& t : mjpc::GetTasks())
-      if (t->Name() == task_name) h->task = t;
+      if (t->Name() == task_name || (t->Name() == "Humanoid Track" && std::string(task_name) == "HumanoidTrack")) h->task = t;
     if (!h->task) { g_error = std::string("unknown task ") + task_name; return nullptr; }
     h->task->Reset(h->storage->model());
     const std::string k = kind ? kind : "sampling";
@@ -108,6 +108,17 @@ int mjpc_planner_task_transition(void* h, double time, int mode) {
   GUARD(h, {
     mjData d{};
     d.time = time;
+    if (mode >= 0) H->task->mode = mode;
+    H->task->Transition(H->storage->model(), &d);
+  });
+}
+// Task::Transition with simulation state: tasks that edit mjData (humanoid::Tracking: mocap_pos, and qpos / qvel on a motion
+// switch) write into the caller's arrays (any of them may be NULL)
+int mjpc_planner_task_transition_state(void* h, double time, int mode, double* qpos, double* qvel, double* mocap_pos) {
+  GUARD(h, {
+    mjData d{};
+    d.time = time;
+    d.qpos = qpos; d.qvel = qvel; d.mocap_pos = mocap_pos;
     if (mode >= 0) H->task->mode = mode;
     H->task->Transition(H->storage->model(), &d);
   });

@@ -47,6 +47,7 @@ def lib():
         L.mjpc_planner_ilqg_policy.argtypes = [vp, C.c_int, c_f64p, c_f64p, c_f64p, c_f64p]
         L.mjpc_planner_best_trajectory.argtypes = [vp, c_f64p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_double)]
         L.mjpc_planner_task_transition.argtypes = [vp, C.c_double, C.c_int]
+        L.mjpc_planner_task_transition_state.argtypes = [vp, C.c_double, C.c_int, c_f64p, c_f64p, c_f64p]
         L.mjpc_planner_task_set_parameter.argtypes = [vp, C.c_int, C.c_double]
         L.mjpc_planner_destroy.argtypes = [vp]
         L.mjpc_planner_last_error.restype = C.c_char_p
@@ -159,6 +160,12 @@ class HostPlanner:
 
     def task_transition(self, time, mode=-1):
         self._chk(lib().mjpc_planner_task_transition(self.h, float(time), int(mode)))
+
+    def task_transition_state(self, time, mode, qpos, qvel, mocap_pos):
+        """Task::Transition for tasks that edit the simulation state (humanoid::Tracking): the arrays are updated in place."""
+        for a in (qpos, qvel, mocap_pos):
+            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+        self._chk(lib().mjpc_planner_task_transition_state(self.h, float(time), int(mode), as_f64p(qpos), as_f64p(qvel), as_f64p(mocap_pos)))
 
     def task_set_parameter(self, index, value):
         self._chk(lib().mjpc_planner_task_set_parameter(self.h, int(index), float(value)))

@@ -112,3 +112,34 @@ def test_contact_feature_scene():
     # something happened: the rods exchanged momentum and the tendon pushed the arm back
     assert tr.states[-1, fm.nq + 6 + 2] < -0.05 and tr.states[-1, fm.nq - 2] < 0.6
     ctx.close()
+
+
+def test_cpp_predictive_sampling_on_the_humanoid_equals_python_planner():
+    """BASELINE configs[3] in miniature: the C++ GpuSamplingPlanner (16 cubic spline points) on the tracking task, the
+    C++ humanoid::Tracking transition providing the initial state, against the Python mirror with the same seed."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.planners import GpuSamplingPlanner, State
+    t = load_task("HumanoidTrack")
+    m = t.model
+    N, H = 64, 32
+    cpp = HostPlanner(t, seed=5, num_trajectory=N, kind="sampling")
+    q, v, mp = np.array(m.qpos0, float), np.zeros(27), np.zeros(48)
+    cpp.task_transition_state(0.0, 9, q, v, mp)
+    e = t.transition(0.0, mode=9)
+    assert np.array_equal(q, e["qpos"]) and np.array_equal(v, e["qvel"]) and np.array_equal(mp.reshape(16, 3), e["mocap_pos"])
+    cpp.reset(H)
+    assert cpp.num_spline_points == 16
+    py = GpuSamplingPlanner(seed=5)
+    py.initialize(m, t); py.num_trajectory_ = N; py.allocate(); py.reset(H)
+    st = State(m)
+    mq = np.tile([1.0, 0, 0, 0], (16, 1))
+    scores = []
+    for k in range(3):
+        tm = 0.005 * k
+        st.set(q, v, mocap_pos=mp.reshape(16, 3), mocap_quat=mq, time=tm); py.set_state(st); py.optimize_policy(H)
+        cpp.set_state(q, v, tm, mocap_pos=mp.reshape(16, 3), mocap_quat=mq); cpp.optimize_policy(H)
+        assert cpp.winner == py.winner and cpp.best_score == py.candidate_score(0)
+        ct, cv = cpp.policy()
+        assert np.array_equal(cv, py.policy.plan.values())
+        scores.append(cpp.best_score)
+    assert "rollout_wave_kernel" in cpp.kernel_name and scores[-1] <= scores[0]
