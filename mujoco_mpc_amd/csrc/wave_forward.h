@@ -488,13 +488,30 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
     const int g1 = on ? m.pair_g1[p0 + lane] : 0, g2 = on ? m.pair_g2[p0 + lane] : 0;
     double cd[2] = {0, 0}, cp[2][3] = {{0, 0, 0}, {0, 0, 0}}, cn[2][3] = {{1, 0, 0}, {1, 0, 0}};
     int cnt = 0;
+    // conservative bounding-sphere pretest on the geom centres (never rejects a pair the narrow phase would accept):
+    // most steps have no self-contact and skip the poses, the narrow phase and the compaction altogether
+    bool near = false;
+    double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+    const double margin = on ? fmax(m.geom_margin[g1], m.geom_margin[g2]) : 0.0;
     if (on) {
-      double p1[3], R1[9], p2[3], R2[9];
+      const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+      double v1[3], v2[3];
+      mv3(v1, d.xmat + 9 * b1, m.geom_pos + 3 * g1);
+      mv3(v2, d.xmat + 9 * b2, m.geom_pos + 3 * g2);
+      double dd = 0;
+      for (int k = 0; k < 3; k++) { p1[k] = d.xpos[3 * b1 + k] + v1[k]; p2[k] = d.xpos[3 * b2 + k] + v2[k]; dd += (p1[k] - p2[k]) * (p1[k] - p2[k]); }
+      const double reach = m.geom_size[3 * g1] + m.geom_size[3 * g2] + margin + 1e-6 +
+                           (m.geom_type[g1] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g1 + 1] : 0.0) +
+                           (m.geom_type[g2] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g2 + 1] : 0.0);
+      near = dd <= reach * reach;
+    }
+    if (__ballot(near) == 0ull) continue;
+    if (near) {
+      double R1[9], R2[9];
       wf_geom_pose(m, d, g1, p1, R1);
       wf_geom_pose(m, d, g2, p2, R2);
       const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
       const double r1 = m.geom_size[3 * g1], r2 = m.geom_size[3 * g2];
-      const double margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
       auto spheres = [&](const double* c1, const double* c2) {
         double n[3], len = 0;
         for (int k = 0; k < 3; k++) { n[k] = c2[k] - c1[k]; len += n[k] * n[k]; }
@@ -1004,10 +1021,22 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       }
       WSYNC();
     }
+    // Per-row facts in registers, lane = row, fetched in the entry loop by v_readlane (no dependent LDS chain per row
+    // visit): kind 0 = nothing to add (inactive, cone member row, diagonal-only row), 1 = active simple inequality row
+    // (frictionless contact, pyramid edge, tendon limit), 2 = head of an elliptic cone outside the top zone.
+    int my_kind = 0, my_id = 0, my_dim = 1;
+    unsigned my_mask = 0;
+    double my_D = 0;
     {
-      const bool is_contact = lane < ne && d.efc_type[lane] >= kEfcNormal;
+      const int t = lane < ne ? d.efc_type[lane] : -1;
+      const bool is_contact = t >= kEfcNormal;
       const unsigned long long b = __ballot(is_contact);
       first_contact = b ? __ffsll((long long)b) - 1 : ne;
+      if (is_contact) {
+        const int id = d.efc_id[lane], zone = d.efc_zone[lane];
+        if (t == kEfcElliptic) { my_kind = zone != kZoneTop ? 2 : 0; my_mask = d.con[id].dofmask; my_id = id; my_dim = d.con[id].dim; }
+        else if (t != kEfcConeRow && zone == kZoneBottom) { my_kind = 1; my_mask = t == kEfcTendon ? m.tendon_dofmask[id] : d.con[id].dofmask; my_D = d.efc_D[lane]; }
+      }
     }
     for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
       // e -> (a >= b)
@@ -1018,17 +1047,18 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       const unsigned need = (1u << a) | (1u << b);
       double h = d.H[a * nv + b];
       for (int r = first_contact; r < ne; r++) {
-        const int t = d.efc_type[r];
-        const int ci = d.efc_id[r];
-        if (t != kEfcElliptic) {  // simple inequality rows: frictionless contact, pyramid edge, tendon limit
-          const unsigned mask = t == kEfcTendon ? m.tendon_dofmask[ci] : d.con[ci].dofmask;
-          if ((mask & need) == need && d.efc_zone[r] == kZoneBottom) h += d.efc_D[r] * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
+        const int kind = __builtin_amdgcn_readlane(my_kind, r);  // wave-uniform
+        if (kind == 0) continue;
+        const unsigned mask = (unsigned)__builtin_amdgcn_readlane((int)my_mask, r);
+        if (kind == 1) {
+          const double D = wbcast(my_D, r);
+          if ((mask & need) == need) h += D * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
           continue;
         }
-        const WaveContact& c = d.con[ci];
-        const int dim = c.dim;
-        if ((c.dofmask & need) == need) {
-          if (d.efc_zone[r] != kZoneTop) {
+        const int ci = __builtin_amdgcn_readlane(my_id, r);
+        const int dim = __builtin_amdgcn_readlane(my_dim, r);
+        if ((mask & need) == need) {
+          {
             const double* Hs = d.coneH + 21 * ci;
             double Ja[6], Jb[6], Hl[21];  // fully unrolled with guards: static indices keep these in registers
 #pragma unroll
