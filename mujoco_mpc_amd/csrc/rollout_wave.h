@@ -61,10 +61,25 @@ struct WaveData {
   double* scal;   // scratch scalars
 };
 
+// Sum over the 64 lanes, same value returned in every lane. DPP row shifts / row broadcasts (6 steps of two 32-bit DPP
+// moves + one add, zero fill at the row boundaries) and one v_readlane of lane 63 -- the ds_bpermute butterfly of
+// __shfl_xor costs a dependent LDS-crossbar round trip per step, and the Newton solver reduces ~16 times per iteration.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_move<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_move<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_move<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of every row of 16 holds the row total
+  v += dpp_move<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ void q_mul(double* r, const double* a, const double* b) {
   const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];

@@ -801,20 +801,25 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
 // ---- penalties: one lane per row; a cone is evaluated by the lane of its first row
 struct ConeEval { double cost, g, h; };
 // value/force/zone at x = jar (+ alpha jv when jv != nullptr); derivative terms along jv when requested
+// LDS-typed views (address space 3): the out-of-line row evaluator would otherwise see generic pointers and go through
+// FLAT loads (aperture check, vmcnt + lgkmcnt) instead of ds_read
+typedef __attribute__((address_space(3))) double wlds_f64;
+typedef __attribute__((address_space(3))) int wlds_i32;
+typedef __attribute__((address_space(3))) WaveContact wlds_con;
 struct RowView {  // by value into the out-of-line row evaluator
-  const int *efc_type, *efc_id;
-  int* efc_zone;
-  const double *efc_D, *efc_R, *efc_floss;
-  double* efc_force;
-  const WaveContact* con;
+  const wlds_i32 *efc_type, *efc_id;
+  wlds_i32* efc_zone;
+  const wlds_f64 *efc_D, *efc_R, *efc_floss;
+  wlds_f64* efc_force;
+  const wlds_con* con;
 };
 struct RowResult { double cost, g1, h2; };
-__device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const double* jar, const double* jv, double alpha,
-                                                   bool write_force) {
+__device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const wlds_f64* jar, const wlds_f64* jv, bool have_jv,
+                                                   double alpha, bool write_force) {
   double cost = 0, g1 = 0, h2 = 0;
   const int type = d.efc_type[r];
   const double D = d.efc_D[r];
-  const double v = jv ? jv[r] : 0.0;
+  const double v = have_jv ? jv[r] : 0.0;
   const double x = jar[r] + alpha * v;
   if (type == kEfcFriction) {
     const double f = d.efc_floss[r], R = d.efc_R[r];
@@ -827,7 +832,7 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
   } else if (type == kEfcElliptic) {
     // loops are unrolled to the maximum cone dimension with guards: static indices keep U/V/X in registers (run-time
     // trip counts would put them in scratch, and this runs for every line-search trial)
-    const WaveContact& c = d.con[d.efc_id[r]];
+    const wlds_con& c = d.con[d.efc_id[r]];
     const int dim = c.dim;
     const double mu = c.mu;
     double U[6], V[6], X[6], Dj[6], T = 0;
@@ -835,7 +840,7 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
 #pragma unroll
     for (int j = 1; j < 6; j++) {
       if (j < dim) {
-        const double vj = jv ? jv[r + j] : 0.0, fj = c.friction[j - 1];
+        const double vj = have_jv ? jv[r + j] : 0.0, fj = c.friction[j - 1];
         X[j] = jar[r + j] + alpha * vj;
         U[j] = X[j] * fj;
         V[j] = vj * fj;
@@ -856,7 +861,7 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
 #pragma unroll
       for (int j = 0; j < 6; j++) {
         if (j < dim) {
-          const double vj = jv ? jv[r + j] : 0.0;
+          const double vj = have_jv ? jv[r + j] : 0.0;
           cost += 0.5 * Dj[j] * X[j] * X[j]; g1 += Dj[j] * X[j] * vj; h2 += Dj[j] * vj * vj;
           if (write_force) d.efc_force[r + j] = -Dj[j] * X[j];
         }
@@ -884,8 +889,9 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
 }
 __device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const double* jar, const double* jv, double alpha,
                                             bool write_force, double& cost, double& g1, double& h2) {
-  const RowView v{d.efc_type, d.efc_id, d.efc_zone, d.efc_D, d.efc_R, d.efc_floss, d.efc_force, d.con};
-  const RowResult res = wf_row_eval_impl(v, r, jar, jv, alpha, write_force);
+  const RowView v{(const wlds_i32*)d.efc_type, (const wlds_i32*)d.efc_id, (wlds_i32*)d.efc_zone, (const wlds_f64*)d.efc_D,
+                  (const wlds_f64*)d.efc_R, (const wlds_f64*)d.efc_floss, (wlds_f64*)d.efc_force, (const wlds_con*)d.con};
+  const RowResult res = wf_row_eval_impl(v, r, (const wlds_f64*)jar, (const wlds_f64*)(jv ? jv : jar), jv != nullptr, alpha, write_force);
   cost = res.cost; g1 = res.g1; h2 = res.h2;
 }
 
