@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
   cart.Residual(cstorage->model(), &d, r);
   CHECK_NEAR(r[0], std::cos(1.0) - 1, 1e-15);
   CHECK(r[1] == 0.3 && r[2] == -0.2 && r[3] == 0.7);
-  CHECK(GetTasks().size() == 4);
+  CHECK(GetTasks().size() == 5);
   if (argc > 3) {  // QuadrupedFlat: ResetLocked ids, Transition state and the frozen residual copy (quadruped.cc:229-391, 520-607)
     auto qstorage = ModelStorage::Load(argv[3]);
     std::shared_ptr<Task> quad;
@@ -78,6 +78,42 @@ int main(int argc, char** argv) {
     CHECK(quad->parameters[4] == 0.45 && quad->parameters[2] == 2 && quad->parameters[3] == 0.03);  // duty, cadence, amplitude of Trot
     CHECK(quad->weight[4] == 0.2 && quad->weight[0] == 1 && quad->weight[1] == 1);                   // balance, upright, height
     CHECK_NEAR(rr[18], 2 * std::sqrt(2 * 9.81 * 0.3) / 9.81, 1e-12);                               // flight_time_
+  }
+  if (argc > 4) {  // humanoid::Tracking: cost parse, marker ids, Transition (tracking.cc:219-264) and the frozen residual copy
+    auto hstorage = ModelStorage::Load(argv[4]);
+    mjModel* hm = hstorage->model();
+    std::shared_ptr<Task> track;
+    for (auto& t : GetTasks()) if (t->Name() == "Humanoid Track") track = t;
+    CHECK(track != nullptr);
+    track->Reset(hm);
+    CHECK(track->num_term == 21 && track->num_residual == 141 && track->num_trace == 1);
+    CHECK(track->trace_site[0] == -1 - NameToId(hm, mjOBJ_BODY, "torso"));  // trace0 is the frame of a body
+    CHECK(hm->nkey == 1889 && hm->nmocap == 16 && hm->ntendon == 2 && hm->nexclude == 2);
+    std::vector<double> qpos(hm->nq, 0.0), qvel(hm->nv, 1.0), mpos(3 * hm->nmocap, 0.0);
+    mjData d{};
+    d.qpos = qpos.data(); d.qvel = qvel.data(); d.mocap_pos = mpos.data();
+    d.time = 0.0;
+    track->mode = 8;  // Run: keys 1340 .. 1378
+    track->Transition(hm, &d);
+    std::vector<int32_t> ri; std::vector<double> rr;
+    track->ResidualState(&ri, &rr);
+    CHECK(ri.size() == 34 && rr.size() == 1 && ri[0] == 1340 && ri[1] == 1378 && rr[0] == 0.0);
+    CHECK(ri[2] == NameToId(hm, mjOBJ_SITE, "tracking[pelvis]") && ri[18] == hm->body_mocapid[NameToId(hm, mjOBJ_BODY, "mocap[pelvis]")]);
+    for (int i = 0; i < hm->nq; i++) CHECK(qpos[i] == hm->key_qpos[(size_t)hm->nq * 1340 + i]);   // reset to the first keyframe
+    CHECK(qvel[0] == hm->key_qvel[(size_t)hm->nv * 1340] && qvel[10] == 0.0);
+    for (int i = 0; i < 48; i++) CHECK(mpos[i] == hm->key_mpos[(size_t)48 * 1340 + i]);
+    d.time = 0.25;  // index 1340 + 7.5: halfway between two keyframes; no reset
+    qpos[0] = 123.0;
+    track->Transition(hm, &d);
+    CHECK(qpos[0] == 123.0);
+    for (int i = 0; i < 48; i++) CHECK_NEAR(mpos[i], 0.5 * hm->key_mpos[(size_t)48 * 1347 + i] + 0.5 * hm->key_mpos[(size_t)48 * 1348 + i], 1e-15);
+    d.time = 100.0;  // past the end of the clip: clamps to the last key
+    track->Transition(hm, &d);
+    for (int i = 0; i < 48; i++) CHECK(mpos[i] == hm->key_mpos[(size_t)48 * 1378 + i]);
+    track->mode = 9;  // motion switch re-references the clock
+    track->Transition(hm, &d);
+    track->ResidualState(&ri, &rr);
+    CHECK(ri[0] == 1379 && ri[1] == 1888 && rr[0] == 100.0);
   }
   TEST_MAIN_END();
 }

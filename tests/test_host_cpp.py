@@ -17,7 +17,7 @@ HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 def blobs(tmp_path_factory):
     build_host()
     d = tmp_path_factory.mktemp("blobs")
-    for name in ("Cartpole", "Particle", "QuadrupedFlat"):
+    for name in ("Cartpole", "Particle", "QuadrupedFlat", "HumanoidTrack"):
         mjcf.save_blob(load_task(name).model, str(d / f"{name}.mjpx"))
     return str(d)
 
@@ -35,7 +35,7 @@ def test_cpu_suites(blobs, exe):
 
 def test_task_and_state_suites(blobs):
     assert "OK" in run("task_test", os.path.join(blobs, "Particle.mjpx"), os.path.join(blobs, "Cartpole.mjpx"),
-                       os.path.join(blobs, "QuadrupedFlat.mjpx"))
+                       os.path.join(blobs, "QuadrupedFlat.mjpx"), os.path.join(blobs, "HumanoidTrack.mjpx"))
     assert "OK" in run("state_test", os.path.join(blobs, "Particle.mjpx"))
 
 
