@@ -25,7 +25,9 @@ double SynchronousPlanningCost(std::string task_name, int planner_thread_count, 
     for (auto& t : GetTasks()) std::cerr << "  " << t->Name() << "\n";
     return -1;
   }
-  const std::string blob = opt.model_dir + "/" + (task_name == "ParticleCopy" ? std::string("Particle") : task_name) + ".mjpx";
+  std::string file = task_name == "ParticleCopy" ? std::string("Particle") : task_name;
+  file.erase(std::remove(file.begin(), file.end(), ' '), file.end());  // "Humanoid Track" -> HumanoidTrack.mjpx
+  const std::string blob = opt.model_dir + "/" + file + ".mjpx";
   std::unique_ptr<ModelStorage> storage;
   try {
     storage = ModelStorage::Load(blob);
@@ -76,6 +78,12 @@ double SynchronousPlanningCost(std::string task_name, int planner_thread_count, 
     double plan_us = 0;
     std::vector<double> full_state(ds), mocap7(7 * (size_t)model->nmocap);
     for (int i = 0; i < total_steps; i++) {
+      {  // agent.ActiveTask()->Transition(model, data) (testspeed.cc:97): tasks may edit qpos / qvel / mocap_pos
+        mjData d{};
+        d.time = time;
+        d.qpos = qpos.data(); d.qvel = qvel.data(); d.mocap_pos = mocap_pos.data(); d.mocap_quat = mocap_quat.data();
+        task->Transition(model, &d);
+      }
       state.Set(model, qpos.data(), qvel.data(), nullptr, mocap_pos.data(), mocap_quat.data(), nullptr, time);
       planner.ActionFromPolicy(ctrl.data(), state.state().data(), time);
       // mj_step of the simulation copy + the stage cost at the pre-step state
@@ -83,6 +91,7 @@ double SynchronousPlanningCost(std::string task_name, int planner_thread_count, 
         mju_copy(mocap7.data() + 7 * k, mocap_pos.data() + 3 * k, 3);
         mju_copy(mocap7.data() + 7 * k + 3, mocap_quat.data() + 4 * k, 4);
       }
+      sim.SyncTask(*task);
       sim.Check(mjpcx_set_state(sim.handle(), state.state().data(), time, mocap7.data(), nullptr));
       sim.Check(mjpcx_rollout_splines(sim.handle(), 1, 2, 1, MJPCX_SPLINE_ZERO, &time, ctrl.data()));
       sim.FetchTrajectory(0, &one);
