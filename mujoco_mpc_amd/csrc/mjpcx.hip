@@ -571,10 +571,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
       }
       const WaveModel& wm = c->wh.m;
-      const size_t lds_state = (8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
+      const size_t lds_state = (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
       const size_t lds = lds_state;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
-      auto kern = wm.nv <= 20 ? rollout_wave_kernel<20> : rollout_wave_kernel<32>;
+      auto kern = wm.nv <= 20 ? w64::rollout_wave_kernel<20> : w64::rollout_wave_kernel<32>;
       le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (le == hipSuccess) {
         hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
@@ -1190,7 +1190,7 @@ int wave_blob(mjpcx_ctx* c, WaveTask* wt) {
 }
 size_t wave_lds_bytes(const mjpcx_ctx* c, int P) {
   const WaveModel& wm = c->wh.m;
-  return (8 * wave_lds_doubles(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, c->wh.t.nr, c->wh.t.nterm, P) + 15) & ~(size_t)15;
+  return (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, c->wh.t.nr, c->wh.t.nterm, P) + 15) & ~(size_t)15;
 }
 
 int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
@@ -1211,7 +1211,7 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
   FeedbackWaveArgs fb{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state};
   const int Ppolicy = (int)((ndx + 2 * ds + nu - 1) / nu + 1);
   const size_t lds = wave_lds_bytes(c, Ppolicy);
-  auto kern = c->wh.m.nv <= 20 ? rollout_feedback_wave_kernel<20> : rollout_feedback_wave_kernel<32>;
+  auto kern = c->wh.m.nv <= 20 ? w64::rollout_feedback_wave_kernel<20> : w64::rollout_feedback_wave_kernel<32>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, c->wh.m, wt, a, fb);
   HIPCHK(c, hipGetLastError());
@@ -1242,11 +1242,11 @@ int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const doubl
   HIPCHK(c, hipMemcpyAsync(base + off_lim, c->ctrllimited.data(), nu * sizeof(int), hipMemcpyHostToDevice, c->stream));
   FdWaveArgs f{d[0], d[1], d[2], Tn, (int)nc, eps, (double*)base, (double*)(base + off_sensor)};
   const size_t lds = wave_lds_bytes(c, 1);
-  auto kern = c->wh.m.nv <= 20 ? transition_fd_wave_kernel<20> : transition_fd_wave_kernel<32>;
+  auto kern = c->wh.m.nv <= 20 ? w64::transition_fd_wave_kernel<20> : w64::transition_fd_wave_kernel<32>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(Tn * nc)), dim3(64), lds, c->stream, c->wh.m, wt, f);
   HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(fd_tangent_kernel, dim3((unsigned)std::min<size_t>((Tn * nc + 63) / 64, 1024)), dim3(64), 0, c->stream, c->wh.m,
+  hipLaunchKernelGGL(w64::fd_tangent_kernel, dim3((unsigned)std::min<size_t>((Tn * nc + 63) / 64, 1024)), dim3(64), 0, c->stream, c->wh.m,
                      (const double*)base, (double*)(base + off_tan), Tn, (int)nc);
   HIPCHK(c, hipGetLastError());
   double* dA = (double*)(base + off_A);

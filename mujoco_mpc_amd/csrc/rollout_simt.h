@@ -18,6 +18,7 @@
 #include "rollout_wave.h"  // WaveModel / WaveTask / small math helpers / residual constants
 
 namespace mjpcx {
+using namespace w64;  // the fp64 instantiation of the wave helpers (rollout_wave.h)
 
 struct SimtLayout {  // offsets (in elements) of the per-lane arrays inside a wavefront's slab
   int qpos, qvel, ctrl, xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, site_xpos, subtree_com, cinert, crb, cdof, cdof_dot,

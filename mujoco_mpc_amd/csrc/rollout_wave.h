@@ -18,298 +18,53 @@
 #include "device_common.h"
 #include "rollout_lane.h"  // RolloutArgs / NoiseArgs
 #include "wave_model.h"
+#include "ilqg_kernels.h"  // find_interval, fd_assemble_kernel
 
+// The device code below is instantiated twice, textually: namespace mjpcx::w64 with wreal = double (the parity path, also
+// the finite-difference and feedback-rollout kernels of iLQG) and mjpcx::w32 with wreal = float (BASELINE configs[3]'s
+// precision: half the LDS per candidate, twice the VALU rate). WL() gives floating literals the working type.
 namespace mjpcx {
-
-// Single-wavefront workgroups: the ordering point between dependent LDS phases only has to (a) stop the compiler from
-// moving LDS accesses across it and (b) wait for this wave's outstanding LDS operations -- no s_barrier, and no wait
-// on outstanding global stores (which __syncthreads() would add through its global-memory fence).
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only (gfx9 encoding: vmcnt = max, expcnt = max)
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+__device__ __forceinline__ void w_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __forceinline__ void w_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+// 32- and 64-bit lanes through v_readlane / DPP moves (zero fill at the row boundaries)
+__device__ __forceinline__ double w_readlane(double v, int src) {  // src must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
 }
-#define WSYNC() wave_lds_sync()
-
-struct WaveContact {
-  int g1, g2, dim, dim0, efc;
-  int nrow;          // rows built: dim (frictionless / elliptic) or up to 2 (dim0 - 1) pyramid edges
-  unsigned dofmask;  // dofs with a non-zero Jacobian column (the chains of the two bodies, minus their common part)
-  double dist, margin, includemargin, mu;
-  double pos[3], frame[9], friction[5], solref[2], solimp[5];
-};
-enum { kEfcFriction = 0, kEfcLimit = 1, kEfcNormal = 2, kEfcElliptic = 3, kEfcConeRow = 4, kEfcTendon = 5, kEfcPyramid = 6 };
-enum { kZoneTop = 0, kZoneMiddle = 1, kZoneBottom = 2 };
-
-// LDS state of one candidate ("mjData")
-struct WaveData {
-  double *qpos, *qvel, *ctrl;
-  double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *site_xpos;
-  double *subtree_com, *cinert, *crb, *cdof, *cdof_dot, *cvel, *cacc, *cfrc, *cfrc_sub, *subtree_linvel;
-  double *M, *L, *H, *Ldinv, *dinv;
-  double *qfrc_passive, *qfrc_bias, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qacc, *qfrc_constraint;
-  double *actuator_force, *grad, *search, *Ma, *Ms, *tmpv, *qacc_warm;
-  double *efc_J, *efc_pos, *efc_margin, *efc_D, *efc_R, *efc_aref, *efc_floss, *efc_force, *jar, *jv;
-  int *efc_type, *efc_id, *efc_zone;
-  double* coneH;  // kWaveMaxCon x 21: lower triangle (j >= k at j (j + 1) / 2 + k) of each cone's symmetric Hessian block
-  double* foot_xpos;  // geom_xpos of the geoms the residual reads (4 x 3)
-  double* residual;
-  double* terms;
-  WaveContact* con;
-  int* counters;  // [0] ncon [1] nefc [2] warning
-  double* scal;   // scratch scalars
-};
-
-// Sum over the 64 lanes, same value returned in every lane. DPP row shifts / row broadcasts (6 steps of two 32-bit DPP
-// moves + one add, zero fill at the row boundaries) and one v_readlane of lane 63 -- the ds_bpermute butterfly of
-// __shfl_xor costs a dependent LDS-crossbar round trip per step, and the Newton solver reduces ~16 times per iteration.
+__device__ __forceinline__ float w_readlane(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_move(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_move<0x111, 0xf>(v);  // row_shr:1
-  v += dpp_move<0x112, 0xf>(v);  // row_shr:2
-  v += dpp_move<0x114, 0xf>(v);  // row_shr:4
-  v += dpp_move<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of every row of 16 holds the row total
-  v += dpp_move<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-  v += dpp_move<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-  return __hiloint2double(hi, lo);
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
-__device__ __forceinline__ void q_mul(double* r, const double* a, const double* b) {
-  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-  const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-  const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
-  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
-}
-__device__ __forceinline__ void q2mat(double* m, const double* q) {
-  const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
-  const double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3], q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
-  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
-  m[1] = 2 * (q12 - q03); m[2] = 2 * (q13 + q02); m[3] = 2 * (q12 + q03);
-  m[5] = 2 * (q23 - q01); m[6] = 2 * (q13 - q02); m[7] = 2 * (q23 + q01);
-}
-__device__ __forceinline__ void q_rot(double* r, const double* v, const double* q) {  // rotate v by q
-  double m[9];
-  q2mat(m, q);
-  const double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
-               z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-__device__ __forceinline__ void q_norm(double* q) {
-  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n < kMinVal) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
-  else { const double s = 1.0 / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
-}
-__device__ __forceinline__ void aa2quat(double* q, const double* axis, double angle) {
-  double s, c;
-  sincos(0.5 * angle, &s, &c);
-  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
-}
-__device__ __forceinline__ void mv3(double* r, const double* m, const double* v) {
-  const double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
-               z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-__device__ __forceinline__ void cr3(double* r, const double* a, const double* b) {
-  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
-  r[0] = x; r[1] = y; r[2] = z;
-}
-// spatial helpers on plain pointers (same formulas as device_common.h's array versions)
-__device__ __forceinline__ void w_inert_com(double* res, const double* inert, const double* mat, const double* dif, double mass) {
-  double tmp[9];
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tmp[3 * i + j] = mat[3 * i + j] * inert[j];
-  res[0] = tmp[0] * mat[0] + tmp[1] * mat[1] + tmp[2] * mat[2];
-  res[1] = tmp[3] * mat[3] + tmp[4] * mat[4] + tmp[5] * mat[5];
-  res[2] = tmp[6] * mat[6] + tmp[7] * mat[7] + tmp[8] * mat[8];
-  res[3] = tmp[0] * mat[3] + tmp[1] * mat[4] + tmp[2] * mat[5];
-  res[4] = tmp[0] * mat[6] + tmp[1] * mat[7] + tmp[2] * mat[8];
-  res[5] = tmp[3] * mat[6] + tmp[4] * mat[7] + tmp[5] * mat[8];
-  res[0] += mass * (dif[1] * dif[1] + dif[2] * dif[2]);
-  res[1] += mass * (dif[0] * dif[0] + dif[2] * dif[2]);
-  res[2] += mass * (dif[0] * dif[0] + dif[1] * dif[1]);
-  res[3] -= mass * dif[0] * dif[1];
-  res[4] -= mass * dif[0] * dif[2];
-  res[5] -= mass * dif[1] * dif[2];
-  res[6] = mass * dif[0]; res[7] = mass * dif[1]; res[8] = mass * dif[2];
-  res[9] = mass;
-}
-__device__ __forceinline__ void w_mul_inert(double* res, const double* i, const double* v) {
-  res[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
-  res[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
-  res[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
-  res[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
-  res[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
-  res[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
-}
-__device__ __forceinline__ void w_cross_motion(double* res, const double* vel, const double* v) {
-  res[0] = -vel[2] * v[1] + vel[1] * v[2];
-  res[1] = vel[2] * v[0] - vel[0] * v[2];
-  res[2] = -vel[1] * v[0] + vel[0] * v[1];
-  res[3] = -vel[2] * v[4] + vel[1] * v[5];
-  res[4] = vel[2] * v[3] - vel[0] * v[5];
-  res[5] = -vel[1] * v[3] + vel[0] * v[4];
-  res[3] += -vel[5] * v[1] + vel[4] * v[2];
-  res[4] += vel[5] * v[0] - vel[3] * v[2];
-  res[5] += -vel[4] * v[0] + vel[3] * v[1];
-}
-__device__ __forceinline__ void w_cross_force(double* res, const double* vel, const double* f) {
-  res[0] = -vel[2] * f[1] + vel[1] * f[2];
-  res[1] = vel[2] * f[0] - vel[0] * f[2];
-  res[2] = -vel[1] * f[0] + vel[0] * f[1];
-  res[3] = -vel[2] * f[4] + vel[1] * f[5];
-  res[4] = vel[2] * f[3] - vel[0] * f[5];
-  res[5] = -vel[1] * f[3] + vel[0] * f[4];
-  res[0] += -vel[5] * f[4] + vel[4] * f[5];
-  res[1] += vel[5] * f[3] - vel[3] * f[5];
-  res[2] += -vel[4] * f[3] + vel[3] * f[4];
-}
-__device__ __forceinline__ double w_dot6(const double* a, const double* b) {
-  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
-}
-
-// ------------------------------------------------------------------ dense SPD algebra, lane i owns row i (n <= NMAX <= 32)
-// Register-resident: lane i keeps ROW i of the matrix in NMAX registers; values of other rows arrive through
-// v_readlane (uniform source lane), so a factorisation or a triangular solve makes no LDS round trips on its
-// dependent chain. Pivots are applied as reciprocals (one v_rsq-based 1/sqrt per column instead of a sqrt and a
-// division per row), which differs from the oracle's divisions by <= 2 ulp.
-__device__ __forceinline__ double wbcast(double v, int src) {  // src must be wave-uniform
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-// in-place: on exit the lower triangle of A (LDS, ld n) holds L with A = L L', dinv[j] = 1 / L[j][j].
-// (not inlined: five call sites per step, and the step loop has to stay inside the instruction cache)
-template <int NMAX>
-__device__ __noinline__ bool wave_chol(double* A, double* dinv, int n, int lane) {
-  double row[NMAX];
-#pragma unroll
-  for (int k = 0; k < NMAX; k++) row[k] = (lane < n && k <= lane) ? A[lane * n + k] : 0.0;
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < NMAX; j++) {
-    if (j < n && ok) {
-      const double djj = wbcast(row[j], j);
-      if (!(djj > kMinVal)) {
-        ok = false;
-      } else {
-        const double inv = rsqrt(djj);
-        const double lij = lane == j ? djj * inv : row[j] * inv;
-        row[j] = lij;
-        if (lane == j) dinv[j] = inv;
-#pragma unroll
-        for (int k = j + 1; k < NMAX; k++) {
-          if (k < n) {
-            const double lkj = wbcast(lij, k);
-            if (lane >= k) row[k] -= lij * lkj;
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NMAX; k++) if (lane < n && k <= lane) A[lane * n + k] = row[k];
-  WSYNC();
-  return ok;
-}
-// x := (L L')^-1 x, x in LDS
-template <int NMAX>
-__device__ __noinline__ void wave_chol_solve(double* x, const double* L, const double* dinv, int n, int lane) {
-  double row[NMAX], col[NMAX];
-#pragma unroll
-  for (int k = 0; k < NMAX; k++) {
-    row[k] = (lane < n && k < lane) ? L[lane * n + k] : 0.0;
-    col[k] = (lane < n && k > lane && k < n) ? L[k * n + lane] : 0.0;
-  }
-  double b = lane < n ? x[lane] : 0.0;
-  const double mydinv = lane < n ? dinv[lane] : 0.0;
-#pragma unroll
-  for (int j = 0; j < NMAX; j++) {
-    if (j < n) {
-      const double yj = wbcast(b, j) * wbcast(mydinv, j);
-      b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
-    }
-  }
-#pragma unroll
-  for (int j = NMAX - 1; j >= 0; j--) {
-    if (j < n) {
-      const double xj = wbcast(b, j) * wbcast(mydinv, j);
-      b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
-    }
-  }
-  if (lane < n) x[lane] = b;
-  WSYNC();
-}
-
-// solimp -> impedance at violation `dist` (oracle impedance())
-__device__ __noinline__ double w_impedance(const double* solimp, double dist) {
-  double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
-  dmin = fmin(fmax(dmin, kMinImp), kMaxImp);
-  dmax = fmin(fmax(dmax, kMinImp), kMaxImp);
-  if (power < 1) power = 1;
-  mid = fmin(fmax(mid, kMinImp), kMaxImp);
-  if (dmin == dmax || width <= kMinVal) return 0.5 * (dmin + dmax);
-  const double x = fabs(dist) / width;
-  if (x >= 1) return dmax;
-  if (x <= 0) return dmin;
-  double y;
-  if (power == 1) y = x;
-  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
-  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
-  return dmin + y * (dmax - dmin);
-}
-__device__ __forceinline__ void w_solref_kb(const WaveModel& m, const double* solref, const double* solimp, double& k, double& b) {
-  const double dmax = fmin(fmax(solimp[1], kMinImp), kMaxImp);
-  if (solref[0] > 0) {
-    double tc = solref[0];
-    if (!(m.disableflags & MJPCX_DSBL_REFSAFE) && tc < 2 * m.timestep) tc = 2 * m.timestep;
-    k = 1.0 / (dmax * dmax * tc * tc * solref[1] * solref[1]);
-    b = 2.0 / (dmax * tc);
-  } else {
-    k = -solref[0] / (dmax * dmax);
-    b = -solref[1] / dmax;
-  }
-}
-__device__ __forceinline__ void w_make_frame(double* frame) {
-  double* x = frame; double* y = frame + 3; double* z = frame + 6;
-  if (x[1] < 0.5 && x[1] > -0.5) { y[0] = 0; y[1] = 1; y[2] = 0; }
-  else { y[0] = 0; y[1] = 0; y[2] = 1; }
-  const double dt = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
-  for (int k = 0; k < 3; k++) y[k] -= dt * x[k];
-  const double n = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-  for (int k = 0; k < 3; k++) y[k] /= n;
-  cr3(z, x, y);
-}
-constexpr double kMinMu = 1e-5;
-
-// runtime-sized mjpc::Norm value (device_common.h norm_value with a run-time slice length)
-__device__ __noinline__ double w_norm_value(const double* x, int n, int type, double p, double q) {
-  double y = 0;
-  switch (type) {
-    case -1: y = x[0]; break;
-    case 0: for (int i = 0; i < n; i++) y += x[i] * x[i]; y *= 0.5; break;
-    case 1: { double c = 0; for (int i = 0; i < n; i++) c += x[i] * x[i]; y = pow(pow(c, q / 2) + pow(p, q), 1 / q) - p; break; }
-    case 2: { double c = 0; for (int i = 0; i < n; i++) c += x[i] * x[i]; y = sqrt(c + p * p) - p; break; }
-    case 3: for (int i = 0; i < n; i++) y += p * p * (cosh(x[i] / p) - 1.0); break;
-    case 5: for (int i = 0; i < n; i++) y += pow(fabs(x[i]), p); break;
-    case 6: for (int i = 0; i < n; i++) y += sqrt(x[i] * x[i] + p * p) - p; break;
-    case 7: for (int i = 0; i < n; i++) y += pow(pow(fabs(x[i]), q) + pow(p, q), 1 / q) - p; break;
-    case 8: for (int i = 0; i < n; i++) y += p > 0 ? p * log(1 + exp(x[i] / p)) : (x[i] > 0 ? x[i] : 0.0); break;
-    default: break;
-  }
-  return y;
-}
-
 }  // namespace mjpcx
 
+#define WL(x) ((wreal)(x))
+
+#define WAVE_NS w64
+#define wreal double
+#define MJPCX_WAVE_ILQG 1
+#include "wave_core.h"
 #include "wave_forward.h"
 #include "wave_residual.h"
 #include "wave_kernel.h"
-#include "ilqg_kernels.h"  // find_interval, fd_assemble_kernel
 #include "wave_ilqg.h"
+#undef MJPCX_WAVE_ILQG
+#undef wreal
+#undef WAVE_NS
+
+#define WAVE_NS w32
+#define wreal float
+#include "wave_core.h"
+#include "wave_forward.h"
+#include "wave_residual.h"
+#include "wave_kernel.h"
+#undef wreal
+#undef WAVE_NS
+#undef WL

@@ -1,15 +1,14 @@
 // wave_forward.h -- mj_forward for one candidate held in LDS, all 64 lanes cooperating (see rollout_wave.h).
 // Stage by stage the arithmetic is oracle/physics.c + oracle/contact.inc; the comments name the oracle function.
-#pragma once
 
-namespace mjpcx {
+namespace mjpcx { namespace WAVE_NS {
 
 // ---- o_kinematics: bodies level by level (a body needs its parent), then sites
-__device__ __forceinline__ void wf_kinematics(const WaveModel& m, const WaveTask& tk, WaveData& d, int lane) {
+__device__ __forceinline__ void wf_kinematics(const WModel& m, const WTask& tk, WaveData& d, int lane) {
   if (lane == 0) {
     d.xpos[0] = d.xpos[1] = d.xpos[2] = 0;
     d.xquat[0] = 1; d.xquat[1] = d.xquat[2] = d.xquat[3] = 0;
-    for (int k = 0; k < 9; k++) d.xmat[k] = d.ximat[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    for (int k = 0; k < 9; k++) d.xmat[k] = d.ximat[k] = (k % 4 == 0) ? WL(1.0) : WL(0.0);
     d.xipos[0] = d.xipos[1] = d.xipos[2] = 0;
   }
   WSYNC();
@@ -18,9 +17,9 @@ __device__ __forceinline__ void wf_kinematics(const WaveModel& m, const WaveTask
     if (idx < m.level_start[l + 1]) {
       const int i = m.level_body[idx];
       const int pid = m.body_parentid[i], jn = m.body_jntnum[i], ja = m.body_jntadr[i];
-      double xpos[3], xquat[4];
+      wreal xpos[3], xquat[4];
       if (m.body_mocapid[i] >= 0) {
-        const double* mp = tk.blob + tk.off_mocap + 7 * m.body_mocapid[i];
+        const wreal* mp = tk.blob + tk.off_mocap + 7 * m.body_mocapid[i];
         for (int k = 0; k < 3; k++) xpos[k] = mp[k];
         for (int k = 0; k < 4; k++) xquat[k] = mp[3 + k];
         q_norm(xquat);
@@ -37,16 +36,16 @@ __device__ __forceinline__ void wf_kinematics(const WaveModel& m, const WaveTask
         q_mul(xquat, d.xquat + 4 * pid, m.body_quat + 4 * i);
         for (int j = ja; j < ja + jn; j++) {
           const int qa = m.jnt_qposadr[j];
-          double anchor[3], axis[3];
+          wreal anchor[3], axis[3];
           q_rot(anchor, m.jnt_pos + 3 * j, xquat);
           for (int k = 0; k < 3; k++) anchor[k] += xpos[k];
           q_rot(axis, m.jnt_axis + 3 * j, xquat);
           const int jt = m.jnt_type[j];
           if (jt == kJntSlide) {
-            const double s = d.qpos[qa] - m.qpos0[qa];
+            const wreal s = d.qpos[qa] - m.qpos0[qa];
             for (int k = 0; k < 3; k++) xpos[k] += axis[k] * s;
           } else if (jt == kJntBall || jt == kJntHinge) {
-            double qloc[4], vec[3];
+            wreal qloc[4], vec[3];
             if (jt == kJntBall) { for (int k = 0; k < 4; k++) qloc[k] = d.qpos[qa + k]; q_norm(qloc); }
             else aa2quat(qloc, m.jnt_axis + 3 * j, d.qpos[qa] - m.qpos0[qa]);
             q_mul(xquat, xquat, qloc);
@@ -57,7 +56,7 @@ __device__ __forceinline__ void wf_kinematics(const WaveModel& m, const WaveTask
         }
       }
       q_norm(xquat);
-      double xmat[9], v[3], q[4];
+      wreal xmat[9], v[3], q[4];
       q2mat(xmat, xquat);
       for (int k = 0; k < 3; k++) d.xpos[3 * i + k] = xpos[k];
       for (int k = 0; k < 4; k++) d.xquat[4 * i + k] = xquat[k];
@@ -71,16 +70,16 @@ __device__ __forceinline__ void wf_kinematics(const WaveModel& m, const WaveTask
   }
   if (lane < m.nsite) {
     const int s = lane, b = m.site_bodyid[s];
-    double v[3];
+    wreal v[3];
     mv3(v, d.xmat + 9 * b, m.site_pos + 3 * s);
     for (int k = 0; k < 3; k++) d.site_xpos[3 * s + k] = d.xpos[3 * b + k] + v[k];
   }
 }
 
 // world pose of a geom (o_geom_kinematics), computed where it is needed instead of being stored for all geoms
-__device__ __forceinline__ void wf_geom_pose(const WaveModel& m, const WaveData& d, int g, double* pos, double* mat) {
+__device__ __forceinline__ void wf_geom_pose(const WModel& m, const WaveData& d, int g, wreal* pos, wreal* mat) {
   const int b = m.geom_bodyid[g];
-  double v[3], q[4];
+  wreal v[3], q[4];
   mv3(v, d.xmat + 9 * b, m.geom_pos + 3 * g);
   for (int k = 0; k < 3; k++) pos[k] = d.xpos[3 * b + k] + v[k];
   q_mul(q, d.xquat + 4 * b, m.geom_quat + 4 * g);
@@ -88,20 +87,20 @@ __device__ __forceinline__ void wf_geom_pose(const WaveModel& m, const WaveData&
 }
 
 // ---- o_compos: subtree centres of mass, cinert, cdof
-__device__ __forceinline__ void wf_compos(const WaveModel& m, WaveData& d, int lane) {
+__device__ __forceinline__ void wf_compos(const WModel& m, WaveData& d, int lane) {
   const int nb = m.nbody;
   if (lane < nb) {
     const int i = lane;
     unsigned long long mask = m.body_subtree_mask[i];
-    double s[3] = {0, 0, 0};
+    wreal s[3] = {0, 0, 0};
     // ascending body order = the oracle's accumulation order reversed; sums of <= 13 terms, parity tolerance covers it
     while (mask) {
       const int j = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
-      const double mj = m.body_mass[j];
+      const wreal mj = m.body_mass[j];
       for (int k = 0; k < 3; k++) s[k] += mj * d.xipos[3 * j + k];
     }
-    const double sm = m.body_subtreemass[i];
+    const wreal sm = m.body_subtreemass[i];
     for (int k = 0; k < 3; k++) d.subtree_com[3 * i + k] = sm < kMinVal ? d.xipos[3 * i + k] : s[k] / sm;
   }
   WSYNC();
@@ -109,8 +108,8 @@ __device__ __forceinline__ void wf_compos(const WaveModel& m, WaveData& d, int l
     const int i = lane;
     if (i == 0) { for (int k = 0; k < 10; k++) d.cinert[k] = 0; }
     else {
-      double off[3];
-      const double* com = d.subtree_com + 3 * m.body_rootid[i];
+      wreal off[3];
+      const wreal* com = d.subtree_com + 3 * m.body_rootid[i];
       for (int k = 0; k < 3; k++) off[k] = d.xipos[3 * i + k] - com[k];
       w_inert_com(d.cinert + 10 * i, m.body_inertia + 3 * i, d.ximat + 9 * i, off, m.body_mass[i]);
     }
@@ -118,14 +117,14 @@ __device__ __forceinline__ void wf_compos(const WaveModel& m, WaveData& d, int l
   if (lane < m.njnt) {
     const int j = lane, b = m.jnt_bodyid[j];
     int da = m.jnt_dofadr[j];
-    double off[3];
-    const double* com = d.subtree_com + 3 * m.body_rootid[b];
+    wreal off[3];
+    const wreal* com = d.subtree_com + 3 * m.body_rootid[b];
     for (int k = 0; k < 3; k++) off[k] = com[k] - d.xanchor[3 * j + k];
-    const double* xmat = d.xmat + 9 * b;
+    const wreal* xmat = d.xmat + 9 * b;
     const int jt = m.jnt_type[j];
     if (jt == kJntFree) {
       for (int k = 0; k < 3; k++) {
-        double* c = d.cdof + 6 * (da + k);
+        wreal* c = d.cdof + 6 * (da + k);
         for (int e = 0; e < 6; e++) c[e] = 0;
         c[3 + k] = 1;
       }
@@ -133,17 +132,17 @@ __device__ __forceinline__ void wf_compos(const WaveModel& m, WaveData& d, int l
     }
     if (jt == kJntFree || jt == kJntBall) {
       for (int k = 0; k < 3; k++) {
-        double* c = d.cdof + 6 * (da + k);
-        const double ax[3] = {xmat[k], xmat[3 + k], xmat[6 + k]};
+        wreal* c = d.cdof + 6 * (da + k);
+        const wreal ax[3] = {xmat[k], xmat[3 + k], xmat[6 + k]};
         for (int e = 0; e < 3; e++) c[e] = ax[e];
         cr3(c + 3, ax, off);
       }
     } else if (jt == kJntSlide) {
-      double* c = d.cdof + 6 * da;
+      wreal* c = d.cdof + 6 * da;
       c[0] = c[1] = c[2] = 0;
       for (int e = 0; e < 3; e++) c[3 + e] = d.xaxis[3 * j + e];
     } else {
-      double* c = d.cdof + 6 * da;
+      wreal* c = d.cdof + 6 * da;
       for (int e = 0; e < 3; e++) c[e] = d.xaxis[3 * j + e];
       cr3(c + 3, d.xaxis + 3 * j, off);
     }
@@ -152,12 +151,12 @@ __device__ __forceinline__ void wf_compos(const WaveModel& m, WaveData& d, int l
 }
 
 // ---- o_crb: composite inertias by subtree masks, then M (dense, both triangles)
-__device__ __forceinline__ void wf_crb(const WaveModel& m, WaveData& d, int lane) {
+__device__ __forceinline__ void wf_crb(const WModel& m, WaveData& d, int lane) {
   const int nb = m.nbody, nv = m.nv;
   if (lane < nb && lane > 0) {
     const int i = lane;
     unsigned long long mask = m.body_subtree_mask[i];
-    double s[10];
+    wreal s[10];
     for (int k = 0; k < 10; k++) s[k] = 0;
     while (mask) {
       const int j = __ffsll((long long)mask) - 1;
@@ -170,11 +169,11 @@ __device__ __forceinline__ void wf_crb(const WaveModel& m, WaveData& d, int lane
   WSYNC();
   if (lane < nv) {
     const int i = lane;
-    double buf[6];
+    wreal buf[6];
     w_mul_inert(buf, d.crb + 10 * m.dof_bodyid[i], d.cdof + 6 * i);
     d.M[i * nv + i] = m.dof_armature[i] + w_dot6(d.cdof + 6 * i, buf);
     for (int j = m.dof_parentid[i]; j >= 0; j = m.dof_parentid[j]) {
-      const double v = w_dot6(d.cdof + 6 * j, buf);
+      const wreal v = w_dot6(d.cdof + 6 * j, buf);
       d.M[i * nv + j] = v;
       d.M[j * nv + i] = v;
     }
@@ -183,14 +182,14 @@ __device__ __forceinline__ void wf_crb(const WaveModel& m, WaveData& d, int lane
 }
 
 // ---- o_comvel: cvel and cdof_dot, level by level
-__device__ __forceinline__ void wf_comvel(const WaveModel& m, WaveData& d, int lane) {
+__device__ __forceinline__ void wf_comvel(const WModel& m, WaveData& d, int lane) {
   if (lane < 6) d.cvel[lane] = 0;
   WSYNC();
   for (int l = 0; l < m.nlevel; l++) {
     const int idx = m.level_start[l] + lane;
     if (idx < m.level_start[l + 1]) {
       const int i = m.level_body[idx];
-      double cvel[6];
+      wreal cvel[6];
       for (int c = 0; c < 6; c++) cvel[c] = d.cvel[6 * m.body_parentid[i] + c];
       for (int j = m.body_jntadr[i]; j < m.body_jntadr[i] + m.body_jntnum[i]; j++) {
         int da = m.jnt_dofadr[j];
@@ -217,14 +216,14 @@ __device__ __forceinline__ void wf_comvel(const WaveModel& m, WaveData& d, int l
 }
 
 // ---- o_passive, o_rne (bias forces), o_actuation, qfrc_smooth
-__device__ __forceinline__ void wf_smooth_forces(const WaveModel& m, WaveData& d, int lane, bool& bad_ctrl) {
+__device__ __forceinline__ void wf_smooth_forces(const WModel& m, WaveData& d, int lane, bool& bad_ctrl) {
   const int nb = m.nbody, nv = m.nv, nu = m.nu;
   // passive
   if (lane < nv) {
-    double f = 0;
+    wreal f = 0;
     if (!(m.disableflags & MJPCX_DSBL_PASSIVE)) {
       const int j = m.dof_jntid[lane], jt = m.jnt_type[j];
-      const double k = m.jnt_stiffness[j];
+      const wreal k = m.jnt_stiffness[j];
       if (k != 0 && (jt == kJntSlide || jt == kJntHinge)) f -= k * (d.qpos[m.jnt_qposadr[j]] - m.qpos_spring[m.jnt_qposadr[j]]);
       f -= m.dof_damping[lane] * d.qvel[lane];
     }
@@ -232,7 +231,7 @@ __device__ __forceinline__ void wf_smooth_forces(const WaveModel& m, WaveData& d
   }
   // RNE forward: cacc level by level, cfrc per body
   if (lane < 6) {
-    d.cacc[lane] = (lane >= 3 && !(m.disableflags & MJPCX_DSBL_GRAVITY)) ? -m.gravity[lane - 3] : 0.0;
+    d.cacc[lane] = (lane >= 3 && !(m.disableflags & MJPCX_DSBL_GRAVITY)) ? -m.gravity[lane - 3] : WL(0.0);
     d.cfrc[lane] = 0;
   }
   WSYNC();
@@ -240,7 +239,7 @@ __device__ __forceinline__ void wf_smooth_forces(const WaveModel& m, WaveData& d
     const int idx = m.level_start[l] + lane;
     if (idx < m.level_start[l + 1]) {
       const int i = m.level_body[idx];
-      double cacc[6], t1[6], t2[6], t3[6];
+      wreal cacc[6], t1[6], t2[6], t3[6];
       for (int c = 0; c < 6; c++) cacc[c] = d.cacc[6 * m.body_parentid[i] + c];
       const int da = m.body_dofadr[i];
       for (int k = da; k >= 0 && k < da + m.body_dofnum[i]; k++)
@@ -257,7 +256,7 @@ __device__ __forceinline__ void wf_smooth_forces(const WaveModel& m, WaveData& d
   if (lane < nb && lane > 0) {
     const int i = lane;
     unsigned long long mask = m.body_subtree_mask[i];
-    double s[6] = {0, 0, 0, 0, 0, 0};
+    wreal s[6] = {0, 0, 0, 0, 0, 0};
     while (mask) {
       const int j = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
@@ -275,13 +274,13 @@ __device__ __forceinline__ void wf_smooth_forces(const WaveModel& m, WaveData& d
   WSYNC();
   if (lane < nu) {
     const int i = lane;
-    double force = 0;
+    wreal force = 0;
     if (!(m.disableflags & MJPCX_DSBL_ACTUATION)) {
-      double ctrl = d.ctrl[i];
+      wreal ctrl = d.ctrl[i];
       if (m.actuator_ctrllimited[i] && !(m.disableflags & MJPCX_DSBL_CLAMPCTRL))
         ctrl = clampv(ctrl, m.actuator_ctrlrange[2 * i], m.actuator_ctrlrange[2 * i + 1]);
       const int j = m.actuator_trnid[i], qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-      const double gear = m.actuator_gear[i];
+      const wreal gear = m.actuator_gear[i];
       force = m.actuator_gainprm[3 * i] * ctrl;
       if (m.actuator_biastype[i] == 1)
         force += m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * gear * d.qpos[qa] + m.actuator_biasprm[3 * i + 2] * gear * d.qvel[da];
@@ -301,12 +300,12 @@ __device__ __forceinline__ void wf_smooth_forces(const WaveModel& m, WaveData& d
 }
 
 // ---- o_collision: one lane per moving geom against each static geom; order-preserving compaction
-__device__ __forceinline__ void wf_contact_param(const WaveModel& m, int g1, int g2, WaveContact& c) {
-  const double margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
-  const double gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
+__device__ __forceinline__ void wf_contact_param(const WModel& m, int g1, int g2, WaveContact& c) {
+  const wreal margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
+  const wreal gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
   c.margin = margin;
   c.includemargin = margin - gap;
-  double fr[3];
+  wreal fr[3];
   const int p1 = m.geom_priority[g1], p2 = m.geom_priority[g2];
   if (p1 != p2) {
     const int g = p1 > p2 ? g1 : g2;
@@ -317,8 +316,8 @@ __device__ __forceinline__ void wf_contact_param(const WaveModel& m, int g1, int
   } else {
     c.dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
     for (int k = 0; k < 3; k++) fr[k] = fmax(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
-    const double s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
-    const double mix = (s1 >= kMinVal && s2 >= kMinVal) ? s1 / (s1 + s2) : (s1 < kMinVal && s2 < kMinVal ? 0.5 : (s1 < kMinVal ? 0.0 : 1.0));
+    const wreal s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
+    const wreal mix = (s1 >= kMinVal && s2 >= kMinVal) ? s1 / (s1 + s2) : (s1 < kMinVal && s2 < kMinVal ? WL(0.5) : (s1 < kMinVal ? WL(0.0) : WL(1.0)));
     for (int k = 0; k < 2; k++) c.solref[k] = mix * m.geom_solref[2 * g1 + k] + (1 - mix) * m.geom_solref[2 * g2 + k];
     for (int k = 0; k < 5; k++) c.solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
   }
@@ -328,27 +327,27 @@ __device__ __forceinline__ void wf_contact_param(const WaveModel& m, int g1, int
   c.dim0 = c.dim;
 }
 
-__device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, int lane) {
+__device__ __forceinline__ void wf_collision(const WModel& m, WaveData& d, int lane) {
   if (lane == 0) d.counters[0] = 0;
   WSYNC();
   if (m.disableflags & (MJPCX_DSBL_CONSTRAINT | MJPCX_DSBL_CONTACT)) return;
   // this lane's moving geom
   const bool have = lane < m.ndynamic_geom;
   const int g2 = have ? m.dynamic_geom[lane] : 0;
-  double p2[3] = {0, 0, 0}, R2[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  wreal p2[3] = {0, 0, 0}, R2[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   if (have) wf_geom_pose(m, d, g2, p2, R2);
   const int t2 = have ? m.geom_type[g2] : -1;
-  const double s2[3] = {have ? m.geom_size[3 * g2] : 0, have ? m.geom_size[3 * g2 + 1] : 0, have ? m.geom_size[3 * g2 + 2] : 0};
+  const wreal s2[3] = {have ? m.geom_size[3 * g2] : 0, have ? m.geom_size[3 * g2 + 1] : 0, have ? m.geom_size[3 * g2 + 2] : 0};
   for (int si = 0; si < m.nstatic_geom; si++) {
     const int g1 = m.static_geom[si], t1 = m.geom_type[g1];
     if (t1 != MJPCX_GEOM_PLANE && t1 != MJPCX_GEOM_SPHERE && t1 != MJPCX_GEOM_BOX) continue;
-    double p1[3], R1[9];
+    wreal p1[3], R1[9];
     wf_geom_pose(m, d, g1, p1, R1);  // wave-uniform
     // up to 4 candidate contacts of this lane: dist, pos, normal
-    double cd[4], cp[4][3], cn[3] = {0, 0, 1};
+    wreal cd[4], cp[4][3], cn[3] = {0, 0, 1};
     int cnt = 0;
     // candidate slots are written through a switch on the count: static indices keep cd / cp in registers
-    auto push = [&](double dist, double px, double py, double pz) {
+    auto push = [&](wreal dist, wreal px, wreal py, wreal pz) {
       switch (cnt) {
         case 0: cd[0] = dist; cp[0][0] = px; cp[0][1] = py; cp[0][2] = pz; break;
         case 1: cd[1] = dist; cp[1][0] = px; cp[1][1] = py; cp[1][2] = pz; break;
@@ -357,68 +356,68 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
       }
       cnt++;
     };
-    double margin = 0;
+    wreal margin = 0;
     const bool pair = have && ((m.geom_contype[g1] & m.geom_conaffinity[g2]) || (m.geom_contype[g2] & m.geom_conaffinity[g1]));
     if (pair) {
       margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
       if (t1 == MJPCX_GEOM_PLANE) {
-        const double n[3] = {R1[2], R1[5], R1[8]};
+        const wreal n[3] = {R1[2], R1[5], R1[8]};
         for (int k = 0; k < 3; k++) cn[k] = n[k];
-        auto sphere_plane = [&](const double* c, double r) {
-          const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2] - r;
-          if (dist < margin) push(dist, c[0] - n[0] * (r + 0.5 * dist), c[1] - n[1] * (r + 0.5 * dist), c[2] - n[2] * (r + 0.5 * dist));
+        auto sphere_plane = [&](const wreal* c, wreal r) {
+          const wreal dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2] - r;
+          if (dist < margin) push(dist, c[0] - n[0] * (r + WL(0.5) * dist), c[1] - n[1] * (r + WL(0.5) * dist), c[2] - n[2] * (r + WL(0.5) * dist));
         };
         if (t2 == MJPCX_GEOM_SPHERE) {
           sphere_plane(p2, s2[0]);
         } else if (t2 == MJPCX_GEOM_CAPSULE) {
           for (int sgn = -1; sgn <= 1; sgn += 2) {
-            double c[3];
+            wreal c[3];
             for (int k = 0; k < 3; k++) c[k] = p2[k] + sgn * s2[1] * R2[3 * k + 2];
             sphere_plane(c, s2[0]);
           }
         } else if (t2 == MJPCX_GEOM_BOX) {
           for (int i = 0; i < 8 && cnt < 4; i++) {
-            const double loc[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])};
-            double c[3];
+            const wreal loc[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])};
+            wreal c[3];
             mv3(c, R2, loc);
             for (int k = 0; k < 3; k++) c[k] += p2[k];
-            const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
-            if (dist < margin) push(dist, c[0] - 0.5 * dist * n[0], c[1] - 0.5 * dist * n[1], c[2] - 0.5 * dist * n[2]);
+            const wreal dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
+            if (dist < margin) push(dist, c[0] - WL(0.5) * dist * n[0], c[1] - WL(0.5) * dist * n[1], c[2] - WL(0.5) * dist * n[2]);
           }
         } else if (t2 == MJPCX_GEOM_CYLINDER) {
-          const double a[3] = {R2[2], R2[5], R2[8]};
-          const double pa = n[0] * a[0] + n[1] * a[1] + n[2] * a[2];
-          const double sgn = pa > 0 ? -1.0 : 1.0;
-          double v[3], vn = 0;
+          const wreal a[3] = {R2[2], R2[5], R2[8]};
+          const wreal pa = n[0] * a[0] + n[1] * a[1] + n[2] * a[2];
+          const wreal sgn = pa > 0 ? -WL(1.0) : WL(1.0);
+          wreal v[3], vn = 0;
           for (int k = 0; k < 3; k++) { v[k] = -(n[k] - pa * a[k]); vn += v[k] * v[k]; }
           vn = sqrt(vn);
-          if (vn < 1e-10) { v[0] = R2[0]; v[1] = R2[3]; v[2] = R2[6]; vn = 1; }
+          if (vn < WL(1e-10)) { v[0] = R2[0]; v[1] = R2[3]; v[2] = R2[6]; vn = 1; }
           for (int k = 0; k < 3; k++) v[k] /= vn;
-          double w[3];
+          wreal w[3];
           cr3(w, a, v);
-          const double cs[3] = {1.0, -0.5, -0.5}, sn[3] = {0.0, 0.8660254037844386, -0.8660254037844386};
+          const wreal cs[3] = {WL(1.0), -WL(0.5), -WL(0.5)}, sn[3] = {WL(0.0), WL(0.8660254037844386), -WL(0.8660254037844386)};
           for (int i = 0; i < 4; i++) {
-            const double side = i < 3 ? sgn : -sgn, cc = i < 3 ? cs[i] : 1.0, ss = i < 3 ? sn[i] : 0.0;
-            double c[3];
+            const wreal side = i < 3 ? sgn : -sgn, cc = i < 3 ? cs[i] : WL(1.0), ss = i < 3 ? sn[i] : WL(0.0);
+            wreal c[3];
             for (int k = 0; k < 3; k++) c[k] = p2[k] + side * s2[1] * a[k] + s2[0] * (cc * v[k] + ss * w[k]);
-            const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
-            if (dist < margin) push(dist, c[0] - 0.5 * dist * n[0], c[1] - 0.5 * dist * n[1], c[2] - 0.5 * dist * n[2]);
+            const wreal dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
+            if (dist < margin) push(dist, c[0] - WL(0.5) * dist * n[0], c[1] - WL(0.5) * dist * n[1], c[2] - WL(0.5) * dist * n[2]);
           }
         }
       } else if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
-        double n[3], len = 0;
+        wreal n[3], len = 0;
         for (int k = 0; k < 3; k++) { n[k] = p2[k] - p1[k]; len += n[k] * n[k]; }
         len = sqrt(len);
         if (len < kMinVal) { n[0] = 1; n[1] = n[2] = 0; } else for (int k = 0; k < 3; k++) n[k] /= len;
-        const double r1 = m.geom_size[3 * g1], dist = len - r1 - s2[0];
+        const wreal r1 = m.geom_size[3 * g1], dist = len - r1 - s2[0];
         if (dist < margin) {
           cd[0] = dist;
-          for (int k = 0; k < 3; k++) { cp[0][k] = p1[k] + n[k] * (r1 + 0.5 * dist); cn[k] = n[k]; }
+          for (int k = 0; k < 3; k++) { cp[0][k] = p1[k] + n[k] * (r1 + WL(0.5) * dist); cn[k] = n[k]; }
           cnt = 1;
         }
       } else if (t1 == MJPCX_GEOM_BOX && t2 == MJPCX_GEOM_SPHERE) {
-        const double* s1 = m.geom_size + 3 * g1;
-        double rel[3], loc[3], clamped[3];
+        const wreal* s1 = m.geom_size + 3 * g1;
+        wreal rel[3], loc[3], clamped[3];
         for (int k = 0; k < 3; k++) rel[k] = p2[k] - p1[k];
         for (int k = 0; k < 3; k++) loc[k] = R1[k] * rel[0] + R1[3 + k] * rel[1] + R1[6 + k] * rel[2];
         bool inside = true;
@@ -426,26 +425,26 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
           clamped[k] = loc[k] < -s1[k] ? -s1[k] : (loc[k] > s1[k] ? s1[k] : loc[k]);
           if (clamped[k] != loc[k]) inside = false;
         }
-        double nl[3] = {0, 0, 0}, dist;
+        wreal nl[3] = {0, 0, 0}, dist;
         if (!inside) {
-          double len = 0;
+          wreal len = 0;
           for (int k = 0; k < 3; k++) { nl[k] = loc[k] - clamped[k]; len += nl[k] * nl[k]; }
           len = sqrt(len);
           for (int k = 0; k < 3; k++) nl[k] /= len;
           dist = len - s2[0];
         } else {
-          int best = 0; double bd = 1e300;
-          for (int k = 0; k < 3; k++) { const double dd = s1[k] - fabs(loc[k]); if (dd < bd) { bd = dd; best = k; } }
+          int best = 0; wreal bd = WL(1e300);
+          for (int k = 0; k < 3; k++) { const wreal dd = s1[k] - fabs(loc[k]); if (dd < bd) { bd = dd; best = k; } }
           nl[best] = loc[best] >= 0 ? 1 : -1;
           clamped[best] = nl[best] * s1[best];
           dist = -bd - s2[0];
         }
         if (dist < margin) {
-          double n[3], surf[3];
+          wreal n[3], surf[3];
           mv3(n, R1, nl);
           mv3(surf, R1, clamped);
           cd[0] = dist;
-          for (int k = 0; k < 3; k++) { cp[0][k] = p1[k] + surf[k] + 0.5 * dist * n[k]; cn[k] = n[k]; }
+          for (int k = 0; k < 3; k++) { cp[0][k] = p1[k] + surf[k] + WL(0.5) * dist * n[k]; cn[k] = n[k]; }
           cnt = 1;
         }
       }
@@ -486,66 +485,66 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
   for (int p0 = 0; p0 < m.npair; p0 += 64) {
     const bool on = p0 + lane < m.npair;
     const int g1 = on ? m.pair_g1[p0 + lane] : 0, g2 = on ? m.pair_g2[p0 + lane] : 0;
-    double cd[2] = {0, 0}, cp[2][3] = {{0, 0, 0}, {0, 0, 0}}, cn[2][3] = {{1, 0, 0}, {1, 0, 0}};
+    wreal cd[2] = {0, 0}, cp[2][3] = {{0, 0, 0}, {0, 0, 0}}, cn[2][3] = {{1, 0, 0}, {1, 0, 0}};
     int cnt = 0;
     // conservative bounding-sphere pretest on the geom centres (never rejects a pair the narrow phase would accept):
     // most steps have no self-contact and skip the poses, the narrow phase and the compaction altogether
     bool near = false;
-    double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
-    const double margin = on ? fmax(m.geom_margin[g1], m.geom_margin[g2]) : 0.0;
+    wreal p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+    const wreal margin = on ? fmax(m.geom_margin[g1], m.geom_margin[g2]) : WL(0.0);
     if (on) {
       const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-      double v1[3], v2[3];
+      wreal v1[3], v2[3];
       mv3(v1, d.xmat + 9 * b1, m.geom_pos + 3 * g1);
       mv3(v2, d.xmat + 9 * b2, m.geom_pos + 3 * g2);
-      double dd = 0;
+      wreal dd = 0;
       for (int k = 0; k < 3; k++) { p1[k] = d.xpos[3 * b1 + k] + v1[k]; p2[k] = d.xpos[3 * b2 + k] + v2[k]; dd += (p1[k] - p2[k]) * (p1[k] - p2[k]); }
-      const double reach = m.geom_size[3 * g1] + m.geom_size[3 * g2] + margin + 1e-6 +
-                           (m.geom_type[g1] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g1 + 1] : 0.0) +
-                           (m.geom_type[g2] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g2 + 1] : 0.0);
+      const wreal reach = m.geom_size[3 * g1] + m.geom_size[3 * g2] + margin + WL(1e-6) +
+                           (m.geom_type[g1] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g1 + 1] : WL(0.0)) +
+                           (m.geom_type[g2] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g2 + 1] : WL(0.0));
       near = dd <= reach * reach;
     }
     if (__ballot(near) == 0ull) continue;
     if (near) {
-      double R1[9], R2[9];
+      wreal R1[9], R2[9];
       wf_geom_pose(m, d, g1, p1, R1);
       wf_geom_pose(m, d, g2, p2, R2);
       const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-      const double r1 = m.geom_size[3 * g1], r2 = m.geom_size[3 * g2];
-      auto spheres = [&](const double* c1, const double* c2) {
-        double n[3], len = 0;
+      const wreal r1 = m.geom_size[3 * g1], r2 = m.geom_size[3 * g2];
+      auto spheres = [&](const wreal* c1, const wreal* c2) {
+        wreal n[3], len = 0;
         for (int k = 0; k < 3; k++) { n[k] = c2[k] - c1[k]; len += n[k] * n[k]; }
         len = sqrt(len);
         if (len < kMinVal) { n[0] = 1; n[1] = n[2] = 0; } else for (int k = 0; k < 3; k++) n[k] /= len;
-        const double dist = len - r1 - r2;
+        const wreal dist = len - r1 - r2;
         if (dist < margin) {
-          if (cnt == 0) { cd[0] = dist; for (int k = 0; k < 3; k++) { cp[0][k] = c1[k] + n[k] * (r1 + 0.5 * dist); cn[0][k] = n[k]; } }
-          else { cd[1] = dist; for (int k = 0; k < 3; k++) { cp[1][k] = c1[k] + n[k] * (r1 + 0.5 * dist); cn[1][k] = n[k]; } }
+          if (cnt == 0) { cd[0] = dist; for (int k = 0; k < 3; k++) { cp[0][k] = c1[k] + n[k] * (r1 + WL(0.5) * dist); cn[0][k] = n[k]; } }
+          else { cd[1] = dist; for (int k = 0; k < 3; k++) { cp[1][k] = c1[k] + n[k] * (r1 + WL(0.5) * dist); cn[1][k] = n[k]; } }
           cnt++;
         }
       };
-      auto seg = [&](const double* p, const double* a, double h, const double* c) {
-        const double x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
+      auto seg = [&](const wreal* p, const wreal* a, wreal h, const wreal* c) {
+        const wreal x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
         return x < -h ? -h : (x > h ? h : x);
       };
       if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
         spheres(p1, p2);
       } else if (t1 == MJPCX_GEOM_SPHERE) {
-        const double a2[3] = {R2[2], R2[5], R2[8]};
-        const double x = seg(p2, a2, m.geom_size[3 * g2 + 1], p1);
-        const double c2[3] = {p2[0] + x * a2[0], p2[1] + x * a2[1], p2[2] + x * a2[2]};
+        const wreal a2[3] = {R2[2], R2[5], R2[8]};
+        const wreal x = seg(p2, a2, m.geom_size[3 * g2 + 1], p1);
+        const wreal c2[3] = {p2[0] + x * a2[0], p2[1] + x * a2[1], p2[2] + x * a2[2]};
         spheres(p1, c2);
       } else {
-        const double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
-        const double h1 = m.geom_size[3 * g1 + 1], h2 = m.geom_size[3 * g2 + 1];
-        const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-        const double mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
-        const double u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
-        const double v = a2[0] * dif[0] + a2[1] * dif[1] + a2[2] * dif[2];
-        const double det = 1.0 - mb * mb;
-        double c1[3], c2[3];
+        const wreal a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
+        const wreal h1 = m.geom_size[3 * g1 + 1], h2 = m.geom_size[3 * g2 + 1];
+        const wreal dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+        const wreal mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
+        const wreal u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
+        const wreal v = a2[0] * dif[0] + a2[1] * dif[1] + a2[2] * dif[2];
+        const wreal det = WL(1.0) - mb * mb;
+        wreal c1[3], c2[3];
         if (fabs(det) >= kMinVal) {
-          double x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
+          wreal x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
           if (x1 > h1) { x1 = h1; x2 = v - mb * x1; } else if (x1 < -h1) { x1 = -h1; x2 = v - mb * x1; }
           if (x2 > h2) { x2 = h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
           else if (x2 < -h2) { x2 = -h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
@@ -553,14 +552,14 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
           spheres(c1, c2);
         } else {
           for (int e = 0; e < 4 && cnt < 2; e++) {
-            const double sgn = (e & 1) ? -1.0 : 1.0;
+            const wreal sgn = (e & 1) ? -WL(1.0) : WL(1.0);
             if (e < 2) {
               for (int k = 0; k < 3; k++) c1[k] = p1[k] + sgn * h1 * a1[k];
-              const double x2 = seg(p2, a2, h2, c1);
+              const wreal x2 = seg(p2, a2, h2, c1);
               for (int k = 0; k < 3; k++) c2[k] = p2[k] + x2 * a2[k];
             } else {
               for (int k = 0; k < 3; k++) c2[k] = p2[k] + sgn * h2 * a2[k];
-              const double x1 = seg(p1, a1, h1, c2);
+              const wreal x1 = seg(p1, a1, h1, c2);
               for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k];
             }
             spheres(c1, c2);
@@ -602,7 +601,7 @@ __device__ __forceinline__ void wf_collision(const WaveModel& m, WaveData& d, in
 }
 
 // ---- o_make_constraint_full: rows in the order friction loss, limits, contacts; then impedance/aref/R per row
-__device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData& d, int lane) {
+__device__ __forceinline__ void wf_make_constraint(const WModel& m, WaveData& d, int lane) {
   const int nv = m.nv;
   int nefc = 0;
   if (m.disableflags & MJPCX_DSBL_CONSTRAINT) { if (lane == 0) { d.counters[0] = 0; d.counters[1] = 0; } WSYNC(); return; }
@@ -624,10 +623,10 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
   // limits: one lane per joint, sides -1 then +1
   {
     bool on0 = false, on1 = false;
-    double dist0 = 0, dist1 = 0, margin = 0;
+    wreal dist0 = 0, dist1 = 0, margin = 0;
     if (!(m.disableflags & MJPCX_DSBL_LIMIT) && lane < m.njnt && m.jnt_limited[lane] &&
         (m.jnt_type[lane] == kJntSlide || m.jnt_type[lane] == kJntHinge)) {
-      const double value = d.qpos[m.jnt_qposadr[lane]];
+      const wreal value = d.qpos[m.jnt_qposadr[lane]];
       margin = m.jnt_margin[lane];
       dist0 = -(m.jnt_range[2 * lane] - value);      // side -1: lower bound
       dist1 = m.jnt_range[2 * lane + 1] - value;     // side +1: upper bound
@@ -650,9 +649,9 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
   // fixed-tendon limits: one lane per tendon (constant Jacobian = the wrap coefficients)
   {
     bool on0 = false, on1 = false;
-    double dist0 = 0, dist1 = 0, margin = 0;
+    wreal dist0 = 0, dist1 = 0, margin = 0;
     if (!(m.disableflags & MJPCX_DSBL_LIMIT) && lane < m.ntendon && m.tendon_limited[lane]) {
-      double value = 0;
+      wreal value = 0;
       for (int w = m.tendon_adr[lane]; w < m.tendon_adr[lane] + m.tendon_num[lane]; w++) value += m.wrap_prm[w] * d.qpos[m.jnt_qposadr[m.wrap_objid[w]]];
       margin = m.tendon_margin[lane];
       dist0 = -(m.tendon_range[2 * lane] - value);
@@ -700,7 +699,7 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
     c.efc = my_efc; c.nrow = my_rows;
     c.dim = pyr ? dim0 : my_rows;
     c.dofmask = m.body_dofmask[m.geom_bodyid[c.g1]] ^ m.body_dofmask[m.geom_bodyid[c.g2]];  // common ancestors cancel exactly
-    c.mu = pyr ? c.friction[0] : c.friction[0] / sqrt(m.impratio > kMinVal ? m.impratio : 1.0);
+    c.mu = pyr ? c.friction[0] : c.friction[0] / sqrt(m.impratio > kMinVal ? m.impratio : WL(1.0));
     for (int row = 0; row < my_rows; row++) {
       const int r = my_efc + row;
       d.efc_type[r] = pyr ? kEfcPyramid : (dim0 == 1 ? kEfcNormal : (row == 0 ? kEfcElliptic : kEfcConeRow));
@@ -717,25 +716,25 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
     if (t != kEfcNormal && t != kEfcElliptic && t != kEfcConeRow && t != kEfcPyramid) continue;
     const WaveContact& c = d.con[d.efc_id[r]];
     const int row = r - c.efc;
-    double v = 0;
+    wreal v = 0;
     if ((c.dofmask >> k) & 1u) {
       const int b2 = m.geom_bodyid[c.g2];
       const bool second = (m.body_dofmask[b2] >> k) & 1u;   // the dof is on exactly one of the two chains
       const int body = second ? b2 : m.geom_bodyid[c.g1];
-      const double* cd = d.cdof + 6 * k;
-      const double* com = d.subtree_com + 3 * m.body_rootid[body];
-      const double off[3] = {c.pos[0] - com[0], c.pos[1] - com[1], c.pos[2] - com[2]};
-      double lin[3];
+      const wreal* cd = d.cdof + 6 * k;
+      const wreal* com = d.subtree_com + 3 * m.body_rootid[body];
+      const wreal off[3] = {c.pos[0] - com[0], c.pos[1] - com[1], c.pos[2] - com[2]};
+      wreal lin[3];
       cr3(lin, cd, off);
       // axis j of the contact frame on the translational (j < 3) or rotational Jacobian of the point
       auto along = [&](int j) {
-        const double* ax = c.frame + 3 * (j < 3 ? j : j - 3);
+        const wreal* ax = c.frame + 3 * (j < 3 ? j : j - 3);
         return j < 3 ? ax[0] * (cd[3] + lin[0]) + ax[1] * (cd[4] + lin[1]) + ax[2] * (cd[5] + lin[2])
                      : ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
       };
       if (t == kEfcPyramid) {
         const int j = 1 + row / 2;
-        const double f = (row & 1) ? -c.friction[j - 1] : c.friction[j - 1];
+        const wreal f = (row & 1) ? -c.friction[j - 1] : c.friction[j - 1];
         v = along(0) + f * along(j);
       } else {
         v = along(row);
@@ -746,13 +745,13 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
   }
   WSYNC();
   // per-row impedance, reference acceleration, regulariser (cone rows after their normal row)
-  double kk = 0, bb = 0, vel = 0;
+  wreal kk = 0, bb = 0, vel = 0;
   int type = -1, id = 0;
   if (lane < nefc) {
     const int r = lane;
     type = d.efc_type[r]; id = d.efc_id[r];
-    const double *solref, *solimp;
-    double diag;
+    const wreal *solref, *solimp;
+    wreal diag;
     if (type == kEfcFriction) { solref = m.dof_solref + 2 * id; solimp = m.dof_solimp + 5 * id; diag = m.dof_invweight0[id]; }
     else if (type == kEfcLimit) { solref = m.jnt_solref + 2 * id; solimp = m.jnt_solimp + 5 * id; diag = m.dof_invweight0[m.jnt_dofadr[id]]; }
     else if (type == kEfcTendon) { solref = m.tendon_solref_lim + 2 * id; solimp = m.tendon_solimp_lim + 5 * id; diag = m.tendon_invweight0[id]; }
@@ -763,7 +762,7 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
       diag = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
       if (type == kEfcPyramid) {  // mj_diagApprox: tran + friction^2 * (tran | rot)
         const int j = 1 + (r - c.efc) / 2;
-        const double f = c.friction[j - 1];
+        const wreal f = c.friction[j - 1];
         diag += f * f * (j < 3 ? diag : m.body_invweight0[2 * b1 + 1] + m.body_invweight0[2 * b2 + 1]);
       }
     }
@@ -771,39 +770,39 @@ __device__ __forceinline__ void wf_make_constraint(const WaveModel& m, WaveData&
     for (int k = 0; k < nv; k++) vel += d.efc_J[r * nv + k] * d.qvel[k];
     w_solref_kb(m, solref, solimp, kk, bb);
     if (type != kEfcConeRow) {
-      const double pos = d.efc_pos[r] - d.efc_margin[r];
-      const double imp = w_impedance(solimp, pos);
-      const double R = (1 - imp) / imp * diag;
+      const wreal pos = d.efc_pos[r] - d.efc_margin[r];
+      const wreal imp = w_impedance(solimp, pos);
+      const wreal R = (1 - imp) / imp * diag;
       d.efc_R[r] = R < kMinVal ? kMinVal : R;
       d.efc_aref[r] = -bb * vel - kk * imp * pos;
-      d.efc_D[r] = 1.0 / d.efc_R[r];
+      d.efc_D[r] = WL(1.0) / d.efc_R[r];
     }
   }
   WSYNC();
-  double Rpy = 0;
+  wreal Rpy = 0;
   if (lane < nefc && type == kEfcConeRow) {
     const int r = lane;
     const WaveContact& c = d.con[id];
-    const double f = c.friction[r - c.efc - 1];
+    const wreal f = c.friction[r - c.efc - 1];
     d.efc_R[r] = d.efc_R[c.efc] * (c.mu * c.mu) / (f * f);
     d.efc_aref[r] = -bb * vel;
-    d.efc_D[r] = 1.0 / d.efc_R[r];
+    d.efc_D[r] = WL(1.0) / d.efc_R[r];
   } else if (lane < nefc && type == kEfcPyramid) {  // every edge: Rpy = 2 mu^2 R of the first edge (read, sync, then write)
     const WaveContact& c = d.con[id];
     Rpy = 2 * c.mu * c.mu * d.efc_R[c.efc];
     if (Rpy < kMinVal) Rpy = kMinVal;
   }
   WSYNC();
-  if (lane < nefc && type == kEfcPyramid) { d.efc_R[lane] = Rpy; d.efc_D[lane] = 1.0 / Rpy; }
+  if (lane < nefc && type == kEfcPyramid) { d.efc_R[lane] = Rpy; d.efc_D[lane] = WL(1.0) / Rpy; }
   WSYNC();
 }
 
 // ---- penalties: one lane per row; a cone is evaluated by the lane of its first row
-struct ConeEval { double cost, g, h; };
+struct ConeEval { wreal cost, g, h; };
 // value/force/zone at x = jar (+ alpha jv when jv != nullptr); derivative terms along jv when requested
 // LDS-typed views (address space 3): the out-of-line row evaluator would otherwise see generic pointers and go through
 // FLAT loads (aperture check, vmcnt + lgkmcnt) instead of ds_read
-typedef __attribute__((address_space(3))) double wlds_f64;
+typedef __attribute__((address_space(3))) wreal wlds_f64;
 typedef __attribute__((address_space(3))) int wlds_i32;
 typedef __attribute__((address_space(3))) WaveContact wlds_con;
 struct RowView {  // by value into the out-of-line row evaluator
@@ -813,34 +812,34 @@ struct RowView {  // by value into the out-of-line row evaluator
   wlds_f64* efc_force;
   const wlds_con* con;
 };
-struct RowResult { double cost, g1, h2; };
+struct RowResult { wreal cost, g1, h2; };
 __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const wlds_f64* jar, const wlds_f64* jv, bool have_jv,
-                                                   double alpha, bool write_force) {
-  double cost = 0, g1 = 0, h2 = 0;
+                                                   wreal alpha, bool write_force) {
+  wreal cost = 0, g1 = 0, h2 = 0;
   const int type = d.efc_type[r];
-  const double D = d.efc_D[r];
-  const double v = have_jv ? jv[r] : 0.0;
-  const double x = jar[r] + alpha * v;
+  const wreal D = d.efc_D[r];
+  const wreal v = have_jv ? jv[r] : WL(0.0);
+  const wreal x = jar[r] + alpha * v;
   if (type == kEfcFriction) {
-    const double f = d.efc_floss[r], R = d.efc_R[r];
-    if (x <= -R * f) { cost = -0.5 * R * f * f - f * x; g1 = -f * v; if (write_force) { d.efc_force[r] = f; d.efc_zone[r] = kZoneTop; } }
-    else if (x >= R * f) { cost = -0.5 * R * f * f + f * x; g1 = f * v; if (write_force) { d.efc_force[r] = -f; d.efc_zone[r] = kZoneTop; } }
-    else { cost = 0.5 * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
+    const wreal f = d.efc_floss[r], R = d.efc_R[r];
+    if (x <= -R * f) { cost = -WL(0.5) * R * f * f - f * x; g1 = -f * v; if (write_force) { d.efc_force[r] = f; d.efc_zone[r] = kZoneTop; } }
+    else if (x >= R * f) { cost = -WL(0.5) * R * f * f + f * x; g1 = f * v; if (write_force) { d.efc_force[r] = -f; d.efc_zone[r] = kZoneTop; } }
+    else { cost = WL(0.5) * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
   } else if (type == kEfcLimit || type == kEfcNormal || type == kEfcTendon || type == kEfcPyramid) {
-    if (x < 0) { cost = 0.5 * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
+    if (x < 0) { cost = WL(0.5) * D * x * x; g1 = D * x * v; h2 = D * v * v; if (write_force) { d.efc_force[r] = -D * x; d.efc_zone[r] = kZoneBottom; } }
     else if (write_force) { d.efc_force[r] = 0; d.efc_zone[r] = kZoneTop; }
   } else if (type == kEfcElliptic) {
     // loops are unrolled to the maximum cone dimension with guards: static indices keep U/V/X in registers (run-time
     // trip counts would put them in scratch, and this runs for every line-search trial)
     const wlds_con& c = d.con[d.efc_id[r]];
     const int dim = c.dim;
-    const double mu = c.mu;
-    double U[6], V[6], X[6], Dj[6], T = 0;
+    const wreal mu = c.mu;
+    wreal U[6], V[6], X[6], Dj[6], T = 0;
     X[0] = x; U[0] = x * mu; V[0] = v * mu; Dj[0] = D;
 #pragma unroll
     for (int j = 1; j < 6; j++) {
       if (j < dim) {
-        const double vj = have_jv ? jv[r + j] : 0.0, fj = c.friction[j - 1];
+        const wreal vj = have_jv ? jv[r + j] : WL(0.0), fj = c.friction[j - 1];
         X[j] = jar[r + j] + alpha * vj;
         U[j] = X[j] * fj;
         V[j] = vj * fj;
@@ -849,7 +848,7 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
       } else { X[j] = U[j] = V[j] = Dj[j] = 0; }
     }
     T = sqrt(T);
-    const double N = U[0];
+    const wreal N = U[0];
     if (N >= mu * T || (T <= 0 && N >= 0)) {
       if (write_force) {
 #pragma unroll
@@ -861,20 +860,20 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
 #pragma unroll
       for (int j = 0; j < 6; j++) {
         if (j < dim) {
-          const double vj = have_jv ? jv[r + j] : 0.0;
-          cost += 0.5 * Dj[j] * X[j] * X[j]; g1 += Dj[j] * X[j] * vj; h2 += Dj[j] * vj * vj;
+          const wreal vj = have_jv ? jv[r + j] : WL(0.0);
+          cost += WL(0.5) * Dj[j] * X[j] * X[j]; g1 += Dj[j] * X[j] * vj; h2 += Dj[j] * vj * vj;
           if (write_force) d.efc_force[r + j] = -Dj[j] * X[j];
         }
       }
       if (write_force) d.efc_zone[r] = kZoneBottom;
     } else {
-      const double Dm = D / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
-      cost = 0.5 * Dm * NT * NT;
-      double UV = 0, VV = 0;
+      const wreal Dm = D / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+      cost = WL(0.5) * Dm * NT * NT;
+      wreal UV = 0, VV = 0;
 #pragma unroll
       for (int j = 1; j < 6; j++) if (j < dim) { UV += U[j] * V[j]; VV += V[j] * V[j]; }
-      const double dNT = V[0] - mu * UV / T;
-      const double d2NT = -mu * (VV / T - UV * UV / (T * T * T));
+      const wreal dNT = V[0] - mu * UV / T;
+      const wreal d2NT = -mu * (VV / T - UV * UV / (T * T * T));
       g1 = Dm * NT * dNT;
       h2 = Dm * (dNT * dNT + NT * d2NT);
       if (write_force) {
@@ -887,8 +886,8 @@ __device__ __noinline__ RowResult wf_row_eval_impl(const RowView d, int r, const
   }
   return RowResult{cost, g1, h2};
 }
-__device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const double* jar, const double* jv, double alpha,
-                                            bool write_force, double& cost, double& g1, double& h2) {
+__device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const wreal* jar, const wreal* jv, wreal alpha,
+                                            bool write_force, wreal& cost, wreal& g1, wreal& h2) {
   const RowView v{(const wlds_i32*)d.efc_type, (const wlds_i32*)d.efc_id, (wlds_i32*)d.efc_zone, (const wlds_f64*)d.efc_D,
                   (const wlds_f64*)d.efc_R, (const wlds_f64*)d.efc_floss, (wlds_f64*)d.efc_force, (const wlds_con*)d.con};
   const RowResult res = wf_row_eval_impl(v, r, (const wlds_f64*)jar, (const wlds_f64*)(jv ? jv : jar), jv != nullptr, alpha, write_force);
@@ -896,9 +895,9 @@ __device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const doub
 }
 
 // cost of all rows at jar; writes force and zone. Returns the wave-uniform sum.
-__device__ __forceinline__ double wf_constraint_cost(WaveData& d, int nefc, int lane) {
-  double c = 0, g, h;
-  if (lane < nefc) wf_row_eval(d, lane, d.jar, nullptr, 0.0, true, c, g, h);
+__device__ __forceinline__ wreal wf_constraint_cost(WaveData& d, int nefc, int lane) {
+  wreal c = 0, g, h;
+  if (lane < nefc) wf_row_eval(d, lane, d.jar, nullptr, WL(0.0), true, c, g, h);
   c = wave_sum(c);
   WSYNC();
   return c;
@@ -906,39 +905,39 @@ __device__ __forceinline__ double wf_constraint_cost(WaveData& d, int nefc, int 
 
 // ---- o_constraint_newton
 template <int NMAX>
-__device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveData& d, int lane, long long* stamp = nullptr, bool have_warm = false) {
+__device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& d, int lane, long long* stamp = nullptr, bool have_warm = false) {
   const int nv = m.nv, ne = d.counters[1];
   if (lane < nv) { d.qfrc_constraint[lane] = 0; d.qacc[lane] = d.qacc_smooth[lane]; }
   WSYNC();
   if (ne == 0) return;
   if (lane < ne) {
-    double s = -d.efc_aref[lane];
+    wreal s = -d.efc_aref[lane];
 #pragma unroll 6
     for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.qacc[k];
     d.jar[lane] = s;
   }
   WSYNC();
-  double cost = wf_constraint_cost(d, ne, lane);
+  wreal cost = wf_constraint_cost(d, ne, lane);
   if (have_warm) {  // warm start (mj_fwdConstraint): begin at the previous step's qacc if its cost is lower
-    double jsave = 0, jw = 0, gauss = 0;
+    wreal jsave = 0, jw = 0, gauss = 0;
     if (lane < ne) {
       jsave = d.jar[lane];
-      double s = -d.efc_aref[lane];
+      wreal s = -d.efc_aref[lane];
 #pragma unroll 6
       for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.qacc_warm[k];
       jw = s;
     }
     if (lane < nv) {
-      double s = 0;
+      wreal s = 0;
 #pragma unroll 6
       for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc_warm[b] - d.qacc_smooth[b]);
-      gauss = 0.5 * s * (d.qacc_warm[lane] - d.qacc_smooth[lane]);
+      gauss = WL(0.5) * s * (d.qacc_warm[lane] - d.qacc_smooth[lane]);
     }
     gauss = wave_sum(gauss);
     WSYNC();
     if (lane < ne) d.jar[lane] = jw;
     WSYNC();
-    const double cw = gauss + wf_constraint_cost(d, ne, lane);
+    const wreal cw = gauss + wf_constraint_cost(d, ne, lane);
     if (cw < cost) {
       cost = cw;
       if (lane < nv) d.qacc[lane] = d.qacc_warm[lane];
@@ -949,16 +948,16 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       wf_constraint_cost(d, ne, lane);  // restore force / zone of the smooth start
     }
   }
-  const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
+  const wreal scale = WL(1.0) / (m.meaninertia * (nv > 1 ? nv : 1));
   bool polish = false;
   long long tacc = 0;
 #define WACC(k) do { if (stamp && lane == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); stamp[k] += now_ - tacc; tacc = now_; } } while (0)
   for (int iter = 0; iter < m.solver_iterations; iter++) {
     if (stamp && lane == 0) tacc = (long long)__builtin_readcyclecounter();
     // gradient = M (qacc - qacc_smooth) - J' force
-    double g = 0;
+    wreal g = 0;
     if (lane < nv) {
-      double s = 0;
+      wreal s = 0;
 #pragma unroll 6
       for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc[b] - d.qacc_smooth[b]);
       d.Ma[lane] = s;
@@ -968,7 +967,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
       d.grad[lane] = g;
       d.search[lane] = -g;
     }
-    const double gnorm = sqrt(wave_sum(lane < nv ? g * g : 0.0));
+    const wreal gnorm = sqrt(wave_sum(lane < nv ? g * g : WL(0.0)));
     if (gnorm == 0) break;
     if (stamp && lane == 0 && iter == 0) stamp[21] = (long long)__builtin_readcyclecounter();
     WACC(32);
@@ -976,30 +975,30 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     if (lane < d.counters[0]) {
       const WaveContact& c = d.con[lane];
       const int r = c.efc, dim = c.dim;
-      double* Hs = d.coneH + 21 * lane;
+      wreal* Hs = d.coneH + 21 * lane;
       if (c.nrow > 0 && dim > 0 && d.efc_type[r] == kEfcElliptic) {
         // lower triangle only, unrolled to dimension 6 with guards (register-resident)
         const int zone = d.efc_zone[r];
-        const double mu = c.mu;
-        double U[6], sc[6], T = 0;
+        const wreal mu = c.mu;
+        wreal U[6], sc[6], T = 0;
         sc[0] = mu; U[0] = d.jar[r] * mu;
 #pragma unroll
         for (int j = 1; j < 6; j++) {
           if (j < dim) { sc[j] = c.friction[j - 1]; U[j] = d.jar[r + j] * sc[j]; T += U[j] * U[j]; } else { sc[j] = 0; U[j] = 0; }
         }
         T = sqrt(T);
-        const double Dm = d.efc_D[r] / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T;
+        const wreal Dm = d.efc_D[r] / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
 #pragma unroll
           for (int k = 0; k <= j; k++) {
             if (j < dim) {
-              double hjk = 0;
-              if (zone == kZoneBottom) hjk = j == k ? d.efc_D[r + j] : 0.0;
+              wreal hjk = 0;
+              if (zone == kZoneBottom) hjk = j == k ? d.efc_D[r + j] : WL(0.0);
               else if (zone == kZoneMiddle) {
                 if (j == 0) hjk = Dm;                                   // (0, 0)
                 else if (k == 0) hjk = -Dm * mu * U[j] / T;             // (j, 0)
-                else hjk = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? 1.0 / T : 0.0) - U[j] * U[k] / (T * T * T));
+                else hjk = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? WL(1.0) / T : WL(0.0)) - U[j] * U[k] / (T * T * T));
                 hjk *= sc[j] * sc[k];
               }
               Hs[j * (j + 1) / 2 + k] = hjk;
@@ -1032,7 +1031,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     // (frictionless contact, pyramid edge, tendon limit), 2 = head of an elliptic cone outside the top zone.
     int my_kind = 0, my_id = 0, my_dim = 1;
     unsigned my_mask = 0;
-    double my_D = 0;
+    wreal my_D = 0;
     {
       const int t = lane < ne ? d.efc_type[lane] : -1;
       const bool is_contact = t >= kEfcNormal;
@@ -1046,18 +1045,18 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     }
     for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
       // e -> (a >= b)
-      int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      int a = (int)((sqrt(WL(8.0) * e + WL(1.0)) - WL(1.0)) * WL(0.5));
       while ((a + 1) * (a + 2) / 2 <= e) a++;
       while (a * (a + 1) / 2 > e) a--;
       const int b = e - a * (a + 1) / 2;
       const unsigned need = (1u << a) | (1u << b);
-      double h = d.H[a * nv + b];
+      wreal h = d.H[a * nv + b];
       for (int r = first_contact; r < ne; r++) {
         const int kind = __builtin_amdgcn_readlane(my_kind, r);  // wave-uniform
         if (kind == 0) continue;
         const unsigned mask = (unsigned)__builtin_amdgcn_readlane((int)my_mask, r);
         if (kind == 1) {
-          const double D = wbcast(my_D, r);
+          const wreal D = wbcast(my_D, r);
           if ((mask & need) == need) h += D * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
           continue;
         }
@@ -1065,15 +1064,15 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
         const int dim = __builtin_amdgcn_readlane(my_dim, r);
         if ((mask & need) == need) {
           {
-            const double* Hs = d.coneH + 21 * ci;
-            double Ja[6], Jb[6], Hl[21];  // fully unrolled with guards: static indices keep these in registers
+            const wreal* Hs = d.coneH + 21 * ci;
+            wreal Ja[6], Jb[6], Hl[21];  // fully unrolled with guards: static indices keep these in registers
 #pragma unroll
-            for (int j = 0; j < 6; j++) { Ja[j] = j < dim ? d.efc_J[(r + j) * nv + a] : 0.0; Jb[j] = j < dim ? d.efc_J[(r + j) * nv + b] : 0.0; }
+            for (int j = 0; j < 6; j++) { Ja[j] = j < dim ? d.efc_J[(r + j) * nv + a] : WL(0.0); Jb[j] = j < dim ? d.efc_J[(r + j) * nv + b] : WL(0.0); }
 #pragma unroll
-            for (int e = 0; e < 21; e++) Hl[e] = e < dim * (dim + 1) / 2 ? Hs[e] : 0.0;
+            for (int e = 0; e < 21; e++) Hl[e] = e < dim * (dim + 1) / 2 ? Hs[e] : WL(0.0);
 #pragma unroll
             for (int j = 0; j < 6; j++) {  // row j of the symmetric block from its packed lower triangle
-              double s = 0;
+              wreal s = 0;
 #pragma unroll
               for (int k = 0; k < 6; k++) s += Hl[j >= k ? j * (j + 1) / 2 + k : k * (k + 1) / 2 + j] * Jb[k];
               h += Ja[j] * s;
@@ -1094,14 +1093,14 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     WACC(35);
     // jv = J search; Gauss part along the ray
     if (lane < ne) {
-      double s = 0;
+      wreal s = 0;
 #pragma unroll 6
       for (int k = 0; k < nv; k++) s += d.efc_J[lane * nv + k] * d.search[k];
       d.jv[lane] = s;
     }
-    double q1 = 0, q2 = 0;
+    wreal q1 = 0, q2 = 0;
     if (lane < nv) {
-      double s = 0;
+      wreal s = 0;
 #pragma unroll 6
       for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * d.search[b];
       q1 = d.search[lane] * d.Ma[lane];
@@ -1111,16 +1110,16 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     WSYNC();
     WACC(36);
     // exact line search: safeguarded 1-D Newton on the (convex, piecewise quadratic) restriction
-    double lo = 0, hi = -1, alpha = 0, d1, d2, c0, g0, h0;
+    wreal lo = 0, hi = -1, alpha = 0, d1, d2, c0, g0, h0;
     c0 = 0; g0 = 0; h0 = 0;
-    if (lane < ne) wf_row_eval(d, lane, d.jar, d.jv, 0.0, false, c0, g0, h0);
+    if (lane < ne) wf_row_eval(d, lane, d.jar, d.jv, WL(0.0), false, c0, g0, h0);
     d1 = wave_sum(g0) + q1; d2 = wave_sum(h0) + q2;
-    const double d10 = fabs(d1);
+    const wreal d10 = fabs(d1);
     // termination as in MuJoCo's PrimalSearch: |derivative| < tolerance * ls_tolerance * |search| / scale
-    const double gtol = m.solver_tolerance * kLsTolerance * sqrt(wave_sum(lane < nv ? d.search[lane] * d.search[lane] : 0.0)) / scale;
+    const wreal gtol = m.solver_tolerance * kLsTolerance * sqrt(wave_sum(lane < nv ? d.search[lane] * d.search[lane] : WL(0.0))) / scale;
     for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
-      double an = alpha - d1 / d2;
-      if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
+      wreal an = alpha - d1 / d2;
+      if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? WL(0.5) * (lo + hi) : 2 * alpha + 1;
       if (an == alpha) break;
       alpha = an;
       c0 = 0; g0 = 0; h0 = 0;
@@ -1135,16 +1134,16 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     if (lane < nv) d.qacc[lane] += alpha * d.search[lane];
     if (lane < ne) d.jar[lane] += alpha * d.jv[lane];
     WSYNC();
-    double gauss = 0;
+    wreal gauss = 0;
     if (lane < nv) {
-      double s = 0;
+      wreal s = 0;
 #pragma unroll 6
       for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc[b] - d.qacc_smooth[b]);
-      gauss = 0.5 * s * (d.qacc[lane] - d.qacc_smooth[lane]);
+      gauss = WL(0.5) * s * (d.qacc[lane] - d.qacc_smooth[lane]);
     }
     gauss = wave_sum(gauss);
-    const double newcost = gauss + wf_constraint_cost(d, ne, lane);
-    const double improvement = cost - newcost;
+    const wreal newcost = gauss + wf_constraint_cost(d, ne, lane);
+    const wreal improvement = cost - newcost;
     cost = newcost;
     WACC(38);
     if (stamp && lane == 0) stamp[20] = iter + 1;
@@ -1152,7 +1151,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
     if (scale * improvement < m.solver_tolerance || scale * gnorm < m.solver_tolerance) polish = true;
   }
   if (lane < nv) {
-    double s = 0;
+    wreal s = 0;
 #pragma unroll 8
     for (int r = 0; r < ne; r++) s += d.efc_J[r * nv + lane] * d.efc_force[r];
     d.qfrc_constraint[lane] = s;
@@ -1163,7 +1162,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WaveModel& m, WaveDat
 // ---- mj_forward up to the constraint solve
 #define WSTAMP(k) do { if (stamp && lane == 0) stamp[k] = (long long)__builtin_readcyclecounter(); } while (0)
 template <int NMAX>
-__device__ __forceinline__ void wf_forward(const WaveModel& m, const WaveTask& tk, WaveData& d, int lane, bool& bad_ctrl,
+__device__ __forceinline__ void wf_forward(const WModel& m, const WTask& tk, WaveData& d, int lane, bool& bad_ctrl,
                                            long long* stamp, bool have_warm) {
   const int nv = m.nv;
   WSTAMP(1);
@@ -1194,9 +1193,9 @@ __device__ __forceinline__ void wf_forward(const WaveModel& m, const WaveTask& t
 
 // ---- o_euler: implicit joint damping, then integrate positions
 template <int NMAX>
-__device__ __forceinline__ void wf_euler(const WaveModel& m, WaveData& d, int lane, double& time) {
+__device__ __forceinline__ void wf_euler(const WModel& m, WaveData& d, int lane, wreal& time) {
   const int nv = m.nv;
-  const double h = m.timestep;
+  const wreal h = m.timestep;
   if (m.any_damping && !(m.disableflags & MJPCX_DSBL_EULERDAMP)) {
     for (int e = lane; e < nv * nv; e += 64) d.H[e] = d.M[e];
     WSYNC();
@@ -1219,11 +1218,11 @@ __device__ __forceinline__ void wf_euler(const WaveModel& m, WaveData& d, int la
       qa += 3; da += 3;
     }
     if (jt == kJntFree || jt == kJntBall) {
-      double ax[3] = {d.qvel[da], d.qvel[da + 1], d.qvel[da + 2]};
-      const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      wreal ax[3] = {d.qvel[da], d.qvel[da + 1], d.qvel[da + 2]};
+      const wreal n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
       if (n < kMinVal) { ax[0] = 1; ax[1] = ax[2] = 0; }
       else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
-      double qrot[4], q[4];
+      wreal qrot[4], q[4];
       aa2quat(qrot, ax, h * n);
       for (int k = 0; k < 4; k++) q[k] = d.qpos[qa + k];
       q_norm(q);
@@ -1237,4 +1236,4 @@ __device__ __forceinline__ void wf_euler(const WaveModel& m, WaveData& d, int la
   WSYNC();
 }
 
-}  // namespace mjpcx
+} }  // namespace mjpcx::WAVE_NS

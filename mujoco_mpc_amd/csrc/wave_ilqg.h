@@ -7,42 +7,41 @@
 //   * rollout_feedback_wave_kernel : Trajectory::RolloutDiscrete with the index policy of iLQGPlanner::ActionRollouts
 //     (ilqg/planner.cc:630-692) and Trajectory::Rollout with iLQGPolicy::Action (ilqg/policy.cc:82-161), StateDiff in
 //     the tangent space (mj_differentiatePos, utilities.cc:543-553).
-#pragma once
 
-namespace mjpcx {
+namespace mjpcx { namespace WAVE_NS {
 
 // rotation vector taking qb to qa in qb's frame (mju_subQuat); oracle iq_sub
-__device__ __forceinline__ void wq_sub(double* res, const double* qa, const double* qb) {
-  const double qn[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
-  double qd[4];
+__device__ __forceinline__ void wq_sub(wreal* res, const wreal* qa, const wreal* qb) {
+  const wreal qn[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
+  wreal qd[4];
   q_mul(qd, qn, qa);
-  double ax[3] = {qd[1], qd[2], qd[3]};
-  const double s = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  wreal ax[3] = {qd[1], qd[2], qd[3]};
+  const wreal s = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
   if (s > kMinVal) for (int k = 0; k < 3; k++) ax[k] /= s;
-  double speed = 2 * atan2(s, qd[0]);
+  wreal speed = 2 * atan2(s, qd[0]);
   if (speed > kQPi) speed -= 2 * kQPi;
   for (int k = 0; k < 3; k++) res[k] = ax[k] * speed;
 }
 // q <- normalize(q) * exp(v h / 2) (mju_quatIntegrate); oracle iq_integrate
-__device__ __forceinline__ void wq_integrate(double* q, const double* v, double h) {
-  double ax[3] = {v[0], v[1], v[2]};
-  const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+__device__ __forceinline__ void wq_integrate(wreal* q, const wreal* v, wreal h) {
+  wreal ax[3] = {v[0], v[1], v[2]};
+  const wreal n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
   if (n < kMinVal) { ax[0] = 1; ax[1] = ax[2] = 0; } else for (int k = 0; k < 3; k++) ax[k] /= n;
-  double sn, cs;
-  sincos(0.5 * h * n, &sn, &cs);
-  const double qr[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn};
+  wreal sn, cs;
+  w_sincos(WL(0.5) * h * n, &sn, &cs);
+  const wreal qr[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn};
   q_norm(q);
   q_mul(q, q, qr);
 }
 // StateDiff: dx (2 nv, LDS) = (s2 - s1) / 1 in the tangent space; one lane per joint, then one per dof for velocities
-__device__ __forceinline__ void w_state_diff(const WaveModel& m, double* dx, const double* s1, const double* s2, int lane) {
+__device__ __forceinline__ void w_state_diff(const WModel& m, wreal* dx, const wreal* s1, const wreal* s2, int lane) {
   const int nq = m.nq, nv = m.nv;
   if (lane < m.njnt) {
     int qa = m.jnt_qposadr[lane], da = m.jnt_dofadr[lane];
     const int jt = m.jnt_type[lane];
     if (jt == kJntFree) { for (int k = 0; k < 3; k++) dx[da + k] = s2[qa + k] - s1[qa + k]; qa += 3; da += 3; }
     if (jt == kJntFree || jt == kJntBall) {
-      double a[4], b[4], r[3];
+      wreal a[4], b[4], r[3];
       for (int k = 0; k < 4; k++) { a[k] = s2[qa + k]; b[k] = s1[qa + k]; }
       wq_sub(r, a, b);
       for (int k = 0; k < 3; k++) dx[da + k] = r[k];
@@ -52,20 +51,20 @@ __device__ __forceinline__ void w_state_diff(const WaveModel& m, double* dx, con
 }
 
 struct FdWaveArgs {
-  const double *times, *states, *actions;  // [Tn], [Tn][nq+nv], [Tn][nu]
+  const wreal *times, *states, *actions;  // [Tn], [Tn][nq+nv], [Tn][nu]
   int Tn, ncol;                            // ncol = 1 + 2 (2 nv + nu): 0 nominal | +x_j | -x_j | +u_k | -u_k
-  double eps;
-  double* next;    // [Tn][ncol][nq+nv] raw next states
-  double* sensor;  // [Tn][ncol][nr]
+  wreal eps;
+  wreal* next;    // [Tn][ncol][nq+nv] raw next states
+  wreal* sensor;  // [Tn][ncol][nr]
 };
 
 template <int NMAX>
-__global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WaveModel m, const WaveTask tk, const FdWaveArgs f) {
+__global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WModel m, const WTask tk, const FdWaveArgs f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   const int t = blockIdx.x / f.ncol, col = blockIdx.x % f.ncol;
   const int nq = m.nq, nv = m.nv, nu = m.nu, ndx = 2 * nv, ds = nq + nv, nr = tk.nr;
-  double *lnodes, *ltimes;
+  wreal *lnodes, *ltimes;
   WaveData d = wave_carve(smem_raw, m, tk, 1, lnodes, ltimes);
   for (int i = lane; i < nq; i += 64) d.qpos[i] = f.states[(size_t)t * ds + i];
   for (int i = lane; i < nv; i += 64) d.qvel[i] = f.states[(size_t)t * ds + nq + i];
@@ -74,17 +73,17 @@ __global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WaveModel 
   WSYNC();
   if (col > 0 && lane == 0) {
     int j = col - 1;
-    double sign = 1;
+    wreal sign = 1;
     if (j < 2 * ndx) { if (j >= ndx) { j -= ndx; sign = -1; } }
     else { j -= 2 * ndx; if (j >= nu) { j -= nu; sign = -1; } j += ndx; }
-    const double e = sign * f.eps;
+    const wreal e = sign * f.eps;
     if (j >= ndx) d.ctrl[j - ndx] += e;
     else if (j >= nv) d.qvel[j - nv] += e;
     else {
       const int jn = m.dof_jntid[j], qa = m.jnt_qposadr[jn], da = m.jnt_dofadr[jn], jt = m.jnt_type[jn];
       if (jt == kJntFree && j - da < 3) d.qpos[qa + (j - da)] += e;
       else if (jt == kJntFree || jt == kJntBall) {
-        double v[3] = {0, 0, 0}, q[4];
+        wreal v[3] = {0, 0, 0}, q[4];
         const int qq = jt == kJntFree ? qa + 3 : qa, k = jt == kJntFree ? j - da - 3 : j - da;
         v[k] = 1;
         for (int c = 0; c < 4; c++) q[c] = d.qpos[qq + c];
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WaveModel 
     }
   }
   WSYNC();
-  double time = f.times[t];
+  wreal time = f.times[t];
   bool bad_ctrl = false;
   wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, nullptr, /*have_warm=*/false);
   wr_residual(m, tk, d, time, lane);
@@ -104,19 +103,19 @@ __global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WaveModel 
 }
 
 // raw next states [Tn][ncol][nq+nv] -> tangent coordinates [Tn][ncol][2 nv] relative to column 0 (oracle state_tangent)
-__global__ void fd_tangent_kernel(const WaveModel m, const double* __restrict__ next, double* __restrict__ tan, int Tn, int ncol) {
+__global__ void fd_tangent_kernel(const WModel m, const wreal* __restrict__ next, wreal* __restrict__ tan, int Tn, int ncol) {
   const int nq = m.nq, nv = m.nv, ds = nq + nv, ndx = 2 * nv;
   for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < Tn * ncol; item += gridDim.x * blockDim.x) {
     const int t = item / ncol;
-    const double* y = next + (size_t)item * ds;
-    const double* y0 = next + (size_t)t * ncol * ds;
-    double* z = tan + (size_t)item * ndx;
+    const wreal* y = next + (size_t)item * ds;
+    const wreal* y0 = next + (size_t)t * ncol * ds;
+    wreal* z = tan + (size_t)item * ndx;
     for (int j = 0; j < m.njnt; j++) {
       int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
       const int jt = m.jnt_type[j];
       if (jt == kJntFree) { for (int k = 0; k < 3; k++) z[da + k] = y[qa + k]; qa += 3; da += 3; }
       if (jt == kJntFree || jt == kJntBall) {
-        double a[4], b[4], r[3];
+        wreal a[4], b[4], r[3];
         for (int k = 0; k < 4; k++) { a[k] = y[qa + k]; b[k] = y0[qa + k]; }
         wq_sub(r, a, b);
         for (int k = 0; k < 3; k++) z[da + k] = r[k];
@@ -127,29 +126,29 @@ __global__ void fd_tangent_kernel(const WaveModel m, const double* __restrict__ 
 }
 
 struct FeedbackWaveArgs {
-  const double *times, *states, *actions, *gains, *improvement, *alpha;  // as FeedbackArgs (ilqg_kernels.h)
+  const wreal *times, *states, *actions, *gains, *improvement, *alpha;  // as FeedbackArgs (ilqg_kernels.h)
   int Tn, mode, representation, use_state;
 };
 
 template <int NMAX>
-__global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WaveModel m, const WaveTask tk, const RolloutArgs<double> a,
+__global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a,
                                                                     const FeedbackWaveArgs fb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x, cand = blockIdx.x;
   const int nq = m.nq, nv = m.nv, nu = m.nu, ndx = 2 * nv, ds = nq + nv, nr = tk.nr, H = a.H, Tn = fb.Tn;
   const size_t N = (size_t)a.N;
-  double *lnodes, *ltimes;
+  wreal *lnodes, *ltimes;
   // the policy scratch (dx[ndx], interpolated state[ds], current state[ds]) lives where the spline nodes would be
   WaveData d = wave_carve(smem_raw, m, tk, /*P=*/(ndx + 2 * ds + nu - 1) / nu + 1, lnodes, ltimes);
-  double* dx = lnodes; double* xi = dx + ndx; double* xs = xi + ds;
+  wreal* dx = lnodes; wreal* xi = dx + ndx; wreal* xs = xi + ds;
   for (int i = lane; i < nq; i += 64) d.qpos[i] = tk.blob[i];
   for (int i = lane; i < nv; i += 64) d.qvel[i] = tk.blob[nq + i];
   if (lane < nu) d.ctrl[lane] = 0;
   if (lane < 4) d.counters[lane] = 0;
-  double time = tk.blob[tk.off_time];
-  const double alpha = fb.alpha[cand];
+  wreal time = tk.blob[tk.off_time];
+  const wreal alpha = fb.alpha[cand];
   WSYNC();
-  double total = 0;
+  wreal total = 0;
   bool failed = false;
   for (int t = 0; t < H; t++) {
     const bool last = t == H - 1;
@@ -157,15 +156,15 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WaveMod
     if (!last) {
       for (int i = lane; i < ds; i += 64) xs[i] = i < nq ? d.qpos[i] : d.qvel[i - nq];
       WSYNC();
-      double u = 0;
+      wreal u = 0;
       if (fb.mode == 0) {  // index policy: u = actions[t] + alpha improvement[t] + K[t] StateDiff(states[t], x)
         const int tt = t < Tn ? t : Tn - 1;
         w_state_diff(m, dx, fb.states + (size_t)tt * ds, xs, lane);
         WSYNC();
         if (lane < nu) {
           u = fb.actions[(size_t)tt * nu + lane] + alpha * fb.improvement[(size_t)tt * nu + lane];
-          double s = 0;
-          const double* K = fb.gains + ((size_t)tt * nu + lane) * ndx;
+          wreal s = 0;
+          const wreal* K = fb.gains + ((size_t)tt * nu + lane) * ndx;
           for (int j = 0; j < ndx; j++) s += K[j] * dx[j];
           u += s;
         }
@@ -176,20 +175,20 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WaveMod
         // FindInterval again over the shorter ranges the reference passes (actions / gains have Tn - 1 entries)
         int a0, a1;
         find_interval(fb.times, time, Tn - 1, a0, a1);
-        const double ta = (zero || a0 == a1) ? 0.0 : (time - fb.times[a0]) / (fb.times[a1] - fb.times[a0]);
+        const wreal ta = (zero || a0 == a1) ? WL(0.0) : (time - fb.times[a0]) / (fb.times[a1] - fb.times[a0]);
         const bool za = zero || a0 == a1;
-        if (lane < nu) u = za ? fb.actions[(size_t)a0 * nu + lane] : fb.actions[(size_t)a0 * nu + lane] * (1.0 - ta) + fb.actions[(size_t)a1 * nu + lane] * ta;
+        if (lane < nu) u = za ? fb.actions[(size_t)a0 * nu + lane] : fb.actions[(size_t)a0 * nu + lane] * (WL(1.0) - ta) + fb.actions[(size_t)a1 * nu + lane] * ta;
         if (fb.use_state) {
-          const double ts = (zero || b0 == b1) ? 0.0 : (time - fb.times[b0]) / (fb.times[b1] - fb.times[b0]);
+          const wreal ts = (zero || b0 == b1) ? WL(0.0) : (time - fb.times[b0]) / (fb.times[b1] - fb.times[b0]);
           const bool zs = zero || b0 == b1;
           for (int i = lane; i < ds; i += 64)
-            xi[i] = zs ? fb.states[(size_t)b0 * ds + i] : fb.states[(size_t)b0 * ds + i] * (1.0 - ts) + fb.states[(size_t)b1 * ds + i] * ts;
+            xi[i] = zs ? fb.states[(size_t)b0 * ds + i] : fb.states[(size_t)b0 * ds + i] * (WL(1.0) - ts) + fb.states[(size_t)b1 * ds + i] * ts;
           WSYNC();
           if (lane < m.njnt) {  // policy.cc:118-125: renormalise interpolated quaternions
             const int jt = m.jnt_type[lane];
             if (jt == kJntFree || jt == kJntBall) {
-              double* q = xi + m.jnt_qposadr[lane] + (jt == kJntFree ? 3 : 0);
-              double qq[4] = {q[0], q[1], q[2], q[3]};
+              wreal* q = xi + m.jnt_qposadr[lane] + (jt == kJntFree ? 3 : 0);
+              wreal qq[4] = {q[0], q[1], q[2], q[3]};
               q_norm(qq);
               for (int k = 0; k < 4; k++) q[k] = qq[k];
             }
@@ -198,10 +197,10 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WaveMod
           w_state_diff(m, dx, xi, xs, lane);
           WSYNC();
           if (lane < nu) {
-            double s = 0;
+            wreal s = 0;
             for (int j = 0; j < ndx; j++) {
-              const double k0 = fb.gains[((size_t)a0 * nu + lane) * ndx + j];
-              const double kj = za ? k0 : k0 * (1.0 - ta) + fb.gains[((size_t)a1 * nu + lane) * ndx + j] * ta;
+              const wreal k0 = fb.gains[((size_t)a0 * nu + lane) * ndx + j];
+              const wreal kj = za ? k0 : k0 * (WL(1.0) - ta) + fb.gains[((size_t)a1 * nu + lane) * ndx + j] * ta;
               s += kj * dx[j];
             }
             u += alpha * s;
@@ -228,10 +227,10 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WaveMod
                       w_norm_value(d.residual + off, tk.dim_norm_residual[lane], tk.norm[lane], tk.blob[tk.off_normp + lane], tk.blob[tk.off_normq + lane]);
     }
     WSYNC();
-    double cost = 0;
+    wreal cost = 0;
     for (int k = 0; k < tk.nterm; k++) cost += d.terms[k];
-    const double risk = tk.blob[tk.off_risk];
-    if (!(fabs(risk) < 1.0e-6)) cost = (exp(risk * cost) - 1.0) / risk;
+    const wreal risk = tk.blob[tk.off_risk];
+    if (!(fabs(risk) < WL(1.0e-6))) cost = (exp(risk * cost) - WL(1.0)) / risk;
     if (!failed) {
       for (int i = lane; i < ds; i += 64) a.states[((size_t)t * ds + i) * N + cand] = i < nq ? d.qpos[i] : d.qvel[i - nq];
       if (lane < nu) a.actions[((size_t)t * nu + lane) * N + cand] = d.ctrl[lane];
@@ -252,9 +251,9 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WaveMod
     wf_euler<NMAX>(m, d, lane, time);
   }
   if (lane == 0) {
-    a.total_return[cand] = failed ? kMaxReturn : total / (double)(H > 1 ? H : 1);
+    a.total_return[cand] = failed ? kMaxReturn : total / (wreal)(H > 1 ? H : 1);
     a.failure[cand] = failed ? 1 : 0;
   }
 }
 
-}  // namespace mjpcx
+} }  // namespace mjpcx::WAVE_NS

@@ -2,11 +2,11 @@
 // wavefront, on top of wf_forward / wf_euler. Candidate generation, spline policy, failure semantics and the output
 // layout ([step][field][candidate]) are those of rollout_lane_kernel, so every downstream entry point (best, top-k,
 // elite moments, fetch) serves both kernel families.
-#pragma once
 
-namespace mjpcx {
+namespace mjpcx { namespace WAVE_NS {
 
-__host__ __device__ inline size_t wave_lds_doubles(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P) {
+// LDS footprint of one candidate in elements of the working type (ints and the contact structs are rounded up to it)
+__host__ __device__ inline size_t wave_lds_elems(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P) {
   size_t n = 0;
   n += nq + nv + nu;                                   // qpos qvel ctrl
   n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 6 * njnt + 3 * nsite;  // kinematics
@@ -14,20 +14,20 @@ __host__ __device__ inline size_t wave_lds_doubles(int nq, int nv, int nu, int n
   n += 2 * (size_t)nv * nv + 2 * nv;                   // M H (the factor of M lives in H until Newton) + reciprocal pivots
   n += 7 * nv + nu + 5 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma tmpv qacc_warm
   n += (size_t)kWaveMaxEfc * nv + 9 * kWaveMaxEfc;     // efc_J + per-row doubles
-  n += (3 * kWaveMaxEfc + 1) / 2 + 1;                  // per-row ints
+  n += (3 * kWaveMaxEfc * sizeof(int) + sizeof(wreal) - 1) / sizeof(wreal) + 1;  // per-row ints
   n += 21 * kWaveMaxCon + 12 + nr + nterm + 8;         // coneH (lower triangles) foot_xpos residual terms scal
-  n += (sizeof(WaveContact) * kWaveMaxCon + 7) / 8;
-  n += 4;                                              // counters
+  n += (sizeof(WaveContact) * kWaveMaxCon + sizeof(wreal) - 1) / sizeof(wreal) + 1;
+  n += 4 * sizeof(int) / sizeof(wreal) + 1;           // counters
   n += (size_t)P * nu + P;                             // spline nodes + node times
   return n + 16;
 }
 
 // the LDS layout of one candidate's mjData (shared by the rollout, feedback-rollout and finite-difference kernels)
-__device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WaveModel& m, const WaveTask& tk, int P, double*& lnodes,
-                                               double*& ltimes) {
+__device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WModel& m, const WTask& tk, int P, wreal*& lnodes,
+                                               wreal*& ltimes) {
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
-  double* p = reinterpret_cast<double*>(smem_raw);
-  auto take = [&](size_t n) { double* q = p; p += n; return q; };
+  wreal* p = reinterpret_cast<wreal*>(smem_raw);
+  auto take = [&](size_t n) { wreal* q = p; p += n; return q; };
   WaveData d;
   d.qpos = take(nq); d.qvel = take(nv); d.ctrl = take(nu);
   d.xpos = take(3 * nb); d.xquat = take(4 * nb); d.xmat = take(9 * nb); d.xipos = take(3 * nb); d.ximat = take(9 * nb);
@@ -44,11 +44,11 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const Wa
   d.efc_pos = take(kWaveMaxEfc); d.efc_margin = take(kWaveMaxEfc); d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
   d.efc_aref = take(kWaveMaxEfc); d.efc_floss = take(kWaveMaxEfc); d.efc_force = take(kWaveMaxEfc); d.jar = take(kWaveMaxEfc);
   d.jv = take(kWaveMaxEfc);
-  int* ip = reinterpret_cast<int*>(take((3 * kWaveMaxEfc + 1) / 2 + 1));
+  int* ip = reinterpret_cast<int*>(take((3 * kWaveMaxEfc * sizeof(int) + sizeof(wreal) - 1) / sizeof(wreal) + 1));
   d.efc_type = ip; d.efc_id = ip + kWaveMaxEfc; d.efc_zone = ip + 2 * kWaveMaxEfc;
   d.coneH = take(21 * kWaveMaxCon); d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
-  d.con = reinterpret_cast<WaveContact*>(take((sizeof(WaveContact) * kWaveMaxCon + 7) / 8));
-  d.counters = reinterpret_cast<int*>(take(4));
+  d.con = reinterpret_cast<WaveContact*>(take((sizeof(WaveContact) * kWaveMaxCon + sizeof(wreal) - 1) / sizeof(wreal) + 1));
+  d.counters = reinterpret_cast<int*>(take(4 * sizeof(int) / sizeof(wreal) + 1));
   lnodes = take((size_t)P * nu);  // [P][nu]
   ltimes = take(P);
 
@@ -56,7 +56,7 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const Wa
 }
 
 template <int NMAX>
-__global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, const WaveTask tk, const RolloutArgs<double> a) {
+__global__ __launch_bounds__(64) void rollout_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x, cand = blockIdx.x;
   // The model and task structs stay in the kernel-argument segment (scalar loads). Staging the model allocation into
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
   const int P = a.P, H = a.H;
   const size_t N = (size_t)a.N;
   // ---- LDS carve
-  double* lnodes; double* ltimes;
+  wreal* lnodes; wreal* ltimes;
   WaveData d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes);
   // ---- candidate spline nodes (SamplingPlanner / CrossEntropyPlanner::AddNoiseToPolicy, as rollout_lane_kernel)
   for (int q = lane; q < P; q += 64) ltimes[q] = a.node_times[q];
@@ -75,29 +75,29 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
     for (int j = lane; j < np; j += 64) lnodes[j] = a.nodes[(size_t)j * N + cand];
   } else {
     const int gi = a.noise.candidate_offset + cand;
-    double std = a.noise.std0;
+    wreal std = a.noise.std0;
     if (a.noise.mode == 0 && a.noise.std1 > 0) {
-      if (bernoulli_uniform(a.noise.seed, (uint32_t)gi, a.noise.iteration) < 0.2) std = a.noise.std1;
+      if (bernoulli_uniform(a.noise.seed, (uint32_t)gi, a.noise.iteration) < WL(0.2)) std = a.noise.std1;
     }
     const bool noised = gi != a.noise.nominal_candidate;
     for (int j0 = 2 * lane; j0 < np; j0 += 128) {
-      double z[2];
+      double z[2];  // the Philox / Box-Muller pair is generated in double whatever the working type
       gaussian_pair(a.noise.seed, (uint32_t)gi, (uint32_t)(j0 >> 1), a.noise.iteration, z);
       for (int e = 0; e < 2; e++) {
         const int j = j0 + e;
         if (j < np) {
           const int k = j % nu;
-          const double lo = m.actuator_ctrlrange[2 * k], hi = m.actuator_ctrlrange[2 * k + 1];
-          double v = a.nominal[j];
+          const wreal lo = m.actuator_ctrlrange[2 * k], hi = m.actuator_ctrlrange[2 * k + 1];
+          wreal v = a.nominal[j];
           if (noised) {
-            double sigma;
-            if (a.noise.mode == 0) sigma = 0.5 * (hi - lo) * std;
+            wreal sigma;
+            if (a.noise.mode == 0) sigma = WL(0.5) * (hi - lo) * std;
             else {
-              const double fl = gi < a.noise.explore_count ? a.noise.std0 : a.noise.std1;
-              const double s = sqrt(a.noise.param_variance[j]);
+              const wreal fl = gi < a.noise.explore_count ? a.noise.std0 : a.noise.std1;
+              const wreal s = sqrt(a.noise.param_variance[j]);
               sigma = s > fl ? s : fl;
             }
-            v = clampv(v + sigma * z[e], lo, hi);
+            v = clampv(v + sigma * (wreal)z[e], lo, hi);
           }
           lnodes[j] = v;
           a.nodes[(size_t)j * N + cand] = v;
@@ -110,18 +110,18 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
   for (int i = lane; i < nv; i += 64) d.qvel[i] = tk.blob[nq + i];
   if (lane < nu) d.ctrl[lane] = 0;
   if (lane < 4) d.counters[lane] = 0;
-  double time = tk.blob[tk.off_time];
+  wreal time = tk.blob[tk.off_time];
   WSYNC();
 
   const int ds = nq + nv;
-  double total = 0;
+  wreal total = 0;
   bool failed = false;
   for (int t = 0; t < H; t++) {
     const bool last = t == H - 1;
     bool bad = false;
     // ================= policy: TimeSpline::Sample + Clamp, one lane per actuator
     if (!last) {
-      double u = 0;
+      wreal u = 0;
       if (lane < nu) {
         const int k = lane;
         int up = 0;
@@ -130,21 +130,21 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
           u = lnodes[(up == 0 ? 0 : P - 1) * nu + k];
         } else {
           const int lo = up - 1;
-          const double tl = ltimes[lo], tu = ltimes[up];
-          const double p0 = lnodes[lo * nu + k], p1 = lnodes[up * nu + k];
+          const wreal tl = ltimes[lo], tu = ltimes[up];
+          const wreal p0 = lnodes[lo * nu + k], p1 = lnodes[up * nu + k];
           if (a.interp == 0) u = p0;
           else {
-            const double s = (time - tl) / (tu - tl);
+            const wreal s = (time - tl) / (tu - tl);
             if (a.interp == 1) u = p0 * (1 - s) + p1 * s;
             else {
-              const double dt_mid = tu - tl, fwd = (p1 - p0) / dt_mid;
-              double m0, m1;
+              const wreal dt_mid = tu - tl, fwd = (p1 - p0) / dt_mid;
+              wreal m0, m1;
               if (lo == 0) m0 = fwd;
-              else m0 = 0.5 * (p1 - p0) / dt_mid + 0.5 * (p0 - lnodes[(lo - 1) * nu + k]) / (tl - ltimes[lo - 1]);
+              else m0 = WL(0.5) * (p1 - p0) / dt_mid + WL(0.5) * (p0 - lnodes[(lo - 1) * nu + k]) / (tl - ltimes[lo - 1]);
               if (up == P - 1) m1 = fwd;
-              else m1 = 0.5 * (lnodes[(up + 1) * nu + k] - p1) / (ltimes[up + 1] - tu) + 0.5 * (p1 - p0) / dt_mid;
-              const double s2 = s * s, s3 = s * s * s;
-              const double c0 = 2 * s3 - 3 * s2 + 1, c1 = (s3 - 2 * s2 + s) * (tu - tl), c2 = -2 * s3 + 3 * s2, c3 = (s3 - s2) * (tu - tl);
+              else m1 = WL(0.5) * (lnodes[(up + 1) * nu + k] - p1) / (ltimes[up + 1] - tu) + WL(0.5) * (p1 - p0) / dt_mid;
+              const wreal s2 = s * s, s3 = s * s * s;
+              const wreal c0 = 2 * s3 - 3 * s2 + 1, c1 = (s3 - 2 * s2 + s) * (tu - tl), c2 = -2 * s3 + 3 * s2, c3 = (s3 - s2) * (tu - tl);
               u = c0 * p0 + c1 * m0 + c2 * p1 + c3 * m1;
             }
           }
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
                       w_norm_value(d.residual + off, tk.dim_norm_residual[lane], tk.norm[lane], tk.blob[tk.off_normp + lane], tk.blob[tk.off_normq + lane]);
     }
     WSYNC();
-    double cost = 0;
+    wreal cost = 0;
     for (int k = 0; k < tk.nterm; k++) cost += d.terms[k];
-    const double risk = tk.blob[tk.off_risk];
-    if (!(fabs(risk) < 1.0e-6)) cost = (exp(risk * cost) - 1.0) / risk;
+    const wreal risk = tk.blob[tk.off_risk];
+    if (!(fabs(risk) < WL(1.0e-6))) cost = (exp(risk * cost) - WL(1.0)) / risk;
     // ================= record step t
     if (!failed) {
       for (int i = lane; i < ds; i += 64) a.states[((size_t)t * ds + i) * N + cand] = i < nq ? d.qpos[i] : d.qvel[i - nq];
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WaveModel m, con
     WSTAMP(14);
   }
   if (lane == 0) {
-    a.total_return[cand] = failed ? kMaxReturn : total / (double)(H > 1 ? H : 1);
+    a.total_return[cand] = failed ? kMaxReturn : total / (wreal)(H > 1 ? H : 1);
     a.failure[cand] = failed ? 1 : 0;
   }
 }
 
-}  // namespace mjpcx
+} }  // namespace mjpcx::WAVE_NS

@@ -11,6 +11,7 @@
 
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mjpcx.h"
@@ -21,28 +22,29 @@ constexpr int kWaveMaxBody = 64, kWaveMaxDof = 32, kWaveMaxGeom = 64, kWaveMaxLe
 constexpr int kWaveMaxCon = 16;   // contacts kept per step (further ones are dropped, as in the oracle)
 constexpr int kWaveMaxEfc = 64;   // constraint rows kept per step
 
-struct WaveModel {
+template <typename T>
+struct WaveModelT {
   int nq, nv, nu, nbody, njnt, nsite, nmocap, ngeom, nkey;
   int cone, disableflags, solver_iterations, any_damping;
   double timestep, gravity[3], solver_tolerance, meaninertia, impratio;
   const int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_mocapid;
-  const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_subtreemass;
+  const T *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_subtreemass;
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
-  const double *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
+  const T *jnt_pos, *jnt_axis, *jnt_stiffness, *jnt_range, *jnt_margin, *jnt_solref, *jnt_solimp;
   const int *dof_bodyid, *dof_jntid, *dof_parentid;
-  const double *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
-  const double *qpos0, *qpos_spring;
+  const T *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
+  const T *qpos0, *qpos_spring;
   const int* site_bodyid;
-  const double *site_pos, *site_quat;
+  const T *site_pos, *site_quat;
   const int *actuator_trnid, *actuator_biastype, *actuator_ctrllimited, *actuator_forcelimited;
-  const double *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
+  const T *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
   const int *geom_type, *geom_bodyid, *geom_contype, *geom_conaffinity, *geom_condim, *geom_priority, *geom_group;
-  const double *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_solmix;
-  const double* key_qpos;
-  const double* key_mpos;                       // nkey x nmocap x 3 (Humanoid tracking residual); stays in HBM / L2
+  const T *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_margin, *geom_gap, *geom_solmix;
+  const T* key_qpos;
+  const T* key_mpos;                       // nkey x nmocap x 3 (Humanoid tracking residual); stays in HBM / L2
   int ntendon;                                  // fixed tendons (limits)
   const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
-  const double *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
+  const T *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
   const unsigned* tendon_dofmask;               // baked: dofs a tendon's Jacobian touches
   // ---- baked helpers (host-computed once)
   const unsigned long long* body_subtree_mask;  // bit j: body j is in the subtree rooted at body i (incl. i)
@@ -61,6 +63,7 @@ struct WaveModel {
   const unsigned char* base;                    // the single device allocation all pointers above point into
   int bytes;                                    // its size (a multiple of 16): the kernel stages it into LDS
 };
+using WaveModel = WaveModelT<double>;  // the parity path, the iLQG kernels and the lane-per-candidate experiment
 
 // every pointer member of WaveModel, for rebasing the struct onto a copy of the allocation (LDS staging)
 #define MJPCX_WAVE_MODEL_POINTERS(X)                                                                                         \
@@ -78,44 +81,71 @@ struct WaveModel {
   X(body_subtree_mask) X(body_dofmask) X(level_body) X(static_geom) X(dynamic_geom) X(ray_geom)
 
 // Per-plan task values: one small blob re-staged with every rollout (Planner::SetState + the frozen ResidualFn copy)
-struct WaveTask {
+template <typename T>
+struct WaveTaskT {
   int residual_id, nr, nterm, ntrace, nparam, nri, nrr;
   const int *dim_norm_residual, *norm, *trace_site;   // static, in the model allocation
   // blob (doubles): state[nq+nv] time mocap[7 nmocap] weight[nterm] norm_p[nterm] norm_q[nterm] parameters[nparam]
   //                 risk residual_real[nrr] ; then residual_int[nri] as int32
-  const double* blob;
+  const T* blob;
   long long* stamps;  // optional (tuning): s_memtime at the phase boundaries of step `stamp_step` of candidate 0
   int stamp_step;
   int off_time, off_mocap, off_weight, off_normp, off_normq, off_param, off_risk, off_rreal, off_rint;
 };
+using WaveTask = WaveTaskT<double>;
 
 // ---------------------------------------------------------------- host side
 struct WaveHost {
   WaveModel m{};
   WaveTask t{};
   void* dev = nullptr;  // the model allocation
+  // fp32 twin (precision 32 contexts): same struct layout, every real array converted to float in its own allocation
+  WaveModelT<float> m32{};
+  WaveTaskT<float> t32{};
+  void* dev32 = nullptr;
+  size_t blob_bytes32 = 0;
   size_t blob_doubles = 0, blob_bytes = 0;
   std::vector<double> state, mocap, weight, norm_p, norm_q, parameters, residual_real;
   std::vector<int32_t> residual_int, norm_types;
   double time = 0, risk = 0;
 
-  void release() { if (dev) (void)hipFree(dev); dev = nullptr; }
+  void release() { if (dev) (void)hipFree(dev); dev = nullptr; if (dev32) (void)hipFree(dev32); dev32 = nullptr; }
 
   // Returns "" or an error message. Requires the device to be current.
-  std::string build(const mjpcx_model* src, const mjpcx_task* task) {
+  std::string build(const mjpcx_model* src, const mjpcx_task* task, bool want32 = false) {
     if (src->nbody > kWaveMaxBody || src->nv > kWaveMaxDof || src->ngeom > 4 * kWaveMaxGeom) return "model exceeds the wave kernel capacity";
     if (src->nbody > 64) return "more than 64 bodies";
-    std::vector<unsigned char> host;
-    auto put = [&](const void* p, size_t bytes) -> size_t {
-      size_t off = (host.size() + 15) & ~(size_t)15;
-      host.resize(off + (bytes ? bytes : 16));
-      if (bytes) std::memcpy(host.data() + off, p, bytes);
+    static_assert(sizeof(WaveModelT<float>) == sizeof(WaveModel) && sizeof(WaveTaskT<float>) == sizeof(WaveTask), "twin layouts");
+    std::vector<unsigned char> host, host32;
+    auto put_in = [](std::vector<unsigned char>& h, const void* p, size_t bytes) -> size_t {
+      size_t off = (h.size() + 15) & ~(size_t)15;
+      h.resize(off + (bytes ? bytes : 16));
+      if (bytes) std::memcpy(h.data() + off, p, bytes);
       return off;
     };
-    struct Fix { size_t field_off; size_t data_off; };
+    auto put = [&](const void* p, size_t bytes) -> size_t {
+      const size_t off = put_in(host, p, bytes);
+      if (want32) put_in(host32, p, bytes);  // same bytes (integers); the image offsets differ, see Fix
+      return off;
+    };
+    struct Fix { size_t field_off; size_t data_off; size_t data_off32; };
     std::vector<Fix> fixes;
+    // integer / mask arrays: identical in both images
     auto reg = [&](const void* field_addr, const void* p, size_t bytes) {
-      fixes.push_back({(size_t)((const char*)field_addr - (const char*)&m), put(p, bytes)});
+      Fix f{(size_t)((const char*)field_addr - (const char*)&m), put_in(host, p, bytes), 0};
+      if (want32) f.data_off32 = put_in(host32, p, bytes);
+      fixes.push_back(f);
+    };
+    // real arrays: doubles in the fp64 image, floats in the fp32 image
+    std::vector<float> narrow;
+    auto regd = [&](const void* field_addr, const double* p, size_t n) {
+      Fix f{(size_t)((const char*)field_addr - (const char*)&m), put_in(host, p, sizeof(double) * n), 0};
+      if (want32) {
+        narrow.resize(n);
+        for (size_t i = 0; i < n; i++) narrow[i] = (float)p[i];
+        f.data_off32 = put_in(host32, narrow.data(), sizeof(float) * n);
+      }
+      fixes.push_back(f);
     };
     std::memset(&m, 0, sizeof m);
     m.nq = src->nq; m.nv = src->nv; m.nu = src->nu; m.nbody = src->nbody; m.njnt = src->njnt; m.nsite = src->nsite;
@@ -125,7 +155,7 @@ struct WaveHost {
     m.solver_tolerance = src->solver_tolerance; m.meaninertia = src->meaninertia; m.impratio = src->impratio;
     const int nb = src->nbody, nj = src->njnt, nv = src->nv, nu = src->nu, ns = src->nsite, ng = src->ngeom;
 #define I(name, n) reg(&m.name, src->name, sizeof(int32_t) * (size_t)(n))
-#define D(name, n) reg(&m.name, src->name, sizeof(double) * (size_t)(n))
+#define D(name, n) regd(&m.name, src->name, (size_t)(n))
     I(body_parentid, nb); I(body_rootid, nb); I(body_jntnum, nb); I(body_jntadr, nb); I(body_dofnum, nb); I(body_dofadr, nb); I(body_mocapid, nb);
     D(body_pos, 3 * nb); D(body_quat, 4 * nb); D(body_ipos, 3 * nb); D(body_iquat, 4 * nb); D(body_mass, nb); D(body_inertia, 3 * nb);
     D(body_invweight0, 2 * nb); D(body_subtreemass, nb);
@@ -141,7 +171,7 @@ struct WaveHost {
     D(geom_size, 3 * ng); D(geom_pos, 3 * ng); D(geom_quat, 4 * ng); D(geom_friction, 3 * ng); D(geom_solref, 2 * ng); D(geom_solimp, 5 * ng);
     D(geom_margin, ng); D(geom_gap, ng); D(geom_solmix, ng);
     D(key_qpos, (size_t)src->nkey * src->nq);
-    if (src->key_mpos) D(key_mpos, (size_t)src->nkey * src->nmocap * 3); else reg(&m.key_mpos, nullptr, 0);
+    if (src->key_mpos) D(key_mpos, (size_t)src->nkey * src->nmocap * 3); else regd(&m.key_mpos, nullptr, 0);
     const int nt = src->ntendon, nw = src->nwrap;
     m.ntendon = nt;
     I(tendon_adr, nt); I(tendon_num, nt); I(tendon_limited, nt); I(wrap_objid, nw);
@@ -225,16 +255,17 @@ struct WaveHost {
     // static task arrays
     t.residual_id = task->residual_id; t.nr = task->num_residual; t.nterm = task->num_term; t.ntrace = task->num_trace;
     t.nparam = task->num_parameter; t.nri = task->num_residual_int; t.nrr = task->num_residual_real;
-    const size_t o_dim = put(task->dim_norm_residual, sizeof(int32_t) * task->num_term);
-    const size_t o_norm = put(task->norm, sizeof(int32_t) * task->num_term);
-    const size_t o_trace = put(task->trace_site, sizeof(int32_t) * task->num_trace);
+    auto put2 = [&](const void* p, size_t bytes) { return std::pair<size_t, size_t>(put_in(host, p, bytes), want32 ? put_in(host32, p, bytes) : 0); };
+    const auto o_dim = put2(task->dim_norm_residual, sizeof(int32_t) * task->num_term);
+    const auto o_norm = put2(task->norm, sizeof(int32_t) * task->num_term);
+    const auto o_trace = put2(task->trace_site, sizeof(int32_t) * task->num_trace);
     host.resize((host.size() + 15) & ~(size_t)15);
     if (hipMalloc(&dev, host.size()) != hipSuccess) return "hipMalloc of the model failed";
     if (hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return "model upload failed";
     for (const Fix& f : fixes) *(const void**)((char*)&m + f.field_off) = (const char*)dev + f.data_off;
-    t.dim_norm_residual = (const int*)((const char*)dev + o_dim);
-    t.norm = (const int*)((const char*)dev + o_norm);
-    t.trace_site = (const int*)((const char*)dev + o_trace);
+    t.dim_norm_residual = (const int*)((const char*)dev + o_dim.first);
+    t.norm = (const int*)((const char*)dev + o_norm.first);
+    t.trace_site = (const int*)((const char*)dev + o_trace.first);
     m.base = (const unsigned char*)dev;
     m.bytes = (int)host.size();
     // blob layout
@@ -247,6 +278,20 @@ struct WaveHost {
     blob_doubles = (size_t)o;
     blob_bytes = blob_doubles * 8 + sizeof(int32_t) * (size_t)task->num_residual_int;
     blob_bytes = (blob_bytes + 15) & ~(size_t)15;
+    if (want32) {  // the fp32 twin: same scalars and baked integers, float arrays, its own allocation
+      std::memcpy((void*)&m32, (const void*)&m, sizeof m);
+      host32.resize((host32.size() + 15) & ~(size_t)15);
+      if (hipMalloc(&dev32, host32.size()) != hipSuccess) return "hipMalloc of the fp32 model failed";
+      if (hipMemcpy(dev32, host32.data(), host32.size(), hipMemcpyHostToDevice) != hipSuccess) return "fp32 model upload failed";
+      for (const Fix& f : fixes) *(const void**)((char*)&m32 + f.field_off) = (const char*)dev32 + f.data_off32;
+      m32.base = (const unsigned char*)dev32;
+      m32.bytes = (int)host32.size();
+      std::memcpy((void*)&t32, (const void*)&t, sizeof t);
+      t32.dim_norm_residual = (const int*)((const char*)dev32 + o_dim.second);
+      t32.norm = (const int*)((const char*)dev32 + o_norm.second);
+      t32.trace_site = (const int*)((const char*)dev32 + o_trace.second);
+      blob_bytes32 = (blob_doubles * 4 + sizeof(int32_t) * (size_t)task->num_residual_int + 15) & ~(size_t)15;
+    }
     // host mirrors of the per-plan values
     state.assign(src->nq + src->nv, 0.0);
     for (int i = 0; i < src->nq; i++) state[i] = src->qpos0[i];
@@ -264,6 +309,18 @@ struct WaveHost {
     residual_int.assign(task->residual_int, task->residual_int + task->num_residual_int);
     risk = task->risk;
     return "";
+  }
+
+  // the same values narrowed to float (blob_bytes32)
+  void fill_blob32(void* dst) const {
+    float* d = (float*)dst;
+    auto cp = [&](int off, const std::vector<double>& v) { for (size_t i = 0; i < v.size(); i++) d[off + i] = (float)v[i]; };
+    cp(0, state);
+    d[t.off_time] = (float)time;
+    cp(t.off_mocap, mocap); cp(t.off_weight, weight); cp(t.off_normp, norm_p); cp(t.off_normq, norm_q); cp(t.off_param, parameters);
+    d[t.off_risk] = (float)risk;
+    cp(t.off_rreal, residual_real);
+    std::memcpy(d + t.off_rint, residual_int.data(), residual_int.size() * sizeof(int32_t));
   }
 
   // serialise the per-plan values into `dst` (blob_bytes)
