@@ -461,7 +461,7 @@ int stage_plan_inputs(mjpcx_ctx* c, int P, const double* node_times, const doubl
   const size_t off_nom = ((size_t)P * sizeof(T) + 15) & ~(size_t)15;
   const size_t off_var = (off_nom + (size_t)np * sizeof(T) + 15) & ~(size_t)15;
   const size_t off_blob = (off_var + (size_t)np * 8 + 15) & ~(size_t)15;
-  const size_t bytes = off_blob + (c->wave ? c->wh.blob_bytes : 0);
+  const size_t bytes = off_blob + (c->wave ? (sizeof(T) == 4 ? c->wh.blob_bytes32 : c->wh.blob_bytes) : 0);
   mjpcx_ctx::Slot& s = c->slots[c->next_slot];
   c->next_slot = (c->next_slot + 1) % mjpcx_ctx::kSlots;
   if (s.pending) { HIPCHK(c, hipEventSynchronize(s.done)); s.pending = false; }
@@ -480,7 +480,7 @@ int stage_plan_inputs(mjpcx_ctx* c, int P, const double* node_times, const doubl
   if (nominal) for (int j = 0; j < np; j++) hn[j] = (T)nominal[j];
   if (variance) std::memcpy(h + off_var, variance, (size_t)np * 8);
   if (c->wave) {
-    c->wh.fill_blob(h + off_blob);
+    if (sizeof(T) == 4) c->wh.fill_blob32(h + off_blob); else c->wh.fill_blob(h + off_blob);
     if (d_blob) *d_blob = (const char*)s.dev.p + off_blob;
   }
   HIPCHK(c, hipMemcpyAsync(s.dev.p, s.host, bytes, hipMemcpyHostToDevice, c->stream));
@@ -489,6 +489,21 @@ int stage_plan_inputs(mjpcx_ctx* c, int P, const double* node_times, const doubl
   *d_variance = (const double*)((char*)s.dev.p + off_var);
   *used = &s;
   return MJPCX_OK;
+}
+
+// tuning aid (MJPCX_STAMPS=<step>): phase cycle stamps of candidate 0 at one step of the wavefront-per-candidate kernel
+void print_wave_stamps(mjpcx_ctx* c, long long* stamps, int stamp_step, size_t lds) {
+  long long h[48];
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipMemcpy(h, stamps, sizeof h, hipMemcpyDeviceToHost);
+  static const char* nm[] = {"policy", "kinematics", "compos", "crb", "cholM", "collision", "comvel", "make_constraint", "smooth", "solve",
+                             "newton", "residual", "cost+record", "euler"};
+  std::fprintf(stderr, "wave kernel phase cycles (step %d, candidate 0; LDS %zu B):", stamp_step, lds);
+  for (int k = 0; k < 14; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k + 1] - h[k]);
+  std::fprintf(stderr, " | newton iters %lld: grad %lld hess %lld chol+solve %lld linesearch %lld\n", h[20], h[21] - h[10], h[22] - h[21],
+               h[23] - h[22], h[24] - h[23]);
+  std::fprintf(stderr, "  newton totals over iterations: grad %lld coneblocks %lld hess %lld chol+solve %lld jv+q %lld linesearch %lld (%lld trials) update+cost %lld\n",
+               h[32], h[33], h[34], h[35], h[36], h[37], h[39], h[38]);
 }
 
 template <typename T>
@@ -580,23 +595,32 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
         le = hipGetLastError();
       }
-      if (wt.stamps && le == hipSuccess) {
-        long long h[48];
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipMemcpy(h, wt.stamps, sizeof h, hipMemcpyDeviceToHost);
-        static const char* nm[] = {"policy", "kinematics", "compos", "crb", "cholM", "collision", "comvel", "make_constraint", "smooth", "solve",
-                                   "newton", "residual", "cost+record", "euler"};
-        std::fprintf(stderr, "wave kernel phase cycles (step %d, candidate 0; LDS %zu B):", wt.stamp_step, lds);
-        for (int k = 0; k < 14; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k + 1] - h[k]);
-        std::fprintf(stderr, " | newton iters %lld: grad %lld hess %lld chol+solve %lld linesearch %lld\n", h[20], h[21] - h[10], h[22] - h[21],
-                     h[23] - h[22], h[24] - h[23]);
-        std::fprintf(stderr, "  newton totals over iterations: grad %lld coneblocks %lld hess %lld chol+solve %lld jv+q %lld linesearch %lld (%lld trials) update+cost %lld\n",
-                     h[32], h[33], h[34], h[35], h[36], h[37], h[39], h[38]);
-      }
+      if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds);
       }
     } else {
       le = c->kernel->launch64(c->hm64, c->ht64, a, c->stream);
     }
+  } else if (c->wave) {
+    // the fp32 instantiation of the wavefront-per-candidate kernel (BASELINE configs[3]'s precision)
+    WaveTaskT<float> wt = c->wh.t32;
+    wt.blob = (const float*)d_blob;
+    wt.stamps = nullptr;
+    if (getenv("MJPCX_STAMPS")) {
+      HIPCHK(c, c->d_stage.reserve(48 * 8));
+      HIPCHK(c, hipMemsetAsync(c->d_stage.p, 0, 48 * 8, c->stream));
+      wt.stamps = (long long*)c->d_stage.p;
+      wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
+    }
+    const WaveModelT<float>& wm = c->wh.m32;
+    const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
+    if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
+    auto kern = wm.nv <= 20 ? w32::rollout_wave_kernel<20> : w32::rollout_wave_kernel<32>;
+    le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (le == hipSuccess) {
+      hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
+      le = hipGetLastError();
+    }
+    if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds);
   } else {
     convert_task(c->ht32, c->ht64);
     le = c->kernel->launch32(c->hm32, c->ht32, a, c->stream);
@@ -669,7 +693,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
   }
   for (int k = 0; k < m->ntendon; k++) needs_wave |= m->tendon_limited[k] != 0;
   if (needs_wave) {
-    if (precision != 64) return bad(MJPCX_EUNSUPPORTED, "the wavefront-per-candidate kernel is fp64 only for now");
+
     for (int j = 0; j < m->njnt; j++)
       if (m->jnt_limited[j] && (m->jnt_type[j] == MJPCX_JNT_FREE || m->jnt_type[j] == MJPCX_JNT_BALL))
         return bad(MJPCX_EUNSUPPORTED, "limits on free/ball joints are not implemented");
@@ -687,7 +711,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     c->dim_norm_residual.assign(t->dim_norm_residual, t->dim_norm_residual + t->num_term);
     c->ctrllimited.assign(m->actuator_ctrllimited, m->actuator_ctrllimited + m->nu);
     c->ctrlrange.assign(m->actuator_ctrlrange, m->actuator_ctrlrange + 2 * m->nu);
-    const std::string err = c->wh.build(m, t);
+    const std::string err = c->wh.build(m, t, precision == 32);
     if (!err.empty()) { mjpcx_destroy(c); return bad(MJPCX_EUNSUPPORTED, err); }
     set_norm_params(c, t->norm_parameter);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
@@ -1195,6 +1219,7 @@ size_t wave_lds_bytes(const mjpcx_ctx* c, int P) {
 
 int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
                      const double* states, const double* actions, const double* gains, const double* improvement, const double* alpha) {
+  if (c->precision != 64) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family are fp64 only");
   int rc;
   if ((rc = reserve_rollout(c, N, H, 1)) != MJPCX_OK) return rc;
   const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu;
@@ -1222,6 +1247,7 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
 
 int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const double* states, const double* actions, double eps,
                           int centered, double* A, double* B, double* C, double* D) {
+  if (c->precision != 64) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family are fp64 only");
   int rc;
   const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu, nr = c->nr;
   const size_t nc = 1 + 2 * (ndx + nu);

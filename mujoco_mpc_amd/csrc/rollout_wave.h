@@ -49,6 +49,7 @@ __device__ __forceinline__ float dpp_move(float v) {
 
 #define WAVE_NS w64
 #define wreal double
+#define WAVE_KERNEL_ATTR
 #define MJPCX_WAVE_ILQG 1
 #include "wave_core.h"
 #include "wave_forward.h"
@@ -56,15 +57,19 @@ __device__ __forceinline__ float dpp_move(float v) {
 #include "wave_kernel.h"
 #include "wave_ilqg.h"
 #undef MJPCX_WAVE_ILQG
+#undef WAVE_KERNEL_ATTR
 #undef wreal
 #undef WAVE_NS
 
+// fp32: 21 KB of LDS per A1 candidate allows 7 per CU, so the kernel is held to 256 registers (2 wavefronts per SIMD)
 #define WAVE_NS w32
 #define wreal float
+#define WAVE_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #include "wave_core.h"
 #include "wave_forward.h"
 #include "wave_residual.h"
 #include "wave_kernel.h"
+#undef WAVE_KERNEL_ATTR
 #undef wreal
 #undef WAVE_NS
 #undef WL

@@ -675,6 +675,7 @@ __device__ __forceinline__ void wf_make_constraint(const WModel& m, WaveData& d,
       nefc += __popcll(b0) + __popcll(b1);
     }
   }
+  bool overflow = nefc > kWaveMaxEfc;  // rows beyond the cap are dropped and flagged (oracle new_row: warning 64 -> the rollout fails)
   if (nefc > kWaveMaxEfc) nefc = kWaveMaxEfc;
   WSYNC();
   // contacts: row ranges by a serial prefix over (<= 16) contacts, every lane computes the same numbers
@@ -687,6 +688,7 @@ __device__ __forceinline__ void wf_make_constraint(const WModel& m, WaveData& d,
       const int dim = d.con[ci].dim0;
       const int rows = (dim > 1 && pyramidal) ? 2 * (dim - 1) : dim;
       const int fit = at + rows <= kWaveMaxEfc ? rows : (kWaveMaxEfc - at > 0 ? kWaveMaxEfc - at : 0);
+      overflow |= fit < rows;
       if (ci == lane) { my_efc = at; my_rows = fit; }
       at += fit;
     }
@@ -707,7 +709,7 @@ __device__ __forceinline__ void wf_make_constraint(const WModel& m, WaveData& d,
       if (row == 0 || pyr) { d.efc_pos[r] = c.dist; d.efc_margin[r] = c.includemargin; }
     }
   }
-  if (lane == 0) d.counters[1] = nefc;
+  if (lane == 0) { d.counters[1] = nefc; if (overflow) d.counters[2] |= 64; }
   WSYNC();
   // contact Jacobian rows: (row, dof) pairs over the lanes; J = J(body of geom2) - J(body of geom1) at the contact point
   for (int e = lane; e < nefc * nv; e += 64) {
@@ -1116,7 +1118,8 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     d1 = wave_sum(g0) + q1; d2 = wave_sum(h0) + q2;
     const wreal d10 = fabs(d1);
     // termination as in MuJoCo's PrimalSearch: |derivative| < tolerance * ls_tolerance * |search| / scale
-    const wreal gtol = m.solver_tolerance * kLsTolerance * sqrt(wave_sum(lane < nv ? d.search[lane] * d.search[lane] : WL(0.0))) / scale;
+    wreal gtol = m.solver_tolerance * kLsTolerance * sqrt(wave_sum(lane < nv ? d.search[lane] * d.search[lane] : WL(0.0))) / scale;
+    if (sizeof(wreal) == 4) gtol = fmax(gtol, WL(1e-4) * d10);  // float: the slope's rounding floor is far above MuJoCo's tolerance
     for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
       wreal an = alpha - d1 / d2;
       if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? WL(0.5) * (lo + hi) : 2 * alpha + 1;

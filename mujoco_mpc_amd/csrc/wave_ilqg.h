@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
     bool bad_ctrl = false;
     wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, nullptr, t > 0);
     if (!last) for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qacc[i]);
+    if (!last) bad |= d.counters[2] != 0;  // CheckWarnings: contact / row cap overflow, indefinite Hessian (oracle odata_warning)
     bad = __any(bad);
     wr_residual(m, tk, d, time, lane);
     if (lane < tk.nterm) {

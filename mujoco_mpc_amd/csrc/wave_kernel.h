@@ -11,15 +11,15 @@ __host__ __device__ inline size_t wave_lds_elems(int nq, int nv, int nu, int nbo
   n += nq + nv + nu;                                   // qpos qvel ctrl
   n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 6 * njnt + 3 * nsite;  // kinematics
   n += 3 * nbody + 10 * nbody + 6 * nv * 2 + 6 * nbody * 4 + 3;                           // com, cinert (crb aliases cacc|cfrc), spatial
-  n += 2 * (size_t)nv * nv + 2 * nv;                   // M H (the factor of M lives in H until Newton) + reciprocal pivots
+  n += 2 * (size_t)nv * nv + nv;                       // M H (the factor of M lives in H until Newton) + reciprocal pivots
   n += 7 * nv + nu + 5 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma tmpv qacc_warm
-  n += (size_t)kWaveMaxEfc * nv + 9 * kWaveMaxEfc;     // efc_J + per-row doubles
+  n += (size_t)kWaveMaxEfc * nv + 7 * kWaveMaxEfc;     // efc_J + per-row reals (efc_pos / efc_margin alias jar / jv)
   n += (3 * kWaveMaxEfc * sizeof(int) + sizeof(wreal) - 1) / sizeof(wreal) + 1;  // per-row ints
   n += 21 * kWaveMaxCon + 12 + nr + nterm + 8;         // coneH (lower triangles) foot_xpos residual terms scal
   n += (sizeof(WaveContact) * kWaveMaxCon + sizeof(wreal) - 1) / sizeof(wreal) + 1;
   n += 4 * sizeof(int) / sizeof(wreal) + 1;           // counters
   n += (size_t)P * nu + P;                             // spline nodes + node times
-  return n + 16;
+  return n + 4;
 }
 
 // the LDS layout of one candidate's mjData (shared by the rollout, feedback-rollout and finite-difference kernels)
@@ -35,15 +35,16 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WM
   d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
   d.cvel = take(6 * nb); d.cacc = take(6 * nb); d.cfrc = take(6 * nb); d.cfrc_sub = take(6 * nb); d.subtree_linvel = take(3);
   d.crb = d.cacc;  // composite inertias (10 nb) are dead before RNE writes cacc | cfrc (12 nb, contiguous)
-  d.M = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = take(nv);
+  d.M = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = d.Ldinv;  // the pivots of chol(M) are dead once qacc_smooth is solved (L aliases H likewise)
   d.L = d.H;       // the factor of M is only needed until qacc_smooth is solved, before Newton builds H
   d.qfrc_passive = take(nv); d.qfrc_bias = take(nv); d.qfrc_actuator = take(nv); d.qfrc_smooth = take(nv);
   d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
   d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = nullptr; d.tmpv = take(nv); d.qacc_warm = take(nv);
   d.efc_J = take((size_t)kWaveMaxEfc * nv);
-  d.efc_pos = take(kWaveMaxEfc); d.efc_margin = take(kWaveMaxEfc); d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
+  d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
   d.efc_aref = take(kWaveMaxEfc); d.efc_floss = take(kWaveMaxEfc); d.efc_force = take(kWaveMaxEfc); d.jar = take(kWaveMaxEfc);
   d.jv = take(kWaveMaxEfc);
+  d.efc_pos = d.jar; d.efc_margin = d.jv;  // row assembly only; the Newton solver overwrites jar / jv afterwards
   int* ip = reinterpret_cast<int*>(take((3 * kWaveMaxEfc * sizeof(int) + sizeof(wreal) - 1) / sizeof(wreal) + 1));
   d.efc_type = ip; d.efc_id = ip + kWaveMaxEfc; d.efc_zone = ip + 2 * kWaveMaxEfc;
   d.coneH = take(21 * kWaveMaxCon); d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
@@ -56,7 +57,7 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WM
 }
 
 template <int NMAX>
-__global__ __launch_bounds__(64) void rollout_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a) {
+__global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x, cand = blockIdx.x;
   // The model and task structs stay in the kernel-argument segment (scalar loads). Staging the model allocation into
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const WModel m, const 
     WSTAMP(0);
     wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, stamp, /*have_warm=*/t > 0);
     if (!last) for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qacc[i]);  // mj_checkAcc
+    if (!last) bad |= d.counters[2] != 0;  // CheckWarnings: contact / row cap overflow, indefinite Hessian (oracle odata_warning)
     bad = __any(bad);
     // ================= sensor stage: task residual and cost (task.cc:71-110)
     wr_residual(m, tk, d, time, lane);

@@ -213,3 +213,24 @@ def test_ilqg_planner_on_the_quadruped():
     a = np.zeros(12)
     py.action_from_policy(a, x, 0.013)
     np.testing.assert_allclose(cpp.action(0.013, state=x), a, rtol=1e-12, atol=1e-14)
+
+
+def test_row_cap_overflow_fails_the_rollout_like_the_oracle(quad):
+    """large exploration noise makes some candidates fall; with > 64 constraint rows (14 contacts of condim 6) the oracle
+    raises its row-cap warning and CheckWarnings fails the rollout (total_return = 1e6): the device must agree"""
+    home = quad.model.keyframes["home"]["qpos"]
+    state = np.concatenate([home, np.zeros(18)])
+    pm, pt = quad.packed_model(), quad.packed()
+    N, P, H = 4, 4, 100
+    rng = np.random.default_rng(0)
+    times = np.arange(P) * (H - 1) * 0.01 / (P - 1)
+    nodes = np.clip(rng.normal(0, 0.3, (N, P, 12)), -1, 1)
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, N, H, P, 1, times, nodes, num_threads=4)
+    assert ref["failure"].sum() >= 1 and ref["failure"].sum() < N
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(state, 0.0, MOCAP)
+    ctx.rollout_splines(H, 1, times, nodes)
+    ret, fail = ctx.returns()
+    assert np.array_equal(fail, ref["failure"])
+    assert close(ret, ref["total_return"], 1e-6)
+    ctx.close()
