@@ -586,7 +586,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
       }
       const WaveModel& wm = c->wh.m;
-      const size_t lds_state = (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
+      const size_t lds_state = (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false) + 15) & ~(size_t)15;
       const size_t lds = lds_state;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
       auto kern = wm.nv <= 20 ? w64::rollout_wave_kernel<20> : w64::rollout_wave_kernel<32>;
@@ -612,7 +612,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
     }
     const WaveModelT<float>& wm = c->wh.m32;
-    const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P) + 15) & ~(size_t)15;
+    const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false) + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
     auto kern = wm.nv <= 20 ? w32::rollout_wave_kernel<20> : w32::rollout_wave_kernel<32>;
     le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1214,7 +1214,7 @@ int wave_blob(mjpcx_ctx* c, WaveTask* wt) {
 }
 size_t wave_lds_bytes(const mjpcx_ctx* c, int P) {
   const WaveModel& wm = c->wh.m;
-  return (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, c->wh.t.nr, c->wh.t.nterm, P) + 15) & ~(size_t)15;
+  return (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, c->wh.t.nr, c->wh.t.nterm, P, wm.cone) + 15) & ~(size_t)15;
 }
 
 int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn, const double* times,

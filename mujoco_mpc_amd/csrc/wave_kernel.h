@@ -6,32 +6,32 @@
 namespace mjpcx { namespace WAVE_NS {
 
 // LDS footprint of one candidate in elements of the working type (ints and the contact structs are rounded up to it)
-__host__ __device__ inline size_t wave_lds_elems(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P) {
+__host__ __device__ inline size_t wave_lds_elems(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P, int cone = 1, bool nodes_in_lds = true) {
   size_t n = 0;
   n += nq + nv + nu;                                   // qpos qvel ctrl
-  n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 6 * njnt + 3 * nsite;  // kinematics
+  n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 3 * nsite;  // kinematics (xanchor / xaxis alias efc_J)
   n += 3 * nbody + 10 * nbody + 6 * nv * 2 + 6 * nbody * 4 + 3;                           // com, cinert (crb aliases cacc|cfrc), spatial
   n += 2 * (size_t)nv * nv + nv;                       // M H (the factor of M lives in H until Newton) + reciprocal pivots
   n += 7 * nv + nu + 5 * nv;                           // qfrc_*, qacc*, actuator_force, grad search Ma tmpv qacc_warm
   n += (size_t)kWaveMaxEfc * nv + 7 * kWaveMaxEfc;     // efc_J + per-row reals (efc_pos / efc_margin alias jar / jv)
   n += (3 * kWaveMaxEfc * sizeof(int) + sizeof(wreal) - 1) / sizeof(wreal) + 1;  // per-row ints
-  n += 21 * kWaveMaxCon + 12 + nr + nterm + 8;         // coneH (lower triangles) foot_xpos residual terms scal
+  n += (cone == 1 ? 21 * kWaveMaxCon : 0) + 12 + nr + nterm + 8;  // coneH (lower triangles; elliptic cones only) foot_xpos residual terms scal
   n += (sizeof(WaveContact) * kWaveMaxCon + sizeof(wreal) - 1) / sizeof(wreal) + 1;
   n += 4 * sizeof(int) / sizeof(wreal) + 1;           // counters
-  n += (size_t)P * nu + P;                             // spline nodes + node times
+  n += (nodes_in_lds ? (size_t)P * nu : 0) + P;        // spline nodes (the rollout kernel reads them from HBM / L2) + node times
   return n + 4;
 }
 
 // the LDS layout of one candidate's mjData (shared by the rollout, feedback-rollout and finite-difference kernels)
 __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WModel& m, const WTask& tk, int P, wreal*& lnodes,
-                                               wreal*& ltimes) {
+                                               wreal*& ltimes, bool nodes_in_lds = true) {
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
   wreal* p = reinterpret_cast<wreal*>(smem_raw);
   auto take = [&](size_t n) { wreal* q = p; p += n; return q; };
   WaveData d;
   d.qpos = take(nq); d.qvel = take(nv); d.ctrl = take(nu);
   d.xpos = take(3 * nb); d.xquat = take(4 * nb); d.xmat = take(9 * nb); d.xipos = take(3 * nb); d.ximat = take(9 * nb);
-  d.xanchor = take(3 * nj); d.xaxis = take(3 * nj); d.site_xpos = take(3 * ns);
+  d.site_xpos = take(3 * ns);
   d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
   d.cvel = take(6 * nb); d.cacc = take(6 * nb); d.cfrc = take(6 * nb); d.cfrc_sub = take(6 * nb); d.subtree_linvel = take(3);
   d.crb = d.cacc;  // composite inertias (10 nb) are dead before RNE writes cacc | cfrc (12 nb, contiguous)
@@ -41,16 +41,17 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WM
   d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
   d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = nullptr; d.tmpv = take(nv); d.qacc_warm = take(nv);
   d.efc_J = take((size_t)kWaveMaxEfc * nv);
+  d.xanchor = d.efc_J; d.xaxis = d.efc_J + 3 * nj;  // joint anchors / axes are dead after cdof, before the rows are assembled
   d.efc_D = take(kWaveMaxEfc); d.efc_R = take(kWaveMaxEfc);
   d.efc_aref = take(kWaveMaxEfc); d.efc_floss = take(kWaveMaxEfc); d.efc_force = take(kWaveMaxEfc); d.jar = take(kWaveMaxEfc);
   d.jv = take(kWaveMaxEfc);
   d.efc_pos = d.jar; d.efc_margin = d.jv;  // row assembly only; the Newton solver overwrites jar / jv afterwards
   int* ip = reinterpret_cast<int*>(take((3 * kWaveMaxEfc * sizeof(int) + sizeof(wreal) - 1) / sizeof(wreal) + 1));
   d.efc_type = ip; d.efc_id = ip + kWaveMaxEfc; d.efc_zone = ip + 2 * kWaveMaxEfc;
-  d.coneH = take(21 * kWaveMaxCon); d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
+  d.coneH = m.cone == 1 ? take(21 * kWaveMaxCon) : nullptr; d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
   d.con = reinterpret_cast<WaveContact*>(take((sizeof(WaveContact) * kWaveMaxCon + sizeof(wreal) - 1) / sizeof(wreal) + 1));
   d.counters = reinterpret_cast<int*>(take(4 * sizeof(int) / sizeof(wreal) + 1));
-  lnodes = take((size_t)P * nu);  // [P][nu]
+  lnodes = nodes_in_lds ? take((size_t)P * nu) : nullptr;  // [P][nu]
   ltimes = take(P);
 
   return d;
@@ -68,12 +69,16 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
   const size_t N = (size_t)a.N;
   // ---- LDS carve
   wreal* lnodes; wreal* ltimes;
-  WaveData d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes);
+  WaveData d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes, /*nodes_in_lds=*/false);
+  // The candidate's spline nodes stay in a.nodes ([node][actuator][candidate], HBM / L2): at most four of them per
+  // actuator are read per step; volatile reads, because other lanes of this wavefront wrote them.
+  const volatile wreal* gnodes = a.nodes + cand;
+#define WNODE(j) gnodes[(size_t)(j) * N]
   // ---- candidate spline nodes (SamplingPlanner / CrossEntropyPlanner::AddNoiseToPolicy, as rollout_lane_kernel)
   for (int q = lane; q < P; q += 64) ltimes[q] = a.node_times[q];
   const int np = P * nu;
   if (a.noise.mode < 0) {
-    for (int j = lane; j < np; j += 64) lnodes[j] = a.nodes[(size_t)j * N + cand];
+    // the caller's splines are already in place
   } else {
     const int gi = a.noise.candidate_offset + cand;
     wreal std = a.noise.std0;
@@ -100,12 +105,12 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
             }
             v = clampv(v + sigma * (wreal)z[e], lo, hi);
           }
-          lnodes[j] = v;
           a.nodes[(size_t)j * N + cand] = v;
         }
       }
     }
   }
+  __threadfence();  // the nodes this wavefront wrote are read back (by other lanes) through L2
   // ---- initial condition (Planner::SetState)
   for (int i = lane; i < nq; i += 64) d.qpos[i] = tk.blob[i];
   for (int i = lane; i < nv; i += 64) d.qvel[i] = tk.blob[nq + i];
@@ -128,11 +133,11 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
         int up = 0;
         while (up < P && ltimes[up] <= time) up++;
         if (up == P || up == 0) {
-          u = lnodes[(up == 0 ? 0 : P - 1) * nu + k];
+          u = WNODE((up == 0 ? 0 : P - 1) * nu + k);
         } else {
           const int lo = up - 1;
           const wreal tl = ltimes[lo], tu = ltimes[up];
-          const wreal p0 = lnodes[lo * nu + k], p1 = lnodes[up * nu + k];
+          const wreal p0 = WNODE(lo * nu + k), p1 = WNODE(up * nu + k);
           if (a.interp == 0) u = p0;
           else {
             const wreal s = (time - tl) / (tu - tl);
@@ -141,9 +146,9 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
               const wreal dt_mid = tu - tl, fwd = (p1 - p0) / dt_mid;
               wreal m0, m1;
               if (lo == 0) m0 = fwd;
-              else m0 = WL(0.5) * (p1 - p0) / dt_mid + WL(0.5) * (p0 - lnodes[(lo - 1) * nu + k]) / (tl - ltimes[lo - 1]);
+              else m0 = WL(0.5) * (p1 - p0) / dt_mid + WL(0.5) * (p0 - WNODE((lo - 1) * nu + k)) / (tl - ltimes[lo - 1]);
               if (up == P - 1) m1 = fwd;
-              else m1 = WL(0.5) * (lnodes[(up + 1) * nu + k] - p1) / (ltimes[up + 1] - tu) + WL(0.5) * (p1 - p0) / dt_mid;
+              else m1 = WL(0.5) * (WNODE((up + 1) * nu + k) - p1) / (ltimes[up + 1] - tu) + WL(0.5) * (p1 - p0) / dt_mid;
               const wreal s2 = s * s, s3 = s * s * s;
               const wreal c0 = 2 * s3 - 3 * s2 + 1, c1 = (s3 - 2 * s2 + s) * (tu - tl), c2 = -2 * s3 + 3 * s2, c3 = (s3 - s2) * (tu - tl);
               u = c0 * p0 + c1 * m0 + c2 * p1 + c3 * m1;

@@ -179,12 +179,31 @@ struct WaveHost {
 #undef I
 #undef D
     for (int i = 0; i < nv; i++) m.any_damping |= src->dof_damping[i] > 0;
+    // Inert trailing bodies: the Humanoid tracking task appends 16 mocap marker bodies (no dofs, no geoms, visual sites) that
+    // its residual never reads (it interpolates key_mpos itself). They are dropped from the device's body / site ranges:
+    // 65 reals of LDS each. Only for that residual -- other tasks may read any body or site.
+    int nb_live = nb, ns_live = ns;
+    if (task->residual_id == MJPCX_RESIDUAL_HUMANOID_TRACK) {
+      auto inert = [&](int b) {
+        if (src->body_mocapid[b] < 0 || src->body_parentid[b] != 0 || src->body_dofnum[b] != 0) return false;
+        for (int g = 0; g < ng; g++) if (src->geom_bodyid[g] == b) return false;
+        for (int c2 = 0; c2 < nb; c2++) if (c2 != b && src->body_parentid[c2] == b) return false;
+        return true;
+      };
+      while (nb_live > 1 && inert(nb_live - 1)) nb_live--;
+      while (ns_live > 0 && src->site_bodyid[ns_live - 1] >= nb_live) ns_live--;
+      for (int k = 0; k < task->num_trace; k++) {
+        const int ts = task->trace_site[k];
+        if ((ts >= 0 && ts >= ns_live) || (ts < 0 && -1 - ts >= nb_live)) { nb_live = nb; ns_live = ns; break; }
+      }
+      for (int i = 0; i < ns_live; i++) if (src->site_bodyid[i] >= nb_live) { nb_live = nb; ns_live = ns; break; }
+    }
     // baked helpers
     std::vector<unsigned long long> sub(nb, 0);
     std::vector<unsigned> dofmask(nb, 0);
     std::vector<int> depth(nb, 0);
     for (int i = 0; i < nb; i++) {
-      for (int b = i; ; b = src->body_parentid[b]) { sub[b] |= 1ull << i; if (b == 0) break; }
+      if (i < nb_live) for (int b = i; ; b = src->body_parentid[b]) { sub[b] |= 1ull << i; if (b == 0) break; }
       if (i > 0) depth[i] = depth[src->body_parentid[i]] + 1;
       unsigned mk = i > 0 ? dofmask[src->body_parentid[i]] : 0u;
       for (int k = 0; k < src->body_dofnum[i]; k++) mk |= 1u << (src->body_dofadr[i] + k);
@@ -197,7 +216,7 @@ struct WaveHost {
     m.nlevel = maxdepth;
     for (int l = 1; l <= maxdepth; l++) {
       m.level_start[l - 1] = (int)level_body.size();
-      for (int i = 1; i < nb; i++) if (depth[i] == l) level_body.push_back(i);
+      for (int i = 1; i < nb_live; i++) if (depth[i] == l) level_body.push_back(i);
     }
     m.level_start[maxdepth] = (int)level_body.size();
     std::vector<int> sg, dg;
@@ -268,6 +287,7 @@ struct WaveHost {
     t.trace_site = (const int*)((const char*)dev + o_trace.first);
     m.base = (const unsigned char*)dev;
     m.bytes = (int)host.size();
+    m.nbody = nb_live; m.nsite = ns_live;  // device ranges (the arrays keep the model's sizes)
     // blob layout
     int o = 0;
     auto seg = [&](int n) { int at = o; o += n; return at; };
