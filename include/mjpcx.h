@@ -263,7 +263,8 @@ typedef struct mjpcx_noise_spec {
 typedef struct mjpcx_ctx mjpcx_ctx;
 
 /* ---- lifecycle --------------------------------------------------------------
- * precision: 64 (fp64, the reference's mjtNum) or 32. Replaces
+ * precision: 64 (fp64, the reference's mjtNum) or 32 (every rollout kernel family has a float instantiation; Trajectory
+ * buffers come back as doubles either way; the iLQG entry points of the contact-model family are fp64 only). Replaces
  * Planner::Initialize/Allocate/ResizeMjData (planners/planner.cc:23-33). */
 int mjpcx_create(const mjpcx_model* model, const mjpcx_task* task, int device,
                  int precision, mjpcx_ctx** out);
