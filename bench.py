@@ -193,6 +193,9 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             if args.task == "Cartpole" and args.candidates == 4096 and H == 128 and args.precision == 64:
                 out["roofline"]["traffic"] = pmc["n4096"]["hbm_bytes_per_launch"]
+            if args.task == "QuadrupedFlat" and args.candidates == 16384 and H == 100:
+                pq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_quadruped.json")))
+                out["roofline"]["traffic"] = pq[f"fp{args.precision}"]["derived"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         if not args.no_cpu_baseline:

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(1024) void sort_kernel(const double* __restrict__ r
 template <typename T>
 __global__ void gather_traj_kernel(const T* states, const T* actions, const T* times, const T* residual,
                                    const T* costs, const T* trace, int N, int H, int ds, int nu, int nr, int ntr3,
-                                   int cand, double* out) {
+                                   int cand, double* out, int candidate_major) {
   const int row = ds + nu + 1 + nr + 1 + ntr3;
   const int total = H * row;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -258,8 +258,9 @@ __global__ void gather_traj_kernel(const T* states, const T* actions, const T* t
     else if ((o -= H) < H * nr) { src = residual; width = nr; }
     else if ((o -= H * nr) < H) { src = costs; width = 1; }
     else { o -= H; src = trace; width = ntr3; }
-    out[i] = (double)src[(size_t)o * N + cand];  // o = t*width + k  ->  [(t*width+k)*N + cand]
-    (void)width;
+    // o = t*width + k -> [(t*width+k)*N + cand] (lane-per-candidate kernels: a wavefront stores 64 consecutive candidates),
+    // or [(cand*H + t)*width + k] (wavefront-per-candidate kernels: a wavefront stores one candidate's row)
+    out[i] = (double)(candidate_major ? src[(size_t)cand * H * width + o] : src[(size_t)o * N + cand]);
   }
 }
 template <typename T>
@@ -319,6 +320,7 @@ struct mjpcx_ctx {
   // rollout buffers
   DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out, d_simt, d_wblob;
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
+  bool traj_candidate_major = false;  // layout of the last rollout's Trajectory buffers (true: wavefront-per-candidate kernels)
   int N = 0, H = 0, P = 0;  // shape of the last rollout
   bool have_rollout = false;
   // wavefront-per-candidate family
@@ -631,6 +633,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
   slot->pending = true;
   c->N = N; c->H = H; c->P = P;
   c->have_rollout = true;
+  {
+    const char* force = getenv("MJPCX_CONTACT_KERNEL");
+    c->traj_candidate_major = c->wave && !(force && std::string(force) == "simt");
+  }
   return MJPCX_OK;
 }
 
@@ -1018,12 +1024,12 @@ int mjpcx_fetch_trajectory(mjpcx_ctx* c, int cand, mjpcx_traj_view* out) {
     hipLaunchKernelGGL((gather_traj_kernel<double>), dim3(blocks), dim3(256), 0, c->stream, (const double*)c->d_states.p,
                        (const double*)c->d_actions.p, (const double*)c->d_times.p, (const double*)c->d_residual.p,
                        (const double*)c->d_costs.p, (const double*)c->d_trace.p, c->N, H, ds, nu, nr, ntr3, cand,
-                       (double*)c->d_stage.p);
+                       (double*)c->d_stage.p, c->traj_candidate_major ? 1 : 0);
   else
     hipLaunchKernelGGL((gather_traj_kernel<float>), dim3(blocks), dim3(256), 0, c->stream, (const float*)c->d_states.p,
                        (const float*)c->d_actions.p, (const float*)c->d_times.p, (const float*)c->d_residual.p,
                        (const float*)c->d_costs.p, (const float*)c->d_trace.p, c->N, H, ds, nu, nr, ntr3, cand,
-                       (double*)c->d_stage.p);
+                       (double*)c->d_stage.p, c->traj_candidate_major ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   c->h_stage.resize(total);
   double ret = 0; int32_t fl = 0;
@@ -1156,6 +1162,7 @@ int do_feedback(mjpcx_ctx* c, int N, int H, int mode, int representation, int us
   if (le != hipSuccess) return fail(c, MJPCX_EDEVICE, std::string("feedback kernel launch: ") + hipGetErrorString(le));
   c->N = N; c->H = H; c->P = 0;
   c->have_rollout = true;
+  c->traj_candidate_major = false;
   return MJPCX_OK;
 }
 
@@ -1242,6 +1249,7 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
   HIPCHK(c, hipGetLastError());
   c->N = N; c->H = H; c->P = 1;
   c->have_rollout = true;
+  c->traj_candidate_major = true;
   return MJPCX_OK;
 }
 

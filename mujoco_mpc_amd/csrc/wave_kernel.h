@@ -188,16 +188,16 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
     if (!(fabs(risk) < WL(1.0e-6))) cost = (exp(risk * cost) - WL(1.0)) / risk;
     // ================= record step t
     if (!failed) {
-      for (int i = lane; i < ds; i += 64) a.states[((size_t)t * ds + i) * N + cand] = i < nq ? d.qpos[i] : d.qvel[i - nq];
-      if (lane < nu) a.actions[((size_t)t * nu + lane) * N + cand] = d.ctrl[lane];
-      for (int i = lane; i < nr; i += 64) a.residual[((size_t)t * nr + i) * N + cand] = d.residual[i];
+      for (int i = lane; i < ds; i += 64) a.states[((size_t)cand * H + t) * ds + i] = i < nq ? d.qpos[i] : d.qvel[i - nq];
+      if (lane < nu) a.actions[((size_t)cand * H + t) * nu + lane] = d.ctrl[lane];
+      for (int i = lane; i < nr; i += 64) a.residual[((size_t)cand * H + t) * nr + i] = d.residual[i];
       if (lane < 3 * tk.ntrace) {
         const int ts = tk.trace_site[lane / 3];  // site id, or -1 - body id for a body frame
-        a.trace[((size_t)t * 3 * tk.ntrace + lane) * N + cand] = ts >= 0 ? d.site_xpos[3 * ts + lane % 3] : d.xpos[3 * (-1 - ts) + lane % 3];
+        a.trace[((size_t)cand * H + t) * 3 * tk.ntrace + lane] = ts >= 0 ? d.site_xpos[3 * ts + lane % 3] : d.xpos[3 * (-1 - ts) + lane % 3];
       }
       if (lane == 0) {
-        a.times[(size_t)t * N + cand] = time;
-        if (!bad) a.costs[(size_t)t * N + cand] = cost;
+        a.times[(size_t)cand * H + t] = time;
+        if (!bad) a.costs[(size_t)cand * H + t] = cost;
       }
     }
     if (bad) failed = true;
