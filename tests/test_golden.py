@@ -91,3 +91,31 @@ def test_gpu_matches_golden_riccati(cartpole):
             for k in ("K", "du"):  # the oracle leaves index T-1 as a copy of T-2 too (backward_pass.cc:297-306)
                 assert close(r[k][:T - 1], o[f"lim{lim}_reg{reg}_{k}"][:T - 1], 1e-9), (lim, reg, k)
     ctx.close()
+
+
+def _mujoco_goldens():
+    import glob
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mujoco_*.npz")))
+
+
+@pytest.mark.skipif(not _mujoco_goldens(), reason="no MuJoCo goldens: tools/dump_mujoco_golden.py needs the mujoco wheel (parity unpinned)")
+@pytest.mark.parametrize("path", _mujoco_goldens() or [None])
+def test_oracle_against_mujoco_goldens(path):
+    """pins the oracle's physics to MuJoCo itself once a golden file exists: compiled constants first (they catch model
+    re-authoring errors), then the first steps of the trajectory (contact-rich rollouts diverge later at any precision)"""
+    from mujoco_mpc_amd.task import load_task
+    from oracle import pyoracle
+    g = np.load(path)
+    name = os.path.basename(path)[len("mujoco_"):-len(".npz")]
+    t = load_task(name)
+    m = t.model
+    assert np.allclose(m.arrays["body_mass"], g["body_mass"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(m.arrays["dof_invweight0"], g["dof_invweight0"], rtol=1e-6)
+    assert abs(m.scalars["meaninertia"] - float(g["meaninertia"])) < 1e-6 * abs(float(g["meaninertia"]))
+    ph = pyoracle.Physics(t.packed_model())
+    ph.set_state(g["qpos"][0], g["qvel"][0], 0.0)
+    for k in range(20):
+        ph.set_ctrl(g["ctrl"][k])
+        ph.step()
+        assert np.allclose(ph.get("qacc"), g["qacc"][k], rtol=1e-5, atol=1e-6), k
+        assert np.allclose(ph.get("qpos"), g["qpos"][k + 1], rtol=0, atol=1e-7), k

@@ -234,3 +234,45 @@ def test_row_cap_overflow_fails_the_rollout_like_the_oracle(quad):
     assert np.array_equal(fail, ref["failure"])
     assert close(ret, ref["total_return"], 1e-6)
     ctx.close()
+
+
+@pytest.mark.parametrize("N,H,P,interp", [(1, 1, 1, 0), (1, 2, 1, 2), (3, 2, 2, 1), (65, 3, 1, 0)])
+def test_degenerate_shapes(quad, N, H, P, interp):
+    """single candidate, horizon 1 (only the final mj_forward), a single spline node, a batch that is not a multiple of 64"""
+    home = quad.model.keyframes["home"]["qpos"]
+    state = np.concatenate([home, np.zeros(18)])
+    pm, pt = quad.packed_model(), quad.packed()
+    rng = np.random.default_rng(N + H)
+    times = np.arange(P) * 0.01
+    nodes = np.clip(rng.normal(0, 0.2, (N, P, 12)), -1, 1)
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(state, 0.25, MOCAP)
+    ctx.rollout_splines(H, interp, times + 0.25, nodes)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.25, MOCAP, N, H, P, interp, times + 0.25, nodes, num_threads=2)
+    assert np.array_equal(fail, ref["failure"]) and close(ret, ref["total_return"], 1e-9)
+    tr = ctx.fetch_trajectory(N - 1)
+    for name in ("states", "actions", "times", "residual", "costs", "trace"):
+        assert close(getattr(tr, name), ref[name][N - 1], 1e-9), name
+    ctx.close()
+
+
+def test_maximum_horizon(quad):
+    """kMaxTrajectoryHorizon = 512 steps (mjpc/trajectory.h): buffers and the time loop hold; a standing robot under its
+    home controls stays finite"""
+    home = quad.model.keyframes["home"]["qpos"]
+    state = np.concatenate([home, np.zeros(18)])
+    pm, pt = quad.packed_model(), quad.packed()
+    N, H, P = 2, 512, 3
+    times = np.array([0.0, 2.0, 5.11])
+    nodes = np.tile(home[7:], (N, P, 1))
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(state, 0.0, MOCAP)
+    ctx.rollout_splines(H, 0, times, nodes)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, N, H, P, 0, times, nodes, num_threads=2)
+    assert not fail.any() and np.array_equal(fail, ref["failure"])
+    assert close(ret, ref["total_return"], 1e-6)
+    tr = ctx.fetch_trajectory(1)
+    assert tr.states.shape == (512, 37) and np.isfinite(tr.states).all() and abs(tr.times[-1] - 5.11) < 1e-9
+    ctx.close()
