@@ -896,6 +896,74 @@ __device__ __forceinline__ void wf_row_eval(const WaveData& d, int r, const wrea
   cost = res.cost; g1 = res.g1; h2 = res.h2;
 }
 
+// ---- line search: the row's data is loaded ONCE per Newton iteration into registers; every trial alpha is then pure
+// register arithmetic (same operations, in the same order, as wf_row_eval_impl with write_force = false)
+struct LsRow {
+  int type, dim;          // type < 0: nothing to evaluate (inactive lane, member row of a cone)
+  wreal D, R, fl, mu;     // row 0 of the cone / the row itself
+  wreal x0[6], v[6], f[6], Dj[6];
+};
+__device__ __forceinline__ LsRow ls_load(const WaveData& d, int r, int ne) {
+  LsRow q;
+  q.type = -1; q.dim = 1; q.D = q.R = q.fl = q.mu = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) { q.x0[j] = q.v[j] = q.f[j] = q.Dj[j] = 0; }
+  if (r >= ne) return q;
+  const int t = d.efc_type[r];
+  if (t == kEfcConeRow) return q;
+  q.type = t;
+  q.D = d.efc_D[r]; q.R = d.efc_R[r]; q.fl = d.efc_floss[r];
+  q.x0[0] = d.jar[r]; q.v[0] = d.jv[r]; q.Dj[0] = q.D;
+  if (t == kEfcElliptic) {
+    const WaveContact& c = d.con[d.efc_id[r]];
+    q.dim = c.dim; q.mu = c.mu;
+#pragma unroll
+    for (int j = 1; j < 6; j++)
+      if (j < q.dim) { q.x0[j] = d.jar[r + j]; q.v[j] = d.jv[r + j]; q.f[j] = c.friction[j - 1]; q.Dj[j] = d.efc_D[r + j]; }
+  }
+  return q;
+}
+// first and second derivative along the search direction of this row's penalty at jar + alpha jv
+__device__ __forceinline__ void ls_eval(const LsRow& q, wreal alpha, wreal& g1, wreal& h2) {
+  g1 = 0; h2 = 0;
+  if (q.type < 0) return;
+  const wreal v = q.v[0], x = q.x0[0] + alpha * v, D = q.D;
+  if (q.type == kEfcFriction) {
+    const wreal f = q.fl, R = q.R;
+    if (x <= -R * f) g1 = -f * v;
+    else if (x >= R * f) g1 = f * v;
+    else { g1 = D * x * v; h2 = D * v * v; }
+  } else if (q.type != kEfcElliptic) {  // limit, tendon limit, frictionless contact, pyramid edge
+    if (x < 0) { g1 = D * x * v; h2 = D * v * v; }
+  } else {
+    const wreal mu = q.mu;
+    wreal U[6], V[6], X[6], T = 0;
+    X[0] = x; U[0] = x * mu; V[0] = v * mu;
+#pragma unroll
+    for (int j = 1; j < 6; j++) {
+      if (j < q.dim) { X[j] = q.x0[j] + alpha * q.v[j]; U[j] = X[j] * q.f[j]; V[j] = q.v[j] * q.f[j]; T += U[j] * U[j]; }
+      else { X[j] = U[j] = V[j] = 0; }
+    }
+    T = sqrt(T);
+    const wreal N = U[0];
+    if (N >= mu * T || (T <= 0 && N >= 0)) {
+    } else if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+        if (j < q.dim) { g1 += q.Dj[j] * X[j] * q.v[j]; h2 += q.Dj[j] * q.v[j] * q.v[j]; }
+    } else {
+      const wreal Dm = D / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+      wreal UV = 0, VV = 0;
+#pragma unroll
+      for (int j = 1; j < 6; j++) if (j < q.dim) { UV += U[j] * V[j]; VV += V[j] * V[j]; }
+      const wreal dNT = V[0] - mu * UV / T;
+      const wreal d2NT = -mu * (VV / T - UV * UV / (T * T * T));
+      g1 = Dm * NT * dNT;
+      h2 = Dm * (dNT * dNT + NT * d2NT);
+    }
+  }
+}
+
 // cost of all rows at jar; writes force and zone. Returns the wave-uniform sum.
 __device__ __forceinline__ wreal wf_constraint_cost(WaveData& d, int nefc, int lane) {
   wreal c = 0, g, h;
@@ -1112,9 +1180,9 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     WSYNC();
     WACC(36);
     // exact line search: safeguarded 1-D Newton on the (convex, piecewise quadratic) restriction
-    wreal lo = 0, hi = -1, alpha = 0, d1, d2, c0, g0, h0;
-    c0 = 0; g0 = 0; h0 = 0;
-    if (lane < ne) wf_row_eval(d, lane, d.jar, d.jv, WL(0.0), false, c0, g0, h0);
+    wreal lo = 0, hi = -1, alpha = 0, d1, d2, g0, h0;
+    const LsRow lsrow = ls_load(d, lane, ne);
+    ls_eval(lsrow, WL(0.0), g0, h0);
     d1 = wave_sum(g0) + q1; d2 = wave_sum(h0) + q2;
     const wreal d10 = fabs(d1);
     // termination as in MuJoCo's PrimalSearch: |derivative| < tolerance * ls_tolerance * |search| / scale
@@ -1125,8 +1193,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
       if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? WL(0.5) * (lo + hi) : 2 * alpha + 1;
       if (an == alpha) break;
       alpha = an;
-      c0 = 0; g0 = 0; h0 = 0;
-      if (lane < ne) wf_row_eval(d, lane, d.jar, d.jv, alpha, false, c0, g0, h0);
+      ls_eval(lsrow, alpha, g0, h0);
       d1 = wave_sum(g0) + q1 + alpha * q2; d2 = wave_sum(h0) + q2;
       if (fabs(d1) < gtol) break;
       if (d1 < 0) lo = alpha; else hi = alpha;
