@@ -160,7 +160,10 @@ __device__ __forceinline__ wreal wbcast(wreal v, int src) { return w_readlane(v,
 // in-place: on exit the lower triangle of A (LDS, ld n) holds L with A = L L', dinv[j] = 1 / L[j][j].
 // (not inlined: five call sites per step, and the step loop has to stay inside the instruction cache)
 template <int NMAX>
-__device__ __noinline__ bool wave_chol(wreal* A, wreal* dinv, int n, int lane) {
+__device__ __noinline__ bool wave_chol(wreal* A, wreal* dinv, int n_, int lane) {
+  // (arguments of an out-of-line function arrive in VGPRs: make the size scalar again, or every guard below becomes a
+  // vector compare + exec-mask branch)
+  const int n = __builtin_amdgcn_readfirstlane(n_);
   wreal row[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; k++) row[k] = (lane < n && k <= lane) ? A[lane * n + k] : WL(0.0);
@@ -176,13 +179,10 @@ __device__ __noinline__ bool wave_chol(wreal* A, wreal* dinv, int n, int lane) {
         const wreal lij = lane == j ? djj * inv : row[j] * inv;
         row[j] = lij;
         if (lane == j) dinv[j] = inv;
+        // no guards in the update: lanes >= n hold zero rows (their broadcast l_kj is 0), lanes < k update an
+        // upper-triangle slot nobody reads
 #pragma unroll
-        for (int k = j + 1; k < NMAX; k++) {
-          if (k < n) {
-            const wreal lkj = wbcast(lij, k);
-            if (lane >= k) row[k] -= lij * lkj;
-          }
-        }
+        for (int k = j + 1; k < NMAX; k++) row[k] -= lij * wbcast(lij, k);
       }
     }
   }
@@ -193,7 +193,8 @@ __device__ __noinline__ bool wave_chol(wreal* A, wreal* dinv, int n, int lane) {
 }
 // x := (L L')^-1 x, x in LDS
 template <int NMAX>
-__device__ __noinline__ void wave_chol_solve(wreal* x, const wreal* L, const wreal* dinv, int n, int lane) {
+__device__ __noinline__ void wave_chol_solve(wreal* x, const wreal* L, const wreal* dinv, int n_, int lane) {
+  const int n = __builtin_amdgcn_readfirstlane(n_);
   wreal row[NMAX], col[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
@@ -202,19 +203,16 @@ __device__ __noinline__ void wave_chol_solve(wreal* x, const wreal* L, const wre
   }
   wreal b = lane < n ? x[lane] : WL(0.0);
   const wreal mydinv = lane < n ? dinv[lane] : WL(0.0);
+  // unguarded sweeps: for j >= n the broadcast pivot reciprocal is 0, so the step is a no-op
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
-    if (j < n) {
-      const wreal yj = wbcast(b, j) * wbcast(mydinv, j);
-      b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
-    }
+    const wreal yj = wbcast(b, j) * wbcast(mydinv, j);
+    b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
   }
 #pragma unroll
   for (int j = NMAX - 1; j >= 0; j--) {
-    if (j < n) {
-      const wreal xj = wbcast(b, j) * wbcast(mydinv, j);
-      b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
-    }
+    const wreal xj = wbcast(b, j) * wbcast(mydinv, j);
+    b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
   }
   if (lane < n) x[lane] = b;
   WSYNC();
