@@ -456,7 +456,7 @@ __device__ __forceinline__ void wf_collision(const WModel& m, WaveData& d, int l
       below += __popcll(b & ((1ull << lane) - 1ull));
       total += __popcll(b);
     }
-    const int base = d.counters[0];
+    const int base = __builtin_amdgcn_readfirstlane(d.counters[0]);
     WSYNC();
     if (cnt > 0) {
       WaveContact proto;
@@ -573,7 +573,7 @@ __device__ __forceinline__ void wf_collision(const WModel& m, WaveData& d, int l
       below += __popcll(b & ((1ull << lane) - 1ull));
       total += __popcll(b);
     }
-    const int base = d.counters[0];
+    const int base = __builtin_amdgcn_readfirstlane(d.counters[0]);
     WSYNC();
     if (cnt > 0) {
       WaveContact proto;
@@ -679,13 +679,13 @@ __device__ __forceinline__ void wf_make_constraint(const WModel& m, WaveData& d,
   if (nefc > kWaveMaxEfc) nefc = kWaveMaxEfc;
   WSYNC();
   // contacts: row ranges by a serial prefix over (<= 16) contacts, every lane computes the same numbers
-  const int ncon = d.counters[0];
+  const int ncon = __builtin_amdgcn_readfirstlane(d.counters[0]);  // wave-uniform, but an LDS load lands in a VGPR: keep loops scalar
   const bool pyramidal = m.cone != 1;
   int my_efc = 0, my_rows = 0;
   {
     int at = nefc;
     for (int ci = 0; ci < ncon; ci++) {
-      const int dim = d.con[ci].dim0;
+      const int dim = __builtin_amdgcn_readfirstlane(d.con[ci].dim0);
       const int rows = (dim > 1 && pyramidal) ? 2 * (dim - 1) : dim;
       const int fit = at + rows <= kWaveMaxEfc ? rows : (kWaveMaxEfc - at > 0 ? kWaveMaxEfc - at : 0);
       overflow |= fit < rows;
@@ -976,7 +976,7 @@ __device__ __forceinline__ wreal wf_constraint_cost(WaveData& d, int nefc, int l
 // ---- o_constraint_newton
 template <int NMAX>
 __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& d, int lane, long long* stamp = nullptr, bool have_warm = false) {
-  const int nv = m.nv, ne = d.counters[1];
+  const int nv = m.nv, ne = __builtin_amdgcn_readfirstlane(d.counters[1]);
   if (lane < nv) { d.qfrc_constraint[lane] = 0; d.qacc[lane] = d.qacc_smooth[lane]; }
   WSYNC();
   if (ne == 0) return;
