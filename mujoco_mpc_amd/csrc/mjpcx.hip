@@ -703,7 +703,8 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     for (int j = 0; j < m->njnt; j++)
       if (m->jnt_limited[j] && (m->jnt_type[j] == MJPCX_JNT_FREE || m->jnt_type[j] == MJPCX_JNT_BALL))
         return bad(MJPCX_EUNSUPPORTED, "limits on free/ball joints are not implemented");
-    if (t->num_trace * 3 > 64 || m->nu > 64 || t->num_term > 64) return bad(MJPCX_EUNSUPPORTED, "task exceeds the wave kernel capacity");
+    if (t->num_trace * 3 > 64 || m->nu > 64 || t->num_term > 64 || t->num_residual > kWaveMaxEfc * m->nv)
+      return bad(MJPCX_EUNSUPPORTED, "task exceeds the wave kernel capacity");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad(MJPCX_EDEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return bad(MJPCX_EINVAL, "device index out of range");

@@ -259,23 +259,32 @@ __device__ __forceinline__ void w_make_frame(wreal* frame) {
 }
 constexpr wreal kMinMu = WL(1e-5);
 
-// runtime-sized mjpc::Norm value (device_common.h norm_value with a run-time slice length)
-__device__ __noinline__ wreal w_norm_value(const wreal* x, int n, int type, wreal p, wreal q) {
-  wreal y = 0;
+// mjpc::Norm value (mjpc/norm.cc:50-210) in two stages so that the transcendental part runs one lane per residual ENTRY:
+// every norm is g(sum_i f(x_i)); w_norm_elem is f, w_norm_finish is g applied to the (sequentially accumulated) sum.
+__device__ __forceinline__ wreal w_norm_elem(wreal x, int type, wreal p, wreal q) {
   switch (type) {
-    case -1: y = x[0]; break;
-    case 0: for (int i = 0; i < n; i++) y += x[i] * x[i]; y *= WL(0.5); break;
-    case 1: { wreal c = 0; for (int i = 0; i < n; i++) c += x[i] * x[i]; y = pow(pow(c, q / 2) + pow(p, q), 1 / q) - p; break; }
-    case 2: { wreal c = 0; for (int i = 0; i < n; i++) c += x[i] * x[i]; y = sqrt(c + p * p) - p; break; }
-    case 3: for (int i = 0; i < n; i++) y += p * p * (cosh(x[i] / p) - WL(1.0)); break;
-    case 5: for (int i = 0; i < n; i++) y += pow(fabs(x[i]), p); break;
-    case 6: for (int i = 0; i < n; i++) y += sqrt(x[i] * x[i] + p * p) - p; break;
-    case 7: for (int i = 0; i < n; i++) y += pow(pow(fabs(x[i]), q) + pow(p, q), 1 / q) - p; break;
-    case 8: for (int i = 0; i < n; i++) y += p > 0 ? p * log(1 + exp(x[i] / p)) : (x[i] > 0 ? x[i] : WL(0.0)); break;
-    default: break;
+    case -1: return x;
+    case 0: case 1: case 2: return x * x;
+    case 3: return p * p * (cosh(x / p) - WL(1.0));
+    case 5: return pow(fabs(x), p);
+    case 6: return sqrt(x * x + p * p) - p;
+    case 7: return pow(pow(fabs(x), q) + pow(p, q), 1 / q) - p;
+    case 8: return p > 0 ? p * log(1 + exp(x / p)) : (x > 0 ? x : WL(0.0));
+    default: return 0;
   }
-  return y;
 }
-
+__device__ __forceinline__ wreal w_norm_finish(wreal c, int type, wreal p, wreal q) {
+  switch (type) {
+    case 0: return c * WL(0.5);
+    case 1: return pow(pow(c, q / 2) + pow(p, q), 1 / q) - p;
+    case 2: return sqrt(c + p * p) - p;
+    default: return c;
+  }
+}
+__device__ __forceinline__ wreal w_norm_value(const wreal* x, int n, int type, wreal p, wreal q) {  // serial form
+  wreal c = 0;
+  for (int i = 0; i < n; i++) c += w_norm_elem(x[i], type, p, q);
+  return w_norm_finish(c, type, p, q);
+}
 
 } }  // namespace mjpcx::WAVE_NS

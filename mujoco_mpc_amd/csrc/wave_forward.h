@@ -712,8 +712,11 @@ __device__ __forceinline__ void wf_make_constraint(const WModel& m, WaveData& d,
   if (lane == 0) { d.counters[1] = nefc; if (overflow) d.counters[2] |= 64; }
   WSYNC();
   // contact Jacobian rows: (row, dof) pairs over the lanes; J = J(body of geom2) - J(body of geom1) at the contact point
-  for (int e = lane; e < nefc * nv; e += 64) {
-    const int r = e / nv, k = e - r * nv;
+  // (r, k) advance incrementally: one integer division per lane instead of one per pass
+  const int step_r = 64 / nv, step_k = 64 - step_r * nv;
+  int r = lane / nv, k = lane - r * nv;
+  for (int e = lane; e < nefc * nv; e += 64, r += step_r, k += step_k) {
+    if (k >= nv) { k -= nv; r++; }
     const int t = d.efc_type[r];
     if (t != kEfcNormal && t != kEfcElliptic && t != kEfcConeRow && t != kEfcPyramid) continue;
     const WaveContact& c = d.con[d.efc_id[r]];

@@ -175,11 +175,18 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
     // ================= sensor stage: task residual and cost (task.cc:71-110)
     wr_residual(m, tk, d, time, lane);
     WSTAMP(12);
+    // cost terms (task.cc:71-110): the per-entry part of every norm one lane per residual entry (scratch: efc_J, dead after
+    // the solve), then one lane per term sums its entries in order and applies the norm's outer function and the weight
+    for (int i = lane; i < nr; i += 64) {
+      const int k = tk.res_term[i];
+      d.efc_J[i] = w_norm_elem(d.residual[i], tk.norm[k], tk.blob[tk.off_normp + k], tk.blob[tk.off_normq + k]);
+    }
+    WSYNC();
     if (lane < tk.nterm) {
-      int off = 0;
-      for (int k = 0; k < lane; k++) off += tk.dim_norm_residual[k];
-      d.terms[lane] = tk.blob[tk.off_weight + lane] *
-                      w_norm_value(d.residual + off, tk.dim_norm_residual[lane], tk.norm[lane], tk.blob[tk.off_normp + lane], tk.blob[tk.off_normq + lane]);
+      const int off = tk.term_off[lane], n = tk.dim_norm_residual[lane];
+      wreal c = 0;
+      for (int i = 0; i < n; i++) c += d.efc_J[off + i];
+      d.terms[lane] = tk.blob[tk.off_weight + lane] * w_norm_finish(c, tk.norm[lane], tk.blob[tk.off_normp + lane], tk.blob[tk.off_normq + lane]);
     }
     WSYNC();
     wreal cost = 0;

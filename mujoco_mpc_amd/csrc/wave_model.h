@@ -85,6 +85,7 @@ template <typename T>
 struct WaveTaskT {
   int residual_id, nr, nterm, ntrace, nparam, nri, nrr;
   const int *dim_norm_residual, *norm, *trace_site;   // static, in the model allocation
+  const int *term_off, *res_term;                     // baked: first residual entry of a term; term of a residual entry
   // blob (doubles): state[nq+nv] time mocap[7 nmocap] weight[nterm] norm_p[nterm] norm_q[nterm] parameters[nparam]
   //                 risk residual_real[nrr] ; then residual_int[nri] as int32
   const T* blob;
@@ -278,6 +279,14 @@ struct WaveHost {
     const auto o_dim = put2(task->dim_norm_residual, sizeof(int32_t) * task->num_term);
     const auto o_norm = put2(task->norm, sizeof(int32_t) * task->num_term);
     const auto o_trace = put2(task->trace_site, sizeof(int32_t) * task->num_trace);
+    std::vector<int32_t> term_off(task->num_term > 0 ? task->num_term : 1, 0), res_term(task->num_residual > 0 ? task->num_residual : 1, 0);
+    for (int k = 0, off = 0; k < task->num_term; k++) {
+      term_off[k] = off;
+      for (int i = 0; i < task->dim_norm_residual[k] && off + i < task->num_residual; i++) res_term[off + i] = k;
+      off += task->dim_norm_residual[k];
+    }
+    const auto o_toff = put2(term_off.data(), sizeof(int32_t) * term_off.size());
+    const auto o_rterm = put2(res_term.data(), sizeof(int32_t) * res_term.size());
     host.resize((host.size() + 15) & ~(size_t)15);
     if (hipMalloc(&dev, host.size()) != hipSuccess) return "hipMalloc of the model failed";
     if (hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) return "model upload failed";
@@ -285,6 +294,8 @@ struct WaveHost {
     t.dim_norm_residual = (const int*)((const char*)dev + o_dim.first);
     t.norm = (const int*)((const char*)dev + o_norm.first);
     t.trace_site = (const int*)((const char*)dev + o_trace.first);
+    t.term_off = (const int*)((const char*)dev + o_toff.first);
+    t.res_term = (const int*)((const char*)dev + o_rterm.first);
     m.base = (const unsigned char*)dev;
     m.bytes = (int)host.size();
     m.nbody = nb_live; m.nsite = ns_live;  // device ranges (the arrays keep the model's sizes)
@@ -310,6 +321,8 @@ struct WaveHost {
       t32.dim_norm_residual = (const int*)((const char*)dev32 + o_dim.second);
       t32.norm = (const int*)((const char*)dev32 + o_norm.second);
       t32.trace_site = (const int*)((const char*)dev32 + o_trace.second);
+      t32.term_off = (const int*)((const char*)dev32 + o_toff.second);
+      t32.res_term = (const int*)((const char*)dev32 + o_rterm.second);
       blob_bytes32 = (blob_doubles * 4 + sizeof(int32_t) * (size_t)task->num_residual_int + 15) & ~(size_t)15;
     }
     // host mirrors of the per-plan values
