@@ -711,42 +711,47 @@ __device__ __forceinline__ void wf_make_constraint(const WModel& m, WaveData& d,
   }
   if (lane == 0) { d.counters[1] = nefc; if (overflow) d.counters[2] |= 64; }
   WSYNC();
-  // contact Jacobian rows: (row, dof) pairs over the lanes; J = J(body of geom2) - J(body of geom1) at the contact point
-  // (r, k) advance incrementally: one integer division per lane instead of one per pass
-  const int step_r = 64 / nv, step_k = 64 - step_r * nv;
-  int r = lane / nv, k = lane - r * nv;
-  for (int e = lane; e < nefc * nv; e += 64, r += step_r, k += step_k) {
-    if (k >= nv) { k -= nv; r++; }
-    const int t = d.efc_type[r];
-    if (t != kEfcNormal && t != kEfcElliptic && t != kEfcConeRow && t != kEfcPyramid) continue;
-    const WaveContact& c = d.con[d.efc_id[r]];
-    const int row = r - c.efc;
-    wreal v = 0;
-    if ((c.dofmask >> k) & 1u) {
-      const int b2 = m.geom_bodyid[c.g2];
-      const bool second = (m.body_dofmask[b2] >> k) & 1u;   // the dof is on exactly one of the two chains
-      const int body = second ? b2 : m.geom_bodyid[c.g1];
-      const wreal* cd = d.cdof + 6 * k;
-      const wreal* com = d.subtree_com + 3 * m.body_rootid[body];
-      const wreal off[3] = {c.pos[0] - com[0], c.pos[1] - com[1], c.pos[2] - com[2]};
-      wreal lin[3];
-      cr3(lin, cd, off);
-      // axis j of the contact frame on the translational (j < 3) or rotational Jacobian of the point
-      auto along = [&](int j) {
-        const wreal* ax = c.frame + 3 * (j < 3 ? j : j - 3);
-        return j < 3 ? ax[0] * (cd[3] + lin[0]) + ax[1] * (cd[4] + lin[1]) + ax[2] * (cd[5] + lin[2])
-                     : ax[0] * cd[0] + ax[1] * cd[1] + ax[2] * cd[2];
-      };
-      if (t == kEfcPyramid) {
-        const int j = 1 + row / 2;
-        const wreal f = (row & 1) ? -c.friction[j - 1] : c.friction[j - 1];
-        v = along(0) + f * along(j);
-      } else {
-        v = along(row);
+  // contact Jacobian rows, J = J(body of geom2) - J(body of geom1) at the contact point: one lane per ROW walks the dofs
+  // of its contact's two chains (the rest of the row stays at the zero fill); the contact's data is read once per row
+  if (lane < nefc) {
+    const int r = lane, t = d.efc_type[r];
+    if (t == kEfcNormal || t == kEfcElliptic || t == kEfcConeRow || t == kEfcPyramid) {
+      const WaveContact& c = d.con[d.efc_id[r]];
+      const int row = r - c.efc;
+      const int b1 = m.geom_bodyid[c.g1], b2 = m.geom_bodyid[c.g2];
+      const unsigned mask2 = m.body_dofmask[b2];
+      const wreal pos[3] = {c.pos[0], c.pos[1], c.pos[2]};
+      wreal off1[3], off2[3];
+      for (int e = 0; e < 3; e++) {
+        off1[e] = pos[e] - d.subtree_com[3 * m.body_rootid[b1] + e];
+        off2[e] = pos[e] - d.subtree_com[3 * m.body_rootid[b2] + e];
       }
-      if (!second) v = -v;
+      // the row is axis ja of the contact frame, plus f times axis jb for a pyramid edge; axes 0..2 act on the translational,
+      // 3..5 on the rotational Jacobian of the point
+      const bool pyr = t == kEfcPyramid;
+      const int ja = pyr ? 0 : row, jb = pyr ? 1 + row / 2 : 0;
+      const wreal f = pyr ? ((row & 1) ? -c.friction[jb - 1] : c.friction[jb - 1]) : WL(0.0);
+      wreal axa[3], axb[3];
+      for (int e = 0; e < 3; e++) { axa[e] = c.frame[3 * (ja < 3 ? ja : ja - 3) + e]; axb[e] = c.frame[3 * (jb < 3 ? jb : jb - 3) + e]; }
+      unsigned mask = c.dofmask;
+      while (mask) {
+        const int k = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        const bool second = (mask2 >> k) & 1u;  // the dof is on exactly one of the two chains
+        const wreal* cd = d.cdof + 6 * k;
+        const wreal cdv[6] = {cd[0], cd[1], cd[2], cd[3], cd[4], cd[5]};
+        wreal lin[3];
+        cr3(lin, cdv, second ? off2 : off1);
+        wreal v = ja < 3 ? axa[0] * (cdv[3] + lin[0]) + axa[1] * (cdv[4] + lin[1]) + axa[2] * (cdv[5] + lin[2])
+                         : axa[0] * cdv[0] + axa[1] * cdv[1] + axa[2] * cdv[2];
+        if (pyr) {
+          const wreal w = jb < 3 ? axb[0] * (cdv[3] + lin[0]) + axb[1] * (cdv[4] + lin[1]) + axb[2] * (cdv[5] + lin[2])
+                                 : axb[0] * cdv[0] + axb[1] * cdv[1] + axb[2] * cdv[2];
+          v = v + f * w;
+        }
+        d.efc_J[r * nv + k] = second ? v : -v;
+      }
     }
-    d.efc_J[r * nv + k] = v;
   }
   WSYNC();
   // per-row impedance, reference acceleration, regulariser (cone rows after their normal row)
