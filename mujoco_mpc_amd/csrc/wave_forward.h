@@ -1093,7 +1093,6 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     // of its body (dofmask), which skips ~3/4 of the (entry, contact) pairs on a legged robot.
     for (int e = lane; e < nv * nv; e += 64) d.H[e] = d.M[e];
     WSYNC();
-    int first_contact = ne;
     for (int pass = 0; pass < 2; pass++) {
       if (lane < ne) {
         const int t = d.efc_type[lane];
@@ -1113,14 +1112,13 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     {
       const int t = lane < ne ? d.efc_type[lane] : -1;
       const bool is_contact = t >= kEfcNormal;
-      const unsigned long long b = __ballot(is_contact);
-      first_contact = b ? __ffsll((long long)b) - 1 : ne;
       if (is_contact) {
         const int id = d.efc_id[lane], zone = d.efc_zone[lane];
         if (t == kEfcElliptic) { my_kind = zone != kZoneTop ? 2 : 0; my_mask = d.con[id].dofmask; my_id = id; my_dim = d.con[id].dim; }
         else if (t != kEfcConeRow && zone == kZoneBottom) { my_kind = 1; my_mask = t == kEfcTendon ? m.tendon_dofmask[id] : d.con[id].dofmask; my_D = d.efc_D[lane]; }
       }
     }
+    const unsigned long long active_rows = __ballot(my_kind != 0);
     for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
       // e -> (a >= b)
       int a = (int)((sqrt(WL(8.0) * e + WL(1.0)) - WL(1.0)) * WL(0.5));
@@ -1129,9 +1127,9 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
       const int b = e - a * (a + 1) / 2;
       const unsigned need = (1u << a) | (1u << b);
       wreal h = d.H[a * nv + b];
-      for (int r = first_contact; r < ne; r++) {
+      for (unsigned long long todo = active_rows; todo; todo &= todo - 1) {  // rows with something to add, scalar loop
+        const int r = __ffsll((long long)todo) - 1;
         const int kind = __builtin_amdgcn_readlane(my_kind, r);  // wave-uniform
-        if (kind == 0) continue;
         const unsigned mask = (unsigned)__builtin_amdgcn_readlane((int)my_mask, r);
         if (kind == 1) {
           const wreal D = wbcast(my_D, r);
@@ -1157,7 +1155,6 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
             }
           }
         }
-        r += (dim > 0 ? dim : 1) - 1;
       }
       d.H[a * nv + b] = h;
       d.H[b * nv + a] = h;
