@@ -157,6 +157,16 @@ __device__ __forceinline__ wreal w_dot6(const wreal* a, const wreal* b) {
 // dependent chain. Pivots are applied as reciprocals (one v_rsq-based 1/sqrt per column instead of a sqrt and a
 // division per row), which differs from the oracle's divisions by <= 2 ulp.
 __device__ __forceinline__ wreal wbcast(wreal v, int src) { return w_readlane(v, src); }  // src must be wave-uniform
+// position of the n-th (0-based) set bit of m (n < popcount(m))
+__device__ __forceinline__ int w_nth_bit(unsigned m, int n) {
+  int base = 0, c;
+  c = __popc(m & 0xFFFFu); if (n >= c) { n -= c; m >>= 16; base += 16; }
+  c = __popc(m & 0xFFu);   if (n >= c) { n -= c; m >>= 8; base += 8; }
+  c = __popc(m & 0xFu);    if (n >= c) { n -= c; m >>= 4; base += 4; }
+  c = __popc(m & 0x3u);    if (n >= c) { n -= c; m >>= 2; base += 2; }
+  c = (int)(m & 1u);       if (n >= c) base += 1;
+  return base;
+}
 // in-place: on exit the lower triangle of A (LDS, ld n) holds L with A = L L', dinv[j] = 1 / L[j][j].
 // (not inlined: five call sites per step, and the step loop has to stay inside the instruction cache)
 template <int NMAX>

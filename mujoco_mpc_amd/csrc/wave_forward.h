@@ -1066,6 +1066,8 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
         }
         T = sqrt(T);
         const wreal Dm = d.efc_D[r] / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T;
+        // one reciprocal instead of ~40 divisions per block (differs from the oracle's divisions by a few ulp)
+        const wreal iT = zone == kZoneMiddle ? WL(1.0) / T : WL(0.0), iT2 = iT * iT, iT3 = iT2 * iT;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
 #pragma unroll
@@ -1075,8 +1077,8 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
               if (zone == kZoneBottom) hjk = j == k ? d.efc_D[r + j] : WL(0.0);
               else if (zone == kZoneMiddle) {
                 if (j == 0) hjk = Dm;                                   // (0, 0)
-                else if (k == 0) hjk = -Dm * mu * U[j] / T;             // (j, 0)
-                else hjk = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? WL(1.0) / T : WL(0.0)) - U[j] * U[k] / (T * T * T));
+                else if (k == 0) hjk = -Dm * mu * U[j] * iT;            // (j, 0)
+                else hjk = Dm * mu * mu * U[j] * U[k] * iT2 - Dm * NT * mu * ((j == k ? iT : WL(0.0)) - U[j] * U[k] * iT3);
                 hjk *= sc[j] * sc[k];
               }
               Hs[j * (j + 1) / 2 + k] = hjk;
@@ -1118,7 +1120,8 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
         else if (t != kEfcConeRow && zone == kZoneBottom) { my_kind = 1; my_mask = t == kEfcTendon ? m.tendon_dofmask[id] : d.con[id].dofmask; my_D = d.efc_D[lane]; }
       }
     }
-    const unsigned long long active_rows = __ballot(my_kind != 0);
+    const unsigned long long simple_rows = __ballot(my_kind == 1), cone_rows = __ballot(my_kind == 2);
+    if (simple_rows)  // (nothing to add on a step whose only active rows are cones and diagonal rows)
     for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
       // e -> (a >= b)
       int a = (int)((sqrt(WL(8.0) * e + WL(1.0)) - WL(1.0)) * WL(0.5));
@@ -1127,39 +1130,51 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
       const int b = e - a * (a + 1) / 2;
       const unsigned need = (1u << a) | (1u << b);
       wreal h = d.H[a * nv + b];
-      for (unsigned long long todo = active_rows; todo; todo &= todo - 1) {  // rows with something to add, scalar loop
+      for (unsigned long long todo = simple_rows; todo; todo &= todo - 1) {  // active simple rows, scalar loop
         const int r = __ffsll((long long)todo) - 1;
-        const int kind = __builtin_amdgcn_readlane(my_kind, r);  // wave-uniform
         const unsigned mask = (unsigned)__builtin_amdgcn_readlane((int)my_mask, r);
-        if (kind == 1) {
-          const wreal D = wbcast(my_D, r);
-          if ((mask & need) == need) h += D * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
-          continue;
-        }
-        const int ci = __builtin_amdgcn_readlane(my_id, r);
-        const int dim = __builtin_amdgcn_readlane(my_dim, r);
-        if ((mask & need) == need) {
-          {
-            const wreal* Hs = d.coneH + 21 * ci;
-            wreal Ja[6], Jb[6], Hl[21];  // fully unrolled with guards: static indices keep these in registers
-#pragma unroll
-            for (int j = 0; j < 6; j++) { Ja[j] = j < dim ? d.efc_J[(r + j) * nv + a] : WL(0.0); Jb[j] = j < dim ? d.efc_J[(r + j) * nv + b] : WL(0.0); }
-#pragma unroll
-            for (int e = 0; e < 21; e++) Hl[e] = e < dim * (dim + 1) / 2 ? Hs[e] : WL(0.0);
-#pragma unroll
-            for (int j = 0; j < 6; j++) {  // row j of the symmetric block from its packed lower triangle
-              wreal s = 0;
-#pragma unroll
-              for (int k = 0; k < 6; k++) s += Hl[j >= k ? j * (j + 1) / 2 + k : k * (k + 1) / 2 + j] * Jb[k];
-              h += Ja[j] * s;
-            }
-          }
-        }
+        const wreal D = wbcast(my_D, r);
+        if ((mask & need) == need) h += D * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
       }
       d.H[a * nv + b] = h;
       d.H[b * nv + a] = h;
     }
     WSYNC();
+    // elliptic cones, one at a time (in row order): the cone's block J_c' Hc J_c only touches the nd <= ~15 dofs of its chains,
+    // so one lane per entry of that nd x nd triangle adds its contribution into H. (The entry-major loop above left lanes
+    // holding trunk entries with one update per cone while most other lanes idled.)
+    for (unsigned long long todo = cone_rows; todo; todo &= todo - 1) {
+      const int r = __ffsll((long long)todo) - 1;
+      const unsigned mask = (unsigned)__builtin_amdgcn_readlane((int)my_mask, r);
+      const int ci = __builtin_amdgcn_readlane(my_id, r);
+      const int dim = __builtin_amdgcn_readlane(my_dim, r);
+      const int nd = __popc(mask);
+      for (int e = lane; e < nd * (nd + 1) / 2; e += 64) {
+        int ia = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+        while ((ia + 1) * (ia + 2) / 2 <= e) ia++;
+        while (ia * (ia + 1) / 2 > e) ia--;
+        const int ib = e - ia * (ia + 1) / 2;
+        const int a = w_nth_bit(mask, ia), b = w_nth_bit(mask, ib);  // a >= b
+        const wreal* Hs = d.coneH + 21 * ci;
+        wreal Ja[6], Jb[6], Hl[21];  // fully unrolled with guards: static indices keep these in registers
+#pragma unroll
+        for (int j = 0; j < 6; j++) { Ja[j] = j < dim ? d.efc_J[(r + j) * nv + a] : WL(0.0); Jb[j] = j < dim ? d.efc_J[(r + j) * nv + b] : WL(0.0); }
+#pragma unroll
+        for (int q = 0; q < 21; q++) Hl[q] = q < dim * (dim + 1) / 2 ? Hs[q] : WL(0.0);
+        wreal h = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {  // row j of the symmetric block from its packed lower triangle
+          wreal sj = 0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) sj += Hl[j >= k ? j * (j + 1) / 2 + k : k * (k + 1) / 2 + j] * Jb[k];
+          h += Ja[j] * sj;
+        }
+        const wreal hn = d.H[a * nv + b] + h;
+        d.H[a * nv + b] = hn;
+        d.H[b * nv + a] = hn;
+      }
+      WSYNC();
+    }
     if (stamp && lane == 0 && iter == 0) stamp[22] = (long long)__builtin_readcyclecounter();
     WACC(34);
     if (!wave_chol<NMAX>(d.H, d.dinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
