@@ -1027,7 +1027,9 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     }
   }
   const wreal scale = WL(1.0) / (m.meaninertia * (nv > 1 ? nv : 1));
-  bool polish = false;
+  bool polish = false, factor_valid = false, refresh = true;
+  const int my_type = lane < ne ? d.efc_type[lane] : -1;
+  int my_zone_prev = -2;
   long long tacc = 0;
 #define WACC(k) do { if (stamp && lane == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); stamp[k] += now_ - tacc; tacc = now_; } } while (0)
   for (int iter = 0; iter < m.solver_iterations; iter++) {
@@ -1049,6 +1051,16 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     if (gnorm == 0) break;
     if (stamp && lane == 0 && iter == 0) stamp[21] = (long long)__builtin_readcyclecounter();
     WACC(32);
+    // H = M + J' (d2s) J depends on the rows' zones only -- and on jar for a cone in its middle (sliding) zone. When no row
+    // changed zone since the last factorisation and no cone slides, the factor still in d.H is bit for bit what a
+    // recomputation would give (the oracle recomputes): reuse it. Typical for the last iterations of a solve.
+    {
+      const int zn = (lane < ne && my_type != kEfcConeRow) ? d.efc_zone[lane] : -1;
+      const bool moved = zn != my_zone_prev || (my_type == kEfcElliptic && zn == kZoneMiddle);
+      my_zone_prev = zn;
+      refresh = !factor_valid || __any(moved);
+    }
+    if (refresh) {
     // cone Hessian blocks (one lane per contact), then H = M + J' (d2s) J over the lower triangle
     if (lane < d.counters[0]) {
       const WaveContact& c = d.con[lane];
@@ -1178,6 +1190,8 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     if (stamp && lane == 0 && iter == 0) stamp[22] = (long long)__builtin_readcyclecounter();
     WACC(34);
     if (!wave_chol<NMAX>(d.H, d.dinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
+    factor_valid = true;
+    }  // refresh
     wave_chol_solve<NMAX>(d.search, d.H, d.dinv, nv, lane);
     if (stamp && lane == 0 && iter == 0) stamp[23] = (long long)__builtin_readcyclecounter();
     WACC(35);
