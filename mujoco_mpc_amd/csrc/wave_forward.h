@@ -1252,7 +1252,10 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     WACC(38);
     if (stamp && lane == 0) stamp[20] = iter + 1;
     if (polish) break;
-    if (scale * improvement < m.solver_tolerance || scale * gnorm < m.solver_tolerance) polish = true;
+    // float: stop where MuJoCo stops (the extra polishing iteration only serves the 1e-9 agreement of the fp64 paths), with the
+    // tolerance floored at what float resolves of a cost of this size
+    const wreal tol = sizeof(wreal) == 4 ? fmax((wreal)m.solver_tolerance, WL(1e-7)) : (wreal)m.solver_tolerance;
+    if (scale * improvement < tol || scale * gnorm < tol) { if (sizeof(wreal) == 4) break; polish = true; }
   }
   if (lane < nv) {
     wreal s = 0;
