@@ -23,7 +23,7 @@ NOISE_SAMPLING, NOISE_CROSS_ENTROPY = 0, 1
 EXPORTS = [
     "mjpcx_create", "mjpcx_destroy", "mjpcx_create_error", "mjpcx_error_string", "mjpcx_last_error",
     "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_set_residual_state", "mjpcx_rollout_splines",
-    "mjpcx_rollout_noise", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
+    "mjpcx_rollout_noise", "mjpcx_rollout_splines_noisy", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
     "mjpcx_fetch_spline", "mjpcx_rollout_feedback", "mjpcx_transition_fd", "mjpcx_cost_derivatives",
     "mjpcx_backward_pass", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
     "mjpcx_device_buffer",
@@ -63,6 +63,8 @@ def lib():
         L.mjpcx_set_residual_state.argtypes = [vp, c_i32p, c_f64p]
         L.mjpcx_rollout_splines.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p]
         L.mjpcx_rollout_noise.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.POINTER(MjpcxNoiseSpec)]
+        L.mjpcx_rollout_splines_noisy.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_double, C.c_double,
+                                                  C.c_uint64, C.c_int]
         L.mjpcx_sync.argtypes = [vp]
         L.mjpcx_get_returns.argtypes = [vp, c_f64p, c_i32p]
         L.mjpcx_get_return_at.argtypes = [vp, C.c_int, C.POINTER(C.c_double), c_i32p]
@@ -181,6 +183,17 @@ class Context:
         N = nv.size // (P * self.nu)
         assert nv.size == N * P * self.nu
         self._chk(lib().mjpcx_rollout_splines(self.handle, N, int(horizon), P, int(interp), as_f64p(nt), as_f64p(nv)))
+        self.N, self.H, self.P = N, int(horizon), P
+
+    def rollout_splines_noisy(self, horizon, interp, node_times, node_values, xfrc_std, xfrc_rate, seed=0, candidate_offset=0):
+        """Trajectory::NoisyRollout for every candidate spline (Ornstein-Uhlenbeck xfrc_applied noise)."""
+        nt = _f(node_times)
+        nv = _f(node_values)
+        P = nt.size
+        N = nv.size // (P * self.nu)
+        assert nv.size == N * P * self.nu
+        self._chk(lib().mjpcx_rollout_splines_noisy(self.handle, N, int(horizon), P, int(interp), as_f64p(nt), as_f64p(nv),
+                                                    float(xfrc_std), float(xfrc_rate), int(seed), int(candidate_offset)))
         self.N, self.H, self.P = N, int(horizon), P
 
     def rollout_noise(self, num_candidates, horizon, interp, node_times, nominal, noise_spec):

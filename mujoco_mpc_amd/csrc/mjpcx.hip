@@ -320,7 +320,8 @@ struct mjpcx_ctx {
   // rollout buffers
   DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out, d_simt, d_wblob;
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
-  bool traj_candidate_major = false;  // layout of the last rollout's Trajectory buffers (true: wavefront-per-candidate kernels)
+  bool traj_candidate_major = false;
+  double xfrc_std = 0, xfrc_rate = 1; uint64_t xfrc_seed = 0; int xfrc_offset = 0;  // pending NoisyRollout request (0: plain Rollout)  // layout of the last rollout's Trajectory buffers (true: wavefront-per-candidate kernels)
   int N = 0, H = 0, P = 0;  // shape of the last rollout
   bool have_rollout = false;
   // wavefront-per-candidate family
@@ -546,6 +547,13 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
   a.states = (T*)c->d_states.p; a.actions = (T*)c->d_actions.p; a.times = (T*)c->d_times.p;
   a.residual = (T*)c->d_residual.p; a.costs = (T*)c->d_costs.p; a.trace = (T*)c->d_trace.p;
   a.total_return = (double*)c->d_ret.p; a.failure = (int*)c->d_fail.p;
+  a.xfrc_decay = 0; a.xfrc_scale = 0; a.xfrc_seed = 0;
+  if (c->wave && c->xfrc_std > 0) {  // Ornstein-Uhlenbeck in discrete time (trajectory.cc:149-150), at the planning timestep
+    a.xfrc_decay = std::exp(-c->wh.m.timestep / c->xfrc_rate);
+    a.xfrc_scale = c->xfrc_std * std::sqrt(1 - a.xfrc_decay * a.xfrc_decay);
+    a.xfrc_seed = c->xfrc_seed;
+    if (a.noise.mode < 0) a.noise.candidate_offset = c->xfrc_offset;
+  }
 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing) {
@@ -588,7 +596,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
       }
       const WaveModel& wm = c->wh.m;
-      const size_t lds_state = (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false) + 15) & ~(size_t)15;
+      const size_t lds_state = (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
       const size_t lds = lds_state;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
       auto kern = wm.nv <= 20 ? w64::rollout_wave_kernel<20> : w64::rollout_wave_kernel<32>;
@@ -614,7 +622,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
     }
     const WaveModelT<float>& wm = c->wh.m32;
-    const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false) + 15) & ~(size_t)15;
+    const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
     auto kern = wm.nv <= 20 ? w32::rollout_wave_kernel<20> : w32::rollout_wave_kernel<32>;
     le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -883,6 +891,20 @@ int mjpcx_rollout_splines(mjpcx_ctx* c, int N, int H, int P, int interp, const d
   if (!node_values) return fail(c, MJPCX_EINVAL, "null node_values");
   return c->precision == 64 ? do_rollout<double>(c, N, H, P, interp, node_times, node_values, nullptr, nullptr)
                             : do_rollout<float>(c, N, H, P, interp, node_times, node_values, nullptr, nullptr);
+}
+
+int mjpcx_rollout_splines_noisy(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node_times, const double* node_values,
+                                double xfrc_std, double xfrc_rate, uint64_t seed, int candidate_offset) {
+  int rc = check_rollout_args(c, N, H, P, interp, node_times);
+  if (rc != MJPCX_OK) return rc;
+  if (!node_values) return fail(c, MJPCX_EINVAL, "null node_values");
+  if (!(xfrc_std >= 0) || !(xfrc_rate > 0)) return fail(c, MJPCX_EINVAL, "xfrc_std must be >= 0 and xfrc_rate > 0");
+  if (!c->wave) return fail(c, MJPCX_EUNSUPPORTED, "xfrc_applied noise is implemented in the wavefront-per-candidate kernels only");
+  c->xfrc_std = xfrc_std; c->xfrc_rate = xfrc_rate; c->xfrc_seed = seed; c->xfrc_offset = candidate_offset;
+  rc = c->precision == 64 ? do_rollout<double>(c, N, H, P, interp, node_times, node_values, nullptr, nullptr)
+                          : do_rollout<float>(c, N, H, P, interp, node_times, node_values, nullptr, nullptr);
+  c->xfrc_std = 0;
+  return rc;
 }
 
 int mjpcx_rollout_noise(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node_times,

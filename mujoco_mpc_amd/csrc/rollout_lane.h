@@ -119,7 +119,10 @@ struct RolloutArgs {
   T *states, *actions, *times, *residual, *costs, *trace;
   double* total_return;
   int* failure;
-  int lds_state_bytes, blob_doubles;  // wave kernel: LDS offset of the staged model, size of the plan blob
+  // Trajectory::NoisyRollout (wavefront-per-candidate kernels): Ornstein-Uhlenbeck xfrc_applied noise, decay = exp(-dt / rate),
+  // scale = std sqrt(1 - decay^2); scale = 0: plain Rollout. Normals: Philox keyed on (seed, global candidate, step, entry).
+  double xfrc_decay, xfrc_scale;
+  uint64_t xfrc_seed;
 };
 
 // weighted sum of norms over the (compile-time) term partition of the residual

@@ -44,6 +44,7 @@ struct WaveData {
   WaveContact* con;
   int* counters;  // [0] ncon [1] nefc [2] warning
   wreal* scal;   // scratch scalars
+  wreal* xfrc;   // 6 nbody: force, torque at each body's centre of mass (mjData.xfrc_applied); nullptr outside NoisyRollout
 };
 
 // Sum over the 64 lanes, same value returned in every lane. DPP row shifts / row broadcasts (6 steps of two 32-bit DPP

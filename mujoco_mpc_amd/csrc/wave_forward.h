@@ -293,8 +293,25 @@ __device__ __forceinline__ void wf_smooth_forces(const WModel& m, WaveData& d, i
     for (int i = 0; i < nu; i++) d.qfrc_actuator[m.jnt_dofadr[m.actuator_trnid[i]]] += m.actuator_gear[i] * d.actuator_force[i];
   WSYNC();
   if (lane < nv) {
-    d.qfrc_smooth[lane] = d.qfrc_passive[lane] - d.qfrc_bias[lane] + d.qfrc_actuator[lane];
-    d.qacc_smooth[lane] = d.qfrc_smooth[lane];
+    wreal q = d.qfrc_passive[lane] - d.qfrc_bias[lane] + d.qfrc_actuator[lane];
+    if (d.xfrc) {
+      // mj_xfrcAccumulate: Cartesian force / torque at the centre of mass of every body below this dof (oracle
+      // o_xfrc_accumulate; bodies in ascending order)
+      const wreal* c = d.cdof + 6 * lane;
+      unsigned long long mask = m.body_subtree_mask[m.dof_bodyid[lane]];
+      while (mask) {
+        const int b = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const wreal* f = d.xfrc + 6 * b;
+        const wreal* com = d.subtree_com + 3 * m.body_rootid[b];
+        const wreal off[3] = {d.xipos[3 * b] - com[0], d.xipos[3 * b + 1] - com[1], d.xipos[3 * b + 2] - com[2]};
+        wreal tq[3];
+        cr3(tq, off, f);
+        q += c[0] * (tq[0] + f[3]) + c[1] * (tq[1] + f[4]) + c[2] * (tq[2] + f[5]) + c[3] * f[0] + c[4] * f[1] + c[5] * f[2];
+      }
+    }
+    d.qfrc_smooth[lane] = q;
+    d.qacc_smooth[lane] = q;
   }
   WSYNC();
 }

@@ -6,7 +6,8 @@
 namespace mjpcx { namespace WAVE_NS {
 
 // LDS footprint of one candidate in elements of the working type (ints and the contact structs are rounded up to it)
-__host__ __device__ inline size_t wave_lds_elems(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P, int cone = 1, bool nodes_in_lds = true) {
+__host__ __device__ inline size_t wave_lds_elems(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P, int cone = 1, bool nodes_in_lds = true,
+                                                 bool xfrc = false) {
   size_t n = 0;
   n += nq + nv + nu;                                   // qpos qvel ctrl
   n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 3 * nsite;  // kinematics (xanchor / xaxis alias efc_J)
@@ -19,12 +20,13 @@ __host__ __device__ inline size_t wave_lds_elems(int nq, int nv, int nu, int nbo
   n += (sizeof(WaveContact) * kWaveMaxCon + sizeof(wreal) - 1) / sizeof(wreal) + 1;
   n += 4 * sizeof(int) / sizeof(wreal) + 1;           // counters
   n += (nodes_in_lds ? (size_t)P * nu : 0) + P;        // spline nodes (the rollout kernel reads them from HBM / L2) + node times
+  n += xfrc ? 6 * nbody : 0;                          // xfrc_applied (NoisyRollout only)
   return n + 4;
 }
 
 // the LDS layout of one candidate's mjData (shared by the rollout, feedback-rollout and finite-difference kernels)
 __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WModel& m, const WTask& tk, int P, wreal*& lnodes,
-                                               wreal*& ltimes, bool nodes_in_lds = true) {
+                                               wreal*& ltimes, bool nodes_in_lds = true, bool xfrc = false) {
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
   wreal* p = reinterpret_cast<wreal*>(smem_raw);
   auto take = [&](size_t n) { wreal* q = p; p += n; return q; };
@@ -53,6 +55,7 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WM
   d.counters = reinterpret_cast<int*>(take(4 * sizeof(int) / sizeof(wreal) + 1));
   lnodes = nodes_in_lds ? take((size_t)P * nu) : nullptr;  // [P][nu]
   ltimes = take(P);
+  d.xfrc = xfrc ? take(6 * nb) : nullptr;
 
   return d;
 }
@@ -69,7 +72,8 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
   const size_t N = (size_t)a.N;
   // ---- LDS carve
   wreal* lnodes; wreal* ltimes;
-  WaveData d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes, /*nodes_in_lds=*/false);
+  const bool noisy = a.xfrc_scale > 0;
+  WaveData d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes, /*nodes_in_lds=*/false, noisy);
   // The candidate's spline nodes stay in a.nodes ([node][actuator][candidate], HBM / L2): at most four of them per
   // actuator are read per step; volatile reads, because other lanes of this wavefront wrote them.
   const volatile wreal* gnodes = a.nodes + cand;
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
   for (int i = lane; i < nv; i += 64) d.qvel[i] = tk.blob[nq + i];
   if (lane < nu) d.ctrl[lane] = 0;
   if (lane < 4) d.counters[lane] = 0;
+  if (noisy) for (int i = lane; i < 6 * nb; i += 64) d.xfrc[i] = 0;  // (the reference inherits the pooled mjData's forces)
   wreal time = tk.blob[tk.off_time];
   WSYNC();
 
@@ -162,6 +167,16 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
       // mj_checkPos / mj_checkVel
       for (int i = lane; i < nq; i += 64) bad |= is_bad(d.qpos[i]);
       for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qvel[i]);
+    }
+    if (noisy && !last) {
+      // Trajectory::NoisyRollout (trajectory.cc:147-155): xfrc_applied = decay * xfrc_applied + N(0, scale) on every body entry
+      const int gi = a.noise.candidate_offset + cand;
+      for (int j = lane; j < 3 * nb; j += 64) {
+        double z[2];
+        gaussian_pair(a.xfrc_seed, (uint32_t)gi, (uint32_t)(t * 3 * m.nbody_model + j), 0x58465243u, z);
+        d.xfrc[2 * j] = (wreal)a.xfrc_decay * d.xfrc[2 * j] + (wreal)(a.xfrc_scale * z[0]);
+        d.xfrc[2 * j + 1] = (wreal)a.xfrc_decay * d.xfrc[2 * j + 1] + (wreal)(a.xfrc_scale * z[1]);
+      }
     }
     WSYNC();
     // ================= mj_forward

@@ -55,6 +55,7 @@ struct WaveModelT {
   const int* static_geom;                       // collidable geoms on bodies without dofs (world, mocap), model order
   const int* dynamic_geom;                      // collidable geoms on moving bodies, model order
   int nstatic_geom, ndynamic_geom;
+  int nbody_model;                              // nbody of the model (nbody above may exclude inert trailing bodies)
   const int *pair_g1, *pair_g2;                 // moving-geom pairs that pass MuJoCo's body filters (oracle: bake_pairs)
   int npair;
   int full;                                     // 1: rows beyond joint limits can occur (Newton path of the oracle)
@@ -299,6 +300,7 @@ struct WaveHost {
     m.base = (const unsigned char*)dev;
     m.bytes = (int)host.size();
     m.nbody = nb_live; m.nsite = ns_live;  // device ranges (the arrays keep the model's sizes)
+    m.nbody_model = nb;
     // blob layout
     int o = 0;
     auto seg = [&](int n) { int at = o; o += n; return at; };

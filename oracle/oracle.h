@@ -72,6 +72,7 @@ void o_step(OData* d);              /* mj_step    */
 void o_forward_task(OData* d, const mjpcx_task* task, double* residual);
 void o_step_task(OData* d, const mjpcx_task* task, double* residual);
 const double* odata_site_xpos(const OData* d);
+double* odata_xfrc_applied(OData* d); /* 6 nbody: force, torque per body (mjData.xfrc_applied) */
 const double* odata_trace_point(const OData* d, int id);
 int odata_warning(const OData* d);  /* !=0: BADQPOS/BADQVEL/BADQACC/BADCTRL seen */
 /* introspection for tests: name in {"qpos","qvel","qacc","qacc_smooth","M",
@@ -113,6 +114,14 @@ int orollout_batch(const mjpcx_model* m, const mjpcx_task* task, const double* s
                    double time, const double* mocap, const double* userdata, int N, int H,
                    int P, int interp, const double* node_times, const double* node_values,
                    int num_threads, OBatchOut* out);
+/* Trajectory::NoisyRollout (trajectory.cc:100-210) for N candidate splines: Ornstein-Uhlenbeck xfrc_applied noise
+ * (rate = exp(-dt / xfrc_rate), scale = xfrc_std sqrt(1 - rate^2)), counter-based normals keyed on
+ * (seed, candidate_offset + i, step, entry) instead of the reference's unseeded absl::BitGen */
+int orollout_batch_noisy(const mjpcx_model* m, const mjpcx_task* task, const double* state,
+                         double time, const double* mocap, const double* userdata, int N, int H,
+                         int P, int interp, const double* node_times, const double* node_values,
+                         double xfrc_std, double xfrc_rate, uint64_t seed, int candidate_offset,
+                         int num_threads, OBatchOut* out);
 
 /* ---------------- iLQG derivatives and feedback rollouts (oracle/ilqg.c) ---------------- */
 /* StateDiff (mjpc/utilities.cc:543-553): (s2 - s1) / h in the tangent space, 2 nv entries */

@@ -46,6 +46,7 @@ struct OData {
   int nq, nv, nu, nbody, njnt, nsite;
   double time;
   double *qpos, *qvel, *ctrl, *mocap_pos, *mocap_quat, *userdata;
+  double* xfrc_applied; /* 6 nbody: Cartesian force, torque at each body's centre of mass (mjData.xfrc_applied) */
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis;
   double *site_xpos, *site_xmat, *subtree_com, *subtree_mass;
   double *cinert, *crb, *cdof, *cdof_dot, *cvel, *cacc, *cfrc;
@@ -215,6 +216,7 @@ OData* odata_new(const mjpcx_model* m) {
   d->scratch_jac = dalloc(12 * nv); d->nw_jar = dalloc(OMAXEFC); d->nw_jv = dalloc(OMAXEFC);
   d->nw_grad = dalloc(nv); d->nw_search = dalloc(nv); d->nw_Ma = dalloc(nv); d->nw_H = dalloc(nv * nv); d->nw_L = dalloc(nv * nv);
   d->qacc_warmstart = dalloc(nv); d->have_warm = 0;
+  d->xfrc_applied = dalloc(6 * nb);
   d->full = 0;
   for (int i = 0; i < nv; i++) if (m->dof_frictionloss[i] > 0 && !(m->disableflags & MJPCX_DSBL_FRICTIONLOSS)) d->full = 1;
   int nstatic = 0, ndynamic = 0;
@@ -247,7 +249,8 @@ void odata_free(OData* d) {
                   &d->qfrc_passive, &d->qfrc_bias, &d->qfrc_actuator, &d->qfrc_smooth,
                   &d->qacc_smooth, &d->qfrc_constraint, &d->qacc, &d->actuator_force, &d->efc_J,
                   &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A, &d->geom_xpos, &d->geom_xmat, &d->scratch_jac,
-                  &d->nw_jar, &d->nw_jv, &d->nw_grad, &d->nw_search, &d->nw_Ma, &d->nw_H, &d->nw_L, &d->qacc_warmstart};
+                  &d->nw_jar, &d->nw_jv, &d->nw_grad, &d->nw_search, &d->nw_Ma, &d->nw_H, &d->nw_L, &d->qacc_warmstart,
+                  &d->xfrc_applied};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
   free(d->geom_static); free(d->pair_g1); free(d->pair_g2);
   free(d);
@@ -264,6 +267,7 @@ void odata_set_state(OData* d, const double* state, double time, const double* m
   }
   if (userdata && m->nuserdata) memcpy(d->userdata, userdata, sizeof(double) * m->nuserdata);
   d->warning = 0;
+  memset(d->xfrc_applied, 0, sizeof(double) * 6 * m->nbody); /* likewise: the reference inherits the pooled mjData's forces */
   d->have_warm = 0; /* a rollout starts without a warm start (the reference inherits whatever the pooled mjData held) */
 }
 void odata_set_ctrl(OData* d, const double* ctrl) { memcpy(d->ctrl, ctrl, sizeof(double) * d->nu); }
@@ -674,6 +678,28 @@ static void o_constraint(OData* d) {
 
 #include "contact.inc"
 
+/* mj_xfrcAccumulate: Cartesian force / torque applied at each body's centre of mass -> generalized forces (mj_applyFT).
+ * cdof is [angular, linear] about the subtree centre of mass of the root body. */
+static void o_xfrc_accumulate(const OData* d, double* qfrc) {
+  const mjpcx_model* m = d->m;
+  for (int b = 1; b < m->nbody; b++) {
+    const double* f = d->xfrc_applied + 6 * b;
+    if (f[0] == 0 && f[1] == 0 && f[2] == 0 && f[3] == 0 && f[4] == 0 && f[5] == 0) continue;
+    int body = b;
+    while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+    if (body <= 0) continue;
+    const double* com = d->subtree_com + 3 * m->body_rootid[b];
+    double off[3], tq[3];
+    for (int k = 0; k < 3; k++) off[k] = d->xipos[3 * b + k] - com[k];
+    cross3(tq, off, f); /* torque of the force about the reference point */
+    for (int k = 0; k < 3; k++) tq[k] += f[3 + k];
+    for (int i = m->body_dofadr[body] + m->body_dofnum[body] - 1; i >= 0; i = m->dof_parentid[i]) {
+      const double* c = d->cdof + 6 * i;
+      qfrc[i] += c[0] * tq[0] + c[1] * tq[1] + c[2] * tq[2] + c[3] * f[0] + c[4] * f[1] + c[5] * f[2];
+    }
+  }
+}
+
 void o_forward(OData* d) {
   const mjpcx_model* m = d->m;
   int nv = m->nv;
@@ -690,6 +716,7 @@ void o_forward(OData* d) {
   o_actuation(d);
   for (int i = 0; i < nv; i++)
     d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+  o_xfrc_accumulate(d, d->qfrc_smooth);
   chol_solve(d->qacc_smooth, d->L, d->qfrc_smooth, nv);
   if (d->full) o_constraint_newton(d); else o_constraint(d);
 }
@@ -755,6 +782,7 @@ void o_step_task(OData* d, const mjpcx_task* task, double* r) {
 }
 void o_step(OData* d) { o_step_task(d, NULL, NULL); }
 const double* odata_site_xpos(const OData* d) { return d->site_xpos; }
+double* odata_xfrc_applied(OData* d) { return d->xfrc_applied; }
 /* GetTraces (utilities.cc:268-286): framepos of a site (id >= 0) or of a body frame (id = -1 - body) */
 const double* odata_trace_point(const OData* d, int id) { return id >= 0 ? d->site_xpos + 3 * id : d->xpos + 3 * (-1 - id); }
 

@@ -93,6 +93,11 @@ def lib():
                                   c_f64p, C.c_int, c_f64p, c_f64p, C.c_double, C.c_double, C.POINTER(MjpcxTrajView)]
         L.orollout_batch.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, c_f64p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_int, C.POINTER(OBatchOut)]
+        L.odata_xfrc_applied.restype = c_f64p
+        L.odata_xfrc_applied.argtypes = [C.c_void_p]
+        L.orollout_batch_noisy.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, c_f64p,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_double, C.c_double,
+                                           C.c_uint64, C.c_int, C.c_int, C.POINTER(OBatchOut)]
         L.otransition_fd.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), C.c_void_p, c_f64p, C.c_double, c_f64p,
                                      C.c_double, C.c_int, c_f64p, c_f64p, c_f64p, c_f64p]
         L.ocost_derivatives.argtypes = [C.POINTER(MjpcxTask), C.c_int, C.c_int, C.c_int] + [c_f64p] * 8
@@ -280,8 +285,9 @@ def rollout_pd(pm, pt, physics, state, time, mocap, horizon, pos_goal, vel_goal,
     return tr
 
 
-def rollout_batch(pm, pt, state, time, mocap, N, H, P, interp, node_times, node_values, num_threads=1, full=True):
-    """N x Trajectory::Rollout over a worker pool. Returns dict of arrays (candidate-major)."""
+def rollout_batch(pm, pt, state, time, mocap, N, H, P, interp, node_times, node_values, num_threads=1, full=True,
+                  xfrc_std=0.0, xfrc_rate=1.0, seed=0, candidate_offset=0):
+    """N x Trajectory::Rollout (NoisyRollout when xfrc_std > 0) over a worker pool. Returns dict of arrays (candidate-major)."""
     m = pm.struct
     ds, nu, nr, ntr = m.nq + m.nv + m.na, m.nu, pt.struct.num_residual, pt.struct.num_trace
     out = dict(total_return=np.zeros(N), failure=np.zeros(N, np.int32))
@@ -295,8 +301,9 @@ def rollout_batch(pm, pt, state, time, mocap, N, H, P, interp, node_times, node_
     nt, nvv = _f(node_times), _f(node_values)
     assert nvv.size == N * P * nu
     mc = None if mocap is None else as_f64p(_f(mocap))
-    lib().orollout_batch(pm.ptr, pt.ptr, as_f64p(_f(state)), float(time), mc, None, N, H, P, interp,
-                         as_f64p(nt), as_f64p(nvv), int(num_threads), C.byref(o))
+    lib().orollout_batch_noisy(pm.ptr, pt.ptr, as_f64p(_f(state)), float(time), mc, None, N, H, P, interp,
+                               as_f64p(nt), as_f64p(nvv), float(xfrc_std), float(xfrc_rate), int(seed), int(candidate_offset),
+                               int(num_threads), C.byref(o))
     return out
 
 

@@ -3,6 +3,7 @@
  * (mjpc/planners/sampling/policy.cc:52-59) as the policy, and of the ThreadPool
  * fan-out of SamplingPlanner::Rollouts (mjpc/planners/sampling/planner.cc:355-393).
  * TEST INFRASTRUCTURE ONLY (see oracle.h). */
+#include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,7 +16,13 @@ typedef void (*policy_fn)(void* user, double* action, const double* state, doubl
 /* trajectory.cc:100-210 */
 static int rollout_core(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state,
                         double time, const double* mocap, const double* userdata, int horizon,
-                        policy_fn policy, void* user, mjpcx_traj_view* out) {
+                        void (*policy)(void*, double*, const double*, double), void* user, mjpcx_traj_view* out);
+#define OXFRC_STREAM 0x58465243u /* "XFRC": Philox stream of the force noise */
+typedef struct { double std, rate; uint64_t seed; int candidate; } XfrcNoise;
+
+static int rollout_core_noisy(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state,
+                              double time, const double* mocap, const double* userdata, int horizon,
+                              policy_fn policy, void* user, mjpcx_traj_view* out, const XfrcNoise* noise) {
   int nq = m->nq, nv = m->nv, nu = m->nu, nr = task->num_residual, ntr = task->num_trace;
   int ds = nq + nv + m->na;
   double* r = (double*)malloc(sizeof(double) * (nr + nu + ds + 8));
@@ -34,6 +41,16 @@ static int rollout_core(const mjpcx_model* m, const mjpcx_task* task, OData* d, 
     policy(user, act, st, cur_time);
     if (out->actions) memcpy(out->actions + t * nu, act, sizeof(double) * nu);
     odata_set_ctrl(d, act);
+    if (noise && noise->std > 0) { /* Ornstein-Uhlenbeck force / torque noise on every body (trajectory.cc:147-155) */
+      double rate = exp(-m->timestep / noise->rate), scale = noise->std * sqrt(1 - rate * rate);
+      double* x = odata_xfrc_applied(d);
+      for (int j = 0; j < 6 * m->nbody; j += 2) {
+        double z[2];
+        ogaussian_pair(noise->seed, (uint32_t)noise->candidate, (uint32_t)(t * 3 * m->nbody + j / 2), OXFRC_STREAM, z);
+        x[j] = rate * x[j] + scale * z[0];
+        x[j + 1] = rate * x[j + 1] + scale * z[1];
+      }
+    }
     /* mj_step; the residual is evaluated inside its forward pass by the
      * mjSTAGE_ACC sensor callback (app.cc:110-126): it sees the pre-integration
      * state, which pairs residual[t] with states[t] (rollout_test.cc:140-145) */
@@ -94,6 +111,12 @@ int orollout_spline(const mjpcx_model* m, const mjpcx_task* task, OData* d, cons
   return rollout_core(m, task, d, state, time, mocap, userdata, horizon, spline_policy, &p, out);
 }
 
+static int rollout_core(const mjpcx_model* m, const mjpcx_task* task, OData* d, const double* state,
+                        double time, const double* mocap, const double* userdata, int horizon,
+                        policy_fn policy, void* user, mjpcx_traj_view* out) {
+  return rollout_core_noisy(m, task, d, state, time, mocap, userdata, horizon, policy, user, out, NULL);
+}
+
 /* PD feedback policy of mjpc/test/agent/rollout_test.cc:84-103 */
 typedef struct { const double *pg, *vg; double P, D; } PdPolicy;
 static void pd_policy(void* user, double* action, const double* state, double time) {
@@ -117,6 +140,7 @@ typedef struct {
   int N, H, P, interp;
   OBatchOut* out;
   int next; /* shared work counter = the FIFO queue of one task per candidate */
+  double xfrc_std, xfrc_rate; uint64_t seed; int candidate_offset; /* NoisyRollout (0: plain Rollout) */
 } Batch;
 
 static void* batch_worker(void* arg) {
@@ -142,7 +166,13 @@ static void* batch_worker(void* arg) {
     if (o->residual) v.residual = o->residual + (size_t)i * H * nr;
     if (o->costs) v.costs = o->costs + (size_t)i * H;
     if (o->trace) v.trace = o->trace + (size_t)i * H * 3 * ntr;
-    orollout_spline(m, b->task, d, b->state, b->time, b->mocap, b->userdata, b->H, &sp, &v);
+    if (b->xfrc_std > 0) {
+      XfrcNoise nz = {b->xfrc_std, b->xfrc_rate, b->seed, b->candidate_offset + i};
+      SplinePolicy pol = {&sp, m};
+      rollout_core_noisy(m, b->task, d, b->state, b->time, b->mocap, b->userdata, b->H, spline_policy, &pol, &v, &nz);
+    } else {
+      orollout_spline(m, b->task, d, b->state, b->time, b->mocap, b->userdata, b->H, &sp, &v);
+    }
     o->total_return[i] = v.total_return;
     o->failure[i] = v.failure;
   }
@@ -155,7 +185,16 @@ int orollout_batch(const mjpcx_model* m, const mjpcx_task* task, const double* s
                    const double* mocap, const double* userdata, int N, int H, int P, int interp,
                    const double* node_times, const double* node_values, int num_threads,
                    OBatchOut* out) {
-  Batch b = {m, task, state, mocap, userdata, node_times, node_values, time, N, H, P, interp, out, 0};
+  return orollout_batch_noisy(m, task, state, time, mocap, userdata, N, H, P, interp, node_times, node_values, 0.0, 1.0, 0, 0,
+                              num_threads, out);
+}
+
+int orollout_batch_noisy(const mjpcx_model* m, const mjpcx_task* task, const double* state, double time,
+                         const double* mocap, const double* userdata, int N, int H, int P, int interp,
+                         const double* node_times, const double* node_values, double xfrc_std, double xfrc_rate,
+                         uint64_t seed, int candidate_offset, int num_threads, OBatchOut* out) {
+  Batch b = {m, task, state, mocap, userdata, node_times, node_values, time, N, H, P, interp, out, 0,
+             xfrc_std, xfrc_rate, seed, candidate_offset};
   if (num_threads < 1) num_threads = 1;
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * num_threads);
   for (int t = 0; t < num_threads; t++) pthread_create(&th[t], NULL, batch_worker, &b);

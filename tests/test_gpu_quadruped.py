@@ -276,3 +276,33 @@ def test_maximum_horizon(quad):
     tr = ctx.fetch_trajectory(1)
     assert tr.states.shape == (512, 37) and np.isfinite(tr.states).all() and abs(tr.times[-1] - 5.11) < 1e-9
     ctx.close()
+
+
+@pytest.mark.parametrize("precision,tol", [(64, 1e-7), (32, 2e-3)])
+def test_noisy_rollout_matches_the_oracle(quad, precision, tol):
+    """Trajectory::NoisyRollout (RobustPlanner): Ornstein-Uhlenbeck xfrc_applied noise from the shared counter-based stream;
+    candidates with the SAME spline diverge from each other, and each one tracks the oracle's rollout with the same noise"""
+    home = quad.model.keyframes["home"]["qpos"]
+    state = np.concatenate([home, np.zeros(18)])
+    pm, pt = quad.packed_model(), quad.packed()
+    N, P, H = 6, 3, 30
+    times = np.arange(P) * 0.15
+    nodes = np.tile(home[7:], (N, P, 1))
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, N, H, P, 0, times, nodes, num_threads=4, xfrc_std=0.3, xfrc_rate=0.1,
+                                 seed=11, candidate_offset=5)
+    assert np.abs(ref["states"][0] - ref["states"][1]).max() > 1e-3      # the noise does something
+    ctx = capi.Context(pm, pt, 0, precision)
+    ctx.set_state(state, 0.0, MOCAP)
+    ctx.rollout_splines_noisy(H, 0, times, nodes, 0.3, 0.1, seed=11, candidate_offset=5)
+    ret, fail = ctx.returns()
+    assert not fail.any() and close(ret, ref["total_return"], tol)
+    for c in (0, N - 1):
+        tr = ctx.fetch_trajectory(c)
+        assert close(tr.states, ref["states"][c], 30 * tol), float(np.abs(tr.states - ref["states"][c]).max())
+    # xfrc_std = 0 is the plain rollout
+    ctx.rollout_splines_noisy(H, 0, times, nodes, 0.0, 0.1)
+    r0, _ = ctx.returns()
+    ctx.rollout_splines(H, 0, times, nodes)
+    r1, _ = ctx.returns()
+    assert np.array_equal(r0, r1)
+    ctx.close()

@@ -137,3 +137,23 @@ def test_quadruped_residual_entries():
     assert np.allclose(r[37:39], [0, 0], atol=1e-12)                                     # Yaw: heading goal 0
     assert np.allclose(r[39:42], 0)                                                      # "Angmom" = subtree linvel
     assert pyoracle.cost_value(pt, r) > 0
+
+
+def test_xfrc_applied_accelerates_a_free_body():
+    """mj_xfrcAccumulate: a Cartesian force f at the centre of mass of a free body in zero gravity gives a = f / m and no
+    angular acceleration; a torque about z spins the ball with alpha = tau / I (I = 2/5 m r^2)"""
+    fm, pm, ph = scene([0, 0, 0])
+    q = fm.arrays["qpos0"].copy()
+    q[2] = 1.0; q[9] = 1.0     # both bodies off the floor
+    ph.set_state(q, np.zeros(fm.nv))
+    import ctypes as C
+    x = np.ctypeslib.as_array(pyoracle.lib().odata_xfrc_applied(ph.d), (6 * fm.nbody,))
+    x[:] = 0
+    ball = fm.name2id("body", "ball")
+    x[6 * ball:6 * ball + 3] = [1.0, -2.0, 0.5]
+    x[6 * ball + 5] = 0.02
+    ph.forward()
+    a = ph.get("qacc")
+    assert np.allclose(a[:3], np.array([1.0, -2.0, 0.5]) / 2.0, atol=1e-12)
+    assert np.allclose(a[3:6], [0, 0, 0.02 / (0.4 * 2.0 * 0.01)], atol=1e-10)
+    assert np.allclose(a[6:], 0, atol=1e-12)
