@@ -238,6 +238,12 @@ void GpuSamplingPlanner::ActionFromCandidatePolicy(double* action, int candidate
   p.Action(action, s, t);
 }
 
+void GpuSamplingPlanner::CandidatePlan(int candidate, spline::TimeSpline* out) {
+  SamplingPolicy p;
+  LoadCandidatePlan(trajectory_order[candidate], &p);
+  *out = p.plan;
+}
+
 void GpuSamplingPlanner::CopyCandidateToPolicy(int candidate) {
   SamplingPolicy p;
   LoadCandidatePlan(trajectory_order[candidate], &p);

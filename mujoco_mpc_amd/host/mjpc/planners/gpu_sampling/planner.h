@@ -45,6 +45,9 @@ class GpuSamplingPlanner : public RankedPlanner {
   void ActionFromCandidatePolicy(double* action, int candidate, const double* state, double time) override;
   void CopyCandidateToPolicy(int candidate) override;
 
+  // the spline of ranked candidate `candidate` (what ActionFromCandidatePolicy evaluates): for planners that roll the
+  // candidates out again on the device (GpuRobustPlanner)
+  void CandidatePlan(int candidate, spline::TimeSpline* out);
   void UpdateNominalPolicy(int horizon);
   void Rollouts(int num_trajectory, int horizon);
 

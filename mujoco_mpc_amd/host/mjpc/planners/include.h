@@ -13,7 +13,7 @@ enum PlannerType : int {
   kGradientPlanner,       // not ported (empty slot)
   kILQGPlanner,           // -> GpuILQGPlanner
   kILQSPlanner,           // not ported
-  kRobustPlanner,         // not ported
+  kRobustPlanner,         // -> GpuRobustPlanner(GpuSamplingPlanner)
   kCrossEntropyPlanner,   // -> GpuCrossEntropyPlanner
   kSampleGradientPlanner, // not ported
   kNumPlannerTypes

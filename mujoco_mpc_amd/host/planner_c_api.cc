@@ -8,6 +8,7 @@
 #include "mjpc/planners/gpu_cross_entropy/planner.h"
 #include "mjpc/planners/gpu_ilqg/planner.h"
 #include "mjpc/planners/gpu_sampling/planner.h"
+#include "mjpc/planners/gpu_robust/robust_planner.h"
 #include "mjpc/tasks/tasks.h"
 #include "model_io.h"
 
@@ -19,6 +20,7 @@ struct Handle {
   mjpc::GpuSamplingPlanner* ps = nullptr;       // exactly one of these three is set
   mjpc::GpuCrossEntropyPlanner* ce = nullptr;
   mjpc::GpuILQGPlanner* ilqg = nullptr;
+  mjpc::GpuRobustPlanner* robust = nullptr;     // wraps a GpuSamplingPlanner: `ps` then points at its delegate
   mjpc::State state;
   mjpc::ThreadPool pool{1};
   std::string error;
@@ -51,6 +53,10 @@ void* mjpc_planner_create_kind(const char* kind, const char* blob_path, const ch
     } else if (k == "ilqg") {
       h->ilqg = new mjpc::GpuILQGPlanner(device, precision);
       h->planner.reset(h->ilqg);
+    } else if (k == "robust") {
+      h->robust = new mjpc::GpuRobustPlanner(std::make_unique<mjpc::GpuSamplingPlanner>(device, precision, seed), device, precision, seed);
+      h->planner.reset(h->robust);
+      h->ps = h->robust->delegate();
     } else {
       g_error = "unknown planner kind " + k;
       return nullptr;
@@ -121,6 +127,23 @@ int mjpc_planner_task_transition_state(void* h, double time, int mode, double* q
     d.qpos = qpos; d.qvel = qvel; d.mocap_pos = mocap_pos;
     if (mode >= 0) H->task->mode = mode;
     H->task->Transition(H->storage->model(), &d);
+  });
+}
+// RobustPlanner knobs and the outcome of its last OptimizePolicy (scores: ncandidates mean perturbed returns)
+int mjpc_planner_robust_config(void* h, int ncandidates, int nrepetitions, double xfrc_std, double xfrc_rate) {
+  GUARD(h, {
+    if (!H->robust) throw std::runtime_error("not a robust planner");
+    if (ncandidates > 0) H->robust->ncandidates_ = ncandidates;
+    if (nrepetitions > 0) H->robust->nrepetitions_ = nrepetitions;
+    if (xfrc_std >= 0) H->robust->xfrc_std_ = xfrc_std;
+    if (xfrc_rate > 0) H->robust->xfrc_rate_ = xfrc_rate;
+  });
+}
+int mjpc_planner_robust_result(void* h, int* best_candidate, double* scores, int capacity) {
+  GUARD(h, {
+    if (!H->robust) throw std::runtime_error("not a robust planner");
+    *best_candidate = H->robust->best_candidate;
+    for (int i = 0; i < capacity && i < (int)H->robust->perturbed_score.size(); i++) scores[i] = H->robust->perturbed_score[i];
   });
 }
 int mjpc_planner_task_set_parameter(void* h, int index, double value) {

@@ -48,6 +48,8 @@ def lib():
         L.mjpc_planner_best_trajectory.argtypes = [vp, c_f64p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_double)]
         L.mjpc_planner_task_transition.argtypes = [vp, C.c_double, C.c_int]
         L.mjpc_planner_task_transition_state.argtypes = [vp, C.c_double, C.c_int, c_f64p, c_f64p, c_f64p]
+        L.mjpc_planner_robust_config.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.mjpc_planner_robust_result.argtypes = [vp, C.POINTER(C.c_int), c_f64p, C.c_int]
         L.mjpc_planner_task_set_parameter.argtypes = [vp, C.c_int, C.c_double]
         L.mjpc_planner_destroy.argtypes = [vp]
         L.mjpc_planner_last_error.restype = C.c_char_p
@@ -160,6 +162,15 @@ class HostPlanner:
 
     def task_transition(self, time, mode=-1):
         self._chk(lib().mjpc_planner_task_transition(self.h, float(time), int(mode)))
+
+    def robust_config(self, ncandidates=0, nrepetitions=0, xfrc_std=-1.0, xfrc_rate=0.0):
+        self._chk(lib().mjpc_planner_robust_config(self.h, int(ncandidates), int(nrepetitions), float(xfrc_std), float(xfrc_rate)))
+
+    def robust_result(self, capacity=64):
+        best = C.c_int(-1)
+        scores = np.zeros(capacity)
+        self._chk(lib().mjpc_planner_robust_result(self.h, C.byref(best), as_f64p(scores), capacity))
+        return best.value, scores
 
     def task_transition_state(self, time, mode, qpos, qvel, mocap_pos):
         """Task::Transition for tasks that edit the simulation state (humanoid::Tracking): the arrays are updated in place."""

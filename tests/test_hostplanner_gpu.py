@@ -202,3 +202,39 @@ def test_cross_entropy_two_ranks_on_one_gpu_equal_one_rank():
         np.testing.assert_allclose(a["plan"], b["plan"], rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(a["variance"], b["variance"], rtol=1e-10, atol=1e-16)
         np.testing.assert_allclose(a["improvement"], b["improvement"], rtol=1e-10, atol=1e-14)
+
+
+def test_cpp_robust_planner_on_the_quadruped():
+    """GpuRobustPlanner (robust_planner.cc:90-170): the delegate's best candidates are re-rolled under xfrc_applied noise in
+    one launch; the winner has the lowest mean perturbed return, its spline becomes the policy, and that mean is what the
+    oracle's NoisyRollout gives for the same spline and noise stream."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.task import load_task
+    from oracle import pyoracle
+    t = load_task("QuadrupedFlat")
+    p = HostPlanner(t, seed=2, num_trajectory=64, kind="robust")
+    K, R = 4, 3
+    p.robust_config(ncandidates=K, nrepetitions=R, xfrc_std=0.3, xfrc_rate=0.1)
+    p.task_transition(0.0)
+    t.transition(0.0)
+    H = t.planning_steps()
+    p.reset(H)
+    home = t.model.keyframes["home"]["qpos"]
+    mp = np.array([[0.3, 0, 0.26], [-2.5, 0, 0]]); mq = np.array([[1.0, 0, 0, 0], [1.0, 0, 0, 0]])
+    p.set_state(home, np.zeros(18), 0.0, mocap_pos=mp, mocap_quat=mq)
+    p.optimize_policy(H)
+    best, scores = p.robust_result()
+    assert 0 <= best < K and scores[best] == scores[:K].min() and np.all(scores[:K] > 0)
+    times, values = p.policy()
+    mocap = np.hstack([mp, mq]).reshape(-1)
+    state = np.concatenate([home, np.zeros(18)])
+    from mujoco_mpc_amd import capi
+    ref = pyoracle.rollout_batch(t.packed_model(), t.packed(), state, 0.0, mocap, R, H, len(times), capi.SPLINE_CUBIC, times,  # PS default
+                                 np.tile(values, (R, 1, 1)), num_threads=2, full=False, xfrc_std=0.3, xfrc_rate=0.1, seed=2,
+                                 candidate_offset=best * R)
+    assert not ref["failure"].any()
+    # the reference's running mean over the valid perturbed rollouts = their plain mean
+    assert abs(ref["total_return"].mean() - scores[best]) < 1e-7 * (1 + abs(scores[best]))
+    # a second plan draws fresh noise (the candidate offset advances with the iteration) and still runs
+    p.optimize_policy(H)
+    assert 0 <= p.robust_result()[0] < K
