@@ -39,6 +39,12 @@ __device__ __forceinline__ double dpp_move(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// one 16 x 16 x 4 MFMA step in the working type; accumulator register rg of lane l holds row (l >> 4) + 4 rg (f64) or
+// 4 (l >> 4) + rg (f32) of the tile, column l & 15
+typedef double w_acc4_f64 __attribute__((ext_vector_type(4)));
+typedef float w_acc4_f32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ w_acc4_f64 w_mfma_16x16x4(double a, double b, w_acc4_f64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ w_acc4_f32 w_mfma_16x16x4(float a, float b, w_acc4_f32 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_move(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));

@@ -4,6 +4,8 @@
 namespace mjpcx { namespace WAVE_NS {
 typedef WaveModelT<wreal> WModel;
 typedef WaveTaskT<wreal> WTask;
+typedef wreal w_acc4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int w_mfma_row(int lk, int rg) { return sizeof(wreal) == 8 ? lk + 4 * rg : 4 * lk + rg; }
 
 
 // Single-wavefront workgroups: the ordering point between dependent LDS phases only has to (a) stop the compiler from

@@ -1150,23 +1150,34 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
       }
     }
     const unsigned long long simple_rows = __ballot(my_kind == 1), cone_rows = __ballot(my_kind == 2);
-    if (simple_rows)  // (nothing to add on a step whose only active rows are cones and diagonal rows)
-    for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
-      // e -> (a >= b)
-      int a = (int)((sqrt(WL(8.0) * e + WL(1.0)) - WL(1.0)) * WL(0.5));
-      while ((a + 1) * (a + 2) / 2 <= e) a++;
-      while (a * (a + 1) / 2 > e) a--;
-      const int b = e - a * (a + 1) / 2;
-      const unsigned need = (1u << a) | (1u << b);
-      wreal h = d.H[a * nv + b];
-      for (unsigned long long todo = simple_rows; todo; todo &= todo - 1) {  // active simple rows, scalar loop
-        const int r = __ffsll((long long)todo) - 1;
-        const unsigned mask = (unsigned)__builtin_amdgcn_readlane((int)my_mask, r);
-        const wreal D = wbcast(my_D, r);
-        if ((mask & need) == need) h += D * d.efc_J[r * nv + a] * d.efc_J[r * nv + b];
-      }
-      d.H[a * nv + b] = h;
-      d.H[b * nv + a] = h;
+    if (simple_rows) {  // (nothing to add on a step whose only active rows are cones and diagonal rows)
+      // Simple inequality rows (frictionless contacts, pyramid edges, tendon limits): H += J' diag(s) J with s_r = D_r on the
+      // active rows and 0 elsewhere -- a (nv x ne)(ne x nv) product on the matrix cores, 16 x 16 output tiles, K = 4 rows per
+      // MFMA (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32). A fragment: lane l holds J'[a = tile_i + (l & 15)][r = 4u + (l >> 4)],
+      // B fragment: s_r J[r][b = tile_j + (l & 15)]. The row scales go through LDS (jv is dead until the line search).
+      if (lane < kWaveMaxEfc) d.jv[lane] = my_kind == 1 ? my_D : WL(0.0);
+      WSYNC();
+      const int li = lane & 15, lk = lane >> 4;
+      const int ksteps = (ne + 3) >> 2;
+      for (int ti = 0; ti < nv; ti += 16)
+        for (int tj = 0; tj < nv; tj += 16) {
+          const int ia = ti + li, jb = tj + li;
+          const bool av = ia < nv, bv = jb < nv;
+          w_acc4 acc = {0, 0, 0, 0};
+          for (int u = 0; u < ksteps; u++) {
+            const int r = 4 * u + lk;
+            const bool rv = r < ne;
+            const wreal sr = rv ? d.jv[r] : WL(0.0);
+            const wreal fa = (rv && av) ? d.efc_J[r * nv + ia] : WL(0.0);
+            const wreal fb = (rv && bv) ? sr * d.efc_J[r * nv + jb] : WL(0.0);
+            acc = w_mfma_16x16x4(fa, fb, acc);
+          }
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) {
+            const int ci = ti + w_mfma_row(lk, rg);
+            if (ci < nv && bv) d.H[ci * nv + jb] += acc[rg];
+          }
+        }
     }
     WSYNC();
     // elliptic cones, one at a time (in row order): the cone's block J_c' Hc J_c only touches the nd <= ~15 dofs of its chains,
