@@ -15,7 +15,7 @@ enum PlannerType : int {
   kILQSPlanner,           // not ported
   kRobustPlanner,         // -> GpuRobustPlanner(GpuSamplingPlanner)
   kCrossEntropyPlanner,   // -> GpuCrossEntropyPlanner
-  kSampleGradientPlanner, // not ported
+  kSampleGradientPlanner, // -> GpuSampleGradientPlanner
   kNumPlannerTypes
 };
 extern const char kPlannerNames[];

@@ -1,5 +1,6 @@
 // Subset of mjpc/utilities.{h,cc} on the rollout path.
 #pragma once
+#include <cstdint>
 #include <chrono>
 #include <cmath>
 #include <optional>
@@ -76,6 +77,26 @@ inline void LinearInterpolation(double* output, double x, const double* xs, cons
   if (bounds[0] == bounds[1]) { mju_copy(output, ys + (size_t)dim * bounds[0], dim); return; }
   const double t = (x - xs[bounds[0]]) / (xs[bounds[1]] - xs[bounds[0]]);
   for (int i = 0; i < dim; i++) output[i] = ys[(size_t)dim * bounds[0] + i] * (1.0 - t) + ys[(size_t)dim * bounds[1] + i] * t;
+}
+// Philox4x32-10 + Box-Muller as specified in include/mjpcx.h (the generator the device kernels use for candidate noise):
+// two standard normals for (seed, candidate, pair, iteration). Host planners that need the raw noise (SampleGradient) draw
+// it here instead of from the reference's function-local absl::BitGen.
+inline void HostGaussianPair(std::uint64_t seed, std::uint32_t cand, std::uint32_t pair, std::uint32_t iter, double z[2]) {
+  std::uint32_t c0 = cand, c1 = pair, c2 = iter, c3 = 0u, k0 = (std::uint32_t)seed, k1 = (std::uint32_t)(seed >> 32);
+  for (int r = 0; r < 10; r++) {
+    const std::uint64_t p0 = (std::uint64_t)0xD2511F53u * c0, p1 = (std::uint64_t)0xCD9E8D57u * c2;
+    const std::uint32_t n0 = (std::uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (std::uint32_t)p1, n2 = (std::uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (std::uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  auto u53 = [](std::uint32_t hi, std::uint32_t lo) {
+    const std::uint64_t k = (((std::uint64_t)hi << 32) | lo) >> 11;
+    return ((double)k + 0.5) * (1.0 / 9007199254740992.0);
+  };
+  const double u1 = u53(c0, c1), u2 = u53(c2, c3);
+  const double r = std::sqrt(-2.0 * std::log(u1));
+  z[0] = r * std::cos(6.283185307179586476925286766559 * u2);
+  z[1] = r * std::sin(6.283185307179586476925286766559 * u2);
 }
 // log-spaced values from min_value up to max_value, utilities.cc:819-826
 inline void LogScale(double* values, double max_value, double min_value, int steps) {

@@ -9,7 +9,9 @@
 #include "mjpc/planners/gpu_ilqg/planner.h"
 #include "mjpc/planners/gpu_sampling/planner.h"
 #include "mjpc/planners/gpu_robust/robust_planner.h"
+#include "mjpc/planners/gpu_sample_gradient/planner.h"
 #include "mjpc/tasks/tasks.h"
+#include "mjpc/utilities.h"
 #include "model_io.h"
 
 namespace {
@@ -20,11 +22,12 @@ struct Handle {
   mjpc::GpuSamplingPlanner* ps = nullptr;       // exactly one of these three is set
   mjpc::GpuCrossEntropyPlanner* ce = nullptr;
   mjpc::GpuILQGPlanner* ilqg = nullptr;
-  mjpc::GpuRobustPlanner* robust = nullptr;     // wraps a GpuSamplingPlanner: `ps` then points at its delegate
+  mjpc::GpuRobustPlanner* robust = nullptr;
+  mjpc::GpuSampleGradientPlanner* sg = nullptr;     // wraps a GpuSamplingPlanner: `ps` then points at its delegate
   mjpc::State state;
   mjpc::ThreadPool pool{1};
   std::string error;
-  mjpc::gpu::Context* context() { return ps ? ps->context() : ce ? ce->context() : ilqg->context(); }
+  mjpc::gpu::Context* context() { return ps ? ps->context() : ce ? ce->context() : sg ? sg->context() : ilqg->context(); }
 };
 thread_local std::string g_error;
 }  // namespace
@@ -53,6 +56,9 @@ void* mjpc_planner_create_kind(const char* kind, const char* blob_path, const ch
     } else if (k == "ilqg") {
       h->ilqg = new mjpc::GpuILQGPlanner(device, precision);
       h->planner.reset(h->ilqg);
+    } else if (k == "sample_gradient") {
+      h->sg = new mjpc::GpuSampleGradientPlanner(device, precision, seed);
+      h->planner.reset(h->sg);
     } else if (k == "robust") {
       h->robust = new mjpc::GpuRobustPlanner(std::make_unique<mjpc::GpuSamplingPlanner>(device, precision, seed), device, precision, seed);
       h->planner.reset(h->robust);
@@ -64,6 +70,7 @@ void* mjpc_planner_create_kind(const char* kind, const char* blob_path, const ch
     h->planner->Initialize(h->storage->model(), *h->task);
     if (num_trajectory > 0) {
       if (h->ps) h->ps->num_trajectory_ = num_trajectory;
+      if (h->sg) h->sg->num_trajectory_ = num_trajectory;
       if (h->ce) { h->ce->num_trajectory_ = num_trajectory; h->ce->n_elite_ = std::max(num_trajectory / 10, 2); }
       if (h->ilqg) h->ilqg->num_rollouts_gui_ = h->ilqg->num_trajectory_ = num_trajectory;
     }
@@ -129,6 +136,26 @@ int mjpc_planner_task_transition_state(void* h, double time, int mode, double* q
     H->task->Transition(H->storage->model(), &d);
   });
 }
+// the host-side normal generator (utilities.h HostGaussianPair), exported for the tests that pin it to the device stream
+void mjpc_host_gaussian_pair(unsigned long long seed, unsigned cand, unsigned pair, unsigned iter, double* z) {
+  mjpc::HostGaussianPair(seed, cand, pair, iter, z);
+}
+// SampleGradientPlanner: number of gradient candidates / filter; its last gradient estimate and winner type
+int mjpc_planner_sample_gradient_config(void* h, int num_gradient, double gradient_filter) {
+  GUARD(h, {
+    if (!H->sg) throw std::runtime_error("not a sample-gradient planner");
+    if (num_gradient >= 0) H->sg->num_gradient_ = num_gradient;
+    if (gradient_filter >= 0) H->sg->gradient_filter_ = gradient_filter;
+  });
+}
+int mjpc_planner_sample_gradient_result(void* h, int* winner_type, double* gradient, int n, double* returns, int nret) {
+  GUARD(h, {
+    if (!H->sg) throw std::runtime_error("not a sample-gradient planner");
+    *winner_type = H->sg->winner_type_;
+    for (int i = 0; i < n && i < (int)H->sg->gradient.size(); i++) gradient[i] = H->sg->gradient[i];
+    for (int i = 0; i < nret && i < (int)H->sg->returns.size(); i++) returns[i] = H->sg->returns[i];
+  });
+}
 // RobustPlanner knobs and the outcome of its last OptimizePolicy (scores: ncandidates mean perturbed returns)
 int mjpc_planner_robust_config(void* h, int ncandidates, int nrepetitions, double xfrc_std, double xfrc_rate) {
   GUARD(h, {
@@ -161,25 +188,28 @@ int mjpc_planner_action_state(void* h, const double* state, double time, int use
 int mjpc_planner_num_parameters(void* h) { return static_cast<Handle*>(h)->planner->NumParameters(); }
 int mjpc_planner_num_spline_points(void* h) {
   Handle* H = static_cast<Handle*>(h);
-  return H->ps ? H->ps->policy.num_spline_points : H->ce ? H->ce->policy.num_spline_points : 0;
+  return H->ps ? H->ps->policy.num_spline_points : H->ce ? H->ce->policy.num_spline_points : H->sg ? H->sg->policy.num_spline_points : 0;
 }
 int mjpc_planner_winner(void* h) {
   Handle* H = static_cast<Handle*>(h);
+  if (H->sg) return H->sg->winner;
   return H->ps ? H->ps->winner : H->ilqg ? H->ilqg->winner : (H->ce->trajectory_order.empty() ? -1 : H->ce->trajectory_order[0]);
 }
 double mjpc_planner_improvement(void* h) {
   Handle* H = static_cast<Handle*>(h);
+  if (H->sg) return H->sg->improvement;
   return H->ps ? H->ps->improvement : H->ce ? H->ce->improvement : H->ilqg->improvement;
 }
 double mjpc_planner_best_score(void* h) {
   Handle* H = static_cast<Handle*>(h);
+  if (H->sg) return H->sg->returns.empty() ? 0.0 : H->sg->returns[H->sg->winner];
   return H->ps ? H->ps->CandidateScore(0) : 0.0;
 }
 // policy spline nodes (sampling / cross-entropy): returns the node count; copies up to `cap` nodes
 int mjpc_planner_policy(void* h, double* times, double* values, int cap) {
   Handle* H = static_cast<Handle*>(h);
   if (H->ilqg) return 0;
-  const auto& plan = H->ps ? H->ps->policy.plan : H->ce->policy.plan;
+  const auto& plan = H->ps ? H->ps->policy.plan : H->sg ? H->sg->policy.plan : H->ce->policy.plan;
   const int n = (int)plan.Size(), nu = H->storage->model()->nu;
   for (int k = 0; k < n && k < cap; k++) {
     times[k] = plan.times()[k];

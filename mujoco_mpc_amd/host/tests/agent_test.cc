@@ -19,7 +19,8 @@ int main(int argc, char** argv) {
     auto planners = LoadPlanners();
     CHECK((int)planners.size() == kNumPlannerTypes);
     CHECK(planners[kSamplingPlanner] && planners[kILQGPlanner] && planners[kCrossEntropyPlanner]);
-    CHECK(!planners[kGradientPlanner] && !planners[kILQSPlanner] && !planners[kSampleGradientPlanner]);
+    CHECK(!planners[kGradientPlanner] && !planners[kILQSPlanner]);
+    CHECK(planners[kSampleGradientPlanner] != nullptr);
     CHECK(planners[kRobustPlanner] != nullptr);  // RobustPlanner over a GpuSamplingPlanner delegate
   }
   for (const char* name : {"Particle", "Cartpole", "QuadrupedFlat"}) {

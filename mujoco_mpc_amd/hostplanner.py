@@ -48,7 +48,11 @@ def lib():
         L.mjpc_planner_best_trajectory.argtypes = [vp, c_f64p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_double)]
         L.mjpc_planner_task_transition.argtypes = [vp, C.c_double, C.c_int]
         L.mjpc_planner_task_transition_state.argtypes = [vp, C.c_double, C.c_int, c_f64p, c_f64p, c_f64p]
+        L.mjpc_host_gaussian_pair.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, c_f64p]
+        L.mjpc_host_gaussian_pair.restype = None
         L.mjpc_planner_robust_config.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.mjpc_planner_sample_gradient_config.argtypes = [vp, C.c_int, C.c_double]
+        L.mjpc_planner_sample_gradient_result.argtypes = [vp, C.POINTER(C.c_int), c_f64p, C.c_int, c_f64p, C.c_int]
         L.mjpc_planner_robust_result.argtypes = [vp, C.POINTER(C.c_int), c_f64p, C.c_int]
         L.mjpc_planner_task_set_parameter.argtypes = [vp, C.c_int, C.c_double]
         L.mjpc_planner_destroy.argtypes = [vp]
@@ -70,6 +74,13 @@ def lib():
         L.mjpc_planner_ctx.argtypes = [vp]
         _LIB = L
     return _LIB
+
+
+def host_gaussian_pair(seed, cand, pair, iteration):
+    """the C++ host's normal generator (must equal the device / oracle stream)"""
+    z = np.zeros(2)
+    lib().mjpc_host_gaussian_pair(int(seed), int(cand), int(pair), int(iteration), as_f64p(z))
+    return z
 
 
 class HostPlanner:
@@ -162,6 +173,15 @@ class HostPlanner:
 
     def task_transition(self, time, mode=-1):
         self._chk(lib().mjpc_planner_task_transition(self.h, float(time), int(mode)))
+
+    def sample_gradient_config(self, num_gradient=-1, gradient_filter=-1.0):
+        self._chk(lib().mjpc_planner_sample_gradient_config(self.h, int(num_gradient), float(gradient_filter)))
+
+    def sample_gradient_result(self, num_parameters, num_trajectory):
+        wt = C.c_int(-1)
+        g, r = np.zeros(num_parameters), np.zeros(num_trajectory)
+        self._chk(lib().mjpc_planner_sample_gradient_result(self.h, C.byref(wt), as_f64p(g), num_parameters, as_f64p(r), num_trajectory))
+        return wt.value, g, r
 
     def robust_config(self, ncandidates=0, nrepetitions=0, xfrc_std=-1.0, xfrc_rate=0.0):
         self._chk(lib().mjpc_planner_robust_config(self.h, int(ncandidates), int(nrepetitions), float(xfrc_std), float(xfrc_rate)))

@@ -59,3 +59,17 @@ def test_testspeed_app(blobs):
     out = run("testspeed_app", "--task=Cartpole", "--total_time=0.5", "--steps_per_planning_iteration=4",
               f"--model_dir={blobs}", "--candidates=4096")
     assert "Average cost per step" in out
+
+
+def test_host_normal_generator_equals_the_oracle_stream(blobs):
+    """HostGaussianPair (mjpc/utilities.h: Philox4x32-10 + Box-Muller) draws what the device and the oracle draw"""
+    import ctypes as C
+    import numpy as np
+    from mujoco_mpc_amd.hostplanner import host_gaussian_pair
+    from oracle import pyoracle
+    L = pyoracle.lib()
+    L.ogaussian_pair.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+    for seed, cand, pair, it in ((0, 0, 0, 0), (3, 17, 5, 2), (2**40 + 7, 65535, 1023, 99)):
+        z = (C.c_double * 2)()
+        L.ogaussian_pair(seed, cand, pair, it, z)
+        assert np.allclose(host_gaussian_pair(seed, cand, pair, it), [z[0], z[1]], rtol=1e-14, atol=0)

@@ -238,3 +238,48 @@ def test_cpp_robust_planner_on_the_quadruped():
     # a second plan draws fresh noise (the candidate offset advances with the iteration) and still runs
     p.optimize_policy(H)
     assert 0 <= p.robust_result()[0] < K
+
+
+def test_cpp_sample_gradient_planner(cartpole):
+    """GpuSampleGradientPlanner (sample_gradient/planner.cc): first iteration checked against a by-hand evaluation of the
+    fitness-shaped gradient from the SAME noise stream (host Philox = device = oracle) and the returned rollout costs;
+    then it keeps improving the plan and uses its gradient candidates."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner, host_gaussian_pair
+    N, G, H = 24, 4, 40
+    p = HostPlanner(cartpole, seed=7, num_trajectory=N, kind="sample_gradient")
+    p.sample_gradient_config(num_gradient=G, gradient_filter=0.8)
+    p.reset(H)
+    P, nu = p.num_spline_points, 1
+    q, v = [0.2, 0.6], [0.0, 0.1]
+    p.set_state(q, v, 0.0)
+    p.optimize_policy(H)
+    wt, g, ret = p.sample_gradient_result(P * nu, N)
+    num_noisy = N - G
+    assert np.all(ret[:N] > 0) and wt in (0, 1, 2)
+    # noise of candidate i, iteration 0: pairs (k >> 1) of the candidate's stream
+    noise = np.zeros((num_noisy, P * nu))
+    for i in range(1, num_noisy):
+        for k in range(0, P * nu, 2):
+            z = host_gaussian_pair(7, i, k >> 1, 0)
+            noise[i, k] = z[0]
+            if k + 1 < P * nu:
+                noise[i, k + 1] = z[1]
+    order = np.argsort(ret[:num_noisy], kind="stable")
+    f0 = np.log(0.5 * num_noisy + 1.0)
+    raw = np.maximum(0.0, f0 - np.log(order + 1.0))      # the reference indexes the shaping by trajectory_order[i]
+    w = raw / raw.sum() - 1.0 / num_noisy
+    expect = sum(noise[order[i]] * (w[i] / num_noisy) for i in range(num_noisy))
+    assert np.allclose(g, expect, rtol=1e-12, atol=1e-15)
+    # the gradient candidates of iteration 0 (zeros + steps along -gradient) are rolled out at iteration 1
+    scores = [ret[p.winner]]
+    types = [wt]
+    for k in range(1, 12):
+        p.set_state(q, v, 0.0)
+        p.optimize_policy(H)
+        wt, g, ret = p.sample_gradient_result(P * nu, N)
+        scores.append(ret[p.winner]); types.append(wt)
+        assert p.best_score == ret[p.winner]
+    assert scores[-1] < scores[0] and all(b <= a + 1e-12 for a, b in zip(scores, scores[1:]))   # the nominal is always a candidate
+    assert 2 in types or 1 in types
+    tr = p.best_trajectory()
+    assert abs(tr["total_return"] - scores[-1]) < 1e-12
