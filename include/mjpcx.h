@@ -402,6 +402,13 @@ int mjpcx_timing_read(mjpcx_ctx* ctx, double* kernel_ms, int64_t* launches);
  * w*[H*(dim_state+nu+1+nr+3*ntrace+1) + P*nu + P + 2]. */
 int64_t mjpcx_algorithmic_bytes(const mjpcx_ctx* ctx, int horizon, int num_nodes);
 
+/* mjData kinematics of the state last given to mjpcx_set_state (mj_kinematics, mj_comPos, mj_comVel, mj_subtreeVel), for
+ * Task::Transition implementations that read them (QuadrupedFlat::TransitionLocked: torso pose, subtree centre of mass and
+ * linear velocity, head site; quadruped.cc:229-391) when the host has no physics of its own. Any output may be NULL; sizes
+ * follow the model (nbody x 3 / 4 / 9, nsite x 3). Contact-model kernel family only. Synchronous. */
+int mjpcx_kinematics(mjpcx_ctx* ctx, double* xpos, double* xquat, double* xmat, double* xipos, double* site_xpos,
+                     double* subtree_com, double* subtree_linvel);
+
 /* Raw device pointers (for zero-copy wrapping, e.g. torch tensors feeding an
  * RCCL collective). which: 0 = total_return (N x fp64), 1 = failure (N x i32). */
 int mjpcx_device_buffer(mjpcx_ctx* ctx, int which, void** ptr, size_t* bytes);

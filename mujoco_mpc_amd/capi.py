@@ -23,7 +23,7 @@ NOISE_SAMPLING, NOISE_CROSS_ENTROPY = 0, 1
 EXPORTS = [
     "mjpcx_create", "mjpcx_destroy", "mjpcx_create_error", "mjpcx_error_string", "mjpcx_last_error",
     "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_set_residual_state", "mjpcx_rollout_splines",
-    "mjpcx_rollout_noise", "mjpcx_rollout_splines_noisy", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
+    "mjpcx_rollout_noise", "mjpcx_rollout_splines_noisy", "mjpcx_kinematics", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
     "mjpcx_fetch_spline", "mjpcx_rollout_feedback", "mjpcx_transition_fd", "mjpcx_cost_derivatives",
     "mjpcx_backward_pass", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
     "mjpcx_device_buffer",
@@ -65,6 +65,7 @@ def lib():
         L.mjpcx_rollout_noise.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.POINTER(MjpcxNoiseSpec)]
         L.mjpcx_rollout_splines_noisy.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_double, C.c_double,
                                                   C.c_uint64, C.c_int]
+        L.mjpcx_kinematics.argtypes = [vp] + [c_f64p] * 7
         L.mjpcx_sync.argtypes = [vp]
         L.mjpcx_get_returns.argtypes = [vp, c_f64p, c_i32p]
         L.mjpcx_get_return_at.argtypes = [vp, C.c_int, C.POINTER(C.c_double), c_i32p]
@@ -195,6 +196,14 @@ class Context:
         self._chk(lib().mjpcx_rollout_splines_noisy(self.handle, N, int(horizon), P, int(interp), as_f64p(nt), as_f64p(nv),
                                                     float(xfrc_std), float(xfrc_rate), int(seed), int(candidate_offset)))
         self.N, self.H, self.P = N, int(horizon), P
+
+    def kinematics(self, nbody, nsite):
+        """mjData kinematics of the state given to set_state: dict of xpos, xquat, xmat, xipos, site_xpos, subtree_com, subtree_linvel."""
+        out = dict(xpos=np.zeros((nbody, 3)), xquat=np.zeros((nbody, 4)), xmat=np.zeros((nbody, 9)), xipos=np.zeros((nbody, 3)),
+                   site_xpos=np.zeros((nsite, 3)), subtree_com=np.zeros((nbody, 3)), subtree_linvel=np.zeros((nbody, 3)))
+        self._chk(lib().mjpcx_kinematics(self.handle, *[as_f64p(out[k]) for k in ("xpos", "xquat", "xmat", "xipos", "site_xpos", "subtree_com",
+                                                                                   "subtree_linvel")]))
+        return out
 
     def rollout_noise(self, num_candidates, horizon, interp, node_times, nominal, noise_spec):
         nt, nom = _f(node_times), _f(nominal)

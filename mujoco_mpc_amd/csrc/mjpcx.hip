@@ -321,6 +321,7 @@ struct mjpcx_ctx {
   DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out, d_simt, d_wblob;
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
   bool traj_candidate_major = false;
+  int nsite_model = 0;
   double xfrc_std = 0, xfrc_rate = 1; uint64_t xfrc_seed = 0; int xfrc_offset = 0;  // pending NoisyRollout request (0: plain Rollout)  // layout of the last rollout's Trajectory buffers (true: wavefront-per-candidate kernels)
   int N = 0, H = 0, P = 0;  // shape of the last rollout
   bool have_rollout = false;
@@ -720,7 +721,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     mjpcx_ctx* c = new (std::nothrow) mjpcx_ctx();
     if (!c) return bad(MJPCX_ENOMEM, "host allocation failed");
     c->device = device; c->precision = precision; c->kernel = &kWaveEntry; c->wave = true;
-    c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap;
+    c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap; c->nsite_model = m->nsite;
     c->nr = t->num_residual; c->nterm = t->num_term; c->ntrace = t->num_trace; c->nparam = t->num_parameter;
     c->num_norm_parameter.assign(t->num_norm_parameter, t->num_norm_parameter + t->num_term);
     c->dim_norm_residual.assign(t->dim_norm_residual, t->dim_norm_residual + t->num_term);
@@ -1348,6 +1349,32 @@ int mjpcx_transition_fd(mjpcx_ctx* c, int Tn, const double* times, const double*
   if (c->wave) return do_transition_fd_wave(c, Tn, times, states, actions, eps, centered, A, B, C, D);
   return c->precision == 64 ? do_transition_fd<double>(c, Tn, times, states, actions, eps, centered, A, B, C, D)
                             : do_transition_fd<float>(c, Tn, times, states, actions, eps, centered, A, B, C, D);
+}
+
+int mjpcx_kinematics(mjpcx_ctx* c, double* xpos, double* xquat, double* xmat, double* xipos, double* site_xpos, double* subtree_com,
+                     double* subtree_linvel) {
+  if (!c) return MJPCX_EINVAL;
+  if (!c->wave) return fail(c, MJPCX_EUNSUPPORTED, "mjpcx_kinematics is implemented for the wavefront-per-candidate models only");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  WaveTask wt;
+  if ((rc = wave_blob(c, &wt)) != MJPCX_OK) return rc;
+  const size_t nb = (size_t)c->wh.m.nbody_model, ns = (size_t)c->nsite_model;
+  const size_t total = 3 * nb + 4 * nb + 9 * nb + 3 * nb + 3 * ns + 3 * nb + 3 * nb;
+  HIPCHK(c, c->d_ilqg_out.reserve(total * 8));
+  HIPCHK(c, hipMemsetAsync(c->d_ilqg_out.p, 0, total * 8, c->stream));
+  const size_t lds = wave_lds_bytes(c, 1);
+  HIPCHK(c, hipFuncSetAttribute((const void*)w64::kinematics_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(w64::kinematics_wave_kernel, dim3(1), dim3(64), lds, c->stream, c->wh.m, wt, (double*)c->d_ilqg_out.p, (int)nb, (int)ns);
+  HIPCHK(c, hipGetLastError());
+  std::vector<double> h(total);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_ilqg_out.p, total * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const double* p = h.data();
+  auto take = [&](double* dst, size_t n) { if (dst) std::memcpy(dst, p, n * 8); p += n; };
+  take(xpos, 3 * nb); take(xquat, 4 * nb); take(xmat, 9 * nb); take(xipos, 3 * nb); take(site_xpos, 3 * ns); take(subtree_com, 3 * nb);
+  take(subtree_linvel, 3 * nb);
+  return MJPCX_OK;
 }
 
 int mjpcx_cost_derivatives(mjpcx_ctx* c, int T, const double* residual, const double* C, const double* D, double* cx,

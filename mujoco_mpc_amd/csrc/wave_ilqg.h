@@ -102,6 +102,50 @@ __global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WModel m, 
   for (int i = lane; i < ds; i += 64) f.next[((size_t)t * f.ncol + col) * ds + i] = i < nq ? d.qpos[i] : d.qvel[i - nq];
 }
 
+// mjData kinematics of the state set by mjpcx_set_state, for Task::Transition implementations that read them (mj_kinematics,
+// mj_comPos, mj_comVel, mj_subtreeVel): out = [xpos 3nb | xquat 4nb | xmat 9nb | xipos 3nb | site_xpos 3ns | subtree_com 3nb |
+// subtree_linvel 3nb] with nb, ns = the MODEL's body / site counts (entries of bodies outside the device range stay zero).
+__global__ __launch_bounds__(64) void kinematics_wave_kernel(const WModel m, const WTask tk, wreal* __restrict__ out, int nb_model,
+                                                             int ns_model) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x;
+  const int nq = m.nq, nv = m.nv, nb = m.nbody, ns = m.nsite;
+  wreal *lnodes, *ltimes;
+  WaveData d = wave_carve(smem_raw, m, tk, 1, lnodes, ltimes);
+  for (int i = lane; i < nq; i += 64) d.qpos[i] = tk.blob[i];
+  for (int i = lane; i < nv; i += 64) d.qvel[i] = tk.blob[nq + i];
+  if (lane < 4) d.counters[lane] = 0;
+  WSYNC();
+  wf_kinematics(m, tk, d, lane);
+  WSYNC();
+  wf_compos(m, d, lane);
+  wf_comvel(m, d, lane);
+  WSYNC();
+  wreal* o_xpos = out; wreal* o_xquat = o_xpos + 3 * nb_model; wreal* o_xmat = o_xquat + 4 * nb_model;
+  wreal* o_xipos = o_xmat + 9 * nb_model; wreal* o_site = o_xipos + 3 * nb_model; wreal* o_com = o_site + 3 * ns_model;
+  wreal* o_linvel = o_com + 3 * nb_model;
+  for (int i = lane; i < 3 * nb; i += 64) { o_xpos[i] = d.xpos[i]; o_xipos[i] = d.xipos[i]; o_com[i] = d.subtree_com[i]; }
+  for (int i = lane; i < 4 * nb; i += 64) o_xquat[i] = d.xquat[i];
+  for (int i = lane; i < 9 * nb; i += 64) o_xmat[i] = d.xmat[i];
+  for (int i = lane; i < 3 * ns; i += 64) o_site[i] = d.site_xpos[i];
+  if (lane < nb) {  // subtree linear velocity: momentum of the bodies below / subtree mass (mj_subtreeVel)
+    wreal mom[3] = {0, 0, 0};
+    unsigned long long mask = m.body_subtree_mask[lane];
+    while (mask) {
+      const int i = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const wreal* cv = d.cvel + 6 * i;
+      const wreal* com = d.subtree_com + 3 * m.body_rootid[i];
+      const wreal off[3] = {d.xipos[3 * i] - com[0], d.xipos[3 * i + 1] - com[1], d.xipos[3 * i + 2] - com[2]};
+      wreal lin[3];
+      cr3(lin, cv, off);
+      for (int k = 0; k < 3; k++) mom[k] += m.body_mass[i] * (cv[3 + k] + lin[k]);
+    }
+    const wreal mass = m.body_subtreemass[lane];
+    for (int k = 0; k < 3; k++) o_linvel[3 * lane + k] = mass > kMinVal ? mom[k] / mass : WL(0.0);
+  }
+}
+
 // raw next states [Tn][ncol][nq+nv] -> tangent coordinates [Tn][ncol][2 nv] relative to column 0 (oracle state_tangent)
 __global__ void fd_tangent_kernel(const WModel m, const wreal* __restrict__ next, wreal* __restrict__ tan, int Tn, int ncol) {
   const int nq = m.nq, nv = m.nv, ds = nq + nv, ndx = 2 * nv;

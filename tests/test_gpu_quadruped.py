@@ -306,3 +306,39 @@ def test_noisy_rollout_matches_the_oracle(quad, precision, tol):
     r1, _ = ctx.returns()
     assert np.array_equal(r0, r1)
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["QuadrupedFlat", "HumanoidTrack"])
+def test_kinematics_query(name):
+    """mjpcx_kinematics: the mjData fields a Task::Transition reads (body / site poses, subtree centre of mass and linear
+    velocity) for the state given to mjpcx_set_state, against the oracle's mj_forward"""
+    t = load_task(name)
+    if name == "QuadrupedFlat":
+        t.transition(0.0)
+    else:
+        t.transition(0.0, mode=3)
+    m = t.model
+    rng = np.random.default_rng(4)
+    q = np.array(m.arrays["qpos0"], float)
+    q[:3] += rng.normal(0, 0.2, 3)
+    q[3:7] = rng.normal(0, 1, 4); q[3:7] /= np.linalg.norm(q[3:7])
+    q[7:] += rng.normal(0, 0.3, m.nq - 7)
+    v = rng.normal(0, 1.0, m.nv)
+    mocap = np.concatenate([np.concatenate([rng.normal(0, 1, 3), [1, 0, 0, 0]]) for _ in range(m.nmocap)])
+    pm, pt = t.packed_model(), t.packed()
+    ph = pyoracle.Physics(pm)
+    ph.set_state(q, v, 0.3, mocap)
+    ph.set_ctrl(np.zeros(m.nu))
+    ph.forward()
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(np.concatenate([q, v]), 0.3, mocap)
+    k = ctx.kinematics(m.nbody, m.nsite)
+    live_b = m.nbody if name == "QuadrupedFlat" else m.nbody - 16   # the humanoid's inert mocap bodies are not on the device
+    live_s = m.nsite if name == "QuadrupedFlat" else m.nsite - 16
+    for key, width, live in (("xpos", 3, live_b), ("xquat", 4, live_b), ("xmat", 9, live_b), ("xipos", 3, live_b),
+                             ("subtree_com", 3, live_b), ("subtree_linvel", 3, live_b), ("site_xpos", 3, live_s)):
+        ref = ph.get(key, cap=16384).reshape(-1, width)
+        first = 1 if key == "subtree_linvel" else 0   # (the oracle's helper does not define the world body's entry)
+        assert close(k[key][first:live], ref[first:live], 1e-12), key
+        assert np.all(k[key][live:] == 0)
+    ctx.close()
