@@ -129,6 +129,25 @@ void Context::SyncTask(const Task& t) {
   if (!ri.empty() || !rr.empty()) Check(mjpcx_set_residual_state(ctx_, ri.empty() ? nullptr : ri.data(), rr.empty() ? nullptr : rr.data()));
 }
 
+void KinematicsBuffers::Allocate(const mjModel* m) {
+  xpos.assign(3 * (size_t)m->nbody, 0.0); xquat.assign(4 * (size_t)m->nbody, 0.0); xmat.assign(9 * (size_t)m->nbody, 0.0);
+  xipos.assign(3 * (size_t)m->nbody, 0.0); site_xpos.assign(3 * (size_t)m->nsite, 0.0);
+  subtree_com.assign(3 * (size_t)m->nbody, 0.0); subtree_linvel.assign(3 * (size_t)m->nbody, 0.0);
+}
+
+void KinematicsBuffers::Attach(mjData* d) {
+  d->xpos = xpos.data(); d->xquat = xquat.data(); d->xmat = xmat.data(); d->xipos = xipos.data(); d->site_xpos = site_xpos.data();
+  d->subtree_com = subtree_com.data(); d->subtree_linvel = subtree_linvel.data();
+}
+
+bool Context::Kinematics(KinematicsBuffers* out) {
+  const int rc = mjpcx_kinematics(ctx_, out->xpos.data(), out->xquat.data(), out->xmat.data(), out->xipos.data(),
+                                  out->site_xpos.data(), out->subtree_com.data(), out->subtree_linvel.data());
+  if (rc == MJPCX_EUNSUPPORTED) return false;
+  Check(rc);
+  return true;
+}
+
 void Context::FetchTrajectory(int index, Trajectory* tr) {
   mjpcx_traj_view v{};
   v.horizon = (int)tr->times.size();

@@ -44,6 +44,13 @@ class FlatTask {
   std::vector<double> residual_real_;
 };
 
+// host copies of the mjData kinematics a Task::Transition may read (quadruped.cc:229-391), filled by Context::Kinematics
+struct KinematicsBuffers {
+  std::vector<double> xpos, xquat, xmat, xipos, site_xpos, subtree_com, subtree_linvel;
+  void Allocate(const mjModel* m);
+  void Attach(mjData* d);  // points the mjData kinematic fields at these buffers
+};
+
 class Context {
  public:
   Context(const mjModel* model, const Task& task, int device, int precision = 64, bool differentiable = false);
@@ -57,6 +64,9 @@ class Context {
   void SyncTask(const Task& task);  // weights, norm/residual parameters, risk and the frozen ResidualFn state
   // gathers candidate `index` into a (pre-allocated) reference-layout Trajectory
   void FetchTrajectory(int index, Trajectory* trajectory);
+  // kinematics of the state last given to mjpcx_set_state; false when this model's kernel family has no such query
+  // (lane-per-candidate models: none of their tasks' Transition reads kinematics), throws on any other error
+  bool Kinematics(KinematicsBuffers* out);
 
  private:
   mjpcx_ctx* ctx_ = nullptr;

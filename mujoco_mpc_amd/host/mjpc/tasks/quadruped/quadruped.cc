@@ -5,6 +5,7 @@
 
 #include "../../../../../include/mjpcx.h"
 #include "../../../model_io.h"
+#include "../../utilities.h"
 
 namespace mjpc {
 
@@ -94,28 +95,72 @@ void QuadrupedFlat::ResetLocked(const mjModel* model) {
   r.land_rot_acc_ = 2 * (r.flight_rot_vel_ * r.land_time_ - kPi / 4) / (r.land_time_ * r.land_time_);
 }
 
-// quadruped.cc:229-391, the parts that need no kinematics (see the header)
+// quadruped.cc:633-649
+void QuadrupedFlat::ResidualFn::Walk(double pos[2], double time) const {
+  if (std::fabs(angvel_) < kMinAngvel) {  // no rotation, go in a straight line
+    double forward[2] = {heading_[0], heading_[1]};
+    const double n = std::sqrt(forward[0] * forward[0] + forward[1] * forward[1]);
+    if (n > 1e-15) { forward[0] /= n; forward[1] /= n; }
+    pos[0] = position_[0] + heading_[0] + time * speed_ * forward[0];
+    pos[1] = position_[1] + heading_[1] + time * speed_ * forward[1];
+  } else {  // walk on a circle
+    const double angle = time * angvel_, cs = std::cos(angle), sn = std::sin(angle);
+    pos[0] = cs * heading_[0] - sn * heading_[1] + position_[0];
+    pos[1] = sn * heading_[0] + cs * heading_[1] + position_[1];
+  }
+}
+
+// quadruped.cc:229-391. Kinematic inputs (data->xpos / xmat / xquat / site_xpos / subtree_com / subtree_linvel, mocap_pos) are
+// the mjData fields the reference reads (it reaches subtree_com / subtree_linvel through the torso_subtreecom /
+// torso_subtreelinvel sensors); NULL pointers skip the part that needs them.
 void QuadrupedFlat::TransitionLocked(mjModel* model, mjData* data) {
   ResidualFn& r = residual_;
   const double time = data->time;
+  // ---------- handle mjData reset ----------
   if (time < r.last_transition_time_ || r.last_transition_time_ == -1) {
     if (mode != ResidualFn::kModeQuadruped && mode != ResidualFn::kModeBiped) mode = ResidualFn::kModeQuadruped;
     r.last_transition_time_ = r.phase_start_time_ = r.phase_start_ = time;
   }
+  // ---------- prevent forbidden mode transitions ----------
   if (mode != r.current_mode_ && r.current_mode_ != ResidualFn::kModeQuadruped) {
     if (mode == ResidualFn::kModeWalk || mode == ResidualFn::kModeFlip) mode = ResidualFn::kModeQuadruped;
   }
+  // ---------- handle phase velocity change ----------
   const double phase_velocity = 2 * kPi * parameters[r.cadence_param_id_];
   if (phase_velocity != r.phase_velocity_) {
     r.phase_start_ = r.GetPhase(time);
     r.phase_start_time_ = time;
     r.phase_velocity_ = phase_velocity;
   }
-  if (mode == ResidualFn::kModeBiped) parameters[r.gait_param_id_] = ResidualFn::kGaitTrot;
+  // ---------- automatic gait switching ----------
+  const int torso = r.torso_body_id_;
+  if (data->subtree_linvel) {
+    const double* comvel = data->subtree_linvel + 3 * torso;
+    const double beta = std::exp(-(time - r.last_transition_time_) / ResidualFn::kAutoGaitFilter);
+    r.com_vel_[0] = beta * r.com_vel_[0] + (1 - beta) * comvel[0];
+    r.com_vel_[1] = beta * r.com_vel_[1] + (1 - beta) * comvel[1];
+  }
+  const int auto_switch = (int)parameters[r.gait_switch_param_id_];
+  if (mode == ResidualFn::kModeBiped) {
+    parameters[r.gait_param_id_] = ResidualFn::kGaitTrot;  // biped always trots
+  } else if (auto_switch && data->subtree_linvel) {
+    const double com_speed = std::sqrt(r.com_vel_[0] * r.com_vel_[0] + r.com_vel_[1] * r.com_vel_[1]);
+    for (int gait : ResidualFn::kGaitAll) {
+      if (mode == ResidualFn::kModeScramble && gait == ResidualFn::kGaitStand) continue;  // scramble requires a non-static gait
+      const bool lower = com_speed > ResidualFn::kGaitAuto[gait];
+      const bool upper = gait == ResidualFn::kGaitGallop || com_speed <= ResidualFn::kGaitAuto[gait + 1];
+      const bool wait = std::fabs(r.gait_switch_time_ - time) > ResidualFn::kAutoGaitMinTime;
+      if (lower && upper && wait) {
+        parameters[r.gait_param_id_] = gait;
+        r.gait_switch_time_ = time;
+      }
+    }
+  }
+  // ---------- handle gait switch, manual or auto ----------
   const double gait_selection = parameters[r.gait_param_id_];
   if (gait_selection != r.current_gait_) {
     r.current_gait_ = gait_selection;
-    const int gait = r.current_mode_ == ResidualFn::kModeBiped ? ResidualFn::kGaitTrot : (int)r.current_gait_;
+    const int gait = r.GetGait();
     parameters[r.duty_param_id_] = ResidualFn::kGaitParam[gait][0];
     parameters[r.cadence_param_id_] = ResidualFn::kGaitParam[gait][1];
     parameters[r.amplitude_param_id_] = ResidualFn::kGaitParam[gait][2];
@@ -123,6 +168,67 @@ void QuadrupedFlat::TransitionLocked(mjModel* model, mjData* data) {
     weight[r.upright_cost_id_] = ResidualFn::kGaitParam[gait][4];
     weight[r.height_cost_id_] = ResidualFn::kGaitParam[gait][5];
   }
+  // ---------- Walk ----------
+  double* goal_pos = data->mocap_pos ? data->mocap_pos + 3 * r.goal_mocap_id_ : nullptr;
+  if (mode == ResidualFn::kModeWalk && goal_pos && data->xmat && data->xpos) {
+    const double angvel = parameters[ParameterIndex(model, "Walk turn")];
+    const double speed = parameters[ParameterIndex(model, "Walk speed")];
+    const double* torso_xmat = data->xmat + 9 * torso;
+    double forward[2] = {torso_xmat[0], torso_xmat[3]};  // current torso direction
+    const double fn = std::sqrt(forward[0] * forward[0] + forward[1] * forward[1]);
+    if (fn > 1e-15) { forward[0] /= fn; forward[1] /= fn; }
+    const double leftward[2] = {-forward[1], forward[0]};
+    // switching into Walk or parameters changed: reset the task state
+    if (mode != r.current_mode_ || r.angvel_ != angvel || r.speed_ != speed) {
+      r.mode_start_time_ = time;
+      r.speed_ = speed;
+      r.angvel_ = angvel;
+      double axis[2] = {data->xpos[3 * torso], data->xpos[3 * torso + 1]};  // rotation axis / walk origin
+      if (std::fabs(angvel) > ResidualFn::kMinAngvel) {
+        const double dd = speed / angvel;
+        axis[0] += dd * leftward[0];
+        axis[1] += dd * leftward[1];
+      }
+      r.position_[0] = axis[0];
+      r.position_[1] = axis[1];
+      r.heading_[0] = goal_pos[0] - axis[0];  // vector from the axis to the initial goal position
+      r.heading_[1] = goal_pos[1] - axis[1];
+    }
+    r.Walk(goal_pos, time - r.mode_start_time_);  // move the goal
+  }
+  // ---------- Flip ----------
+  if (mode == ResidualFn::kModeFlip && data->xquat && data->subtree_com) {
+    if (mode != r.current_mode_) {  // switching into Flip: reset the task state
+      r.mode_start_time_ = time;
+      mju_copy(r.orientation_, data->xquat + 4 * torso, 4);
+      r.ground_ = Ground(model, data, data->subtree_com + 3 * torso);
+      r.save_weight_ = weight;
+      r.save_gait_switch_ = parameters[r.gait_switch_param_id_];
+      auto term = [&](const char* name) {
+        for (int i = 0; i < num_term; i++) if (weight_names[i] == name) return i;
+        throw std::runtime_error(std::string("cost term '") + name + "' not found");
+      };
+      weight[term("Upright")] = 0.2;
+      weight[term("Height")] = 5;
+      weight[term("Position")] = 0;
+      weight[term("Gait")] = 0;
+      weight[term("Balance")] = 0;
+      weight[term("Effort")] = 0.005;
+      weight[term("Posture")] = 0.1;
+      parameters[r.gait_switch_param_id_] = 0;
+    }
+    const double flip_time = time - r.mode_start_time_;
+    if (flip_time >= r.jump_time_ + r.flight_time_ + r.land_time_) {  // Flip ended: back to Quadruped, restore the values
+      mode = ResidualFn::kModeQuadruped;
+      weight = r.save_weight_;
+      parameters[r.gait_switch_param_id_] = r.save_gait_switch_;
+      if (goal_pos && data->site_xpos) {
+        goal_pos[0] = data->site_xpos[3 * r.head_site_id_ + 0];
+        goal_pos[1] = data->site_xpos[3 * r.head_site_id_ + 1];
+      }
+    }
+  }
+  // save mode
   r.current_mode_ = static_cast<ResidualFn::A1Mode>(mode);
   r.last_transition_time_ = time;
 }

@@ -77,20 +77,30 @@ double SynchronousPlanningCost(std::string task_name, int planner_thread_count, 
     int plans = 0;
     double plan_us = 0;
     std::vector<double> full_state(ds), mocap7(7 * (size_t)model->nmocap);
+    gpu::KinematicsBuffers kin;
+    kin.Allocate(model);
+    auto pack_mocap = [&]() {
+      for (int k = 0; k < model->nmocap; k++) {
+        mju_copy(mocap7.data() + 7 * k, mocap_pos.data() + 3 * k, 3);
+        mju_copy(mocap7.data() + 7 * k + 3, mocap_quat.data() + 4 * k, 4);
+      }
+    };
     for (int i = 0; i < total_steps; i++) {
-      {  // agent.ActiveTask()->Transition(model, data) (testspeed.cc:97): tasks may edit qpos / qvel / mocap_pos
+      {  // agent.ActiveTask()->Transition(model, data) (testspeed.cc:97): tasks may edit qpos / qvel / mocap_pos and read the
+         // kinematics of the current state, which the reference's mjData holds after mj_step and this host asks the device for
         mjData d{};
         d.time = time;
         d.qpos = qpos.data(); d.qvel = qvel.data(); d.mocap_pos = mocap_pos.data(); d.mocap_quat = mocap_quat.data();
+        state.Set(model, qpos.data(), qvel.data(), nullptr, mocap_pos.data(), mocap_quat.data(), nullptr, time);
+        pack_mocap();
+        sim.Check(mjpcx_set_state(sim.handle(), state.state().data(), time, mocap7.data(), nullptr));
+        if (sim.Kinematics(&kin)) kin.Attach(&d);
         task->Transition(model, &d);
       }
       state.Set(model, qpos.data(), qvel.data(), nullptr, mocap_pos.data(), mocap_quat.data(), nullptr, time);
       planner.ActionFromPolicy(ctrl.data(), state.state().data(), time);
       // mj_step of the simulation copy + the stage cost at the pre-step state
-      for (int k = 0; k < model->nmocap; k++) {
-        mju_copy(mocap7.data() + 7 * k, mocap_pos.data() + 3 * k, 3);
-        mju_copy(mocap7.data() + 7 * k + 3, mocap_quat.data() + 4 * k, 4);
-      }
+      pack_mocap();
       sim.SyncTask(*task);
       sim.Check(mjpcx_set_state(sim.handle(), state.state().data(), time, mocap7.data(), nullptr));
       sim.Check(mjpcx_rollout_splines(sim.handle(), 1, 2, 1, MJPCX_SPLINE_ZERO, &time, ctrl.data()));

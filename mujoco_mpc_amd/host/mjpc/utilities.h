@@ -1,5 +1,7 @@
 // Subset of mjpc/utilities.{h,cc} on the rollout path.
 #pragma once
+#include <stdexcept>
+#include <algorithm>
 #include <cstdint>
 #include <chrono>
 #include <cmath>
@@ -77,6 +79,73 @@ inline void LinearInterpolation(double* output, double x, const double* xs, cons
   if (bounds[0] == bounds[1]) { mju_copy(output, ys + (size_t)dim * bounds[0], dim); return; }
   const double t = (x - xs[bounds[0]]) / (xs[bounds[1]] - xs[bounds[0]]);
   for (int i = 0; i < dim; i++) output[i] = ys[(size_t)dim * bounds[0] + i] * (1.0 - t) + ys[(size_t)dim * bounds[1] + i] * t;
+}
+// Ground (utilities.cc:556-574): global height of the nearest group-0 geom under `pos`, by a ray cast straight down from
+// 0.5 m above it. Host stand-in for mj_ray over the geoms a planning scene has below the robot: planes, spheres and boxes on
+// the world body or on mocap bodies (their pose = mocap pose o geom pose). Returns pos[2] + 0.5 - distance; throws if
+// nothing is hit, where the reference calls mju_error.
+inline double Ground(const mjModel* m, const mjData* d, const double pos[3]) {
+  const double height_offset = 0.5;
+  const double o[3] = {pos[0], pos[1], pos[2] + height_offset};
+  double best = -1;
+  auto quat2mat = [](const double* q, double* R) {
+    const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3], q11 = q[1] * q[1], q12 = q[1] * q[2],
+                 q13 = q[1] * q[3], q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+    R[0] = q00 + q11 - q22 - q33; R[4] = q00 - q11 + q22 - q33; R[8] = q00 - q11 - q22 + q33;
+    R[1] = 2 * (q12 - q03); R[2] = 2 * (q13 + q02); R[3] = 2 * (q12 + q03); R[5] = 2 * (q23 - q01); R[6] = 2 * (q13 - q02); R[7] = 2 * (q23 + q01);
+  };
+  for (int g = 0; g < m->ngeom; g++) {
+    if (m->geom_group[g] != 0) continue;
+    const int b = m->geom_bodyid[g];
+    const bool world = b == 0, mocap = b > 0 && m->body_mocapid[b] >= 0;
+    if (!world && !mocap) continue;
+    // geom frame in the world
+    double bp[3] = {0, 0, 0}, bq[4] = {1, 0, 0, 0};
+    if (mocap) {
+      if (!d->mocap_pos || !d->mocap_quat) continue;
+      for (int k = 0; k < 3; k++) bp[k] = d->mocap_pos[3 * m->body_mocapid[b] + k];
+      for (int k = 0; k < 4; k++) bq[k] = d->mocap_quat[4 * m->body_mocapid[b] + k];
+    }
+    double Rb[9], Rg[9], R[9], gp[3];
+    quat2mat(bq, Rb);
+    quat2mat(m->geom_quat + 4 * g, Rg);
+    for (int i = 0; i < 3; i++) {
+      gp[i] = bp[i] + Rb[3 * i] * m->geom_pos[3 * g] + Rb[3 * i + 1] * m->geom_pos[3 * g + 1] + Rb[3 * i + 2] * m->geom_pos[3 * g + 2];
+      for (int j = 0; j < 3; j++) R[3 * i + j] = Rb[3 * i] * Rg[j] + Rb[3 * i + 1] * Rg[3 + j] + Rb[3 * i + 2] * Rg[6 + j];
+    }
+    const double* size = m->geom_size + 3 * g;
+    // ray in the geom frame: origin lo, direction ld (world direction (0, 0, -1))
+    double rel[3] = {o[0] - gp[0], o[1] - gp[1], o[2] - gp[2]}, lo[3], ld[3];
+    for (int j = 0; j < 3; j++) {
+      lo[j] = R[j] * rel[0] + R[3 + j] * rel[1] + R[6 + j] * rel[2];
+      ld[j] = -R[6 + j];
+    }
+    double dist = -1;
+    if (m->geom_type[g] == 0) {  // plane z = 0 (infinite when size is 0, else bounded)
+      if (ld[2] < -1e-15 && lo[2] > 0) {
+        const double t = -lo[2] / ld[2], x = lo[0] + t * ld[0], y = lo[1] + t * ld[1];
+        if ((size[0] <= 0 || std::fabs(x) <= size[0]) && (size[1] <= 0 || std::fabs(y) <= size[1])) dist = t;
+      }
+    } else if (m->geom_type[g] == 2) {  // sphere
+      const double bq2 = lo[0] * ld[0] + lo[1] * ld[1] + lo[2] * ld[2], c = lo[0] * lo[0] + lo[1] * lo[1] + lo[2] * lo[2] - size[0] * size[0];
+      const double disc = bq2 * bq2 - c;
+      if (disc >= 0) { const double t = -bq2 - std::sqrt(disc); if (t >= 0) dist = t; }
+    } else if (m->geom_type[g] == 6) {  // box: slabs
+      double tmin = -1e300, tmax = 1e300;
+      bool hit = true;
+      for (int j = 0; j < 3 && hit; j++) {
+        if (std::fabs(ld[j]) < 1e-15) { if (std::fabs(lo[j]) > size[j]) hit = false; continue; }
+        double t1 = (-size[j] - lo[j]) / ld[j], t2 = (size[j] - lo[j]) / ld[j];
+        if (t1 > t2) std::swap(t1, t2);
+        tmin = std::max(tmin, t1); tmax = std::min(tmax, t2);
+        if (tmin > tmax) hit = false;
+      }
+      if (hit && tmin >= 0) dist = tmin;
+    }
+    if (dist >= 0 && (best < 0 || dist < best)) best = dist;
+  }
+  if (best < 0) throw std::runtime_error("no group 0 geom detected by raycast");
+  return pos[2] + height_offset - best;
 }
 // Philox4x32-10 + Box-Muller as specified in include/mjpcx.h (the generator the device kernels use for candidate noise):
 // two standard normals for (seed, candidate, pair, iteration). Host planners that need the raw noise (SampleGradient) draw

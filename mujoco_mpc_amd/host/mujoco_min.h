@@ -71,6 +71,8 @@ struct mjModel {
 struct mjData {
   mjtNum time;
   mjtNum *qpos, *qvel, *act, *ctrl, *mocap_pos, *mocap_quat, *userdata, *sensordata;
+  // kinematics a Task::Transition may read (filled by the simulation; NULL when the caller has none):
+  mjtNum *xpos, *xquat, *xmat, *xipos, *site_xpos, *subtree_com, *subtree_linvel;
 };
 
 #define mjMAX(a, b) (((a) > (b)) ? (a) : (b))

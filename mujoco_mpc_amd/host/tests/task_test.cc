@@ -78,6 +78,88 @@ int main(int argc, char** argv) {
     CHECK(quad->parameters[4] == 0.45 && quad->parameters[2] == 2 && quad->parameters[3] == 0.03);  // duty, cadence, amplitude of Trot
     CHECK(quad->weight[4] == 0.2 && quad->weight[0] == 1 && quad->weight[1] == 1);                   // balance, upright, height
     CHECK_NEAR(rr[18], 2 * std::sqrt(2 * 9.81 * 0.3) / 9.81, 1e-12);                               // flight_time_
+    // ---- the kinematics-dependent parts of TransitionLocked, on synthetic mjData kinematics ----
+    mjModel* qm = qstorage->model();
+    const int torso = ri[1], head = ri[2], goal = ri[3];
+    std::vector<double> xpos(3 * qm->nbody, 0.0), xquat(4 * qm->nbody, 0.0), xmat(9 * qm->nbody, 0.0), com(3 * qm->nbody, 0.0),
+        linvel(3 * qm->nbody, 0.0), site(3 * qm->nsite, 0.0), mpos(3 * qm->nmocap, 0.0), mquat(4 * qm->nmocap, 0.0);
+    for (int b = 0; b < qm->nbody; b++) { xquat[4 * b] = 1; xmat[9 * b] = xmat[9 * b + 4] = xmat[9 * b + 8] = 1; }
+    for (int b = 0; b < qm->nbody; b++) if (qm->body_mocapid[b] >= 0) {
+      for (int k = 0; k < 3; k++) mpos[3 * qm->body_mocapid[b] + k] = qm->body_pos[3 * b + k];
+      mquat[4 * qm->body_mocapid[b]] = 1;
+    }
+    d.xpos = xpos.data(); d.xquat = xquat.data(); d.xmat = xmat.data(); d.subtree_com = com.data(); d.subtree_linvel = linvel.data();
+    d.site_xpos = site.data(); d.mocap_pos = mpos.data(); d.mocap_quat = mquat.data();
+    // Ground (utilities.cc:556-574) against the scene's group-0 geoms: floor plane, mocap box, tilted ramp, hill sphere
+    { const double p0[3] = {20, -20, 1}; CHECK_NEAR(Ground(qm, &d, p0), -0.01, 1e-12); }
+    { const double p0[3] = {-2.5, 0.2, 1}; CHECK_NEAR(Ground(qm, &d, p0), 0.3, 1e-12); }
+    { const double p0[3] = {3.13, 2.5, 0.6}; CHECK_NEAR(Ground(qm, &d, p0), -0.18 + 0.5 / std::cos(0.2), 1e-9); }
+    { const double p0[3] = {6, 6, 1}; CHECK_NEAR(Ground(qm, &d, p0), 0.5, 1e-12); }
+    // automatic gait switching: filtered COM speed 0 -> 0.632 -> 0.970 m/s selects Canter once kAutoGaitMinTime has passed
+    quad->Reset(qm);
+    CHECK(quad->parameters[1] == 1);  // Gait switch = Automatic in the XML
+    linvel[3 * torso] = 1.0;
+    d.time = 0.5; quad->Transition(qm, &d);
+    CHECK(quad->parameters[0] == 0);
+    d.time = 0.7; quad->Transition(qm, &d);
+    CHECK(quad->parameters[0] == 0);  // in the Canter range, but less than 1 s since the last switch (t = 0)
+    d.time = 1.2; quad->Transition(qm, &d);
+    quad->ResidualState(&ri, &rr);
+    CHECK(quad->parameters[0] == 3 && ri[8] == 3);
+    CHECK(quad->parameters[4] == 0.4 && quad->parameters[2] == 4 && quad->parameters[3] == 0.05);  // Canter duty, cadence, amplitude
+    d.time = 1.3; linvel[3 * torso] = 0.0; quad->Transition(qm, &d);
+    CHECK(quad->parameters[0] == 3);  // still waiting
+    // Walk: straight line, then a circle about the axis speed / angvel to the left of the torso
+    quad->parameters[1] = 0;
+    xpos[3 * torso] = 1; xpos[3 * torso + 1] = 2; xpos[3 * torso + 2] = 0.3;
+    mpos[3 * goal] = 3; mpos[3 * goal + 1] = 2;
+    quad->parameters[5] = 0.5; quad->parameters[6] = 0;
+    quad->mode = 2;
+    d.time = 2.0; quad->Transition(qm, &d);
+    quad->ResidualState(&ri, &rr);
+    CHECK(ri[0] == 2 && rr[0] == 2.0 && rr[1] == 1 && rr[2] == 2 && rr[4] == 2 && rr[5] == 0 && rr[6] == 0.5 && rr[7] == 0);
+    CHECK_NEAR(mpos[3 * goal], 3, 1e-15); CHECK_NEAR(mpos[3 * goal + 1], 2, 1e-15);
+    d.time = 3.0; quad->Transition(qm, &d);
+    CHECK_NEAR(mpos[3 * goal], 3.5, 1e-15); CHECK_NEAR(mpos[3 * goal + 1], 2, 1e-15);
+    quad->parameters[6] = 0.5;  // turn: the walk state resets, axis = torso + (speed / angvel) leftward = (1, 3)
+    d.time = 4.0; quad->Transition(qm, &d);
+    quad->ResidualState(&ri, &rr);
+    CHECK(rr[0] == 4.0 && rr[1] == 1 && rr[2] == 3 && rr[4] == 2.5 && rr[5] == -1 && rr[7] == 0.5);
+    d.time = 5.0; quad->Transition(qm, &d);
+    CHECK_NEAR(mpos[3 * goal], 1 + std::cos(0.5) * 2.5 + std::sin(0.5), 1e-14);
+    CHECK_NEAR(mpos[3 * goal + 1], 3 + std::sin(0.5) * 2.5 - std::cos(0.5), 1e-14);
+    // forbidden transition: Walk -> Flip falls back to Quadruped
+    quad->mode = 4;
+    d.time = 5.1; quad->Transition(qm, &d);
+    quad->ResidualState(&ri, &rr);
+    CHECK(quad->mode == 0 && ri[0] == 0);
+    // Flip from Quadruped: saves the weights and the gait switch, records orientation and ground height, and ends after
+    // jump + flight + land time with the goal under the head
+    quad->parameters[1] = 1;
+    d.time = 5.9; quad->Transition(qm, &d);  // automatic switching settles on Stand (filtered speed ~ 0) before the weights are saved
+    CHECK(quad->parameters[0] == 0);
+    std::vector<double> w0 = quad->weight;
+    com[3 * torso] = 6; com[3 * torso + 1] = 6; com[3 * torso + 2] = 0.8;
+    xquat[4 * torso] = 0.6; xquat[4 * torso + 3] = 0.8;
+    site[3 * head] = 6.2; site[3 * head + 1] = 6.1;
+    quad->mode = 4;
+    d.time = 6.0; quad->Transition(qm, &d);
+    quad->ResidualState(&ri, &rr);
+    CHECK(ri[0] == 4 && rr[0] == 6.0 && rr[9] == 0.6 && rr[12] == 0.8);
+    CHECK_NEAR(rr[8], 0.5, 1e-12);  // on top of the hill
+    CHECK(quad->weight[0] == 0.2 && quad->weight[1] == 5 && quad->weight[2] == 0 && quad->weight[3] == 0 && quad->weight[4] == 0);
+    CHECK(quad->weight[5] == 0.005 && quad->weight[6] == 0.1 && quad->parameters[1] == 0);
+    const double flip_total = rr[22] + rr[18] + rr[24];
+    d.time = 6.0 + 0.5 * flip_total; quad->Transition(qm, &d);
+    CHECK(quad->mode == 4);
+    d.time = 6.0 + flip_total + 1e-9; quad->Transition(qm, &d);
+    quad->ResidualState(&ri, &rr);
+    CHECK(quad->mode == 0 && ri[0] == 0 && quad->weight == w0 && quad->parameters[1] == 1);
+    CHECK(mpos[3 * goal] == 6.2 && mpos[3 * goal + 1] == 6.1);
+    // mjData reset (time going backwards) restarts the phase clock
+    d.time = 0.1; quad->Transition(qm, &d);
+    quad->ResidualState(&ri, &rr);
+    CHECK(rr[13] == 0.1 && rr[14] == 0.1);
   }
   if (argc > 4) {  // humanoid::Tracking: cost parse, marker ids, Transition (tracking.cc:219-264) and the frozen residual copy
     auto hstorage = ModelStorage::Load(argv[4]);

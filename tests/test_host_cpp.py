@@ -61,6 +61,15 @@ def test_testspeed_app(blobs):
     assert "Average cost per step" in out
 
 
+@pytest.mark.gpu
+def test_testspeed_app_quadruped_transition_reads_device_kinematics(blobs):
+    """QuadrupedFlat::TransitionLocked (quadruped.cc:229-391) runs every simulation step on mjData kinematics fetched through
+    mjpcx_kinematics (automatic gait switching is on in the task XML)"""
+    out = run("testspeed_app", "--task=QuadrupedFlat", "--total_time=0.2", "--steps_per_planning_iteration=10",
+              f"--model_dir={blobs}", "--candidates=64")
+    assert "Average cost per step" in out
+
+
 def test_host_normal_generator_equals_the_oracle_stream(blobs):
     """HostGaussianPair (mjpc/utilities.h: Philox4x32-10 + Box-Muller) draws what the device and the oracle draw"""
     import ctypes as C
