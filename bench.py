@@ -184,8 +184,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": avg_kernel_s * 1e3, "bytes_per_launch": bytes_per_launch,
-                         "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time on the context's stream; "
-                                 "the kernel is fp64-latency-bound at this batch size, see DESIGN.md"},
+                         "note": "algorithmic bytes (SURVEY 8d) / HIP-event time of one rollout on the context's stream "
+                                 "(lane-per-candidate models: its three launches -- time loop, sensor stage, returns; "
+                                 "profiles/ lists each); issue/latency-bound at this batch size, see DESIGN.md"},
         }
         # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
         # collected in separate --pmc runs as MI355X_MICROARCH.md prescribes); only for the profiled workload

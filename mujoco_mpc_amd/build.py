@@ -32,7 +32,10 @@ def _stale(target, deps):
 def build_native(force=False, verbose=False):
     from . import codegen
     codegen.main([])  # regenerate generated/static_models.h if the model XMLs changed
-    deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS]
+    import glob
+    # every header of csrc/ is a dependency of both translation units (the wave_*.h / ilqg_*.h files are included by mjpcx.hip)
+    deps = sorted(set([os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS] +
+                      glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "generated", "*.h"))))
     if not force and not _stale(LIB, deps):
         return LIB
     objdir = os.path.join(PKG_DIR, "build")

@@ -3,6 +3,7 @@
 // their own translation unit (lane_static.hip) built with -fno-signed-zeros -ffinite-math-only so
 // that arithmetic on exact-zero model constants folds away.
 #pragma once
+#include <cstdlib>
 #include "../../include/mjpcx.h"
 #include "generated/static_models.h"
 #include "ilqg_kernels.h"
@@ -31,7 +32,16 @@ hipError_t launch_lane_impl(const LaneModel<T>& m, const LaneTask<T>& tk, const 
   static_assert(sizeof(LaneModel<T>) + sizeof(LaneTask<T>) + sizeof(RolloutArgs<T>) <= 4096, "kernarg segment is 4 KiB");
   const int blocks = (a.N + 63) / 64;
   const size_t shmem = ((size_t)a.P * TP::NU * 64 + a.P) * sizeof(T);
-  hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
+  static const bool fused = std::getenv("MJPCX_LANE_FUSED") != nullptr;  // the single-launch form, for A/B measurements
+  if (fused) {
+    hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC, false>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
+    return hipGetLastError();
+  }
+  // time loop (dynamics only) -> sensor stage of every (step, candidate) -> ordered returns; see rollout_lane_kernel
+  hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC, true>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
+  const size_t items = (size_t)a.N * a.H;
+  hipLaunchKernelGGL((cost_lane_kernel<TP, TK, T, MC>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, m, tk, a);
+  hipLaunchKernelGGL((return_lane_kernel<T>), dim3(blocks), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

@@ -586,6 +586,21 @@ __device__ __forceinline__ void lane_record(const RolloutArgs<T>& a, int t, int 
   if (!bad) a.costs[base] = cost;
 }
 
+template <class TP, typename T>
+__device__ __forceinline__ void lane_record_state(const RolloutArgs<T>& a, int t, int cand, const T (&qpos)[TP::NV],
+                                                  const T (&qvel)[TP::NV], const T (&ctrl)[TP::NU], T time) {
+  constexpr int NV = TP::NV, NU = TP::NU, DS = 2 * NV;
+  const size_t N = (size_t)a.N;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    a.states[((size_t)t * DS + i) * N + cand] = qpos[i];
+    a.states[((size_t)t * DS + NV + i) * N + cand] = qvel[i];
+  }
+#pragma unroll
+  for (int k = 0; k < NU; k++) a.actions[((size_t)t * NU + k) * N + cand] = ctrl[k];
+  a.times[(size_t)t * N + cand] = time;
+}
+
 // Where the model's numeric constants come from:
 //   RuntimeModel  - the kernel-argument copy (general path: any model with this topology)
 //   StaticXxx     - a generated constexpr object (generated/static_models.h): every constant is an
@@ -601,7 +616,12 @@ struct StaticModel {  // returns the constexpr object BY VALUE: a local constant
 };
 
 // ------------------------------------------------------------------ the kernel
-template <class TP, class TK, typename T, class MC>
+// SPLIT = true is the first of three launches (launch_lane_impl): the time loop keeps only what the NEXT step depends on --
+// policy, mj_forward, mj_Euler -- and records states / actions / times; the residual, the cost, the traces
+// (cost_lane_kernel: one lane per (step, candidate), no serial dependence) and the ordered sum over the horizon
+// (return_lane_kernel) run afterwards at full occupancy. With 64 wavefronts of one candidate per lane the loop is bound by
+// its instruction count, and the sensor stage was ~40 % of it. `failure` carries (first bad step + 1) between the launches.
+template <class TP, class TK, typename T, class MC, bool SPLIT = false>
 __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_karg, const LaneTask<T> tk,
                                                            const RolloutArgs<T> a) {
   decltype(auto) m = MC::template get<T>(m_karg);
@@ -675,6 +695,8 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
 
   // spline segment cache
   int up = 0, cached_up = -1;
+  const T kTimeInf = T(3.0e38);
+  T t_next = P > 0 ? ltimes[0] : kTimeInf;
   T sp0[NU], sp1[NU], sm0[NU], sm1[NU];
 #pragma unroll
   for (int k = 0; k < NU; k++) sp0[k] = sp1[k] = sm0[k] = sm1[k] = 0;
@@ -682,13 +704,16 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
 
   double total = 0;
   bool failed = false;
+  int first_bad = 0;
 
   for (int t = 0; t < H; t++) {
     const bool last = (t == H - 1);
     bool bad_ctrl = false;
     // ================= policy: TimeSpline::Sample + Clamp (spline.cc:103-156, policy.cc:52-59)
     if (!last) {
-      while (up < P && ltimes[up] <= time) up++;  // upper_bound; time is wave-uniform
+      // upper_bound; time is wave-uniform. The next node time sits in a register (t_next = ltimes[up], +inf past the end), so a
+      // step inside a segment touches no LDS
+      while (t_next <= time) { up++; t_next = up < P ? ltimes[up] : kTimeInf; }
       if (up != cached_up) {
         cached_up = up;
         const int lo = up - 1;
@@ -769,15 +794,20 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
       for (int i = 0; i < NV; i++) bad |= is_bad(qacc[i]);
     }
 
-    // ================= sensor stage: task residual (mjcb_sensor at mjSTAGE_ACC), cost
-    T r[NR];
-    lane_residual<TP, TK, T>(tk, qpos, qvel, ctrl, r);
-    T cost = lane_cost<TK, T>(tk, r);  // task.cc:71-110
+    if constexpr (SPLIT) {
+      if (live && !failed) lane_record_state<TP, T>(a, t, cand, qpos, qvel, ctrl, time);
+      if (bad && !failed) { failed = true; first_bad = t + 1; }
+    } else {
+      // ================= sensor stage: task residual (mjcb_sensor at mjSTAGE_ACC), cost
+      T r[NR];
+      lane_residual<TP, TK, T>(tk, qpos, qvel, ctrl, r);
+      T cost = lane_cost<TK, T>(tk, r);  // task.cc:71-110
 
-    // ================= record step t: coalesced [t][field][candidate] stores
-    if (live && !failed) lane_record<TP, TK, T>(a, t, cand, qpos, qvel, ctrl, time, r, site_xpos, cost, bad);
-    if (bad) failed = true;  // CheckWarnings -> abort (trajectory.cc:169-173)
-    total += (double)cost;
+      // ================= record step t: coalesced [t][field][candidate] stores
+      if (live && !failed) lane_record<TP, TK, T>(a, t, cand, qpos, qvel, ctrl, time, r, site_xpos, cost, bad);
+      if (bad) failed = true;  // CheckWarnings -> abort (trajectory.cc:169-173)
+      total += (double)cost;
+    }
     if (last) break;
 
     // ================= mj_Euler (implicit joint damping) + advance
@@ -786,9 +816,73 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
   }
 
   if (live) {
-    a.total_return[cand] = failed ? kMaxReturn : total / (double)(H > 1 ? H : 1);
-    a.failure[cand] = failed ? 1 : 0;
+    if constexpr (SPLIT) {
+      a.failure[cand] = first_bad;
+    } else {
+      a.total_return[cand] = failed ? kMaxReturn : total / (double)(H > 1 ? H : 1);
+      a.failure[cand] = failed ? 1 : 0;
+    }
   }
+}
+
+// Second launch of the split rollout: the sensor stage of step t of candidate c for every (t, c) at once. Reads the recorded
+// state / action, redoes the position stage (what remains of lane_forward once only site_xpos is used), evaluates the residual
+// and the cost exactly as the fused loop does, and applies its recording rules: nothing after the first bad step, no cost AT it.
+template <class TP, class TK, typename T, class MC>
+__global__ __launch_bounds__(256) void cost_lane_kernel(const LaneModel<T> m_karg, const LaneTask<T> tk, const RolloutArgs<T> a) {
+  decltype(auto) m = MC::template get<T>(m_karg);
+  constexpr int NV = TP::NV, NU = TP::NU, NS = TP::NSITE, NR = TK::NR, NTR = TK::NTRACE, DS = 2 * NV;
+  const size_t N = (size_t)a.N;
+  const size_t item = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (item >= N * (size_t)a.H) return;
+  const int t = (int)(item / N), cand = (int)(item - (size_t)t * N);
+  const int fb = a.failure[cand];
+  if (fb && t > fb - 1) return;
+  T qpos[NV], qvel[NV], ctrl[NU];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    qpos[i] = a.states[((size_t)t * DS + i) * N + cand];
+    qvel[i] = a.states[((size_t)t * DS + NV + i) * N + cand];
+  }
+#pragma unroll
+  for (int k = 0; k < NU; k++) ctrl[k] = a.actions[((size_t)t * NU + k) * N + cand];
+  T qacc[NV], qfrc[NV], qfrc_c[NV], M[NV][NV];
+  T site_xpos[NS > 0 ? NS : 1][3];
+  lane_forward<TP, T>(m, tk, qpos, qvel, ctrl, qacc, qfrc, qfrc_c, M, site_xpos);
+  T r[NR];
+  lane_residual<TP, TK, T>(tk, qpos, qvel, ctrl, r);
+  const T cost = lane_cost<TK, T>(tk, r);
+#pragma unroll
+  for (int i = 0; i < NR; i++) a.residual[((size_t)t * NR + i) * N + cand] = r[i];
+#pragma unroll
+  for (int k = 0; k < NTR; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) a.trace[((size_t)t * 3 * NTR + 3 * k + c) * N + cand] = site_xpos[TK::trace_site(k)][c];
+  if (!(fb && t == fb - 1)) a.costs[item] = cost;
+}
+
+// Third launch: Trajectory::total_return = sum of the step costs in step order (the fused loop's order, so the same bits),
+// divided by the horizon (trajectory.cc:203-207); kMaxReturn and failure = 1 for a failed rollout.
+template <typename T>
+__global__ __launch_bounds__(64) void return_lane_kernel(const RolloutArgs<T> a) {
+  const int cand = blockIdx.x * 64 + threadIdx.x;
+  if (cand >= a.N) return;
+  const int fb = a.failure[cand];
+  double total = 0;
+  if (!fb) {
+    // loads in batches of 32 (independent, one latency per batch), additions in step order
+    int t = 0;
+    for (; t + 32 <= a.H; t += 32) {
+      T c[32];
+#pragma unroll
+      for (int i = 0; i < 32; i++) c[i] = a.costs[(size_t)(t + i) * a.N + cand];
+#pragma unroll
+      for (int i = 0; i < 32; i++) total += (double)c[i];
+    }
+    for (; t < a.H; t++) total += (double)a.costs[(size_t)t * a.N + cand];
+  }
+  a.total_return[cand] = fb ? kMaxReturn : total / (double)(a.H > 1 ? a.H : 1);
+  a.failure[cand] = fb ? 1 : 0;
 }
 
 }  // namespace mjpcx

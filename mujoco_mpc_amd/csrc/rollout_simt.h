@@ -772,10 +772,10 @@ __device__ __forceinline__ void simt_newton(const WaveModel& m, const SimtData& 
     }
   }
   const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
-  bool polish = false, done = false;
+  double improvement = 0;
   // every lane runs the same number of trips as the slowest lane of its wavefront would anyway (SIMT); a finished
   // lane just stops updating
-  for (int iter = 0; iter < m.solver_iterations && !done; iter++) {
+  for (int iter = 0; iter < m.solver_iterations; iter++) {
     double gnorm = 0;
     for (int a = 0; a < nv; a++) {
       double s = 0;
@@ -788,6 +788,7 @@ __device__ __forceinline__ void simt_newton(const WaveModel& m, const SimtData& 
     }
     gnorm = sqrt(gnorm);
     if (gnorm == 0) break;
+    if (iter > 0 && (scale * improvement < m.solver_tolerance || scale * gnorm < m.solver_tolerance)) break;  // MuJoCo's order
     simt_hessian(m, d, ne);
     if (!simt_chol(d, o.L, o.H, nv)) { warning |= 16; break; }
     for (int a = 0; a < nv; a++) d.at(o.search, a) = -d.at(o.grad, a);
@@ -831,10 +832,8 @@ __device__ __forceinline__ void simt_newton(const WaveModel& m, const SimtData& 
       gauss += 0.5 * s * (d.at(o.qacc, a) - d.at(o.qacc_smooth, a));
     }
     const double newcost = gauss + simt_rows<true, false>(d, ne, 0.0, g1, h2);
-    const double improvement = cost - newcost;
+    improvement = cost - newcost;
     cost = newcost;
-    if (polish) done = true;
-    else if (scale * improvement < m.solver_tolerance || scale * gnorm < m.solver_tolerance) polish = true;
   }
   for (int c = 0; c < nv; c++) {
     double s = 0;

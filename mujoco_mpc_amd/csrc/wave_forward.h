@@ -1044,7 +1044,8 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     }
   }
   const wreal scale = WL(1.0) / (m.meaninertia * (nv > 1 ? nv : 1));
-  bool polish = false, factor_valid = false, refresh = true;
+  bool factor_valid = false, refresh = true;
+  wreal improvement = 0;
   const int my_type = lane < ne ? d.efc_type[lane] : -1;
   int my_zone_prev = -2;
   long long tacc = 0;
@@ -1066,6 +1067,13 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     }
     const wreal gnorm = sqrt(wave_sum(lane < nv ? g * g : WL(0.0)));
     if (gnorm == 0) break;
+    // termination as in MuJoCo's primal solvers (engine_solver.c): the test uses the gradient AFTER the update, so it sits
+    // between the gradient and the Hessian work of the next pass. float: tolerance floored at what float resolves of a cost
+    // of this size
+    {
+      const wreal tol = sizeof(wreal) == 4 ? fmax((wreal)m.solver_tolerance, WL(1e-7)) : (wreal)m.solver_tolerance;
+      if (iter > 0 && (scale * improvement < tol || scale * gnorm < tol)) break;
+    }
     if (stamp && lane == 0 && iter == 0) stamp[21] = (long long)__builtin_readcyclecounter();
     WACC(32);
     // H = M + J' (d2s) J depends on the rows' zones only -- and on jar for a cone in its middle (sliding) zone. When no row
@@ -1275,15 +1283,10 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     }
     gauss = wave_sum(gauss);
     const wreal newcost = gauss + wf_constraint_cost(d, ne, lane);
-    const wreal improvement = cost - newcost;
+    improvement = cost - newcost;
     cost = newcost;
     WACC(38);
     if (stamp && lane == 0) stamp[20] = iter + 1;
-    if (polish) break;
-    // float: stop where MuJoCo stops (the extra polishing iteration only serves the 1e-9 agreement of the fp64 paths), with the
-    // tolerance floored at what float resolves of a cost of this size
-    const wreal tol = sizeof(wreal) == 4 ? fmax((wreal)m.solver_tolerance, WL(1e-7)) : (wreal)m.solver_tolerance;
-    if (scale * improvement < tol || scale * gnorm < tol) { if (sizeof(wreal) == 4) break; polish = true; }
   }
   if (lane < nv) {
     wreal s = 0;
