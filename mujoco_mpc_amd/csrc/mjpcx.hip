@@ -508,6 +508,7 @@ void print_wave_stamps(mjpcx_ctx* c, long long* stamps, int stamp_step, size_t l
                h[23] - h[22], h[24] - h[23]);
   std::fprintf(stderr, "  newton totals over iterations: grad %lld coneblocks %lld hess %lld chol+solve %lld jv+q %lld linesearch %lld (%lld trials) update+cost %lld\n",
                h[32], h[33], h[34], h[35], h[36], h[37], h[39], h[38]);
+  std::fprintf(stderr, "  hessian parts: copy M %lld diagonal rows %lld row facts %lld simple rows (MFMA) %lld cones = hess - these\n", h[40], h[41], h[42], h[43]);
 }
 
 template <typename T>

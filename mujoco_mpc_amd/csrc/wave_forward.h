@@ -1132,6 +1132,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     // of its body (dofmask), which skips ~3/4 of the (entry, contact) pairs on a legged robot.
     for (int e = lane; e < nv * nv; e += 64) d.H[e] = d.M[e];
     WSYNC();
+    WACC(40);
     for (int pass = 0; pass < 2; pass++) {
       if (lane < ne) {
         const int t = d.efc_type[lane];
@@ -1145,6 +1146,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
     // Per-row facts in registers, lane = row, fetched in the entry loop by v_readlane (no dependent LDS chain per row
     // visit): kind 0 = nothing to add (inactive, cone member row, diagonal-only row), 1 = active simple inequality row
     // (frictionless contact, pyramid edge, tendon limit), 2 = head of an elliptic cone outside the top zone.
+    WACC(41);
     int my_kind = 0, my_id = 0, my_dim = 1;
     unsigned my_mask = 0;
     wreal my_D = 0;
@@ -1158,6 +1160,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
       }
     }
     const unsigned long long simple_rows = __ballot(my_kind == 1), cone_rows = __ballot(my_kind == 2);
+    WACC(42);
     if (simple_rows) {  // (nothing to add on a step whose only active rows are cones and diagonal rows)
       // Simple inequality rows (frictionless contacts, pyramid edges, tendon limits): H += J' diag(s) J with s_r = D_r on the
       // active rows and 0 elsewhere -- a (nv x ne)(ne x nv) product on the matrix cores, 16 x 16 output tiles, K = 4 rows per
@@ -1188,6 +1191,7 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
         }
     }
     WSYNC();
+    WACC(43);
     // elliptic cones, one at a time (in row order): the cone's block J_c' Hc J_c only touches the nd <= ~15 dofs of its chains,
     // so one lane per entry of that nd x nd triangle adds its contribution into H. (The entry-major loop above left lanes
     // holding trunk entries with one update per cone while most other lanes idled.)
