@@ -1,5 +1,6 @@
 #include "agent.h"
 
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <sstream>
@@ -84,16 +85,49 @@ void Agent::Plan(std::atomic<bool>& exitrequest, std::atomic<int>& uiloadrequest
 int Agent::GetTaskIdByName(std::string_view name) const {
   for (size_t i = 0; i < tasks_.size(); i++)
     if (tasks_[i]->Name() == name) return (int)i;
+  for (size_t i = 0; i < tasks_.size(); i++)  // the spelling without spaces (model file names, the Python registry)
+    if (SameTaskName(tasks_[i]->Name(), name)) return (int)i;
   return -1;
 }
 
+namespace {
+bool StartsWith(std::string_view s, std::string_view p) { return s.substr(0, p.size()) == p; }
+bool EqualsIgnoreCase(std::string_view a, std::string_view b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); i++)
+    if (std::tolower((unsigned char)a[i]) != std::tolower((unsigned char)b[i])) return false;
+  return true;
+}
+}  // namespace
+
+// agent.cc:395-419: name with or without the "residual_" prefix, compared ignoring case; returns the numeric's id
 int Agent::SetParamByName(std::string_view name, double value) {
-  const std::string full = "residual_" + std::string(name);
+  if (StartsWith(name, "residual_")) name.remove_prefix(9);
+  if (StartsWith(name, "selection_")) return -1;  // SetSelectionParamByName is the interface for those
   int shift = 0;
   for (int i = 0; i < model_->nnumeric; i++) {
-    const std::string n = model_->names + model_->name_numericadr[i];
-    if (n.rfind("residual_", 0) != 0) continue;
-    if (n == full) { ActiveTask()->parameters[shift] = value; return shift; }
+    const std::string_view n(model_->names + model_->name_numericadr[i]);
+    if (!StartsWith(n, "residual_")) continue;
+    if (EqualsIgnoreCase(n.substr(9), name)) { ActiveTask()->parameters[shift] = value; return i; }
+    shift++;
+  }
+  return -1;
+}
+
+// agent.cc:421-444. The parameter slot is the position among ALL "residual_" numerics, which is how Task::parameters is laid
+// out (task.cc:225-243); the reference counts only the "residual_select_" ones before it and so writes the wrong slot when a
+// plain parameter precedes the selection.
+int Agent::SetSelectionParamByName(std::string_view name, std::string_view value) {
+  if (StartsWith(name, "residual_select_")) name.remove_prefix(16);
+  if (StartsWith(name, "selection_")) name.remove_prefix(10);
+  int shift = 0;
+  for (int i = 0; i < model_->nnumeric; i++) {
+    const std::string_view n(model_->names + model_->name_numericadr[i]);
+    if (!StartsWith(n, "residual_")) continue;
+    if (StartsWith(n, "residual_select_") && EqualsIgnoreCase(n.substr(16), name)) {
+      ActiveTask()->parameters[shift] = ResidualParameterFromSelection(model_, n.substr(16), value);
+      return i;
+    }
     shift++;
   }
   return -1;
@@ -102,14 +136,29 @@ int Agent::SetParamByName(std::string_view name, double value) {
 int Agent::SetWeightByName(std::string_view name, double value) {
   Task* t = ActiveTask();
   for (int i = 0; i < t->num_term; i++)
-    if (t->weight_names[i] == name) { t->weight[i] = value; return i; }
+    if (EqualsIgnoreCase(t->weight_names[i], name)) { t->weight[i] = value; return i; }
   return -1;
 }
 
+std::vector<std::string> Agent::GetAllModeNames() const {
+  if (const char* transition = GetCustomTextData(model_, "task_transition")) return SplitBar(transition, true);
+  return {"default_mode"};
+}
+
+std::string Agent::GetModeName() const {
+  const std::vector<std::string> names = GetAllModeNames();
+  const int mode = ActiveTask()->mode;
+  return mode >= 0 && mode < (int)names.size() ? names[mode] : "";
+}
+
 int Agent::SetModeByName(std::string_view name) {
-  // the mode list is the '|'-separated custom text "task_transition"; this build's model blob carries no text fields,
-  // so modes are resolved from the registered task's own list when it provides one
-  (void)name;
+  if (GetCustomTextData(model_, "task_transition")) {
+    const std::vector<std::string> names = GetAllModeNames();
+    for (size_t i = 0; i < names.size(); i++)
+      if (names[i] == name) { ActiveTask()->mode = (int)i; return (int)i; }
+    return -1;
+  }
+  if (name == "default_mode") { ActiveTask()->mode = 0; return 0; }
   return -1;
 }
 

@@ -39,7 +39,11 @@ class Agent {
   void SetPlanner(int planner) { planner_ = planner; }
   int SetParamByName(std::string_view name, double value);   // "residual_<name>" numerics (agent.cc:1016-1030)
   int SetWeightByName(std::string_view name, double value);  // cost-term weights (agent.cc:1061-1075)
-  int SetModeByName(std::string_view name);                  // task_transition entries (agent.cc:1078-1092)
+  int SetModeByName(std::string_view name);                  // task_transition entries (agent.cc:472-490)
+  int SetSelectionParamByName(std::string_view name, std::string_view value);  // drop-down parameters (agent.cc:421-444)
+  std::vector<std::string> GetAllModeNames() const;          // agent.cc:458-465
+  std::string GetModeName() const;                           // agent.cc:467-470
+  mjModel* GetModel() const { return model_; }
 
   State state;
   bool plan_enabled = true, action_enabled = true, allocate_enabled = false;

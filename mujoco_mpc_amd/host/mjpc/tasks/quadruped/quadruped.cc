@@ -24,7 +24,7 @@ int ParameterIndex(const mjModel* model, const std::string& name) {  // utilitie
 }
 }  // namespace
 
-std::string QuadrupedFlat::Name() const { return "QuadrupedFlat"; }
+std::string QuadrupedFlat::Name() const { return "Quadruped Flat"; }  // quadruped.cc:31
 std::string QuadrupedFlat::XmlPath() const { return "quadruped/task_flat.xml"; }
 int QuadrupedFlat::DeviceResidualId() const { return MJPCX_RESIDUAL_QUADRUPED_FLAT; }
 

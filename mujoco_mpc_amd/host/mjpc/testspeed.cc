@@ -19,7 +19,7 @@ double SynchronousPlanningCost(std::string task_name, int planner_thread_count, 
                                double total_time, const TestSpeedOptions& opt) {
   std::shared_ptr<Task> task;
   for (auto& t : GetTasks())
-    if (t->Name() == task_name) task = t;
+    if (SameTaskName(t->Name(), task_name)) task = t;
   if (!task) {
     std::cerr << "Invalid --task flag: '" << task_name << "'. Valid values:\n";
     for (auto& t : GetTasks()) std::cerr << "  " << t->Name() << "\n";

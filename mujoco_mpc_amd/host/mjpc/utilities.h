@@ -2,6 +2,7 @@
 #pragma once
 #include <stdexcept>
 #include <algorithm>
+#include <string>
 #include <cstdint>
 #include <chrono>
 #include <cmath>
@@ -14,6 +15,48 @@
 namespace mjpc {
 
 // custom <numeric> lookup, utilities.h:40-68
+// task names compared with spaces removed: "QuadrupedFlat" (model file / Python registry spelling) == "Quadruped Flat"
+inline bool SameTaskName(std::string_view a, std::string_view b) {
+  std::string x(a), y(b);
+  x.erase(std::remove(x.begin(), x.end(), ' '), x.end());
+  y.erase(std::remove(y.begin(), y.end(), ' '), y.end());
+  return x == y;
+}
+// custom text field by name (utilities.cc:186-198); nullptr if the model has none of that name
+inline char* GetCustomTextData(const mjModel* m, std::string_view name) {
+  for (int i = 0; i < m->ntext; i++)
+    if (name == std::string_view(m->names + m->name_textadr[i])) return m->text_data + m->text_adr[i];
+  return nullptr;
+}
+inline std::vector<std::string> SplitBar(std::string_view s, bool skip_empty) {
+  std::vector<std::string> out;
+  size_t b = 0;
+  while (b <= s.size()) {
+    size_t e = s.find('|', b);
+    if (e == std::string_view::npos) e = s.size();
+    if (e > b || !skip_empty) out.emplace_back(s.substr(b, e - b));
+    b = e + 1;
+  }
+  return out;
+}
+// drop-down selections (utilities.cc:142-181): "residual_select_<name>" holds the index into the '|'-separated custom text
+// "residual_list_<name>". This build keeps the index as a plain number in Task::parameters (the reference stores the bits of an
+// int64 in the double); the by-name interfaces below exchange the option strings, so the difference is not observable.
+inline std::string ResidualSelection(const mjModel* m, std::string_view name, double residual_parameter) {
+  const char* options = GetCustomTextData(m, "residual_list_" + std::string(name));
+  if (!options) return "";
+  const std::vector<std::string> v = SplitBar(options, false);
+  const int i = (int)residual_parameter;
+  return i >= 0 && i < (int)v.size() ? v[i] : "";
+}
+inline double ResidualParameterFromSelection(const mjModel* m, std::string_view name, std::string_view value) {
+  const char* options = GetCustomTextData(m, "residual_list_" + std::string(name));
+  if (!options) return 0;
+  const std::vector<std::string> v = SplitBar(options, false);
+  for (size_t i = 0; i < v.size(); i++) if (v[i] == value) return (double)i;
+  return 0;
+}
+
 inline double* GetCustomNumericData(const mjModel* m, std::string_view name) {
   for (int i = 0; i < m->nnumeric; i++)
     if (name == std::string_view(m->names + m->name_numericadr[i])) return m->numeric_data + m->numeric_adr[i];

@@ -123,6 +123,8 @@ void ModelStorage::Bind() {
     m.wrap_type = wt.data();
   }
   BR(key_mpos, (size_t)m.nkey * 3 * m.nmocap);
+  BI(text_adr, m.ntext); BI(text_size, m.ntext); BI(name_textadr, m.ntext);
+  m.text_data = reinterpret_cast<char*>(B("text_data", 0));
   m.names = reinterpret_cast<char*>(B("names", 1));
 #undef BI
 #undef BR

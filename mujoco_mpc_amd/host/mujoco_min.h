@@ -64,7 +64,9 @@ struct mjModel {
   int *tendon_adr, *tendon_num, *wrap_type, *wrap_objid, *exclude_signature;
   mjtByte* tendon_limited;
   mjtNum *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
-  int *name_bodyadr, *name_jntadr, *name_siteadr, *name_sensoradr, *name_numericadr, *name_keyadr, *name_geomadr;
+  int *name_bodyadr, *name_jntadr, *name_siteadr, *name_sensoradr, *name_numericadr, *name_keyadr, *name_geomadr, *name_textadr;
+  int *text_adr, *text_size;  // custom text fields: zero-terminated strings in text_data
+  char* text_data;
   char* names;
 };
 
@@ -78,6 +80,8 @@ struct mjData {
 #define mjMAX(a, b) (((a) > (b)) ? (a) : (b))
 #define mjMIN(a, b) (((a) < (b)) ? (a) : (b))
 inline void mju_copy(mjtNum* dst, const mjtNum* src, int n) { if (n > 0) std::memcpy(dst, src, sizeof(mjtNum) * n); }
+inline void mju_addTo(mjtNum* res, const mjtNum* vec, int n) { for (int i = 0; i < n; i++) res[i] += vec[i]; }
+inline void mju_scl(mjtNum* res, const mjtNum* vec, mjtNum scl, int n) { for (int i = 0; i < n; i++) res[i] = vec[i] * scl; }
 inline void mju_zero(mjtNum* dst, int n) { if (n > 0) std::memset(dst, 0, sizeof(mjtNum) * n); }
 inline mjtNum mju_max(mjtNum a, mjtNum b) { return a > b ? a : b; }
 inline mjtNum mju_min(mjtNum a, mjtNum b) { return a < b ? a : b; }

@@ -43,7 +43,7 @@ void* mjpc_planner_create_kind(const char* kind, const char* blob_path, const ch
     auto h = std::make_unique<Handle>();
     h->storage = mjpc::ModelStorage::Load(blob_path);
     for (auto& t : mjpc::GetTasks())
-      if (t->Name() == task_name || (t->Name() == "Humanoid Track" && std::string(task_name) == "HumanoidTrack")) h->task = t;
+      if (mjpc::SameTaskName(t->Name(), task_name)) h->task = t;
     if (!h->task) { g_error = std::string("unknown task ") + task_name; return nullptr; }
     h->task->Reset(h->storage->model());
     const std::string k = kind ? kind : "sampling";

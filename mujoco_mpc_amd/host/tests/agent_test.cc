@@ -1,6 +1,7 @@
 // mjpc/test/agent/agent_test.cc in spirit: an Agent constructed on a task plans (PlanIteration), its action becomes
 // non-trivial, and the by-name setters reach the task. argv[1] = directory with Particle.mjpx / Cartpole.mjpx /
 // QuadrupedFlat.mjpx. Needs a GPU (the planners have no CPU path).
+#include <algorithm>
 #include <cmath>
 #include <string>
 
@@ -23,15 +24,17 @@ int main(int argc, char** argv) {
     CHECK(planners[kSampleGradientPlanner] != nullptr);
     CHECK(planners[kRobustPlanner] != nullptr);  // RobustPlanner over a GpuSamplingPlanner delegate
   }
-  for (const char* name : {"Particle", "Cartpole", "QuadrupedFlat"}) {
-    auto storage = ModelStorage::Load(dir + "/" + name + ".mjpx");
+  for (const char* name : {"Particle", "Cartpole", "Quadruped Flat"}) {
+    std::string file = name;
+    file.erase(std::remove(file.begin(), file.end(), ' '), file.end());
+    auto storage = ModelStorage::Load(dir + "/" + file + ".mjpx");
     std::shared_ptr<Task> task;
     for (auto& t : GetTasks()) if (t->Name() == name) task = t;
     CHECK(task != nullptr);
     Agent agent;
     agent.SetTaskList({task});
     agent.Initialize(storage->model());
-    if (std::string(name) == "QuadrupedFlat") agent.SetPlanner(kCrossEntropyPlanner);  // its XML asks for iLQG (not yet on contact models)
+    if (std::string(name) == "Quadruped Flat") agent.SetPlanner(kCrossEntropyPlanner);  // its XML asks for iLQG (not yet on contact models)
     agent.Allocate();
     agent.Reset();
     const mjModel* m = storage->model();

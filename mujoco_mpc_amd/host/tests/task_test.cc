@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
   if (argc > 3) {  // QuadrupedFlat: ResetLocked ids, Transition state and the frozen residual copy (quadruped.cc:229-391, 520-607)
     auto qstorage = ModelStorage::Load(argv[3]);
     std::shared_ptr<Task> quad;
-    for (auto& t : GetTasks()) if (t->Name() == "QuadrupedFlat") quad = t;
+    for (auto& t : GetTasks()) if (t->Name() == "Quadruped Flat") quad = t;
     CHECK(quad != nullptr);
     quad->Reset(qstorage->model());
     CHECK(quad->num_term == 9 && quad->num_residual == 42 && quad->num_trace == 1 && quad->parameters.size() == 11);

@@ -912,6 +912,13 @@ def save_blob(fm: FlatModel, path: str):
     put_i("name_bodyadr", name_table(fm.names["body"])); put_i("name_jntadr", name_table(fm.names["joint"]))
     put_i("name_siteadr", name_table(fm.names["site"])); put_i("name_sensoradr", name_table(fm.names["sensor"]))
     put_i("name_numericadr", name_table(list(fm.numeric.keys()))); put_i("name_keyadr", name_table([k[0] for k in keys]))
+    # custom text (mjModel.text_adr / text_size / text_data: zero-terminated strings; task_transition, residual_list_*)
+    tadr, tsize, tdata = [], [], bytearray()
+    for v in fm.text.values():
+        b = v.encode() + b"\0"
+        tadr.append(len(tdata)); tsize.append(len(b)); tdata.extend(b)
+    put_i("text_adr", tadr); put_i("text_size", tsize); put_b("text_data", np.frombuffer(bytes(tdata), dtype=np.uint8))
+    put_i("name_textadr", name_table(list(fm.text.keys())))
     put_i("name_geomadr", name_table(fm.names.get("geom", [])))
     put_b("names", np.frombuffer(bytes(names) or b"\0", dtype=np.uint8))
     with open(path, "wb") as f:
