@@ -15,6 +15,9 @@
  *     against MuJoCo itself. It is validated by analytic checks (closed-form
  *     cart-pole dynamics, energy conservation, free fall, pendulum period) and
  *     the reference's behavioural tests (rollout_test.cc).
+ *   - capacity: OMAXEFC = 64 constraint rows and OMAXCON = 16 contacts per step mirror the device kernel's lane = row
+ *     layout; where MuJoCo would grow its arena, the oracle raises a warning and the rollout fails (as the device does).
+ *     DESIGN.md section 2 states how often that happens on the BASELINE workloads.
  */
 #ifndef MJPC_ORACLE_H_
 #define MJPC_ORACLE_H_

@@ -5,6 +5,7 @@
  * TEST INFRASTRUCTURE ONLY (see oracle.h). */
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
@@ -59,6 +60,7 @@ static int rollout_core_noisy(const mjpcx_model* m, const mjpcx_task* task, ODat
     for (int k = 0; k < ntr && out->trace; k++) /* GetTraces, utilities.cc:268-286 */
       memcpy(out->trace + (t * ntr + k) * 3, odata_trace_point(d, task->trace_site[k]), 3 * sizeof(double));
     if (odata_warning(d)) { /* CheckWarnings, trajectory.cc:169-173 */
+      if (getenv("ODEBUG_FAIL")) fprintf(stderr, "rollout failed at step %d: warning bits %d\n", t, odata_warning(d));
       out->total_return = KMAX_RETURN;
       out->failure = 1;
       free(r);

@@ -1,0 +1,83 @@
+"""-m gpu: BASELINE.json configs[2] (Quadruped, Cross-Entropy, 16384 candidates x horizon 100) and configs[3]'s per-GPU share
+(Humanoid tracking, 8192 of 65536 candidates x horizon 64, fp32 as quoted and fp64) at FULL size, through properties that do
+not need the oracle to roll out the whole batch: determinism, the un-noised nominal candidate, return == mean of the recorded
+costs == CostValue(residual), invariance under sharding the candidate range (the multi-GPU path), top-k == sorted returns, and
+the oracle on a strided sample. Tolerances as in the per-model suites (1e-6 (1 + |x|) over these horizons in fp64)."""
+import numpy as np
+import pytest
+
+from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.task import load_task
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.all(np.abs(a - b) <= tol * (1 + np.abs(b)))
+
+
+def mocap7(mpos):
+    return np.concatenate([np.concatenate([p, [1, 0, 0, 0]]) for p in np.asarray(mpos).reshape(-1, 3)])
+
+
+def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, tol, sample_stride):
+    pm, pt = task.packed_model(), task.packed()
+    nu = task.model.nu
+    dt = task.model.get_number("agent_timestep", task.model.timestep)
+    times = np.arange(P) * ((H - 1) * dt / (P - 1))
+    nominal = np.clip(np.random.default_rng(5).normal(0, 0.2, (P, nu)), -1, 1)
+    var = np.full(P * nu, 0.1 ** 2)
+    kw = dict(param_variance=var, explore_count=N // 10, std1=0.01) if mode == capi.NOISE_CROSS_ENTROPY else {}
+    ns = capi.make_noise_spec(seed=11, iteration=3, mode=mode, std0=0.1, **kw)
+    ctx = capi.Context(pm, pt, 0, precision)
+    ctx.set_state(state, 0.0, mocap)
+    ctx.rollout_noise(N, H, interp, times, nominal, ns)
+    ret, fail = ctx.returns()
+    # a tumbling A1 can exceed the solver's row capacity: such a rollout FAILS (return 1e6), on the device as in the oracle
+    assert fail.mean() < 0.05 and np.all(np.isfinite(ret)) and np.all(ret > 0) and np.all(ret[fail != 0] == 1.0e6)
+    # (a) determinism
+    ctx.rollout_noise(N, H, interp, times, nominal, ns)
+    assert np.array_equal(ctx.returns()[0], ret)
+    # (b) candidate 0 is the un-noised nominal (sampling/planner.cc:326-352): equals the oracle's rollout of the nominal spline
+    ref0 = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, 1, H, P, interp, times, nominal[None])
+    tr0 = ctx.fetch_trajectory(0)
+    assert close(tr0.states, ref0["states"][0], tol) and close(ret[0], ref0["total_return"][0], tol)
+    # (c) top-k == sorted returns; winner: return == mean of its costs, costs == CostValue(residual)
+    idx, best = ctx.topk(8)
+    order = np.lexsort((np.arange(N), ret))[:8]
+    assert np.array_equal(idx, order) and np.array_equal(best, ret[order])
+    trw = ctx.fetch_trajectory(int(idx[0]))
+    ctol = 1e-12 if precision == 64 else 1e-5
+    assert abs(trw.total_return - trw.costs.mean()) <= ctol * (1 + abs(trw.total_return)) and trw.total_return == ret[idx[0]]
+    for k in (0, H // 2, H - 1):
+        assert abs(trw.costs[k] - pyoracle.cost_value(pt, trw.residual[k])) <= ctol * (1 + abs(trw.costs[k]))
+    # (d) sharding invariance: the upper half of the candidate range as its own launch (rank 1 of 2) gives the same returns
+    half = capi.make_noise_spec(seed=11, iteration=3, mode=mode, std0=0.1, candidate_offset=N // 2, **kw)
+    ctx.rollout_noise(N // 2, H, interp, times, nominal, half)
+    assert np.array_equal(ctx.returns()[0], ret[N // 2:])
+    # (e) the oracle on a strided sample of the batch
+    sample = np.arange(1, N, sample_stride)
+    nodes = pyoracle.noise_candidates(pm, ns, P, nominal, sample)
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, len(sample), H, P, interp, times, nodes, num_threads=16)
+    assert np.array_equal(ref["failure"], fail[sample]) and close(ret[sample], ref["total_return"], tol)
+    ctx.close()
+
+
+def test_config3_quadruped_cross_entropy_n16384_h100():
+    quad = load_task("QuadrupedFlat")
+    quad.transition(0.0)
+    state = np.concatenate([quad.model.keyframes["home"]["qpos"], np.zeros(18)])
+    mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
+    # zero-order splines (the Cross-Entropy planner's default, cross_entropy/planner.h:141-142), 3 points
+    full_size_properties(quad, state, mocap, N=16384, H=100, P=3, interp=0, mode=capi.NOISE_CROSS_ENTROPY, precision=64, tol=1e-5,
+                         sample_stride=1024)
+
+
+@pytest.mark.parametrize("precision,tol", [(64, 1e-6), (32, 2e-3)])
+def test_config4_humanoid_tracking_n8192_h64(precision, tol):
+    t = load_task("HumanoidTrack")
+    e = t.transition(0.0, mode=9)
+    full_size_properties(t, np.concatenate([e["qpos"], e["qvel"]]), mocap7(e["mocap_pos"]), N=8192, H=64, P=16, interp=2,
+                         mode=capi.NOISE_SAMPLING, precision=precision, tol=tol, sample_stride=512)
