@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     Agent agent;
     agent.SetTaskList({task});
     agent.Initialize(storage->model());
-    if (std::string(name) == "Quadruped Flat") agent.SetPlanner(kCrossEntropyPlanner);  // its XML asks for iLQG (not yet on contact models)
+    if (std::string(name) == "Quadruped Flat") agent.SetPlanner(kCrossEntropyPlanner);  // (the XML asks for iLQG; this loop exercises the sampling-family planners)
     agent.Allocate();
     agent.Reset();
     const mjModel* m = storage->model();

@@ -30,6 +30,42 @@ ROLLOUT_CASES = {
 }
 
 
+# contact models: (task, transition mode or None, N, H, P, interp, noise std, seed, GPU tolerance); the state is the task's
+# start state (A1: home keyframe; humanoid: first frame of the Walk clip, mocap markers from Transition)
+CONTACT_CASES = {
+    "quadruped_trot_zero": ("QuadrupedFlat", None, 4, 30, 3, capi.SPLINE_ZERO, 0.4, 21, 1e-6),
+    "humanoid_walk_cubic": ("HumanoidTrack", 9, 3, 24, 6, capi.SPLINE_CUBIC, 0.3, 22, 1e-6),
+}
+
+
+def prepare_contact_task(tname, mode):
+    """task with its Transition applied at time 0, start state and mocap (7 per mocap body) -- shared with tests/test_golden.py"""
+    task = load_task(tname)
+    if tname == "QuadrupedFlat":
+        task.parameters[task.parameter_index("select_Gait")] = 2  # Trot: the gait terms of the residual are active
+        task.transition(0.0)
+        state = np.concatenate([task.model.keyframes["home"]["qpos"], np.zeros(task.model.nv)])
+        mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
+    else:
+        e = task.transition(0.0, mode=mode)
+        state = np.concatenate([e["qpos"], e["qvel"]])
+        mocap = np.concatenate([np.concatenate([p, [1, 0, 0, 0]]) for p in np.asarray(e["mocap_pos"]).reshape(-1, 3)])
+    return task, state, mocap
+
+
+def contact_case(name):
+    tname, mode, N, H, P, interp, std, seed, tol = CONTACT_CASES[name]
+    task, state, mocap = prepare_contact_task(tname, mode)
+    dt = task.model.get_number("agent_timestep", task.model.timestep)
+    times = np.arange(P) * ((H - 1) * dt / (P - 1))
+    nodes = np.clip(np.random.default_rng(seed).normal(0, std, (N, P, task.model.nu)), -1, 1)
+    ref = pyoracle.rollout_batch(task.packed_model(), task.packed(), state, 0.0, mocap, N, H, P, interp, times, nodes, num_threads=1)
+    assert not ref["failure"].any()
+    inputs = dict(task=tname, state=state, time=0.0, mocap=mocap, N=N, H=H, P=P, interp=interp, times=times, nodes=nodes,
+                  mode=-1 if mode is None else mode, gpu_tol=tol)
+    return inputs, ref
+
+
 def rollout_case(name):
     tname, state, time, mocap, N, H, P, interp, span, seed = ROLLOUT_CASES[name]
     task = load_task(tname)
@@ -64,6 +100,10 @@ def main():
     pyoracle.build()
     for name in ROLLOUT_CASES:
         inputs, ref = rollout_case(name)
+        np.savez_compressed(os.path.join(OUT, f"rollout_{name}.npz"), **{f"in_{k}": v for k, v in inputs.items()},
+                            **{f"out_{k}": np.asarray(v) for k, v in ref.items()})
+    for name in CONTACT_CASES:
+        inputs, ref = contact_case(name)
         np.savez_compressed(os.path.join(OUT, f"rollout_{name}.npz"), **{f"in_{k}": v for k, v in inputs.items()},
                             **{f"out_{k}": np.asarray(v) for k, v in ref.items()})
     inputs, out = ilqg_case()
