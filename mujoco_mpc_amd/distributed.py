@@ -76,6 +76,55 @@ class RankGroup:
         self.dist.broadcast(x, src=src)
         return x.cpu().numpy()
 
+    def time_shard(self, T):
+        """[begin, end) of this rank's share of T time steps (contiguous, the first T % world ranks get one more)"""
+        q, r = divmod(T, self.world)
+        begin = self.rank * q + min(self.rank, r)
+        return begin, begin + q + (1 if self.rank < r else 0)
+
+    def sharded_transition_fd(self, fd, times, states, actions, **kw):
+        """iLQG derivative sweep over ranks (SURVEY.md section 8e): every (t, perturbation column) of ModelDerivatives::Compute
+        is independent, so rank r evaluates `fd(times[b:e], states[b:e], actions[b:e], **kw)` -> (A, B, C, D) for its share of
+        the time steps (fd = capi.Context.transition_fd) and the blocks are all-gathered; every rank returns the full
+        (T, ...) arrays, bit-identical to the unsharded call. The backward pass is a serial recursion and stays replicated.
+        (At the A1's T = 36 the sweep takes 1.4 ms on one GPU: sharding it pays only for long horizons.)"""
+        t = self.torch
+        T = len(times)
+        b, e = self.time_shard(T)
+        states, actions = np.asarray(states, np.float64).reshape(T, -1), np.asarray(actions, np.float64).reshape(T, -1)
+        parts = fd(np.asarray(times, np.float64)[b:e], states[b:e], actions[b:e], **kw) if e > b else None
+        shapes = None
+        if parts is not None:
+            shapes = [p.shape[1:] for p in parts]
+        # per-step sizes are the same on every rank; a rank with an empty share learns them from rank 0 (which is never
+        # empty when T >= 1)
+        meta = t.zeros(8, dtype=t.int64, device=self.device)
+        if self.rank == 0:
+            flat = [d for sh in shapes for d in sh]
+            meta[:len(flat)] = t.as_tensor(flat, dtype=t.int64, device=self.device)
+        self.dist.broadcast(meta, src=0)
+        dims = meta.cpu().numpy().tolist()
+        shapes = [(dims[0], dims[1]), (dims[2], dims[3]), (dims[4], dims[5]), (dims[6], dims[7])]
+        per_step = sum(a * c for a, c in shapes)
+        cap = -(-T // self.world)  # equal-sized all-gather blocks: pad the smaller shares
+        local = t.zeros(cap * per_step, dtype=t.float64, device=self.device)
+        if parts is not None:
+            packed = np.concatenate([np.asarray(p, np.float64).reshape(e - b, -1) for p in parts], axis=1).reshape(-1)
+            local[:packed.size] = t.as_tensor(packed, device=self.device)
+        gathered = [t.empty_like(local) for _ in range(self.world)]
+        self.dist.all_gather(gathered, local)
+        rows = []
+        q, r = divmod(T, self.world)
+        for k, g in enumerate(gathered):
+            n = q + (1 if k < r else 0)
+            rows.append(g.cpu().numpy()[:n * per_step].reshape(n, per_step))
+        full = np.concatenate(rows, axis=0)
+        out, o = [], 0
+        for a, c in shapes:
+            out.append(full[:, o:o + a * c].reshape(T, a, c).copy())
+            o += a * c
+        return tuple(out)
+
     def sum_array(self, values):
         """all-reduce(sum) of a small fp64 vector (the CE elite moments)."""
         t = self.torch

@@ -45,6 +45,22 @@ for it in range(2):
     ce.optimize_policy(H)
     log.append(dict(winner=ce.trajectory_order[0], score=float(ce.improvement), improvement=float(ce.variance[:10].sum()),
                     plan=ce.policy.plan.values().tolist()))
+# iLQG derivative sweep sharded over the time steps (RankGroup.sharded_transition_fd); T = 7 is not divisible by 2
+from oracle import pyoracle
+pm, pt = task.packed_model(), task.packed()
+rng = np.random.default_rng(3)
+T = 7
+fd_times, fd_states, fd_actions = np.arange(T) * 0.01, rng.normal(0, 0.3, (T, 4)), rng.uniform(-1, 1, (T, 1))
+fd = lambda tt, ss, aa, **kw: pyoracle.transition_fd(pm, pt, ss, tt, aa, **kw)
+full = fd(fd_times, fd_states, fd_actions, centered=1)
+if group is not None:
+    assert group.time_shard(7) == ((0, 4) if group.rank == 0 else (4, 7))
+    sharded = group.sharded_transition_fd(fd, fd_times, fd_states, fd_actions, centered=1)
+    for a, b in zip(full, sharded):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    one_step = group.sharded_transition_fd(fd, fd_times[:1], fd_states[:1], fd_actions[:1], centered=1)  # rank 1's share is empty
+    assert all(np.array_equal(a[:1], b) for a, b in zip(full, one_step))
+log.append(dict(winner=0, score=float(full[0].sum()), improvement=float(full[2].sum()), plan=full[1].reshape(-1).tolist()))
 if group is None or group.rank == 0:
     print("RESULT " + json.dumps(log))
 if group is not None:
@@ -75,10 +91,10 @@ def run(world):
 
 def test_two_ranks_equal_one_rank():
     one, two = run(1), run(2)
-    assert len(one) == len(two) == 5
+    assert len(one) == len(two) == 6
     for k, (a, b) in enumerate(zip(one, two)):
         assert a["winner"] == b["winner"]
-        if k < 3:   # Predictive Sampling: bit-identical
+        if k < 3 or k == 5:   # Predictive Sampling, and the sharded iLQG derivative sweep: bit-identical
             assert a["score"] == b["score"] and a["improvement"] == b["improvement"]
             assert np.array_equal(np.array(a["plan"]), np.array(b["plan"]))
         else:       # Cross-Entropy: sums are re-associated across ranks
