@@ -302,8 +302,7 @@ int mjpcx_rollout_splines(mjpcx_ctx* ctx, int num_candidates, int horizon,
  * 120-140): as mjpcx_rollout_splines, with Ornstein-Uhlenbeck force / torque noise on every body's xfrc_applied,
  * xfrc[i] <- exp(-dt / xfrc_rate) xfrc[i] + N(0, xfrc_std sqrt(1 - exp(-2 dt / xfrc_rate))) before every step (starting
  * from zero). The normals are counter-based, keyed on (seed, candidate_offset + candidate, step, entry) -- the reference's
- * absl::BitGen is unseeded, so there is no stream to reproduce. Contact-model kernel family only (MJPCX_EUNSUPPORTED
- * otherwise). */
+ * absl::BitGen is unseeded, so there is no stream to reproduce. Both kernel families. */
 int mjpcx_rollout_splines_noisy(mjpcx_ctx* ctx, int num_candidates, int horizon, int num_nodes, int interpolation,
                                 const double* node_times, const double* node_values, double xfrc_std, double xfrc_rate,
                                 uint64_t seed, int candidate_offset);

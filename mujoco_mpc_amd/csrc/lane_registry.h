@@ -33,12 +33,13 @@ hipError_t launch_lane_impl(const LaneModel<T>& m, const LaneTask<T>& tk, const 
   const int blocks = (a.N + 63) / 64;
   const size_t shmem = ((size_t)a.P * TP::NU * 64 + a.P) * sizeof(T);
   static const bool fused = std::getenv("MJPCX_LANE_FUSED") != nullptr;  // the single-launch form, for A/B measurements
-  if (fused) {
+  if (fused && !(a.xfrc_scale > 0)) {
     hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC, false>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
     return hipGetLastError();
   }
   // time loop (dynamics only) -> sensor stage of every (step, candidate) -> ordered returns; see rollout_lane_kernel
-  hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC, true>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
+  if (a.xfrc_scale > 0) hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC, true, true>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
+  else hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC, true>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
   const size_t items = (size_t)a.N * a.H;
   hipLaunchKernelGGL((cost_lane_kernel<TP, TK, T, MC>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, m, tk, a);
   hipLaunchKernelGGL((return_lane_kernel<T>), dim3(blocks), dim3(64), 0, s, a);

@@ -550,8 +550,8 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
   a.residual = (T*)c->d_residual.p; a.costs = (T*)c->d_costs.p; a.trace = (T*)c->d_trace.p;
   a.total_return = (double*)c->d_ret.p; a.failure = (int*)c->d_fail.p;
   a.xfrc_decay = 0; a.xfrc_scale = 0; a.xfrc_seed = 0;
-  if (c->wave && c->xfrc_std > 0) {  // Ornstein-Uhlenbeck in discrete time (trajectory.cc:149-150), at the planning timestep
-    a.xfrc_decay = std::exp(-c->wh.m.timestep / c->xfrc_rate);
+  if (c->xfrc_std > 0) {  // Ornstein-Uhlenbeck in discrete time (trajectory.cc:149-150), at the planning timestep
+    a.xfrc_decay = std::exp(-(c->wave ? c->wh.m.timestep : c->hm64.timestep) / c->xfrc_rate);
     a.xfrc_scale = c->xfrc_std * std::sqrt(1 - a.xfrc_decay * a.xfrc_decay);
     a.xfrc_seed = c->xfrc_seed;
     if (a.noise.mode < 0) a.noise.candidate_offset = c->xfrc_offset;
@@ -901,7 +901,6 @@ int mjpcx_rollout_splines_noisy(mjpcx_ctx* c, int N, int H, int P, int interp, c
   if (rc != MJPCX_OK) return rc;
   if (!node_values) return fail(c, MJPCX_EINVAL, "null node_values");
   if (!(xfrc_std >= 0) || !(xfrc_rate > 0)) return fail(c, MJPCX_EINVAL, "xfrc_std must be >= 0 and xfrc_rate > 0");
-  if (!c->wave) return fail(c, MJPCX_EUNSUPPORTED, "xfrc_applied noise is implemented in the wavefront-per-candidate kernels only");
   c->xfrc_std = xfrc_std; c->xfrc_rate = xfrc_rate; c->xfrc_seed = seed; c->xfrc_offset = candidate_offset;
   rc = c->precision == 64 ? do_rollout<double>(c, N, H, P, interp, node_times, node_values, nullptr, nullptr)
                           : do_rollout<float>(c, N, H, P, interp, node_times, node_values, nullptr, nullptr);

@@ -80,6 +80,11 @@ struct Topo {
     while (k >= 0) { if (k == j) return true; k = dof_parent(k); }
     return false;
   }
+  // does dof i move body b (its joint sits on b or on an ancestor of b)
+  __host__ __device__ static constexpr bool dof_moves_body(int i, int b) {
+    while (b > 0) { if (jbody(i) == b) return true; b = parent(b); }
+    return false;
+  }
   __host__ __device__ static constexpr int num_limited() {
     int n = 0;
     for (int j = 0; j < NV_; j++) n += jlimited(j) ? 1 : 0;
@@ -141,7 +146,8 @@ template <class TP, typename T, class MODEL>
 __device__ __forceinline__ void lane_forward(const MODEL& m, const LaneTask<T>& tk, const T (&qpos)[TP::NV],
                                              const T (&qvel)[TP::NV], const T (&ctrl)[TP::NU], T (&qacc)[TP::NV],
                                              T (&qfrc)[TP::NV], T (&qfrc_c)[TP::NV], T (&M)[TP::NV][TP::NV],
-                                             T (&site_xpos)[TP::NSITE > 0 ? TP::NSITE : 1][3]) {
+                                             T (&site_xpos)[TP::NSITE > 0 ? TP::NSITE : 1][3],
+                                             const T (*xfrc)[6] = nullptr) {
   constexpr int NB = TP::NB, NV = TP::NV, NU = TP::NU, NS = TP::NSITE;
   const T h = m.timestep;
   // ================= position stage: kinematics
@@ -386,6 +392,27 @@ __device__ __forceinline__ void lane_forward(const MODEL& m, const LaneTask<T>& 
     }
   }
 
+  // mj_xfrcAccumulate (Trajectory::NoisyRollout): Cartesian force / torque on each body, through the dofs above it; bodies in
+  // ascending order per dof, as oracle/physics.c o_xfrc_accumulate sums them
+  if (xfrc) {
+#pragma unroll
+    for (int b = 1; b < NB; b++) {
+      if (TP::moves(b)) {
+        T off[3], tq[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) off[c] = xipos[b][c] - com[TP::root(b)][c];
+        const T f[3] = {xfrc[b][0], xfrc[b][1], xfrc[b][2]};
+        cross3(tq, off, f);
+#pragma unroll
+        for (int c = 0; c < 3; c++) tq[c] += xfrc[b][3 + c];
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+          if (TP::dof_moves_body(i, b))
+            qfrc[i] += cdof[i][0] * tq[0] + cdof[i][1] * tq[1] + cdof[i][2] * tq[2] + cdof[i][3] * f[0] + cdof[i][4] * f[1] + cdof[i][5] * f[2];
+      }
+    }
+  }
+
   // ================= acceleration stage
   ldl_solve<NV>(qacc, Lm, Dinv, qfrc);  // qacc_smooth
 
@@ -621,7 +648,9 @@ struct StaticModel {  // returns the constexpr object BY VALUE: a local constant
 // (cost_lane_kernel: one lane per (step, candidate), no serial dependence) and the ordered sum over the horizon
 // (return_lane_kernel) run afterwards at full occupancy. With 64 wavefronts of one candidate per lane the loop is bound by
 // its instruction count, and the sensor stage was ~40 % of it. `failure` carries (first bad step + 1) between the launches.
-template <class TP, class TK, typename T, class MC, bool SPLIT = false>
+// NOISY = true: Trajectory::NoisyRollout -- Ornstein-Uhlenbeck xfrc_applied noise on every body (its own instantiation, so the
+// plain rollout carries neither the 6 NB force registers nor the Philox draws).
+template <class TP, class TK, typename T, class MC, bool SPLIT = false, bool NOISY = false>
 __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_karg, const LaneTask<T> tk,
                                                            const RolloutArgs<T> a) {
   decltype(auto) m = MC::template get<T>(m_karg);
@@ -705,6 +734,11 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
   double total = 0;
   bool failed = false;
   int first_bad = 0;
+  T xfrc[NB][6];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int c = 0; c < 6; c++) xfrc[b][c] = 0;  // (the reference inherits the pooled mjData's forces)
 
   for (int t = 0; t < H; t++) {
     const bool last = (t == H - 1);
@@ -783,10 +817,23 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
       for (int i = 0; i < NV; i++) bad |= is_bad(qpos[i]) || is_bad(qvel[i]);
     }
 
+    if constexpr (NOISY) {
+      if (!last) {  // trajectory.cc:147-155: xfrc_applied = decay * xfrc_applied + N(0, scale) on every body entry
+        const int gi = a.noise.candidate_offset + ci;
+#pragma unroll
+        for (int j = 0; j < 3 * NB; j++) {
+          double z[2];
+          gaussian_pair(a.xfrc_seed, (uint32_t)gi, (uint32_t)(t * 3 * NB + j), 0x58465243u, z);
+          T* e = &xfrc[0][0] + 2 * j;
+          e[0] = (T)a.xfrc_decay * e[0] + (T)(a.xfrc_scale * z[0]);
+          e[1] = (T)a.xfrc_decay * e[1] + (T)(a.xfrc_scale * z[1]);
+        }
+      }
+    }
     // ================= mj_forward for this candidate (lane_forward)
     T qacc[NV], qfrc[NV], qfrc_c[NV], M[NV][NV];
     T site_xpos[NS > 0 ? NS : 1][3];
-    lane_forward<TP, T>(m, tk, qpos, qvel, ctrl, qacc, qfrc, qfrc_c, M, site_xpos);
+    lane_forward<TP, T>(m, tk, qpos, qvel, ctrl, qacc, qfrc, qfrc_c, M, site_xpos, NOISY ? xfrc : nullptr);
 
     // ================= mj_checkAcc
     if (!last) {

@@ -11,6 +11,7 @@ import pytest
 
 from conftest import random_nodes
 from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.task import load_task
 from oracle import pyoracle
 
 pytestmark = pytest.mark.gpu
@@ -305,3 +306,34 @@ def test_fp32_kernel(cartpole):
     ref = pyoracle.rollout_batch(pm, pt, [0.2, 2.9, 0.1, -0.2], 0.0, None, N, H, P, 2, times, nodes)
     assert not fail.any() and close(ret, ref["total_return"], 2e-3)
     assert ctx.algorithmic_bytes(H, P) * 2 == capi.Context(pm, pt, 0, 64).algorithmic_bytes(H, P)
+
+
+@pytest.mark.parametrize("name,state,mocap", [("Cartpole", [0.2, 2.9, 0.1, -0.2], None),
+                                              ("Particle", [0.05, -0.1, 0.2, 0.0], [0.15, -0.1, 0.01, 1, 0, 0, 0])])
+@pytest.mark.parametrize("precision,tol", [(64, 1e-9), (32, 2e-3)])
+def test_noisy_rollout_on_the_lane_kernels(name, state, mocap, precision, tol):
+    """Trajectory::NoisyRollout (trajectory.cc:147-155) on the lane-per-candidate family: Ornstein-Uhlenbeck xfrc_applied noise
+    from the shared counter-based stream, accumulated through mj_xfrcAccumulate; each candidate tracks the oracle's rollout
+    with the same noise, identical splines diverge, and xfrc_std = 0 is the plain rollout bit for bit."""
+    task = load_task(name)
+    pm, pt = task.packed_model(), task.packed()
+    N, P, H = 70, 4, 40
+    times = np.linspace(0, 0.39, P)
+    nodes = np.tile(random_nodes(5, 1, P, task.model.nu), (N, 1, 1))
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, N, H, P, 2, times, nodes, num_threads=4, xfrc_std=0.8, xfrc_rate=0.05,
+                                 seed=3, candidate_offset=9)
+    assert np.abs(ref["states"][0] - ref["states"][1]).max() > 1e-4
+    ctx = capi.Context(pm, pt, 0, precision)
+    assert "rollout_lane" in ctx.kernel_name
+    ctx.set_state(state, 0.0, mocap)
+    ctx.rollout_splines_noisy(H, 2, times, nodes, 0.8, 0.05, seed=3, candidate_offset=9)
+    ret, fail = ctx.returns()
+    assert np.array_equal(fail, ref["failure"]) and close(ret, ref["total_return"], tol)
+    for c in (0, 37, N - 1):
+        tr = ctx.fetch_trajectory(c)
+        assert close(tr.states, ref["states"][c], tol) and close(tr.residual, ref["residual"][c], tol)
+    ctx.rollout_splines_noisy(H, 2, times, nodes, 0.0, 0.05)
+    r0, _ = ctx.returns()
+    ctx.rollout_splines(H, 2, times, nodes)
+    assert np.array_equal(r0, ctx.returns()[0])
+    ctx.close()

@@ -283,3 +283,27 @@ def test_cpp_sample_gradient_planner(cartpole):
     assert 2 in types or 1 in types
     tr = p.best_trajectory()
     assert abs(tr["total_return"] - scores[-1]) < 1e-12
+
+
+def test_cpp_robust_planner_on_the_cartpole():
+    """the same planner on a lane-per-candidate model (NoisyRollout in rollout_lane_kernel<..., NOISY = true>)"""
+    from mujoco_mpc_amd import capi
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.task import load_task
+    from oracle import pyoracle
+    t = load_task("Cartpole")
+    p = HostPlanner(t, seed=4, num_trajectory=128, kind="robust")
+    K, R = 5, 4
+    p.robust_config(ncandidates=K, nrepetitions=R, xfrc_std=0.5, xfrc_rate=0.05)
+    H = t.planning_steps()
+    p.reset(H)
+    p.set_state([0.4, 2.6], [0.1, -0.3], 0.0)
+    p.optimize_policy(H)
+    best, scores = p.robust_result()
+    assert 0 <= best < K and scores[best] == scores[:K].min() and np.all(scores[:K] > 0)
+    times, values = p.policy()
+    ref = pyoracle.rollout_batch(t.packed_model(), t.packed(), [0.4, 2.6, 0.1, -0.3], 0.0, None, R, H, len(times), capi.SPLINE_CUBIC,
+                                 times, np.tile(values, (R, 1, 1)), num_threads=2, xfrc_std=0.5, xfrc_rate=0.05, seed=4,
+                                 candidate_offset=best * R)
+    assert abs(ref["total_return"].mean() - scores[best]) <= 1e-9 * (1 + abs(scores[best]))
+    p.close()
