@@ -172,26 +172,15 @@ __device__ __forceinline__ int w_nth_bit(unsigned m, int n) {
 }
 // in-place: on exit the lower triangle of A (LDS, ld n) holds L with A = L L', dinv[j] = 1 / L[j][j].
 // (not inlined: five call sites per step, and the step loop has to stay inside the instruction cache)
-// The pointers are typed as LDS: through generic pointers the loads and stores compile to FLAT instructions, and the per-column
-// store of the pivot reciprocal made every column wait (vmcnt/lgkmcnt 0) for a FLAT store's round trip. Loads are
-// unconditional from a clamped address (one ds_read each, no exec-mask branch per element), the reciprocal stays in the
-// owning lane's register until the end.
-typedef __attribute__((address_space(3))) wreal wlds_real;
 template <int NMAX>
-__device__ __noinline__ bool wave_chol_lds(wlds_real* A, wlds_real* dinv, int n_, int lane) {
+__device__ __noinline__ bool wave_chol(wreal* A, wreal* dinv, int n_, int lane) {
   // (arguments of an out-of-line function arrive in VGPRs: make the size scalar again, or every guard below becomes a
   // vector compare + exec-mask branch)
   const int n = __builtin_amdgcn_readfirstlane(n_);
-  const bool mine = lane < n;
-  const int rbase = (mine ? lane : 0) * n;
   wreal row[NMAX];
 #pragma unroll
-  for (int k = 0; k < NMAX; k++) {
-    const wreal v = A[rbase + (k < n ? k : 0)];
-    row[k] = (mine && k <= lane) ? v : WL(0.0);
-  }
+  for (int k = 0; k < NMAX; k++) row[k] = (lane < n && k <= lane) ? A[lane * n + k] : WL(0.0);
   bool ok = true;
-  wreal myinv = 0;
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
     if (j < n && ok) {
@@ -202,7 +191,7 @@ __device__ __noinline__ bool wave_chol_lds(wlds_real* A, wlds_real* dinv, int n_
         const wreal inv = rsqrt(djj);
         const wreal lij = lane == j ? djj * inv : row[j] * inv;
         row[j] = lij;
-        if (lane == j) myinv = inv;
+        if (lane == j) dinv[j] = inv;
         // no guards in the update: lanes >= n hold zero rows (their broadcast l_kj is 0), lanes < k update an
         // upper-triangle slot nobody reads
 #pragma unroll
@@ -210,34 +199,23 @@ __device__ __noinline__ bool wave_chol_lds(wlds_real* A, wlds_real* dinv, int n_
       }
     }
   }
-  if (mine) {
-    dinv[lane] = myinv;  // columns past a failed pivot keep 0 (the caller abandons the factor)
 #pragma unroll
-    for (int k = 0; k < NMAX; k++) if (k <= lane) A[rbase + k] = row[k];
-  }
+  for (int k = 0; k < NMAX; k++) if (lane < n && k <= lane) A[lane * n + k] = row[k];
   WSYNC();
   return ok;
 }
-template <int NMAX>
-__device__ __forceinline__ bool wave_chol(wreal* A, wreal* dinv, int n_, int lane) {
-  return wave_chol_lds<NMAX>((wlds_real*)A, (wlds_real*)dinv, n_, lane);
-}
 // x := (L L')^-1 x, x in LDS
 template <int NMAX>
-__device__ __noinline__ void wave_chol_solve_lds(wlds_real* x, const wlds_real* L, const wlds_real* dinv, int n_, int lane) {
+__device__ __noinline__ void wave_chol_solve(wreal* x, const wreal* L, const wreal* dinv, int n_, int lane) {
   const int n = __builtin_amdgcn_readfirstlane(n_);
-  const bool mine = lane < n;
-  const int li = mine ? lane : 0;
   wreal row[NMAX], col[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
-    const int kk = k < n ? k : 0;
-    const wreal r = L[li * n + kk], c = L[kk * n + li];
-    row[k] = (mine && k < lane) ? r : WL(0.0);
-    col[k] = (mine && k > lane && k < n) ? c : WL(0.0);
+    row[k] = (lane < n && k < lane) ? L[lane * n + k] : WL(0.0);
+    col[k] = (lane < n && k > lane && k < n) ? L[k * n + lane] : WL(0.0);
   }
-  wreal b = mine ? x[li] : WL(0.0);
-  const wreal mydinv = mine ? dinv[li] : WL(0.0);
+  wreal b = lane < n ? x[lane] : WL(0.0);
+  const wreal mydinv = lane < n ? dinv[lane] : WL(0.0);
   // unguarded sweeps: for j >= n the broadcast pivot reciprocal is 0, so the step is a no-op
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
@@ -249,12 +227,8 @@ __device__ __noinline__ void wave_chol_solve_lds(wlds_real* x, const wlds_real* 
     const wreal xj = wbcast(b, j) * wbcast(mydinv, j);
     b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
   }
-  if (mine) x[lane] = b;
+  if (lane < n) x[lane] = b;
   WSYNC();
-}
-template <int NMAX>
-__device__ __forceinline__ void wave_chol_solve(wreal* x, const wreal* L, const wreal* dinv, int n_, int lane) {
-  wave_chol_solve_lds<NMAX>((wlds_real*)x, (const wlds_real*)L, (const wlds_real*)dinv, n_, lane);
 }
 
 // solimp -> impedance at violation `dist` (oracle impedance())
