@@ -136,3 +136,25 @@ def test_quadruped_session(stub):
         stub.Step(M("StepRequest")())
     z1 = stub.GetState(M("GetStateRequest")()).state
     assert z1.time > z0.time and np.all(np.isfinite(z1.qpos)) and abs(z1.qpos[2] - z0.qpos[2]) < 0.1
+
+
+def test_init_with_a_model_override(stub):
+    """InitRequest.model.xml (grpc_agent_util.cc:535-560, Agent::OverrideModel): the client sends a self-contained MJCF -- here
+    the Cartpole task with its includes expanded and a shorter horizon -- and the agent plans on THAT model"""
+    import os
+    import xml.etree.ElementTree as ET
+    from mujoco_mpc_amd import mjcf
+    from mujoco_mpc_amd.task import MODELS_DIR
+    path = os.path.join(MODELS_DIR, "cartpole", "task.xml")
+    root = ET.parse(path).getroot()
+    mjcf._expand_includes(root, os.path.dirname(path))
+    for n in root.iter("numeric"):
+        if n.get("name") == "agent_horizon":
+            n.set("data", "0.5")
+    stub.Init(M("InitRequest")(task_id="Cartpole", model=M("MjModel")(xml=ET.tostring(root, encoding="unicode"))))
+    stub.PlannerStep(M("PlannerStepRequest")())
+    tr = stub.GetBestTrajectory(M("GetBestTrajectoryRequest")())
+    assert tr.steps == 51 and len(tr.actions) == 50  # 0.5 s / 0.01 s + 1 (agent.cc:288-293), not the task file's 1.0 s
+    stub.Init(M("InitRequest")(task_id="Cartpole"))   # a later Init without a model starts afresh on the registered one
+    stub.PlannerStep(M("PlannerStepRequest")())
+    assert stub.GetBestTrajectory(M("GetBestTrajectoryRequest")()).steps == 101

@@ -101,3 +101,11 @@ def test_init_without_a_gpu_fails_loudly(server):
     with pytest.raises(grpc.RpcError) as e:
         server.Init(gs.message("InitRequest")(task_id="Cartpole"))
     assert e.value.code() == grpc.StatusCode.INTERNAL and "HIP" in e.value.details()
+
+
+def test_init_with_an_unloadable_model_xml(server):
+    """InitRequest.model.xml goes through this package's MJCF compiler; a document it cannot compile is reported as the
+    reference reports a model that fails to load (agent_service.cc:99-104)"""
+    with pytest.raises(grpc.RpcError) as e:
+        server.Init(gs.message("InitRequest")(task_id="Cartpole", model=gs.message("MjModel")(xml="<mujoco><include file='nope.xml'/></mujoco>")))
+    assert e.value.code() == grpc.StatusCode.INTERNAL and e.value.details().startswith("Failed to load model:")
