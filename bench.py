@@ -197,6 +197,9 @@ def main():
             if args.task == "QuadrupedFlat" and args.candidates == 16384 and H == 100:
                 pq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_quadruped.json")))
                 out["roofline"]["traffic"] = pq[f"fp{args.precision}"]["derived"]["hbm_bytes_per_launch"]
+            if args.task == "HumanoidTrack" and args.candidates == 8192 and H == 64:
+                ph = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_humanoid.json")))
+                out["roofline"]["traffic"] = ph[f"fp{args.precision}"]["derived"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         if not args.no_cpu_baseline:

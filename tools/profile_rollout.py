@@ -27,11 +27,17 @@ dt = task.model.get_number("agent_timestep", task.model.timestep)
 times = np.arange(P) * ((a.horizon - 1) * dt / (P - 1))
 home = task.model.keyframes.get("home")
 state = np.concatenate([home["qpos"], home["qvel"]]) if home else np.zeros(task.model.nq + task.model.nv)
-if hasattr(task, "transition"):
+mocap = None
+if a.task == "HumanoidTrack":  # first frame of the Walk clip; the markers come from the task's Transition
+    e = task.transition(0.0, mode=9)
+    state = np.concatenate([e["qpos"], e["qvel"]])
+    mocap = np.concatenate([np.concatenate([p, [1, 0, 0, 0]]) for p in np.asarray(e["mocap_pos"]).reshape(-1, 3)])
+elif hasattr(task, "transition"):
     task.transition(0.0)
+if hasattr(task, "transition"):
     ctx.set_task_params(task.weight, task.norm_parameter, task.parameters, task.risk)
     ctx.set_residual_state(task.residual_int, task.residual_real)
-ctx.set_state(state, 0.0)
+ctx.set_state(state, 0.0, mocap)
 ctx.timing_reset()
 for k in range(a.launches):
     ctx.rollout_noise(a.n, a.horizon, a.interp, times, np.zeros((P, task.model.nu)),
