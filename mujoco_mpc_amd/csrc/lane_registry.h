@@ -32,7 +32,12 @@ hipError_t launch_lane_impl(const LaneModel<T>& m, const LaneTask<T>& tk, const 
   static_assert(sizeof(LaneModel<T>) + sizeof(LaneTask<T>) + sizeof(RolloutArgs<T>) <= 4096, "kernarg segment is 4 KiB");
   const int blocks = (a.N + 63) / 64;
   const size_t shmem = ((size_t)a.P * TP::NU * 64 + a.P) * sizeof(T);
-  static const bool fused = std::getenv("MJPCX_LANE_FUSED") != nullptr;  // the single-launch form, for A/B measurements
+  // One fused launch or three (see rollout_lane_kernel). The split form wins while the time loop is issue-bound on a few
+  // wavefronts (N = 4096: 166 vs 280 us); its sensor-stage launch re-reads the recorded states and runs at the HBM roofline
+  // (N = 65536: 143 us at 6.1 TB/s), so beyond ~10^5 candidates the fused form, with 30 % less traffic, is the faster one
+  // (N = 262144: 0.91 vs 1.38 ms). MJPCX_LANE_FUSED / MJPCX_LANE_SPLIT force one form for A/B measurements.
+  static const bool force_fused = std::getenv("MJPCX_LANE_FUSED") != nullptr, force_split = std::getenv("MJPCX_LANE_SPLIT") != nullptr;
+  const bool fused = force_fused || (!force_split && a.N > 98304);
   if (fused && !(a.xfrc_scale > 0)) {
     hipLaunchKernelGGL((rollout_lane_kernel<TP, TK, T, MC, false>), dim3(blocks), dim3(64), shmem, s, m, tk, a);
     return hipGetLastError();
