@@ -601,7 +601,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       const size_t lds_state = (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
       const size_t lds = lds_state;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
-      auto kern = wm.nv <= 20 ? w64::rollout_wave_kernel<20> : w64::rollout_wave_kernel<32>;
+      // the register-resident Cholesky is unrolled to NMAX columns: instantiations that fit the registered models exactly (A1:
+      // nv = 18, humanoid: 27) skip the padding columns' updates (humanoid: 30 % of the factorisation's instructions)
+      auto kern = wm.nv <= 18 ? w64::rollout_wave_kernel<18> : wm.nv <= 20 ? w64::rollout_wave_kernel<20>
+                : wm.nv <= 28 ? w64::rollout_wave_kernel<28> : w64::rollout_wave_kernel<32>;
       le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (le == hipSuccess) {
         hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
@@ -626,7 +629,8 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     const WaveModelT<float>& wm = c->wh.m32;
     const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
-    auto kern = wm.nv <= 20 ? w32::rollout_wave_kernel<20> : w32::rollout_wave_kernel<32>;
+    auto kern = wm.nv <= 18 ? w32::rollout_wave_kernel<18> : wm.nv <= 20 ? w32::rollout_wave_kernel<20>
+              : wm.nv <= 28 ? w32::rollout_wave_kernel<28> : w32::rollout_wave_kernel<32>;
     le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (le == hipSuccess) {
       hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
