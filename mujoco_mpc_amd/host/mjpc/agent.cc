@@ -25,7 +25,10 @@ void Agent::Initialize(mjModel* model) {
     if (!model_->actuator_ctrllimited[i]) { num_missing++; std::printf("actuator %i missing limits\n", i); }
   if (num_missing > 0) throw std::runtime_error("Ctrl limits required for all actuators.");
   planner_ = GetNumberOrDefault(0, model, "agent_planner");
-  if (planner_ < 0 || planner_ >= (int)planners_.size() || !planners_[planner_]) planner_ = kSamplingPlanner;  // unported slot
+  if (planner_ < 0 || planner_ >= (int)planners_.size() || !planners_[planner_]) {  // a slot this build does not fill (Gradient, iLQS)
+    std::fprintf(stderr, "agent_planner %d is not available on the GPU path; using the Sampling planner\n", planner_);
+    planner_ = kSamplingPlanner;
+  }
   integrator_ = GetNumberOrDefault(model->opt.integrator, model, "agent_integrator");
   horizon_ = GetNumberOrDefault(0.5, model, "agent_horizon");
   timestep_ = GetNumberOrDefault(1.0e-2, model, "agent_timestep");
