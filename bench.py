@@ -6,15 +6,21 @@ Sampling plan iteration's timed span in the reference (`rollouts_compute_time`,
 mjpc/planners/sampling/planner.cc:169-191) = candidate noise + N rollouts of H steps +
 selection of the best candidate, followed by the policy update that feeds the next step.
 
-Workload at --gpus 1 = BASELINE.json configs[1]: Cartpole, Predictive Sampling,
-4096 candidates, horizon 128, fp64, 10 cubic spline points. With --gpus N every rank
-rolls out its own 4096 candidates of a global batch of N*4096 (weak scaling) and the
-ranks exchange (best cost, index) + the winner's spline over RCCL.
+Headline workload (--gpus 1, no other flags) = the workload BASELINE.json's `north_star` states its target
+on: **Quadruped (Unitree A1, flat terrain) Predictive Sampling, 16384 candidates, horizon 100, fp64**
+(model and batch of BASELINE configs[2]; the reference's arithmetic type). With --gpus N every rank rolls
+out its own 16384 candidates of a global batch of N*16384 (weak scaling) and the ranks exchange
+(best cost, index) + the winner's spline.
 
-Prints ONE JSON line (rank 0) with the fields of the driver contract plus `roofline`
-and `cpu_baseline`.
+The same JSON line carries, in `extra`, one entry per further single-GPU BASELINE config so that one
+driver run covers them all: configs[1] (Cartpole PS 4096 x 128 fp64), configs[2] through the Cross-Entropy
+planner, configs[3] (Humanoid tracking PS, one GPU's 8192-candidate share, fp32) and configs[4] (one iLQG
+iteration on the Quadruped, with the CPU port's iteration time beside it).
+
+Prints ONE JSON line (rank 0) with the fields of the driver contract plus `roofline`, `cpu_baseline`, `extra`.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,23 +31,40 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TF = 78.6   # MI355X vector FP64 (not in the local guide)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--task", default="Cartpole")
-    ap.add_argument("--candidates", type=int, default=4096, help="candidates per GPU")
-    ap.add_argument("--horizon", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--task", default="QuadrupedFlat")
+    ap.add_argument("--candidates", type=int, default=0, help="candidates per GPU (0: the BASELINE size of the task)")
+    ap.add_argument("--horizon", type=int, default=0, help="0: the BASELINE horizon of the task")
     ap.add_argument("--precision", type=int, default=64, choices=[32, 64])
     ap.add_argument("--planner", default="sampling", choices=["sampling", "cross_entropy"],
-                    help="host planner driving the hot path (cross_entropy: BASELINE configs[2] with --task QuadrupedFlat)")
+                    help="host planner driving the hot path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` configs (they only run at --gpus 1)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
+
+
+# BASELINE.json sizes per task: (candidates per GPU, horizon, label)
+BASELINE_SIZE = {
+    "Cartpole": (4096, 128, "BASELINE.json configs[1]"),
+    "QuadrupedFlat": (16384, 100, "north_star workload; model and batch of BASELINE.json configs[2]"),
+    "HumanoidTrack": (8192, 64, "BASELINE.json configs[3]: one GPU's 8192-candidate share of 65536"),
+}
+
+
+def lib_sha16():
+    from mujoco_mpc_amd import capi
+    path = os.path.join(ROOT, "mujoco_mpc_amd", "libmjpcx.so")
+    capi.lib()
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
 def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=None, interp=None):
@@ -64,12 +87,11 @@ def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=Non
                                     times, nodes[:n], num_threads=threads)
         return n / (time.perf_counter() - t0)
 
-    run(64, 1)
-    single = max(run(256, 1), run(256, 1))
+    run(min(64, n_per_call), 1)
+    single = max(run(min(128, n_per_call), 1), run(min(128, n_per_call), 1))
     best_threads, best_rate = 1, 0.0
     for threads in sorted({max(1, cores // d) for d in (1, 2, 4, 8, 16)}):
-        n = min(n_per_call, 64 * threads)
-        run(n, threads)
+        n = min(n_per_call, 32 * threads)
         rate = max(run(n, threads), run(n, threads))
         if rate > best_rate:
             best_threads, best_rate = threads, rate
@@ -86,6 +108,172 @@ def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=Non
                        f"gcc -O3 -march=native -flto; CPU restatement, not MuJoCo")
 
 
+def initial_condition(task_name, task, planner):
+    """synthetic initial condition: the task's home keyframe"""
+    model = task.model
+    home = model.keyframes.get("home")
+    qpos = np.array(home["qpos"] if home else model.qpos0, float)
+    qvel = np.array(home["qvel"] if home else np.zeros(model.nv), float)
+    mocap_pos = mocap_quat = None
+    if model.nmocap:  # mocap bodies at their model pose (State::Reset)
+        ids = [b for b in range(model.nbody) if model.arrays["body_mocapid"][b] >= 0]
+        ids.sort(key=lambda b: model.arrays["body_mocapid"][b])
+        mocap_pos = np.array([model.arrays["body_pos"][b] for b in ids], float)
+        mocap_quat = np.array([model.arrays["body_quat"][b] for b in ids], float)
+    if task_name == "HumanoidTrack":
+        # Task::Transition edits the simulation state: first keyframe of the motion, interpolated marker positions
+        mode = 9   # Walk (SURVEY 8d, C4)
+        planner.task_transition_state(0.0, mode, qpos, qvel, mocap_pos.reshape(-1))
+        task.transition(0.0, mode)   # the Python mirror keeps the frozen residual state for the cpu_baseline leg
+    elif hasattr(task, "transition"):
+        planner.task_transition(0.0)
+    return qpos, qvel, mocap_pos, mocap_quat
+
+
+def pmc_summary(task_name, candidates, horizon, precision):
+    """Counter-derived figures of the rollout kernel for THIS build: profiles/r02_pmc_<task>.json is written by
+    tools/pmc_rollout.sh (separate --pmc passes, as MI355X_MICROARCH.md prescribes) and records the sha256 of the
+    libmjpcx.so it profiled; a summary of any other build is ignored (never a stale lookup)."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_{task_name.lower()}_fp{precision}.json")
+    try:
+        s = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if s.get("lib_sha16") != lib_sha16() or s.get("candidates") != candidates or s.get("horizon") != horizon:
+        return None
+    return s
+
+
+def run_config(args, task_name, kind, candidates, horizon, precision, steps, warmup, world, local_rank, group, want_cpu, rank):
+    """one BASELINE config through the C++ planner over the C ABI; returns the fields of a bench line"""
+    import torch
+    from mujoco_mpc_amd import capi
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.task import load_task
+
+    task = load_task(task_name)
+    H = horizon
+    planner = HostPlanner(task, device=local_rank, precision=precision, seed=0,
+                          num_trajectory=candidates * world,  # lifts kMaxTrajectory = 128 (SURVEY F5)
+                          group=group, kind=kind)
+    qpos, qvel, mocap_pos, mocap_quat = initial_condition(task_name, task, planner)
+    planner.reset(H)
+    P = planner.num_spline_points
+    planner.set_state(qpos, qvel, 0.0, mocap_pos=mocap_pos, mocap_quat=mocap_quat)
+
+    def fence():
+        if group is not None:
+            group.barrier()
+        planner.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        planner.optimize_policy(H)
+    fence()
+    planner.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        planner.optimize_policy(H)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = planner.timing_read()
+    if group is not None:
+        elapsed = group.max_scalar(elapsed)
+    value = candidates * world * steps / elapsed
+    if rank != 0:
+        planner.close()
+        return None
+    bytes_per_launch = planner.algorithmic_bytes(H, P) * candidates
+    avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
+    achieved = bytes_per_launch / avg_kernel_s / 1e9
+    interp = "cubic" if kind == "sampling" and task_name != "QuadrupedFlat" else None
+    label = BASELINE_SIZE.get(task_name, (0, 0, ""))[2]
+    out = {
+        "value": value, "unit": "rollouts/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "dtype": "f64" if precision == 64 else "f32",
+        "config": {"workload": f"{task_name} {'Predictive Sampling' if kind == 'sampling' else 'Cross-Entropy'}, {candidates} candidates/GPU, "
+                               f"horizon {H}, {P} spline points, fp{precision} ({label})",
+                   "candidates_per_gpu": candidates, "horizon": H, "spline_points": P,
+                   "parallelism": f"candidates sharded over {world} rank(s)", "kernel": planner.kernel_name,
+                   "host": ("C++ mjpc::GpuSamplingPlanner" if kind == "sampling" else "C++ mjpc::GpuCrossEntropyPlanner") + " over the C ABI"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": avg_kernel_s * 1e3, "bytes_per_launch": bytes_per_launch,
+                     "note": "algorithmic bytes (SURVEY 8d) / HIP-event time of one rollout on the context's stream; the contact "
+                             "models are VALU-issue / latency-bound, not HBM-bound (DESIGN.md 4): see `valu`"},
+    }
+    del interp
+    pmc = pmc_summary(task_name, candidates, H, precision)
+    if pmc is not None:
+        out["roofline"]["traffic"] = pmc.get("hbm_bytes_per_launch")
+        if "valu" in pmc:
+            out["roofline"]["valu"] = pmc["valu"]
+    if want_cpu:
+        st = np.concatenate([qpos, qvel])
+        cores = os.cpu_count() or 1
+        n_cpu = min(max(1024, 32 * cores), candidates) if task_name != "Cartpole" else max(candidates, 64 * cores)
+        out["cpu_baseline"] = cpu_baseline(task, st, H, P, args.cpu_seconds, n_cpu,
+                                           mocap=None if mocap_pos is None else np.hstack([mocap_pos, mocap_quat]).reshape(-1),
+                                           interp=capi.SPLINE_ZERO if task_name == "QuadrupedFlat" or kind == "cross_entropy" else capi.SPLINE_CUBIC)
+    planner.close()
+    return out
+
+
+def run_ilqg(local_rank, iterations=6, warmup=2):
+    """BASELINE configs[4]: one iLQG iteration on the Quadruped (T = 36, 10 line-search rollouts, forward differences,
+    MakeDifferentiable on) through the C++ mjpc::GpuILQGPlanner; beside it the same iteration by the Python mirror of the
+    planner on the CPU oracle (tests/oracle_backend.py: oracle/{ilqg,riccati}.c) on the host cores."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.task import load_task
+    task = load_task("QuadrupedFlat")
+    planner = HostPlanner(task, device=local_rank, precision=64, seed=0, kind="ilqg")
+    qpos, qvel, mocap_pos, mocap_quat = initial_condition("QuadrupedFlat", task, planner)
+    T = task.planning_steps()
+    planner.reset(T)
+    planner.set_state(qpos, qvel, 0.0, mocap_pos=mocap_pos, mocap_quat=mocap_quat)
+    for _ in range(warmup):
+        planner.optimize_policy(T)
+    planner.sync()
+    t0 = time.perf_counter()
+    for _ in range(iterations):
+        planner.optimize_policy(T)
+    planner.sync()
+    gpu_ms = (time.perf_counter() - t0) / iterations * 1e3
+    info = planner.ilqg_info()
+    planner.close()
+    out = {"name": "configs[4] Quadruped iLQG iteration", "value": gpu_ms, "unit": "ms/iteration", "higher_is_better": False,
+           "iterations": iterations, "dtype": "f64",
+           "config": {"workload": f"QuadrupedFlat iLQG, T = {T}, 10 line-search rollouts, forward differences, derivative_skip 0, fp64",
+                      "host": "C++ mjpc::GpuILQGPlanner over the C ABI"},
+           "total_return": info["total_return"]}
+    # CPU port of the same iteration
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_backend import OracleContext
+        from mujoco_mpc_amd.planners import GpuILQGPlanner, State
+        task2 = load_task("QuadrupedFlat")
+        task2.transition(0.0)
+        threads = max(1, min(16, (os.cpu_count() or 1)))
+        pl = GpuILQGPlanner(backend_factory=lambda tk: OracleContext(tk, threads=threads, differentiable=True))
+        pl.initialize(task2.model, task2); pl.allocate(); pl.reset(T)
+        st = State(task2.model)
+        st.set(qpos, qvel, mocap_pos=mocap_pos, mocap_quat=mocap_quat, time=0.0)
+        pl.set_state(st)
+        pl.optimize_policy(T)
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            pl.optimize_policy(T)
+        cpu_ms = (time.perf_counter() - t0) / n * 1e3
+        out["cpu_baseline"] = {"value": cpu_ms, "unit": "ms/iteration", "cores": threads, "kind": "port",
+                               "sample": f"{n} iterations of the planner's Python mirror on the C oracle (derivative sweep and line-search "
+                                         f"rollouts fanned over {threads} threads); CPU restatement, not MuJoCo"}
+    except Exception as e:  # the CPU leg must never take the bench line down
+        out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -95,9 +283,6 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     import torch
-    from mujoco_mpc_amd import capi
-    from mujoco_mpc_amd.hostplanner import HostPlanner
-    from mujoco_mpc_amd.task import load_task
 
     group = None
     if world > 1:
@@ -110,106 +295,41 @@ def main():
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
-    task = load_task(args.task)
-    model = task.model
-    # the C++ mjpc::GpuSamplingPlanner (mujoco_mpc_amd/host) drives the C ABI; Python only lends it
-    # torch.distributed as the transport of the per-step candidate exchange when there are several ranks
-    H = args.horizon
-    planner = HostPlanner(task, device=local_rank, precision=args.precision, seed=0,
-                          num_trajectory=args.candidates * world,  # lifts kMaxTrajectory = 128
-                          group=group, kind=args.planner)
-    # synthetic initial condition: the task's home keyframe
-    home = model.keyframes.get("home")
-    qpos = np.array(home["qpos"] if home else model.qpos0, float)
-    qvel = np.array(home["qvel"] if home else np.zeros(model.nv), float)
-    mocap_pos = mocap_quat = None
-    if model.nmocap:  # mocap bodies at their model pose (State::Reset)
-        ids = [b for b in range(model.nbody) if model.arrays["body_mocapid"][b] >= 0]
-        ids.sort(key=lambda b: model.arrays["body_mocapid"][b])
-        mocap_pos = np.array([model.arrays["body_pos"][b] for b in ids], float)
-        mocap_quat = np.array([model.arrays["body_quat"][b] for b in ids], float)
-    if args.task == "HumanoidTrack":
-        # Task::Transition edits the simulation state: first keyframe of the motion, interpolated marker positions
-        mode = 9   # Walk
-        planner.task_transition_state(0.0, mode, qpos, qvel, mocap_pos.reshape(-1))
-        task.transition(0.0, mode)   # the Python mirror keeps the frozen residual state for the cpu_baseline leg
-    elif hasattr(task, "transition"):
-        planner.task_transition(0.0)
-    planner.reset(H)
-    P = planner.num_spline_points
-    planner.set_state(qpos, qvel, 0.0, mocap_pos=mocap_pos, mocap_quat=mocap_quat)
-
-    def step():
-        planner.optimize_policy(H)
-
-    def fence():
-        if group is not None:
-            group.barrier()
-        planner.sync()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    planner.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = planner.timing_read()
-    if group is not None:
-        elapsed = group.max_scalar(elapsed)
-
-    total_rollouts = args.candidates * world * args.steps
-    value = total_rollouts / elapsed
+    n0, h0, _ = BASELINE_SIZE.get(args.task, (4096, 128, ""))
+    candidates = args.candidates or n0
+    H = args.horizon or h0
+    main_line = run_config(args, args.task, args.planner, candidates, H, args.precision, args.steps, args.warmup, world, local_rank,
+                           group, want_cpu=not args.no_cpu_baseline, rank=rank)
     if rank == 0:
-        bytes_per_rollout = planner.algorithmic_bytes(H, P)
-        bytes_per_launch = bytes_per_rollout * args.candidates
-        avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
-        achieved = bytes_per_launch / avg_kernel_s / 1e9
-        out = {
-            "metric": "candidate-trajectory rollouts/sec (fixed horizon)",
-            "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
-            "config": {"workload": (f"{args.task} Predictive Sampling, {args.candidates} candidates/GPU, horizon {H}, "
-                                    f"{P} cubic spline points, fp{args.precision} " +
-                                    {"Cartpole": "(BASELINE.json configs[1])", "HumanoidTrack": "(BASELINE.json configs[3]: one GPU's 8192-candidate share, fp64 instead of fp32)"}.get(args.task, "")) if args.planner == "sampling" else
-                                   (f"{args.task} Cross-Entropy, {args.candidates} candidates/GPU, horizon {H}, {P} zero-order spline "
-                                    f"points, fp{args.precision} (BASELINE.json configs[2] at --task QuadrupedFlat --candidates 16384 --horizon 100)"),
-                       "candidates_per_gpu": args.candidates, "horizon": H, "spline_points": P,
-                       "parallelism": f"candidates sharded over {world} rank(s)", "kernel": planner.kernel_name, "host": ("C++ mjpc::GpuSamplingPlanner" if args.planner == "sampling" else "C++ mjpc::GpuCrossEntropyPlanner") + " over the C ABI"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": avg_kernel_s * 1e3, "bytes_per_launch": bytes_per_launch,
-                         "note": "algorithmic bytes (SURVEY 8d) / HIP-event time of one rollout on the context's stream "
-                                 "(lane-per-candidate models: its three launches -- time loop, sensor stage, returns; "
-                                 "profiles/ lists each); issue/latency-bound at this batch size, see DESIGN.md"},
-        }
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # collected in separate --pmc runs as MI355X_MICROARCH.md prescribes); only for the profiled workload
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            if args.task == "Cartpole" and args.candidates == 4096 and H == 128 and args.precision == 64:
-                out["roofline"]["traffic"] = pmc["n4096"]["hbm_bytes_per_launch"]
-            if args.task == "QuadrupedFlat" and args.candidates == 16384 and H == 100:
-                pq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_quadruped.json")))
-                out["roofline"]["traffic"] = pq[f"fp{args.precision}"]["derived"]["hbm_bytes_per_launch"]
-            if args.task == "HumanoidTrack" and args.candidates == 8192 and H == 64:
-                ph = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_humanoid.json")))
-                out["roofline"]["traffic"] = ph[f"fp{args.precision}"]["derived"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        if not args.no_cpu_baseline:
-            st = np.concatenate([qpos, qvel])
-            # same workload (model, horizon, spline), batch enlarged so that every host thread has
-            # >= 64 rollouts per fan-out and thread start-up does not dominate the CPU number
-            n_cpu = max(args.candidates, 64 * (os.cpu_count() or 1))
-            out["cpu_baseline"] = cpu_baseline(task, st, H, P, args.cpu_seconds, n_cpu,
-                                               mocap=None if mocap_pos is None else np.hstack([mocap_pos, mocap_quat]).reshape(-1),
-                                               interp=capi.SPLINE_CUBIC if args.planner == "sampling" else capi.SPLINE_ZERO)
+        out = {"metric": "candidate-trajectory rollouts/sec (fixed horizon)", "value": main_line["value"], "unit": "rollouts/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_line["dtype"], "data": "synthetic",
+               "config": main_line["config"], "roofline": main_line["roofline"]}
+        if "cpu_baseline" in main_line:
+            out["cpu_baseline"] = main_line["cpu_baseline"]
+            out["target_check"] = {"gpu_over_cpu": main_line["value"] / main_line["cpu_baseline"]["value"], "north_star_target": 64.0,
+                                   "note": "GPU rollouts/s over the CPU port's at its best thread count (a port, not MuJoCo)"}
+        default_run = (args.task == "QuadrupedFlat" and args.planner == "sampling" and not args.candidates and not args.horizon
+                       and args.precision == 64)
+        if world == 1 and default_run and not args.no_extra:
+            extra = []
+            for name, task_name, kind, prec, steps in (("configs[1]", "Cartpole", "sampling", 64, 50),
+                                                       ("configs[2] (Cross-Entropy planner)", "QuadrupedFlat", "cross_entropy", 64, 5),
+                                                       ("configs[3] (one GPU's share)", "HumanoidTrack", "sampling", 32, 10)):
+                n, h, _ = BASELINE_SIZE[task_name]
+                try:
+                    e = run_config(args, task_name, kind, n, h, prec, steps, 2, 1, local_rank, None,
+                                   want_cpu=(task_name != "QuadrupedFlat") and not args.no_cpu_baseline, rank=0)
+                    e["name"] = name
+                    e["metric"] = "candidate-trajectory rollouts/sec (fixed horizon)"
+                except Exception as ex:
+                    e = {"name": name, "error": repr(ex)}
+                extra.append(e)
+            try:
+                extra.append(run_ilqg(local_rank))
+            except Exception as ex:
+                extra.append({"name": "configs[4] Quadruped iLQG iteration", "error": repr(ex)})
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if group is not None:
         group.barrier()

@@ -19,7 +19,6 @@
 #include "lane_registry.h"
 #include "ilqg_dense.h"
 #include "rollout_wave.h"
-#include "rollout_simt.h"
 
 using namespace mjpcx;
 
@@ -318,7 +317,7 @@ struct mjpcx_ctx {
   // pinned + device-mapped result record of mjpcx_best
   void* best_host = nullptr; void* best_dev = nullptr; size_t best_cap = 0;
   // rollout buffers
-  DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out, d_simt, d_wblob;
+  DevBuf d_nodes, d_in_nodes, d_ilqg, d_ilqg_out, d_wblob;
   DevBuf d_states, d_actions, d_times, d_residual, d_costs, d_trace, d_ret, d_fail, d_sort, d_stage;
   bool traj_candidate_major = false;
   int nsite_model = 0;
@@ -330,6 +329,8 @@ struct mjpcx_ctx {
   WaveHost wh;
   std::vector<unsigned char> blob_scratch;
   std::vector<double> h_stage;
+  // tuning aids read from the environment ONCE, in mjpcx_create: MJPCX_STAMPS=<step> (phase cycle stamps of candidate 0)
+  int stamp_step = -1;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -575,27 +576,11 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       WaveTask wt = c->wh.t;
       wt.blob = (const double*)d_blob;
       wt.stamps = nullptr;
-      // A second mapping of the same step function exists for experiments: lane per candidate with the per-lane state in
-      // the private segment (MJPCX_CONTACT_KERNEL=simt). Measured 4-10x SLOWER than the wavefront-per-candidate kernel
-      // at N <= 16384 (every state access is a dependent ~1 us memory round trip and there are too few wavefronts to
-      // hide it), so it is never selected automatically.
-      const char* force = getenv("MJPCX_CONTACT_KERNEL");
-      const bool simt = force && std::string(force) == "simt";
-      if (simt) {
-        if (c->wh.m.ntendon > 0 || c->wh.m.npair > 0 || c->wh.m.cone != 1)
-          return fail(c, MJPCX_EUNSUPPORTED, "the lane-per-candidate experiment covers elliptic cones and static-vs-moving contacts only");
-        const SimtLayout lay = simt_layout(c->wh.m.nq, c->wh.m.nv, c->wh.m.nu, c->wh.m.nbody, c->wh.m.njnt, c->wh.m.nsite, wt.nr, P);
-        const int nblk = (N + 63) / 64;
-        if (lay.total > kSimtPrivateDoubles) return fail(c, MJPCX_EUNSUPPORTED, "model state exceeds the lane kernel's private segment");
-        if (!MJPCX_SIMT_PRIVATE) HIPCHK(c, c->d_simt.reserve((size_t)nblk * lay.total * 64 * 8));
-        hipLaunchKernelGGL(rollout_simt_kernel, dim3(nblk), dim3(64), 0, c->stream, c->wh.m, wt, a, lay, (double*)c->d_simt.p);
-        le = hipGetLastError();
-      } else {
-      if (getenv("MJPCX_STAMPS")) {
+      if (c->stamp_step >= 0) {
         HIPCHK(c, c->d_stage.reserve(48 * 8));
         HIPCHK(c, hipMemsetAsync(c->d_stage.p, 0, 48 * 8, c->stream));
         wt.stamps = (long long*)c->d_stage.p;
-        wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
+        wt.stamp_step = c->stamp_step;
       }
       const WaveModel& wm = c->wh.m;
       const size_t lds_state = (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
@@ -611,7 +596,6 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         le = hipGetLastError();
       }
       if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds);
-      }
     } else {
       le = c->kernel->launch64(c->hm64, c->ht64, a, c->stream);
     }
@@ -620,11 +604,11 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     WaveTaskT<float> wt = c->wh.t32;
     wt.blob = (const float*)d_blob;
     wt.stamps = nullptr;
-    if (getenv("MJPCX_STAMPS")) {
+    if (c->stamp_step >= 0) {
       HIPCHK(c, c->d_stage.reserve(48 * 8));
       HIPCHK(c, hipMemsetAsync(c->d_stage.p, 0, 48 * 8, c->stream));
       wt.stamps = (long long*)c->d_stage.p;
-      wt.stamp_step = std::atoi(getenv("MJPCX_STAMPS"));
+      wt.stamp_step = c->stamp_step;
     }
     const WaveModelT<float>& wm = c->wh.m32;
     const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
@@ -647,10 +631,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
   slot->pending = true;
   c->N = N; c->H = H; c->P = P;
   c->have_rollout = true;
-  {
-    const char* force = getenv("MJPCX_CONTACT_KERNEL");
-    c->traj_candidate_major = c->wave && !(force && std::string(force) == "simt");
-  }
+  c->traj_candidate_major = c->wave;
   return MJPCX_OK;
 }
 
@@ -686,6 +667,8 @@ const char* mjpcx_last_error(const mjpcx_ctx* ctx) { return ctx ? ctx->last_erro
 const char* mjpcx_kernel_name(const mjpcx_ctx* ctx) { return ctx && ctx->kernel ? ctx->kernel->name : ""; }
 
 static thread_local std::string g_create_error;
+// the environment is read when a context is created, never on the launch path
+static int env_stamp_step() { const char* e = getenv("MJPCX_STAMPS"); return e ? std::atoi(e) : -1; }
 const char* mjpcx_create_error(void) { return g_create_error.c_str(); }
 
 int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int precision, mjpcx_ctx** out) {
@@ -725,7 +708,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     if (hipSetDevice(device) != hipSuccess) return bad(MJPCX_EDEVICE, "hipSetDevice failed");
     mjpcx_ctx* c = new (std::nothrow) mjpcx_ctx();
     if (!c) return bad(MJPCX_ENOMEM, "host allocation failed");
-    c->device = device; c->precision = precision; c->kernel = &kWaveEntry; c->wave = true;
+    c->device = device; c->precision = precision; c->stamp_step = env_stamp_step(); c->kernel = &kWaveEntry; c->wave = true;
     c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap; c->nsite_model = m->nsite;
     c->nr = t->num_residual; c->nterm = t->num_term; c->ntrace = t->num_trace; c->nparam = t->num_parameter;
     c->num_norm_parameter.assign(t->num_norm_parameter, t->num_norm_parameter + t->num_term);
@@ -799,7 +782,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
 
   mjpcx_ctx* c = new (std::nothrow) mjpcx_ctx();
   if (!c) return bad(MJPCX_ENOMEM, "host allocation failed");
-  c->device = device; c->precision = precision; c->kernel = entry;
+  c->device = device; c->precision = precision; c->stamp_step = env_stamp_step(); c->kernel = entry;
   c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap;
   c->nr = t->num_residual; c->nterm = t->num_term; c->ntrace = t->num_trace; c->nparam = t->num_parameter;
   c->num_norm_parameter.assign(t->num_norm_parameter, t->num_norm_parameter + t->num_term);
@@ -837,7 +820,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   }
   if (c->best_host) (void)hipHostFree(c->best_host);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_simt, &c->d_wblob,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();
@@ -1268,7 +1251,7 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
   a.states = (double*)c->d_states.p; a.actions = (double*)c->d_actions.p; a.times = (double*)c->d_times.p;
   a.residual = (double*)c->d_residual.p; a.costs = (double*)c->d_costs.p; a.trace = (double*)c->d_trace.p;
   a.total_return = (double*)c->d_ret.p; a.failure = (int*)c->d_fail.p;
-  FeedbackWaveArgs fb{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state};
+  w64::FeedbackWaveArgs fb{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state};
   const int Ppolicy = (int)((ndx + 2 * ds + nu - 1) / nu + 1);
   const size_t lds = wave_lds_bytes(c, Ppolicy);
   auto kern = c->wh.m.nv <= 20 ? w64::rollout_feedback_wave_kernel<20> : w64::rollout_feedback_wave_kernel<32>;
@@ -1302,7 +1285,7 @@ int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const doubl
   HIPCHK(c, c->d_ilqg_out.reserve(off_A + (nA + nB + nC + nD) * 8));
   char* base = (char*)c->d_ilqg_out.p;
   HIPCHK(c, hipMemcpyAsync(base + off_lim, c->ctrllimited.data(), nu * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  FdWaveArgs f{d[0], d[1], d[2], Tn, (int)nc, eps, (double*)base, (double*)(base + off_sensor)};
+  w64::FdWaveArgs f{d[0], d[1], d[2], Tn, (int)nc, eps, (double*)base, (double*)(base + off_sensor)};
   const size_t lds = wave_lds_bytes(c, 1);
   auto kern = c->wh.m.nv <= 20 ? w64::transition_fd_wave_kernel<20> : w64::transition_fd_wave_kernel<32>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1439,7 +1422,7 @@ int mjpcx_backward_pass(mjpcx_ctx* c, int n, int m, int T, double mu, int reg_ty
   a.A = d[0]; a.B = d[1]; a.cx = d[2]; a.cu = d[3]; a.cxx = d[4]; a.cxu = d[5]; a.cuu = d[6]; a.actions = d[7]; a.limits = d[8];
   a.Vx = o; a.Vxx = a.Vx + sT * sn; a.K = a.Vxx + sT * sn * sn; a.du = a.K + sT * sm * sn; a.dV = a.du + sT * sm;
   a.status = (int*)(a.dV + 2);
-  a.stamps = getenv("MJPCX_STAMPS") ? (long long*)(a.dV + 4) : nullptr;
+  a.stamps = c->stamp_step >= 0 ? (long long*)(a.dV + 4) : nullptr;
   const int NP = (n + 15) & ~15;
   const size_t lds = (size_t)(5 * NP * NP + 2 * NP + 6 * NP * 16 + 5 * 256 + 16 * 23 + 16 * 12) * 8;
   hipEvent_t e0, e1;

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
         if (!bad) a.costs[(size_t)cand * H + t] = cost;
       }
     }
-    if (bad) failed = true;
+    if (bad) { failed = true; break; }  // RolloutDiscrete returns at the first warning (trajectory.cc:268-272)
     total += cost;
     if (last) break;
     if (lane < nv) d.qacc_warm[lane] = d.qacc[lane];

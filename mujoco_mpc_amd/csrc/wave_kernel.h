@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
         if (!bad) a.costs[(size_t)cand * H + t] = cost;
       }
     }
-    if (bad) failed = true;
+    if (bad) { failed = true; break; }  // Trajectory::Rollout returns at the first warning (trajectory.cc:169-173); `bad` is wave-uniform
     total += cost;
     if (last) break;
     WSTAMP(13);

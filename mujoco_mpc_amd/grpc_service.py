@@ -217,13 +217,19 @@ class AgentServicer:
                 context.abort(grpc.StatusCode.INVALID_ARGUMENT, "InitRequest.model.mjb is not supported: send the MJCF in model.xml")
             if request.model.HasField("xml"):
                 from . import mjcf
-                self._tmp = tempfile.TemporaryDirectory(prefix="mjpc_grpc_")
+                from .task import task_names
+                # the task id names the files written below: only a registered task name is accepted (never a path --
+                # "../x" or an absolute path would let a client choose where the server writes), and <include> is resolved
+                # inside the temporary directory only
                 name = request.task_id.replace(" ", "")
+                if name not in {t.replace(" ", "") for t in task_names()} or os.path.basename(name) != name:
+                    context.abort(grpc.StatusCode.INVALID_ARGUMENT, f"Invalid task_id: '{request.task_id}'")
+                self._tmp = tempfile.TemporaryDirectory(prefix="mjpc_grpc_")
                 xml_path = os.path.join(self._tmp.name, name + ".xml")
                 with open(xml_path, "w") as f:
                     f.write(request.model.xml)
                 try:
-                    mjcf.save_blob(mjcf.load_xml(xml_path), os.path.join(self._tmp.name, name + ".mjpx"))
+                    mjcf.save_blob(mjcf.load_xml(xml_path, include_root=self._tmp.name), os.path.join(self._tmp.name, name + ".mjpx"))
                 except Exception as e:  # noqa: BLE001 -- reported to the client as the reference reports a load error
                     context.abort(grpc.StatusCode.INTERNAL, f"Failed to load model: {e}")
                 model_dir = self._tmp.name

@@ -411,8 +411,11 @@ Status AgentService::GetBestTrajectory(std::vector<double>* states, std::vector<
   if (!Initialized()) return kNotInitialized;
   try {
     const Trajectory* tr = agent_.ActivePlanner().BestTrajectory();
+    // no plan yet (right after Init / Reset, or after NominalTrajectory on the Cross-Entropy planner): the planners return
+    // nullptr where the reference returns its pre-allocated buffer -- report it instead of dereferencing
+    if (tr == nullptr) return {kFailedPrecondition, "No trajectory has been planned yet: call PlannerStep first."};
     const int ns = tr->dim_state, na = tr->dim_action;
-    *steps = agent_.PlanSteps();
+    *steps = agent_.PlanSteps() < tr->horizon ? agent_.PlanSteps() : tr->horizon;  // never past the rows this plan wrote
     states->clear(); actions->clear(); times->clear();
     for (int t = 0; t < *steps; t++) {
       states->insert(states->end(), tr->states.begin() + (size_t)t * ns, tr->states.begin() + (size_t)(t + 1) * ns);

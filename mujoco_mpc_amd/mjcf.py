@@ -175,20 +175,25 @@ class _Defaults:
         return out
 
 
-def _expand_includes(elem, base_dir):
+def _expand_includes(elem, base_dir, include_root=None):
+    """include_root: when given, every included file must resolve inside that directory (models sent by a client)"""
     i = 0
     children = list(elem)
     for child in children:
         if child.tag == "include":
             path = os.path.join(base_dir, child.get("file"))
+            if include_root is not None:
+                real, root = os.path.realpath(path), os.path.realpath(include_root)
+                if os.path.commonpath([real, root]) != root:
+                    raise ValueError(f"<include file='{child.get('file')}'> resolves outside the model directory")
             sub = ET.parse(path).getroot()
-            _expand_includes(sub, os.path.dirname(path))
+            _expand_includes(sub, os.path.dirname(path), include_root)
             idx = list(elem).index(child)
             elem.remove(child)
             for k, sc in enumerate(list(sub)):
                 elem.insert(idx + k, sc)
         else:
-            _expand_includes(child, base_dir)
+            _expand_includes(child, base_dir, include_root)
         i += 1
 
 
@@ -819,10 +824,10 @@ def attach_keyframes(fm: FlatModel, names, qpos, qvel, mpos):
                                mpos=fm.arrays["key_mpos"][i])
 
 
-def load_xml(path: str) -> FlatModel:
+def load_xml(path: str, include_root: str = None) -> FlatModel:
     path = os.path.abspath(path)
     root = ET.parse(path).getroot()
-    _expand_includes(root, os.path.dirname(path))
+    _expand_includes(root, os.path.dirname(path), include_root)
     return _Compiler(root, path).compile()
 
 
