@@ -321,7 +321,9 @@ int mjpcx_set_residual_state(mjpcx_ctx* ctx, const int32_t* residual_int, const 
 /* Block until everything queued on the context's stream has finished. */
 int mjpcx_sync(mjpcx_ctx* ctx);
 
-/* total_return[N], failure[N] (Trajectory::total_return / failure). */
+/* total_return[N], failure[N] (Trajectory::total_return / failure). failure: 0 = the rollout completed, non-zero = it
+ * stopped at a warning (trajectory.cc:169-173). The wavefront-per-candidate kernels put diagnostics above the low
+ * byte: (warning bits << 8) | (failing step << 16); bits: 16 = Hessian not positive definite, 32 = contact list full. */
 int mjpcx_get_returns(mjpcx_ctx* ctx, double* total_return, int32_t* failure);
 
 /* total_return / failure of one candidate (e.g. trajectory[0], the nominal,

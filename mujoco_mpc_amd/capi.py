@@ -220,7 +220,10 @@ class Context:
         ret = np.zeros(self.N)
         fl = np.zeros(self.N, np.int32)
         self._chk(lib().mjpcx_get_returns(self.handle, as_f64p(ret), as_i32p(fl)))
-        return ret, fl
+        # non-zero = failed (Trajectory::failure); the wavefront kernels add diagnostics above the low byte
+        # (warning bits << 8 | failing step << 16), kept for tools in failure_raw
+        self.failure_raw = fl.copy()
+        return ret, (fl != 0).astype(np.int32)
 
     def return_of(self, candidate):
         r = C.c_double()

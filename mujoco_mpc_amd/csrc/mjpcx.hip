@@ -331,6 +331,7 @@ struct mjpcx_ctx {
   std::vector<double> h_stage;
   // tuning aids read from the environment ONCE, in mjpcx_create: MJPCX_STAMPS=<step> (phase cycle stamps of candidate 0)
   int stamp_step = -1;
+  bool no_tree = false;  // MJPCX_NO_TREE=1: keep the row-table constraint path (A/B runs)
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -583,12 +584,14 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         wt.stamp_step = c->stamp_step;
       }
       const WaveModel& wm = c->wh.m;
-      const size_t lds_state = (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
-      const size_t lds = lds_state;
+      const bool tree = c->wh.tree_ok && !c->no_tree;
+      const size_t lds = tree ? (8 * w64::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, a.xfrc_scale > 0) + 15) & ~(size_t)15
+                              : (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
       // the register-resident Cholesky is unrolled to NMAX columns: instantiations that fit the registered models exactly (A1:
       // nv = 18, humanoid: 27) skip the padding columns' updates (humanoid: 30 % of the factorisation's instructions)
-      auto kern = wm.nv <= 18 ? w64::rollout_wave_kernel<18> : wm.nv <= 20 ? w64::rollout_wave_kernel<20>
+      auto kern = tree ? (wm.nv <= 18 ? w64::rollout_wave_kernel<18, true> : w64::rollout_wave_kernel<32, true>)
+                : wm.nv <= 18 ? w64::rollout_wave_kernel<18> : wm.nv <= 20 ? w64::rollout_wave_kernel<20>
                 : wm.nv <= 28 ? w64::rollout_wave_kernel<28> : w64::rollout_wave_kernel<32>;
       le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (le == hipSuccess) {
@@ -708,7 +711,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     if (hipSetDevice(device) != hipSuccess) return bad(MJPCX_EDEVICE, "hipSetDevice failed");
     mjpcx_ctx* c = new (std::nothrow) mjpcx_ctx();
     if (!c) return bad(MJPCX_ENOMEM, "host allocation failed");
-    c->device = device; c->precision = precision; c->stamp_step = env_stamp_step(); c->kernel = &kWaveEntry; c->wave = true;
+    c->device = device; c->precision = precision; c->stamp_step = env_stamp_step(); c->no_tree = getenv("MJPCX_NO_TREE") != nullptr; c->kernel = &kWaveEntry; c->wave = true;
     c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap; c->nsite_model = m->nsite;
     c->nr = t->num_residual; c->nterm = t->num_term; c->ntrace = t->num_trace; c->nparam = t->num_parameter;
     c->num_norm_parameter.assign(t->num_norm_parameter, t->num_norm_parameter + t->num_term);

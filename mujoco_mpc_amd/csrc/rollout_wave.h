@@ -59,6 +59,7 @@ __device__ __forceinline__ float dpp_move(float v) {
 #define MJPCX_WAVE_ILQG 1
 #include "wave_core.h"
 #include "wave_forward.h"
+#include "wave_tree.h"
 #include "wave_residual.h"
 #include "wave_kernel.h"
 #include "wave_ilqg.h"
@@ -73,6 +74,7 @@ __device__ __forceinline__ float dpp_move(float v) {
 #define WAVE_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #include "wave_core.h"
 #include "wave_forward.h"
+#include "wave_tree.h"
 #include "wave_residual.h"
 #include "wave_kernel.h"
 #undef WAVE_KERNEL_ATTR

@@ -60,7 +60,7 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WM
   return d;
 }
 
-template <int NMAX>
+template <int NMAX, bool TREE = false>
 __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x, cand = blockIdx.x;
@@ -73,7 +73,10 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
   // ---- LDS carve
   wreal* lnodes; wreal* ltimes;
   const bool noisy = a.xfrc_scale > 0;
-  WaveData d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes, /*nodes_in_lds=*/false, noisy);
+  TreeData tree;
+  WaveData d;
+  if constexpr (TREE) { lnodes = nullptr; d = wave_carve_tree(smem_raw, m, tk, P, ltimes, noisy, tree); }
+  else d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes, /*nodes_in_lds=*/false, noisy);
   // The candidate's spline nodes stay in a.nodes ([node][actuator][candidate], HBM / L2): at most four of them per
   // actuator are read per step; volatile reads, because other lanes of this wavefront wrote them.
   const volatile wreal* gnodes = a.nodes + cand;
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
   const int ds = nq + nv;
   wreal total = 0;
   bool failed = false;
+  int fail_info = 0;  // diagnostics of a failed rollout: warning bits << 8 | step << 16 (failure stays "non-zero = failed")
   for (int t = 0; t < H; t++) {
     const bool last = t == H - 1;
     bool bad = false;
@@ -183,7 +187,8 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
     bool bad_ctrl = false;
     long long* stamp = (tk.stamps && cand == 0 && t == tk.stamp_step) ? tk.stamps : nullptr;
     WSTAMP(0);
-    wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, stamp, /*have_warm=*/t > 0);
+    if constexpr (TREE) wt_forward<NMAX>(m, tk, d, tree, lane, bad_ctrl, stamp, /*have_warm=*/t > 0);
+    else wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, stamp, /*have_warm=*/t > 0);
     if (!last) for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qacc[i]);  // mj_checkAcc
     if (!last) bad |= d.counters[2] != 0;  // CheckWarnings: contact / row cap overflow, indefinite Hessian (oracle odata_warning)
     bad = __any(bad);
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
         if (!bad) a.costs[(size_t)cand * H + t] = cost;
       }
     }
-    if (bad) { failed = true; break; }  // Trajectory::Rollout returns at the first warning (trajectory.cc:169-173); `bad` is wave-uniform
+    if (bad) { failed = true; fail_info = (d.counters[2] << 8) | (t << 16); break; }  // Trajectory::Rollout returns at the first warning (trajectory.cc:169-173); `bad` is wave-uniform
     total += cost;
     if (last) break;
     WSTAMP(13);
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
   }
   if (lane == 0) {
     a.total_return[cand] = failed ? kMaxReturn : total / (wreal)(H > 1 ? H : 1);
-    a.failure[cand] = failed ? 1 : 0;
+    a.failure[cand] = failed ? (1 | fail_info) : 0;
   }
 }
 

@@ -107,6 +107,7 @@ struct WaveHost {
   void* dev32 = nullptr;
   size_t blob_bytes32 = 0;
   size_t blob_doubles = 0, blob_bytes = 0;
+  bool tree_ok = false;  // the Jacobian-free constraint path (wave_tree.h) covers this model
   std::vector<double> state, mocap, weight, norm_p, norm_q, parameters, residual_real;
   std::vector<int32_t> residual_int, norm_types;
   double time = 0, risk = 0;
@@ -262,6 +263,19 @@ struct WaveHost {
     reg(&m.pair_g1, pg1.data(), sizeof(int) * pg1.size());
     reg(&m.pair_g2, pg2.data(), sizeof(int) * pg2.size());
     for (int j = 0; j < nj; j++) m.full |= src->jnt_type[j] == MJPCX_JNT_FREE || src->jnt_type[j] == MJPCX_JNT_BALL;
+    {
+      // wave_tree.h: one moving kinematic tree (all cdof about the same point), no limited tendons, elliptic cones or
+      // frictionless contacts only
+      int root = -1;
+      bool one_tree = true, limited_tendon = false;
+      int max_condim = 1;
+      for (int b = 1; b < nb; b++)
+        if (dofmask[b] != 0) { if (root < 0) root = src->body_rootid[b]; else one_tree &= src->body_rootid[b] == root; }
+      for (int t = 0; t < nt; t++) limited_tendon |= src->tendon_limited[t] != 0;
+      for (int g = 0; g < ng; g++)
+        if (src->geom_contype[g] || src->geom_conaffinity[g]) max_condim = src->geom_condim[g] > max_condim ? src->geom_condim[g] : max_condim;
+      tree_ok = one_tree && !limited_tendon && (src->cone == 1 || max_condim == 1) && nv <= 32;
+    }
     reg(&m.body_subtree_mask, sub.data(), sizeof(unsigned long long) * nb);
     reg(&m.body_dofmask, dofmask.data(), sizeof(unsigned) * nb);
     reg(&m.level_body, level_body.data(), sizeof(int) * level_body.size());

@@ -30,8 +30,8 @@
 #define OMAXIMP 0.9999 /* mjMAXIMP */
 #define OLS_TOLERANCE 0.01 /* mjOption.ls_tolerance default (not carried by mjpcx_model) */
 #define OMAXVAL 1e10  /* mjMAXVAL */
-#define OMAXEFC 64 /* = kWaveMaxEfc of the device kernel: rows beyond the cap are dropped identically */
-#define OMAXCON 16 /* = kWaveMaxCon */
+#define OMAXEFC 1024 /* MuJoCo grows its arena on demand; the oracle carries a MuJoCo-sized one (cap-induced failures are the device's to avoid) */
+#define OMAXCON 256
 #define OMINMU 1e-5 /* mjMINMU */
 
 typedef struct OContact {

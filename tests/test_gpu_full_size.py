@@ -35,8 +35,10 @@ def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, t
     ctx.set_state(state, 0.0, mocap)
     ctx.rollout_noise(N, H, interp, times, nominal, ns)
     ret, fail = ctx.returns()
-    # a tumbling A1 can exceed the solver's row capacity: such a rollout FAILS (return 1e6), on the device as in the oracle
-    assert fail.mean() < 0.05 and np.all(np.isfinite(ret)) and np.all(ret > 0) and np.all(ret[fail != 0] == 1.0e6)
+    # no capacity-induced failures: MuJoCo grows its arena, the oracle carries a MuJoCo-sized one, and none of these workloads
+    # produces a genuine warning (the sample in (e) pins the failure flags to the oracle's one by one)
+    assert not fail.any(), (int(fail.sum()), [hex(int(x)) for x in ctx.failure_raw[fail != 0][:8]])
+    assert np.all(np.isfinite(ret)) and np.all(ret > 0)
     # (a) determinism
     ctx.rollout_noise(N, H, interp, times, nominal, ns)
     assert np.array_equal(ctx.returns()[0], ret)
