@@ -95,6 +95,8 @@ const KernelEntry kKernels[] = {
 
 // the wavefront-per-candidate family is selected by model FEATURES (free/ball joints, friction loss, contacts),
 // not by topology: one generic kernel that reads the model through WaveModel
+const KernelEntry kTreeEntryA1 = {"rollout_tree_kernel<A1> (registered model: hot arrays staged in LDS behind compile-time offsets, persistent wavefronts, "
+                                   "Jacobian-free Newton contact solver)", TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 const KernelEntry kWaveEntry = {"rollout_wave_kernel (wavefront per candidate, model in LDS/L1; Newton contact solver)",
                                 TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -332,6 +334,14 @@ struct mjpcx_ctx {
   // tuning aids read from the environment ONCE, in mjpcx_create: MJPCX_STAMPS=<step> (phase cycle stamps of candidate 0)
   int stamp_step = -1;
   bool no_tree = false;  // MJPCX_NO_TREE=1: keep the row-table constraint path (A/B runs)
+  bool no_lds_model = false;  // MJPCX_NO_LDS_MODEL=1: generic kernel even for a registered model (A/B runs)
+  int max_waves = 8;          // MJPCX_TREE_WAVES=<1..8>: wavefronts per workgroup of the registered-model kernel
+  int tree_mode = 0;          // MJPCX_TREE_MODE=2: image self-check launch (tree_kernel.h)
+  bool no_second_pass = false;  // MJPCX_TREE_ONE_PASS=1: leave list overflows as failures (tuning: counts them)
+  DevBuf d_work;              // its self-check counter
+  DevBuf d_ovf;               // its global slabs for cones beyond the LDS list
+  bool no_cone_slabs = false; // MJPCX_TREE_NO_SLABS=1: overflow goes to the second pass instead (A/B runs)
+  int num_cu = 256;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -498,19 +508,82 @@ int stage_plan_inputs(mjpcx_ctx* c, int P, const double* node_times, const doubl
 }
 
 // tuning aid (MJPCX_STAMPS=<step>): phase cycle stamps of candidate 0 at one step of the wavefront-per-candidate kernel
-void print_wave_stamps(mjpcx_ctx* c, long long* stamps, int stamp_step, size_t lds) {
+void print_wave_stamps(mjpcx_ctx* c, long long* stamps, int stamp_step, size_t lds, bool tree = false) {
   long long h[48];
   (void)hipStreamSynchronize(c->stream);
   (void)hipMemcpy(h, stamps, sizeof h, hipMemcpyDeviceToHost);
   static const char* nm[] = {"policy", "kinematics", "compos", "crb", "cholM", "collision", "comvel", "make_constraint", "smooth", "solve",
                              "newton", "residual", "cost+record", "euler"};
+  static const char* nt[] = {"policy", "kinematics", "compos", "crb", "cholM", "comvel", "smooth", "solve", "collision", "make_constraint",
+                             "newton", "residual", "cost+record", "euler"};
   std::fprintf(stderr, "wave kernel phase cycles (step %d, candidate 0; LDS %zu B):", stamp_step, lds);
-  for (int k = 0; k < 14; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k + 1] - h[k]);
+  for (int k = 0; k < 14; k++) std::fprintf(stderr, " %s %lld", tree ? nt[k] : nm[k], h[k + 1] - h[k]);
   std::fprintf(stderr, " | newton iters %lld: grad %lld hess %lld chol+solve %lld linesearch %lld\n", h[20], h[21] - h[10], h[22] - h[21],
                h[23] - h[22], h[24] - h[23]);
   std::fprintf(stderr, "  newton totals over iterations: grad %lld coneblocks %lld hess %lld chol+solve %lld jv+q %lld linesearch %lld (%lld trials) update+cost %lld\n",
                h[32], h[33], h[34], h[35], h[36], h[37], h[39], h[38]);
   std::fprintf(stderr, "  hessian parts: copy M %lld diagonal rows %lld row facts %lld simple rows (MFMA) %lld cones = hess - these\n", h[40], h[41], h[42], h[43]);
+}
+
+// registered model (lds_model.h / tree_kernel.h): [image | blob | W arenas] of LDS per workgroup, W <= 8 wavefronts, persistent.
+// Two launches: the batch with the small contact lists, then the candidates that overflowed them with the large lists.
+template <class C, typename T, bool BIG>
+hipError_t launch_tree_pass(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>& wt, const RolloutArgs<T>& a, const void* image, size_t blob_bytes,
+                            int N, int P) {
+  const int caps = BIG ? (sizeof(T) == 8 ? w64::kTreeMaxSimpleBig : w32::kTreeMaxSimpleBig) : (sizeof(T) == 8 ? w64::kTreeMaxSimple : w32::kTreeMaxSimple);
+  const int capc = BIG ? (sizeof(T) == 8 ? w64::kTreeMaxConeBig : w32::kTreeMaxConeBig) : (sizeof(T) == 8 ? w64::kTreeMaxCone : w32::kTreeMaxCone);
+  const size_t arena = sizeof(T) == 8
+      ? (8 * w64::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, a.xfrc_scale > 0, caps, capc) + 15) & ~(size_t)15
+      : (4 * w32::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, a.xfrc_scale > 0, caps, capc) + 15) & ~(size_t)15;
+  const size_t fixed = LdsLayout<C, T>::kBytes + blob_bytes;
+  if (fixed + arena > 160 * 1024) return hipErrorInvalidValue;
+  int W = (int)std::min<size_t>((size_t)c->max_waves, (160 * 1024 - fixed) / arena);
+  W = std::max(1, std::min(W, (N + c->num_cu - 1) / c->num_cu));  // small batches: spread over the CUs first
+  int grid = std::min(c->num_cu, (N + W - 1) / W);
+  if (BIG) grid = std::min(grid, 64);  // the second pass scans the failure flags; a handful of rollouts at most
+  const int mode = BIG ? 0 : c->tree_mode;
+  const size_t lds = fixed + (size_t)W * arena;
+  hipError_t e = c->d_work.reserve(16);
+  if (e != hipSuccess) return e;
+  if (mode & 2) if ((e = hipMemsetAsync(c->d_work.p, 0, 8, c->stream)) != hipSuccess) return e;
+  // first pass: one slab per wavefront for the cones beyond the LDS list (wave_tree.h; a few tens of MB, never touched in the common case)
+  void* slabs = nullptr;
+  if (!BIG && !c->no_cone_slabs) {
+    const size_t per_wave = (size_t)(w64::kTreeMaxConeTotal - capc) * w64::kConeRec * sizeof(T);
+    if ((e = c->d_ovf.reserve((size_t)grid * W * per_wave)) != hipSuccess) return e;
+    slabs = c->d_ovf.p;
+  }
+  if constexpr (sizeof(T) == 8) {
+    auto kern = w64::rollout_tree_kernel<C, BIG>;
+    if ((e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, c->stream, wm, wt, a, (const unsigned char*)image, (unsigned)blob_bytes, (unsigned)arena,
+                       (int*)c->d_work.p, mode, (T*)slabs);
+  } else {
+    auto kern = w32::rollout_tree_kernel<C, BIG>;
+    if ((e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, c->stream, wm, wt, a, (const unsigned char*)image, (unsigned)blob_bytes, (unsigned)arena,
+                       (int*)c->d_work.p, mode, (T*)slabs);
+  }
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (c->stamp_step >= 0) std::fprintf(stderr, "rollout_tree_kernel%s: %d wavefronts per workgroup, grid %d, LDS %zu B (arena %zu B)\n", BIG ? " (second pass)" : "", W, grid, lds, arena);
+  if (mode & 2) {  // self-check launch: report the mismatch count
+    int h[2] = {0, 0};
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h, c->d_work.p, 8, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "rollout_tree_kernel self-check: %d mismatching entries between the LDS image and the model (W = %d, grid = %d, lds = %zu B)\n", h[1], W, grid, lds);
+  }
+  return hipSuccess;
+}
+template <class C, typename T>
+hipError_t launch_tree(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>& wt, const RolloutArgs<T>& a, const void* image, size_t blob_bytes,
+                       int N, int P) {
+  hipError_t e = launch_tree_pass<C, T, false>(c, wm, wt, a, image, blob_bytes, N, P);
+  if (e != hipSuccess || (c->tree_mode & 2) || c->no_second_pass) return e;
+  RolloutArgs<T> a2 = a;
+  a2.noise.mode = -1;  // the first pass left every candidate's spline nodes in a.nodes
+  WaveTaskT<T> wt2 = wt;
+  wt2.stamps = nullptr;
+  return launch_tree_pass<C, T, true>(c, wm, wt2, a2, image, blob_bytes, N, P);
 }
 
 template <typename T>
@@ -584,8 +657,12 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         wt.stamp_step = c->stamp_step;
       }
       const WaveModel& wm = c->wh.m;
+      if (c->wh.registered == 0) {
+        le = launch_tree<TreeCfgA1, double>(c, wm, wt, a, c->wh.dev_image, c->wh.blob_bytes, N, P);
+        if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
+      } else {
       const bool tree = c->wh.tree_ok && !c->no_tree;
-      const size_t lds = tree ? (8 * w64::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, a.xfrc_scale > 0) + 15) & ~(size_t)15
+      const size_t lds = tree ? (8 * w64::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, a.xfrc_scale > 0, w64::kTreeMaxSimpleBig, w64::kTreeMaxConeBig) + 15) & ~(size_t)15
                               : (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
       // the register-resident Cholesky is unrolled to NMAX columns: instantiations that fit the registered models exactly (A1:
@@ -598,7 +675,8 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
         le = hipGetLastError();
       }
-      if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds);
+      if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds, tree);
+      }
     } else {
       le = c->kernel->launch64(c->hm64, c->ht64, a, c->stream);
     }
@@ -614,6 +692,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       wt.stamp_step = c->stamp_step;
     }
     const WaveModelT<float>& wm = c->wh.m32;
+    if (c->wh.registered == 0) {
+      le = launch_tree<TreeCfgA1, float>(c, wm, wt, a, c->wh.dev_image32, c->wh.blob_bytes32, N, P);
+      if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
+    } else {
     const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
     auto kern = wm.nv <= 18 ? w32::rollout_wave_kernel<18> : wm.nv <= 20 ? w32::rollout_wave_kernel<20>
@@ -624,6 +706,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       le = hipGetLastError();
     }
     if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds);
+    }
   } else {
     convert_task(c->ht32, c->ht64);
     le = c->kernel->launch32(c->hm32, c->ht32, a, c->stream);
@@ -711,7 +794,12 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     if (hipSetDevice(device) != hipSuccess) return bad(MJPCX_EDEVICE, "hipSetDevice failed");
     mjpcx_ctx* c = new (std::nothrow) mjpcx_ctx();
     if (!c) return bad(MJPCX_ENOMEM, "host allocation failed");
-    c->device = device; c->precision = precision; c->stamp_step = env_stamp_step(); c->no_tree = getenv("MJPCX_NO_TREE") != nullptr; c->kernel = &kWaveEntry; c->wave = true;
+    c->device = device; c->precision = precision; c->stamp_step = env_stamp_step(); c->no_tree = getenv("MJPCX_NO_TREE") != nullptr; c->no_lds_model = getenv("MJPCX_NO_LDS_MODEL") != nullptr;
+    if (const char* e = getenv("MJPCX_TREE_WAVES")) c->max_waves = std::max(1, std::min(8, std::atoi(e)));
+    if (const char* e = getenv("MJPCX_TREE_MODE")) c->tree_mode = std::atoi(e);
+    c->no_second_pass = getenv("MJPCX_TREE_ONE_PASS") != nullptr;
+    c->no_cone_slabs = getenv("MJPCX_TREE_NO_SLABS") != nullptr;
+    c->kernel = &kWaveEntry; c->wave = true;
     c->nq = m->nq; c->nv = m->nv; c->nu = m->nu; c->na = m->na; c->nmocap = m->nmocap; c->nsite_model = m->nsite;
     c->nr = t->num_residual; c->nterm = t->num_term; c->ntrace = t->num_trace; c->nparam = t->num_parameter;
     c->num_norm_parameter.assign(t->num_norm_parameter, t->num_norm_parameter + t->num_term);
@@ -720,6 +808,19 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     c->ctrlrange.assign(m->actuator_ctrlrange, m->actuator_ctrlrange + 2 * m->nu);
     const std::string err = c->wh.build(m, t, precision == 32);
     if (!err.empty()) { mjpcx_destroy(c); return bad(MJPCX_EUNSUPPORTED, err); }
+    if (c->wh.tree_ok && !c->no_tree && !c->no_lds_model && lds_model_matches<TreeCfgA1>(m, t, c->wh)) {
+      // registered model: the LDS image of its hot arrays (lds_model.h), in the context's precision
+      std::vector<unsigned char> img = precision == 64 ? lds_model_image<TreeCfgA1, double>(m, t, c->wh) : lds_model_image<TreeCfgA1, float>(m, t, c->wh);
+      void** slot = precision == 64 ? &c->wh.dev_image : &c->wh.dev_image32;
+      if (hipMalloc(slot, img.size()) != hipSuccess || hipMemcpy(*slot, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        mjpcx_destroy(c);
+        return bad(MJPCX_ENOMEM, "upload of the model's LDS image failed");
+      }
+      c->wh.registered = 0;
+      c->kernel = &kTreeEntryA1;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
+    }
     set_norm_params(c, t->norm_parameter);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
     *out = c;
@@ -823,7 +924,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   }
   if (c->best_host) (void)hipHostFree(c->best_host);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();

@@ -18,6 +18,8 @@
 #include "device_common.h"
 #include "rollout_lane.h"  // RolloutArgs / NoiseArgs
 #include "wave_model.h"
+#include "lds_model.h"
+#include "tree_registry.h"
 #include "ilqg_kernels.h"  // find_interval, fd_assemble_kernel
 
 // The device code below is instantiated twice, textually: namespace mjpcx::w64 with wreal = double (the parity path, also
@@ -62,6 +64,7 @@ __device__ __forceinline__ float dpp_move(float v) {
 #include "wave_tree.h"
 #include "wave_residual.h"
 #include "wave_kernel.h"
+#include "tree_kernel.h"
 #include "wave_ilqg.h"
 #undef MJPCX_WAVE_ILQG
 #undef WAVE_KERNEL_ATTR
@@ -77,6 +80,7 @@ __device__ __forceinline__ float dpp_move(float v) {
 #include "wave_tree.h"
 #include "wave_residual.h"
 #include "wave_kernel.h"
+#include "tree_kernel.h"
 #undef WAVE_KERNEL_ATTR
 #undef wreal
 #undef WAVE_NS

@@ -248,7 +248,8 @@ __device__ __noinline__ wreal w_impedance(const wreal* solimp, wreal dist) {
   else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
   return dmin + y * (dmax - dmin);
 }
-__device__ __forceinline__ void w_solref_kb(const WModel& m, const wreal* solref, const wreal* solimp, wreal& k, wreal& b) {
+template <class MODEL>
+__device__ __forceinline__ void w_solref_kb(const MODEL& m, const wreal* solref, const wreal* solimp, wreal& k, wreal& b) {
   const wreal dmax = fmin(fmax(solimp[1], kMinImp), kMaxImp);
   if (solref[0] > 0) {
     wreal tc = solref[0];

@@ -4,7 +4,8 @@
 namespace mjpcx { namespace WAVE_NS {
 
 // ---- o_kinematics: bodies level by level (a body needs its parent), then sites
-__device__ __forceinline__ void wf_kinematics(const WModel& m, const WTask& tk, WaveData& d, int lane) {
+template <class MODEL, class TASK>
+__device__ __forceinline__ void wf_kinematics(const MODEL& m, const TASK& tk, WaveData& d, int lane) {
   if (lane == 0) {
     d.xpos[0] = d.xpos[1] = d.xpos[2] = 0;
     d.xquat[0] = 1; d.xquat[1] = d.xquat[2] = d.xquat[3] = 0;
@@ -77,7 +78,8 @@ __device__ __forceinline__ void wf_kinematics(const WModel& m, const WTask& tk, 
 }
 
 // world pose of a geom (o_geom_kinematics), computed where it is needed instead of being stored for all geoms
-__device__ __forceinline__ void wf_geom_pose(const WModel& m, const WaveData& d, int g, wreal* pos, wreal* mat) {
+template <class MODEL>
+__device__ __forceinline__ void wf_geom_pose(const MODEL& m, const WaveData& d, int g, wreal* pos, wreal* mat) {
   const int b = m.geom_bodyid[g];
   wreal v[3], q[4];
   mv3(v, d.xmat + 9 * b, m.geom_pos + 3 * g);
@@ -87,7 +89,8 @@ __device__ __forceinline__ void wf_geom_pose(const WModel& m, const WaveData& d,
 }
 
 // ---- o_compos: subtree centres of mass, cinert, cdof
-__device__ __forceinline__ void wf_compos(const WModel& m, WaveData& d, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void wf_compos(const MODEL& m, WaveData& d, int lane) {
   const int nb = m.nbody;
   if (lane < nb) {
     const int i = lane;
@@ -151,7 +154,8 @@ __device__ __forceinline__ void wf_compos(const WModel& m, WaveData& d, int lane
 }
 
 // ---- o_crb: composite inertias by subtree masks, then M (dense, both triangles)
-__device__ __forceinline__ void wf_crb(const WModel& m, WaveData& d, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void wf_crb(const MODEL& m, WaveData& d, int lane) {
   const int nb = m.nbody, nv = m.nv;
   if (lane < nb && lane > 0) {
     const int i = lane;
@@ -182,7 +186,8 @@ __device__ __forceinline__ void wf_crb(const WModel& m, WaveData& d, int lane) {
 }
 
 // ---- o_comvel: cvel and cdof_dot, level by level
-__device__ __forceinline__ void wf_comvel(const WModel& m, WaveData& d, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void wf_comvel(const MODEL& m, WaveData& d, int lane) {
   if (lane < 6) d.cvel[lane] = 0;
   WSYNC();
   for (int l = 0; l < m.nlevel; l++) {
@@ -216,7 +221,8 @@ __device__ __forceinline__ void wf_comvel(const WModel& m, WaveData& d, int lane
 }
 
 // ---- o_passive, o_rne (bias forces), o_actuation, qfrc_smooth
-__device__ __forceinline__ void wf_smooth_forces(const WModel& m, WaveData& d, int lane, bool& bad_ctrl) {
+template <class MODEL>
+__device__ __forceinline__ void wf_smooth_forces(const MODEL& m, WaveData& d, int lane, bool& bad_ctrl) {
   const int nb = m.nbody, nv = m.nv, nu = m.nu;
   // passive
   if (lane < nv) {
@@ -317,7 +323,8 @@ __device__ __forceinline__ void wf_smooth_forces(const WModel& m, WaveData& d, i
 }
 
 // ---- o_collision: one lane per moving geom against each static geom; order-preserving compaction
-__device__ __forceinline__ void wf_contact_param(const WModel& m, int g1, int g2, WaveContact& c) {
+template <class MODEL>
+__device__ __forceinline__ void wf_contact_param(const MODEL& m, int g1, int g2, WaveContact& c) {
   const wreal margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
   const wreal gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
   c.margin = margin;
@@ -344,7 +351,8 @@ __device__ __forceinline__ void wf_contact_param(const WModel& m, int g1, int g2
   c.dim0 = c.dim;
 }
 
-__device__ __forceinline__ void wf_collision(const WModel& m, WaveData& d, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void wf_collision(const MODEL& m, WaveData& d, int lane) {
   if (lane == 0) d.counters[0] = 0;
   WSYNC();
   if (m.disableflags & (MJPCX_DSBL_CONSTRAINT | MJPCX_DSBL_CONTACT)) return;
@@ -618,7 +626,8 @@ __device__ __forceinline__ void wf_collision(const WModel& m, WaveData& d, int l
 }
 
 // ---- o_make_constraint_full: rows in the order friction loss, limits, contacts; then impedance/aref/R per row
-__device__ __forceinline__ void wf_make_constraint(const WModel& m, WaveData& d, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void wf_make_constraint(const MODEL& m, WaveData& d, int lane) {
   const int nv = m.nv;
   int nefc = 0;
   if (m.disableflags & MJPCX_DSBL_CONSTRAINT) { if (lane == 0) { d.counters[0] = 0; d.counters[1] = 0; } WSYNC(); return; }
@@ -999,8 +1008,8 @@ __device__ __forceinline__ wreal wf_constraint_cost(WaveData& d, int nefc, int l
 }
 
 // ---- o_constraint_newton
-template <int NMAX>
-__device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& d, int lane, long long* stamp = nullptr, bool have_warm = false) {
+template <int NMAX, class MODEL>
+__device__ __forceinline__ void wf_constraint_newton(const MODEL& m, WaveData& d, int lane, long long* stamp = nullptr, bool have_warm = false) {
   const int nv = m.nv, ne = __builtin_amdgcn_readfirstlane(d.counters[1]);
   if (lane < nv) { d.qfrc_constraint[lane] = 0; d.qacc[lane] = d.qacc_smooth[lane]; }
   WSYNC();
@@ -1303,8 +1312,8 @@ __device__ __forceinline__ void wf_constraint_newton(const WModel& m, WaveData& 
 
 // ---- mj_forward up to the constraint solve
 #define WSTAMP(k) do { if (stamp && lane == 0) stamp[k] = (long long)__builtin_readcyclecounter(); } while (0)
-template <int NMAX>
-__device__ __forceinline__ void wf_forward(const WModel& m, const WTask& tk, WaveData& d, int lane, bool& bad_ctrl,
+template <int NMAX, class MODEL, class TASK>
+__device__ __forceinline__ void wf_forward(const MODEL& m, const TASK& tk, WaveData& d, int lane, bool& bad_ctrl,
                                            long long* stamp, bool have_warm) {
   const int nv = m.nv;
   WSTAMP(1);
@@ -1334,8 +1343,8 @@ __device__ __forceinline__ void wf_forward(const WModel& m, const WTask& tk, Wav
 }
 
 // ---- o_euler: implicit joint damping, then integrate positions
-template <int NMAX>
-__device__ __forceinline__ void wf_euler(const WModel& m, WaveData& d, int lane, wreal& time) {
+template <int NMAX, class MODEL>
+__device__ __forceinline__ void wf_euler(const MODEL& m, WaveData& d, int lane, wreal& time) {
   const int nv = m.nv;
   const wreal h = m.timestep;
   if (m.any_damping && !(m.disableflags & MJPCX_DSBL_EULERDAMP)) {

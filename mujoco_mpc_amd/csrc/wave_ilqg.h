@@ -34,7 +34,8 @@ __device__ __forceinline__ void wq_integrate(wreal* q, const wreal* v, wreal h) 
   q_mul(q, q, qr);
 }
 // StateDiff: dx (2 nv, LDS) = (s2 - s1) / 1 in the tangent space; one lane per joint, then one per dof for velocities
-__device__ __forceinline__ void w_state_diff(const WModel& m, wreal* dx, const wreal* s1, const wreal* s2, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void w_state_diff(const MODEL& m, wreal* dx, const wreal* s1, const wreal* s2, int lane) {
   const int nq = m.nq, nv = m.nv;
   if (lane < m.njnt) {
     int qa = m.jnt_qposadr[lane], da = m.jnt_dofadr[lane];

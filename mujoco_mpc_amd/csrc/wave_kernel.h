@@ -25,7 +25,8 @@ __host__ __device__ inline size_t wave_lds_elems(int nq, int nv, int nu, int nbo
 }
 
 // the LDS layout of one candidate's mjData (shared by the rollout, feedback-rollout and finite-difference kernels)
-__device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WModel& m, const WTask& tk, int P, wreal*& lnodes,
+template <class MODEL, class TASK>
+__device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const MODEL& m, const TASK& tk, int P, wreal*& lnodes,
                                                wreal*& ltimes, bool nodes_in_lds = true, bool xfrc = false) {
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
   wreal* p = reinterpret_cast<wreal*>(smem_raw);
@@ -60,13 +61,10 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const WM
   return d;
 }
 
-template <int NMAX, bool TREE = false>
-__global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lane = threadIdx.x, cand = blockIdx.x;
-  // The model and task structs stay in the kernel-argument segment (scalar loads). Staging the model allocation into
-  // LDS was tried (DESIGN.md 4.5): no shorter step, fewer candidates per CU, and a run-time-rebased copy of this struct
-  // ends up in the private segment -- every pointer fetch becomes a scratch load.
+// One candidate's Trajectory::Rollout + UpdateReturn by one wavefront; `smem_raw` is the wavefront's own arena in LDS.
+template <int NMAX, bool TREE, int CAPS = kTreeMaxSimple, int CAPC = kTreeMaxCone, class MODEL, class TASK>
+__device__ __forceinline__ void wave_rollout_body(const MODEL& m, const TASK& tk, const RolloutArgs<wreal>& a, unsigned char* smem_raw, int cand, int lane,
+                                                  wreal* cone_slab = nullptr) {
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
   const int P = a.P, H = a.H;
   const size_t N = (size_t)a.N;
@@ -75,7 +73,8 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
   const bool noisy = a.xfrc_scale > 0;
   TreeData tree;
   WaveData d;
-  if constexpr (TREE) { lnodes = nullptr; d = wave_carve_tree(smem_raw, m, tk, P, ltimes, noisy, tree); }
+  if constexpr (TREE) { lnodes = nullptr; d = wave_carve_tree(smem_raw, m, tk, P, ltimes, noisy, tree, CAPS, CAPC);
+    if (cone_slab) { tree.ovf = cone_slab; tree.cap_tot = kTreeMaxConeTotal; } }
   else d = wave_carve(smem_raw, m, tk, P, lnodes, ltimes, /*nodes_in_lds=*/false, noisy);
   // The candidate's spline nodes stay in a.nodes ([node][actuator][candidate], HBM / L2): at most four of them per
   // actuator are read per step; volatile reads, because other lanes of this wavefront wrote them.
@@ -233,13 +232,24 @@ __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const
     WSTAMP(13);
     // ================= mj_Euler + advance (qacc is kept as the next step's warm start)
     if (lane < nv) d.qacc_warm[lane] = d.qacc[lane];
-    wf_euler<NMAX>(m, d, lane, time);
+    if constexpr (TREE) wt_euler<NMAX>(m, d, lane, time);
+    else wf_euler<NMAX>(m, d, lane, time);
     WSTAMP(14);
   }
   if (lane == 0) {
     a.total_return[cand] = failed ? kMaxReturn : total / (wreal)(H > 1 ? H : 1);
     a.failure[cand] = failed ? (1 | fail_info) : 0;
   }
+}
+
+// generic models: one wavefront per workgroup, one candidate per wavefront, the model behind the kernel-argument pointers
+template <int NMAX, bool TREE = false>
+__global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // The model and task structs stay in the kernel-argument segment (scalar loads). Staging the model allocation into
+  // LDS was tried (DESIGN.md 4.5): no shorter step, fewer candidates per CU, and a run-time-rebased copy of this struct
+  // ends up in the private segment -- every pointer fetch becomes a scratch load. (Registered models: tree_kernel.h.)
+  wave_rollout_body<NMAX, TREE, kTreeMaxSimpleBig, kTreeMaxConeBig>(m, tk, a, smem_raw, blockIdx.x, threadIdx.x);  // (generic models: the large lists)
 }
 
 } }  // namespace mjpcx::WAVE_NS

@@ -108,11 +108,20 @@ struct WaveHost {
   size_t blob_bytes32 = 0;
   size_t blob_doubles = 0, blob_bytes = 0;
   bool tree_ok = false;  // the Jacobian-free constraint path (wave_tree.h) covers this model
+  // host copies of the baked helpers (lds_model.h builds the LDS image of a registered model from them)
+  std::vector<unsigned long long> h_subtree_mask;
+  std::vector<unsigned> h_dofmask;
+  std::vector<int> h_level_body, h_static_geom, h_dynamic_geom, h_ray_geom, h_term_off, h_res_term;
+  void* dev_image = nullptr; void* dev_image32 = nullptr;  // LDS images of a registered model (fp64 / fp32)
+  int registered = -1;                                     // index into the registered configurations, -1: generic kernels
   std::vector<double> state, mocap, weight, norm_p, norm_q, parameters, residual_real;
   std::vector<int32_t> residual_int, norm_types;
   double time = 0, risk = 0;
 
-  void release() { if (dev) (void)hipFree(dev); dev = nullptr; if (dev32) (void)hipFree(dev32); dev32 = nullptr; }
+  void release() {
+    if (dev) (void)hipFree(dev); dev = nullptr; if (dev32) (void)hipFree(dev32); dev32 = nullptr;
+    if (dev_image) (void)hipFree(dev_image); dev_image = nullptr; if (dev_image32) (void)hipFree(dev_image32); dev_image32 = nullptr;
+  }
 
   // Returns "" or an error message. Requires the device to be current.
   std::string build(const mjpcx_model* src, const mjpcx_task* task, bool want32 = false) {
@@ -274,7 +283,8 @@ struct WaveHost {
       for (int t = 0; t < nt; t++) limited_tendon |= src->tendon_limited[t] != 0;
       for (int g = 0; g < ng; g++)
         if (src->geom_contype[g] || src->geom_conaffinity[g]) max_condim = src->geom_condim[g] > max_condim ? src->geom_condim[g] : max_condim;
-      tree_ok = one_tree && !limited_tendon && (src->cone == 1 || max_condim == 1) && nv <= 32;
+      // (nb_live <= nv: the per-body Newton work vectors reuse cdof_dot's storage, wave_carve_tree)
+      tree_ok = one_tree && !limited_tendon && (src->cone == 1 || max_condim == 1) && nv <= 32 && nb_live <= nv;
     }
     reg(&m.body_subtree_mask, sub.data(), sizeof(unsigned long long) * nb);
     reg(&m.body_dofmask, dofmask.data(), sizeof(unsigned) * nb);
@@ -300,6 +310,8 @@ struct WaveHost {
       for (int i = 0; i < task->dim_norm_residual[k] && off + i < task->num_residual; i++) res_term[off + i] = k;
       off += task->dim_norm_residual[k];
     }
+    h_subtree_mask = sub; h_dofmask = dofmask; h_level_body = level_body; h_static_geom = sg; h_dynamic_geom = dg; h_ray_geom = rg;
+    h_term_off.assign(term_off.begin(), term_off.end()); h_res_term.assign(res_term.begin(), res_term.end());
     const auto o_toff = put2(term_off.data(), sizeof(int32_t) * term_off.size());
     const auto o_rterm = put2(res_term.data(), sizeof(int32_t) * res_term.size());
     host.resize((host.size() + 15) & ~(size_t)15);

@@ -14,7 +14,8 @@ namespace mjpcx { namespace WAVE_NS {
 constexpr wreal kQPi = WL(3.14159265358979323846);
 
 // mj_ray straight down against the geoms of group 0 (plane / sphere / box), as Ground() asks (utilities.cc:556-574)
-__device__ __forceinline__ wreal wr_ray_down(const WModel& m, const WaveData& d, const wreal* from) {
+template <class MODEL>
+__device__ __forceinline__ wreal wr_ray_down(const MODEL& m, const WaveData& d, const wreal* from) {
   wreal best = -1;
   for (int gi = 0; gi < m.nray_geom; gi++) {
     const int g = m.ray_geom[gi];
@@ -71,7 +72,8 @@ __device__ __forceinline__ wreal wr_step_height(wreal time, wreal footphase, wre
   return fabs(value) < WL(1e-6) ? WL(0.0) : value;
 }
 
-__device__ __forceinline__ void wr_quadruped(const WModel& m, const WTask& tk, WaveData& d, wreal time, int lane) {
+template <class MODEL, class TASK>
+__device__ __forceinline__ void wr_quadruped(const MODEL& m, const TASK& tk, WaveData& d, wreal time, int lane) {
   const int* ri = (const int*)(tk.blob + tk.off_rint);
   const wreal* re = tk.blob + tk.off_rreal;
   const wreal* par = tk.blob + tk.off_param;
@@ -262,7 +264,8 @@ __device__ __forceinline__ void wr_quadruped(const WModel& m, const WTask& tk, W
 // residual_int = [first key, last key, 16 tracking-site ids, 16 mocap ids], residual_real = [reference_time].
 // Lanes 0..15: one marker each (interpolated keyframe position, site position and linear velocity); the averages are
 // wave reductions in the oracle's summation order (serial over the 16 markers).
-__device__ __forceinline__ void wr_humanoid_track(const WModel& m, const WTask& tk, WaveData& d, wreal time, int lane) {
+template <class MODEL, class TASK>
+__device__ __forceinline__ void wr_humanoid_track(const MODEL& m, const TASK& tk, WaveData& d, wreal time, int lane) {
   const int* ri = reinterpret_cast<const int*>(tk.blob + tk.off_rint);
   const wreal ref_time = tk.blob[tk.off_rreal];
   const int start = ri[0], last = ri[1];
@@ -309,7 +312,8 @@ __device__ __forceinline__ void wr_humanoid_track(const WModel& m, const WTask& 
   WSYNC();
 }
 
-__device__ __forceinline__ void wr_residual(const WModel& m, const WTask& tk, WaveData& d, wreal time, int lane) {
+template <class MODEL, class TASK>
+__device__ __forceinline__ void wr_residual(const MODEL& m, const TASK& tk, WaveData& d, wreal time, int lane) {
   if (tk.residual_id == MJPCX_RESIDUAL_QUADRUPED_FLAT) { wr_quadruped(m, tk, d, time, lane); return; }
   if (tk.residual_id == MJPCX_RESIDUAL_HUMANOID_TRACK) { wr_humanoid_track(m, tk, d, time, lane); return; }
   for (int i = lane; i < tk.nr; i += 64) d.residual[i] = 0;

@@ -19,8 +19,11 @@
 // instead of O(rows * depth^2).
 namespace mjpcx { namespace WAVE_NS {
 
-constexpr int kTreeMaxCone = 24;    // contacts with condim > 1 kept per step (elliptic cones; A1: every contact with the floor)
-constexpr int kTreeMaxSimple = 16;  // frictionless contacts kept per step
+// Capacity of the two contact lists, per step. A rollout that overflows them is flagged (warning bit 32) and rolled out again by
+// a second, small launch with the large lists (tree_kernel.h): the common case pays for 16 cones of LDS, no rollout fails for
+// lack of space (MuJoCo grows its arena instead).
+constexpr int kTreeMaxCone = 16, kTreeMaxSimple = 12;         // first pass (A1: every contact with the floor is a cone)
+constexpr int kTreeMaxConeBig = 56, kTreeMaxSimpleBig = 32;   // second pass (one lane per contact: at most 64)
 
 struct TreeData {
   // frictionless contacts: generator a = [off x n, n] of the single row, the body it acts on
@@ -29,35 +32,52 @@ struct TreeData {
   int* s_body;   // [kTreeMaxSimple][2]: body of geom 1 (static: no dofs) and of geom 2
   int* s_geom;   // [kTreeMaxSimple][2]
   // elliptic cones
-  wreal* c_geo;  // [kTreeMaxCone][12]: off (3), frame (9)
-  wreal* c_par;  // [kTreeMaxCone][12]: mu, friction[5], D[6]
-  wreal* c_jar;  // [kTreeMaxCone][6]   ([0] holds dist until the rows are built)
-  wreal* c_F;    // [kTreeMaxCone][6]: A' force = [torque about the tree's com, force]
-  wreal* c_X;    // [kTreeMaxCone][21]: A' Hc A, packed lower triangle (holds aref[6] while the rows are built)
-  int* c_body;   // [kTreeMaxCone][2]
-  int* c_geom;   // [kTreeMaxCone][2]
-  int* c_dim;    // [kTreeMaxCone]
+  wreal* c_geo;  // [cap_c][12]: off (3), frame (9)
+  wreal* c_par;  // [cap_c][12]: mu, friction[5], D[6]
+  wreal* c_jar;  // [cap_c][6]   ([0] holds dist until the rows are built)
+  wreal* c_X;    // [cap_c][21]: A' Hc A, packed lower triangle, while the Hessian is assembled; otherwise [0..5] A' force =
+                 //   [torque about the tree's com, force] and, until the Newton loop starts, [6..11] aref
+  int* c_meta;   // [cap_c][5]: body of geom 1, body of geom 2, geom 1, geom 2, condim
+  // cones beyond cap_c (a robot lying on the floor): records of kConeRec reals in GLOBAL memory, one slab per wavefront
+  // (registered-model kernel only; nullptr: the list ends at cap_c). Slow, rare, and no rollout fails for lack of LDS.
+  wreal* ovf;
+  int cap_tot;   // cap_c, or cap_c + the slab's capacity
   wreal* Vb;     // [nbody][6]: S_b v for the vector at hand
   int* cnt;      // [0] simple contacts [1] cones
+  int cap_s, cap_c;  // capacity of the two lists
 };
 
-__host__ __device__ inline size_t tree_lds_elems(int nbody) {
+__host__ __device__ inline size_t tree_lds_elems(int kTreeMaxSimple, int kTreeMaxCone) {  // (Vb lives elsewhere: wave_carve_tree)
   const size_t ints = (size_t)kTreeMaxSimple * 4 + (size_t)kTreeMaxCone * 5 + 2;
-  return (size_t)kTreeMaxSimple * 8 + (size_t)kTreeMaxCone * (12 + 12 + 6 + 6 + 21) + 6 * (size_t)nbody +
-         (ints * sizeof(int) + sizeof(wreal) - 1) / sizeof(wreal) + 2;
+  return (size_t)kTreeMaxSimple * 8 + (size_t)kTreeMaxCone * (12 + 12 + 6 + 21) + (ints * sizeof(int) + sizeof(wreal) - 1) / sizeof(wreal) + 2;
 }
-__device__ __forceinline__ TreeData tree_carve(wreal* p, int nbody) {
+constexpr int kConeRec = 56;                    // geo 12 | par 12 | jar 6 | X 21 | meta (5 ints) | pad
+constexpr int kTreeMaxConeTotal = 64;           // one lane per cone
+// view of one cone's storage (LDS arrays or a global record)
+struct ConeRef { wreal *geo, *par, *jar, *X; int* meta; };
+__device__ __forceinline__ TreeData tree_carve(wreal* p, int kTreeMaxSimple, int kTreeMaxCone) {
   TreeData t;
+  t.cap_s = kTreeMaxSimple; t.cap_c = kTreeMaxCone; t.ovf = nullptr; t.cap_tot = kTreeMaxCone;
   auto take = [&](size_t n) { wreal* q = p; p += n; return q; };
   t.s_a = take(6 * kTreeMaxSimple); t.s_fd = take(2 * kTreeMaxSimple);
-  t.c_geo = take(12 * kTreeMaxCone); t.c_par = take(12 * kTreeMaxCone); t.c_jar = take(6 * kTreeMaxCone); t.c_F = take(6 * kTreeMaxCone);
+  t.c_geo = take(12 * kTreeMaxCone); t.c_par = take(12 * kTreeMaxCone); t.c_jar = take(6 * kTreeMaxCone);
   t.c_X = take(21 * kTreeMaxCone);
-  t.Vb = take(6 * (size_t)nbody);
+  t.Vb = nullptr;
   int* ip = reinterpret_cast<int*>(p);
-  t.s_body = ip; t.s_geom = ip + 2 * kTreeMaxSimple; t.c_body = ip + 4 * kTreeMaxSimple; t.c_geom = t.c_body + 2 * kTreeMaxCone;
-  t.c_dim = t.c_geom + 2 * kTreeMaxCone; t.cnt = t.c_dim + kTreeMaxCone;
+  t.s_body = ip; t.s_geom = ip + 2 * kTreeMaxSimple; t.c_meta = ip + 4 * kTreeMaxSimple; t.cnt = t.c_meta + 5 * kTreeMaxCone;
   return t;
 }
+__device__ __forceinline__ ConeRef cone_lds(const TreeData& t, int i) { return ConeRef{t.c_geo + 12 * i, t.c_par + 12 * i, t.c_jar + 6 * i, t.c_X + 21 * i, t.c_meta + 5 * i}; }
+__device__ __forceinline__ ConeRef cone_ovf(const TreeData& t, int i) {
+  wreal* r = t.ovf + (size_t)kConeRec * (i - t.cap_c);
+  return ConeRef{r, r + 12, r + 24, r + 30, reinterpret_cast<int*>(r + 51)};
+}
+// run a statement block on cone i through the view `c`: written once, compiled twice (LDS-typed / global-typed accesses)
+#define WT_CONE(i, ...)                                                      \
+  do {                                                                       \
+    if ((i) < t.cap_c) { const ConeRef c = cone_lds(t, (i)); __VA_ARGS__ }   \
+    else { const ConeRef c = cone_ovf(t, (i)); __VA_ARGS__ }                 \
+  } while (0)
 
 // rows that live in the registers of one lane
 struct TreeRows {
@@ -106,8 +126,8 @@ __device__ __forceinline__ void sym6_mulvec_acc(wreal* y, const wreal* X, const 
 
 // contacts found by one pass of the narrow phase (<= K per lane, same geom pair per lane): split by class (condim of the
 // pair, mj_contactParam) and appended to the two lists in lane-major, contact-minor order (= the oracle's detection order)
-template <int K>
-__device__ __forceinline__ void wt_emit(const WModel& m, WaveData& d, TreeData& t, int lane, int cnt, const wreal* cd, const wreal (*cp)[3],
+template <int K, class MODEL>
+__device__ __forceinline__ void wt_emit(const MODEL& m, WaveData& d, TreeData& t, int lane, int cnt, const wreal* cd, const wreal (*cp)[3],
                                         const wreal (*cn)[3], int g1, int g2, int b1, int b2, const wreal* com) {
   int dim = 1;
   if (cnt > 0) {
@@ -136,7 +156,7 @@ __device__ __forceinline__ void wt_emit(const WModel& m, WaveData& d, TreeData& 
       const wreal off[3] = {cp[k][0] - com[0], cp[k][1] - com[1], cp[k][2] - com[2]};
       if (!cone) {
         const int at = base_s + below_s + k;
-        if (at < kTreeMaxSimple) {
+        if (at < t.cap_s) {
           wreal rot[3];
           cr3(rot, off, frame);  // off x n
           for (int e = 0; e < 3; e++) { t.s_a[6 * at + e] = rot[e]; t.s_a[6 * at + 3 + e] = frame[e]; }
@@ -145,26 +165,27 @@ __device__ __forceinline__ void wt_emit(const WModel& m, WaveData& d, TreeData& 
         }
       } else {
         const int at = base_c + below_c + k;
-        if (at < kTreeMaxCone) {
-          for (int e = 0; e < 3; e++) t.c_geo[12 * at + e] = off[e];
-          for (int e = 0; e < 9; e++) t.c_geo[12 * at + 3 + e] = frame[e];
-          t.c_jar[6 * at] = cd[k];
-          t.c_body[2 * at] = b1; t.c_body[2 * at + 1] = b2; t.c_geom[2 * at] = g1; t.c_geom[2 * at + 1] = g2; t.c_dim[at] = dim;
-        }
+        if (at < t.cap_tot)
+          WT_CONE(at,
+            for (int e = 0; e < 3; e++) c.geo[e] = off[e];
+            for (int e = 0; e < 9; e++) c.geo[3 + e] = frame[e];
+            c.jar[0] = cd[k];
+            c.meta[0] = b1; c.meta[1] = b2; c.meta[2] = g1; c.meta[3] = g2; c.meta[4] = dim;);
       }
     }
   }
   if (lane == 0) {
     const int ns = base_s + total_s, nc = base_c + total_c;
-    if (ns > kTreeMaxSimple || nc > kTreeMaxCone) d.counters[2] |= 32;
-    t.cnt[0] = ns > kTreeMaxSimple ? kTreeMaxSimple : ns;
-    t.cnt[1] = nc > kTreeMaxCone ? kTreeMaxCone : nc;
+    if (ns > t.cap_s || nc > t.cap_tot) d.counters[2] |= 32;
+    t.cnt[0] = ns > t.cap_s ? t.cap_s : ns;
+    t.cnt[1] = nc > t.cap_tot ? t.cap_tot : nc;
   }
   WSYNC();
 }
 
 // ---- collision: wf_collision's narrow phase (o_collision), contacts split by class and compacted in detection order
-__device__ __forceinline__ void wt_collision(const WModel& m, WaveData& d, TreeData& t, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeData& t, int lane) {
   if (lane == 0) { t.cnt[0] = 0; t.cnt[1] = 0; }
   WSYNC();
   if (m.disableflags & (MJPCX_DSBL_CONSTRAINT | MJPCX_DSBL_CONTACT)) return;
@@ -381,6 +402,160 @@ __device__ __forceinline__ void wt_collision(const WModel& m, WaveData& d, TreeD
   }
 }
 
+// ---- packed symmetric matrices (lower triangle, row-major: (i, j), i >= j, at i (i + 1) / 2 + j)
+__device__ __forceinline__ int wt_tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+// (M v)[lane] for a packed symmetric M; lane < nv
+template <int NMAX>
+__device__ __forceinline__ wreal wt_sym_mulvec(const wreal* Mp, const wreal* v, int nv, int lane) {
+  wreal s = 0;
+  const int rowadr = lane * (lane + 1) / 2;
+#pragma unroll
+  for (int b = 0; b < NMAX; b++)
+    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * v[b];
+  return s;
+}
+// same with v = x - y
+template <int NMAX>
+__device__ __forceinline__ wreal wt_sym_mulvec_diff(const wreal* Mp, const wreal* x, const wreal* y, int nv, int lane) {
+  wreal s = 0;
+  const int rowadr = lane * (lane + 1) / 2;
+#pragma unroll
+  for (int b = 0; b < NMAX; b++)
+    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * (x[b] - y[b]);
+  return s;
+}
+
+// o_crb on the tree path: composite inertias by subtree masks, then M packed (entries off the kinematic chains are zero)
+template <class MODEL>
+__device__ __forceinline__ void wt_crb(const MODEL& m, WaveData& d, int lane) {
+  const int nb = m.nbody, nv = m.nv;
+  if (lane < nb && lane > 0) {
+    const int i = lane;
+    unsigned long long mask = m.body_subtree_mask[i];
+    wreal s[10];
+    for (int k = 0; k < 10; k++) s[k] = 0;
+    while (mask) {
+      const int j = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      for (int k = 0; k < 10; k++) s[k] += d.cinert[10 * j + k];
+    }
+    for (int k = 0; k < 10; k++) d.crb[10 * i + k] = s[k];
+  }
+  for (int e = lane; e < nv * (nv + 1) / 2; e += 64) d.M[e] = 0;
+  WSYNC();
+  if (lane < nv) {
+    const int i = lane;
+    wreal buf[6];
+    w_mul_inert(buf, d.crb + 10 * m.dof_bodyid[i], d.cdof + 6 * i);
+    d.M[wt_tri(i, i)] = m.dof_armature[i] + w_dot6(d.cdof + 6 * i, buf);
+    for (int j = m.dof_parentid[i]; j >= 0; j = m.dof_parentid[j]) d.M[wt_tri(i, j)] = w_dot6(d.cdof + 6 * j, buf);
+  }
+  WSYNC();
+}
+
+// Cholesky of a packed SPD matrix, lane i owns row i in registers (values of other rows through v_readlane): dst := L with
+// src = L L' (dst may be src), dinv[j] = 1 / L[j][j]. LDS-typed pointers: ds_read / ds_write, never FLAT.
+template <int NMAX>
+__device__ __noinline__ bool wt_chol(const wlds_f64* src, wlds_f64* dst, wlds_f64* dinv, int n_, int lane) {
+  const int n = __builtin_amdgcn_readfirstlane(n_);
+  const int rowadr = lane * (lane + 1) / 2;
+  wreal row[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) row[k] = (lane < n && k <= lane) ? src[rowadr + k] : WL(0.0);
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    if (j < n && ok) {
+      const wreal djj = wbcast(row[j], j);
+      if (!(djj > kMinVal)) {
+        ok = false;
+      } else {
+        const wreal inv = rsqrt(djj);
+        const wreal lij = lane == j ? djj * inv : row[j] * inv;
+        row[j] = lij;
+        if (lane == j) dinv[j] = inv;
+#pragma unroll
+        for (int k = j + 1; k < NMAX; k++) row[k] -= lij * wbcast(lij, k);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) if (lane < n && k <= lane) dst[rowadr + k] = row[k];
+  WSYNC();
+  return ok;
+}
+// x := (L L')^-1 x, L packed, x in LDS
+template <int NMAX>
+__device__ __noinline__ void wt_chol_solve(wlds_f64* x, const wlds_f64* L, const wlds_f64* dinv, int n_, int lane) {
+  const int n = __builtin_amdgcn_readfirstlane(n_);
+  const int rowadr = lane * (lane + 1) / 2;
+  wreal row[NMAX], col[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) {
+    row[k] = (lane < n && k < lane) ? L[rowadr + k] : WL(0.0);
+    col[k] = (lane < n && k > lane && k < n) ? L[k * (k + 1) / 2 + lane] : WL(0.0);
+  }
+  wreal b = lane < n ? x[lane] : WL(0.0);
+  const wreal mydinv = lane < n ? dinv[lane] : WL(0.0);
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    const wreal yj = wbcast(b, j) * wbcast(mydinv, j);
+    b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
+  }
+#pragma unroll
+  for (int j = NMAX - 1; j >= 0; j--) {
+    const wreal xj = wbcast(b, j) * wbcast(mydinv, j);
+    b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
+  }
+  if (lane < n) x[lane] = b;
+  WSYNC();
+}
+
+// o_euler on the tree path (packed M): implicit joint damping, then integrate positions
+template <int NMAX, class MODEL>
+__device__ __forceinline__ void wt_euler(const MODEL& m, WaveData& d, int lane, wreal& time) {
+  const int nv = m.nv;
+  const wreal h = m.timestep;
+  if (m.any_damping && !(m.disableflags & MJPCX_DSBL_EULERDAMP)) {
+    for (int e = lane; e < nv * (nv + 1) / 2; e += 64) d.H[e] = d.M[e];
+    WSYNC();
+    if (lane < nv) { d.H[wt_tri(lane, lane)] += h * m.dof_damping[lane]; d.tmpv[lane] = d.qfrc_smooth[lane] + d.qfrc_constraint[lane]; }
+    WSYNC();
+    if (wt_chol<NMAX>((const wlds_f64*)d.H, (wlds_f64*)d.H, (wlds_f64*)d.dinv, nv, lane)) wt_chol_solve<NMAX>((wlds_f64*)d.tmpv, (const wlds_f64*)d.H, (const wlds_f64*)d.dinv, nv, lane);
+    else { if (lane < nv) d.tmpv[lane] = d.qacc[lane]; WSYNC(); }
+  } else {
+    if (lane < nv) d.tmpv[lane] = d.qacc[lane];
+    WSYNC();
+  }
+  if (lane < nv) d.qvel[lane] += h * d.tmpv[lane];
+  WSYNC();
+  if (lane < m.njnt) {
+    const int j = lane;
+    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    const int jt = m.jnt_type[j];
+    if (jt == kJntFree) {
+      for (int k = 0; k < 3; k++) d.qpos[qa + k] += h * d.qvel[da + k];
+      qa += 3; da += 3;
+    }
+    if (jt == kJntFree || jt == kJntBall) {
+      wreal ax[3] = {d.qvel[da], d.qvel[da + 1], d.qvel[da + 2]};
+      const wreal n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      if (n < kMinVal) { ax[0] = 1; ax[1] = ax[2] = 0; }
+      else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
+      wreal qrot[4], q[4];
+      aa2quat(qrot, ax, h * n);
+      for (int k = 0; k < 4; k++) q[k] = d.qpos[qa + k];
+      q_norm(q);
+      q_mul(q, q, qrot);
+      for (int k = 0; k < 4; k++) d.qpos[qa + k] = q[k];
+    } else {
+      d.qpos[qa] += h * d.qvel[da];
+    }
+  }
+  time += h;
+  WSYNC();
+}
+
 // rows of a cone from a spatial vector V = [rot, lin] of its body (about the tree's com): x_j = a_j . V
 __device__ __forceinline__ void wt_cone_project(wreal* x, const wreal* geo, const wreal* V, int dim) {
   const wreal off[3] = {geo[0], geo[1], geo[2]};
@@ -465,7 +640,8 @@ __device__ __forceinline__ void wt_cone_line(const wreal* x0, const wreal* v, wr
 
 // ---- rows: friction loss (lane = dof), joint limits (lane = joint), contacts (lane = list index); impedance, reference
 // acceleration and regulariser per row as o_make_constraint_full. J qvel of a contact row is the body's cvel projected.
-__device__ __forceinline__ void wt_make_constraint(const WModel& m, WaveData& d, TreeData& t, TreeRows& q, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, TreeData& t, TreeRows& q, int lane) {
   const int nv = m.nv;
   q.f_on = false; q.l_on[0] = q.l_on[1] = false; q.s_on = false; q.c_on = false;
   q.f_D = q.f_R = q.f_fl = q.f_aref = q.f_jar = q.f_force = 0; q.f_zone = kZoneTop;
@@ -527,43 +703,42 @@ __device__ __forceinline__ void wt_make_constraint(const WModel& m, WaveData& d,
     q.s_on = true; q.s_D = WL(1.0) / R; q.s_aref = -bb * vel - kk * imp * pos;
   }
   // elliptic cones
-  if (lane < nc) {
-    const int g1 = t.c_geom[2 * lane], g2 = t.c_geom[2 * lane + 1], b1 = t.c_body[2 * lane], b2 = t.c_body[2 * lane + 1];
-    WaveContact c;
-    wf_contact_param(m, g1, g2, c);
-    const int dim = t.c_dim[lane];
-    const wreal dist = t.c_jar[6 * lane];
-    wreal kk, bb;
-    w_solref_kb(m, c.solref, c.solimp, kk, bb);
-    const wreal pos = dist - c.includemargin;
-    const wreal imp = w_impedance(c.solimp, pos);
-    const wreal diag = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
-    wreal R0 = (1 - imp) / imp * diag;
-    if (R0 < kMinVal) R0 = kMinVal;
-    const wreal mu = c.friction[0] / sqrt(m.impratio > kMinVal ? (wreal)m.impratio : WL(1.0));
-    wreal geo[12], vel[6];
-    for (int e = 0; e < 12; e++) geo[e] = t.c_geo[12 * lane + e];
-    wreal cv[6];
-    for (int e = 0; e < 6; e++) cv[e] = d.cvel[6 * b2 + e] - d.cvel[6 * b1 + e];
-    wt_cone_project(vel, geo, cv, dim);
-    wreal* par = t.c_par + 12 * lane;
-    wreal* aref = t.c_X + 21 * lane;
-    par[0] = mu;
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      if (j >= 1) par[j] = c.friction[j - 1];
-      wreal Rj = R0;
-      if (j >= 1) { const wreal f = c.friction[j - 1]; Rj = R0 * (mu * mu) / (f * f); }
-      par[6 + j] = j < dim ? WL(1.0) / Rj : WL(0.0);
-      aref[j] = j == 0 ? -bb * vel[0] - kk * imp * pos : -bb * vel[j];
-    }
-    q.c_on = true; q.c_dim = dim;
-  }
+  if (lane < nc)
+    WT_CONE(lane,
+      const int b1 = c.meta[0]; const int b2 = c.meta[1]; const int g1 = c.meta[2]; const int g2 = c.meta[3]; const int dim = c.meta[4];
+      WaveContact cp;
+      wf_contact_param(m, g1, g2, cp);
+      const wreal dist = c.jar[0];
+      wreal kk; wreal bb;
+      w_solref_kb(m, cp.solref, cp.solimp, kk, bb);
+      const wreal pos = dist - cp.includemargin;
+      const wreal imp = w_impedance(cp.solimp, pos);
+      const wreal diag = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+      wreal R0 = (1 - imp) / imp * diag;
+      if (R0 < kMinVal) R0 = kMinVal;
+      const wreal mu = cp.friction[0] / sqrt(m.impratio > kMinVal ? (wreal)m.impratio : WL(1.0));
+      wreal geo[12]; wreal vel[6]; wreal cv[6];
+      for (int e = 0; e < 12; e++) geo[e] = c.geo[e];
+      for (int e = 0; e < 6; e++) cv[e] = d.cvel[6 * b2 + e] - d.cvel[6 * b1 + e];
+      wt_cone_project(vel, geo, cv, dim);
+      wreal* par = c.par;
+      wreal* aref = c.X + 6;
+      par[0] = mu;
+      _Pragma("unroll")
+      for (int j = 0; j < 6; j++) {
+        if (j >= 1) par[j] = cp.friction[j - 1];
+        wreal Rj = R0;
+        if (j >= 1) { const wreal f = cp.friction[j - 1]; Rj = R0 * (mu * mu) / (f * f); }
+        par[6 + j] = j < dim ? WL(1.0) / Rj : WL(0.0);
+        aref[j] = j == 0 ? -bb * vel[0] - kk * imp * pos : -bb * vel[j];
+      }
+      q.c_on = true; q.c_dim = dim;);
   WSYNC();
 }
 
 // Vb[b] = sum over the dofs k on the chain of body b of cdof_k v[k]  (one lane per body)
-__device__ __forceinline__ void wt_body_vectors(const WModel& m, const WaveData& d, TreeData& t, const wreal* v, int lane) {
+template <class MODEL>
+__device__ __forceinline__ void wt_body_vectors(const MODEL& m, const WaveData& d, TreeData& t, const wreal* v, int lane) {
   if (lane < m.nbody) {
     unsigned mask = m.body_dofmask[lane];
     wreal V[6] = {0, 0, 0, 0, 0, 0};
@@ -607,62 +782,64 @@ __device__ __forceinline__ wreal wt_cost(WaveData& d, TreeData& t, TreeRows& q, 
     t.s_fd[2 * lane] = q.s_force;
     t.s_fd[2 * lane + 1] = q.s_zone == kZoneBottom ? D : WL(0.0);
   }
-  if (q.c_on) {
-    wreal x[6], par[12], force[6], geo[12];
-    for (int e = 0; e < 6; e++) x[e] = t.c_jar[6 * lane + e];
-    for (int e = 0; e < 12; e++) par[e] = t.c_par[12 * lane + e];
-    for (int e = 0; e < 12; e++) geo[e] = t.c_geo[12 * lane + e];
-    cost += wt_cone_cost(x, par, q.c_dim, force, q.c_zone);
-    // A' force = [off x F + sum_{j>=3} f_{j-3} force_j, F], F = sum_{j<3} f_j force_j
-    wreal F[3] = {0, 0, 0}, tq[3] = {0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-      for (int e = 0; e < 3; e++) { F[e] += geo[3 + 3 * j + e] * force[j]; tq[e] += geo[3 + 3 * j + e] * force[3 + j]; }
-    wreal cx[3];
-    cr3(cx, geo, F);
-    for (int e = 0; e < 3; e++) { t.c_F[6 * lane + e] = cx[e] + tq[e]; t.c_F[6 * lane + 3 + e] = F[e]; }
-  }
+  if (q.c_on)
+    WT_CONE(lane,
+      wreal x[6]; wreal par[12]; wreal force[6]; wreal geo[12];
+      for (int e = 0; e < 6; e++) x[e] = c.jar[e];
+      for (int e = 0; e < 12; e++) par[e] = c.par[e];
+      for (int e = 0; e < 12; e++) geo[e] = c.geo[e];
+      cost += wt_cone_cost(x, par, q.c_dim, force, q.c_zone);
+      // A' force = [off x F + sum_{j>=3} f_{j-3} force_j, F], F = sum_{j<3} f_j force_j
+      wreal F[3] = {0, 0, 0}; wreal tq[3] = {0, 0, 0};
+      _Pragma("unroll")
+      for (int j = 0; j < 3; j++)
+        for (int e = 0; e < 3; e++) { F[e] += geo[3 + 3 * j + e] * force[j]; tq[e] += geo[3 + 3 * j + e] * force[3 + j]; }
+      wreal cx[3];
+      cr3(cx, geo, F);
+      for (int e = 0; e < 3; e++) { c.X[e] = cx[e] + tq[e]; c.X[3 + e] = F[e]; });
   cost = wave_sum(cost);
   WSYNC();
   return cost;
 }
 
 // sign of dof k in J = A (S_b2 - S_b1): +1 on the chain of body 2 only, -1 on the chain of body 1 only, 0 elsewhere
-__device__ __forceinline__ int wt_sign(const WModel& m, int b1, int b2, int k) {
+template <class MODEL>
+__device__ __forceinline__ int wt_sign(const MODEL& m, int b1, int b2, int k) {
   return (int)((m.body_dofmask[b2] >> k) & 1u) - (int)((m.body_dofmask[b1] >> k) & 1u);
 }
 
 // (J' force)[dof = lane] from the forces written by wt_cost
-__device__ __forceinline__ wreal wt_jt_force(const WModel& m, const WaveData& d, const TreeData& t, const TreeRows& q, int ns, int nc, int lane) {
+template <class MODEL>
+__device__ __forceinline__ wreal wt_jt_force(const MODEL& m, const WaveData& d, const TreeData& t, const TreeRows& q, int ns, int nc, int lane) {
   wreal s = q.f_on ? q.f_force : WL(0.0);
   const wreal lim = (q.l_on[0] ? q.l_force[0] : WL(0.0)) - (q.l_on[1] ? q.l_force[1] : WL(0.0));
   s += wt_pull_from_joint(lim, q.jnt_of_dof);
   if (lane < m.nv) {
-    wreal c[6];
-    for (int e = 0; e < 6; e++) c[e] = d.cdof[6 * lane + e];
+    wreal cd[6];
+    for (int e = 0; e < 6; e++) cd[e] = d.cdof[6 * lane + e];
     for (int i = 0; i < ns; i++) {
       const int sg = wt_sign(m, t.s_body[2 * i], t.s_body[2 * i + 1], lane);
       if (sg != 0) {
         wreal ja = 0;
-        for (int e = 0; e < 6; e++) ja += t.s_a[6 * i + e] * c[e];
+        for (int e = 0; e < 6; e++) ja += t.s_a[6 * i + e] * cd[e];
         s += (sg > 0 ? ja : -ja) * t.s_fd[2 * i];
       }
     }
-    for (int i = 0; i < nc; i++) {
-      const int sg = wt_sign(m, t.c_body[2 * i], t.c_body[2 * i + 1], lane);
-      if (sg != 0) {
-        wreal ja = 0;
-        for (int e = 0; e < 6; e++) ja += t.c_F[6 * i + e] * c[e];
-        s += sg > 0 ? ja : -ja;
-      }
-    }
+    for (int i = 0; i < nc; i++)
+      WT_CONE(i,
+        const int sg = wt_sign(m, c.meta[0], c.meta[1], lane);
+        if (sg != 0) {
+          wreal ja = 0;
+          for (int e = 0; e < 6; e++) ja += c.X[e] * cd[e];
+          s += sg > 0 ? ja : -ja;
+        });
   }
   return s;
 }
 
 // ---- the Newton solver (o_constraint_newton) on the tree
-template <int NMAX>
-__device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& d, TreeData& t, TreeRows& q, int lane, long long* stamp = nullptr,
+template <int NMAX, class MODEL>
+__device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d, TreeData& t, TreeRows& q, int lane, long long* stamp = nullptr,
                                                      bool have_warm = false) {
   const int nv = m.nv;
   const int ns = __builtin_amdgcn_readfirstlane(t.cnt[0]), nc = __builtin_amdgcn_readfirstlane(t.cnt[1]);
@@ -682,15 +859,15 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
       for (int e = 0; e < 6; e++) s += t.s_a[6 * lane + e] * (t.Vb[6 * b2 + e] - t.Vb[6 * b1 + e]);
       q.s_jar = s;
     }
-    if (q.c_on) {
-      wreal geo[12], V[6], x[6];
-      const int b1 = t.c_body[2 * lane], b2 = t.c_body[2 * lane + 1];
-      const wreal* aref = t.c_X + 21 * lane;  // (c_X is first written by the Hessian, after the last set_jar)
-      for (int e = 0; e < 12; e++) geo[e] = t.c_geo[12 * lane + e];
-      for (int e = 0; e < 6; e++) V[e] = t.Vb[6 * b2 + e] - t.Vb[6 * b1 + e];
-      wt_cone_project(x, geo, V, q.c_dim);
-      for (int e = 0; e < 6; e++) t.c_jar[6 * lane + e] = e < q.c_dim ? x[e] - aref[e] : WL(0.0);
-    }
+    if (q.c_on)
+      WT_CONE(lane,
+        wreal geo[12]; wreal V[6]; wreal x[6];
+        const int b1 = c.meta[0]; const int b2 = c.meta[1];
+        const wreal* aref = c.X + 6;  // (overwritten by the first Hessian, after the last set_jar)
+        for (int e = 0; e < 12; e++) geo[e] = c.geo[e];
+        for (int e = 0; e < 6; e++) V[e] = t.Vb[6 * b2 + e] - t.Vb[6 * b1 + e];
+        wt_cone_project(x, geo, V, q.c_dim);
+        for (int e = 0; e < 6; e++) c.jar[e] = e < q.c_dim ? x[e] - aref[e] : WL(0.0););
     WSYNC();
   };
   set_jar(d.qacc);
@@ -698,9 +875,7 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
   if (have_warm) {  // warm start (mj_fwdConstraint): begin at the previous step's qacc if its cost is lower
     wreal gauss = 0;
     if (lane < nv) {
-      wreal s = 0;
-#pragma unroll 6
-      for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc_warm[b] - d.qacc_smooth[b]);
+      const wreal s = wt_sym_mulvec_diff<NMAX>(d.M, d.qacc_warm, d.qacc_smooth, nv, lane);
       gauss = WL(0.5) * s * (d.qacc_warm[lane] - d.qacc_smooth[lane]);
     }
     gauss = wave_sum(gauss);
@@ -727,12 +902,9 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
     wreal g = 0;
     const wreal jtf = wt_jt_force(m, d, t, q, ns, nc, lane);
     if (lane < nv) {
-      wreal s = 0;
-#pragma unroll 6
-      for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc[b] - d.qacc_smooth[b]);
+      const wreal s = wt_sym_mulvec_diff<NMAX>(d.M, d.qacc, d.qacc_smooth, nv, lane);
       d.Ma[lane] = s;
       g = s - jtf;
-      d.grad[lane] = g;
       d.search[lane] = -g;
     }
     const wreal gnorm = sqrt(wave_sum(lane < nv ? g * g : WL(0.0)));
@@ -753,46 +925,46 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
     }
     if (refresh) {
       // X_c = A' Hc A of every cone outside its top zone (one lane per cone)
-      if (q.c_on) {
-        wreal X[21];
-#pragma unroll
-        for (int e = 0; e < 21; e++) X[e] = 0;
-        if (q.c_zone != kZoneTop) {
-          wreal geo[12], par[12], x[6], a[6];
-          for (int e = 0; e < 12; e++) { geo[e] = t.c_geo[12 * lane + e]; par[e] = t.c_par[12 * lane + e]; }
-          for (int e = 0; e < 6; e++) x[e] = t.c_jar[6 * lane + e];
-          const int dim = q.c_dim;
-          if (q.c_zone == kZoneBottom) {
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-              if (j < dim) { wt_cone_gen(a, geo, j); if (j < 3) sym6_rank1(X, par[6 + j], a); else sym3_rank1(X, par[6 + j], a); }
-          } else {
-            // Hc = Dm w w' - c (S^2 - y y'),  w = (mu, -mu f_j u_j), y = (0, f_j u_j), u = U_t / |U_t|, c = Dm NT mu / T
-            const wreal mu = par[0];
-            wreal U[6], T = 0;
-            U[0] = x[0] * mu;
-#pragma unroll
-            for (int j = 1; j < 6; j++) { U[j] = j < dim ? x[j] * par[j] : WL(0.0); T += U[j] * U[j]; }
-            T = sqrt(T);
-            const wreal iT = WL(1.0) / T;
-            const wreal Dm = par[6] / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T, cc = Dm * NT * mu * iT;
-            wreal p[6] = {0, 0, 0, 0, 0, 0}, r[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-              if (j < dim) {
-                wt_cone_gen(a, geo, j);
-                const wreal yj = j == 0 ? WL(0.0) : par[j] * U[j] * iT;
-                const wreal wj = j == 0 ? mu : -mu * yj;
-                for (int e = 0; e < 6; e++) { p[e] += wj * a[e]; r[e] += yj * a[e]; }
-                if (j >= 1) { if (j < 3) sym6_rank1(X, -cc * par[j] * par[j], a); else sym3_rank1(X, -cc * par[j] * par[j], a); }
-              }
-            sym6_rank1(X, Dm, p);
-            sym6_rank1(X, cc, r);
+      if (q.c_on)
+        WT_CONE(lane,
+          wreal X[21];
+          _Pragma("unroll")
+          for (int e = 0; e < 21; e++) X[e] = 0;
+          if (q.c_zone != kZoneTop) {
+            wreal geo[12]; wreal par[12]; wreal x[6]; wreal a[6];
+            for (int e = 0; e < 12; e++) { geo[e] = c.geo[e]; par[e] = c.par[e]; }
+            for (int e = 0; e < 6; e++) x[e] = c.jar[e];
+            const int dim = q.c_dim;
+            if (q.c_zone == kZoneBottom) {
+              _Pragma("unroll")
+              for (int j = 0; j < 6; j++)
+                if (j < dim) { wt_cone_gen(a, geo, j); if (j < 3) sym6_rank1(X, par[6 + j], a); else sym3_rank1(X, par[6 + j], a); }
+            } else {
+              // Hc = Dm w w' - c (S^2 - y y'),  w = (mu, -mu f_j u_j), y = (0, f_j u_j), u = U_t / |U_t|, c = Dm NT mu / T
+              const wreal mu = par[0];
+              wreal U[6]; wreal T = 0;
+              U[0] = x[0] * mu;
+              _Pragma("unroll")
+              for (int j = 1; j < 6; j++) { U[j] = j < dim ? x[j] * par[j] : WL(0.0); T += U[j] * U[j]; }
+              T = sqrt(T);
+              const wreal iT = WL(1.0) / T;
+              const wreal Dm = par[6] / (mu * mu * (1 + mu * mu)); const wreal NT = U[0] - mu * T; const wreal cc = Dm * NT * mu * iT;
+              wreal p[6] = {0, 0, 0, 0, 0, 0}; wreal r[6] = {0, 0, 0, 0, 0, 0};
+              _Pragma("unroll")
+              for (int j = 0; j < 6; j++)
+                if (j < dim) {
+                  wt_cone_gen(a, geo, j);
+                  const wreal yj = j == 0 ? WL(0.0) : par[j] * U[j] * iT;
+                  const wreal wj = j == 0 ? mu : -mu * yj;
+                  for (int e = 0; e < 6; e++) { p[e] += wj * a[e]; r[e] += yj * a[e]; }
+                  if (j >= 1) { if (j < 3) sym6_rank1(X, -cc * par[j] * par[j], a); else sym3_rank1(X, -cc * par[j] * par[j], a); }
+                }
+              sym6_rank1(X, Dm, p);
+              sym6_rank1(X, cc, r);
+            }
           }
-        }
-        for (int e = 0; e < 21; e++) t.c_X[21 * lane + e] = X[e];
-      }
-      for (int e = lane; e < nv * nv; e += 64) d.H[e] = d.M[e];
+          for (int e = 0; e < 21; e++) c.X[e] = X[e];);
+      for (int e = lane; e < nv * (nv + 1) / 2; e += 64) d.H[e] = d.M[e];
       WSYNC();
       WACC(33);
       // row i of H, one lane per dof: z = sum over the contacts below dof i of X_c cdof_i, H_ij = M_ij + cdof_j . z on the chain
@@ -800,8 +972,8 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
         const wreal lim = (q.l_on[0] && q.l_zone[0] == kZoneBottom ? q.l_D[0] : WL(0.0)) + (q.l_on[1] && q.l_zone[1] == kZoneBottom ? q.l_D[1] : WL(0.0));
         const wreal dlim = wt_pull_from_joint(lim, q.jnt_of_dof);
         if (lane < nv) {
-          wreal c[6], z[6] = {0, 0, 0, 0, 0, 0};
-          for (int e = 0; e < 6; e++) c[e] = d.cdof[6 * lane + e];
+          wreal cd[6], z[6] = {0, 0, 0, 0, 0, 0};
+          for (int e = 0; e < 6; e++) cd[e] = d.cdof[6 * lane + e];
           // contacts against static geoms: every dof j <= i on the chain of i is on the contact's chain too, so their X_c cdof_i
           // add up before the chain is walked once; a contact between two moving bodies walks its own dof set
           bool any = false;
@@ -814,7 +986,7 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
               wreal s = 0;
               for (int e = 0; e < 6; e++) s += d.cdof[6 * j + e] * zc[e];
               const int sj = wt_sign(m, b1, b2, j) * sg;
-              d.H[lane * nv + j] += sj > 0 ? s : -s;
+              d.H[wt_tri(lane, j)] += sj > 0 ? s : -s;
             }
           };
           for (int i = 0; i < ns; i++) {
@@ -823,19 +995,19 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
             const wreal D = t.s_fd[2 * i + 1];
             if (sg != 0 && D != 0) {
               wreal a[6], ja = 0;
-              for (int e = 0; e < 6; e++) { a[e] = t.s_a[6 * i + e]; ja += a[e] * c[e]; }
+              for (int e = 0; e < 6; e++) { a[e] = t.s_a[6 * i + e]; ja += a[e] * cd[e]; }
               if (m.body_dofmask[b1] == 0) { for (int e = 0; e < 6; e++) z[e] += D * ja * a[e]; any = true; }
               else { wreal zc[6]; for (int e = 0; e < 6; e++) zc[e] = D * ja * a[e]; pair_rows(zc, b1, b2, sg); }
             }
           }
-          for (int i = 0; i < nc; i++) {
-            const int b1 = t.c_body[2 * i], b2 = t.c_body[2 * i + 1];
-            const int sg = wt_sign(m, b1, b2, lane);
-            if (sg != 0) {
-              if (m.body_dofmask[b1] == 0) { sym6_mulvec_acc(z, t.c_X + 21 * i, c); any = true; }
-              else { wreal zc[6] = {0, 0, 0, 0, 0, 0}; sym6_mulvec_acc(zc, t.c_X + 21 * i, c); pair_rows(zc, b1, b2, sg); }
-            }
-          }
+          for (int i = 0; i < nc; i++)
+            WT_CONE(i,
+              const int b1 = c.meta[0]; const int b2 = c.meta[1];
+              const int sg = wt_sign(m, b1, b2, lane);
+              if (sg != 0) {
+                if (m.body_dofmask[b1] == 0) { sym6_mulvec_acc(z, c.X, cd); any = true; }
+                else { wreal zc[6] = {0, 0, 0, 0, 0, 0}; sym6_mulvec_acc(zc, c.X, cd); pair_rows(zc, b1, b2, sg); }
+              });
           const wreal diag = (q.f_on && q.f_zone == kZoneBottom ? q.f_D : WL(0.0)) + dlim;
           if (any) {
             unsigned chain = m.body_dofmask[m.dof_bodyid[lane]] & lowmask;  // dofs j <= i on the chain of i
@@ -844,19 +1016,19 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
               chain &= chain - 1;
               wreal s = 0;
               for (int e = 0; e < 6; e++) s += d.cdof[6 * j + e] * z[e];
-              d.H[lane * nv + j] += s;
+              d.H[wt_tri(lane, j)] += s;
             }
           }
-          if (diag != 0) d.H[lane * nv + lane] += diag;
+          if (diag != 0) d.H[wt_tri(lane, lane)] += diag;
         }
       }
       WSYNC();
       if (stamp && lane == 0 && iter == 0) stamp[22] = (long long)__builtin_readcyclecounter();
       WACC(34);
-      if (!wave_chol<NMAX>(d.H, d.dinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
+      if (!wt_chol<NMAX>((const wlds_f64*)d.H, (wlds_f64*)d.H, (wlds_f64*)d.dinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
       factor_valid = true;
     }
-    wave_chol_solve<NMAX>(d.search, d.H, d.dinv, nv, lane);
+    wt_chol_solve<NMAX>((wlds_f64*)d.search, (const wlds_f64*)d.H, (const wlds_f64*)d.dinv, nv, lane);
     if (stamp && lane == 0 && iter == 0) stamp[23] = (long long)__builtin_readcyclecounter();
     WACC(35);
     // jv = J search (registers); Gauss part along the ray
@@ -871,18 +1043,16 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
       const int b1 = t.s_body[2 * lane], b2 = t.s_body[2 * lane + 1];
       for (int e = 0; e < 6; e++) s_jv += t.s_a[6 * lane + e] * (t.Vb[6 * b2 + e] - t.Vb[6 * b1 + e]);
     }
-    if (q.c_on) {
-      wreal geo[12], V[6];
-      const int b1 = t.c_body[2 * lane], b2 = t.c_body[2 * lane + 1];
-      for (int e = 0; e < 12; e++) { geo[e] = t.c_geo[12 * lane + e]; c_par[e] = t.c_par[12 * lane + e]; }
-      for (int e = 0; e < 6; e++) { V[e] = t.Vb[6 * b2 + e] - t.Vb[6 * b1 + e]; c_x0[e] = t.c_jar[6 * lane + e]; }
-      wt_cone_project(c_jv, geo, V, q.c_dim);
-    }
+    if (q.c_on)
+      WT_CONE(lane,
+        wreal geo[12]; wreal V[6];
+        const int b1 = c.meta[0]; const int b2 = c.meta[1];
+        for (int e = 0; e < 12; e++) { geo[e] = c.geo[e]; c_par[e] = c.par[e]; }
+        for (int e = 0; e < 6; e++) { V[e] = t.Vb[6 * b2 + e] - t.Vb[6 * b1 + e]; c_x0[e] = c.jar[e]; }
+        wt_cone_project(c_jv, geo, V, q.c_dim););
     wreal q1 = 0, q2 = 0;
     if (lane < nv) {
-      wreal s = 0;
-#pragma unroll 6
-      for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * d.search[b];
+      const wreal s = wt_sym_mulvec<NMAX>(d.M, d.search, nv, lane);
       q1 = d.search[lane] * d.Ma[lane];
       q2 = d.search[lane] * s;
     }
@@ -937,13 +1107,11 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
     if (q.l_on[0]) q.l_jar[0] += alpha * l_jv[0];
     if (q.l_on[1]) q.l_jar[1] += alpha * l_jv[1];
     if (q.s_on) q.s_jar += alpha * s_jv;
-    if (q.c_on) for (int e = 0; e < 6; e++) t.c_jar[6 * lane + e] = c_x0[e] + alpha * c_jv[e];
+    if (q.c_on) WT_CONE(lane, for (int e = 0; e < 6; e++) c.jar[e] = c_x0[e] + alpha * c_jv[e];);
     WSYNC();
     wreal gauss = 0;
     if (lane < nv) {
-      wreal s = 0;
-#pragma unroll 6
-      for (int b = 0; b < nv; b++) s += d.M[lane * nv + b] * (d.qacc[b] - d.qacc_smooth[b]);
+      const wreal s = wt_sym_mulvec_diff<NMAX>(d.M, d.qacc, d.qacc_smooth, nv, lane);
       gauss = WL(0.5) * s * (d.qacc[lane] - d.qacc_smooth[lane]);
     }
     gauss = wave_sum(gauss);
@@ -961,79 +1129,104 @@ __device__ __forceinline__ void wt_constraint_newton(const WModel& m, WaveData& 
 
 
 // ---- mj_forward up to the constraint solve on the tree path (wf_forward with the Jacobian-free constraint stages)
-template <int NMAX>
-__device__ __forceinline__ void wt_forward(const WModel& m, const WTask& tk, WaveData& d, TreeData& t, int lane, bool& bad_ctrl,
+template <int NMAX, class MODEL, class TASK>
+__device__ __forceinline__ void wt_forward(const MODEL& m, const TASK& tk, WaveData& d, TreeData& t, int lane, bool& bad_ctrl,
                                            long long* stamp, bool have_warm) {
   const int nv = m.nv;
+  // Order: the smooth dynamics run BEFORE collision and the rows (they do not depend on them): the RNE work arrays, cinert
+  // and cdof_dot are dead when the contact lists are born, so the lists live in the same LDS (wave_carve_tree)
   WSTAMP(1);
   wf_kinematics(m, tk, d, lane);
   WSYNC();
   WSTAMP(2);
   wf_compos(m, d, lane);
   WSTAMP(3);
-  wf_crb(m, d, lane);
+  wt_crb(m, d, lane);
   WSTAMP(4);
-  for (int e = lane; e < nv * nv; e += 64) d.L[e] = d.M[e];
-  WSYNC();
-  if (!wave_chol<NMAX>(d.L, d.Ldinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; }
+  if (!wt_chol<NMAX>((const wlds_f64*)d.M, (wlds_f64*)d.L, (wlds_f64*)d.Ldinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; }
   WSTAMP(5);
-  wt_collision(m, d, t, lane);
-  WSTAMP(6);
   wf_comvel(m, d, lane);
+  WSTAMP(6);
+  wf_smooth_forces(m, d, lane, bad_ctrl);
   WSTAMP(7);
+  wt_chol_solve<NMAX>((wlds_f64*)d.qacc_smooth, (const wlds_f64*)d.L, (const wlds_f64*)d.Ldinv, nv, lane);
+  WSTAMP(8);
+  wt_collision(m, d, t, lane);
+  WSTAMP(9);
   TreeRows q;
   wt_make_constraint(m, d, t, q, lane);
-  WSTAMP(8);
-  wf_smooth_forces(m, d, lane, bad_ctrl);
-  WSTAMP(9);
-  wave_chol_solve<NMAX>(d.qacc_smooth, d.L, d.Ldinv, nv, lane);
   WSTAMP(10);
   wt_constraint_newton<NMAX>(m, d, t, q, lane, stamp, have_warm);
   WSTAMP(11);
 }
 
-// LDS footprint / layout of one candidate on the tree path: wave_carve without the row table, the contact structs and the
-// cone blocks; `efc_J` survives as a scratch area (joint anchors / axes during kinematics, the cost norms' per-entry values)
-__host__ __device__ inline size_t wave_lds_elems_tree(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P, bool xfrc = false) {
-  size_t n = 0;
-  n += nq + nv + nu;
-  n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 9 * nbody + 3 * nsite;
-  n += 3 * nbody + 10 * nbody + 6 * nv * 2 + 6 * nbody * 4 + 3;
-  n += 2 * (size_t)nv * nv + nv;
-  n += 7 * nv + nu + 5 * nv;
-  n += (size_t)(nr > 6 * njnt ? nr : 6 * njnt);
-  n += 12 + nr + nterm + 8;
-  n += 4 * sizeof(int) / sizeof(wreal) + 1;
-  n += P;
-  n += xfrc ? 6 * nbody : 0;
-  return n + tree_lds_elems(nbody) + 4;
+// LDS footprint / layout of one candidate on the tree path. Arrays with disjoint lifetimes share storage:
+//   U1: ximat | xanchor | xaxis (kinematics -> compos)   over   cvel | cdof_dot (comvel -> residual / RNE); Vb (Newton) over cdof_dot
+//   R : cinert | cacc | cfrc | cfrc_sub, crb over cacc|cfrc (compos -> RNE)   over   the contact lists (collision -> Newton)
+//       over   foot_xpos | residual | terms | scal | the cost norms' per-entry scratch (sensor stage)
+//   qfrc_passive / bias / actuator (smooth forces) over search / Ma / tmpv (Newton, Euler)
+// M and the Cholesky factors are packed lower triangles. P (node times) is the only run-time size: it comes last.
+__host__ __device__ inline size_t wave_tree_u1(int nv, int nbody, int njnt) {
+  const size_t a = 6 * (size_t)nbody + 6 * (size_t)nv, b = 9 * (size_t)nbody + 6 * (size_t)njnt;
+  return a > b ? a : b;
 }
-__device__ __forceinline__ WaveData wave_carve_tree(unsigned char* smem_raw, const WModel& m, const WTask& tk, int P, wreal*& ltimes, bool xfrc, TreeData& t) {
+__host__ __device__ inline size_t wave_tree_r(int nbody, int nr, int nterm, int caps, int capc) {
+  size_t r = 28 * (size_t)nbody;
+  if (tree_lds_elems(caps, capc) > r) r = tree_lds_elems(caps, capc);
+  const size_t sensor = 12 + 2 * (size_t)nr + nterm + 8;
+  return sensor > r ? sensor : r;
+}
+__host__ __device__ inline size_t wave_lds_elems_tree(int nq, int nv, int nu, int nbody, int njnt, int nsite, int nr, int nterm, int P, bool xfrc = false,
+                                                      int caps = kTreeMaxSimple, int capc = kTreeMaxCone) {
+  size_t n = 0;
+  n += nq + nv + nu + nu + nv;                                       // qpos qvel ctrl actuator_force qacc_warm
+  n += 3 * nbody + 4 * nbody + 9 * nbody + 3 * nbody + 3 * nsite + 3 * nbody + 3;  // xpos xquat xmat xipos site_xpos subtree_com subtree_linvel
+  n += 6 * nv;                                                       // cdof
+  n += (size_t)nv * (nv + 1) + nv;                                   // M, H (packed) + reciprocal pivots
+  n += wave_tree_u1(nv, nbody, njnt);
+  n += wave_tree_r(nbody, nr, nterm, caps, capc);
+  n += 7 * nv;                                                       // qfrc_smooth qacc_smooth qacc qfrc_constraint search Ma tmpv
+  n += 4 * sizeof(int) / sizeof(wreal) + 1;                          // counters
+  n += xfrc ? 6 * nbody : 0;
+  n += P;
+  return n + 4;
+}
+template <class MODEL, class TASK>
+__device__ __forceinline__ WaveData wave_carve_tree(unsigned char* smem_raw, const MODEL& m, const TASK& tk, int P, wreal*& ltimes, bool xfrc, TreeData& t,
+                                                    int caps = kTreeMaxSimple, int capc = kTreeMaxCone) {
   const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
   wreal* p = reinterpret_cast<wreal*>(smem_raw);
   auto take = [&](size_t n) { wreal* q = p; p += n; return q; };
   WaveData d;
-  d.qpos = take(nq); d.qvel = take(nv); d.ctrl = take(nu);
-  d.xpos = take(3 * nb); d.xquat = take(4 * nb); d.xmat = take(9 * nb); d.xipos = take(3 * nb); d.ximat = take(9 * nb);
-  d.site_xpos = take(3 * ns);
-  d.subtree_com = take(3 * nb); d.cinert = take(10 * nb); d.cdof = take(6 * nv); d.cdof_dot = take(6 * nv);
-  d.cvel = take(6 * nb); d.cacc = take(6 * nb); d.cfrc = take(6 * nb); d.cfrc_sub = take(6 * nb); d.subtree_linvel = take(3);
-  d.crb = d.cacc;
-  d.M = take((size_t)nv * nv); d.H = take((size_t)nv * nv); d.Ldinv = take(nv); d.dinv = d.Ldinv;
-  d.L = d.H;
-  d.qfrc_passive = take(nv); d.qfrc_bias = take(nv); d.qfrc_actuator = take(nv); d.qfrc_smooth = take(nv);
-  d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv); d.actuator_force = take(nu);
-  d.grad = take(nv); d.search = take(nv); d.Ma = take(nv); d.Ms = nullptr; d.tmpv = take(nv); d.qacc_warm = take(nv);
-  d.efc_J = take((size_t)(nr > 6 * nj ? nr : 6 * nj));
-  d.xanchor = d.efc_J; d.xaxis = d.efc_J + 3 * nj;
+  d.qpos = take(nq); d.qvel = take(nv); d.ctrl = take(nu); d.actuator_force = take(nu); d.qacc_warm = take(nv);
+  d.xpos = take(3 * nb); d.xquat = take(4 * nb); d.xmat = take(9 * nb); d.xipos = take(3 * nb); d.site_xpos = take(3 * ns);
+  d.subtree_com = take(3 * nb); d.subtree_linvel = take(3);
+  d.cdof = take(6 * nv);
+  d.M = take((size_t)nv * (nv + 1) / 2); d.H = take((size_t)nv * (nv + 1) / 2); d.Ldinv = take(nv); d.dinv = d.Ldinv; d.L = d.H;
+  {
+    wreal* u1 = take(wave_tree_u1(nv, nb, nj));
+    d.cvel = u1; d.cdof_dot = u1 + 6 * nb;
+    d.ximat = u1; d.xanchor = u1 + 9 * nb; d.xaxis = d.xanchor + 3 * nj;
+    t.Vb = d.cdof_dot;  // 6 nbody <= 6 nv for a model the tree path takes? not in general: checked on the host (wave_tree_fits)
+  }
+  {
+    wreal* r = take(wave_tree_r(nb, nr, tk.nterm, caps, capc));
+    d.cinert = r; d.cacc = r + 10 * nb; d.cfrc = d.cacc + 6 * nb; d.cfrc_sub = d.cfrc + 6 * nb; d.crb = d.cacc;
+    wreal* vb = t.Vb;
+    t = tree_carve(r, caps, capc);
+    t.Vb = vb;
+    d.foot_xpos = r; d.residual = r + 12; d.terms = d.residual + nr; d.scal = d.terms + tk.nterm; d.efc_J = d.scal + 8;
+  }
+  d.qfrc_smooth = take(nv); d.qacc_smooth = take(nv); d.qacc = take(nv); d.qfrc_constraint = take(nv);
+  d.search = take(nv); d.Ma = take(nv); d.tmpv = take(nv);
+  d.qfrc_passive = d.search; d.qfrc_bias = d.Ma; d.qfrc_actuator = d.tmpv;
+  d.grad = nullptr; d.Ms = nullptr;
   d.efc_D = d.efc_R = d.efc_aref = d.efc_floss = d.efc_force = d.jar = d.jv = d.efc_pos = d.efc_margin = nullptr;
   d.efc_type = d.efc_id = d.efc_zone = nullptr;
   d.coneH = nullptr; d.con = nullptr;
-  d.foot_xpos = take(12); d.residual = take(nr); d.terms = take(tk.nterm); d.scal = take(8);
   d.counters = reinterpret_cast<int*>(take(4 * sizeof(int) / sizeof(wreal) + 1));
-  ltimes = take(P);
   d.xfrc = xfrc ? take(6 * nb) : nullptr;
-  t = tree_carve(p, nb);
+  ltimes = take(P);
   return d;
 }
 

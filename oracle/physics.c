@@ -58,7 +58,7 @@ struct OData {
   double *efc_J; /* OMAXEFC x nv */
   double efc_pos[OMAXEFC], efc_margin[OMAXEFC], efc_R[OMAXEFC], efc_aref[OMAXEFC];
   double efc_b[OMAXEFC], efc_force[OMAXEFC];
-  double *scratch_minvjt, *scratch_qacc, *scratch_A; /* preallocated work arrays */
+  double *scratch_minvjt, *scratch_qacc, *scratch_A, *scratch_AR; /* preallocated work arrays */
   /* contacts / friction loss / Newton solver (contact.inc) */
   int full; /* 1: constraint rows beyond joint limits can occur -> Newton path */
   int ngeom, ncon, solver_iter;
@@ -209,6 +209,7 @@ OData* odata_new(const mjpcx_model* m) {
   d->qacc = dalloc(nv); d->actuator_force = dalloc(nu);
   d->efc_J = dalloc(OMAXEFC * nv);
   d->scratch_minvjt = dalloc(OMAXEFC * nv); d->scratch_qacc = dalloc(nv); d->scratch_A = dalloc(2 * nv * nv);
+  d->scratch_AR = dalloc((2 * nj + 1) * (2 * nj + 1));
   /* geoms and the Newton solver's work space */
   d->ngeom = m->ngeom;
   d->geom_xpos = dalloc(3 * m->ngeom); d->geom_xmat = dalloc(9 * m->ngeom);
@@ -248,7 +249,7 @@ void odata_free(OData* d) {
                   &d->crb, &d->cdof, &d->cdof_dot, &d->cvel, &d->cacc, &d->cfrc, &d->M, &d->L,
                   &d->qfrc_passive, &d->qfrc_bias, &d->qfrc_actuator, &d->qfrc_smooth,
                   &d->qacc_smooth, &d->qfrc_constraint, &d->qacc, &d->actuator_force, &d->efc_J,
-                  &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A, &d->geom_xpos, &d->geom_xmat, &d->scratch_jac,
+                  &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A, &d->scratch_AR, &d->geom_xpos, &d->geom_xmat, &d->scratch_jac,
                   &d->nw_jar, &d->nw_jv, &d->nw_grad, &d->nw_search, &d->nw_Ma, &d->nw_H, &d->nw_L, &d->qacc_warmstart,
                   &d->xfrc_applied};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
@@ -615,7 +616,7 @@ static void o_constraint(OData* d) {
   memset(d->qfrc_constraint, 0, sizeof(double) * nv);
   memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
   if (ne == 0) return;
-  double AR[OMAXEFC * OMAXEFC];
+  double* AR = d->scratch_AR; /* (2 njnt)^2: this path only has joint-limit rows, two per joint at most */
   double* MinvJt = d->scratch_minvjt;
   for (int r = 0; r < ne; r++) {
     int j = d->efc_jnt[r];

@@ -34,7 +34,7 @@ def run(task, state, N, H, P, interp, seed, tol, time=0.0):
     times = time + np.arange(P) * max((H - 1) * dt / max(P - 1, 1), 1e-3)
     nodes = np.clip(rng.normal(0, 0.4, (N, P, task.model.nu)), -1, 1)
     ctx = capi.Context(pm, pt, 0, 64)
-    assert "rollout_wave_kernel" in ctx.kernel_name
+    assert "rollout_wave_kernel" in ctx.kernel_name or "rollout_tree_kernel" in ctx.kernel_name
     ctx.set_state(state, time, MOCAP)
     ctx.rollout_splines(H, interp, times, nodes)
     ret, fail = ctx.returns()

@@ -90,7 +90,7 @@ def test_cpp_cross_entropy_on_the_quadruped_equals_python_planner():
         ct, cv = cpp.policy()
         assert np.array_equal(ct, py.policy.plan.times()) and np.array_equal(cv, py.policy.plan.values())
         assert cpp.improvement == py.improvement
-    assert "rollout_wave_kernel" in cpp.kernel_name
+    assert "rollout_wave_kernel" in cpp.kernel_name or "rollout_tree_kernel" in cpp.kernel_name
 
 
 def test_cpp_predictive_sampling_replans_on_the_quadruped():
