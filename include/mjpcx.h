@@ -362,7 +362,7 @@ int mjpcx_fetch_spline(mjpcx_ctx* ctx, int candidate, double* node_values);
 /* N candidate rollouts under a feedback policy built on a shared nominal trajectory of Tn steps.
  *   mode 0: Trajectory::RolloutDiscrete with the index policy of iLQGPlanner::ActionRollouts
  *           (ilqg/planner.cc:630-692): u = clamp(actions[t] + alpha_i * improvement[t] + gains[t] (x - states[t]))
- *   mode 1: Trajectory::Rollout with iLQGPolicy::Action (ilqg/policy.cc:82-161), representation 0/1
+ *   mode 1: Trajectory::Rollout with iLQGPolicy::Action (ilqg/policy.cc:82-161), representation 0 / 1 / 2 (zero-order, linear, cubic)
  *           (zero-order / linear interpolation over `times`), feedback scaled by alpha_i, applied iff use_state
  *           (FeedbackRollouts, ilqg/planner.cc:695-724)
  * gains: Tn x nu x ndx (feedback_gain), improvement: Tn x nu (action_improvement), alpha: N. */

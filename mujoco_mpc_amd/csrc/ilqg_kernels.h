@@ -20,7 +20,7 @@ struct FeedbackArgs {
   const T* alpha;        // [N]             line-search step (mode 0) / feedback_scaling (mode 1)
   int Tn;
   int mode;            // 0: index policy (RolloutDiscrete), 1: continuous-time iLQGPolicy::Action
-  int representation;  // mode 1: 0 zero-order, 1 linear (ilqg_representation)
+  int representation;  // mode 1: 0 zero-order, 1 linear, 2 cubic (ilqg_representation)
   int use_state;       // mode 1: settings.nominal_feedback_scaling
 };
 
@@ -33,6 +33,41 @@ __device__ __forceinline__ void find_interval(const T* xs, T value, int length, 
   if (lo < 0) { b0 = b1 = 0; }
   else if (lo > length - 1) { b0 = b1 = length - 1; }
   else { b0 = lo; b1 = up < length - 1 ? up : length - 1; }
+}
+
+// Weights of Zero / Linear / CubicInterpolation (mjpc/utilities.cc:304-422) over the grid xs[0 .. length) at `value`: the
+// interpolant of any series y on that grid is  w[0] y[g - 1] + w[1] y[g] + w[2] y[g + 1] + w[3] y[g + 2]  with g = bounds[0]
+// (indices clamped to the grid where the weight is zero). Cubic = Hermite with finite-difference slopes (mean of the two
+// neighbouring secants, one-sided at the ends of the grid, zero on a two-point grid: FiniteDifferenceSlope).
+template <typename T>
+struct InterpWeights { int g; int i[4]; T w[4]; };
+template <typename T>
+__device__ __forceinline__ InterpWeights<T> interp_weights(const T* xs, T value, int length, int representation) {
+  InterpWeights<T> r;
+  int b0, b1;
+  find_interval(xs, value, length, b0, b1);
+  r.g = b0;
+  const int last = length - 1;
+  r.i[0] = b0 > 0 ? b0 - 1 : 0; r.i[1] = b0; r.i[2] = b0 < last ? b0 + 1 : last; r.i[3] = b0 + 2 <= last ? b0 + 2 : last;
+  r.w[0] = r.w[2] = r.w[3] = 0; r.w[1] = 1;
+  if (b0 == b1 || representation == 0) return r;
+  const T span = xs[b1] - xs[b0], t = (value - xs[b0]) / span;
+  if (representation != 2) { r.w[1] = T(1) - t; r.w[2] = t; return r; }
+  const T t2 = t * t, t3 = t2 * t;
+  const T c0 = T(2) * t3 - T(3) * t2 + T(1), c1 = (t3 - T(2) * t2 + t) * span, c2 = -T(2) * t3 + T(3) * t2, c3 = (t3 - t2) * span;
+  // slope at grid point b0 (never the last point here): secant(b1, b0) if b0 == 0, else the mean of the secants on both sides
+  // slope at grid point b1: one-sided secant(b1, b1 - 1) if b1 is the last point (0 on a two-point grid), else the mean
+  T m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};  // slopes as weights on y[g-1], y[g], y[g+1], y[g+2]
+  const T is1 = T(1) / span;
+  if (b0 == 0) { m0[1] = -is1; m0[2] = is1; }
+  else { const T isl = T(1) / (xs[b0] - xs[b0 - 1]); m0[0] = -T(0.5) * isl; m0[1] = T(0.5) * isl - T(0.5) * is1; m0[2] = T(0.5) * is1; }
+  if (b1 == last) { if (length > 2) { m1[1] = -is1; m1[2] = is1; } }
+  else { const T isr = T(1) / (xs[b1 + 1] - xs[b1]); m1[1] = -T(0.5) * is1; m1[2] = T(0.5) * is1 - T(0.5) * isr; m1[3] = T(0.5) * isr; }
+  r.w[0] = c1 * m0[0];
+  r.w[1] = c0 + c1 * m0[1] + c3 * m1[1];
+  r.w[2] = c2 + c1 * m0[2] + c3 * m1[2];
+  r.w[3] = c3 * m1[3];
+  return r;
 }
 
 template <class TP, class TK, typename T, class MC>
@@ -91,34 +126,31 @@ __global__ __launch_bounds__(64) void rollout_feedback_kernel(const LaneModel<T>
         // iLQGPolicy::Action, policy.cc:82-161
         int b0, b1;
         find_interval(l_times, time, fb.Tn, b0, b1);
-        const bool zero = (b0 == b1) || fb.representation == 0;
-        int a0, a1, s0, s1;
-        find_interval(l_times, time, fb.Tn - 1, a0, a1);  // actions / gains: horizon - 1 entries
-        find_interval(l_times, time, fb.Tn, s0, s1);      // states: horizon entries
-        T wa = 0, ws = 0;
-        if (!zero) {
-          if (a0 != a1) wa = (time - l_times[a0]) / (l_times[a1] - l_times[a0]);
-          if (s0 != s1) ws = (time - l_times[s0]) / (l_times[s1] - l_times[s0]);
-        }
+        const int rep = (b0 == b1) ? 0 : fb.representation;
+        const InterpWeights<T> wa = interp_weights(l_times, time, fb.Tn - 1, rep);  // actions / gains: horizon - 1 entries
+        const InterpWeights<T> ws = interp_weights(l_times, time, fb.Tn, rep);      // states: horizon entries
         T dx[NDX];
         if (fb.use_state) {
 #pragma unroll
           for (int j = 0; j < NDX; j++) {
-            const T xi = (zero || s0 == s1) ? l_states[s0 * DS + j]
-                                            : l_states[s0 * DS + j] * (T(1) - ws) + l_states[s1 * DS + j] * ws;
+            T xi = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) xi += ws.w[q] * l_states[ws.i[q] * DS + j];
             dx[j] = x[j] - xi;
           }
         }
 #pragma unroll
         for (int k = 0; k < NU; k++) {
-          T u = (zero || a0 == a1) ? l_actions[a0 * NU + k]
-                                   : l_actions[a0 * NU + k] * (T(1) - wa) + l_actions[a1 * NU + k] * wa;
+          T u = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) u += wa.w[q] * l_actions[wa.i[q] * NU + k];
           if (fb.use_state) {
             T fbk = 0;
 #pragma unroll
             for (int j = 0; j < NDX; j++) {
-              const T g = (zero || a0 == a1) ? l_gains[(a0 * NU + k) * NDX + j]
-                                             : l_gains[(a0 * NU + k) * NDX + j] * (T(1) - wa) + l_gains[(a1 * NU + k) * NDX + j] * wa;
+              T g = 0;
+#pragma unroll
+              for (int q = 0; q < 4; q++) g += wa.w[q] * l_gains[(wa.i[q] * NU + k) * NDX + j];
               fbk += g * dx[j];
             }
             u += alpha * fbk;  // feedback_scaling

@@ -541,7 +541,7 @@ hipError_t launch_tree_pass(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTas
   W = std::max(1, std::min(W, (N + c->num_cu - 1) / c->num_cu));  // small batches: spread over the CUs first
   int grid = std::min(c->num_cu, (N + W - 1) / W);
   if (BIG) grid = std::min(grid, 64);  // the second pass scans the failure flags; a handful of rollouts at most
-  const int mode = BIG ? 0 : c->tree_mode;
+  const int mode = BIG ? (c->tree_mode & 8) : c->tree_mode;
   const size_t lds = fixed + (size_t)W * arena;
   hipError_t e = c->d_work.reserve(16);
   if (e != hipSuccess) return e;
@@ -1423,7 +1423,7 @@ int mjpcx_rollout_feedback(mjpcx_ctx* c, int N, int H, int mode, int representat
   if (N < 1 || H < 1 || Tn < 1) return fail(c, MJPCX_EINVAL, "N, H and Tn must be >= 1");
   if (mode == 0 && H > Tn) return fail(c, MJPCX_EINVAL, "index policy needs a nominal trajectory at least as long as the horizon");
   if (mode != 0 && mode != 1) return fail(c, MJPCX_EINVAL, "unknown feedback policy mode");
-  if (mode == 1 && representation != 0 && representation != 1) return fail(c, MJPCX_EUNSUPPORTED, "only zero-order / linear iLQG policy representations are implemented");
+  if (mode == 1 && (representation < 0 || representation > 2)) return fail(c, MJPCX_EINVAL, "iLQG policy representation must be 0 (zero-order), 1 (linear) or 2 (cubic)");
   HIPCHK(c, hipSetDevice(c->device));
   if (c->wave) return do_feedback_wave(c, N, H, mode, representation, use_state, Tn, times, states, actions, gains, improvement, alpha);
   const size_t shmem = (size_t)Tn * (1 + 2 * c->nv + 2 * c->nu + c->nu * 2 * c->nv) * esize(c);

@@ -7,6 +7,7 @@
 //     Newton iterations) does not hold a whole workgroup's LDS back.
 namespace mjpcx { namespace WAVE_NS {
 
+// mode bit 3 (8): poison every arena before each rollout (uninitialised-read detector, tests/test_gpu_quadruped.py)
 // mode bit 1: self-check -- compare the staged image with the generic model's arrays, mismatches are counted in work[1]
 //             and the launch rolls nothing out (tuning / bring-up aid, MJPCX_TREE_CHECK=1)
 // BIG: second pass -- only the candidates the first pass flagged "contact list full" (failure bits, mjpcx.h), with the large lists
@@ -58,6 +59,10 @@ __global__ __launch_bounds__(512) void rollout_tree_kernel(const WModel m_in, co
   // cones beyond the LDS list go to this wavefront's slab in global memory (wave_tree.h)
   wreal* slab = cone_slabs ? cone_slabs + (size_t)(blockIdx.x * (nth >> 6) + wave) * (size_t)((kTreeMaxConeTotal - kTreeMaxCone) * kConeRec) : nullptr;
   for (int cand = blockIdx.x * (nth >> 6) + wave; cand < a.N; cand += gridDim.x * (nth >> 6)) {
+    if (mode & 8) {  // bring-up aid (MJPCX_TREE_MODE=8): poison the arena -- a read of storage this rollout never wrote shows up as NaN / -1
+      for (unsigned i = lane; i < arena_bytes / 4; i += 64) reinterpret_cast<unsigned*>(arena)[i] = 0xFFFFFFFFu;
+      WSYNC();
+    }
     if constexpr (BIG) {
       if (!(a.failure[cand] & (32 << 8))) continue;  // wave-uniform
       wave_rollout_body<C::NV, true, kTreeMaxSimpleBig, kTreeMaxConeBig>(m, tk, a, arena, cand, lane);

@@ -244,6 +244,8 @@ __device__ __noinline__ wreal w_impedance(const wreal* solimp, wreal dist) {
   if (x <= 0) return dmin;
   wreal y;
   if (power == 1) y = x;
+  else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);  // MuJoCo's default: no pow() (~1000 instructions, and
+                                                                                         // every lane of a divergent wavefront pays for it)
   else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
   else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
   return dmin + y * (dmax - dmin);

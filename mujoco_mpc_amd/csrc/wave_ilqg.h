@@ -216,18 +216,20 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
       } else {  // iLQGPolicy::Action at `time`
         int b0, b1;
         find_interval(fb.times, time, Tn, b0, b1);
-        const bool zero = b0 == b1 || fb.representation == 0;
-        // FindInterval again over the shorter ranges the reference passes (actions / gains have Tn - 1 entries)
-        int a0, a1;
-        find_interval(fb.times, time, Tn - 1, a0, a1);
-        const wreal ta = (zero || a0 == a1) ? WL(0.0) : (time - fb.times[a0]) / (fb.times[a1] - fb.times[a0]);
-        const bool za = zero || a0 == a1;
-        if (lane < nu) u = za ? fb.actions[(size_t)a0 * nu + lane] : fb.actions[(size_t)a0 * nu + lane] * (WL(1.0) - ta) + fb.actions[(size_t)a1 * nu + lane] * ta;
+        const int rep = (b0 == b1) ? 0 : fb.representation;
+        // weights over the shorter range the reference passes for actions / gains (Tn - 1 entries) and over Tn for states
+        const InterpWeights<wreal> wa = interp_weights(fb.times, time, Tn - 1, rep);
+        if (lane < nu) {
+          u = 0;
+          for (int q = 0; q < 4; q++) u += wa.w[q] * fb.actions[(size_t)wa.i[q] * nu + lane];
+        }
         if (fb.use_state) {
-          const wreal ts = (zero || b0 == b1) ? WL(0.0) : (time - fb.times[b0]) / (fb.times[b1] - fb.times[b0]);
-          const bool zs = zero || b0 == b1;
-          for (int i = lane; i < ds; i += 64)
-            xi[i] = zs ? fb.states[(size_t)b0 * ds + i] : fb.states[(size_t)b0 * ds + i] * (WL(1.0) - ts) + fb.states[(size_t)b1 * ds + i] * ts;
+          const InterpWeights<wreal> ws = interp_weights(fb.times, time, Tn, rep);
+          for (int i = lane; i < ds; i += 64) {
+            wreal v = 0;
+            for (int q = 0; q < 4; q++) v += ws.w[q] * fb.states[(size_t)ws.i[q] * ds + i];
+            xi[i] = v;
+          }
           WSYNC();
           if (lane < m.njnt) {  // policy.cc:118-125: renormalise interpolated quaternions
             const int jt = m.jnt_type[lane];
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
           if (lane < nu) {
             wreal s = 0;
             for (int j = 0; j < ndx; j++) {
-              const wreal k0 = fb.gains[((size_t)a0 * nu + lane) * ndx + j];
-              const wreal kj = za ? k0 : k0 * (WL(1.0) - ta) + fb.gains[((size_t)a1 * nu + lane) * ndx + j] * ta;
+              wreal kj = 0;
+              for (int q = 0; q < 4; q++) kj += wa.w[q] * fb.gains[((size_t)wa.i[q] * nu + lane) * ndx + j];
               s += kj * dx[j];
             }
             u += alpha * s;

@@ -89,8 +89,11 @@ struct TreeRows {
   int jnt_of_dof;    // lane = dof: the (slide / hinge) joint that owns it, -1 for free / ball dofs
   // frictionless contact, lane = index in the list
   bool s_on; wreal s_D, s_aref, s_jar, s_force; int s_zone;
+  unsigned s_mp, s_mm;  // dofs with J = +A cdof (chain of body 2 only) / J = -A cdof (chain of body 1 only); other lanes read them with v_readlane
   // cone, lane = index in the list (its rows are in LDS)
   bool c_on; int c_dim, c_zone;
+  wreal c_Dm;  // D_normal / (mu^2 (1 + mu^2)): the cone's middle-zone stiffness (one division per step, not per line-search trial)
+  unsigned c_mp, c_mm;
 };
 
 // packed lower triangle helpers (i >= j at i (i + 1) / 2 + j)
@@ -577,7 +580,7 @@ __device__ __forceinline__ void wt_cone_gen(wreal* a, const wreal* geo, int j) {
 }
 
 // penalty of an elliptic cone at x (oracle constraint_cost, EFC_ELLIPTIC): cost, forces, zone
-__device__ __forceinline__ wreal wt_cone_cost(const wreal* x, const wreal* par, int dim, wreal* force, int& zone) {
+__device__ __forceinline__ wreal wt_cone_cost(const wreal* x, const wreal* par, wreal Dm, int dim, wreal* force, int& zone) {
   const wreal mu = par[0];
   wreal U[6], T = 0, cost = 0;
   U[0] = x[0] * mu;
@@ -598,17 +601,18 @@ __device__ __forceinline__ wreal wt_cone_cost(const wreal* x, const wreal* par, 
     }
     zone = kZoneBottom;
   } else {
-    const wreal Dm = par[6] / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+    const wreal NT = N - mu * T;
     cost = WL(0.5) * Dm * NT * NT;
     force[0] = -Dm * NT * mu;
+    const wreal kT = Dm * NT * mu / T;  // (one division; the oracle divides per row: a few ulp)
 #pragma unroll
-    for (int j = 1; j < 6; j++) force[j] = j < dim ? Dm * NT * mu * U[j] * par[j] / T : WL(0.0);
+    for (int j = 1; j < 6; j++) force[j] = j < dim ? kT * U[j] * par[j] : WL(0.0);
     zone = kZoneMiddle;
   }
   return cost;
 }
 // first / second derivative along v at x (oracle constraint_line, EFC_ELLIPTIC)
-__device__ __forceinline__ void wt_cone_line(const wreal* x0, const wreal* v, wreal alpha, const wreal* par, int dim, wreal& g1, wreal& h2) {
+__device__ __forceinline__ void wt_cone_line(const wreal* x0, const wreal* v, wreal alpha, const wreal* par, wreal Dm, int dim, wreal& g1, wreal& h2) {
   const wreal mu = par[0];
   wreal U[6], V[6], X[6], T = 0;
   X[0] = x0[0] + alpha * v[0]; U[0] = X[0] * mu; V[0] = v[0] * mu;
@@ -626,7 +630,7 @@ __device__ __forceinline__ void wt_cone_line(const wreal* x0, const wreal* v, wr
     for (int j = 0; j < 6; j++)
       if (j < dim) { g1 += par[6 + j] * X[j] * v[j]; h2 += par[6 + j] * v[j] * v[j]; }
   } else {
-    const wreal Dm = par[6] / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+    const wreal NT = N - mu * T;
     wreal UV = 0, VV = 0;
 #pragma unroll
     for (int j = 1; j < 6; j++) if (j < dim) { UV += U[j] * V[j]; VV += V[j] * V[j]; }
@@ -645,7 +649,7 @@ __device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, 
   const int nv = m.nv;
   q.f_on = false; q.l_on[0] = q.l_on[1] = false; q.s_on = false; q.c_on = false;
   q.f_D = q.f_R = q.f_fl = q.f_aref = q.f_jar = q.f_force = 0; q.f_zone = kZoneTop;
-  q.s_D = q.s_aref = q.s_jar = q.s_force = 0; q.s_zone = kZoneTop; q.c_dim = 0; q.c_zone = kZoneTop;
+  q.s_D = q.s_aref = q.s_jar = q.s_force = 0; q.s_zone = kZoneTop; q.c_dim = 0; q.c_zone = kZoneTop; q.s_mp = q.s_mm = q.c_mp = q.c_mm = 0; q.c_Dm = 0;
   for (int s = 0; s < 2; s++) { q.l_D[s] = q.l_aref[s] = q.l_jar[s] = q.l_force[s] = 0; q.l_zone[s] = kZoneTop; }
   q.l_dof = 0; q.jnt_of_dof = -1;
   if (lane < nv) {
@@ -701,6 +705,7 @@ __device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, 
     wreal vel = 0;
     for (int e = 0; e < 6; e++) vel += t.s_a[6 * lane + e] * (d.cvel[6 * b2 + e] - d.cvel[6 * b1 + e]);
     q.s_on = true; q.s_D = WL(1.0) / R; q.s_aref = -bb * vel - kk * imp * pos;
+    { const unsigned m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2]; q.s_mp = m2 & ~m1; q.s_mm = m1 & ~m2; }
   }
   // elliptic cones
   if (lane < nc)
@@ -732,7 +737,8 @@ __device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, 
         par[6 + j] = j < dim ? WL(1.0) / Rj : WL(0.0);
         aref[j] = j == 0 ? -bb * vel[0] - kk * imp * pos : -bb * vel[j];
       }
-      q.c_on = true; q.c_dim = dim;);
+      q.c_on = true; q.c_dim = dim; q.c_Dm = par[6] / (mu * mu * (1 + mu * mu));
+      { const unsigned m1 = m.body_dofmask[b1]; const unsigned m2 = m.body_dofmask[b2]; q.c_mp = m2 & ~m1; q.c_mm = m1 & ~m2; });
   WSYNC();
 }
 
@@ -788,7 +794,7 @@ __device__ __forceinline__ wreal wt_cost(WaveData& d, TreeData& t, TreeRows& q, 
       for (int e = 0; e < 6; e++) x[e] = c.jar[e];
       for (int e = 0; e < 12; e++) par[e] = c.par[e];
       for (int e = 0; e < 12; e++) geo[e] = c.geo[e];
-      cost += wt_cone_cost(x, par, q.c_dim, force, q.c_zone);
+      cost += wt_cone_cost(x, par, q.c_Dm, q.c_dim, force, q.c_zone);
       // A' force = [off x F + sum_{j>=3} f_{j-3} force_j, F], F = sum_{j<3} f_j force_j
       wreal F[3] = {0, 0, 0}; wreal tq[3] = {0, 0, 0};
       _Pragma("unroll")
@@ -817,24 +823,40 @@ __device__ __forceinline__ wreal wt_jt_force(const MODEL& m, const WaveData& d, 
   if (lane < m.nv) {
     wreal cd[6];
     for (int e = 0; e < 6; e++) cd[e] = d.cdof[6 * lane + e];
+    // contact i's dof masks come from its lane's registers (v_readlane, i is wave-uniform): no dependent LDS round trips
     for (int i = 0; i < ns; i++) {
-      const int sg = wt_sign(m, t.s_body[2 * i], t.s_body[2 * i + 1], lane);
+      const unsigned mp = (unsigned)__builtin_amdgcn_readlane((int)q.s_mp, i), mm = (unsigned)__builtin_amdgcn_readlane((int)q.s_mm, i);
+      const int sg = (int)((mp >> lane) & 1u) - (int)((mm >> lane) & 1u);
       if (sg != 0) {
         wreal ja = 0;
         for (int e = 0; e < 6; e++) ja += t.s_a[6 * i + e] * cd[e];
         s += (sg > 0 ? ja : -ja) * t.s_fd[2 * i];
       }
     }
-    for (int i = 0; i < nc; i++)
-      WT_CONE(i,
-        const int sg = wt_sign(m, c.meta[0], c.meta[1], lane);
-        if (sg != 0) {
+    for (int i = 0; i < nc; i++) {
+      const unsigned mp = (unsigned)__builtin_amdgcn_readlane((int)q.c_mp, i), mm = (unsigned)__builtin_amdgcn_readlane((int)q.c_mm, i);
+      const int sg = (int)((mp >> lane) & 1u) - (int)((mm >> lane) & 1u);
+      if (sg != 0)
+        WT_CONE(i,
           wreal ja = 0;
           for (int e = 0; e < 6; e++) ja += c.X[e] * cd[e];
-          s += sg > 0 ? ja : -ja;
-        });
+          s += sg > 0 ? ja : -ja;);
+    }
   }
   return s;
+}
+
+// rows of a contact between two moving bodies: H[i][j] += s_i s_j cdof_j . zc over the dofs j <= i the contact touches (zc = X cdof_i)
+__device__ __forceinline__ void wt_pair_rows(WaveData& d, int lane, const wreal* zc, unsigned mp, unsigned mm, int sg, unsigned lowmask) {
+  unsigned both = (mp | mm) & lowmask;
+  while (both) {
+    const int j = __ffs((int)both) - 1;
+    both &= both - 1;
+    wreal s = 0;
+    for (int e = 0; e < 6; e++) s += d.cdof[6 * j + e] * zc[e];
+    const int sj = ((int)((mp >> j) & 1u) - (int)((mm >> j) & 1u)) * sg;
+    d.H[wt_tri(lane, j)] += sj > 0 ? s : -s;
+  }
 }
 
 // ---- the Newton solver (o_constraint_newton) on the tree
@@ -948,7 +970,7 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
               for (int j = 1; j < 6; j++) { U[j] = j < dim ? x[j] * par[j] : WL(0.0); T += U[j] * U[j]; }
               T = sqrt(T);
               const wreal iT = WL(1.0) / T;
-              const wreal Dm = par[6] / (mu * mu * (1 + mu * mu)); const wreal NT = U[0] - mu * T; const wreal cc = Dm * NT * mu * iT;
+              const wreal Dm = q.c_Dm; const wreal NT = U[0] - mu * T; const wreal cc = Dm * NT * mu * iT;
               wreal p[6] = {0, 0, 0, 0, 0, 0}; wreal r[6] = {0, 0, 0, 0, 0, 0};
               _Pragma("unroll")
               for (int j = 0; j < 6; j++)
@@ -978,36 +1000,26 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
           // add up before the chain is walked once; a contact between two moving bodies walks its own dof set
           bool any = false;
           const unsigned lowmask = (2u << lane) - 1u;  // dofs j <= i
-          auto pair_rows = [&](const wreal* zc, int b1, int b2, int sg) {
-            unsigned both = (m.body_dofmask[b1] ^ m.body_dofmask[b2]) & lowmask;
-            while (both) {
-              const int j = __ffs((int)both) - 1;
-              both &= both - 1;
-              wreal s = 0;
-              for (int e = 0; e < 6; e++) s += d.cdof[6 * j + e] * zc[e];
-              const int sj = wt_sign(m, b1, b2, j) * sg;
-              d.H[wt_tri(lane, j)] += sj > 0 ? s : -s;
-            }
-          };
           for (int i = 0; i < ns; i++) {
-            const int b1 = t.s_body[2 * i], b2 = t.s_body[2 * i + 1];
-            const int sg = wt_sign(m, b1, b2, lane);
+            const unsigned mp = (unsigned)__builtin_amdgcn_readlane((int)q.s_mp, i), mm = (unsigned)__builtin_amdgcn_readlane((int)q.s_mm, i);
+            const int sg = (int)((mp >> lane) & 1u) - (int)((mm >> lane) & 1u);
             const wreal D = t.s_fd[2 * i + 1];
-            if (sg != 0 && D != 0) {
+            if (D != 0) {  // (wave-uniform)
               wreal a[6], ja = 0;
               for (int e = 0; e < 6; e++) { a[e] = t.s_a[6 * i + e]; ja += a[e] * cd[e]; }
-              if (m.body_dofmask[b1] == 0) { for (int e = 0; e < 6; e++) z[e] += D * ja * a[e]; any = true; }
-              else { wreal zc[6]; for (int e = 0; e < 6; e++) zc[e] = D * ja * a[e]; pair_rows(zc, b1, b2, sg); }
+              if (mm == 0) { for (int e = 0; e < 6; e++) z[e] += (wreal)sg * D * ja * a[e]; any |= sg != 0; }
+              else if (sg != 0) { wreal zc[6]; for (int e = 0; e < 6; e++) zc[e] = D * ja * a[e]; wt_pair_rows(d, lane, zc, mp, mm, sg, lowmask); }
             }
           }
-          for (int i = 0; i < nc; i++)
+          for (int i = 0; i < nc; i++) {
+            const unsigned mp = (unsigned)__builtin_amdgcn_readlane((int)q.c_mp, i), mm = (unsigned)__builtin_amdgcn_readlane((int)q.c_mm, i);
+            const int sg = (int)((mp >> lane) & 1u) - (int)((mm >> lane) & 1u);
+            const int zone_i = __builtin_amdgcn_readlane(q.c_zone, i);
+            if (zone_i == kZoneTop) continue;  // X_c = 0 (wave-uniform)
             WT_CONE(i,
-              const int b1 = c.meta[0]; const int b2 = c.meta[1];
-              const int sg = wt_sign(m, b1, b2, lane);
-              if (sg != 0) {
-                if (m.body_dofmask[b1] == 0) { sym6_mulvec_acc(z, c.X, cd); any = true; }
-                else { wreal zc[6] = {0, 0, 0, 0, 0, 0}; sym6_mulvec_acc(zc, c.X, cd); pair_rows(zc, b1, b2, sg); }
-              });
+              if (mm == 0) { if (sg != 0) { sym6_mulvec_acc(z, c.X, cd); any = true; } }
+              else if (sg != 0) { wreal zc[6] = {0, 0, 0, 0, 0, 0}; sym6_mulvec_acc(zc, c.X, cd); wt_pair_rows(d, lane, zc, mp, mm, sg, lowmask); });
+          }
           const wreal diag = (q.f_on && q.f_zone == kZoneBottom ? q.f_D : WL(0.0)) + dlim;
           if (any) {
             unsigned chain = m.body_dofmask[m.dof_bodyid[lane]] & lowmask;  // dofs j <= i on the chain of i
@@ -1079,7 +1091,7 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
       }
       if (q.c_on) {
         wreal cg, ch;
-        wt_cone_line(c_x0, c_jv, alpha, c_par, q.c_dim, cg, ch);
+        wt_cone_line(c_x0, c_jv, alpha, c_par, q.c_Dm, q.c_dim, cg, ch);
         g1 += cg; h2 += ch;
       }
     };

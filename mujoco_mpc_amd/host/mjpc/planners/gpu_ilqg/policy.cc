@@ -38,9 +38,9 @@ void iLQGPolicy::Action(double* action, const double* state, double time) const 
   int bounds[2];
   FindInterval(bounds, trajectory.times.data(), time, H);
   const bool zero = bounds[0] == bounds[1] || representation == kZeroOrder;
-  if (!zero && representation == kCubic) throw std::runtime_error("iLQGPolicy: cubic representation is not built");
   auto interp = [&](double* out, const double* ys, int dim, int length) {
     if (zero) ZeroInterpolation(out, time, trajectory.times.data(), ys, dim, length);
+    else if (representation == kCubic) CubicInterpolation(out, time, trajectory.times.data(), ys, dim, length);
     else LinearInterpolation(out, time, trajectory.times.data(), ys, dim, length);
   };
   interp(action, trajectory.actions.data(), nu, H - 1);

@@ -9,6 +9,7 @@
 #include "../task.h"
 #include "../threadpool.h"
 #include "../trajectory.h"
+#include "../utilities.h"
 
 struct mjvScene_;  typedef struct mjvScene_ mjvScene;
 struct mjUI_;      typedef struct mjUI_ mjUI;
@@ -34,6 +35,12 @@ class Planner {
   virtual void Plots(mjvFigure* fig_planner, mjvFigure* fig_timer, int planner_shift, int timer_shift, int planning,
                      int* shift) = 0;
   virtual int NumParameters() = 0;
+
+  // planners/planner.h:78-79: one mjData per pool thread. The GPU planners roll nothing out on the host, so a single
+  // mjData (the state / control scratch a caller of Trajectory::Rollout hands over) is all they keep; the members stay
+  // so that code written against the reference's Planner compiles unchanged.
+  std::vector<UniqueMjData> data_;
+  void ResizeMjData(const mjModel* model, int num_threads);
 };
 
 class RankedPlanner : public Planner {

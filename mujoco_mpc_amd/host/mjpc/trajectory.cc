@@ -1,8 +1,124 @@
 #include "trajectory.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <utility>
+
+#include "gpu/context.h"
 
 namespace mjpc {
+
+namespace {
+constexpr double kMaxReturnValue = 1.0e6;  // trajectory.cc:29
+
+// One device context per (model, task) the host-policy rollouts are asked for; created on first use, kept for the process.
+gpu::Context* RolloutContext(const mjModel* model, const Task* task) {
+  static std::mutex mtx;
+  static std::map<std::pair<const mjModel*, const Task*>, std::unique_ptr<gpu::Context>> contexts;
+  const std::lock_guard<std::mutex> lock(mtx);
+  auto& slot = contexts[{model, task}];
+  if (!slot) slot = std::make_unique<gpu::Context>(model, *task, /*device=*/0, /*precision=*/64);
+  return slot.get();
+}
+
+// The body shared by Rollout and RolloutDiscrete: `policy(action, state, t)` with t the step index.
+template <class Policy>
+void HostPolicyRollout(Trajectory* tr, Policy policy, const Task* task, const mjModel* model, mjData* data, const double* state, double time,
+                       const double* mocap, const double* userdata, int steps) {
+  tr->failure = false;
+  tr->horizon = steps;
+  const int nx = tr->dim_state, nu = tr->dim_action, nr = tr->dim_residual, ntr = tr->dim_trace;
+  gpu::Context* ctx = RolloutContext(model, task);
+  ctx->SyncTask(*task);
+  Trajectory one;  // the two rows a single mj_step produces
+  one.Initialize(nx, nu, nr, ntr / 3, 2);
+  one.Allocate(2);
+  // trajectory.cc:118-132: mocap, userdata, state, time
+  if (data) {
+    if (mocap) { for (int i = 0; i < model->nmocap; i++) { mju_copy(data->mocap_pos + 3 * i, mocap + 7 * i, 3); mju_copy(data->mocap_quat + 4 * i, mocap + 7 * i + 3, 4); } }
+    if (userdata) mju_copy(data->userdata, userdata, model->nuserdata);
+    data->time = time;
+  }
+  mju_copy(tr->states.data(), state, nx);
+  tr->times[0] = time;
+  const double node_time = 0;  // a one-node, zero-order spline IS a constant control
+  for (int t = 0; t < steps - 1; t++) {
+    double* action = tr->actions.data() + (size_t)t * nu;
+    const double* x = tr->states.data() + (size_t)t * nx;
+    policy(action, x, t, tr->times[t]);                     // policy(DataAt(actions, t * nu), DataAt(states, t * nx), data->time)
+    if (data) mju_copy(data->ctrl, action, nu);
+    // mj_step + the sensor callback at x (+ mj_forward at the next state, unused except at the end) on the device
+    ctx->Check(mjpcx_set_state(ctx->handle(), x, tr->times[t], mocap, userdata));
+    ctx->Check(mjpcx_rollout_splines(ctx->handle(), 1, 2, 1, MJPCX_SPLINE_ZERO, &node_time, action));
+    one.horizon = 2;
+    ctx->FetchTrajectory(0, &one);
+    mju_copy(action, one.actions.data(), nu);               // the device clamps the control as mj_step's ctrl clamp does not: see (2) below
+    mju_copy(tr->residual.data() + (size_t)t * nr, one.residual.data(), nr);
+    mju_copy(tr->trace.data() + (size_t)t * ntr, one.trace.data(), ntr);
+    if (one.failure) {                                      // trajectory.cc:169-173
+      tr->failure = true;
+      tr->total_return = kMaxReturnValue;
+      std::fprintf(stderr, "Rollout divergence at step %d\n", t);
+      return;
+    }
+    mju_copy(tr->states.data() + (size_t)(t + 1) * nx, one.states.data() + nx, nx);
+    tr->times[t + 1] = one.times[1];
+    if (data) { data->time = one.times[1]; mju_copy(data->qpos, one.states.data() + nx, model->nq); mju_copy(data->qvel, one.states.data() + nx + model->nq, model->nv); }
+    if (t == steps - 2) {
+      // the last launch also ran mj_forward at the final state with the last control: trajectory.cc:194-206
+      mju_copy(tr->residual.data() + (size_t)(steps - 1) * nr, one.residual.data() + nr, nr);
+      mju_copy(tr->trace.data() + (size_t)(steps - 1) * ntr, one.trace.data() + ntr, ntr);
+    }
+  }
+  if (steps > 1) {
+    mju_copy(tr->actions.data() + (size_t)(steps - 1) * nu, tr->actions.data() + (size_t)(steps - 2) * nu, nu);  // trajectory.cc:190-192
+  } else {
+    // a single row: mj_forward at the given state with the controls the caller left in `data`
+    std::vector<double> u(nu, 0.0);
+    if (data) mju_copy(u.data(), data->ctrl, nu);
+    ctx->Check(mjpcx_set_state(ctx->handle(), state, time, mocap, userdata));
+    ctx->Check(mjpcx_rollout_splines(ctx->handle(), 1, 1, 1, MJPCX_SPLINE_ZERO, &node_time, u.data()));
+    one.horizon = 1;
+    ctx->FetchTrajectory(0, &one);
+    mju_copy(tr->residual.data(), one.residual.data(), nr);
+    mju_copy(tr->trace.data(), one.trace.data(), ntr);
+  }
+  tr->UpdateReturn(task);
+}
+}  // namespace
+
+// Deviations from trajectory.cc:100-210, both confined to this compatibility path:
+//  (1) every step is its own device launch, so the constraint solver starts each step from the unconstrained acceleration
+//      instead of the previous step's solution (mj_step's warm start); the solutions agree to the solver tolerance (1e-8);
+//  (2) actions[t] is stored after the device's clamp to actuator_ctrlrange, which every policy of this code base applies
+//      itself (sampling/policy.cc:58, ilqg/policy.cc:160).
+void Trajectory::Rollout(std::function<void(double* action, const double* state, double time)> policy, const Task* task, const mjModel* model,
+                         mjData* data, const double* state, double time, const double* mocap, const double* userdata, int steps) {
+  HostPolicyRollout(this, [&](double* a, const double* x, int, double t) { policy(a, x, t); }, task, model, data, state, time, mocap, userdata, steps);
+}
+
+void Trajectory::RolloutDiscrete(std::function<void(double* action, const double* state, int index)> policy, const Task* task,
+                                 const mjModel* model, mjData* data, const double* state, double time, const double* mocap,
+                                 const double* userdata, int steps) {
+  HostPolicyRollout(this, [&](double* a, const double* x, int index, double) { policy(a, x, index); }, task, model, data, state, time, mocap, userdata, steps);
+}
+
+void Trajectory::NoisyRollout(std::function<void(double* action, const double* state, double time)> policy, const Task* task,
+                              const mjModel* model, mjData* data, const double* state, double time, const double* mocap,
+                              const double* userdata, double xfrc_std, double xfrc_rate, int steps) {
+  if (xfrc_std > 0) {
+    // the Ornstein-Uhlenbeck force noise lives in the device's rollout kernels (one stream per candidate and step); a host
+    // policy cannot be interleaved with it. Fatal configuration error, reported the way the reference reports them.
+    std::fprintf(stderr, "Trajectory::NoisyRollout with xfrc_std > 0 and a host policy: use GpuRobustPlanner (mjpcx_rollout_splines_noisy)\n");
+    std::abort();
+  }
+  (void)xfrc_rate;
+  Rollout(std::move(policy), task, model, data, state, time, mocap, userdata, steps);
+}
 
 void Trajectory::Initialize(int dim_state_, int dim_action_, int dim_residual_, int num_trace, int horizon_) {
   horizon = horizon_;

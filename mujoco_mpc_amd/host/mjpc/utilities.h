@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <chrono>
 #include <cmath>
+#include <memory>
 #include <optional>
 #include <string_view>
 #include <vector>
@@ -93,6 +94,10 @@ inline double GetDuration(std::chrono::steady_clock::time_point start) {
   return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - start).count();
 }
 
+// utilities.h:261-265
+using UniqueMjData = std::unique_ptr<mjData, void (*)(mjData*)>;
+inline UniqueMjData MakeUniqueMjData(mjData* d) { return UniqueMjData(d, mj_deleteData); }
+
 // keyframe qpos by name, utilities.cc:288-296
 inline double* KeyQPosByName(const mjModel* m, std::string_view name) {
   for (int i = 0; i < m->nkey; i++)
@@ -122,6 +127,29 @@ inline void LinearInterpolation(double* output, double x, const double* xs, cons
   if (bounds[0] == bounds[1]) { mju_copy(output, ys + (size_t)dim * bounds[0], dim); return; }
   const double t = (x - xs[bounds[0]]) / (xs[bounds[1]] - xs[bounds[0]]);
   for (int i = 0; i < dim; i++) output[i] = ys[(size_t)dim * bounds[0] + i] * (1.0 - t) + ys[(size_t)dim * bounds[1] + i] * t;
+}
+// cubic Hermite interpolation with finite-difference slopes (utilities.cc:336-422): the slope at a grid point is the mean of
+// the two neighbouring secants, one-sided at the ends of the grid and zero on a two-point grid
+inline double FiniteDifferenceSlope(double x, const double* xs, const double* ys, int dim, int length, int i) {
+  int b[2];
+  FindInterval(b, xs, x, length);
+  const auto secant = [&](int hi, int lo) { return (ys[(size_t)dim * hi + i] - ys[(size_t)dim * lo + i]) / (xs[hi] - xs[lo]); };
+  if (b[0] == 0 && b[1] == 0) return length > 2 ? secant(1, 0) : 0.0;                                        // below the grid
+  if (b[0] == length - 1 && b[1] == length - 1) return length > 2 ? secant(length - 1, length - 2) : 0.0;   // above it
+  if (b[0] == 0) return secant(b[1], 0);                                                                    // first interval
+  return 0.5 * secant(b[1], b[0]) + 0.5 * secant(b[0], b[0] - 1);
+}
+inline void CubicInterpolation(double* output, double x, const double* xs, const double* ys, int dim, int length) {
+  int b[2];
+  FindInterval(b, xs, x, length);
+  if (b[0] == b[1]) { mju_copy(output, ys + (size_t)dim * b[0], dim); return; }
+  const double span = xs[b[1]] - xs[b[0]], t = (x - xs[b[0]]) / span;
+  const double t2 = t * t, t3 = t2 * t;
+  const double c0 = 2.0 * t3 - 3.0 * t2 + 1.0, c1 = (t3 - 2.0 * t2 + t) * span, c2 = -2.0 * t3 + 3 * t2, c3 = (t3 - t2) * span;
+  for (int i = 0; i < dim; i++) {
+    const double m0 = FiniteDifferenceSlope(xs[b[0]], xs, ys, dim, length, i), m1 = FiniteDifferenceSlope(xs[b[1]], xs, ys, dim, length, i);
+    output[i] = c0 * ys[(size_t)dim * b[0] + i] + c1 * m0 + c2 * ys[(size_t)dim * b[1] + i] + c3 * m1;
+  }
 }
 // Ground (utilities.cc:556-574): global height of the nearest group-0 geom under `pos`, by a ray cast straight down from
 // 0.5 m above it. Host stand-in for mj_ray over the geoms a planning scene has below the robot: planes, spheres and boxes on

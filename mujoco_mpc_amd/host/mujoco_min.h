@@ -77,6 +77,27 @@ struct mjData {
   mjtNum *xpos, *xquat, *xmat, *xipos, *site_xpos, *subtree_com, *subtree_linvel;
 };
 
+// mj_makeData / mj_deleteData for the fields above (the state a planner thread's mjData carries: Planner::data_)
+inline mjData* mj_makeData(const mjModel* m) {
+  mjData* d = new mjData();
+  auto arr = [](int n) { mjtNum* p = new mjtNum[n > 0 ? n : 1]; std::memset(p, 0, sizeof(mjtNum) * (n > 0 ? n : 1)); return p; };
+  d->time = 0;
+  d->qpos = arr(m->nq); d->qvel = arr(m->nv); d->act = arr(m->na); d->ctrl = arr(m->nu);
+  d->mocap_pos = arr(3 * m->nmocap); d->mocap_quat = arr(4 * m->nmocap); d->userdata = arr(m->nuserdata);
+  int nsensordata = 0;
+  for (int i = 0; i < m->nsensor; i++) nsensordata = m->sensor_adr[i] + m->sensor_dim[i] > nsensordata ? m->sensor_adr[i] + m->sensor_dim[i] : nsensordata;
+  d->sensordata = arr(nsensordata);
+  if (m->qpos0) std::memcpy(d->qpos, m->qpos0, sizeof(mjtNum) * m->nq);
+  d->xpos = d->xquat = d->xmat = d->xipos = d->site_xpos = d->subtree_com = d->subtree_linvel = nullptr;
+  return d;
+}
+inline void mj_deleteData(mjData* d) {
+  if (!d) return;
+  delete[] d->qpos; delete[] d->qvel; delete[] d->act; delete[] d->ctrl; delete[] d->mocap_pos; delete[] d->mocap_quat;
+  delete[] d->userdata; delete[] d->sensordata;
+  delete d;
+}
+
 #define mjMAX(a, b) (((a) > (b)) ? (a) : (b))
 #define mjMIN(a, b) (((a) < (b)) ? (a) : (b))
 inline void mju_copy(mjtNum* dst, const mjtNum* src, int n) { if (n > 0) std::memcpy(dst, src, sizeof(mjtNum) * n); }

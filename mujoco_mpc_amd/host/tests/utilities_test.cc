@@ -37,6 +37,26 @@ int main() {
     LinearInterpolation(&out, 2.5, x.data(), y, 1, 2); CHECK_NEAR(out, 2.0, 1e-5);
     ZeroInterpolation(&out, 1.9, x.data(), y, 1, 2); CHECK_NEAR(out, 1.0, 1e-12);
   }
+  {  // CubicInterpolation (utilities.cc:397-422): Hermite with finite-difference slopes
+    std::vector<double> x{0.0, 1.0, 2.0, 4.0};
+    double out;
+    double lin[4] = {1.0, 3.0, 5.0, 9.0};          // y = 1 + 2 x: every secant is 2, the cubic reproduces the line
+    for (double q : {0.25, 1.5, 2.7, 3.9}) { CubicInterpolation(&out, q, x.data(), lin, 1, 4); CHECK_NEAR(out, 1.0 + 2.0 * q, 1e-12); }
+    CubicInterpolation(&out, -1.0, x.data(), lin, 1, 4); CHECK_NEAR(out, 1.0, 1e-12);   // below the grid: first value
+    CubicInterpolation(&out, 5.0, x.data(), lin, 1, 4); CHECK_NEAR(out, 9.0, 1e-12);    // above: last value
+    double y[4] = {0.0, 1.0, 0.0, 2.0};
+    // interval [1, 2]: m(1) = mean of the secants +1 and -1 = 0, m(2) = mean of +1 and -1 = 0: the middle value is 0.5 (1 + 0)
+    CubicInterpolation(&out, 1.5, x.data(), y, 1, 4); CHECK_NEAR(out, 0.5, 1e-12);
+    // first interval: m(0) = secant(1, 0) = 1 (one-sided), m(1) = 0: p(0.5) = 0.5 * 0 + 0.125 * 1 + 0.5 * 1 - 0.125 * 0 = 0.625
+    CubicInterpolation(&out, 0.5, x.data(), y, 1, 4); CHECK_NEAR(out, 0.625, 1e-12);
+    // last interval [2, 4]: m(2) = 0, m(4) = secant(3, 2) = 1 (one-sided): p(3) = 0.5 * 0 + 0 + 0.5 * 2 - 0.125 * 2 * 1 = 0.75
+    CubicInterpolation(&out, 3.0, x.data(), y, 1, 4); CHECK_NEAR(out, 0.75, 1e-12);
+    // two-point grid: the end slopes are zero except the first interval's one-sided secant
+    std::vector<double> x2{0.0, 1.0};
+    double y2[2] = {0.0, 1.0};
+    CHECK_NEAR(FiniteDifferenceSlope(1.0, x2.data(), y2, 1, 2, 0), 0.0, 1e-15);
+    CHECK_NEAR(FiniteDifferenceSlope(0.0, x2.data(), y2, 1, 2, 0), 1.0, 1e-15);
+  }
   {  // LogScale: ascending from min to max, geometric
     double v[4];
     LogScale(v, 1.0, 1.0e-3, 4);

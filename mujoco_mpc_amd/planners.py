@@ -622,26 +622,39 @@ class ILQGPolicy:
         self.action_improvement[:horizon] = other.action_improvement[:horizon]
 
     @staticmethod
-    def _interp(x, xs, ys, length, zero):
+    def _slope(g, xs, ys, length):
+        """FiniteDifferenceSlope (utilities.cc:362-395) at grid point g"""
+        if g == length - 1:
+            return (ys[g] - ys[g - 1]) / (xs[g] - xs[g - 1]) if length > 2 else np.zeros_like(ys[g])
+        if g == 0:
+            return (ys[1] - ys[0]) / (xs[1] - xs[0])
+        return 0.5 * (ys[g + 1] - ys[g]) / (xs[g + 1] - xs[g]) + 0.5 * (ys[g] - ys[g - 1]) / (xs[g] - xs[g - 1])
+
+    @classmethod
+    def _interp(cls, x, xs, ys, length, zero, representation=1):
         b0, b1 = find_interval(xs, x, length)
         if zero or b0 == b1:
             return ys[b0].copy()
-        t = (x - xs[b0]) / (xs[b1] - xs[b0])
-        return ys[b0] * (1.0 - t) + ys[b1] * t
+        span = xs[b1] - xs[b0]
+        t = (x - xs[b0]) / span
+        if representation != 2:
+            return ys[b0] * (1.0 - t) + ys[b1] * t
+        c0, c1 = 2.0 * t ** 3 - 3.0 * t * t + 1.0, (t ** 3 - 2.0 * t * t + t) * span
+        c2, c3 = -2.0 * t ** 3 + 3 * t * t, (t ** 3 - t * t) * span
+        return c0 * ys[b0] + c1 * cls._slope(b0, xs, ys, length) + c2 * ys[b1] + c3 * cls._slope(b1, xs, ys, length)
 
     def action(self, action, state, time):
-        """policy.cc:82-161 (zero-order / linear representations)."""
+        """policy.cc:82-161 (zero-order / linear / cubic representations)."""
         tr, H = self.trajectory, self.trajectory.horizon
         b0, b1 = find_interval(tr.times, time, H)
         zero = b0 == b1 or self.representation == 0
-        if self.representation == 2 and not zero:
-            raise NotImplementedError("cubic iLQG policy representation")
-        action[:] = self._interp(time, tr.times, tr.actions, H - 1, zero)
+        rep = self.representation
+        action[:] = self._interp(time, tr.times, tr.actions, H - 1, zero, rep)
         if state is not None:
-            xi = self._interp(time, tr.times, tr.states, H, zero)
+            xi = self._interp(time, tr.times, tr.states, H, zero, rep)
             if self.model.nq != self.model.nv:
                 xi = normalize_state_quaternions(self.model, xi)
-            K = self._interp(time, tr.times, self.feedback_gain, H - 1, zero)
+            K = self._interp(time, tr.times, self.feedback_gain, H - 1, zero, rep)
             action += self.feedback_scaling * (K @ state_diff(self.model, xi, np.asarray(state, float)))
         return clamp(action, self.model.actuator_ctrlrange)
 

@@ -222,12 +222,32 @@ static void find_interval(const double* xs, double v, int length, int* b) { /* u
   else if (lo > length - 1) { b[0] = b[1] = length - 1; }
   else { b[0] = lo; b[1] = up < length - 1 ? up : length - 1; }
 }
-static void interp(double* out, double x, const double* xs, const double* ys, int dim, int length, int zero) {
+/* FiniteDifferenceSlope (utilities.cc:362-395): slope of component i at grid value x */
+static double fd_slope(double x, const double* xs, const double* ys, int dim, int length, int i) {
+  int b[2];
+  find_interval(xs, x, length, b);
+  if (b[0] == 0 && b[1] == 0) return length > 2 ? (ys[dim * 1 + i] - ys[i]) / (xs[1] - xs[0]) : 0.0;
+  if (b[0] == length - 1 && b[1] == length - 1)
+    return length > 2 ? (ys[dim * b[0] + i] - ys[dim * (b[0] - 1) + i]) / (xs[b[0]] - xs[b[0] - 1]) : 0.0;
+  if (b[0] == 0) return (ys[dim * b[1] + i] - ys[dim * b[0] + i]) / (xs[b[1]] - xs[b[0]]);
+  return 0.5 * (ys[dim * b[1] + i] - ys[dim * b[0] + i]) / (xs[b[1]] - xs[b[0]]) +
+         0.5 * (ys[dim * b[0] + i] - ys[dim * (b[0] - 1) + i]) / (xs[b[0]] - xs[b[0] - 1]);
+}
+/* Zero / Linear / CubicInterpolation (utilities.cc:304-422); representation: 0 zero-order, 1 linear, 2 cubic */
+static void interp(double* out, double x, const double* xs, const double* ys, int dim, int length, int zero, int representation) {
   int b[2];
   find_interval(xs, x, length, b);
   if (zero || b[0] == b[1]) { memcpy(out, ys + dim * b[0], sizeof(double) * dim); return; }
-  const double t = (x - xs[b[0]]) / (xs[b[1]] - xs[b[0]]);
-  for (int i = 0; i < dim; i++) out[i] = ys[dim * b[0] + i] * (1.0 - t) + ys[dim * b[1] + i] * t;
+  const double span = xs[b[1]] - xs[b[0]], t = (x - xs[b[0]]) / span;
+  if (representation != 2) {
+    for (int i = 0; i < dim; i++) out[i] = ys[dim * b[0] + i] * (1.0 - t) + ys[dim * b[1] + i] * t;
+    return;
+  }
+  const double c0 = 2.0 * t * t * t - 3.0 * t * t + 1.0, c1 = (t * t * t - 2.0 * t * t + t) * span;
+  const double c2 = -2.0 * t * t * t + 3 * t * t, c3 = (t * t * t - t * t) * span;
+  for (int i = 0; i < dim; i++)
+    out[i] = c0 * ys[dim * b[0] + i] + c1 * fd_slope(xs[b[0]], xs, ys, dim, length, i) + c2 * ys[dim * b[1] + i] +
+             c3 * fd_slope(xs[b[1]], xs, ys, dim, length, i);
 }
 static void clamp_ctrl(const mjpcx_model* m, double* u) {
   for (int k = 0; k < m->nu; k++) {
@@ -248,10 +268,10 @@ static void fb_action(const FbPolicy* p, double* action, const double* state, do
     int b[2];
     find_interval(p->times, time, p->Tn, b);
     const int zero = b[0] == b[1] || p->representation == 0;
-    interp(action, time, p->times, p->actions, nu, p->Tn - 1, zero);
+    interp(action, time, p->times, p->actions, nu, p->Tn - 1, zero, p->representation);
     if (p->use_state) {
-      interp(xi, time, p->times, p->states, ds, p->Tn, zero);
-      interp(K, time, p->times, p->gains, nu * ndx, p->Tn - 1, zero);
+      interp(xi, time, p->times, p->states, ds, p->Tn, zero, p->representation);
+      interp(K, time, p->times, p->gains, nu * ndx, p->Tn - 1, zero, p->representation);
       for (int j = 0; j < m->njnt; j++) { /* policy.cc:118-125: renormalise interpolated quaternions */
         const int tj = m->jnt_type[j];
         if (tj == MJPCX_JNT_FREE || tj == MJPCX_JNT_BALL) {

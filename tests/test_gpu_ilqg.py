@@ -139,7 +139,7 @@ def test_backward_pass_reports_failure(cartpole):
     assert not pyoracle.riccati(6, 2, 5, 0.0, 0, 0, *prob)["ok"]
 
 
-@pytest.mark.parametrize("mode,representation,use_state", [(0, 0, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0)])
+@pytest.mark.parametrize("mode,representation,use_state", [(0, 0, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0), (1, 2, 1), (1, 2, 0)])
 def test_rollout_feedback(cartpole, mode, representation, use_state):
     H = 30
     pm, pt, nom = nominal(cartpole, H, 5, [0.1, 2.5, 0.0, 0.2])

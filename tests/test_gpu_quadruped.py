@@ -84,6 +84,31 @@ def test_trot_gait_residual(quad):
     run(t, np.concatenate([home, np.zeros(18)]), N=4, H=20, P=3, interp=0, seed=7, tol=1e-7, time=0.0)
 
 
+@pytest.mark.parametrize("mode,biped_type,gait,flip_dir", [(1, 0, 0, 0), (1, 1, 0, 0), (2, 0, 1, 0), (3, 0, 3, 0), (4, 0, 0, 0), (4, 0, 0, 1),
+                                                           (0, 0, 4, 0)])
+def test_every_residual_mode_on_the_device(mode, biped_type, gait, flip_dir):
+    """QuadrupedFlat::ResidualFn::Residual (quadruped.cc:33-226) has five modes -- Quadruped, Biped (feet or handstand), Walk,
+    Scramble, Flip -- and five gaits; the frozen ResidualFn state selects the branch. Each branch on the device against the oracle
+    (residual entries, costs, returns), with the task state a Transition into that mode leaves (mode start time, a non-trivial
+    saved orientation / position / heading for the Flip and Walk branches)."""
+    t = load_task("QuadrupedFlat")
+    t.parameters[t.ids["gait"]] = float(gait)
+    t.parameters[t.ids["biped_type"]] = float(biped_type)
+    t.parameters[t.ids["flip_dir"]] = float(flip_dir)
+    t.transition(0.0)
+    t.mode = t.current_mode = mode
+    t.mode_start_time = 0.02
+    t.position, t.heading_vec, t.speed, t.angvel, t.ground = [0.05, -0.02, 0.27], [0.9, 0.1], 0.3, 0.2, 0.0
+    t.orientation = [0.995, 0.02, 0.05, 0.08]
+    t._freeze()
+    home = t.model.keyframes["home"]["qpos"].copy()
+    v = np.zeros(18)
+    v[0:3] = [0.2, -0.1, 0.0]
+    v[3:6] = [0.1, 0.3, -0.2]
+    worst = run(t, np.concatenate([home, v]), N=4, H=24, P=3, interp=1, seed=40 + mode, tol=1e-7, time=0.05)
+    assert worst < 1e-7
+
+
 def test_cross_entropy_planner_on_the_quadruped(quad):
     """BASELINE configs[2] in miniature: Cross-Entropy on the A1 (zero-order splines, 3 nodes) closes the loop with the
     oracle as the plant for a few steps; the planned return improves on the zero policy and the robot stays up."""
@@ -144,7 +169,7 @@ def test_transition_fd_on_the_quadruped(quad, centered):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode,representation,use_state", [(0, 0, 1), (1, 1, 1), (1, 0, 0)])
+@pytest.mark.parametrize("mode,representation,use_state", [(0, 0, 1), (1, 1, 1), (1, 0, 0), (1, 2, 1)])
 def test_rollout_feedback_on_the_quadruped(quad, mode, representation, use_state):
     """RolloutDiscrete / iLQGPolicy::Action with StateDiff on the free joint's quaternion"""
     H = 20

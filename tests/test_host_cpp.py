@@ -17,7 +17,7 @@ HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 def blobs(tmp_path_factory):
     build_host()
     d = tmp_path_factory.mktemp("blobs")
-    for name in ("Cartpole", "Particle", "QuadrupedFlat", "HumanoidTrack"):
+    for name in ("Cartpole", "Particle", "ParticleCopy", "QuadrupedFlat", "HumanoidTrack"):
         mjcf.save_blob(load_task(name).model, str(d / f"{name}.mjpx"))
     return str(d)
 
@@ -47,6 +47,13 @@ def test_host_library_links_the_c_abi(blobs):
 @pytest.mark.gpu
 def test_gpu_sampling_planner_cpp(blobs):
     assert "OK" in run("gpu_planner_test", blobs)
+
+
+@pytest.mark.gpu
+def test_trajectory_rollout_cpp(blobs):
+    """mjpc/test/agent/rollout_test.cc through the restored Trajectory::Rollout / RolloutDiscrete / NoisyRollout (host policy,
+    device physics) and Planner::data_ / ResizeMjData"""
+    assert "OK" in run("rollout_test", blobs)
 
 
 @pytest.mark.gpu

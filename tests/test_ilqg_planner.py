@@ -71,3 +71,45 @@ def test_ilqg_gpu_tracks_oracle_backend():
         assert wg == wo and mg == mo and sg == so
         assert abs(rg - ro) < 1e-7 * (1 + abs(ro))
     assert np.allclose(g.policy.feedback_gain[:steps], o.policy.feedback_gain[:steps], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("representation", [0, 1, 2])
+def test_oracle_time_policy_matches_the_python_policy(representation):
+    """iLQGPolicy::Action (ilqg/policy.cc:82-161) in its three representations -- zero-order, linear, cubic (Hermite with
+    finite-difference slopes, utilities.cc:336-422): the C oracle's time-based feedback rollout against a step-by-step rollout of
+    the oracle's physics driven by the Python ILQGPolicy (two implementations of the interpolation)."""
+    from mujoco_mpc_amd.planners import ILQGPolicy
+    from mujoco_mpc_amd.task import load_task
+    from oracle import pyoracle
+    task = load_task("Particle")
+    pm, pt = task.packed_model(), task.packed()
+    m = task.model
+    H = 12
+    rng = np.random.default_rng(3)
+    pol = ILQGPolicy(m, task)
+    pol.reset(H)
+    pol.representation = representation
+    tr = pol.trajectory
+    tr.horizon = H
+    dt = float(pm.struct.timestep)  # the planning copy of the model steps at agent_timestep
+    tr.times[:H] = 2.3 * dt + dt * np.arange(H)  # knots off the step grid: every step interpolates
+    tr.states[:H] = 0.1 * rng.normal(size=(H, 4))
+    tr.actions[:H] = 0.3 * rng.normal(size=(H, 2))
+    pol.feedback_gain[:H] = 0.4 * rng.normal(size=(H, 2, 4))
+    pol.feedback_scaling = 0.7
+    state0 = np.array([0.05, -0.02, 0.1, 0.0])
+    t0 = 0.0  # starts BEFORE the first knot: the policy extrapolates by holding the first value
+    ref = pyoracle.rollout_feedback(pm, pt, state0, t0, np.zeros(7), H + 4, 1, representation, 1, tr.times[:H], tr.states[:H], tr.actions[:H],
+                                    pol.feedback_gain[:H], np.zeros((H, 2)), np.array([pol.feedback_scaling]))
+    ph = pyoracle.Physics(pm)
+    x, t = state0.copy(), t0
+    for k in range(H + 3):
+        u = np.zeros(2)
+        pol.action(u, x, t)
+        assert np.allclose(ref["actions"][0][k], u, rtol=0, atol=1e-12), (representation, k)
+        ph.set_state(x[:2], x[2:], t, np.zeros(7))
+        ph.set_ctrl(u)
+        ph.step()
+        x = np.concatenate([ph.get("qpos"), ph.get("qvel")])
+        t += dt
+        assert np.allclose(ref["states"][0][k + 1], x, rtol=0, atol=1e-12)
