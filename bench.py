@@ -144,7 +144,7 @@ def pmc_summary(task_name, candidates, horizon, precision):
     return s
 
 
-def run_config(args, task_name, kind, candidates, horizon, precision, steps, warmup, world, local_rank, group, want_cpu, rank):
+def run_config(args, task_name, kind, candidates, horizon, precision, steps, warmup, world, local_rank, group, want_cpu, rank, native=None):
     """one BASELINE config through the C++ planner over the C ABI; returns the fields of a bench line"""
     import torch
     from mujoco_mpc_amd import capi
@@ -155,7 +155,7 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
     H = horizon
     planner = HostPlanner(task, device=local_rank, precision=precision, seed=0,
                           num_trajectory=candidates * world,  # lifts kMaxTrajectory = 128
-                          group=group, kind=kind)
+                          group=None if native is not None else group, kind=kind, native_comm=native)
     qpos, qvel, mocap_pos, mocap_quat = initial_condition(task_name, task, planner)
     planner.reset(H)
     P = planner.num_spline_points
@@ -195,7 +195,8 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
         "config": {"workload": f"{task_name} {'Predictive Sampling' if kind == 'sampling' else 'Cross-Entropy'}, {candidates} candidates/GPU, "
                                f"horizon {H}, {P} spline points, fp{precision} ({label})",
                    "candidates_per_gpu": candidates, "horizon": H, "spline_points": P,
-                   "parallelism": f"candidates sharded over {world} rank(s)", "kernel": planner.kernel_name,
+                   "parallelism": f"candidates sharded over {world} rank(s)" + (", exchange over RCCL inside libmjpcx.so" if native is not None else ""),
+                   "kernel": planner.kernel_name,
                    "host": ("C++ mjpc::GpuSamplingPlanner" if kind == "sampling" else "C++ mjpc::GpuCrossEntropyPlanner") + " over the C ABI"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -285,13 +286,23 @@ def main():
     import torch
 
     group = None
+    native = None
     if world > 1:
+        # torch.distributed only rendezvouses the ranks (barriers, the max over ranks of the elapsed time, and shipping the
+        # RCCL unique id); the per-step candidate exchange runs inside libmjpcx.so on its own RCCL communicator
         import torch.distributed as dist
         from mujoco_mpc_amd.distributed import RankGroup
+        from mujoco_mpc_amd.hostplanner import comm_unique_id
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         group = RankGroup(dist, torch.device("cuda", local_rank))
+        if os.environ.get("MJPC_BENCH_TRANSPORT", "rccl") != "torch":  # ("torch": the exchange through torch.distributed callbacks)
+            uid = torch.zeros(128, dtype=torch.uint8, device=torch.device("cuda", local_rank))
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            native = (bytes(uid.cpu().numpy().tobytes()), rank, world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -299,7 +310,7 @@ def main():
     candidates = args.candidates or n0
     H = args.horizon or h0
     main_line = run_config(args, args.task, args.planner, candidates, H, args.precision, args.steps, args.warmup, world, local_rank,
-                           group, want_cpu=not args.no_cpu_baseline, rank=rank)
+                           group, want_cpu=not args.no_cpu_baseline, rank=rank, native=native)
     if rank == 0:
         out = {"metric": "candidate-trajectory rollouts/sec (fixed horizon)", "value": main_line["value"], "unit": "rollouts/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],

@@ -414,6 +414,31 @@ int mjpcx_kinematics(mjpcx_ctx* ctx, double* xpos, double* xquat, double* xmat, 
  * RCCL collective). which: 0 = total_return (N x fp64), 1 = failure (N x i32). */
 int mjpcx_device_buffer(mjpcx_ctx* ctx, int which, void** ptr, size_t* bytes);
 
+/* ---- multi-GPU: one process per GPU, candidates partitioned by rank (candidate_offset in the noise spec), ONE small
+ * exchange per plan iteration over RCCL (xGMI). SURVEY.md 8b / 8e. The library resolves librccl.so.1 at the first call
+ * (MJPCX_EUNSUPPORTED if it is absent); every rank must make the same sequence of collective calls.
+ *   mjpcx_comm_unique_id : rank 0 only; the caller ships the 128 bytes to the other ranks (any side channel)
+ *   mjpcx_comm_init      : every rank; ncclCommInitRank on the context's device
+ *   mjpcx_exchange_best  : Predictive Sampling (replaces the partial_sort over one process's candidates,
+ *                          sampling/planner.cc:184-188): all-gather of (best return, global index, nominal return), winner =
+ *                          lowest return, ties to the lowest global index, NaN ranked last; then the winner's owner broadcasts
+ *                          its n spline values. In/out: this rank's record -> the global winner's. nominal_return is rank 0's
+ *                          (global candidate 0 lives there).
+ *   mjpcx_merge_topk     : Cross-Entropy (cross_entropy/planner.cc:240-250): in = this rank's k best (global index, return),
+ *                          unused slots index -1; out = the global k best, identical on every rank (ties by global index)
+ *   mjpcx_elite_allreduce: in-place sum over the ranks of a small fp64 vector (the elite moments)
+ *   mjpcx_comm_barrier   : all ranks reach it (a 1-element all-reduce + stream sync)
+ */
+#define MJPCX_COMM_ID_BYTES 128
+int mjpcx_comm_unique_id(void* id_out);
+int mjpcx_comm_init(mjpcx_ctx* ctx, const void* unique_id, int rank, int world);
+int mjpcx_comm_info(const mjpcx_ctx* ctx, int* rank, int* world); /* world = 1, rank = 0 before mjpcx_comm_init */
+int mjpcx_exchange_best(mjpcx_ctx* ctx, int32_t* index, double* best_return, double* nominal_return, double* spline_values, int n);
+int mjpcx_merge_topk(mjpcx_ctx* ctx, int k, int64_t* index, double* total_return);
+int mjpcx_elite_allreduce(mjpcx_ctx* ctx, double* values, int n);
+int mjpcx_comm_barrier(mjpcx_ctx* ctx);
+int mjpcx_comm_destroy(mjpcx_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

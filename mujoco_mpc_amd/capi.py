@@ -26,7 +26,8 @@ EXPORTS = [
     "mjpcx_rollout_noise", "mjpcx_rollout_splines_noisy", "mjpcx_kinematics", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
     "mjpcx_fetch_spline", "mjpcx_rollout_feedback", "mjpcx_transition_fd", "mjpcx_cost_derivatives",
     "mjpcx_backward_pass", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
-    "mjpcx_device_buffer",
+    "mjpcx_device_buffer", "mjpcx_comm_unique_id", "mjpcx_comm_init", "mjpcx_comm_info", "mjpcx_exchange_best", "mjpcx_merge_topk",
+    "mjpcx_elite_allreduce", "mjpcx_comm_barrier", "mjpcx_comm_destroy",
 ]
 
 _LIB = None

@@ -39,6 +39,7 @@ struct LaneModel {
   T qpos0[kLaneMaxDof], qpos_spring[kLaneMaxDof];
   T dof_armature[kLaneMaxDof], dof_damping[kLaneMaxDof], dof_invweight0[kLaneMaxDof];
   int any_damping;
+  int integrator;  // MJPCX_INT_EULER / MJPCX_INT_RK4
   T site_pos[kLaneMaxSite][3];
   T act_gear[kLaneMaxAct], act_gain[kLaneMaxAct], act_bias[kLaneMaxAct][3];
   T act_ctrlrange[kLaneMaxAct][2], act_forcerange[kLaneMaxAct][2];

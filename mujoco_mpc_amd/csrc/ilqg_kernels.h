@@ -180,7 +180,8 @@ __global__ __launch_bounds__(64) void rollout_feedback_kernel(const LaneModel<T>
     if (bad) failed = true;
     total += (double)cost;
     if (last) break;
-    lane_euler<TP, T>(m, qpos, qvel, qacc, qfrc, qfrc_c, M);
+    lane_integrate<TP, T>(m, tk, qpos, qvel, ctrl, qacc, qfrc, qfrc_c, M, nullptr, site_xpos);
+    if (m.integrator == 1 && live && !failed) lane_record_trace<TP, TK, T>(a, t, cand, site_xpos);
     time += h;
   }
   if (live) {
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(64) void transition_fd_kernel(const LaneModel<T> m_
   // sensors see the clamped control, as data->ctrl is clamped only inside mj_fwdActuation: the residual reads
   // data->ctrl (unclamped) in the reference, so pass the raw perturbed value
   lane_residual<TP, TK, T>(tk, qpos, qvel, ctrl, r);
-  lane_euler<TP, T>(m, qpos, qvel, qacc, qfrc, qfrc_c, M);
+  lane_integrate<TP, T>(m, tk, qpos, qvel, ctrl, qacc, qfrc, qfrc_c, M);
   T* y = f.next + ((size_t)t * NC + c) * NDX;
 #pragma unroll
   for (int i = 0; i < NV; i++) { y[i] = qpos[i]; y[NV + i] = qvel[i]; }

@@ -203,7 +203,8 @@ inline bool lds_model_matches(const mjpcx_model* m, const mjpcx_task* t, const W
   return m->nq == C::NQ && m->nv == C::NV && m->nu == C::NU && m->nbody == C::NB && m->njnt == C::NJ && m->nsite == C::NS && m->ngeom == C::NG &&
          m->nkey == C::NKEY && m->nmocap == C::NMOCAP && wh.m.nbody == C::NB && wh.m.nsite == C::NS && (int)wh.h_static_geom.size() == C::NSG &&
          (int)wh.h_dynamic_geom.size() == C::NDG && (int)wh.h_ray_geom.size() == C::NRAY && t->num_residual == C::NR && t->num_term == C::NTERM &&
-         t->num_trace == C::NTRACE && m->ntendon == 0;
+         t->num_trace == C::NTRACE && m->ntendon == 0 &&
+         m->integrator == MJPCX_INT_EULER;  // (RK4 runs in the generic kernels: wave_kernel.h)
 }
 
 }  // namespace mjpcx

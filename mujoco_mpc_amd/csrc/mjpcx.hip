@@ -19,6 +19,9 @@
 #include "lane_registry.h"
 #include "ilqg_dense.h"
 #include "rollout_wave.h"
+#include <dlfcn.h>
+#include <mutex>
+#include <rccl/rccl.h>
 
 using namespace mjpcx;
 
@@ -338,6 +341,11 @@ struct mjpcx_ctx {
   int max_waves = 8;          // MJPCX_TREE_WAVES=<1..8>: wavefronts per workgroup of the registered-model kernel
   int tree_mode = 0;          // MJPCX_TREE_MODE=2: image self-check launch (tree_kernel.h)
   bool no_second_pass = false;  // MJPCX_TREE_ONE_PASS=1: leave list overflows as failures (tuning: counts them)
+  // multi-GPU (mjpcx_comm_*): the RCCL communicator of this context's rank and its staging buffers
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  DevBuf d_comm_send, d_comm_recv;
+  std::vector<double> h_comm;
   DevBuf d_work;              // its self-check counter
   DevBuf d_ovf;               // its global slabs for cones beyond the LDS list
   bool no_cone_slabs = false; // MJPCX_TREE_NO_SLABS=1: overflow goes to the second pass instead (A/B runs)
@@ -389,6 +397,7 @@ void fill_model(LaneModel<T>& d, const mjpcx_model* m) {
     d.root_invmass[b] = (T)(sub[b] > kMinVal ? 1.0 / sub[b] : 0.0);
   }
   d.any_damping = 0;
+  d.integrator = m->integrator;
   for (int j = 0; j < m->njnt; j++) {
     for (int k = 0; k < 3; k++) { d.jnt_pos[j][k] = (T)m->jnt_pos[3 * j + k]; d.jnt_axis[j][k] = (T)m->jnt_axis[3 * j + k]; }
     d.jnt_stiffness[j] = (T)m->jnt_stiffness[j];
@@ -667,7 +676,9 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
       // the register-resident Cholesky is unrolled to NMAX columns: instantiations that fit the registered models exactly (A1:
       // nv = 18, humanoid: 27) skip the padding columns' updates (humanoid: 30 % of the factorisation's instructions)
-      auto kern = tree ? (wm.nv <= 18 ? w64::rollout_wave_kernel<18, true> : w64::rollout_wave_kernel<32, true>)
+      const bool rk4 = wm.integrator == MJPCX_INT_RK4;  // one (NMAX = 32) instantiation per kernel family carries mj_RungeKutta
+      auto kern = rk4 ? (tree ? w64::rollout_wave_kernel<32, true, true> : w64::rollout_wave_kernel<32, false, true>)
+                : tree ? (wm.nv <= 18 ? w64::rollout_wave_kernel<18, true> : w64::rollout_wave_kernel<32, true>)
                 : wm.nv <= 18 ? w64::rollout_wave_kernel<18> : wm.nv <= 20 ? w64::rollout_wave_kernel<20>
                 : wm.nv <= 28 ? w64::rollout_wave_kernel<28> : w64::rollout_wave_kernel<32>;
       le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -698,7 +709,8 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     } else {
     const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
     if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
-    auto kern = wm.nv <= 18 ? w32::rollout_wave_kernel<18> : wm.nv <= 20 ? w32::rollout_wave_kernel<20>
+    auto kern = wm.integrator == MJPCX_INT_RK4 ? w32::rollout_wave_kernel<32, false, true>
+              : wm.nv <= 18 ? w32::rollout_wave_kernel<18> : wm.nv <= 20 ? w32::rollout_wave_kernel<20>
               : wm.nv <= 28 ? w32::rollout_wave_kernel<28> : w32::rollout_wave_kernel<32>;
     le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (le == hipSuccess) {
@@ -765,7 +777,8 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
   if (precision != 64 && precision != 32) return bad(MJPCX_EINVAL, "precision must be 64 or 32");
   // ---- features the device kernels cover today
   if (m->na != 0) return bad(MJPCX_EUNSUPPORTED, "actuator activations (na > 0) unsupported");
-  if (m->integrator != MJPCX_INT_EULER) return bad(MJPCX_EUNSUPPORTED, "only the Euler integrator is implemented");
+  if (m->integrator != MJPCX_INT_EULER && m->integrator != MJPCX_INT_RK4)
+    return bad(MJPCX_EUNSUPPORTED, "integrators: Euler and RK4 (implicit / implicitfast are not implemented)");
   // ---- wavefront-per-candidate family: free/ball joints, friction loss, contacts
   bool needs_wave = false;
   for (int j = 0; j < m->njnt; j++) needs_wave |= m->jnt_type[j] == MJPCX_JNT_FREE || m->jnt_type[j] == MJPCX_JNT_BALL;
@@ -923,8 +936,9 @@ void mjpcx_destroy(mjpcx_ctx* c) {
     sl.dev.release();
   }
   if (c->best_host) (void)hipHostFree(c->best_host);
+  (void)mjpcx_comm_destroy(c);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_comm_send, &c->d_comm_recv,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();
@@ -1342,6 +1356,7 @@ size_t wave_lds_bytes(const mjpcx_ctx* c, int P) {
 int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
                      const double* states, const double* actions, const double* gains, const double* improvement, const double* alpha) {
   if (c->precision != 64) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family are fp64 only");
+  if (c->wh.m.integrator != MJPCX_INT_EULER) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family integrate with Euler only");
   int rc;
   if ((rc = reserve_rollout(c, N, H, 1)) != MJPCX_OK) return rc;
   const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu;
@@ -1371,6 +1386,7 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
 int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const double* states, const double* actions, double eps,
                           int centered, double* A, double* B, double* C, double* D) {
   if (c->precision != 64) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family are fp64 only");
+  if (c->wh.m.integrator != MJPCX_INT_EULER) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family integrate with Euler only");
   int rc;
   const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu, nr = c->nr;
   const size_t nc = 1 + 2 * (ndx + nu);
@@ -1558,6 +1574,181 @@ int mjpcx_backward_pass(mjpcx_ctx* c, int n, int m, int T, double mu, int reg_ty
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return MJPCX_OK;
+}
+
+}  // extern "C"
+
+// ===================================================================== multi-GPU exchange over RCCL
+namespace {
+// librccl.so.1 is resolved at run time: the library loads (and every single-GPU entry point works) without it
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+RcclApi* rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) { api.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
+#define MJPCX_SYM(field, sym)                                                              \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, #sym));                \
+    if (!api.field) api.error = std::string("RCCL symbol missing: ") + #sym;
+    MJPCX_SYM(GetUniqueId, ncclGetUniqueId) MJPCX_SYM(CommInitRank, ncclCommInitRank) MJPCX_SYM(CommDestroy, ncclCommDestroy)
+    MJPCX_SYM(AllGather, ncclAllGather) MJPCX_SYM(AllReduce, ncclAllReduce) MJPCX_SYM(Broadcast, ncclBroadcast)
+    MJPCX_SYM(GetErrorString, ncclGetErrorString)
+#undef MJPCX_SYM
+  });
+  return &api;
+}
+#define NCCLCHK(c, expr)                                                                                   \
+  do {                                                                                                     \
+    ncclResult_t r__ = (expr);                                                                             \
+    if (r__ != ncclSuccess) return fail(c, MJPCX_EDEVICE, std::string(#expr) + ": " + rccl()->GetErrorString(r__)); \
+  } while (0)
+
+// all-gather of `n` doubles per rank: host in -> host out [world][n]
+int comm_all_gather(mjpcx_ctx* c, const double* in, int n, std::vector<double>* out) {
+  RcclApi* R = rccl();
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->d_comm_send.reserve((size_t)n * 8));
+  HIPCHK(c, c->d_comm_recv.reserve((size_t)n * 8 * c->comm_world));
+  HIPCHK(c, hipMemcpyAsync(c->d_comm_send.p, in, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(c, R->AllGather(c->d_comm_send.p, c->d_comm_recv.p, (size_t)n, ncclFloat64, (ncclComm_t)c->comm, c->stream));
+  out->resize((size_t)n * c->comm_world);
+  HIPCHK(c, hipMemcpyAsync(out->data(), c->d_comm_recv.p, (size_t)n * 8 * c->comm_world, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mjpcx_comm_unique_id(void* id_out) {
+  if (!id_out) return MJPCX_EINVAL;
+  RcclApi* R = rccl();
+  if (!R->lib || !R->error.empty()) { g_create_error = R->error; return MJPCX_EUNSUPPORTED; }
+  static_assert(sizeof(ncclUniqueId) == MJPCX_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  if (R->GetUniqueId(&id) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return MJPCX_EDEVICE; }
+  std::memcpy(id_out, &id, sizeof id);
+  return MJPCX_OK;
+}
+
+int mjpcx_comm_init(mjpcx_ctx* c, const void* unique_id, int rank, int world) {
+  if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return fail(c, MJPCX_EINVAL, "bad communicator arguments");
+  RcclApi* R = rccl();
+  if (!R->lib || !R->error.empty()) return fail(c, MJPCX_EUNSUPPORTED, R->error);
+  if (c->comm) return fail(c, MJPCX_ESTATE, "the context already has a communicator");
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof id);
+  ncclComm_t comm = nullptr;
+  NCCLCHK(c, R->CommInitRank(&comm, world, id, rank));
+  c->comm = comm;
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return MJPCX_OK;
+}
+
+int mjpcx_comm_info(const mjpcx_ctx* c, int* rank, int* world) {
+  if (!c) return MJPCX_EINVAL;
+  if (rank) *rank = c->comm_rank;
+  if (world) *world = c->comm_world;
+  return MJPCX_OK;
+}
+
+int mjpcx_comm_destroy(mjpcx_ctx* c) {
+  if (!c) return MJPCX_EINVAL;
+  if (c->comm) {
+    (void)hipSetDevice(c->device);
+    (void)rccl()->CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+  }
+  c->comm_rank = 0;
+  c->comm_world = 1;
+  return MJPCX_OK;
+}
+
+int mjpcx_exchange_best(mjpcx_ctx* c, int32_t* index, double* best_return, double* nominal_return, double* spline_values, int n) {
+  if (!c || !index || !best_return || !nominal_return || (n > 0 && !spline_values) || n < 0) return fail(c, MJPCX_EINVAL, "null argument");
+  if (!c->comm) return c->comm_world == 1 ? MJPCX_OK : fail(c, MJPCX_ESTATE, "mjpcx_comm_init has not been called");  // no communicator: one rank
+  const double rec[3] = {*best_return, (double)*index, *nominal_return};
+  int rc;
+  if ((rc = comm_all_gather(c, rec, 3, &c->h_comm)) != MJPCX_OK) return rc;
+  int owner = 0;
+  auto key = [&](int r) { const double v = c->h_comm[3 * r]; return v != v ? (double)INFINITY : v; };
+  for (int r = 1; r < c->comm_world; r++)
+    if (key(r) < key(owner) || (key(r) == key(owner) && c->h_comm[3 * r + 1] < c->h_comm[3 * owner + 1])) owner = r;
+  *best_return = c->h_comm[3 * owner];
+  *index = (int32_t)c->h_comm[3 * owner + 1];
+  *nominal_return = c->h_comm[2];  // global candidate 0 lives on rank 0
+  if (n > 0) {
+    RcclApi* R = rccl();
+    HIPCHK(c, c->d_comm_send.reserve((size_t)n * 8));
+    if (c->comm_rank == owner) HIPCHK(c, hipMemcpyAsync(c->d_comm_send.p, spline_values, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, R->Broadcast(c->d_comm_send.p, c->d_comm_send.p, (size_t)n, ncclFloat64, owner, (ncclComm_t)c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(spline_values, c->d_comm_send.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return MJPCX_OK;
+}
+
+int mjpcx_merge_topk(mjpcx_ctx* c, int k, int64_t* index, double* total_return) {
+  if (!c || k < 1 || !index || !total_return) return fail(c, MJPCX_EINVAL, "null argument");
+  if (!c->comm) return c->comm_world == 1 ? MJPCX_OK : fail(c, MJPCX_ESTATE, "mjpcx_comm_init has not been called");
+  std::vector<double> mine(2 * (size_t)k);
+  for (int i = 0; i < k; i++) {
+    const bool used = index[i] >= 0;
+    mine[2 * i] = used ? total_return[i] : (double)INFINITY;
+    mine[2 * i + 1] = used ? (double)index[i] : 4503599627370496.0;  // 2^52: sorts after every real index
+  }
+  int rc;
+  if ((rc = comm_all_gather(c, mine.data(), 2 * k, &c->h_comm)) != MJPCX_OK) return rc;
+  const int total = k * c->comm_world;
+  std::vector<int> order(total);
+  for (int i = 0; i < total; i++) order[i] = i;
+  const std::vector<double>& all = c->h_comm;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    if (all[2 * a] != all[2 * b]) return all[2 * a] < all[2 * b];
+    return all[2 * a + 1] < all[2 * b + 1];
+  });
+  for (int i = 0; i < k; i++) {
+    const int o = order[i];
+    const bool used = all[2 * o + 1] < 4503599627370496.0;
+    index[i] = used ? (int64_t)all[2 * o + 1] : -1;
+    total_return[i] = used ? all[2 * o] : 1.0e300;
+  }
+  return MJPCX_OK;
+}
+
+int mjpcx_elite_allreduce(mjpcx_ctx* c, double* values, int n) {
+  if (!c || !values || n < 1) return fail(c, MJPCX_EINVAL, "null argument");
+  if (!c->comm) return c->comm_world == 1 ? MJPCX_OK : fail(c, MJPCX_ESTATE, "mjpcx_comm_init has not been called");
+  RcclApi* R = rccl();
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->d_comm_send.reserve((size_t)n * 8));
+  HIPCHK(c, hipMemcpyAsync(c->d_comm_send.p, values, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(c, R->AllReduce(c->d_comm_send.p, c->d_comm_send.p, (size_t)n, ncclFloat64, ncclSum, (ncclComm_t)c->comm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(values, c->d_comm_send.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MJPCX_OK;
+}
+
+int mjpcx_comm_barrier(mjpcx_ctx* c) {
+  if (!c) return MJPCX_EINVAL;
+  double one = 1.0;
+  return mjpcx_elite_allreduce(c, &one, 1);
 }
 
 }  // extern "C"

@@ -587,6 +587,61 @@ __device__ __forceinline__ void lane_euler(const MODEL& m, T (&qpos)[TP::NV], T 
   }
 }
 
+// mj_step's integrator after the step's mj_forward: mj_Euler, or mj_RungeKutta(m, d, 4) (MuJoCo engine_forward.c). RK4: stage 0 is
+// the forward pass just done (F_0 = (qvel, qacc)); stages 1..3 re-run mj_forward -- no sensor stage -- at X_0 + h A_i F_{i-1}
+// (the Butcher tableau has one non-zero per row: 1/2, 1/2, 1), and the step is X_0 + h sum_i B_i F_i with B = (1/6, 1/3, 1/3,
+// 1/6). Joint damping is explicit there. The three extra stages share ONE inlined copy of lane_forward (the loop is not
+// unrolled), so the kernels grow by one forward pass of code, not three.
+template <class TP, typename T, class MODEL, class TASKV>
+__device__ __forceinline__ void lane_integrate(const MODEL& m, const TASKV& tk, T (&qpos)[TP::NV], T (&qvel)[TP::NV],
+                                               const T (&ctrl)[TP::NU], const T (&qacc)[TP::NV], const T (&qfrc)[TP::NV],
+                                               const T (&qfrc_c)[TP::NV], const T (&M)[TP::NV][TP::NV],
+                                               const T (*xfrc)[6] = nullptr, T (*site_out)[3] = nullptr) {
+  constexpr int NV = TP::NV, NS = TP::NSITE;
+  if (m.integrator != 1) {
+    lane_euler<TP, T>(m, qpos, qvel, qacc, qfrc, qfrc_c, M);
+    return;
+  }
+  const T h = m.timestep;
+  T q0[NV], v0[NV], kv[NV], ka[NV], sv[NV], sa[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    q0[i] = qpos[i]; v0[i] = qvel[i];
+    kv[i] = qvel[i]; ka[i] = qacc[i];
+    sv[i] = kv[i] * T(1.0 / 6); sa[i] = ka[i] * T(1.0 / 6);
+  }
+#pragma unroll 1
+  for (int stage = 1; stage < 4; stage++) {
+    const T c = stage == 3 ? T(1) : T(0.5);
+    const T b = stage == 3 ? T(1.0 / 6) : T(1.0 / 3);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      qpos[i] = q0[i] + h * (c * kv[i]);
+      qvel[i] = v0[i] + h * (c * ka[i]);
+    }
+    T qacc2[NV], qfrc2[NV], qfrc_c2[NV], M2[NV][NV];
+    T site2[NS > 0 ? NS : 1][3];
+    lane_forward<TP, T>(m, tk, qpos, qvel, ctrl, qacc2, qfrc2, qfrc_c2, M2, site2, xfrc);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      kv[i] = qvel[i]; ka[i] = qacc2[i];
+      sv[i] += b * kv[i]; sa[i] += b * ka[i];
+    }
+    // data->site_xpos after mj_step is the LAST stage's: that is what Trajectory::Rollout copies into the trace (trajectory.cc:165)
+    if (site_out && stage == 3) {
+#pragma unroll
+      for (int k = 0; k < NS; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) site_out[k][c] = site2[k][c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    qvel[i] = v0[i] + h * sa[i];
+    qpos[i] = q0[i] + h * sv[i];
+  }
+}
+
 // one step's Trajectory row of this candidate -> [step][field][candidate] SoA (coalesced across the wave)
 template <class TP, class TK, typename T>
 __device__ __forceinline__ void lane_record(const RolloutArgs<T>& a, int t, int cand, const T (&qpos)[TP::NV],
@@ -611,6 +666,18 @@ __device__ __forceinline__ void lane_record(const RolloutArgs<T>& a, int t, int 
 #pragma unroll
     for (int c = 0; c < 3; c++) a.trace[((size_t)t * 3 * NTR + 3 * k + c) * N + cand] = site_xpos[TK::trace_site(k)][c];
   if (!bad) a.costs[base] = cost;
+}
+
+// the trace row of step t alone (RK4: re-recorded after the step, from the last stage's site positions)
+template <class TP, class TK, typename T>
+__device__ __forceinline__ void lane_record_trace(const RolloutArgs<T>& a, int t, int cand,
+                                                  const T (&site_xpos)[TP::NSITE > 0 ? TP::NSITE : 1][3]) {
+  constexpr int NTR = TK::NTRACE;
+  const size_t N = (size_t)a.N;
+#pragma unroll
+  for (int k = 0; k < NTR; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) a.trace[((size_t)t * 3 * NTR + 3 * k + c) * N + cand] = site_xpos[TK::trace_site(k)][c];
 }
 
 template <class TP, typename T>
@@ -858,7 +925,8 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
     if (last) break;
 
     // ================= mj_Euler (implicit joint damping) + advance
-    lane_euler<TP, T>(m, qpos, qvel, qacc, qfrc, qfrc_c, M);
+    lane_integrate<TP, T>(m, tk, qpos, qvel, ctrl, qacc, qfrc, qfrc_c, M, NOISY ? xfrc : nullptr, site_xpos);
+    if (m.integrator == 1 && live && !failed) lane_record_trace<TP, TK, T>(a, t, cand, site_xpos);
     time += h;
   }
 
@@ -901,10 +969,8 @@ __global__ __launch_bounds__(256) void cost_lane_kernel(const LaneModel<T> m_kar
   const T cost = lane_cost<TK, T>(tk, r);
 #pragma unroll
   for (int i = 0; i < NR; i++) a.residual[((size_t)t * NR + i) * N + cand] = r[i];
-#pragma unroll
-  for (int k = 0; k < NTR; k++)
-#pragma unroll
-    for (int c = 0; c < 3; c++) a.trace[((size_t)t * 3 * NTR + 3 * k + c) * N + cand] = site_xpos[TK::trace_site(k)][c];
+  // (RK4: the time loop recorded the trace of every integrated step from the last stage's site positions)
+  if (m.integrator != 1 || t == a.H - 1) lane_record_trace<TP, TK, T>(a, t, cand, site_xpos);
   if (!(fb && t == fb - 1)) a.costs[item] = cost;
 }
 

@@ -1342,6 +1342,34 @@ __device__ __forceinline__ void wf_forward(const MODEL& m, const TASK& tk, WaveD
   WSTAMP(11);
 }
 
+// ---- mj_integratePos: qpos advanced by h along the generalized velocity `vel` (one lane per joint; quaternions by the exponential map)
+template <class MODEL>
+__device__ __forceinline__ void w_integrate_pos(const MODEL& m, WaveData& d, const wreal* vel, wreal h, int lane) {
+  if (lane < m.njnt) {
+    const int j = lane;
+    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    const int jt = m.jnt_type[j];
+    if (jt == kJntFree) {
+      for (int k = 0; k < 3; k++) d.qpos[qa + k] += h * vel[da + k];
+      qa += 3; da += 3;
+    }
+    if (jt == kJntFree || jt == kJntBall) {
+      wreal ax[3] = {vel[da], vel[da + 1], vel[da + 2]};
+      const wreal n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      if (n < kMinVal) { ax[0] = 1; ax[1] = ax[2] = 0; }
+      else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
+      wreal qrot[4], q[4];
+      aa2quat(qrot, ax, h * n);
+      for (int k = 0; k < 4; k++) q[k] = d.qpos[qa + k];
+      q_norm(q);
+      q_mul(q, q, qrot);
+      for (int k = 0; k < 4; k++) d.qpos[qa + k] = q[k];
+    } else {
+      d.qpos[qa] += h * vel[da];
+    }
+  }
+}
+
 // ---- o_euler: implicit joint damping, then integrate positions
 template <int NMAX, class MODEL>
 __device__ __forceinline__ void wf_euler(const MODEL& m, WaveData& d, int lane, wreal& time) {
@@ -1360,29 +1388,7 @@ __device__ __forceinline__ void wf_euler(const MODEL& m, WaveData& d, int lane, 
   }
   if (lane < nv) d.qvel[lane] += h * d.tmpv[lane];
   WSYNC();
-  if (lane < m.njnt) {
-    const int j = lane;
-    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-    const int jt = m.jnt_type[j];
-    if (jt == kJntFree) {
-      for (int k = 0; k < 3; k++) d.qpos[qa + k] += h * d.qvel[da + k];
-      qa += 3; da += 3;
-    }
-    if (jt == kJntFree || jt == kJntBall) {
-      wreal ax[3] = {d.qvel[da], d.qvel[da + 1], d.qvel[da + 2]};
-      const wreal n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-      if (n < kMinVal) { ax[0] = 1; ax[1] = ax[2] = 0; }
-      else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
-      wreal qrot[4], q[4];
-      aa2quat(qrot, ax, h * n);
-      for (int k = 0; k < 4; k++) q[k] = d.qpos[qa + k];
-      q_norm(q);
-      q_mul(q, q, qrot);
-      for (int k = 0; k < 4; k++) d.qpos[qa + k] = q[k];
-    } else {
-      d.qpos[qa] += h * d.qvel[da];
-    }
-  }
+  w_integrate_pos(m, d, d.qvel, h, lane);
   time += h;
   WSYNC();
 }

@@ -25,7 +25,7 @@ constexpr int kWaveMaxEfc = 64;   // constraint rows kept per step
 template <typename T>
 struct WaveModelT {
   int nq, nv, nu, nbody, njnt, nsite, nmocap, ngeom, nkey;
-  int cone, disableflags, solver_iterations, any_damping;
+  int cone, disableflags, solver_iterations, any_damping, integrator;
   double timestep, gravity[3], solver_tolerance, meaninertia, impratio;
   const int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_mocapid;
   const T *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0, *body_subtreemass;
@@ -161,7 +161,7 @@ struct WaveHost {
     };
     std::memset(&m, 0, sizeof m);
     m.nq = src->nq; m.nv = src->nv; m.nu = src->nu; m.nbody = src->nbody; m.njnt = src->njnt; m.nsite = src->nsite;
-    m.nmocap = src->nmocap; m.ngeom = src->ngeom; m.nkey = src->nkey; m.cone = src->cone; m.disableflags = src->disableflags;
+    m.nmocap = src->nmocap; m.ngeom = src->ngeom; m.nkey = src->nkey; m.cone = src->cone; m.disableflags = src->disableflags; m.integrator = src->integrator;
     m.solver_iterations = src->solver_iterations; m.timestep = src->timestep;
     for (int k = 0; k < 3; k++) m.gravity[k] = src->gravity[k];
     m.solver_tolerance = src->solver_tolerance; m.meaninertia = src->meaninertia; m.impratio = src->impratio;

@@ -28,8 +28,11 @@ class RankGroup:
         self.dist.barrier()
 
     def owner_of(self, global_idx, num_trajectory):
-        n = num_trajectory // self.world
-        return min(global_idx // n, self.world - 1) if n > 0 else self.world - 1
+        """rank whose contiguous candidate range holds `global_idx` (the first N % world ranks hold one more candidate)"""
+        q, r = divmod(num_trajectory, self.world)
+        if global_idx >= num_trajectory:
+            return self.world - 1
+        return global_idx // (q + 1) if global_idx < r * (q + 1) else r + (global_idx - r * (q + 1)) // max(q, 1)
 
     def merge_topk(self, idx, ret, k):
         """Global k best from each rank's local k best; ties broken by global index."""

@@ -101,9 +101,13 @@ void GpuCrossEntropyPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
   const int P = resampled_policy.num_spline_points, nu = model->nu, np = P * nu;
 
   // ---- Rollouts (:388-443): N noised candidates + the nominal as global candidate N (on the last rank)
-  n_local_ = num_trajectory / world_;
-  offset_ = rank_ * n_local_;
-  if (rank_ == world_ - 1) n_local_ = num_trajectory - offset_ + 1;
+  if (world_ > num_trajectory) throw gpu::Error(MJPCX_EINVAL, "more ranks than candidates: every rank needs at least one rollout");
+  {
+    const int q = num_trajectory / world_, r = num_trajectory % world_;  // contiguous ranges, the first (N % world) ranks take one more
+    n_local_ = q + (rank_ < r ? 1 : 0);
+    offset_ = rank_ * q + std::min(rank_, r);
+    if (rank_ == world_ - 1) n_local_ += 1;  // the last rank also rolls out the nominal (global candidate N)
+  }
   int explore_count = 0;  // candidates i < N * explore_fraction use std_initial instead of the fitted variance (:367-371)
   for (int i = 0; i < num_trajectory; i++) explore_count += i < num_trajectory * explore_fraction_;
   mjpcx_noise_spec ns{};
@@ -131,8 +135,8 @@ void GpuCrossEntropyPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
   ret.resize(n_elite + 1, 1.0e300);
   for (int i = 0; i < k; i++) idx[i] = (std::int64_t)idx32[i] + offset_;
   if (world_ > 1) {
-    if (!merge_ || !sum_) throw gpu::Error(MJPCX_EINVAL, "sharded planner without exchange functions");
-    if (merge_(user_, n_elite + 1, idx.data(), ret.data()) != 0) throw gpu::Error(MJPCX_EDEVICE, "top-k exchange failed");
+    if (merge_) { if (merge_(user_, n_elite + 1, idx.data(), ret.data()) != 0) throw gpu::Error(MJPCX_EDEVICE, "top-k exchange failed"); }
+    else ctx_->Check(mjpcx_merge_topk(ctx_->handle(), n_elite + 1, idx.data(), ret.data()));  // RCCL inside the library
   }
   trajectory_order.clear();
   double best_return = 0;
@@ -151,12 +155,17 @@ void GpuCrossEntropyPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
     if (g >= offset_ && g < offset_ + n_local_) mine.push_back(g - offset_);
   std::vector<double> sums(np + 1, 0.0), mean(np), sq(np, 0.0);
   ctx_->Check(mjpcx_elite_moments(ctx_->handle(), (int)mine.size(), mine.data(), nullptr, sums.data(), &sums[np]));
-  if (world_ > 1 && sum_(user_, sums.data(), np + 1) != 0) throw gpu::Error(MJPCX_EDEVICE, "moment exchange failed");
+  auto all_sum = [&](double* v, int n) {
+    if (world_ <= 1) return;
+    if (sum_) { if (sum_(user_, v, n) != 0) throw gpu::Error(MJPCX_EDEVICE, "moment exchange failed"); }
+    else ctx_->Check(mjpcx_elite_allreduce(ctx_->handle(), v, n));
+  };
+  all_sum(sums.data(), np + 1);
   for (int j = 0; j < np; j++) mean[j] = sums[j] / n_elite;
   const double avg_return = sums[np] / n_elite;
   double unused = 0;
   ctx_->Check(mjpcx_elite_moments(ctx_->handle(), (int)mine.size(), mine.data(), mean.data(), sq.data(), &unused));
-  if (world_ > 1 && sum_(user_, sq.data(), np) != 0) throw gpu::Error(MJPCX_EDEVICE, "moment exchange failed");
+  all_sum(sq.data(), np);
   std::fill(variance.begin(), variance.end(), 0.0);
   for (int j = 0; j < np; j++) variance[j] = sq[j] / (n_elite - 1);  // n_elite == 1: inf/nan, as the reference (:267)
   std::copy(mean.begin(), mean.end(), parameters_scratch.begin());

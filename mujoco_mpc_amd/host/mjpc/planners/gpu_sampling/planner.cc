@@ -106,10 +106,11 @@ void GpuSamplingPlanner::SetSharding(int rank, int world, ExchangeFn exchange, v
 
 // the device fan-out: noise + N rollouts + returns, one launch (sampling/planner.cc:355-393)
 void GpuSamplingPlanner::Rollouts(int num_trajectory, int horizon) {
-  // this rank's slice of the global batch
-  int n_local = num_trajectory / world_;
-  offset_ = rank_ * n_local;
-  if (rank_ == world_ - 1) n_local = num_trajectory - offset_;
+  // this rank's slice of the global batch: contiguous ranges, the first (num_trajectory % world) ranks take one more
+  if (world_ > num_trajectory) throw gpu::Error(MJPCX_EINVAL, "more ranks than candidates: every rank needs at least one rollout");
+  const int q = num_trajectory / world_, r = num_trajectory % world_;
+  const int n_local = q + (rank_ < r ? 1 : 0);
+  offset_ = rank_ * q + std::min(rank_, r);
   mjpcx_noise_spec ns{};
   ns.seed = seed_;
   ns.iteration = iteration;
@@ -128,6 +129,8 @@ void GpuSamplingPlanner::Rollouts(int num_trajectory, int horizon) {
 }
 
 int GpuSamplingPlanner::OptimizePolicyCandidates(int ncandidates, int horizon, ThreadPool& pool) {
+  // the ranked interface (RobustPlanner's delegate) ranks one process's candidates: a sharded batch would rank each shard on its own
+  if (world_ > 1) throw gpu::Error(MJPCX_EUNSUPPORTED, "OptimizePolicyCandidates is not sharded: run the robust planner's delegate on one rank");
   UpdateNominalPolicy(horizon);
   const int num_trajectory = num_trajectory_;
   ncandidates = std::min(ncandidates, num_trajectory);
@@ -156,13 +159,16 @@ void GpuSamplingPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
                          values.data()));
   index += offset_;  // global candidate index
   if (world_ > 1) {
-    if (!exchange_) throw gpu::Error(MJPCX_EINVAL, "sharded planner without an exchange function");
-    double record[3] = {best_return, (double)index, nominal_return};
-    if (exchange_(exchange_user_, record, values.data(), (int)values.size()) != 0)
-      throw gpu::Error(MJPCX_EDEVICE, "candidate exchange failed");
-    best_return = record[0];
-    index = (int32_t)record[1];
-    nominal_return = record[2];
+    if (exchange_) {  // a transport lent by the caller (gloo in the CPU-side tests)
+      double record[3] = {best_return, (double)index, nominal_return};
+      if (exchange_(exchange_user_, record, values.data(), (int)values.size()) != 0)
+        throw gpu::Error(MJPCX_EDEVICE, "candidate exchange failed");
+      best_return = record[0];
+      index = (int32_t)record[1];
+      nominal_return = record[2];
+    } else {          // RCCL inside the library (mjpcx_comm_init on this planner's context)
+      ctx_->Check(mjpcx_exchange_best(ctx_->handle(), &index, &best_return, &nominal_return, values.data(), (int)values.size()));
+    }
   }
   trajectory_order.assign(1, index);
   scores_.assign(1, best_return);

@@ -122,7 +122,7 @@ void ModelStorage::Bind() {
     auto& wt = ints_["wrap_type"]; wt.assign(nw ? nw : 1, mjWRAP_JOINT);
     m.wrap_type = wt.data();
   }
-  BR(key_mpos, (size_t)m.nkey * 3 * m.nmocap);
+  BR(key_mpos, (size_t)m.nkey * 3 * m.nmocap); BR(key_ctrl, (size_t)m.nkey * nu);
   BI(text_adr, m.ntext); BI(text_size, m.ntext); BI(name_textadr, m.ntext);
   m.text_data = reinterpret_cast<char*>(B("text_data", 0));
   m.names = reinterpret_cast<char*>(B("names", 1));

@@ -60,7 +60,7 @@ struct mjModel {
   mjtNum* sensor_user;
   int *numeric_adr, *numeric_size;
   mjtNum* numeric_data;
-  mjtNum *key_qpos, *key_qvel, *key_mpos;
+  mjtNum *key_qpos, *key_qvel, *key_mpos, *key_ctrl;
   int *tendon_adr, *tendon_num, *wrap_type, *wrap_objid, *exclude_signature;
   mjtByte* tendon_limited;
   mjtNum *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
@@ -88,8 +88,23 @@ inline mjData* mj_makeData(const mjModel* m) {
   for (int i = 0; i < m->nsensor; i++) nsensordata = m->sensor_adr[i] + m->sensor_dim[i] > nsensordata ? m->sensor_adr[i] + m->sensor_dim[i] : nsensordata;
   d->sensordata = arr(nsensordata);
   if (m->qpos0) std::memcpy(d->qpos, m->qpos0, sizeof(mjtNum) * m->nq);
+  for (int b = 0; b < m->nbody; b++) {  // mj_resetData: mocap bodies start at their model pose
+    const int id = m->body_mocapid ? m->body_mocapid[b] : -1;
+    if (id < 0) continue;
+    std::memcpy(d->mocap_pos + 3 * id, m->body_pos + 3 * b, sizeof(mjtNum) * 3);
+    std::memcpy(d->mocap_quat + 4 * id, m->body_quat + 4 * b, sizeof(mjtNum) * 4);
+  }
   d->xpos = d->xquat = d->xmat = d->xipos = d->site_xpos = d->subtree_com = d->subtree_linvel = nullptr;
   return d;
+}
+// mj_resetDataKeyframe for the fields above: time 0, qpos / qvel / ctrl / mocap_pos of the key
+inline void mj_resetDataKeyframe(const mjModel* m, mjData* d, int key) {
+  if (key < 0 || key >= m->nkey) return;
+  d->time = 0;
+  std::memcpy(d->qpos, m->key_qpos + (size_t)key * m->nq, sizeof(mjtNum) * m->nq);
+  std::memcpy(d->qvel, m->key_qvel + (size_t)key * m->nv, sizeof(mjtNum) * m->nv);
+  if (m->key_ctrl) std::memcpy(d->ctrl, m->key_ctrl + (size_t)key * m->nu, sizeof(mjtNum) * m->nu);
+  if (m->nmocap && m->key_mpos) std::memcpy(d->mocap_pos, m->key_mpos + (size_t)key * 3 * m->nmocap, sizeof(mjtNum) * 3 * m->nmocap);
 }
 inline void mj_deleteData(mjData* d) {
   if (!d) return;

@@ -100,6 +100,25 @@ int mjpc_planner_set_sharding_ce(void* h, int rank, int world, mjpc::GpuCrossEnt
                                  mjpc::GpuCrossEntropyPlanner::SumFn sum, void* user) {
   GUARD(h, { if (!H->ce) throw std::runtime_error("not a cross-entropy planner"); H->ce->SetSharding(rank, world, merge, sum, user); });
 }
+// RCCL inside libmjpcx.so (include/mjpcx.h, mjpcx_comm_*): rank 0 makes the id, every rank joins with it; the planner then shards
+// its candidates by rank and exchanges through the library (no transport callback)
+int mjpc_comm_unique_id(void* id_out) { return mjpcx_comm_unique_id(id_out); }
+int mjpc_planner_comm_init(void* h, const void* unique_id, int rank, int world) {
+  GUARD(h, {
+    mjpc::gpu::Context* ctx = H->ps ? H->ps->context() : (H->ce ? H->ce->context() : nullptr);
+    if (!ctx) throw std::runtime_error("this planner kind is not sharded (replicas only)");
+    ctx->Check(mjpcx_comm_init(ctx->handle(), unique_id, rank, world));
+    if (H->ps) H->ps->SetSharding(rank, world, nullptr, nullptr);
+    else H->ce->SetSharding(rank, world, nullptr, nullptr, nullptr);
+  });
+}
+int mjpc_planner_comm_barrier(void* h) {
+  GUARD(h, {
+    mjpc::gpu::Context* ctx = H->ps ? H->ps->context() : (H->ce ? H->ce->context() : nullptr);
+    if (!ctx) throw std::runtime_error("this planner kind has no communicator");
+    ctx->Check(mjpcx_comm_barrier(ctx->handle()));
+  });
+}
 int mjpc_planner_reset(void* h, int horizon) { GUARD(h, H->planner->Reset(horizon)); }
 int mjpc_planner_set_state(void* h, const double* qpos, const double* qvel, const double* mocap_pos,
                            const double* mocap_quat, double time) {

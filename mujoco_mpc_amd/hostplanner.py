@@ -59,6 +59,9 @@ def lib():
         L.mjpc_planner_last_error.restype = C.c_char_p
         L.mjpc_planner_last_error.argtypes = [vp]
         L.mjpc_planner_set_sharding.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
+        L.mjpc_comm_unique_id.argtypes = [C.c_void_p]
+        L.mjpc_planner_comm_init.argtypes = [vp, C.c_void_p, C.c_int, C.c_int]
+        L.mjpc_planner_comm_barrier.argtypes = [vp]
         L.mjpc_planner_reset.argtypes = [vp, C.c_int]
         L.mjpc_planner_set_state.argtypes = [vp, c_f64p, c_f64p, c_f64p, c_f64p, C.c_double]
         L.mjpc_planner_optimize.argtypes = [vp, C.c_int]
@@ -76,6 +79,15 @@ def lib():
     return _LIB
 
 
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 calls this and ships the bytes to the other ranks)"""
+    buf = C.create_string_buffer(128)
+    rc = lib().mjpc_comm_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError(f"mjpcx_comm_unique_id failed ({rc}): " + capi.lib().mjpcx_create_error().decode())
+    return buf.raw
+
+
 def host_gaussian_pair(seed, cand, pair, iteration):
     """the C++ host's normal generator (must equal the device / oracle stream)"""
     z = np.zeros(2)
@@ -84,7 +96,9 @@ def host_gaussian_pair(seed, cand, pair, iteration):
 
 
 class HostPlanner:
-    def __init__(self, task, device=0, precision=64, seed=0, num_trajectory=0, group=None, kind="sampling"):
+    def __init__(self, task, device=0, precision=64, seed=0, num_trajectory=0, group=None, kind="sampling", native_comm=None):
+        """group: a RankGroup (torch.distributed) lending the transport of the per-step exchange -- the CPU-side gloo tests;
+        native_comm = (unique_id bytes, rank, world): RCCL inside libmjpcx.so instead (mjpcx_comm_init), no Python on the path"""
         self.task = task
         self.kind = kind
         self.nu = task.model.nu
@@ -96,6 +110,11 @@ class HostPlanner:
             raise RuntimeError(lib().mjpc_planner_last_error(None).decode())
         self.group = group
         self._cb = None
+        if native_comm is not None:
+            uid, rank, world = native_comm
+            buf = C.create_string_buffer(bytes(uid), 128)
+            self._chk(lib().mjpc_planner_comm_init(self.h, buf, int(rank), int(world)))
+            self.group = group = None
         if group is not None and group.world > 1 and kind == "cross_entropy":
             def merge(user, k, index, ret):
                 try:
@@ -158,6 +177,9 @@ class HostPlanner:
             self.close()
         except Exception:
             pass
+
+    def comm_barrier(self):
+        self._chk(lib().mjpc_planner_comm_barrier(self.h))
 
     def reset(self, horizon):
         self._chk(lib().mjpc_planner_reset(self.h, horizon))

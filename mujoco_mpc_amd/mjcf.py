@@ -653,8 +653,15 @@ class _Compiler:
                               if keyframes else np.zeros((0, nq)))
         arrays["key_qvel"] = (np.array([k["qvel"] for k in keyframes.values()], float).reshape(len(keyframes), nv)
                               if keyframes else np.zeros((0, nv)))
-        arrays["key_mpos"] = (np.array([k.get("mpos", np.zeros(3 * nmocap)) for k in keyframes.values()], float).reshape(len(keyframes), 3 * nmocap)
+        # a key without mpos keeps the mocap bodies where the model puts them (mj_resetDataKeyframe after mj_resetData)
+        mpos0 = np.zeros(3 * nmocap)
+        for i in range(nb):
+            if body_mocapid[i] >= 0:
+                mpos0[3 * body_mocapid[i]:3 * body_mocapid[i] + 3] = self.bodies[i]["pos"]
+        arrays["key_mpos"] = (np.array([k.get("mpos", mpos0) for k in keyframes.values()], float).reshape(len(keyframes), 3 * nmocap)
                               if keyframes and nmocap else np.zeros((0, 3 * nmocap)))
+        arrays["key_ctrl"] = (np.array([k["ctrl"] for k in keyframes.values()], float).reshape(len(keyframes), nu)
+                              if keyframes else np.zeros((0, nu)))
         names = dict(body=[b["name"] for b in self.bodies], joint=joint_names, geom=self.geom_names,
                      key=list(keyframes.keys()), tendon=tendon_names,
                      site=[s["name"] for s in self.sites], actuator=act_names,
@@ -817,6 +824,7 @@ def attach_keyframes(fm: FlatModel, names, qpos, qvel, mpos):
     fm.arrays["key_qpos"] = np.asarray(qpos, float).reshape(n, fm.nq)
     fm.arrays["key_qvel"] = np.asarray(qvel, float).reshape(n, fm.nv)
     fm.arrays["key_mpos"] = np.asarray(mpos, float).reshape(n, 3 * fm.nmocap)
+    fm.arrays["key_ctrl"] = np.zeros((n, fm.nu))
     fm.names["key"] = list(names)
     fm.keyframes.clear()
     for i, k in enumerate(names):
@@ -909,6 +917,7 @@ def save_blob(fm: FlatModel, path: str):
         nadr.append(len(ndata)); nsize.append(len(v)); ndata += list(v)
     put_i("numeric_adr", nadr); put_i("numeric_size", nsize); put_r("numeric_data", ndata)
     put_r("key_qpos", a["key_qpos"]); put_r("key_qvel", a["key_qvel"]); put_r("key_mpos", a["key_mpos"])
+    put_r("key_ctrl", a.get("key_ctrl", np.zeros((a["key_qpos"].shape[0] if hasattr(a["key_qpos"], "shape") else 0, sc["nu"]))))
     put_i("tendon_sizes", [sc.get("ntendon", 0), sc.get("nwrap", 0), sc.get("nexclude", 0)])
     for k in ("tendon_adr", "tendon_num", "tendon_limited", "wrap_objid", "exclude_signature", "body_weldid"):
         put_i(k, a[k])

@@ -216,8 +216,11 @@ class GpuSamplingPlanner:
         plan = self.policy.plan
         rank, world = (self.group.rank, self.group.world) if self.group else (0, 1)
         # candidates [rank*n, (rank+1)*n) of the global batch; candidate 0 is the un-noised nominal
-        n_local = num_trajectory // world
-        offset = rank * n_local
+        if world > num_trajectory:
+            raise ValueError("more ranks than candidates: every rank needs at least one rollout")
+        q, r = divmod(num_trajectory, world)   # contiguous ranges, the first (N % world) ranks take one more
+        n_local = q + (1 if rank < r else 0)
+        offset = rank * q + min(rank, r)
         if rank == world - 1:
             n_local = num_trajectory - offset
         ns = capi.make_noise_spec(seed=self.seed, iteration=self.iteration, mode=capi.NOISE_SAMPLING,
@@ -438,8 +441,11 @@ class GpuCrossEntropyPlanner:
         np_ = P * nu
         # ---- Rollouts, planner.cc:388-443: N noised candidates + the nominal as global candidate N
         rank, world = (self.group.rank, self.group.world) if self.group else (0, 1)
-        n_local = num_trajectory // world
-        offset = rank * n_local
+        if world > num_trajectory:
+            raise ValueError("more ranks than candidates: every rank needs at least one rollout")
+        q, r = divmod(num_trajectory, world)   # contiguous ranges, the first (N % world) ranks take one more
+        n_local = q + (1 if rank < r else 0)
+        offset = rank * q + min(rank, r)
         if rank == world - 1:
             n_local = num_trajectory - offset + 1          # the last rank also rolls out the nominal
         explore_count = int(np.sum(np.arange(num_trajectory) < num_trajectory * self.explore_fraction_))

@@ -83,6 +83,9 @@ int odata_warning(const OData* d);  /* !=0: BADQPOS/BADQVEL/BADQACC/BADCTRL seen
  * "qfrc_passive","qfrc_actuator","qfrc_constraint","actuator_force","time",
  * "efc_force","nefc","energy"}; returns count written (<= cap), -1 unknown. */
 int odata_get(const OData* d, const char* name, double* out, int cap);
+/* tests only: the dual of the constraint problem of the last o_forward by projected Gauss-Seidel (contact.inc); qacc_out[nv],
+ * force_out[nefc] (may be NULL); returns the sweeps taken */
+int o_solve_pgs(OData* d, int max_sweeps, double tol, double* qacc_out, double* force_out);
 
 /* residual dispatch (the ResidualFn::Residual overrides) */
 void oresidual(const mjpcx_task* task, const OData* d, double* residual);

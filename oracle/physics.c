@@ -59,6 +59,7 @@ struct OData {
   double efc_pos[OMAXEFC], efc_margin[OMAXEFC], efc_R[OMAXEFC], efc_aref[OMAXEFC];
   double efc_b[OMAXEFC], efc_force[OMAXEFC];
   double *scratch_minvjt, *scratch_qacc, *scratch_A, *scratch_AR; /* preallocated work arrays */
+  double* rk_scratch; /* mj_RungeKutta: X0 (nq + nv), F (4 x 2 nv), dX (2 nv) */
   /* contacts / friction loss / Newton solver (contact.inc) */
   int full; /* 1: constraint rows beyond joint limits can occur -> Newton path */
   int ngeom, ncon, solver_iter;
@@ -186,7 +187,7 @@ OData* odata_new(const mjpcx_model* m) {
   for (int j = 0; j < m->njnt; j++)
     if (m->jnt_limited[j] && (m->jnt_type[j] == MJPCX_JNT_BALL || m->jnt_type[j] == MJPCX_JNT_FREE))
       return NULL;
-  if (m->integrator != MJPCX_INT_EULER || m->na != 0) return NULL;
+  if ((m->integrator != MJPCX_INT_EULER && m->integrator != MJPCX_INT_RK4) || m->na != 0) return NULL;
 
   OData* d = (OData*)calloc(1, sizeof(OData));
   d->m = m;
@@ -210,6 +211,7 @@ OData* odata_new(const mjpcx_model* m) {
   d->efc_J = dalloc(OMAXEFC * nv);
   d->scratch_minvjt = dalloc(OMAXEFC * nv); d->scratch_qacc = dalloc(nv); d->scratch_A = dalloc(2 * nv * nv);
   d->scratch_AR = dalloc((2 * nj + 1) * (2 * nj + 1));
+  d->rk_scratch = dalloc(nq + nv + 10 * nv);
   /* geoms and the Newton solver's work space */
   d->ngeom = m->ngeom;
   d->geom_xpos = dalloc(3 * m->ngeom); d->geom_xmat = dalloc(9 * m->ngeom);
@@ -249,7 +251,7 @@ void odata_free(OData* d) {
                   &d->crb, &d->cdof, &d->cdof_dot, &d->cvel, &d->cacc, &d->cfrc, &d->M, &d->L,
                   &d->qfrc_passive, &d->qfrc_bias, &d->qfrc_actuator, &d->qfrc_smooth,
                   &d->qacc_smooth, &d->qfrc_constraint, &d->qacc, &d->actuator_force, &d->efc_J,
-                  &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A, &d->scratch_AR, &d->geom_xpos, &d->geom_xmat, &d->scratch_jac,
+                  &d->scratch_minvjt, &d->scratch_qacc, &d->scratch_A, &d->scratch_AR, &d->rk_scratch, &d->geom_xpos, &d->geom_xmat, &d->scratch_jac,
                   &d->nw_jar, &d->nw_jv, &d->nw_grad, &d->nw_search, &d->nw_Ma, &d->nw_H, &d->nw_L, &d->qacc_warmstart,
                   &d->xfrc_applied};
   for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
@@ -722,6 +724,71 @@ void o_forward(OData* d) {
   if (d->full) o_constraint_newton(d); else o_constraint(d);
 }
 
+/* mj_integratePos: qpos advanced by h along the velocity `vel` (quaternions by the exponential map) */
+static void integrate_pos(const mjpcx_model* m, double* qpos, const double* vel, double h) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    switch (m->jnt_type[j]) {
+      case MJPCX_JNT_FREE:
+        for (int k = 0; k < 3; k++) qpos[qa + k] += h * vel[da + k];
+        qa += 3; da += 3;
+        /* fallthrough */
+      case MJPCX_JNT_BALL: {
+        double ax[3] = {vel[da], vel[da + 1], vel[da + 2]};
+        double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        if (n < OMINVAL) { ax[0] = 1; ax[1] = ax[2] = 0; }
+        else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
+        double qrot[4];
+        axis_angle2quat(qrot, ax, h * n);
+        normalize4(qpos + qa);
+        mul_quat(qpos + qa, qpos + qa, qrot);
+        break;
+      }
+      default:
+        qpos[qa] += h * vel[da];
+    }
+  }
+}
+
+/* mj_RungeKutta(m, d, 4) (MuJoCo engine_forward.c): the classical fourth-order scheme on (qpos, qvel). Stage 0 is the mj_forward
+ * mj_step has just run (with the sensor stage); stages 1..3 re-run mj_forward without sensors at the intermediate states
+ * X_i = X_0 + h sum_j A_ij F_j (positions through mj_integratePos), F_j = (qvel_j, qacc_j); the step is then taken from X_0 with
+ * the weights B. No implicit joint damping (an Euler-only feature). The solver's warm start stays the previous step's qacc for all
+ * four stages and is replaced, in mj_advance, by the last stage's qacc. */
+static void o_rk4(OData* d) {
+  const mjpcx_model* m = d->m;
+  const int nq = m->nq, nv = m->nv;
+  const double h = m->timestep, t0 = d->time;
+  static const double A[3][3] = {{0.5, 0, 0}, {0, 0.5, 0}, {0, 0, 1.0}}, B[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6}, C[3] = {0.5, 0.5, 1.0};
+  double* X0 = d->rk_scratch;             /* nq + nv */
+  double* F = X0 + nq + nv;               /* 4 x (nv + nv): velocity, acceleration */
+  double* dX = F + 8 * nv;                /* nv + nv */
+  memcpy(X0, d->qpos, sizeof(double) * nq);
+  memcpy(X0 + nq, d->qvel, sizeof(double) * nv);
+  memcpy(F, d->qvel, sizeof(double) * nv);
+  memcpy(F + nv, d->qacc, sizeof(double) * nv);
+  for (int i = 1; i < 4; i++) {
+    for (int k = 0; k < 2 * nv; k++) { double s = 0; for (int j = 0; j < i; j++) s += A[i - 1][j] * F[j * 2 * nv + k]; dX[k] = s; }
+    memcpy(d->qpos, X0, sizeof(double) * nq);
+    integrate_pos(m, d->qpos, dX, h);
+    for (int k = 0; k < nv; k++) d->qvel[k] = X0[nq + k] + h * dX[nv + k];
+    d->time = t0 + C[i - 1] * h;
+    o_forward(d); /* mj_forwardSkip(m, d, mjSTAGE_NONE, 1): no sensor stage */
+    memcpy(F + i * 2 * nv, d->qvel, sizeof(double) * nv);
+    memcpy(F + i * 2 * nv + nv, d->qacc, sizeof(double) * nv);
+  }
+  for (int k = 0; k < 2 * nv; k++) { double s = 0; for (int j = 0; j < 4; j++) s += B[j] * F[j * 2 * nv + k]; dX[k] = s; }
+  memcpy(d->qpos, X0, sizeof(double) * nq);
+  memcpy(d->qvel, X0 + nq, sizeof(double) * nv);
+  d->time = t0;
+  /* mj_advance(m, d, act_dot, qacc = dX acceleration, qvel = dX velocity) */
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  d->have_warm = 1;
+  for (int k = 0; k < nv; k++) d->qvel[k] += h * dX[nv + k];
+  integrate_pos(m, d->qpos, dX, h);
+  d->time += h;
+}
+
 /* mj_Euler with implicit joint damping, then mj_advance */
 static void o_euler(OData* d) {
   const mjpcx_model* m = d->m;
@@ -743,28 +810,7 @@ static void o_euler(OData* d) {
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv); /* mj_advance: save for the next step's solver */
   d->have_warm = 1;
   for (int i = 0; i < nv; i++) d->qvel[i] += h * qacc[i];
-  for (int j = 0; j < m->njnt; j++) { /* mj_integratePos */
-    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
-    switch (m->jnt_type[j]) {
-      case MJPCX_JNT_FREE:
-        for (int k = 0; k < 3; k++) d->qpos[qa + k] += h * d->qvel[da + k];
-        qa += 3; da += 3;
-        /* fallthrough */
-      case MJPCX_JNT_BALL: {
-        double ax[3] = {d->qvel[da], d->qvel[da + 1], d->qvel[da + 2]};
-        double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-        if (n < OMINVAL) { ax[0] = 1; ax[1] = ax[2] = 0; }
-        else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
-        double qrot[4];
-        axis_angle2quat(qrot, ax, h * n);
-        normalize4(d->qpos + qa);
-        mul_quat(d->qpos + qa, d->qpos + qa, qrot);
-        break;
-      }
-      default:
-        d->qpos[qa] += h * d->qvel[da];
-    }
-  }
+  integrate_pos(m, d->qpos, d->qvel, h);
   d->time += h;
 }
 
@@ -779,7 +825,7 @@ void o_step_task(OData* d, const mjpcx_task* task, double* r) {
   for (int i = 0; i < m->nv; i++) if (is_bad(d->qvel[i])) { d->warning |= 2; break; }
   o_forward_task(d, task, r);
   for (int i = 0; i < m->nv; i++) if (is_bad(d->qacc[i])) { d->warning |= 4; break; }
-  o_euler(d);
+  if (m->integrator == MJPCX_INT_RK4) o_rk4(d); else o_euler(d);
 }
 void o_step(OData* d) { o_step_task(d, NULL, NULL); }
 const double* odata_site_xpos(const OData* d) { return d->site_xpos; }
@@ -861,8 +907,18 @@ int odata_get(const OData* d, const char* name, double* out, int cap) {
   F("cvel", d->cvel, 6 * nb); F("cdof", d->cdof, 6 * nv);
   F("geom_xpos", d->geom_xpos, 3 * m->ngeom); F("geom_xmat", d->geom_xmat, 9 * m->ngeom);
   F("efc_J", d->efc_J, d->nefc * nv); F("efc_aref", d->efc_aref, d->nefc); F("efc_R", d->efc_R, d->nefc);
-  F("efc_pos", d->efc_pos, d->nefc);
+  F("efc_pos", d->efc_pos, d->nefc); F("efc_floss", d->efc_floss, d->nefc);
 #undef F
+  if (!strcmp(name, "efc_type") || !strcmp(name, "efc_id")) { /* row kind (contact.inc EFC_*), and its joint / dof / tendon / contact index */
+    int n = 0;
+    for (int r = 0; r < d->nefc && n < cap; r++) out[n++] = name[4] == 't' ? d->efc_type[r] : d->efc_id[r];
+    return n;
+  }
+  if (!strcmp(name, "contact_friction")) { /* per contact: regularised mu, friction[5] */
+    int n = 0;
+    for (int i = 0; i < d->ncon && n + 6 <= cap; i++) { out[n++] = d->con[i].mu; for (int k = 0; k < 5; k++) out[n++] = d->con[i].friction[k]; }
+    return n;
+  }
   if (!strcmp(name, "ncon")) { double v = d->ncon; return put(out, cap, &v, 1); }
   if (!strcmp(name, "solver_iter")) { double v = d->solver_iter; return put(out, cap, &v, 1); }
   if (!strcmp(name, "warning")) { double v = d->warning; return put(out, cap, &v, 1); }

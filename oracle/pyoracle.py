@@ -65,6 +65,8 @@ def lib():
         L.odata_set_state.argtypes = [C.c_void_p, c_f64p, C.c_double, c_f64p, c_f64p]
         L.odata_set_ctrl.argtypes = [C.c_void_p, c_f64p]
         L.o_forward.argtypes = [C.c_void_p]
+        L.o_solve_pgs.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.o_solve_pgs.restype = C.c_int
         L.o_step.argtypes = [C.c_void_p]
         L.o_forward_task.argtypes = [C.c_void_p, C.POINTER(MjpcxTask), c_f64p]
         L.o_step_task.argtypes = [C.c_void_p, C.POINTER(MjpcxTask), c_f64p]
@@ -210,6 +212,14 @@ class Physics:
 
     def step(self):
         lib().o_step(self.d)
+
+    def solve_pgs(self, max_sweeps=200000, tol=1e-13):
+        """tests only: the constraint problem of the last forward() re-solved in its dual form by projected Gauss-Seidel
+        (contact.inc o_solve_pgs) -> (qacc, efc_force, sweeps)"""
+        nefc = int(self.get("nefc")[0])
+        qacc, force = np.zeros(self.m.nv), np.zeros(max(nefc, 1))
+        sweeps = lib().o_solve_pgs(self.d, int(max_sweeps), float(tol), qacc.ctypes.data, force.ctypes.data)
+        return qacc, force[:nefc], sweeps
 
     def forward_task(self, packed_task):
         """mj_forward with the task residual evaluated at the sensor-callback point"""

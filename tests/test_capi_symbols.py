@@ -71,7 +71,7 @@ def test_unsupported_models_fail_loudly(cartpole):
     lib = capi.lib()
     t = copy.copy(cartpole)
     pm = t.packed_model()
-    pm.struct.integrator = 1  # RK4 has no device kernel yet
+    pm.struct.integrator = 2  # mjINT_IMPLICIT has no device kernel (Euler and RK4 do)
     h = C.c_void_p()
     assert lib.mjpcx_create(pm.ptr, t.packed().ptr, 0, 64, C.byref(h)) == -2
     assert b"Euler" in lib.mjpcx_create_error()

@@ -23,8 +23,8 @@ def close(a, b, tol=TOL):
     return np.all(np.abs(a - b) <= tol * (1 + np.abs(b)))
 
 
-def compare_batch(task, state, time, mocap, N, H, P, interp, times, nodes, sample=None, precision=64, tol=TOL):
-    pm, pt = task.packed_model(), task.packed()
+def compare_batch(task, state, time, mocap, N, H, P, interp, times, nodes, sample=None, precision=64, tol=TOL, pm=None):
+    pm, pt = pm or task.packed_model(), task.packed()
     ctx = capi.Context(pm, pt, 0, precision)
     ctx.set_state(state, time, mocap)
     ctx.rollout_splines(H, interp, times, nodes)
@@ -337,3 +337,20 @@ def test_noisy_rollout_on_the_lane_kernels(name, state, mocap, precision, tol):
     ctx.rollout_splines(H, 2, times, nodes)
     assert np.array_equal(r0, ctx.returns()[0])
     ctx.close()
+
+
+@pytest.mark.parametrize("N,H,interp", [(70, 48, 2), (257, 16, 1), (33, 1, 0)])
+def test_rk4_integrator_on_the_lane_kernels(cartpole, particle, N, H, interp):
+    """mjINT_RK4 (agent_integrator / <option integrator="RK4">): mj_RungeKutta(4) inside every mj_step of the rollout, on the
+    candidate-per-lane kernels, against oracle/physics.c o_rk4"""
+    P = 4
+    pm = cartpole.packed_model(); pm.struct.integrator = 1
+    times = 0.25 + np.arange(P) * 0.01 * max(H - 1, 1) / (P - 1)
+    ret, ref = compare_batch(cartpole, [0.3, 2.7, -0.4, 0.9], 0.25, None, N, H, P, interp, times, random_nodes(N + H, N, P, 1), pm=pm)
+    if H > 1:  # and it IS a different integrator: the Euler rollout of the same splines differs
+        eu = pyoracle.rollout_batch(cartpole.packed_model(), cartpole.packed(), [0.3, 2.7, -0.4, 0.9], 0.25, None, N, H, P, interp, times,
+                                    random_nodes(N + H, N, P, 1), num_threads=8)
+        assert np.abs(eu["total_return"] - ref["total_return"]).max() > 1e-6
+    pm = particle.packed_model(); pm.struct.integrator = 1
+    mocap = [0.2, -0.1, 0.01, 1, 0, 0, 0]
+    compare_batch(particle, [0.05, -0.1, 0.3, 0.2], 0.0, mocap, N, H, P, interp, np.arange(P) * 0.1 * max(H - 1, 1) / (P - 1) , random_nodes(N, N, P, 2), pm=pm)

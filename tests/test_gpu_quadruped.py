@@ -27,8 +27,10 @@ def close(a, b, tol):
     return np.all(np.abs(a - b) <= tol * (1 + np.abs(b)))
 
 
-def run(task, state, N, H, P, interp, seed, tol, time=0.0):
+def run(task, state, N, H, P, interp, seed, tol, time=0.0, integrator=None):
     pm, pt = task.packed_model(), task.packed()
+    if integrator is not None:
+        pm.struct.integrator = integrator
     rng = np.random.default_rng(seed)
     dt = task.model.get_number("agent_timestep", task.model.timestep)
     times = time + np.arange(P) * max((H - 1) * dt / max(P - 1, 1), 1e-3)
@@ -74,6 +76,17 @@ def test_falling_and_tumbling(quad):
     v = np.zeros(18)
     v[3:6] = [2.0, -1.0, 0.5]
     run(quad, np.concatenate([q, v]), N=4, H=60, P=3, interp=0, seed=5, tol=1e-5)
+
+
+@pytest.mark.parametrize("tree", [True, False])
+def test_rk4_integrator_on_the_wave_kernels(quad, tree, monkeypatch):
+    """mjINT_RK4 on the A1: four forward passes (contacts, friction loss, the Newton solver warm-started from the previous step in
+    every stage) per mj_step, on the Jacobian-free kernel and on the row-table kernel, against oracle/physics.c o_rk4"""
+    if not tree:
+        monkeypatch.setenv("MJPCX_NO_TREE", "1")
+    home = quad.model.keyframes["home"]["qpos"]
+    v = np.zeros(18); v[0:3] = [0.3, 0.0, -0.2]; v[3:6] = [0.5, -0.4, 0.3]
+    run(quad, np.concatenate([home, v]), N=5, H=30, P=3, interp=2, seed=11, tol=1e-6, integrator=1)
 
 
 def test_trot_gait_residual(quad):

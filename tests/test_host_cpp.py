@@ -50,6 +50,12 @@ def test_gpu_sampling_planner_cpp(blobs):
 
 
 @pytest.mark.gpu
+def test_reference_behavioural_suites_cpp(blobs):
+    """sampling_planner_test.cc, robust_planner_test.cc and ilqg_test.cc with the reference's own settings on the GPU planners"""
+    assert "OK" in run("behaviour_test", blobs)
+
+
+@pytest.mark.gpu
 def test_trajectory_rollout_cpp(blobs):
     """mjpc/test/agent/rollout_test.cc through the restored Trajectory::Rollout / RolloutDiscrete / NoisyRollout (host policy,
     device physics) and Planner::data_ / ResizeMjData"""

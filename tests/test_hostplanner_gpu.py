@@ -307,3 +307,52 @@ def test_cpp_robust_planner_on_the_cartpole():
                                  candidate_offset=best * R)
     assert abs(ref["total_return"].mean() - scores[best]) <= 1e-9 * (1 + abs(scores[best]))
     p.close()
+
+
+def test_native_rccl_exchange_on_one_rank():
+    """mjpcx_comm_* (include/mjpcx.h): a one-rank RCCL communicator on this GPU -- every collective the sharded planners use
+    goes through librccl (all-gather, broadcast, all-reduce) and must leave a single rank's records unchanged. (More than one
+    rank needs more than one GPU: RCCL refuses two ranks on one device. The exchange LOGIC for several ranks is covered by the
+    gloo test through the planners' transport callbacks, tests/test_distributed_gloo.py.)"""
+    import ctypes as C
+    from mujoco_mpc_amd import capi
+    from mujoco_mpc_amd.hostplanner import comm_unique_id
+    from mujoco_mpc_amd.task import load_task
+    L = capi.lib()
+    L.mjpcx_last_error.restype = C.c_char_p
+    t = load_task("Particle")
+    ctx = capi.Context(t.packed_model(), t.packed(), 0, 64)
+    uid = C.create_string_buffer(comm_unique_id(), 128)
+    assert L.mjpcx_comm_init(ctx.handle, uid, 0, 1) == 0, L.mjpcx_last_error(ctx.handle)
+    rank, world = C.c_int(-1), C.c_int(-1)
+    assert L.mjpcx_comm_info(ctx.handle, C.byref(rank), C.byref(world)) == 0 and (rank.value, world.value) == (0, 1)
+    idx, best, nominal = C.c_int32(17), C.c_double(0.25), C.c_double(0.5)
+    vals = (C.c_double * 6)(1, 2, 3, 4, 5, 6)
+    assert L.mjpcx_exchange_best(ctx.handle, C.byref(idx), C.byref(best), C.byref(nominal), vals, 6) == 0, L.mjpcx_last_error(ctx.handle)
+    assert (idx.value, best.value, nominal.value, list(vals)) == (17, 0.25, 0.5, [1, 2, 3, 4, 5, 6])
+    k = 4
+    index = (C.c_int64 * k)(9, 3, 12, -1)
+    ret = (C.c_double * k)(0.5, 0.5, 0.1, 1e300)
+    assert L.mjpcx_merge_topk(ctx.handle, k, index, ret) == 0, L.mjpcx_last_error(ctx.handle)
+    assert list(index) == [12, 3, 9, -1] and list(ret)[:3] == [0.1, 0.5, 0.5]   # sorted by return, ties by global index
+    v = (C.c_double * 3)(1.5, -2.0, 4.0)
+    assert L.mjpcx_elite_allreduce(ctx.handle, v, 3) == 0 and list(v) == [1.5, -2.0, 4.0]
+    assert L.mjpcx_comm_barrier(ctx.handle) == 0
+    assert L.mjpcx_comm_destroy(ctx.handle) == 0
+    ctx.close()
+
+
+def test_cpp_planner_with_a_native_one_rank_communicator(particle):
+    """the C++ planner's sharded code path with the library's own exchange (no transport callback): world = 1 == unsharded"""
+    from mujoco_mpc_amd.hostplanner import HostPlanner, comm_unique_id
+    ref = HostPlanner(particle, seed=3, num_trajectory=64)
+    nat = HostPlanner(particle, seed=3, num_trajectory=64, native_comm=(comm_unique_id(), 0, 1))
+    for p in (ref, nat):
+        p.reset(11)
+        p.set_state([0.02, -0.05], [0.0, 0.1])
+    for _ in range(3):
+        ref.optimize_policy(11)
+        nat.optimize_policy(11)
+        assert ref.winner == nat.winner and ref.best_score == nat.best_score
+    assert np.array_equal(ref.policy()[1], nat.policy()[1])
+    nat.comm_barrier()

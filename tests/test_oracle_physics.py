@@ -138,7 +138,7 @@ def test_euler_implicit_damping(particle):
 
 
 def test_unsupported_features_are_rejected():
-    fm = _model("""<mujoco><option integrator="RK4"><flag contact="disable"/></option><worldbody><body><joint type="hinge"/>
+    fm = _model("""<mujoco><option integrator="implicit"><flag contact="disable"/></option><worldbody><body><joint type="hinge"/>
       <geom type="sphere" size="0.1"/></body></worldbody></mujoco>""")
     with pytest.raises(NotImplementedError):
         pyoracle.Physics(PackedModel(fm))
