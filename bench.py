@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` configs (they only run at --gpus 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test without a device: rendezvous over gloo, the unique-id broadcast, the candidate split, the "
+                         "barrier + max-over-ranks timing and the JSON line -- everything of the --gpus N path except the kernels")
     return ap.parse_args()
 
 
@@ -275,6 +278,52 @@ def run_ilqg(local_rank, iterations=6, warmup=2):
     return out
 
 
+def dry_run(args, rank, world):
+    """The --gpus N launch path with the device taken out (tests/test_distributed_gloo.py runs it at WORLD_SIZE = 2): what can
+    be wrong the first time an 8-GPU node appears -- env parsing, rendezvous, the 128-byte communicator id reaching every rank,
+    candidate ranges that tile [0, N) -- is exercised here; the RCCL calls themselves are covered at world = 1 on the GPU."""
+    import torch
+    import torch.distributed as dist
+    from mujoco_mpc_amd.distributed import RankGroup
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    group = RankGroup(dist, torch.device("cpu")) if world > 1 else None
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(hashlib.sha256(b"dry-run communicator id").digest() * 4), dtype=torch.uint8))
+    if world > 1:
+        dist.broadcast(uid, src=0)
+    assert bytes(uid.numpy().tobytes()) == hashlib.sha256(b"dry-run communicator id").digest() * 4
+    n0, h0, _ = BASELINE_SIZE.get(args.task, (4096, 128, ""))
+    candidates = args.candidates or n0
+    total = candidates * world
+    q, r = divmod(total, world)                      # the planners' split: the first N % world ranks hold one more candidate
+    begin = rank * q + min(rank, r)
+    count = q + (1 if rank < r else 0)
+    if group is not None:
+        assert all(group.owner_of(g, total) == rank for g in (begin, begin + count - 1))
+        group.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1) * args.steps)       # rank-dependent "work": the reported time must be the slowest rank's
+    if group is not None:
+        group.barrier()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        elapsed = group.max_scalar(elapsed)
+        covered = group.max_scalar(float(begin + count))
+        assert covered == total
+    if rank == 0:
+        assert elapsed >= 0.01 * world * args.steps
+        print(json.dumps({"metric": "candidate-trajectory rollouts/sec (fixed horizon)", "value": None, "unit": "rollouts/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": f"{args.task} launcher dry run", "candidates_per_gpu": candidates,
+                                     "ranges": "contiguous, first N % world ranks +1"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -283,6 +332,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     import torch
 
     group = None

@@ -100,3 +100,27 @@ def test_two_ranks_equal_one_rank():
         else:       # Cross-Entropy: sums are re-associated across ranks
             assert abs(a["score"] - b["score"]) < 1e-12 and abs(a["improvement"] - b["improvement"]) < 1e-12
             assert np.allclose(np.array(a["plan"]), np.array(b["plan"]), rtol=0, atol=1e-14)
+
+
+def test_bench_launcher_dry_run_at_world_size_two():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank, 127.0.0.1), with
+    --dry-run taking the device out: rendezvous, the communicator-id broadcast, the candidate split and the max-over-ranks timing
+    run for real; rank 0 prints exactly one JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run",
+           "--candidates", "4097"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["dry_run"] is True and line["scaling"] == "weak"
+    assert line["ms_per_step"] >= 20.0          # the slower rank (2 x 10 ms per step), not rank 0's own 10 ms
