@@ -156,9 +156,25 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
 
     task = load_task(task_name)
     H = horizon
-    planner = HostPlanner(task, device=local_rank, precision=precision, seed=0,
-                          num_trajectory=candidates * world,  # lifts kMaxTrajectory = 128
-                          group=None if native is not None else group, kind=kind, native_comm=native)
+    planner, transport = None, ("rccl" if native is not None else "torch")
+    if native is not None:
+        # RCCL inside libmjpcx.so; if the communicator cannot be created on ANY rank (mismatched RCCL builds, IPC limits), every
+        # rank falls back together to the torch.distributed callbacks -- the line says which transport ran
+        try:
+            planner = HostPlanner(task, device=local_rank, precision=precision, seed=0, num_trajectory=candidates * world, kind=kind,
+                                  native_comm=native)
+            failed = 0.0
+        except Exception as ex:  # noqa: BLE001
+            print(f"rank {rank}: native communicator failed ({ex}); falling back to torch.distributed", file=sys.stderr, flush=True)
+            failed = 1.0
+        if group.max_scalar(failed) > 0:
+            if planner is not None:
+                planner.close()
+            planner, native, transport = None, None, "torch (native communicator failed)"
+    if planner is None:
+        planner = HostPlanner(task, device=local_rank, precision=precision, seed=0,
+                              num_trajectory=candidates * world,  # lifts kMaxTrajectory = 128
+                              group=group, kind=kind)
     qpos, qvel, mocap_pos, mocap_quat = initial_condition(task_name, task, planner)
     planner.reset(H)
     P = planner.num_spline_points
@@ -198,7 +214,7 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
         "config": {"workload": f"{task_name} {'Predictive Sampling' if kind == 'sampling' else 'Cross-Entropy'}, {candidates} candidates/GPU, "
                                f"horizon {H}, {P} spline points, fp{precision} ({label})",
                    "candidates_per_gpu": candidates, "horizon": H, "spline_points": P,
-                   "parallelism": f"candidates sharded over {world} rank(s)" + (", exchange over RCCL inside libmjpcx.so" if native is not None else ""),
+                   "parallelism": f"candidates sharded over {world} rank(s)" + (", exchange over RCCL inside libmjpcx.so" if native is not None else (f", exchange over {transport}" if world > 1 else "")),
                    "kernel": planner.kernel_name,
                    "host": ("C++ mjpc::GpuSamplingPlanner" if kind == "sampling" else "C++ mjpc::GpuCrossEntropyPlanner") + " over the C ABI"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

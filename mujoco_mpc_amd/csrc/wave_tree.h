@@ -458,8 +458,13 @@ __device__ __forceinline__ void wt_crb(const MODEL& m, WaveData& d, int lane) {
 
 // Cholesky of a packed SPD matrix, lane i owns row i in registers (values of other rows through v_readlane): dst := L with
 // src = L L' (dst may be src), dinv[j] = 1 / L[j][j]. LDS-typed pointers: ds_read / ds_write, never FLAT.
+#ifdef MJPCX_TREE_INLINE_CHOL
+#define WT_CHOL_LINKAGE __forceinline__
+#else
+#define WT_CHOL_LINKAGE __noinline__
+#endif
 template <int NMAX>
-__device__ __noinline__ bool wt_chol(const wlds_f64* src, wlds_f64* dst, wlds_f64* dinv, int n_, int lane) {
+__device__ WT_CHOL_LINKAGE bool wt_chol(const wlds_f64* src, wlds_f64* dst, wlds_f64* dinv, int n_, int lane) {
   const int n = __builtin_amdgcn_readfirstlane(n_);
   const int rowadr = lane * (lane + 1) / 2;
   wreal row[NMAX];
@@ -489,7 +494,7 @@ __device__ __noinline__ bool wt_chol(const wlds_f64* src, wlds_f64* dst, wlds_f6
 }
 // x := (L L')^-1 x, L packed, x in LDS
 template <int NMAX>
-__device__ __noinline__ void wt_chol_solve(wlds_f64* x, const wlds_f64* L, const wlds_f64* dinv, int n_, int lane) {
+__device__ WT_CHOL_LINKAGE void wt_chol_solve(wlds_f64* x, const wlds_f64* L, const wlds_f64* dinv, int n_, int lane) {
   const int n = __builtin_amdgcn_readfirstlane(n_);
   const int rowadr = lane * (lane + 1) / 2;
   wreal row[NMAX], col[NMAX];

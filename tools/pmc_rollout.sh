@@ -12,5 +12,5 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p3 -o p -- $CMD
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p4 -o p -- $CMD > $O/p4.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/p5 -o p -- $CMD > $O/p5.log 2>&1
 python $R/tools/summarize_pmc.py $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 --kernel=rollout_ > $O/summary.json
-cat $O/summary.json
+python $R/tools/derive_pmc.py $O/summary.json QuadrupedFlat $N 100 $PREC $O/r02_pmc_quadrupedflat_fp$PREC.json
 tail -2 $O/p1.log
