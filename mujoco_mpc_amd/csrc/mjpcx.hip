@@ -1348,8 +1348,12 @@ int wave_blob(mjpcx_ctx* c, WaveTask* wt) {
   wt->stamp_step = 0;
   return MJPCX_OK;
 }
-size_t wave_lds_bytes(const mjpcx_ctx* c, int P) {
+// tree: the iLQG kernels of a model wave_tree.h covers run its forward pass (P = the scratch elements kept in the node-time slot)
+size_t wave_lds_bytes(const mjpcx_ctx* c, int P, bool tree = false) {
   const WaveModel& wm = c->wh.m;
+  if (tree)
+    return (8 * w64::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, c->wh.t.nr, c->wh.t.nterm, P, false, w64::kTreeMaxSimpleBig,
+                                         w64::kTreeMaxConeBig) + 15) & ~(size_t)15;
   return (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, c->wh.t.nr, c->wh.t.nterm, P, wm.cone) + 15) & ~(size_t)15;
 }
 
@@ -1371,9 +1375,11 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
   a.residual = (double*)c->d_residual.p; a.costs = (double*)c->d_costs.p; a.trace = (double*)c->d_trace.p;
   a.total_return = (double*)c->d_ret.p; a.failure = (int*)c->d_fail.p;
   w64::FeedbackWaveArgs fb{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state};
-  const int Ppolicy = (int)((ndx + 2 * ds + nu - 1) / nu + 1);
-  const size_t lds = wave_lds_bytes(c, Ppolicy);
-  auto kern = c->wh.m.nv <= 20 ? w64::rollout_feedback_wave_kernel<20> : w64::rollout_feedback_wave_kernel<32>;
+  const bool tree = c->wh.tree_ok && !c->no_tree;
+  const int Ppolicy = tree ? (int)(ndx + 2 * ds) : (int)((ndx + 2 * ds + nu - 1) / nu + 1);
+  const size_t lds = wave_lds_bytes(c, Ppolicy, tree);
+  auto kern = tree ? (c->wh.m.nv <= 18 ? w64::rollout_feedback_wave_kernel<18, true> : w64::rollout_feedback_wave_kernel<32, true>)
+            : c->wh.m.nv <= 20 ? w64::rollout_feedback_wave_kernel<20> : w64::rollout_feedback_wave_kernel<32>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, c->wh.m, wt, a, fb);
   HIPCHK(c, hipGetLastError());
@@ -1406,8 +1412,10 @@ int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const doubl
   char* base = (char*)c->d_ilqg_out.p;
   HIPCHK(c, hipMemcpyAsync(base + off_lim, c->ctrllimited.data(), nu * sizeof(int), hipMemcpyHostToDevice, c->stream));
   w64::FdWaveArgs f{d[0], d[1], d[2], Tn, (int)nc, eps, (double*)base, (double*)(base + off_sensor)};
-  const size_t lds = wave_lds_bytes(c, 1);
-  auto kern = c->wh.m.nv <= 20 ? w64::transition_fd_wave_kernel<20> : w64::transition_fd_wave_kernel<32>;
+  const bool tree = c->wh.tree_ok && !c->no_tree;
+  const size_t lds = wave_lds_bytes(c, 1, tree);
+  auto kern = tree ? (c->wh.m.nv <= 18 ? w64::transition_fd_wave_kernel<18, true> : w64::transition_fd_wave_kernel<32, true>)
+            : c->wh.m.nv <= 20 ? w64::transition_fd_wave_kernel<20> : w64::transition_fd_wave_kernel<32>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(Tn * nc)), dim3(64), lds, c->stream, c->wh.m, wt, f);
   HIPCHK(c, hipGetLastError());

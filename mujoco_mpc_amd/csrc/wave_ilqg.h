@@ -59,14 +59,19 @@ struct FdWaveArgs {
   wreal* sensor;  // [Tn][ncol][nr]
 };
 
-template <int NMAX>
+// TREE: the Jacobian-free forward pass of wave_tree.h (its LDS layout, its contact lists at the large capacities) instead of the
+// row-table one -- the same step function the rollout kernels of such a model use
+template <int NMAX, bool TREE = false>
 __global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WModel m, const WTask tk, const FdWaveArgs f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
   const int t = blockIdx.x / f.ncol, col = blockIdx.x % f.ncol;
   const int nq = m.nq, nv = m.nv, nu = m.nu, ndx = 2 * nv, ds = nq + nv, nr = tk.nr;
   wreal *lnodes, *ltimes;
-  WaveData d = wave_carve(smem_raw, m, tk, 1, lnodes, ltimes);
+  TreeData tree;
+  WaveData d;
+  if constexpr (TREE) d = wave_carve_tree(smem_raw, m, tk, 1, ltimes, false, tree, kTreeMaxSimpleBig, kTreeMaxConeBig);
+  else d = wave_carve(smem_raw, m, tk, 1, lnodes, ltimes);
   for (int i = lane; i < nq; i += 64) d.qpos[i] = f.states[(size_t)t * ds + i];
   for (int i = lane; i < nv; i += 64) d.qvel[i] = f.states[(size_t)t * ds + nq + i];
   if (lane < nu) d.ctrl[lane] = f.actions[(size_t)t * nu + lane];
@@ -96,10 +101,12 @@ __global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WModel m, 
   WSYNC();
   wreal time = f.times[t];
   bool bad_ctrl = false;
-  wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, nullptr, /*have_warm=*/false);
+  if constexpr (TREE) wt_forward<NMAX>(m, tk, d, tree, lane, bad_ctrl, nullptr, /*have_warm=*/false);
+  else wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, nullptr, /*have_warm=*/false);
   wr_residual(m, tk, d, time, lane);
   for (int i = lane; i < nr; i += 64) f.sensor[((size_t)t * f.ncol + col) * nr + i] = d.residual[i];
-  wf_euler<NMAX>(m, d, lane, time);
+  if constexpr (TREE) wt_euler<NMAX>(m, d, lane, time);
+  else wf_euler<NMAX>(m, d, lane, time);
   for (int i = lane; i < ds; i += 64) f.next[((size_t)t * f.ncol + col) * ds + i] = i < nq ? d.qpos[i] : d.qvel[i - nq];
 }
 
@@ -175,7 +182,7 @@ struct FeedbackWaveArgs {
   int Tn, mode, representation, use_state;
 };
 
-template <int NMAX>
+template <int NMAX, bool TREE = false>
 __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a,
                                                                     const FeedbackWaveArgs fb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -184,7 +191,10 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
   const size_t N = (size_t)a.N;
   wreal *lnodes, *ltimes;
   // the policy scratch (dx[ndx], interpolated state[ds], current state[ds]) lives where the spline nodes would be
-  WaveData d = wave_carve(smem_raw, m, tk, /*P=*/(ndx + 2 * ds + nu - 1) / nu + 1, lnodes, ltimes);
+  TreeData tree;
+  WaveData d;
+  if constexpr (TREE) { d = wave_carve_tree(smem_raw, m, tk, /*P=*/ndx + 2 * ds, ltimes, false, tree, kTreeMaxSimpleBig, kTreeMaxConeBig); lnodes = ltimes; }
+  else d = wave_carve(smem_raw, m, tk, /*P=*/(ndx + 2 * ds + nu - 1) / nu + 1, lnodes, ltimes);
   wreal* dx = lnodes; wreal* xi = dx + ndx; wreal* xs = xi + ds;
   for (int i = lane; i < nq; i += 64) d.qpos[i] = tk.blob[i];
   for (int i = lane; i < nv; i += 64) d.qvel[i] = tk.blob[nq + i];
@@ -263,7 +273,8 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
     }
     WSYNC();
     bool bad_ctrl = false;
-    wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, nullptr, t > 0);
+    if constexpr (TREE) wt_forward<NMAX>(m, tk, d, tree, lane, bad_ctrl, nullptr, t > 0);
+    else wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, nullptr, t > 0);
     if (!last) for (int i = lane; i < nv; i += 64) bad |= is_bad(d.qacc[i]);
     if (!last) bad |= d.counters[2] != 0;  // CheckWarnings: contact / row cap overflow, indefinite Hessian (oracle odata_warning)
     bad = __any(bad);
@@ -303,7 +314,8 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
     total += cost;
     if (last) break;
     if (lane < nv) d.qacc_warm[lane] = d.qacc[lane];
-    wf_euler<NMAX>(m, d, lane, time);
+    if constexpr (TREE) wt_euler<NMAX>(m, d, lane, time);
+    else wf_euler<NMAX>(m, d, lane, time);
   }
   if (lane == 0) {
     a.total_return[cand] = failed ? kMaxReturn : total / (wreal)(H > 1 ? H : 1);

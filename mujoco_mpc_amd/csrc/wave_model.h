@@ -249,25 +249,34 @@ struct WaveHost {
     reg(&m.tendon_dofmask, tmask.data(), sizeof(unsigned) * (size_t)nt);
     // moving-geom pairs (sphere | capsule) after MuJoCo's body filters; canonical order = lower geom type first
     std::vector<int> pg1, pg2;
-    if (src->body_weldid)
+    {
+      std::vector<int> weld(nb);  // (a caller that passes no body_weldid: every body is its own weld, as for a model without welds)
+      for (int b = 0; b < nb; b++) weld[b] = src->body_weldid ? src->body_weldid[b] : b;
+      const bool contacts_on = !(src->disableflags & (MJPCX_DSBL_CONTACT | MJPCX_DSBL_CONSTRAINT));
       for (int a = 0; a < ng; a++)
         for (int b = a + 1; b < ng; b++) {
           if (dofmask[src->geom_bodyid[a]] == 0 || dofmask[src->geom_bodyid[b]] == 0) continue;
-          const int ta = src->geom_type[a], tb = src->geom_type[b];
-          if ((ta != MJPCX_GEOM_SPHERE && ta != MJPCX_GEOM_CAPSULE) || (tb != MJPCX_GEOM_SPHERE && tb != MJPCX_GEOM_CAPSULE)) continue;
           if (!((src->geom_contype[a] & src->geom_conaffinity[b]) || (src->geom_contype[b] & src->geom_conaffinity[a]))) continue;
           const int b1 = src->geom_bodyid[a], b2 = src->geom_bodyid[b];
-          const int w1 = src->body_weldid[b1], w2 = src->body_weldid[b2];
+          const int w1 = weld[b1], w2 = weld[b2];
           if (w1 == w2) continue;
-          const int pw1 = src->body_weldid[src->body_parentid[w1]], pw2 = src->body_weldid[src->body_parentid[w2]];
+          const int pw1 = weld[src->body_parentid[w1]], pw2 = weld[src->body_parentid[w2]];
           if (w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
           const int sig = ((b1 < b2 ? b1 : b2) << 16) + (b1 < b2 ? b2 : b1);
           bool excluded = false;
           for (int e = 0; e < src->nexclude; e++) excluded |= src->exclude_signature[e] == sig;
           if (excluded) continue;
+          // the pair passes MuJoCo's filters: it must be one the kernels collide, or the rollouts would silently run other physics
+          const int ta = src->geom_type[a], tb = src->geom_type[b];
+          if ((ta != MJPCX_GEOM_SPHERE && ta != MJPCX_GEOM_CAPSULE) || (tb != MJPCX_GEOM_SPHERE && tb != MJPCX_GEOM_CAPSULE)) {
+            if (!contacts_on) continue;
+            return "a collidable pair of geoms on two moving bodies has a type other than sphere / capsule (geoms " + std::to_string(a) + ", " +
+                   std::to_string(b) + "): not implemented -- exclude the pair (contype / conaffinity / <exclude>) or use spheres and capsules";
+          }
           pg1.push_back(ta > tb ? b : a);
           pg2.push_back(ta > tb ? a : b);
         }
+    }
     m.npair = (int)pg1.size();
     reg(&m.pair_g1, pg1.data(), sizeof(int) * pg1.size());
     reg(&m.pair_g2, pg2.data(), sizeof(int) * pg2.size());

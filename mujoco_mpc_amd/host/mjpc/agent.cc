@@ -45,6 +45,20 @@ void Agent::Initialize(mjModel* model) {
   count_ = 0;
 }
 
+void Agent::SetPlanner(int planner) {
+  if (planner < 0 || planner >= (int)planners_.size() || !planners_[planner]) {
+    std::fprintf(stderr, "planner %d is not available on the GPU path; using the Sampling planner\n", planner);
+    planner = kSamplingPlanner;
+  }
+  if (planner == planner_) return;
+  planner_ = planner;
+  // Allocate() only ever gave the then-active planner a device context: the new one gets its own before it is asked to plan
+  if (model_ && !allocate_enabled) {
+    ActivePlanner().Allocate();
+    ActivePlanner().Reset(kMaxTrajectoryHorizon);
+  }
+}
+
 void Agent::Allocate() {
   // only the active planner gets a device context here (the reference allocates every planner's buffers; on the
   // device that would mean one model upload and LDS/scratch budget per unused planner)

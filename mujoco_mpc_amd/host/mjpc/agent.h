@@ -36,7 +36,10 @@ class Agent {
   int GetActionDim() const { return model_->nu; }
   int GetTaskIdByName(std::string_view name) const;
   void SetTaskByIndex(int id) { active_task_id_ = id; }
-  void SetPlanner(int planner) { planner_ = planner; }
+  // an index without a planner behind it (kGradient / iLQS have no device implementation, see Initialize) falls back to
+  // Sampling, as Initialize does for the agent_planner numeric; the newly active planner is (re)allocated before it plans
+  void SetPlanner(int planner);
+  int planner_id() const { return planner_; }
   int SetParamByName(std::string_view name, double value);   // "residual_<name>" numerics (agent.cc:1016-1030)
   int SetWeightByName(std::string_view name, double value);  // cost-term weights (agent.cc:1061-1075)
   int SetModeByName(std::string_view name);                  // task_transition entries (agent.cc:472-490)

@@ -89,7 +89,8 @@ FlatTask::FlatTask(const Task& t) {
   flat_.num_norm_parameter = t.num_norm_parameter.data();
   flat_.weight = t.weight.data();
   flat_.norm_parameter = t.norm_parameter.data();
-  flat_.parameters = t.parameters.data();
+  parameters_ = t.NumericParameters();
+  flat_.parameters = parameters_.data();
   flat_.trace_site = t.trace_site.data();
   flat_.risk = t.risk;
   t.ResidualState(&residual_int_, &residual_real_);
@@ -122,7 +123,8 @@ void Context::Check(int rc) const {
 
 // the per-plan frozen task copy (Agent::PlanIteration: residual_fn_ = task->Residual(), agent.cc:319)
 void Context::SyncTask(const Task& t) {
-  Check(mjpcx_set_task_params(ctx_, t.weight.data(), t.norm_parameter.data(), t.parameters.data(), t.risk));
+  const std::vector<double> parameters = t.NumericParameters();
+  Check(mjpcx_set_task_params(ctx_, t.weight.data(), t.norm_parameter.data(), parameters.data(), t.risk));
   std::vector<int32_t> ri;
   std::vector<double> rr;
   t.ResidualState(&ri, &rr);

@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "../../../../include/mjpcx.h"
-#include "../../mujoco_min.h"
+#include <mujoco/mujoco.h>
 #include "../task.h"
 #include "../trajectory.h"
 
@@ -41,7 +41,7 @@ class FlatTask {
  private:
   mjpcx_task flat_{};
   std::vector<int32_t> norm_, residual_int_;
-  std::vector<double> residual_real_;
+  std::vector<double> residual_real_, parameters_;
 };
 
 // host copies of the mjData kinematics a Task::Transition may read (quadruped.cc:229-391), filled by Context::Kinematics

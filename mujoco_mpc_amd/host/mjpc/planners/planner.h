@@ -4,7 +4,7 @@
 #pragma once
 #include <vector>
 
-#include "../../mujoco_min.h"
+#include <mujoco/mujoco.h>
 #include "../states/state.h"
 #include "../task.h"
 #include "../threadpool.h"

@@ -1,6 +1,6 @@
 // mjpc::Policy (mjpc/planners/policy.h)
 #pragma once
-#include "../../mujoco_min.h"
+#include <mujoco/mujoco.h>
 #include "../task.h"
 
 namespace mjpc {

@@ -3,7 +3,7 @@
 #include <shared_mutex>
 #include <vector>
 
-#include "../../mujoco_min.h"
+#include <mujoco/mujoco.h>
 
 namespace mjpc {
 

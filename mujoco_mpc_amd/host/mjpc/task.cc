@@ -80,11 +80,27 @@ double Task::CostValue(const double* residual) const {
 }
 
 void Task::SetFeatureParameters(const mjModel* model) {
+  // task.cc:38-64: "residual_select_*" fields carry an integer's bits (DefaultResidualSelection), the others their value
   parameters.clear();
+  parameter_is_selection.clear();
   for (int i = 0; i < model->nnumeric; i++) {
     const char* name = model->names + model->name_numericadr[i];
-    if (StartsWith(name, "residual_")) parameters.push_back(model->numeric_data[model->numeric_adr[i]]);
+    if (StartsWith(name, "residual_select_")) {
+      parameters.push_back(DefaultResidualSelection(model, i));
+      parameter_is_selection.push_back(1);
+    } else if (StartsWith(name, "residual_")) {
+      parameters.push_back(model->numeric_data[model->numeric_adr[i]]);
+      parameter_is_selection.push_back(0);
+    }
   }
+}
+
+// what the device kernels read (include/mjpcx.h mjpcx_task.parameters): every field as a plain number
+std::vector<double> Task::NumericParameters() const {
+  std::vector<double> out(parameters);
+  for (size_t i = 0; i < out.size() && i < parameter_is_selection.size(); i++)
+    if (parameter_is_selection[i]) out[i] = (double)ReinterpretAsInt(parameters[i]);
+  return out;
 }
 
 void Task::Reset(const mjModel* model) {

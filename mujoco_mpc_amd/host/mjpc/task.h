@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "../mujoco_min.h"
+#include <mujoco/mujoco.h>
 #include "norm.h"
 
 namespace mjpc {
@@ -76,6 +76,10 @@ class Task {
   std::vector<double> norm_parameter;
   double risk = 0;
   std::vector<double> parameters;
+  // which of them are "residual_select_*" drop-downs (an integer's bits in the double: utilities.h ReinterpretAsInt), and the
+  // decoded copy handed to the device, whose kernels read numbers
+  std::vector<unsigned char> parameter_is_selection;
+  std::vector<double> NumericParameters() const;
   std::vector<int> trace_site;  // site id behind sensor "trace%i" (resolved once instead of per GetTraces call)
 
  protected:

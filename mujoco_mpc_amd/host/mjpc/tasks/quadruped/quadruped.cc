@@ -75,7 +75,7 @@ void QuadrupedFlat::ResetLocked(const mjModel* model) {
   for (double& v : r.position_) v = 0;
   for (double& v : r.heading_) v = 0;
   for (double& v : r.orientation_) v = 0;
-  r.current_gait_ = ResidualFn::kGaitStand;
+  r.current_gait_ = ReinterpretAsDouble(ResidualFn::kGaitStand);
   r.phase_start_ = r.phase_start_time_ = r.phase_velocity_ = 0;
   // derived kinematic quantities for Flip
   r.gravity_ = std::sqrt(model->opt.gravity[0] * model->opt.gravity[0] + model->opt.gravity[1] * model->opt.gravity[1] +
@@ -140,9 +140,9 @@ void QuadrupedFlat::TransitionLocked(mjModel* model, mjData* data) {
     r.com_vel_[0] = beta * r.com_vel_[0] + (1 - beta) * comvel[0];
     r.com_vel_[1] = beta * r.com_vel_[1] + (1 - beta) * comvel[1];
   }
-  const int auto_switch = (int)parameters[r.gait_switch_param_id_];
+  const int auto_switch = ReinterpretAsInt(parameters[r.gait_switch_param_id_]);  // quadruped.cc:267
   if (mode == ResidualFn::kModeBiped) {
-    parameters[r.gait_param_id_] = ResidualFn::kGaitTrot;  // biped always trots
+    parameters[r.gait_param_id_] = ReinterpretAsDouble(ResidualFn::kGaitTrot);  // biped always trots
   } else if (auto_switch && data->subtree_linvel) {
     const double com_speed = std::sqrt(r.com_vel_[0] * r.com_vel_[0] + r.com_vel_[1] * r.com_vel_[1]);
     for (int gait : ResidualFn::kGaitAll) {
@@ -151,7 +151,7 @@ void QuadrupedFlat::TransitionLocked(mjModel* model, mjData* data) {
       const bool upper = gait == ResidualFn::kGaitGallop || com_speed <= ResidualFn::kGaitAuto[gait + 1];
       const bool wait = std::fabs(r.gait_switch_time_ - time) > ResidualFn::kAutoGaitMinTime;
       if (lower && upper && wait) {
-        parameters[r.gait_param_id_] = gait;
+        parameters[r.gait_param_id_] = ReinterpretAsDouble(gait);
         r.gait_switch_time_ = time;
       }
     }
@@ -215,7 +215,7 @@ void QuadrupedFlat::TransitionLocked(mjModel* model, mjData* data) {
       weight[term("Balance")] = 0;
       weight[term("Effort")] = 0.005;
       weight[term("Posture")] = 0.1;
-      parameters[r.gait_switch_param_id_] = 0;
+      parameters[r.gait_switch_param_id_] = ReinterpretAsDouble(0);
     }
     const double flip_time = time - r.mode_start_time_;
     if (flip_time >= r.jump_time_ + r.flight_time_ + r.land_time_) {  // Flip ended: back to Quadruped, restore the values
@@ -238,8 +238,8 @@ void QuadrupedFlat::ResidualState(std::vector<int32_t>* ints, std::vector<double
   std::lock_guard<std::mutex> lock(mutex_);
   const ResidualFn& r = residual_;
   *ints = {(int32_t)r.current_mode_, r.torso_body_id_, r.head_site_id_, r.goal_mocap_id_, r.foot_geom_id_[0], r.foot_geom_id_[1],
-           r.foot_geom_id_[2], r.foot_geom_id_[3], (int32_t)r.current_gait_, (int32_t)parameters[r.flip_dir_param_id_],
-           (int32_t)parameters[r.biped_type_param_id_], r.amplitude_param_id_, r.duty_param_id_, r.arm_posture_param_id_,
+           r.foot_geom_id_[2], r.foot_geom_id_[3], (int32_t)ReinterpretAsInt(r.current_gait_), (int32_t)ReinterpretAsInt(parameters[r.flip_dir_param_id_]),
+           (int32_t)ReinterpretAsInt(parameters[r.biped_type_param_id_]), r.amplitude_param_id_, r.duty_param_id_, r.arm_posture_param_id_,
            r.heading_param_id_, r.key_home_, r.key_crouch_};
   *reals = {r.mode_start_time_, r.position_[0], r.position_[1], r.position_[2], r.heading_[0], r.heading_[1], r.speed_, r.angvel_,
             r.ground_, r.orientation_[0], r.orientation_[1], r.orientation_[2], r.orientation_[3], r.phase_start_,

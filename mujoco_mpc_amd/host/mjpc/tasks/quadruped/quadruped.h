@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../task.h"
+#include "../../utilities.h"
 
 namespace mjpc {
 
@@ -44,7 +45,7 @@ class QuadrupedFlat : public Task {
     constexpr static double kHeightQuadruped = 0.25, kCrouchHeight = 0.15, kLeapHeight = 0.5, kMaxHeight = 0.8;
 
     double GetPhase(double time) const { return phase_start_ + (time - phase_start_time_) * phase_velocity_; }
-    A1Gait GetGait() const { return current_mode_ == kModeBiped ? kGaitTrot : static_cast<A1Gait>((int)current_gait_); }
+    A1Gait GetGait() const { return current_mode_ == kModeBiped ? kGaitTrot : static_cast<A1Gait>(ReinterpretAsInt(current_gait_)); }
     void Walk(double pos[2], double time) const;  // horizontal Walk trajectory (quadruped.cc:633-649)
 
     // task state, managed by Transition (quadruped.h:186-214)
@@ -52,7 +53,7 @@ class QuadrupedFlat : public Task {
     double last_transition_time_ = -1;
     double mode_start_time_ = 0, position_[3] = {0}, heading_[2] = {0}, speed_ = 0, angvel_ = 0;
     double ground_ = 0, orientation_[4] = {0};
-    double current_gait_ = kGaitStand, phase_start_ = 0, phase_start_time_ = 0, phase_velocity_ = 0;
+    double current_gait_ = 0 /* bits of kGaitStand */, phase_start_ = 0, phase_start_time_ = 0, phase_velocity_ = 0;
     double com_vel_[2] = {0, 0}, gait_switch_time_ = 0;
     std::vector<double> save_weight_;
     double save_gait_switch_ = 0;

@@ -10,7 +10,7 @@
 #include <functional>
 #include <vector>
 
-#include "../mujoco_min.h"
+#include <mujoco/mujoco.h>
 #include "task.h"
 
 namespace mjpc {

@@ -1,5 +1,7 @@
 // Subset of mjpc/utilities.{h,cc} on the rollout path.
 #pragma once
+#include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <algorithm>
 #include <string>
@@ -11,7 +13,7 @@
 #include <string_view>
 #include <vector>
 
-#include "../mujoco_min.h"
+#include <mujoco/mujoco.h>
 
 namespace mjpc {
 
@@ -40,21 +42,29 @@ inline std::vector<std::string> SplitBar(std::string_view s, bool skip_empty) {
   }
   return out;
 }
+// A double field of Task::parameters that stores an integer (utilities.cc:118-124): the reference keeps the BITS of an int64 in
+// the double ("residual_select_*" drop-downs), read back through its low 32 bits. Same encoding here, so that code written
+// against the reference (ReinterpretAsInt(parameters[...]) in a task's Residual / Transition) sees the same values.
+inline int ReinterpretAsInt(double value) { int i; std::memcpy(&i, &value, sizeof i); return i; }
+inline double ReinterpretAsDouble(std::int64_t value) { double d; std::memcpy(&d, &value, sizeof d); return d; }
+// utilities.cc:225-229: the XML's numeric value of a "residual_select_*" field, stored as an integer's bits
+inline double DefaultResidualSelection(const mjModel* m, int numeric_index) {
+  return ReinterpretAsDouble((std::int64_t)m->numeric_data[m->numeric_adr[numeric_index]]);
+}
 // drop-down selections (utilities.cc:142-181): "residual_select_<name>" holds the index into the '|'-separated custom text
-// "residual_list_<name>". This build keeps the index as a plain number in Task::parameters (the reference stores the bits of an
-// int64 in the double); the by-name interfaces below exchange the option strings, so the difference is not observable.
+// "residual_list_<name>"
 inline std::string ResidualSelection(const mjModel* m, std::string_view name, double residual_parameter) {
   const char* options = GetCustomTextData(m, "residual_list_" + std::string(name));
   if (!options) return "";
   const std::vector<std::string> v = SplitBar(options, false);
-  const int i = (int)residual_parameter;
+  const int i = ReinterpretAsInt(residual_parameter);
   return i >= 0 && i < (int)v.size() ? v[i] : "";
 }
 inline double ResidualParameterFromSelection(const mjModel* m, std::string_view name, std::string_view value) {
   const char* options = GetCustomTextData(m, "residual_list_" + std::string(name));
   if (!options) return 0;
   const std::vector<std::string> v = SplitBar(options, false);
-  for (size_t i = 0; i < v.size(); i++) if (v[i] == value) return (double)i;
+  for (size_t i = 0; i < v.size(); i++) if (v[i] == value) return ReinterpretAsDouble((std::int64_t)i);
   return 0;
 }
 

@@ -6,7 +6,7 @@
 #include <string>
 #include <vector>
 
-#include "mujoco_min.h"
+#include <mujoco/mujoco.h>
 
 namespace mjpc {
 

@@ -193,7 +193,9 @@ int mjpc_planner_robust_result(void* h, int* best_candidate, double* scores, int
   });
 }
 int mjpc_planner_task_set_parameter(void* h, int index, double value) {
-  GUARD(h, { if (index < 0 || index >= (int)H->task->parameters.size()) throw std::runtime_error("parameter index"); H->task->parameters[index] = value; });
+  GUARD(h, { if (index < 0 || index >= (int)H->task->parameters.size()) throw std::runtime_error("parameter index"); // callers pass numbers; "residual_select_*" slots keep an integer's bits (utilities.h)
+    const bool sel = index < (int)H->task->parameter_is_selection.size() && H->task->parameter_is_selection[index];
+    H->task->parameters[index] = sel ? mjpc::ReinterpretAsDouble((std::int64_t)value) : value; });
 }
 int mjpc_planner_optimize(void* h, int horizon) { GUARD(h, H->planner->OptimizePolicy(horizon, H->pool)); }
 int mjpc_planner_nominal(void* h, int horizon) { GUARD(h, H->planner->NominalTrajectory(horizon, H->pool)); }

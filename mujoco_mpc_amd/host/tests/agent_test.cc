@@ -60,5 +60,29 @@ int main(int argc, char** argv) {
     agent.PlanIteration(&pool);
     CHECK(agent.ActivePlanner().BestTrajectory() != nullptr);
   }
+  {  // SetPlanner: out-of-range and unfilled slots fall back to Sampling; a real switch allocates the new planner before use
+    auto storage = ModelStorage::Load(dir + "/Particle.mjpx");
+    std::shared_ptr<Task> task;
+    for (auto& t : GetTasks()) if (t->Name() == "Particle") task = t;
+    CHECK(task != nullptr);
+    Agent agent;
+    agent.SetTaskList({task});
+    agent.Initialize(storage->model());
+    agent.Allocate();
+    agent.Reset();
+    const mjModel* m = storage->model();
+    std::vector<double> qpos(m->qpos0, m->qpos0 + m->nq), qvel(m->nv, 0.0);
+    const double mp[3] = {0.25, 0, 0.01}, mq[4] = {1, 0, 0, 0};
+    agent.state.Set(m, qpos.data(), qvel.data(), nullptr, mp, mq, nullptr, 0.0);
+    agent.SetPlanner(99);
+    CHECK(agent.planner_id() == kSamplingPlanner);
+    agent.SetPlanner(kGradientPlanner);  // no device implementation behind this slot
+    CHECK(agent.planner_id() == kSamplingPlanner);
+    agent.SetPlanner(kCrossEntropyPlanner);
+    CHECK(agent.planner_id() == kCrossEntropyPlanner);
+    ThreadPool pool(1);
+    agent.PlanIteration(&pool);  // would dereference an unallocated planner without the lazy Allocate
+    CHECK(agent.ActivePlanner().BestTrajectory() != nullptr);
+  }
   TEST_MAIN_END();
 }

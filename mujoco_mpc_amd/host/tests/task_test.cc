@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     CHECK(ri[0] == 0 && ri[8] == 0 && rr[15] == 0.0);  // Quadruped mode, Stand, phase clock not started
     mjData d{};
     d.time = 0.5;
-    quad->parameters[0] = 2;  // select_Gait = Trot
+    quad->parameters[0] = ReinterpretAsDouble(2);  // select_Gait = Trot
     quad->Transition(qstorage->model(), &d);
     quad->ResidualState(&ri, &rr);
     CHECK(ri[8] == 2);                                  // gait switched
@@ -97,20 +97,24 @@ int main(int argc, char** argv) {
     { const double p0[3] = {6, 6, 1}; CHECK_NEAR(Ground(qm, &d, p0), 0.5, 1e-12); }
     // automatic gait switching: filtered COM speed 0 -> 0.632 -> 0.970 m/s selects Canter once kAutoGaitMinTime has passed
     quad->Reset(qm);
-    CHECK(quad->parameters[1] == 1);  // Gait switch = Automatic in the XML
+    CHECK(ReinterpretAsInt(quad->parameters[1]) == 1);  // Gait switch = Automatic in the XML
+    // the reference's encoding of drop-down fields (task.cc:57, utilities.cc:118-124,225): an integer's BITS in the double; the
+    // device is handed plain numbers (Task::NumericParameters)
+    CHECK(quad->parameters[1] == ReinterpretAsDouble(1) && quad->parameters[1] < 1e-300 && quad->parameter_is_selection[1] == 1);
+    CHECK(quad->NumericParameters()[1] == 1.0 && quad->NumericParameters()[4] == quad->parameters[4] && quad->parameter_is_selection[4] == 0);
     linvel[3 * torso] = 1.0;
     d.time = 0.5; quad->Transition(qm, &d);
-    CHECK(quad->parameters[0] == 0);
+    CHECK(ReinterpretAsInt(quad->parameters[0]) == 0);
     d.time = 0.7; quad->Transition(qm, &d);
-    CHECK(quad->parameters[0] == 0);  // in the Canter range, but less than 1 s since the last switch (t = 0)
+    CHECK(ReinterpretAsInt(quad->parameters[0]) == 0);  // in the Canter range, but less than 1 s since the last switch (t = 0)
     d.time = 1.2; quad->Transition(qm, &d);
     quad->ResidualState(&ri, &rr);
-    CHECK(quad->parameters[0] == 3 && ri[8] == 3);
+    CHECK(ReinterpretAsInt(quad->parameters[0]) == 3 && ri[8] == 3);
     CHECK(quad->parameters[4] == 0.4 && quad->parameters[2] == 4 && quad->parameters[3] == 0.05);  // Canter duty, cadence, amplitude
     d.time = 1.3; linvel[3 * torso] = 0.0; quad->Transition(qm, &d);
-    CHECK(quad->parameters[0] == 3);  // still waiting
+    CHECK(ReinterpretAsInt(quad->parameters[0]) == 3);  // still waiting
     // Walk: straight line, then a circle about the axis speed / angvel to the left of the torso
-    quad->parameters[1] = 0;
+    quad->parameters[1] = ReinterpretAsDouble(0);
     xpos[3 * torso] = 1; xpos[3 * torso + 1] = 2; xpos[3 * torso + 2] = 0.3;
     mpos[3 * goal] = 3; mpos[3 * goal + 1] = 2;
     quad->parameters[5] = 0.5; quad->parameters[6] = 0;
@@ -135,9 +139,9 @@ int main(int argc, char** argv) {
     CHECK(quad->mode == 0 && ri[0] == 0);
     // Flip from Quadruped: saves the weights and the gait switch, records orientation and ground height, and ends after
     // jump + flight + land time with the goal under the head
-    quad->parameters[1] = 1;
+    quad->parameters[1] = ReinterpretAsDouble(1);
     d.time = 5.9; quad->Transition(qm, &d);  // automatic switching settles on Stand (filtered speed ~ 0) before the weights are saved
-    CHECK(quad->parameters[0] == 0);
+    CHECK(ReinterpretAsInt(quad->parameters[0]) == 0);
     std::vector<double> w0 = quad->weight;
     com[3 * torso] = 6; com[3 * torso + 1] = 6; com[3 * torso + 2] = 0.8;
     xquat[4 * torso] = 0.6; xquat[4 * torso + 3] = 0.8;
@@ -148,13 +152,13 @@ int main(int argc, char** argv) {
     CHECK(ri[0] == 4 && rr[0] == 6.0 && rr[9] == 0.6 && rr[12] == 0.8);
     CHECK_NEAR(rr[8], 0.5, 1e-12);  // on top of the hill
     CHECK(quad->weight[0] == 0.2 && quad->weight[1] == 5 && quad->weight[2] == 0 && quad->weight[3] == 0 && quad->weight[4] == 0);
-    CHECK(quad->weight[5] == 0.005 && quad->weight[6] == 0.1 && quad->parameters[1] == 0);
+    CHECK(quad->weight[5] == 0.005 && quad->weight[6] == 0.1 && ReinterpretAsInt(quad->parameters[1]) == 0);
     const double flip_total = rr[22] + rr[18] + rr[24];
     d.time = 6.0 + 0.5 * flip_total; quad->Transition(qm, &d);
     CHECK(quad->mode == 4);
     d.time = 6.0 + flip_total + 1e-9; quad->Transition(qm, &d);
     quad->ResidualState(&ri, &rr);
-    CHECK(quad->mode == 0 && ri[0] == 0 && quad->weight == w0 && quad->parameters[1] == 1);
+    CHECK(quad->mode == 0 && ri[0] == 0 && quad->weight == w0 && ReinterpretAsInt(quad->parameters[1]) == 1);
     CHECK(mpos[3 * goal] == 6.2 && mpos[3 * goal + 1] == 6.1);
     // mjData reset (time going backwards) restarts the phase clock
     d.time = 0.1; quad->Transition(qm, &d);

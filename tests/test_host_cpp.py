@@ -39,6 +39,21 @@ def test_task_and_state_suites(blobs):
     assert "OK" in run("state_test", os.path.join(blobs, "Particle.mjpx"))
 
 
+def test_host_code_names_mujoco_by_its_public_header():
+    """every mjpc/ header reaches MuJoCo's types through <mujoco/mujoco.h> (host/include/mujoco/mujoco.h forwards to the subset this
+    build carries), so the host layer is source-compatible with a real MuJoCo include path; a TU that only knows the public name
+    compiles"""
+    for dirpath, _, files in os.walk(os.path.join(HOST, "mjpc")):
+        for f in files:
+            if f.endswith((".h", ".cc")):
+                assert "mujoco_min.h" not in open(os.path.join(dirpath, f)).read(), f
+    src = '#include <mujoco/mujoco.h>\n#include "mjpc/planners/planner.h"\n#include "mjpc/trajectory.h"\n' \
+          'int main() { mjModel* m = nullptr; mjData* d = nullptr; mjtNum x = mju_max(1.0, 2.0); (void)m; (void)d; return x > 0 ? 0 : 1; }\n'
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(HOST, "include"), "-I", HOST, "-x", "c++", "-"],
+                       input=src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_host_library_links_the_c_abi(blobs):
     out = subprocess.run(["ldd", os.path.join(HOST, "build", "libmjpc_host.so")], capture_output=True, text=True).stdout
     assert "libmjpcx.so" in out
