@@ -269,7 +269,9 @@ typedef struct mjpcx_ctx mjpcx_ctx;
 int mjpcx_create(const mjpcx_model* model, const mjpcx_task* task, int device,
                  int precision, mjpcx_ctx** out);
 void mjpcx_destroy(mjpcx_ctx* ctx);
-const char* mjpcx_create_error(void); /* detail of the calling thread's last failed mjpcx_create */
+const char* mjpcx_create_error(void); /* detail of the calling thread's last failed mjpcx_create; after a successful one: "" or a
+                                         non-fatal warning naming what of the model the device does not reproduce (e.g. collidable
+                                         pairs of non-sphere/capsule geoms between two moving bodies, which are left out) */
 const char* mjpcx_error_string(int code);
 const char* mjpcx_last_error(const mjpcx_ctx* ctx); /* detail of last failure */
 const char* mjpcx_kernel_name(const mjpcx_ctx* ctx); /* rollout kernel variant */

@@ -132,6 +132,7 @@ class Context:
         rc = lib().mjpcx_create(packed_model.ptr, packed_task.ptr, int(device), int(precision), C.byref(self.handle))
         if rc != 0:
             raise MjpcxError(rc, lib().mjpcx_create_error().decode())
+        self.create_warning = lib().mjpcx_create_error().decode()  # "" or what of the model the device does not reproduce
         m, t = packed_model.struct, packed_task.struct
         self.nq, self.nv, self.nu, self.na = m.nq, m.nv, m.nu, m.na
         self.dim_state = m.nq + m.nv + m.na

@@ -836,6 +836,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     }
     set_norm_params(c, t->norm_parameter);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
+    g_create_error = c->wh.warning;  // (empty, or what this context does NOT model of the caller's mjModel)
     *out = c;
     return MJPCX_OK;
   }

@@ -113,6 +113,7 @@ struct WaveHost {
   std::vector<unsigned> h_dofmask;
   std::vector<int> h_level_body, h_static_geom, h_dynamic_geom, h_ray_geom, h_term_off, h_res_term;
   void* dev_image = nullptr; void* dev_image32 = nullptr;  // LDS images of a registered model (fp64 / fp32)
+  std::string warning;                                     // non-fatal findings of build() (reported through mjpcx_create_error after MJPCX_OK)
   int registered = -1;                                     // index into the registered configurations, -1: generic kernels
   std::vector<double> state, mocap, weight, norm_p, norm_q, parameters, residual_real;
   std::vector<int32_t> residual_int, norm_types;
@@ -249,6 +250,7 @@ struct WaveHost {
     reg(&m.tendon_dofmask, tmask.data(), sizeof(unsigned) * (size_t)nt);
     // moving-geom pairs (sphere | capsule) after MuJoCo's body filters; canonical order = lower geom type first
     std::vector<int> pg1, pg2;
+    int skipped_pairs = 0, skipped_a = -1, skipped_b = -1;
     {
       std::vector<int> weld(nb);  // (a caller that passes no body_weldid: every body is its own weld, as for a model without welds)
       for (int b = 0; b < nb; b++) weld[b] = src->body_weldid ? src->body_weldid[b] : b;
@@ -269,14 +271,20 @@ struct WaveHost {
           // the pair passes MuJoCo's filters: it must be one the kernels collide, or the rollouts would silently run other physics
           const int ta = src->geom_type[a], tb = src->geom_type[b];
           if ((ta != MJPCX_GEOM_SPHERE && ta != MJPCX_GEOM_CAPSULE) || (tb != MJPCX_GEOM_SPHERE && tb != MJPCX_GEOM_CAPSULE)) {
-            if (!contacts_on) continue;
-            return "a collidable pair of geoms on two moving bodies has a type other than sphere / capsule (geoms " + std::to_string(a) + ", " +
-                   std::to_string(b) + "): not implemented -- exclude the pair (contype / conaffinity / <exclude>) or use spheres and capsules";
+            // MuJoCo would hand this pair to its general convex collider (boxes, cylinders, ellipsoids, meshes). There is no device
+            // (or oracle) counterpart: the pair is left out, and create says so (mjpcx_create_error() after MJPCX_OK).
+            if (contacts_on && skipped_pairs++ == 0) { skipped_a = a; skipped_b = b; }
+            continue;
           }
           pg1.push_back(ta > tb ? b : a);
           pg2.push_back(ta > tb ? a : b);
         }
     }
+    warning.clear();
+    if (skipped_pairs > 0)
+      warning = std::to_string(skipped_pairs) + " collidable geom pair(s) between two moving bodies involve a geom that is neither sphere nor capsule "
+                "(first: geoms " + std::to_string(skipped_a) + ", " + std::to_string(skipped_b) + ") and are NOT collided: MuJoCo's general convex collider has no "
+                "device counterpart (contacts with static geoms are unaffected)";
     m.npair = (int)pg1.size();
     reg(&m.pair_g1, pg1.data(), sizeof(int) * pg1.size());
     reg(&m.pair_g2, pg2.data(), sizeof(int) * pg2.size());
