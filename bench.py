@@ -377,7 +377,7 @@ def main():
     candidates = args.candidates or n0
     H = args.horizon or h0
     main_line = run_config(args, args.task, args.planner, candidates, H, args.precision, args.steps, args.warmup, world, local_rank,
-                           group, want_cpu=not args.no_cpu_baseline, rank=rank, native=native)
+                           group, want_cpu=not args.no_cpu_baseline and world == 1, rank=rank, native=native)
     if rank == 0:
         out = {"metric": "candidate-trajectory rollouts/sec (fixed horizon)", "value": main_line["value"], "unit": "rollouts/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],

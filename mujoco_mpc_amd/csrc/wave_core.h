@@ -231,8 +231,14 @@ __device__ __noinline__ void wave_chol_solve(wreal* x, const wreal* L, const wre
   WSYNC();
 }
 
-// solimp -> impedance at violation `dist` (oracle impedance())
-__device__ __noinline__ wreal w_impedance(const wreal* solimp, wreal dist) {
+// solimp -> impedance at violation `dist` (oracle impedance()). The general exponent needs pow() (~1000 instructions each): that path
+// is an out-of-line call taken only for non-default solimp; the default (power 2) and linear cases are inline, so the callers' live
+// registers are not saved and restored around a call on every contact.
+__device__ __noinline__ wreal w_impedance_pow(wreal x, wreal mid, wreal power) {
+  if (x <= mid) return pow(x, power) / pow(mid, power - 1);
+  return 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+}
+__device__ __forceinline__ wreal w_impedance(const wreal* solimp, wreal dist) {
   wreal dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
   dmin = fmin(fmax(dmin, kMinImp), kMaxImp);
   dmax = fmin(fmax(dmax, kMinImp), kMaxImp);
@@ -244,10 +250,8 @@ __device__ __noinline__ wreal w_impedance(const wreal* solimp, wreal dist) {
   if (x <= 0) return dmin;
   wreal y;
   if (power == 1) y = x;
-  else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);  // MuJoCo's default: no pow() (~1000 instructions, and
-                                                                                         // every lane of a divergent wavefront pays for it)
-  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
-  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);  // MuJoCo's default
+  else y = w_impedance_pow(x, mid, power);
   return dmin + y * (dmax - dmin);
 }
 template <class MODEL>

@@ -56,6 +56,36 @@ def test_fp32_rollouts_track_the_fp64_oracle(name, H, rtol, stol):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["QuadrupedFlat", "HumanoidTrack"])
+def test_fp32_rk4_rollouts_track_the_fp64_oracle(name):
+    """mjINT_RK4 in the float instantiation (w32::rollout_wave_kernel<32, false, true>): the A1 (elliptic cones, friction loss) and
+    the humanoid (pyramidal cones, tendons) over 20 steps = 80 forward passes"""
+    t, q, v, mocap, std = setup(name)
+    pm, pt = t.packed_model(), t.packed()
+    pm.struct.integrator = 1
+    N, P, H = 8, 3, 20
+    rng = np.random.default_rng(3)
+    dt = t.model.get_number("agent_timestep", t.model.timestep)
+    times = np.arange(P) * (H - 1) * dt / (P - 1)
+    nodes = np.clip(rng.normal(0, std, (N, P, t.model.nu)), -1, 1)
+    state = np.concatenate([q, v])
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, N, H, P, 1, times, nodes, num_threads=8)
+    eul = pyoracle.rollout_batch(t.packed_model(), pt, state, 0.0, mocap, N, H, P, 1, times, nodes, num_threads=8)
+    assert not ref["failure"].any()
+    ctx = capi.Context(pm, pt, 0, 32)
+    ctx.set_state(state, 0.0, mocap)
+    ctx.rollout_splines(H, 1, times, nodes)
+    ret, fail = ctx.returns()
+    assert not fail.any()
+    rel = np.abs(ret - ref["total_return"]) / np.abs(ref["total_return"])
+    assert rel.max() < 1e-4, rel.max()
+    # ... and closer to the RK4 oracle than the Euler rollout of the same splines is (it IS the other integrator)
+    assert np.abs(ret - ref["total_return"]).max() < 0.1 * np.abs(eul["total_return"] - ref["total_return"]).max()
+    tr = ctx.fetch_trajectory(0)
+    assert np.abs(tr.states - ref["states"][0]).max() < 2e-2
+    ctx.close()
+
+
 def test_fp32_planner_on_the_humanoid():
     """the C++ Predictive-Sampling planner at precision 32 improves the tracking cost like the fp64 one"""
     from mujoco_mpc_amd.hostplanner import HostPlanner

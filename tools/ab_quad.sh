@@ -1,0 +1,7 @@
+#!/bin/bash
+# same-box A/B of alternative builds of libmjpcx.so on the north-star line: tools/ab_quad.sh <other.so> [<other2.so> ...]
+cd $GRAFT_REPO_ROOT
+run() { python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extra 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['value']), round(d['roofline']['kernel_ms'],2))"; }
+cp mujoco_mpc_amd/libmjpcx.so /tmp/main.so
+run main
+for so in "$@"; do cp $so mujoco_mpc_amd/libmjpcx.so; run $so; cp /tmp/main.so mujoco_mpc_amd/libmjpcx.so; run main; done
