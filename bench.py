@@ -63,11 +63,20 @@ BASELINE_SIZE = {
 }
 
 
-def lib_sha16():
+def kernel_source_sha16():
+    """identity of the device code being benchmarked: sha256 over the kernel sources (csrc/*.h, *.hip, generated/*, include/mjpcx.h),
+    so that a PMC summary is tied to the code it profiled and survives a rebuild of the same sources"""
+    import glob
     from mujoco_mpc_amd import capi
-    path = os.path.join(ROOT, "mujoco_mpc_amd", "libmjpcx.so")
-    capi.lib()
-    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    capi.lib()  # (the library must exist: the product path fails loudly without it)
+    csrc = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "generated", "*.h"))
+                   + [os.path.join(ROOT, "include", "mjpcx.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=None, interp=None):
@@ -136,13 +145,13 @@ def initial_condition(task_name, task, planner):
 def pmc_summary(task_name, candidates, horizon, precision):
     """Counter-derived figures of the rollout kernel for THIS build: profiles/r02_pmc_<task>.json is written by
     tools/pmc_rollout.sh (separate --pmc passes, as MI355X_MICROARCH.md prescribes) and records the sha256 of the
-    libmjpcx.so it profiled; a summary of any other build is ignored (never a stale lookup)."""
+    kernel sources it profiled; a summary of any other source state is ignored (never a stale lookup)."""
     path = os.path.join(ROOT, "profiles", f"r02_pmc_{task_name.lower()}_fp{precision}.json")
     try:
         s = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if s.get("lib_sha16") != lib_sha16() or s.get("candidates") != candidates or s.get("horizon") != horizon:
+    if s.get("src_sha16") != kernel_source_sha16() or s.get("candidates") != candidates or s.get("horizon") != horizon:
         return None
     return s
 

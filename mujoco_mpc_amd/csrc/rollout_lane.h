@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
                                                            const RolloutArgs<T> a) {
   decltype(auto) m = MC::template get<T>(m_karg);
   constexpr int NB = TP::NB, NV = TP::NV, NU = TP::NU, NS = TP::NSITE;
-  constexpr int NR = TK::NR, NTR = TK::NTRACE, DS = 2 * NV;
+  [[maybe_unused]] constexpr int NR = TK::NR, NTR = TK::NTRACE, DS = 2 * NV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lnodes = reinterpret_cast<T*>(smem_raw);  // [P][NU][64]
   // node times also live in LDS: a global LOAD inside the time loop would need s_waitcnt vmcnt(0),
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
 template <class TP, class TK, typename T, class MC>
 __global__ __launch_bounds__(256) void cost_lane_kernel(const LaneModel<T> m_karg, const LaneTask<T> tk, const RolloutArgs<T> a) {
   decltype(auto) m = MC::template get<T>(m_karg);
-  constexpr int NV = TP::NV, NU = TP::NU, NS = TP::NSITE, NR = TK::NR, NTR = TK::NTRACE, DS = 2 * NV;
+  constexpr int NV = TP::NV, NU = TP::NU, NS = TP::NSITE, NR = TK::NR, DS = 2 * NV;
   const size_t N = (size_t)a.N;
   const size_t item = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (item >= N * (size_t)a.H) return;

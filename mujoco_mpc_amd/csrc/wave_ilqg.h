@@ -188,7 +188,6 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x, cand = blockIdx.x;
   const int nq = m.nq, nv = m.nv, nu = m.nu, ndx = 2 * nv, ds = nq + nv, nr = tk.nr, H = a.H, Tn = fb.Tn;
-  const size_t N = (size_t)a.N;
   wreal *lnodes, *ltimes;
   // the policy scratch (dx[ndx], interpolated state[ds], current state[ds]) lives where the spline nodes would be
   TreeData tree;

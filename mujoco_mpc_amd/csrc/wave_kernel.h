@@ -68,7 +68,7 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const MO
 template <int NMAX, bool TREE, int CAPS = kTreeMaxSimple, int CAPC = kTreeMaxCone, bool RK4 = false, class MODEL, class TASK>
 __device__ __forceinline__ void wave_rollout_body(const MODEL& m, const TASK& tk, const RolloutArgs<wreal>& a, unsigned char* smem_raw, int cand, int lane,
                                                   wreal* cone_slab = nullptr) {
-  const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nj = m.njnt, ns = m.nsite, nr = tk.nr;
+  const int nq = m.nq, nv = m.nv, nu = m.nu, nb = m.nbody, nr = tk.nr;
   const int P = a.P, H = a.H;
   const size_t N = (size_t)a.N;
   // ---- LDS carve

@@ -136,11 +136,6 @@ struct WaveHost {
       if (bytes) std::memcpy(h.data() + off, p, bytes);
       return off;
     };
-    auto put = [&](const void* p, size_t bytes) -> size_t {
-      const size_t off = put_in(host, p, bytes);
-      if (want32) put_in(host32, p, bytes);  // same bytes (integers); the image offsets differ, see Fix
-      return off;
-    };
     struct Fix { size_t field_off; size_t data_off; size_t data_off32; };
     std::vector<Fix> fixes;
     // integer / mask arrays: identical in both images

@@ -2,7 +2,8 @@
 """gpurun_out/pmc/summary.json (tools/pmc_rollout.sh, tools/summarize_pmc.py) -> the per-build counter summary bench.py reads
 (profiles/r02_pmc_<task>_fp<prec>.json): python tools/derive_pmc.py <summary.json> <task> <candidates> <horizon> <precision> <out.json>
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB per dispatch; the x2 is MI355X_MICROARCH.md's gfx950 correction for wide reads).
-The summary is tied to the library it profiled by the sha256 of libmjpcx.so; bench.py ignores it for any other build."""
+The summary is tied to the code it profiled by the sha256 of the kernel sources (bench.kernel_source_sha16); bench.py ignores it
+for any other source state."""
 import hashlib
 import json
 import os
@@ -27,7 +28,7 @@ waves_steps = N * H
 out = dict(c)
 out.update({
     "kernel": name, "task": task, "candidates": N, "horizon": H, "precision": prec,
-    "lib_sha16": hashlib.sha256(open(os.path.join(ROOT, "mujoco_mpc_amd", "libmjpcx.so"), "rb").read()).hexdigest()[:16],
+    "src_sha16": __import__("bench").kernel_source_sha16(),
     "hbm_bytes_per_launch": (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024.0,
     "algorithmic_bytes_per_launch": per_rollout * N,
     "valu": {
@@ -44,4 +45,4 @@ out.update({
     "other_kernels": {k: v for k, v in summary.items() if k != name},
 })
 json.dump(out, open(dst, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("kernel", "lib_sha16", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "valu")}, indent=1))
+print(json.dumps({k: out[k] for k in ("kernel", "src_sha16", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "valu")}, indent=1))
