@@ -464,7 +464,7 @@ __device__ __forceinline__ void wt_crb(const MODEL& m, WaveData& d, int lane) {
 #define WT_CHOL_LINKAGE __noinline__
 #endif
 template <int NMAX>
-__device__ __forceinline__ bool wt_chol_impl(const wlds_f64* src, wlds_f64* dst, wlds_f64* dinv, int n_, int lane) {
+__device__ WT_CHOL_LINKAGE bool wt_chol(const wlds_f64* src, wlds_f64* dst, wlds_f64* dinv, int n_, int lane) {
   const int n = __builtin_amdgcn_readfirstlane(n_);
   const int rowadr = lane * (lane + 1) / 2;
   wreal row[NMAX];
@@ -494,9 +494,7 @@ __device__ __forceinline__ bool wt_chol_impl(const wlds_f64* src, wlds_f64* dst,
 }
 // x := (L L')^-1 x, L packed, x in LDS
 template <int NMAX>
-__device__ WT_CHOL_LINKAGE bool wt_chol(const wlds_f64* src, wlds_f64* dst, wlds_f64* dinv, int n_, int lane) { return wt_chol_impl<NMAX>(src, dst, dinv, n_, lane); }
-template <int NMAX>
-__device__ __forceinline__ void wt_chol_solve_impl(wlds_f64* x, const wlds_f64* L, const wlds_f64* dinv, int n_, int lane) {
+__device__ WT_CHOL_LINKAGE void wt_chol_solve(wlds_f64* x, const wlds_f64* L, const wlds_f64* dinv, int n_, int lane) {
   const int n = __builtin_amdgcn_readfirstlane(n_);
   const int rowadr = lane * (lane + 1) / 2;
   wreal row[NMAX], col[NMAX];
@@ -520,17 +518,6 @@ __device__ __forceinline__ void wt_chol_solve_impl(wlds_f64* x, const wlds_f64* 
   if (lane < n) x[lane] = b;
   WSYNC();
 }
-template <int NMAX>
-__device__ WT_CHOL_LINKAGE void wt_chol_solve(wlds_f64* x, const wlds_f64* L, const wlds_f64* dinv, int n_, int lane) { wt_chol_solve_impl<NMAX>(x, L, dinv, n_, lane); }
-// the Newton loop's factorisation and solve: inline there when MJPCX_NEWTON_INLINE_CHOL is defined (the loop's live values are then
-// not parked in scratch around two calls per iteration), out of line everywhere else
-#ifdef MJPCX_NEWTON_INLINE_CHOL
-#define WT_NEWTON_CHOL wt_chol_impl
-#define WT_NEWTON_SOLVE wt_chol_solve_impl
-#else
-#define WT_NEWTON_CHOL wt_chol
-#define WT_NEWTON_SOLVE wt_chol_solve
-#endif
 
 // o_euler on the tree path (packed M): implicit joint damping, then integrate positions
 template <int NMAX, class MODEL>
@@ -1033,10 +1020,10 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
       WSYNC();
       if (stamp && lane == 0 && iter == 0) stamp[22] = (long long)__builtin_readcyclecounter();
       WACC(34);
-      if (!WT_NEWTON_CHOL<NMAX>((const wlds_f64*)d.H, (wlds_f64*)d.H, (wlds_f64*)d.dinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
+      if (!wt_chol<NMAX>((const wlds_f64*)d.H, (wlds_f64*)d.H, (wlds_f64*)d.dinv, nv, lane)) { if (lane == 0) d.counters[2] |= 16; WSYNC(); break; }
       factor_valid = true;
     }
-    WT_NEWTON_SOLVE<NMAX>((wlds_f64*)d.search, (const wlds_f64*)d.H, (const wlds_f64*)d.dinv, nv, lane);
+    wt_chol_solve<NMAX>((wlds_f64*)d.search, (const wlds_f64*)d.H, (const wlds_f64*)d.dinv, nv, lane);
     if (stamp && lane == 0 && iter == 0) stamp[23] = (long long)__builtin_readcyclecounter();
     WACC(35);
     // jv = J search (registers); Gauss part along the ray
