@@ -1361,7 +1361,6 @@ size_t wave_lds_bytes(const mjpcx_ctx* c, int P, bool tree = false) {
 int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
                      const double* states, const double* actions, const double* gains, const double* improvement, const double* alpha) {
   if (c->precision != 64) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family are fp64 only");
-  if (c->wh.m.integrator != MJPCX_INT_EULER) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family integrate with Euler only");
   int rc;
   if ((rc = reserve_rollout(c, N, H, 1)) != MJPCX_OK) return rc;
   const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu;
@@ -1379,7 +1378,9 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
   const bool tree = c->wh.tree_ok && !c->no_tree;
   const int Ppolicy = tree ? (int)(ndx + 2 * ds) : (int)((ndx + 2 * ds + nu - 1) / nu + 1);
   const size_t lds = wave_lds_bytes(c, Ppolicy, tree);
-  auto kern = tree ? (c->wh.m.nv <= 18 ? w64::rollout_feedback_wave_kernel<18, true> : w64::rollout_feedback_wave_kernel<32, true>)
+  const bool rk4 = c->wh.m.integrator == MJPCX_INT_RK4;  // (one NMAX = 32 instantiation per family carries mj_RungeKutta)
+  auto kern = rk4 ? (tree ? w64::rollout_feedback_wave_kernel<32, true, true> : w64::rollout_feedback_wave_kernel<32, false, true>)
+            : tree ? (c->wh.m.nv <= 18 ? w64::rollout_feedback_wave_kernel<18, true> : w64::rollout_feedback_wave_kernel<32, true>)
             : c->wh.m.nv <= 20 ? w64::rollout_feedback_wave_kernel<20> : w64::rollout_feedback_wave_kernel<32>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, c->wh.m, wt, a, fb);
@@ -1393,7 +1394,6 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
 int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const double* states, const double* actions, double eps,
                           int centered, double* A, double* B, double* C, double* D) {
   if (c->precision != 64) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family are fp64 only");
-  if (c->wh.m.integrator != MJPCX_INT_EULER) return fail(c, MJPCX_EUNSUPPORTED, "the iLQG kernels of the wavefront-per-candidate family integrate with Euler only");
   int rc;
   const size_t ds = c->nq + c->nv, ndx = 2 * (size_t)c->nv, nu = c->nu, nr = c->nr;
   const size_t nc = 1 + 2 * (ndx + nu);
@@ -1415,7 +1415,9 @@ int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const doubl
   w64::FdWaveArgs f{d[0], d[1], d[2], Tn, (int)nc, eps, (double*)base, (double*)(base + off_sensor)};
   const bool tree = c->wh.tree_ok && !c->no_tree;
   const size_t lds = wave_lds_bytes(c, 1, tree);
-  auto kern = tree ? (c->wh.m.nv <= 18 ? w64::transition_fd_wave_kernel<18, true> : w64::transition_fd_wave_kernel<32, true>)
+  const bool rk4 = c->wh.m.integrator == MJPCX_INT_RK4;
+  auto kern = rk4 ? (tree ? w64::transition_fd_wave_kernel<32, true, true> : w64::transition_fd_wave_kernel<32, false, true>)
+            : tree ? (c->wh.m.nv <= 18 ? w64::transition_fd_wave_kernel<18, true> : w64::transition_fd_wave_kernel<32, true>)
             : c->wh.m.nv <= 20 ? w64::transition_fd_wave_kernel<20> : w64::transition_fd_wave_kernel<32>;
   HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(Tn * nc)), dim3(64), lds, c->stream, c->wh.m, wt, f);

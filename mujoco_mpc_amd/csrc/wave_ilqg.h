@@ -61,7 +61,7 @@ struct FdWaveArgs {
 
 // TREE: the Jacobian-free forward pass of wave_tree.h (its LDS layout, its contact lists at the large capacities) instead of the
 // row-table one -- the same step function the rollout kernels of such a model use
-template <int NMAX, bool TREE = false>
+template <int NMAX, bool TREE = false, bool RK4 = false>
 __global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WModel m, const WTask tk, const FdWaveArgs f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x;
@@ -105,7 +105,10 @@ __global__ __launch_bounds__(64) void transition_fd_wave_kernel(const WModel m, 
   else wf_forward<NMAX>(m, tk, d, lane, bad_ctrl, nullptr, /*have_warm=*/false);
   wr_residual(m, tk, d, time, lane);
   for (int i = lane; i < nr; i += 64) f.sensor[((size_t)t * f.ncol + col) * nr + i] = d.residual[i];
-  if constexpr (TREE) wt_euler<NMAX>(m, d, lane, time);
+  bool rk4 = false;
+  if constexpr (RK4) rk4 = m.integrator == 1;
+  if (rk4) { if constexpr (RK4) (void)wave_rk4_step<NMAX, TREE>(m, tk, d, tree, lane, time, /*have_warm=*/false); }
+  else if constexpr (TREE) wt_euler<NMAX>(m, d, lane, time);
   else wf_euler<NMAX>(m, d, lane, time);
   for (int i = lane; i < ds; i += 64) f.next[((size_t)t * f.ncol + col) * ds + i] = i < nq ? d.qpos[i] : d.qvel[i - nq];
 }
@@ -182,7 +185,7 @@ struct FeedbackWaveArgs {
   int Tn, mode, representation, use_state;
 };
 
-template <int NMAX, bool TREE = false>
+template <int NMAX, bool TREE = false, bool RK4 = false>
 __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a,
                                                                     const FeedbackWaveArgs fb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -312,6 +315,17 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
     if (bad) { failed = true; break; }  // RolloutDiscrete returns at the first warning (trajectory.cc:268-272)
     total += cost;
     if (last) break;
+    if constexpr (RK4) {
+      if (m.integrator == 1) {
+        const bool warned = wave_rk4_step<NMAX, TREE>(m, tk, d, tree, lane, time, /*have_warm=*/t > 0);
+        if (lane < 3 * tk.ntrace) {  // the trace of an RK4 step is the last stage's (wave_kernel.h)
+          const int ts = tk.trace_site[lane / 3];
+          a.trace[((size_t)cand * H + t) * 3 * tk.ntrace + lane] = ts >= 0 ? d.site_xpos[3 * ts + lane % 3] : d.xpos[3 * (-1 - ts) + lane % 3];
+        }
+        if (warned) { failed = true; break; }
+        continue;
+      }
+    }
     if (lane < nv) d.qacc_warm[lane] = d.qacc[lane];
     if constexpr (TREE) wt_euler<NMAX>(m, d, lane, time);
     else wf_euler<NMAX>(m, d, lane, time);

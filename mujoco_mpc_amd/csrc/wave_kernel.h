@@ -62,6 +62,46 @@ __device__ __forceinline__ WaveData wave_carve(unsigned char* smem_raw, const MO
 }
 
 // One candidate's Trajectory::Rollout + UpdateReturn by one wavefront; `smem_raw` is the wavefront's own arena in LDS.
+// mj_RungeKutta(m, d, 4), MuJoCo engine_forward.c (restated in oracle/physics.c o_rk4), after the step's own forward pass: F_0 = (qvel,
+// qacc) of that pass; stages 1..3 at X_0 + h A_i F_{i-1} with A = (1/2, 1/2, 1), no sensor stage, the solver warm-started from the
+// previous STEP in every stage; then X_0 + h sum B_i F_i, B = (1/6, 1/3, 1/3, 1/6), and the last stage's qacc becomes the next
+// step's warm start. No implicit joint damping. The stage values live in registers (one lane per coordinate: nq, nv <= 64), so
+// the LDS arena is the Euler kernel's. On return d holds the last stage's kinematics (site_xpos / xpos: the trace of the step) and
+// the advanced state; the result says whether any stage raised a solver / capacity warning (wave-uniform).
+template <int NMAX, bool TREE, class MODEL, class TASK>
+__device__ __forceinline__ bool wave_rk4_step(const MODEL& m, const TASK& tk, WaveData& d, TreeData& tree, int lane, wreal& time, bool have_warm) {
+  const int nq = m.nq, nv = m.nv;
+  const wreal hh = m.timestep, t0 = time;
+  const wreal q0 = lane < nq ? d.qpos[lane] : WL(0.0), v0 = lane < nv ? d.qvel[lane] : WL(0.0);
+  wreal kv = v0, ka = lane < nv ? d.qacc[lane] : WL(0.0);
+  wreal sv = WL(1.0) / WL(6.0) * kv, sa = WL(1.0) / WL(6.0) * ka;
+#pragma unroll 1
+  for (int stage = 1; stage < 4; stage++) {
+    const wreal c = stage == 3 ? WL(1.0) : WL(0.5), b = stage == 3 ? WL(1.0) / WL(6.0) : WL(1.0) / WL(3.0);
+    WSYNC();
+    if (lane < nq) d.qpos[lane] = q0;
+    if (lane < nv) { d.tmpv[lane] = c * kv; d.qvel[lane] = v0 + hh * (c * ka); }
+    WSYNC();
+    w_integrate_pos(m, d, d.tmpv, hh, lane);
+    WSYNC();
+    time = t0 + c * hh;
+    bool bc2 = false;
+    if constexpr (TREE) wt_forward<NMAX>(m, tk, d, tree, lane, bc2, nullptr, have_warm);
+    else wf_forward<NMAX>(m, tk, d, lane, bc2, nullptr, have_warm);
+    if (lane < nv) { kv = d.qvel[lane]; ka = d.qacc[lane]; }
+    sv += b * kv; sa += b * ka;
+  }
+  const bool warned = d.counters[2] != 0;
+  WSYNC();
+  if (lane < nq) d.qpos[lane] = q0;
+  if (lane < nv) { d.tmpv[lane] = sv; d.qvel[lane] = v0 + hh * sa; d.qacc_warm[lane] = d.qacc[lane]; }
+  WSYNC();
+  w_integrate_pos(m, d, d.tmpv, hh, lane);
+  time = t0 + hh;
+  WSYNC();
+  return __any(warned);
+}
+
 // RK4 = true compiles mj_RungeKutta(m, d, 4) in beside mj_Euler (chosen at run time by the model's integrator): three more forward
 // passes per step, which share one extra inlined copy of the forward pass. The stage values live in registers (one lane per
 // coordinate), so the LDS arena is the Euler kernel's.
@@ -235,45 +275,14 @@ __device__ __forceinline__ void wave_rollout_body(const MODEL& m, const TASK& tk
     WSTAMP(13);
     if constexpr (RK4) {
       if (m.integrator == 1) {
-        // ================= mj_RungeKutta(m, d, 4), MuJoCo engine_forward.c (restated in oracle/physics.c o_rk4): F_0 = (qvel, qacc) of the
-        // forward pass above; stages 1..3 at X_0 + h A_i F_{i-1} with A = (1/2, 1/2, 1), no sensor stage, the solver warm-started
-        // from the previous STEP in every stage; then X_0 + h sum B_i F_i, B = (1/6, 1/3, 1/3, 1/6), and the last stage's qacc
-        // becomes the next step's warm start. No implicit joint damping.
-        const wreal hh = m.timestep, t0 = time;
-        const wreal q0 = lane < nq ? d.qpos[lane] : WL(0.0), v0 = lane < nv ? d.qvel[lane] : WL(0.0);
-        wreal kv = v0, ka = lane < nv ? d.qacc[lane] : WL(0.0);
-        wreal sv = WL(1.0) / WL(6.0) * kv, sa = WL(1.0) / WL(6.0) * ka;
-#pragma unroll 1
-        for (int stage = 1; stage < 4; stage++) {
-          const wreal c = stage == 3 ? WL(1.0) : WL(0.5), b = stage == 3 ? WL(1.0) / WL(6.0) : WL(1.0) / WL(3.0);
-          WSYNC();
-          if (lane < nq) d.qpos[lane] = q0;
-          if (lane < nv) { d.tmpv[lane] = c * kv; d.qvel[lane] = v0 + hh * (c * ka); }
-          WSYNC();
-          w_integrate_pos(m, d, d.tmpv, hh, lane);
-          WSYNC();
-          time = t0 + c * hh;
-          bool bc2 = false;
-          if constexpr (TREE) wt_forward<NMAX>(m, tk, d, tree, lane, bc2, nullptr, /*have_warm=*/t > 0);
-          else wf_forward<NMAX>(m, tk, d, lane, bc2, nullptr, /*have_warm=*/t > 0);
-          if (lane < nv) { kv = d.qvel[lane]; ka = d.qacc[lane]; }
-          sv += b * kv; sa += b * ka;
-        }
+        const bool warned = wave_rk4_step<NMAX, TREE>(m, tk, d, tree, lane, time, /*have_warm=*/t > 0);
         // data->site_xpos / xpos after mj_step are the LAST stage's: that is what Trajectory::Rollout copies into the trace
         // (trajectory.cc:165), so the row recorded above from the first stage is replaced
         if (lane < 3 * tk.ntrace) {
           const int ts = tk.trace_site[lane / 3];
           a.trace[((size_t)cand * H + t) * 3 * tk.ntrace + lane] = ts >= 0 ? d.site_xpos[3 * ts + lane % 3] : d.xpos[3 * (-1 - ts) + lane % 3];
         }
-        const bool warned = d.counters[2] != 0;
-        WSYNC();
-        if (lane < nq) d.qpos[lane] = q0;
-        if (lane < nv) { d.tmpv[lane] = sv; d.qvel[lane] = v0 + hh * sa; d.qacc_warm[lane] = d.qacc[lane]; }
-        WSYNC();
-        w_integrate_pos(m, d, d.tmpv, hh, lane);
-        time = t0 + hh;
-        WSYNC();
-        if (__any(warned)) { failed = true; fail_info = (d.counters[2] << 8) | (t << 16); break; }  // CheckWarnings after mj_step
+        if (warned) { failed = true; fail_info = (d.counters[2] << 8) | (t << 16); break; }  // CheckWarnings after mj_step
         continue;
       }
     }

@@ -161,3 +161,34 @@ def test_rollout_feedback(cartpole, mode, representation, use_state):
             assert close(getattr(tr, name), ref[name][c], 1e-9), (name, c)
     if use_state:
         assert np.ptp(ret) > 1e-6
+
+
+def test_ilqg_lane_kernels_with_the_rk4_integrator(cartpole):
+    """mjINT_RK4 through lane_integrate in the finite-difference sweep and the feedback rollouts of the candidate-per-lane family"""
+    H = 20
+    pm, pt = cartpole.packed_model(), cartpole.packed()
+    pm.struct.integrator = 1
+    P = 5
+    times = np.linspace(0, (H - 1) * pm.struct.timestep, P)
+    nodes = np.clip(np.random.default_rng(9).normal(0, 0.5, (1, P, 1)), -1, 1)
+    state = [0.3, 2.0, 0.1, -0.5]
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, None, 1, H, P, 2, times, nodes)
+    nom = {k: v[0] for k, v in ref.items()}
+    ctx = capi.Context(pm, pt, 0, 64)
+    A, B, C, D = ctx.transition_fd(nom["times"], nom["states"], nom["actions"], 1e-6, 1)
+    Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], 1e-6, 1)
+    for g, o in ((A, Ao), (B, Bo), (C, Co), (D, Do)):
+        assert close(g, o, 5e-8), np.abs(g - o).max()
+    rng = np.random.default_rng(3)
+    gains, improvement = 0.5 * rng.normal(size=(H, 1, 4)), 0.2 * rng.normal(size=(H, 1))
+    alpha = np.array([1.0, 0.5, 0.1, 0.0])
+    start = [0.32, 1.95, 0.15, -0.45]
+    ctx.set_state(start, 0.0)
+    ctx.rollout_feedback(H, 1, 2, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+    ret, fail = ctx.returns()
+    refb = pyoracle.rollout_feedback(pm, pt, start, 0.0, None, H, 1, 2, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+    assert np.array_equal(fail, refb["failure"]) and close(ret, refb["total_return"], 1e-9)
+    tr = ctx.fetch_trajectory(2)
+    for name in ("states", "actions", "times", "residual", "costs", "trace"):
+        assert close(getattr(tr, name), refb[name][2], 1e-9), name
+    ctx.close()

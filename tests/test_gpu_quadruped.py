@@ -213,6 +213,45 @@ def test_rollout_feedback_on_the_quadruped(quad, mode, representation, use_state
     ctx.close()
 
 
+@pytest.mark.parametrize("tree", [True, False])
+def test_ilqg_kernels_with_the_rk4_integrator(quad, tree, monkeypatch):
+    """mjINT_RK4 in the iLQG entry points of the wavefront family: the finite-difference sweep (every perturbed column is one RK4
+    step = four forward passes) and the feedback rollouts, on both forward-pass forms, against the oracle's RK4"""
+    if not tree:
+        monkeypatch.setenv("MJPCX_NO_TREE", "1")
+    H = 8
+    pm, pt = quad.packed_model(), quad.packed()
+    pm.struct.integrator = 1
+    rng = np.random.default_rng(21)
+    home = quad.model.keyframes["home"]["qpos"]
+    state = np.concatenate([home, np.zeros(18)])
+    times = np.arange(4) * (H - 1) * 0.01 / 3
+    nodes = np.clip(rng.normal(0, 0.15, (1, 4, 12)), -1, 1)
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, 1, H, 4, 1, times, nodes, num_threads=1)
+    nom = {k: v[0] for k, v in ref.items() if k not in ("total_return", "failure")}
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(state, 0.0, MOCAP)
+    A, B, C, D = ctx.transition_fd(nom["times"], nom["states"], nom["actions"], 1e-6, 0)
+    Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], 1e-6, 0, mocap=MOCAP)
+    for g, o in ((A, Ao), (B, Bo), (C, Co), (D, Do)):
+        assert close(g, o, 2e-5), float(np.abs(g - o).max())
+    gains = 0.05 * rng.normal(size=(H, 12, 36))
+    improvement = 0.05 * rng.normal(size=(H, 12))
+    alpha = np.array([1.0, 0.3, 0.0])
+    start = state.copy()
+    start[19:] = 0.05 * rng.normal(size=18)
+    ctx.set_state(start, 0.0, MOCAP)
+    ctx.rollout_feedback(H, 1, 1, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+    ret, fail = ctx.returns()
+    refb = pyoracle.rollout_feedback(pm, pt, start, 0.0, MOCAP, H, 1, 1, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+    assert np.array_equal(fail, refb["failure"]) and not fail.any()
+    assert close(ret, refb["total_return"], 1e-7)
+    tr = ctx.fetch_trajectory(1)
+    for name in ("states", "actions", "times", "residual", "costs", "trace"):
+        assert close(getattr(tr, name), refb[name][1], 1e-7), name
+    ctx.close()
+
+
 def test_ilqg_planner_on_the_quadruped():
     """BASELINE configs[4] in miniature: iLQG on the A1 (T = 36, 10 line-search rollouts, forward differences) -- the
     device sweep (49 perturbed steps per time step), cost derivatives, the MFMA Riccati pass at n = 36, m = 12 and the
