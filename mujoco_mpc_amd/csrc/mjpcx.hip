@@ -339,7 +339,7 @@ struct mjpcx_ctx {
   bool no_tree = false;  // MJPCX_NO_TREE=1: keep the row-table constraint path (A/B runs)
   bool no_lds_model = false;  // MJPCX_NO_LDS_MODEL=1: generic kernel even for a registered model (A/B runs)
   int max_waves = 8;          // MJPCX_TREE_WAVES=<1..8>: wavefronts per workgroup of the registered-model kernel
-  int tree_mode = 0;          // MJPCX_TREE_MODE=2: image self-check launch (tree_kernel.h)
+  int tree_mode = 16;         // tree_kernel.h mode bits: 16 dynamic candidate hand-out (default), 8 arena poison, 2 image self-check (MJPCX_TREE_MODE)
   bool no_second_pass = false;  // MJPCX_TREE_ONE_PASS=1: leave list overflows as failures (tuning: counts them)
   // multi-GPU (mjpcx_comm_*): the RCCL communicator of this context's rank and its staging buffers
   void* comm = nullptr;
@@ -554,7 +554,7 @@ hipError_t launch_tree_pass(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTas
   const size_t lds = fixed + (size_t)W * arena;
   hipError_t e = c->d_work.reserve(16);
   if (e != hipSuccess) return e;
-  if (mode & 2) if ((e = hipMemsetAsync(c->d_work.p, 0, 8, c->stream)) != hipSuccess) return e;
+  if (mode & (2 | 16)) if ((e = hipMemsetAsync(c->d_work.p, 0, 16, c->stream)) != hipSuccess) return e;  // self-check count / work counter
   // first pass: one slab per wavefront for the cones beyond the LDS list (wave_tree.h; a few tens of MB, never touched in the common case)
   void* slabs = nullptr;
   if (!BIG && !c->no_cone_slabs) {

@@ -3,10 +3,11 @@
 //   * the model's hot arrays staged ONCE per workgroup into LDS behind compile-time offsets (lds_model.h): no global
 //     load, no pointer held in SGPRs and no run-time size in the step loop;
 //   * up to 8 wavefronts per workgroup sharing that image, each with its own candidate arena;
-//   * persistent wavefronts (grid-stride over the candidates): the image is staged once per CU, and a long rollout (more
-//     Newton iterations) does not hold a whole workgroup's LDS back.
+//   * persistent wavefronts drawing candidates from an atomic counter: the image is staged once per CU, and a long rollout (more
+//     Newton iterations) neither holds a whole workgroup's LDS back nor decides when the launch ends.
 namespace mjpcx { namespace WAVE_NS {
 
+// mode bit 4 (16): dynamic candidate hand-out (the default; 0 = static grid stride, for A/B runs: tools/ab_mode.sh)
 // mode bit 3 (8): poison every arena before each rollout (uninitialised-read detector, tests/test_gpu_quadruped.py)
 // mode bit 1: self-check -- compare the staged image with the generic model's arrays, mismatches are counted in work[1]
 //             and the launch rolls nothing out (tuning / bring-up aid, MJPCX_TREE_CHECK=1)
@@ -54,20 +55,32 @@ __global__ __launch_bounds__(512) void rollout_tree_kernel(const WModel m_in, co
     if (bad) atomicAdd(work + 1, bad);
     return;
   }
-  // persistent wavefronts, static assignment: a dynamic (atomic-counter) hand-out was tried and faulted on this toolchain; the
-  // grid-stride form leaves at most one rollout of imbalance per wavefront
+  // Persistent wavefronts. Every wavefront starts on candidate (workgroup, wavefront); after that, mode bit 4 (16) hands the
+  // remaining candidates out through one atomic counter (work[2], zeroed by the host before the launch) -- a wavefront that drew
+  // cheap rollouts (few Newton iterations) takes more of them, so the launch ends with the mean, not with the unluckiest
+  // stride; without the bit, the static grid stride. Results do not depend on which wavefront rolls a candidate out.
   // cones beyond the LDS list go to this wavefront's slab in global memory (wave_tree.h)
+  const int total_waves = gridDim.x * (nth >> 6);
   wreal* slab = cone_slabs ? cone_slabs + (size_t)(blockIdx.x * (nth >> 6) + wave) * (size_t)((kTreeMaxConeTotal - kTreeMaxCone) * kConeRec) : nullptr;
-  for (int cand = blockIdx.x * (nth >> 6) + wave; cand < a.N; cand += gridDim.x * (nth >> 6)) {
+  const bool dynamic = !BIG && (mode & 16);
+  int cand = blockIdx.x * (nth >> 6) + wave;
+  while (cand < a.N) {
     if (mode & 8) {  // bring-up aid (MJPCX_TREE_MODE=8): poison the arena -- a read of storage this rollout never wrote shows up as NaN / -1
       for (unsigned i = lane; i < arena_bytes / 4; i += 64) reinterpret_cast<unsigned*>(arena)[i] = 0xFFFFFFFFu;
       WSYNC();
     }
     if constexpr (BIG) {
-      if (!(a.failure[cand] & (32 << 8))) continue;  // wave-uniform
-      wave_rollout_body<C::NV, true, kTreeMaxSimpleBig, kTreeMaxConeBig>(m, tk, a, arena, cand, lane);
+      if (a.failure[cand] & (32 << 8))  // wave-uniform
+        wave_rollout_body<C::NV, true, kTreeMaxSimpleBig, kTreeMaxConeBig>(m, tk, a, arena, cand, lane);
     } else {
       wave_rollout_body<C::NV, true>(m, tk, a, arena, cand, lane, slab);
+    }
+    if (dynamic) {
+      int next = 0;
+      if (lane == 0) next = atomicAdd(work + 2, 1);
+      cand = total_waves + __builtin_amdgcn_readfirstlane(next);
+    } else {
+      cand += total_waves;
     }
   }
 }
