@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from mujoco_mpc_amd import capi, cstructs
@@ -106,3 +108,25 @@ def test_moving_geom_pairs_the_kernels_cannot_collide_are_reported():
     ctx = capi.Context(hum.packed_model(), hum.packed(), 0, 64)
     assert ctx.create_warning == ""
     ctx.close()
+
+
+def test_registered_tree_configs_match_the_shipped_models():
+    """csrc/tree_registry.h fixes the dimensions of the LDS-staged kernel at build time; they must be the shipped A1 model's, or
+    the north-star workload silently runs the generic kernel (the smoke test asserts the kernel name on the GPU; this one needs none)"""
+    import re
+    from mujoco_mpc_amd.task import load_task
+    src = open(os.path.join(ROOT, "mujoco_mpc_amd", "csrc", "tree_registry.h")).read()
+    body = src[src.index("struct TreeCfgA1"):]
+    cfg = {k: int(v) for k, v in re.findall(r"\b(N[A-Z]+) = (\d+)", body[:body.index("};")])}
+    t = load_task("QuadrupedFlat")
+    m, a = t.model, t.model.arrays
+    st = t.packed().struct
+    dofs_of_body = np.zeros(m.nbody, int)
+    for b in range(1, m.nbody):
+        dofs_of_body[b] = dofs_of_body[a["body_parentid"][b]] + a["body_dofnum"][b]
+    coll = [g for g in range(m.ngeom) if a["geom_contype"][g] or a["geom_conaffinity"][g]]
+    expect = dict(NQ=m.nq, NV=m.nv, NU=m.nu, NB=m.nbody, NJ=m.njnt, NS=m.nsite, NG=m.ngeom, NKEY=len(m.keyframes), NMOCAP=m.nmocap,
+                  NSG=sum(dofs_of_body[a["geom_bodyid"][g]] == 0 for g in coll), NDG=sum(dofs_of_body[a["geom_bodyid"][g]] > 0 for g in coll),
+                  NRAY=sum(a["geom_group"][g] == 0 and a["geom_type"][g] in (0, 2, 6) for g in range(m.ngeom)),
+                  NR=st.num_residual, NTERM=st.num_term, NTRACE=st.num_trace)
+    assert cfg == {k: int(v) for k, v in expect.items()}, (cfg, expect)
