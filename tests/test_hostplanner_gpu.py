@@ -356,3 +356,34 @@ def test_cpp_planner_with_a_native_one_rank_communicator(particle):
         assert ref.winner == nat.winner and ref.best_score == nat.best_score
     assert np.array_equal(ref.policy()[1], nat.policy()[1])
     nat.comm_barrier()
+
+
+def test_agent_integrator_rk4_reaches_the_device_through_the_cpp_planner():
+    """`<numeric name="agent_integrator" data="1"/>` (mjINT_RK4) in a task: Agent::PlanIteration plans on a model copy with that
+    integrator (agent.cc:288-291). The C++ planner passes it through FlatModel to the device; plans equal the Python mirror's, which
+    reads the same numeric, and differ from the Euler plans of the same seed."""
+    import copy
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.planners import GpuSamplingPlanner, State
+    from mujoco_mpc_amd.task import load_task
+    euler = load_task("Cartpole")
+    rk4 = load_task("Cartpole")
+    rk4.model = copy.deepcopy(rk4.model)
+    rk4.model.numeric["agent_integrator"] = [1.0]
+    assert rk4.packed_model().struct.integrator == 1 and euler.packed_model().struct.integrator == 0
+    H, N = 40, 256
+    plans = {}
+    for name, task in (("euler", euler), ("rk4", rk4)):
+        cpp = HostPlanner(task, seed=3, num_trajectory=N)
+        cpp.reset(H)
+        py = GpuSamplingPlanner(seed=3)
+        py.initialize(task.model, task); py.num_trajectory_ = N; py.allocate(); py.reset(H)
+        st = State(task.model)
+        for k in range(3):
+            q, v, t = [0.1 * k, 0.5], [0.0, -0.1], 0.04 * k
+            st.set(q, v, time=t); py.set_state(st); py.optimize_policy(H)
+            cpp.set_state(q, v, t); cpp.optimize_policy(H)
+            assert cpp.winner == py.winner and cpp.best_score == py.candidate_score(0)
+        plans[name] = (cpp.best_score, cpp.policy()[1].copy())
+        cpp.close()
+    assert plans["euler"][0] != plans["rk4"][0]
