@@ -1,0 +1,387 @@
+// quad_model.h -- model constants of the QUAD kernel family (quad_step.h, quad_kernel.h): four lanes per candidate, one lane
+// per LEG of a legged floating-base robot (the Unitree A1 of BASELINE configs[2]: trunk with a free joint + 4 chains of 3 hinge
+// links). Sixteen candidates share a wavefront; every per-leg quantity (kinematics of the three links, the leg's 3 x 3 block
+// of M and of the Newton Hessian, its contacts, friction-loss and limit rows, its three actuators) lives in the lane's own
+// registers, everything of the trunk is replicated in the four lanes, and the only cross-lane traffic is DPP quad
+// permutes (sums over the four legs). The inertia matrix of such a tree is an ARROWHEAD: four independent 3 x 3 leg blocks
+// coupled only through the 6 x 6 trunk block -- a contact on a leg touches the trunk dofs and that leg's dofs, so the
+// Newton Hessian M + J' D J keeps that shape (quad_step.h: qd_arrow_factor).
+//
+// This header is plain C++ (no HIP): the host builds the struct once per context (mjpcx_create) and the CPU emulator of the
+// kernel (tests/quademu, test infrastructure) builds the same one.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mjpcx.h"
+
+namespace mjpcx {
+
+constexpr int kQLegs = 4, kQLinks = 3;
+constexpr int kQLegGeom = 8;     // collidable geoms per leg
+constexpr int kQTrunkGeom = 8;   // collidable geoms on the trunk (dealt over the four lanes: lane l tests geoms l, l + 4)
+constexpr int kQStatic = 4;      // collidable static geoms (world / mocap bodies)
+constexpr int kQPairGeom = 6;    // sphere | capsule geoms per leg in moving-geom pairs; kQTrunkPairGeom on the trunk
+constexpr int kQTrunkPairGeom = 2;
+constexpr int kQMaxKey = 4, kQMaxTrace = 2, kQMaxTerm = 16, kQMaxRay = 4;
+constexpr int kQMaxCon = 6;      // contacts per lane and step; more -> the candidate is handed to the wavefront-per-candidate kernel
+constexpr int kQFallback = 0x40000000;  // failure[] marker of a candidate the quad kernel handed on (cleared by the fallback pass)
+
+// contact parameters of a (static geom, moving geom) pair: mj_contactParam with solref / solimp pre-digested
+// (oracle/contact.inc contact_param, solref_kb, impedance's clipping)
+struct QuadPair {
+  int collide, dim;
+  double margin, includemargin, mu, fric1, fric3, fric4;  // mu = friction[0] / sqrt(impratio); tangential, torsional, rolling
+  double k, b;                                            // reference acceleration: aref = -b vel - k imp pos
+  double imp[5];                                          // dmin dmax width mid power, clipped
+  double diag;                                            // mj_diagApprox: translational body_invweight0 of the two bodies
+};
+
+struct QuadGeom {
+  int type, link, model_id, pad;  // link: -1 trunk, 0..2 link of the lane's leg
+  double pos[3], rot[9], size[3]; // pose in the body frame (rotation matrix of geom_quat)
+};
+
+struct QuadStatic {
+  int type, mocap, model_id, ray;  // mocap: mocap id of its body or -1 (world); ray: group 0 (Ground() casts against it)
+  double pos[3], rot[9], size[3];  // pose in the body frame (world body: world pose)
+};
+
+struct QuadLeg {
+  double body_pos[kQLinks][3], body_quat[kQLinks][4], body_ipos[kQLinks][3], body_iquat[kQLinks][4];
+  double body_mass[kQLinks], body_inertia[kQLinks][3];
+  double jnt_pos[kQLinks][3], jnt_axis[kQLinks][3];
+  double qpos0[kQLinks], qpos_spring[kQLinks], stiffness[kQLinks], armature[kQLinks], damping[kQLinks];
+  double range[kQLinks][2], margin[kQLinks];
+  double lim_k[kQLinks], lim_b[kQLinks], lim_imp[kQLinks][5], lim_diag[kQLinks];
+  double floss[kQLinks], floss_R[kQLinks], floss_D[kQLinks], floss_b[kQLinks];
+  double act_gear[kQLinks], act_gain[kQLinks], act_bias[kQLinks][3], ctrlrange[kQLinks][2], forcerange[kQLinks][2];
+  double key_q[kQMaxKey][kQLinks];  // keyframe joint values of this leg (Posture residual)
+  int limited[kQLinks], act_biastype[kQLinks], ctrllimited[kQLinks], forcelimited[kQLinks];
+  int ngeom, foot_slot, foot_index, npg;  // foot_slot: the leg's geom the residual reads; foot_index: its place in foot_geom_id_ (FL HL FR HR)
+  int pg_slot[kQPairGeom];                // the leg's sphere | capsule geoms that can touch another leg or the trunk (self-collision test)
+  QuadGeom geom[kQLegGeom];
+};
+
+struct QuadModel {
+  double timestep, gravity[3], tolerance, meaninertia, total_mass;
+  int iterations, gravity_on, nstatic, ntrunk_geom, ntrace, nterm, nr, nray;
+  // trunk
+  double trunk_ipos[3], trunk_iquat[4], trunk_mass, trunk_inertia[3];
+  double head_pos[3];               // the site the Position residual reads (trunk frame)
+  double trace_pos[kQMaxTrace][3];  // traced points (trunk frame)
+  QuadGeom trunk_geom[kQTrunkGeom];
+  QuadStatic stat[kQStatic];
+  QuadLeg leg[kQLegs];
+  // cost terms
+  int term_dim[kQMaxTerm], term_norm[kQMaxTerm], term_off[kQMaxTerm];
+  // model ids the host needs when it decodes results
+  int trunk_body, first_leg_body, goal_mocap, npair;
+  // self-collision: the moving-geom pairs MuJoCo's filters leave are ALL pairs (leg geom, geom of another leg) and (trunk geom, leg geom)
+  // over these sets (checked by quad_build); the kernel only tests them -- a pair within pair_margin hands the candidate on
+  int ntpg, tpg_slot[kQTrunkPairGeom];
+  double pair_margin;
+};
+
+// everything the kernel needs that is too rarely read to deserve LDS: the pair table [static][trunk geoms | leg geoms]
+struct QuadTables {
+  QuadPair trunk[kQStatic][kQTrunkGeom];
+  QuadPair leg[kQLegs][kQStatic][kQLegGeom];
+  int npair;
+};
+
+namespace quad_detail {
+inline void quat2mat(double* m, const double* q) {
+  const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  const double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3], q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2 * (q12 - q03); m[2] = 2 * (q13 + q02); m[3] = 2 * (q12 + q03);
+  m[5] = 2 * (q23 - q01); m[6] = 2 * (q13 - q02); m[7] = 2 * (q23 + q01);
+}
+inline double clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+inline void digest_solimp(double* out, const double* solimp) {
+  out[0] = clip(solimp[0], 0.0001, 0.9999); out[1] = clip(solimp[1], 0.0001, 0.9999); out[2] = solimp[2];
+  out[3] = clip(solimp[3], 0.0001, 0.9999); out[4] = solimp[4] < 1 ? 1 : solimp[4];
+}
+inline void solref_kb(const mjpcx_model* m, const double* solref, const double* solimp, double* k, double* b) {
+  const double dmax = clip(solimp[1], 0.0001, 0.9999);
+  if (solref[0] > 0) {
+    double tc = solref[0];
+    if (!(m->disableflags & MJPCX_DSBL_REFSAFE) && tc < 2 * m->timestep) tc = 2 * m->timestep;
+    *k = 1.0 / (dmax * dmax * tc * tc * solref[1] * solref[1]);
+    *b = 2.0 / (dmax * tc);
+  } else {
+    *k = -solref[0] / (dmax * dmax);
+    *b = -solref[1] / dmax;
+  }
+}
+// impedance at zero violation (friction-loss rows: pos = margin = 0)
+inline double impedance0(const double* solimp) {
+  double d[5];
+  digest_solimp(d, solimp);
+  if (d[0] == d[1] || d[2] <= 1e-15) return 0.5 * (d[0] + d[1]);
+  return d[0];
+}
+}  // namespace quad_detail
+
+// Builds the quad kernel's view of a model + task. Returns "" on success, otherwise why the model is outside the class the
+// kernel covers (the caller then keeps the wavefront-per-candidate kernels: not an error).
+inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, QuadModel* qm, QuadTables* qt) {
+  using namespace quad_detail;
+  std::memset(qm, 0, sizeof *qm);
+  std::memset(qt, 0, sizeof *qt);
+  if (m->integrator != MJPCX_INT_EULER) return "integrator is not Euler";
+  if (m->disableflags != 0) return "non-default disable flags";
+  if (m->ntendon != 0 || m->na != 0) return "tendons / activations";
+  if (m->nv != 6 + kQLegs * kQLinks || m->nq != 7 + kQLegs * kQLinks || m->nu != kQLegs * kQLinks) return "not a 6 + 4 x 3 dof model";
+  // the trunk: the only body with a free joint, child of the world; the legs: 12 bodies after it, leg-major, one hinge each
+  int trunk = -1;
+  for (int b = 1; b < m->nbody; b++)
+    if (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == MJPCX_JNT_FREE) { trunk = b; break; }
+  if (trunk < 0 || m->body_parentid[trunk] != 0 || m->body_dofadr[trunk] != 0 || m->jnt_qposadr[m->body_jntadr[trunk]] != 0) return "no floating base at dof 0";
+  if (trunk + kQLegs * kQLinks > m->nbody - 1) return "fewer than 12 bodies after the trunk";
+  for (int b = 1; b < m->nbody; b++) {
+    const bool leg_body = b > trunk && b <= trunk + kQLegs * kQLinks;
+    if (b == trunk || leg_body) continue;
+    if (m->body_dofnum[b] != 0 || m->body_parentid[b] != 0) return "a moving body outside the trunk + legs";
+  }
+  for (int l = 0; l < kQLegs; l++)
+    for (int j = 0; j < kQLinks; j++) {
+      const int b = trunk + 1 + kQLinks * l + j;
+      if (m->body_parentid[b] != (j == 0 ? trunk : b - 1)) return "leg bodies are not chains of the trunk";
+      if (m->body_jntnum[b] != 1 || m->body_dofnum[b] != 1) return "a leg link without exactly one joint";
+      const int jn = m->body_jntadr[b];
+      if (m->jnt_type[jn] != MJPCX_JNT_HINGE) return "a leg joint that is not a hinge";
+      if (m->jnt_dofadr[jn] != 6 + kQLinks * l + j || m->jnt_qposadr[jn] != 7 + kQLinks * l + j) return "leg dofs are not leg-major";
+      if (m->actuator_trnid[kQLinks * l + j] != jn) return "actuators are not one per leg joint, in joint order";
+      if (m->body_mocapid[b] >= 0) return "mocap leg body";
+    }
+  for (int i = 0; i < 6; i++)
+    if (m->dof_frictionloss[i] > 0 || m->dof_damping[i] > 0 || m->dof_armature[i] != 0) return "friction loss / damping / armature on the floating base";
+  if (m->jnt_stiffness[m->body_jntadr[trunk]] != 0) return "spring on the floating base";
+  int max_condim = 1;
+  for (int g = 0; g < m->ngeom; g++) if (m->geom_contype[g] || m->geom_conaffinity[g]) max_condim = std::max(max_condim, (int)m->geom_condim[g]);
+  if (m->cone != 1 && max_condim > 1) return "pyramidal friction cones";
+  if (m->nkey > kQMaxKey) return "more keyframes than the quad kernel stages";
+
+  qm->timestep = m->timestep; qm->tolerance = m->solver_tolerance; qm->meaninertia = m->meaninertia; qm->iterations = m->solver_iterations;
+  for (int k = 0; k < 3; k++) qm->gravity[k] = m->gravity[k];
+  qm->gravity_on = 1;
+  qm->trunk_body = trunk; qm->first_leg_body = trunk + 1;
+  qm->total_mass = m->body_subtreemass ? m->body_subtreemass[trunk] : 0;
+  if (!(qm->total_mass > 0)) {
+    qm->total_mass = 0;
+    for (int b = trunk; b <= trunk + kQLegs * kQLinks; b++) qm->total_mass += m->body_mass[b];
+  }
+  for (int k = 0; k < 3; k++) { qm->trunk_ipos[k] = m->body_ipos[3 * trunk + k]; qm->trunk_inertia[k] = m->body_inertia[3 * trunk + k]; }
+  for (int k = 0; k < 4; k++) qm->trunk_iquat[k] = m->body_iquat[4 * trunk + k];
+  qm->trunk_mass = m->body_mass[trunk];
+
+  for (int l = 0; l < kQLegs; l++) {
+    QuadLeg& L = qm->leg[l];
+    for (int j = 0; j < kQLinks; j++) {
+      const int b = trunk + 1 + kQLinks * l + j, jn = m->body_jntadr[b], dof = 6 + kQLinks * l + j, qa = 7 + kQLinks * l + j, u = kQLinks * l + j;
+      for (int k = 0; k < 3; k++) {
+        L.body_pos[j][k] = m->body_pos[3 * b + k]; L.body_ipos[j][k] = m->body_ipos[3 * b + k]; L.body_inertia[j][k] = m->body_inertia[3 * b + k];
+        L.jnt_pos[j][k] = m->jnt_pos[3 * jn + k]; L.jnt_axis[j][k] = m->jnt_axis[3 * jn + k];
+      }
+      for (int k = 0; k < 4; k++) { L.body_quat[j][k] = m->body_quat[4 * b + k]; L.body_iquat[j][k] = m->body_iquat[4 * b + k]; }
+      L.body_mass[j] = m->body_mass[b];
+      L.qpos0[j] = m->qpos0[qa]; L.qpos_spring[j] = m->qpos_spring[qa]; L.stiffness[j] = m->jnt_stiffness[jn];
+      L.armature[j] = m->dof_armature[dof]; L.damping[j] = m->dof_damping[dof];
+      L.range[j][0] = m->jnt_range[2 * jn]; L.range[j][1] = m->jnt_range[2 * jn + 1]; L.margin[j] = m->jnt_margin[jn];
+      L.limited[j] = m->jnt_limited[jn];
+      if (L.limited[j] && !(L.range[j][1] - L.range[j][0] > 2 * L.margin[j])) return "a joint whose two limits can be active at once";
+      solref_kb(m, m->jnt_solref + 2 * jn, m->jnt_solimp + 5 * jn, &L.lim_k[j], &L.lim_b[j]);
+      digest_solimp(L.lim_imp[j], m->jnt_solimp + 5 * jn);
+      L.lim_diag[j] = m->dof_invweight0[dof];
+      L.floss[j] = m->dof_frictionloss[dof];
+      if (L.floss[j] > 0) {
+        const double imp = impedance0(m->dof_solimp + 5 * dof);
+        double R = (1 - imp) / imp * m->dof_invweight0[dof];
+        if (R < 1e-15) R = 1e-15;
+        double k_;
+        solref_kb(m, m->dof_solref + 2 * dof, m->dof_solimp + 5 * dof, &k_, &L.floss_b[j]);
+        L.floss_R[j] = R; L.floss_D[j] = 1.0 / R;
+      }
+      L.act_gear[j] = m->actuator_gear[u]; L.act_gain[j] = m->actuator_gainprm[3 * u];
+      for (int k = 0; k < 3; k++) L.act_bias[j][k] = m->actuator_biasprm[3 * u + k];
+      L.act_biastype[j] = m->actuator_biastype[u]; L.ctrllimited[j] = m->actuator_ctrllimited[u]; L.forcelimited[j] = m->actuator_forcelimited[u];
+      for (int k = 0; k < 2; k++) { L.ctrlrange[j][k] = m->actuator_ctrlrange[2 * u + k]; L.forcerange[j][k] = m->actuator_forcerange[2 * u + k]; }
+      for (int key = 0; key < m->nkey; key++) L.key_q[key][j] = m->key_qpos[(size_t)key * m->nq + qa];
+    }
+    L.foot_slot = -1; L.foot_index = -1;
+  }
+
+  // ---- geoms: static (world / mocap bodies) and moving (trunk, legs), collidable ones only
+  std::vector<int> slot_leg(m->ngeom, -2), slot_idx(m->ngeom, -1);  // moving geoms: leg (-1 trunk), slot
+  std::vector<int> static_slot(m->ngeom, -1);
+  for (int g = 0; g < m->ngeom; g++) {
+    const int b = m->geom_bodyid[g];
+    const bool collidable = m->geom_contype[g] || m->geom_conaffinity[g];
+    const bool ray = m->geom_group[g] == 0 && (m->geom_type[g] == MJPCX_GEOM_PLANE || m->geom_type[g] == MJPCX_GEOM_SPHERE || m->geom_type[g] == MJPCX_GEOM_BOX);
+    double rot[9];
+    quat2mat(rot, m->geom_quat + 4 * g);
+    if (b < trunk || b > trunk + kQLegs * kQLinks) {  // static
+      if (!collidable && !ray) continue;
+      if (qm->nstatic == kQStatic) return "more static geoms than the quad kernel stages";
+      QuadStatic& s = qm->stat[qm->nstatic];
+      s.type = m->geom_type[g]; s.mocap = m->body_mocapid[b]; s.model_id = g; s.ray = ray;
+      if (b != 0 && s.mocap < 0) return "static geom on a non-mocap body";
+      for (int k = 0; k < 3; k++) { s.pos[k] = m->geom_pos[3 * g + k]; s.size[k] = m->geom_size[3 * g + k]; }
+      std::memcpy(s.rot, rot, sizeof rot);
+      static_slot[g] = collidable ? qm->nstatic : -1;
+      if (!collidable) s.type = -1 - s.type;  // ray-only geom: the collision pass skips it
+      qm->nstatic++;
+      if (ray) qm->nray++;
+      continue;
+    }
+    if (ray) return "a moving geom in group 0 (Ground() would hit it)";
+    if (!collidable) continue;
+    QuadGeom* dst;
+    if (b == trunk) {
+      if (qm->ntrunk_geom == kQTrunkGeom) return "more trunk geoms than the quad kernel stages";
+      slot_leg[g] = -1; slot_idx[g] = qm->ntrunk_geom;
+      dst = &qm->trunk_geom[qm->ntrunk_geom++];
+      dst->link = -1;
+    } else {
+      const int l = (b - trunk - 1) / kQLinks, j = (b - trunk - 1) % kQLinks;
+      QuadLeg& L = qm->leg[l];
+      if (L.ngeom == kQLegGeom) return "more geoms on a leg than the quad kernel stages";
+      slot_leg[g] = l; slot_idx[g] = L.ngeom;
+      dst = &L.geom[L.ngeom++];
+      dst->link = j;
+    }
+    dst->type = m->geom_type[g]; dst->model_id = g;
+    for (int k = 0; k < 3; k++) { dst->pos[k] = m->geom_pos[3 * g + k]; dst->size[k] = m->geom_size[3 * g + k]; }
+    std::memcpy(dst->rot, rot, sizeof rot);
+  }
+  // pair parameters (oracle/contact.inc contact_param; o_collision's type table)
+  const double impratio = m->impratio > 1e-15 ? m->impratio : 1.0;
+  for (int s = 0; s < qm->nstatic; s++) {
+    const int g1 = qm->stat[s].model_id;
+    if (static_slot[g1] < 0) continue;
+    const int t1 = m->geom_type[g1];
+    for (int g2 = 0; g2 < m->ngeom; g2++) {
+      if (slot_leg[g2] == -2) continue;
+      QuadPair& p = slot_leg[g2] < 0 ? qt->trunk[s][slot_idx[g2]] : qt->leg[slot_leg[g2]][s][slot_idx[g2]];
+      const int t2 = m->geom_type[g2];
+      bool ok = (m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]);
+      if (t1 == MJPCX_GEOM_PLANE) ok &= t2 == MJPCX_GEOM_SPHERE || t2 == MJPCX_GEOM_CAPSULE || t2 == MJPCX_GEOM_BOX || t2 == MJPCX_GEOM_CYLINDER;
+      else if (t1 == MJPCX_GEOM_SPHERE || t1 == MJPCX_GEOM_BOX) ok &= t2 == MJPCX_GEOM_SPHERE;
+      else ok = false;
+      p.collide = ok;
+      if (!ok) continue;
+      const double margin = std::max(m->geom_margin[g1], m->geom_margin[g2]), gap = std::max(m->geom_gap[g1], m->geom_gap[g2]);
+      p.margin = margin; p.includemargin = margin - gap;
+      double fr[3], solref[2], solimp[5];
+      const int p1 = m->geom_priority[g1], p2 = m->geom_priority[g2];
+      if (p1 != p2) {
+        const int g = p1 > p2 ? g1 : g2;
+        p.dim = m->geom_condim[g];
+        for (int k = 0; k < 3; k++) fr[k] = m->geom_friction[3 * g + k];
+        std::memcpy(solref, m->geom_solref + 2 * g, sizeof solref);
+        std::memcpy(solimp, m->geom_solimp + 5 * g, sizeof solimp);
+      } else {
+        p.dim = std::max(m->geom_condim[g1], m->geom_condim[g2]);
+        for (int k = 0; k < 3; k++) fr[k] = std::max(m->geom_friction[3 * g1 + k], m->geom_friction[3 * g2 + k]);
+        const double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2];
+        const double mix = (s1 >= 1e-15 && s2 >= 1e-15) ? s1 / (s1 + s2) : (s1 < 1e-15 && s2 < 1e-15 ? 0.5 : (s1 < 1e-15 ? 0.0 : 1.0));
+        for (int k = 0; k < 2; k++) solref[k] = mix * m->geom_solref[2 * g1 + k] + (1 - mix) * m->geom_solref[2 * g2 + k];
+        for (int k = 0; k < 5; k++) solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
+      }
+      if (p.dim != 1 && p.dim != 3 && p.dim != 4 && p.dim != 6) return "unsupported condim";
+      p.fric1 = std::max(fr[0], 1e-5); p.fric3 = std::max(fr[1], 1e-5); p.fric4 = std::max(fr[2], 1e-5);
+      p.mu = p.fric1 / std::sqrt(impratio);
+      solref_kb(m, solref, solimp, &p.k, &p.b);
+      digest_solimp(p.imp, solimp);
+      p.diag = m->body_invweight0[2 * m->geom_bodyid[g1]] + m->body_invweight0[2 * m->geom_bodyid[g2]];
+    }
+  }
+  // moving-geom pairs (oracle/contact.inc bake_pairs): tested only. The kernel walks them as a cross product, so the set must be one.
+  {
+    std::vector<char> in_pair(m->ngeom, 0);
+    int npair = 0;
+    double pmargin = 0;
+    std::vector<std::pair<int, int>> plist;
+    if (m->body_weldid)
+      for (int a = 0; a < m->ngeom; a++)
+        for (int b = a + 1; b < m->ngeom; b++) {
+          if (slot_leg[a] == -2 || slot_leg[b] == -2) continue;
+          const int ta = m->geom_type[a], tb = m->geom_type[b];
+          if ((ta != MJPCX_GEOM_SPHERE && ta != MJPCX_GEOM_CAPSULE) || (tb != MJPCX_GEOM_SPHERE && tb != MJPCX_GEOM_CAPSULE)) continue;
+          if (!((m->geom_contype[a] & m->geom_conaffinity[b]) || (m->geom_contype[b] & m->geom_conaffinity[a]))) continue;
+          const int b1 = m->geom_bodyid[a], b2 = m->geom_bodyid[b];
+          const int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
+          if (w1 == w2) continue;
+          const int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
+          if (w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
+          const int sig = ((b1 < b2 ? b1 : b2) << 16) + (b1 < b2 ? b2 : b1);
+          bool excluded = false;
+          for (int e = 0; e < m->nexclude; e++) excluded |= m->exclude_signature[e] == sig;
+          if (excluded) continue;
+          in_pair[a] = in_pair[b] = 1;
+          plist.emplace_back(a, b);
+          pmargin = std::max(pmargin, std::max(m->geom_margin[a], m->geom_margin[b]));
+          npair++;
+        }
+    for (int g = 0; g < m->ngeom; g++) {
+      if (!in_pair[g]) continue;
+      if (slot_leg[g] < 0) { if (qm->ntpg == kQTrunkPairGeom) return "more trunk geoms in self-collision pairs than staged"; qm->tpg_slot[qm->ntpg++] = slot_idx[g]; }
+      else { QuadLeg& L = qm->leg[slot_leg[g]]; if (L.npg == kQPairGeom) return "more leg geoms in self-collision pairs than staged"; L.pg_slot[L.npg++] = slot_idx[g]; }
+    }
+    int expect = 0;
+    for (int l = 0; l < kQLegs; l++) { expect += qm->leg[l].npg * qm->ntpg; for (int l2 = l + 1; l2 < kQLegs; l2++) expect += qm->leg[l].npg * qm->leg[l2].npg; }
+    for (auto& pr : plist) if (slot_leg[pr.first] == slot_leg[pr.second]) return "a self-collision pair inside one leg";
+    if (npair != expect) return "self-collision pairs are not the cross product of the legs' pair geoms";
+    qt->npair = npair;
+    qm->pair_margin = pmargin;
+  }
+  qm->npair = qt->npair;
+
+  // ---- task: QuadrupedFlat residual (wave_residual.h / oracle/quadruped.inc), traces, cost terms
+  if (task->residual_id != MJPCX_RESIDUAL_QUADRUPED_FLAT) return "residual is not QuadrupedFlat";
+  if (task->num_residual_int < 17 || task->num_residual_real < 30) return "frozen residual state too short";
+  const int32_t* ri = task->residual_int;
+  if (ri[1] != trunk) return "torso body is not the floating base";
+  if (ri[2] < 0 || ri[2] >= m->nsite || m->site_bodyid[ri[2]] != trunk) return "head site is not on the trunk";
+  for (int k = 0; k < 3; k++) qm->head_pos[k] = m->site_pos[3 * ri[2] + k];
+  qm->goal_mocap = ri[3];
+  for (int f = 0; f < 4; f++) {
+    const int g = ri[4 + f];
+    if (g < 0 || g >= m->ngeom || slot_leg[g] < 0) return "a foot geom that is not a collidable leg geom";
+    QuadLeg& L = qm->leg[slot_leg[g]];
+    if (L.foot_slot >= 0) return "two foot geoms on one leg";
+    L.foot_slot = slot_idx[g]; L.foot_index = f;
+  }
+  for (int l = 0; l < kQLegs; l++) if (qm->leg[l].foot_slot < 0) return "a leg without a foot geom";
+  if (ri[15] < 0 || ri[15] >= m->nkey || ri[16] < 0 || ri[16] >= m->nkey) return "home / crouch keyframes missing";
+  if (task->num_trace > kQMaxTrace) return "more traces than the quad kernel records";
+  qm->ntrace = task->num_trace;
+  for (int t = 0; t < task->num_trace; t++) {
+    const int ts = task->trace_site[t];
+    if (ts >= 0) {
+      if (m->site_bodyid[ts] != trunk) return "a traced site off the trunk";
+      for (int k = 0; k < 3; k++) qm->trace_pos[t][k] = m->site_pos[3 * ts + k];
+    } else if (-1 - ts != trunk) return "a traced body other than the trunk";
+  }
+  if (task->num_term > kQMaxTerm) return "more cost terms than the quad kernel stages";
+  qm->nterm = task->num_term; qm->nr = task->num_residual;
+  if (qm->nr != 18 + 2 * m->nu) return "unexpected residual size";
+  for (int k = 0, off = 0; k < task->num_term; k++) {
+    qm->term_dim[k] = task->dim_norm_residual[k]; qm->term_norm[k] = task->norm[k]; qm->term_off[k] = off;
+    off += task->dim_norm_residual[k];
+  }
+  // the kernel's residual code assumes the reference's term partition: Upright 3 | Height 1 | Position 3 | Gait 4 | Balance 2 |
+  // Effort nu | Posture nu | Yaw 2 | Angmom 3
+  const int want[9] = {3, 1, 3, 4, 2, m->nu, m->nu, 2, 3};
+  if (task->num_term != 9) return "unexpected cost-term partition";
+  for (int k = 0; k < 9; k++) if (task->dim_norm_residual[k] != want[k]) return "unexpected cost-term partition";
+  return "";
+}
+
+}  // namespace mjpcx

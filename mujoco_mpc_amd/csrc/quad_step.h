@@ -1,0 +1,1537 @@
+// quad_step.h -- the step function of the QUAD kernel family: Trajectory::Rollout (mjpc/trajectory.cc:100-210) of ONE candidate
+// by FOUR lanes, one per leg of a floating-base quadruped (quad_model.h). Written as a SIMT program: every variable is the
+// calling lane's own; `leg` is the lane's index in its quad. The only cross-lane operations are the quad primitives
+//     qd_sum(x)        sum over the four lanes of the quad, bit-identical in all four
+//     qd_bcast<k>(x)   lane k's value
+//     qd_or(i)         bitwise or over the quad
+// which the including translation unit provides (DPP quad permutes on gfx950: quad_kernel.h; a four-thread lock-step
+// emulator on the CPU: tests/quademu, test infrastructure). Control flow around a primitive is quad-uniform by
+// construction: every loop bound and branch condition on such a path derives from quad-summed or trunk (replicated) values.
+//
+// The physics is the oracle's (oracle/physics.c, contact.inc, quadruped.inc -- restating mj_step / mj_forward and
+// QuadrupedFlat::ResidualFn::Residual), re-derived for the arrowhead structure of a legged tree:
+//   * everything of the trunk (pose, cdof, 6 x 6 block T of M) is computed redundantly in the four lanes;
+//   * a leg's links, its 3 x 3 block L of M, the 3 x 6 coupling B, its contacts, friction-loss and limit rows live in its lane;
+//   * sums over the legs (centre of mass, composite inertia and bias force of the trunk, Schur complements, line-search
+//     derivatives, costs) are quad sums.
+// No Jacobian is formed: a contact is its frame F and offset from the centre of mass; J v = A V_b with V_b the spatial velocity
+// of its body, J' f a spatial force, and J' D J = S' X S with X = A' (d2s) A a 6 x 6 (as csrc/wave_tree.h does per wavefront).
+//
+// A candidate the quad form does not cover at some step (a contact between two moving geoms, more than kQMaxCon contacts in
+// one lane, an indefinite Hessian, a non-finite state, both limits of a joint) is FLAGGED and handed to the
+// wavefront-per-candidate kernel, which rolls it out from the start (quad_kernel.h): results never depend on which kernel ran.
+#pragma once
+#include <stdint.h>
+
+#include "quad_model.h"
+
+#ifndef QD
+#error "define QD (function qualifiers) and the quad primitives before including quad_step.h"
+#endif
+
+namespace mjpcx { namespace quad {
+
+constexpr double kQMinVal = 1e-15, kQMaxVal = 1e10, kQPi = 3.14159265358979323846;
+constexpr double kQLsTol = 0.01;
+
+enum { kFlagOverflow = 1, kFlagPair = 2, kFlagNotPD = 4, kFlagBad = 8, kFlagLimits = 16 };
+
+// ---------------------------------------------------------------- small algebra
+QD bool qbad(double x) { return !(x <= kQMaxVal && x >= -kQMaxVal); }
+QD void q_mul(double* r, const double* a, const double* b) {
+  const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+QD void q2mat(double* m, const double* q) {
+  const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  const double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3], q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2 * (q12 - q03); m[2] = 2 * (q13 + q02); m[3] = 2 * (q12 + q03);
+  m[5] = 2 * (q23 - q01); m[6] = 2 * (q13 - q02); m[7] = 2 * (q23 + q01);
+}
+QD void q_norm(double* q) {
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < kQMinVal) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else { const double s = 1.0 / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+}
+QD void mv3(double* r, const double* m, const double* v) {
+  const double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+               z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+QD void q_rot(double* r, const double* v, const double* q) { double m[9]; q2mat(m, q); mv3(r, m, v); }
+QD void cr3(double* r, const double* a, const double* b) {
+  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+QD double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+QD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+// rotated inertia R diag(I) R' (6 unique: xx yy zz xy xz yz) -- the part of inert_com that does not need the reference point
+QD void rot_inertia(double* res, const double* inert, const double* mat) {
+  double tmp[9];
+  for (int c = 0; c < 3; c++) { tmp[c] = inert[0] * mat[3 * c]; tmp[3 + c] = inert[1] * mat[3 * c + 1]; tmp[6 + c] = inert[2] * mat[3 * c + 2]; }
+  res[0] = mat[0] * tmp[0] + mat[1] * tmp[3] + mat[2] * tmp[6];
+  res[1] = mat[3] * tmp[1] + mat[4] * tmp[4] + mat[5] * tmp[7];
+  res[2] = mat[6] * tmp[2] + mat[7] * tmp[5] + mat[8] * tmp[8];
+  res[3] = mat[0] * tmp[1] + mat[1] * tmp[4] + mat[2] * tmp[7];
+  res[4] = mat[0] * tmp[2] + mat[1] * tmp[5] + mat[2] * tmp[8];
+  res[5] = mat[3] * tmp[2] + mat[4] * tmp[5] + mat[5] * tmp[8];
+}
+// spatial inertia about the reference point: rotated inertia + parallel-axis terms of the offset `dif` (oracle inert_com)
+QD void inert_shift(double* res, const double* irot, const double* dif, double mass) {
+  res[0] = irot[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+  res[1] = irot[1] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+  res[2] = irot[2] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+  res[3] = irot[3] - mass * dif[0] * dif[1];
+  res[4] = irot[4] - mass * dif[0] * dif[2];
+  res[5] = irot[5] - mass * dif[1] * dif[2];
+  res[6] = mass * dif[0]; res[7] = mass * dif[1]; res[8] = mass * dif[2];
+  res[9] = mass;
+}
+QD void mul_inert(double* res, const double* i, const double* v) {
+  res[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  res[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  res[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  res[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  res[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  res[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+QD void cross_motion(double* res, const double* vel, const double* v) {
+  double a[3], b[3], c[3];
+  cr3(a, vel, v); cr3(b, vel, v + 3); cr3(c, vel + 3, v);
+  res[0] = a[0]; res[1] = a[1]; res[2] = a[2];
+  res[3] = b[0] + c[0]; res[4] = b[1] + c[1]; res[5] = b[2] + c[2];
+}
+QD void cross_force(double* res, const double* vel, const double* f) {
+  double a[3], b[3], c[3];
+  cr3(a, vel, f); cr3(b, vel + 3, f + 3); cr3(c, vel, f + 3);
+  res[0] = a[0] + b[0]; res[1] = a[1] + b[1]; res[2] = a[2] + b[2];
+  res[3] = c[0]; res[4] = c[1]; res[5] = c[2];
+}
+QD double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// solimp (digested: quad_model.h) -> impedance at violation `dist` (oracle impedance())
+QD double impedance(const double* d, double dist) {
+  const double dmin = d[0], dmax = d[1], width = d[2], mid = d[3], power = d[4];
+  if (dmin == dmax || width <= kQMinVal) return 0.5 * (dmin + dmax);
+  const double x = fabs(dist) / width;
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  double y;
+  if (power == 1) y = x;
+  else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+  else y = x <= mid ? pow(x, power) / pow(mid, power - 1) : 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+QD void make_frame(double* frame) {
+  double* x = frame; double* y = frame + 3; double* z = frame + 6;
+  if (x[1] < 0.5 && x[1] > -0.5) { y[0] = 0; y[1] = 1; y[2] = 0; }
+  else { y[0] = 0; y[1] = 0; y[2] = 1; }
+  const double dt = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
+  for (int k = 0; k < 3; k++) y[k] -= dt * x[k];
+  const double n = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+  for (int k = 0; k < 3; k++) y[k] /= n;
+  cr3(z, x, y);
+}
+QD void qd_sum_n(double* v, int n) { for (int i = 0; i < n; i++) v[i] = qd_sum(v[i]); }
+
+// packed lower triangle of a symmetric 6 x 6: (r >= c) at r (r + 1) / 2 + c
+QD constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
+
+// ---------------------------------------------------------------- arrowhead matrices
+// Symmetric positive-definite matrix of the legged tree: per lane the leg block L (3 x 3, packed lower triangle l[tri]), the
+// coupling B (3 leg dofs x 6 trunk dofs); replicated in the four lanes the trunk block T (6 x 6, packed).
+struct Arrow { double l[6], b[3][6], t[21]; };
+// its factor: the leg block as unit-lower L D L' (l10 l20 l21, reciprocal pivots), Z = Lblock^-1 B, and the L D L' factor of
+// the Schur complement S = T - sum_legs B' Z (packed: unit-lower entries below the diagonal, RECIPROCAL pivots on it)
+struct ArrowFactor { double l10, l20, l21, di[3], z[3][6], s[21]; };
+
+QD void leg_solve(const ArrowFactor& f, double* x) {  // x := Lblock^-1 x
+  x[1] -= f.l10 * x[0];
+  x[2] -= f.l20 * x[0] + f.l21 * x[1];
+  x[0] *= f.di[0]; x[1] *= f.di[1]; x[2] *= f.di[2];
+  x[1] -= f.l21 * x[2];
+  x[0] -= f.l10 * x[1] + f.l20 * x[2];
+}
+// returns false (quad-uniform) if a pivot is not positive
+QD bool arrow_factor(const Arrow& a, ArrowFactor& f) {
+  bool ok = true;
+  const double d0 = a.l[0];
+  ok &= d0 > kQMinVal;
+  f.di[0] = 1.0 / d0;
+  f.l10 = a.l[1] * f.di[0]; f.l20 = a.l[3] * f.di[0];
+  const double d1 = a.l[2] - f.l10 * f.l10 * d0;
+  ok &= d1 > kQMinVal;
+  f.di[1] = 1.0 / d1;
+  f.l21 = (a.l[4] - f.l20 * f.l10 * d0) * f.di[1];
+  const double d2 = a.l[5] - f.l20 * f.l20 * d0 - f.l21 * f.l21 * d1;
+  ok &= d2 > kQMinVal;
+  f.di[2] = 1.0 / d2;
+  for (int k = 0; k < 6; k++) {
+    double col[3] = {a.b[0][k], a.b[1][k], a.b[2][k]};
+    leg_solve(f, col);
+    f.z[0][k] = col[0]; f.z[1][k] = col[1]; f.z[2][k] = col[2];
+  }
+  double s[21];
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c <= r; c++) s[tri(r, c)] = a.b[0][r] * f.z[0][c] + a.b[1][r] * f.z[1][c] + a.b[2][r] * f.z[2][c];
+  qd_sum_n(s, 21);
+  for (int i = 0; i < 21; i++) s[i] = a.t[i] - s[i];
+  // L D L' of S (replicated)
+  double d[6];
+  for (int j = 0; j < 6; j++) {
+    double dj = s[tri(j, j)];
+    for (int k = 0; k < j; k++) dj -= s[tri(j, k)] * s[tri(j, k)] * d[k];
+    ok &= dj > kQMinVal;
+    d[j] = dj;
+    const double inv = 1.0 / dj;
+    for (int i = j + 1; i < 6; i++) {
+      double v = s[tri(i, j)];
+      for (int k = 0; k < j; k++) v -= s[tri(i, k)] * s[tri(j, k)] * d[k];
+      s[tri(i, j)] = v * inv;
+    }
+    s[tri(j, j)] = inv;
+  }
+  for (int i = 0; i < 21; i++) f.s[i] = s[i];
+  return qd_or(ok ? 0 : 1) == 0;
+}
+// x := A^-1 x  (xl: the lane's three leg entries, xt: the six trunk entries, replicated)
+QD void arrow_solve(const ArrowFactor& f, double* xl, double* xt) {
+  double zt[6];
+  for (int k = 0; k < 6; k++) zt[k] = f.z[0][k] * xl[0] + f.z[1][k] * xl[1] + f.z[2][k] * xl[2];
+  qd_sum_n(zt, 6);
+  for (int k = 0; k < 6; k++) xt[k] -= zt[k];
+  for (int i = 1; i < 6; i++) for (int k = 0; k < i; k++) xt[i] -= f.s[tri(i, k)] * xt[k];
+  for (int i = 0; i < 6; i++) xt[i] *= f.s[tri(i, i)];
+  for (int i = 4; i >= 0; i--) for (int k = i + 1; k < 6; k++) xt[i] -= f.s[tri(k, i)] * xt[k];
+  leg_solve(f, xl);
+  for (int j = 0; j < 3; j++) for (int k = 0; k < 6; k++) xl[j] -= f.z[j][k] * xt[k];
+}
+// y = A x; yt needs the quad sum of the coupling term
+QD void arrow_mul(const Arrow& a, const double* xl, const double* xt, double* yl, double* yt) {
+  for (int j = 0; j < 3; j++) {
+    double s = 0;
+    for (int i = 0; i < 3; i++) s += a.l[tri(j, i)] * xl[i];
+    for (int k = 0; k < 6; k++) s += a.b[j][k] * xt[k];
+    yl[j] = s;
+  }
+  double c[6];
+  for (int k = 0; k < 6; k++) c[k] = a.b[0][k] * xl[0] + a.b[1][k] * xl[1] + a.b[2][k] * xl[2];
+  qd_sum_n(c, 6);
+  for (int k = 0; k < 6; k++) {
+    double s = c[k];
+    for (int i = 0; i < 6; i++) s += a.t[tri(k, i)] * xt[i];
+    yt[k] = s;
+  }
+}
+// x' y over all 18 dofs (trunk part counted once)
+QD double arrow_dot(const double* xl, const double* xt, const double* yl, const double* yt) {
+  const double s = qd_sum(xl[0] * yl[0] + xl[1] * yl[1] + xl[2] * yl[2]);
+  return s + (xt[0] * yt[0] + xt[1] * yt[1] + xt[2] * yt[2] + xt[3] * yt[3] + xt[4] * yt[4] + xt[5] * yt[5]);
+}
+
+// ---------------------------------------------------------------- per-candidate data
+struct QState {
+  double tq[7], tv[6], lq[3], lv[3];  // trunk qpos (position, quaternion) / qvel, the leg's joint positions / velocities
+  double wt[6], wl[3];                // previous step's qacc (solver warm start)
+  double time;
+};
+
+struct QContact {
+  double F[9], off[3];          // frame (rows: normal, tangent 1, tangent 2), point - centre of mass
+  double D0, mu, f1, f3, f4;    // D of the normal row, regularised mu, friction coefficients (tangential, torsional, rolling)
+  double aref[6], jar[6], jv[6];
+  int dim, depth;               // depth: leg dofs on the body's chain (0: trunk)
+};
+
+// world poses of the static geoms, computed once per rollout (mocap bodies do not move during a rollout)
+struct QStaticPose { double pos[3], mat[9]; };
+
+// what one forward pass leaves for the sensor stage, the recording and the integrator
+struct QForward {
+  Arrow M;
+  double txm[9], txq[4], txipos[3], com[3], comvel[3], head[3], foot[3];
+  double trace[kQMaxTrace][3];
+  double act_force[3];
+  double qacc_l[3], qacc_t[6], fs_l[3], fs_t[6], fc_l[3], fc_t[6];  // qacc; qfrc_smooth; qfrc_constraint
+  int iters;
+};
+
+// world pose of the lane's sphere | capsule geoms that take part in moving-geom pairs (self-collision test)
+struct QPairGeoms { double c[kQPairGeom][3], a[kQPairGeom][3]; };
+
+// rows of a contact acting on the spatial velocity [angular; linear] about the centre of mass
+QD void contact_rows(const QContact& c, double A[6][6]) {
+  for (int r = 0; r < 3; r++) {
+    const double* Fr = c.F + 3 * r;
+    cr3(A[r], c.off, Fr);                      // (off x F_r) . w  =  F_r . (w x off)
+    A[r][3] = Fr[0]; A[r][4] = Fr[1]; A[r][5] = Fr[2];
+    A[r + 3][0] = Fr[0]; A[r + 3][1] = Fr[1]; A[r + 3][2] = Fr[2];
+    A[r + 3][3] = 0; A[r + 3][4] = 0; A[r + 3][5] = 0;
+  }
+}
+QD double cfric(const QContact& c, int j) { return j < 3 ? c.f1 : (j == 3 ? c.f3 : c.f4); }  // friction[j - 1] of row j >= 1
+QD double cD(const QContact& c, int j) { if (j == 0) return c.D0; const double f = cfric(c, j); return c.D0 * (f * f) / (c.mu * c.mu); }
+
+// penalty of one contact at jar: cost, force (= -ds/djar) and zone (0 top, 1 middle, 2 bottom); oracle constraint_cost
+QD double contact_cost(const QContact& c, const double* jar, double* force, int& zone) {
+  const int dim = c.dim;
+  for (int j = 0; j < 6; j++) force[j] = 0;
+  if (dim == 1) {
+    if (jar[0] < 0) { force[0] = -c.D0 * jar[0]; zone = 2; return 0.5 * c.D0 * jar[0] * jar[0]; }
+    zone = 0;
+    return 0;
+  }
+  const double mu = c.mu;
+  double U[6], T = 0;
+  U[0] = jar[0] * mu;
+  for (int j = 1; j < 6; j++) { U[j] = j < dim ? jar[j] * cfric(c, j) : 0.0; T += U[j] * U[j]; }
+  T = sqrt(T);
+  const double N = U[0];
+  if (N >= mu * T || (T <= 0 && N >= 0)) { zone = 0; return 0; }
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    double cost = 0;
+    for (int j = 0; j < 6; j++) if (j < dim) { const double D = cD(c, j); cost += 0.5 * D * jar[j] * jar[j]; force[j] = -D * jar[j]; }
+    zone = 2;
+    return cost;
+  }
+  const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+  force[0] = -Dm * NT * mu;
+  for (int j = 1; j < 6; j++) if (j < dim) force[j] = Dm * NT * mu * U[j] * cfric(c, j) / T;
+  zone = 1;
+  return 0.5 * Dm * NT * NT;
+}
+// first and second derivative of the contact's penalty along jv at jar + alpha jv (oracle constraint_line)
+QD void contact_line(const QContact& c, double alpha, double& g, double& h) {
+  const int dim = c.dim;
+  if (dim == 1) {
+    const double x = c.jar[0] + alpha * c.jv[0];
+    if (x < 0) { g += c.D0 * x * c.jv[0]; h += c.D0 * c.jv[0] * c.jv[0]; }
+    return;
+  }
+  const double mu = c.mu;
+  double U[6], V[6], T = 0;
+  U[0] = (c.jar[0] + alpha * c.jv[0]) * mu; V[0] = c.jv[0] * mu;
+  for (int j = 1; j < 6; j++) {
+    const double f = j < dim ? cfric(c, j) : 0.0;
+    U[j] = (c.jar[j] + alpha * c.jv[j]) * f; V[j] = c.jv[j] * f;
+    T += U[j] * U[j];
+  }
+  T = sqrt(T);
+  const double N = U[0];
+  if (N >= mu * T || (T <= 0 && N >= 0)) return;
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    for (int j = 0; j < 6; j++) if (j < dim) {
+      const double xj = c.jar[j] + alpha * c.jv[j], D = cD(c, j);
+      g += D * xj * c.jv[j]; h += D * c.jv[j] * c.jv[j];
+    }
+    return;
+  }
+  const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+  double UV = 0, VV = 0;
+  for (int j = 1; j < 6; j++) { UV += U[j] * V[j]; VV += V[j] * V[j]; }
+  const double dNT = V[0] - mu * UV / T, d2NT = -mu * (VV / T - UV * UV / (T * T * T));
+  g += Dm * NT * dNT;
+  h += Dm * (dNT * dNT + NT * d2NT);
+}
+// X += A' (d2s/djar2) A for one contact in zone `zone` at jar (oracle constraint_hessian's cone block); X packed 6 x 6
+QD void contact_hessian(const QContact& c, int zone, double* X) {
+  if (zone == 0) return;
+  const int dim = c.dim;
+  double A[6][6];
+  contact_rows(c, A);
+  double Hc[6][6];
+  for (int j = 0; j < 6; j++) for (int k = 0; k < 6; k++) Hc[j][k] = 0;
+  if (zone == 2 || dim == 1) {
+    for (int j = 0; j < 6; j++) if (j < dim) Hc[j][j] = cD(c, j);
+  } else {
+    const double mu = c.mu;
+    double U[6], s[6], T = 0;
+    s[0] = mu; U[0] = c.jar[0] * mu;
+    for (int j = 1; j < 6; j++) { s[j] = j < dim ? cfric(c, j) : 0.0; U[j] = c.jar[j] * s[j]; T += U[j] * U[j]; }
+    T = sqrt(T);
+    const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T;
+    Hc[0][0] = Dm;
+    for (int j = 1; j < 6; j++) {
+      if (j >= dim) continue;
+      Hc[0][j] = Hc[j][0] = -Dm * mu * U[j] / T;
+      for (int k = 1; k < 6; k++)
+        if (k < dim) Hc[j][k] = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? 1.0 / T : 0.0) - U[j] * U[k] / (T * T * T));
+    }
+    for (int j = 0; j < 6; j++) for (int k = 0; k < 6; k++) Hc[j][k] *= s[j] * s[k];
+  }
+  // Y = Hc A (dim x 6), X += A' Y
+  double Y[6][6];
+  for (int j = 0; j < 6; j++)
+    for (int q = 0; q < 6; q++) {
+      double v = 0;
+      for (int k = 0; k < 6; k++) v += Hc[j][k] * A[k][q];
+      Y[j][q] = v;
+    }
+  for (int p = 0; p < 6; p++)
+    for (int q = 0; q <= p; q++) {
+      double v = 0;
+      for (int j = 0; j < 6; j++) v += A[j][p] * Y[j][q];
+      X[tri(p, q)] += v;
+    }
+}
+
+// the position-dependent part of a forward pass a lane keeps in registers
+struct QKin {
+  double cdof[3][6];             // the leg's three hinge dofs
+  double ca[3][3], cl[3][3];     // the trunk's rotational dofs: angular = body axes, linear = axis x (com - trunk origin)
+  double xpos[3][3], xmat[3][9]; // link frames
+  double cvel[3][6], cvelT[6];   // spatial velocities of the links / the trunk
+};
+
+// V = spatial velocity of the body at chain depth d for the dof vector (xl, xt): Vp[0] trunk, Vp[d] = + leg dofs < d
+QD void chain_velocity(const QKin& k, const double* xl, const double* xt, double Vp[4][6]) {
+  for (int c = 0; c < 3; c++) {
+    Vp[0][c] = k.ca[0][c] * xt[3] + k.ca[1][c] * xt[4] + k.ca[2][c] * xt[5];
+    Vp[0][3 + c] = xt[c] + k.cl[0][c] * xt[3] + k.cl[1][c] * xt[4] + k.cl[2][c] * xt[5];
+  }
+  for (int j = 0; j < 3; j++) for (int c = 0; c < 6; c++) Vp[j + 1][c] = Vp[j][c] + k.cdof[j][c] * xl[j];
+}
+// trunk dof k of the spatial force Fs: cdofT_k . Fs
+QD double trunk_dot(const QKin& k, int dof, const double* Fs) {
+  if (dof < 3) return Fs[3 + dof];
+  return dot3(k.ca[dof - 3], Fs) + dot3(k.cl[dof - 3], Fs + 3);
+}
+
+// ---------------------------------------------------------------- constraint solve (oracle o_constraint_newton)
+struct QRows {
+  // friction loss (one row per leg dof with frictionloss > 0) and the active joint limit of each joint (side 0: none)
+  double fl_aref[3], fl_jar[3], fl_jv[3];
+  double lm_aref[3], lm_D[3], lm_jar[3], lm_jv[3];
+  int lm_side[3];
+};
+
+// jar = J qacc - aref for every row of the lane
+QD void rows_set_jar(const QuadLeg& L, const QKin& kin, QRows& R, QContact* con, int ncon, const double* xl, const double* xt) {
+  for (int j = 0; j < 3; j++) {
+    R.fl_jar[j] = xl[j] - R.fl_aref[j];
+    R.lm_jar[j] = -R.lm_side[j] * xl[j] - R.lm_aref[j];
+  }
+  double Vp[4][6];
+  chain_velocity(kin, xl, xt, Vp);
+  for (int i = 0; i < ncon; i++) {
+    double A[6][6];
+    contact_rows(con[i], A);
+    const double* V = Vp[con[i].depth];
+    for (int r = 0; r < 6; r++) con[i].jar[r] = r < con[i].dim ? dot6(A[r], V) - con[i].aref[r] : 0.0;
+  }
+}
+QD void rows_set_jv(const QKin& kin, QRows& R, QContact* con, int ncon, const double* xl, const double* xt) {
+  for (int j = 0; j < 3; j++) { R.fl_jv[j] = xl[j]; R.lm_jv[j] = -R.lm_side[j] * xl[j]; }
+  double Vp[4][6];
+  chain_velocity(kin, xl, xt, Vp);
+  for (int i = 0; i < ncon; i++) {
+    double A[6][6];
+    contact_rows(con[i], A);
+    const double* V = Vp[con[i].depth];
+    for (int r = 0; r < 6; r++) con[i].jv[r] = r < con[i].dim ? dot6(A[r], V) : 0.0;
+  }
+}
+// cost of all rows at the current jar (quad sum) and J' force: jl (lane's leg dofs), jt (trunk dofs, quad-summed, replicated)
+QD double rows_cost(const QuadLeg& L, const QKin& kin, const QRows& R, const QContact* con, int ncon, double* jl, double* jt) {
+  double cost = 0;
+  double Fsuf[3][6], Fall[6];
+  for (int c = 0; c < 6; c++) { Fall[c] = 0; Fsuf[0][c] = Fsuf[1][c] = Fsuf[2][c] = 0; }
+  for (int j = 0; j < 3; j++) {
+    double f = 0;
+    if (L.floss[j] > 0) {
+      const double x = R.fl_jar[j], fl = L.floss[j], Rr = L.floss_R[j];
+      if (x <= -Rr * fl) { cost += -0.5 * Rr * fl * fl - fl * x; f += fl; }
+      else if (x >= Rr * fl) { cost += -0.5 * Rr * fl * fl + fl * x; f += -fl; }
+      else { cost += 0.5 * L.floss_D[j] * x * x; f += -L.floss_D[j] * x; }
+    }
+    if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) {
+      cost += 0.5 * R.lm_D[j] * R.lm_jar[j] * R.lm_jar[j];
+      f += -R.lm_side[j] * (-R.lm_D[j] * R.lm_jar[j]);  // J' force, J = -side
+    }
+    jl[j] = f;
+  }
+  for (int i = 0; i < ncon; i++) {
+    double force[6];
+    int zone;
+    cost += contact_cost(con[i], con[i].jar, force, zone);
+    if (zone == 0) continue;
+    const double* F = con[i].F;
+    double fl[3], ft[3], Fs[6];
+    for (int k = 0; k < 3; k++) {
+      fl[k] = F[k] * force[0] + F[3 + k] * force[1] + F[6 + k] * force[2];
+      ft[k] = F[k] * force[3] + F[3 + k] * force[4] + F[6 + k] * force[5];
+    }
+    cr3(Fs, con[i].off, fl);
+    for (int k = 0; k < 3; k++) { Fs[k] += ft[k]; Fs[3 + k] = fl[k]; }
+    for (int c = 0; c < 6; c++) {
+      Fall[c] += Fs[c];
+      if (con[i].depth >= 1) Fsuf[0][c] += Fs[c];
+      if (con[i].depth >= 2) Fsuf[1][c] += Fs[c];
+      if (con[i].depth >= 3) Fsuf[2][c] += Fs[c];
+    }
+  }
+  for (int j = 0; j < 3; j++) jl[j] += dot6(kin.cdof[j], Fsuf[j]);
+  qd_sum_n(Fall, 6);
+  for (int k = 0; k < 6; k++) jt[k] = trunk_dot(kin, k, Fall);
+  return qd_sum(cost);
+}
+// derivatives of the row penalties along the search direction at step alpha (quad sums)
+QD void rows_line(const QuadLeg& L, const QRows& R, const QContact* con, int ncon, double alpha, double& d1, double& d2) {
+  double g = 0, h = 0;
+  for (int j = 0; j < 3; j++) {
+    if (L.floss[j] > 0) {
+      const double x = R.fl_jar[j] + alpha * R.fl_jv[j], fl = L.floss[j], Rr = L.floss_R[j];
+      if (x <= -Rr * fl) g += -fl * R.fl_jv[j];
+      else if (x >= Rr * fl) g += fl * R.fl_jv[j];
+      else { g += L.floss_D[j] * x * R.fl_jv[j]; h += L.floss_D[j] * R.fl_jv[j] * R.fl_jv[j]; }
+    }
+    if (R.lm_side[j] != 0) {
+      const double x = R.lm_jar[j] + alpha * R.lm_jv[j];
+      if (x < 0) { g += R.lm_D[j] * x * R.lm_jv[j]; h += R.lm_D[j] * R.lm_jv[j] * R.lm_jv[j]; }
+    }
+  }
+  for (int i = 0; i < ncon; i++) contact_line(con[i], alpha, g, h);
+  d1 = qd_sum(g); d2 = qd_sum(h);
+}
+
+// Newton solver; on entry qacc = qacc_smooth in (al, at). Returns the flag bits (quad-uniform). Leaves J' force in (fc_l, fc_t).
+QD int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin, const Arrow& M, QRows& R, QContact* con, int ncon,
+                         const double* sl, const double* st, const double* wl, const double* wt, bool have_warm,
+                         double* al, double* at, double* fc_l, double* fc_t, int& iters) {
+  iters = 0;
+  for (int j = 0; j < 3; j++) al[j] = sl[j];
+  for (int k = 0; k < 6; k++) at[k] = st[k];
+  rows_set_jar(L, kin, R, con, ncon, al, at);
+  double cost = rows_cost(L, kin, R, con, ncon, fc_l, fc_t);  // the Gauss term is zero at qacc_smooth
+  if (have_warm) {
+    double dl[3], dt[6], Ml[3], Mt[6];
+    for (int j = 0; j < 3; j++) dl[j] = wl[j] - sl[j];
+    for (int k = 0; k < 6; k++) dt[k] = wt[k] - st[k];
+    arrow_mul(M, dl, dt, Ml, Mt);
+    const double gauss = 0.5 * arrow_dot(dl, dt, Ml, Mt);
+    rows_set_jar(L, kin, R, con, ncon, wl, wt);
+    double jl[3], jt[6];
+    const double cw = gauss + rows_cost(L, kin, R, con, ncon, jl, jt);
+    if (cw < cost) {
+      cost = cw;
+      for (int j = 0; j < 3; j++) { al[j] = wl[j]; fc_l[j] = jl[j]; }
+      for (int k = 0; k < 6; k++) { at[k] = wt[k]; fc_t[k] = jt[k]; }
+    } else {
+      rows_set_jar(L, kin, R, con, ncon, al, at);
+    }
+  }
+  const double scale = 1.0 / (m.meaninertia * 18.0);
+  double improvement = 0;
+  for (int iter = 0; iter < m.iterations; iter++) {
+    // gradient = M (qacc - qacc_smooth) - J' force
+    double dl[3], dt[6], Mal[3], Mat[6], gl[3], gt[6];
+    for (int j = 0; j < 3; j++) dl[j] = al[j] - sl[j];
+    for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
+    arrow_mul(M, dl, dt, Mal, Mat);
+    for (int j = 0; j < 3; j++) gl[j] = Mal[j] - fc_l[j];
+    for (int k = 0; k < 6; k++) gt[k] = Mat[k] - fc_t[k];
+    const double gnorm = sqrt(arrow_dot(gl, gt, gl, gt));
+    if (gnorm == 0) break;
+    if (iter > 0 && (scale * improvement < m.tolerance || scale * gnorm < m.tolerance)) break;
+    // H = M + J' (d2s) J: diagonal rows, then the contacts through their 6 x 6 spatial blocks
+    Arrow H = M;
+    for (int j = 0; j < 3; j++) {
+      if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.l[tri(j, j)] += L.floss_D[j]; }
+      if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.l[tri(j, j)] += R.lm_D[j];
+    }
+    {
+      double Xs[3][21], Xall[21];
+      for (int i = 0; i < 21; i++) { Xall[i] = 0; Xs[0][i] = Xs[1][i] = Xs[2][i] = 0; }
+      bool any = false;
+      for (int i = 0; i < ncon; i++) {
+        double force[6], X[21];
+        int zone;
+        (void)contact_cost(con[i], con[i].jar, force, zone);
+        if (zone == 0) continue;
+        any = true;
+        for (int e = 0; e < 21; e++) X[e] = 0;
+        contact_hessian(con[i], zone, X);
+        for (int e = 0; e < 21; e++) {
+          Xall[e] += X[e];
+          if (con[i].depth >= 1) Xs[0][e] += X[e];
+          if (con[i].depth >= 2) Xs[1][e] += X[e];
+          if (con[i].depth >= 3) Xs[2][e] += X[e];
+        }
+      }
+      if (any) {
+        for (int j = 0; j < 3; j++) {
+          double Y[6];
+          for (int p = 0; p < 6; p++) { double v = 0; for (int q = 0; q < 6; q++) v += Xs[j][tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
+          for (int i = 0; i <= j; i++) H.l[tri(j, i)] += dot6(kin.cdof[i], Y);
+          for (int k = 0; k < 6; k++) H.b[j][k] += trunk_dot(kin, k, Y);
+        }
+      }
+      qd_sum_n(Xall, 21);
+      for (int k = 0; k < 6; k++) {
+        double Y[6];  // Xall cdofT_k
+        for (int p = 0; p < 6; p++) {
+          if (k < 3) Y[p] = Xall[tri(p, 3 + k)];
+          else { double v = 0; for (int q = 0; q < 3; q++) v += Xall[tri(p, q)] * kin.ca[k - 3][q] + Xall[tri(p, 3 + q)] * kin.cl[k - 3][q]; Y[p] = v; }
+        }
+        for (int i = 0; i <= k; i++) H.t[tri(k, i)] += trunk_dot(kin, i, Y);
+      }
+    }
+    ArrowFactor Hf;
+    if (!arrow_factor(H, Hf)) return kFlagNotPD;
+    double hl[3], ht[6];  // search direction
+    for (int j = 0; j < 3; j++) hl[j] = -gl[j];
+    for (int k = 0; k < 6; k++) ht[k] = -gt[k];
+    arrow_solve(Hf, hl, ht);
+    rows_set_jv(kin, R, con, ncon, hl, ht);
+    double Msl[3], Mst[6];
+    arrow_mul(M, hl, ht, Msl, Mst);
+    const double q1 = arrow_dot(hl, ht, Mal, Mat), q2 = arrow_dot(hl, ht, Msl, Mst);
+    double lo = 0, hi = -1, alpha = 0, d1, d2;
+    rows_line(L, R, con, ncon, 0.0, d1, d2);
+    d1 += q1; d2 += q2;
+    const double d10 = fabs(d1);
+    const double snorm = arrow_dot(hl, ht, hl, ht);
+    const double gtol = m.tolerance * kQLsTol * sqrt(snorm) / scale;
+    for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
+      double an = alpha - d1 / d2;
+      if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
+      if (an == alpha) break;
+      alpha = an;
+      rows_line(L, R, con, ncon, alpha, d1, d2);
+      d1 += q1 + alpha * q2; d2 += q2;
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+    }
+    for (int j = 0; j < 3; j++) { al[j] += alpha * hl[j]; R.fl_jar[j] += alpha * R.fl_jv[j]; R.lm_jar[j] += alpha * R.lm_jv[j]; }
+    for (int k = 0; k < 6; k++) at[k] += alpha * ht[k];
+    for (int i = 0; i < ncon; i++) for (int r = 0; r < 6; r++) con[i].jar[r] += alpha * con[i].jv[r];
+    for (int j = 0; j < 3; j++) dl[j] = al[j] - sl[j];
+    for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
+    arrow_mul(M, dl, dt, Mal, Mat);
+    const double gauss = 0.5 * arrow_dot(dl, dt, Mal, Mat);
+    const double newcost = gauss + rows_cost(L, kin, R, con, ncon, fc_l, fc_t);
+    improvement = cost - newcost;
+    cost = newcost;
+    iters = iter + 1;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- collision of the lane's geoms with the static geoms
+QD void add_contact(const QuadPair& p, const QKin& kin, const double* com, const double* cvel, int depth, double dist, const double* pos,
+                    const double* normal, QContact* con, int& ncon, int& flags) {
+  if (!(dist < p.margin)) return;
+  if (ncon >= kQMaxCon) { flags |= kFlagOverflow; return; }
+  QContact& c = con[ncon++];
+  c.dim = p.dim; c.depth = depth;
+  c.F[0] = normal[0]; c.F[1] = normal[1]; c.F[2] = normal[2];
+  make_frame(c.F);
+  for (int k = 0; k < 3; k++) c.off[k] = pos[k] - com[k];
+  c.mu = p.mu; c.f1 = p.fric1; c.f3 = p.fric3; c.f4 = p.fric4;
+  // J qvel: the rows applied to the body's spatial velocity
+  double A[6][6];
+  contact_rows(c, A);
+  const double x = dist - p.includemargin;
+  const double imp = impedance(p.imp, x);
+  double R0 = (1 - imp) / imp * p.diag;
+  if (R0 < kQMinVal) R0 = kQMinVal;
+  c.D0 = 1.0 / R0;
+  for (int r = 0; r < 6; r++) {
+    const double vel = r < c.dim ? dot6(A[r], cvel) : 0.0;
+    c.aref[r] = -p.b * vel - (r == 0 ? p.k * imp * x : 0.0);
+    c.jar[r] = 0; c.jv[r] = 0;
+  }
+}
+QD void sphere_plane(const QuadPair& p, const QKin& kin, const double* com, const double* cvel, int depth, const double* pp, const double* pn,
+                     const double* c, double r, QContact* con, int& ncon, int& flags) {
+  const double dist = (c[0] - pp[0]) * pn[0] + (c[1] - pp[1]) * pn[1] + (c[2] - pp[2]) * pn[2] - r;
+  double pos[3];
+  for (int k = 0; k < 3; k++) pos[k] = c[k] - pn[k] * (r + 0.5 * dist);
+  add_contact(p, kin, com, cvel, depth, dist, pos, pn, con, ncon, flags);
+}
+// one moving geom (world pose gp / gR) against every static geom; oracle o_collision's pair table
+QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& g, const QuadPair* pairs /* [kQStatic] stride */, int pair_stride,
+                     const QKin& kin, const double* com, const double* cvel, int depth, const double* gp, const double* gR,
+                     QContact* con, int& ncon, int& flags) {
+  for (int s = 0; s < m.nstatic; s++) {
+    const QuadStatic& S = m.stat[s];
+    if (S.type < 0) continue;
+    const QuadPair& p = pairs[s * pair_stride];
+    if (!p.collide) continue;
+    const double* p1 = sp[s].pos; const double* R1 = sp[s].mat;
+    if (S.type == MJPCX_GEOM_PLANE) {
+      const double n[3] = {R1[2], R1[5], R1[8]};
+      // bounding-sphere rejection: nothing of the geom within the margin of the plane
+      const double cd = (gp[0] - p1[0]) * n[0] + (gp[1] - p1[1]) * n[1] + (gp[2] - p1[2]) * n[2];
+      double bound = g.size[0];
+      if (g.type == MJPCX_GEOM_CAPSULE) bound = g.size[0] + g.size[1];
+      else if (g.type == MJPCX_GEOM_CYLINDER) bound = sqrt(g.size[0] * g.size[0] + g.size[1] * g.size[1]);
+      else if (g.type == MJPCX_GEOM_BOX) bound = sqrt(g.size[0] * g.size[0] + g.size[1] * g.size[1] + g.size[2] * g.size[2]);
+      if (cd - bound * 1.0000001 - 1e-12 >= p.margin) continue;
+      if (g.type == MJPCX_GEOM_SPHERE) {
+        sphere_plane(p, kin, com, cvel, depth, p1, n, gp, g.size[0], con, ncon, flags);
+      } else if (g.type == MJPCX_GEOM_CAPSULE) {
+        for (int sgn = -1; sgn <= 1; sgn += 2) {
+          double c[3];
+          for (int k = 0; k < 3; k++) c[k] = gp[k] + sgn * g.size[1] * gR[3 * k + 2];
+          sphere_plane(p, kin, com, cvel, depth, p1, n, c, g.size[0], con, ncon, flags);
+        }
+      } else if (g.type == MJPCX_GEOM_BOX) {
+        int cnt = 0;
+        for (int i = 0; i < 8 && cnt < 4; i++) {
+          const double loc[3] = {(i & 1 ? g.size[0] : -g.size[0]), (i & 2 ? g.size[1] : -g.size[1]), (i & 4 ? g.size[2] : -g.size[2])};
+          double c[3];
+          mv3(c, gR, loc);
+          for (int k = 0; k < 3; k++) c[k] += gp[k];
+          const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
+          if (dist < p.margin) {
+            double pos[3];
+            for (int k = 0; k < 3; k++) pos[k] = c[k] - 0.5 * dist * n[k];
+            add_contact(p, kin, com, cvel, depth, dist, pos, n, con, ncon, flags);
+            cnt++;
+          }
+        }
+      } else if (g.type == MJPCX_GEOM_CYLINDER) {
+        const double a[3] = {gR[2], gR[5], gR[8]};
+        const double pa = n[0] * a[0] + n[1] * a[1] + n[2] * a[2];
+        const double sgn = pa > 0 ? -1.0 : 1.0;
+        double v[3], vn = 0;
+        for (int k = 0; k < 3; k++) { v[k] = -(n[k] - pa * a[k]); vn += v[k] * v[k]; }
+        vn = sqrt(vn);
+        if (vn < 1e-10) { v[0] = gR[0]; v[1] = gR[3]; v[2] = gR[6]; vn = 1; }
+        for (int k = 0; k < 3; k++) v[k] /= vn;
+        double w[3];
+        cr3(w, a, v);
+        const double cs[3] = {1.0, -0.5, -0.5}, sn[3] = {0.0, 0.8660254037844386, -0.8660254037844386};
+        for (int i = 0; i < 4; i++) {
+          double c[3];
+          const double side = i < 3 ? sgn : -sgn, cc = i < 3 ? cs[i] : 1.0, ss = i < 3 ? sn[i] : 0.0;
+          for (int k = 0; k < 3; k++) c[k] = gp[k] + side * g.size[1] * a[k] + g.size[0] * (cc * v[k] + ss * w[k]);
+          const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
+          double pos[3];
+          for (int k = 0; k < 3; k++) pos[k] = c[k] - 0.5 * dist * n[k];
+          add_contact(p, kin, com, cvel, depth, dist, pos, n, con, ncon, flags);
+        }
+      }
+    } else if (S.type == MJPCX_GEOM_SPHERE) {  // static sphere x moving sphere
+      double n[3], len = 0;
+      for (int k = 0; k < 3; k++) { n[k] = gp[k] - p1[k]; len += n[k] * n[k]; }
+      len = sqrt(len);
+      const double r1 = S.size[0], dist = len - r1 - g.size[0];
+      if (!(dist < p.margin)) continue;
+      if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else for (int k = 0; k < 3; k++) n[k] /= len;
+      double pos[3];
+      for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * (r1 + 0.5 * dist);
+      add_contact(p, kin, com, cvel, depth, dist, pos, n, con, ncon, flags);
+    } else if (S.type == MJPCX_GEOM_BOX) {  // static box x moving sphere
+      const double* s1 = S.size;
+      double rel[3], loc[3], clamped[3];
+      for (int k = 0; k < 3; k++) rel[k] = gp[k] - p1[k];
+      // bounding-sphere rejection
+      const double br = sqrt(s1[0] * s1[0] + s1[1] * s1[1] + s1[2] * s1[2]) + g.size[0];
+      if (rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] > (br + p.margin) * (br + p.margin) * 1.000001) continue;
+      for (int k = 0; k < 3; k++) loc[k] = R1[k] * rel[0] + R1[3 + k] * rel[1] + R1[6 + k] * rel[2];
+      bool inside = true;
+      for (int k = 0; k < 3; k++) {
+        clamped[k] = loc[k] < -s1[k] ? -s1[k] : (loc[k] > s1[k] ? s1[k] : loc[k]);
+        if (clamped[k] != loc[k]) inside = false;
+      }
+      double nl[3] = {0, 0, 0}, dist;
+      if (!inside) {
+        double len = 0;
+        for (int k = 0; k < 3; k++) { nl[k] = loc[k] - clamped[k]; len += nl[k] * nl[k]; }
+        len = sqrt(len);
+        for (int k = 0; k < 3; k++) nl[k] /= len;
+        dist = len - g.size[0];
+      } else {
+        int best = 0; double bd = 1e300;
+        for (int k = 0; k < 3; k++) { const double dd = s1[k] - fabs(loc[k]); if (dd < bd) { bd = dd; best = k; } }
+        for (int k = 0; k < 3; k++) if (k == best) { nl[k] = loc[k] >= 0 ? 1 : -1; clamped[k] = nl[k] * s1[k]; }
+        dist = -bd - g.size[0];
+      }
+      double n[3], surf[3], pos[3];
+      mv3(n, R1, nl);
+      mv3(surf, R1, clamped);
+      for (int k = 0; k < 3; k++) pos[k] = p1[k] + surf[k] + 0.5 * dist * n[k];
+      add_contact(p, kin, com, cvel, depth, dist, pos, n, con, ncon, flags);
+    }
+  }
+}
+
+// nearest-point distance of two sphere | capsule geoms (oracle pair_collide), minus radii; parallel capsules: the minimum over
+// the end-point tests. Only the DISTANCE is needed: a pair within its margin hands the candidate on.
+QD double pair_distance(int t1, const double* p1, const double* a1, double r1, double h1, int t2, const double* p2, const double* a2, double r2, double h2) {
+  double c1[3], c2[3];
+  auto seg = [](const double* p, const double* a, double h, const double* c) {
+    const double x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
+    return x < -h ? -h : (x > h ? h : x);
+  };
+  auto dist2 = [&](const double* u, const double* v) { return sqrt((u[0] - v[0]) * (u[0] - v[0]) + (u[1] - v[1]) * (u[1] - v[1]) + (u[2] - v[2]) * (u[2] - v[2])) - r1 - r2; };
+  if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) return dist2(p1, p2);
+  if (t1 == MJPCX_GEOM_SPHERE) { const double x = seg(p2, a2, h2, p1); for (int k = 0; k < 3; k++) c2[k] = p2[k] + x * a2[k]; return dist2(p1, c2); }
+  if (t2 == MJPCX_GEOM_SPHERE) { const double x = seg(p1, a1, h1, p2); for (int k = 0; k < 3; k++) c1[k] = p1[k] + x * a1[k]; return dist2(c1, p2); }
+  const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const double mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
+  const double u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
+  const double v = a2[0] * dif[0] + a2[1] * dif[1] + a2[2] * dif[2];
+  const double det = 1.0 - mb * mb;
+  if (fabs(det) >= kQMinVal) {
+    double x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
+    if (x1 > h1) { x1 = h1; x2 = v - mb * x1; } else if (x1 < -h1) { x1 = -h1; x2 = v - mb * x1; }
+    if (x2 > h2) { x2 = h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
+    else if (x2 < -h2) { x2 = -h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
+    for (int k = 0; k < 3; k++) { c1[k] = p1[k] + x1 * a1[k]; c2[k] = p2[k] + x2 * a2[k]; }
+    return dist2(c1, c2);
+  }
+  double best = 1e300;
+  for (int e = 0; e < 4; e++) {
+    const double sgn = (e & 1) ? -1.0 : 1.0;
+    if (e < 2) { for (int k = 0; k < 3; k++) c1[k] = p1[k] + sgn * h1 * a1[k]; const double x2 = seg(p2, a2, h2, c1); for (int k = 0; k < 3; k++) c2[k] = p2[k] + x2 * a2[k]; }
+    else { for (int k = 0; k < 3; k++) c2[k] = p2[k] + sgn * h2 * a2[k]; const double x1 = seg(p1, a1, h1, c2); for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k]; }
+    const double d = dist2(c1, c2);
+    best = d < best ? d : best;
+  }
+  return best;
+}
+
+// Self-collision test over the cross product of the legs' (and the trunk's) pair geoms: bounding spheres first, the exact nearest-point
+// distance for the pairs that pass. The other legs' centres / axes arrive through quad rotations; radii and half lengths are model
+// constants. Rotations by one and two legs cover the six leg pairs (opposite legs twice). Returns (lane-local) whether a pair is within
+// the margin.
+QD bool pair_near(const QuadModel& m, int leg, const QPairGeoms& pg, const double* txpos, const double* txm) {
+  const QuadLeg& L = m.leg[leg];
+  const double mg = m.pair_margin;
+  bool near = false;
+  auto test = [&](int t1, const double* c1, const double* a1, double r1, double h1, int t2, const double* c2, const double* a2, double r2, double h2) {
+    const double dx = c1[0] - c2[0], dy = c1[1] - c2[1], dz = c1[2] - c2[2];
+    const double reach = r1 + h1 + r2 + h2 + mg;
+    if (dx * dx + dy * dy + dz * dz >= reach * reach) return;
+    if (pair_distance(t1, c1, a1, r1, h1, t2, c2, a2, r2, h2) < mg) near = true;
+  };
+  for (int i = 0; i < m.ntpg; i++) {
+    const QuadGeom& g = m.trunk_geom[m.tpg_slot[i]];
+    double c[3], a[3];
+    mv3(c, txm, g.pos);
+    for (int k = 0; k < 3; k++) { c[k] += txpos[k]; a[k] = txm[3 * k] * g.rot[2] + txm[3 * k + 1] * g.rot[5] + txm[3 * k + 2] * g.rot[8]; }
+    const double h1 = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
+    for (int j = 0; j < L.npg; j++) {
+      const QuadGeom& g2 = L.geom[L.pg_slot[j]];
+      test(g.type, c, a, g.size[0], h1, g2.type, pg.c[j], pg.a[j], g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0);
+    }
+  }
+  for (int d = 1; d <= 2; d++) {
+    const QuadLeg& O = m.leg[(leg + d) & 3];
+    for (int j = 0; j < kQPairGeom; j++) {
+      double c2[3], a2[3];
+      for (int k = 0; k < 3; k++) {
+        c2[k] = d == 1 ? qd_rot<1>(pg.c[j][k]) : qd_rot<2>(pg.c[j][k]);
+        a2[k] = d == 1 ? qd_rot<1>(pg.a[j][k]) : qd_rot<2>(pg.a[j][k]);
+      }
+      if (j >= O.npg) continue;
+      const QuadGeom& g2 = O.geom[O.pg_slot[j]];
+      const double h2 = g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0;
+      for (int i = 0; i < L.npg; i++) {
+        const QuadGeom& g1 = L.geom[L.pg_slot[i]];
+        test(g1.type, pg.c[i], pg.a[i], g1.size[0], g1.type == MJPCX_GEOM_CAPSULE ? g1.size[1] : 0.0, g2.type, c2, a2, g2.size[0], h2);
+      }
+    }
+  }
+  return near;
+}
+
+// ---------------------------------------------------------------- mj_forward (oracle o_forward) for the lane's share of one candidate
+// ctrl: the leg's three (already clamped) controls. Returns flag bits (quad-uniform; 0: fine).
+QD int forward(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp, int leg, const QState& S, const double* ctrl, bool have_warm,
+               QContact* con, QForward& out) {
+  const QuadLeg& L = m.leg[leg];
+  QKin kin;
+  int flags = 0;
+  // ================= kinematics (o_kinematics): trunk, then the leg's chain
+  double txpos[3] = {S.tq[0], S.tq[1], S.tq[2]};
+  double txq[4] = {S.tq[3], S.tq[4], S.tq[5], S.tq[6]};
+  q_norm(txq); q_norm(txq);  // (the oracle normalises when it reads qpos and again at the end of the body loop)
+  double txm[9];
+  q2mat(txm, txq);
+  double tmp3[3], tmpq[4];
+  mv3(tmp3, txm, m.trunk_ipos);
+  double txipos[3] = {txpos[0] + tmp3[0], txpos[1] + tmp3[1], txpos[2] + tmp3[2]};
+  double tirot[6];
+  { double timat[9]; q_mul(tmpq, txq, m.trunk_iquat); q2mat(timat, tmpq); rot_inertia(tirot, m.trunk_inertia, timat); }
+  double xipos[3][3], irot[3][6], anchor[3][3], axis[3][3];
+  {
+    double ppos[3] = {txpos[0], txpos[1], txpos[2]}, pquat[4] = {txq[0], txq[1], txq[2], txq[3]}, pmat[9];
+    for (int k = 0; k < 9; k++) pmat[k] = txm[k];
+    for (int j = 0; j < 3; j++) {
+      double xpos[3], xquat[4];
+      mv3(xpos, pmat, L.body_pos[j]);
+      for (int k = 0; k < 3; k++) xpos[k] += ppos[k];
+      q_mul(xquat, pquat, L.body_quat[j]);
+      q_rot(anchor[j], L.jnt_pos[j], xquat);
+      for (int k = 0; k < 3; k++) anchor[j][k] += xpos[k];
+      q_rot(axis[j], L.jnt_axis[j], xquat);
+      const double angle = S.lq[j] - L.qpos0[j];
+      double qloc[4] = {1, 0, 0, 0};
+      if (angle != 0) {
+        double s, c;
+        sincos(0.5 * angle, &s, &c);
+        qloc[0] = c; qloc[1] = L.jnt_axis[j][0] * s; qloc[2] = L.jnt_axis[j][1] * s; qloc[3] = L.jnt_axis[j][2] * s;
+      }
+      q_mul(xquat, xquat, qloc);
+      double vec[3];
+      q_rot(vec, L.jnt_pos[j], xquat);
+      for (int k = 0; k < 3; k++) xpos[k] = anchor[j][k] - vec[k];
+      q_norm(xquat);
+      q2mat(pmat, xquat);
+      for (int k = 0; k < 3; k++) { ppos[k] = xpos[k]; kin.xpos[j][k] = xpos[k]; }
+      for (int k = 0; k < 4; k++) pquat[k] = xquat[k];
+      for (int k = 0; k < 9; k++) kin.xmat[j][k] = pmat[k];
+      mv3(tmp3, pmat, L.body_ipos[j]);
+      for (int k = 0; k < 3; k++) xipos[j][k] = xpos[k] + tmp3[k];
+      double imat[9];
+      q_mul(tmpq, xquat, L.body_iquat[j]);
+      q2mat(imat, tmpq);
+      rot_inertia(irot[j], L.body_inertia[j], imat);
+    }
+  }
+  // ================= centre of mass, spatial inertias, dof axes (o_compos)
+  double com[3];
+  for (int k = 0; k < 3; k++) {
+    const double s = L.body_mass[0] * xipos[0][k] + L.body_mass[1] * xipos[1][k] + L.body_mass[2] * xipos[2][k];
+    com[k] = (qd_sum(s) + m.trunk_mass * txipos[k]) / m.total_mass;
+  }
+  double cin[3][10], cinT[10];
+  for (int j = 0; j < 3; j++) {
+    const double dif[3] = {xipos[j][0] - com[0], xipos[j][1] - com[1], xipos[j][2] - com[2]};
+    inert_shift(cin[j], irot[j], dif, L.body_mass[j]);
+  }
+  { const double dif[3] = {txipos[0] - com[0], txipos[1] - com[1], txipos[2] - com[2]}; inert_shift(cinT, tirot, dif, m.trunk_mass); }
+  {
+    const double off[3] = {com[0] - txpos[0], com[1] - txpos[1], com[2] - txpos[2]};
+    for (int k = 0; k < 3; k++) {
+      kin.ca[k][0] = txm[k]; kin.ca[k][1] = txm[3 + k]; kin.ca[k][2] = txm[6 + k];
+      cr3(kin.cl[k], kin.ca[k], off);
+    }
+    for (int j = 0; j < 3; j++) {
+      const double o[3] = {com[0] - anchor[j][0], com[1] - anchor[j][1], com[2] - anchor[j][2]};
+      for (int k = 0; k < 3; k++) kin.cdof[j][k] = axis[j][k];
+      cr3(kin.cdof[j] + 3, axis[j], o);
+    }
+  }
+  // ================= composite inertia -> M (o_crb), in arrowhead form
+  Arrow& M = out.M;
+  {
+    double crb[3][10], crbT[10];
+    for (int e = 0; e < 10; e++) { crb[2][e] = cin[2][e]; crb[1][e] = cin[1][e] + crb[2][e]; crb[0][e] = cin[0][e] + crb[1][e]; }
+    for (int e = 0; e < 10; e++) crbT[e] = cinT[e] + qd_sum(crb[0][e]);
+    for (int j = 0; j < 3; j++) {
+      double buf[6];
+      mul_inert(buf, crb[j], kin.cdof[j]);
+      M.l[tri(j, j)] = L.armature[j] + dot6(kin.cdof[j], buf);
+      for (int i = 0; i < j; i++) M.l[tri(j, i)] = dot6(kin.cdof[i], buf);
+      for (int k = 0; k < 6; k++) M.b[j][k] = trunk_dot(kin, k, buf);
+    }
+    for (int k = 0; k < 6; k++) {
+      double cd[6], buf[6];
+      if (k < 3) { for (int c = 0; c < 6; c++) cd[c] = 0; cd[3 + k] = 1; }
+      else { for (int c = 0; c < 3; c++) { cd[c] = kin.ca[k - 3][c]; cd[3 + c] = kin.cl[k - 3][c]; } }
+      mul_inert(buf, crbT, cd);
+      for (int i = 0; i <= k; i++) M.t[tri(k, i)] = trunk_dot(kin, i, buf);
+    }
+  }
+  ArrowFactor Mf;
+  if (!arrow_factor(M, Mf)) return kFlagNotPD;
+  // ================= velocities (o_comvel)
+  double cdof_dot[3][6], cdT_dot[3][6];
+  {
+    double cvel[6] = {0, 0, 0, S.tv[0], S.tv[1], S.tv[2]};
+    for (int k = 0; k < 3; k++) {
+      double cd[6] = {kin.ca[k][0], kin.ca[k][1], kin.ca[k][2], kin.cl[k][0], kin.cl[k][1], kin.cl[k][2]};
+      cross_motion(cdT_dot[k], cvel, cd);
+    }
+    for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) { cvel[c] += kin.ca[k][c] * S.tv[3 + k]; cvel[3 + c] += kin.cl[k][c] * S.tv[3 + k]; }
+    for (int c = 0; c < 6; c++) kin.cvelT[c] = cvel[c];
+    for (int j = 0; j < 3; j++) {
+      cross_motion(cdof_dot[j], cvel, kin.cdof[j]);
+      for (int c = 0; c < 6; c++) { cvel[c] += kin.cdof[j][c] * S.lv[j]; kin.cvel[j][c] = cvel[c]; }
+    }
+  }
+  // ================= collision (o_collision): the leg's geoms and the lane's share of the trunk geoms
+  int ncon = 0;
+  QPairGeoms pg;
+  int npg_seen = 0;
+  for (int gi = 0; gi < L.ngeom; gi++) {
+    const QuadGeom& g = L.geom[gi];
+    double gp[3], gR[9];
+    const double* bm = kin.xmat[g.link];
+    mv3(gp, bm, g.pos);
+    for (int k = 0; k < 3; k++) gp[k] += kin.xpos[g.link][k];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) gR[3 * r + c] = bm[3 * r] * g.rot[c] + bm[3 * r + 1] * g.rot[3 + c] + bm[3 * r + 2] * g.rot[6 + c];
+    if (gi == L.foot_slot) for (int k = 0; k < 3; k++) out.foot[k] = gp[k];
+    if (npg_seen < L.npg && L.pg_slot[npg_seen] == gi) {
+      for (int k = 0; k < 3; k++) { pg.c[npg_seen][k] = gp[k]; pg.a[npg_seen][k] = gR[3 * k + 2]; }
+      npg_seen++;
+    }
+    collide_geom(m, sp, g, &tab.leg[leg][0][gi], kQLegGeom, kin, com, kin.cvel[g.link], g.link + 1, gp, gR, con, ncon, flags);
+  }
+  for (int gi = leg; gi < m.ntrunk_geom; gi += kQLegs) {
+    const QuadGeom& g = m.trunk_geom[gi];
+    double gp[3], gR[9];
+    mv3(gp, txm, g.pos);
+    for (int k = 0; k < 3; k++) gp[k] += txpos[k];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
+    collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, kin, com, kin.cvelT, 0, gp, gR, con, ncon, flags);
+  }
+  // ================= passive, bias (o_rne), actuation, smooth acceleration
+  double fs_l[3], fs_t[6];
+  {
+    const double g0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    double caccT[6], cacc[6], cfrc[3][6], cfrcT[6], t1[6], t2[6], t3[6];
+    for (int c = 0; c < 6; c++) caccT[c] = g0[c] + cdT_dot[0][c] * S.tv[3] + cdT_dot[1][c] * S.tv[4] + cdT_dot[2][c] * S.tv[5];
+    mul_inert(t1, cinT, caccT); mul_inert(t2, cinT, kin.cvelT); cross_force(t3, kin.cvelT, t2);
+    for (int c = 0; c < 6; c++) { cfrcT[c] = t1[c] + t3[c]; cacc[c] = caccT[c]; }
+    for (int j = 0; j < 3; j++) {
+      for (int c = 0; c < 6; c++) cacc[c] += cdof_dot[j][c] * S.lv[j];
+      mul_inert(t1, cin[j], cacc); mul_inert(t2, cin[j], kin.cvel[j]); cross_force(t3, kin.cvel[j], t2);
+      for (int c = 0; c < 6; c++) cfrc[j][c] = t1[c] + t3[c];
+    }
+    for (int c = 0; c < 6; c++) { cfrc[1][c] += cfrc[2][c]; cfrc[0][c] += cfrc[1][c]; cfrcT[c] += qd_sum(cfrc[0][c]); }
+    for (int j = 0; j < 3; j++) {
+      const double bias = dot6(kin.cdof[j], cfrc[j]);
+      double passive = -L.damping[j] * S.lv[j];
+      if (L.stiffness[j] != 0) passive -= L.stiffness[j] * (S.lq[j] - L.qpos_spring[j]);
+      double u = ctrl[j];
+      if (L.ctrllimited[j]) u = clampd(u, L.ctrlrange[j][0], L.ctrlrange[j][1]);
+      double force = L.act_gain[j] * u;
+      if (L.act_biastype[j] == 1) force += L.act_bias[j][0] + L.act_bias[j][1] * L.act_gear[j] * S.lq[j] + L.act_bias[j][2] * L.act_gear[j] * S.lv[j];
+      if (L.forcelimited[j]) force = clampd(force, L.forcerange[j][0], L.forcerange[j][1]);
+      out.act_force[j] = force;
+      fs_l[j] = passive - bias + L.act_gear[j] * force;
+    }
+    for (int k = 0; k < 6; k++) fs_t[k] = -trunk_dot(kin, k, cfrcT);
+  }
+  double sl[3] = {fs_l[0], fs_l[1], fs_l[2]}, st[6] = {fs_t[0], fs_t[1], fs_t[2], fs_t[3], fs_t[4], fs_t[5]};
+  arrow_solve(Mf, sl, st);  // qacc_smooth
+  // ================= constraint rows of the lane: friction loss, joint limits (o_make_constraint_full); contacts are in `con`
+  QRows R;
+  for (int j = 0; j < 3; j++) {
+    R.fl_aref[j] = -L.floss_b[j] * S.lv[j];
+    R.fl_jar[j] = R.fl_jv[j] = 0;
+    R.lm_side[j] = 0; R.lm_aref[j] = 0; R.lm_D[j] = 0; R.lm_jar[j] = R.lm_jv[j] = 0;
+    if (L.limited[j]) {
+      const double dlo = S.lq[j] - L.range[j][0], dhi = L.range[j][1] - S.lq[j];
+      int side = 0; double dist = 0;
+      if (dlo < L.margin[j]) { side = -1; dist = dlo; }
+      if (dhi < L.margin[j]) { if (side != 0) flags |= kFlagLimits; side = 1; dist = dhi; }
+      if (side != 0) {
+        const double pos = dist - L.margin[j], imp = impedance(L.lim_imp[j], pos), vel = -side * S.lv[j];
+        double Rr = (1 - imp) / imp * L.lim_diag[j];
+        if (Rr < kQMinVal) Rr = kQMinVal;
+        R.lm_side[j] = side; R.lm_D[j] = 1.0 / Rr; R.lm_aref[j] = -L.lim_b[j] * vel - L.lim_k[j] * imp * pos;
+      }
+    }
+  }
+  // ================= moving-geom pairs: tested only (a pair within its margin is handed to the other kernel)
+  if (pair_near(m, leg, pg, txpos, txm)) flags |= kFlagPair;
+  flags = qd_or(flags);
+  if (flags) return flags;
+  // ================= constraint solve
+  const int rc = constraint_newton(m, L, kin, M, R, con, ncon, sl, st, S.wl, S.wt, have_warm, out.qacc_l, out.qacc_t, out.fc_l, out.fc_t, out.iters);
+  if (rc) return rc;
+  for (int j = 0; j < 3; j++) out.fs_l[j] = fs_l[j];
+  for (int k = 0; k < 6; k++) out.fs_t[k] = fs_t[k];
+  // ================= what the sensor stage and the recording read
+  for (int k = 0; k < 9; k++) out.txm[k] = txm[k];
+  for (int k = 0; k < 4; k++) out.txq[k] = txq[k];
+  for (int k = 0; k < 3; k++) { out.txipos[k] = txipos[k]; out.com[k] = com[k]; }
+  mv3(tmp3, txm, m.head_pos);
+  for (int k = 0; k < 3; k++) out.head[k] = txpos[k] + tmp3[k];
+  for (int t = 0; t < m.ntrace; t++) { mv3(tmp3, txm, m.trace_pos[t]); for (int k = 0; k < 3; k++) out.trace[t][k] = txpos[k] + tmp3[k]; }
+  {  // subtree linear velocity of the trunk (o_subtree_linvel)
+    double mom[3] = {0, 0, 0};
+    for (int j = 0; j < 3; j++) {
+      const double off[3] = {xipos[j][0] - com[0], xipos[j][1] - com[1], xipos[j][2] - com[2]};
+      double lin[3];
+      cr3(lin, kin.cvel[j], off);
+      for (int k = 0; k < 3; k++) mom[k] += L.body_mass[j] * (kin.cvel[j][3 + k] + lin[k]);
+    }
+    const double off[3] = {txipos[0] - com[0], txipos[1] - com[1], txipos[2] - com[2]};
+    double lin[3];
+    cr3(lin, kin.cvelT, off);
+    for (int k = 0; k < 3; k++) out.comvel[k] = (qd_sum(mom[k]) + m.trunk_mass * (kin.cvelT[3 + k] + lin[k])) / m.total_mass;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- mj_Euler with implicit joint damping + mj_advance (oracle o_euler)
+QD int euler(const QuadModel& m, int leg, QState& S, const QForward& f) {
+  const QuadLeg& L = m.leg[leg];
+  const double h = m.timestep;
+  double al[3], at[6];
+  const bool damped = qd_or((L.damping[0] > 0 || L.damping[1] > 0 || L.damping[2] > 0) ? 1 : 0) != 0;
+  if (damped) {
+    Arrow A = f.M;
+    for (int j = 0; j < 3; j++) A.l[tri(j, j)] += h * L.damping[j];
+    ArrowFactor Af;
+    for (int j = 0; j < 3; j++) al[j] = f.fs_l[j] + f.fc_l[j];
+    for (int k = 0; k < 6; k++) at[k] = f.fs_t[k] + f.fc_t[k];
+    if (arrow_factor(A, Af)) arrow_solve(Af, al, at);
+    else { for (int j = 0; j < 3; j++) al[j] = f.qacc_l[j]; for (int k = 0; k < 6; k++) at[k] = f.qacc_t[k]; }
+  } else {
+    for (int j = 0; j < 3; j++) al[j] = f.qacc_l[j];
+    for (int k = 0; k < 6; k++) at[k] = f.qacc_t[k];
+  }
+  for (int j = 0; j < 3; j++) { S.wl[j] = f.qacc_l[j]; S.lv[j] += h * al[j]; S.lq[j] += h * S.lv[j]; }
+  for (int k = 0; k < 6; k++) { S.wt[k] = f.qacc_t[k]; S.tv[k] += h * at[k]; }
+  for (int k = 0; k < 3; k++) S.tq[k] += h * S.tv[k];
+  {
+    double ax[3] = {S.tv[3], S.tv[4], S.tv[5]};
+    const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    if (n < kQMinVal) { ax[0] = 1; ax[1] = ax[2] = 0; } else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
+    const double angle = h * n;
+    double qrot[4] = {1, 0, 0, 0};
+    if (angle != 0) { double s, c; sincos(0.5 * angle, &s, &c); qrot[0] = c; qrot[1] = ax[0] * s; qrot[2] = ax[1] * s; qrot[3] = ax[2] * s; }
+    q_norm(S.tq + 3);
+    q_mul(S.tq + 3, S.tq + 3, qrot);
+  }
+  S.time += h;
+  return 0;
+}
+
+// ---------------------------------------------------------------- QuadrupedFlat residual (oracle/quadruped.inc) + cost (task.cc:71-110)
+// mj_ray straight down against the static geoms of group 0 (oracle ray_down)
+QD double ray_down(const QuadModel& m, const QStaticPose* sp, const double* from) {
+  double best = -1;
+  for (int s = 0; s < m.nstatic; s++) {
+    const QuadStatic& S = m.stat[s];
+    if (!S.ray) continue;
+    const int type = S.type < 0 ? -1 - S.type : S.type;
+    const double* p = sp[s].pos; const double* R = sp[s].mat; const double* sz = S.size;
+    double x = -1;
+    if (type == MJPCX_GEOM_PLANE) {
+      const double n[3] = {R[2], R[5], R[8]};
+      const double denom = -n[2];
+      if (fabs(denom) >= kQMinVal) {
+        const double t = -((from[0] - p[0]) * n[0] + (from[1] - p[1]) * n[1] + (from[2] - p[2]) * n[2]) / denom;
+        if (t >= 0) {
+          const double hit[3] = {from[0] - p[0], from[1] - p[1], from[2] - t - p[2]};
+          const double lx = R[0] * hit[0] + R[3] * hit[1] + R[6] * hit[2], ly = R[1] * hit[0] + R[4] * hit[1] + R[7] * hit[2];
+          if ((sz[0] <= 0 || fabs(lx) <= sz[0]) && (sz[1] <= 0 || fabs(ly) <= sz[1])) x = t;
+        }
+      }
+    } else if (type == MJPCX_GEOM_SPHERE) {
+      const double o[3] = {from[0] - p[0], from[1] - p[1], from[2] - p[2]};
+      const double b = -o[2], c = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] - sz[0] * sz[0];
+      const double disc = b * b - c;
+      if (disc >= 0) { const double sq = sqrt(disc), t0 = -b - sq, t1 = -b + sq; x = t0 >= 0 ? t0 : (t1 >= 0 ? t1 : -1); }
+    } else if (type == MJPCX_GEOM_BOX) {
+      double o[3], dl[3];
+      const double rel[3] = {from[0] - p[0], from[1] - p[1], from[2] - p[2]};
+      for (int k = 0; k < 3; k++) { o[k] = R[k] * rel[0] + R[3 + k] * rel[1] + R[6 + k] * rel[2]; dl[k] = -R[6 + k]; }
+      double tmin = -1e300, tmax = 1e300;
+      bool miss = false;
+      for (int k = 0; k < 3; k++) {
+        if (fabs(dl[k]) < kQMinVal) { if (fabs(o[k]) > sz[k]) miss = true; continue; }
+        double ta = (-sz[k] - o[k]) / dl[k], tb = (sz[k] - o[k]) / dl[k];
+        if (ta > tb) { const double tt = ta; ta = tb; tb = tt; }
+        if (ta > tmin) tmin = ta;
+        if (tb < tmax) tmax = tb;
+      }
+      if (!(miss || tmin > tmax || tmax < 0)) x = tmin >= 0 ? tmin : tmax;
+    }
+    if (x >= 0 && (best < 0 || x < best)) best = x;
+  }
+  return best;
+}
+QD double step_height(double time, double footphase, double duty_ratio) {
+  double angle = fmod(time + kQPi - footphase, 2 * kQPi) - kQPi;
+  double value = 0;
+  if (duty_ratio < 1) {
+    angle *= 0.5 / (1 - duty_ratio);
+    value = cos(clampd(angle, -kQPi / 2, kQPi / 2));
+  }
+  return fabs(value) < 1e-6 ? 0.0 : value;
+}
+QD void flip_quat(const double* re, int flip_dir, double* quat, double time) {
+  const double jump_time = re[22], flight_time = re[18], land_time = re[24], crouch_time = re[20];
+  double angle = 0;
+  if (time >= jump_time + flight_time + land_time) angle = 2 * kQPi;
+  else if (time >= crouch_time && time < jump_time) { time -= crouch_time; angle = 0.5 * re[28] * time * time + re[27] * time; }
+  else if (time >= jump_time && time < jump_time + flight_time) { time -= jump_time; angle = kQPi / 2 + re[26] * time; }
+  else if (time >= jump_time + flight_time) { time -= jump_time + flight_time; angle = 1.75 * kQPi + re[26] * time - 0.5 * re[29] * time * time; }
+  double q[4] = {1, 0, 0, 0};
+  if (angle != 0) { double s, c; sincos(0.5 * angle, &s, &c); q[0] = c; q[1] = 0; q[2] = (flip_dir ? 1.0 : -1.0) * s; q[3] = 0; }
+  q_mul(quat, re + 9, q);
+}
+QD double flip_height(const double* re, double time) {
+  const double jump_time = re[22], flight_time = re[18], land_time = re[24], ground = re[8];
+  if (time >= jump_time + flight_time + land_time) return 0.25 + ground;
+  double h = 0;
+  if (time < jump_time) h = 0.25 + time * re[23] + 0.5 * time * time * re[19];
+  else if (time >= jump_time && time < jump_time + flight_time) { time -= jump_time; h = 0.5 + re[17] * time - 0.5 * 9.81 * time * time; }
+  else if (time >= jump_time + flight_time) { time -= jump_time + flight_time; h = 0.5 - re[17] * time + 0.5 * re[25] * time * time; }
+  return h + ground;
+}
+QD void sub_quat(double* res, const double* qa, const double* qb) {
+  const double qn[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
+  double qdif[4];
+  q_mul(qdif, qn, qa);
+  double axis[3] = {qdif[1], qdif[2], qdif[3]};
+  const double sin_a_2 = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+  if (sin_a_2 > kQMinVal) for (int k = 0; k < 3; k++) axis[k] /= sin_a_2;
+  double speed = 2 * atan2(sin_a_2, qdif[0]);
+  if (speed > kQPi) speed -= 2 * kQPi;
+  for (int k = 0; k < 3; k++) res[k] = axis[k] * speed;
+}
+QD double norm_elem(double x, int type, double p, double q) {
+  switch (type) {
+    case -1: return x;
+    case 0: case 1: case 2: return x * x;
+    case 3: return p * p * (cosh(x / p) - 1.0);
+    case 5: return pow(fabs(x), p);
+    case 6: return sqrt(x * x + p * p) - p;
+    case 7: return pow(pow(fabs(x), q) + pow(p, q), 1 / q) - p;
+    case 8: return p > 0 ? p * log(1 + exp(x / p)) : (x > 0 ? x : 0.0);
+    default: return 0;
+  }
+}
+QD double norm_finish(double c, int type, double p, double q) {
+  switch (type) {
+    case 0: return c * 0.5;
+    case 1: return pow(pow(c, q / 2) + pow(p, q), 1 / q) - p;
+    case 2: return sqrt(c + p * p) - p;
+    default: return c;
+  }
+}
+
+// per-plan task values (the blob WaveHost::fill_blob stages: wave_model.h)
+struct QTask {
+  const double *mocap, *weight, *norm_p, *norm_q, *param, *re;  // mocap[7 nmocap] ...
+  const int* ri;
+  double risk;
+};
+
+// The residual entries are dealt over the quad: `shared` = the 18 entries of Upright Height Position Balance Yaw Angmom + the four
+// Gait entries (every lane computes the shared ones identically, lane `foot_index` owns Gait entry foot_index), `own` = the
+// lane's three Effort and three Posture entries. Returns the cost (task.cc:71-110 + the risk transform), replicated.
+struct QResidual { double shared[18]; double gait; double effort[3], posture[3]; };
+QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* sp, int leg, const QState& S, const QForward& f, QResidual& r) {
+  const QuadLeg& L = m.leg[leg];
+  const int* ri = tk.ri; const double* re = tk.re; const double* par = tk.param;
+  const int mode = ri[0], handstand = ri[10], fi = L.foot_index;
+  const double kGaitPhase[5][4] = {{0, 0, 0, 0}, {0, 0.75, 0.5, 0.25}, {0, 0.5, 0.5, 0}, {0, 0.33, 0.33, 0.66}, {0, 0.4, 0.05, 0.35}};
+  // foot positions of the four legs in the reference's order FL HL FR HR
+  double fp[4][3];
+  {
+    double mine[4][3];
+    for (int q = 0; q < 4; q++) for (int k = 0; k < 3; k++) mine[q][k] = q == fi ? f.foot[k] : 0.0;
+    for (int q = 0; q < 4; q++) for (int k = 0; k < 3; k++) fp[q][k] = qd_sum(mine[q][k]);
+  }
+  const bool is_biped = mode == 1;
+  double avg[3];
+  if (is_biped) { const int a = handstand ? 0 : 1, b = handstand ? 2 : 3; for (int k = 0; k < 3; k++) avg[k] = 0.5 * (fp[a][k] + fp[b][k]); }
+  else for (int k = 0; k < 3; k++) avg[k] = 0.25 * (fp[1][k] + fp[3][k] + fp[0][k] + fp[2][k]);
+  const double* goal = tk.mocap + 7 * m.goal_mocap;
+  int n = 0;
+  double* R = r.shared;
+  // Upright
+  if (mode != 4) {
+    R[n++] = is_biped ? f.txm[6] - (handstand ? -1 : 1) : f.txm[8] - 1;
+    R[n++] = 0; R[n++] = 0;
+  } else {
+    double quat[4];
+    flip_quat(re, ri[9], quat, S.time - re[0]);
+    sub_quat(R + n, f.txq, quat);
+    n += 3;
+  }
+  // Height
+  const double height_goal = is_biped ? 0.6 : 0.25;
+  if (mode == 3) R[n++] = 0;
+  else if (mode == 4) R[n++] = f.txipos[2] - flip_height(re, S.time - re[0]);
+  else R[n++] = (f.txipos[2] - avg[2]) - height_goal;
+  // Position
+  double target[3];
+  if (mode == 2) {
+    const double t = S.time - re[0];
+    const double* position = re + 1; const double* heading = re + 4;
+    const double speed = re[6], angvel = re[7];
+    if (fabs(angvel) < 0.01) {
+      double fwd[2] = {heading[0], heading[1]};
+      const double nn = sqrt(fwd[0] * fwd[0] + fwd[1] * fwd[1]);
+      if (nn > kQMinVal) { fwd[0] /= nn; fwd[1] /= nn; } else { fwd[0] = 1; fwd[1] = 0; }
+      target[0] = position[0] + heading[0] + t * speed * fwd[0];
+      target[1] = position[1] + heading[1] + t * speed * fwd[1];
+    } else {
+      const double angle = t * angvel, c = cos(angle), s = sin(angle);
+      target[0] = c * heading[0] - s * heading[1] + position[0];
+      target[1] = s * heading[0] + c * heading[1] + position[1];
+    }
+    target[2] = 0;
+  } else { target[0] = goal[0]; target[1] = goal[1]; target[2] = goal[2]; }
+  R[n++] = f.head[0] - target[0];
+  R[n++] = f.head[1] - target[1];
+  R[n++] = mode == 3 ? 2 * (f.head[2] - target[2]) : 0;
+  // Gait: the lane's own foot
+  {
+    const int gait = is_biped ? 2 : ri[8];
+    const double phase = re[13] + (S.time - re[14]) * re[15];
+    const double amplitude = par[ri[11]], duty_ratio = par[ri[12]];
+    const double step = amplitude * step_height(phase, 2 * kQPi * kGaitPhase[gait][fi], duty_ratio);
+    const bool front_hand = is_biped && !handstand && (fi == 0 || fi == 2), back_hand = is_biped && handstand && (fi == 1 || fi == 3);
+    if (front_hand || back_hand) r.gait = 0;
+    else {
+      double query[3] = {f.foot[0], f.foot[1], f.foot[2]};
+      if (mode == 3) {
+        double v[3] = {goal[0] - f.foot[0], goal[1] - f.foot[1], 0};
+        const double nn = sqrt(v[0] * v[0] + v[1] * v[1]);
+        if (nn > kQMinVal) { v[0] /= nn; v[1] /= nn; } else { v[0] = 1; v[1] = 0; }
+        for (int k = 0; k < 3; k++) query[k] += 0.15 * v[k];
+      }
+      const double q3[3] = {query[0], query[1], query[2] + 0.5};
+      const double ground = query[2] + 0.5 - ray_down(m, sp, q3);
+      double hd = f.foot[2] - (ground + 0.02 + step);
+      if (mode == 3) hd = hd < 0 ? hd : 0;
+      r.gait = step ? hd : 0;
+    }
+  }
+  // Balance
+  const double fall_time = sqrt(2 * height_goal / 9.81);
+  R[n++] = f.com[0] + f.comvel[0] * fall_time - avg[0];
+  R[n++] = f.com[1] + f.comvel[1] * fall_time - avg[1];
+  // Effort, Posture: the lane's joints
+  for (int j = 0; j < 3; j++) {
+    r.effort[j] = 2e-2 * f.act_force[j];
+    double p = S.lq[j] - L.key_q[ri[15]][j];
+    if (mode == 4) {
+      const double ft = S.time - re[0];
+      if (ft < re[20]) p = S.lq[j] - L.key_q[ri[16]][j];
+      else if (ft >= re[20] && ft < re[22] + re[18]) p = 0;
+    }
+    p *= j == 0 ? 2.0 : 1.0;
+    // actuators (= legs) 0..5 / 6..11 are the reference's "arm" halves of the Posture term
+    if (is_biped) { const int base = handstand ? 6 : 0; const int u = 3 * leg + j; if (u >= base && u < base + 6) p *= par[ri[13]]; }
+    r.posture[j] = p;
+  }
+  // Yaw
+  double th[2] = {f.txm[0], f.txm[3]};
+  if (is_biped) { const int hs = handstand ? 1 : -1; th[0] = hs * f.txm[2]; th[1] = hs * f.txm[5]; }
+  const double nn = sqrt(th[0] * th[0] + th[1] * th[1]);
+  if (nn < kQMinVal) { th[0] = 1; th[1] = 0; } else { th[0] /= nn; th[1] /= nn; }
+  const double heading_goal = par[ri[14]];
+  R[n++] = th[0] - cos(heading_goal);
+  R[n++] = th[1] - sin(heading_goal);
+  for (int k = 0; k < 3; k++) R[n++] = f.comvel[k];
+  // ---- cost: terms Upright(3) Height(1) Position(3) Gait(4) Balance(2) Effort(12) Posture(12) Yaw(2) Angmom(3)
+  auto term_shared = [&](int term, const double* x, int cnt) {
+    double c = 0;
+    for (int i = 0; i < cnt; i++) c += norm_elem(x[i], m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+    return tk.weight[term] * norm_finish(c, m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+  };
+  auto term_dealt = [&](int term, const double* x, int cnt) {
+    double c = 0;
+    for (int i = 0; i < cnt; i++) c += norm_elem(x[i], m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+    c = qd_sum(c);
+    return tk.weight[term] * norm_finish(c, m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+  };
+  double cost = 0;
+  cost += term_shared(0, R + 0, 3);
+  cost += term_shared(1, R + 3, 1);
+  cost += term_shared(2, R + 4, 3);
+  cost += term_dealt(3, &r.gait, 1);
+  cost += term_shared(4, R + 7, 2);
+  cost += term_dealt(5, r.effort, 3);
+  cost += term_dealt(6, r.posture, 3);
+  cost += term_shared(7, R + 9, 2);
+  cost += term_shared(8, R + 11, 3);
+  if (!(fabs(tk.risk) < 1.0e-6)) cost = (exp(tk.risk * cost) - 1.0) / tk.risk;
+  return cost;
+}
+
+
+// ---------------------------------------------------------------- candidate generation + Trajectory::Rollout
+// Philox4x32-10 + Box-Muller exactly as include/mjpcx.h specifies (device_common.h gaussian_pair; oracle/rng.c)
+QD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+QD double u53(uint32_t hi, uint32_t lo) {
+  const uint64_t k = (((uint64_t)hi << 32) | lo) >> 11;
+  return ((double)k + 0.5) * (1.0 / 9007199254740992.0);
+}
+QD void gaussian_pair(uint64_t seed, uint32_t cand, uint32_t pair, uint32_t iter, double* z) {
+  uint32_t o[4];
+  philox4x32_10(cand, pair, iter, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  const double u1 = u53(o[0], o[1]), u2 = u53(o[2], o[3]);
+  const double r = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+  z[0] = r * cs; z[1] = r * sn;
+}
+QD double bernoulli_uniform(uint64_t seed, uint32_t cand, uint32_t iter) {
+  uint32_t o[4];
+  philox4x32_10(cand, 0u, iter, 1u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  return u53(o[0], o[1]);
+}
+
+// the rollout request (RolloutArgs<double> of rollout_lane.h, flattened so that the CPU emulator can fill it too)
+struct QArgs {
+  int N, H, P, interp;
+  const double* node_times;  // P
+  double* nodes;             // [P][nu][N]
+  const double* nominal;     // [P][nu]
+  int noise_mode;            // -1: candidates given in `nodes`
+  uint64_t seed; uint32_t iteration;
+  int candidate_offset, nominal_candidate, explore_count;
+  double std0, std1;
+  const double* param_variance;
+  double *states, *actions, *times, *residual, *costs, *trace, *total_return;  // [candidate][step][field]
+  int* failure;
+};
+
+// One lane's share of one candidate's rollout. `state0` = qpos[19] qvel[18] of the plan (Planner::SetState), `con` the lane's contact
+// list storage (kQMaxCon records). Returns the flag bits (0: rolled out; otherwise failure[cand] carries kQFallback and the
+// wavefront-per-candidate kernel takes the candidate over).
+QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp, const QTask& tk, const double* state0, double time0, const QArgs& a,
+               int cand, int leg, QContact* con) {
+  const QuadLeg& L = m.leg[leg];
+  const int nu = kQLegs * kQLinks, P = a.P, H = a.H, nr = m.nr;
+  const size_t N = (size_t)a.N;
+  // ---- the candidate's spline nodes of this leg's three actuators (AddNoiseToPolicy)
+  if (a.noise_mode >= 0) {
+    const int gi = a.candidate_offset + cand;
+    double std = a.std0;
+    if (a.noise_mode == 0 && a.std1 > 0) { if (bernoulli_uniform(a.seed, (uint32_t)gi, a.iteration) < 0.2) std = a.std1; }
+    const bool noised = gi != a.nominal_candidate;
+    for (int p = 0; p < P; p++)
+      for (int e = 0; e < 3; e++) {
+        const int k = 3 * leg + e, j = p * nu + k;
+        double v = a.nominal[j];
+        if (noised) {
+          double z[2];
+          gaussian_pair(a.seed, (uint32_t)gi, (uint32_t)(j >> 1), a.iteration, z);
+          const double lo = L.ctrlrange[e][0], hi = L.ctrlrange[e][1];
+          double sigma;
+          if (a.noise_mode == 0) sigma = 0.5 * (hi - lo) * std;
+          else {
+            const double fl = gi < a.explore_count ? a.std0 : a.std1;
+            const double sd = sqrt(a.param_variance[j]);
+            sigma = sd > fl ? sd : fl;
+          }
+          v = clampd(v + sigma * z[j & 1], lo, hi);
+        }
+        a.nodes[(size_t)j * N + cand] = v;
+      }
+  }
+#define QNODE(p, e) a.nodes[(size_t)((p) * nu + 3 * leg + (e)) * N + cand]
+  QState S;
+  for (int k = 0; k < 7; k++) S.tq[k] = state0[k];
+  for (int j = 0; j < 3; j++) { S.lq[j] = state0[7 + 3 * leg + j]; S.lv[j] = state0[19 + 6 + 3 * leg + j]; S.wl[j] = 0; }
+  for (int k = 0; k < 6; k++) { S.tv[k] = state0[19 + k]; S.wt[k] = 0; }
+  S.time = time0;
+  const size_t ds = 37;
+  double total = 0;
+  double ctrl[3] = {0, 0, 0};
+  int flags = 0;
+  for (int t = 0; t < H; t++) {
+    const bool last = t == H - 1;
+    bool bad = false;
+    if (!last) {
+      // policy: TimeSpline::Sample + Clamp (SamplingPolicy::Action)
+      int up = 0;
+      while (up < P && a.node_times[up] <= S.time) up++;
+      for (int e = 0; e < 3; e++) {
+        double u;
+        if (up == P || up == 0) u = QNODE(up == 0 ? 0 : P - 1, e);
+        else {
+          const int lo = up - 1;
+          const double tl = a.node_times[lo], tu = a.node_times[up];
+          const double p0 = QNODE(lo, e), p1 = QNODE(up, e);
+          if (a.interp == 0) u = p0;
+          else {
+            const double s = (S.time - tl) / (tu - tl);
+            if (a.interp == 1) u = p0 * (1 - s) + p1 * s;
+            else {
+              const double dt_mid = tu - tl, fwd = (p1 - p0) / dt_mid;
+              double m0, m1;
+              if (lo == 0) m0 = fwd;
+              else m0 = 0.5 * (p1 - p0) / dt_mid + 0.5 * (p0 - QNODE(lo - 1, e)) / (tl - a.node_times[lo - 1]);
+              if (up == P - 1) m1 = fwd;
+              else m1 = 0.5 * (QNODE(up + 1, e) - p1) / (a.node_times[up + 1] - tu) + 0.5 * (p1 - p0) / dt_mid;
+              const double s2 = s * s, s3 = s * s * s;
+              const double c0 = 2 * s3 - 3 * s2 + 1, c1 = (s3 - 2 * s2 + s) * (tu - tl), c2 = -2 * s3 + 3 * s2, c3 = (s3 - s2) * (tu - tl);
+              u = c0 * p0 + c1 * m0 + c2 * p1 + c3 * m1;
+            }
+          }
+        }
+        bad |= qbad(u);
+        ctrl[e] = clampd(u, L.ctrlrange[e][0], L.ctrlrange[e][1]);
+      }
+      for (int k = 0; k < 7; k++) bad |= qbad(S.tq[k]);
+      for (int k = 0; k < 6; k++) bad |= qbad(S.tv[k]);
+      for (int j = 0; j < 3; j++) bad |= qbad(S.lq[j]) || qbad(S.lv[j]);
+    }
+    if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
+    QForward f;
+    flags = forward(m, tab, sp, leg, S, ctrl, t > 0, con, f);
+    if (flags) break;
+    if (!last) {
+      for (int j = 0; j < 3; j++) bad |= qbad(f.qacc_l[j]);
+      for (int k = 0; k < 6; k++) bad |= qbad(f.qacc_t[k]);
+      if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
+    }
+    QResidual r;
+    const double cost = residual_cost(m, tk, sp, leg, S, f, r);
+    // ---- record step t: the quad's four lanes share the row
+    {
+      double* st = a.states + ((size_t)cand * H + t) * ds;
+      if (leg == 0) for (int k = 0; k < 7; k++) st[k] = S.tq[k];
+      if (leg == 1) for (int k = 0; k < 6; k++) st[19 + k] = S.tv[k];
+      for (int j = 0; j < 3; j++) { st[7 + 3 * leg + j] = S.lq[j]; st[25 + 3 * leg + j] = S.lv[j]; }
+      double* ac = a.actions + ((size_t)cand * H + t) * nu;
+      for (int j = 0; j < 3; j++) ac[3 * leg + j] = ctrl[j];
+      double* rs = a.residual + ((size_t)cand * H + t) * nr;
+      if (leg == 2) { for (int i = 0; i < 7; i++) rs[i] = r.shared[i]; }
+      if (leg == 3) { rs[11] = r.shared[7]; rs[12] = r.shared[8]; for (int i = 0; i < 5; i++) rs[37 + i] = r.shared[9 + i]; }
+      rs[7 + L.foot_index] = r.gait;
+      for (int j = 0; j < 3; j++) { rs[13 + 3 * leg + j] = r.effort[j]; rs[25 + 3 * leg + j] = r.posture[j]; }
+      if (leg == 0) { a.times[(size_t)cand * H + t] = S.time; a.costs[(size_t)cand * H + t] = cost; }
+      if (leg == 1) for (int q = 0; q < m.ntrace; q++) for (int k = 0; k < 3; k++) a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k] = f.trace[q][k];
+    }
+    total += cost;
+    if (last) break;
+    euler(m, leg, S, f);
+  }
+#undef QNODE
+  if (leg == 0) {
+    a.total_return[cand] = flags ? 1.0e6 : total / (double)(H > 1 ? H : 1);
+    a.failure[cand] = flags ? (kQFallback | flags) : 0;
+  }
+  return flags;
+}
+
+// world poses of the static geoms for this rollout (mocap poses from the plan blob)
+QD void static_pose(const QuadModel& m, const double* mocap, int s, QStaticPose& out) {
+  const QuadStatic& S = m.stat[s];
+  if (S.mocap < 0) {
+    for (int k = 0; k < 3; k++) out.pos[k] = S.pos[k];
+    for (int k = 0; k < 9; k++) out.mat[k] = S.rot[k];
+    return;
+  }
+  const double* mp = mocap + 7 * S.mocap;
+  double q[4] = {mp[3], mp[4], mp[5], mp[6]}, bm[9], v[3];
+  q_norm(q); q_norm(q);
+  q2mat(bm, q);
+  mv3(v, bm, S.pos);
+  for (int k = 0; k < 3; k++) out.pos[k] = mp[k] + v[k];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out.mat[3 * r + c] = bm[3 * r] * S.rot[c] + bm[3 * r + 1] * S.rot[3 + c] + bm[3 * r + 2] * S.rot[6 + c];
+}
+
+} }  // namespace mjpcx::quad
