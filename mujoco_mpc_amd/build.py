@@ -10,7 +10,11 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libmjpcx.so")
 # (source, extra flags). lane_static.hip holds the instantiations specialised for compile-time model
 # constants; its flags let exact-zero arithmetic fold (see the file header).
-SOURCES = [("mjpcx.hip", []), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"])]
+SOURCES = [("mjpcx.hip", []), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]), ("quad_kernel.hip", [])]
+# headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
+# re-compile the wavefront-per-candidate kernels, and vice versa)
+QUAD_ONLY = ["quad_step.h", "quad_kernel.h"]
+QUAD_DEPS = ["quad_step.h", "quad_kernel.h", "quad_model.h", "quad_launch.h", "quad_kernel.hip", os.path.join("..", "..", "include", "mjpcx.h")]
 HEADERS = ["device_common.h", "rollout_lane.h", "lane_registry.h", os.path.join("generated", "static_models.h"),
            os.path.join("..", "..", "include", "mjpcx.h")]
 
@@ -45,7 +49,11 @@ def build_native(force=False, verbose=False):
     for src, flags in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, deps):
+        if src == "quad_kernel.hip":
+            mine = [os.path.join(CSRC, h) for h in QUAD_DEPS]
+        else:
+            mine = [d for d in deps if os.path.basename(d) not in QUAD_ONLY and os.path.basename(d) != "quad_kernel.hip"]
+        if force or _stale(obj, mine):
             cmd = common + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))

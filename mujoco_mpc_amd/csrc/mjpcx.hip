@@ -19,6 +19,7 @@
 #include "lane_registry.h"
 #include "ilqg_dense.h"
 #include "rollout_wave.h"
+#include "quad_launch.h"
 #include <dlfcn.h>
 #include <mutex>
 #include <rccl/rccl.h>
@@ -100,6 +101,8 @@ const KernelEntry kKernels[] = {
 // not by topology: one generic kernel that reads the model through WaveModel
 const KernelEntry kTreeEntryA1 = {"rollout_tree_kernel<A1> (registered model: hot arrays staged in LDS behind compile-time offsets, persistent wavefronts, "
                                    "Jacobian-free Newton contact solver)", TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+const KernelEntry kQuadEntryA1 = {"rollout_quad_kernel (four lanes per candidate, one per leg: 16 candidates per wavefront, arrowhead Newton contact solver; "
+                                   "candidates it hands on run rollout_tree_kernel<A1>)", TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 const KernelEntry kWaveEntry = {"rollout_wave_kernel (wavefront per candidate, model in LDS/L1; Newton contact solver)",
                                 TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -350,6 +353,13 @@ struct mjpcx_ctx {
   DevBuf d_ovf;               // its global slabs for cones beyond the LDS list
   bool no_cone_slabs = false; // MJPCX_TREE_NO_SLABS=1: overflow goes to the second pass instead (A/B runs)
   int num_cu = 256;
+  // quad kernel (quad_kernel.h): four lanes per candidate; fp64 contexts of a model quad_build accepts
+  bool quad_ok = false;       // MJPCX_NO_QUAD=1 keeps the wavefront-per-candidate kernels (A/B runs)
+  bool quad_stamps = false;   // MJPCX_QUAD_STAMPS=1: phase cycle stamps of wavefront 0 (tuning aid; synchronises every rollout)
+  bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
+  std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
+  int quad_ids[7] = {0, 0, 0, 0, 0, 0, 0};  // residual_int[1..7] the quad model was built for (torso, head site, goal mocap, feet)
+  DevBuf d_qmodel, d_qtab, d_qstats, d_qstamps;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -538,7 +548,7 @@ void print_wave_stamps(mjpcx_ctx* c, long long* stamps, int stamp_step, size_t l
 // Two launches: the batch with the small contact lists, then the candidates that overflowed them with the large lists.
 template <class C, typename T, bool BIG>
 hipError_t launch_tree_pass(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>& wt, const RolloutArgs<T>& a, const void* image, size_t blob_bytes,
-                            int N, int P) {
+                            int N, int P, bool only_flagged = false) {
   const int caps = BIG ? (sizeof(T) == 8 ? w64::kTreeMaxSimpleBig : w32::kTreeMaxSimpleBig) : (sizeof(T) == 8 ? w64::kTreeMaxSimple : w32::kTreeMaxSimple);
   const int capc = BIG ? (sizeof(T) == 8 ? w64::kTreeMaxConeBig : w32::kTreeMaxConeBig) : (sizeof(T) == 8 ? w64::kTreeMaxCone : w32::kTreeMaxCone);
   const size_t arena = sizeof(T) == 8
@@ -550,7 +560,7 @@ hipError_t launch_tree_pass(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTas
   W = std::max(1, std::min(W, (N + c->num_cu - 1) / c->num_cu));  // small batches: spread over the CUs first
   int grid = std::min(c->num_cu, (N + W - 1) / W);
   if (BIG) grid = std::min(grid, 64);  // the second pass scans the failure flags; a handful of rollouts at most
-  const int mode = BIG ? (c->tree_mode & 8) : c->tree_mode;
+  const int mode = (BIG ? (c->tree_mode & 8) : c->tree_mode) | (only_flagged && !BIG ? 32 : 0);  // 32: only the candidates the quad kernel handed on
   const size_t lds = fixed + (size_t)W * arena;
   hipError_t e = c->d_work.reserve(16);
   if (e != hipSuccess) return e;
@@ -585,14 +595,55 @@ hipError_t launch_tree_pass(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTas
 }
 template <class C, typename T>
 hipError_t launch_tree(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>& wt, const RolloutArgs<T>& a, const void* image, size_t blob_bytes,
-                       int N, int P) {
-  hipError_t e = launch_tree_pass<C, T, false>(c, wm, wt, a, image, blob_bytes, N, P);
+                       int N, int P, bool only_flagged = false) {
+  hipError_t e = launch_tree_pass<C, T, false>(c, wm, wt, a, image, blob_bytes, N, P, only_flagged);
   if (e != hipSuccess || (c->tree_mode & 2) || c->no_second_pass) return e;
   RolloutArgs<T> a2 = a;
   a2.noise.mode = -1;  // the first pass left every candidate's spline nodes in a.nodes
   WaveTaskT<T> wt2 = wt;
   wt2.stamps = nullptr;
   return launch_tree_pass<C, T, true>(c, wm, wt2, a2, image, blob_bytes, N, P);
+}
+
+// quad kernel (quad_kernel.h), then the wavefront-per-candidate kernel for the candidates it handed on
+hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, const RolloutArgs<double>& a, int N, int P) {
+  quad::QArgs q{};
+  q.N = a.N; q.H = a.H; q.P = a.P; q.interp = a.interp; q.node_times = a.node_times; q.nodes = a.nodes; q.nominal = a.nominal;
+  q.noise_mode = a.noise.mode; q.seed = a.noise.seed; q.iteration = a.noise.iteration; q.candidate_offset = a.noise.candidate_offset;
+  q.nominal_candidate = a.noise.nominal_candidate; q.explore_count = a.noise.explore_count; q.std0 = a.noise.std0; q.std1 = a.noise.std1;
+  q.param_variance = a.noise.param_variance;
+  q.states = a.states; q.actions = a.actions; q.times = a.times; q.residual = a.residual; q.costs = a.costs; q.trace = a.trace;
+  q.total_return = a.total_return; q.failure = a.failure;
+  const quad::QBlob bo{wt.off_time, wt.off_mocap, wt.off_weight, wt.off_normp, wt.off_normq, wt.off_param, wt.off_risk, wt.off_rreal, wt.off_rint};
+  hipError_t e;
+  if (c->quad_stats && (e = hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream)) != hipSuccess) return e;
+  if (c->quad_stamps) {
+    if ((e = hipMemsetAsync(c->d_qstamps.p, 0, 256, c->stream)) != hipSuccess) return e;
+    q.stamps = (long long*)c->d_qstamps.p;
+  }
+  if ((e = quad::launch_rollout_quad((const QuadModel*)c->d_qmodel.p, (const QuadTables*)c->d_qtab.p, wt.blob, bo, q, c->quad_stats ? (int*)c->d_qstats.p : nullptr,
+                                     c->stream)) != hipSuccess) return e;
+  if (c->quad_stamps) {
+    long long h[32];
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h, c->d_qstamps.p, 256, hipMemcpyDeviceToHost);
+    static const char* nm[13] = {"policy", "kin..rne", "collision", "pairs", "factor+rows", "residual+record", "newton", "euler", "n:grad", "n:hessian", "n:factor+solve",
+                                 "n:linesearch", "n:update+eval"};
+    std::fprintf(stderr, "rollout_quad_kernel cycles of wavefront 0 (H = %d):", a.H);
+    for (int k = 0; k < 13; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k]);
+    std::fprintf(stderr, " | newton iterations %lld, line-search trials %lld\n", h[16], h[17]);
+  }
+  RolloutArgs<double> a2 = a;
+  a2.noise.mode = -1;  // the quad kernel left every candidate's spline nodes in a.nodes
+  e = launch_tree<TreeCfgA1, double>(c, wm, wt, a2, c->wh.dev_image, c->wh.blob_bytes, N, P, /*only_flagged=*/true);
+  if (e == hipSuccess && c->quad_stats) {
+    int h[8] = {0};
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h, c->d_qstats.p, 32, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "rollout_quad_kernel: %d of %d candidates handed to rollout_tree_kernel (contact list full %d, moving-geom pair %d, indefinite Hessian %d, "
+                 "non-finite %d, both joint limits %d)\n", h[0], N, h[1], h[2], h[3], h[4], h[5]);
+  }
+  return e;
 }
 
 template <typename T>
@@ -666,7 +717,9 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         wt.stamp_step = c->stamp_step;
       }
       const WaveModel& wm = c->wh.m;
-      if (c->wh.registered == 0) {
+      if (c->wh.registered == 0 && c->quad_ok && a.xfrc_scale == 0 && !wt.stamps) {
+        le = launch_quad(c, wm, wt, a, N, P);
+      } else if (c->wh.registered == 0) {
         le = launch_tree<TreeCfgA1, double>(c, wm, wt, a, c->wh.dev_image, c->wh.blob_bytes, N, P);
         if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
       } else {
@@ -833,6 +886,25 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       c->kernel = &kTreeEntryA1;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
+      c->quad_stats = getenv("MJPCX_QUAD_STATS") != nullptr;
+      c->quad_stamps = getenv("MJPCX_QUAD_STAMPS") != nullptr;
+      if (precision == 64 && !getenv("MJPCX_NO_QUAD")) {
+        // the quad kernel family (four lanes per candidate): models of the legged class quad_build accepts
+        std::vector<unsigned char> hq(sizeof(QuadModel)), ht(sizeof(QuadTables));
+        c->quad_why = quad_build(m, t, (QuadModel*)hq.data(), (QuadTables*)ht.data());
+        if (c->quad_why.empty()) {
+          if (c->d_qmodel.reserve(hq.size()) != hipSuccess || c->d_qtab.reserve(ht.size()) != hipSuccess || c->d_qstats.reserve(32) != hipSuccess ||
+              c->d_qstamps.reserve(256) != hipSuccess ||
+              hipMemcpy(c->d_qmodel.p, hq.data(), hq.size(), hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemcpy(c->d_qtab.p, ht.data(), ht.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            mjpcx_destroy(c);
+            return bad(MJPCX_ENOMEM, "upload of the quad kernel's model failed");
+          }
+          c->quad_ok = true;
+          c->kernel = &kQuadEntryA1;
+          for (int k = 0; k < 7; k++) c->quad_ids[k] = t->residual_int[1 + k];
+        }
+      }
     }
     set_norm_params(c, t->norm_parameter);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
@@ -939,7 +1011,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   if (c->best_host) (void)hipHostFree(c->best_host);
   (void)mjpcx_comm_destroy(c);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_comm_send, &c->d_comm_recv,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_qmodel, &c->d_qtab, &c->d_qstats, &c->d_qstamps, &c->d_comm_send, &c->d_comm_recv,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();
@@ -988,6 +1060,8 @@ int mjpcx_set_residual_state(mjpcx_ctx* c, const int32_t* residual_int, const do
   if (!c) return MJPCX_EINVAL;
   if (!c->wave) return (residual_int || residual_real) ? fail(c, MJPCX_EUNSUPPORTED, "this task's residual has no frozen state") : MJPCX_OK;
   if (residual_int) c->wh.residual_int.assign(residual_int, residual_int + c->wh.t.nri);
+  if (residual_int && c->quad_ok)  // the quad model bakes the ids Task::Reset resolves; a caller that changes them gets the generic path
+    for (int k = 0; k < 7; k++) if (residual_int[1 + k] != c->quad_ids[k]) { c->quad_ok = false; c->kernel = &kTreeEntryA1; }
   if (residual_real) c->wh.residual_real.assign(residual_real, residual_real + c->wh.t.nrr);
   return MJPCX_OK;
 }

@@ -1,0 +1,141 @@
+// quad_kernel.h -- the gfx950 launch shape of the QUAD kernel family (quad_step.h): FOUR LANES PER CANDIDATE, one per leg of
+// the floating-base quadruped, sixteen candidates per wavefront. The north-star workload (Quadruped, 16384 candidates) is
+// 1024 wavefronts = one per SIMD of the 256 CUs, each with the whole 512-entry register file of its SIMD; the per-candidate
+// state that the wavefront-per-candidate kernels keep in a 17.6 KB LDS arena is the four lanes' registers here, and a
+// reduction over the legs is two DPP quad permutes instead of an LDS round trip.
+//
+//   qd_sum    v + quad_perm[1,0,3,2](v), then + quad_perm[2,3,0,1]: every lane adds the same pairs in the same order, so the four
+//             lanes hold bit-identical sums and every branch on one is quad-uniform
+//   qd_rot<D> lane (l + D) mod 4 of the quad;  qd_bcast<K> lane K;  qd_or bitwise or
+//
+// The model (quad_model.h, ~12 KB) is staged into LDS once per workgroup (a workgroup is ONE wavefront: no barrier on the step
+// path) and read with lane-dependent (per-leg) addresses; the pair-parameter tables stay in global memory (read when a contact
+// is instantiated). A candidate the quad form does not cover is flagged in failure[] (kQFallback) and rolled out again, from
+// the start, by rollout_tree_kernel (tree_kernel.h, mode bit 32): results do not depend on which kernel produced them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "quad_model.h"
+
+namespace mjpcx { namespace quad {
+template <int CTRL> __device__ __forceinline__ double qdpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+} }
+__device__ __forceinline__ double qd_sum(double v) {
+  v += mjpcx::quad::qdpp<0xB1>(v);  // quad_perm:[1,0,3,2]
+  v += mjpcx::quad::qdpp<0x4E>(v);  // quad_perm:[2,3,0,1]
+  return v;
+}
+template <int K> __device__ __forceinline__ double qd_bcast(double v) { return mjpcx::quad::qdpp<K * 0x55>(v); }
+template <int D> __device__ __forceinline__ double qd_rot(double v) {
+  return mjpcx::quad::qdpp<(((0 + D) & 3) | (((1 + D) & 3) << 2) | (((2 + D) & 3) << 4) | (((3 + D) & 3) << 6))>(v);
+}
+__device__ __forceinline__ int qd_or(int v) {
+  v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+  v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+  return v;
+}
+
+// ---- the lane's contact store: the first kQLdsSlots records in LDS ([slot][field][lane]: a wavefront's access to one field is one
+// conflict-free ds_read_b64 / ds_write_b64), further ones in a private overflow array (scratch; touched by the rare lane with more contacts).
+// ---- the store of M while the solver runs: leg block + coupling per lane ([entry][lane]), the trunk block once per QUAD ([entry][quad]:
+// its four lanes write the same value and read it back as an LDS broadcast).
+namespace mjpcx { namespace quad {
+struct QContact;
+constexpr int kQLdsSlots = 2;
+typedef __attribute__((address_space(3))) double qlds_f64;  // a typed LDS pointer: ds_read / ds_write instead of FLAT accesses
+struct LdsStore { qlds_f64* lds; double* ovf; };
+struct LdsM { qlds_f64* ml; qlds_f64* mt; };
+struct QProf { long long* buf; long long last; };
+} }
+__device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int slot, mjpcx::quad::QContact& c);
+__device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c);
+__device__ __forceinline__ void qcs_store_jar(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c);
+__device__ __forceinline__ double qms_l(const mjpcx::quad::LdsM& m, int i) { return m.ml[i * 64]; }
+__device__ __forceinline__ double qms_b(const mjpcx::quad::LdsM& m, int j, int k) { return m.ml[(6 + 6 * j + k) * 64]; }
+__device__ __forceinline__ double qms_t(const mjpcx::quad::LdsM& m, int i) { return m.mt[i * 16]; }
+__device__ __forceinline__ void qms_set_l(mjpcx::quad::LdsM& m, int i, double v) { m.ml[i * 64] = v; }
+__device__ __forceinline__ void qms_set_b(mjpcx::quad::LdsM& m, int j, int k, double v) { m.ml[(6 + 6 * j + k) * 64] = v; }
+__device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v) { m.mt[i * 16] = v; }
+// phase cycle stamps of wavefront 0 (pf.buf != nullptr only there): s_memtime deltas accumulated per phase
+#define QPROF(pf, idx) do { if ((pf).buf) { const long long now_ = __builtin_readcyclecounter(); (pf).buf[idx] += now_ - (pf).last; (pf).last = now_; } } while (0)
+#define QPROF_COUNT(pf, idx, n) do { if ((pf).buf) (pf).buf[idx] += (n); } while (0)
+
+// every fixed-trip loop over a small array is unrolled: a loop the compiler keeps rolled indexes its array at run time, and a private array
+// indexed at run time lives in scratch
+#define QUNROLL _Pragma("unroll")
+#define QD __device__ __forceinline__
+#include "quad_step.h"
+#undef QD
+
+// record layout: n 0-2, off 3-5, D0 6, aref 7-12, jar 13-18, (depth, friction set) 19
+__device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int slot, mjpcx::quad::QContact& c) {
+  using namespace mjpcx::quad;
+  double v[kQConRec];
+  if (slot < kQLdsSlots) { const qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f * 64]; }
+  else { const double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f]; }
+  QUNROLL for (int k = 0; k < 3; k++) { c.n[k] = v[k]; c.off[k] = v[3 + k]; }
+  c.D0 = v[6];
+  QUNROLL for (int k = 0; k < 6; k++) { c.aref[k] = v[7 + k]; c.jar[k] = v[13 + k]; }
+  const int meta = (int)v[19];
+  c.depth = meta & 3; c.fid = meta >> 2;
+}
+__device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
+  using namespace mjpcx::quad;
+  double v[kQConRec];
+  QUNROLL for (int k = 0; k < 3; k++) { v[k] = c.n[k]; v[3 + k] = c.off[k]; }
+  v[6] = c.D0;
+  QUNROLL for (int k = 0; k < 6; k++) { v[7 + k] = c.aref[k]; v[13 + k] = c.jar[k]; }
+  v[19] = (double)(c.depth | (c.fid << 2));
+  if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) p[f * 64] = v[f]; }
+  else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) p[f] = v[f]; }
+}
+__device__ __forceinline__ void qcs_store_jar(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
+  using namespace mjpcx::quad;
+  if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int k = 0; k < 6; k++) p[(13 + k) * 64] = c.jar[k]; }
+  else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int k = 0; k < 6; k++) p[13 + k] = c.jar[k]; }
+}
+
+namespace mjpcx { namespace quad {
+
+constexpr size_t kQWaveCon = (size_t)kQLdsSlots * kQConRec * 64, kQWaveMl = 24 * 64, kQWaveMt = 21 * 16;  // doubles per wavefront: contacts, M
+constexpr size_t kQWaveLds = (kQWaveCon + kQWaveMl + kQWaveMt) * sizeof(double);
+
+// Workgroup = W wavefronts (W = 4 for the large batches: one per SIMD of a CU, sharing one model image; W = 1 spreads small batches
+// over the CUs). stats[0]: candidates handed to the fallback kernel, stats[1 + log2(flag)]: by reason.
+__global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __restrict__ gm, const QuadTables* __restrict__ tab, const double* __restrict__ blob,
+                                                           const QBlob bo, const QArgs a, int* __restrict__ stats) {
+  __shared__ QuadModel sm;
+  __shared__ QStaticPose sp[kQStatic];
+  extern __shared__ __attribute__((aligned(16))) double con_lds[];
+  {
+    static_assert(sizeof(QuadModel) % 8 == 0, "QuadModel is staged in 8-byte words");
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(gm);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&sm);
+    for (unsigned i = threadIdx.x; i < sizeof(QuadModel) / 8; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < sm.nstatic) static_pose(sm, blob + bo.off_mocap, threadIdx.x, sp[threadIdx.x]);
+  __syncthreads();
+  const int cand = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, leg = threadIdx.x & 3;
+  if (cand >= a.N) return;  // (whole quads leave together)
+  QTask tk;
+  tk.mocap = blob + bo.off_mocap; tk.weight = blob + bo.off_weight; tk.norm_p = blob + bo.off_normp; tk.norm_q = blob + bo.off_normq;
+  tk.param = blob + bo.off_param; tk.re = blob + bo.off_rreal; tk.ri = reinterpret_cast<const int*>(blob + bo.off_rint); tk.risk = blob[bo.off_risk];
+  double ovf[(kQMaxCon - kQLdsSlots) * kQConRec];
+  qlds_f64* wave_lds = (qlds_f64*)con_lds + (threadIdx.x >> 6) * (kQWaveLds / sizeof(double));
+  LdsStore cs{wave_lds + (threadIdx.x & 63), ovf};
+  LdsM ms{wave_lds + kQWaveCon + (threadIdx.x & 63), wave_lds + kQWaveCon + kQWaveMl + ((threadIdx.x & 63) >> 2)};
+  QProf pf{nullptr, 0};
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x < 64) { pf.buf = a.stamps; pf.last = __builtin_readcyclecounter(); }
+  const int flags = rollout(sm, *tab, sp, tk, blob, blob[bo.off_time], a, cand, leg, cs, ms, pf);
+  if (flags && leg == 0 && stats) {
+    atomicAdd(stats, 1);
+    QUNROLL for (int b = 0; b < 5; b++) if (flags & (1 << b)) atomicAdd(stats + 1 + b, 1);
+  }
+}
+
+} }  // namespace mjpcx::quad

@@ -17,6 +17,8 @@
 #include <utility>
 #include <vector>
 
+#include <stdint.h>
+
 #include "../../include/mjpcx.h"
 
 namespace mjpcx {
@@ -27,6 +29,7 @@ constexpr int kQTrunkGeom = 8;   // collidable geoms on the trunk (dealt over th
 constexpr int kQStatic = 4;      // collidable static geoms (world / mocap bodies)
 constexpr int kQPairGeom = 6;    // sphere | capsule geoms per leg in moving-geom pairs; kQTrunkPairGeom on the trunk
 constexpr int kQTrunkPairGeom = 2;
+constexpr int kQMaxFric = 8;     // distinct friction sets (mu, tangential, torsional, rolling) over the contact pairs
 constexpr int kQMaxKey = 4, kQMaxTrace = 2, kQMaxTerm = 16, kQMaxRay = 4;
 constexpr int kQMaxCon = 6;      // contacts per lane and step; more -> the candidate is handed to the wavefront-per-candidate kernel
 constexpr int kQFallback = 0x40000000;  // failure[] marker of a candidate the quad kernel handed on (cleared by the fallback pass)
@@ -34,7 +37,7 @@ constexpr int kQFallback = 0x40000000;  // failure[] marker of a candidate the q
 // contact parameters of a (static geom, moving geom) pair: mj_contactParam with solref / solimp pre-digested
 // (oracle/contact.inc contact_param, solref_kb, impedance's clipping)
 struct QuadPair {
-  int collide, dim;
+  int collide, dim, fid, pad;   // fid: friction set (QuadModel::fric)
   double margin, includemargin, mu, fric1, fric3, fric4;  // mu = friction[0] / sqrt(impratio); tangential, torsional, rolling
   double k, b;                                            // reference acceleration: aref = -b vel - k imp pos
   double imp[5];                                          // dmin dmax width mid power, clipped
@@ -44,11 +47,13 @@ struct QuadPair {
 struct QuadGeom {
   int type, link, model_id, pad;  // link: -1 trunk, 0..2 link of the lane's leg
   double pos[3], rot[9], size[3]; // pose in the body frame (rotation matrix of geom_quat)
+  double bound;                   // radius of its bounding sphere
 };
 
 struct QuadStatic {
   int type, mocap, model_id, ray;  // mocap: mocap id of its body or -1 (world); ray: group 0 (Ground() casts against it)
   double pos[3], rot[9], size[3];  // pose in the body frame (world body: world pose)
+  double bound;                    // radius of its bounding sphere (box)
 };
 
 struct QuadLeg {
@@ -85,6 +90,10 @@ struct QuadModel {
   // over these sets (checked by quad_build); the kernel only tests them -- a pair within pair_margin hands the candidate on
   int ntpg, tpg_slot[kQTrunkPairGeom];
   double pair_margin;
+  // friction sets of the contact pairs: regularised mu, then the tangential / torsional / rolling coefficient, ZERO for rows the pair's
+  // condim does not have (the cone formulas then reduce to the lower condim's)
+  int nfric, pad2;
+  double fric[kQMaxFric][4];
 };
 
 // everything the kernel needs that is too rarely read to deserve LDS: the pair table [static][trunk geoms | leg geoms]
@@ -93,6 +102,27 @@ struct QuadTables {
   QuadPair leg[kQLegs][kQStatic][kQLegGeom];
   int npair;
 };
+
+namespace quad {
+// the rollout request (RolloutArgs<double> of rollout_lane.h, flattened so that the CPU emulator can fill it too)
+struct QArgs {
+  int N, H, P, interp;
+  const double* node_times;  // P
+  double* nodes;             // [P][nu][N]
+  const double* nominal;     // [P][nu]
+  int noise_mode;            // -1: candidates given in `nodes`
+  uint64_t seed; uint32_t iteration;
+  int candidate_offset, nominal_candidate, explore_count;
+  double std0, std1;
+  const double* param_variance;
+  double *states, *actions, *times, *residual, *costs, *trace, *total_return;  // [candidate][step][field]
+  int* failure;
+  long long* stamps;  // nullptr, or 32 counters: phase cycles of wavefront 0 (tuning aid, MJPCX_QUAD_STAMPS=1)
+};
+
+// offsets into the per-plan blob (WaveTaskT: wave_model.h)
+struct QBlob { int off_time, off_mocap, off_weight, off_normp, off_normq, off_param, off_risk, off_rreal, off_rint; };
+}  // namespace quad
 
 namespace quad_detail {
 inline void quat2mat(double* m, const double* q) {
@@ -234,6 +264,7 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
       if (b != 0 && s.mocap < 0) return "static geom on a non-mocap body";
       for (int k = 0; k < 3; k++) { s.pos[k] = m->geom_pos[3 * g + k]; s.size[k] = m->geom_size[3 * g + k]; }
       std::memcpy(s.rot, rot, sizeof rot);
+      s.bound = std::sqrt(s.size[0] * s.size[0] + s.size[1] * s.size[1] + s.size[2] * s.size[2]);
       static_slot[g] = collidable ? qm->nstatic : -1;
       if (!collidable) s.type = -1 - s.type;  // ray-only geom: the collision pass skips it
       qm->nstatic++;
@@ -259,6 +290,9 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
     dst->type = m->geom_type[g]; dst->model_id = g;
     for (int k = 0; k < 3; k++) { dst->pos[k] = m->geom_pos[3 * g + k]; dst->size[k] = m->geom_size[3 * g + k]; }
     std::memcpy(dst->rot, rot, sizeof rot);
+    const double* sz = dst->size;
+    dst->bound = dst->type == MJPCX_GEOM_CAPSULE ? sz[0] + sz[1] : dst->type == MJPCX_GEOM_CYLINDER ? std::sqrt(sz[0] * sz[0] + sz[1] * sz[1])
+               : dst->type == MJPCX_GEOM_BOX ? std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]) : sz[0];
   }
   // pair parameters (oracle/contact.inc contact_param; o_collision's type table)
   const double impratio = m->impratio > 1e-15 ? m->impratio : 1.0;
@@ -300,6 +334,15 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
       solref_kb(m, solref, solimp, &p.k, &p.b);
       digest_solimp(p.imp, solimp);
       p.diag = m->body_invweight0[2 * m->geom_bodyid[g1]] + m->body_invweight0[2 * m->geom_bodyid[g2]];
+      if (!(p.margin < 0.009)) return "a contact margin of 9 mm or more (the collision pass rejects geoms 1 cm clear of a static geom)";
+      const double fs[4] = {p.mu, p.dim >= 3 ? p.fric1 : 0.0, p.dim >= 4 ? p.fric3 : 0.0, p.dim >= 6 ? p.fric4 : 0.0};
+      p.fid = -1;
+      for (int f = 0; f < qm->nfric; f++) if (std::memcmp(qm->fric[f], fs, sizeof fs) == 0) p.fid = f;
+      if (p.fid < 0) {
+        if (qm->nfric == kQMaxFric) return "more distinct friction sets than the quad kernel stages";
+        std::memcpy(qm->fric[qm->nfric], fs, sizeof fs);
+        p.fid = qm->nfric++;
+      }
     }
   }
   // moving-geom pairs (oracle/contact.inc bake_pairs): tested only. The kernel walks them as a cross product, so the set must be one.

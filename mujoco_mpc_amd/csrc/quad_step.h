@@ -25,6 +25,13 @@
 
 #include "quad_model.h"
 
+#ifndef QPROF
+#define QPROF(pf, idx)
+#define QPROF_COUNT(pf, idx, n)
+#endif
+#ifndef QUNROLL
+#define QUNROLL
+#endif
 #ifndef QD
 #error "define QD (function qualifiers) and the quad primitives before including quad_step.h"
 #endif
@@ -72,7 +79,7 @@ QD double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b
 // rotated inertia R diag(I) R' (6 unique: xx yy zz xy xz yz) -- the part of inert_com that does not need the reference point
 QD void rot_inertia(double* res, const double* inert, const double* mat) {
   double tmp[9];
-  for (int c = 0; c < 3; c++) { tmp[c] = inert[0] * mat[3 * c]; tmp[3 + c] = inert[1] * mat[3 * c + 1]; tmp[6 + c] = inert[2] * mat[3 * c + 2]; }
+  QUNROLL for (int c = 0; c < 3; c++) { tmp[c] = inert[0] * mat[3 * c]; tmp[3 + c] = inert[1] * mat[3 * c + 1]; tmp[6 + c] = inert[2] * mat[3 * c + 2]; }
   res[0] = mat[0] * tmp[0] + mat[1] * tmp[3] + mat[2] * tmp[6];
   res[1] = mat[3] * tmp[1] + mat[4] * tmp[4] + mat[5] * tmp[7];
   res[2] = mat[6] * tmp[2] + mat[7] * tmp[5] + mat[8] * tmp[8];
@@ -131,9 +138,9 @@ QD void make_frame(double* frame) {
   if (x[1] < 0.5 && x[1] > -0.5) { y[0] = 0; y[1] = 1; y[2] = 0; }
   else { y[0] = 0; y[1] = 0; y[2] = 1; }
   const double dt = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
-  for (int k = 0; k < 3; k++) y[k] -= dt * x[k];
+  QUNROLL for (int k = 0; k < 3; k++) y[k] -= dt * x[k];
   const double n = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-  for (int k = 0; k < 3; k++) y[k] /= n;
+  QUNROLL for (int k = 0; k < 3; k++) y[k] /= n;
   cr3(z, x, y);
 }
 QD void qd_sum_n(double* v, int n) { for (int i = 0; i < n; i++) v[i] = qd_sum(v[i]); }
@@ -142,88 +149,81 @@ QD void qd_sum_n(double* v, int n) { for (int i = 0; i < n; i++) v[i] = qd_sum(v
 QD constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 
 // ---------------------------------------------------------------- arrowhead matrices
-// Symmetric positive-definite matrix of the legged tree: per lane the leg block L (3 x 3, packed lower triangle l[tri]), the
-// coupling B (3 leg dofs x 6 trunk dofs); replicated in the four lanes the trunk block T (6 x 6, packed).
+// Symmetric positive-definite matrix of the legged tree: per lane the leg block (3 x 3, packed lower triangle l[tri]), the coupling
+// b (3 leg dofs x 6 trunk dofs); replicated in the four lanes the trunk block t (6 x 6, packed). arrow_factor turns it IN PLACE into
+// its factor: the leg block as unit-lower L D L' (l[1] = l10, l[3] = l20, l[4] = l21, reciprocal pivots in l[0], l[2], l[5]),
+// b := Z = Lblock^-1 B, t := the L D L' factor of the Schur complement S = T - sum_legs B' Z (unit-lower entries below the diagonal,
+// RECIPROCAL pivots on it).
 struct Arrow { double l[6], b[3][6], t[21]; };
-// its factor: the leg block as unit-lower L D L' (l10 l20 l21, reciprocal pivots), Z = Lblock^-1 B, and the L D L' factor of
-// the Schur complement S = T - sum_legs B' Z (packed: unit-lower entries below the diagonal, RECIPROCAL pivots on it)
-struct ArrowFactor { double l10, l20, l21, di[3], z[3][6], s[21]; };
 
-QD void leg_solve(const ArrowFactor& f, double* x) {  // x := Lblock^-1 x
-  x[1] -= f.l10 * x[0];
-  x[2] -= f.l20 * x[0] + f.l21 * x[1];
-  x[0] *= f.di[0]; x[1] *= f.di[1]; x[2] *= f.di[2];
-  x[1] -= f.l21 * x[2];
-  x[0] -= f.l10 * x[1] + f.l20 * x[2];
+QD void leg_solve(const Arrow& f, double* x) {  // x := Lblock^-1 x (f factored)
+  x[1] -= f.l[1] * x[0];
+  x[2] -= f.l[3] * x[0] + f.l[4] * x[1];
+  x[0] *= f.l[0]; x[1] *= f.l[2]; x[2] *= f.l[5];
+  x[1] -= f.l[4] * x[2];
+  x[0] -= f.l[1] * x[1] + f.l[3] * x[2];
 }
 // returns false (quad-uniform) if a pivot is not positive
-QD bool arrow_factor(const Arrow& a, ArrowFactor& f) {
+QD bool arrow_factor(Arrow& a) {
   bool ok = true;
   const double d0 = a.l[0];
   ok &= d0 > kQMinVal;
-  f.di[0] = 1.0 / d0;
-  f.l10 = a.l[1] * f.di[0]; f.l20 = a.l[3] * f.di[0];
-  const double d1 = a.l[2] - f.l10 * f.l10 * d0;
+  const double i0 = 1.0 / d0, l10 = a.l[1] * i0, l20 = a.l[3] * i0;
+  const double d1 = a.l[2] - l10 * l10 * d0;
   ok &= d1 > kQMinVal;
-  f.di[1] = 1.0 / d1;
-  f.l21 = (a.l[4] - f.l20 * f.l10 * d0) * f.di[1];
-  const double d2 = a.l[5] - f.l20 * f.l20 * d0 - f.l21 * f.l21 * d1;
+  const double i1 = 1.0 / d1, l21 = (a.l[4] - l20 * l10 * d0) * i1;
+  const double d2 = a.l[5] - l20 * l20 * d0 - l21 * l21 * d1;
   ok &= d2 > kQMinVal;
-  f.di[2] = 1.0 / d2;
-  for (int k = 0; k < 6; k++) {
-    double col[3] = {a.b[0][k], a.b[1][k], a.b[2][k]};
-    leg_solve(f, col);
-    f.z[0][k] = col[0]; f.z[1][k] = col[1]; f.z[2][k] = col[2];
+  const double i2 = 1.0 / d2;
+  a.l[0] = i0; a.l[1] = l10; a.l[2] = i1; a.l[3] = l20; a.l[4] = l21; a.l[5] = i2;
+  // Y = L^-1 B in place (forward substitution only); the Schur complement needs Y' D^-1 Y
+  QUNROLL for (int k = 0; k < 6; k++) { a.b[1][k] -= l10 * a.b[0][k]; a.b[2][k] -= l20 * a.b[0][k] + l21 * a.b[1][k]; }
+  QUNROLL for (int r = 0; r < 6; r++)
+    QUNROLL for (int c = 0; c <= r; c++)
+      a.t[tri(r, c)] -= qd_sum(a.b[0][r] * a.b[0][c] * i0 + a.b[1][r] * a.b[1][c] * i1 + a.b[2][r] * a.b[2][c] * i2);
+  // Z = L^-T D^-1 Y in place
+  QUNROLL for (int k = 0; k < 6; k++) {
+    a.b[2][k] *= i2;
+    a.b[1][k] = a.b[1][k] * i1 - l21 * a.b[2][k];
+    a.b[0][k] = a.b[0][k] * i0 - l10 * a.b[1][k] - l20 * a.b[2][k];
   }
-  double s[21];
-  for (int r = 0; r < 6; r++)
-    for (int c = 0; c <= r; c++) s[tri(r, c)] = a.b[0][r] * f.z[0][c] + a.b[1][r] * f.z[1][c] + a.b[2][r] * f.z[2][c];
-  qd_sum_n(s, 21);
-  for (int i = 0; i < 21; i++) s[i] = a.t[i] - s[i];
   // L D L' of S (replicated)
   double d[6];
-  for (int j = 0; j < 6; j++) {
-    double dj = s[tri(j, j)];
-    for (int k = 0; k < j; k++) dj -= s[tri(j, k)] * s[tri(j, k)] * d[k];
+  QUNROLL for (int j = 0; j < 6; j++) {
+    double dj = a.t[tri(j, j)];
+    QUNROLL for (int k = 0; k < j; k++) dj -= a.t[tri(j, k)] * a.t[tri(j, k)] * d[k];
     ok &= dj > kQMinVal;
     d[j] = dj;
     const double inv = 1.0 / dj;
     for (int i = j + 1; i < 6; i++) {
-      double v = s[tri(i, j)];
-      for (int k = 0; k < j; k++) v -= s[tri(i, k)] * s[tri(j, k)] * d[k];
-      s[tri(i, j)] = v * inv;
+      double v = a.t[tri(i, j)];
+      QUNROLL for (int k = 0; k < j; k++) v -= a.t[tri(i, k)] * a.t[tri(j, k)] * d[k];
+      a.t[tri(i, j)] = v * inv;
     }
-    s[tri(j, j)] = inv;
+    a.t[tri(j, j)] = inv;
   }
-  for (int i = 0; i < 21; i++) f.s[i] = s[i];
   return qd_or(ok ? 0 : 1) == 0;
 }
-// x := A^-1 x  (xl: the lane's three leg entries, xt: the six trunk entries, replicated)
-QD void arrow_solve(const ArrowFactor& f, double* xl, double* xt) {
-  double zt[6];
-  for (int k = 0; k < 6; k++) zt[k] = f.z[0][k] * xl[0] + f.z[1][k] * xl[1] + f.z[2][k] * xl[2];
-  qd_sum_n(zt, 6);
-  for (int k = 0; k < 6; k++) xt[k] -= zt[k];
-  for (int i = 1; i < 6; i++) for (int k = 0; k < i; k++) xt[i] -= f.s[tri(i, k)] * xt[k];
-  for (int i = 0; i < 6; i++) xt[i] *= f.s[tri(i, i)];
-  for (int i = 4; i >= 0; i--) for (int k = i + 1; k < 6; k++) xt[i] -= f.s[tri(k, i)] * xt[k];
+// x := A^-1 x  (xl: the lane's three leg entries, xt: the six trunk entries, replicated); f factored
+QD void arrow_solve(const Arrow& f, double* xl, double* xt) {
+  QUNROLL for (int k = 0; k < 6; k++) xt[k] -= qd_sum(f.b[0][k] * xl[0] + f.b[1][k] * xl[1] + f.b[2][k] * xl[2]);
+  QUNROLL for (int i = 1; i < 6; i++) QUNROLL for (int k = 0; k < i; k++) xt[i] -= f.t[tri(i, k)] * xt[k];
+  QUNROLL for (int i = 0; i < 6; i++) xt[i] *= f.t[tri(i, i)];
+  QUNROLL for (int i = 4; i >= 0; i--) for (int k = i + 1; k < 6; k++) xt[i] -= f.t[tri(k, i)] * xt[k];
   leg_solve(f, xl);
-  for (int j = 0; j < 3; j++) for (int k = 0; k < 6; k++) xl[j] -= f.z[j][k] * xt[k];
+  QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) xl[j] -= f.b[j][k] * xt[k];
 }
 // y = A x; yt needs the quad sum of the coupling term
 QD void arrow_mul(const Arrow& a, const double* xl, const double* xt, double* yl, double* yt) {
-  for (int j = 0; j < 3; j++) {
+  QUNROLL for (int j = 0; j < 3; j++) {
     double s = 0;
-    for (int i = 0; i < 3; i++) s += a.l[tri(j, i)] * xl[i];
-    for (int k = 0; k < 6; k++) s += a.b[j][k] * xt[k];
+    QUNROLL for (int i = 0; i < 3; i++) s += a.l[tri(j, i)] * xl[i];
+    QUNROLL for (int k = 0; k < 6; k++) s += a.b[j][k] * xt[k];
     yl[j] = s;
   }
-  double c[6];
-  for (int k = 0; k < 6; k++) c[k] = a.b[0][k] * xl[0] + a.b[1][k] * xl[1] + a.b[2][k] * xl[2];
-  qd_sum_n(c, 6);
-  for (int k = 0; k < 6; k++) {
-    double s = c[k];
-    for (int i = 0; i < 6; i++) s += a.t[tri(k, i)] * xt[i];
+  QUNROLL for (int k = 0; k < 6; k++) {
+    double s = qd_sum(a.b[0][k] * xl[0] + a.b[1][k] * xl[1] + a.b[2][k] * xl[2]);
+    QUNROLL for (int i = 0; i < 6; i++) s += a.t[tri(k, i)] * xt[i];
     yt[k] = s;
   }
 }
@@ -240,207 +240,167 @@ struct QState {
   double time;
 };
 
+// A contact in WORLD axes at the contact point. The rows of MuJoCo's contact frame (normal, two tangents; then torsion and two
+// rolling axes) only ever enter the elliptic-cone penalty through the normal component and the LENGTH of the tangential / rolling
+// parts -- both tangents share one friction coefficient, both rolling axes another -- so the tangent axes are never formed: the
+// "row space" of a contact is the 6-vector [angular; linear] of relative velocity / acceleration at the point, and
+//     jar = A V_body - aref,   A [w; v] = [w; v + w x off]   (off = point - centre of mass, V_body about the centre of mass).
+// condim 1 / 3 / 4 are the same formulas with the friction coefficients of the missing rows set to zero.
 struct QContact {
-  double F[9], off[3];          // frame (rows: normal, tangent 1, tangent 2), point - centre of mass
-  double D0, mu, f1, f3, f4;    // D of the normal row, regularised mu, friction coefficients (tangential, torsional, rolling)
-  double aref[6], jar[6], jv[6];
-  int dim, depth;               // depth: leg dofs on the body's chain (0: trunk)
+  double n[3], off[3];
+  double D0;               // D of the normal row
+  double aref[6], jar[6];  // [angular; linear]
+  int depth;               // leg dofs on the body's chain (0: trunk)
+  int fid;                 // friction set (QuadModel::fric): regularised mu, tangential / torsional / rolling friction (0: row absent)
 };
+constexpr int kQConRec = 20;  // doubles per stored contact (quad_kernel.h / the emulator provide the store: qcs_load, qcs_store, qcs_store_jar)
 
 // world poses of the static geoms, computed once per rollout (mocap bodies do not move during a rollout)
 struct QStaticPose { double pos[3], mat[9]; };
 
-// what one forward pass leaves for the sensor stage, the recording and the integrator
-struct QForward {
-  Arrow M;
-  double txm[9], txq[4], txipos[3], com[3], comvel[3], head[3], foot[3];
-  double trace[kQMaxTrace][3];
-  double act_force[3];
-  double qacc_l[3], qacc_t[6], fs_l[3], fs_t[6], fc_l[3], fc_t[6];  // qacc; qfrc_smooth; qfrc_constraint
-  int iters;
-};
-
 // world pose of the lane's sphere | capsule geoms that take part in moving-geom pairs (self-collision test)
 struct QPairGeoms { double c[kQPairGeom][3], a[kQPairGeom][3]; };
 
-// rows of a contact acting on the spatial velocity [angular; linear] about the centre of mass
-QD void contact_rows(const QContact& c, double A[6][6]) {
-  for (int r = 0; r < 3; r++) {
-    const double* Fr = c.F + 3 * r;
-    cr3(A[r], c.off, Fr);                      // (off x F_r) . w  =  F_r . (w x off)
-    A[r][3] = Fr[0]; A[r][4] = Fr[1]; A[r][5] = Fr[2];
-    A[r + 3][0] = Fr[0]; A[r + 3][1] = Fr[1]; A[r + 3][2] = Fr[2];
-    A[r + 3][3] = 0; A[r + 3][4] = 0; A[r + 3][5] = 0;
-  }
-}
-QD double cfric(const QContact& c, int j) { return j < 3 ? c.f1 : (j == 3 ? c.f3 : c.f4); }  // friction[j - 1] of row j >= 1
-QD double cD(const QContact& c, int j) { if (j == 0) return c.D0; const double f = cfric(c, j); return c.D0 * (f * f) / (c.mu * c.mu); }
-
-// penalty of one contact at jar: cost, force (= -ds/djar) and zone (0 top, 1 middle, 2 bottom); oracle constraint_cost
-QD double contact_cost(const QContact& c, const double* jar, double* force, int& zone) {
-  const int dim = c.dim;
-  for (int j = 0; j < 6; j++) force[j] = 0;
-  if (dim == 1) {
-    if (jar[0] < 0) { force[0] = -c.D0 * jar[0]; zone = 2; return 0.5 * c.D0 * jar[0] * jar[0]; }
-    zone = 0;
-    return 0;
-  }
-  const double mu = c.mu;
-  double U[6], T = 0;
-  U[0] = jar[0] * mu;
-  for (int j = 1; j < 6; j++) { U[j] = j < dim ? jar[j] * cfric(c, j) : 0.0; T += U[j] * U[j]; }
-  T = sqrt(T);
-  const double N = U[0];
-  if (N >= mu * T || (T <= 0 && N >= 0)) { zone = 0; return 0; }
-  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-    double cost = 0;
-    for (int j = 0; j < 6; j++) if (j < dim) { const double D = cD(c, j); cost += 0.5 * D * jar[j] * jar[j]; force[j] = -D * jar[j]; }
-    zone = 2;
-    return cost;
-  }
-  const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
-  force[0] = -Dm * NT * mu;
-  for (int j = 1; j < 6; j++) if (j < dim) force[j] = Dm * NT * mu * U[j] * cfric(c, j) / T;
-  zone = 1;
-  return 0.5 * Dm * NT * NT;
-}
-// first and second derivative of the contact's penalty along jv at jar + alpha jv (oracle constraint_line)
-QD void contact_line(const QContact& c, double alpha, double& g, double& h) {
-  const int dim = c.dim;
-  if (dim == 1) {
-    const double x = c.jar[0] + alpha * c.jv[0];
-    if (x < 0) { g += c.D0 * x * c.jv[0]; h += c.D0 * c.jv[0] * c.jv[0]; }
-    return;
-  }
-  const double mu = c.mu;
-  double U[6], V[6], T = 0;
-  U[0] = (c.jar[0] + alpha * c.jv[0]) * mu; V[0] = c.jv[0] * mu;
-  for (int j = 1; j < 6; j++) {
-    const double f = j < dim ? cfric(c, j) : 0.0;
-    U[j] = (c.jar[j] + alpha * c.jv[j]) * f; V[j] = c.jv[j] * f;
-    T += U[j] * U[j];
-  }
-  T = sqrt(T);
-  const double N = U[0];
-  if (N >= mu * T || (T <= 0 && N >= 0)) return;
-  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-    for (int j = 0; j < 6; j++) if (j < dim) {
-      const double xj = c.jar[j] + alpha * c.jv[j], D = cD(c, j);
-      g += D * xj * c.jv[j]; h += D * c.jv[j] * c.jv[j];
-    }
-    return;
-  }
-  const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
-  double UV = 0, VV = 0;
-  for (int j = 1; j < 6; j++) { UV += U[j] * V[j]; VV += V[j] * V[j]; }
-  const double dNT = V[0] - mu * UV / T, d2NT = -mu * (VV / T - UV * UV / (T * T * T));
-  g += Dm * NT * dNT;
-  h += Dm * (dNT * dNT + NT * d2NT);
-}
-// X += A' (d2s/djar2) A for one contact in zone `zone` at jar (oracle constraint_hessian's cone block); X packed 6 x 6
-QD void contact_hessian(const QContact& c, int zone, double* X) {
-  if (zone == 0) return;
-  const int dim = c.dim;
-  double A[6][6];
-  contact_rows(c, A);
-  double Hc[6][6];
-  for (int j = 0; j < 6; j++) for (int k = 0; k < 6; k++) Hc[j][k] = 0;
-  if (zone == 2 || dim == 1) {
-    for (int j = 0; j < 6; j++) if (j < dim) Hc[j][j] = cD(c, j);
-  } else {
-    const double mu = c.mu;
-    double U[6], s[6], T = 0;
-    s[0] = mu; U[0] = c.jar[0] * mu;
-    for (int j = 1; j < 6; j++) { s[j] = j < dim ? cfric(c, j) : 0.0; U[j] = c.jar[j] * s[j]; T += U[j] * U[j]; }
-    T = sqrt(T);
-    const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = U[0] - mu * T;
-    Hc[0][0] = Dm;
-    for (int j = 1; j < 6; j++) {
-      if (j >= dim) continue;
-      Hc[0][j] = Hc[j][0] = -Dm * mu * U[j] / T;
-      for (int k = 1; k < 6; k++)
-        if (k < dim) Hc[j][k] = Dm * mu * mu * U[j] * U[k] / (T * T) - Dm * NT * mu * ((j == k ? 1.0 / T : 0.0) - U[j] * U[k] / (T * T * T));
-    }
-    for (int j = 0; j < 6; j++) for (int k = 0; k < 6; k++) Hc[j][k] *= s[j] * s[k];
-  }
-  // Y = Hc A (dim x 6), X += A' Y
-  double Y[6][6];
-  for (int j = 0; j < 6; j++)
-    for (int q = 0; q < 6; q++) {
-      double v = 0;
-      for (int k = 0; k < 6; k++) v += Hc[j][k] * A[k][q];
-      Y[j][q] = v;
-    }
-  for (int p = 0; p < 6; p++)
-    for (int q = 0; q <= p; q++) {
-      double v = 0;
-      for (int j = 0; j < 6; j++) v += A[j][p] * Y[j][q];
-      X[tri(p, q)] += v;
-    }
-}
-
-// the position-dependent part of a forward pass a lane keeps in registers
+// the position-dependent part of a forward pass that the constraint solve needs
 struct QKin {
   double cdof[3][6];             // the leg's three hinge dofs
   double ca[3][3], cl[3][3];     // the trunk's rotational dofs: angular = body axes, linear = axis x (com - trunk origin)
-  double xpos[3][3], xmat[3][9]; // link frames
-  double cvel[3][6], cvelT[6];   // spatial velocities of the links / the trunk
 };
 
-// V = spatial velocity of the body at chain depth d for the dof vector (xl, xt): Vp[0] trunk, Vp[d] = + leg dofs < d
+// spatial velocity [angular; linear about the centre of mass] of the bodies on the lane's chain for the dof vector (xl, xt):
+// Vp[0] trunk, Vp[d] = + leg dofs < d
 QD void chain_velocity(const QKin& k, const double* xl, const double* xt, double Vp[4][6]) {
-  for (int c = 0; c < 3; c++) {
+  QUNROLL for (int c = 0; c < 3; c++) {
     Vp[0][c] = k.ca[0][c] * xt[3] + k.ca[1][c] * xt[4] + k.ca[2][c] * xt[5];
     Vp[0][3 + c] = xt[c] + k.cl[0][c] * xt[3] + k.cl[1][c] * xt[4] + k.cl[2][c] * xt[5];
   }
-  for (int j = 0; j < 3; j++) for (int c = 0; c < 6; c++) Vp[j + 1][c] = Vp[j][c] + k.cdof[j][c] * xl[j];
+  QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int c = 0; c < 6; c++) Vp[j + 1][c] = Vp[j][c] + k.cdof[j][c] * xl[j];
+}
+// the contact's point-space 6-vector of body velocity V: [w; v + w x off]
+QD void point_vel(const QContact& c, const double Vp[4][6], double* out) {
+  double V[6];
+  QUNROLL for (int k = 0; k < 6; k++) V[k] = c.depth == 3 ? Vp[3][k] : (c.depth == 2 ? Vp[2][k] : (c.depth == 1 ? Vp[1][k] : Vp[0][k]));
+  double w[3];
+  cr3(w, V, c.off);
+  QUNROLL for (int k = 0; k < 3; k++) { out[k] = V[k]; out[3 + k] = V[3 + k] + w[k]; }
 }
 // trunk dof k of the spatial force Fs: cdofT_k . Fs
 QD double trunk_dot(const QKin& k, int dof, const double* Fs) {
   if (dof < 3) return Fs[3 + dof];
   return dot3(k.ca[dof - 3], Fs) + dot3(k.cl[dof - 3], Fs + 3);
 }
+// X (packed symmetric 6 x 6 over [angular; linear]) += w v v'
+QD void add_outer(double* X, double w, const double* v) {
+  QUNROLL for (int p = 0; p < 6; p++) { const double wp = w * v[p]; QUNROLL for (int q = 0; q <= p; q++) X[tri(p, q)] += wp * v[q]; }
+}
+// X += w Qt, Qt = A' blkdiag(f3^2 nn' + f4^2 P, f1^2 P) A about the centre of mass (P = I - nn', g = off x n):
+//   ll = f1^2 P;  al = f1^2 ([off]x - g n');  aa = f3^2 nn' + f4^2 P + f1^2 (|off|^2 I - off off' - g g')
+QD void add_Qt(double* X, double w, const QContact& c, const double* fr, const double* g) {
+  const double f1s = w * fr[1] * fr[1], f3s = w * fr[2] * fr[2], f4s = w * fr[3] * fr[3];
+  const double* n = c.n; const double* o = c.off;
+  const double o2 = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+  QUNROLL for (int p = 0; p < 3; p++)
+    QUNROLL for (int q = 0; q <= p; q++) {
+      const double nn = n[p] * n[q], id = p == q ? 1.0 : 0.0;
+      X[tri(p, q)] += f3s * nn + f4s * (id - nn) + f1s * (o2 * id - o[p] * o[q] - g[p] * g[q]);
+      X[tri(3 + p, 3 + q)] += f1s * (id - nn);
+    }
+  // rows linear (3 + i), columns angular (j): al[j][i] = f1^2 ([off]x[j][i] - g[j] n[i]);  [off]x = [[0,-o2,o1],[o2,0,-o0],[-o1,o0,0]]
+  const double ox[3][3] = {{0, -o[2], o[1]}, {o[2], 0, -o[0]}, {-o[1], o[0], 0}};
+  QUNROLL for (int i = 0; i < 3; i++) QUNROLL for (int j = 0; j < 3; j++) X[tri(3 + i, j)] += f1s * (ox[j][i] - g[j] * n[i]);
+}
+// Penalty of one contact at c.jar: returns the cost, adds the spatial force about the centre of mass (J' force for the chain) to Fs
+// and, if X, the Hessian block A' (d2s / djar2) A to X. zone: 0 top (nothing), 1 middle, 2 bottom (oracle constraint_cost /
+// constraint_hessian, in point space).
+QD double contact_eval(const QContact& c, const double* fr, double* Fs, double* X, int& zone) {
+  const double* n = c.n;
+  const double jn = dot3(n, c.jar + 3), an = dot3(n, c.jar);
+  double tl[3], ar[3];
+  QUNROLL for (int k = 0; k < 3; k++) { tl[k] = c.jar[3 + k] - jn * n[k]; ar[k] = c.jar[k] - an * n[k]; }
+  const double mu = fr[0], f1s = fr[1] * fr[1], f3s = fr[2] * fr[2], f4s = fr[3] * fr[3];
+  const double T2 = f1s * dot3(tl, tl) + f3s * an * an + f4s * dot3(ar, ar), T = sqrt(T2), N = mu * jn;
+  if (N >= mu * T || (T <= 0 && N >= 0)) { zone = 0; return 0; }
+  double ra[3], rl[3], g[3], Fl[3], Fa[3], cost;
+  QUNROLL for (int k = 0; k < 3; k++) { ra[k] = f3s * an * n[k] + f4s * ar[k]; rl[k] = f1s * tl[k]; }
+  cr3(g, c.off, n);
+  const double et[6] = {g[0], g[1], g[2], n[0], n[1], n[2]};  // the normal row about the centre of mass
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    const double Dq = c.D0 / (mu * mu);
+    cost = 0.5 * c.D0 * jn * jn + 0.5 * Dq * T2;
+    QUNROLL for (int k = 0; k < 3; k++) { Fl[k] = -c.D0 * jn * n[k] - Dq * rl[k]; Fa[k] = -Dq * ra[k]; }
+    if (X) { add_outer(X, c.D0, et); add_Qt(X, Dq, c, fr, g); }
+    zone = 2;
+  } else {
+    const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T, s = Dm * NT * mu, sT = s / T;
+    cost = 0.5 * Dm * NT * NT;
+    QUNROLL for (int k = 0; k < 3; k++) { Fl[k] = -s * n[k] + sT * rl[k]; Fa[k] = sT * ra[k]; }
+    if (X) {
+      // X = Dm a a' - (s / T) (Qt - r r'),  r = A' (Q jar) / T,  a = mu (et - r)
+      const double iT = 1.0 / T;
+      double rt[6], at[6], w[3];
+      cr3(w, c.off, rl);
+      QUNROLL for (int k = 0; k < 3; k++) { rt[k] = (ra[k] + w[k]) * iT; rt[3 + k] = rl[k] * iT; }
+      QUNROLL for (int k = 0; k < 6; k++) at[k] = mu * (et[k] - rt[k]);
+      add_outer(X, Dm, at);
+      add_Qt(X, -sT, c, fr, g);
+      add_outer(X, sT, rt);
+    }
+    zone = 1;
+  }
+  double w[3];
+  cr3(w, c.off, Fl);
+  QUNROLL for (int k = 0; k < 3; k++) { Fs[k] += w[k] + Fa[k]; Fs[3 + k] += Fl[k]; }
+  return cost;
+}
+// first and second derivative of the contact's penalty along jv at jar + alpha jv (oracle constraint_line, in point space)
+QD void contact_line(const QContact& c, const double* fr, const double* jv, double alpha, double& g, double& h) {
+  const double* n = c.n;
+  double x[6];
+  QUNROLL for (int k = 0; k < 6; k++) x[k] = c.jar[k] + alpha * jv[k];
+  const double jn = dot3(n, x + 3), an = dot3(n, x), vn = dot3(n, jv + 3), wn = dot3(n, jv);
+  double tl[3], ar[3];
+  QUNROLL for (int k = 0; k < 3; k++) { tl[k] = x[3 + k] - jn * n[k]; ar[k] = x[k] - an * n[k]; }
+  const double mu = fr[0], f1s = fr[1] * fr[1], f3s = fr[2] * fr[2], f4s = fr[3] * fr[3];
+  const double T = sqrt(f1s * dot3(tl, tl) + f3s * an * an + f4s * dot3(ar, ar)), N = mu * jn;
+  if (N >= mu * T || (T <= 0 && N >= 0)) return;
+  const double UV = f1s * dot3(tl, jv + 3) + f3s * an * wn + f4s * dot3(ar, jv);
+  const double VV = f1s * (dot3(jv + 3, jv + 3) - vn * vn) + f3s * wn * wn + f4s * (dot3(jv, jv) - wn * wn);
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    const double Dq = c.D0 / (mu * mu);
+    g += c.D0 * jn * vn + Dq * UV;
+    h += c.D0 * vn * vn + Dq * VV;
+    return;
+  }
+  const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+  const double dNT = mu * vn - mu * UV / T, d2NT = -mu * (VV / T - UV * UV / (T * T * T));
+  g += Dm * NT * dNT;
+  h += Dm * (dNT * dNT + NT * d2NT);
+}
 
 // ---------------------------------------------------------------- constraint solve (oracle o_constraint_newton)
 struct QRows {
   // friction loss (one row per leg dof with frictionloss > 0) and the active joint limit of each joint (side 0: none)
-  double fl_aref[3], fl_jar[3], fl_jv[3];
-  double lm_aref[3], lm_D[3], lm_jar[3], lm_jv[3];
+  double fl_aref[3], fl_jar[3];
+  double lm_aref[3], lm_D[3], lm_jar[3];
   int lm_side[3];
 };
-
-// jar = J qacc - aref for every row of the lane
-QD void rows_set_jar(const QuadLeg& L, const QKin& kin, QRows& R, QContact* con, int ncon, const double* xl, const double* xt) {
-  for (int j = 0; j < 3; j++) {
-    R.fl_jar[j] = xl[j] - R.fl_aref[j];
-    R.lm_jar[j] = -R.lm_side[j] * xl[j] - R.lm_aref[j];
-  }
-  double Vp[4][6];
-  chain_velocity(kin, xl, xt, Vp);
-  for (int i = 0; i < ncon; i++) {
-    double A[6][6];
-    contact_rows(con[i], A);
-    const double* V = Vp[con[i].depth];
-    for (int r = 0; r < 6; r++) con[i].jar[r] = r < con[i].dim ? dot6(A[r], V) - con[i].aref[r] : 0.0;
-  }
-}
-QD void rows_set_jv(const QKin& kin, QRows& R, QContact* con, int ncon, const double* xl, const double* xt) {
-  for (int j = 0; j < 3; j++) { R.fl_jv[j] = xl[j]; R.lm_jv[j] = -R.lm_side[j] * xl[j]; }
-  double Vp[4][6];
-  chain_velocity(kin, xl, xt, Vp);
-  for (int i = 0; i < ncon; i++) {
-    double A[6][6];
-    contact_rows(con[i], A);
-    const double* V = Vp[con[i].depth];
-    for (int r = 0; r < 6; r++) con[i].jv[r] = r < con[i].dim ? dot6(A[r], V) : 0.0;
-  }
-}
-// cost of all rows at the current jar (quad sum) and J' force: jl (lane's leg dofs), jt (trunk dofs, quad-summed, replicated)
-QD double rows_cost(const QuadLeg& L, const QKin& kin, const QRows& R, const QContact* con, int ncon, double* jl, double* jt) {
+enum { kEvalKeep = 0, kEvalSet = 1, kEvalStep = 2 };
+// One pass over the lane's rows. what = kEvalSet: jar := J x - aref for the dof vector x (xl: its leg part, Vp: chain_velocity of x);
+// kEvalStep: jar += alpha J x; kEvalKeep: jar as it is. Then the penalty at jar: returns the cost of ALL rows of the candidate (quad sum), J' force in jl (lane's
+// leg dofs) / jt (trunk dofs, replicated), and in X the sum of the lane's contacts' Hessian blocks (packed 6 x 6; NOT yet quad-summed).
+// nshallow counts the lane's contacts in a penalty zone whose body is not the last link (their blocks need the correction of
+// hessian_blocks).
+template <class CS>
+QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows& R, CS& cs, int ncon, int what, const double* xl, const double Vp[4][6], double alpha,
+                    double* jl, double* jt, double* X, int& nshallow) {
   double cost = 0;
-  double Fsuf[3][6], Fall[6];
-  for (int c = 0; c < 6; c++) { Fall[c] = 0; Fsuf[0][c] = Fsuf[1][c] = Fsuf[2][c] = 0; }
-  for (int j = 0; j < 3; j++) {
+  double Fown[6];
+  QUNROLL for (int c = 0; c < 6; c++) Fown[c] = 0;
+  QUNROLL for (int e = 0; e < 21; e++) X[e] = 0;
+  nshallow = 0;
+  QUNROLL for (int j = 0; j < 3; j++) {
+    if (what == kEvalSet) { R.fl_jar[j] = xl[j] - R.fl_aref[j]; R.lm_jar[j] = -R.lm_side[j] * xl[j] - R.lm_aref[j]; }
+    else if (what == kEvalStep) { R.fl_jar[j] += alpha * xl[j]; R.lm_jar[j] += alpha * (-R.lm_side[j] * xl[j]); }
     double f = 0;
     if (L.floss[j] > 0) {
       const double x = R.fl_jar[j], fl = L.floss[j], Rr = L.floss_R[j];
@@ -455,230 +415,295 @@ QD double rows_cost(const QuadLeg& L, const QKin& kin, const QRows& R, const QCo
     jl[j] = f;
   }
   for (int i = 0; i < ncon; i++) {
-    double force[6];
-    int zone;
-    cost += contact_cost(con[i], con[i].jar, force, zone);
-    if (zone == 0) continue;
-    const double* F = con[i].F;
-    double fl[3], ft[3], Fs[6];
-    for (int k = 0; k < 3; k++) {
-      fl[k] = F[k] * force[0] + F[3 + k] * force[1] + F[6 + k] * force[2];
-      ft[k] = F[k] * force[3] + F[3 + k] * force[4] + F[6 + k] * force[5];
+    QContact c;
+    qcs_load(cs, i, c);
+    if (what != kEvalKeep) {
+      double pv[6];
+      point_vel(c, Vp, pv);
+      if (what == kEvalSet) QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = pv[k] - c.aref[k];
+      else QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k];
+      qcs_store_jar(cs, i, c);
     }
-    cr3(Fs, con[i].off, fl);
-    for (int k = 0; k < 3; k++) { Fs[k] += ft[k]; Fs[3 + k] = fl[k]; }
-    for (int c = 0; c < 6; c++) {
-      Fall[c] += Fs[c];
-      if (con[i].depth >= 1) Fsuf[0][c] += Fs[c];
-      if (con[i].depth >= 2) Fsuf[1][c] += Fs[c];
-      if (con[i].depth >= 3) Fsuf[2][c] += Fs[c];
+    double Fs[6] = {0, 0, 0, 0, 0, 0};
+    int zone;
+    cost += contact_eval(c, m.fric[c.fid], Fs, X, zone);
+    if (zone == 0) continue;
+    QUNROLL for (int k = 0; k < 6; k++) Fown[k] += Fs[k];
+    if (c.depth < 3) {  // rare: a contact on the trunk (this lane's share), the hip or the thigh link does not act on the dofs below it
+      nshallow++;
+      QUNROLL for (int j = 0; j < 3; j++) if (j >= c.depth) jl[j] -= dot6(kin.cdof[j], Fs);
     }
   }
-  for (int j = 0; j < 3; j++) jl[j] += dot6(kin.cdof[j], Fsuf[j]);
-  qd_sum_n(Fall, 6);
-  for (int k = 0; k < 6; k++) jt[k] = trunk_dot(kin, k, Fall);
+  QUNROLL for (int j = 0; j < 3; j++) jl[j] += dot6(kin.cdof[j], Fown);
+  qd_sum_n(Fown, 6);
+  QUNROLL for (int k = 0; k < 6; k++) jt[k] = trunk_dot(kin, k, Fown);
   return qd_sum(cost);
 }
 // derivatives of the row penalties along the search direction at step alpha (quad sums)
-QD void rows_line(const QuadLeg& L, const QRows& R, const QContact* con, int ncon, double alpha, double& d1, double& d2) {
+// (xl: the search direction's leg part, Vp: its chain_velocity; J search is recomputed per row: 9 flops per contact)
+template <class CS>
+QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, int ncon, double alpha, const double* xl, const double Vp[4][6], double& d1, double& d2) {
   double g = 0, h = 0;
-  for (int j = 0; j < 3; j++) {
+  QUNROLL for (int j = 0; j < 3; j++) {
     if (L.floss[j] > 0) {
-      const double x = R.fl_jar[j] + alpha * R.fl_jv[j], fl = L.floss[j], Rr = L.floss_R[j];
-      if (x <= -Rr * fl) g += -fl * R.fl_jv[j];
-      else if (x >= Rr * fl) g += fl * R.fl_jv[j];
-      else { g += L.floss_D[j] * x * R.fl_jv[j]; h += L.floss_D[j] * R.fl_jv[j] * R.fl_jv[j]; }
+      const double jv = xl[j], x = R.fl_jar[j] + alpha * jv, fl = L.floss[j], Rr = L.floss_R[j];
+      if (x <= -Rr * fl) g += -fl * jv;
+      else if (x >= Rr * fl) g += fl * jv;
+      else { g += L.floss_D[j] * x * jv; h += L.floss_D[j] * jv * jv; }
     }
     if (R.lm_side[j] != 0) {
-      const double x = R.lm_jar[j] + alpha * R.lm_jv[j];
-      if (x < 0) { g += R.lm_D[j] * x * R.lm_jv[j]; h += R.lm_D[j] * R.lm_jv[j] * R.lm_jv[j]; }
+      const double jv = -R.lm_side[j] * xl[j], x = R.lm_jar[j] + alpha * jv;
+      if (x < 0) { g += R.lm_D[j] * x * jv; h += R.lm_D[j] * jv * jv; }
     }
   }
-  for (int i = 0; i < ncon; i++) contact_line(con[i], alpha, g, h);
+  for (int i = 0; i < ncon; i++) {
+    QContact c;
+    qcs_load(cs, i, c);
+    double jv[6];
+    point_vel(c, Vp, jv);
+    contact_line(c, m.fric[c.fid], jv, alpha, g, h);
+  }
   d1 = qd_sum(g); d2 = qd_sum(h);
 }
+// H += J' (d2s) J of the contacts: the lane's leg block and coupling from its own contacts' blocks (X, from rows_eval), the trunk block
+// from the quad sum of X. Contacts whose body is not the last link were counted for dofs below their body: taken out again.
+template <class CS>
+QD void hessian_blocks(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H) {
+  QUNROLL for (int j = 0; j < 3; j++) {
+    double Y[6];
+    QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += X[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
+    QUNROLL for (int i = 0; i <= j; i++) H.l[tri(j, i)] += dot6(kin.cdof[i], Y);
+    QUNROLL for (int k = 0; k < 6; k++) H.b[j][k] += trunk_dot(kin, k, Y);
+  }
+  if (nshallow > 0) {
+    for (int i = 0; i < ncon; i++) {
+      QContact c;
+      qcs_load(cs, i, c);
+      if (c.depth >= 3) continue;
+      double Fs[6] = {0, 0, 0, 0, 0, 0}, Xc[21];
+      QUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
+      int zone;
+      (void)contact_eval(c, m.fric[c.fid], Fs, Xc, zone);
+      if (zone == 0) continue;
+      QUNROLL for (int j = 0; j < 3; j++) {
+        if (j < c.depth) continue;
+        double Y[6];
+        QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += Xc[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
+        QUNROLL for (int ii = 0; ii <= j; ii++) H.l[tri(j, ii)] -= dot6(kin.cdof[ii], Y);
+        QUNROLL for (int k = 0; k < 6; k++) H.b[j][k] -= trunk_dot(kin, k, Y);
+      }
+    }
+  }
+  qd_sum_n(X, 21);
+  QUNROLL for (int k = 0; k < 6; k++) {
+    double Y[6];  // X cdofT_k
+    QUNROLL for (int p = 0; p < 6; p++) {
+      if (k < 3) Y[p] = X[tri(p, 3 + k)];
+      else { double v = 0; QUNROLL for (int q = 0; q < 3; q++) v += X[tri(p, q)] * kin.ca[k - 3][q] + X[tri(p, 3 + q)] * kin.cl[k - 3][q]; Y[p] = v; }
+    }
+    QUNROLL for (int i = 0; i <= k; i++) H.t[tri(k, i)] += trunk_dot(kin, i, Y);
+  }
+}
 
-// Newton solver; on entry qacc = qacc_smooth in (al, at). Returns the flag bits (quad-uniform). Leaves J' force in (fc_l, fc_t).
-QD int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin, const Arrow& M, QRows& R, QContact* con, int ncon,
+// M lives in the includer's store while the solver runs (LDS on the device: the leg block and the coupling per lane, the trunk block
+// once per quad): element accessors qms_l / qms_b / qms_t, setters qms_set_*.
+template <class MS>
+QD void store_arrow(MS& ms, const Arrow& M) {
+  QUNROLL for (int i = 0; i < 6; i++) qms_set_l(ms, i, M.l[i]);
+  QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) qms_set_b(ms, j, k, M.b[j][k]);
+  QUNROLL for (int i = 0; i < 21; i++) qms_set_t(ms, i, M.t[i]);
+}
+template <class MS>
+QD void load_arrow(const MS& ms, Arrow& M) {
+  QUNROLL for (int i = 0; i < 6; i++) M.l[i] = qms_l(ms, i);
+  QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) M.b[j][k] = qms_b(ms, j, k);
+  QUNROLL for (int i = 0; i < 21; i++) M.t[i] = qms_t(ms, i);
+}
+template <class MS>
+QD void arrow_mul_s(const MS& ms, const double* xl, const double* xt, double* yl, double* yt) {
+  double c[6];
+  QUNROLL for (int k = 0; k < 6; k++) c[k] = 0;
+  QUNROLL for (int j = 0; j < 3; j++) {
+    double s = 0;
+    QUNROLL for (int i = 0; i < 3; i++) s += qms_l(ms, tri(j, i)) * xl[i];
+    QUNROLL for (int k = 0; k < 6; k++) { const double b = qms_b(ms, j, k); s += b * xt[k]; c[k] += b * xl[j]; }
+    yl[j] = s;
+  }
+  QUNROLL for (int k = 0; k < 6; k++) {
+    double s = qd_sum(c[k]);
+    QUNROLL for (int i = 0; i < 6; i++) s += qms_t(ms, tri(k, i)) * xt[i];
+    yt[k] = s;
+  }
+}
+
+// Newton solver. (sl, st) = qacc_smooth, (wl, wt) = warm start, M in the store `ms`; leaves qacc in (al, at) and J' force in
+// (fc_l, fc_t). Returns the flag bits (quad-uniform).
+template <class CS, class MS, class QProfT>
+QD int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon,
                          const double* sl, const double* st, const double* wl, const double* wt, bool have_warm,
-                         double* al, double* at, double* fc_l, double* fc_t, int& iters) {
+                         double* al, double* at, double* fc_l, double* fc_t, int& iters, QProfT& pf) {
   iters = 0;
-  for (int j = 0; j < 3; j++) al[j] = sl[j];
-  for (int k = 0; k < 6; k++) at[k] = st[k];
-  rows_set_jar(L, kin, R, con, ncon, al, at);
-  double cost = rows_cost(L, kin, R, con, ncon, fc_l, fc_t);  // the Gauss term is zero at qacc_smooth
-  if (have_warm) {
-    double dl[3], dt[6], Ml[3], Mt[6];
-    for (int j = 0; j < 3; j++) dl[j] = wl[j] - sl[j];
-    for (int k = 0; k < 6; k++) dt[k] = wt[k] - st[k];
-    arrow_mul(M, dl, dt, Ml, Mt);
-    const double gauss = 0.5 * arrow_dot(dl, dt, Ml, Mt);
-    rows_set_jar(L, kin, R, con, ncon, wl, wt);
-    double jl[3], jt[6];
-    const double cw = gauss + rows_cost(L, kin, R, con, ncon, jl, jt);
-    if (cw < cost) {
-      cost = cw;
-      for (int j = 0; j < 3; j++) { al[j] = wl[j]; fc_l[j] = jl[j]; }
-      for (int k = 0; k < 6; k++) { at[k] = wt[k]; fc_t[k] = jt[k]; }
-    } else {
-      rows_set_jar(L, kin, R, con, ncon, al, at);
+  double X[21];
+  int nshallow;
+  QUNROLL for (int j = 0; j < 3; j++) al[j] = sl[j];
+  QUNROLL for (int k = 0; k < 6; k++) at[k] = st[k];
+  double Mal[3] = {0, 0, 0}, Mat[6] = {0, 0, 0, 0, 0, 0};  // M (qacc - qacc_smooth), carried through the iterations
+  double cost;
+  {
+    double Vp[4][6];
+    chain_velocity(kin, al, at, Vp);
+    cost = rows_eval(m, L, kin, R, cs, ncon, kEvalSet, al, Vp, 0.0, fc_l, fc_t, X, nshallow);  // the Gauss term is zero at qacc_smooth
+    if (have_warm) {
+      double dl[3], dt[6], Ml[3], Mt[6];
+      QUNROLL for (int j = 0; j < 3; j++) dl[j] = wl[j] - sl[j];
+      QUNROLL for (int k = 0; k < 6; k++) dt[k] = wt[k] - st[k];
+      arrow_mul_s(ms, dl, dt, Ml, Mt);
+      const double gauss = 0.5 * arrow_dot(dl, dt, Ml, Mt);
+      double jl[3], jt[6], Xw[21], Vw[4][6];
+      int nsw;
+      chain_velocity(kin, wl, wt, Vw);
+      const double cw = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalSet, wl, Vw, 0.0, jl, jt, Xw, nsw);
+      if (cw < cost) {
+        cost = cw; nshallow = nsw;
+        QUNROLL for (int j = 0; j < 3; j++) { al[j] = wl[j]; fc_l[j] = jl[j]; Mal[j] = Ml[j]; }
+        QUNROLL for (int k = 0; k < 6; k++) { at[k] = wt[k]; fc_t[k] = jt[k]; Mat[k] = Mt[k]; }
+        QUNROLL for (int e = 0; e < 21; e++) X[e] = Xw[e];
+      } else {
+        (void)rows_eval(m, L, kin, R, cs, ncon, kEvalSet, al, Vp, 0.0, fc_l, fc_t, X, nshallow);
+      }
     }
   }
   const double scale = 1.0 / (m.meaninertia * 18.0);
   double improvement = 0;
   for (int iter = 0; iter < m.iterations; iter++) {
     // gradient = M (qacc - qacc_smooth) - J' force
-    double dl[3], dt[6], Mal[3], Mat[6], gl[3], gt[6];
-    for (int j = 0; j < 3; j++) dl[j] = al[j] - sl[j];
-    for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
-    arrow_mul(M, dl, dt, Mal, Mat);
-    for (int j = 0; j < 3; j++) gl[j] = Mal[j] - fc_l[j];
-    for (int k = 0; k < 6; k++) gt[k] = Mat[k] - fc_t[k];
-    const double gnorm = sqrt(arrow_dot(gl, gt, gl, gt));
+    double hl[3], ht[6];
+    QUNROLL for (int j = 0; j < 3; j++) hl[j] = Mal[j] - fc_l[j];
+    QUNROLL for (int k = 0; k < 6; k++) ht[k] = Mat[k] - fc_t[k];
+    const double gnorm = sqrt(arrow_dot(hl, ht, hl, ht));
     if (gnorm == 0) break;
     if (iter > 0 && (scale * improvement < m.tolerance || scale * gnorm < m.tolerance)) break;
-    // H = M + J' (d2s) J: diagonal rows, then the contacts through their 6 x 6 spatial blocks
-    Arrow H = M;
-    for (int j = 0; j < 3; j++) {
-      if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.l[tri(j, j)] += L.floss_D[j]; }
-      if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.l[tri(j, j)] += R.lm_D[j];
-    }
+    QPROF(pf, 8);
     {
-      double Xs[3][21], Xall[21];
-      for (int i = 0; i < 21; i++) { Xall[i] = 0; Xs[0][i] = Xs[1][i] = Xs[2][i] = 0; }
-      bool any = false;
-      for (int i = 0; i < ncon; i++) {
-        double force[6], X[21];
-        int zone;
-        (void)contact_cost(con[i], con[i].jar, force, zone);
-        if (zone == 0) continue;
-        any = true;
-        for (int e = 0; e < 21; e++) X[e] = 0;
-        contact_hessian(con[i], zone, X);
-        for (int e = 0; e < 21; e++) {
-          Xall[e] += X[e];
-          if (con[i].depth >= 1) Xs[0][e] += X[e];
-          if (con[i].depth >= 2) Xs[1][e] += X[e];
-          if (con[i].depth >= 3) Xs[2][e] += X[e];
-        }
+      // H = M + J' (d2s) J: diagonal rows, then the contacts through their 6 x 6 spatial blocks; factored in place
+      Arrow H;
+      load_arrow(ms, H);
+      QUNROLL for (int j = 0; j < 3; j++) {
+        if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.l[tri(j, j)] += L.floss_D[j]; }
+        if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.l[tri(j, j)] += R.lm_D[j];
       }
-      if (any) {
-        for (int j = 0; j < 3; j++) {
-          double Y[6];
-          for (int p = 0; p < 6; p++) { double v = 0; for (int q = 0; q < 6; q++) v += Xs[j][tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
-          for (int i = 0; i <= j; i++) H.l[tri(j, i)] += dot6(kin.cdof[i], Y);
-          for (int k = 0; k < 6; k++) H.b[j][k] += trunk_dot(kin, k, Y);
-        }
-      }
-      qd_sum_n(Xall, 21);
-      for (int k = 0; k < 6; k++) {
-        double Y[6];  // Xall cdofT_k
-        for (int p = 0; p < 6; p++) {
-          if (k < 3) Y[p] = Xall[tri(p, 3 + k)];
-          else { double v = 0; for (int q = 0; q < 3; q++) v += Xall[tri(p, q)] * kin.ca[k - 3][q] + Xall[tri(p, 3 + q)] * kin.cl[k - 3][q]; Y[p] = v; }
-        }
-        for (int i = 0; i <= k; i++) H.t[tri(k, i)] += trunk_dot(kin, i, Y);
-      }
+      hessian_blocks(m, kin, cs, ncon, X, nshallow, H);
+      QPROF(pf, 9);
+      if (!arrow_factor(H)) return kFlagNotPD;
+      QUNROLL for (int j = 0; j < 3; j++) hl[j] = -hl[j];  // search direction
+      QUNROLL for (int k = 0; k < 6; k++) ht[k] = -ht[k];
+      arrow_solve(H, hl, ht);
     }
-    ArrowFactor Hf;
-    if (!arrow_factor(H, Hf)) return kFlagNotPD;
-    double hl[3], ht[6];  // search direction
-    for (int j = 0; j < 3; j++) hl[j] = -gl[j];
-    for (int k = 0; k < 6; k++) ht[k] = -gt[k];
-    arrow_solve(Hf, hl, ht);
-    rows_set_jv(kin, R, con, ncon, hl, ht);
-    double Msl[3], Mst[6];
-    arrow_mul(M, hl, ht, Msl, Mst);
-    const double q1 = arrow_dot(hl, ht, Mal, Mat), q2 = arrow_dot(hl, ht, Msl, Mst);
-    double lo = 0, hi = -1, alpha = 0, d1, d2;
-    rows_line(L, R, con, ncon, 0.0, d1, d2);
-    d1 += q1; d2 += q2;
-    const double d10 = fabs(d1);
-    const double snorm = arrow_dot(hl, ht, hl, ht);
-    const double gtol = m.tolerance * kQLsTol * sqrt(snorm) / scale;
-    for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
-      double an = alpha - d1 / d2;
-      if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
-      if (an == alpha) break;
-      alpha = an;
-      rows_line(L, R, con, ncon, alpha, d1, d2);
-      d1 += q1 + alpha * q2; d2 += q2;
-      if (fabs(d1) < gtol) break;
-      if (d1 < 0) lo = alpha; else hi = alpha;
+    QPROF(pf, 10);
+    double q1, q2, snorm;
+    {
+      double Msl[3], Mst[6];
+      arrow_mul_s(ms, hl, ht, Msl, Mst);
+      q1 = arrow_dot(hl, ht, Mal, Mat); q2 = arrow_dot(hl, ht, Msl, Mst); snorm = arrow_dot(hl, ht, hl, ht);
+      // M (qacc - qacc_smooth) moves along M search: Mal += alpha Msl after the line search
+      double Vs[4][6];
+      chain_velocity(kin, hl, ht, Vs);
+      double lo = 0, hi = -1, alpha = 0, d1, d2;
+      rows_line(m, L, R, cs, ncon, 0.0, hl, Vs, d1, d2);
+      d1 += q1; d2 += q2;
+      const double d10 = fabs(d1);
+      const double gtol = m.tolerance * kQLsTol * sqrt(snorm) / scale;
+      double step1 = 1e300, step2 = 1e300;  // the last step and the one before (rtsafe safeguard, oracle/contact.inc)
+      for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
+        double an = alpha - d1 / d2;
+        if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
+        else if (hi >= 0 && fabs(an - alpha) > 0.5 * step2) an = 0.5 * (lo + hi);
+        if (an == alpha) break;
+        step2 = step1; step1 = fabs(an - alpha);
+        alpha = an;
+        rows_line(m, L, R, cs, ncon, alpha, hl, Vs, d1, d2);
+        d1 += q1 + alpha * q2; d2 += q2;
+        if (fabs(d1) < gtol) break;
+        if (d1 < 0) lo = alpha; else hi = alpha;
+        QPROF_COUNT(pf, 17, 1);
+      }
+      QPROF(pf, 11);
+      QUNROLL for (int j = 0; j < 3; j++) al[j] += alpha * hl[j];
+      QUNROLL for (int k = 0; k < 6; k++) at[k] += alpha * ht[k];
+      // the Gauss term at the new point, as the oracle evaluates it: from M (qacc - qacc_smooth) recomputed
+      double dl[3], dt[6];
+      QUNROLL for (int j = 0; j < 3; j++) dl[j] = al[j] - sl[j];
+      QUNROLL for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
+      arrow_mul_s(ms, dl, dt, Mal, Mat);
+      const double gauss = 0.5 * arrow_dot(dl, dt, Mal, Mat);
+      const double newcost = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, X, nshallow);
+      improvement = cost - newcost;
+      cost = newcost;
     }
-    for (int j = 0; j < 3; j++) { al[j] += alpha * hl[j]; R.fl_jar[j] += alpha * R.fl_jv[j]; R.lm_jar[j] += alpha * R.lm_jv[j]; }
-    for (int k = 0; k < 6; k++) at[k] += alpha * ht[k];
-    for (int i = 0; i < ncon; i++) for (int r = 0; r < 6; r++) con[i].jar[r] += alpha * con[i].jv[r];
-    for (int j = 0; j < 3; j++) dl[j] = al[j] - sl[j];
-    for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
-    arrow_mul(M, dl, dt, Mal, Mat);
-    const double gauss = 0.5 * arrow_dot(dl, dt, Mal, Mat);
-    const double newcost = gauss + rows_cost(L, kin, R, con, ncon, fc_l, fc_t);
-    improvement = cost - newcost;
-    cost = newcost;
     iters = iter + 1;
+    QPROF(pf, 12);
   }
   return 0;
 }
 
 // ---------------------------------------------------------------- collision of the lane's geoms with the static geoms
-QD void add_contact(const QuadPair& p, const QKin& kin, const double* com, const double* cvel, int depth, double dist, const double* pos,
-                    const double* normal, QContact* con, int& ncon, int& flags) {
+// a contact found: its record (mj_instantiateContact + mj_makeImpedance for its rows, in point space) goes to the lane's store
+template <class CS>
+QD void add_contact(const QuadPair& p, const double* com, const double* cvel, int depth, double dist, const double* pos, const double* normal,
+                    CS& cs, int& ncon, int& flags) {
   if (!(dist < p.margin)) return;
   if (ncon >= kQMaxCon) { flags |= kFlagOverflow; return; }
-  QContact& c = con[ncon++];
-  c.dim = p.dim; c.depth = depth;
-  c.F[0] = normal[0]; c.F[1] = normal[1]; c.F[2] = normal[2];
-  make_frame(c.F);
-  for (int k = 0; k < 3; k++) c.off[k] = pos[k] - com[k];
-  c.mu = p.mu; c.f1 = p.fric1; c.f3 = p.fric3; c.f4 = p.fric4;
-  // J qvel: the rows applied to the body's spatial velocity
-  double A[6][6];
-  contact_rows(c, A);
+  QContact c;
+  c.depth = depth;
+  QUNROLL for (int k = 0; k < 3; k++) { c.n[k] = normal[k]; c.off[k] = pos[k] - com[k]; }
+  c.fid = p.fid;
   const double x = dist - p.includemargin;
   const double imp = impedance(p.imp, x);
   double R0 = (1 - imp) / imp * p.diag;
   if (R0 < kQMinVal) R0 = kQMinVal;
   c.D0 = 1.0 / R0;
-  for (int r = 0; r < 6; r++) {
-    const double vel = r < c.dim ? dot6(A[r], cvel) : 0.0;
-    c.aref[r] = -p.b * vel - (r == 0 ? p.k * imp * x : 0.0);
-    c.jar[r] = 0; c.jv[r] = 0;
+  // aref = -b (J qvel) - k imp x on the normal row: J qvel in point space is the body's velocity at the point
+  double w[3];
+  cr3(w, cvel, c.off);
+  const double kx = p.k * imp * x;
+  QUNROLL for (int k = 0; k < 3; k++) {
+    c.aref[k] = p.dim >= 4 ? -p.b * cvel[k] : 0.0;
+    c.aref[3 + k] = -p.b * (cvel[3 + k] + w[k]) - kx * c.n[k];
+    c.jar[k] = c.jar[3 + k] = 0;
   }
+  qcs_store(cs, ncon, c);
+  ncon++;
 }
-QD void sphere_plane(const QuadPair& p, const QKin& kin, const double* com, const double* cvel, int depth, const double* pp, const double* pn,
-                     const double* c, double r, QContact* con, int& ncon, int& flags) {
+template <class CS>
+QD void sphere_plane(const QuadPair& p, const double* com, const double* cvel, int depth, const double* pp, const double* pn,
+                     const double* c, double r, CS& cs, int& ncon, int& flags) {
   const double dist = (c[0] - pp[0]) * pn[0] + (c[1] - pp[1]) * pn[1] + (c[2] - pp[2]) * pn[2] - r;
   double pos[3];
-  for (int k = 0; k < 3; k++) pos[k] = c[k] - pn[k] * (r + 0.5 * dist);
-  add_contact(p, kin, com, cvel, depth, dist, pos, pn, con, ncon, flags);
+  QUNROLL for (int k = 0; k < 3; k++) pos[k] = c[k] - pn[k] * (r + 0.5 * dist);
+  add_contact(p, com, cvel, depth, dist, pos, pn, cs, ncon, flags);
 }
 // one moving geom (world pose gp / gR) against every static geom; oracle o_collision's pair table
+template <class CS>
 QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& g, const QuadPair* pairs /* [kQStatic] stride */, int pair_stride,
-                     const QKin& kin, const double* com, const double* cvel, int depth, const double* gp, const double* gR,
-                     QContact* con, int& ncon, int& flags) {
+                     const double* com, const double* cvel, int depth, const double* gp, const double* gR, CS& cs, int& ncon, int& flags) {
   for (int s = 0; s < m.nstatic; s++) {
     const QuadStatic& S = m.stat[s];
     if (S.type < 0) continue;
-    const QuadPair& p = pairs[s * pair_stride];
-    if (!p.collide) continue;
     const double* p1 = sp[s].pos; const double* R1 = sp[s].mat;
     if (S.type == MJPCX_GEOM_PLANE) {
       const double n[3] = {R1[2], R1[5], R1[8]};
-      // bounding-sphere rejection: nothing of the geom within the margin of the plane
+      // bounding-sphere rejection: nothing of the geom within the margin of the plane (margins are far below this slack)
       const double cd = (gp[0] - p1[0]) * n[0] + (gp[1] - p1[1]) * n[1] + (gp[2] - p1[2]) * n[2];
-      double bound = g.size[0];
-      if (g.type == MJPCX_GEOM_CAPSULE) bound = g.size[0] + g.size[1];
-      else if (g.type == MJPCX_GEOM_CYLINDER) bound = sqrt(g.size[0] * g.size[0] + g.size[1] * g.size[1]);
-      else if (g.type == MJPCX_GEOM_BOX) bound = sqrt(g.size[0] * g.size[0] + g.size[1] * g.size[1] + g.size[2] * g.size[2]);
-      if (cd - bound * 1.0000001 - 1e-12 >= p.margin) continue;
+      if (cd - g.bound >= 0.01) continue;
+      const QuadPair& p = pairs[s * pair_stride];
+      if (!p.collide) continue;
       if (g.type == MJPCX_GEOM_SPHERE) {
-        sphere_plane(p, kin, com, cvel, depth, p1, n, gp, g.size[0], con, ncon, flags);
+        sphere_plane(p, com, cvel, depth, p1, n, gp, g.size[0], cs, ncon, flags);
       } else if (g.type == MJPCX_GEOM_CAPSULE) {
         for (int sgn = -1; sgn <= 1; sgn += 2) {
           double c[3];
-          for (int k = 0; k < 3; k++) c[k] = gp[k] + sgn * g.size[1] * gR[3 * k + 2];
-          sphere_plane(p, kin, com, cvel, depth, p1, n, c, g.size[0], con, ncon, flags);
+          QUNROLL for (int k = 0; k < 3; k++) c[k] = gp[k] + sgn * g.size[1] * gR[3 * k + 2];
+          sphere_plane(p, com, cvel, depth, p1, n, c, g.size[0], cs, ncon, flags);
         }
       } else if (g.type == MJPCX_GEOM_BOX) {
         int cnt = 0;
@@ -686,12 +711,12 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
           const double loc[3] = {(i & 1 ? g.size[0] : -g.size[0]), (i & 2 ? g.size[1] : -g.size[1]), (i & 4 ? g.size[2] : -g.size[2])};
           double c[3];
           mv3(c, gR, loc);
-          for (int k = 0; k < 3; k++) c[k] += gp[k];
+          QUNROLL for (int k = 0; k < 3; k++) c[k] += gp[k];
           const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
           if (dist < p.margin) {
             double pos[3];
-            for (int k = 0; k < 3; k++) pos[k] = c[k] - 0.5 * dist * n[k];
-            add_contact(p, kin, com, cvel, depth, dist, pos, n, con, ncon, flags);
+            QUNROLL for (int k = 0; k < 3; k++) pos[k] = c[k] - 0.5 * dist * n[k];
+            add_contact(p, com, cvel, depth, dist, pos, n, cs, ncon, flags);
             cnt++;
           }
         }
@@ -700,64 +725,71 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
         const double pa = n[0] * a[0] + n[1] * a[1] + n[2] * a[2];
         const double sgn = pa > 0 ? -1.0 : 1.0;
         double v[3], vn = 0;
-        for (int k = 0; k < 3; k++) { v[k] = -(n[k] - pa * a[k]); vn += v[k] * v[k]; }
+        QUNROLL for (int k = 0; k < 3; k++) { v[k] = -(n[k] - pa * a[k]); vn += v[k] * v[k]; }
         vn = sqrt(vn);
         if (vn < 1e-10) { v[0] = gR[0]; v[1] = gR[3]; v[2] = gR[6]; vn = 1; }
-        for (int k = 0; k < 3; k++) v[k] /= vn;
+        QUNROLL for (int k = 0; k < 3; k++) v[k] /= vn;
         double w[3];
         cr3(w, a, v);
-        const double cs[3] = {1.0, -0.5, -0.5}, sn[3] = {0.0, 0.8660254037844386, -0.8660254037844386};
-        for (int i = 0; i < 4; i++) {
+        const double cs3[3] = {1.0, -0.5, -0.5}, sn3[3] = {0.0, 0.8660254037844386, -0.8660254037844386};
+        QUNROLL for (int i = 0; i < 4; i++) {
           double c[3];
-          const double side = i < 3 ? sgn : -sgn, cc = i < 3 ? cs[i] : 1.0, ss = i < 3 ? sn[i] : 0.0;
-          for (int k = 0; k < 3; k++) c[k] = gp[k] + side * g.size[1] * a[k] + g.size[0] * (cc * v[k] + ss * w[k]);
+          const double side = i < 3 ? sgn : -sgn, cc = i < 3 ? cs3[i] : 1.0, ss = i < 3 ? sn3[i] : 0.0;
+          QUNROLL for (int k = 0; k < 3; k++) c[k] = gp[k] + side * g.size[1] * a[k] + g.size[0] * (cc * v[k] + ss * w[k]);
           const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
           double pos[3];
-          for (int k = 0; k < 3; k++) pos[k] = c[k] - 0.5 * dist * n[k];
-          add_contact(p, kin, com, cvel, depth, dist, pos, n, con, ncon, flags);
+          QUNROLL for (int k = 0; k < 3; k++) pos[k] = c[k] - 0.5 * dist * n[k];
+          add_contact(p, com, cvel, depth, dist, pos, n, cs, ncon, flags);
         }
       }
-    } else if (S.type == MJPCX_GEOM_SPHERE) {  // static sphere x moving sphere
+    } else if (g.type != MJPCX_GEOM_SPHERE) {
+      continue;  // static spheres and boxes collide with moving spheres only
+    } else if (S.type == MJPCX_GEOM_SPHERE) {
       double n[3], len = 0;
-      for (int k = 0; k < 3; k++) { n[k] = gp[k] - p1[k]; len += n[k] * n[k]; }
+      QUNROLL for (int k = 0; k < 3; k++) { n[k] = gp[k] - p1[k]; len += n[k] * n[k]; }
+      const double reach = S.size[0] + g.size[0] + 0.01;
+      if (len >= reach * reach) continue;
+      const QuadPair& p = pairs[s * pair_stride];
+      if (!p.collide) continue;
       len = sqrt(len);
       const double r1 = S.size[0], dist = len - r1 - g.size[0];
       if (!(dist < p.margin)) continue;
-      if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else for (int k = 0; k < 3; k++) n[k] /= len;
+      if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else QUNROLL for (int k = 0; k < 3; k++) n[k] /= len;
       double pos[3];
-      for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * (r1 + 0.5 * dist);
-      add_contact(p, kin, com, cvel, depth, dist, pos, n, con, ncon, flags);
-    } else if (S.type == MJPCX_GEOM_BOX) {  // static box x moving sphere
+      QUNROLL for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * (r1 + 0.5 * dist);
+      add_contact(p, com, cvel, depth, dist, pos, n, cs, ncon, flags);
+    } else if (S.type == MJPCX_GEOM_BOX) {
       const double* s1 = S.size;
       double rel[3], loc[3], clamped[3];
-      for (int k = 0; k < 3; k++) rel[k] = gp[k] - p1[k];
-      // bounding-sphere rejection
-      const double br = sqrt(s1[0] * s1[0] + s1[1] * s1[1] + s1[2] * s1[2]) + g.size[0];
-      if (rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] > (br + p.margin) * (br + p.margin) * 1.000001) continue;
-      for (int k = 0; k < 3; k++) loc[k] = R1[k] * rel[0] + R1[3 + k] * rel[1] + R1[6 + k] * rel[2];
+      QUNROLL for (int k = 0; k < 3; k++) rel[k] = gp[k] - p1[k];
+      const double br = S.bound + g.size[0] + 0.01;
+      if (rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] >= br * br) continue;
+      const QuadPair& p = pairs[s * pair_stride];
+      if (!p.collide) continue;
+      QUNROLL for (int k = 0; k < 3; k++) loc[k] = R1[k] * rel[0] + R1[3 + k] * rel[1] + R1[6 + k] * rel[2];
       bool inside = true;
-      for (int k = 0; k < 3; k++) {
+      QUNROLL for (int k = 0; k < 3; k++) {
         clamped[k] = loc[k] < -s1[k] ? -s1[k] : (loc[k] > s1[k] ? s1[k] : loc[k]);
         if (clamped[k] != loc[k]) inside = false;
       }
       double nl[3] = {0, 0, 0}, dist;
       if (!inside) {
         double len = 0;
-        for (int k = 0; k < 3; k++) { nl[k] = loc[k] - clamped[k]; len += nl[k] * nl[k]; }
+        QUNROLL for (int k = 0; k < 3; k++) { nl[k] = loc[k] - clamped[k]; len += nl[k] * nl[k]; }
         len = sqrt(len);
-        for (int k = 0; k < 3; k++) nl[k] /= len;
+        QUNROLL for (int k = 0; k < 3; k++) nl[k] /= len;
         dist = len - g.size[0];
       } else {
         int best = 0; double bd = 1e300;
-        for (int k = 0; k < 3; k++) { const double dd = s1[k] - fabs(loc[k]); if (dd < bd) { bd = dd; best = k; } }
-        for (int k = 0; k < 3; k++) if (k == best) { nl[k] = loc[k] >= 0 ? 1 : -1; clamped[k] = nl[k] * s1[k]; }
+        QUNROLL for (int k = 0; k < 3; k++) { const double dd = s1[k] - fabs(loc[k]); if (dd < bd) { bd = dd; best = k; } }
+        QUNROLL for (int k = 0; k < 3; k++) if (k == best) { nl[k] = loc[k] >= 0 ? 1 : -1; clamped[k] = nl[k] * s1[k]; }
         dist = -bd - g.size[0];
       }
       double n[3], surf[3], pos[3];
       mv3(n, R1, nl);
       mv3(surf, R1, clamped);
-      for (int k = 0; k < 3; k++) pos[k] = p1[k] + surf[k] + 0.5 * dist * n[k];
-      add_contact(p, kin, com, cvel, depth, dist, pos, n, con, ncon, flags);
+      QUNROLL for (int k = 0; k < 3; k++) pos[k] = p1[k] + surf[k] + 0.5 * dist * n[k];
+      add_contact(p, com, cvel, depth, dist, pos, n, cs, ncon, flags);
     }
   }
 }
@@ -772,8 +804,8 @@ QD double pair_distance(int t1, const double* p1, const double* a1, double r1, d
   };
   auto dist2 = [&](const double* u, const double* v) { return sqrt((u[0] - v[0]) * (u[0] - v[0]) + (u[1] - v[1]) * (u[1] - v[1]) + (u[2] - v[2]) * (u[2] - v[2])) - r1 - r2; };
   if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) return dist2(p1, p2);
-  if (t1 == MJPCX_GEOM_SPHERE) { const double x = seg(p2, a2, h2, p1); for (int k = 0; k < 3; k++) c2[k] = p2[k] + x * a2[k]; return dist2(p1, c2); }
-  if (t2 == MJPCX_GEOM_SPHERE) { const double x = seg(p1, a1, h1, p2); for (int k = 0; k < 3; k++) c1[k] = p1[k] + x * a1[k]; return dist2(c1, p2); }
+  if (t1 == MJPCX_GEOM_SPHERE) { const double x = seg(p2, a2, h2, p1); QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + x * a2[k]; return dist2(p1, c2); }
+  if (t2 == MJPCX_GEOM_SPHERE) { const double x = seg(p1, a1, h1, p2); QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + x * a1[k]; return dist2(c1, p2); }
   const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
   const double mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
   const double u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
@@ -784,14 +816,14 @@ QD double pair_distance(int t1, const double* p1, const double* a1, double r1, d
     if (x1 > h1) { x1 = h1; x2 = v - mb * x1; } else if (x1 < -h1) { x1 = -h1; x2 = v - mb * x1; }
     if (x2 > h2) { x2 = h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
     else if (x2 < -h2) { x2 = -h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
-    for (int k = 0; k < 3; k++) { c1[k] = p1[k] + x1 * a1[k]; c2[k] = p2[k] + x2 * a2[k]; }
+    QUNROLL for (int k = 0; k < 3; k++) { c1[k] = p1[k] + x1 * a1[k]; c2[k] = p2[k] + x2 * a2[k]; }
     return dist2(c1, c2);
   }
   double best = 1e300;
-  for (int e = 0; e < 4; e++) {
+  QUNROLL for (int e = 0; e < 4; e++) {
     const double sgn = (e & 1) ? -1.0 : 1.0;
-    if (e < 2) { for (int k = 0; k < 3; k++) c1[k] = p1[k] + sgn * h1 * a1[k]; const double x2 = seg(p2, a2, h2, c1); for (int k = 0; k < 3; k++) c2[k] = p2[k] + x2 * a2[k]; }
-    else { for (int k = 0; k < 3; k++) c2[k] = p2[k] + sgn * h2 * a2[k]; const double x1 = seg(p1, a1, h1, c2); for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k]; }
+    if (e < 2) { QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + sgn * h1 * a1[k]; const double x2 = seg(p2, a2, h2, c1); QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + x2 * a2[k]; }
+    else { QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + sgn * h2 * a2[k]; const double x1 = seg(p1, a1, h1, c2); QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k]; }
     const double d = dist2(c1, c2);
     best = d < best ? d : best;
   }
@@ -816,25 +848,27 @@ QD bool pair_near(const QuadModel& m, int leg, const QPairGeoms& pg, const doubl
     const QuadGeom& g = m.trunk_geom[m.tpg_slot[i]];
     double c[3], a[3];
     mv3(c, txm, g.pos);
-    for (int k = 0; k < 3; k++) { c[k] += txpos[k]; a[k] = txm[3 * k] * g.rot[2] + txm[3 * k + 1] * g.rot[5] + txm[3 * k + 2] * g.rot[8]; }
+    QUNROLL for (int k = 0; k < 3; k++) { c[k] += txpos[k]; a[k] = txm[3 * k] * g.rot[2] + txm[3 * k + 1] * g.rot[5] + txm[3 * k + 2] * g.rot[8]; }
     const double h1 = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
-    for (int j = 0; j < L.npg; j++) {
+    QUNROLL for (int j = 0; j < kQPairGeom; j++) {
+      if (j >= L.npg) continue;
       const QuadGeom& g2 = L.geom[L.pg_slot[j]];
       test(g.type, c, a, g.size[0], h1, g2.type, pg.c[j], pg.a[j], g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0);
     }
   }
-  for (int d = 1; d <= 2; d++) {
+  QUNROLL for (int d = 1; d <= 2; d++) {
     const QuadLeg& O = m.leg[(leg + d) & 3];
-    for (int j = 0; j < kQPairGeom; j++) {
+    QUNROLL for (int j = 0; j < kQPairGeom; j++) {
       double c2[3], a2[3];
-      for (int k = 0; k < 3; k++) {
+      QUNROLL for (int k = 0; k < 3; k++) {
         c2[k] = d == 1 ? qd_rot<1>(pg.c[j][k]) : qd_rot<2>(pg.c[j][k]);
         a2[k] = d == 1 ? qd_rot<1>(pg.a[j][k]) : qd_rot<2>(pg.a[j][k]);
       }
       if (j >= O.npg) continue;
       const QuadGeom& g2 = O.geom[O.pg_slot[j]];
       const double h2 = g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0;
-      for (int i = 0; i < L.npg; i++) {
+      QUNROLL for (int i = 0; i < kQPairGeom; i++) {
+        if (i >= L.npg) continue;
         const QuadGeom& g1 = L.geom[L.pg_slot[i]];
         test(g1.type, pg.c[i], pg.a[i], g1.size[0], g1.type == MJPCX_GEOM_CAPSULE ? g1.size[1] : 0.0, g2.type, c2, a2, g2.size[0], h2);
       }
@@ -844,11 +878,27 @@ QD bool pair_near(const QuadModel& m, int leg, const QPairGeoms& pg, const doubl
 }
 
 // ---------------------------------------------------------------- mj_forward (oracle o_forward) for the lane's share of one candidate
-// ctrl: the leg's three (already clamped) controls. Returns flag bits (quad-uniform; 0: fine).
-QD int forward(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp, int leg, const QState& S, const double* ctrl, bool have_warm,
-               QContact* con, QForward& out) {
-  const QuadLeg& L = m.leg[leg];
+// what the sensor stage (residual, traces) reads: nothing of it depends on the constraint solve
+struct QSense {
+  double txm[9], txq[4], txipos[3], com[3], comvel[3], head[3], foot[3];
+  double trace[kQMaxTrace][3];
+  double act_force[3];
+};
+// what the constraint solve and the integrator read
+struct QDyn {
   QKin kin;
+  QRows R;
+  double sl[3], st[6];      // qacc_smooth
+  double fs_l[3], fs_t[6];  // qfrc_smooth
+  int ncon;
+};
+// Position and velocity stages, collision, smooth dynamics, constraint rows: everything of mj_forward before the constraint solve.
+// ctrl: the leg's three controls. Returns flag bits (quad-uniform; 0: fine).
+template <class CS, class MS, class QProfT>
+QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp, int leg, const QState& S, const double* ctrl, CS& cs, MS& ms,
+                      QDyn& D, QSense& out, QProfT& pf) {
+  const QuadLeg& L = m.leg[leg];
+  QKin& kin = D.kin;
   int flags = 0;
   // ================= kinematics (o_kinematics): trunk, then the leg's chain
   double txpos[3] = {S.tq[0], S.tq[1], S.tq[2]};
@@ -861,36 +911,36 @@ QD int forward(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
   double txipos[3] = {txpos[0] + tmp3[0], txpos[1] + tmp3[1], txpos[2] + tmp3[2]};
   double tirot[6];
   { double timat[9]; q_mul(tmpq, txq, m.trunk_iquat); q2mat(timat, tmpq); rot_inertia(tirot, m.trunk_inertia, timat); }
-  double xipos[3][3], irot[3][6], anchor[3][3], axis[3][3];
+  double xpos[3][3], xmat[3][9], xipos[3][3], irot[3][6], anchor[3][3], axis[3][3];
   {
     double ppos[3] = {txpos[0], txpos[1], txpos[2]}, pquat[4] = {txq[0], txq[1], txq[2], txq[3]}, pmat[9];
-    for (int k = 0; k < 9; k++) pmat[k] = txm[k];
-    for (int j = 0; j < 3; j++) {
-      double xpos[3], xquat[4];
-      mv3(xpos, pmat, L.body_pos[j]);
-      for (int k = 0; k < 3; k++) xpos[k] += ppos[k];
+    QUNROLL for (int k = 0; k < 9; k++) pmat[k] = txm[k];
+    QUNROLL for (int j = 0; j < 3; j++) {
+      double xp[3], xquat[4];
+      mv3(xp, pmat, L.body_pos[j]);
+      QUNROLL for (int k = 0; k < 3; k++) xp[k] += ppos[k];
       q_mul(xquat, pquat, L.body_quat[j]);
       q_rot(anchor[j], L.jnt_pos[j], xquat);
-      for (int k = 0; k < 3; k++) anchor[j][k] += xpos[k];
+      QUNROLL for (int k = 0; k < 3; k++) anchor[j][k] += xp[k];
       q_rot(axis[j], L.jnt_axis[j], xquat);
       const double angle = S.lq[j] - L.qpos0[j];
       double qloc[4] = {1, 0, 0, 0};
       if (angle != 0) {
-        double s, c;
-        sincos(0.5 * angle, &s, &c);
-        qloc[0] = c; qloc[1] = L.jnt_axis[j][0] * s; qloc[2] = L.jnt_axis[j][1] * s; qloc[3] = L.jnt_axis[j][2] * s;
+        double sn, cs_;
+        sincos(0.5 * angle, &sn, &cs_);
+        qloc[0] = cs_; qloc[1] = L.jnt_axis[j][0] * sn; qloc[2] = L.jnt_axis[j][1] * sn; qloc[3] = L.jnt_axis[j][2] * sn;
       }
       q_mul(xquat, xquat, qloc);
       double vec[3];
       q_rot(vec, L.jnt_pos[j], xquat);
-      for (int k = 0; k < 3; k++) xpos[k] = anchor[j][k] - vec[k];
+      QUNROLL for (int k = 0; k < 3; k++) xp[k] = anchor[j][k] - vec[k];
       q_norm(xquat);
       q2mat(pmat, xquat);
-      for (int k = 0; k < 3; k++) { ppos[k] = xpos[k]; kin.xpos[j][k] = xpos[k]; }
-      for (int k = 0; k < 4; k++) pquat[k] = xquat[k];
-      for (int k = 0; k < 9; k++) kin.xmat[j][k] = pmat[k];
+      QUNROLL for (int k = 0; k < 3; k++) { ppos[k] = xp[k]; xpos[j][k] = xp[k]; }
+      QUNROLL for (int k = 0; k < 4; k++) pquat[k] = xquat[k];
+      QUNROLL for (int k = 0; k < 9; k++) xmat[j][k] = pmat[k];
       mv3(tmp3, pmat, L.body_ipos[j]);
-      for (int k = 0; k < 3; k++) xipos[j][k] = xpos[k] + tmp3[k];
+      QUNROLL for (int k = 0; k < 3; k++) xipos[j][k] = xp[k] + tmp3[k];
       double imat[9];
       q_mul(tmpq, xquat, L.body_iquat[j]);
       q2mat(imat, tmpq);
@@ -899,107 +949,78 @@ QD int forward(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
   }
   // ================= centre of mass, spatial inertias, dof axes (o_compos)
   double com[3];
-  for (int k = 0; k < 3; k++) {
+  QUNROLL for (int k = 0; k < 3; k++) {
     const double s = L.body_mass[0] * xipos[0][k] + L.body_mass[1] * xipos[1][k] + L.body_mass[2] * xipos[2][k];
     com[k] = (qd_sum(s) + m.trunk_mass * txipos[k]) / m.total_mass;
   }
   double cin[3][10], cinT[10];
-  for (int j = 0; j < 3; j++) {
+  QUNROLL for (int j = 0; j < 3; j++) {
     const double dif[3] = {xipos[j][0] - com[0], xipos[j][1] - com[1], xipos[j][2] - com[2]};
     inert_shift(cin[j], irot[j], dif, L.body_mass[j]);
   }
   { const double dif[3] = {txipos[0] - com[0], txipos[1] - com[1], txipos[2] - com[2]}; inert_shift(cinT, tirot, dif, m.trunk_mass); }
   {
     const double off[3] = {com[0] - txpos[0], com[1] - txpos[1], com[2] - txpos[2]};
-    for (int k = 0; k < 3; k++) {
+    QUNROLL for (int k = 0; k < 3; k++) {
       kin.ca[k][0] = txm[k]; kin.ca[k][1] = txm[3 + k]; kin.ca[k][2] = txm[6 + k];
       cr3(kin.cl[k], kin.ca[k], off);
     }
-    for (int j = 0; j < 3; j++) {
+    QUNROLL for (int j = 0; j < 3; j++) {
       const double o[3] = {com[0] - anchor[j][0], com[1] - anchor[j][1], com[2] - anchor[j][2]};
-      for (int k = 0; k < 3; k++) kin.cdof[j][k] = axis[j][k];
+      QUNROLL for (int k = 0; k < 3; k++) kin.cdof[j][k] = axis[j][k];
       cr3(kin.cdof[j] + 3, axis[j], o);
     }
   }
   // ================= composite inertia -> M (o_crb), in arrowhead form
-  Arrow& M = out.M;
+  Arrow M;
   {
     double crb[3][10], crbT[10];
-    for (int e = 0; e < 10; e++) { crb[2][e] = cin[2][e]; crb[1][e] = cin[1][e] + crb[2][e]; crb[0][e] = cin[0][e] + crb[1][e]; }
-    for (int e = 0; e < 10; e++) crbT[e] = cinT[e] + qd_sum(crb[0][e]);
-    for (int j = 0; j < 3; j++) {
+    QUNROLL for (int e = 0; e < 10; e++) { crb[2][e] = cin[2][e]; crb[1][e] = cin[1][e] + crb[2][e]; crb[0][e] = cin[0][e] + crb[1][e]; }
+    QUNROLL for (int e = 0; e < 10; e++) crbT[e] = cinT[e] + qd_sum(crb[0][e]);
+    QUNROLL for (int j = 0; j < 3; j++) {
       double buf[6];
       mul_inert(buf, crb[j], kin.cdof[j]);
       M.l[tri(j, j)] = L.armature[j] + dot6(kin.cdof[j], buf);
-      for (int i = 0; i < j; i++) M.l[tri(j, i)] = dot6(kin.cdof[i], buf);
-      for (int k = 0; k < 6; k++) M.b[j][k] = trunk_dot(kin, k, buf);
+      QUNROLL for (int i = 0; i < j; i++) M.l[tri(j, i)] = dot6(kin.cdof[i], buf);
+      QUNROLL for (int k = 0; k < 6; k++) M.b[j][k] = trunk_dot(kin, k, buf);
     }
-    for (int k = 0; k < 6; k++) {
+    QUNROLL for (int k = 0; k < 6; k++) {
       double cd[6], buf[6];
-      if (k < 3) { for (int c = 0; c < 6; c++) cd[c] = 0; cd[3 + k] = 1; }
-      else { for (int c = 0; c < 3; c++) { cd[c] = kin.ca[k - 3][c]; cd[3 + c] = kin.cl[k - 3][c]; } }
+      if (k < 3) { QUNROLL for (int c = 0; c < 6; c++) cd[c] = 0; cd[3 + k] = 1; }
+      else { QUNROLL for (int c = 0; c < 3; c++) { cd[c] = kin.ca[k - 3][c]; cd[3 + c] = kin.cl[k - 3][c]; } }
       mul_inert(buf, crbT, cd);
-      for (int i = 0; i <= k; i++) M.t[tri(k, i)] = trunk_dot(kin, i, buf);
+      QUNROLL for (int i = 0; i <= k; i++) M.t[tri(k, i)] = trunk_dot(kin, i, buf);
     }
   }
-  ArrowFactor Mf;
-  if (!arrow_factor(M, Mf)) return kFlagNotPD;
   // ================= velocities (o_comvel)
-  double cdof_dot[3][6], cdT_dot[3][6];
+  double cdof_dot[3][6], cdT_dot[3][6], cvel[3][6], cvelT[6];
   {
-    double cvel[6] = {0, 0, 0, S.tv[0], S.tv[1], S.tv[2]};
-    for (int k = 0; k < 3; k++) {
-      double cd[6] = {kin.ca[k][0], kin.ca[k][1], kin.ca[k][2], kin.cl[k][0], kin.cl[k][1], kin.cl[k][2]};
-      cross_motion(cdT_dot[k], cvel, cd);
+    double cv[6] = {0, 0, 0, S.tv[0], S.tv[1], S.tv[2]};
+    QUNROLL for (int k = 0; k < 3; k++) {
+      const double cd[6] = {kin.ca[k][0], kin.ca[k][1], kin.ca[k][2], kin.cl[k][0], kin.cl[k][1], kin.cl[k][2]};
+      cross_motion(cdT_dot[k], cv, cd);
     }
-    for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) { cvel[c] += kin.ca[k][c] * S.tv[3 + k]; cvel[3 + c] += kin.cl[k][c] * S.tv[3 + k]; }
-    for (int c = 0; c < 6; c++) kin.cvelT[c] = cvel[c];
-    for (int j = 0; j < 3; j++) {
-      cross_motion(cdof_dot[j], cvel, kin.cdof[j]);
-      for (int c = 0; c < 6; c++) { cvel[c] += kin.cdof[j][c] * S.lv[j]; kin.cvel[j][c] = cvel[c]; }
+    QUNROLL for (int k = 0; k < 3; k++) QUNROLL for (int c = 0; c < 3; c++) { cv[c] += kin.ca[k][c] * S.tv[3 + k]; cv[3 + c] += kin.cl[k][c] * S.tv[3 + k]; }
+    QUNROLL for (int c = 0; c < 6; c++) cvelT[c] = cv[c];
+    QUNROLL for (int j = 0; j < 3; j++) {
+      cross_motion(cdof_dot[j], cv, kin.cdof[j]);
+      QUNROLL for (int c = 0; c < 6; c++) { cv[c] += kin.cdof[j][c] * S.lv[j]; cvel[j][c] = cv[c]; }
     }
   }
-  // ================= collision (o_collision): the leg's geoms and the lane's share of the trunk geoms
-  int ncon = 0;
-  QPairGeoms pg;
-  int npg_seen = 0;
-  for (int gi = 0; gi < L.ngeom; gi++) {
-    const QuadGeom& g = L.geom[gi];
-    double gp[3], gR[9];
-    const double* bm = kin.xmat[g.link];
-    mv3(gp, bm, g.pos);
-    for (int k = 0; k < 3; k++) gp[k] += kin.xpos[g.link][k];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) gR[3 * r + c] = bm[3 * r] * g.rot[c] + bm[3 * r + 1] * g.rot[3 + c] + bm[3 * r + 2] * g.rot[6 + c];
-    if (gi == L.foot_slot) for (int k = 0; k < 3; k++) out.foot[k] = gp[k];
-    if (npg_seen < L.npg && L.pg_slot[npg_seen] == gi) {
-      for (int k = 0; k < 3; k++) { pg.c[npg_seen][k] = gp[k]; pg.a[npg_seen][k] = gR[3 * k + 2]; }
-      npg_seen++;
-    }
-    collide_geom(m, sp, g, &tab.leg[leg][0][gi], kQLegGeom, kin, com, kin.cvel[g.link], g.link + 1, gp, gR, con, ncon, flags);
-  }
-  for (int gi = leg; gi < m.ntrunk_geom; gi += kQLegs) {
-    const QuadGeom& g = m.trunk_geom[gi];
-    double gp[3], gR[9];
-    mv3(gp, txm, g.pos);
-    for (int k = 0; k < 3; k++) gp[k] += txpos[k];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
-    collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, kin, com, kin.cvelT, 0, gp, gR, con, ncon, flags);
-  }
-  // ================= passive, bias (o_rne), actuation, smooth acceleration
-  double fs_l[3], fs_t[6];
+  // ================= passive, bias (o_rne), actuation -> qfrc_smooth
   {
     const double g0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
     double caccT[6], cacc[6], cfrc[3][6], cfrcT[6], t1[6], t2[6], t3[6];
-    for (int c = 0; c < 6; c++) caccT[c] = g0[c] + cdT_dot[0][c] * S.tv[3] + cdT_dot[1][c] * S.tv[4] + cdT_dot[2][c] * S.tv[5];
-    mul_inert(t1, cinT, caccT); mul_inert(t2, cinT, kin.cvelT); cross_force(t3, kin.cvelT, t2);
-    for (int c = 0; c < 6; c++) { cfrcT[c] = t1[c] + t3[c]; cacc[c] = caccT[c]; }
-    for (int j = 0; j < 3; j++) {
-      for (int c = 0; c < 6; c++) cacc[c] += cdof_dot[j][c] * S.lv[j];
-      mul_inert(t1, cin[j], cacc); mul_inert(t2, cin[j], kin.cvel[j]); cross_force(t3, kin.cvel[j], t2);
-      for (int c = 0; c < 6; c++) cfrc[j][c] = t1[c] + t3[c];
+    QUNROLL for (int c = 0; c < 6; c++) caccT[c] = g0[c] + cdT_dot[0][c] * S.tv[3] + cdT_dot[1][c] * S.tv[4] + cdT_dot[2][c] * S.tv[5];
+    mul_inert(t1, cinT, caccT); mul_inert(t2, cinT, cvelT); cross_force(t3, cvelT, t2);
+    QUNROLL for (int c = 0; c < 6; c++) { cfrcT[c] = t1[c] + t3[c]; cacc[c] = caccT[c]; }
+    QUNROLL for (int j = 0; j < 3; j++) {
+      QUNROLL for (int c = 0; c < 6; c++) cacc[c] += cdof_dot[j][c] * S.lv[j];
+      mul_inert(t1, cin[j], cacc); mul_inert(t2, cin[j], cvel[j]); cross_force(t3, cvel[j], t2);
+      QUNROLL for (int c = 0; c < 6; c++) cfrc[j][c] = t1[c] + t3[c];
     }
-    for (int c = 0; c < 6; c++) { cfrc[1][c] += cfrc[2][c]; cfrc[0][c] += cfrc[1][c]; cfrcT[c] += qd_sum(cfrc[0][c]); }
-    for (int j = 0; j < 3; j++) {
+    QUNROLL for (int c = 0; c < 6; c++) { cfrc[1][c] += cfrc[2][c]; cfrc[0][c] += cfrc[1][c]; cfrcT[c] += qd_sum(cfrc[0][c]); }
+    QUNROLL for (int j = 0; j < 3; j++) {
       const double bias = dot6(kin.cdof[j], cfrc[j]);
       double passive = -L.damping[j] * S.lv[j];
       if (L.stiffness[j] != 0) passive -= L.stiffness[j] * (S.lq[j] - L.qpos_spring[j]);
@@ -1009,18 +1030,77 @@ QD int forward(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
       if (L.act_biastype[j] == 1) force += L.act_bias[j][0] + L.act_bias[j][1] * L.act_gear[j] * S.lq[j] + L.act_bias[j][2] * L.act_gear[j] * S.lv[j];
       if (L.forcelimited[j]) force = clampd(force, L.forcerange[j][0], L.forcerange[j][1]);
       out.act_force[j] = force;
-      fs_l[j] = passive - bias + L.act_gear[j] * force;
+      D.fs_l[j] = passive - bias + L.act_gear[j] * force;
     }
-    for (int k = 0; k < 6; k++) fs_t[k] = -trunk_dot(kin, k, cfrcT);
+    QUNROLL for (int k = 0; k < 6; k++) D.fs_t[k] = -trunk_dot(kin, k, cfrcT);
   }
-  double sl[3] = {fs_l[0], fs_l[1], fs_l[2]}, st[6] = {fs_t[0], fs_t[1], fs_t[2], fs_t[3], fs_t[4], fs_t[5]};
-  arrow_solve(Mf, sl, st);  // qacc_smooth
-  // ================= constraint rows of the lane: friction loss, joint limits (o_make_constraint_full); contacts are in `con`
-  QRows R;
-  for (int j = 0; j < 3; j++) {
+  // ================= what the sensor stage reads
+  QUNROLL for (int k = 0; k < 9; k++) out.txm[k] = txm[k];
+  QUNROLL for (int k = 0; k < 4; k++) out.txq[k] = txq[k];
+  QUNROLL for (int k = 0; k < 3; k++) { out.txipos[k] = txipos[k]; out.com[k] = com[k]; }
+  mv3(tmp3, txm, m.head_pos);
+  QUNROLL for (int k = 0; k < 3; k++) out.head[k] = txpos[k] + tmp3[k];
+  for (int t = 0; t < m.ntrace; t++) { mv3(tmp3, txm, m.trace_pos[t]); QUNROLL for (int k = 0; k < 3; k++) out.trace[t][k] = txpos[k] + tmp3[k]; }
+  {  // subtree linear velocity of the trunk (o_subtree_linvel)
+    double mom[3] = {0, 0, 0};
+    QUNROLL for (int j = 0; j < 3; j++) {
+      const double off[3] = {xipos[j][0] - com[0], xipos[j][1] - com[1], xipos[j][2] - com[2]};
+      double lin[3];
+      cr3(lin, cvel[j], off);
+      QUNROLL for (int k = 0; k < 3; k++) mom[k] += L.body_mass[j] * (cvel[j][3 + k] + lin[k]);
+    }
+    const double off[3] = {txipos[0] - com[0], txipos[1] - com[1], txipos[2] - com[2]};
+    double lin[3];
+    cr3(lin, cvelT, off);
+    QUNROLL for (int k = 0; k < 3; k++) out.comvel[k] = (qd_sum(mom[k]) + m.trunk_mass * (cvelT[3 + k] + lin[k])) / m.total_mass;
+  }
+  QPROF(pf, 1);
+  // ================= collision (o_collision): the leg's geoms and the lane's share of the trunk geoms; the self-collision test
+  int ncon = 0;
+  QPairGeoms pg;
+  QUNROLL for (int i = 0; i < kQPairGeom; i++) QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = 0; pg.a[i][k] = 0; }
+  for (int gi = 0; gi < L.ngeom; gi++) {
+    const QuadGeom& g = L.geom[gi];
+    double gp[3], gR[9];
+    const int lk = g.link;
+    double bm[9], bp[3], bv[6];
+    QUNROLL for (int k = 0; k < 9; k++) bm[k] = lk == 0 ? xmat[0][k] : (lk == 1 ? xmat[1][k] : xmat[2][k]);
+    QUNROLL for (int k = 0; k < 3; k++) bp[k] = lk == 0 ? xpos[0][k] : (lk == 1 ? xpos[1][k] : xpos[2][k]);
+    QUNROLL for (int k = 0; k < 6; k++) bv[k] = lk == 0 ? cvel[0][k] : (lk == 1 ? cvel[1][k] : cvel[2][k]);
+    mv3(gp, bm, g.pos);
+    QUNROLL for (int k = 0; k < 3; k++) gp[k] += bp[k];
+    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = bm[3 * r] * g.rot[c] + bm[3 * r + 1] * g.rot[3 + c] + bm[3 * r + 2] * g.rot[6 + c];
+    if (gi == L.foot_slot) QUNROLL for (int k = 0; k < 3; k++) out.foot[k] = gp[k];
+    QUNROLL for (int i = 0; i < kQPairGeom; i++) {  // (compile-time slots: a run-time index would put the array in scratch)
+      const bool hit = i < L.npg && L.pg_slot[i] == gi;
+      QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = hit ? gp[k] : pg.c[i][k]; pg.a[i][k] = hit ? gR[3 * k + 2] : pg.a[i][k]; }
+    }
+    collide_geom(m, sp, g, &tab.leg[leg][0][gi], kQLegGeom, com, bv, lk + 1, gp, gR, cs, ncon, flags);
+  }
+  for (int gi = leg; gi < m.ntrunk_geom; gi += kQLegs) {
+    const QuadGeom& g = m.trunk_geom[gi];
+    double gp[3], gR[9];
+    mv3(gp, txm, g.pos);
+    QUNROLL for (int k = 0; k < 3; k++) gp[k] += txpos[k];
+    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
+    collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, com, cvelT, 0, gp, gR, cs, ncon, flags);
+  }
+  D.ncon = ncon;
+  QPROF(pf, 2);
+  if (pair_near(m, leg, pg, txpos, txm)) flags |= kFlagPair;
+  QPROF(pf, 3);
+  // ================= M goes to the store (the solver and the integrator read it there); its factor gives qacc_smooth and is dropped
+  store_arrow(ms, M);
+  if (!arrow_factor(M)) flags |= kFlagNotPD;
+  QUNROLL for (int j = 0; j < 3; j++) D.sl[j] = D.fs_l[j];
+  QUNROLL for (int k = 0; k < 6; k++) D.st[k] = D.fs_t[k];
+  arrow_solve(M, D.sl, D.st);
+  // ================= constraint rows of the lane: friction loss, joint limits (o_make_constraint_full); contacts are in the store
+  QRows& R = D.R;
+  QUNROLL for (int j = 0; j < 3; j++) {
     R.fl_aref[j] = -L.floss_b[j] * S.lv[j];
-    R.fl_jar[j] = R.fl_jv[j] = 0;
-    R.lm_side[j] = 0; R.lm_aref[j] = 0; R.lm_D[j] = 0; R.lm_jar[j] = R.lm_jv[j] = 0;
+    R.fl_jar[j] = 0;
+    R.lm_side[j] = 0; R.lm_aref[j] = 0; R.lm_D[j] = 0; R.lm_jar[j] = 0;
     if (L.limited[j]) {
       const double dlo = S.lq[j] - L.range[j][0], dhi = L.range[j][1] - S.lq[j];
       int side = 0; double dist = 0;
@@ -1034,71 +1114,44 @@ QD int forward(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
       }
     }
   }
-  // ================= moving-geom pairs: tested only (a pair within its margin is handed to the other kernel)
-  if (pair_near(m, leg, pg, txpos, txm)) flags |= kFlagPair;
-  flags = qd_or(flags);
-  if (flags) return flags;
-  // ================= constraint solve
-  const int rc = constraint_newton(m, L, kin, M, R, con, ncon, sl, st, S.wl, S.wt, have_warm, out.qacc_l, out.qacc_t, out.fc_l, out.fc_t, out.iters);
-  if (rc) return rc;
-  for (int j = 0; j < 3; j++) out.fs_l[j] = fs_l[j];
-  for (int k = 0; k < 6; k++) out.fs_t[k] = fs_t[k];
-  // ================= what the sensor stage and the recording read
-  for (int k = 0; k < 9; k++) out.txm[k] = txm[k];
-  for (int k = 0; k < 4; k++) out.txq[k] = txq[k];
-  for (int k = 0; k < 3; k++) { out.txipos[k] = txipos[k]; out.com[k] = com[k]; }
-  mv3(tmp3, txm, m.head_pos);
-  for (int k = 0; k < 3; k++) out.head[k] = txpos[k] + tmp3[k];
-  for (int t = 0; t < m.ntrace; t++) { mv3(tmp3, txm, m.trace_pos[t]); for (int k = 0; k < 3; k++) out.trace[t][k] = txpos[k] + tmp3[k]; }
-  {  // subtree linear velocity of the trunk (o_subtree_linvel)
-    double mom[3] = {0, 0, 0};
-    for (int j = 0; j < 3; j++) {
-      const double off[3] = {xipos[j][0] - com[0], xipos[j][1] - com[1], xipos[j][2] - com[2]};
-      double lin[3];
-      cr3(lin, kin.cvel[j], off);
-      for (int k = 0; k < 3; k++) mom[k] += L.body_mass[j] * (kin.cvel[j][3 + k] + lin[k]);
-    }
-    const double off[3] = {txipos[0] - com[0], txipos[1] - com[1], txipos[2] - com[2]};
-    double lin[3];
-    cr3(lin, kin.cvelT, off);
-    for (int k = 0; k < 3; k++) out.comvel[k] = (qd_sum(mom[k]) + m.trunk_mass * (kin.cvelT[3 + k] + lin[k])) / m.total_mass;
-  }
-  return 0;
+  QPROF(pf, 4);
+  return qd_or(flags);
 }
 
 // ---------------------------------------------------------------- mj_Euler with implicit joint damping + mj_advance (oracle o_euler)
-QD int euler(const QuadModel& m, int leg, QState& S, const QForward& f) {
+// (al, at) = the solver's qacc, (fc_l, fc_t) = qfrc_constraint; M from the store
+template <class MS>
+QD void euler(const QuadModel& m, int leg, QState& S, const QDyn& D, const MS& ms, const double* al, const double* at, const double* fc_l, const double* fc_t) {
   const QuadLeg& L = m.leg[leg];
   const double h = m.timestep;
-  double al[3], at[6];
+  double ql[3], qt[6];
+  QUNROLL for (int j = 0; j < 3; j++) ql[j] = al[j];
+  QUNROLL for (int k = 0; k < 6; k++) qt[k] = at[k];
   const bool damped = qd_or((L.damping[0] > 0 || L.damping[1] > 0 || L.damping[2] > 0) ? 1 : 0) != 0;
   if (damped) {
-    Arrow A = f.M;
-    for (int j = 0; j < 3; j++) A.l[tri(j, j)] += h * L.damping[j];
-    ArrowFactor Af;
-    for (int j = 0; j < 3; j++) al[j] = f.fs_l[j] + f.fc_l[j];
-    for (int k = 0; k < 6; k++) at[k] = f.fs_t[k] + f.fc_t[k];
-    if (arrow_factor(A, Af)) arrow_solve(Af, al, at);
-    else { for (int j = 0; j < 3; j++) al[j] = f.qacc_l[j]; for (int k = 0; k < 6; k++) at[k] = f.qacc_t[k]; }
-  } else {
-    for (int j = 0; j < 3; j++) al[j] = f.qacc_l[j];
-    for (int k = 0; k < 6; k++) at[k] = f.qacc_t[k];
+    Arrow A;
+    load_arrow(ms, A);
+    QUNROLL for (int j = 0; j < 3; j++) A.l[tri(j, j)] += h * L.damping[j];
+    if (arrow_factor(A)) {
+      QUNROLL for (int j = 0; j < 3; j++) ql[j] = D.fs_l[j] + fc_l[j];
+      QUNROLL for (int k = 0; k < 6; k++) qt[k] = D.fs_t[k] + fc_t[k];
+      arrow_solve(A, ql, qt);
+    }
   }
-  for (int j = 0; j < 3; j++) { S.wl[j] = f.qacc_l[j]; S.lv[j] += h * al[j]; S.lq[j] += h * S.lv[j]; }
-  for (int k = 0; k < 6; k++) { S.wt[k] = f.qacc_t[k]; S.tv[k] += h * at[k]; }
-  for (int k = 0; k < 3; k++) S.tq[k] += h * S.tv[k];
+  QUNROLL for (int j = 0; j < 3; j++) { S.wl[j] = al[j]; S.lv[j] += h * ql[j]; S.lq[j] += h * S.lv[j]; }
+  QUNROLL for (int k = 0; k < 6; k++) { S.wt[k] = at[k]; S.tv[k] += h * qt[k]; }
+  QUNROLL for (int k = 0; k < 3; k++) S.tq[k] += h * S.tv[k];
   {
     double ax[3] = {S.tv[3], S.tv[4], S.tv[5]};
     const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
     if (n < kQMinVal) { ax[0] = 1; ax[1] = ax[2] = 0; } else { ax[0] /= n; ax[1] /= n; ax[2] /= n; }
     const double angle = h * n;
     double qrot[4] = {1, 0, 0, 0};
-    if (angle != 0) { double s, c; sincos(0.5 * angle, &s, &c); qrot[0] = c; qrot[1] = ax[0] * s; qrot[2] = ax[1] * s; qrot[3] = ax[2] * s; }
+    if (angle != 0) { double sn, cs_; sincos(0.5 * angle, &sn, &cs_); qrot[0] = cs_; qrot[1] = ax[0] * sn; qrot[2] = ax[1] * sn; qrot[3] = ax[2] * sn; }
     q_norm(S.tq + 3);
     q_mul(S.tq + 3, S.tq + 3, qrot);
   }
   S.time += h;
-  return 0;
 }
 
 // ---------------------------------------------------------------- QuadrupedFlat residual (oracle/quadruped.inc) + cost (task.cc:71-110)
@@ -1130,10 +1183,10 @@ QD double ray_down(const QuadModel& m, const QStaticPose* sp, const double* from
     } else if (type == MJPCX_GEOM_BOX) {
       double o[3], dl[3];
       const double rel[3] = {from[0] - p[0], from[1] - p[1], from[2] - p[2]};
-      for (int k = 0; k < 3; k++) { o[k] = R[k] * rel[0] + R[3 + k] * rel[1] + R[6 + k] * rel[2]; dl[k] = -R[6 + k]; }
+      QUNROLL for (int k = 0; k < 3; k++) { o[k] = R[k] * rel[0] + R[3 + k] * rel[1] + R[6 + k] * rel[2]; dl[k] = -R[6 + k]; }
       double tmin = -1e300, tmax = 1e300;
       bool miss = false;
-      for (int k = 0; k < 3; k++) {
+      QUNROLL for (int k = 0; k < 3; k++) {
         if (fabs(dl[k]) < kQMinVal) { if (fabs(o[k]) > sz[k]) miss = true; continue; }
         double ta = (-sz[k] - o[k]) / dl[k], tb = (sz[k] - o[k]) / dl[k];
         if (ta > tb) { const double tt = ta; ta = tb; tb = tt; }
@@ -1181,10 +1234,10 @@ QD void sub_quat(double* res, const double* qa, const double* qb) {
   q_mul(qdif, qn, qa);
   double axis[3] = {qdif[1], qdif[2], qdif[3]};
   const double sin_a_2 = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
-  if (sin_a_2 > kQMinVal) for (int k = 0; k < 3; k++) axis[k] /= sin_a_2;
+  if (sin_a_2 > kQMinVal) QUNROLL for (int k = 0; k < 3; k++) axis[k] /= sin_a_2;
   double speed = 2 * atan2(sin_a_2, qdif[0]);
   if (speed > kQPi) speed -= 2 * kQPi;
-  for (int k = 0; k < 3; k++) res[k] = axis[k] * speed;
+  QUNROLL for (int k = 0; k < 3; k++) res[k] = axis[k] * speed;
 }
 QD double norm_elem(double x, int type, double p, double q) {
   switch (type) {
@@ -1218,7 +1271,7 @@ struct QTask {
 // Gait entries (every lane computes the shared ones identically, lane `foot_index` owns Gait entry foot_index), `own` = the
 // lane's three Effort and three Posture entries. Returns the cost (task.cc:71-110 + the risk transform), replicated.
 struct QResidual { double shared[18]; double gait; double effort[3], posture[3]; };
-QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* sp, int leg, const QState& S, const QForward& f, QResidual& r) {
+QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* sp, int leg, const QState& S, const QSense& f, QResidual& r) {
   const QuadLeg& L = m.leg[leg];
   const int* ri = tk.ri; const double* re = tk.re; const double* par = tk.param;
   const int mode = ri[0], handstand = ri[10], fi = L.foot_index;
@@ -1227,31 +1280,30 @@ QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* 
   double fp[4][3];
   {
     double mine[4][3];
-    for (int q = 0; q < 4; q++) for (int k = 0; k < 3; k++) mine[q][k] = q == fi ? f.foot[k] : 0.0;
-    for (int q = 0; q < 4; q++) for (int k = 0; k < 3; k++) fp[q][k] = qd_sum(mine[q][k]);
+    QUNROLL for (int q = 0; q < 4; q++) QUNROLL for (int k = 0; k < 3; k++) mine[q][k] = q == fi ? f.foot[k] : 0.0;
+    QUNROLL for (int q = 0; q < 4; q++) QUNROLL for (int k = 0; k < 3; k++) fp[q][k] = qd_sum(mine[q][k]);
   }
   const bool is_biped = mode == 1;
   double avg[3];
-  if (is_biped) { const int a = handstand ? 0 : 1, b = handstand ? 2 : 3; for (int k = 0; k < 3; k++) avg[k] = 0.5 * (fp[a][k] + fp[b][k]); }
-  else for (int k = 0; k < 3; k++) avg[k] = 0.25 * (fp[1][k] + fp[3][k] + fp[0][k] + fp[2][k]);
+  if (is_biped) { const int a = handstand ? 0 : 1, b = handstand ? 2 : 3; QUNROLL for (int k = 0; k < 3; k++) avg[k] = 0.5 * (fp[a][k] + fp[b][k]); }
+  else QUNROLL for (int k = 0; k < 3; k++) avg[k] = 0.25 * (fp[1][k] + fp[3][k] + fp[0][k] + fp[2][k]);
   const double* goal = tk.mocap + 7 * m.goal_mocap;
-  int n = 0;
-  double* R = r.shared;
+  double* R = r.shared;  // [0..2] Upright [3] Height [4..6] Position [7..8] Balance [9..10] Yaw [11..13] Angmom
   // Upright
   if (mode != 4) {
-    R[n++] = is_biped ? f.txm[6] - (handstand ? -1 : 1) : f.txm[8] - 1;
-    R[n++] = 0; R[n++] = 0;
+    R[0] = is_biped ? f.txm[6] - (handstand ? -1 : 1) : f.txm[8] - 1;
+    R[1] = 0; R[2] = 0;
   } else {
-    double quat[4];
+    double quat[4], up[3];
     flip_quat(re, ri[9], quat, S.time - re[0]);
-    sub_quat(R + n, f.txq, quat);
-    n += 3;
+    sub_quat(up, f.txq, quat);
+    R[0] = up[0]; R[1] = up[1]; R[2] = up[2];
   }
   // Height
   const double height_goal = is_biped ? 0.6 : 0.25;
-  if (mode == 3) R[n++] = 0;
-  else if (mode == 4) R[n++] = f.txipos[2] - flip_height(re, S.time - re[0]);
-  else R[n++] = (f.txipos[2] - avg[2]) - height_goal;
+  if (mode == 3) R[3] = 0;
+  else if (mode == 4) R[3] = f.txipos[2] - flip_height(re, S.time - re[0]);
+  else R[3] = (f.txipos[2] - avg[2]) - height_goal;
   // Position
   double target[3];
   if (mode == 2) {
@@ -1271,9 +1323,9 @@ QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* 
     }
     target[2] = 0;
   } else { target[0] = goal[0]; target[1] = goal[1]; target[2] = goal[2]; }
-  R[n++] = f.head[0] - target[0];
-  R[n++] = f.head[1] - target[1];
-  R[n++] = mode == 3 ? 2 * (f.head[2] - target[2]) : 0;
+  R[4] = f.head[0] - target[0];
+  R[5] = f.head[1] - target[1];
+  R[6] = mode == 3 ? 2 * (f.head[2] - target[2]) : 0;
   // Gait: the lane's own foot
   {
     const int gait = is_biped ? 2 : ri[8];
@@ -1288,7 +1340,7 @@ QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* 
         double v[3] = {goal[0] - f.foot[0], goal[1] - f.foot[1], 0};
         const double nn = sqrt(v[0] * v[0] + v[1] * v[1]);
         if (nn > kQMinVal) { v[0] /= nn; v[1] /= nn; } else { v[0] = 1; v[1] = 0; }
-        for (int k = 0; k < 3; k++) query[k] += 0.15 * v[k];
+        QUNROLL for (int k = 0; k < 3; k++) query[k] += 0.15 * v[k];
       }
       const double q3[3] = {query[0], query[1], query[2] + 0.5};
       const double ground = query[2] + 0.5 - ray_down(m, sp, q3);
@@ -1299,10 +1351,10 @@ QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* 
   }
   // Balance
   const double fall_time = sqrt(2 * height_goal / 9.81);
-  R[n++] = f.com[0] + f.comvel[0] * fall_time - avg[0];
-  R[n++] = f.com[1] + f.comvel[1] * fall_time - avg[1];
+  R[7] = f.com[0] + f.comvel[0] * fall_time - avg[0];
+  R[8] = f.com[1] + f.comvel[1] * fall_time - avg[1];
   // Effort, Posture: the lane's joints
-  for (int j = 0; j < 3; j++) {
+  QUNROLL for (int j = 0; j < 3; j++) {
     r.effort[j] = 2e-2 * f.act_force[j];
     double p = S.lq[j] - L.key_q[ri[15]][j];
     if (mode == 4) {
@@ -1321,9 +1373,9 @@ QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* 
   const double nn = sqrt(th[0] * th[0] + th[1] * th[1]);
   if (nn < kQMinVal) { th[0] = 1; th[1] = 0; } else { th[0] /= nn; th[1] /= nn; }
   const double heading_goal = par[ri[14]];
-  R[n++] = th[0] - cos(heading_goal);
-  R[n++] = th[1] - sin(heading_goal);
-  for (int k = 0; k < 3; k++) R[n++] = f.comvel[k];
+  R[9] = th[0] - cos(heading_goal);
+  R[10] = th[1] - sin(heading_goal);
+  QUNROLL for (int k = 0; k < 3; k++) R[11 + k] = f.comvel[k];
   // ---- cost: terms Upright(3) Height(1) Position(3) Gait(4) Balance(2) Effort(12) Posture(12) Yaw(2) Angmom(3)
   auto term_shared = [&](int term, const double* x, int cnt) {
     double c = 0;
@@ -1354,7 +1406,7 @@ QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* 
 // ---------------------------------------------------------------- candidate generation + Trajectory::Rollout
 // Philox4x32-10 + Box-Muller exactly as include/mjpcx.h specifies (device_common.h gaussian_pair; oracle/rng.c)
 QD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
-  for (int r = 0; r < 10; r++) {
+  QUNROLL for (int r = 0; r < 10; r++) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
@@ -1381,26 +1433,12 @@ QD double bernoulli_uniform(uint64_t seed, uint32_t cand, uint32_t iter) {
   return u53(o[0], o[1]);
 }
 
-// the rollout request (RolloutArgs<double> of rollout_lane.h, flattened so that the CPU emulator can fill it too)
-struct QArgs {
-  int N, H, P, interp;
-  const double* node_times;  // P
-  double* nodes;             // [P][nu][N]
-  const double* nominal;     // [P][nu]
-  int noise_mode;            // -1: candidates given in `nodes`
-  uint64_t seed; uint32_t iteration;
-  int candidate_offset, nominal_candidate, explore_count;
-  double std0, std1;
-  const double* param_variance;
-  double *states, *actions, *times, *residual, *costs, *trace, *total_return;  // [candidate][step][field]
-  int* failure;
-};
-
 // One lane's share of one candidate's rollout. `state0` = qpos[19] qvel[18] of the plan (Planner::SetState), `con` the lane's contact
 // list storage (kQMaxCon records). Returns the flag bits (0: rolled out; otherwise failure[cand] carries kQFallback and the
 // wavefront-per-candidate kernel takes the candidate over).
+template <class CS, class MS, class QProfT>
 QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp, const QTask& tk, const double* state0, double time0, const QArgs& a,
-               int cand, int leg, QContact* con) {
+               int cand, int leg, CS& cs, MS& ms, QProfT& pf) {
   const QuadLeg& L = m.leg[leg];
   const int nu = kQLegs * kQLinks, P = a.P, H = a.H, nr = m.nr;
   const size_t N = (size_t)a.N;
@@ -1411,7 +1449,7 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     if (a.noise_mode == 0 && a.std1 > 0) { if (bernoulli_uniform(a.seed, (uint32_t)gi, a.iteration) < 0.2) std = a.std1; }
     const bool noised = gi != a.nominal_candidate;
     for (int p = 0; p < P; p++)
-      for (int e = 0; e < 3; e++) {
+      QUNROLL for (int e = 0; e < 3; e++) {
         const int k = 3 * leg + e, j = p * nu + k;
         double v = a.nominal[j];
         if (noised) {
@@ -1432,9 +1470,9 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
   }
 #define QNODE(p, e) a.nodes[(size_t)((p) * nu + 3 * leg + (e)) * N + cand]
   QState S;
-  for (int k = 0; k < 7; k++) S.tq[k] = state0[k];
-  for (int j = 0; j < 3; j++) { S.lq[j] = state0[7 + 3 * leg + j]; S.lv[j] = state0[19 + 6 + 3 * leg + j]; S.wl[j] = 0; }
-  for (int k = 0; k < 6; k++) { S.tv[k] = state0[19 + k]; S.wt[k] = 0; }
+  QUNROLL for (int k = 0; k < 7; k++) S.tq[k] = state0[k];
+  QUNROLL for (int j = 0; j < 3; j++) { S.lq[j] = state0[7 + 3 * leg + j]; S.lv[j] = state0[19 + 6 + 3 * leg + j]; S.wl[j] = 0; }
+  QUNROLL for (int k = 0; k < 6; k++) { S.tv[k] = state0[19 + k]; S.wt[k] = 0; }
   S.time = time0;
   const size_t ds = 37;
   double total = 0;
@@ -1447,7 +1485,7 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
       // policy: TimeSpline::Sample + Clamp (SamplingPolicy::Action)
       int up = 0;
       while (up < P && a.node_times[up] <= S.time) up++;
-      for (int e = 0; e < 3; e++) {
+      QUNROLL for (int e = 0; e < 3; e++) {
         double u;
         if (up == P || up == 0) u = QNODE(up == 0 ? 0 : P - 1, e);
         else {
@@ -1474,40 +1512,50 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
         bad |= qbad(u);
         ctrl[e] = clampd(u, L.ctrlrange[e][0], L.ctrlrange[e][1]);
       }
-      for (int k = 0; k < 7; k++) bad |= qbad(S.tq[k]);
-      for (int k = 0; k < 6; k++) bad |= qbad(S.tv[k]);
-      for (int j = 0; j < 3; j++) bad |= qbad(S.lq[j]) || qbad(S.lv[j]);
+      QUNROLL for (int k = 0; k < 7; k++) bad |= qbad(S.tq[k]);
+      QUNROLL for (int k = 0; k < 6; k++) bad |= qbad(S.tv[k]);
+      QUNROLL for (int j = 0; j < 3; j++) bad |= qbad(S.lq[j]) || qbad(S.lv[j]);
     }
     if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
-    QForward f;
-    flags = forward(m, tab, sp, leg, S, ctrl, t > 0, con, f);
+    QPROF(pf, 0);
+    QDyn D;
+    QSense f;
+    flags = forward_smooth(m, tab, sp, leg, S, ctrl, cs, ms, D, f, pf);
     if (flags) break;
-    if (!last) {
-      for (int j = 0; j < 3; j++) bad |= qbad(f.qacc_l[j]);
-      for (int k = 0; k < 6; k++) bad |= qbad(f.qacc_t[k]);
-      if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
-    }
+    // the sensor stage (residual, cost, traces) does not depend on the constraint solve: evaluated and recorded first, so that
+    // nothing of it is live during the solve
     QResidual r;
     const double cost = residual_cost(m, tk, sp, leg, S, f, r);
     // ---- record step t: the quad's four lanes share the row
     {
       double* st = a.states + ((size_t)cand * H + t) * ds;
-      if (leg == 0) for (int k = 0; k < 7; k++) st[k] = S.tq[k];
-      if (leg == 1) for (int k = 0; k < 6; k++) st[19 + k] = S.tv[k];
-      for (int j = 0; j < 3; j++) { st[7 + 3 * leg + j] = S.lq[j]; st[25 + 3 * leg + j] = S.lv[j]; }
+      if (leg == 0) QUNROLL for (int k = 0; k < 7; k++) st[k] = S.tq[k];
+      if (leg == 1) QUNROLL for (int k = 0; k < 6; k++) st[19 + k] = S.tv[k];
+      QUNROLL for (int j = 0; j < 3; j++) { st[7 + 3 * leg + j] = S.lq[j]; st[25 + 3 * leg + j] = S.lv[j]; }
       double* ac = a.actions + ((size_t)cand * H + t) * nu;
-      for (int j = 0; j < 3; j++) ac[3 * leg + j] = ctrl[j];
+      QUNROLL for (int j = 0; j < 3; j++) ac[3 * leg + j] = ctrl[j];
       double* rs = a.residual + ((size_t)cand * H + t) * nr;
-      if (leg == 2) { for (int i = 0; i < 7; i++) rs[i] = r.shared[i]; }
-      if (leg == 3) { rs[11] = r.shared[7]; rs[12] = r.shared[8]; for (int i = 0; i < 5; i++) rs[37 + i] = r.shared[9 + i]; }
+      if (leg == 2) { QUNROLL for (int i = 0; i < 7; i++) rs[i] = r.shared[i]; }
+      if (leg == 3) { rs[11] = r.shared[7]; rs[12] = r.shared[8]; QUNROLL for (int i = 0; i < 5; i++) rs[37 + i] = r.shared[9 + i]; }
       rs[7 + L.foot_index] = r.gait;
-      for (int j = 0; j < 3; j++) { rs[13 + 3 * leg + j] = r.effort[j]; rs[25 + 3 * leg + j] = r.posture[j]; }
+      QUNROLL for (int j = 0; j < 3; j++) { rs[13 + 3 * leg + j] = r.effort[j]; rs[25 + 3 * leg + j] = r.posture[j]; }
       if (leg == 0) { a.times[(size_t)cand * H + t] = S.time; a.costs[(size_t)cand * H + t] = cost; }
-      if (leg == 1) for (int q = 0; q < m.ntrace; q++) for (int k = 0; k < 3; k++) a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k] = f.trace[q][k];
+      if (leg == 1) for (int q = 0; q < m.ntrace; q++) QUNROLL for (int k = 0; k < 3; k++) a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k] = f.trace[q][k];
     }
     total += cost;
-    if (last) break;
-    euler(m, leg, S, f);
+    QPROF(pf, 5);
+    if (last) break;  // (the last step's mj_forward only feeds the sensor stage)
+    double al[3], at[6], fc_l[3], fc_t[6];
+    int iters;
+    flags = constraint_newton(m, L, D.kin, ms, D.R, cs, D.ncon, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+    if (flags) break;
+    QPROF(pf, 6);
+    QPROF_COUNT(pf, 16, iters);
+    QUNROLL for (int j = 0; j < 3; j++) bad |= qbad(al[j]);
+    QUNROLL for (int k = 0; k < 6; k++) bad |= qbad(at[k]);
+    if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
+    euler(m, leg, S, D, ms, al, at, fc_l, fc_t);
+    QPROF(pf, 7);
   }
 #undef QNODE
   if (leg == 0) {
@@ -1521,8 +1569,8 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
 QD void static_pose(const QuadModel& m, const double* mocap, int s, QStaticPose& out) {
   const QuadStatic& S = m.stat[s];
   if (S.mocap < 0) {
-    for (int k = 0; k < 3; k++) out.pos[k] = S.pos[k];
-    for (int k = 0; k < 9; k++) out.mat[k] = S.rot[k];
+    QUNROLL for (int k = 0; k < 3; k++) out.pos[k] = S.pos[k];
+    QUNROLL for (int k = 0; k < 9; k++) out.mat[k] = S.rot[k];
     return;
   }
   const double* mp = mocap + 7 * S.mocap;
@@ -1530,8 +1578,8 @@ QD void static_pose(const QuadModel& m, const double* mocap, int s, QStaticPose&
   q_norm(q); q_norm(q);
   q2mat(bm, q);
   mv3(v, bm, S.pos);
-  for (int k = 0; k < 3; k++) out.pos[k] = mp[k] + v[k];
-  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out.mat[3 * r + c] = bm[3 * r] * S.rot[c] + bm[3 * r + 1] * S.rot[3 + c] + bm[3 * r + 2] * S.rot[6 + c];
+  QUNROLL for (int k = 0; k < 3; k++) out.pos[k] = mp[k] + v[k];
+  QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) out.mat[3 * r + c] = bm[3 * r] * S.rot[c] + bm[3 * r + 1] * S.rot[3 + c] + bm[3 * r + 2] * S.rot[6 + c];
 }
 
 } }  // namespace mjpcx::quad

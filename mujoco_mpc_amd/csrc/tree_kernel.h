@@ -7,6 +7,7 @@
 //     Newton iterations) neither holds a whole workgroup's LDS back nor decides when the launch ends.
 namespace mjpcx { namespace WAVE_NS {
 
+// mode bit 5 (32): roll out only the candidates whose failure[] carries kQFallback -- the ones rollout_quad_kernel (quad_kernel.h) handed on
 // mode bit 4 (16): dynamic candidate hand-out (the default; 0 = static grid stride, for A/B runs: tools/ab_mode.sh)
 // mode bit 3 (8): poison every arena before each rollout (uninitialised-read detector, tests/test_gpu_quadruped.py)
 // mode bit 1: self-check -- compare the staged image with the generic model's arrays, mismatches are counted in work[1]
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(512) void rollout_tree_kernel(const WModel m_in, co
       if (a.failure[cand] & (32 << 8))  // wave-uniform
         wave_rollout_body<C::NV, true, kTreeMaxSimpleBig, kTreeMaxConeBig>(m, tk, a, arena, cand, lane);
     } else {
-      wave_rollout_body<C::NV, true>(m, tk, a, arena, cand, lane, slab);
+      if (!(mode & 32) || (a.failure[cand] & kQFallback))  // wave-uniform
+        wave_rollout_body<C::NV, true>(m, tk, a, arena, cand, lane, slab);
     }
     if (dynamic) {
       int next = 0;

@@ -1271,10 +1271,13 @@ __device__ __forceinline__ void wf_constraint_newton(const MODEL& m, WaveData& d
     // termination as in MuJoCo's PrimalSearch: |derivative| < tolerance * ls_tolerance * |search| / scale
     wreal gtol = m.solver_tolerance * kLsTolerance * sqrt(wave_sum(lane < nv ? d.search[lane] * d.search[lane] : WL(0.0))) / scale;
     if (sizeof(wreal) == 4) gtol = fmax(gtol, WL(1e-4) * d10);  // float: the slope's rounding floor is far above MuJoCo's tolerance
+    wreal step1 = WL(1e30), step2 = WL(1e30);  // the last step and the one before (rtsafe safeguard, oracle/contact.inc)
     for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
       wreal an = alpha - d1 / d2;
       if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? WL(0.5) * (lo + hi) : 2 * alpha + 1;
+      else if (hi >= 0 && fabs(an - alpha) > WL(0.5) * step2) an = WL(0.5) * (lo + hi);
       if (an == alpha) break;
+      step2 = step1; step1 = fabs(an - alpha);
       alpha = an;
       ls_eval(lsrow, alpha, g0, h0);
       d1 = wave_sum(g0) + q1 + alpha * q2; d2 = wave_sum(h0) + q2;

@@ -60,7 +60,26 @@ static inline int qd_or(int x) {
 }
 
 #define QD static inline
+#include "../../mujoco_mpc_amd/csrc/quad_model.h"
+// the lane's contact store: a plain array here (LDS slots + a scratch overflow on the device, quad_kernel.h)
+namespace mjpcx { namespace quad { struct QContact; } }
+struct EmuProf {};
+struct EmuStore { mjpcx::quad::QContact* p; };
+static inline void qcs_load(const EmuStore& cs, int slot, mjpcx::quad::QContact& c);
+static inline void qcs_store(EmuStore& cs, int slot, const mjpcx::quad::QContact& c);
+static inline void qcs_store_jar(EmuStore& cs, int slot, const mjpcx::quad::QContact& c);
+// the store of M (LDS on the device; the trunk block once per quad there, per lane here)
+struct EmuM { double l[6], b[3][6], t[21]; };
+static inline double qms_l(const EmuM& m, int i) { return m.l[i]; }
+static inline double qms_b(const EmuM& m, int j, int k) { return m.b[j][k]; }
+static inline double qms_t(const EmuM& m, int i) { return m.t[i]; }
+static inline void qms_set_l(EmuM& m, int i, double v) { m.l[i] = v; }
+static inline void qms_set_b(EmuM& m, int j, int k, double v) { m.b[j][k] = v; }
+static inline void qms_set_t(EmuM& m, int i, double v) { m.t[i] = v; }
 #include "../../mujoco_mpc_amd/csrc/quad_step.h"
+static inline void qcs_load(const EmuStore& cs, int slot, mjpcx::quad::QContact& c) { c = cs.p[slot]; }
+static inline void qcs_store(EmuStore& cs, int slot, const mjpcx::quad::QContact& c) { cs.p[slot] = c; }
+static inline void qcs_store_jar(EmuStore& cs, int slot, const mjpcx::quad::QContact& c) { for (int k = 0; k < 6; k++) cs.p[slot].jar[k] = c.jar[k]; }
 
 using namespace mjpcx;
 using namespace mjpcx::quad;
@@ -128,28 +147,37 @@ int quademu_forward(const mjpcx_model* model, const mjpcx_task* task, const doub
     for (int j = 0; j < 3; j++) { S.lq[j] = state[7 + 3 * leg + j]; S.lv[j] = state[25 + 3 * leg + j]; S.wl[j] = warm ? warm[6 + 3 * leg + j] : 0; }
     S.time = time;
     QContact con[kQMaxCon];
-    QForward f;
+    EmuStore cs{con};
+    EmuM ms;
+    QDyn D;
+    QSense f;
     const double c3[3] = {ctrl[3 * leg], ctrl[3 * leg + 1], ctrl[3 * leg + 2]};
-    const int fl = forward(b->qm, b->qt, b->sp, leg, S, c3, warm != nullptr, con, f);
+    EmuProf pf;
+    int fl = forward_smooth(b->qm, b->qt, b->sp, leg, S, c3, cs, ms, D, f, pf);
     flags_out[leg] = fl;
     if (fl) return;
     QResidual r;
     const double cost = residual_cost(b->qm, b->tk, b->sp, leg, S, f, r);
+    double al[3], at[6], fc_l[3], fc_t[6];
+    int iters;
+    fl = constraint_newton(b->qm, b->qm.leg[leg], D.kin, ms, D.R, cs, D.ncon, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
+    flags_out[leg] = fl;
+    if (fl) return;
     for (int j = 0; j < 3; j++) {
-      out[6 + 3 * leg + j] = f.qacc_l[j]; out[18 + 6 + 3 * leg + j] = f.fs_l[j]; out[36 + 6 + 3 * leg + j] = f.fc_l[j];
-      for (int i = 0; i < 3; i++) M[6 + 3 * leg + j][6 + 3 * leg + i] = f.M.l[tri(j, i)];
-      for (int k = 0; k < 6; k++) M[6 + 3 * leg + j][k] = M[k][6 + 3 * leg + j] = f.M.b[j][k];
+      out[6 + 3 * leg + j] = al[j]; out[18 + 6 + 3 * leg + j] = D.fs_l[j]; out[36 + 6 + 3 * leg + j] = fc_l[j];
+      for (int i = 0; i < 3; i++) M[6 + 3 * leg + j][6 + 3 * leg + i] = ms.l[tri(j, i)];
+      for (int k = 0; k < 6; k++) M[6 + 3 * leg + j][k] = M[k][6 + 3 * leg + j] = ms.b[j][k];
     }
     double* res = out + 54 + 324 + 3;
     res[7 + b->qm.leg[leg].foot_index] = r.gait;
     for (int j = 0; j < 3; j++) { res[13 + 3 * leg + j] = r.effort[j]; res[25 + 3 * leg + j] = r.posture[j]; }
     if (leg == 0) {
-      for (int k = 0; k < 6; k++) { out[k] = f.qacc_t[k]; out[18 + k] = f.fs_t[k]; out[36 + k] = f.fc_t[k]; for (int i = 0; i < 6; i++) M[k][i] = f.M.t[tri(k, i)]; }
+      for (int k = 0; k < 6; k++) { out[k] = at[k]; out[18 + k] = D.fs_t[k]; out[36 + k] = fc_t[k]; for (int i = 0; i < 6; i++) M[k][i] = ms.t[tri(k, i)]; }
       for (int k = 0; k < 3; k++) out[54 + 324 + k] = f.com[k];
       for (int i = 0; i < 7; i++) res[i] = r.shared[i];
       res[11] = r.shared[7]; res[12] = r.shared[8];
       for (int i = 0; i < 5; i++) res[37 + i] = r.shared[9 + i];
-      res[42] = cost; res[43] = 0; res[44] = f.iters;
+      res[42] = cost; res[43] = D.ncon; res[44] = iters;
     }
   });
   std::memcpy(out + 54, M, sizeof M);
@@ -190,7 +218,10 @@ int quademu_rollout(const mjpcx_model* model, const mjpcx_task* task, const doub
         if (cand >= N) break;
         run_quad([&](int leg) {
           QContact con[kQMaxCon];
-          const int fl = rollout(b->qm, b->qt, b->sp, b->tk, state, time, a, cand, leg, con);
+          EmuStore cs{con};
+          EmuProf pf;
+          EmuM ms;
+          const int fl = rollout(b->qm, b->qt, b->sp, b->tk, state, time, a, cand, leg, cs, ms, pf);
           if (leg == 0 && flags) flags[cand] = fl;
         });
       }
