@@ -13,8 +13,8 @@ LIB = os.path.join(PKG_DIR, "libmjpcx.so")
 SOURCES = [("mjpcx.hip", []), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]), ("quad_kernel.hip", [])]
 # headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
 # re-compile the wavefront-per-candidate kernels, and vice versa)
-QUAD_ONLY = ["quad_step.h", "quad_kernel.h"]
-QUAD_DEPS = ["quad_step.h", "quad_kernel.h", "quad_model.h", "quad_launch.h", "quad_kernel.hip", os.path.join("..", "..", "include", "mjpcx.h")]
+QUAD_ONLY = ["quad_step.h", "quad_kernel.h", "quad_model.h"]
+QUAD_DEPS = ["quad_step.h", "quad_kernel.h", "quad_model.h", "quad_abi.h", "quad_launch.h", "quad_kernel.hip", os.path.join("..", "..", "include", "mjpcx.h")]
 HEADERS = ["device_common.h", "rollout_lane.h", "lane_registry.h", os.path.join("generated", "static_models.h"),
            os.path.join("..", "..", "include", "mjpcx.h")]
 

@@ -621,7 +621,7 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
     if ((e = hipMemsetAsync(c->d_qstamps.p, 0, 256, c->stream)) != hipSuccess) return e;
     q.stamps = (long long*)c->d_qstamps.p;
   }
-  if ((e = quad::launch_rollout_quad((const QuadModel*)c->d_qmodel.p, (const QuadTables*)c->d_qtab.p, wt.blob, bo, q, c->quad_stats ? (int*)c->d_qstats.p : nullptr,
+  if ((e = quad::launch_rollout_quad(c->d_qmodel.p, c->d_qtab.p, wt.blob, bo, q, c->quad_stats ? (int*)c->d_qstats.p : nullptr,
                                      c->stream)) != hipSuccess) return e;
   if (c->quad_stamps) {
     long long h[32];
@@ -890,8 +890,8 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       c->quad_stamps = getenv("MJPCX_QUAD_STAMPS") != nullptr;
       if (precision == 64 && !getenv("MJPCX_NO_QUAD")) {
         // the quad kernel family (four lanes per candidate): models of the legged class quad_build accepts
-        std::vector<unsigned char> hq(sizeof(QuadModel)), ht(sizeof(QuadTables));
-        c->quad_why = quad_build(m, t, (QuadModel*)hq.data(), (QuadTables*)ht.data());
+        std::vector<unsigned char> hq, ht;
+        c->quad_why = quad::build_images(m, t, hq, ht);
         if (c->quad_why.empty()) {
           if (c->d_qmodel.reserve(hq.size()) != hipSuccess || c->d_qtab.reserve(ht.size()) != hipSuccess || c->d_qstats.reserve(32) != hipSuccess ||
               c->d_qstamps.reserve(256) != hipSuccess ||

@@ -1,0 +1,30 @@
+// quad_abi.h -- the part of the quad kernel family that the rest of the library sees (mjpcx.hip, tree_kernel.h): the rollout request, the
+// failure[] marker of a candidate handed to the wavefront-per-candidate kernel, and the host entry points of the quad kernel's own
+// translation unit (quad_kernel.hip). Kept apart from quad_model.h so that a change of the quad kernel's model layout does not
+// re-compile the wavefront-per-candidate kernels.
+#pragma once
+#include <stdint.h>
+
+namespace mjpcx {
+constexpr int kQFallback = 0x40000000;  // failure[] marker of a candidate the quad kernel handed on (cleared by the fallback pass)
+namespace quad {
+// the rollout request (RolloutArgs<double> of rollout_lane.h, flattened so that the CPU emulator can fill it too)
+struct QArgs {
+  int N, H, P, interp;
+  const double* node_times;  // P
+  double* nodes;             // [P][nu][N]
+  const double* nominal;     // [P][nu]
+  int noise_mode;            // -1: candidates given in `nodes`
+  uint64_t seed; uint32_t iteration;
+  int candidate_offset, nominal_candidate, explore_count;
+  double std0, std1;
+  const double* param_variance;
+  double *states, *actions, *times, *residual, *costs, *trace, *total_return;  // [candidate][step][field]
+  int* failure;
+  long long* stamps;  // nullptr, or 32 counters: phase cycles of wavefront 0 (tuning aid, MJPCX_QUAD_STAMPS=1)
+};
+
+// offsets into the per-plan blob (WaveTaskT: wave_model.h)
+struct QBlob { int off_time, off_mocap, off_weight, off_normp, off_normq, off_param, off_risk, off_rreal, off_rint; };
+}  // namespace quad
+}  // namespace mjpcx

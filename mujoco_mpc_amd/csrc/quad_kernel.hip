@@ -3,8 +3,14 @@
 #include "quad_launch.h"
 
 namespace mjpcx { namespace quad {
-hipError_t launch_rollout_quad(const QuadModel* model, const QuadTables* tables, const double* blob, const QBlob& bo, const QArgs& a, int* stats,
-                               hipStream_t stream) {
+std::string build_images(const mjpcx_model* m, const mjpcx_task* t, std::vector<unsigned char>& model, std::vector<unsigned char>& tables) {
+  model.assign(sizeof(QuadModel), 0);
+  tables.assign(sizeof(QuadTables), 0);
+  return quad_build(m, t, reinterpret_cast<QuadModel*>(model.data()), reinterpret_cast<QuadTables*>(tables.data()));
+}
+hipError_t launch_rollout_quad(const void* model_, const void* tables_, const double* blob, const QBlob& bo, const QArgs& a, int* stats, hipStream_t stream) {
+  const QuadModel* model = static_cast<const QuadModel*>(model_);
+  const QuadTables* tables = static_cast<const QuadTables*>(tables_);
   // four wavefronts (64 candidates) per workgroup once every CU has one; single-wavefront workgroups for smaller batches
   const int W = a.N >= 64 * 128 ? 4 : 1;
   const size_t lds = W * kQWaveLds;

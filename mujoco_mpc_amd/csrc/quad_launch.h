@@ -3,10 +3,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "quad_model.h"
+#include <string>
+#include <vector>
+
+#include "../../include/mjpcx.h"
+#include "quad_abi.h"
 
 namespace mjpcx { namespace quad {
 // stats: nullptr, or 8 ints (zeroed by the caller): [0] candidates handed on, [1..5] by reason (quad_step.h kFlag*)
-hipError_t launch_rollout_quad(const QuadModel* model, const QuadTables* tables, const double* blob, const QBlob& bo, const QArgs& a, int* stats,
-                               hipStream_t stream);
+// the kernel's view of a model + task as two opaque images (QuadModel, QuadTables of quad_model.h); returns "" or why the model is
+// outside the class the quad kernel covers
+std::string build_images(const mjpcx_model* m, const mjpcx_task* t, std::vector<unsigned char>& model, std::vector<unsigned char>& tables);
+hipError_t launch_rollout_quad(const void* model, const void* tables, const double* blob, const QBlob& bo, const QArgs& a, int* stats, hipStream_t stream);
 } }

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "../../include/mjpcx.h"
+#include "quad_abi.h"
 
 namespace mjpcx {
 
@@ -32,7 +33,6 @@ constexpr int kQTrunkPairGeom = 2;
 constexpr int kQMaxFric = 8;     // distinct friction sets (mu, tangential, torsional, rolling) over the contact pairs
 constexpr int kQMaxKey = 4, kQMaxTrace = 2, kQMaxTerm = 16, kQMaxRay = 4;
 constexpr int kQMaxCon = 6;      // contacts per lane and step; more -> the candidate is handed to the wavefront-per-candidate kernel
-constexpr int kQFallback = 0x40000000;  // failure[] marker of a candidate the quad kernel handed on (cleared by the fallback pass)
 
 // contact parameters of a (static geom, moving geom) pair: mj_contactParam with solref / solimp pre-digested
 // (oracle/contact.inc contact_param, solref_kb, impedance's clipping)
@@ -93,7 +93,7 @@ struct QuadModel {
   // friction sets of the contact pairs: regularised mu, then the tangential / torsional / rolling coefficient, ZERO for rows the pair's
   // condim does not have (the cone formulas then reduce to the lower condim's)
   int nfric, pad2;
-  double fric[kQMaxFric][4];
+  double fric[kQMaxFric][6];   // mu, tangential, torsional, rolling, 1 / mu^2, 1 / (mu^2 (1 + mu^2))
 };
 
 // everything the kernel needs that is too rarely read to deserve LDS: the pair table [static][trunk geoms | leg geoms]
@@ -103,26 +103,6 @@ struct QuadTables {
   int npair;
 };
 
-namespace quad {
-// the rollout request (RolloutArgs<double> of rollout_lane.h, flattened so that the CPU emulator can fill it too)
-struct QArgs {
-  int N, H, P, interp;
-  const double* node_times;  // P
-  double* nodes;             // [P][nu][N]
-  const double* nominal;     // [P][nu]
-  int noise_mode;            // -1: candidates given in `nodes`
-  uint64_t seed; uint32_t iteration;
-  int candidate_offset, nominal_candidate, explore_count;
-  double std0, std1;
-  const double* param_variance;
-  double *states, *actions, *times, *residual, *costs, *trace, *total_return;  // [candidate][step][field]
-  int* failure;
-  long long* stamps;  // nullptr, or 32 counters: phase cycles of wavefront 0 (tuning aid, MJPCX_QUAD_STAMPS=1)
-};
-
-// offsets into the per-plan blob (WaveTaskT: wave_model.h)
-struct QBlob { int off_time, off_mocap, off_weight, off_normp, off_normq, off_param, off_risk, off_rreal, off_rint; };
-}  // namespace quad
 
 namespace quad_detail {
 inline void quat2mat(double* m, const double* q) {
@@ -335,7 +315,8 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
       digest_solimp(p.imp, solimp);
       p.diag = m->body_invweight0[2 * m->geom_bodyid[g1]] + m->body_invweight0[2 * m->geom_bodyid[g2]];
       if (!(p.margin < 0.009)) return "a contact margin of 9 mm or more (the collision pass rejects geoms 1 cm clear of a static geom)";
-      const double fs[4] = {p.mu, p.dim >= 3 ? p.fric1 : 0.0, p.dim >= 4 ? p.fric3 : 0.0, p.dim >= 6 ? p.fric4 : 0.0};
+      const double fs[6] = {p.mu, p.dim >= 3 ? p.fric1 : 0.0, p.dim >= 4 ? p.fric3 : 0.0, p.dim >= 6 ? p.fric4 : 0.0, 1.0 / (p.mu * p.mu),
+                            1.0 / (p.mu * p.mu * (1 + p.mu * p.mu))};
       p.fid = -1;
       for (int f = 0; f < qm->nfric; f++) if (std::memcmp(qm->fric[f], fs, sizeof fs) == 0) p.fid = f;
       if (p.fid < 0) {

@@ -32,6 +32,9 @@
 #ifndef QUNROLL
 #define QUNROLL
 #endif
+#ifndef QNOINLINE
+#define QNOINLINE QD
+#endif
 #ifndef QD
 #error "define QD (function qualifiers) and the quad primitives before including quad_step.h"
 #endif
@@ -276,10 +279,13 @@ QD void chain_velocity(const QKin& k, const double* xl, const double* xt, double
   }
   QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int c = 0; c < 6; c++) Vp[j + 1][c] = Vp[j][c] + k.cdof[j][c] * xl[j];
 }
-// the contact's point-space 6-vector of body velocity V: [w; v + w x off]
+// the contact's point-space 6-vector of body velocity V: [w; v + w x off]. The body's velocity is picked arithmetically (the last link's
+// minus the dofs below the body, 0 / 1 weights): selecting among the four chain velocities element by element compiles to a cascade of
+// exec-mask branches that costs more than the contact's arithmetic.
 QD void point_vel(const QContact& c, const double Vp[4][6], double* out) {
+  const double w2 = c.depth < 3 ? 1.0 : 0.0, w1 = c.depth < 2 ? 1.0 : 0.0, w0 = c.depth < 1 ? 1.0 : 0.0;
   double V[6];
-  QUNROLL for (int k = 0; k < 6; k++) V[k] = c.depth == 3 ? Vp[3][k] : (c.depth == 2 ? Vp[2][k] : (c.depth == 1 ? Vp[1][k] : Vp[0][k]));
+  QUNROLL for (int k = 0; k < 6; k++) V[k] = Vp[3][k] - w2 * (Vp[3][k] - Vp[2][k]) - w1 * (Vp[2][k] - Vp[1][k]) - w0 * (Vp[1][k] - Vp[0][k]);
   double w[3];
   cr3(w, V, c.off);
   QUNROLL for (int k = 0; k < 3; k++) { out[k] = V[k]; out[3 + k] = V[3 + k] + w[k]; }
@@ -325,18 +331,17 @@ QD double contact_eval(const QContact& c, const double* fr, double* Fs, double* 
   cr3(g, c.off, n);
   const double et[6] = {g[0], g[1], g[2], n[0], n[1], n[2]};  // the normal row about the centre of mass
   if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-    const double Dq = c.D0 / (mu * mu);
+    const double Dq = c.D0 * fr[4];
     cost = 0.5 * c.D0 * jn * jn + 0.5 * Dq * T2;
     QUNROLL for (int k = 0; k < 3; k++) { Fl[k] = -c.D0 * jn * n[k] - Dq * rl[k]; Fa[k] = -Dq * ra[k]; }
     if (X) { add_outer(X, c.D0, et); add_Qt(X, Dq, c, fr, g); }
     zone = 2;
   } else {
-    const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T, s = Dm * NT * mu, sT = s / T;
+    const double Dm = c.D0 * fr[5], NT = N - mu * T, s = Dm * NT * mu, iT = 1.0 / T, sT = s * iT;
     cost = 0.5 * Dm * NT * NT;
     QUNROLL for (int k = 0; k < 3; k++) { Fl[k] = -s * n[k] + sT * rl[k]; Fa[k] = sT * ra[k]; }
     if (X) {
       // X = Dm a a' - (s / T) (Qt - r r'),  r = A' (Q jar) / T,  a = mu (et - r)
-      const double iT = 1.0 / T;
       double rt[6], at[6], w[3];
       cr3(w, c.off, rl);
       QUNROLL for (int k = 0; k < 3; k++) { rt[k] = (ra[k] + w[k]) * iT; rt[3 + k] = rl[k] * iT; }
@@ -366,13 +371,13 @@ QD void contact_line(const QContact& c, const double* fr, const double* jv, doub
   const double UV = f1s * dot3(tl, jv + 3) + f3s * an * wn + f4s * dot3(ar, jv);
   const double VV = f1s * (dot3(jv + 3, jv + 3) - vn * vn) + f3s * wn * wn + f4s * (dot3(jv, jv) - wn * wn);
   if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-    const double Dq = c.D0 / (mu * mu);
+    const double Dq = c.D0 * fr[4];
     g += c.D0 * jn * vn + Dq * UV;
     h += c.D0 * vn * vn + Dq * VV;
     return;
   }
-  const double Dm = c.D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
-  const double dNT = mu * vn - mu * UV / T, d2NT = -mu * (VV / T - UV * UV / (T * T * T));
+  const double Dm = c.D0 * fr[5], NT = N - mu * T, iT = 1.0 / T;
+  const double dNT = mu * vn - mu * UV * iT, d2NT = -mu * (VV * iT - UV * UV * (iT * iT * iT));
   g += Dm * NT * dNT;
   h += Dm * (dNT * dNT + NT * d2NT);
 }
@@ -420,8 +425,8 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
     if (what != kEvalKeep) {
       double pv[6];
       point_vel(c, Vp, pv);
-      if (what == kEvalSet) QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = pv[k] - c.aref[k];
-      else QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k];
+      if (what == kEvalSet) { QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = pv[k] - c.aref[k]; }
+      else { QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k]; }
       qcs_store_jar(cs, i, c);
     }
     double Fs[6] = {0, 0, 0, 0, 0, 0};
@@ -539,9 +544,9 @@ QD void arrow_mul_s(const MS& ms, const double* xl, const double* xt, double* yl
 // Newton solver. (sl, st) = qacc_smooth, (wl, wt) = warm start, M in the store `ms`; leaves qacc in (al, at) and J' force in
 // (fc_l, fc_t). Returns the flag bits (quad-uniform).
 template <class CS, class MS, class QProfT>
-QD int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon,
-                         const double* sl, const double* st, const double* wl, const double* wt, bool have_warm,
-                         double* al, double* at, double* fc_l, double* fc_t, int& iters, QProfT& pf) {
+QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon,
+                   const double* sl, const double* st, const double* wl, const double* wt, bool have_warm,
+                   double* al, double* at, double* fc_l, double* fc_t, int& iters, QProfT& pf) {
   iters = 0;
   double X[21];
   int nshallow;
@@ -644,6 +649,28 @@ QD int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin, 
     QPROF(pf, 12);
   }
   return 0;
+}
+
+template <class CS, class MS, class QProfT>
+QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon,
+                         const double* sl_in, const double* st_in, const double* wl_in, const double* wt_in, bool have_warm,
+                         double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf) {
+  // (an out-of-line function on the device: its register allocation starts afresh, so the rollout's state is parked once per step instead
+  // of being spilled around inside the iteration. Everything that arrives by reference is copied to locals first: a by-reference operand
+  // is re-read from the caller's stack at every use.)
+  const QKin kin = kin_in;
+  const MS ms = ms_in;
+  QRows R = R_in;
+  CS cs = cs_in;
+  double sl[3], st[6], wl[3], wt[6], al[3], at[6], fc_l[3], fc_t[6];
+  QUNROLL for (int j = 0; j < 3; j++) { sl[j] = sl_in[j]; wl[j] = wl_in[j]; }
+  QUNROLL for (int k = 0; k < 6; k++) { st[k] = st_in[k]; wt[k] = wt_in[k]; }
+  int iters = 0;
+  const int rc = newton_body(m, L, kin, ms, R, cs, ncon, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
+  QUNROLL for (int j = 0; j < 3; j++) { al_out[j] = al[j]; fc_l_out[j] = fc_l[j]; }
+  QUNROLL for (int k = 0; k < 6; k++) { at_out[k] = at[k]; fc_t_out[k] = fc_t[k]; }
+  iters_out = iters;
+  return rc;
 }
 
 // ---------------------------------------------------------------- collision of the lane's geoms with the static geoms
@@ -953,12 +980,6 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     const double s = L.body_mass[0] * xipos[0][k] + L.body_mass[1] * xipos[1][k] + L.body_mass[2] * xipos[2][k];
     com[k] = (qd_sum(s) + m.trunk_mass * txipos[k]) / m.total_mass;
   }
-  double cin[3][10], cinT[10];
-  QUNROLL for (int j = 0; j < 3; j++) {
-    const double dif[3] = {xipos[j][0] - com[0], xipos[j][1] - com[1], xipos[j][2] - com[2]};
-    inert_shift(cin[j], irot[j], dif, L.body_mass[j]);
-  }
-  { const double dif[3] = {txipos[0] - com[0], txipos[1] - com[1], txipos[2] - com[2]}; inert_shift(cinT, tirot, dif, m.trunk_mass); }
   {
     const double off[3] = {com[0] - txpos[0], com[1] - txpos[1], com[2] - txpos[2]};
     QUNROLL for (int k = 0; k < 3; k++) {
@@ -971,68 +992,26 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
       cr3(kin.cdof[j] + 3, axis[j], o);
     }
   }
-  // ================= composite inertia -> M (o_crb), in arrowhead form
-  Arrow M;
-  {
-    double crb[3][10], crbT[10];
-    QUNROLL for (int e = 0; e < 10; e++) { crb[2][e] = cin[2][e]; crb[1][e] = cin[1][e] + crb[2][e]; crb[0][e] = cin[0][e] + crb[1][e]; }
-    QUNROLL for (int e = 0; e < 10; e++) crbT[e] = cinT[e] + qd_sum(crb[0][e]);
-    QUNROLL for (int j = 0; j < 3; j++) {
-      double buf[6];
-      mul_inert(buf, crb[j], kin.cdof[j]);
-      M.l[tri(j, j)] = L.armature[j] + dot6(kin.cdof[j], buf);
-      QUNROLL for (int i = 0; i < j; i++) M.l[tri(j, i)] = dot6(kin.cdof[i], buf);
-      QUNROLL for (int k = 0; k < 6; k++) M.b[j][k] = trunk_dot(kin, k, buf);
-    }
-    QUNROLL for (int k = 0; k < 6; k++) {
-      double cd[6], buf[6];
-      if (k < 3) { QUNROLL for (int c = 0; c < 6; c++) cd[c] = 0; cd[3 + k] = 1; }
-      else { QUNROLL for (int c = 0; c < 3; c++) { cd[c] = kin.ca[k - 3][c]; cd[3 + c] = kin.cl[k - 3][c]; } }
-      mul_inert(buf, crbT, cd);
-      QUNROLL for (int i = 0; i <= k; i++) M.t[tri(k, i)] = trunk_dot(kin, i, buf);
-    }
-  }
-  // ================= velocities (o_comvel)
-  double cdof_dot[3][6], cdT_dot[3][6], cvel[3][6], cvelT[6];
+  // (from here on the stages are ordered so that the big per-link arrays die early: velocities and the bias-acceleration recursion, the
+  // sensor values, collision (the last reader of the link frames), then inertias -> bias forces -> M)
+  // ================= velocities (o_comvel) and the acceleration recursion of o_rne (cdof_dot q-dot terms), link by link
+  double cvel[3][6], cvelT[6], cacc[3][6], caccT[6];
   {
     double cv[6] = {0, 0, 0, S.tv[0], S.tv[1], S.tv[2]};
-    QUNROLL for (int k = 0; k < 3; k++) {
+    double ca_[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    QUNROLL for (int k = 0; k < 3; k++) {  // the free joint's rotational dofs: cdof_dot = cvel (after the translations) x cdof
       const double cd[6] = {kin.ca[k][0], kin.ca[k][1], kin.ca[k][2], kin.cl[k][0], kin.cl[k][1], kin.cl[k][2]};
-      cross_motion(cdT_dot[k], cv, cd);
+      double dd[6];
+      cross_motion(dd, cv, cd);
+      QUNROLL for (int c = 0; c < 6; c++) ca_[c] += dd[c] * S.tv[3 + k];
     }
     QUNROLL for (int k = 0; k < 3; k++) QUNROLL for (int c = 0; c < 3; c++) { cv[c] += kin.ca[k][c] * S.tv[3 + k]; cv[3 + c] += kin.cl[k][c] * S.tv[3 + k]; }
-    QUNROLL for (int c = 0; c < 6; c++) cvelT[c] = cv[c];
+    QUNROLL for (int c = 0; c < 6; c++) { cvelT[c] = cv[c]; caccT[c] = ca_[c]; }
     QUNROLL for (int j = 0; j < 3; j++) {
-      cross_motion(cdof_dot[j], cv, kin.cdof[j]);
-      QUNROLL for (int c = 0; c < 6; c++) { cv[c] += kin.cdof[j][c] * S.lv[j]; cvel[j][c] = cv[c]; }
+      double dd[6];
+      cross_motion(dd, cv, kin.cdof[j]);
+      QUNROLL for (int c = 0; c < 6; c++) { ca_[c] += dd[c] * S.lv[j]; cacc[j][c] = ca_[c]; cv[c] += kin.cdof[j][c] * S.lv[j]; cvel[j][c] = cv[c]; }
     }
-  }
-  // ================= passive, bias (o_rne), actuation -> qfrc_smooth
-  {
-    const double g0[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-    double caccT[6], cacc[6], cfrc[3][6], cfrcT[6], t1[6], t2[6], t3[6];
-    QUNROLL for (int c = 0; c < 6; c++) caccT[c] = g0[c] + cdT_dot[0][c] * S.tv[3] + cdT_dot[1][c] * S.tv[4] + cdT_dot[2][c] * S.tv[5];
-    mul_inert(t1, cinT, caccT); mul_inert(t2, cinT, cvelT); cross_force(t3, cvelT, t2);
-    QUNROLL for (int c = 0; c < 6; c++) { cfrcT[c] = t1[c] + t3[c]; cacc[c] = caccT[c]; }
-    QUNROLL for (int j = 0; j < 3; j++) {
-      QUNROLL for (int c = 0; c < 6; c++) cacc[c] += cdof_dot[j][c] * S.lv[j];
-      mul_inert(t1, cin[j], cacc); mul_inert(t2, cin[j], cvel[j]); cross_force(t3, cvel[j], t2);
-      QUNROLL for (int c = 0; c < 6; c++) cfrc[j][c] = t1[c] + t3[c];
-    }
-    QUNROLL for (int c = 0; c < 6; c++) { cfrc[1][c] += cfrc[2][c]; cfrc[0][c] += cfrc[1][c]; cfrcT[c] += qd_sum(cfrc[0][c]); }
-    QUNROLL for (int j = 0; j < 3; j++) {
-      const double bias = dot6(kin.cdof[j], cfrc[j]);
-      double passive = -L.damping[j] * S.lv[j];
-      if (L.stiffness[j] != 0) passive -= L.stiffness[j] * (S.lq[j] - L.qpos_spring[j]);
-      double u = ctrl[j];
-      if (L.ctrllimited[j]) u = clampd(u, L.ctrlrange[j][0], L.ctrlrange[j][1]);
-      double force = L.act_gain[j] * u;
-      if (L.act_biastype[j] == 1) force += L.act_bias[j][0] + L.act_bias[j][1] * L.act_gear[j] * S.lq[j] + L.act_bias[j][2] * L.act_gear[j] * S.lv[j];
-      if (L.forcelimited[j]) force = clampd(force, L.forcerange[j][0], L.forcerange[j][1]);
-      out.act_force[j] = force;
-      D.fs_l[j] = passive - bias + L.act_gear[j] * force;
-    }
-    QUNROLL for (int k = 0; k < 6; k++) D.fs_t[k] = -trunk_dot(kin, k, cfrcT);
   }
   // ================= what the sensor stage reads
   QUNROLL for (int k = 0; k < 9; k++) out.txm[k] = txm[k];
@@ -1057,44 +1036,96 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
   QPROF(pf, 1);
   // ================= collision (o_collision): the leg's geoms and the lane's share of the trunk geoms; the self-collision test
   int ncon = 0;
-  QPairGeoms pg;
-  QUNROLL for (int i = 0; i < kQPairGeom; i++) QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = 0; pg.a[i][k] = 0; }
-  for (int gi = 0; gi < L.ngeom; gi++) {
-    const QuadGeom& g = L.geom[gi];
-    double gp[3], gR[9];
-    const int lk = g.link;
-    double bm[9], bp[3], bv[6];
-    QUNROLL for (int k = 0; k < 9; k++) bm[k] = lk == 0 ? xmat[0][k] : (lk == 1 ? xmat[1][k] : xmat[2][k]);
-    QUNROLL for (int k = 0; k < 3; k++) bp[k] = lk == 0 ? xpos[0][k] : (lk == 1 ? xpos[1][k] : xpos[2][k]);
-    QUNROLL for (int k = 0; k < 6; k++) bv[k] = lk == 0 ? cvel[0][k] : (lk == 1 ? cvel[1][k] : cvel[2][k]);
-    mv3(gp, bm, g.pos);
-    QUNROLL for (int k = 0; k < 3; k++) gp[k] += bp[k];
-    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = bm[3 * r] * g.rot[c] + bm[3 * r + 1] * g.rot[3 + c] + bm[3 * r + 2] * g.rot[6 + c];
-    if (gi == L.foot_slot) QUNROLL for (int k = 0; k < 3; k++) out.foot[k] = gp[k];
-    QUNROLL for (int i = 0; i < kQPairGeom; i++) {  // (compile-time slots: a run-time index would put the array in scratch)
-      const bool hit = i < L.npg && L.pg_slot[i] == gi;
-      QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = hit ? gp[k] : pg.c[i][k]; pg.a[i][k] = hit ? gR[3 * k + 2] : pg.a[i][k]; }
+  {
+    QPairGeoms pg;
+    QUNROLL for (int i = 0; i < kQPairGeom; i++) QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = 0; pg.a[i][k] = 0; }
+    for (int gi = 0; gi < L.ngeom; gi++) {
+      const QuadGeom& g = L.geom[gi];
+      double gp[3], gR[9];
+      const int lk = g.link;
+      double bm[9], bp[3], bv[6];
+      QUNROLL for (int k = 0; k < 9; k++) bm[k] = lk == 0 ? xmat[0][k] : (lk == 1 ? xmat[1][k] : xmat[2][k]);
+      QUNROLL for (int k = 0; k < 3; k++) bp[k] = lk == 0 ? xpos[0][k] : (lk == 1 ? xpos[1][k] : xpos[2][k]);
+      QUNROLL for (int k = 0; k < 6; k++) bv[k] = lk == 0 ? cvel[0][k] : (lk == 1 ? cvel[1][k] : cvel[2][k]);
+      mv3(gp, bm, g.pos);
+      QUNROLL for (int k = 0; k < 3; k++) gp[k] += bp[k];
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = bm[3 * r] * g.rot[c] + bm[3 * r + 1] * g.rot[3 + c] + bm[3 * r + 2] * g.rot[6 + c];
+      if (gi == L.foot_slot) { QUNROLL for (int k = 0; k < 3; k++) out.foot[k] = gp[k]; }
+      QUNROLL for (int i = 0; i < kQPairGeom; i++) {  // (compile-time slots: a run-time index would put the array in scratch)
+        const bool hit = i < L.npg && L.pg_slot[i] == gi;
+        QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = hit ? gp[k] : pg.c[i][k]; pg.a[i][k] = hit ? gR[3 * k + 2] : pg.a[i][k]; }
+      }
+      collide_geom(m, sp, g, &tab.leg[leg][0][gi], kQLegGeom, com, bv, lk + 1, gp, gR, cs, ncon, flags);
     }
-    collide_geom(m, sp, g, &tab.leg[leg][0][gi], kQLegGeom, com, bv, lk + 1, gp, gR, cs, ncon, flags);
+    for (int gi = leg; gi < m.ntrunk_geom; gi += kQLegs) {
+      const QuadGeom& g = m.trunk_geom[gi];
+      double gp[3], gR[9];
+      mv3(gp, txm, g.pos);
+      QUNROLL for (int k = 0; k < 3; k++) gp[k] += txpos[k];
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
+      collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, com, cvelT, 0, gp, gR, cs, ncon, flags);
+    }
+    D.ncon = ncon;
+    QPROF(pf, 2);
+    if (pair_near(m, leg, pg, txpos, txm)) flags |= kFlagPair;
+    QPROF(pf, 3);
   }
-  for (int gi = leg; gi < m.ntrunk_geom; gi += kQLegs) {
-    const QuadGeom& g = m.trunk_geom[gi];
-    double gp[3], gR[9];
-    mv3(gp, txm, g.pos);
-    QUNROLL for (int k = 0; k < 3; k++) gp[k] += txpos[k];
-    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
-    collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, com, cvelT, 0, gp, gR, cs, ncon, flags);
+  // ================= spatial inertias about the centre of mass (o_compos); bias forces (o_rne), passive, actuation -> qfrc_smooth
+  double cin[3][10], cinT[10];
+  QUNROLL for (int j = 0; j < 3; j++) {
+    const double dif[3] = {xipos[j][0] - com[0], xipos[j][1] - com[1], xipos[j][2] - com[2]};
+    inert_shift(cin[j], irot[j], dif, L.body_mass[j]);
   }
-  D.ncon = ncon;
-  QPROF(pf, 2);
-  if (pair_near(m, leg, pg, txpos, txm)) flags |= kFlagPair;
-  QPROF(pf, 3);
-  // ================= M goes to the store (the solver and the integrator read it there); its factor gives qacc_smooth and is dropped
-  store_arrow(ms, M);
-  if (!arrow_factor(M)) flags |= kFlagNotPD;
-  QUNROLL for (int j = 0; j < 3; j++) D.sl[j] = D.fs_l[j];
-  QUNROLL for (int k = 0; k < 6; k++) D.st[k] = D.fs_t[k];
-  arrow_solve(M, D.sl, D.st);
+  { const double dif[3] = {txipos[0] - com[0], txipos[1] - com[1], txipos[2] - com[2]}; inert_shift(cinT, tirot, dif, m.trunk_mass); }
+  {
+    double cfrc[3][6], cfrcT[6], t1[6], t2[6], t3[6];
+    mul_inert(t1, cinT, caccT); mul_inert(t2, cinT, cvelT); cross_force(t3, cvelT, t2);
+    QUNROLL for (int c = 0; c < 6; c++) cfrcT[c] = t1[c] + t3[c];
+    QUNROLL for (int j = 0; j < 3; j++) {
+      mul_inert(t1, cin[j], cacc[j]); mul_inert(t2, cin[j], cvel[j]); cross_force(t3, cvel[j], t2);
+      QUNROLL for (int c = 0; c < 6; c++) cfrc[j][c] = t1[c] + t3[c];
+    }
+    QUNROLL for (int c = 0; c < 6; c++) { cfrc[1][c] += cfrc[2][c]; cfrc[0][c] += cfrc[1][c]; cfrcT[c] += qd_sum(cfrc[0][c]); }
+    QUNROLL for (int j = 0; j < 3; j++) {
+      const double bias = dot6(kin.cdof[j], cfrc[j]);
+      double passive = -L.damping[j] * S.lv[j];
+      if (L.stiffness[j] != 0) passive -= L.stiffness[j] * (S.lq[j] - L.qpos_spring[j]);
+      double u = ctrl[j];
+      if (L.ctrllimited[j]) u = clampd(u, L.ctrlrange[j][0], L.ctrlrange[j][1]);
+      double force = L.act_gain[j] * u;
+      if (L.act_biastype[j] == 1) force += L.act_bias[j][0] + L.act_bias[j][1] * L.act_gear[j] * S.lq[j] + L.act_bias[j][2] * L.act_gear[j] * S.lv[j];
+      if (L.forcelimited[j]) force = clampd(force, L.forcerange[j][0], L.forcerange[j][1]);
+      out.act_force[j] = force;
+      D.fs_l[j] = passive - bias + L.act_gear[j] * force;
+    }
+    QUNROLL for (int k = 0; k < 6; k++) D.fs_t[k] = -trunk_dot(kin, k, cfrcT);
+  }
+  // ================= composite inertia (in place) -> M (o_crb), in arrowhead form; M goes to the store (the solver and the integrator read
+  // it there); its factor gives qacc_smooth and is dropped
+  {
+    Arrow M;
+    QUNROLL for (int e = 0; e < 10; e++) { cin[1][e] += cin[2][e]; cin[0][e] += cin[1][e]; }
+    QUNROLL for (int e = 0; e < 10; e++) cinT[e] += qd_sum(cin[0][e]);
+    QUNROLL for (int j = 0; j < 3; j++) {
+      double buf[6];
+      mul_inert(buf, cin[j], kin.cdof[j]);
+      M.l[tri(j, j)] = L.armature[j] + dot6(kin.cdof[j], buf);
+      QUNROLL for (int i = 0; i < j; i++) M.l[tri(j, i)] = dot6(kin.cdof[i], buf);
+      QUNROLL for (int k = 0; k < 6; k++) M.b[j][k] = trunk_dot(kin, k, buf);
+    }
+    QUNROLL for (int k = 0; k < 6; k++) {
+      double cd[6], buf[6];
+      if (k < 3) { QUNROLL for (int c = 0; c < 6; c++) cd[c] = 0; cd[3 + k] = 1; }
+      else { QUNROLL for (int c = 0; c < 3; c++) { cd[c] = kin.ca[k - 3][c]; cd[3 + c] = kin.cl[k - 3][c]; } }
+      mul_inert(buf, cinT, cd);
+      QUNROLL for (int i = 0; i <= k; i++) M.t[tri(k, i)] = trunk_dot(kin, i, buf);
+    }
+    store_arrow(ms, M);
+    if (!arrow_factor(M)) flags |= kFlagNotPD;
+    QUNROLL for (int j = 0; j < 3; j++) D.sl[j] = D.fs_l[j];
+    QUNROLL for (int k = 0; k < 6; k++) D.st[k] = D.fs_t[k];
+    arrow_solve(M, D.sl, D.st);
+  }
   // ================= constraint rows of the lane: friction loss, joint limits (o_make_constraint_full); contacts are in the store
   QRows& R = D.R;
   QUNROLL for (int j = 0; j < 3; j++) {

@@ -20,7 +20,7 @@
 #include "wave_model.h"
 #include "lds_model.h"
 #include "tree_registry.h"
-#include "quad_model.h"  // kQFallback
+#include "quad_abi.h"  // kQFallback
 #include "ilqg_kernels.h"  // find_interval, fd_assemble_kernel
 
 // The device code below is instantiated twice, textually: namespace mjpcx::w64 with wreal = double (the parity path, also
