@@ -45,7 +45,7 @@ __device__ __forceinline__ int qd_or(int v) {
 // its four lanes write the same value and read it back as an LDS broadcast).
 namespace mjpcx { namespace quad {
 struct QContact;
-constexpr int kQLdsSlots = 2;
+constexpr int kQLdsSlots = 3;
 typedef __attribute__((address_space(3))) double qlds_f64;  // a typed LDS pointer: ds_read / ds_write instead of FLAT accesses
 struct LdsStore { qlds_f64* lds; double* ovf; };
 struct LdsM { qlds_f64* ml; qlds_f64* mt; };
@@ -72,7 +72,7 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
 #include "quad_step.h"
 #undef QD
 
-// record layout: n 0-2, off 3-5, D0 6, aref 7-12, jar 13-18, (depth, friction set) 19
+// record layout: n 0-2, off 3-5, D0 6, jar 7-12, (depth, friction set) 13
 __device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int slot, mjpcx::quad::QContact& c) {
   using namespace mjpcx::quad;
   double v[kQConRec];
@@ -80,8 +80,8 @@ __device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int sl
   else { const double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f]; }
   QUNROLL for (int k = 0; k < 3; k++) { c.n[k] = v[k]; c.off[k] = v[3 + k]; }
   c.D0 = v[6];
-  QUNROLL for (int k = 0; k < 6; k++) { c.aref[k] = v[7 + k]; c.jar[k] = v[13 + k]; }
-  const int meta = (int)v[19];
+  QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = v[7 + k];
+  const int meta = (int)v[13];
   c.depth = meta & 3; c.fid = meta >> 2;
 }
 __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
@@ -89,15 +89,15 @@ __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, c
   double v[kQConRec];
   QUNROLL for (int k = 0; k < 3; k++) { v[k] = c.n[k]; v[3 + k] = c.off[k]; }
   v[6] = c.D0;
-  QUNROLL for (int k = 0; k < 6; k++) { v[7 + k] = c.aref[k]; v[13 + k] = c.jar[k]; }
-  v[19] = (double)(c.depth | (c.fid << 2));
+  QUNROLL for (int k = 0; k < 6; k++) v[7 + k] = c.jar[k];
+  v[13] = (double)(c.depth | (c.fid << 2));
   if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) p[f * 64] = v[f]; }
   else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) p[f] = v[f]; }
 }
 __device__ __forceinline__ void qcs_store_jar(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
   using namespace mjpcx::quad;
-  if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int k = 0; k < 6; k++) p[(13 + k) * 64] = c.jar[k]; }
-  else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int k = 0; k < 6; k++) p[13 + k] = c.jar[k]; }
+  if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int k = 0; k < 6; k++) p[(7 + k) * 64] = c.jar[k]; }
+  else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int k = 0; k < 6; k++) p[7 + k] = c.jar[k]; }
 }
 
 namespace mjpcx { namespace quad {

@@ -251,12 +251,12 @@ struct QState {
 // condim 1 / 3 / 4 are the same formulas with the friction coefficients of the missing rows set to zero.
 struct QContact {
   double n[3], off[3];
-  double D0;               // D of the normal row
-  double aref[6], jar[6];  // [angular; linear]
-  int depth;               // leg dofs on the body's chain (0: trunk)
-  int fid;                 // friction set (QuadModel::fric): regularised mu, tangential / torsional / rolling friction (0: row absent)
+  double D0;      // D of the normal row
+  double jar[6];  // [angular; linear]; holds -aref from the contact's creation until the solver's first pass adds J qacc_smooth
+  int depth;      // leg dofs on the body's chain (0: trunk)
+  int fid;        // friction set (QuadModel::fric): regularised mu, tangential / torsional / rolling friction (0: row absent)
 };
-constexpr int kQConRec = 20;  // doubles per stored contact (quad_kernel.h / the emulator provide the store: qcs_load, qcs_store, qcs_store_jar)
+constexpr int kQConRec = 14;  // doubles per stored contact (quad_kernel.h / the emulator provide the store: qcs_load, qcs_store, qcs_store_jar)
 
 // world poses of the static geoms, computed once per rollout (mocap bodies do not move during a rollout)
 struct QStaticPose { double pos[3], mat[9]; };
@@ -384,14 +384,16 @@ QD void contact_line(const QContact& c, const double* fr, const double* jv, doub
 
 // ---------------------------------------------------------------- constraint solve (oracle o_constraint_newton)
 struct QRows {
-  // friction loss (one row per leg dof with frictionloss > 0) and the active joint limit of each joint (side 0: none)
-  double fl_aref[3], fl_jar[3];
-  double lm_aref[3], lm_D[3], lm_jar[3];
+  // friction loss (one row per leg dof with frictionloss > 0) and the active joint limit of each joint (side 0: none); the jar entries
+  // hold -aref until the solver's first pass
+  double fl_jar[3];
+  double lm_D[3], lm_jar[3];
   int lm_side[3];
 };
-enum { kEvalKeep = 0, kEvalSet = 1, kEvalStep = 2 };
-// One pass over the lane's rows. what = kEvalSet: jar := J x - aref for the dof vector x (xl: its leg part, Vp: chain_velocity of x);
-// kEvalStep: jar += alpha J x; kEvalKeep: jar as it is. Then the penalty at jar: returns the cost of ALL rows of the candidate (quad sum), J' force in jl (lane's
+enum { kEvalKeep = 0, kEvalStep = 2 };
+// One pass over the lane's rows. what = kEvalStep: jar += alpha J x for the dof vector x (xl: its leg part, Vp: chain_velocity of x);
+// kEvalKeep: jar as it is. (The rows are created holding -aref, so the solver's first pass -- a step of 1 along qacc_smooth -- makes
+// jar = J qacc_smooth - aref, and moving to the warm start is a step along their difference: aref itself is never stored.) Then the penalty at jar: returns the cost of ALL rows of the candidate (quad sum), J' force in jl (lane's
 // leg dofs) / jt (trunk dofs, replicated), and in X the sum of the lane's contacts' Hessian blocks (packed 6 x 6; NOT yet quad-summed).
 // nshallow counts the lane's contacts in a penalty zone whose body is not the last link (their blocks need the correction of
 // hessian_blocks).
@@ -404,8 +406,7 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
   QUNROLL for (int e = 0; e < 21; e++) X[e] = 0;
   nshallow = 0;
   QUNROLL for (int j = 0; j < 3; j++) {
-    if (what == kEvalSet) { R.fl_jar[j] = xl[j] - R.fl_aref[j]; R.lm_jar[j] = -R.lm_side[j] * xl[j] - R.lm_aref[j]; }
-    else if (what == kEvalStep) { R.fl_jar[j] += alpha * xl[j]; R.lm_jar[j] += alpha * (-R.lm_side[j] * xl[j]); }
+    if (what == kEvalStep) { R.fl_jar[j] += alpha * xl[j]; R.lm_jar[j] += alpha * (-R.lm_side[j] * xl[j]); }
     double f = 0;
     if (L.floss[j] > 0) {
       const double x = R.fl_jar[j], fl = L.floss[j], Rr = L.floss_R[j];
@@ -425,8 +426,7 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
     if (what != kEvalKeep) {
       double pv[6];
       point_vel(c, Vp, pv);
-      if (what == kEvalSet) { QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = pv[k] - c.aref[k]; }
-      else { QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k]; }
+      QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k];
       qcs_store_jar(cs, i, c);
     }
     double Fs[6] = {0, 0, 0, 0, 0, 0};
@@ -557,24 +557,24 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
   {
     double Vp[4][6];
     chain_velocity(kin, al, at, Vp);
-    cost = rows_eval(m, L, kin, R, cs, ncon, kEvalSet, al, Vp, 0.0, fc_l, fc_t, X, nshallow);  // the Gauss term is zero at qacc_smooth
+    cost = rows_eval(m, L, kin, R, cs, ncon, kEvalStep, al, Vp, 1.0, fc_l, fc_t, X, nshallow);  // jar = J qacc_smooth - aref; the Gauss term is zero here
     if (have_warm) {
       double dl[3], dt[6], Ml[3], Mt[6];
       QUNROLL for (int j = 0; j < 3; j++) dl[j] = wl[j] - sl[j];
       QUNROLL for (int k = 0; k < 6; k++) dt[k] = wt[k] - st[k];
       arrow_mul_s(ms, dl, dt, Ml, Mt);
       const double gauss = 0.5 * arrow_dot(dl, dt, Ml, Mt);
-      double jl[3], jt[6], Xw[21], Vw[4][6];
+      double jl[3], jt[6], Xw[21];
       int nsw;
-      chain_velocity(kin, wl, wt, Vw);
-      const double cw = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalSet, wl, Vw, 0.0, jl, jt, Xw, nsw);
+      chain_velocity(kin, dl, dt, Vp);  // the rows move from qacc_smooth to the warm start along their difference
+      const double cw = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, 1.0, jl, jt, Xw, nsw);
       if (cw < cost) {
         cost = cw; nshallow = nsw;
         QUNROLL for (int j = 0; j < 3; j++) { al[j] = wl[j]; fc_l[j] = jl[j]; Mal[j] = Ml[j]; }
         QUNROLL for (int k = 0; k < 6; k++) { at[k] = wt[k]; fc_t[k] = jt[k]; Mat[k] = Mt[k]; }
         QUNROLL for (int e = 0; e < 21; e++) X[e] = Xw[e];
       } else {
-        (void)rows_eval(m, L, kin, R, cs, ncon, kEvalSet, al, Vp, 0.0, fc_l, fc_t, X, nshallow);
+        (void)rows_eval(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, -1.0, fc_l, fc_t, X, nshallow);  // and back
       }
     }
   }
@@ -689,14 +689,13 @@ QD void add_contact(const QuadPair& p, const double* com, const double* cvel, in
   double R0 = (1 - imp) / imp * p.diag;
   if (R0 < kQMinVal) R0 = kQMinVal;
   c.D0 = 1.0 / R0;
-  // aref = -b (J qvel) - k imp x on the normal row: J qvel in point space is the body's velocity at the point
+  // jar starts as -aref, aref = -b (J qvel) - k imp x on the normal row; J qvel in point space is the body's velocity at the point
   double w[3];
   cr3(w, cvel, c.off);
   const double kx = p.k * imp * x;
   QUNROLL for (int k = 0; k < 3; k++) {
-    c.aref[k] = p.dim >= 4 ? -p.b * cvel[k] : 0.0;
-    c.aref[3 + k] = -p.b * (cvel[3 + k] + w[k]) - kx * c.n[k];
-    c.jar[k] = c.jar[3 + k] = 0;
+    c.jar[k] = p.dim >= 4 ? p.b * cvel[k] : 0.0;
+    c.jar[3 + k] = p.b * (cvel[3 + k] + w[k]) + kx * c.n[k];
   }
   qcs_store(cs, ncon, c);
   ncon++;
@@ -1129,9 +1128,8 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
   // ================= constraint rows of the lane: friction loss, joint limits (o_make_constraint_full); contacts are in the store
   QRows& R = D.R;
   QUNROLL for (int j = 0; j < 3; j++) {
-    R.fl_aref[j] = -L.floss_b[j] * S.lv[j];
-    R.fl_jar[j] = 0;
-    R.lm_side[j] = 0; R.lm_aref[j] = 0; R.lm_D[j] = 0; R.lm_jar[j] = 0;
+    R.fl_jar[j] = L.floss_b[j] * S.lv[j];  // -aref
+    R.lm_side[j] = 0; R.lm_D[j] = 0; R.lm_jar[j] = 0;
     if (L.limited[j]) {
       const double dlo = S.lq[j] - L.range[j][0], dhi = L.range[j][1] - S.lq[j];
       int side = 0; double dist = 0;
@@ -1141,7 +1139,7 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
         const double pos = dist - L.margin[j], imp = impedance(L.lim_imp[j], pos), vel = -side * S.lv[j];
         double Rr = (1 - imp) / imp * L.lim_diag[j];
         if (Rr < kQMinVal) Rr = kQMinVal;
-        R.lm_side[j] = side; R.lm_D[j] = 1.0 / Rr; R.lm_aref[j] = -L.lim_b[j] * vel - L.lim_k[j] * imp * pos;
+        R.lm_side[j] = side; R.lm_D[j] = 1.0 / Rr; R.lm_jar[j] = L.lim_b[j] * vel + L.lim_k[j] * imp * pos;  // -aref
       }
     }
   }
