@@ -48,7 +48,7 @@ def parse():
                     help="host planner driving the hot path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` configs (they only run at --gpus 1)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test without a device: rendezvous over gloo, the unique-id broadcast, the candidate split, the "
                          "barrier + max-over-ranks timing and the JSON line -- everything of the --gpus N path except the kernels")
@@ -79,34 +79,66 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=None, interp=None):
-    """Times the CPU oracle (a port, NOT MuJoCo) driven through the reference's fan-out structure
-    (one task per candidate, one physics arena per worker thread; sampling/planner.cc:355-393) on the
-    GPU box's host cores. The thread count is the best of a short probe over {all, 1/2, 1/4, 1/8} of the
-    visible cores (containers often expose more CPUs than their quota lets them run)."""
+def host_cpu_budget():
+    """what the process may actually use: CPUs the box shows, CPUs in the affinity mask, and the cgroup CPU quota (containers often show
+    every core of the host and are throttled to a fraction of them)"""
+    visible = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = visible
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return dict(visible=visible, affinity=affinity, quota=quota)
+
+
+def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=None, interp=None, nominal=None, std=None):
+    """Times the CPU oracle (a port, NOT MuJoCo) driven through the reference's fan-out structure (one task per candidate, one physics
+    arena per worker thread; sampling/planner.cc:355-393) on the GPU box's host cores, on the SAME kind of candidates the device leg rolls:
+    clamp(nominal + N(0, sigma)) around the planner's converged nominal spline (pyoracle.noise_candidates with the planner's noise
+    spec), so that both legs do the same solver work per rollout. Reports the whole thread-count probe, the single-thread rate, the
+    parallel efficiency of the best count, the cgroup quota, and the rate at the reference's default thread count (testspeed: hardware
+    threads - 5, mjpc/testspeed_app.cc:24)."""
     from mujoco_mpc_amd import capi
     from oracle import pyoracle
     pm, pt = task.packed_model(), task.packed()
-    cores = os.cpu_count() or 1
+    budget = host_cpu_budget()
+    cores = budget["affinity"]
     dt = task.model.get_number("agent_timestep", task.model.timestep)
     times = np.array([k * (horizon - 1) * dt / (num_nodes - 1) for k in range(num_nodes)])
-    rng = np.random.default_rng(0)
-    nodes = np.clip(rng.normal(0, task.model.get_number("sampling_exploration", 0.5), (n_per_call, num_nodes, task.model.nu)), -1, 1)
+    sigma = task.model.get_number("sampling_exploration", 0.5) if std is None else std
+    nom = np.zeros((num_nodes, task.model.nu)) if nominal is None else np.asarray(nominal, float).reshape(num_nodes, task.model.nu)
+    ns = capi.make_noise_spec(seed=0, iteration=1, mode=capi.NOISE_SAMPLING, std0=sigma)
+    nodes = pyoracle.noise_candidates(pm, ns, num_nodes, nom, np.arange(1, n_per_call + 1))
+    ip = capi.SPLINE_CUBIC if interp is None else interp
 
     def run(n, threads):
         t0 = time.perf_counter()
-        pyoracle.rollout_batch_fast(pm, pt, state, 0.0, mocap, n, horizon, num_nodes, capi.SPLINE_CUBIC if interp is None else interp,
-                                    times, nodes[:n], num_threads=threads)
+        pyoracle.rollout_batch_fast(pm, pt, state, 0.0, mocap, n, horizon, num_nodes, ip, times, nodes[:n], num_threads=threads)
         return n / (time.perf_counter() - t0)
 
     run(min(64, n_per_call), 1)
     single = max(run(min(128, n_per_call), 1), run(min(128, n_per_call), 1))
-    best_threads, best_rate = 1, 0.0
-    for threads in sorted({max(1, cores // d) for d in (1, 2, 4, 8, 16)}):
+    probe = {}
+    counts = sorted({max(1, cores // d) for d in (1, 2, 4, 8, 16)} | ({max(1, int(round(budget["quota"])))} if budget["quota"] else set()))
+    for threads in counts:
         n = min(n_per_call, 32 * threads)
-        rate = max(run(n, threads), run(n, threads))
-        if rate > best_rate:
-            best_threads, best_rate = threads, rate
+        probe[threads] = max(run(n, threads), run(n, threads))
+    best_threads = max(probe, key=probe.get)
+    ref_threads = max(1, budget["visible"] - 5)
+    ref_rate = run(min(n_per_call, 32 * min(ref_threads, 256)), ref_threads)
     done, t0 = 0, time.perf_counter()
     while True:
         run(n_per_call, best_threads)
@@ -114,10 +146,15 @@ def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=Non
         el = time.perf_counter() - t0
         if el >= seconds:
             break
-    return dict(value=done / el, unit="rollouts/s", cores=best_threads, kind="port",
-                sample=f"{done} rollouts of H={horizon} ({el:.1f} s) through the C oracle's ThreadPool-style fan-out, "
-                       f"{best_threads} threads (best of a probe over {cores} visible CPUs; 1 thread: {single:.0f} rollouts/s); "
-                       f"gcc -O3 -march=native -flto; CPU restatement, not MuJoCo")
+    value = done / el
+    return dict(value=value, unit="rollouts/s", cores=best_threads, kind="port",
+                sample=f"{done} rollouts of H={horizon} ({el:.1f} s) through the C oracle's ThreadPool-style fan-out on candidates drawn like the "
+                       f"device's (noise {sigma} around the planner's nominal), {best_threads} threads; gcc -O3 -march=native -flto; CPU restatement, "
+                       f"not MuJoCo",
+                host=budget, single_thread=single, parallel_efficiency=value / (best_threads * single),
+                probe={str(k): v for k, v in probe.items()},
+                reference_default_threads={"threads": ref_threads, "value": ref_rate,
+                                           "note": "testspeed's default: hardware threads - 5 (mjpc/testspeed_app.cc:24)"})
 
 
 def initial_condition(task_name, task, planner):
@@ -143,10 +180,10 @@ def initial_condition(task_name, task, planner):
 
 
 def pmc_summary(task_name, candidates, horizon, precision):
-    """Counter-derived figures of the rollout kernel for THIS build: profiles/r02_pmc_<task>.json is written by
+    """Counter-derived figures of the rollout kernel for THIS build: profiles/r03_pmc_<task>.json is written by
     tools/pmc_rollout.sh (separate --pmc passes, as MI355X_MICROARCH.md prescribes) and records the sha256 of the
     kernel sources it profiled; a summary of any other source state is ignored (never a stale lookup)."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_{task_name.lower()}_fp{precision}.json")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_{task_name.lower()}_fp{precision}.json")
     try:
         s = json.load(open(path))
     except (OSError, ValueError):
@@ -205,7 +242,10 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
         planner.optimize_policy(H)
     fence()
     elapsed = time.perf_counter() - t0
+    main_ms, _ = planner.timing_read_main()
     kernel_ms, launches = planner.timing_read()
+    handed_on = planner.quad_stats()
+    nominal_nodes = planner.policy()[1]
     if group is not None:
         elapsed = group.max_scalar(elapsed)
     value = candidates * world * steps / elapsed
@@ -213,7 +253,8 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
         planner.close()
         return None
     bytes_per_launch = planner.algorithmic_bytes(H, P) * candidates
-    avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
+    avg_kernel_s = main_ms / max(launches, 1) * 1e-3      # the kernel that rolls the batch out (the roofline's kernel)
+    avg_rollout_s = kernel_ms / max(launches, 1) * 1e-3   # + the pass over the candidates it handed on / the lane family's sensor stage
     achieved = bytes_per_launch / avg_kernel_s / 1e9
     interp = "cubic" if kind == "sampling" and task_name != "QuadrupedFlat" else None
     label = BASELINE_SIZE.get(task_name, (0, 0, ""))[2]
@@ -228,9 +269,13 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
                    "host": ("C++ mjpc::GpuSamplingPlanner" if kind == "sampling" else "C++ mjpc::GpuCrossEntropyPlanner") + " over the C ABI"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel_ms": avg_kernel_s * 1e3, "bytes_per_launch": bytes_per_launch,
-                     "note": "algorithmic bytes (SURVEY 8d) / HIP-event time of one rollout on the context's stream; the contact "
-                             "models are VALU-issue / latency-bound, not HBM-bound (DESIGN.md 4): see `valu`"},
+                     "kernel_ms": avg_kernel_s * 1e3, "all_rollout_kernels_ms": avg_rollout_s * 1e3, "bytes_per_launch": bytes_per_launch,
+                     "handed_on_last_step": {"candidates": handed_on[0], "contact_list_full": handed_on[1], "leg_leg_contact": handed_on[2],
+                                             "indefinite_hessian": handed_on[3], "non_finite": handed_on[4], "both_limits": handed_on[5],
+                                             "trunk_leg_contact": handed_on[6]},
+                     "note": "algorithmic bytes (SURVEY 8d) / HIP-event time of the kernel that rolls the batch out (mjpcx_timing_read_main), on "
+                             "the context's stream; all_rollout_kernels_ms adds the pass over the candidates it handed to the "
+                             "wavefront-per-candidate kernel. The contact models are latency / issue-bound, not HBM-bound (DESIGN.md 4): see `valu`"},
     }
     del interp
     pmc = pmc_summary(task_name, candidates, H, precision)
@@ -244,7 +289,8 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
         n_cpu = min(max(1024, 32 * cores), candidates) if task_name != "Cartpole" else max(candidates, 64 * cores)
         out["cpu_baseline"] = cpu_baseline(task, st, H, P, args.cpu_seconds, n_cpu,
                                            mocap=None if mocap_pos is None else np.hstack([mocap_pos, mocap_quat]).reshape(-1),
-                                           interp=capi.SPLINE_ZERO if task_name == "QuadrupedFlat" or kind == "cross_entropy" else capi.SPLINE_CUBIC)
+                                           interp=capi.SPLINE_ZERO if task_name == "QuadrupedFlat" or kind == "cross_entropy" else capi.SPLINE_CUBIC,
+                                           nominal=nominal_nodes if nominal_nodes.shape[0] == P else None)
     planner.close()
     return out
 
@@ -394,8 +440,12 @@ def main():
                "config": main_line["config"], "roofline": main_line["roofline"]}
         if "cpu_baseline" in main_line:
             out["cpu_baseline"] = main_line["cpu_baseline"]
-            out["target_check"] = {"gpu_over_cpu": main_line["value"] / main_line["cpu_baseline"]["value"], "north_star_target": 64.0,
-                                   "note": "GPU rollouts/s over the CPU port's at its best thread count (a port, not MuJoCo)"}
+            cb = main_line["cpu_baseline"]
+            out["target_check"] = {"gpu_over_cpu": main_line["value"] / cb["value"], "north_star_target": 64.0,
+                                   "gpu_over_one_cpu_thread": main_line["value"] / cb["single_thread"],
+                                   "gpu_over_cpu_at_reference_default_threads": main_line["value"] / cb["reference_default_threads"]["value"],
+                                   "note": "GPU rollouts/s over the CPU port's at its best thread count (a port, not MuJoCo); the box's cgroup quota "
+                                           "and the whole probe are in cpu_baseline.host / .probe"}
         default_run = (args.task == "QuadrupedFlat" and args.planner == "sampling" and not args.candidates and not args.horizon
                        and args.precision == 64)
         if world == 1 and default_run and not args.no_extra:

@@ -400,6 +400,14 @@ int mjpcx_backward_pass(mjpcx_ctx* ctx, int n, int m, int T, double mu, int reg_
  * returns the summed kernel time [ms] and launch count since the reset. */
 int mjpcx_timing_reset(mjpcx_ctx* ctx);
 int mjpcx_timing_read(mjpcx_ctx* ctx, double* kernel_ms, int64_t* launches);
+/* The same accumulation for the rollout's FIRST kernel alone -- the one that rolls the batch out (rollout_quad_kernel, the first pass
+ * of rollout_tree_kernel, the time loop of the lane family); what follows it (the pass over the candidates it handed on, the sensor
+ * stage of the lane family) is in mjpcx_timing_read's total only. Call before mjpcx_timing_read (which ends the timing window). */
+int mjpcx_timing_read_main(mjpcx_ctx* ctx, double* main_kernel_ms, int64_t* launches);
+/* rollout_quad_kernel only (zeros otherwise): of the last rollout, [0] candidates handed to the wavefront-per-candidate kernel, then by
+ * reason: [1] contact list full [2] contact between two legs [3] indefinite Hessian [4] non-finite value [5] both limits of a joint
+ * [6] contact between the trunk and a leg. Synchronises. */
+int mjpcx_quad_stats(mjpcx_ctx* ctx, int32_t* handed_on /* 8 */);
 
 /* Algorithmic bytes of one candidate rollout:
  * w*[H*(dim_state+nu+1+nr+3*ntrace+1) + P*nu + P + 2]. */

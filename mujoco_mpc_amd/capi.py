@@ -25,7 +25,7 @@ EXPORTS = [
     "mjpcx_kernel_name", "mjpcx_set_state", "mjpcx_set_task_params", "mjpcx_set_residual_state", "mjpcx_rollout_splines",
     "mjpcx_rollout_noise", "mjpcx_rollout_splines_noisy", "mjpcx_kinematics", "mjpcx_sync", "mjpcx_get_returns", "mjpcx_get_return_at", "mjpcx_best", "mjpcx_topk", "mjpcx_elite_moments", "mjpcx_fetch_trajectory",
     "mjpcx_fetch_spline", "mjpcx_rollout_feedback", "mjpcx_transition_fd", "mjpcx_cost_derivatives",
-    "mjpcx_backward_pass", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_algorithmic_bytes",
+    "mjpcx_backward_pass", "mjpcx_timing_reset", "mjpcx_timing_read", "mjpcx_timing_read_main", "mjpcx_quad_stats", "mjpcx_algorithmic_bytes",
     "mjpcx_device_buffer", "mjpcx_comm_unique_id", "mjpcx_comm_init", "mjpcx_comm_info", "mjpcx_exchange_best", "mjpcx_merge_topk",
     "mjpcx_elite_allreduce", "mjpcx_comm_barrier", "mjpcx_comm_destroy",
 ]
@@ -82,6 +82,8 @@ def lib():
                                           [c_i32p, C.POINTER(C.c_double)])
         L.mjpcx_timing_reset.argtypes = [vp]
         L.mjpcx_timing_read.argtypes = [vp, c_f64p, C.POINTER(C.c_int64)]
+        L.mjpcx_timing_read_main.argtypes = [vp, c_f64p, C.POINTER(C.c_int64)]
+        L.mjpcx_quad_stats.argtypes = [vp, c_i32p]
         L.mjpcx_algorithmic_bytes.restype = C.c_int64
         L.mjpcx_algorithmic_bytes.argtypes = [vp, C.c_int, C.c_int]
         L.mjpcx_device_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -316,6 +318,20 @@ class Context:
         n = C.c_int64()
         self._chk(lib().mjpcx_timing_read(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def timing_read_main(self):
+        """HIP-event time of the rollouts' first (dominant) kernel alone; call before timing_read"""
+        ms = C.c_double()
+        n = C.c_int64()
+        self._chk(lib().mjpcx_timing_read_main(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def quad_stats(self):
+        """rollout_quad_kernel: candidates of the last rollout handed to the wavefront-per-candidate kernel, total and by reason"""
+        h = np.zeros(8, np.int32)
+        self._chk(lib().mjpcx_quad_stats(self.handle, as_i32p(h)))
+        return dict(handed_on=int(h[0]), contact_list_full=int(h[1]), leg_leg_contact=int(h[2]), indefinite_hessian=int(h[3]), non_finite=int(h[4]),
+                    both_limits=int(h[5]), trunk_leg_contact=int(h[6]))
 
     def algorithmic_bytes(self, horizon, num_nodes):
         return lib().mjpcx_algorithmic_bytes(self.handle, int(horizon), int(num_nodes))

@@ -363,6 +363,8 @@ struct mjpcx_ctx {
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<hipEvent_t> events_main;  // recorded right after the rollout's FIRST (dominant) kernel: events[i].first .. events_main[i] is that kernel alone
+  hipEvent_t cur_main = nullptr;
   size_t events_used = 0;
 };
 
@@ -616,13 +618,14 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
   q.total_return = a.total_return; q.failure = a.failure;
   const quad::QBlob bo{wt.off_time, wt.off_mocap, wt.off_weight, wt.off_normp, wt.off_normq, wt.off_param, wt.off_risk, wt.off_rreal, wt.off_rint};
   hipError_t e;
-  if (c->quad_stats && (e = hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream)) != hipSuccess) return e;  // (how many candidates are handed on, by reason: mjpcx_quad_stats)
   if (c->quad_stamps) {
     if ((e = hipMemsetAsync(c->d_qstamps.p, 0, 256, c->stream)) != hipSuccess) return e;
     q.stamps = (long long*)c->d_qstamps.p;
   }
-  if ((e = quad::launch_rollout_quad(c->d_qmodel.p, c->d_qtab.p, wt.blob, bo, q, c->quad_stats ? (int*)c->d_qstats.p : nullptr,
+  if ((e = quad::launch_rollout_quad(c->d_qmodel.p, c->d_qtab.p, wt.blob, bo, q, (int*)c->d_qstats.p,
                                      c->stream)) != hipSuccess) return e;
+  if (c->timing && c->cur_main) { if ((e = hipEventRecord(c->cur_main, c->stream)) != hipSuccess) return e; c->cur_main = nullptr; }
   if (c->quad_stamps) {
     long long h[32];
     (void)hipStreamSynchronize(c->stream);
@@ -641,7 +644,7 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemcpy(h, c->d_qstats.p, 32, hipMemcpyDeviceToHost);
     std::fprintf(stderr, "rollout_quad_kernel: %d of %d candidates handed to rollout_tree_kernel (contact list full %d, moving-geom pair %d, indefinite Hessian %d, "
-                 "non-finite %d, both joint limits %d)\n", h[0], N, h[1], h[2], h[3], h[4], h[5]);
+                 "non-finite %d, both joint limits %d, trunk-leg pair %d)\n", h[0], N, h[1], h[2], h[3], h[4], h[5], h[6]);
   }
   return e;
 }
@@ -699,8 +702,12 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       HIPCHK(c, hipEventCreate(&x));
       HIPCHK(c, hipEventCreate(&y));
       c->events.emplace_back(x, y);
+      hipEvent_t z;
+      HIPCHK(c, hipEventCreate(&z));
+      c->events_main.push_back(z);
     }
     e0 = c->events[c->events_used].first; e1 = c->events[c->events_used].second;
+    c->cur_main = c->events_main[c->events_used];
     c->events_used++;
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
@@ -777,6 +784,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     le = c->kernel->launch32(c->hm32, c->ht32, a, c->stream);
   }
   if (le != hipSuccess) return fail(c, MJPCX_EDEVICE, std::string("rollout kernel launch: ") + hipGetErrorString(le));
+  if (c->timing && c->cur_main) { HIPCHK(c, hipEventRecord(c->cur_main, c->stream)); c->cur_main = nullptr; }  // (paths with one kernel, or whose first pass is not singled out)
   if (c->timing) HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipEventRecord(slot->done, c->stream));
   slot->pending = true;
@@ -1003,6 +1011,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto& ev : c->events_main) (void)hipEventDestroy(ev);
   for (auto& sl : c->slots) {
     if (sl.host) (void)hipHostFree(sl.host);
     if (sl.done) (void)hipEventDestroy(sl.done);
@@ -1300,6 +1309,31 @@ int mjpcx_timing_read(mjpcx_ctx* c, double* kernel_ms, int64_t* launches) {
   if (kernel_ms) *kernel_ms = total;
   if (launches) *launches = (int64_t)c->events_used;
   c->timing = false;
+  return MJPCX_OK;
+}
+
+int mjpcx_timing_read_main(mjpcx_ctx* c, double* main_kernel_ms, int64_t* launches) {
+  if (!c) return MJPCX_EINVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double total = 0;
+  for (size_t i = 0; i < c->events_used; i++) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->events[i].first, c->events_main[i]));
+    total += ms;
+  }
+  if (main_kernel_ms) *main_kernel_ms = total;
+  if (launches) *launches = (int64_t)c->events_used;
+  return MJPCX_OK;
+}
+
+int mjpcx_quad_stats(mjpcx_ctx* c, int32_t* handed_on) {
+  if (!c || !handed_on) return MJPCX_EINVAL;
+  for (int k = 0; k < 8; k++) handed_on[k] = 0;
+  if (!c->quad_ok) return MJPCX_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(handed_on, c->d_qstats.p, 32, hipMemcpyDeviceToHost));
   return MJPCX_OK;
 }
 

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __re
   const int flags = rollout(sm, *tab, sp, tk, blob, blob[bo.off_time], a, cand, leg, cs, ms, pf);
   if (flags && leg == 0 && stats) {
     atomicAdd(stats, 1);
-    QUNROLL for (int b = 0; b < 5; b++) if (flags & (1 << b)) atomicAdd(stats + 1 + b, 1);
+    QUNROLL for (int b = 0; b < 6; b++) if (flags & (1 << b)) atomicAdd(stats + 1 + b, 1);
   }
 }
 

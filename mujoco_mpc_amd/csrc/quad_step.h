@@ -44,7 +44,7 @@ namespace mjpcx { namespace quad {
 constexpr double kQMinVal = 1e-15, kQMaxVal = 1e10, kQPi = 3.14159265358979323846;
 constexpr double kQLsTol = 0.01;
 
-enum { kFlagOverflow = 1, kFlagPair = 2, kFlagNotPD = 4, kFlagBad = 8, kFlagLimits = 16 };
+enum { kFlagOverflow = 1, kFlagPair = 2, kFlagNotPD = 4, kFlagBad = 8, kFlagLimits = 16, kFlagPairTrunk = 32 };
 
 // ---------------------------------------------------------------- small algebra
 QD bool qbad(double x) { return !(x <= kQMaxVal && x >= -kQMaxVal); }
@@ -860,15 +860,15 @@ QD double pair_distance(int t1, const double* p1, const double* a1, double r1, d
 // distance for the pairs that pass. The other legs' centres / axes arrive through quad rotations; radii and half lengths are model
 // constants. Rotations by one and two legs cover the six leg pairs (opposite legs twice). Returns (lane-local) whether a pair is within
 // the margin.
-QD bool pair_near(const QuadModel& m, int leg, const QPairGeoms& pg, const double* txpos, const double* txm) {
+QD int pair_near(const QuadModel& m, int leg, const QPairGeoms& pg, const double* txpos, const double* txm) {
   const QuadLeg& L = m.leg[leg];
   const double mg = m.pair_margin;
-  bool near = false;
-  auto test = [&](int t1, const double* c1, const double* a1, double r1, double h1, int t2, const double* c2, const double* a2, double r2, double h2) {
+  bool near = false, near_trunk = false;
+  auto test = [&](int t1, const double* c1, const double* a1, double r1, double h1, int t2, const double* c2, const double* a2, double r2, double h2, bool trunk) {
     const double dx = c1[0] - c2[0], dy = c1[1] - c2[1], dz = c1[2] - c2[2];
     const double reach = r1 + h1 + r2 + h2 + mg;
     if (dx * dx + dy * dy + dz * dz >= reach * reach) return;
-    if (pair_distance(t1, c1, a1, r1, h1, t2, c2, a2, r2, h2) < mg) near = true;
+    if (pair_distance(t1, c1, a1, r1, h1, t2, c2, a2, r2, h2) < mg) { if (trunk) near_trunk = true; else near = true; }
   };
   for (int i = 0; i < m.ntpg; i++) {
     const QuadGeom& g = m.trunk_geom[m.tpg_slot[i]];
@@ -879,7 +879,7 @@ QD bool pair_near(const QuadModel& m, int leg, const QPairGeoms& pg, const doubl
     QUNROLL for (int j = 0; j < kQPairGeom; j++) {
       if (j >= L.npg) continue;
       const QuadGeom& g2 = L.geom[L.pg_slot[j]];
-      test(g.type, c, a, g.size[0], h1, g2.type, pg.c[j], pg.a[j], g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0);
+      test(g.type, c, a, g.size[0], h1, g2.type, pg.c[j], pg.a[j], g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0, true);
     }
   }
   QUNROLL for (int d = 1; d <= 2; d++) {
@@ -896,11 +896,11 @@ QD bool pair_near(const QuadModel& m, int leg, const QPairGeoms& pg, const doubl
       QUNROLL for (int i = 0; i < kQPairGeom; i++) {
         if (i >= L.npg) continue;
         const QuadGeom& g1 = L.geom[L.pg_slot[i]];
-        test(g1.type, pg.c[i], pg.a[i], g1.size[0], g1.type == MJPCX_GEOM_CAPSULE ? g1.size[1] : 0.0, g2.type, c2, a2, g2.size[0], h2);
+        test(g1.type, pg.c[i], pg.a[i], g1.size[0], g1.type == MJPCX_GEOM_CAPSULE ? g1.size[1] : 0.0, g2.type, c2, a2, g2.size[0], h2, false);
       }
     }
   }
-  return near;
+  return (near ? 1 : 0) | (near_trunk ? 2 : 0);
 }
 
 // ---------------------------------------------------------------- mj_forward (oracle o_forward) for the lane's share of one candidate
@@ -1066,7 +1066,7 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     }
     D.ncon = ncon;
     QPROF(pf, 2);
-    if (pair_near(m, leg, pg, txpos, txm)) flags |= kFlagPair;
+    { const int pn = pair_near(m, leg, pg, txpos, txm); if (pn & 1) flags |= kFlagPair; if (pn & 2) flags |= kFlagPairTrunk; }
     QPROF(pf, 3);
   }
   // ================= spatial inertias about the centre of mass (o_compos); bias forces (o_rne), passive, actuation -> qfrc_smooth

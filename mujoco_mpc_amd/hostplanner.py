@@ -314,6 +314,19 @@ class HostPlanner:
         capi.lib().mjpcx_timing_read(self._ctx(), C.byref(ms), C.byref(n))
         return ms.value, n.value
 
+    def timing_read_main(self):
+        """HIP-event time of the rollouts' first (dominant) kernel alone (mjpcx_timing_read_main); call before timing_read"""
+        ms, n = C.c_double(), C.c_int64()
+        capi.lib().mjpcx_timing_read_main(self._ctx(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def quad_stats(self):
+        """rollout_quad_kernel: candidates of the last rollout handed to the wavefront-per-candidate kernel ([0] total, then by reason)"""
+        import numpy as np
+        hh = np.zeros(8, np.int32)
+        capi.lib().mjpcx_quad_stats(self._ctx(), capi.as_i32p(hh))
+        return [int(x) for x in hh]
+
     def algorithmic_bytes(self, horizon, num_nodes):
         return capi.lib().mjpcx_algorithmic_bytes(self._ctx(), horizon, num_nodes)
 

@@ -77,6 +77,17 @@ def test_config3_quadruped_cross_entropy_n16384_h100():
                          sample_stride=1024)
 
 
+def test_north_star_quadruped_predictive_sampling_n16384_h100():
+    """the workload bench.py times: Predictive-Sampling noise (task_flat.xml's sampling_exploration), zero-order splines, 16384 x 100,
+    with the oracle on 64 candidates of the batch"""
+    quad = load_task("QuadrupedFlat")
+    quad.transition(0.0)
+    state = np.concatenate([quad.model.keyframes["home"]["qpos"], np.zeros(18)])
+    mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
+    full_size_properties(quad, state, mocap, N=16384, H=100, P=3, interp=0, mode=capi.NOISE_SAMPLING, precision=64, tol=1e-6,
+                         sample_stride=256)
+
+
 @pytest.mark.parametrize("precision,tol", [(64, 1e-6), (32, 2e-3)])
 def test_config4_humanoid_tracking_n8192_h64(precision, tol):
     t = load_task("HumanoidTrack")

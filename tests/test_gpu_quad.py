@@ -1,0 +1,114 @@
+"""-m gpu: rollout_quad_kernel (mujoco_mpc_amd/csrc/quad_kernel.h: four lanes per candidate, one per leg) through the C ABI against the
+oracle, and against the wavefront-per-candidate kernel it hands uncovered candidates to. Tolerances: fp64, 1e-9 (1 + |x|) on every
+Trajectory buffer over 100 steps for the candidates the quad kernel rolls out itself (observed 1e-13); candidates it hands on are the
+wavefront-per-candidate kernel's and carry that suite's tolerance (1e-6 over these horizons)."""
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.task import load_task
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+MOCAP = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0.0])
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.all(np.abs(a - b) <= tol * (1 + np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def quad():
+    t = load_task("QuadrupedFlat")
+    t.transition(0.0)
+    return t
+
+
+def context(t, env=None):
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        ctx = capi.Context(t.packed_model(), t.packed(), 0, 64)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ctx.set_state(np.concatenate([t.model.keyframes["home"]["qpos"], np.zeros(18)]), 0.0, MOCAP)
+    return ctx
+
+
+def test_the_quad_kernel_serves_the_a1(quad):
+    ctx = context(quad)
+    assert "rollout_quad_kernel" in ctx.kernel_name
+    ctx.close()
+    ctx = context(quad, {"MJPCX_NO_QUAD": "1"})
+    assert "rollout_tree_kernel" in ctx.kernel_name
+    ctx.close()
+
+
+@pytest.mark.parametrize("interp,std", [(capi.SPLINE_ZERO, 0.04), (capi.SPLINE_CUBIC, 0.08)])
+def test_all_six_buffers_against_the_oracle(quad, interp, std):
+    pm, pt = quad.packed_model(), quad.packed()
+    N, H, P = 48, 100, 4
+    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+    nominal = np.clip(np.random.default_rng(2).normal(0, 0.05, (P, 12)), -1, 1)
+    ns = capi.make_noise_spec(seed=21, iteration=2, mode=capi.NOISE_SAMPLING, std0=std)
+    ctx = context(quad)
+    ctx.rollout_noise(N, H, interp, times, nominal, ns)
+    ret, fail = ctx.returns()
+    handed = ctx.quad_stats()
+    nodes = pyoracle.noise_candidates(pm, ns, P, nominal, np.arange(N))
+    ref = pyoracle.rollout_batch(pm, pt, np.concatenate([quad.model.keyframes["home"]["qpos"], np.zeros(18)]), 0.0, MOCAP, N, H, P, interp, times,
+                                 nodes, num_threads=16)
+    assert np.array_equal(fail != 0, ref["failure"] != 0)
+    tol = 1e-9 if handed["handed_on"] == 0 else 1e-6
+    assert close(ret, ref["total_return"], tol)
+    for c in range(0, N, 5):
+        tr = ctx.fetch_trajectory(c)
+        for k in ("states", "actions", "times", "residual", "costs", "trace"):
+            assert close(getattr(tr, k), ref[k][c], tol), (c, k)
+    ctx.close()
+
+
+def test_handed_on_candidates_come_back_from_the_other_kernel(quad):
+    """large noise: legs cross, lanes overflow -- those candidates are rolled out by rollout_tree_kernel; every return equals what a
+    context without the quad kernel computes (to that kernel's tolerance against itself: the same code ran)"""
+    N, H, P = 64, 100, 3
+    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+    ns = capi.make_noise_spec(seed=5, iteration=1, mode=capi.NOISE_SAMPLING, std0=0.25)
+    nominal = np.zeros((P, 12))
+    a = context(quad)
+    a.rollout_noise(N, H, 0, times, nominal, ns)
+    ra, fa = a.returns()
+    handed = a.quad_stats()
+    assert 0 < handed["handed_on"] < N and handed["leg_leg_contact"] + handed["trunk_leg_contact"] + handed["contact_list_full"] > 0
+    b = context(quad, {"MJPCX_NO_QUAD": "1"})
+    b.rollout_noise(N, H, 0, times, nominal, ns)
+    rb, fb = b.returns()
+    assert np.array_equal(fa, fb)
+    # chaotic rollouts at this noise level: the two kernels agree where the dynamics are not yet chaotic; a handed-on candidate is
+    # bit-identical (the same kernel rolled it out in both contexts)
+    d = np.abs(ra - rb) / (1 + np.abs(rb))
+    assert np.sum(d == 0) >= handed["handed_on"] and np.median(d) < 1e-12
+    a.close(); b.close()
+
+
+def test_determinism_and_sharding(quad):
+    N, H, P = 256, 40, 3
+    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+    nominal = np.zeros((P, 12))
+    ns = capi.make_noise_spec(seed=3, iteration=7, mode=capi.NOISE_SAMPLING, std0=0.04)
+    ctx = context(quad)
+    ctx.rollout_noise(N, H, 0, times, nominal, ns)
+    r1 = ctx.returns()[0].copy()
+    ctx.rollout_noise(N, H, 0, times, nominal, ns)
+    assert np.array_equal(ctx.returns()[0], r1)
+    half = capi.make_noise_spec(seed=3, iteration=7, mode=capi.NOISE_SAMPLING, std0=0.04, candidate_offset=N // 2)
+    ctx.rollout_noise(N // 2, H, 0, times, nominal, half)
+    assert np.array_equal(ctx.returns()[0], r1[N // 2:])
+    ctx.close()

@@ -1,0 +1,121 @@
+"""CPU tests of the quad kernel's step function (mujoco_mpc_amd/csrc/quad_step.h) through its lock-step emulator (tests/quademu): the
+SAME source hipcc compiles for gfx950 -- four lanes per candidate, one per leg, cross-lane traffic only through the quad primitives -- run
+as four threads per candidate and compared with the oracle. Tolerances as in the GPU parity suites (fp64: 1e-9 (1 + |x|) on every
+Trajectory buffer); observed 1e-13. The -m gpu suite (tests/test_gpu_quad.py) runs the device build of the same source."""
+import numpy as np
+import pytest
+
+from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.task import load_task
+from oracle import pyoracle
+from tests import quademu
+
+MOCAP = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0.0])
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.all(np.abs(a - b) <= tol * (1 + np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def quad():
+    t = load_task("QuadrupedFlat")
+    t.transition(0.0)
+    return t
+
+
+def home_state(t):
+    return np.concatenate([t.model.keyframes["home"]["qpos"], np.zeros(18)])
+
+
+def test_the_a1_is_in_the_class_the_quad_kernel_covers(quad):
+    assert quademu.check(quad.packed_model(), quad.packed()) == ""
+
+
+def test_other_models_are_declined_with_a_reason():
+    h = load_task("HumanoidTrack")
+    h.transition(0.0, mode=9)
+    why = quademu.check(h.packed_model(), h.packed())
+    assert why != ""  # (the humanoid has tendons, 27 dofs, no legged arrowhead)
+
+
+def test_forward_pass_matches_the_oracle(quad):
+    """mj_forward + residual at the home pose (no contact yet) and 30 steps later (feet and calves on the floor, Newton solver active)"""
+    pm, pt = quad.packed_model(), quad.packed()
+    rng = np.random.default_rng(0)
+    ctrl = rng.uniform(-0.3, 0.3, 12)
+    ph = pyoracle.Physics(pm)
+    ph.set_state(quad.model.keyframes["home"]["qpos"], np.zeros(18), 0.0, MOCAP)
+    states = [(home_state(quad), 0.0)]
+    for _ in range(30):
+        ph.set_ctrl(ctrl)
+        ph.step()
+    states.append((np.concatenate([ph.get("qpos"), ph.get("qvel")]), 0.3))
+    for st, tm in states:
+        ph.set_state(st[:19], st[19:], tm, MOCAP)
+        ph.set_ctrl(ctrl)
+        r = ph.forward_task(pt)
+        o = quademu.forward(pm, pt, st, tm, MOCAP, ctrl)
+        assert o["flags"] == 0 and o["iters"] == int(ph.get("solver_iter")[0])
+        assert close(o["qacc"], ph.get("qacc"), 1e-10) and close(o["qfrc_constraint"], ph.get("qfrc_constraint"), 1e-10)
+        assert close(o["M"], ph.get("M").reshape(18, 18), 1e-12)
+        assert close(o["residual"], r, 1e-12) and abs(o["cost"] - pyoracle.cost_value(pt, r)) <= 1e-12 * (1 + abs(o["cost"]))
+
+
+@pytest.mark.parametrize("interp", [capi.SPLINE_ZERO, capi.SPLINE_LINEAR, capi.SPLINE_CUBIC])
+def test_rollouts_match_the_oracle(quad, interp):
+    """Trajectory::Rollout of noisy candidates: all six buffers and the return (60 steps; standing, stepping, feet sliding)"""
+    pm, pt = quad.packed_model(), quad.packed()
+    N, H, P = 6, 60, 4
+    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+    nodes = np.clip(np.random.default_rng(3 + interp).normal(0, 0.06, (N, P, 12)), -1, 1)
+    ref = pyoracle.rollout_batch(pm, pt, home_state(quad), 0.0, MOCAP, N, H, P, interp, times, nodes, num_threads=4)
+    emu = quademu.rollout(pm, pt, home_state(quad), 0.0, MOCAP, N, H, P, interp, times, node_values=nodes)
+    ok = emu["flags"] == 0
+    assert ok.sum() >= N - 1 and not ref["failure"][ok].any()
+    for k in ("states", "actions", "times", "residual", "costs", "trace", "total_return"):
+        assert close(emu[k][ok], ref[k][ok], 1e-9), k
+
+
+def test_candidate_generation_is_the_specified_noise(quad):
+    """the lanes draw their own three actuators' nodes: together they are pyoracle.noise_candidates (Philox keyed on the global index)"""
+    pm, pt = quad.packed_model(), quad.packed()
+    N, H, P = 5, 3, 3
+    times = np.arange(P) * 0.01
+    nominal = np.clip(np.random.default_rng(1).normal(0, 0.2, (P, 12)), -1, 1)
+    ns = capi.make_noise_spec(seed=9, iteration=4, mode=capi.NOISE_SAMPLING, std0=0.1, std1=0.3, candidate_offset=100, nominal_candidate=102)
+    emu = quademu.rollout(pm, pt, home_state(quad), 0.0, MOCAP, N, H, P, 0, times, noise=ns, nominal=nominal)
+    want = pyoracle.noise_candidates(pm, ns, P, nominal, np.arange(100, 100 + N))
+    assert np.array_equal(emu["nodes"], want) and np.array_equal(emu["nodes"][2], nominal)
+
+
+def test_uncovered_situations_are_flagged_not_computed(quad):
+    """large noise: legs cross (a contact between two moving geoms) or a lane collects more contacts than it stages -- the candidate is
+    flagged for the wavefront-per-candidate kernel (failure carries kQFallback), never rolled out approximately; the others match"""
+    pm, pt = quad.packed_model(), quad.packed()
+    N, H, P = 12, 100, 3
+    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+    nodes = np.clip(np.random.default_rng(5).normal(0, 0.3, (N, P, 12)), -1, 1)
+    emu = quademu.rollout(pm, pt, home_state(quad), 0.0, MOCAP, N, H, P, 0, times, node_values=nodes)
+    flagged = emu["flags"] != 0
+    assert flagged.any() and (~flagged).any()
+    assert np.all((emu["failure"][flagged] & 0x40000000) != 0) and np.all(emu["failure"][~flagged] == 0)
+    ref = pyoracle.rollout_batch(pm, pt, home_state(quad), 0.0, MOCAP, N, H, P, 0, times, nodes, num_threads=4)
+    assert close(emu["total_return"][~flagged], ref["total_return"][~flagged], 1e-7)
+
+
+def test_other_modes_of_the_residual(quad):
+    """Walk, Scramble, Biped (hand stand) and Flip: the residual through the quad's dealt entries equals the oracle's"""
+    for mode in (1, 2, 3, 4):
+        t = load_task("QuadrupedFlat")
+        t.transition(0.0, mode=mode) if "mode" in t.transition.__code__.co_varnames else t.transition(0.0)
+        pm, pt = t.packed_model(), t.packed()
+        ph = pyoracle.Physics(pm)
+        st = home_state(t)
+        ph.set_state(st[:19], st[19:], 0.05, MOCAP)
+        ctrl = np.full(12, 0.1)
+        ph.set_ctrl(ctrl)
+        r = ph.forward_task(pt)
+        o = quademu.forward(pm, pt, st, 0.05, MOCAP, ctrl)
+        assert o["flags"] == 0 and close(o["residual"], r, 1e-12), mode
