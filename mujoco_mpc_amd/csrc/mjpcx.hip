@@ -356,6 +356,7 @@ struct mjpcx_ctx {
   // quad kernel (quad_kernel.h): four lanes per candidate; fp64 contexts of a model quad_build accepts
   bool quad_ok = false;       // MJPCX_NO_QUAD=1 keeps the wavefront-per-candidate kernels (A/B runs)
   bool quad_stamps = false;   // MJPCX_QUAD_STAMPS=1: phase cycle stamps of wavefront 0 (tuning aid; synchronises every rollout)
+  bool quad_no_fallback = false;  // MJPCX_QUAD_NO_FALLBACK=1: leave the handed-on candidates flagged (tuning: failure[] then carries reason and step)
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
   int quad_ids[7] = {0, 0, 0, 0, 0, 0, 0};  // residual_int[1..7] the quad model was built for (torso, head site, goal mocap, feet)
@@ -636,6 +637,7 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
     for (int k = 0; k < 13; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k]);
     std::fprintf(stderr, " | newton iterations %lld, line-search trials %lld\n", h[16], h[17]);
   }
+  if (c->quad_no_fallback) return hipSuccess;
   RolloutArgs<double> a2 = a;
   a2.noise.mode = -1;  // the quad kernel left every candidate's spline nodes in a.nodes
   e = launch_tree<TreeCfgA1, double>(c, wm, wt, a2, c->wh.dev_image, c->wh.blob_bytes, N, P, /*only_flagged=*/true);
@@ -896,6 +898,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
       c->quad_stats = getenv("MJPCX_QUAD_STATS") != nullptr;
       c->quad_stamps = getenv("MJPCX_QUAD_STAMPS") != nullptr;
+      c->quad_no_fallback = getenv("MJPCX_QUAD_NO_FALLBACK") != nullptr;
       if (precision == 64 && !getenv("MJPCX_NO_QUAD")) {
         // the quad kernel family (four lanes per candidate): models of the legged class quad_build accepts
         std::vector<unsigned char> hq, ht;

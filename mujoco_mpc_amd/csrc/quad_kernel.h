@@ -33,6 +33,13 @@ template <int K> __device__ __forceinline__ double qd_bcast(double v) { return m
 template <int D> __device__ __forceinline__ double qd_rot(double v) {
   return mjpcx::quad::qdpp<(((0 + D) & 3) | (((1 + D) & 3) << 2) | (((2 + D) & 3) << 4) | (((3 + D) & 3) << 6))>(v);
 }
+// lane (l xor p) of the quad, p in {0, 1, 2, 3} at run time (quad-uniform): the LDS crossbar (ds_bpermute), no LDS memory
+__device__ __forceinline__ double qd_partner(double v, int p) {
+  const int src = ((int)(threadIdx.x & 63) ^ p) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ int qd_or(int v) {
   v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
   v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
@@ -82,7 +89,7 @@ __device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int sl
   c.D0 = v[6];
   QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = v[7 + k];
   const int meta = (int)v[13];
-  c.depth = meta & 3; c.fid = meta >> 2;
+  c.depth = meta & 3; c.fid = (meta >> 2) & 7; c.rel = (meta >> 5) & 1; c.sgn = (meta & 64) ? 1 : -1; c.pd = (meta >> 7) & 3;
 }
 __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
   using namespace mjpcx::quad;
@@ -90,7 +97,7 @@ __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, c
   QUNROLL for (int k = 0; k < 3; k++) { v[k] = c.n[k]; v[3 + k] = c.off[k]; }
   v[6] = c.D0;
   QUNROLL for (int k = 0; k < 6; k++) v[7 + k] = c.jar[k];
-  v[13] = (double)(c.depth | (c.fid << 2));
+  v[13] = (double)(c.depth | (c.fid << 2) | (c.rel << 5) | (c.sgn > 0 ? 64 : 0) | (c.pd << 7));
   if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) p[f * 64] = v[f]; }
   else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) p[f] = v[f]; }
 }

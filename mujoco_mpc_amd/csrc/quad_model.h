@@ -100,6 +100,9 @@ struct QuadModel {
 struct QuadTables {
   QuadPair trunk[kQStatic][kQTrunkGeom];
   QuadPair leg[kQLegs][kQStatic][kQLegGeom];
+  // moving-geom pairs (self-collision): [own leg][own pair geom][other leg, kQLegs = the trunk][other pair geom]; `pad` = 1 if the own geom
+  // is geom1 of the pair in MuJoCo's order (lower geom type first, then lower index): the contact normal points from geom1 to geom2
+  QuadPair mm[kQLegs][kQPairGeom][kQLegs + 1][kQPairGeom];
   int npair;
 };
 
@@ -276,20 +279,8 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
   }
   // pair parameters (oracle/contact.inc contact_param; o_collision's type table)
   const double impratio = m->impratio > 1e-15 ? m->impratio : 1.0;
-  for (int s = 0; s < qm->nstatic; s++) {
-    const int g1 = qm->stat[s].model_id;
-    if (static_slot[g1] < 0) continue;
-    const int t1 = m->geom_type[g1];
-    for (int g2 = 0; g2 < m->ngeom; g2++) {
-      if (slot_leg[g2] == -2) continue;
-      QuadPair& p = slot_leg[g2] < 0 ? qt->trunk[s][slot_idx[g2]] : qt->leg[slot_leg[g2]][s][slot_idx[g2]];
-      const int t2 = m->geom_type[g2];
-      bool ok = (m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]);
-      if (t1 == MJPCX_GEOM_PLANE) ok &= t2 == MJPCX_GEOM_SPHERE || t2 == MJPCX_GEOM_CAPSULE || t2 == MJPCX_GEOM_BOX || t2 == MJPCX_GEOM_CYLINDER;
-      else if (t1 == MJPCX_GEOM_SPHERE || t1 == MJPCX_GEOM_BOX) ok &= t2 == MJPCX_GEOM_SPHERE;
-      else ok = false;
-      p.collide = ok;
-      if (!ok) continue;
+  // contact parameters of a geom pair (oracle/contact.inc contact_param + the solref / solimp digestion), "" or an error
+  auto pair_params = [&](int g1, int g2, QuadPair& p) -> std::string {
       const double margin = std::max(m->geom_margin[g1], m->geom_margin[g2]), gap = std::max(m->geom_gap[g1], m->geom_gap[g2]);
       p.margin = margin; p.includemargin = margin - gap;
       double fr[3], solref[2], solimp[5];
@@ -308,22 +299,39 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
         for (int k = 0; k < 2; k++) solref[k] = mix * m->geom_solref[2 * g1 + k] + (1 - mix) * m->geom_solref[2 * g2 + k];
         for (int k = 0; k < 5; k++) solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
       }
-      if (p.dim != 1 && p.dim != 3 && p.dim != 4 && p.dim != 6) return "unsupported condim";
+      if (p.dim != 1 && p.dim != 3 && p.dim != 4 && p.dim != 6) return std::string("unsupported condim");
       p.fric1 = std::max(fr[0], 1e-5); p.fric3 = std::max(fr[1], 1e-5); p.fric4 = std::max(fr[2], 1e-5);
       p.mu = p.fric1 / std::sqrt(impratio);
       solref_kb(m, solref, solimp, &p.k, &p.b);
       digest_solimp(p.imp, solimp);
       p.diag = m->body_invweight0[2 * m->geom_bodyid[g1]] + m->body_invweight0[2 * m->geom_bodyid[g2]];
-      if (!(p.margin < 0.009)) return "a contact margin of 9 mm or more (the collision pass rejects geoms 1 cm clear of a static geom)";
+      if (!(p.margin < 0.009)) return std::string("a contact margin of 9 mm or more (the collision pass rejects geoms 1 cm clear of a static geom)");
       const double fs[6] = {p.mu, p.dim >= 3 ? p.fric1 : 0.0, p.dim >= 4 ? p.fric3 : 0.0, p.dim >= 6 ? p.fric4 : 0.0, 1.0 / (p.mu * p.mu),
                             1.0 / (p.mu * p.mu * (1 + p.mu * p.mu))};
       p.fid = -1;
       for (int f = 0; f < qm->nfric; f++) if (std::memcmp(qm->fric[f], fs, sizeof fs) == 0) p.fid = f;
       if (p.fid < 0) {
-        if (qm->nfric == kQMaxFric) return "more distinct friction sets than the quad kernel stages";
+        if (qm->nfric == kQMaxFric) return std::string("more distinct friction sets than the quad kernel stages");
         std::memcpy(qm->fric[qm->nfric], fs, sizeof fs);
         p.fid = qm->nfric++;
       }
+      return std::string();
+  };
+  for (int s = 0; s < qm->nstatic; s++) {
+    const int g1 = qm->stat[s].model_id;
+    if (static_slot[g1] < 0) continue;
+    const int t1 = m->geom_type[g1];
+    for (int g2 = 0; g2 < m->ngeom; g2++) {
+      if (slot_leg[g2] == -2) continue;
+      QuadPair& p = slot_leg[g2] < 0 ? qt->trunk[s][slot_idx[g2]] : qt->leg[slot_leg[g2]][s][slot_idx[g2]];
+      const int t2 = m->geom_type[g2];
+      bool ok = (m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]);
+      if (t1 == MJPCX_GEOM_PLANE) ok &= t2 == MJPCX_GEOM_SPHERE || t2 == MJPCX_GEOM_CAPSULE || t2 == MJPCX_GEOM_BOX || t2 == MJPCX_GEOM_CYLINDER;
+      else if (t1 == MJPCX_GEOM_SPHERE || t1 == MJPCX_GEOM_BOX) ok &= t2 == MJPCX_GEOM_SPHERE;
+      else ok = false;
+      p.collide = ok;
+      if (!ok) continue;
+      { const std::string err = pair_params(g1, g2, p); if (!err.empty()) return err; }
     }
   }
   // moving-geom pairs (oracle/contact.inc bake_pairs): tested only. The kernel walks them as a cross product, so the set must be one.
@@ -364,6 +372,20 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
     if (npair != expect) return "self-collision pairs are not the cross product of the legs' pair geoms";
     qt->npair = npair;
     qm->pair_margin = pmargin;
+    auto pg_index = [&](int g) { const int l = slot_leg[g]; const int* sl = l < 0 ? qm->tpg_slot : qm->leg[l].pg_slot; const int n = l < 0 ? qm->ntpg : qm->leg[l].npg;
+                                 for (int i = 0; i < n; i++) if (sl[i] == slot_idx[g]) return i; return -1; };
+    for (auto& pr : plist) {
+      const int ta = m->geom_type[pr.first], tb = m->geom_type[pr.second];
+      const int g1 = ta > tb ? pr.second : pr.first, g2 = ta > tb ? pr.first : pr.second;  // MuJoCo's order: lower geom type first, then lower index
+      for (int side = 0; side < 2; side++) {
+        const int own = side == 0 ? g1 : g2, other = side == 0 ? g2 : g1;
+        if (slot_leg[own] < 0) continue;  // (the trunk has no lane of its own: the leg's lane handles a trunk-leg pair)
+        QuadPair& p = qt->mm[slot_leg[own]][pg_index(own)][slot_leg[other] < 0 ? kQLegs : slot_leg[other]][pg_index(other)];
+        const std::string err = pair_params(g1, g2, p);
+        if (!err.empty()) return err;
+        p.collide = 1; p.pad = own == g1;
+      }
+    }
   }
   qm->npair = qt->npair;
 

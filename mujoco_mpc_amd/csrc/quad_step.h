@@ -152,33 +152,70 @@ QD void qd_sum_n(double* v, int n) { for (int i = 0; i < n; i++) v[i] = qd_sum(v
 QD constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 
 // ---------------------------------------------------------------- arrowhead matrices
+// SUPER-LEGS. A contact between two legs does not involve the trunk (its motion cancels in the relative velocity), so it adds to the
+// Hessian the two legs' own blocks and ONE cross block between them: legs A < B paired by `pmode` (B = A xor pmode) form a 6-dof
+// super-leg whose cross block ab (rows: A's dofs, columns: B's) lives in A's lane. arrow_factor(a, leg, pmode) eliminates A first
+// (Y = Haa^-1 Hab replaces ab), hands B the Schur updates of its block and of its trunk coupling (24 numbers through qd_partner), and
+// carries on as for independent legs; arrow_solve mirrors it (3 numbers each way). pmode = 0: no pairing (M, the integrator's matrix).
+//
 // Symmetric positive-definite matrix of the legged tree: per lane the leg block (3 x 3, packed lower triangle l[tri]), the coupling
 // b (3 leg dofs x 6 trunk dofs); replicated in the four lanes the trunk block t (6 x 6, packed). arrow_factor turns it IN PLACE into
 // its factor: the leg block as unit-lower L D L' (l[1] = l10, l[3] = l20, l[4] = l21, reciprocal pivots in l[0], l[2], l[5]),
 // b := Z = Lblock^-1 B, t := the L D L' factor of the Schur complement S = T - sum_legs B' Z (unit-lower entries below the diagonal,
 // RECIPROCAL pivots on it).
-struct Arrow { double l[6], b[3][6], t[21]; };
+struct Arrow { double l[6], b[3][6], t[21]; double ab[3][3]; };
 
-QD void leg_solve(const Arrow& f, double* x) {  // x := Lblock^-1 x (f factored)
-  x[1] -= f.l[1] * x[0];
-  x[2] -= f.l[3] * x[0] + f.l[4] * x[1];
-  x[0] *= f.l[0]; x[1] *= f.l[2]; x[2] *= f.l[5];
-  x[1] -= f.l[4] * x[2];
-  x[0] -= f.l[1] * x[1] + f.l[3] * x[2];
+// unit-lower L D L' of a packed 3 x 3 block in place (l[1] = l10, l[3] = l20, l[4] = l21, reciprocal pivots in l[0], l[2], l[5])
+QD bool leg_ldl(double* l) {
+  bool ok = true;
+  const double d0 = l[0];
+  ok &= d0 > kQMinVal;
+  const double i0 = 1.0 / d0, l10 = l[1] * i0, l20 = l[3] * i0;
+  const double d1 = l[2] - l10 * l10 * d0;
+  ok &= d1 > kQMinVal;
+  const double i1 = 1.0 / d1, l21 = (l[4] - l20 * l10 * d0) * i1;
+  const double d2 = l[5] - l20 * l20 * d0 - l21 * l21 * d1;
+  ok &= d2 > kQMinVal;
+  l[0] = i0; l[1] = l10; l[2] = i1; l[3] = l20; l[4] = l21; l[5] = 1.0 / d2;
+  return ok;
+}
+QD void leg_solve_l(const double* l, double* x) {  // x := block^-1 x, block factored by leg_ldl
+  x[1] -= l[1] * x[0];
+  x[2] -= l[3] * x[0] + l[4] * x[1];
+  x[0] *= l[0]; x[1] *= l[2]; x[2] *= l[5];
+  x[1] -= l[4] * x[2];
+  x[0] -= l[1] * x[1] + l[3] * x[2];
 }
 // returns false (quad-uniform) if a pivot is not positive
-QD bool arrow_factor(Arrow& a) {
+QD bool arrow_factor(Arrow& a, int leg, int pmode) {
   bool ok = true;
-  const double d0 = a.l[0];
-  ok &= d0 > kQMinVal;
-  const double i0 = 1.0 / d0, l10 = a.l[1] * i0, l20 = a.l[3] * i0;
-  const double d1 = a.l[2] - l10 * l10 * d0;
-  ok &= d1 > kQMinVal;
-  const double i1 = 1.0 / d1, l21 = (a.l[4] - l20 * l10 * d0) * i1;
-  const double d2 = a.l[5] - l20 * l20 * d0 - l21 * l21 * d1;
-  ok &= d2 > kQMinVal;
-  const double i2 = 1.0 / d2;
-  a.l[0] = i0; a.l[1] = l10; a.l[2] = i1; a.l[3] = l20; a.l[4] = l21; a.l[5] = i2;
+  if (pmode != 0) {  // (quad-uniform)
+    // super-legs: the lower leg of each pair eliminates itself first; its partner receives the Schur updates
+    const bool isA = leg < (leg ^ pmode);
+    double lf[6];
+    QUNROLL for (int i = 0; i < 6; i++) lf[i] = a.l[i];
+    (void)leg_ldl(lf);  // (A's pivots are checked by the common pass below, which factors the unchanged block again)
+    double G[6], W[3][6];
+    {
+      double Y[3][3];  // Haa^-1 Hab, column by column
+      QUNROLL for (int c = 0; c < 3; c++) {
+        double col[3] = {a.ab[0][c], a.ab[1][c], a.ab[2][c]};
+        leg_solve_l(lf, col);
+        Y[0][c] = col[0]; Y[1][c] = col[1]; Y[2][c] = col[2];
+      }
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c <= r; c++) G[tri(r, c)] = a.ab[0][r] * Y[0][c] + a.ab[1][r] * Y[1][c] + a.ab[2][r] * Y[2][c];
+      QUNROLL for (int k = 0; k < 6; k++) {
+        double col[3] = {a.b[0][k], a.b[1][k], a.b[2][k]};
+        leg_solve_l(lf, col);
+        QUNROLL for (int r = 0; r < 3; r++) W[r][k] = a.ab[0][r] * col[0] + a.ab[1][r] * col[1] + a.ab[2][r] * col[2];
+      }
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) a.ab[r][c] = Y[r][c];
+    }
+    QUNROLL for (int i = 0; i < 6; i++) { const double g = qd_partner(G[i], pmode); if (!isA) a.l[i] -= g; }
+    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int k = 0; k < 6; k++) { const double w = qd_partner(W[r][k], pmode); if (!isA) a.b[r][k] -= w; }
+  }
+  ok &= leg_ldl(a.l);
+  const double i0 = a.l[0], l10 = a.l[1], i1 = a.l[2], l20 = a.l[3], l21 = a.l[4], i2 = a.l[5];
   // Y = L^-1 B in place (forward substitution only); the Schur complement needs Y' D^-1 Y
   QUNROLL for (int k = 0; k < 6; k++) { a.b[1][k] -= l10 * a.b[0][k]; a.b[2][k] -= l20 * a.b[0][k] + l21 * a.b[1][k]; }
   QUNROLL for (int r = 0; r < 6; r++)
@@ -198,7 +235,7 @@ QD bool arrow_factor(Arrow& a) {
     ok &= dj > kQMinVal;
     d[j] = dj;
     const double inv = 1.0 / dj;
-    for (int i = j + 1; i < 6; i++) {
+    QUNROLL for (int i = j + 1; i < 6; i++) {
       double v = a.t[tri(i, j)];
       QUNROLL for (int k = 0; k < j; k++) v -= a.t[tri(i, k)] * a.t[tri(j, k)] * d[k];
       a.t[tri(i, j)] = v * inv;
@@ -207,14 +244,27 @@ QD bool arrow_factor(Arrow& a) {
   }
   return qd_or(ok ? 0 : 1) == 0;
 }
-// x := A^-1 x  (xl: the lane's three leg entries, xt: the six trunk entries, replicated); f factored
-QD void arrow_solve(const Arrow& f, double* xl, double* xt) {
+// x := A^-1 x  (xl: the lane's three leg entries, xt: the six trunk entries, replicated); f factored with the same leg / pmode
+QD void arrow_solve(const Arrow& f, double* xl, double* xt, int leg, int pmode) {
+  const bool isA = pmode != 0 && leg < (leg ^ pmode);
+  double ya[3] = {0, 0, 0};
+  if (pmode != 0) {
+    // B's right-hand side loses Hba Haa^-1 g_A = Y' g_A
+    double v[3];
+    QUNROLL for (int c = 0; c < 3; c++) v[c] = f.ab[0][c] * xl[0] + f.ab[1][c] * xl[1] + f.ab[2][c] * xl[2];
+    QUNROLL for (int c = 0; c < 3; c++) { const double w = qd_partner(v[c], pmode); if (!isA) xl[c] -= w; }
+  }
   QUNROLL for (int k = 0; k < 6; k++) xt[k] -= qd_sum(f.b[0][k] * xl[0] + f.b[1][k] * xl[1] + f.b[2][k] * xl[2]);
   QUNROLL for (int i = 1; i < 6; i++) QUNROLL for (int k = 0; k < i; k++) xt[i] -= f.t[tri(i, k)] * xt[k];
   QUNROLL for (int i = 0; i < 6; i++) xt[i] *= f.t[tri(i, i)];
-  QUNROLL for (int i = 4; i >= 0; i--) for (int k = i + 1; k < 6; k++) xt[i] -= f.t[tri(k, i)] * xt[k];
-  leg_solve(f, xl);
+  QUNROLL for (int i = 4; i >= 0; i--) QUNROLL for (int k = i + 1; k < 6; k++) xt[i] -= f.t[tri(k, i)] * xt[k];
+  leg_solve_l(f.l, xl);
   QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) xl[j] -= f.b[j][k] * xt[k];
+  if (pmode != 0) {
+    // A: x_A -= Y x_B
+    QUNROLL for (int c = 0; c < 3; c++) ya[c] = qd_partner(xl[c], pmode);
+    if (isA) { QUNROLL for (int r = 0; r < 3; r++) xl[r] -= f.ab[r][0] * ya[0] + f.ab[r][1] * ya[1] + f.ab[r][2] * ya[2]; }
+  }
 }
 // y = A x; yt needs the quad sum of the coupling term
 QD void arrow_mul(const Arrow& a, const double* xl, const double* xt, double* yl, double* yt) {
@@ -255,6 +305,11 @@ struct QContact {
   double jar[6];  // [angular; linear]; holds -aref from the contact's creation until the solver's first pass adds J qacc_smooth
   int depth;      // leg dofs on the body's chain (0: trunk)
   int fid;        // friction set (QuadModel::fric): regularised mu, tangential / torsional / rolling friction (0: row absent)
+  // A contact between two MOVING geoms (self-collision): the trunk's motion cancels in the relative velocity, so its rows act on the
+  // own leg's dofs below the body (depth) and, for a leg-leg contact, on the partner leg's (pd > 0; pd = 0: the other geom is the
+  // trunk's). Both legs' lanes hold a copy of a leg-leg contact (bit-identical jar; each counts half its cost and applies its own
+  // side of the force). sgn = +1 if the own body carries geom2 (J = jac(body2) - jac(body1)).
+  int rel, sgn, pd;
 };
 constexpr int kQConRec = 14;  // doubles per stored contact (quad_kernel.h / the emulator provide the store: qcs_load, qcs_store, qcs_store_jar)
 
@@ -286,6 +341,25 @@ QD void point_vel(const QContact& c, const double Vp[4][6], double* out) {
   const double w2 = c.depth < 3 ? 1.0 : 0.0, w1 = c.depth < 2 ? 1.0 : 0.0, w0 = c.depth < 1 ? 1.0 : 0.0;
   double V[6];
   QUNROLL for (int k = 0; k < 6; k++) V[k] = Vp[3][k] - w2 * (Vp[3][k] - Vp[2][k]) - w1 * (Vp[2][k] - Vp[1][k]) - w0 * (Vp[1][k] - Vp[0][k]);
+  double w[3];
+  cr3(w, V, c.off);
+  QUNROLL for (int k = 0; k < 3; k++) { out[k] = V[k]; out[3 + k] = V[3 + k] + w[k]; }
+}
+// what a lane's pass over its rows needs of the PARTNER leg for self-collision contacts: the partner's chain velocities relative to
+// the trunk, dq[d - 1] = Vp[d] - Vp[0] of the partner's dof vector (exchanged once per pass through qd_partner)
+struct QRel { double dq[3][6]; };
+QD void rel_exchange(const double Vp[4][6], int pmode, QRel& q) {
+  QUNROLL for (int d = 0; d < 3; d++) QUNROLL for (int k = 0; k < 6; k++) q.dq[d][k] = qd_partner(Vp[d + 1][k] - Vp[0][k], pmode);
+}
+// the point-space relative velocity of a self-collision contact: sgn ((V_own_body - V_trunk) - (V_partner_body - V_trunk))
+QD void point_vel_rel(const QContact& c, const double Vp[4][6], const QRel& q, double* out) {
+  const double w2 = c.depth < 3 ? 1.0 : 0.0, w1 = c.depth < 2 ? 1.0 : 0.0;
+  const double u3 = c.pd == 3 ? 1.0 : 0.0, u2 = c.pd == 2 ? 1.0 : 0.0, u1 = c.pd == 1 ? 1.0 : 0.0, sg = c.sgn;
+  double V[6];
+  QUNROLL for (int k = 0; k < 6; k++) {
+    const double own = (Vp[3][k] - Vp[0][k]) - w2 * (Vp[3][k] - Vp[2][k]) - w1 * (Vp[2][k] - Vp[1][k]);  // (depth >= 1 for a moving geom of a leg)
+    V[k] = sg * (own - (u3 * q.dq[2][k] + u2 * q.dq[1][k] + u1 * q.dq[0][k]));
+  }
   double w[3];
   cr3(w, V, c.off);
   QUNROLL for (int k = 0; k < 3; k++) { out[k] = V[k]; out[3 + k] = V[3 + k] + w[k]; }
@@ -399,7 +473,7 @@ enum { kEvalKeep = 0, kEvalStep = 2 };
 // hessian_blocks).
 template <class CS>
 QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows& R, CS& cs, int ncon, int what, const double* xl, const double Vp[4][6], double alpha,
-                    double* jl, double* jt, double* X, int& nshallow) {
+                    double* jl, double* jt, double* X, int& nshallow, int pmode, bool have_rel) {
   double cost = 0;
   double Fown[6];
   QUNROLL for (int c = 0; c < 6; c++) Fown[c] = 0;
@@ -420,17 +494,25 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
     }
     jl[j] = f;
   }
+  QRel rq;
+  if (have_rel && what != kEvalKeep) rel_exchange(Vp, pmode, rq);  // (quad-uniform)
   for (int i = 0; i < ncon; i++) {
     QContact c;
     qcs_load(cs, i, c);
     if (what != kEvalKeep) {
       double pv[6];
-      point_vel(c, Vp, pv);
+      if (c.rel) point_vel_rel(c, Vp, rq, pv); else point_vel(c, Vp, pv);
       QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k];
       qcs_store_jar(cs, i, c);
     }
     double Fs[6] = {0, 0, 0, 0, 0, 0};
     int zone;
+    if (c.rel) {  // self-collision: own leg's dofs only, the own side of the force; a leg-leg contact is counted half here, half in its partner's lane
+      const double cc = contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
+      cost += c.pd > 0 ? 0.5 * cc : cc;
+      if (zone != 0) { QUNROLL for (int j = 0; j < 3; j++) if (j < c.depth) jl[j] += c.sgn * dot6(kin.cdof[j], Fs); }
+      continue;
+    }
     cost += contact_eval(c, m.fric[c.fid], Fs, X, zone);
     if (zone == 0) continue;
     QUNROLL for (int k = 0; k < 6; k++) Fown[k] += Fs[k];
@@ -447,7 +529,8 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
 // derivatives of the row penalties along the search direction at step alpha (quad sums)
 // (xl: the search direction's leg part, Vp: its chain_velocity; J search is recomputed per row: 9 flops per contact)
 template <class CS>
-QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, int ncon, double alpha, const double* xl, const double Vp[4][6], double& d1, double& d2) {
+QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, int ncon, double alpha, const double* xl, const double Vp[4][6], const QRel& rq,
+                  double& d1, double& d2) {
   double g = 0, h = 0;
   QUNROLL for (int j = 0; j < 3; j++) {
     if (L.floss[j] > 0) {
@@ -465,15 +548,45 @@ QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, 
     QContact c;
     qcs_load(cs, i, c);
     double jv[6];
-    point_vel(c, Vp, jv);
-    contact_line(c, m.fric[c.fid], jv, alpha, g, h);
+    if (c.rel) {
+      point_vel_rel(c, Vp, rq, jv);
+      double gr = 0, hr = 0;
+      contact_line(c, m.fric[c.fid], jv, alpha, gr, hr);
+      const double w = c.pd > 0 ? 0.5 : 1.0;
+      g += w * gr; h += w * hr;
+    } else {
+      point_vel(c, Vp, jv);
+      contact_line(c, m.fric[c.fid], jv, alpha, g, h);
+    }
   }
   d1 = qd_sum(g); d2 = qd_sum(h);
 }
 // H += J' (d2s) J of the contacts: the lane's leg block and coupling from its own contacts' blocks (X, from rows_eval), the trunk block
 // from the quad sum of X. Contacts whose body is not the last link were counted for dofs below their body: taken out again.
 template <class CS>
-QD void hessian_blocks(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H) {
+QD void hessian_blocks(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H, int leg, int pmode, bool have_rel) {
+  if (have_rel) {  // (quad-uniform) self-collision contacts: the own leg's block, and for the lower leg of a pair the cross block
+    double cq[3][6];  // the partner leg's dof axes
+    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) cq[j][k] = qd_partner(kin.cdof[j][k], pmode);
+    const bool isA = leg < (leg ^ pmode);
+    for (int i = 0; i < ncon; i++) {
+      QContact c;
+      qcs_load(cs, i, c);
+      if (!c.rel) continue;
+      double Fs[6] = {0, 0, 0, 0, 0, 0}, Xc[21];
+      QUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
+      int zone;
+      (void)contact_eval(c, m.fric[c.fid], Fs, Xc, zone);
+      if (zone == 0) continue;
+      QUNROLL for (int j = 0; j < 3; j++) {
+        if (j >= c.depth) continue;
+        double Y[6];
+        QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += Xc[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
+        QUNROLL for (int ii = 0; ii <= j; ii++) H.l[tri(j, ii)] += dot6(kin.cdof[ii], Y);
+        if (isA) { QUNROLL for (int ii = 0; ii < 3; ii++) if (ii < c.pd) H.ab[j][ii] -= dot6(cq[ii], Y); }
+      }
+    }
+  }
   QUNROLL for (int j = 0; j < 3; j++) {
     double Y[6];
     QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += X[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
@@ -484,7 +597,7 @@ QD void hessian_blocks(const QuadModel& m, const QKin& kin, CS& cs, int ncon, do
     for (int i = 0; i < ncon; i++) {
       QContact c;
       qcs_load(cs, i, c);
-      if (c.depth >= 3) continue;
+      if (c.depth >= 3 || c.rel) continue;
       double Fs[6] = {0, 0, 0, 0, 0, 0}, Xc[21];
       QUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
       int zone;
@@ -523,6 +636,7 @@ QD void load_arrow(const MS& ms, Arrow& M) {
   QUNROLL for (int i = 0; i < 6; i++) M.l[i] = qms_l(ms, i);
   QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) M.b[j][k] = qms_b(ms, j, k);
   QUNROLL for (int i = 0; i < 21; i++) M.t[i] = qms_t(ms, i);
+  QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) M.ab[r][c] = 0;
 }
 template <class MS>
 QD void arrow_mul_s(const MS& ms, const double* xl, const double* xt, double* yl, double* yt) {
@@ -544,7 +658,7 @@ QD void arrow_mul_s(const MS& ms, const double* xl, const double* xt, double* yl
 // Newton solver. (sl, st) = qacc_smooth, (wl, wt) = warm start, M in the store `ms`; leaves qacc in (al, at) and J' force in
 // (fc_l, fc_t). Returns the flag bits (quad-uniform).
 template <class CS, class MS, class QProfT>
-QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon,
+QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon, int leg, int pmode, bool have_rel,
                    const double* sl, const double* st, const double* wl, const double* wt, bool have_warm,
                    double* al, double* at, double* fc_l, double* fc_t, int& iters, QProfT& pf) {
   iters = 0;
@@ -557,7 +671,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
   {
     double Vp[4][6];
     chain_velocity(kin, al, at, Vp);
-    cost = rows_eval(m, L, kin, R, cs, ncon, kEvalStep, al, Vp, 1.0, fc_l, fc_t, X, nshallow);  // jar = J qacc_smooth - aref; the Gauss term is zero here
+    cost = rows_eval(m, L, kin, R, cs, ncon, kEvalStep, al, Vp, 1.0, fc_l, fc_t, X, nshallow, pmode, have_rel);  // jar = J qacc_smooth - aref; the Gauss term is zero here
     if (have_warm) {
       double dl[3], dt[6], Ml[3], Mt[6];
       QUNROLL for (int j = 0; j < 3; j++) dl[j] = wl[j] - sl[j];
@@ -567,14 +681,14 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       double jl[3], jt[6], Xw[21];
       int nsw;
       chain_velocity(kin, dl, dt, Vp);  // the rows move from qacc_smooth to the warm start along their difference
-      const double cw = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, 1.0, jl, jt, Xw, nsw);
+      const double cw = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, 1.0, jl, jt, Xw, nsw, pmode, have_rel);
       if (cw < cost) {
         cost = cw; nshallow = nsw;
         QUNROLL for (int j = 0; j < 3; j++) { al[j] = wl[j]; fc_l[j] = jl[j]; Mal[j] = Ml[j]; }
         QUNROLL for (int k = 0; k < 6; k++) { at[k] = wt[k]; fc_t[k] = jt[k]; Mat[k] = Mt[k]; }
         QUNROLL for (int e = 0; e < 21; e++) X[e] = Xw[e];
       } else {
-        (void)rows_eval(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, -1.0, fc_l, fc_t, X, nshallow);  // and back
+        (void)rows_eval(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, -1.0, fc_l, fc_t, X, nshallow, pmode, have_rel);  // and back
       }
     }
   }
@@ -597,12 +711,12 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
         if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.l[tri(j, j)] += L.floss_D[j]; }
         if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.l[tri(j, j)] += R.lm_D[j];
       }
-      hessian_blocks(m, kin, cs, ncon, X, nshallow, H);
+      hessian_blocks(m, kin, cs, ncon, X, nshallow, H, leg, pmode, have_rel);
       QPROF(pf, 9);
-      if (!arrow_factor(H)) return kFlagNotPD;
+      if (!arrow_factor(H, leg, have_rel ? pmode : 0)) return kFlagNotPD;
       QUNROLL for (int j = 0; j < 3; j++) hl[j] = -hl[j];  // search direction
       QUNROLL for (int k = 0; k < 6; k++) ht[k] = -ht[k];
-      arrow_solve(H, hl, ht);
+      arrow_solve(H, hl, ht, leg, have_rel ? pmode : 0);
     }
     QPROF(pf, 10);
     double q1, q2, snorm;
@@ -613,8 +727,10 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       // M (qacc - qacc_smooth) moves along M search: Mal += alpha Msl after the line search
       double Vs[4][6];
       chain_velocity(kin, hl, ht, Vs);
+      QRel rq;
+      if (have_rel) rel_exchange(Vs, pmode, rq);
       double lo = 0, hi = -1, alpha = 0, d1, d2;
-      rows_line(m, L, R, cs, ncon, 0.0, hl, Vs, d1, d2);
+      rows_line(m, L, R, cs, ncon, 0.0, hl, Vs, rq, d1, d2);
       d1 += q1; d2 += q2;
       const double d10 = fabs(d1);
       const double gtol = m.tolerance * kQLsTol * sqrt(snorm) / scale;
@@ -626,7 +742,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
         if (an == alpha) break;
         step2 = step1; step1 = fabs(an - alpha);
         alpha = an;
-        rows_line(m, L, R, cs, ncon, alpha, hl, Vs, d1, d2);
+        rows_line(m, L, R, cs, ncon, alpha, hl, Vs, rq, d1, d2);
         d1 += q1 + alpha * q2; d2 += q2;
         if (fabs(d1) < gtol) break;
         if (d1 < 0) lo = alpha; else hi = alpha;
@@ -641,7 +757,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       QUNROLL for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
       arrow_mul_s(ms, dl, dt, Mal, Mat);
       const double gauss = 0.5 * arrow_dot(dl, dt, Mal, Mat);
-      const double newcost = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, X, nshallow);
+      const double newcost = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, X, nshallow, pmode, have_rel);
       improvement = cost - newcost;
       cost = newcost;
     }
@@ -652,7 +768,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
 }
 
 template <class CS, class MS, class QProfT>
-QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon,
+QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmode, bool have_rel,
                          const double* sl_in, const double* st_in, const double* wl_in, const double* wt_in, bool have_warm,
                          double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf) {
   // (an out-of-line function on the device: its register allocation starts afresh, so the rollout's state is parked once per step instead
@@ -666,7 +782,7 @@ QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin
   QUNROLL for (int j = 0; j < 3; j++) { sl[j] = sl_in[j]; wl[j] = wl_in[j]; }
   QUNROLL for (int k = 0; k < 6; k++) { st[k] = st_in[k]; wt[k] = wt_in[k]; }
   int iters = 0;
-  const int rc = newton_body(m, L, kin, ms, R, cs, ncon, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
+  const int rc = newton_body(m, L, kin, ms, R, cs, ncon, leg, pmode, have_rel, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
   QUNROLL for (int j = 0; j < 3; j++) { al_out[j] = al[j]; fc_l_out[j] = fc_l[j]; }
   QUNROLL for (int k = 0; k < 6; k++) { at_out[k] = at[k]; fc_t_out[k] = fc_t[k]; }
   iters_out = iters;
@@ -677,11 +793,11 @@ QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin
 // a contact found: its record (mj_instantiateContact + mj_makeImpedance for its rows, in point space) goes to the lane's store
 template <class CS>
 QD void add_contact(const QuadPair& p, const double* com, const double* cvel, int depth, double dist, const double* pos, const double* normal,
-                    CS& cs, int& ncon, int& flags) {
+                    CS& cs, int& ncon, int& flags, int rel = 0, int sgn = 1, int pd = 0) {
   if (!(dist < p.margin)) return;
   if (ncon >= kQMaxCon) { flags |= kFlagOverflow; return; }
   QContact c;
-  c.depth = depth;
+  c.depth = depth; c.rel = rel; c.sgn = sgn; c.pd = pd;
   QUNROLL for (int k = 0; k < 3; k++) { c.n[k] = normal[k]; c.off[k] = pos[k] - com[k]; }
   c.fid = p.fid;
   const double x = dist - p.includemargin;
@@ -820,87 +936,120 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
   }
 }
 
-// nearest-point distance of two sphere | capsule geoms (oracle pair_collide), minus radii; parallel capsules: the minimum over
-// the end-point tests. Only the DISTANCE is needed: a pair within its margin hands the candidate on.
-QD double pair_distance(int t1, const double* p1, const double* a1, double r1, double h1, int t2, const double* p2, const double* a2, double r2, double h2) {
-  double c1[3], c2[3];
-  auto seg = [](const double* p, const double* a, double h, const double* c) {
-    const double x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
-    return x < -h ? -h : (x > h ? h : x);
-  };
-  auto dist2 = [&](const double* u, const double* v) { return sqrt((u[0] - v[0]) * (u[0] - v[0]) + (u[1] - v[1]) * (u[1] - v[1]) + (u[2] - v[2]) * (u[2] - v[2])) - r1 - r2; };
-  if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) return dist2(p1, p2);
-  if (t1 == MJPCX_GEOM_SPHERE) { const double x = seg(p2, a2, h2, p1); QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + x * a2[k]; return dist2(p1, c2); }
-  if (t2 == MJPCX_GEOM_SPHERE) { const double x = seg(p1, a1, h1, p2); QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + x * a1[k]; return dist2(c1, p2); }
-  const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-  const double mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
-  const double u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
-  const double v = a2[0] * dif[0] + a2[1] * dif[1] + a2[2] * dif[2];
-  const double det = 1.0 - mb * mb;
-  if (fabs(det) >= kQMinVal) {
-    double x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
-    if (x1 > h1) { x1 = h1; x2 = v - mb * x1; } else if (x1 < -h1) { x1 = -h1; x2 = v - mb * x1; }
-    if (x2 > h2) { x2 = h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
-    else if (x2 < -h2) { x2 = -h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
-    QUNROLL for (int k = 0; k < 3; k++) { c1[k] = p1[k] + x1 * a1[k]; c2[k] = p2[k] + x2 * a2[k]; }
-    return dist2(c1, c2);
-  }
-  double best = 1e300;
-  QUNROLL for (int e = 0; e < 4; e++) {
-    const double sgn = (e & 1) ? -1.0 : 1.0;
-    if (e < 2) { QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + sgn * h1 * a1[k]; const double x2 = seg(p2, a2, h2, c1); QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + x2 * a2[k]; }
-    else { QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + sgn * h2 * a2[k]; const double x1 = seg(p1, a1, h1, c2); QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k]; }
-    const double d = dist2(c1, c2);
-    best = d < best ? d : best;
-  }
-  return best;
-}
-
-// Self-collision test over the cross product of the legs' (and the trunk's) pair geoms: bounding spheres first, the exact nearest-point
-// distance for the pairs that pass. The other legs' centres / axes arrive through quad rotations; radii and half lengths are model
-// constants. Rotations by one and two legs cover the six leg pairs (opposite legs twice). Returns (lane-local) whether a pair is within
-// the margin.
-QD int pair_near(const QuadModel& m, int leg, const QPairGeoms& pg, const double* txpos, const double* txm) {
+// Self-collision (oracle pair_collide over the baked moving-geom pairs): the cross product of the own leg's pair geoms with the trunk's
+// and with every other leg's (their centres / axes / link velocities arrive through quad rotations). Bounding spheres first, the exact
+// nearest points for the pairs that pass; a pair within its margin becomes a RELATIVE contact (QContact::rel) in the own lane's list --
+// and, for a leg-leg pair, identically in the partner's lane, which walks the same pair from its side with the same arithmetic (the two
+// geoms are always taken in MuJoCo's order: geom1 first). pmask collects 1 << (own leg xor partner leg) of the leg-leg contacts.
+template <class CS>
+QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const QPairGeoms& pg, const double* txpos, const double* txm, const double* com,
+                      const double cvel[3][6], const double* cvelT, CS& cs, int& ncon, int& flags, int& pmask, int& nrel) {
   const QuadLeg& L = m.leg[leg];
   const double mg = m.pair_margin;
-  bool near = false, near_trunk = false;
-  auto test = [&](int t1, const double* c1, const double* a1, double r1, double h1, int t2, const double* c2, const double* a2, double r2, double h2, bool trunk) {
-    const double dx = c1[0] - c2[0], dy = c1[1] - c2[1], dz = c1[2] - c2[2];
-    const double reach = r1 + h1 + r2 + h2 + mg;
+  // one pair: own geom (index i of the leg's pair geoms) against (other leg o or kQLegs = trunk, index j)
+  auto one = [&](int i, int o, int j, const double* oc, const double* oa, int otype, double orad, double ohalf, const double* ovel, int odepth) {
+    const QuadGeom& g = L.geom[L.pg_slot[i]];
+    const double r0 = g.size[0], h0 = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
+    const double dx = pg.c[i][0] - oc[0], dy = pg.c[i][1] - oc[1], dz = pg.c[i][2] - oc[2];
+    const double reach = r0 + h0 + orad + ohalf + mg;
     if (dx * dx + dy * dy + dz * dz >= reach * reach) return;
-    if (pair_distance(t1, c1, a1, r1, h1, t2, c2, a2, r2, h2) < mg) { if (trunk) near_trunk = true; else near = true; }
+    const QuadPair& P = tab.mm[leg][i][o][j];
+    if (!P.collide) return;
+    const bool own_first = P.pad != 0;
+    // geom1 / geom2 in MuJoCo's order
+    const double* p1 = own_first ? pg.c[i] : oc; const double* p2 = own_first ? oc : pg.c[i];
+    const double* a1 = own_first ? pg.a[i] : oa; const double* a2 = own_first ? oa : pg.a[i];
+    const int t1 = own_first ? g.type : otype, t2 = own_first ? otype : g.type;
+    const double r1 = own_first ? r0 : orad, r2 = own_first ? orad : r0, h1 = own_first ? h0 : ohalf, h2 = own_first ? ohalf : h0;
+    const double* v1 = own_first ? cvel[g.link] : ovel; const double* v2 = own_first ? ovel : cvel[g.link];
+    double vrel[6];
+    QUNROLL for (int k = 0; k < 6; k++) vrel[k] = v2[k] - v1[k];  // J qvel of J = jac(body2) - jac(body1), about the centre of mass
+    const int sgn = own_first ? -1 : 1, depth = g.link + 1;
+    auto spheres = [&](const double* c1, const double* c2) {  // oracle sphere_vs_sphere -> add_contact; returns whether a contact was added
+      double n[3], len = 0, pos[3];
+      QUNROLL for (int k = 0; k < 3; k++) { n[k] = c2[k] - c1[k]; len += n[k] * n[k]; }
+      len = sqrt(len);
+      if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else { QUNROLL for (int k = 0; k < 3; k++) n[k] /= len; }
+      const double dist = len - r1 - r2;
+      if (!(dist < P.margin)) return false;
+      QUNROLL for (int k = 0; k < 3; k++) pos[k] = c1[k] + n[k] * (r1 + 0.5 * dist);
+      const int before = ncon;
+      add_contact(P, com, vrel, depth, dist, pos, n, cs, ncon, flags, 1, sgn, odepth);
+      if (ncon > before) { nrel++; if (o < kQLegs) pmask |= 1 << (leg ^ o); }
+      return true;
+    };
+    auto seg = [](const double* p, const double* a, double h, const double* c) {
+      const double x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
+      return x < -h ? -h : (x > h ? h : x);
+    };
+    double c1[3], c2[3];
+    if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) { (void)spheres(p1, p2); return; }
+    if (t1 == MJPCX_GEOM_SPHERE) {  // (sphere, capsule): spheres come first in MuJoCo's order
+      const double x = seg(p2, a2, h2, p1);
+      QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + x * a2[k];
+      (void)spheres(p1, c2);
+      return;
+    }
+    const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const double mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
+    const double u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
+    const double v = a2[0] * dif[0] + a2[1] * dif[1] + a2[2] * dif[2];
+    const double det = 1.0 - mb * mb;
+    if (fabs(det) >= kQMinVal) {
+      double x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
+      if (x1 > h1) { x1 = h1; x2 = v - mb * x1; } else if (x1 < -h1) { x1 = -h1; x2 = v - mb * x1; }
+      if (x2 > h2) { x2 = h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
+      else if (x2 < -h2) { x2 = -h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
+      QUNROLL for (int k = 0; k < 3; k++) { c1[k] = p1[k] + x1 * a1[k]; c2[k] = p2[k] + x2 * a2[k]; }
+      (void)spheres(c1, c2);
+    } else {  // parallel: the ends of capsule 1 against axis 2, then the ends of capsule 2 against axis 1, two contacts at most
+      int added = 0;
+      for (int e = 0; e < 4 && added < 2; e++) {
+        const double sg = (e & 1) ? -1.0 : 1.0;
+        if (e < 2) {
+          QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + sg * h1 * a1[k];
+          const double x2 = seg(p2, a2, h2, c1);
+          QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + x2 * a2[k];
+        } else {
+          QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + sg * h2 * a2[k];
+          const double x1 = seg(p1, a1, h1, c2);
+          QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k];
+        }
+        if (spheres(c1, c2)) added++;
+      }
+    }
   };
-  for (int i = 0; i < m.ntpg; i++) {
-    const QuadGeom& g = m.trunk_geom[m.tpg_slot[i]];
+  // the trunk's pair geoms
+  for (int j = 0; j < m.ntpg; j++) {
+    const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
     double c[3], a[3];
     mv3(c, txm, g.pos);
     QUNROLL for (int k = 0; k < 3; k++) { c[k] += txpos[k]; a[k] = txm[3 * k] * g.rot[2] + txm[3 * k + 1] * g.rot[5] + txm[3 * k + 2] * g.rot[8]; }
-    const double h1 = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
-    QUNROLL for (int j = 0; j < kQPairGeom; j++) {
-      if (j >= L.npg) continue;
-      const QuadGeom& g2 = L.geom[L.pg_slot[j]];
-      test(g.type, c, a, g.size[0], h1, g2.type, pg.c[j], pg.a[j], g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0, true);
-    }
+    QUNROLL for (int i = 0; i < kQPairGeom; i++)
+      if (i < L.npg) one(i, kQLegs, j, c, a, g.type, g.size[0], g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, cvelT, 0);
   }
-  QUNROLL for (int d = 1; d <= 2; d++) {
-    const QuadLeg& O = m.leg[(leg + d) & 3];
+  // the other three legs
+  QUNROLL for (int d = 1; d <= 3; d++) {
+    const int o = (leg + d) & 3;
+    const QuadLeg& O = m.leg[o];
+    double ov[3][6];
+    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) ov[j][k] = d == 1 ? qd_rot<1>(cvel[j][k]) : (d == 2 ? qd_rot<2>(cvel[j][k]) : qd_rot<3>(cvel[j][k]));
     QUNROLL for (int j = 0; j < kQPairGeom; j++) {
       double c2[3], a2[3];
       QUNROLL for (int k = 0; k < 3; k++) {
-        c2[k] = d == 1 ? qd_rot<1>(pg.c[j][k]) : qd_rot<2>(pg.c[j][k]);
-        a2[k] = d == 1 ? qd_rot<1>(pg.a[j][k]) : qd_rot<2>(pg.a[j][k]);
+        c2[k] = d == 1 ? qd_rot<1>(pg.c[j][k]) : (d == 2 ? qd_rot<2>(pg.c[j][k]) : qd_rot<3>(pg.c[j][k]));
+        a2[k] = d == 1 ? qd_rot<1>(pg.a[j][k]) : (d == 2 ? qd_rot<2>(pg.a[j][k]) : qd_rot<3>(pg.a[j][k]));
       }
       if (j >= O.npg) continue;
       const QuadGeom& g2 = O.geom[O.pg_slot[j]];
       const double h2 = g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0;
-      QUNROLL for (int i = 0; i < kQPairGeom; i++) {
-        if (i >= L.npg) continue;
-        const QuadGeom& g1 = L.geom[L.pg_slot[i]];
-        test(g1.type, pg.c[i], pg.a[i], g1.size[0], g1.type == MJPCX_GEOM_CAPSULE ? g1.size[1] : 0.0, g2.type, c2, a2, g2.size[0], h2, false);
-      }
+      const int lk = g2.link;
+      double v2[6];
+      QUNROLL for (int k = 0; k < 6; k++) v2[k] = lk == 0 ? ov[0][k] : (lk == 1 ? ov[1][k] : ov[2][k]);
+      QUNROLL for (int i = 0; i < kQPairGeom; i++)
+        if (i < L.npg) one(i, o, j, c2, a2, g2.type, g2.size[0], h2, v2, lk + 1);
     }
   }
-  return (near ? 1 : 0) | (near_trunk ? 2 : 0);
 }
 
 // ---------------------------------------------------------------- mj_forward (oracle o_forward) for the lane's share of one candidate
@@ -917,6 +1066,7 @@ struct QDyn {
   double sl[3], st[6];      // qacc_smooth
   double fs_l[3], fs_t[6];  // qfrc_smooth
   int ncon;
+  int pmode, have_rel;      // self-collision: which legs pair up (B = A xor pmode), whether the candidate has such contacts at all (quad-uniform)
 };
 // Position and velocity stages, collision, smooth dynamics, constraint rows: everything of mj_forward before the constraint solve.
 // ctrl: the leg's three controls. Returns flag bits (quad-uniform; 0: fine).
@@ -1064,9 +1214,16 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
       QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
       collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, com, cvelT, 0, gp, gR, cs, ncon, flags);
     }
-    D.ncon = ncon;
     QPROF(pf, 2);
-    { const int pn = pair_near(m, leg, pg, txpos, txm); if (pn & 1) flags |= kFlagPair; if (pn & 2) flags |= kFlagPairTrunk; }
+    int pmask = 0, nrel = 0;
+    pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, cs, ncon, flags, pmask, nrel);
+    D.ncon = ncon;
+    // the legs in contact with each other must pair up one way (A with A xor pmode): two legs touching the same third one, or legs touching
+    // across two different pairings, are handed on
+    pmask = qd_or(pmask);
+    D.have_rel = qd_or(nrel > 0 ? 1 : 0);
+    D.pmode = pmask == 0 ? 0 : (pmask == 2 ? 1 : (pmask == 4 ? 2 : (pmask == 8 ? 3 : -1)));
+    if (D.pmode < 0) { flags |= kFlagPair; D.pmode = 0; }
     QPROF(pf, 3);
   }
   // ================= spatial inertias about the centre of mass (o_compos); bias forces (o_rne), passive, actuation -> qfrc_smooth
@@ -1119,11 +1276,12 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
       mul_inert(buf, cinT, cd);
       QUNROLL for (int i = 0; i <= k; i++) M.t[tri(k, i)] = trunk_dot(kin, i, buf);
     }
+    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) M.ab[r][c] = 0;
     store_arrow(ms, M);
-    if (!arrow_factor(M)) flags |= kFlagNotPD;
+    if (!arrow_factor(M, leg, 0)) flags |= kFlagNotPD;
     QUNROLL for (int j = 0; j < 3; j++) D.sl[j] = D.fs_l[j];
     QUNROLL for (int k = 0; k < 6; k++) D.st[k] = D.fs_t[k];
-    arrow_solve(M, D.sl, D.st);
+    arrow_solve(M, D.sl, D.st, leg, 0);
   }
   // ================= constraint rows of the lane: friction loss, joint limits (o_make_constraint_full); contacts are in the store
   QRows& R = D.R;
@@ -1161,10 +1319,10 @@ QD void euler(const QuadModel& m, int leg, QState& S, const QDyn& D, const MS& m
     Arrow A;
     load_arrow(ms, A);
     QUNROLL for (int j = 0; j < 3; j++) A.l[tri(j, j)] += h * L.damping[j];
-    if (arrow_factor(A)) {
+    if (arrow_factor(A, leg, 0)) {
       QUNROLL for (int j = 0; j < 3; j++) ql[j] = D.fs_l[j] + fc_l[j];
       QUNROLL for (int k = 0; k < 6; k++) qt[k] = D.fs_t[k] + fc_t[k];
-      arrow_solve(A, ql, qt);
+      arrow_solve(A, ql, qt, leg, 0);
     }
   }
   QUNROLL for (int j = 0; j < 3; j++) { S.wl[j] = al[j]; S.lv[j] += h * ql[j]; S.lq[j] += h * S.lv[j]; }
@@ -1506,8 +1664,9 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
   const size_t ds = 37;
   double total = 0;
   double ctrl[3] = {0, 0, 0};
-  int flags = 0;
+  int flags = 0, flag_step = 0;
   for (int t = 0; t < H; t++) {
+    flag_step = t;
     const bool last = t == H - 1;
     bool bad = false;
     if (!last) {
@@ -1576,7 +1735,7 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     if (last) break;  // (the last step's mj_forward only feeds the sensor stage)
     double al[3], at[6], fc_l[3], fc_t[6];
     int iters;
-    flags = constraint_newton(m, L, D.kin, ms, D.R, cs, D.ncon, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+    flags = constraint_newton(m, L, D.kin, ms, D.R, cs, D.ncon, leg, D.pmode, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     if (flags) break;
     QPROF(pf, 6);
     QPROF_COUNT(pf, 16, iters);
@@ -1589,7 +1748,7 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
 #undef QNODE
   if (leg == 0) {
     a.total_return[cand] = flags ? 1.0e6 : total / (double)(H > 1 ? H : 1);
-    a.failure[cand] = flags ? (kQFallback | flags) : 0;
+    a.failure[cand] = flags ? (kQFallback | flags | (flag_step << 8)) : 0;  // (the step it was handed on at: diagnostics)
   }
   return flags;
 }

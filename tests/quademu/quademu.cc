@@ -52,6 +52,12 @@ template <int D> static inline double qd_rot(double x) {  // lane (l + D) % 4's 
   g_ctx->bar.wait(g_sense);
   return g_ctx->dbuf[s][(g_lane + D) & 3];
 }
+static inline double qd_partner(double x, int p) {  // lane (l xor p)'s value
+  const int s = g_phase++ & 1;
+  g_ctx->dbuf[s][g_lane] = x;
+  g_ctx->bar.wait(g_sense);
+  return g_ctx->dbuf[s][g_lane ^ p];
+}
 static inline int qd_or(int x) {
   const int s = g_phase++ & 1;
   g_ctx->ibuf[s][g_lane] = x;
@@ -160,7 +166,7 @@ int quademu_forward(const mjpcx_model* model, const mjpcx_task* task, const doub
     const double cost = residual_cost(b->qm, b->tk, b->sp, leg, S, f, r);
     double al[3], at[6], fc_l[3], fc_t[6];
     int iters;
-    fl = constraint_newton(b->qm, b->qm.leg[leg], D.kin, ms, D.R, cs, D.ncon, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
+    fl = constraint_newton(b->qm, b->qm.leg[leg], D.kin, ms, D.R, cs, D.ncon, leg, D.pmode, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
     flags_out[leg] = fl;
     if (fl) return;
     for (int j = 0; j < 3; j++) {
