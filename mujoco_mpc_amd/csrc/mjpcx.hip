@@ -356,6 +356,7 @@ struct mjpcx_ctx {
   // quad kernel (quad_kernel.h): four lanes per candidate; fp64 contexts of a model quad_build accepts
   bool quad_ok = false;       // MJPCX_NO_QUAD=1 keeps the wavefront-per-candidate kernels (A/B runs)
   bool quad_stamps = false;   // MJPCX_QUAD_STAMPS=1: phase cycle stamps of wavefront 0 (tuning aid; synchronises every rollout)
+  int quad_con_cap = 0;           // MJPCX_QUAD_CON_CAP=<n>: hand on candidates with more than n contacts in a lane (tests of the hand-on path)
   bool quad_no_fallback = false;  // MJPCX_QUAD_NO_FALLBACK=1: leave the handed-on candidates flagged (tuning: failure[] then carries reason and step)
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
@@ -616,26 +617,30 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
   q.nominal_candidate = a.noise.nominal_candidate; q.explore_count = a.noise.explore_count; q.std0 = a.noise.std0; q.std1 = a.noise.std1;
   q.param_variance = a.noise.param_variance;
   q.states = a.states; q.actions = a.actions; q.times = a.times; q.residual = a.residual; q.costs = a.costs; q.trace = a.trace;
-  q.total_return = a.total_return; q.failure = a.failure;
+  q.total_return = a.total_return; q.failure = a.failure; q.con_cap = c->quad_con_cap;
   const quad::QBlob bo{wt.off_time, wt.off_mocap, wt.off_weight, wt.off_normp, wt.off_normq, wt.off_param, wt.off_risk, wt.off_rreal, wt.off_rint};
   hipError_t e;
   if ((e = hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream)) != hipSuccess) return e;  // (how many candidates are handed on, by reason: mjpcx_quad_stats)
   if (c->quad_stamps) {
-    if ((e = hipMemsetAsync(c->d_qstamps.p, 0, 256, c->stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c->d_qstamps.p, 0, 512, c->stream)) != hipSuccess) return e;
     q.stamps = (long long*)c->d_qstamps.p;
   }
   if ((e = quad::launch_rollout_quad(c->d_qmodel.p, c->d_qtab.p, wt.blob, bo, q, (int*)c->d_qstats.p,
                                      c->stream)) != hipSuccess) return e;
   if (c->timing && c->cur_main) { if ((e = hipEventRecord(c->cur_main, c->stream)) != hipSuccess) return e; c->cur_main = nullptr; }
   if (c->quad_stamps) {
-    long long h[32];
+    long long h[64];
     (void)hipStreamSynchronize(c->stream);
-    (void)hipMemcpy(h, c->d_qstamps.p, 256, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, c->d_qstamps.p, 512, hipMemcpyDeviceToHost);
     static const char* nm[13] = {"policy", "kin..rne", "collision", "pairs", "factor+rows", "residual+record", "newton", "euler", "n:grad", "n:hessian", "n:factor+solve",
                                  "n:linesearch", "n:update+eval"};
     std::fprintf(stderr, "rollout_quad_kernel cycles of wavefront 0 (H = %d):", a.H);
     for (int k = 0; k < 13; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k]);
     std::fprintf(stderr, " | newton iterations %lld, line-search trials %lld\n", h[16], h[17]);
+    std::fprintf(stderr, "  newton: entry %lld, first pass %lld, warm start %lld; line search: entry %lld, coefficients %lld, trials %lld\n", h[13], h[14], h[15], h[40], h[41], h[42]);
+    std::fprintf(stderr, "  steps at which some lane of the wavefront holds > 0 1 2 3 4 6 8 12 contacts: %lld %lld %lld %lld %lld %lld %lld %lld; contacts per lane-step %.2f; "
+                 "Newton iterations per candidate-step %.2f (the wavefront runs the slowest's: %.2f)\n", h[18], h[19], h[20], h[21], h[22], h[23], h[24], h[25],
+                 (double)h[26] / (64.0 * a.H), (double)h[36] / (64.0 * a.H), (double)h[37] / a.H);
   }
   if (c->quad_no_fallback) return hipSuccess;
   RolloutArgs<double> a2 = a;
@@ -899,13 +904,14 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       c->quad_stats = getenv("MJPCX_QUAD_STATS") != nullptr;
       c->quad_stamps = getenv("MJPCX_QUAD_STAMPS") != nullptr;
       c->quad_no_fallback = getenv("MJPCX_QUAD_NO_FALLBACK") != nullptr;
+      if (const char* e = getenv("MJPCX_QUAD_CON_CAP")) c->quad_con_cap = std::atoi(e);
       if (precision == 64 && !getenv("MJPCX_NO_QUAD")) {
         // the quad kernel family (four lanes per candidate): models of the legged class quad_build accepts
         std::vector<unsigned char> hq, ht;
         c->quad_why = quad::build_images(m, t, hq, ht);
         if (c->quad_why.empty()) {
           if (c->d_qmodel.reserve(hq.size()) != hipSuccess || c->d_qtab.reserve(ht.size()) != hipSuccess || c->d_qstats.reserve(32) != hipSuccess ||
-              c->d_qstamps.reserve(256) != hipSuccess ||
+              c->d_qstamps.reserve(512) != hipSuccess ||
               hipMemcpy(c->d_qmodel.p, hq.data(), hq.size(), hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(c->d_qtab.p, ht.data(), ht.size(), hipMemcpyHostToDevice) != hipSuccess) {
             mjpcx_destroy(c);

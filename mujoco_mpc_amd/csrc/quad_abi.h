@@ -21,7 +21,8 @@ struct QArgs {
   const double* param_variance;
   double *states, *actions, *times, *residual, *costs, *trace, *total_return;  // [candidate][step][field]
   int* failure;
-  long long* stamps;  // nullptr, or 32 counters: phase cycles of wavefront 0 (tuning aid, MJPCX_QUAD_STAMPS=1)
+  long long* stamps;  // nullptr, or 64 counters: phase cycles of wavefront 0 (tuning aid, MJPCX_QUAD_STAMPS=1)
+  int con_cap;        // a lane that collects more contacts than this hands its candidate on (0: kQMaxCon, the store's capacity; MJPCX_QUAD_CON_CAP lowers it, for tests of the hand-on)
 };
 
 // offsets into the per-plan blob (WaveTaskT: wave_model.h)

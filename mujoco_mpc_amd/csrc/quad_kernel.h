@@ -40,6 +40,8 @@ __device__ __forceinline__ double qd_partner(double v, int p) {
   const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// true in every lane of the wavefront if pred holds in any (the four-lane quads of a wavefront share its instruction stream)
+__device__ __forceinline__ bool qw_any(bool pred) { return __ballot(pred) != 0; }
 __device__ __forceinline__ int qd_or(int v) {
   v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
   v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
@@ -70,6 +72,11 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
 // phase cycle stamps of wavefront 0 (pf.buf != nullptr only there): s_memtime deltas accumulated per phase
 #define QPROF(pf, idx) do { if ((pf).buf) { const long long now_ = __builtin_readcyclecounter(); (pf).buf[idx] += now_ - (pf).last; (pf).last = now_; } } while (0)
 #define QPROF_COUNT(pf, idx, n) do { if ((pf).buf) (pf).buf[idx] += (n); } while (0)
+// buf[idx + k] += 1 if any lane of the wavefront has v > bound_k (bounds 0 1 2 3 4 6 8 12), buf[idx + 8] += the sum of v over the lanes, buf[idx + 9] += the largest
+#define QPROF_WAVE_HIST(pf, idx, v) do { if ((pf).buf) { const int b_[8] = {0, 1, 2, 3, 4, 6, 8, 12}; \
+    for (int k_ = 0; k_ < 8; k_++) if (__ballot((v) > b_[k_])) (pf).buf[(idx) + k_] += 1; \
+    int s_ = (v), m_ = (v); for (int o_ = 32; o_ > 0; o_ >>= 1) { s_ += __shfl_xor(s_, o_); const int t_ = __shfl_xor(m_, o_); m_ = t_ > m_ ? t_ : m_; } \
+    (pf).buf[(idx) + 8] += s_; (pf).buf[(idx) + 9] += m_; } } while (0)
 
 // every fixed-trip loop over a small array is unrolled: a loop the compiler keeps rolled indexes its array at run time, and a private array
 // indexed at run time lives in scratch
@@ -79,7 +86,7 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
 #include "quad_step.h"
 #undef QD
 
-// record layout: n 0-2, off 3-5, D0 6, jar 7-12, (depth, friction set) 13
+// record layout: n 0-2, off 3-5, D0 6, jar 7-12, (depth, friction set, self-collision fields) 13
 __device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int slot, mjpcx::quad::QContact& c) {
   using namespace mjpcx::quad;
   double v[kQConRec];
@@ -89,7 +96,7 @@ __device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int sl
   c.D0 = v[6];
   QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = v[7 + k];
   const int meta = (int)v[13];
-  c.depth = meta & 3; c.fid = (meta >> 2) & 7; c.rel = (meta >> 5) & 1; c.sgn = (meta & 64) ? 1 : -1; c.pd = (meta >> 7) & 3;
+  c.depth = meta & 3; c.fid = (meta >> 2) & 7; c.rel = (meta >> 5) & 1; c.sgn = (meta & 64) ? 1 : -1; c.pd = (meta >> 7) & 3; c.px = (meta >> 9) & 3;
 }
 __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
   using namespace mjpcx::quad;
@@ -97,7 +104,7 @@ __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, c
   QUNROLL for (int k = 0; k < 3; k++) { v[k] = c.n[k]; v[3 + k] = c.off[k]; }
   v[6] = c.D0;
   QUNROLL for (int k = 0; k < 6; k++) v[7 + k] = c.jar[k];
-  v[13] = (double)(c.depth | (c.fid << 2) | (c.rel << 5) | (c.sgn > 0 ? 64 : 0) | (c.pd << 7));
+  v[13] = (double)(c.depth | (c.fid << 2) | (c.rel << 5) | (c.sgn > 0 ? 64 : 0) | (c.pd << 7) | (c.px << 9));
   if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) p[f * 64] = v[f]; }
   else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) p[f] = v[f]; }
 }

@@ -32,7 +32,7 @@ constexpr int kQPairGeom = 6;    // sphere | capsule geoms per leg in moving-geo
 constexpr int kQTrunkPairGeom = 2;
 constexpr int kQMaxFric = 8;     // distinct friction sets (mu, tangential, torsional, rolling) over the contact pairs
 constexpr int kQMaxKey = 4, kQMaxTrace = 2, kQMaxTerm = 16, kQMaxRay = 4;
-constexpr int kQMaxCon = 10;     // contacts per lane and step; more -> the candidate is handed to the wavefront-per-candidate kernel
+constexpr int kQMaxCon = 24;     // contacts per lane and step; more -> the candidate is handed to the wavefront-per-candidate kernel
 
 // contact parameters of a (static geom, moving geom) pair: mj_contactParam with solref / solimp pre-digested
 // (oracle/contact.inc contact_param, solref_kb, impedance's clipping)

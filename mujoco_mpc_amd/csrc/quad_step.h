@@ -28,6 +28,7 @@
 #ifndef QPROF
 #define QPROF(pf, idx)
 #define QPROF_COUNT(pf, idx, n)
+#define QPROF_WAVE_HIST(pf, idx, v)
 #endif
 #ifndef QUNROLL
 #define QUNROLL
@@ -310,6 +311,7 @@ struct QContact {
   // trunk's). Both legs' lanes hold a copy of a leg-leg contact (bit-identical jar; each counts half its cost and applies its own
   // side of the force). sgn = +1 if the own body carries geom2 (J = jac(body2) - jac(body1)).
   int rel, sgn, pd;
+  int px;  // leg-leg contact: own leg index xor the partner's (1..3); 0 otherwise
 };
 constexpr int kQConRec = 14;  // doubles per stored contact (quad_kernel.h / the emulator provide the store: qcs_load, qcs_store, qcs_store_jar)
 
@@ -348,6 +350,14 @@ QD void point_vel(const QContact& c, const double Vp[4][6], double* out) {
 // what a lane's pass over its rows needs of the PARTNER leg for self-collision contacts: the partner's chain velocities relative to
 // the trunk, dq[d - 1] = Vp[d] - Vp[0] of the partner's dof vector (exchanged once per pass through qd_partner)
 struct QRel { double dq[3][6]; };
+// A lane's pass over its contacts runs once per xor value x present in pmask (bits 1..3), exchanging with the partner A xor x each time
+// and taking the leg-leg contacts of that partner; everything else belongs to the first pass, which always runs. next_x: the smallest
+// value above `after`, 4 when there is none.
+QD int next_x(int pmask, int after) {
+  const int mk = pmask & ~((2 << after) - 1) & 14;
+  return mk ? __builtin_ctz(mk) : 4;
+}
+QD bool in_pass(const QContact& c, int pass, int x) { return (c.rel && c.px != 0) ? c.px == x : pass == 0; }
 QD void rel_exchange(const double Vp[4][6], int pmode, QRel& q) {
   QUNROLL for (int d = 0; d < 3; d++) QUNROLL for (int k = 0; k < 6; k++) q.dq[d][k] = qd_partner(Vp[d + 1][k] - Vp[0][k], pmode);
 }
@@ -456,6 +466,43 @@ QD void contact_line(const QContact& c, const double* fr, const double* jv, doub
   h += Dm * (dNT * dNT + NT * d2NT);
 }
 
+// The same along a fixed search direction, for the first kQLineSlots contacts of a lane: alpha enters a contact's penalty only through
+// jn = jn0 + alpha vn and the quadratic T^2 = A + 2 B alpha + C alpha^2 (B = UV at 0, C = VV, which does not depend on alpha), so a
+// trial costs a dozen flops per contact instead of a pass over its record. D0 carries the half weight of a leg-leg contact.
+constexpr int kQLineSlots = 4;
+#ifndef QGENERAL_FROM
+#define QGENERAL_FROM 2  // (tests build the emulator with 1: single pairs through the dense elimination as well)
+#endif
+constexpr int kQGeneralFrom = QGENERAL_FROM;
+struct QLine { double jn0, vn, A, B, C, D0, mu, Dq, Dm; };
+QD void line_empty(QLine& q) { q.jn0 = 1; q.vn = 0; q.A = 0; q.B = 0; q.C = 0; q.D0 = 0; q.mu = 1; q.Dq = 0; q.Dm = 0; }  // (top zone at every alpha)
+QD void line_coeffs(const QContact& c, const double* fr, const double* jv, double w, QLine& q) {
+  const double* n = c.n;
+  const double jn = dot3(n, c.jar + 3), an = dot3(n, c.jar), vn = dot3(n, jv + 3), wn = dot3(n, jv);
+  double tl[3], ar[3];
+  QUNROLL for (int k = 0; k < 3; k++) { tl[k] = c.jar[3 + k] - jn * n[k]; ar[k] = c.jar[k] - an * n[k]; }
+  const double f1s = fr[1] * fr[1], f3s = fr[2] * fr[2], f4s = fr[3] * fr[3];
+  q.jn0 = jn; q.vn = vn;
+  q.A = f1s * dot3(tl, tl) + f3s * an * an + f4s * dot3(ar, ar);
+  q.B = f1s * dot3(tl, jv + 3) + f3s * an * wn + f4s * dot3(ar, jv);
+  q.C = f1s * (dot3(jv + 3, jv + 3) - vn * vn) + f3s * wn * wn + f4s * (dot3(jv, jv) - wn * wn);
+  q.D0 = w * c.D0; q.mu = fr[0]; q.Dq = q.D0 * fr[4]; q.Dm = q.D0 * fr[5];
+}
+// (no branches: the slots of a lane are independent chains the scheduler can interleave -- with one wavefront per SIMD nothing else hides
+// the latency of dependent fp64 instructions -- and the three zones differ by a handful of flops)
+QD void line_eval(const QLine& q, double alpha, double& g, double& h) {
+  const double mu = q.mu, jn = q.jn0 + alpha * q.vn, T2 = q.A + alpha * (2 * q.B + alpha * q.C);
+  const bool pos = T2 > 0;
+  const double T = pos ? sqrt(T2) : 0.0, iT = pos ? 1.0 / T : 0.0, N = mu * jn;
+  const bool top = N >= mu * T || (!pos && N >= 0), bottom = mu * N + T <= 0 || (!pos && N < 0);
+  const double UV = q.B + alpha * q.C;
+  const double gb = q.D0 * jn * q.vn + q.Dq * UV, hb = q.D0 * q.vn * q.vn + q.Dq * q.C;
+  const double NT = N - mu * T, dNT = mu * q.vn - mu * UV * iT, d2NT = -mu * (q.C * iT - UV * UV * (iT * iT * iT));
+  const double gm = q.Dm * NT * dNT, hm = q.Dm * (dNT * dNT + NT * d2NT);
+  g += top ? 0.0 : (bottom ? gb : gm);
+  h += top ? 0.0 : (bottom ? hb : hm);
+}
+
 // ---------------------------------------------------------------- constraint solve (oracle o_constraint_newton)
 struct QRows {
   // friction loss (one row per leg dof with frictionloss > 0) and the active joint limit of each joint (side 0: none); the jar entries
@@ -471,9 +518,9 @@ enum { kEvalKeep = 0, kEvalStep = 2 };
 // leg dofs) / jt (trunk dofs, replicated), and in X the sum of the lane's contacts' Hessian blocks (packed 6 x 6; NOT yet quad-summed).
 // nshallow counts the lane's contacts in a penalty zone whose body is not the last link (their blocks need the correction of
 // hessian_blocks).
-template <class CS>
+template <bool MULTI, class CS>
 QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows& R, CS& cs, int ncon, int what, const double* xl, const double Vp[4][6], double alpha,
-                    double* jl, double* jt, double* X, int& nshallow, int pmode, bool have_rel) {
+                    double* jl, double* jt, double* X, int& nshallow, int pmask) {
   double cost = 0;
   double Fown[6];
   QUNROLL for (int c = 0; c < 6; c++) Fown[c] = 0;
@@ -495,74 +542,168 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
     jl[j] = f;
   }
   QRel rq;
-  if (have_rel && what != kEvalKeep) rel_exchange(Vp, pmode, rq);  // (quad-uniform)
-  for (int i = 0; i < ncon; i++) {
-    QContact c;
-    qcs_load(cs, i, c);
-    if (what != kEvalKeep) {
-      double pv[6];
-      if (c.rel) point_vel_rel(c, Vp, rq, pv); else point_vel(c, Vp, pv);
-      QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k];
-      qcs_store_jar(cs, i, c);
+  int x = next_x(pmask, 0);
+  for (int pass = 0; pass == 0 || (MULTI && x < 4); pass++) {  // (quad-uniform; one pass unless MULTI)
+    if (x < 4 && what != kEvalKeep) rel_exchange(Vp, x, rq);
+    for (int i = 0; i < ncon; i++) {
+      QContact c;
+      qcs_load(cs, i, c);
+      if (MULTI && !in_pass(c, pass, x)) continue;
+      if (what != kEvalKeep) {
+        double pv[6];
+        if (c.rel) point_vel_rel(c, Vp, rq, pv); else point_vel(c, Vp, pv);
+        QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k];
+        qcs_store_jar(cs, i, c);
+      }
+      double Fs[6] = {0, 0, 0, 0, 0, 0};
+      int zone;
+      if (c.rel) {  // self-collision: own leg's dofs only, the own side of the force; a leg-leg contact is counted half here, half in its partner's lane
+        const double cc = contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
+        cost += c.pd > 0 ? 0.5 * cc : cc;
+        if (zone != 0) { QUNROLL for (int j = 0; j < 3; j++) if (j < c.depth) jl[j] += c.sgn * dot6(kin.cdof[j], Fs); }
+        continue;
+      }
+      cost += contact_eval(c, m.fric[c.fid], Fs, X, zone);
+      if (zone == 0) continue;
+      QUNROLL for (int k = 0; k < 6; k++) Fown[k] += Fs[k];
+      if (c.depth < 3) {  // rare: a contact on the trunk (this lane's share), the hip or the thigh link does not act on the dofs below it
+        nshallow++;
+        QUNROLL for (int j = 0; j < 3; j++) if (j >= c.depth) jl[j] -= dot6(kin.cdof[j], Fs);
+      }
     }
-    double Fs[6] = {0, 0, 0, 0, 0, 0};
-    int zone;
-    if (c.rel) {  // self-collision: own leg's dofs only, the own side of the force; a leg-leg contact is counted half here, half in its partner's lane
-      const double cc = contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
-      cost += c.pd > 0 ? 0.5 * cc : cc;
-      if (zone != 0) { QUNROLL for (int j = 0; j < 3; j++) if (j < c.depth) jl[j] += c.sgn * dot6(kin.cdof[j], Fs); }
-      continue;
-    }
-    cost += contact_eval(c, m.fric[c.fid], Fs, X, zone);
-    if (zone == 0) continue;
-    QUNROLL for (int k = 0; k < 6; k++) Fown[k] += Fs[k];
-    if (c.depth < 3) {  // rare: a contact on the trunk (this lane's share), the hip or the thigh link does not act on the dofs below it
-      nshallow++;
-      QUNROLL for (int j = 0; j < 3; j++) if (j >= c.depth) jl[j] -= dot6(kin.cdof[j], Fs);
-    }
+    if (MULTI) x = next_x(pmask, x);
   }
   QUNROLL for (int j = 0; j < 3; j++) jl[j] += dot6(kin.cdof[j], Fown);
   qd_sum_n(Fown, 6);
   QUNROLL for (int k = 0; k < 6; k++) jt[k] = trunk_dot(kin, k, Fown);
   return qd_sum(cost);
 }
+// jar += alpha J x and nothing else (the way back from a rejected warm start)
+template <bool MULTI, class CS>
+QD void rows_step_only(const QuadLeg& L, QRows& R, CS& cs, int ncon, const double* xl, const double Vp[4][6], double alpha, int pmask) {
+  QUNROLL for (int j = 0; j < 3; j++) { R.fl_jar[j] += alpha * xl[j]; R.lm_jar[j] += alpha * (-R.lm_side[j] * xl[j]); }
+  QRel rq;
+  int x = next_x(pmask, 0);
+  for (int pass = 0; pass == 0 || (MULTI && x < 4); pass++) {
+    if (x < 4) rel_exchange(Vp, x, rq);
+    for (int i = 0; i < ncon; i++) {
+      QContact c;
+      qcs_load(cs, i, c);
+      if (MULTI && !in_pass(c, pass, x)) continue;
+      double pv[6];
+      if (c.rel) point_vel_rel(c, Vp, rq, pv); else point_vel(c, Vp, pv);
+      QUNROLL for (int k = 0; k < 6; k++) c.jar[k] += alpha * pv[k];
+      qcs_store_jar(cs, i, c);
+    }
+    if (MULTI) x = next_x(pmask, x);
+  }
+}
 // derivatives of the row penalties along the search direction at step alpha (quad sums)
 // (xl: the search direction's leg part, Vp: its chain_velocity; J search is recomputed per row: 9 flops per contact)
-template <class CS>
-QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, int ncon, double alpha, const double* xl, const double Vp[4][6], const QRel& rq,
-                  double& d1, double& d2) {
+template <bool MULTI, class CS>
+QD void rows_line_prepare(const QuadModel& m, CS& cs, int ncon, const double Vp[4][6], int pmask, QRel& rq, QLine* ql) {
+  QUNROLL for (int i = 0; i < kQLineSlots; i++) line_empty(ql[i]);
+  int x = next_x(pmask, 0);
+  for (int pass = 0; pass == 0 || (MULTI && x < 4); pass++) {
+    QRel rx;
+    if (x < 4) rel_exchange(Vp, x, rx);
+    if (pass == 0) rq = rx;  // (kept for the contacts beyond the slots: rows_line)
+    QUNROLL for (int i = 0; i < kQLineSlots; i++) {
+      if (i >= ncon) continue;
+      QContact c;
+      qcs_load(cs, i, c);
+      if (MULTI && !in_pass(c, pass, x)) continue;
+      double jv[6];
+      if (c.rel) point_vel_rel(c, Vp, rx, jv); else point_vel(c, Vp, jv);
+      line_coeffs(c, m.fric[c.fid], jv, c.rel && c.pd > 0 ? 0.5 : 1.0, ql[i]);
+    }
+    if (MULTI) x = next_x(pmask, x);
+  }
+}
+template <bool MULTI, class CS>
+QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, int ncon, double alpha, const double* xl, const double Vp[4][6], int pmask,
+                  bool beyond_slots, const QRel& rq, const QLine* ql, double& d1, double& d2) {
   double g = 0, h = 0;
   QUNROLL for (int j = 0; j < 3; j++) {
-    if (L.floss[j] > 0) {
-      const double jv = xl[j], x = R.fl_jar[j] + alpha * jv, fl = L.floss[j], Rr = L.floss_R[j];
-      if (x <= -Rr * fl) g += -fl * jv;
-      else if (x >= Rr * fl) g += fl * jv;
-      else { g += L.floss_D[j] * x * jv; h += L.floss_D[j] * jv * jv; }
+    {
+      const double jv = xl[j], x = R.fl_jar[j] + alpha * jv, fl = L.floss[j], Rr = L.floss_R[j], D = L.floss_D[j];
+      const bool on = fl > 0, low = x <= -Rr * fl, high = x >= Rr * fl;
+      const double gq = low ? -fl * jv : (high ? fl * jv : D * x * jv), hq = (low || high) ? 0.0 : D * jv * jv;
+      g += on ? gq : 0.0; h += on ? hq : 0.0;
     }
-    if (R.lm_side[j] != 0) {
+    {
       const double jv = -R.lm_side[j] * xl[j], x = R.lm_jar[j] + alpha * jv;
-      if (x < 0) { g += R.lm_D[j] * x * jv; h += R.lm_D[j] * jv * jv; }
+      const bool on = R.lm_side[j] != 0 && x < 0;
+      g += on ? R.lm_D[j] * x * jv : 0.0; h += on ? R.lm_D[j] * jv * jv : 0.0;
     }
   }
-  for (int i = 0; i < ncon; i++) {
-    QContact c;
-    qcs_load(cs, i, c);
-    double jv[6];
-    if (c.rel) {
-      point_vel_rel(c, Vp, rq, jv);
-      double gr = 0, hr = 0;
-      contact_line(c, m.fric[c.fid], jv, alpha, gr, hr);
-      const double w = c.pd > 0 ? 0.5 : 1.0;
-      g += w * gr; h += w * hr;
-    } else {
-      point_vel(c, Vp, jv);
-      contact_line(c, m.fric[c.fid], jv, alpha, g, h);
+  QUNROLL for (int i = 0; i < kQLineSlots; i++) line_eval(ql[i], alpha, g, h);
+  if (beyond_slots) {  // (quad-uniform: a lane of the quad holds more contacts than slots -- from the records; rq is the first pass's exchange)
+    int x = next_x(pmask, 0);
+    for (int pass = 0; pass == 0 || (MULTI && x < 4); pass++) {
+      QRel rx;
+      if (pass > 0) rel_exchange(Vp, x, rx); else rx = rq;
+      for (int i = kQLineSlots; i < ncon; i++) {
+        QContact c;
+        qcs_load(cs, i, c);
+        if (MULTI && !in_pass(c, pass, x)) continue;
+        double jv[6];
+        if (c.rel) {
+          point_vel_rel(c, Vp, rx, jv);
+          double gr = 0, hr = 0;
+          contact_line(c, m.fric[c.fid], jv, alpha, gr, hr);
+          const double w = c.pd > 0 ? 0.5 : 1.0;
+          g += w * gr; h += w * hr;
+        } else {
+          point_vel(c, Vp, jv);
+          contact_line(c, m.fric[c.fid], jv, alpha, g, h);
+        }
+      }
+      if (MULTI) x = next_x(pmask, x);
     }
   }
   d1 = qd_sum(g); d2 = qd_sum(h);
 }
+// The exact line search of one Newton iteration (oracle constraint_newton's inner loop: Newton on the derivative, bracketed, with the
+// rtsafe safeguard). Out of line on the device, like the solver itself: the loop's working set (the contacts' coefficients, the diagonal
+// rows) then has the register file to itself instead of competing with everything the iteration keeps alive around it.
+template <bool MULTI, class CS, class QProfT>
+QNOINLINE double line_search(const QuadModel& m, const QuadLeg& L, const QRows& R_in, CS& cs_in, int ncon, const double* hl_in, const double (*Vs)[6], int pmask,
+                             double q1, double q2, double gtol, QProfT& pf) {
+  const QRows R = R_in;
+  CS cs = cs_in;
+  const double hl[3] = {hl_in[0], hl_in[1], hl_in[2]};
+  QLine ql[kQLineSlots];
+  QRel rq;
+  QPROF(pf, 40);
+  rows_line_prepare<MULTI>(m, cs, ncon, Vs, pmask, rq, ql);
+  const bool beyond = qd_or(ncon > kQLineSlots ? 1 : 0) != 0;
+  QPROF(pf, 41);
+  double lo = 0, hi = -1, alpha = 0, d1, d2;
+  rows_line<MULTI>(m, L, R, cs, ncon, 0.0, hl, Vs, pmask, beyond, rq, ql, d1, d2);
+  d1 += q1; d2 += q2;
+  const double d10 = fabs(d1);
+  double step1 = 1e300, step2 = 1e300;  // the last step and the one before (rtsafe safeguard, oracle/contact.inc)
+  for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
+    double an = alpha - d1 / d2;
+    if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
+    else if (hi >= 0 && fabs(an - alpha) > 0.5 * step2) an = 0.5 * (lo + hi);
+    if (an == alpha) break;
+    step2 = step1; step1 = fabs(an - alpha);
+    alpha = an;
+    rows_line<MULTI>(m, L, R, cs, ncon, alpha, hl, Vs, pmask, beyond, rq, ql, d1, d2);
+    d1 += q1 + alpha * q2; d2 += q2;
+    if (fabs(d1) < gtol) break;
+    if (d1 < 0) lo = alpha; else hi = alpha;
+    QPROF_COUNT(pf, 17, 1);
+  }
+  QPROF(pf, 42);
+  return alpha;
+}
 // H += J' (d2s) J of the contacts: the lane's leg block and coupling from its own contacts' blocks (X, from rows_eval), the trunk block
 // from the quad sum of X. Contacts whose body is not the last link were counted for dofs below their body: taken out again.
+template <class CS>
+QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H);
 template <class CS>
 QD void hessian_blocks(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H, int leg, int pmode, bool have_rel) {
   if (have_rel) {  // (quad-uniform) self-collision contacts: the own leg's block, and for the lower leg of a pair the cross block
@@ -587,6 +728,10 @@ QD void hessian_blocks(const QuadModel& m, const QKin& kin, CS& cs, int ncon, do
       }
     }
   }
+  hessian_common(m, kin, cs, ncon, X, nshallow, H);
+}
+template <class CS>
+QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H) {
   QUNROLL for (int j = 0; j < 3; j++) {
     double Y[6];
     QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += X[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
@@ -623,6 +768,108 @@ QD void hessian_blocks(const QuadModel& m, const QKin& kin, CS& cs, int ncon, do
   }
 }
 
+// ---------------------------------------------------------------- self-collision, the general case: a leg in contact with two others
+// The leg blocks no longer decouple into pairs: dense block elimination of the four leg blocks in leg order (0, 1, 2, 3) with fill, then
+// the trunk as for independent legs. Lane A holds, per xor value x, the block between A and A xor x if A xor x > A (rows: A's dofs,
+// columns: the other leg's) and, once A is eliminated, Y = Haa^-1 of it. A few candidates in ten thousand come here, so everything is
+// exchanged by broadcast and computed redundantly in the four lanes; the pair case above is this elimination restricted to one block.
+struct ArrowG { Arrow a; double x[3][3][3]; };
+QD double bcast_k(double v, int k) { return k == 0 ? qd_bcast<0>(v) : (k == 1 ? qd_bcast<1>(v) : (k == 2 ? qd_bcast<2>(v) : qd_bcast<3>(v))); }
+QD void pick_block(const double B[3][3][3], int idx, double out[3][3]) {
+  QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) out[r][c] = idx == 0 ? B[0][r][c] : (idx == 1 ? B[1][r][c] : B[2][r][c]);
+}
+template <class CS>
+QD void hessian_rel_general(const QuadModel& m, const QKin& kin, CS& cs, int ncon, ArrowG& H, int leg, int pmask) {
+  int x = next_x(pmask, 0);
+  for (int pass = 0; pass == 0 || x < 4; pass++) {
+    double cq[3][6];  // the partner leg's dof axes
+    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) cq[j][k] = qd_partner(kin.cdof[j][k], x & 3);
+    const bool upper = x < 4 && (leg ^ x) > leg;
+    for (int i = 0; i < ncon; i++) {
+      QContact c;
+      qcs_load(cs, i, c);
+      if (!c.rel || !in_pass(c, pass, x)) continue;
+      double Fs[6] = {0, 0, 0, 0, 0, 0}, Xc[21];
+      QUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
+      int zone;
+      (void)contact_eval(c, m.fric[c.fid], Fs, Xc, zone);
+      if (zone == 0) continue;
+      QUNROLL for (int j = 0; j < 3; j++) {
+        if (j >= c.depth) continue;
+        double Y[6];
+        QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += Xc[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
+        QUNROLL for (int ii = 0; ii <= j; ii++) H.a.l[tri(j, ii)] += dot6(kin.cdof[ii], Y);
+        if (upper && c.pd > 0) {
+          QUNROLL for (int ii = 0; ii < 3; ii++) {
+            if (ii >= c.pd) continue;
+            const double v = dot6(cq[ii], Y);
+            QUNROLL for (int xx = 0; xx < 3; xx++) if (xx == x - 1) H.x[xx][j][ii] -= v;
+          }
+        }
+      }
+    }
+    x = next_x(pmask, x);
+  }
+}
+// returns false (quad-uniform) if a pivot is not positive
+QD bool arrow_factor_general(ArrowG& g, int leg) {
+  QUNROLL for (int k = 0; k < 3; k++) {  // eliminate leg k: its lane's blocks to everybody, the arithmetic in every lane
+    double lk[6], bk[3][6], xk[3][3][3];
+    QUNROLL for (int i = 0; i < 6; i++) lk[i] = bcast_k(g.a.l[i], k);
+    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 6; c++) bk[r][c] = bcast_k(g.a.b[r][c], k);
+    QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) xk[x][r][c] = bcast_k(g.x[x][r][c], k);
+    (void)leg_ldl(lk);  // (the pivots are checked by the common pass, which factors the block again)
+    double Y[3][3][3], Z[3][6];
+    QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int c = 0; c < 3; c++) {
+      double col[3] = {xk[x][0][c], xk[x][1][c], xk[x][2][c]};
+      leg_solve_l(lk, col);
+      Y[x][0][c] = col[0]; Y[x][1][c] = col[1]; Y[x][2][c] = col[2];
+    }
+    QUNROLL for (int c = 0; c < 6; c++) {
+      double col[3] = {bk[0][c], bk[1][c], bk[2][c]};
+      leg_solve_l(lk, col);
+      Z[0][c] = col[0]; Z[1][c] = col[1]; Z[2][c] = col[2];
+    }
+    if (leg == k) {
+      QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) g.x[x][r][c] = Y[x][r][c];
+    } else if (leg > k) {
+      double Hkm[3][3], Ym[3][3];  // leg k's block to this leg (rows: k's dofs) and Hkk^-1 of it
+      pick_block(xk, (leg ^ k) - 1, Hkm);
+      pick_block(Y, (leg ^ k) - 1, Ym);
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c <= r; c++) g.a.l[tri(r, c)] -= Hkm[0][r] * Ym[0][c] + Hkm[1][r] * Ym[1][c] + Hkm[2][r] * Ym[2][c];
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 6; c++) g.a.b[r][c] -= Hkm[0][r] * Z[0][c] + Hkm[1][r] * Z[1][c] + Hkm[2][r] * Z[2][c];
+      QUNROLL for (int xp = 1; xp <= 3; xp++) {  // this leg's blocks to the legs above it: fill from k's blocks to both
+        const int p = leg ^ xp;
+        if (p <= leg) continue;
+        double Yp[3][3];
+        pick_block(Y, (k ^ p) - 1, Yp);
+        QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) g.x[xp - 1][r][c] -= Hkm[0][r] * Yp[0][c] + Hkm[1][r] * Yp[1][c] + Hkm[2][r] * Yp[2][c];
+      }
+    }
+  }
+  return arrow_factor(g.a, leg, 0);
+}
+QD void arrow_solve_general(const ArrowG& g, double* xl, double* xt, int leg) {
+  QUNROLL for (int k = 0; k < 3; k++) {  // forward: x_o -= Y_ko' x_k
+    double vb[3][3];  // per xor value: Y' x_k of leg k
+    QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int c = 0; c < 3; c++)
+      vb[x][c] = bcast_k(g.x[x][0][c] * xl[0] + g.x[x][1][c] * xl[1] + g.x[x][2][c] * xl[2], k);
+    if (leg > k) {
+      const int xo = (leg ^ k) - 1;
+      QUNROLL for (int c = 0; c < 3; c++) xl[c] -= xo == 0 ? vb[0][c] : (xo == 1 ? vb[1][c] : vb[2][c]);
+    }
+  }
+  arrow_solve(g.a, xl, xt, leg, 0);
+  QUNROLL for (int k = 2; k >= 0; k--) {  // backward: x_k -= Y_ko x_o over the legs o above k (final by now)
+    QUNROLL for (int x = 1; x <= 3; x++) {
+      const int o = k ^ x;
+      if (o <= k) continue;
+      const double xo[3] = {bcast_k(xl[0], o), bcast_k(xl[1], o), bcast_k(xl[2], o)};
+      if (leg == k) { QUNROLL for (int r = 0; r < 3; r++) xl[r] -= g.x[x - 1][r][0] * xo[0] + g.x[x - 1][r][1] * xo[1] + g.x[x - 1][r][2] * xo[2]; }
+    }
+  }
+}
+
 // M lives in the includer's store while the solver runs (LDS on the device: the leg block and the coupling per lane, the trunk block
 // once per quad): element accessors qms_l / qms_b / qms_t, setters qms_set_*.
 template <class MS>
@@ -655,23 +902,55 @@ QD void arrow_mul_s(const MS& ms, const double* xl, const double* xt, double* yl
   }
 }
 
+// search direction -H^-1 gradient in the general case of self-collision (out of line: rare, and it needs room for three cross blocks)
+template <class CS, class MS>
+QD bool newton_direction_general(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, const QRows& R_in, CS& cs_in, int ncon,
+                                        const double* X_in, int nshallow, int leg, int pmask, double* hl_io, double* ht_io) {
+  const QKin kin = kin_in;
+  const MS ms = ms_in;
+  const QRows R = R_in;
+  CS cs = cs_in;
+  double X[21], hl[3], ht[6];
+  QUNROLL for (int e = 0; e < 21; e++) X[e] = X_in[e];
+  QUNROLL for (int j = 0; j < 3; j++) hl[j] = -hl_io[j];
+  QUNROLL for (int k = 0; k < 6; k++) ht[k] = -ht_io[k];
+  ArrowG H;
+  load_arrow(ms, H.a);
+  QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) H.x[x][r][c] = 0;
+  QUNROLL for (int j = 0; j < 3; j++) {
+    if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.a.l[tri(j, j)] += L.floss_D[j]; }
+    if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.a.l[tri(j, j)] += R.lm_D[j];
+  }
+  hessian_rel_general(m, kin, cs, ncon, H, leg, pmask);
+  hessian_common(m, kin, cs, ncon, X, nshallow, H.a);
+  if (!arrow_factor_general(H, leg)) return false;
+  arrow_solve_general(H, hl, ht, leg);
+  QUNROLL for (int j = 0; j < 3; j++) hl_io[j] = hl[j];
+  QUNROLL for (int k = 0; k < 6; k++) ht_io[k] = ht[k];
+  return true;
+}
+
 // Newton solver. (sl, st) = qacc_smooth, (wl, wt) = warm start, M in the store `ms`; leaves qacc in (al, at) and J' force in
 // (fc_l, fc_t). Returns the flag bits (quad-uniform).
-template <class CS, class MS, class QProfT>
-QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon, int leg, int pmode, bool have_rel,
+template <bool GENERAL, class CS, class MS, class QProfT>
+QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon, int leg, int pmask, bool have_rel,
                    const double* sl, const double* st, const double* wl, const double* wt, bool have_warm,
                    double* al, double* at, double* fc_l, double* fc_t, int& iters, QProfT& pf) {
   iters = 0;
+  // !GENERAL: one pair pattern (or none), the super-leg factorisation; GENERAL: the dense elimination of the leg blocks
+  const int pmode = GENERAL ? 0 : (next_x(pmask, 0) & 3);
   double X[21];
   int nshallow;
   QUNROLL for (int j = 0; j < 3; j++) al[j] = sl[j];
   QUNROLL for (int k = 0; k < 6; k++) at[k] = st[k];
   double Mal[3] = {0, 0, 0}, Mat[6] = {0, 0, 0, 0, 0, 0};  // M (qacc - qacc_smooth), carried through the iterations
   double cost;
+  QPROF(pf, 13);
   {
     double Vp[4][6];
     chain_velocity(kin, al, at, Vp);
-    cost = rows_eval(m, L, kin, R, cs, ncon, kEvalStep, al, Vp, 1.0, fc_l, fc_t, X, nshallow, pmode, have_rel);  // jar = J qacc_smooth - aref; the Gauss term is zero here
+    cost = rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, al, Vp, 1.0, fc_l, fc_t, X, nshallow, pmask);  // jar = J qacc_smooth - aref; the Gauss term is zero here
+    QPROF(pf, 14);
     if (have_warm) {
       double dl[3], dt[6], Ml[3], Mt[6];
       QUNROLL for (int j = 0; j < 3; j++) dl[j] = wl[j] - sl[j];
@@ -681,17 +960,18 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       double jl[3], jt[6], Xw[21];
       int nsw;
       chain_velocity(kin, dl, dt, Vp);  // the rows move from qacc_smooth to the warm start along their difference
-      const double cw = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, 1.0, jl, jt, Xw, nsw, pmode, have_rel);
+      const double cw = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, 1.0, jl, jt, Xw, nsw, pmask);
       if (cw < cost) {
         cost = cw; nshallow = nsw;
         QUNROLL for (int j = 0; j < 3; j++) { al[j] = wl[j]; fc_l[j] = jl[j]; Mal[j] = Ml[j]; }
         QUNROLL for (int k = 0; k < 6; k++) { at[k] = wt[k]; fc_t[k] = jt[k]; Mat[k] = Mt[k]; }
         QUNROLL for (int e = 0; e < 21; e++) X[e] = Xw[e];
       } else {
-        (void)rows_eval(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, -1.0, fc_l, fc_t, X, nshallow, pmode, have_rel);  // and back
+        rows_step_only<GENERAL>(L, R, cs, ncon, dl, Vp, -1.0, pmask);  // and back: the first pass's cost, forces and Hessian blocks are still held
       }
     }
   }
+  QPROF(pf, 15);
   const double scale = 1.0 / (m.meaninertia * 18.0);
   double improvement = 0;
   for (int iter = 0; iter < m.iterations; iter++) {
@@ -703,7 +983,9 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
     if (gnorm == 0) break;
     if (iter > 0 && (scale * improvement < m.tolerance || scale * gnorm < m.tolerance)) break;
     QPROF(pf, 8);
-    {
+    if constexpr (GENERAL) {
+      if (!newton_direction_general(m, L, kin, ms, R, cs, ncon, X, nshallow, leg, pmask, hl, ht)) return kFlagNotPD;
+    } else {
       // H = M + J' (d2s) J: diagonal rows, then the contacts through their 6 x 6 spatial blocks; factored in place
       Arrow H;
       load_arrow(ms, H);
@@ -713,10 +995,10 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       }
       hessian_blocks(m, kin, cs, ncon, X, nshallow, H, leg, pmode, have_rel);
       QPROF(pf, 9);
-      if (!arrow_factor(H, leg, have_rel ? pmode : 0)) return kFlagNotPD;
+      if (!arrow_factor(H, leg, pmode)) return kFlagNotPD;
       QUNROLL for (int j = 0; j < 3; j++) hl[j] = -hl[j];  // search direction
       QUNROLL for (int k = 0; k < 6; k++) ht[k] = -ht[k];
-      arrow_solve(H, hl, ht, leg, have_rel ? pmode : 0);
+      arrow_solve(H, hl, ht, leg, pmode);
     }
     QPROF(pf, 10);
     double q1, q2, snorm;
@@ -727,27 +1009,8 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       // M (qacc - qacc_smooth) moves along M search: Mal += alpha Msl after the line search
       double Vs[4][6];
       chain_velocity(kin, hl, ht, Vs);
-      QRel rq;
-      if (have_rel) rel_exchange(Vs, pmode, rq);
-      double lo = 0, hi = -1, alpha = 0, d1, d2;
-      rows_line(m, L, R, cs, ncon, 0.0, hl, Vs, rq, d1, d2);
-      d1 += q1; d2 += q2;
-      const double d10 = fabs(d1);
       const double gtol = m.tolerance * kQLsTol * sqrt(snorm) / scale;
-      double step1 = 1e300, step2 = 1e300;  // the last step and the one before (rtsafe safeguard, oracle/contact.inc)
-      for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
-        double an = alpha - d1 / d2;
-        if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
-        else if (hi >= 0 && fabs(an - alpha) > 0.5 * step2) an = 0.5 * (lo + hi);
-        if (an == alpha) break;
-        step2 = step1; step1 = fabs(an - alpha);
-        alpha = an;
-        rows_line(m, L, R, cs, ncon, alpha, hl, Vs, rq, d1, d2);
-        d1 += q1 + alpha * q2; d2 += q2;
-        if (fabs(d1) < gtol) break;
-        if (d1 < 0) lo = alpha; else hi = alpha;
-        QPROF_COUNT(pf, 17, 1);
-      }
+      const double alpha = line_search<GENERAL>(m, L, R, cs, ncon, hl, Vs, pmask, q1, q2, gtol, pf);
       QPROF(pf, 11);
       QUNROLL for (int j = 0; j < 3; j++) al[j] += alpha * hl[j];
       QUNROLL for (int k = 0; k < 6; k++) at[k] += alpha * ht[k];
@@ -757,7 +1020,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       QUNROLL for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
       arrow_mul_s(ms, dl, dt, Mal, Mat);
       const double gauss = 0.5 * arrow_dot(dl, dt, Mal, Mat);
-      const double newcost = gauss + rows_eval(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, X, nshallow, pmode, have_rel);
+      const double newcost = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, X, nshallow, pmask);
       improvement = cost - newcost;
       cost = newcost;
     }
@@ -767,8 +1030,8 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
   return 0;
 }
 
-template <class CS, class MS, class QProfT>
-QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmode, bool have_rel,
+template <bool GENERAL, class CS, class MS, class QProfT>
+QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmask, bool have_rel,
                          const double* sl_in, const double* st_in, const double* wl_in, const double* wt_in, bool have_warm,
                          double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf) {
   // (an out-of-line function on the device: its register allocation starts afresh, so the rollout's state is parked once per step instead
@@ -782,7 +1045,7 @@ QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin
   QUNROLL for (int j = 0; j < 3; j++) { sl[j] = sl_in[j]; wl[j] = wl_in[j]; }
   QUNROLL for (int k = 0; k < 6; k++) { st[k] = st_in[k]; wt[k] = wt_in[k]; }
   int iters = 0;
-  const int rc = newton_body(m, L, kin, ms, R, cs, ncon, leg, pmode, have_rel, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
+  const int rc = newton_body<GENERAL>(m, L, kin, ms, R, cs, ncon, leg, pmask, have_rel, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
   QUNROLL for (int j = 0; j < 3; j++) { al_out[j] = al[j]; fc_l_out[j] = fc_l[j]; }
   QUNROLL for (int k = 0; k < 6; k++) { at_out[k] = at[k]; fc_t_out[k] = fc_t[k]; }
   iters_out = iters;
@@ -793,11 +1056,11 @@ QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin
 // a contact found: its record (mj_instantiateContact + mj_makeImpedance for its rows, in point space) goes to the lane's store
 template <class CS>
 QD void add_contact(const QuadPair& p, const double* com, const double* cvel, int depth, double dist, const double* pos, const double* normal,
-                    CS& cs, int& ncon, int& flags, int rel = 0, int sgn = 1, int pd = 0) {
+                    CS& cs, int& ncon, int& flags, int rel = 0, int sgn = 1, int pd = 0, int px = 0) {
   if (!(dist < p.margin)) return;
   if (ncon >= kQMaxCon) { flags |= kFlagOverflow; return; }
   QContact c;
-  c.depth = depth; c.rel = rel; c.sgn = sgn; c.pd = pd;
+  c.depth = depth; c.rel = rel; c.sgn = sgn; c.pd = pd; c.px = px;
   QUNROLL for (int k = 0; k < 3; k++) { c.n[k] = normal[k]; c.off[k] = pos[k] - com[k]; }
   c.fid = p.fid;
   const double x = dist - p.includemargin;
@@ -950,20 +1213,25 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
   auto one = [&](int i, int o, int j, const double* oc, const double* oa, int otype, double orad, double ohalf, const double* ovel, int odepth) {
     const QuadGeom& g = L.geom[L.pg_slot[i]];
     const double r0 = g.size[0], h0 = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
-    const double dx = pg.c[i][0] - oc[0], dy = pg.c[i][1] - oc[1], dz = pg.c[i][2] - oc[2];
-    const double reach = r0 + h0 + orad + ohalf + mg;
-    if (dx * dx + dy * dy + dz * dz >= reach * reach) return;
+    double ci[3], ai[3];  // the own geom, picked from the register arrays (i is a run-time index here)
+    QUNROLL for (int k = 0; k < 3; k++) {
+      double vc = pg.c[0][k], va = pg.a[0][k];
+      QUNROLL for (int q = 1; q < kQPairGeom; q++) { vc = i == q ? pg.c[q][k] : vc; va = i == q ? pg.a[q][k] : va; }
+      ci[k] = vc; ai[k] = va;
+    }
     const QuadPair& P = tab.mm[leg][i][o][j];
     if (!P.collide) return;
     const bool own_first = P.pad != 0;
     // geom1 / geom2 in MuJoCo's order
-    const double* p1 = own_first ? pg.c[i] : oc; const double* p2 = own_first ? oc : pg.c[i];
-    const double* a1 = own_first ? pg.a[i] : oa; const double* a2 = own_first ? oa : pg.a[i];
+    const double* p1 = own_first ? ci : oc; const double* p2 = own_first ? oc : ci;
+    const double* a1 = own_first ? ai : oa; const double* a2 = own_first ? oa : ai;
     const int t1 = own_first ? g.type : otype, t2 = own_first ? otype : g.type;
     const double r1 = own_first ? r0 : orad, r2 = own_first ? orad : r0, h1 = own_first ? h0 : ohalf, h2 = own_first ? ohalf : h0;
-    const double* v1 = own_first ? cvel[g.link] : ovel; const double* v2 = own_first ? ovel : cvel[g.link];
-    double vrel[6];
-    QUNROLL for (int k = 0; k < 6; k++) vrel[k] = v2[k] - v1[k];  // J qvel of J = jac(body2) - jac(body1), about the centre of mass
+    double vrel[6];  // J qvel of J = jac(body2) - jac(body1), about the centre of mass
+    QUNROLL for (int k = 0; k < 6; k++) {
+      const double vo = g.link == 0 ? cvel[0][k] : (g.link == 1 ? cvel[1][k] : cvel[2][k]);
+      vrel[k] = own_first ? ovel[k] - vo : vo - ovel[k];
+    }
     const int sgn = own_first ? -1 : 1, depth = g.link + 1;
     auto spheres = [&](const double* c1, const double* c2) {  // oracle sphere_vs_sphere -> add_contact; returns whether a contact was added
       double n[3], len = 0, pos[3];
@@ -974,7 +1242,7 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
       if (!(dist < P.margin)) return false;
       QUNROLL for (int k = 0; k < 3; k++) pos[k] = c1[k] + n[k] * (r1 + 0.5 * dist);
       const int before = ncon;
-      add_contact(P, com, vrel, depth, dist, pos, n, cs, ncon, flags, 1, sgn, odepth);
+      add_contact(P, com, vrel, depth, dist, pos, n, cs, ncon, flags, 1, sgn, odepth, o < kQLegs ? (leg ^ o) : 0);
       if (ncon > before) { nrel++; if (o < kQLegs) pmask |= 1 << (leg ^ o); }
       return true;
     };
@@ -1019,35 +1287,77 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
       }
     }
   };
+  // Bounding-sphere tests are straight-line code over the compile-time (i, j) grid and only set bits; the pairs that pass (rare) are then
+  // walked in a run-time loop, their geoms picked from the register arrays by select chains -- ONE instance of the exact test per
+  // partner instead of one per (i, j).
+  auto pick3 = [](const double (*arr)[3], int idx, double* out) {
+    QUNROLL for (int k = 0; k < 3; k++) {
+      double v = arr[0][k];
+      QUNROLL for (int q = 1; q < kQPairGeom; q++) v = idx == q ? arr[q][k] : v;
+      out[k] = v;
+    }
+  };
+  auto near_mask = [&](const double (*oc)[3], int on, const QuadGeom* ogeoms, const int* oslots) {  // bit 8 * i + j: pair (own i, other j) may touch
+    unsigned long long mask = 0;
+    QUNROLL for (int j = 0; j < kQPairGeom; j++) {
+      if (j >= on) continue;
+      const QuadGeom& g2 = ogeoms[oslots[j]];
+      const double reach2 = g2.size[0] + (g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0) + mg;
+      QUNROLL for (int i = 0; i < kQPairGeom; i++) {
+        if (i >= L.npg) continue;
+        const QuadGeom& g = L.geom[L.pg_slot[i]];
+        const double reach = g.size[0] + (g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0) + reach2;
+        const double dx = pg.c[i][0] - oc[j][0], dy = pg.c[i][1] - oc[j][1], dz = pg.c[i][2] - oc[j][2];
+        if (dx * dx + dy * dy + dz * dz < reach * reach) mask |= 1ull << (8 * i + j);
+      }
+    }
+    return mask;
+  };
   // the trunk's pair geoms
-  for (int j = 0; j < m.ntpg; j++) {
-    const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
-    double c[3], a[3];
-    mv3(c, txm, g.pos);
-    QUNROLL for (int k = 0; k < 3; k++) { c[k] += txpos[k]; a[k] = txm[3 * k] * g.rot[2] + txm[3 * k + 1] * g.rot[5] + txm[3 * k + 2] * g.rot[8]; }
-    QUNROLL for (int i = 0; i < kQPairGeom; i++)
-      if (i < L.npg) one(i, kQLegs, j, c, a, g.type, g.size[0], g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, cvelT, 0);
+  {
+    double tc[kQPairGeom][3], ta[kQPairGeom][3];
+    QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++) { tc[j][k] = 0; ta[j][k] = 0; }
+    QUNROLL for (int j = 0; j < kQTrunkPairGeom; j++) {
+      if (j >= m.ntpg) continue;
+      const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
+      double c[3];
+      mv3(c, txm, g.pos);
+      QUNROLL for (int k = 0; k < 3; k++) { tc[j][k] = c[k] + txpos[k]; ta[j][k] = txm[3 * k] * g.rot[2] + txm[3 * k + 1] * g.rot[5] + txm[3 * k + 2] * g.rot[8]; }
+    }
+    unsigned long long mask = near_mask(tc, m.ntpg, m.trunk_geom, m.tpg_slot);
+    while (mask) {
+      const int bit = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int i = bit >> 3, j = bit & 7;
+      const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
+      double c[3], a[3];
+      pick3(tc, j, c); pick3(ta, j, a);
+      one(i, kQLegs, j, c, a, g.type, g.size[0], g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, cvelT, 0);
+    }
   }
   // the other three legs
   QUNROLL for (int d = 1; d <= 3; d++) {
     const int o = (leg + d) & 3;
     const QuadLeg& O = m.leg[o];
-    double ov[3][6];
+    double oc[kQPairGeom][3];
+    QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++)
+      oc[j][k] = d == 1 ? qd_rot<1>(pg.c[j][k]) : (d == 2 ? qd_rot<2>(pg.c[j][k]) : qd_rot<3>(pg.c[j][k]));
+    unsigned long long mask = near_mask(oc, O.npg, O.geom, O.pg_slot);
+    if (qd_or(mask != 0 ? 1 : 0) == 0) continue;  // (quad-uniform: the axes and velocities are only fetched for a partner that is near)
+    double oa[kQPairGeom][3], ov[3][6];
+    QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++)
+      oa[j][k] = d == 1 ? qd_rot<1>(pg.a[j][k]) : (d == 2 ? qd_rot<2>(pg.a[j][k]) : qd_rot<3>(pg.a[j][k]));
     QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) ov[j][k] = d == 1 ? qd_rot<1>(cvel[j][k]) : (d == 2 ? qd_rot<2>(cvel[j][k]) : qd_rot<3>(cvel[j][k]));
-    QUNROLL for (int j = 0; j < kQPairGeom; j++) {
-      double c2[3], a2[3];
-      QUNROLL for (int k = 0; k < 3; k++) {
-        c2[k] = d == 1 ? qd_rot<1>(pg.c[j][k]) : (d == 2 ? qd_rot<2>(pg.c[j][k]) : qd_rot<3>(pg.c[j][k]));
-        a2[k] = d == 1 ? qd_rot<1>(pg.a[j][k]) : (d == 2 ? qd_rot<2>(pg.a[j][k]) : qd_rot<3>(pg.a[j][k]));
-      }
-      if (j >= O.npg) continue;
+    while (mask) {
+      const int bit = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int i = bit >> 3, j = bit & 7;
       const QuadGeom& g2 = O.geom[O.pg_slot[j]];
-      const double h2 = g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0;
+      double c2[3], a2[3], v2[6];
+      pick3(oc, j, c2); pick3(oa, j, a2);
       const int lk = g2.link;
-      double v2[6];
       QUNROLL for (int k = 0; k < 6; k++) v2[k] = lk == 0 ? ov[0][k] : (lk == 1 ? ov[1][k] : ov[2][k]);
-      QUNROLL for (int i = 0; i < kQPairGeom; i++)
-        if (i < L.npg) one(i, o, j, c2, a2, g2.type, g2.size[0], h2, v2, lk + 1);
+      one(i, o, j, c2, a2, g2.type, g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0, v2, lk + 1);
     }
   }
 }
@@ -1066,7 +1376,7 @@ struct QDyn {
   double sl[3], st[6];      // qacc_smooth
   double fs_l[3], fs_t[6];  // qfrc_smooth
   int ncon;
-  int pmode, have_rel;      // self-collision: which legs pair up (B = A xor pmode), whether the candidate has such contacts at all (quad-uniform)
+  int pmask, have_rel;      // self-collision: bit x set if some leg A touches leg A xor x; whether the candidate has such contacts at all (quad-uniform)
 };
 // Position and velocity stages, collision, smooth dynamics, constraint rows: everything of mj_forward before the constraint solve.
 // ctrl: the leg's three controls. Returns flag bits (quad-uniform; 0: fine).
@@ -1218,12 +1528,11 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     int pmask = 0, nrel = 0;
     pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, cs, ncon, flags, pmask, nrel);
     D.ncon = ncon;
-    // the legs in contact with each other must pair up one way (A with A xor pmode): two legs touching the same third one, or legs touching
-    // across two different pairings, are handed on
-    pmask = qd_or(pmask);
+    // bit x of pmask: some leg A touches leg A xor x. One bit set (the common case of self-collision) means disjoint pairs, which the
+    // arrowhead factorisation takes as super-legs; two or three (a leg touching two others) go through the dense elimination of the
+    // leg blocks (newton_direction_general)
+    D.pmask = qd_or(pmask);
     D.have_rel = qd_or(nrel > 0 ? 1 : 0);
-    D.pmode = pmask == 0 ? 0 : (pmask == 2 ? 1 : (pmask == 4 ? 2 : (pmask == 8 ? 3 : -1)));
-    if (D.pmode < 0) { flags |= kFlagPair; D.pmode = 0; }
     QPROF(pf, 3);
   }
   // ================= spatial inertias about the centre of mass (o_compos); bias forces (o_rne), passive, actuation -> qfrc_smooth
@@ -1731,14 +2040,22 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
       if (leg == 1) for (int q = 0; q < m.ntrace; q++) QUNROLL for (int k = 0; k < 3; k++) a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k] = f.trace[q][k];
     }
     total += cost;
+    if (a.con_cap > 0 && qd_or(D.ncon > a.con_cap ? 1 : 0)) { flags = kFlagOverflow; break; }
     QPROF(pf, 5);
     if (last) break;  // (the last step's mj_forward only feeds the sensor stage)
     double al[3], at[6], fc_l[3], fc_t[6];
     int iters;
-    flags = constraint_newton(m, L, D.kin, ms, D.R, cs, D.ncon, leg, D.pmode, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+    // one pair pattern of legs in contact (or none): the super-leg solver; a leg touching two others (rare): the general one -- for
+    // every candidate of the wavefront then (it covers the other cases too, and the wavefront runs one solver instead of both in turn)
+    if (qw_any(((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom))
+      flags = constraint_newton<true>(m, L, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+    else
+      flags = constraint_newton<false>(m, L, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     if (flags) break;
     QPROF(pf, 6);
     QPROF_COUNT(pf, 16, iters);
+    QPROF_WAVE_HIST(pf, 18, D.ncon);
+    QPROF_WAVE_HIST(pf, 28, iters);
     QUNROLL for (int j = 0; j < 3; j++) bad |= qbad(al[j]);
     QUNROLL for (int k = 0; k < 6; k++) bad |= qbad(at[k]);
     if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }

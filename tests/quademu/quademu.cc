@@ -58,6 +58,7 @@ static inline double qd_partner(double x, int p) {  // lane (l xor p)'s value
   g_ctx->bar.wait(g_sense);
   return g_ctx->dbuf[s][g_lane ^ p];
 }
+static inline bool qw_any(bool pred) { return pred; }  // (the emulator's wavefront is one quad)
 static inline int qd_or(int x) {
   const int s = g_phase++ & 1;
   g_ctx->ibuf[s][g_lane] = x;
@@ -166,7 +167,10 @@ int quademu_forward(const mjpcx_model* model, const mjpcx_task* task, const doub
     const double cost = residual_cost(b->qm, b->tk, b->sp, leg, S, f, r);
     double al[3], at[6], fc_l[3], fc_t[6];
     int iters;
-    fl = constraint_newton(b->qm, b->qm.leg[leg], D.kin, ms, D.R, cs, D.ncon, leg, D.pmode, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
+    if (((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom)
+      fl = constraint_newton<true>(b->qm, b->qm.leg[leg], D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
+    else
+      fl = constraint_newton<false>(b->qm, b->qm.leg[leg], D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
     flags_out[leg] = fl;
     if (fl) return;
     for (int j = 0; j < 3; j++) {

@@ -75,18 +75,41 @@ def test_all_six_buffers_against_the_oracle(quad, interp, std):
     ctx.close()
 
 
+def test_tangled_legs_stay_in_the_quad_kernel(quad):
+    """saturating noise: legs cross and tangle (a leg touching two others takes the dense elimination of the leg blocks) -- nothing is handed
+    on, and the returns are the oracle's"""
+    pm, pt = quad.packed_model(), quad.packed()
+    N, H, P = 64, 100, 3
+    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+    ns = capi.make_noise_spec(seed=5, iteration=1, mode=capi.NOISE_SAMPLING, std0=1.0)
+    nominal = np.zeros((P, 12))
+    ctx = context(quad)
+    ctx.rollout_noise(N, H, 0, times, nominal, ns)
+    ret, fail = ctx.returns()
+    assert ctx.quad_stats()["handed_on"] == 0 and not fail.any()
+    nodes = pyoracle.noise_candidates(pm, ns, P, nominal, np.arange(N))
+    ref = pyoracle.rollout_batch(pm, pt, np.concatenate([quad.model.keyframes["home"]["qpos"], np.zeros(18)]), 0.0, MOCAP, N, H, P, 0, times, nodes, num_threads=16)
+    assert close(ret, ref["total_return"], 1e-8)
+    ctx.close()
+
+
 def test_handed_on_candidates_come_back_from_the_other_kernel(quad):
-    """large noise: legs cross, lanes overflow -- those candidates are rolled out by rollout_tree_kernel; every return equals what a
-    context without the quad kernel computes (to that kernel's tolerance against itself: the same code ran)"""
+    """MJPCX_QUAD_CON_CAP=<n> (a test aid: the real limit is the 24 contacts a lane can store): candidates with more than n contacts on one leg are
+    rolled out by rollout_tree_kernel; every return equals what a context without the quad kernel computes (to that kernel's tolerance
+    against itself: the same code ran)"""
     N, H, P = 64, 100, 3
     times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
     ns = capi.make_noise_spec(seed=5, iteration=1, mode=capi.NOISE_SAMPLING, std0=0.25)
     nominal = np.zeros((P, 12))
-    a = context(quad)
-    a.rollout_noise(N, H, 0, times, nominal, ns)
-    ra, fa = a.returns()
-    handed = a.quad_stats()
-    assert 0 < handed["handed_on"] < N and handed["leg_leg_contact"] + handed["trunk_leg_contact"] + handed["contact_list_full"] > 0
+    for cap in (3, 4, 5, 6, 8):  # (the smallest cap that splits the batch)
+        a = context(quad, {"MJPCX_QUAD_CON_CAP": str(cap)})
+        a.rollout_noise(N, H, 0, times, nominal, ns)
+        ra, fa = a.returns()
+        handed = a.quad_stats()
+        if handed["handed_on"] < N:
+            break
+        a.close()
+    assert 0 < handed["handed_on"] < N and handed["contact_list_full"] == handed["handed_on"]
     b = context(quad, {"MJPCX_NO_QUAD": "1"})
     b.rollout_noise(N, H, 0, times, nominal, ns)
     rb, fb = b.returns()
