@@ -361,7 +361,7 @@ struct mjpcx_ctx {
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
   int quad_ids[7] = {0, 0, 0, 0, 0, 0, 0};  // residual_int[1..7] the quad model was built for (torso, head site, goal mocap, feet)
-  DevBuf d_qmodel, d_qtab, d_qstats, d_qstamps;
+  DevBuf d_qmodel, d_qtab, d_qstats, d_qstamps, d_qwave;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -624,6 +624,9 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
   if (c->quad_stamps) {
     if ((e = hipMemsetAsync(c->d_qstamps.p, 0, 512, c->stream)) != hipSuccess) return e;
     q.stamps = (long long*)c->d_qstamps.p;
+    const size_t wb = (size_t)((N + 15) / 16) * 32;
+    if ((e = c->d_qwave.reserve(wb)) != hipSuccess || (e = hipMemsetAsync(c->d_qwave.p, 0, wb, c->stream)) != hipSuccess) return e;
+    q.wave_times = (long long*)c->d_qwave.p;
   }
   if ((e = quad::launch_rollout_quad(c->d_qmodel.p, c->d_qtab.p, wt.blob, bo, q, (int*)c->d_qstats.p,
                                      c->stream)) != hipSuccess) return e;
@@ -637,7 +640,22 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
     std::fprintf(stderr, "rollout_quad_kernel cycles of wavefront 0 (H = %d):", a.H);
     for (int k = 0; k < 13; k++) std::fprintf(stderr, " %s %lld", nm[k], h[k]);
     std::fprintf(stderr, " | newton iterations %lld, line-search trials %lld\n", h[16], h[17]);
+    std::fprintf(stderr, "  raw counters 40..63:");
+    for (int k = 40; k < 64; k++) std::fprintf(stderr, " %lld", h[k]);
+    std::fprintf(stderr, "\n");
     std::fprintf(stderr, "  newton: entry %lld, first pass %lld, warm start %lld; line search: entry %lld, coefficients %lld, trials %lld\n", h[13], h[14], h[15], h[40], h[41], h[42]);
+    {
+      const int W = (N + 15) / 16;
+      std::vector<long long> w((size_t)W * 4);
+      (void)hipMemcpy(w.data(), c->d_qwave.p, w.size() * 8, hipMemcpyDeviceToHost);
+      std::vector<int> order(W);
+      for (int i = 0; i < W; i++) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](int x, int y) { return w[4 * x] < w[4 * y]; });
+      std::fprintf(stderr, "  wavefronts by cycles (Newton iterations run, steps in the general solver, sum of largest per-lane contact counts):");
+      const double qs[7] = {0.0, 0.1, 0.5, 0.9, 0.99, 0.999, 1.0};
+      for (double qq : qs) { const int i = order[(size_t)(qq * (W - 1))]; std::fprintf(stderr, " p%g %lld (%lld, %lld, %lld)", 100 * qq, w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]); }
+      std::fprintf(stderr, "\n");
+    }
     std::fprintf(stderr, "  steps at which some lane of the wavefront holds > 0 1 2 3 4 6 8 12 contacts: %lld %lld %lld %lld %lld %lld %lld %lld; contacts per lane-step %.2f; "
                  "Newton iterations per candidate-step %.2f (the wavefront runs the slowest's: %.2f)\n", h[18], h[19], h[20], h[21], h[22], h[23], h[24], h[25],
                  (double)h[26] / (64.0 * a.H), (double)h[36] / (64.0 * a.H), (double)h[37] / a.H);
@@ -1029,7 +1047,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   if (c->best_host) (void)hipHostFree(c->best_host);
   (void)mjpcx_comm_destroy(c);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_qmodel, &c->d_qtab, &c->d_qstats, &c->d_qstamps, &c->d_comm_send, &c->d_comm_recv,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_qmodel, &c->d_qtab, &c->d_qstats, &c->d_qstamps, &c->d_qwave, &c->d_comm_send, &c->d_comm_recv,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();

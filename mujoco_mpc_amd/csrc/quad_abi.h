@@ -22,6 +22,7 @@ struct QArgs {
   double *states, *actions, *times, *residual, *costs, *trace, *total_return;  // [candidate][step][field]
   int* failure;
   long long* stamps;  // nullptr, or 64 counters: phase cycles of wavefront 0 (tuning aid, MJPCX_QUAD_STAMPS=1)
+  long long* wave_times;  // nullptr, or [wavefront][4] (tuning aid, with stamps): cycles; Newton iterations run (each step the slowest candidate's); steps through the general solver; the largest per-lane contact count, summed over the steps
   int con_cap;        // a lane that collects more contacts than this hands its candidate on (0: kQMaxCon, the store's capacity; MJPCX_QUAD_CON_CAP lowers it, for tests of the hand-on)
 };
 

@@ -78,11 +78,35 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
     int s_ = (v), m_ = (v); for (int o_ = 32; o_ > 0; o_ >>= 1) { s_ += __shfl_xor(s_, o_); const int t_ = __shfl_xor(m_, o_); m_ = t_ > m_ ? t_ : m_; } \
     (pf).buf[(idx) + 8] += s_; (pf).buf[(idx) + 9] += m_; } } while (0)
 
+// per-wavefront totals (a.wave_times): [1] += the slowest candidate's Newton iterations, [2] += 1 if the general solver ran, [3] += the
+// largest per-lane contact count; [0] (cycles) is written by the kernel at the end
+#define QWAVE_TIMES(a, iters, general, ncon) do { if ((a).wave_times) { int mi_ = (iters), mc_ = (ncon); \
+    for (int o_ = 32; o_ > 0; o_ >>= 1) { const int t_ = __shfl_xor(mi_, o_); mi_ = t_ > mi_ ? t_ : mi_; const int u_ = __shfl_xor(mc_, o_); mc_ = u_ > mc_ ? u_ : mc_; } \
+    long long* w_ = (a).wave_times + 4 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6); \
+    if ((threadIdx.x & 63) == 0) { w_[1] += mi_; w_[2] += (general) ? 1 : 0; w_[3] += mc_; } } } while (0)
+
 // every fixed-trip loop over a small array is unrolled: a loop the compiler keeps rolled indexes its array at run time, and a private array
 // indexed at run time lives in scratch
 #define QUNROLL _Pragma("unroll")
 #define QNOINLINE __device__ __noinline__
 #define QD __device__ __forceinline__
+#define QFAST_MATH 1
+// x > 0, normal: Newton refinement of the hardware estimates (v_rsq_f64 / v_rcp_f64 are good to about 2^-26)
+__device__ __forceinline__ void q_sqrt_rsqrt(double x, double& s, double& r) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(y, fma(-hx * y, y, 0.5), y);   // y (1.5 - 0.5 x y^2)
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  double g = x * y;
+  g = fma(fma(-g, g, x), 0.5 * y, g);    // one correction of the root itself
+  s = g; r = y;
+}
+__device__ __forceinline__ double q_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
 #include "quad_step.h"
 #undef QD
 
@@ -146,7 +170,9 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __re
   LdsM ms{wave_lds + kQWaveCon + (threadIdx.x & 63), wave_lds + kQWaveCon + kQWaveMl + ((threadIdx.x & 63) >> 2)};
   QProf pf{nullptr, 0};
   if (a.stamps && blockIdx.x == 0 && threadIdx.x < 64) { pf.buf = a.stamps; pf.last = __builtin_readcyclecounter(); }
+  const long long wave_t0 = a.wave_times ? __builtin_readcyclecounter() : 0;
   const int flags = rollout(sm, *tab, sp, tk, blob, blob[bo.off_time], a, cand, leg, cs, ms, pf);
+  if (a.wave_times && (threadIdx.x & 63) == 0) a.wave_times[4 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)] = __builtin_readcyclecounter() - wave_t0;
   if (flags && leg == 0 && stats) {
     atomicAdd(stats, 1);
     QUNROLL for (int b = 0; b < 6; b++) if (flags & (1 << b)) atomicAdd(stats + 1 + b, 1);

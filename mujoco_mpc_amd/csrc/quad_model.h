@@ -69,6 +69,7 @@ struct QuadLeg {
   int limited[kQLinks], act_biastype[kQLinks], ctrllimited[kQLinks], forcelimited[kQLinks];
   int ngeom, foot_slot, foot_index, npg;  // foot_slot: the leg's geom the residual reads; foot_index: its place in foot_geom_id_ (FL HL FR HR)
   int pg_slot[kQPairGeom];                // the leg's sphere | capsule geoms that can touch another leg or the trunk (self-collision test)
+  unsigned long long pg_first[kQLegs + 1];  // per other leg (kQLegs: the trunk), bit 8 i + j: the own pair geom i is geom1 of the pair with the other's j
   QuadGeom geom[kQLegGeom];
 };
 
@@ -384,6 +385,7 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
         const std::string err = pair_params(g1, g2, p);
         if (!err.empty()) return err;
         p.collide = 1; p.pad = own == g1;
+        if (own == g1) qm->leg[slot_leg[own]].pg_first[slot_leg[other] < 0 ? kQLegs : slot_leg[other]] |= 1ull << (8 * pg_index(own) + pg_index(other));
       }
     }
   }

@@ -29,6 +29,7 @@
 #define QPROF(pf, idx)
 #define QPROF_COUNT(pf, idx, n)
 #define QPROF_WAVE_HIST(pf, idx, v)
+#define QWAVE_TIMES(a, iters, general, ncon)
 #endif
 #ifndef QUNROLL
 #define QUNROLL
@@ -48,6 +49,12 @@ constexpr double kQLsTol = 0.01;
 enum { kFlagOverflow = 1, kFlagPair = 2, kFlagNotPD = 4, kFlagBad = 8, kFlagLimits = 16, kFlagPairTrunk = 32 };
 
 // ---------------------------------------------------------------- small algebra
+// square root with its reciprocal, and a reciprocal, for the line search's inner loop: the includer may supply faster ones (the device
+// build refines v_rsq_f64 / v_rcp_f64 by Newton steps: an ulp or two from the correctly rounded values, a third of the instructions)
+#ifndef QFAST_MATH
+QD void q_sqrt_rsqrt(double x, double& s, double& r) { s = sqrt(x); r = 1.0 / s; }
+QD double q_rcp(double x) { return 1.0 / x; }
+#endif
 QD bool qbad(double x) { return !(x <= kQMaxVal && x >= -kQMaxVal); }
 QD void q_mul(double* r, const double* a, const double* b) {
   const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
@@ -492,8 +499,10 @@ QD void line_coeffs(const QContact& c, const double* fr, const double* jv, doubl
 // the latency of dependent fp64 instructions -- and the three zones differ by a handful of flops)
 QD void line_eval(const QLine& q, double alpha, double& g, double& h) {
   const double mu = q.mu, jn = q.jn0 + alpha * q.vn, T2 = q.A + alpha * (2 * q.B + alpha * q.C);
-  const bool pos = T2 > 0;
-  const double T = pos ? sqrt(T2) : 0.0, iT = pos ? 1.0 / T : 0.0, N = mu * jn;
+  const bool pos = T2 > 1e-200;  // (below: the cone's axis, where the zones are told apart by the sign of N alone)
+  double Ts, iTs;
+  q_sqrt_rsqrt(pos ? T2 : 1.0, Ts, iTs);
+  const double T = pos ? Ts : 0.0, iT = pos ? iTs : 0.0, N = mu * jn;
   const bool top = N >= mu * T || (!pos && N >= 0), bottom = mu * N + T <= 0 || (!pos && N < 0);
   const double UV = q.B + alpha * q.C;
   const double gb = q.D0 * jn * q.vn + q.Dq * UV, hb = q.D0 * q.vn * q.vn + q.Dq * q.C;
@@ -684,8 +693,12 @@ QNOINLINE double line_search(const QuadModel& m, const QuadLeg& L, const QRows& 
   d1 += q1; d2 += q2;
   const double d10 = fabs(d1);
   double step1 = 1e300, step2 = 1e300;  // the last step and the one before (rtsafe safeguard, oracle/contact.inc)
+#ifdef QEXP_MAXLS
+  for (int ls = 0; ls < QEXP_MAXLS && d10 >= gtol; ls++) {
+#else
   for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
-    double an = alpha - d1 / d2;
+#endif
+    double an = alpha - d1 * q_rcp(d2);
     if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * alpha + 1;
     else if (hi >= 0 && fabs(an - alpha) > 0.5 * step2) an = 0.5 * (lo + hi);
     if (an == alpha) break;
@@ -974,7 +987,11 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
   QPROF(pf, 15);
   const double scale = 1.0 / (m.meaninertia * 18.0);
   double improvement = 0;
+#ifdef QEXP_MAXITER
+  for (int iter = 0; iter < QEXP_MAXITER; iter++) {
+#else
   for (int iter = 0; iter < m.iterations; iter++) {
+#endif
     // gradient = M (qacc - qacc_smooth) - J' force
     double hl[3], ht[6];
     QUNROLL for (int j = 0; j < 3; j++) hl[j] = Mal[j] - fc_l[j];
@@ -1204,13 +1221,16 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
 // nearest points for the pairs that pass; a pair within its margin becomes a RELATIVE contact (QContact::rel) in the own lane's list --
 // and, for a leg-leg pair, identically in the partner's lane, which walks the same pair from its side with the same arithmetic (the two
 // geoms are always taken in MuJoCo's order: geom1 first). pmask collects 1 << (own leg xor partner leg) of the leg-leg contacts.
-template <class CS>
+template <class CS, class QProfT>
 QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const QPairGeoms& pg, const double* txpos, const double* txm, const double* com,
-                      const double cvel[3][6], const double* cvelT, CS& cs, int& ncon, int& flags, int& pmask, int& nrel) {
+                      const double cvel[3][6], const double* cvelT, CS& cs, int& ncon, int& flags, int& pmask, int& nrel, QProfT& pf) {
   const QuadLeg& L = m.leg[leg];
   const double mg = m.pair_margin;
   // one pair: own geom (index i of the leg's pair geoms) against (other leg o or kQLegs = trunk, index j)
-  auto one = [&](int i, int o, int j, const double* oc, const double* oa, int otype, double orad, double ohalf, const double* ovel, int odepth) {
+  // (nothing of the pair's table record -- global memory -- is touched before a distance is below the largest margin: the order of the two
+  // geoms comes from the leg's bit mask, the record is read when a contact is created)
+  auto one = [&](int i, int o, int j, const double* oc, const double* oa, int otype, double orad, double ohalf, const double* ov0, const double* ov1, const double* ov2,
+                 int olink, int odepth) {
     const QuadGeom& g = L.geom[L.pg_slot[i]];
     const double r0 = g.size[0], h0 = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
     double ci[3], ai[3];  // the own geom, picked from the register arrays (i is a run-time index here)
@@ -1219,29 +1239,33 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
       QUNROLL for (int q = 1; q < kQPairGeom; q++) { vc = i == q ? pg.c[q][k] : vc; va = i == q ? pg.a[q][k] : va; }
       ci[k] = vc; ai[k] = va;
     }
-    const QuadPair& P = tab.mm[leg][i][o][j];
-    if (!P.collide) return;
-    const bool own_first = P.pad != 0;
+    const bool own_first = ((L.pg_first[o] >> (8 * i + j)) & 1) != 0;
     // geom1 / geom2 in MuJoCo's order
     const double* p1 = own_first ? ci : oc; const double* p2 = own_first ? oc : ci;
     const double* a1 = own_first ? ai : oa; const double* a2 = own_first ? oa : ai;
     const int t1 = own_first ? g.type : otype, t2 = own_first ? otype : g.type;
     const double r1 = own_first ? r0 : orad, r2 = own_first ? orad : r0, h1 = own_first ? h0 : ohalf, h2 = own_first ? ohalf : h0;
-    double vrel[6];  // J qvel of J = jac(body2) - jac(body1), about the centre of mass
-    QUNROLL for (int k = 0; k < 6; k++) {
-      const double vo = g.link == 0 ? cvel[0][k] : (g.link == 1 ? cvel[1][k] : cvel[2][k]);
-      vrel[k] = own_first ? ovel[k] - vo : vo - ovel[k];
-    }
     const int sgn = own_first ? -1 : 1, depth = g.link + 1;
     auto spheres = [&](const double* c1, const double* c2) {  // oracle sphere_vs_sphere -> add_contact; returns whether a contact was added
       double n[3], len = 0, pos[3];
       QUNROLL for (int k = 0; k < 3; k++) { n[k] = c2[k] - c1[k]; len += n[k] * n[k]; }
       len = sqrt(len);
-      if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else { QUNROLL for (int k = 0; k < 3; k++) n[k] /= len; }
       const double dist = len - r1 - r2;
-      if (!(dist < P.margin)) return false;
+      if (!(dist < mg)) return false;
+      const QuadPair& P = tab.mm[leg][i][o][j];
+      if (!P.collide || !(dist < P.margin)) return false;
+      if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else { QUNROLL for (int k = 0; k < 3; k++) n[k] /= len; }
+      double vrel[6];  // J qvel of J = jac(body2) - jac(body1), about the centre of mass
+      QUNROLL for (int k = 0; k < 6; k++) {
+        const double vo = g.link == 0 ? cvel[0][k] : (g.link == 1 ? cvel[1][k] : cvel[2][k]);
+        const double vp = olink == 0 ? ov0[k] : (olink == 1 ? ov1[k] : ov2[k]);
+        vrel[k] = own_first ? vp - vo : vo - vp;
+      }
       QUNROLL for (int k = 0; k < 3; k++) pos[k] = c1[k] + n[k] * (r1 + 0.5 * dist);
       const int before = ncon;
+#ifdef QEXP_PAIRS_DRY
+      if (dist > -1e30) return false;
+#endif
       add_contact(P, com, vrel, depth, dist, pos, n, cs, ncon, flags, 1, sgn, odepth, o < kQLegs ? (leg ^ o) : 0);
       if (ncon > before) { nrel++; if (o < kQLegs) pmask |= 1 << (leg ^ o); }
       return true;
@@ -1326,13 +1350,14 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
     }
     unsigned long long mask = near_mask(tc, m.ntpg, m.trunk_geom, m.tpg_slot);
     while (mask) {
+      QPROF_COUNT(pf, 43, 1);
       const int bit = __builtin_ctzll(mask);
       mask &= mask - 1;
       const int i = bit >> 3, j = bit & 7;
       const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
       double c[3], a[3];
       pick3(tc, j, c); pick3(ta, j, a);
-      one(i, kQLegs, j, c, a, g.type, g.size[0], g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, cvelT, 0);
+      one(i, kQLegs, j, c, a, g.type, g.size[0], g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, cvelT, cvelT, cvelT, 0, 0);
     }
   }
   // the other three legs
@@ -1348,16 +1373,16 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
     QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++)
       oa[j][k] = d == 1 ? qd_rot<1>(pg.a[j][k]) : (d == 2 ? qd_rot<2>(pg.a[j][k]) : qd_rot<3>(pg.a[j][k]));
     QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) ov[j][k] = d == 1 ? qd_rot<1>(cvel[j][k]) : (d == 2 ? qd_rot<2>(cvel[j][k]) : qd_rot<3>(cvel[j][k]));
+    QPROF_COUNT(pf, 45, 1);
     while (mask) {
+      QPROF_COUNT(pf, 44, 1);
       const int bit = __builtin_ctzll(mask);
       mask &= mask - 1;
       const int i = bit >> 3, j = bit & 7;
       const QuadGeom& g2 = O.geom[O.pg_slot[j]];
-      double c2[3], a2[3], v2[6];
+      double c2[3], a2[3];
       pick3(oc, j, c2); pick3(oa, j, a2);
-      const int lk = g2.link;
-      QUNROLL for (int k = 0; k < 6; k++) v2[k] = lk == 0 ? ov[0][k] : (lk == 1 ? ov[1][k] : ov[2][k]);
-      one(i, o, j, c2, a2, g2.type, g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0, v2, lk + 1);
+      one(i, o, j, c2, a2, g2.type, g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0, ov[0], ov[1], ov[2], g2.link, g2.link + 1);
     }
   }
 }
@@ -1526,7 +1551,9 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     }
     QPROF(pf, 2);
     int pmask = 0, nrel = 0;
-    pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, cs, ncon, flags, pmask, nrel);
+#ifndef QEXP_NOPAIRS
+    pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, cs, ncon, flags, pmask, nrel, pf);
+#endif
     D.ncon = ncon;
     // bit x of pmask: some leg A touches leg A xor x. One bit set (the common case of self-collision) means disjoint pairs, which the
     // arrowhead factorisation takes as super-legs; two or three (a leg touching two others) go through the dense elimination of the
@@ -2047,11 +2074,13 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     int iters;
     // one pair pattern of legs in contact (or none): the super-leg solver; a leg touching two others (rare): the general one -- for
     // every candidate of the wavefront then (it covers the other cases too, and the wavefront runs one solver instead of both in turn)
-    if (qw_any(((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom))
+    const bool wave_general = qw_any(((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom);
+    if (wave_general)
       flags = constraint_newton<true>(m, L, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     else
       flags = constraint_newton<false>(m, L, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     if (flags) break;
+    QWAVE_TIMES(a, iters, wave_general, D.ncon);
     QPROF(pf, 6);
     QPROF_COUNT(pf, 16, iters);
     QPROF_WAVE_HIST(pf, 18, D.ncon);

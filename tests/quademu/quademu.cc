@@ -136,6 +136,27 @@ const char* quademu_check(const mjpcx_model* model, const mjpcx_task* task) {
   return msg.c_str();
 }
 
+// prints the self-collision tables of the model (bring-up aid)
+void quademu_dump_pairs(const mjpcx_model* model, const mjpcx_task* task) {
+  Built* b = new Built;
+  if (!quad_build(model, task, &b->qm, &b->qt).empty()) { delete b; return; }
+  for (int l = 0; l < kQLegs; l++) {
+    const QuadLeg& L = b->qm.leg[l];
+    std::printf("leg %d: %d pair geoms:", l, L.npg);
+    for (int i = 0; i < L.npg; i++) { const QuadGeom& g = L.geom[L.pg_slot[i]]; std::printf(" [link %d type %d r %.3f h %.3f]", g.link, g.type, g.size[0], g.size[1]); }
+    std::printf("\n");
+    for (int o = 0; o <= kQLegs; o++) {
+      if (o == l) continue;
+      int n = 0;
+      std::printf("  vs %d:", o);
+      for (int i = 0; i < kQPairGeom; i++) for (int j = 0; j < kQPairGeom; j++) if (b->qt.mm[l][i][o][j].collide) { n++; std::printf(" (%d,%d)", i, j); }
+      std::printf("  = %d\n", n);
+    }
+  }
+  std::printf("trunk pair geoms: %d; pair_margin %g\n", b->qm.ntpg, b->qm.pair_margin);
+  delete b;
+}
+
 // one mj_forward + residual at (state, ctrl): out = qacc[18] qfrc_smooth[18] qfrc_constraint[18] M[18*18] com[3] residual[42] cost
 // ncon iters ; returns the flag bits
 int quademu_forward(const mjpcx_model* model, const mjpcx_task* task, const double* state, double time, const double* mocap, const double* ctrl,
