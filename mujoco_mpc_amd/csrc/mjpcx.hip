@@ -1746,7 +1746,7 @@ RcclApi* rccl() {
       api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (api.lib) break;
     }
-    if (!api.lib) { api.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
+    if (!api.lib) { const char* why = dlerror(); api.error = std::string("librccl.so.1 not found: ") + (why ? why : ""); return; }  // (dlerror() clears itself: one call)
 #define MJPCX_SYM(field, sym)                                                              \
     api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, #sym));                \
     if (!api.field) api.error = std::string("RCCL symbol missing: ") + #sym;
@@ -1856,7 +1856,7 @@ int mjpcx_merge_topk(mjpcx_ctx* c, int k, int64_t* index, double* total_return) 
   std::vector<double> mine(2 * (size_t)k);
   for (int i = 0; i < k; i++) {
     const bool used = index[i] >= 0;
-    mine[2 * i] = used ? total_return[i] : (double)INFINITY;
+    mine[2 * i] = used && total_return[i] == total_return[i] ? total_return[i] : (double)INFINITY;  // (NaN ranks last, and keeps the comparator a strict weak order)
     mine[2 * i + 1] = used ? (double)index[i] : 4503599627370496.0;  // 2^52: sorts after every real index
   }
   int rc;

@@ -136,7 +136,12 @@ void GpuCrossEntropyPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
   for (int i = 0; i < k; i++) idx[i] = (std::int64_t)idx32[i] + offset_;
   if (world_ > 1) {
     if (merge_) { if (merge_(user_, n_elite + 1, idx.data(), ret.data()) != 0) throw gpu::Error(MJPCX_EDEVICE, "top-k exchange failed"); }
-    else ctx_->Check(mjpcx_merge_topk(ctx_->handle(), n_elite + 1, idx.data(), ret.data()));  // RCCL inside the library
+    else {  // RCCL inside the library: it must hold a communicator of this world size, or the merge is silently the identity
+      int comm_rank = 0, comm_world = 1;
+      ctx_->Check(mjpcx_comm_info(ctx_->handle(), &comm_rank, &comm_world));
+      if (comm_world != world_) throw gpu::Error(MJPCX_ESTATE, "sharded planner has neither exchange callbacks nor a communicator of its world size (mjpcx_comm_init)");
+      ctx_->Check(mjpcx_merge_topk(ctx_->handle(), n_elite + 1, idx.data(), ret.data()));
+    }
   }
   trajectory_order.clear();
   double best_return = 0;

@@ -167,6 +167,10 @@ void GpuSamplingPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
       index = (int32_t)record[1];
       nominal_return = record[2];
     } else {          // RCCL inside the library (mjpcx_comm_init on this planner's context)
+      // without a communicator of this world size the library's exchange is the identity: every rank would adopt its own best silently
+      int comm_rank = 0, comm_world = 1;
+      ctx_->Check(mjpcx_comm_info(ctx_->handle(), &comm_rank, &comm_world));
+      if (comm_world != world_) throw gpu::Error(MJPCX_ESTATE, "sharded planner has neither an exchange callback nor a communicator of its world size (mjpcx_comm_init)");
       ctx_->Check(mjpcx_exchange_best(ctx_->handle(), &index, &best_return, &nominal_return, values.data(), (int)values.size()));
     }
   }
