@@ -46,6 +46,12 @@ def parse():
     ap.add_argument("--precision", type=int, default=64, choices=[32, 64])
     ap.add_argument("--planner", default="sampling", choices=["sampling", "cross_entropy"],
                     help="host planner driving the hot path")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank rolls out --candidates; strong: --candidates is the GLOBAL batch (BASELINE configs[2]: "
+                         "16384 candidates, 1 -> 8 GPUs), split over the ranks in contiguous ranges")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one GPU: time the share of every rank of a W-rank strong-scaling run in turn (N / W candidates at that rank's "
+                         "candidate offset) -- what the per-rank time of --scaling strong will be before the hardware shows up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` configs (they only run at --gpus 1)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
@@ -193,8 +199,10 @@ def pmc_summary(task_name, candidates, horizon, precision):
     return s
 
 
-def run_config(args, task_name, kind, candidates, horizon, precision, steps, warmup, world, local_rank, group, want_cpu, rank, native=None):
-    """one BASELINE config through the C++ planner over the C ABI; returns the fields of a bench line"""
+def run_config(args, task_name, kind, candidates, horizon, precision, steps, warmup, world, local_rank, group, want_cpu, rank, native=None,
+               total=None):
+    """one BASELINE config through the C++ planner over the C ABI; returns the fields of a bench line. candidates: this rank's share;
+    total: the global batch (default candidates * world)"""
     import torch
     from mujoco_mpc_amd import capi
     from mujoco_mpc_amd.hostplanner import HostPlanner
@@ -202,12 +210,13 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
 
     task = load_task(task_name)
     H = horizon
+    total = total or candidates * world
     planner, transport = None, ("rccl" if native is not None else "torch")
     if native is not None:
         # RCCL inside libmjpcx.so; if the communicator cannot be created on ANY rank (mismatched RCCL builds, IPC limits), every
         # rank falls back together to the torch.distributed callbacks -- the line says which transport ran
         try:
-            planner = HostPlanner(task, device=local_rank, precision=precision, seed=0, num_trajectory=candidates * world, kind=kind,
+            planner = HostPlanner(task, device=local_rank, precision=precision, seed=0, num_trajectory=total, kind=kind,
                                   native_comm=native)
             failed = 0.0
         except Exception as ex:  # noqa: BLE001
@@ -219,7 +228,7 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
             planner, native, transport = None, None, "torch (native communicator failed)"
     if planner is None:
         planner = HostPlanner(task, device=local_rank, precision=precision, seed=0,
-                              num_trajectory=candidates * world,  # lifts kMaxTrajectory = 128
+                              num_trajectory=total,  # lifts kMaxTrajectory = 128
                               group=group, kind=kind)
     qpos, qvel, mocap_pos, mocap_quat = initial_condition(task_name, task, planner)
     planner.reset(H)
@@ -248,7 +257,7 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
     nominal_nodes = planner.policy()[1]
     if group is not None:
         elapsed = group.max_scalar(elapsed)
-    value = candidates * world * steps / elapsed
+    value = total * steps / elapsed
     if rank != 0:
         planner.close()
         return None
@@ -349,6 +358,120 @@ def run_ilqg(local_rank, iterations=6, warmup=2):
     return out
 
 
+class _OneOfMany:
+    """transport of a rank whose peers are not there: every exchange returns the rank's own record (one-GPU emulation of a rank's share)"""
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def barrier(self):
+        pass
+
+    def exchange_best(self, idx, best, nominal, values):
+        return idx, best, nominal, values
+
+    def merge_topk(self, idx, ret, k):
+        return idx, ret
+
+    def sum_array(self, v):
+        return v
+
+    def max_scalar(self, v):
+        return v
+
+
+def emulate_strong(args, total, H, local_rank):
+    """--emulate-world W on one GPU: the share of every rank of a W-rank strong-scaling run (total / W candidates at its candidate offset),
+    one after the other through the C++ planner, timed like a bench step. The slowest share is what --scaling strong would report per
+    step on W GPUs (plus the exchange); printed as one JSON line."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.task import load_task
+    W = args.emulate_world
+    task = load_task(args.task)
+    per_rank = []
+    kernel = None
+    for r in range(W):
+        planner = HostPlanner(task, device=local_rank, precision=args.precision, seed=0, num_trajectory=total, kind=args.planner,
+                              group=_OneOfMany(r, W))
+        qpos, qvel, mocap_pos, mocap_quat = initial_condition(args.task, task, planner)
+        planner.reset(H)
+        planner.set_state(qpos, qvel, 0.0, mocap_pos=mocap_pos, mocap_quat=mocap_quat)
+        for _ in range(args.warmup):
+            planner.optimize_policy(H)
+        planner.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            planner.optimize_policy(H)
+        planner.sync()
+        per_rank.append((time.perf_counter() - t0) / args.steps * 1e3)
+        kernel = planner.kernel_name
+        planner.close()
+    slowest = max(per_rank)
+    print(json.dumps({"metric": "candidate-trajectory rollouts/sec (fixed horizon)", "emulation": True, "value": total / slowest * 1e3,
+                      "unit": "rollouts/s", "n_gpus": 1, "emulated_world": W, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": slowest, "per_rank_ms": per_rank, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                      "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
+                      "config": {"workload": f"{args.task}, global batch {total}, horizon {H}: each of {W} ranks' share ({total // W} candidates) timed "
+                                             "in turn on ONE GPU, no exchange", "kernel": kernel},
+                      "note": "value = global batch / the slowest rank's step time: the throughput an ideal exchange would give W GPUs"}), flush=True)
+
+
+def run_testspeed(local_rank, plans=100):
+    """BASELINE configs[0]: the reference's plumbing case -- testspeed_app's closed loop on Cartpole with 8 Predictive-Sampling candidates
+    (simulate + plan synchronously; host/tests/testspeed_app.cc has testspeed_app.cc's flags) -- `plans` plan iterations; beside it the
+    CPU port rolling the same 8 candidates out."""
+    import re
+    import subprocess
+    import tempfile
+    from mujoco_mpc_amd import mjcf
+    from mujoco_mpc_amd.build import build_host
+    from mujoco_mpc_amd.task import load_task
+    from oracle import pyoracle
+    build_host()
+    task = load_task("Cartpole")
+    d = tempfile.mkdtemp(prefix="mjpx_")
+    mjcf.save_blob(task.model, os.path.join(d, "Cartpole.mjpx"))
+    spi = 4
+    dt = float(task.model.scalars["timestep"])
+    total_time = plans * spi * dt
+    exe = os.path.join(ROOT, "mujoco_mpc_amd", "host", "build", "testspeed_app")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=str(local_rank))
+    out = subprocess.run([exe, "--task=Cartpole", f"--total_time={total_time}", f"--steps_per_planning_iteration={spi}", f"--model_dir={d}",
+                          "--candidates=8"], capture_output=True, text=True, timeout=300, env=env)
+    if out.returncode != 0:
+        raise RuntimeError(out.stdout[-500:] + out.stderr[-500:])
+    m1 = re.search(r"(\d+) plan iterations of (\d+) candidates x (\d+) steps\): ([0-9.]+) s", out.stdout)
+    m2 = re.search(r"Mean plan iteration: ([0-9.]+) us", out.stdout)
+    m3 = re.search(r"Average cost per step \(lower is better\): ([-0-9.eE+]+)", out.stdout)
+    nplans, ncand, steps, wall = int(m1.group(1)), int(m1.group(2)), int(m1.group(3)), float(m1.group(4))
+    plan_us = float(m2.group(1))
+    line = {"name": "configs[0] testspeed closed loop", "metric": "candidate-trajectory rollouts/sec (fixed horizon)",
+            "value": ncand / (plan_us * 1e-6), "unit": "rollouts/s", "higher_is_better": True, "dtype": "f64",
+            "plan_iterations": nplans, "mean_plan_iteration_us": plan_us, "closed_loop_wall_s": wall, "average_cost": float(m3.group(1)),
+            "config": {"workload": f"Cartpole Predictive Sampling, {ncand} candidates, horizon {steps} steps, testspeed_app closed loop "
+                                   "(BASELINE.json configs[0]: the reference's own CPU-runnable case)",
+                       "host": "host/tests/testspeed_app.cc -> mjpc::SynchronousPlanningCost (simulation step and planner both on the device)"},
+            "note": "latency-bound by construction (8 candidates = 8 lanes of one wavefront, one launch + one sync per plan iteration): the "
+                    "plumbing check BASELINE.json lists first, not a throughput case"}
+    # CPU port: the same number of candidates and steps through the oracle's thread pool
+    pm, pt = task.packed_model(), task.packed()
+    P = 3
+    times = np.arange(P) * ((steps - 1) * dt / (P - 1))
+    nodes = np.random.default_rng(0).normal(0, 0.1, (ncand, P, task.model.nu))
+    st = np.zeros(task.model.nq + task.model.nv)
+    budget = host_cpu_budget()
+    threads = max(1, min(ncand, int(budget["quota"] or budget["affinity"])))
+    pyoracle.rollout_batch(pm, pt, st, 0.0, None, ncand, steps, P, 0, times, nodes, num_threads=threads)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 2.0:
+        pyoracle.rollout_batch(pm, pt, st, 0.0, None, ncand, steps, P, 0, times, nodes, num_threads=threads)
+        reps += 1
+    cpu = reps * ncand / (time.perf_counter() - t0)
+    line["cpu_baseline"] = {"value": cpu, "unit": "rollouts/s", "cores": threads, "kind": "port",
+                            "sample": f"{reps} batches of {ncand} rollouts x {steps} steps through oracle/ (thread pool of {threads}); CPU restatement, not MuJoCo"}
+    return line
+
+
 def dry_run(args, rank, world):
     """The --gpus N launch path with the device taken out (tests/test_distributed_gloo.py runs it at WORLD_SIZE = 2): what can
     be wrong the first time an 8-GPU node appears -- env parsing, rendezvous, the 128-byte communicator id reaching every rank,
@@ -368,7 +491,7 @@ def dry_run(args, rank, world):
     assert bytes(uid.numpy().tobytes()) == hashlib.sha256(b"dry-run communicator id").digest() * 4
     n0, h0, _ = BASELINE_SIZE.get(args.task, (4096, 128, ""))
     candidates = args.candidates or n0
-    total = candidates * world
+    total = candidates if args.scaling == "strong" else candidates * world
     q, r = divmod(total, world)                      # the planners' split: the first N % world ranks hold one more candidate
     begin = rank * q + min(rank, r)
     count = q + (1 if rank < r else 0)
@@ -388,7 +511,7 @@ def dry_run(args, rank, world):
         assert elapsed >= 0.01 * world * args.steps
         print(json.dumps({"metric": "candidate-trajectory rollouts/sec (fixed horizon)", "value": None, "unit": "rollouts/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dry_run": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dry_run": True,
                           "config": {"workload": f"{args.task} launcher dry run", "candidates_per_gpu": candidates,
                                      "ranges": "contiguous, first N % world ranks +1"}}), flush=True)
     if world > 1:
@@ -431,12 +554,18 @@ def main():
     n0, h0, _ = BASELINE_SIZE.get(args.task, (4096, 128, ""))
     candidates = args.candidates or n0
     H = args.horizon or h0
+    total = None
+    if args.scaling == "strong":   # the global batch is fixed; a rank's share is total / world (the first total % world ranks hold one more)
+        total = candidates
+        candidates = total // world + (1 if rank < total % world else 0)
+    if args.emulate_world > 1 and world == 1:
+        return emulate_strong(args, candidates, H, local_rank)
     main_line = run_config(args, args.task, args.planner, candidates, H, args.precision, args.steps, args.warmup, world, local_rank,
-                           group, want_cpu=not args.no_cpu_baseline and world == 1, rank=rank, native=native)
+                           group, want_cpu=not args.no_cpu_baseline and world == 1, rank=rank, native=native, total=total)
     if rank == 0:
         out = {"metric": "candidate-trajectory rollouts/sec (fixed horizon)", "value": main_line["value"], "unit": "rollouts/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_line["dtype"], "data": "synthetic",
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_line["dtype"], "data": "synthetic",
                "config": main_line["config"], "roofline": main_line["roofline"]}
         if "cpu_baseline" in main_line:
             out["cpu_baseline"] = main_line["cpu_baseline"]
@@ -462,6 +591,10 @@ def main():
                 except Exception as ex:
                     e = {"name": name, "error": repr(ex)}
                 extra.append(e)
+            try:
+                extra.append(run_testspeed(local_rank))
+            except Exception as ex:
+                extra.append({"name": "configs[0] testspeed closed loop", "error": repr(ex)})
             try:
                 extra.append(run_ilqg(local_rank))
             except Exception as ex:

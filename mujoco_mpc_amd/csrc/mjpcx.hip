@@ -22,6 +22,10 @@
 #include "quad_launch.h"
 #include <dlfcn.h>
 #include <mutex>
+#include <chrono>
+#include <memory>
+#include <thread>
+#include <condition_variable>
 #include <rccl/rccl.h>
 
 using namespace mjpcx;
@@ -356,6 +360,7 @@ struct mjpcx_ctx {
   // quad kernel (quad_kernel.h): four lanes per candidate; fp64 contexts of a model quad_build accepts
   bool quad_ok = false;       // MJPCX_NO_QUAD=1 keeps the wavefront-per-candidate kernels (A/B runs)
   bool quad_stamps = false;   // MJPCX_QUAD_STAMPS=1: phase cycle stamps of wavefront 0 (tuning aid; synchronises every rollout)
+  int quad_min_n = 4096;          // batches below this go to rollout_tree_kernel<A1> (MJPCX_QUAD_MIN_N)
   int quad_con_cap = 0;           // MJPCX_QUAD_CON_CAP=<n>: hand on candidates with more than n contacts in a lane (tests of the hand-on path)
   bool quad_no_fallback = false;  // MJPCX_QUAD_NO_FALLBACK=1: leave the handed-on candidates flagged (tuning: failure[] then carries reason and step)
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
@@ -749,7 +754,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         wt.stamp_step = c->stamp_step;
       }
       const WaveModel& wm = c->wh.m;
-      if (c->wh.registered == 0 && c->quad_ok && a.xfrc_scale == 0 && !wt.stamps) {
+      // A rank's share of the batch decides the kernel: the quad kernel packs 16 candidates into a wavefront, which fills the 1024 SIMDs
+      // at N = 16384 but leaves most of them idle below a quarter of that, where one wavefront per candidate (a third of the latency per
+      // step) is quicker -- measured cross-over on MI355X: N = 4096 (tools/quad_n_sweep.py; MJPCX_QUAD_MIN_N moves it)
+      if (c->wh.registered == 0 && c->quad_ok && a.xfrc_scale == 0 && !wt.stamps && N >= c->quad_min_n) {
         le = launch_quad(c, wm, wt, a, N, P);
       } else if (c->wh.registered == 0) {
         le = launch_tree<TreeCfgA1, double>(c, wm, wt, a, c->wh.dev_image, c->wh.blob_bytes, N, P);
@@ -923,6 +931,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       c->quad_stamps = getenv("MJPCX_QUAD_STAMPS") != nullptr;
       c->quad_no_fallback = getenv("MJPCX_QUAD_NO_FALLBACK") != nullptr;
       if (const char* e = getenv("MJPCX_QUAD_CON_CAP")) c->quad_con_cap = std::atoi(e);
+      if (const char* e = getenv("MJPCX_QUAD_MIN_N")) c->quad_min_n = std::atoi(e);
       if (precision == 64 && !getenv("MJPCX_NO_QUAD")) {
         // the quad kernel family (four lanes per candidate): models of the legged class quad_build accepts
         std::vector<unsigned char> hq, ht;
@@ -1799,8 +1808,29 @@ int mjpcx_comm_init(mjpcx_ctx* c, const void* unique_id, int rank, int world) {
   HIPCHK(c, hipSetDevice(c->device));
   ncclUniqueId id;
   std::memcpy(&id, unique_id, sizeof id);
-  ncclComm_t comm = nullptr;
-  NCCLCHK(c, R->CommInitRank(&comm, world, id, rank));
+  // ncclCommInitRank blocks until every rank of the world has joined: a rank that never arrives (a crashed peer, a mismatched id) would
+  // hang the planner for good. The call runs on a helper thread with a deadline (MJPCX_COMM_TIMEOUT_S, default 120 s); past it the
+  // context stays without a communicator, the caller gets MJPCX_EDEVICE and can fall back to its own transport (bench.py does).
+  struct InitState { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t rc = ncclSuccess; ncclComm_t comm = nullptr; };
+  auto st = std::make_shared<InitState>();
+  const int device = c->device;
+  std::thread([st, R, world, id, rank, device]() {
+    (void)hipSetDevice(device);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rc = R->CommInitRank(&comm, world, id, rank);
+    std::lock_guard<std::mutex> lk(st->m);
+    st->rc = rc; st->comm = comm; st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  double deadline = 120.0;
+  if (const char* e = getenv("MJPCX_COMM_TIMEOUT_S")) deadline = std::atof(e);
+  {
+    std::unique_lock<std::mutex> lk(st->m);
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(deadline), [&] { return st->done; }))
+      return fail(c, MJPCX_EDEVICE, "ncclCommInitRank did not complete within MJPCX_COMM_TIMEOUT_S: a rank of the world is missing");
+  }
+  NCCLCHK(c, st->rc);
+  ncclComm_t comm = st->comm;
   c->comm = comm;
   c->comm_rank = rank;
   c->comm_world = world;

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -102,7 +103,8 @@ def test_two_ranks_equal_one_rank():
             assert np.allclose(np.array(a["plan"]), np.array(b["plan"]), rtol=0, atol=1e-14)
 
 
-def test_bench_launcher_dry_run_at_world_size_two():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_launcher_dry_run_at_world_size_two(scaling):
     """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank, 127.0.0.1), with
     --dry-run taking the device out: rendezvous, the communicator-id broadcast, the candidate split and the max-over-ranks timing
     run for real; rank 0 prints exactly one JSON line."""
@@ -116,11 +118,11 @@ def test_bench_launcher_dry_run_at_world_size_two():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run",
-           "--candidates", "4097"]
+           "--candidates", "4097", "--scaling", scaling]  # (strong: 4097 is the global batch, 2049 + 2048; weak: each rank's)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["dry_run"] is True and line["scaling"] == "weak"
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["dry_run"] is True and line["scaling"] == scaling
     assert line["ms_per_step"] >= 20.0          # the slower rank (2 x 10 ms per step), not rank 0's own 10 ms

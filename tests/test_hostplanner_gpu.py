@@ -387,3 +387,52 @@ def test_agent_integrator_rk4_reaches_the_device_through_the_cpp_planner():
         plans[name] = (cpp.best_score, cpp.policy()[1].copy())
         cpp.close()
     assert plans["euler"][0] != plans["rk4"][0]
+
+
+def test_a_missing_rank_does_not_hang_the_communicator():
+    """mjpcx_comm_init with a world of 2 and nobody else joining: ncclCommInitRank would block for good; the library gives up after
+    MJPCX_COMM_TIMEOUT_S and reports MJPCX_EDEVICE, so a planner can fall back to its own transport. (In a child process: the abandoned
+    RCCL bootstrap thread stays blocked until the process ends.)"""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys, time
+os.environ["MJPCX_COMM_TIMEOUT_S"] = "4"
+from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.hostplanner import comm_unique_id
+from mujoco_mpc_amd.task import load_task
+L = capi.lib()
+t = load_task("Particle")
+ctx = capi.Context(t.packed_model(), t.packed(), 0, 64)
+uid = C.create_string_buffer(comm_unique_id(), 128)
+t0 = time.time()
+rc = L.mjpcx_comm_init(ctx.handle, uid, 0, 2)
+dt = time.time() - t0
+rank, world = C.c_int(-1), C.c_int(-1)
+L.mjpcx_comm_info(ctx.handle, C.byref(rank), C.byref(world))
+print("RESULT", rc, round(dt, 1), world.value, flush=True)
+os._exit(0)
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, out.stdout + out.stderr
+    rc, dt, world = line[0].split()[1:]
+    assert int(rc) == -3 and 3.0 <= float(dt) < 30.0 and int(world) == 1   # MJPCX_EDEVICE, after the deadline, no communicator
+
+
+def test_a_sharded_planner_without_a_transport_says_so(particle):
+    """world > 1 with neither exchange callbacks nor a communicator of that size: the library's exchange would be the identity and every
+    rank would silently keep its own best -- the planners refuse instead (MJPCX_ESTATE)"""
+    from mujoco_mpc_amd.hostplanner import HostPlanner, lib
+    for kind in ("sampling", "cross_entropy"):
+        p = HostPlanner(particle, seed=3, num_trajectory=64, kind=kind)
+        if kind == "sampling":
+            assert lib().mjpc_planner_set_sharding(p.h, 0, 2, None, None) == 0
+        else:
+            assert lib().mjpc_planner_set_sharding_ce(p.h, 0, 2, None, None, None) == 0
+        p.reset(10)
+        p.set_state(np.zeros(2), np.zeros(2), 0.0, mocap_pos=np.array([[0.2, 0.1, 0.01]]), mocap_quat=np.array([[1.0, 0, 0, 0]]))
+        with pytest.raises(RuntimeError, match="communicator of its world size"):
+            p.optimize_policy(10)
+        p.close()
