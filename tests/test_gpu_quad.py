@@ -28,8 +28,9 @@ def quad():
 
 
 def context(t, env=None):
-    old = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})
+    env = dict({"MJPCX_QUAD_MIN_N": "0"}, **(env or {}))  # (batches below 4096 go to the wavefront-per-candidate kernel otherwise)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         ctx = capi.Context(t.packed_model(), t.packed(), 0, 64)
     finally:

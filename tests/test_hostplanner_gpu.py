@@ -424,13 +424,14 @@ os._exit(0)
 def test_a_sharded_planner_without_a_transport_says_so(particle):
     """world > 1 with neither exchange callbacks nor a communicator of that size: the library's exchange would be the identity and every
     rank would silently keep its own best -- the planners refuse instead (MJPCX_ESTATE)"""
-    from mujoco_mpc_amd.hostplanner import HostPlanner, lib
+    import ctypes as C
+    from mujoco_mpc_amd.hostplanner import EXCHANGE_FN, MERGE_TOPK_FN, SUM_FN, HostPlanner, lib
     for kind in ("sampling", "cross_entropy"):
         p = HostPlanner(particle, seed=3, num_trajectory=64, kind=kind)
         if kind == "sampling":
-            assert lib().mjpc_planner_set_sharding(p.h, 0, 2, None, None) == 0
+            assert lib().mjpc_planner_set_sharding(p.h, 0, 2, C.cast(None, EXCHANGE_FN), None) == 0
         else:
-            assert lib().mjpc_planner_set_sharding_ce(p.h, 0, 2, None, None, None) == 0
+            assert lib().mjpc_planner_set_sharding_ce(p.h, 0, 2, C.cast(None, MERGE_TOPK_FN), C.cast(None, SUM_FN), None) == 0
         p.reset(10)
         p.set_state(np.zeros(2), np.zeros(2), 0.0, mocap_pos=np.array([[0.2, 0.1, 0.01]]), mocap_quat=np.array([[1.0, 0, 0, 0]]))
         with pytest.raises(RuntimeError, match="communicator of its world size"):

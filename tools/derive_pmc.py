@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gpurun_out/pmc/summary.json (tools/pmc_rollout.sh, tools/summarize_pmc.py) -> the per-build counter summary bench.py reads
-(profiles/r02_pmc_<task>_fp<prec>.json): python tools/derive_pmc.py <summary.json> <task> <candidates> <horizon> <precision> <out.json>
+(profiles/r03_pmc_<task>_fp<prec>.json): python tools/derive_pmc.py <summary.json> <task> <candidates> <horizon> <precision> <out.json>
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB per dispatch; the x2 is MI355X_MICROARCH.md's gfx950 correction for wide reads).
 The summary is tied to the code it profiled by the sha256 of the kernel sources (bench.kernel_source_sha16); bench.py ignores it
 for any other source state."""
@@ -24,7 +24,9 @@ m = t.packed_model().struct
 nr, ntr = t.packed().struct.num_residual, t.packed().struct.num_trace
 wsz = 8 if prec == 64 else 4
 per_rollout = wsz * (H * (m.nq + m.nv + m.nu + 1 + nr + 3 * ntr + 1) + P * m.nu + P + 2)  # == mjpcx_algorithmic_bytes
-waves_steps = N * H
+# per wavefront and step: the quad kernel packs 16 candidates into a wavefront, the lane kernels 64, the others take one each
+per_wave = 16 if "rollout_quad" in name else (64 if "lane" in name else 1)
+waves_steps = (N + per_wave - 1) // per_wave * H
 out = dict(c)
 out.update({
     "kernel": name, "task": task, "candidates": N, "horizon": H, "precision": prec,
@@ -40,7 +42,7 @@ out.update({
         "active_inst_any_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_ACTIVE_INST_ANY" in c else None,
         "lds_bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
         "icache_hit_frac": c["SQC_ICACHE_HITS"] / c["SQC_ICACHE_REQ"] if c.get("SQC_ICACHE_REQ") else None,
-        "wavefronts_per_cu": None,
+        "candidates_per_wavefront": per_wave,
     },
     "other_kernels": {k: v for k, v in summary.items() if k != name},
 })

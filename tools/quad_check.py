@@ -4,6 +4,7 @@ share of candidates handed to the fallback kernel (MJPCX_QUAD_STATS=1), and the 
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MJPCX_QUAD_STATS", "1")
+os.environ.setdefault("MJPCX_QUAD_MIN_N", "0")  # (the 64-candidate parity batches would go to the wavefront-per-candidate kernel otherwise)
 import numpy as np
 from mujoco_mpc_amd import capi
 from mujoco_mpc_amd.task import load_task
