@@ -143,3 +143,39 @@ def test_cpp_predictive_sampling_on_the_humanoid_equals_python_planner():
         assert np.array_equal(cv, py.policy.plan.values())
         scores.append(cpp.best_score)
     assert "rollout_wave_kernel" in cpp.kernel_name and scores[-1] <= scores[0]
+
+
+def test_a_folded_body_with_more_contacts_than_the_kernel_stages():
+    """a folded humanoid pressed into the floor: 36 contacts / 135 constraint rows in the oracle (MuJoCo-sized arena). The generic
+    wavefront-per-candidate kernel still carries round 1's staging limits for THIS model class (the A1's kernels do not: DESIGN 2), so
+    what must hold is that it never returns a silently truncated rollout: either it rolls the candidates out like the oracle, or it
+    says it could not (failure flag set where the oracle's is not)."""
+    t = load_task("HumanoidTrack")
+    e = t.transition(0.0, mode=0)
+    q = np.array([-0.04934, -0.00198, 0.032594, 0.351929, -0.166098, 0.001753, 0.92117, -0.571485, 0.278631, -0.418609, 0.178522, 0.04022,
+                  0.050714, 0.63989, -0.043285, 0.662039, 0.162139, 0.387659, -0.046413, 0.214907, 0.638488, 0.143949, 0.316314, -0.489671,
+                  -0.674248, 0.724606, -0.506946, -0.298564])
+    q[3:7] /= np.linalg.norm(q[3:7])
+    pm, pt = t.packed_model(), t.packed()
+    mocap = mocap7(e["mocap_pos"])
+    ph = pyoracle.Physics(pm)
+    ph.set_state(q, np.zeros(27), 0.0, mocap)
+    ph.set_ctrl(np.zeros(21))
+    ph.forward_task(pt)
+    assert int(ph.get("ncon")[0]) > 16 and int(ph.get("nefc")[0]) > 64
+    N, H, P = 2, 4, 2
+    dt = t.model.get_number("agent_timestep", t.model.timestep)
+    times = np.arange(P) * max((H - 1) * dt, 1e-3)
+    nodes = np.zeros((N, P, t.model.nu))
+    state = np.concatenate([q, np.zeros(27)])
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(state, 0.0, mocap)
+    ctx.rollout_splines(H, 0, times, nodes)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, N, H, P, 0, times, nodes, num_threads=2)
+    for c in range(N):
+        if fail[c] == ref["failure"][c]:
+            assert close(ret[c], ref["total_return"][c], 1e-6)
+        else:
+            assert fail[c] != 0 and ret[c] == 1.0e6   # refused, not truncated
+    ctx.close()

@@ -96,6 +96,32 @@ def test_particle_copy_residual_equals_state(particle_copy):
     compare_batch(particle_copy, np.zeros(4), 0.0, mocap, N, H, P, 1, np.linspace(0, 2.9, P), random_nodes(2, N, P, 2))
 
 
+def test_rollouts_that_diverge_midway_match_up_to_the_failing_step(cartpole):
+    """a pole spinning at 1e4 rad/s blows the integration up after a dozen steps (mjWARN_BADQACC, trajectory.cc:169-173): the rollout
+    stops there with the return 1e6, and what it recorded before -- states, actions, residual, trace up to and including the failing step,
+    costs before it -- is the oracle's (the candidates fail at different steps: 11 and 20 in the oracle)"""
+    pm, pt = cartpole.packed_model(), cartpole.packed()
+    N, H, P = 2, 60, 2
+    nodes = np.zeros((N, P, 1)); nodes[1] = 1.0
+    state = [0.0, 0.1, 0.0, 1e4]
+    ctx = capi.Context(pm, pt, 0, 64)
+    ctx.set_state(state, 0.0)
+    ctx.rollout_splines(H, 0, [0.0, 0.1], nodes)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, None, N, H, P, 0, [0.0, 0.1], nodes)
+    assert fail.all() and ref["failure"].all() and np.all(ret == 1.0e6)
+    steps = []
+    for c in range(N):
+        last = int(np.max(np.nonzero(np.abs(ref["states"][c]).sum(axis=1))[0]))   # the failing step: the last row the oracle wrote
+        steps.append(last)
+        tr = ctx.fetch_trajectory(c)
+        for name in ("states", "actions", "residual", "trace"):
+            assert close(getattr(tr, name)[:last + 1], ref[name][c][:last + 1], 1e-6), (name, c)
+        assert close(tr.costs[:last], ref["costs"][c][:last], 1e-6)
+    assert steps[0] != steps[1] and min(steps) > 3
+    ctx.close()
+
+
 def test_divergent_candidates_flagged(cartpole):
     pm, pt = cartpole.packed_model(), cartpole.packed()
     ctx = capi.Context(pm, pt, 0, 64)
