@@ -873,6 +873,10 @@ __global__ __launch_bounds__(64) void rollout_lane_kernel(const LaneModel<T> m_k
         bad_ctrl |= is_bad(ctrl[k]);  // mjWARN_BADCTRL; tested before Clamp, which may not propagate NaN
         ctrl[k] = clampv(ctrl[k], m.act_ctrlrange[k][0], m.act_ctrlrange[k][1]);
       }
+      if (bad_ctrl) {  // mj_fwdActuation: a bad control zeroes ALL controls for this forward pass (the failing step's residual sees 0)
+#pragma unroll
+        for (int k = 0; k < NU; k++) ctrl[k] = 0;
+      }
     }
     // (last step: mj_forward with the previous control still in data->ctrl; the recorded
     //  action is a copy of the previous one, trajectory.cc:190-198)
