@@ -953,6 +953,11 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     set_norm_params(c, t->norm_parameter);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
     g_create_error = c->wh.warning;  // (empty, or what this context does NOT model of the caller's mjModel)
+    // a model the Jacobian-free path could serve, but with no registered configuration (dimensions in tree_registry.h): it runs -- on the
+    // generic kernel, at a fraction of the registered kernel's rate. Say so instead of leaving the caller to find out from the clock.
+    if (c->wh.tree_ok && c->wh.registered != 0 && !c->no_tree && !c->no_lds_model)
+      g_create_error += std::string(g_create_error.empty() ? "" : "; ") + "note: no registered kernel configuration for this model's dimensions (tree_registry.h): "
+                        "served by the generic wavefront-per-candidate kernel";
     *out = c;
     return MJPCX_OK;
   }

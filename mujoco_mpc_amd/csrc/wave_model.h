@@ -19,8 +19,8 @@
 namespace mjpcx {
 
 constexpr int kWaveMaxBody = 64, kWaveMaxDof = 32, kWaveMaxGeom = 64, kWaveMaxLevel = 16;
-constexpr int kWaveMaxCon = 16;   // contacts kept per step (further ones are dropped, as in the oracle)
-constexpr int kWaveMaxEfc = 64;   // constraint rows kept per step
+constexpr int kWaveMaxCon = 16;   // contacts the row-table kernels stage per step: a candidate with more is FLAGGED (failure), not truncated --
+constexpr int kWaveMaxEfc = 64;   // constraint rows likewise. (The oracle carries a MuJoCo-sized arena; the Jacobian-free kernels have no such cap.)
 
 template <typename T>
 struct WaveModelT {

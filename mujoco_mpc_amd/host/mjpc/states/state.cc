@@ -29,24 +29,34 @@ void State::Set(const mjModel* model, const double* qpos, const double* qvel, co
                 const double* mocap_pos, const double* mocap_quat, const double* userdata, double time) {
   const std::unique_lock<std::shared_mutex> lock(mtx_);
   Resize(model);
-  SetPosition(model, qpos);
-  SetVelocity(model, qvel);
-  SetAct(model, act);
-  SetMocap(model, mocap_pos, mocap_quat);
-  SetUserData(model, userdata);
-  SetTime(model, time);
+  PutPosition(model, qpos);
+  PutVelocity(model, qvel);
+  PutAct(model, act);
+  PutMocap(model, mocap_pos, mocap_quat);
+  PutUserData(model, userdata);
+  time_ = time;
 }
-void State::SetPosition(const mjModel* m, const double* qpos) { mju_copy(state_.data(), qpos, m->nq); }
-void State::SetVelocity(const mjModel* m, const double* qvel) { mju_copy(state_.data() + m->nq, qvel, m->nv); }
-void State::SetAct(const mjModel* m, const double* act) { if (m->na) mju_copy(state_.data() + m->nq + m->nv, act, m->na); }
-void State::SetMocap(const mjModel* m, const double* mocap_pos, const double* mocap_quat) {
+// the single-field setters are public (the reference's simulation thread uses them one by one) and take the lock themselves; Set()
+// holds it once around the unlocked Put* helpers
+void State::PutPosition(const mjModel* m, const double* qpos) { mju_copy(state_.data(), qpos, m->nq); }
+void State::PutVelocity(const mjModel* m, const double* qvel) { mju_copy(state_.data() + m->nq, qvel, m->nv); }
+void State::PutAct(const mjModel* m, const double* act) { if (m->na) mju_copy(state_.data() + m->nq + m->nv, act, m->na); }
+void State::PutMocap(const mjModel* m, const double* mocap_pos, const double* mocap_quat) {
   for (int i = 0; i < m->nmocap; i++) {
     mju_copy(mocap_.data() + 7 * i, mocap_pos + 3 * i, 3);
     mju_copy(mocap_.data() + 7 * i + 3, mocap_quat + 4 * i, 4);
   }
 }
-void State::SetUserData(const mjModel* m, const double* userdata) { if (m->nuserdata) mju_copy(userdata_.data(), userdata, m->nuserdata); }
-void State::SetTime(const mjModel*, double time) { time_ = time; }
+void State::PutUserData(const mjModel* m, const double* userdata) { if (m->nuserdata) mju_copy(userdata_.data(), userdata, m->nuserdata); }
+void State::SetPosition(const mjModel* m, const double* qpos) { const std::unique_lock<std::shared_mutex> lock(mtx_); PutPosition(m, qpos); }
+void State::SetVelocity(const mjModel* m, const double* qvel) { const std::unique_lock<std::shared_mutex> lock(mtx_); PutVelocity(m, qvel); }
+void State::SetAct(const mjModel* m, const double* act) { const std::unique_lock<std::shared_mutex> lock(mtx_); PutAct(m, act); }
+void State::SetMocap(const mjModel* m, const double* mocap_pos, const double* mocap_quat) {
+  const std::unique_lock<std::shared_mutex> lock(mtx_);
+  PutMocap(m, mocap_pos, mocap_quat);
+}
+void State::SetUserData(const mjModel* m, const double* userdata) { const std::unique_lock<std::shared_mutex> lock(mtx_); PutUserData(m, userdata); }
+void State::SetTime(const mjModel*, double time) { const std::unique_lock<std::shared_mutex> lock(mtx_); time_ = time; }
 void State::CopyTo(double* dst_state, double* dst_mocap, double* dst_userdata, double* dst_time) const {
   const std::shared_lock<std::shared_mutex> lock(mtx_);
   mju_copy(dst_state, state_.data(), (int)state_.size());

@@ -31,6 +31,12 @@ class State {
 
  private:
   void Resize(const mjModel* model);
+  // unlocked bodies of the setters (callers hold mtx_)
+  void PutPosition(const mjModel* model, const double* qpos);
+  void PutVelocity(const mjModel* model, const double* qvel);
+  void PutAct(const mjModel* model, const double* act);
+  void PutMocap(const mjModel* model, const double* mocap_pos, const double* mocap_quat);
+  void PutUserData(const mjModel* model, const double* userdata);
   std::vector<double> state_, mocap_, userdata_;
   double time_ = 0;
   mutable std::shared_mutex mtx_;

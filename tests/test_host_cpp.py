@@ -39,6 +39,19 @@ def test_task_and_state_suites(blobs):
     assert "OK" in run("state_test", os.path.join(blobs, "Particle.mjpx"))
 
 
+def test_shared_classes_under_thread_sanitizer(blobs):
+    """`make tsan` (host/Makefile): State -- one writer through Set / SetTime, three readers through CopyTo, no torn snapshot -- and
+    ThreadPool -- rounds of Schedule / WaitCount / ResetCount -- built with -fsanitize=thread, with the reference's own state and
+    thread-pool tests beside them; a report ends the run (halt_on_error)"""
+    r = subprocess.run(["make", "-C", HOST, "-s", "tsan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1")
+    for exe in ("concurrency_test", "state_test", "threadpool_test"):
+        out = subprocess.run([os.path.join(HOST, "build", "tsan", exe), os.path.join(blobs, "Particle.mjpx")], capture_output=True, text=True,
+                             timeout=600, env=env)
+        assert out.returncode == 0 and "OK" in out.stdout and "ThreadSanitizer" not in out.stderr, exe + ": " + out.stderr[-2000:]
+
+
 def test_host_code_names_mujoco_by_its_public_header():
     """every mjpc/ header reaches MuJoCo's types through <mujoco/mujoco.h> (host/include/mujoco/mujoco.h forwards to the subset this
     build carries), so the host layer is source-compatible with a real MuJoCo include path; a TU that only knows the public name
