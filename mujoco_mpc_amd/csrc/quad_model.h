@@ -69,6 +69,7 @@ struct QuadLeg {
   int limited[kQLinks], act_biastype[kQLinks], ctrllimited[kQLinks], forcelimited[kQLinks];
   int ngeom, foot_slot, foot_index, npg;  // foot_slot: the leg's geom the residual reads; foot_index: its place in foot_geom_id_ (FL HL FR HR)
   int pg_slot[kQPairGeom];                // the leg's sphere | capsule geoms that can touch another leg or the trunk (self-collision test)
+  double pg_reach[kQPairGeom];              // radius of the pair geom's bounding sphere about its centre (capsule: radius + half length)
   unsigned long long pg_first[kQLegs + 1];  // per other leg (kQLegs: the trunk), bit 8 i + j: the own pair geom i is geom1 of the pair with the other's j
   QuadGeom geom[kQLegGeom];
 };
@@ -90,6 +91,7 @@ struct QuadModel {
   // self-collision: the moving-geom pairs MuJoCo's filters leave are ALL pairs (leg geom, geom of another leg) and (trunk geom, leg geom)
   // over these sets (checked by quad_build); the kernel only tests them -- a pair within pair_margin hands the candidate on
   int ntpg, tpg_slot[kQTrunkPairGeom];
+  double tpg_reach[kQTrunkPairGeom];  // bounding-sphere radii of the trunk's pair geoms (as QuadLeg::pg_reach)
   double pair_margin;
   // friction sets of the contact pairs: regularised mu, then the tangential / torsional / rolling coefficient, ZERO for rows the pair's
   // condim does not have (the cone formulas then reduce to the lower condim's)
@@ -388,6 +390,11 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
         if (own == g1) qm->leg[slot_leg[own]].pg_first[slot_leg[other] < 0 ? kQLegs : slot_leg[other]] |= 1ull << (8 * pg_index(own) + pg_index(other));
       }
     }
+  }
+  {
+    auto reach = [](const QuadGeom& g) { return g.size[0] + (g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0); };
+    for (int l = 0; l < kQLegs; l++) for (int i = 0; i < qm->leg[l].npg; i++) qm->leg[l].pg_reach[i] = reach(qm->leg[l].geom[qm->leg[l].pg_slot[i]]);
+    for (int j = 0; j < qm->ntpg; j++) qm->tpg_reach[j] = reach(qm->trunk_geom[qm->tpg_slot[j]]);
   }
   qm->npair = qt->npair;
 
