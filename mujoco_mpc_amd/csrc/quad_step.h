@@ -529,12 +529,10 @@ enum { kEvalKeep = 0, kEvalStep = 2 };
 // hessian_blocks).
 template <bool MULTI, class CS>
 QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows& R, CS& cs, int ncon, int what, const double* xl, const double Vp[4][6], double alpha,
-                    double* jl, double* jt, double* X, int& nshallow, int pmask) {
+                    double* jl, double* jt, int pmask) {
   double cost = 0;
   double Fown[6];
   QUNROLL for (int c = 0; c < 6; c++) Fown[c] = 0;
-  QUNROLL for (int e = 0; e < 21; e++) X[e] = 0;
-  nshallow = 0;
   QUNROLL for (int j = 0; j < 3; j++) {
     if (what == kEvalStep) { R.fl_jar[j] += alpha * xl[j]; R.lm_jar[j] += alpha * (-R.lm_side[j] * xl[j]); }
     double f = 0;
@@ -572,11 +570,10 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
         if (zone != 0) { QUNROLL for (int j = 0; j < 3; j++) if (j < c.depth) jl[j] += c.sgn * dot6(kin.cdof[j], Fs); }
         continue;
       }
-      cost += contact_eval(c, m.fric[c.fid], Fs, X, zone);
+      cost += contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
       if (zone == 0) continue;
       QUNROLL for (int k = 0; k < 6; k++) Fown[k] += Fs[k];
       if (c.depth < 3) {  // rare: a contact on the trunk (this lane's share), the hip or the thigh link does not act on the dofs below it
-        nshallow++;
         QUNROLL for (int j = 0; j < 3; j++) if (j >= c.depth) jl[j] -= dot6(kin.cdof[j], Fs);
       }
     }
@@ -586,6 +583,24 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
   qd_sum_n(Fown, 6);
   QUNROLL for (int k = 0; k < 6; k++) jt[k] = trunk_dot(kin, k, Fown);
   return qd_sum(cost);
+}
+// The sum of the lane's contacts' Hessian blocks at the current jar (packed 6 x 6 over [angular; linear]; NOT yet quad-summed), for the
+// iteration that is about to factor: a pass of its own, so that the cost / force passes (two per step more than there are
+// factorisations, and the line search between them) do not carry 21 accumulators. nshallow counts the lane's contacts in a penalty
+// zone whose body is not the last link (their blocks need the correction of hessian_common).
+template <class CS>
+QD void rows_X(const QuadModel& m, CS& cs, int ncon, double* X, int& nshallow) {
+  QUNROLL for (int e = 0; e < 21; e++) X[e] = 0;
+  nshallow = 0;
+  for (int i = 0; i < ncon; i++) {
+    QContact c;
+    qcs_load(cs, i, c);
+    if (c.rel) continue;  // (self-collision contacts: hessian_blocks walks them itself)
+    double Fs[6] = {0, 0, 0, 0, 0, 0};
+    int zone;
+    (void)contact_eval(c, m.fric[c.fid], Fs, X, zone);
+    if (zone != 0 && c.depth < 3) nshallow++;
+  }
 }
 // jar += alpha J x and nothing else (the way back from a rejected warm start)
 template <bool MULTI, class CS>
@@ -952,8 +967,6 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
   iters = 0;
   // !GENERAL: one pair pattern (or none), the super-leg factorisation; GENERAL: the dense elimination of the leg blocks
   const int pmode = GENERAL ? 0 : (next_x(pmask, 0) & 3);
-  double X[21];
-  int nshallow;
   QUNROLL for (int j = 0; j < 3; j++) al[j] = sl[j];
   QUNROLL for (int k = 0; k < 6; k++) at[k] = st[k];
   double Mal[3] = {0, 0, 0}, Mat[6] = {0, 0, 0, 0, 0, 0};  // M (qacc - qacc_smooth), carried through the iterations
@@ -962,7 +975,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
   {
     double Vp[4][6];
     chain_velocity(kin, al, at, Vp);
-    cost = rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, al, Vp, 1.0, fc_l, fc_t, X, nshallow, pmask);  // jar = J qacc_smooth - aref; the Gauss term is zero here
+    cost = rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, al, Vp, 1.0, fc_l, fc_t, pmask);  // jar = J qacc_smooth - aref; the Gauss term is zero here
     QPROF(pf, 14);
     if (have_warm) {
       double dl[3], dt[6], Ml[3], Mt[6];
@@ -970,17 +983,15 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       QUNROLL for (int k = 0; k < 6; k++) dt[k] = wt[k] - st[k];
       arrow_mul_s(ms, dl, dt, Ml, Mt);
       const double gauss = 0.5 * arrow_dot(dl, dt, Ml, Mt);
-      double jl[3], jt[6], Xw[21];
-      int nsw;
+      double jl[3], jt[6];
       chain_velocity(kin, dl, dt, Vp);  // the rows move from qacc_smooth to the warm start along their difference
-      const double cw = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, 1.0, jl, jt, Xw, nsw, pmask);
+      const double cw = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, dl, Vp, 1.0, jl, jt, pmask);
       if (cw < cost) {
-        cost = cw; nshallow = nsw;
+        cost = cw;
         QUNROLL for (int j = 0; j < 3; j++) { al[j] = wl[j]; fc_l[j] = jl[j]; Mal[j] = Ml[j]; }
         QUNROLL for (int k = 0; k < 6; k++) { at[k] = wt[k]; fc_t[k] = jt[k]; Mat[k] = Mt[k]; }
-        QUNROLL for (int e = 0; e < 21; e++) X[e] = Xw[e];
       } else {
-        rows_step_only<GENERAL>(L, R, cs, ncon, dl, Vp, -1.0, pmask);  // and back: the first pass's cost, forces and Hessian blocks are still held
+        rows_step_only<GENERAL>(L, R, cs, ncon, dl, Vp, -1.0, pmask);  // and back: the first pass's cost and forces are still held
       }
     }
   }
@@ -1000,6 +1011,9 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
     if (gnorm == 0) break;
     if (iter > 0 && (scale * improvement < m.tolerance || scale * gnorm < m.tolerance)) break;
     QPROF(pf, 8);
+    double X[21];
+    int nshallow;
+    rows_X(m, cs, ncon, X, nshallow);
     if constexpr (GENERAL) {
       if (!newton_direction_general(m, L, kin, ms, R, cs, ncon, X, nshallow, leg, pmask, hl, ht)) return kFlagNotPD;
     } else {
@@ -1037,7 +1051,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       QUNROLL for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
       arrow_mul_s(ms, dl, dt, Mal, Mat);
       const double gauss = 0.5 * arrow_dot(dl, dt, Mal, Mat);
-      const double newcost = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, X, nshallow, pmask);
+      const double newcost = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, pmask);
       improvement = cost - newcost;
       cost = newcost;
     }
