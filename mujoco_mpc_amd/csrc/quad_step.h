@@ -692,11 +692,10 @@ QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, 
 // rtsafe safeguard). Out of line on the device, like the solver itself: the loop's working set (the contacts' coefficients, the diagonal
 // rows) then has the register file to itself instead of competing with everything the iteration keeps alive around it.
 template <bool MULTI, class CS, class QProfT>
-QNOINLINE double line_search(const QuadModel& m, const QuadLeg& L, const QRows& R_in, CS& cs_in, int ncon, const double* hl_in, const double (*Vs)[6], int pmask,
+QNOINLINE double line_search(const QuadModel& m, const QuadLeg& L, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs)[6], int pmask,
                              double q1, double q2, double gtol, QProfT& pf) {
-  const QRows R = R_in;
-  CS cs = cs_in;
-  const double hl[3] = {hl_in[0], hl_in[1], hl_in[2]};
+  // (everything small arrives by value: an argument passed by reference pins the caller's copy in memory for the whole iteration)
+  const double hl[3] = {hl0, hl1, hl2};
   QLine ql[kQLineSlots];
   QRel rq;
   QPROF(pf, 40);
@@ -1041,7 +1040,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       double Vs[4][6];
       chain_velocity(kin, hl, ht, Vs);
       const double gtol = m.tolerance * kQLsTol * sqrt(snorm) / scale;
-      const double alpha = line_search<GENERAL>(m, L, R, cs, ncon, hl, Vs, pmask, q1, q2, gtol, pf);
+      const double alpha = line_search<GENERAL>(m, L, R, cs, ncon, hl[0], hl[1], hl[2], Vs, pmask, q1, q2, gtol, pf);
       QPROF(pf, 11);
       QUNROLL for (int j = 0; j < 3; j++) al[j] += alpha * hl[j];
       QUNROLL for (int k = 0; k < 6; k++) at[k] += alpha * ht[k];
