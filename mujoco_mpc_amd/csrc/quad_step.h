@@ -1050,7 +1050,9 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       QUNROLL for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
       arrow_mul_s(ms, dl, dt, Mal, Mat);
       const double gauss = 0.5 * arrow_dot(dl, dt, Mal, Mat);
-      const double newcost = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, pmask);
+      double Ve[4][6];  // (the chain velocities again: Vs was handed to the line search by address, which pins it in memory)
+      chain_velocity(kin, hl, ht, Ve);
+      const double newcost = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, hl, Ve, alpha, fc_l, fc_t, pmask);
       improvement = cost - newcost;
       cost = newcost;
     }
