@@ -1,6 +1,7 @@
 // wave_tree.h -- constraint pipeline of the wavefront-per-candidate kernels WITHOUT a stored constraint Jacobian
-// (per-precision include, see rollout_wave.h). Covers models with ONE moving kinematic tree, no tendon limits and elliptic or
-// frictionless cones -- the Quadruped class; contacts against static geoms and between two bodies of the tree.
+// (per-precision include, see rollout_wave.h). Covers models with ONE moving kinematic tree: elliptic, pyramidal or frictionless
+// contacts against static geoms and between two bodies of the tree, limits of joints and of fixed tendons -- the Quadruped and the
+// Humanoid of the BASELINE configs.
 //
 // Same primal problem and the same Newton iteration as wf_constraint_newton / oracle o_constraint_newton
 // (1/2 |a - a_smooth|^2_M + s(J a - a_ref), exact line search, MuJoCo's termination tests), but every product with J is
@@ -90,7 +91,12 @@ struct TreeRows {
   // frictionless contact, lane = index in the list
   bool s_on; wreal s_D, s_aref, s_jar, s_force; int s_zone;
   unsigned s_mp, s_mm;  // dofs with J = +A cdof (chain of body 2 only) / J = -A cdof (chain of body 1 only); other lanes read them with v_readlane
-  // cone, lane = index in the list (its rows are in LDS)
+  int s_pair, c_pair;   // both bodies move (body 1 may be an ANCESTOR of body 2: s_mm == 0, yet the dofs above body 1 cancel and must stay out of the Hessian rows)
+  // limits of fixed tendons, lane = tendon; side 0: lower bound (J = +coef), side 1: upper bound (J = -coef); the Jacobian is the
+  // tendon's wrap coefficients on the dofs of its joints (wt_tendon_coef)
+  bool t_on[2]; wreal t_D[2], t_aref[2], t_jar[2], t_force[2]; int t_zone[2];
+  // cone, lane = index in the list (its rows are in LDS). Pyramidal cones (m.cone != 1) keep the same record: par[6] is the D of
+  // every edge, c_zone is (mask of active edges) << 2 (0 = none: 'top'), c_Dm is unused
   bool c_on; int c_dim, c_zone;
   wreal c_Dm;  // D_normal / (mu^2 (1 + mu^2)): the cone's middle-zone stiffness (one division per step, not per line-search trial)
   unsigned c_mp, c_mm;
@@ -625,6 +631,52 @@ __device__ __forceinline__ void wt_cone_line(const wreal* x0, const wreal* v, wr
   }
 }
 
+// Pyramidal cone (oracle EFC_PYRAMID rows): 2 (dim - 1) edges  r = x_0 +- f_j x_j >= 0, each with the penalty 1/2 D min(0, r)^2.
+// Same order as the oracle's rows: (j = 1, +), (j = 1, -), (j = 2, +), ...; bit 2 (j - 1) + (0: +, 1: -) of the mask = edge active.
+__device__ __forceinline__ wreal wt_pyr_cost(const wreal* x, const wreal* par, int dim, wreal* force, int& zone) {
+  const wreal D = par[6];
+  wreal cost = 0;
+  int mask = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) force[j] = 0;
+#pragma unroll
+  for (int j = 1; j < 6; j++)
+    if (j < dim) {
+      const wreal f = par[j], rp = x[0] + f * x[j], rm = x[0] - f * x[j];
+      if (rp < 0) { cost += WL(0.5) * D * rp * rp; force[0] -= D * rp; force[j] -= D * f * rp; mask |= 1 << (2 * (j - 1)); }
+      if (rm < 0) { cost += WL(0.5) * D * rm * rm; force[0] -= D * rm; force[j] += D * f * rm; mask |= 2 << (2 * (j - 1)); }
+    }
+  zone = mask << 2;
+  return cost;
+}
+__device__ __forceinline__ void wt_pyr_line(const wreal* x0, const wreal* v, wreal alpha, const wreal* par, int dim, wreal& g1, wreal& h2) {
+  const wreal D = par[6], xn = x0[0] + alpha * v[0];
+  g1 = 0; h2 = 0;
+#pragma unroll
+  for (int j = 1; j < 6; j++)
+    if (j < dim) {
+      const wreal f = par[j], xj = x0[j] + alpha * v[j];
+      const wreal rp = xn + f * xj, rm = xn - f * xj, vp = v[0] + f * v[j], vm = v[0] - f * v[j];
+      if (rp < 0) { g1 += D * rp * vp; h2 += D * vp * vp; }
+      if (rm < 0) { g1 += D * rm * vm; h2 += D * vm * vm; }
+    }
+}
+// coefficient of fixed tendon i on dof k (0 if its Jacobian does not touch the dof): the wrap list is two or three entries long
+template <class MODEL>
+__device__ __forceinline__ wreal wt_tendon_coef(const MODEL& m, int i, int k) {
+  wreal c = 0;
+  for (int w = m.tendon_adr[i]; w < m.tendon_adr[i] + m.tendon_num[i]; w++)
+    if (m.jnt_dofadr[m.wrap_objid[w]] == k) c += m.wrap_prm[w];
+  return c;
+}
+// J v of this lane's tendon (lane < ntendon) for a vector v in LDS
+template <class MODEL>
+__device__ __forceinline__ wreal wt_tendon_jv(const MODEL& m, int lane, const wreal* v) {
+  wreal s = 0;
+  for (int w = m.tendon_adr[lane]; w < m.tendon_adr[lane] + m.tendon_num[lane]; w++) s += m.wrap_prm[w] * v[m.jnt_dofadr[m.wrap_objid[w]]];
+  return s;
+}
+
 // ---- rows: friction loss (lane = dof), joint limits (lane = joint), contacts (lane = list index); impedance, reference
 // acceleration and regulariser per row as o_make_constraint_full. J qvel of a contact row is the body's cvel projected.
 template <class MODEL>
@@ -633,7 +685,9 @@ __device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, 
   q.f_on = false; q.l_on[0] = q.l_on[1] = false; q.s_on = false; q.c_on = false;
   q.f_D = q.f_R = q.f_fl = q.f_aref = q.f_jar = q.f_force = 0; q.f_zone = kZoneTop;
   q.s_D = q.s_aref = q.s_jar = q.s_force = 0; q.s_zone = kZoneTop; q.c_dim = 0; q.c_zone = kZoneTop; q.s_mp = q.s_mm = q.c_mp = q.c_mm = 0; q.c_Dm = 0;
+  q.s_pair = q.c_pair = 0;
   for (int s = 0; s < 2; s++) { q.l_D[s] = q.l_aref[s] = q.l_jar[s] = q.l_force[s] = 0; q.l_zone[s] = kZoneTop; }
+  for (int s = 0; s < 2; s++) { q.t_on[s] = false; q.t_D[s] = q.t_aref[s] = q.t_jar[s] = q.t_force[s] = 0; q.t_zone[s] = kZoneTop; }
   q.l_dof = 0; q.jnt_of_dof = -1;
   if (lane < nv) {
     const int j = m.dof_jntid[lane], jt = m.jnt_type[j];
@@ -671,6 +725,26 @@ __device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, 
       }
     }
   }
+  // limits of fixed tendons (o_make_constraint_full, EFC_TENDON): length = sum coef q_joint
+  if (!(m.disableflags & MJPCX_DSBL_LIMIT) && lane < m.ntendon && m.tendon_limited[lane]) {
+    wreal value = 0;
+    for (int w = m.tendon_adr[lane]; w < m.tendon_adr[lane] + m.tendon_num[lane]; w++) value += m.wrap_prm[w] * d.qpos[m.jnt_qposadr[m.wrap_objid[w]]];
+    const wreal margin = m.tendon_margin[lane], jv = wt_tendon_jv(m, lane, d.qvel);
+    wreal kk, bb;
+    w_solref_kb(m, m.tendon_solref_lim + 2 * lane, m.tendon_solimp_lim + 5 * lane, kk, bb);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const wreal dist = s == 0 ? -(m.tendon_range[2 * lane] - value) : m.tendon_range[2 * lane + 1] - value;
+      if (dist < margin) {
+        const wreal pos = dist - margin;
+        const wreal imp = w_impedance(m.tendon_solimp_lim + 5 * lane, pos);
+        wreal R = (1 - imp) / imp * m.tendon_invweight0[lane];
+        if (R < kMinVal) R = kMinVal;
+        const wreal vel = s == 0 ? jv : -jv;
+        q.t_on[s] = true; q.t_D[s] = WL(1.0) / R; q.t_aref[s] = -bb * vel - kk * imp * pos;
+      }
+    }
+  }
   const int ns = __builtin_amdgcn_readfirstlane(t.cnt[0]), nc = __builtin_amdgcn_readfirstlane(t.cnt[1]);
   // frictionless contacts
   if (lane < ns) {
@@ -688,7 +762,7 @@ __device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, 
     wreal vel = 0;
     for (int e = 0; e < 6; e++) vel += t.s_a[6 * lane + e] * (d.cvel[6 * b2 + e] - d.cvel[6 * b1 + e]);
     q.s_on = true; q.s_D = WL(1.0) / R; q.s_aref = -bb * vel - kk * imp * pos;
-    { const unsigned m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2]; q.s_mp = m2 & ~m1; q.s_mm = m1 & ~m2; }
+    { const unsigned m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2]; q.s_mp = m2 & ~m1; q.s_mm = m1 & ~m2; q.s_pair = (m1 != 0 && m2 != 0) ? 1 : 0; }
   }
   // elliptic cones
   if (lane < nc)
@@ -704,7 +778,17 @@ __device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, 
       const wreal diag = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
       wreal R0 = (1 - imp) / imp * diag;
       if (R0 < kMinVal) R0 = kMinVal;
-      const wreal mu = cp.friction[0] / sqrt(m.impratio > kMinVal ? (wreal)m.impratio : WL(1.0));
+      const bool pyr = m.cone != 1;
+      const wreal mu = pyr ? cp.friction[0] : cp.friction[0] / sqrt(m.impratio > kMinVal ? (wreal)m.impratio : WL(1.0));
+      wreal Dpy = 0;
+      if (pyr) {  // every edge gets Rpy = 2 mu^2 R of the first edge, whose mj_diagApprox is tran + friction_0^2 tran (mj_makeImpedance)
+        const wreal f0 = cp.friction[0];
+        wreal R1 = (1 - imp) / imp * (diag + f0 * f0 * diag);
+        if (R1 < kMinVal) R1 = kMinVal;
+        wreal Rpy = 2 * mu * mu * R1;
+        if (Rpy < kMinVal) Rpy = kMinVal;
+        Dpy = WL(1.0) / Rpy;
+      }
       wreal geo[12]; wreal vel[6]; wreal cv[6];
       for (int e = 0; e < 12; e++) geo[e] = c.geo[e];
       for (int e = 0; e < 6; e++) cv[e] = d.cvel[6 * b2 + e] - d.cvel[6 * b1 + e];
@@ -717,11 +801,11 @@ __device__ __forceinline__ void wt_make_constraint(const MODEL& m, WaveData& d, 
         if (j >= 1) par[j] = cp.friction[j - 1];
         wreal Rj = R0;
         if (j >= 1) { const wreal f = cp.friction[j - 1]; Rj = R0 * (mu * mu) / (f * f); }
-        par[6 + j] = j < dim ? WL(1.0) / Rj : WL(0.0);
+        par[6 + j] = j < dim ? (pyr ? Dpy : WL(1.0) / Rj) : WL(0.0);
         aref[j] = j == 0 ? -bb * vel[0] - kk * imp * pos : -bb * vel[j];
       }
-      q.c_on = true; q.c_dim = dim; q.c_Dm = par[6] / (mu * mu * (1 + mu * mu));
-      { const unsigned m1 = m.body_dofmask[b1]; const unsigned m2 = m.body_dofmask[b2]; q.c_mp = m2 & ~m1; q.c_mm = m1 & ~m2; });
+      q.c_on = true; q.c_dim = dim; q.c_Dm = pyr ? WL(0.0) : par[6] / (mu * mu * (1 + mu * mu));
+      { const unsigned m1 = m.body_dofmask[b1]; const unsigned m2 = m.body_dofmask[b2]; q.c_mp = m2 & ~m1; q.c_mm = m1 & ~m2; q.c_pair = (m1 != 0 && m2 != 0) ? 1 : 0; });
   WSYNC();
 }
 
@@ -749,7 +833,7 @@ __device__ __forceinline__ wreal wt_pull_from_joint(wreal v_on_joint_lane, int j
 }
 
 // cost of all rows at the current jar (registers / c_jar); writes forces and zones (registers, s_fd, c_F). Wave-uniform sum.
-__device__ __forceinline__ wreal wt_cost(WaveData& d, TreeData& t, TreeRows& q, int lane) {
+__device__ __forceinline__ wreal wt_cost(WaveData& d, TreeData& t, TreeRows& q, int lane, bool pyr) {
   wreal cost = 0;
   if (q.f_on) {
     const wreal x = q.f_jar, f = q.f_fl, R = q.f_R, D = q.f_D;
@@ -764,6 +848,13 @@ __device__ __forceinline__ wreal wt_cost(WaveData& d, TreeData& t, TreeRows& q, 
       if (x < 0) { cost += WL(0.5) * D * x * x; q.l_force[s] = -D * x; q.l_zone[s] = kZoneBottom; }
       else { q.l_force[s] = 0; q.l_zone[s] = kZoneTop; }
     }
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+    if (q.t_on[s]) {
+      const wreal x = q.t_jar[s], D = q.t_D[s];
+      if (x < 0) { cost += WL(0.5) * D * x * x; q.t_force[s] = -D * x; q.t_zone[s] = kZoneBottom; }
+      else { q.t_force[s] = 0; q.t_zone[s] = kZoneTop; }
+    }
   if (q.s_on) {
     const wreal x = q.s_jar, D = q.s_D;
     if (x < 0) { cost += WL(0.5) * D * x * x; q.s_force = -D * x; q.s_zone = kZoneBottom; }
@@ -777,7 +868,7 @@ __device__ __forceinline__ wreal wt_cost(WaveData& d, TreeData& t, TreeRows& q, 
       for (int e = 0; e < 6; e++) x[e] = c.jar[e];
       for (int e = 0; e < 12; e++) par[e] = c.par[e];
       for (int e = 0; e < 12; e++) geo[e] = c.geo[e];
-      cost += wt_cone_cost(x, par, q.c_Dm, q.c_dim, force, q.c_zone);
+      cost += pyr ? wt_pyr_cost(x, par, q.c_dim, force, q.c_zone) : wt_cone_cost(x, par, q.c_Dm, q.c_dim, force, q.c_zone);
       // A' force = [off x F + sum_{j>=3} f_{j-3} force_j, F], F = sum_{j<3} f_j force_j
       wreal F[3] = {0, 0, 0}; wreal tq[3] = {0, 0, 0};
       _Pragma("unroll")
@@ -803,6 +894,10 @@ __device__ __forceinline__ wreal wt_jt_force(const MODEL& m, const WaveData& d, 
   wreal s = q.f_on ? q.f_force : WL(0.0);
   const wreal lim = (q.l_on[0] ? q.l_force[0] : WL(0.0)) - (q.l_on[1] ? q.l_force[1] : WL(0.0));
   s += wt_pull_from_joint(lim, q.jnt_of_dof);
+  for (int i = 0; i < m.ntendon; i++) {  // (wave-uniform trip count; the force of tendon i comes from its lane's registers)
+    const wreal fi = (wreal)__shfl((q.t_on[0] ? q.t_force[0] : WL(0.0)) - (q.t_on[1] ? q.t_force[1] : WL(0.0)), i, 64);
+    if (fi != 0 && lane < m.nv && ((m.tendon_dofmask[i] >> lane) & 1u)) s += wt_tendon_coef(m, i, lane) * fi;
+  }
   if (lane < m.nv) {
     wreal cd[6];
     for (int e = 0; e < 6; e++) cd[e] = d.cdof[6 * lane + e];
@@ -850,7 +945,8 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
   const int ns = __builtin_amdgcn_readfirstlane(t.cnt[0]), nc = __builtin_amdgcn_readfirstlane(t.cnt[1]);
   if (lane < nv) { d.qfrc_constraint[lane] = 0; d.qacc[lane] = d.qacc_smooth[lane]; }
   WSYNC();
-  const bool any_row = __any(q.f_on || q.l_on[0] || q.l_on[1] || q.s_on || q.c_on);
+  const bool pyr = m.cone != 1;
+  const bool any_row = __any(q.f_on || q.l_on[0] || q.l_on[1] || q.t_on[0] || q.t_on[1] || q.s_on || q.c_on);
   if (!any_row) return;
   // jar = J qacc - aref at a vector v (LDS, nv entries): registers for the lane-owned rows, c_jar for the cones
   auto set_jar = [&](const wreal* v) {
@@ -858,6 +954,11 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     if (q.f_on) q.f_jar = v[lane] - q.f_aref;
     if (q.l_on[0]) q.l_jar[0] = v[q.l_dof] - q.l_aref[0];
     if (q.l_on[1]) q.l_jar[1] = -v[q.l_dof] - q.l_aref[1];
+    if (q.t_on[0] || q.t_on[1]) {
+      const wreal jv = wt_tendon_jv(m, lane, v);
+      if (q.t_on[0]) q.t_jar[0] = jv - q.t_aref[0];
+      if (q.t_on[1]) q.t_jar[1] = -jv - q.t_aref[1];
+    }
     if (q.s_on) {
       wreal s = -q.s_aref;
       const int b1 = t.s_body[2 * lane], b2 = t.s_body[2 * lane + 1];
@@ -876,7 +977,7 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     WSYNC();
   };
   set_jar(d.qacc);
-  wreal cost = wt_cost(d, t, q, lane);
+  wreal cost = wt_cost(d, t, q, lane, pyr);
   if (have_warm) {  // warm start (mj_fwdConstraint): begin at the previous step's qacc if its cost is lower
     wreal gauss = 0;
     if (lane < nv) {
@@ -885,20 +986,20 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     }
     gauss = wave_sum(gauss);
     set_jar(d.qacc_warm);
-    const wreal cw = gauss + wt_cost(d, t, q, lane);
+    const wreal cw = gauss + wt_cost(d, t, q, lane, pyr);
     if (cw < cost) {
       cost = cw;
       if (lane < nv) d.qacc[lane] = d.qacc_warm[lane];
       WSYNC();
     } else {
       set_jar(d.qacc);
-      wt_cost(d, t, q, lane);  // restore jar / force / zone of the smooth start
+      wt_cost(d, t, q, lane, pyr);  // restore jar / force / zone of the smooth start
     }
   }
   const wreal scale = WL(1.0) / (m.meaninertia * (nv > 1 ? nv : 1));
   bool factor_valid = false;
   wreal improvement = 0;
-  int zf_prev = -2, zl0_prev = -2, zl1_prev = -2, zs_prev = -2, zc_prev = -2;
+  int zf_prev = -2, zl0_prev = -2, zl1_prev = -2, zs_prev = -2, zc_prev = -2, zt0_prev = -2, zt1_prev = -2;
   long long tacc = 0;
 #define WACC(k) do { if (stamp && lane == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); stamp[k] += now_ - tacc; tacc = now_; } } while (0)
   for (int iter = 0; iter < m.solver_iterations; iter++) {
@@ -924,8 +1025,9 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     bool refresh;
     {
       const bool moved = (q.f_on && q.f_zone != zf_prev) || (q.l_on[0] && q.l_zone[0] != zl0_prev) || (q.l_on[1] && q.l_zone[1] != zl1_prev) ||
-                         (q.s_on && q.s_zone != zs_prev) || (q.c_on && (q.c_zone != zc_prev || q.c_zone == kZoneMiddle));
-      zf_prev = q.f_zone; zl0_prev = q.l_zone[0]; zl1_prev = q.l_zone[1]; zs_prev = q.s_zone; zc_prev = q.c_zone;
+                         (q.s_on && q.s_zone != zs_prev) || (q.c_on && (q.c_zone != zc_prev || q.c_zone == kZoneMiddle)) ||
+                         (q.t_on[0] && q.t_zone[0] != zt0_prev) || (q.t_on[1] && q.t_zone[1] != zt1_prev);
+      zf_prev = q.f_zone; zl0_prev = q.l_zone[0]; zl1_prev = q.l_zone[1]; zs_prev = q.s_zone; zc_prev = q.c_zone; zt0_prev = q.t_zone[0]; zt1_prev = q.t_zone[1];
       refresh = !factor_valid || __any(moved);
     }
     if (refresh) {
@@ -940,7 +1042,21 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
             for (int e = 0; e < 12; e++) { geo[e] = c.geo[e]; par[e] = c.par[e]; }
             for (int e = 0; e < 6; e++) x[e] = c.jar[e];
             const int dim = q.c_dim;
-            if (q.c_zone == kZoneBottom) {
+            if (pyr) {
+              // Hc = D sum over the active edges of e e', e = a_0 +- f_j a_j
+              wreal a0[6];
+              wt_cone_gen(a0, geo, 0);
+              const int mask = q.c_zone >> 2;
+              _Pragma("unroll")
+              for (int j = 1; j < 6; j++)
+                if (j < dim) {
+                  wt_cone_gen(a, geo, j);
+                  wreal e[6];
+                  if (mask & (1 << (2 * (j - 1)))) { for (int k = 0; k < 6; k++) e[k] = a0[k] + par[j] * a[k]; sym6_rank1(X, par[6], e); }
+                  if (mask & (2 << (2 * (j - 1)))) { for (int k = 0; k < 6; k++) e[k] = a0[k] - par[j] * a[k]; sym6_rank1(X, par[6], e); }
+                }
+              (void)x;
+            } else if (q.c_zone == kZoneBottom) {
               _Pragma("unroll")
               for (int j = 0; j < 6; j++)
                 if (j < dim) { wt_cone_gen(a, geo, j); if (j < 3) sym6_rank1(X, par[6 + j], a); else sym3_rank1(X, par[6 + j], a); }
@@ -987,10 +1103,11 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
             const unsigned mp = (unsigned)__builtin_amdgcn_readlane((int)q.s_mp, i), mm = (unsigned)__builtin_amdgcn_readlane((int)q.s_mm, i);
             const int sg = (int)((mp >> lane) & 1u) - (int)((mm >> lane) & 1u);
             const wreal D = t.s_fd[2 * i + 1];
+            const bool pair = __builtin_amdgcn_readlane(q.s_pair, i) != 0;
             if (D != 0) {  // (wave-uniform)
               wreal a[6], ja = 0;
               for (int e = 0; e < 6; e++) { a[e] = t.s_a[6 * i + e]; ja += a[e] * cd[e]; }
-              if (mm == 0) { for (int e = 0; e < 6; e++) z[e] += (wreal)sg * D * ja * a[e]; any |= sg != 0; }
+              if (mm == 0 && !pair) { for (int e = 0; e < 6; e++) z[e] += (wreal)sg * D * ja * a[e]; any |= sg != 0; }
               else if (sg != 0) { wreal zc[6]; for (int e = 0; e < 6; e++) zc[e] = D * ja * a[e]; wt_pair_rows(d, lane, zc, mp, mm, sg, lowmask); }
             }
           }
@@ -998,9 +1115,10 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
             const unsigned mp = (unsigned)__builtin_amdgcn_readlane((int)q.c_mp, i), mm = (unsigned)__builtin_amdgcn_readlane((int)q.c_mm, i);
             const int sg = (int)((mp >> lane) & 1u) - (int)((mm >> lane) & 1u);
             const int zone_i = __builtin_amdgcn_readlane(q.c_zone, i);
+            const bool pair = __builtin_amdgcn_readlane(q.c_pair, i) != 0;
             if (zone_i == kZoneTop) continue;  // X_c = 0 (wave-uniform)
             WT_CONE(i,
-              if (mm == 0) { if (sg != 0) { sym6_mulvec_acc(z, c.X, cd); any = true; } }
+              if (mm == 0 && !pair) { if (sg != 0) { sym6_mulvec_acc(z, c.X, cd); any = true; } }
               else if (sg != 0) { wreal zc[6] = {0, 0, 0, 0, 0, 0}; sym6_mulvec_acc(zc, c.X, cd); wt_pair_rows(d, lane, zc, mp, mm, sg, lowmask); });
           }
           const wreal diag = (q.f_on && q.f_zone == kZoneBottom ? q.f_D : WL(0.0)) + dlim;
@@ -1015,6 +1133,21 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
             }
           }
           if (diag != 0) d.H[wt_tri(lane, lane)] += diag;
+        }
+        // limits of fixed tendons: H += D coef coef' over the tendon's dofs (row = this lane's dof, columns j <= row)
+        for (int i = 0; i < m.ntendon; i++) {
+          const wreal Di = (wreal)__shfl((q.t_on[0] && q.t_zone[0] == kZoneBottom ? q.t_D[0] : WL(0.0)) + (q.t_on[1] && q.t_zone[1] == kZoneBottom ? q.t_D[1] : WL(0.0)), i, 64);
+          if (Di == 0) continue;  // (wave-uniform)
+          const unsigned tm = m.tendon_dofmask[i];
+          if (lane < nv && ((tm >> lane) & 1u)) {
+            const wreal ci = wt_tendon_coef(m, i, lane);
+            unsigned cols = tm & ((2u << lane) - 1u);
+            while (cols) {
+              const int j = __ffs((int)cols) - 1;
+              cols &= cols - 1;
+              d.H[wt_tri(lane, j)] += Di * ci * wt_tendon_coef(m, i, j);
+            }
+          }
         }
       }
       WSYNC();
@@ -1034,6 +1167,8 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     if (q.f_on) f_jv = d.search[lane];
     if (q.l_on[0]) l_jv[0] = d.search[q.l_dof];
     if (q.l_on[1]) l_jv[1] = -d.search[q.l_dof];
+    wreal t_jv = 0;
+    if (q.t_on[0] || q.t_on[1]) t_jv = wt_tendon_jv(m, lane, d.search);
     if (q.s_on) {
       const int b1 = t.s_body[2 * lane], b2 = t.s_body[2 * lane + 1];
       for (int e = 0; e < 6; e++) s_jv += t.s_a[6 * lane + e] * (t.Vb[6 * b2 + e] - t.Vb[6 * b1 + e]);
@@ -1068,13 +1203,20 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
           const wreal v = l_jv[s], x = q.l_jar[s] + alpha * v, D = q.l_D[s];
           if (x < 0) { g1 += D * x * v; h2 += D * v * v; }
         }
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+        if (q.t_on[s]) {
+          const wreal v = s == 0 ? t_jv : -t_jv, x = q.t_jar[s] + alpha * v, D = q.t_D[s];
+          if (x < 0) { g1 += D * x * v; h2 += D * v * v; }
+        }
       if (q.s_on) {
         const wreal v = s_jv, x = q.s_jar + alpha * v, D = q.s_D;
         if (x < 0) { g1 += D * x * v; h2 += D * v * v; }
       }
       if (q.c_on) {
         wreal cg, ch;
-        wt_cone_line(c_x0, c_jv, alpha, c_par, q.c_Dm, q.c_dim, cg, ch);
+        if (pyr) wt_pyr_line(c_x0, c_jv, alpha, c_par, q.c_dim, cg, ch);
+        else wt_cone_line(c_x0, c_jv, alpha, c_par, q.c_Dm, q.c_dim, cg, ch);
         g1 += cg; h2 += ch;
       }
     };
@@ -1104,6 +1246,8 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     if (q.f_on) q.f_jar += alpha * f_jv;
     if (q.l_on[0]) q.l_jar[0] += alpha * l_jv[0];
     if (q.l_on[1]) q.l_jar[1] += alpha * l_jv[1];
+    if (q.t_on[0]) q.t_jar[0] += alpha * t_jv;
+    if (q.t_on[1]) q.t_jar[1] -= alpha * t_jv;
     if (q.s_on) q.s_jar += alpha * s_jv;
     if (q.c_on) WT_CONE(lane, for (int e = 0; e < 6; e++) c.jar[e] = c_x0[e] + alpha * c_jv[e];);
     WSYNC();
@@ -1113,7 +1257,7 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
       gauss = WL(0.5) * s * (d.qacc[lane] - d.qacc_smooth[lane]);
     }
     gauss = wave_sum(gauss);
-    const wreal newcost = gauss + wt_cost(d, t, q, lane);
+    const wreal newcost = gauss + wt_cost(d, t, q, lane, pyr);
     improvement = cost - newcost;
     cost = newcost;
     WACC(38);
