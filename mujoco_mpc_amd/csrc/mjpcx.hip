@@ -764,20 +764,38 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
       } else {
       const bool tree = c->wh.tree_ok && !c->no_tree;
-      const size_t lds = tree ? (8 * w64::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, a.xfrc_scale > 0, w64::kTreeMaxSimpleBig, w64::kTreeMaxConeBig) + 15) & ~(size_t)15
-                              : (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
-      if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
+      const bool rk4 = wm.integrator == MJPCX_INT_RK4;  // one (NMAX = 32) instantiation per kernel family carries mj_RungeKutta
+      // Jacobian-free path, Euler: two launches -- short contact lists for everybody, the long ones for the candidates that overflowed
+      const bool two_pass = tree && !rk4 && !c->no_second_pass;
+      auto tree_lds = [&](int caps, int capc) { return (8 * w64::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, a.xfrc_scale > 0, caps, capc) + 15) & ~(size_t)15; };
+      const size_t lds_big = tree ? tree_lds(w64::kTreeMaxSimpleBig, w64::kTreeMaxConeBig)
+                                  : (8 * w64::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
+      const size_t lds = two_pass ? tree_lds(w64::kTreeMaxSimple, w64::kTreeMaxCone) : lds_big;
+      if (lds_big > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
       // the register-resident Cholesky is unrolled to NMAX columns: instantiations that fit the registered models exactly (A1:
       // nv = 18, humanoid: 27) skip the padding columns' updates (humanoid: 30 % of the factorisation's instructions)
-      const bool rk4 = wm.integrator == MJPCX_INT_RK4;  // one (NMAX = 32) instantiation per kernel family carries mj_RungeKutta
-      auto kern = rk4 ? (tree ? w64::rollout_wave_kernel<32, true, true> : w64::rollout_wave_kernel<32, false, true>)
-                : tree ? (wm.nv <= 18 ? w64::rollout_wave_kernel<18, true> : w64::rollout_wave_kernel<32, true>)
+      auto kern_big = rk4 ? (tree ? w64::rollout_wave_kernel<32, true, true> : w64::rollout_wave_kernel<32, false, true>)
+                : tree ? (wm.nv <= 18 ? w64::rollout_wave_kernel<18, true> : wm.nv <= 28 ? w64::rollout_wave_kernel<28, true> : w64::rollout_wave_kernel<32, true>)
                 : wm.nv <= 18 ? w64::rollout_wave_kernel<18> : wm.nv <= 20 ? w64::rollout_wave_kernel<20>
                 : wm.nv <= 28 ? w64::rollout_wave_kernel<28> : w64::rollout_wave_kernel<32>;
+      auto kern = !two_pass ? kern_big
+                : wm.nv <= 18 ? w64::rollout_wave_kernel<18, true, false, true> : wm.nv <= 28 ? w64::rollout_wave_kernel<28, true, false, true>
+                : w64::rollout_wave_kernel<32, true, false, true>;
       le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (le == hipSuccess) {
         hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
         le = hipGetLastError();
+      }
+      if (two_pass && le == hipSuccess) {
+        if (c->timing && c->cur_main) { if ((le = hipEventRecord(c->cur_main, c->stream)) == hipSuccess) c->cur_main = nullptr; }
+        RolloutArgs<double> a2 = a;
+        a2.noise.mode = -1;  // the first pass left every candidate's spline nodes in a.nodes
+        a2.only_overflowed = 1;
+        if (le == hipSuccess) le = hipFuncSetAttribute((const void*)kern_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+        if (le == hipSuccess) {
+          hipLaunchKernelGGL(kern_big, dim3(N), dim3(64), lds_big, c->stream, wm, wt, a2);
+          le = hipGetLastError();
+        }
       }
       if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds, tree);
       }
@@ -800,17 +818,39 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       le = launch_tree<TreeCfgA1, float>(c, wm, wt, a, c->wh.dev_image32, c->wh.blob_bytes32, N, P);
       if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
     } else {
-    const size_t lds = (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
-    if (lds > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
-    auto kern = wm.integrator == MJPCX_INT_RK4 ? w32::rollout_wave_kernel<32, false, true>
+    // (the Jacobian-free constraint path in fp32 for the models it covers that are not RK4 -- the Humanoid of configs[3] --, in two
+    // passes as in fp64)
+    const bool tree = c->wh.tree_ok && !c->no_tree && wm.integrator != MJPCX_INT_RK4;
+    const bool two_pass = tree && !c->no_second_pass;
+    auto tree_lds = [&](int caps, int capc) { return (4 * w32::wave_lds_elems_tree(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, a.xfrc_scale > 0, caps, capc) + 15) & ~(size_t)15; };
+    const size_t lds_big = tree ? tree_lds(w32::kTreeMaxSimpleBig, w32::kTreeMaxConeBig)
+                                : (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
+    const size_t lds = two_pass ? tree_lds(w32::kTreeMaxSimple, w32::kTreeMaxCone) : lds_big;
+    if (lds_big > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
+    auto kern_big = wm.integrator == MJPCX_INT_RK4 ? w32::rollout_wave_kernel<32, false, true>
+              : tree ? (wm.nv <= 18 ? w32::rollout_wave_kernel<18, true> : wm.nv <= 28 ? w32::rollout_wave_kernel<28, true> : w32::rollout_wave_kernel<32, true>)
               : wm.nv <= 18 ? w32::rollout_wave_kernel<18> : wm.nv <= 20 ? w32::rollout_wave_kernel<20>
               : wm.nv <= 28 ? w32::rollout_wave_kernel<28> : w32::rollout_wave_kernel<32>;
+    auto kern = !two_pass ? kern_big
+              : wm.nv <= 18 ? w32::rollout_wave_kernel<18, true, false, true> : wm.nv <= 28 ? w32::rollout_wave_kernel<28, true, false, true>
+              : w32::rollout_wave_kernel<32, true, false, true>;
     le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (le == hipSuccess) {
       hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
       le = hipGetLastError();
     }
-    if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds);
+    if (two_pass && le == hipSuccess) {
+      if (c->timing && c->cur_main) { if ((le = hipEventRecord(c->cur_main, c->stream)) == hipSuccess) c->cur_main = nullptr; }
+      RolloutArgs<float> a2 = a;
+      a2.noise.mode = -1;
+      a2.only_overflowed = 1;
+      if (le == hipSuccess) le = hipFuncSetAttribute((const void*)kern_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+      if (le == hipSuccess) {
+        hipLaunchKernelGGL(kern_big, dim3(N), dim3(64), lds_big, c->stream, wm, wt, a2);
+        le = hipGetLastError();
+      }
+    }
+    if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds, tree);
     }
   } else {
     convert_task(c->ht32, c->ht64);

@@ -128,6 +128,8 @@ struct RolloutArgs {
   // scale = std sqrt(1 - decay^2); scale = 0: plain Rollout. Normals: Philox keyed on (seed, global candidate, step, entry).
   double xfrc_decay, xfrc_scale;
   uint64_t xfrc_seed;
+  // generic Jacobian-free kernels, second pass: roll out only the candidates whose failure[] carries the list-overflow warning (bit 32 << 8)
+  int only_overflowed;
 };
 
 // weighted sum of norms over the (compile-time) term partition of the residual

@@ -299,13 +299,17 @@ __device__ __forceinline__ void wave_rollout_body(const MODEL& m, const TASK& tk
 }
 
 // generic models: one wavefront per workgroup, one candidate per wavefront, the model behind the kernel-argument pointers
-template <int NMAX, bool TREE = false, bool RK4 = false>
+// SMALL (Jacobian-free path only): the first pass with the short contact lists (12 frictionless + 16 cones: three times the
+// candidates per CU); a candidate that overflows them is flagged and rolled out again by a second launch of the large-list
+// instantiation with a.only_overflowed set -- the scheme of the registered-model kernel (tree_kernel.h) for the generic one.
+template <int NMAX, bool TREE = false, bool RK4 = false, bool SMALL = false>
 __global__ __launch_bounds__(64) WAVE_KERNEL_ATTR void rollout_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (a.only_overflowed && !((a.failure[blockIdx.x] >> 8) & 32)) return;  // (wave-uniform)
   // The model and task structs stay in the kernel-argument segment (scalar loads). Staging the model allocation into
   // LDS was tried: no shorter step, fewer candidates per CU, and a run-time-rebased copy of this struct
   // ends up in the private segment -- every pointer fetch becomes a scratch load. (Registered models: tree_kernel.h.)
-  wave_rollout_body<NMAX, TREE, kTreeMaxSimpleBig, kTreeMaxConeBig, RK4>(m, tk, a, smem_raw, blockIdx.x, threadIdx.x);  // (generic models: the large lists)
+  wave_rollout_body<NMAX, TREE, SMALL ? kTreeMaxSimple : kTreeMaxSimpleBig, SMALL ? kTreeMaxCone : kTreeMaxConeBig, RK4>(m, tk, a, smem_raw, blockIdx.x, threadIdx.x);
 }
 
 } }  // namespace mjpcx::WAVE_NS
