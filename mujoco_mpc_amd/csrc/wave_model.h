@@ -20,7 +20,8 @@ namespace mjpcx {
 
 constexpr int kWaveMaxBody = 64, kWaveMaxDof = 32, kWaveMaxGeom = 64, kWaveMaxLevel = 16;
 constexpr int kWaveMaxCon = 16;   // contacts the row-table kernels stage per step: a candidate with more is FLAGGED (failure), not truncated --
-constexpr int kWaveMaxEfc = 64;   // constraint rows likewise. (The oracle carries a MuJoCo-sized arena; the Jacobian-free kernels have no such cap.)
+constexpr int kWaveMaxEfc = 64;   // constraint rows likewise. (The oracle carries a MuJoCo-sized arena; the Jacobian-free kernels, which serve every
+                                  // shipped contact model since round 3, have no such cap: the row-table kernels remain for RK4 models and A/B runs.)
 
 template <typename T>
 struct WaveModelT {
