@@ -72,10 +72,11 @@ __device__ __forceinline__ float dpp_move(float v) {
 #undef wreal
 #undef WAVE_NS
 
-// fp32: 21 KB of LDS per A1 candidate allows 7 per CU, so the kernel is held to 256 registers (2 wavefronts per SIMD)
+// fp32 generic kernels: the Jacobian-free path's first pass needs 12.7 KB of LDS per Humanoid candidate, i.e. 12 candidates per CU, so
+// the kernels are held to 168 registers (3 wavefronts per SIMD; 2 until the row table left in round 3: +5 % on configs[3])
 #define WAVE_NS w32
 #define wreal float
-#define WAVE_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#define WAVE_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
 #include "wave_core.h"
 #include "wave_forward.h"
 #include "wave_tree.h"
