@@ -1,3 +1,5 @@
+"""Bring-up aid: the Humanoid walk of tests/test_gpu_humanoid.py on the Jacobian-free path and (MJPCX_NO_TREE=1) on the row-table path, per
+candidate: raw failure words (warning bits << 8, step << 16), return error and the first step whose state leaves 1e-6 of the oracle."""
 import os, sys, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from mujoco_mpc_amd import capi
