@@ -126,3 +126,81 @@ def test_bench_launcher_dry_run_at_world_size_two(scaling):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["dry_run"] is True and line["scaling"] == scaling
     assert line["ms_per_step"] >= 20.0          # the slower rank (2 x 10 ms per step), not rank 0's own 10 ms
+
+
+# ---------------------------------------------------------------- the C++ planners (what bench.py ships), on a CPU stand-in for the device
+CPP_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from mujoco_mpc_amd.distributed import RankGroup
+from mujoco_mpc_amd.hostplanner import HostPlanner
+from mujoco_mpc_amd.task import load_task
+world = int(os.environ.get("WORLD_SIZE", "1"))
+group = None
+if world > 1:
+    dist.init_process_group(backend="gloo")
+    group = RankGroup(dist, torch.device("cpu"))
+task = load_task("Particle")
+log = []
+for kind, n in (("sampling", 49), ("cross_entropy", 40)):      # 49: the first rank holds one candidate more
+    p = HostPlanner(task, seed=5, num_trajectory=n, kind=kind, group=group)
+    import ctypes as C
+    glob = C.CDLL(None)                                         # the process's global symbol scope: the preloaded stand-in comes first
+    glob.mjpcx_kernel_name.restype = C.c_char_p
+    glob.mjpcx_kernel_name.argtypes = [C.c_void_p]
+    assert b"cpu stub" in glob.mjpcx_kernel_name(p._ctx())      # ... and it is what the C++ planner's context is made of
+    if kind == "cross_entropy":
+        p.ce_set(n_elite=6, std_initial=0.3, std_min=0.05, explore_fraction=0.2)
+    H = 20
+    p.reset(H)
+    p.set_state(np.array([0.1, -0.05]), np.array([0.0, 0.02]), 0.0, mocap_pos=np.array([[0.2, 0.1, 0.01]]), mocap_quat=np.array([[1.0, 0, 0, 0]]))
+    for it in range(3):
+        p.optimize_policy(H)
+        times, values = p.policy()
+        log.append(dict(kind=kind, winner=int(p.winner), score=float(p.best_score), plan=np.asarray(values).reshape(-1).tolist()))
+    p.close()
+if group is None or group.rank == 0:
+    print("RESULT " + json.dumps(log))
+if group is not None:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def run_cpp(world):
+    from mujoco_mpc_amd.build import build_host
+    build_host()
+    stub_dir = os.path.join(ROOT, "tests", "stub")
+    so = os.path.join(stub_dir, "libmjpcx_stub.so")
+    src = os.path.join(stub_dir, "mjpcx_stub.c")
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-Wall", "-o", so, src, "-lm"])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", LD_PRELOAD=so)
+    script = CPP_WORKER % dict(root=ROOT)
+    if world == 1:
+        cmd = [sys.executable, "-c", script]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", "29541", "--no-python", sys.executable, "-c", script]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    import json
+    return json.loads(line[7:])
+
+
+def test_cpp_planners_two_ranks_equal_one_rank_on_a_cpu_stand_in():
+    """The C++ planners bench.py drives (host/mjpc/planners/gpu_sampling, gpu_cross_entropy) at world size 1 and 2 over gloo, WITHOUT a
+    device: tests/stub/mjpcx_stub.c is preloaded in place of libmjpcx.so -- a stand-in whose "rollout" is a fixed function of the
+    candidate's spline and whose noise is keyed on the global candidate index, i.e. the sharding contract and nothing else. What is under
+    test is the planners' own sharding: contiguous ranges (49 candidates: 25 + 24), candidate_offset, the exchange / merge / sum callbacks.
+    The winner, its score and the policy must not depend on the number of ranks."""
+    one, two = run_cpp(1), run_cpp(2)
+    assert len(one) == len(two) == 6
+    for a, b in zip(one, two):
+        assert a["kind"] == b["kind"] and a["winner"] == b["winner"]
+        if a["kind"] == "sampling":   # bit-identical
+            assert a["score"] == b["score"] and a["plan"] == b["plan"]
+        else:                         # elite sums are re-associated across ranks
+            assert abs(a["score"] - b["score"]) < 1e-12 and np.allclose(a["plan"], b["plan"], rtol=0, atol=1e-13)
