@@ -415,7 +415,9 @@ QD double contact_eval(const QContact& c, const double* fr, double* Fs, double* 
   double tl[3], ar[3];
   QUNROLL for (int k = 0; k < 3; k++) { tl[k] = c.jar[3 + k] - jn * n[k]; ar[k] = c.jar[k] - an * n[k]; }
   const double mu = fr[0], f1s = fr[1] * fr[1], f3s = fr[2] * fr[2], f4s = fr[3] * fr[3];
-  const double T2 = f1s * dot3(tl, tl) + f3s * an * an + f4s * dot3(ar, ar), T = sqrt(T2), N = mu * jn;
+  const double T2 = f1s * dot3(tl, tl) + f3s * an * an + f4s * dot3(ar, ar), N = mu * jn;
+  double T = 0, iTq = 0;  // (below 1e-200 the cone's axis: the zones are told apart by the sign of N alone, as in line_eval)
+  if (T2 > 1e-200) q_sqrt_rsqrt(T2, T, iTq);
   if (N >= mu * T || (T <= 0 && N >= 0)) { zone = 0; return 0; }
   double ra[3], rl[3], g[3], Fl[3], Fa[3], cost;
   QUNROLL for (int k = 0; k < 3; k++) { ra[k] = f3s * an * n[k] + f4s * ar[k]; rl[k] = f1s * tl[k]; }
@@ -428,7 +430,7 @@ QD double contact_eval(const QContact& c, const double* fr, double* Fs, double* 
     if (X) { add_outer(X, c.D0, et); add_Qt(X, Dq, c, fr, g); }
     zone = 2;
   } else {
-    const double Dm = c.D0 * fr[5], NT = N - mu * T, s = Dm * NT * mu, iT = 1.0 / T, sT = s * iT;
+    const double Dm = c.D0 * fr[5], NT = N - mu * T, s = Dm * NT * mu, iT = iTq, sT = s * iT;
     cost = 0.5 * Dm * NT * NT;
     QUNROLL for (int k = 0; k < 3; k++) { Fl[k] = -s * n[k] + sT * rl[k]; Fa[k] = sT * ra[k]; }
     if (X) {
