@@ -331,6 +331,33 @@ def run_ilqg(local_rank, iterations=6, warmup=2):
            "config": {"workload": f"QuadrupedFlat iLQG, T = {T}, 10 line-search rollouts, forward differences, derivative_skip 0, fp64",
                       "host": "C++ mjpc::GpuILQGPlanner over the C ABI"},
            "total_return": info["total_return"]}
+    # the Riccati backward pass of this shape on its own (its share of the MFMA f64 peak): backward_pass_kernel on a random
+    # SPD problem with the config's dimensions -- the part of the iteration that is dense linear algebra
+    try:
+        from mujoco_mpc_amd import capi
+        n_x, n_u = 2 * task.model.nv, task.model.nu
+        rng = np.random.default_rng(0)
+        A = np.eye(n_x)[None] + 0.1 * rng.normal(size=(T, n_x, n_x))
+        B = 0.3 * rng.normal(size=(T, n_x, n_u))
+
+        def spd(k, scale):
+            M = rng.normal(size=(T, k, k))
+            return scale * (M @ np.transpose(M, (0, 2, 1)) / k + 0.5 * np.eye(k))
+        prob = (A, B, rng.normal(size=(T, n_x)), rng.normal(size=(T, n_u)), spd(n_x, 1.0), 0.05 * rng.normal(size=(T, n_x, n_u)), spd(n_u, 0.5),
+                rng.uniform(-0.9, 0.9, size=(T, n_u)), np.tile([-1.0, 1.0], (n_u, 1)))
+        ctx = capi.Context(task.packed_model(), task.packed(), local_rank, 64)
+        ms = [ctx.backward_pass(0.3, 0, 1, *prob)["kernel_ms"] for _ in range(10)]
+        ctx.close()
+        flops = (T - 1) * 2.0 * (2 * n_x ** 3 + 3 * n_x * n_x * n_u + 2 * n_x * n_u * n_u + n_u ** 3 / 3 + n_x * n_x * n_u)
+        kernel_s = float(np.median(ms)) * 1e-3
+        out["backward_pass"] = {"n": n_x, "m": n_u, "T": T, "kernel_ms": kernel_s * 1e3,
+                                "roofline": {"bound": "mfma", "achieved": flops / kernel_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                                             "frac": flops / kernel_s / 1e12 / FP64_VALU_PEAK_TF, "traffic": None,
+                                             "note": "Riccati flops of the (T - 1) steps / HIP-event time of backward_pass_kernel (v_mfma_f64_16x16x4_f64); "
+                                                     "peak = MI355X FP64 matrix = vector peak. One workgroup walks T sequential steps of 36 x 36 "
+                                                     "products: latency-bound by construction (DESIGN.md 4.4)"}}
+    except Exception as e:  # noqa: BLE001
+        out["backward_pass"] = {"error": repr(e)}
     # CPU port of the same iteration
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

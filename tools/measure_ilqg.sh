@@ -1,0 +1,12 @@
+#!/bin/bash
+# kernel trace of one Quadruped iLQG planning run (configs[4]) -> gpurun_out/r03/ilqg_kernel_stats.csv (copy to profiles/r03_ilqg_kernel_stats.csv)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ilqg_trace -o ilqg -- python -c "
+import sys; sys.path.insert(0, '$R')
+import bench
+print(bench.run_ilqg(0, iterations=6, warmup=2))
+" > $O/ilqg_trace.log 2>&1
+find $O/ilqg_trace -name "*kernel_stats.csv" -exec cp {} $O/ilqg_kernel_stats.csv \;
+head -12 $O/ilqg_kernel_stats.csv | cut -c1-200
+tail -2 $O/ilqg_trace.log | cut -c1-1200
