@@ -97,7 +97,7 @@ template <class C, typename T>
 struct LdsModelT {
   typedef LdsLayout<C, T> Layout;
   static constexpr int nq = C::NQ, nv = C::NV, nu = C::NU, nbody = C::NB, njnt = C::NJ, nsite = C::NS, ngeom = C::NG, nkey = C::NKEY;
-  static constexpr int nmocap = C::NMOCAP, nbody_model = C::NB, ntendon = 0;
+  static constexpr int nmocap = C::NMOCAP, nbody_model = C::NBM, ntendon = C::NT;
   static constexpr int nstatic_geom = C::NSG, ndynamic_geom = C::NDG, nray_geom = C::NRAY;
 #define X(tag, name, count) LdsArr<typename LdsTagType<kLds##tag, T>::type, Layout::offset(kLdsF_##name)> name;
   MJPCX_LDS_MODEL_FIELDS(X)
@@ -109,7 +109,7 @@ struct LdsModelT {
   // cold arrays (global memory)
   const T *geom_friction, *geom_solref, *geom_solimp, *geom_gap, *geom_solmix, *key_mpos;
   const int *pair_g1, *pair_g2;
-  // members the generic code names but a registered (tendon-free) model never reaches
+  // the (two or three) limited fixed tendons of a model stay behind global pointers: a handful of reads per step
   const int *tendon_adr, *tendon_num, *tendon_limited, *wrap_objid;
   const T *wrap_prm, *tendon_range, *tendon_margin, *tendon_solref_lim, *tendon_solimp_lim, *tendon_invweight0;
   const unsigned* tendon_dofmask;
@@ -118,9 +118,9 @@ struct LdsModelT {
       : cone(m.cone), disableflags(m.disableflags), solver_iterations(m.solver_iterations), any_damping(m.any_damping), nlevel(m.nlevel),
         npair(m.npair), full(m.full), timestep(m.timestep), solver_tolerance(m.solver_tolerance), meaninertia(m.meaninertia), impratio(m.impratio),
         geom_friction(m.geom_friction), geom_solref(m.geom_solref), geom_solimp(m.geom_solimp), geom_gap(m.geom_gap), geom_solmix(m.geom_solmix),
-        key_mpos(m.key_mpos), pair_g1(m.pair_g1), pair_g2(m.pair_g2), tendon_adr(nullptr), tendon_num(nullptr), tendon_limited(nullptr),
-        wrap_objid(nullptr), wrap_prm(nullptr), tendon_range(nullptr), tendon_margin(nullptr), tendon_solref_lim(nullptr),
-        tendon_solimp_lim(nullptr), tendon_invweight0(nullptr), tendon_dofmask(nullptr) {
+        key_mpos(m.key_mpos), pair_g1(m.pair_g1), pair_g2(m.pair_g2), tendon_adr(m.tendon_adr), tendon_num(m.tendon_num), tendon_limited(m.tendon_limited),
+        wrap_objid(m.wrap_objid), wrap_prm(m.wrap_prm), tendon_range(m.tendon_range), tendon_margin(m.tendon_margin), tendon_solref_lim(m.tendon_solref_lim),
+        tendon_solimp_lim(m.tendon_solimp_lim), tendon_invweight0(m.tendon_invweight0), tendon_dofmask(m.tendon_dofmask) {
     for (int k = 0; k < 3; k++) gravity[k] = m.gravity[k];
     for (int k = 0; k <= kWaveMaxLevel; k++) level_start[k] = m.level_start[k];
   }
@@ -200,10 +200,10 @@ inline std::vector<unsigned char> lds_model_image(const mjpcx_model* src, const 
 // does the run-time model have exactly the registered dimensions?
 template <class C>
 inline bool lds_model_matches(const mjpcx_model* m, const mjpcx_task* t, const WaveHost& wh) {
-  return m->nq == C::NQ && m->nv == C::NV && m->nu == C::NU && m->nbody == C::NB && m->njnt == C::NJ && m->nsite == C::NS && m->ngeom == C::NG &&
-         m->nkey == C::NKEY && m->nmocap == C::NMOCAP && wh.m.nbody == C::NB && wh.m.nsite == C::NS && (int)wh.h_static_geom.size() == C::NSG &&
+  return m->nq == C::NQ && m->nv == C::NV && m->nu == C::NU && m->nbody == C::NBM && m->njnt == C::NJ && m->nsite >= C::NS && m->ngeom == C::NG &&
+         (C::NKEY == 0 || m->nkey == C::NKEY) && m->nmocap == C::NMOCAP && wh.m.nbody == C::NB && wh.m.nsite == C::NS && (int)wh.h_static_geom.size() == C::NSG &&
          (int)wh.h_dynamic_geom.size() == C::NDG && (int)wh.h_ray_geom.size() == C::NRAY && t->num_residual == C::NR && t->num_term == C::NTERM &&
-         t->num_trace == C::NTRACE && m->ntendon == 0 &&
+         t->num_trace == C::NTRACE && m->ntendon == C::NT &&
          m->integrator == MJPCX_INT_EULER;  // (RK4 runs in the generic kernels: wave_kernel.h)
 }
 

@@ -105,6 +105,8 @@ const KernelEntry kKernels[] = {
 // not by topology: one generic kernel that reads the model through WaveModel
 const KernelEntry kTreeEntryA1 = {"rollout_tree_kernel<A1> (registered model: hot arrays staged in LDS behind compile-time offsets, persistent wavefronts, "
                                    "Jacobian-free Newton contact solver)", TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+const KernelEntry kTreeEntryHumanoid = {"rollout_tree_kernel<Humanoid> (registered model: hot arrays staged in LDS behind compile-time offsets, persistent wavefronts, "
+                                         "Jacobian-free Newton contact solver: pyramidal cones, tendon limits)", TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 const KernelEntry kQuadEntryA1 = {"rollout_quad_kernel (four lanes per candidate, one per leg: 16 candidates per wavefront, arrowhead Newton contact solver; "
                                    "candidates it hands on run rollout_tree_kernel<A1>)", TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 const KernelEntry kWaveEntry = {"rollout_wave_kernel (wavefront per candidate, model in LDS/L1; Newton contact solver)",
@@ -762,6 +764,9 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       } else if (c->wh.registered == 0) {
         le = launch_tree<TreeCfgA1, double>(c, wm, wt, a, c->wh.dev_image, c->wh.blob_bytes, N, P);
         if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
+      } else if (c->wh.registered == 1 && wm.integrator != MJPCX_INT_RK4) {
+        le = launch_tree<TreeCfgHumanoid, double>(c, wm, wt, a, c->wh.dev_image, c->wh.blob_bytes, N, P);
+        if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
       } else {
       const bool tree = c->wh.tree_ok && !c->no_tree;
       const bool rk4 = wm.integrator == MJPCX_INT_RK4;  // one (NMAX = 32) instantiation per kernel family carries mj_RungeKutta
@@ -816,6 +821,9 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     const WaveModelT<float>& wm = c->wh.m32;
     if (c->wh.registered == 0) {
       le = launch_tree<TreeCfgA1, float>(c, wm, wt, a, c->wh.dev_image32, c->wh.blob_bytes32, N, P);
+      if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
+    } else if (c->wh.registered == 1 && wm.integrator != MJPCX_INT_RK4) {
+      le = launch_tree<TreeCfgHumanoid, float>(c, wm, wt, a, c->wh.dev_image32, c->wh.blob_bytes32, N, P);
       if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
     } else {
     // (the Jacobian-free constraint path in fp32 for the models it covers that are not RK4 -- the Humanoid of configs[3] --, in two
@@ -990,14 +998,33 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
         }
       }
     }
+    else if (c->wh.tree_ok && !c->no_tree && !c->no_lds_model && lds_model_matches<TreeCfgHumanoid>(m, t, c->wh)) {
+      std::vector<unsigned char> img = precision == 64 ? lds_model_image<TreeCfgHumanoid, double>(m, t, c->wh) : lds_model_image<TreeCfgHumanoid, float>(m, t, c->wh);
+      void** slot = precision == 64 ? &c->wh.dev_image : &c->wh.dev_image32;
+      if (hipMalloc(slot, img.size()) != hipSuccess || hipMemcpy(*slot, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        mjpcx_destroy(c);
+        return bad(MJPCX_ENOMEM, "upload of the model's LDS image failed");
+      }
+      c->wh.registered = 1;
+      c->kernel = &kTreeEntryHumanoid;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
+    }
     set_norm_params(c, t->norm_parameter);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
     g_create_error = c->wh.warning;  // (empty, or what this context does NOT model of the caller's mjModel)
     // a model the Jacobian-free path could serve, but with no registered configuration (dimensions in tree_registry.h): it runs -- on the
     // generic kernel, at a fraction of the registered kernel's rate. Say so instead of leaving the caller to find out from the clock.
-    if (c->wh.tree_ok && c->wh.registered != 0 && !c->no_tree && !c->no_lds_model)
+    if (c->wh.tree_ok && c->wh.registered < 0 && !c->no_tree && !c->no_lds_model)
+    {
+      char dims[320];
+      std::snprintf(dims, sizeof dims, " (a configuration for it would read NQ = %d, NV = %d, NU = %d, NB = %d, NJ = %d, NS = %d, NG = %d, NKEY = %d, NMOCAP = %d, "
+                    "NSG = %d, NDG = %d, NRAY = %d, NR = %d, NTERM = %d, NTRACE = %d, NT = %d)", m->nq, m->nv, m->nu, c->wh.m.nbody, m->njnt, c->wh.m.nsite, m->ngeom,
+                    m->nkey, m->nmocap, (int)c->wh.h_static_geom.size(), (int)c->wh.h_dynamic_geom.size(), (int)c->wh.h_ray_geom.size(), t->num_residual,
+                    t->num_term, t->num_trace, m->ntendon);
       g_create_error += std::string(g_create_error.empty() ? "" : "; ") + "note: no registered kernel configuration for this model's dimensions (tree_registry.h): "
-                        "served by the generic wavefront-per-candidate kernel";
+                        "served by the generic wavefront-per-candidate kernel" + dims;
+    }
     *out = c;
     return MJPCX_OK;
   }

@@ -72,10 +72,10 @@ __global__ __launch_bounds__(512) void rollout_tree_kernel(const WModel m_in, co
     }
     if constexpr (BIG) {
       if (a.failure[cand] & (32 << 8))  // wave-uniform
-        wave_rollout_body<C::NV, true, kTreeMaxSimpleBig, kTreeMaxConeBig>(m, tk, a, arena, cand, lane);
+        wave_rollout_body<C::NMAX, true, kTreeMaxSimpleBig, kTreeMaxConeBig>(m, tk, a, arena, cand, lane);
     } else {
       if (!(mode & 32) || (a.failure[cand] & kQFallback))  // wave-uniform
-        wave_rollout_body<C::NV, true>(m, tk, a, arena, cand, lane, slab);
+        wave_rollout_body<C::NMAX, true>(m, tk, a, arena, cand, lane, slab);
     }
     if (dynamic) {
       int next = 0;

@@ -106,8 +106,8 @@ def test_moving_geom_pairs_the_kernels_cannot_collide_are_reported():
     ctx.close()
     hum = load_task("HumanoidTrack")
     ctx = capi.Context(hum.packed_model(), hum.packed(), 0, 64)
-    # nothing left uncollided; what it does say: the model runs the generic kernel of the Jacobian-free path (no registered configuration)
-    assert "NOT collided" not in ctx.create_warning and "no registered kernel configuration" in ctx.create_warning
+    assert ctx.create_warning == ""   # nothing left uncollided, and the model has a registered kernel configuration (tree_registry.h)
+    assert "rollout_tree_kernel<Humanoid>" in ctx.kernel_name
     ctx.close()
 
 
@@ -130,4 +130,21 @@ def test_registered_tree_configs_match_the_shipped_models():
                   NSG=sum(dofs_of_body[a["geom_bodyid"][g]] == 0 for g in coll), NDG=sum(dofs_of_body[a["geom_bodyid"][g]] > 0 for g in coll),
                   NRAY=sum(a["geom_group"][g] == 0 and a["geom_type"][g] in (0, 2, 6) for g in range(m.ngeom)),
                   NR=st.num_residual, NTERM=st.num_term, NTRACE=st.num_trace)
+    expect.update(NBM=m.nbody, NT=0, NMAX=18)
     assert cfg == {k: int(v) for k, v in expect.items()}, (cfg, expect)
+    # the Humanoid of configs[3]: NB / NS are the live prefix (the mocap marker bodies and their sites trail the model), NKEY = 0 (the
+    # keyframes are not staged)
+    body = src[src.index("struct TreeCfgHumanoid"):]
+    cfg = {k: int(v) for k, v in re.findall(r"\b(N[A-Z]+) = (\d+)", body[:body.index("};")])}
+    t = load_task("HumanoidTrack")
+    m, a = t.model, t.model.arrays
+    st = t.packed().struct
+    dofs_of_body = np.zeros(m.nbody, int)
+    for b in range(1, m.nbody):
+        dofs_of_body[b] = dofs_of_body[a["body_parentid"][b]] + a["body_dofnum"][b]
+    live = 1 + max(b for b in range(m.nbody) if dofs_of_body[b] > 0)
+    coll = [g for g in range(m.ngeom) if a["geom_contype"][g] or a["geom_conaffinity"][g]]
+    assert cfg["NQ"] == m.nq and cfg["NV"] == m.nv and cfg["NU"] == m.nu and cfg["NJ"] == m.njnt and cfg["NG"] == m.ngeom and cfg["NMOCAP"] == m.nmocap
+    assert cfg["NBM"] == m.nbody and live <= cfg["NB"] <= m.nbody and cfg["NS"] <= m.nsite and cfg["NKEY"] == 0 and cfg["NMAX"] >= m.nv
+    assert cfg["NSG"] == sum(dofs_of_body[a["geom_bodyid"][g]] == 0 for g in coll) and cfg["NDG"] == sum(dofs_of_body[a["geom_bodyid"][g]] > 0 for g in coll)
+    assert (cfg["NR"], cfg["NTERM"], cfg["NTRACE"]) == (st.num_residual, st.num_term, st.num_trace) and cfg["NT"] == int(np.sum(a["tendon_limited"] != 0))

@@ -1,4 +1,4 @@
-"""-m gpu: the wavefront-per-candidate kernel on the Humanoid mocap-tracking task of BASELINE configs[3]
+"""-m gpu: the wavefront-per-candidate kernel (since round 3: the registered Jacobian-free one, rollout_tree_kernel<Humanoid>) on the Humanoid mocap-tracking task of BASELINE configs[3]
 (28/27/21, 37 bodies, pyramidal cones, capsule self-collision, fixed-tendon limits, the 141-entry tracking residual)
 against the CPU oracle. Tolerances as for the Quadruped: 1e-9 (1 + |x|) over the first steps, looser with the horizon."""
 import numpy as np
@@ -34,7 +34,7 @@ def run(task, state, mocap, N, H, P, interp, seed, tol, time=0.0, std=0.3):
     times = time + np.arange(P) * max((H - 1) * dt / max(P - 1, 1), 1e-3)
     nodes = np.clip(rng.normal(0, std, (N, P, task.model.nu)), -1, 1)
     ctx = capi.Context(pm, pt, 0, 64)
-    assert "rollout_wave_kernel" in ctx.kernel_name
+    assert "rollout_tree_kernel<Humanoid>" in ctx.kernel_name
     ctx.set_state(state, time, mocap)
     ctx.rollout_splines(H, interp, times, nodes)
     ret, fail = ctx.returns()
@@ -96,7 +96,7 @@ def test_contact_feature_scene():
     v[0] = 0.3                    # the puck slides/rolls
     pm, pt = task.packed_model(), task.packed()
     ctx = capi.Context(pm, pt, 0, 64)
-    assert "rollout_wave_kernel" in ctx.kernel_name
+    assert "rollout_tree_kernel<Humanoid>" in ctx.kernel_name
     state = np.concatenate([q, v])
     H, P, N = 60, 2, 2
     times = np.array([0.0, 1.0])
@@ -142,7 +142,7 @@ def test_cpp_predictive_sampling_on_the_humanoid_equals_python_planner():
         ct, cv = cpp.policy()
         assert np.array_equal(cv, py.policy.plan.values())
         scores.append(cpp.best_score)
-    assert "rollout_wave_kernel" in cpp.kernel_name and scores[-1] <= scores[0]
+    assert "rollout_tree_kernel<Humanoid>" in cpp.kernel_name and scores[-1] <= scores[0]
 
 
 def test_a_folded_body_with_more_contacts_than_the_first_pass_stages():
