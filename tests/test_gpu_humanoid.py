@@ -96,7 +96,7 @@ def test_contact_feature_scene():
     v[0] = 0.3                    # the puck slides/rolls
     pm, pt = task.packed_model(), task.packed()
     ctx = capi.Context(pm, pt, 0, 64)
-    assert "rollout_tree_kernel<Humanoid>" in ctx.kernel_name
+    assert "rollout_wave_kernel" in ctx.kernel_name   # (an unregistered model: the generic kernel, Jacobian-free path, two passes)
     state = np.concatenate([q, v])
     H, P, N = 60, 2, 2
     times = np.array([0.0, 1.0])
