@@ -780,11 +780,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       // the register-resident Cholesky is unrolled to NMAX columns: instantiations that fit the registered models exactly (A1:
       // nv = 18, humanoid: 27) skip the padding columns' updates (humanoid: 30 % of the factorisation's instructions)
       auto kern_big = rk4 ? (tree ? w64::rollout_wave_kernel<32, true, true> : w64::rollout_wave_kernel<32, false, true>)
-                : tree ? (wm.nv <= 18 ? w64::rollout_wave_kernel<18, true> : wm.nv <= 28 ? w64::rollout_wave_kernel<28, true> : w64::rollout_wave_kernel<32, true>)
+                : tree ? w64::rollout_wave_kernel<32, true>  // (the shipped tree models are registered: one width serves the unregistered ones)
                 : wm.nv <= 18 ? w64::rollout_wave_kernel<18> : wm.nv <= 20 ? w64::rollout_wave_kernel<20>
                 : wm.nv <= 28 ? w64::rollout_wave_kernel<28> : w64::rollout_wave_kernel<32>;
       auto kern = !two_pass ? kern_big
-                : wm.nv <= 18 ? w64::rollout_wave_kernel<18, true, false, true> : wm.nv <= 28 ? w64::rollout_wave_kernel<28, true, false, true>
                 : w64::rollout_wave_kernel<32, true, false, true>;
       le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (le == hipSuccess) {
@@ -836,11 +835,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     const size_t lds = two_pass ? tree_lds(w32::kTreeMaxSimple, w32::kTreeMaxCone) : lds_big;
     if (lds_big > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
     auto kern_big = wm.integrator == MJPCX_INT_RK4 ? w32::rollout_wave_kernel<32, false, true>
-              : tree ? (wm.nv <= 18 ? w32::rollout_wave_kernel<18, true> : wm.nv <= 28 ? w32::rollout_wave_kernel<28, true> : w32::rollout_wave_kernel<32, true>)
+              : tree ? w32::rollout_wave_kernel<32, true>
               : wm.nv <= 18 ? w32::rollout_wave_kernel<18> : wm.nv <= 20 ? w32::rollout_wave_kernel<20>
               : wm.nv <= 28 ? w32::rollout_wave_kernel<28> : w32::rollout_wave_kernel<32>;
     auto kern = !two_pass ? kern_big
-              : wm.nv <= 18 ? w32::rollout_wave_kernel<18, true, false, true> : wm.nv <= 28 ? w32::rollout_wave_kernel<28, true, false, true>
               : w32::rollout_wave_kernel<32, true, false, true>;
     le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (le == hipSuccess) {
