@@ -52,10 +52,13 @@ void Agent::SetPlanner(int planner) {
   }
   if (planner == planner_) return;
   planner_ = planner;
-  // Allocate() only ever gave the then-active planner a device context: the new one gets its own before it is asked to plan
-  if (model_ && !allocate_enabled) {
+  // Allocate() only ever gave the then-active planner a device context: a planner gets its own the FIRST time it becomes active and
+  // keeps it (and its policy) when the caller switches away and back, as the reference's planners keep their buffers
+  if (allocated_.size() != planners_.size()) allocated_.assign(planners_.size(), false);
+  if (model_ && !allocate_enabled && !allocated_[planner_]) {
     ActivePlanner().Allocate();
     ActivePlanner().Reset(kMaxTrajectoryHorizon);
+    allocated_[planner_] = true;
   }
 }
 
@@ -63,6 +66,8 @@ void Agent::Allocate() {
   // only the active planner gets a device context here (the reference allocates every planner's buffers; on the
   // device that would mean one model upload and LDS/scratch budget per unused planner)
   ActivePlanner().Allocate();
+  allocated_.assign(planners_.size(), false);  // (a new model / task: every other planner's context is stale)
+  allocated_[planner_] = true;
   allocate_enabled = false;
 }
 

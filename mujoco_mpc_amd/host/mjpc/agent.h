@@ -50,6 +50,7 @@ class Agent {
 
   State state;
   bool plan_enabled = true, action_enabled = true, allocate_enabled = false;
+  std::vector<bool> allocated_;  // per planner: holds a device context for the current model / task (allocated on first activation)
   int gui_task_id = 0;
 
  private:
