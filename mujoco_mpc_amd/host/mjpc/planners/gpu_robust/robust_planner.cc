@@ -67,14 +67,28 @@ void GpuRobustPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
     }
     for (int j = 0; j < repetitions; j++) std::copy(plan.values().begin(), plan.values().end(), values.begin() + ((size_t)repetitions * i + j) * np);
   }
+  // sharded (the delegate's ranks): the N perturbed rollouts are split into contiguous ranges like the delegate's candidates -- the
+  // force noise is keyed on the GLOBAL rollout index --, every rank writes its returns into a zeroed table and the sum over the
+  // ranks is the table; all ranks then select the same candidate
+  const int world = delegate_->world(), rank = delegate_->rank();
+  if (world > N) throw gpu::Error(MJPCX_EINVAL, "more ranks than perturbed rollouts: every rank needs at least one");
+  const int q = N / world, r = N % world;
+  const int n_local = q + (rank < r ? 1 : 0), lo = rank * q + std::min(rank, r);
   ctx_->SyncTask(*task_);
   ctx_->Check(mjpcx_set_state(ctx_->handle(), state_.data(), time_, mocap_.data(), userdata_.data()));
-  ctx_->Check(mjpcx_rollout_splines_noisy(ctx_->handle(), N, horizon, (int)times.size(), interpolation, times.data(), values.data(),
-                                          xfrc_std_, xfrc_rate_, seed_, /*candidate_offset=*/(int)(iteration * (std::uint32_t)N)));
+  ctx_->Check(mjpcx_rollout_splines_noisy(ctx_->handle(), n_local, horizon, (int)times.size(), interpolation, times.data(),
+                                          values.data() + (size_t)lo * np, xfrc_std_, xfrc_rate_, seed_,
+                                          /*candidate_offset=*/(int)(iteration * (std::uint32_t)N) + lo));
   iteration++;
-  std::vector<double> returns(N);
-  std::vector<int32_t> failure(N);
-  ctx_->Check(mjpcx_get_returns(ctx_->handle(), returns.data(), failure.data()));
+  std::vector<double> returns(N, 0.0);
+  std::vector<int32_t> failure(N, 0);
+  ctx_->Check(mjpcx_get_returns(ctx_->handle(), returns.data() + lo, failure.data() + lo));
+  if (world > 1) {
+    std::vector<double> table(2 * (size_t)N, 0.0);
+    for (int i = lo; i < lo + n_local; i++) { table[i] = failure[i] ? 0.0 : returns[i]; table[N + i] = failure[i] ? 1.0 : 0.0; }  // (a failed rollout's return is not used)
+    delegate_->AllReduceSum(table.data(), (int)table.size());
+    for (int i = 0; i < N; i++) { returns[i] = table[i]; failure[i] = table[N + i] != 0.0; }
+  }
   // the candidate with the best mean perturbed return (failed rollouts do not count), robust_planner.cc:141-163
   best_candidate = -1;
   double best_score = 0;

@@ -126,21 +126,70 @@ void GpuSamplingPlanner::Rollouts(int num_trajectory, int horizon) {
                                   plan.times().data(), plan.values().data(), &ns));
   num_rolled_ = n_local;
   best_valid_ = false;
+  candidate_values_.clear();
+}
+
+void GpuSamplingPlanner::SetRankedSharding(MergeTopkFn merge, SumFn sum, void* user) {
+  merge_ = merge;
+  sum_ = sum;
+  ranked_user_ = user;
+}
+
+// without a communicator of this world size the library's collectives are the identity: every rank would keep its own numbers silently
+void GpuSamplingPlanner::RequireCommunicator() {
+  int comm_rank = 0, comm_world = 1;
+  ctx_->Check(mjpcx_comm_info(ctx_->handle(), &comm_rank, &comm_world));
+  if (comm_world != world_) throw gpu::Error(MJPCX_ESTATE, "sharded planner has neither an exchange callback nor a communicator of its world size (mjpcx_comm_init)");
+}
+
+void GpuSamplingPlanner::AllReduceSum(double* values, int n) {
+  if (world_ <= 1 || n <= 0) return;
+  if (sum_) {
+    if (sum_(ranked_user_, values, n) != 0) throw gpu::Error(MJPCX_EDEVICE, "sum over the ranks failed");
+    return;
+  }
+  RequireCommunicator();
+  ctx_->Check(mjpcx_elite_allreduce(ctx_->handle(), values, n));
 }
 
 int GpuSamplingPlanner::OptimizePolicyCandidates(int ncandidates, int horizon, ThreadPool& pool) {
-  // the ranked interface (RobustPlanner's delegate) ranks one process's candidates: a sharded batch would rank each shard on its own
-  if (world_ > 1) throw gpu::Error(MJPCX_EUNSUPPORTED, "OptimizePolicyCandidates is not sharded: run the robust planner's delegate on one rank");
   UpdateNominalPolicy(horizon);
   const int num_trajectory = num_trajectory_;
   ncandidates = std::min(ncandidates, num_trajectory);
   const auto start = std::chrono::steady_clock::now();
   policy.plan.SetInterpolation(interpolation_);
   Rollouts(num_trajectory, horizon);
-  std::vector<int32_t> idx(ncandidates);
+  // this rank's best (at most its own share), then -- sharded -- the best of all ranks
+  const int k_local = std::min(ncandidates, num_rolled_);
+  std::vector<int32_t> idx(std::max(k_local, 1));
+  std::vector<double> ret(std::max(k_local, 1), 0.0);
+  if (k_local > 0) ctx_->Check(mjpcx_topk(ctx_->handle(), k_local, idx.data(), ret.data()));
+  trajectory_order.assign(ncandidates, -1);
   scores_.assign(ncandidates, 0.0);
-  ctx_->Check(mjpcx_topk(ctx_->handle(), ncandidates, idx.data(), scores_.data()));
-  trajectory_order.assign(idx.begin(), idx.end());
+  if (world_ <= 1) {
+    for (int i = 0; i < ncandidates; i++) { trajectory_order[i] = idx[i]; scores_[i] = ret[i]; }
+  } else {
+    std::vector<std::int64_t> gidx(ncandidates, -1);
+    std::vector<double> gret(ncandidates, 1.0e300);
+    for (int i = 0; i < k_local; i++) { gidx[i] = (std::int64_t)offset_ + idx[i]; gret[i] = ret[i]; }
+    if (merge_) {
+      if (merge_(ranked_user_, ncandidates, gidx.data(), gret.data()) != 0) throw gpu::Error(MJPCX_EDEVICE, "top-k exchange failed");
+    } else {
+      RequireCommunicator();
+      ctx_->Check(mjpcx_merge_topk(ctx_->handle(), ncandidates, gidx.data(), gret.data()));
+    }
+    // the merged candidates' splines: every owner writes its own into a zeroed table, the sum over the ranks is the table
+    const size_t np = policy.plan.Size() * (size_t)model->nu;
+    candidate_values_.assign((size_t)ncandidates * np, 0.0);
+    for (int i = 0; i < ncandidates; i++) {
+      if (gidx[i] < 0) throw gpu::Error(MJPCX_ESTATE, "top-k exchange returned fewer candidates than the ranks hold");
+      trajectory_order[i] = (int)gidx[i];
+      scores_[i] = gret[i];
+      const std::int64_t local = gidx[i] - offset_;
+      if (local >= 0 && local < num_rolled_) ctx_->Check(mjpcx_fetch_spline(ctx_->handle(), (int)local, candidate_values_.data() + (size_t)i * np));
+    }
+    AllReduceSum(candidate_values_.data(), (int)candidate_values_.size());
+  }
   rollouts_compute_time = GetDuration(start);
   iteration++;
   return ncandidates;
@@ -167,10 +216,7 @@ void GpuSamplingPlanner::OptimizePolicy(int horizon, ThreadPool& pool) {
       index = (int32_t)record[1];
       nominal_return = record[2];
     } else {          // RCCL inside the library (mjpcx_comm_init on this planner's context)
-      // without a communicator of this world size the library's exchange is the identity: every rank would adopt its own best silently
-      int comm_rank = 0, comm_world = 1;
-      ctx_->Check(mjpcx_comm_info(ctx_->handle(), &comm_rank, &comm_world));
-      if (comm_world != world_) throw gpu::Error(MJPCX_ESTATE, "sharded planner has neither an exchange callback nor a communicator of its world size (mjpcx_comm_init)");
+      RequireCommunicator();
       ctx_->Check(mjpcx_exchange_best(ctx_->handle(), &index, &best_return, &nominal_return, values.data(), (int)values.size()));
     }
   }
@@ -209,6 +255,18 @@ void GpuSamplingPlanner::LoadCandidatePlan(int index, SamplingPolicy* out) {
     out->plan.AddNode(policy.plan.times()[k], spline::Span<const double>(values.data() + k * nu, nu));
 }
 
+// ranked candidate -> its spline: from this process's device buffers, or (sharded) from the table OptimizePolicyCandidates summed
+void GpuSamplingPlanner::LoadRankedPlan(int candidate, SamplingPolicy* out) {
+  if (candidate_values_.empty()) return LoadCandidatePlan(trajectory_order[candidate], out);
+  const int nu = model->nu;
+  const size_t np = policy.plan.Size() * (size_t)nu;
+  out->model = model;
+  out->num_spline_points = policy.num_spline_points;
+  out->plan = TimeSpline(nu, policy.plan.Interpolation());
+  for (size_t k = 0; k < policy.plan.Size(); k++)
+    out->plan.AddNode(policy.plan.times()[k], spline::Span<const double>(candidate_values_.data() + (size_t)candidate * np + k * nu, nu));
+}
+
 void GpuSamplingPlanner::NominalTrajectory(int horizon, ThreadPool& pool) {
   const TimeSpline& plan = winner_policy.plan.Size() ? winner_policy.plan : policy.plan;
   std::vector<double> times(plan.times()), values(plan.values());
@@ -244,19 +302,19 @@ double GpuSamplingPlanner::CandidateScore(int candidate) const { return scores_[
 
 void GpuSamplingPlanner::ActionFromCandidatePolicy(double* action, int candidate, const double* s, double t) {
   SamplingPolicy p;
-  LoadCandidatePlan(trajectory_order[candidate], &p);
+  LoadRankedPlan(candidate, &p);
   p.Action(action, s, t);
 }
 
 void GpuSamplingPlanner::CandidatePlan(int candidate, spline::TimeSpline* out) {
   SamplingPolicy p;
-  LoadCandidatePlan(trajectory_order[candidate], &p);
+  LoadRankedPlan(candidate, &p);
   *out = p.plan;
 }
 
 void GpuSamplingPlanner::CopyCandidateToPolicy(int candidate) {
   SamplingPolicy p;
-  LoadCandidatePlan(trajectory_order[candidate], &p);
+  LoadRankedPlan(candidate, &p);
   SetWinner(trajectory_order[candidate], p.plan.values());
 }
 

@@ -60,6 +60,17 @@ class GpuSamplingPlanner : public RankedPlanner {
   // RCCL/xGMI in bench.py, gloo in the CPU tests.
   using ExchangeFn = int (*)(void* user, double record[3], double* spline, int np);
   void SetSharding(int rank, int world, ExchangeFn exchange, void* user);
+  // The ranked interface (OptimizePolicyCandidates, RobustPlanner's delegate) sharded: every rank ranks its share, the k best of all
+  // ranks are merged (in: this rank's k best as (global index, return), unused slots -1; out: the global k best, ties by global
+  // index, identical on every rank) and their splines are summed into place from their owners. Callbacks as for the Cross-Entropy
+  // planner (gloo in the CPU-side tests); without them the library's own communicator (mjpcx_merge_topk, mjpcx_elite_allreduce).
+  using MergeTopkFn = int (*)(void* user, int k, std::int64_t* index, double* total_return);
+  using SumFn = int (*)(void* user, double* values, int n);
+  void SetRankedSharding(MergeTopkFn merge, SumFn sum, void* user);
+  // in-place sum of a small vector over the ranks (identity on one rank): for planners built on this one (GpuRobustPlanner)
+  void AllReduceSum(double* values, int n);
+  int rank() const { return rank_; }
+  int world() const { return world_; }
   gpu::Context* context() { return ctx_.get(); }
 
   // ----- members (names as in the reference) ----- //
@@ -87,11 +98,17 @@ class GpuSamplingPlanner : public RankedPlanner {
   double PlanningTimestep() const;  // agent_timestep if the model defines it (agent.cc:288-291)
   void SetWinner(int index, const std::vector<double>& values);
   void LoadCandidatePlan(int index, SamplingPolicy* out);
+  void LoadRankedPlan(int candidate, SamplingPolicy* out);
   int device_, precision_;
   std::uint64_t seed_;
   int rank_ = 0, world_ = 1, offset_ = 0;
   ExchangeFn exchange_ = nullptr;
   void* exchange_user_ = nullptr;
+  MergeTopkFn merge_ = nullptr;
+  SumFn sum_ = nullptr;
+  void* ranked_user_ = nullptr;
+  void RequireCommunicator();
+  std::vector<double> candidate_values_;  // sharded ranked interface: the merged candidates' splines, k x (P nu); else empty
   std::unique_ptr<gpu::Context> ctx_;
   std::vector<double> scores_;
   Trajectory best_;

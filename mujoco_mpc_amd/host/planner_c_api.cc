@@ -96,6 +96,15 @@ void mjpc_planner_destroy(void* h) { delete static_cast<Handle*>(h); }
 int mjpc_planner_set_sharding(void* h, int rank, int world, mjpc::GpuSamplingPlanner::ExchangeFn fn, void* user) {
   GUARD(h, { if (!H->ps) throw std::runtime_error("not a sampling planner"); H->ps->SetSharding(rank, world, fn, user); });
 }
+// the ranked interface of a sampling planner (the robust planner's delegate): top-k merge + sum callbacks, as the Cross-Entropy planner's
+int mjpc_planner_set_sharding_ranked(void* h, int rank, int world, mjpc::GpuSamplingPlanner::MergeTopkFn merge,
+                                     mjpc::GpuSamplingPlanner::SumFn sum, void* user) {
+  GUARD(h, {
+    if (!H->ps) throw std::runtime_error("not a sampling planner");
+    H->ps->SetSharding(rank, world, nullptr, nullptr);
+    H->ps->SetRankedSharding(merge, sum, user);
+  });
+}
 int mjpc_planner_set_sharding_ce(void* h, int rank, int world, mjpc::GpuCrossEntropyPlanner::MergeTopkFn merge,
                                  mjpc::GpuCrossEntropyPlanner::SumFn sum, void* user) {
   GUARD(h, { if (!H->ce) throw std::runtime_error("not a cross-entropy planner"); H->ce->SetSharding(rank, world, merge, sum, user); });

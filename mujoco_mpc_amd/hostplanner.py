@@ -59,6 +59,7 @@ def lib():
         L.mjpc_planner_last_error.restype = C.c_char_p
         L.mjpc_planner_last_error.argtypes = [vp]
         L.mjpc_planner_set_sharding.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
+        L.mjpc_planner_set_sharding_ranked.argtypes = [vp, C.c_int, C.c_int, MERGE_TOPK_FN, SUM_FN, vp]
         L.mjpc_comm_unique_id.argtypes = [C.c_void_p]
         L.mjpc_planner_comm_init.argtypes = [vp, C.c_void_p, C.c_int, C.c_int]
         L.mjpc_planner_comm_barrier.argtypes = [vp]
@@ -115,7 +116,7 @@ class HostPlanner:
             buf = C.create_string_buffer(bytes(uid), 128)
             self._chk(lib().mjpc_planner_comm_init(self.h, buf, int(rank), int(world)))
             self.group = group = None
-        if group is not None and group.world > 1 and kind == "cross_entropy":
+        if group is not None and group.world > 1 and kind in ("cross_entropy", "robust"):
             def merge(user, k, index, ret):
                 try:
                     idx = np.ctypeslib.as_array(index, (k,))
@@ -140,10 +141,12 @@ class HostPlanner:
                     print("sum exchange failed:", e, flush=True)
                     return 1
             self._cb = (MERGE_TOPK_FN(merge), SUM_FN(total))
-            self._chk(lib().mjpc_planner_set_sharding_ce(self.h, group.rank, group.world, self._cb[0], self._cb[1], None))
+            # (robust: the delegate ranks its share, the k best of all ranks are merged; the perturbed rollouts are sharded the same way)
+            setter = lib().mjpc_planner_set_sharding_ce if kind == "cross_entropy" else lib().mjpc_planner_set_sharding_ranked
+            self._chk(setter(self.h, group.rank, group.world, self._cb[0], self._cb[1], None))
         elif group is not None and group.world > 1:
             if kind != "sampling":
-                raise ValueError("the iLQG planner is not sharded (replicas only)")
+                raise ValueError(f"the {kind} planner is not sharded (replicas only)")
 
             def exchange(user, record, spline, n):
                 try:

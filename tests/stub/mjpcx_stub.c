@@ -1,11 +1,11 @@
 /* A CPU stand-in for libmjpcx.so -- TEST INFRASTRUCTURE ONLY, never shipped, never on a product path.
  *
  * tests/test_distributed_gloo.py preloads it (LD_PRELOAD) under the C++ planners of mujoco_mpc_amd/host so that their SHARDING logic --
- * contiguous candidate ranges, candidate_offset, the exchange callbacks, top-k merge, elite moments -- runs on a machine without a
+ * contiguous candidate ranges, candidate_offset, the exchange callbacks, top-k merge, elite moments, the robust planner's perturbed second stage -- runs on a machine without a
  * device at world size 1 and 2. It is not physics: a "rollout" is a fixed function of the candidate's spline nodes and the state, and a
  * candidate's noise is a hash of (seed, GLOBAL candidate index, iteration, entry) -- exactly the property the sharding contract rests
  * on (results independent of the number of ranks), with none of the numbers of the real kernels. Entry points the sampling /
- * cross-entropy planners do not call return MJPCX_EUNSUPPORTED. */
+ * cross-entropy / robust planners do not call return MJPCX_EUNSUPPORTED. */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -72,8 +72,17 @@ int mjpcx_rollout_splines(mjpcx_ctx* c, int N, int H, int P, int interp, const d
   for (int i = 0; i < N; i++) c->returns[i] = score(c, c->nodes + (size_t)i * P * c->nu);
   return MJPCX_OK;
 }
+/* the perturbation of a "noisy rollout": a function of (seed, GLOBAL rollout index) on top of the spline's score */
 int mjpcx_rollout_splines_noisy(mjpcx_ctx* c, int N, int H, int P, int interp, const double* t, const double* v, double s, double r, uint64_t seed, int off) {
-  (void)c; (void)N; (void)H; (void)P; (void)interp; (void)t; (void)v; (void)s; (void)r; (void)seed; (void)off; return MJPCX_EUNSUPPORTED;
+  (void)interp; (void)t; (void)r;
+  int rc = reserve(c, N, H, P);
+  if (rc) return rc;
+  memcpy(c->nodes, v, sizeof(double) * (size_t)N * P * c->nu);
+  for (int i = 0; i < N; i++) {
+    const double z = normal(seed, (uint32_t)(off + i), 0x7fffu, 0);
+    c->returns[i] = score(c, c->nodes + (size_t)i * P * c->nu) * (1.0 + s * z * z);
+  }
+  return MJPCX_OK;
 }
 int mjpcx_rollout_noise(mjpcx_ctx* c, int N, int H, int P, int interp, const double* times, const double* nominal, const mjpcx_noise_spec* ns) {
   (void)interp; (void)times;

@@ -144,7 +144,7 @@ if world > 1:
     group = RankGroup(dist, torch.device("cpu"))
 task = load_task("Particle")
 log = []
-for kind, n in (("sampling", 49), ("cross_entropy", 40)):      # 49: the first rank holds one candidate more
+for kind, n in (("sampling", 49), ("cross_entropy", 40), ("robust", 45)):      # 49, 45: the first rank holds one candidate more
     p = HostPlanner(task, seed=5, num_trajectory=n, kind=kind, group=group)
     import ctypes as C
     glob = C.CDLL(None)                                         # the process's global symbol scope: the preloaded stand-in comes first
@@ -153,13 +153,19 @@ for kind, n in (("sampling", 49), ("cross_entropy", 40)):      # 49: the first r
     assert b"cpu stub" in glob.mjpcx_kernel_name(p._ctx())      # ... and it is what the C++ planner's context is made of
     if kind == "cross_entropy":
         p.ce_set(n_elite=6, std_initial=0.3, std_min=0.05, explore_fraction=0.2)
+    if kind == "robust":                                        # 7 ranked candidates x 3 perturbed rollouts = 21: 11 + 10
+        p.robust_config(ncandidates=7, nrepetitions=3, xfrc_std=0.4, xfrc_rate=0.1)
     H = 20
     p.reset(H)
     p.set_state(np.array([0.1, -0.05]), np.array([0.0, 0.02]), 0.0, mocap_pos=np.array([[0.2, 0.1, 0.01]]), mocap_quat=np.array([[1.0, 0, 0, 0]]))
     for it in range(3):
         p.optimize_policy(H)
         times, values = p.policy()
-        log.append(dict(kind=kind, winner=int(p.winner), score=float(p.best_score), plan=np.asarray(values).reshape(-1).tolist()))
+        entry = dict(kind=kind, winner=int(p.winner), score=float(p.best_score), plan=np.asarray(values).reshape(-1).tolist())
+        if kind == "robust":
+            best, scores = p.robust_result(7)
+            entry.update(best_candidate=int(best), perturbed=np.asarray(scores).tolist())
+        log.append(entry)
     p.close()
 if group is None or group.rank == 0:
     print("RESULT " + json.dumps(log))
@@ -197,10 +203,13 @@ def test_cpp_planners_two_ranks_equal_one_rank_on_a_cpu_stand_in():
     test is the planners' own sharding: contiguous ranges (49 candidates: 25 + 24), candidate_offset, the exchange / merge / sum callbacks.
     The winner, its score and the policy must not depend on the number of ranks."""
     one, two = run_cpp(1), run_cpp(2)
-    assert len(one) == len(two) == 6
+    assert len(one) == len(two) == 9
     for a, b in zip(one, two):
         assert a["kind"] == b["kind"] and a["winner"] == b["winner"]
         if a["kind"] == "sampling":   # bit-identical
             assert a["score"] == b["score"] and a["plan"] == b["plan"]
+        elif a["kind"] == "robust":   # the ranked candidates of all ranks merged, the perturbed rollouts split 11 + 10: bit-identical
+            assert a["best_candidate"] == b["best_candidate"] and a["perturbed"] == b["perturbed"] and a["plan"] == b["plan"]
+            assert len(a["perturbed"]) == 7 and len(set(a["perturbed"])) == 7
         else:                         # elite sums are re-associated across ranks
             assert abs(a["score"] - b["score"]) < 1e-12 and np.allclose(a["plan"], b["plan"], rtol=0, atol=1e-13)

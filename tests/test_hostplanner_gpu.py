@@ -160,6 +160,8 @@ kind = os.environ.get("MJPC_TEST_KIND", "sampling")
 task = load_task("Cartpole")
 p = HostPlanner(task, device=0, seed=7, num_trajectory=1000, group=group, kind=kind)
 H = 32
+if kind == "robust":
+    p.robust_config(ncandidates=9, nrepetitions=3, xfrc_std=0.2, xfrc_rate=0.1)
 p.reset(H)
 log = []
 for k in range(4):
@@ -167,6 +169,9 @@ for k in range(4):
     p.optimize_policy(H)
     t, v = p.policy()
     rec = dict(winner=p.winner, score=p.best_score, improvement=p.improvement, plan=v.tolist())
+    if kind == "robust":
+        best, scores = p.robust_result(9)
+        rec.update(best_candidate=best, perturbed=scores.tolist())
     if kind == "cross_entropy":
         rec["elites"] = p.ce_elites().tolist()
         rec["variance"] = p.ce_variance(v.size).tolist()
@@ -202,6 +207,15 @@ def test_cross_entropy_two_ranks_on_one_gpu_equal_one_rank():
         np.testing.assert_allclose(a["plan"], b["plan"], rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(a["variance"], b["variance"], rtol=1e-10, atol=1e-16)
         np.testing.assert_allclose(a["improvement"], b["improvement"], rtol=1e-10, atol=1e-14)
+
+
+def test_robust_planner_two_ranks_on_one_gpu_equal_one_rank():
+    """GpuRobustPlanner sharded: the delegate's 1000 candidates 500 + 500, the 9 best of both ranks merged (with their splines), the
+    27 perturbed rollouts 14 + 13 with the force noise keyed on the global rollout index -- same ranked candidates, same perturbed
+    means, same policy as one rank, bit for bit (the exchanges move numbers, they do not re-associate sums)."""
+    one, two = run(1, "robust"), run(2, "robust")
+    assert one == two
+    assert all(0 <= r["best_candidate"] < 9 and len(set(r["perturbed"])) == 9 for r in one)
 
 
 def test_cpp_robust_planner_on_the_quadruped():
