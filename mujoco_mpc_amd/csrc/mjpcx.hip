@@ -1596,8 +1596,17 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
   auto kern = rk4 ? (tree ? w64::rollout_feedback_wave_kernel<32, true, true> : w64::rollout_feedback_wave_kernel<32, false, true>)
             : tree ? (c->wh.m.nv <= 18 ? w64::rollout_feedback_wave_kernel<18, true> : w64::rollout_feedback_wave_kernel<32, true>)
             : c->wh.m.nv <= 20 ? w64::rollout_feedback_wave_kernel<20> : w64::rollout_feedback_wave_kernel<32>;
-  HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, c->wh.m, wt, a, fb);
+  const size_t fixed = LdsLayout<TreeCfgA1, double>::kBytes + c->wh.blob_bytes;
+  if (c->wh.registered == 0 && tree && !rk4 && c->wh.dev_image && fixed + lds <= 160 * 1024) {
+    // registered model: image + blob + one arena per workgroup (the launch is a handful of wavefronts: nothing to share an image between)
+    auto reg = w64::rollout_feedback_tree_kernel<TreeCfgA1>;
+    HIPCHK(c, hipFuncSetAttribute((const void*)reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fixed + lds)));
+    hipLaunchKernelGGL(reg, dim3(N), dim3(64), fixed + lds, c->stream, c->wh.m, wt, a, fb, (const unsigned char*)c->wh.dev_image,
+                       (unsigned)c->wh.blob_bytes);
+  } else {
+    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, c->wh.m, wt, a, fb);
+  }
   HIPCHK(c, hipGetLastError());
   c->N = N; c->H = H; c->P = 1;
   c->have_rollout = true;

@@ -185,11 +185,11 @@ struct FeedbackWaveArgs {
   int Tn, mode, representation, use_state;
 };
 
-template <int NMAX, bool TREE = false, bool RK4 = false>
-__global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a,
-                                                                    const FeedbackWaveArgs fb) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lane = threadIdx.x, cand = blockIdx.x;
+// one candidate's rollout under the feedback policy, by one wavefront; MODEL / TASK: the generic structs (arrays behind global pointers)
+// or a registered model's LDS image (lds_model.h)
+template <int NMAX, bool TREE, bool RK4, class MODEL, class TASK>
+__device__ __forceinline__ void feedback_rollout_body(const MODEL& m, const TASK& tk, const RolloutArgs<wreal>& a, const FeedbackWaveArgs& fb,
+                                                      unsigned char* smem_raw, int cand, int lane) {
   const int nq = m.nq, nv = m.nv, nu = m.nu, ndx = 2 * nv, ds = nq + nv, nr = tk.nr, H = a.H, Tn = fb.Tn;
   wreal *lnodes, *ltimes;
   // the policy scratch (dx[ndx], interpolated state[ds], current state[ds]) lives where the spline nodes would be
@@ -334,6 +334,36 @@ __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel 
     a.total_return[cand] = failed ? kMaxReturn : total / (wreal)(H > 1 ? H : 1);
     a.failure[cand] = failed ? 1 : 0;
   }
+}
+
+template <int NMAX, bool TREE = false, bool RK4 = false>
+__global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a,
+                                                                    const FeedbackWaveArgs fb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  feedback_rollout_body<NMAX, TREE, RK4>(m, tk, a, fb, smem_raw, blockIdx.x, threadIdx.x);
+}
+
+// the same for a REGISTERED model (tree_registry.h): its image and the per-plan blob staged into LDS as rollout_tree_kernel does
+// (tree_kernel.h). The iLQG phases are 1 and ~10 rollouts of pure per-step latency, and every model read on that chain is an LDS read
+// at a compile-time offset instead of a load through the caches: 0.20 against 0.26 ms per step (profiles/r03_latency_probe.log).
+template <class C>
+__global__ __launch_bounds__(64) void rollout_feedback_tree_kernel(const WModel m_in, const WTask tk_in, const RolloutArgs<wreal> a,
+                                                                    const FeedbackWaveArgs fb, const unsigned char* __restrict__ image,
+                                                                    unsigned blob_bytes) {
+  typedef LdsLayout<C, wreal> L;
+  const int lane = threadIdx.x;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(image);
+    uint4* dst = reinterpret_cast<uint4*>(mjpcx_lds);
+    for (unsigned i = lane; i < L::kBytes / 16; i += 64) dst[i] = src[i];
+    const uint4* bs = reinterpret_cast<const uint4*>(tk_in.blob);
+    uint4* bd = reinterpret_cast<uint4*>(mjpcx_lds + L::kBytes);
+    for (unsigned i = lane; i < blob_bytes / 16; i += 64) bd[i] = bs[i];
+  }
+  __syncthreads();
+  const LdsModelT<C, wreal> m(m_in);
+  const LdsTaskT<C, wreal> tk(tk_in, reinterpret_cast<const wreal*>(mjpcx_lds + L::kBytes));
+  feedback_rollout_body<C::NMAX, true, false>(m, tk, a, fb, mjpcx_lds + L::kBytes + blob_bytes, blockIdx.x, lane);
 }
 
 } }  // namespace mjpcx::WAVE_NS
