@@ -78,6 +78,36 @@ def test_falling_and_tumbling(quad):
     run(quad, np.concatenate([q, v]), N=4, H=60, P=3, interp=0, seed=5, tol=1e-5)
 
 
+def test_rollout_feedback_registered_and_generic_kernels_agree(quad, monkeypatch):
+    """The A1's feedback rollouts run on rollout_feedback_tree_kernel<A1> (model image and plan blob in LDS); MJPCX_NO_LDS_MODEL=1
+    keeps the context on the generic kernel (model behind global pointers). One step function, two sources of the same numbers."""
+    H = 24
+    pm, pt, nom, state = nominal_quad(quad, H, 21)
+    rng = np.random.default_rng(22)
+    gains = 0.05 * rng.normal(size=(H, 12, 36))
+    improvement = 0.05 * rng.normal(size=(H, 12))
+    alpha = np.concatenate([np.exp(np.linspace(0, np.log(1e-3), 9)), [0.0]])
+    start = state.copy()
+    start[19:] = 0.05 * rng.normal(size=18)
+    got = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("MJPCX_NO_LDS_MODEL", "1")
+        ctx = capi.Context(pm, pt, 0, 64)
+        assert ctx.kernel_name.startswith("rollout_wave_kernel" if generic else "rollout_quad_kernel")   # (the latter: a registered A1)
+        ctx.set_state(start, 0.0, MOCAP)
+        for mode, rep in ((0, 0), (1, 2)):
+            ctx.rollout_feedback(H, mode, rep, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+            ret, fail = ctx.returns()
+            tr = ctx.fetch_trajectory(3)
+            got.append((ret.copy(), fail.copy(), tr.states.copy(), tr.actions.copy(), tr.residual.copy(), tr.costs.copy()))
+        ctx.close()
+    for a, b in zip(got[:2], got[2:]):
+        assert not a[1].any() and not b[1].any()
+        for x, y in zip(a, b):
+            assert close(x, y, 1e-12), float(np.abs(x - y).max())
+
+
 @pytest.mark.parametrize("tree", [True, False])
 def test_rk4_integrator_on_the_wave_kernels(quad, tree, monkeypatch):
     """mjINT_RK4 on the A1: four forward passes (contacts, friction loss, the Newton solver warm-started from the previous step in
