@@ -91,6 +91,17 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
 #define QNOINLINE __device__ __noinline__
 #define QD __device__ __forceinline__
 #define QFAST_MATH 1
+#ifndef QEXP_NO_NT
+// trajectory buffers are written once and read by the host or a later kernel: stream them past the caches the spill traffic lives in
+#define QREC(dst, v) __builtin_nontemporal_store((v), &(dst))
+#endif
+#ifndef QEXP_NO_UNIFORM_TIME
+// every lane of a launch is at the same time: the node search of the policy becomes scalar loads and a scalar loop
+__device__ __forceinline__ double q_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+#define QUNIFORM_TIME(t) q_uniform(t)
+#endif
 // x > 0, normal: Newton refinement of the hardware estimates (v_rsq_f64 / v_rcp_f64 are good to about 2^-26)
 __device__ __forceinline__ void q_sqrt_rsqrt(double x, double& s, double& r) {
   double y = __builtin_amdgcn_rsq(x);

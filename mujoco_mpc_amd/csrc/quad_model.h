@@ -45,7 +45,7 @@ struct QuadPair {
 };
 
 struct QuadGeom {
-  int type, link, model_id, pad;  // link: -1 trunk, 0..2 link of the lane's leg
+  int type, link, model_id, static_mask;  // link: -1 trunk, 0..2 link of the lane's leg; static_mask: bit s = collides with static geom s
   double pos[3], rot[9], size[3]; // pose in the body frame (rotation matrix of geom_quat)
   double bound;                   // radius of its bounding sphere
 };
@@ -334,6 +334,7 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
       else ok = false;
       p.collide = ok;
       if (!ok) continue;
+      (slot_leg[g2] < 0 ? qm->trunk_geom[slot_idx[g2]] : qm->leg[slot_leg[g2]].geom[slot_idx[g2]]).static_mask |= 1 << s;
       { const std::string err = pair_params(g1, g2, p); if (!err.empty()) return err; }
     }
   }

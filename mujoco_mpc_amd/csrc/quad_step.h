@@ -479,6 +479,12 @@ QD void contact_line(const QContact& c, const double* fr, const double* jv, doub
 // jn = jn0 + alpha vn and the quadratic T^2 = A + 2 B alpha + C alpha^2 (B = UV at 0, C = VV, which does not depend on alpha), so a
 // trial costs a dozen flops per contact instead of a pass over its record. D0 carries the half weight of a leg-leg contact.
 constexpr int kQLineSlots = 4;
+#ifndef QREC
+#define QREC(dst, v) (dst) = (v)   // a trajectory-buffer store (the device build streams them past the caches: quad_kernel.h)
+#endif
+#ifndef QUNIFORM_TIME
+#define QUNIFORM_TIME(t) (t)       // the rollout's time is the same in every lane (the device build says so to the compiler)
+#endif
 #ifndef QGENERAL_FROM
 #define QGENERAL_FROM 2  // (tests build the emulator with 1: single pairs through the dense elimination as well)
 #endif
@@ -1134,8 +1140,8 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
       // bounding-sphere rejection: nothing of the geom within the margin of the plane (margins are far below this slack)
       const double cd = (gp[0] - p1[0]) * n[0] + (gp[1] - p1[1]) * n[1] + (gp[2] - p1[2]) * n[2];
       if (cd - g.bound >= 0.01) continue;
+      if (!((g.static_mask >> s) & 1)) continue;  // (QuadPair::collide, kept with the geom: the pair table is global memory)
       const QuadPair& p = pairs[s * pair_stride];
-      if (!p.collide) continue;
       if (g.type == MJPCX_GEOM_SPHERE) {
         sphere_plane(p, com, cvel, depth, p1, n, gp, g.size[0], cs, ncon, flags);
       } else if (g.type == MJPCX_GEOM_CAPSULE) {
@@ -1188,8 +1194,8 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
       QUNROLL for (int k = 0; k < 3; k++) { n[k] = gp[k] - p1[k]; len += n[k] * n[k]; }
       const double reach = S.size[0] + g.size[0] + 0.01;
       if (len >= reach * reach) continue;
+      if (!((g.static_mask >> s) & 1)) continue;
       const QuadPair& p = pairs[s * pair_stride];
-      if (!p.collide) continue;
       len = sqrt(len);
       const double r1 = S.size[0], dist = len - r1 - g.size[0];
       if (!(dist < p.margin)) continue;
@@ -1203,8 +1209,8 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
       QUNROLL for (int k = 0; k < 3; k++) rel[k] = gp[k] - p1[k];
       const double br = S.bound + g.size[0] + 0.01;
       if (rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] >= br * br) continue;
+      if (!((g.static_mask >> s) & 1)) continue;
       const QuadPair& p = pairs[s * pair_stride];
-      if (!p.collide) continue;
       QUNROLL for (int k = 0; k < 3; k++) loc[k] = R1[k] * rel[0] + R1[3 + k] * rel[1] + R1[6 + k] * rel[2];
       bool inside = true;
       QUNROLL for (int k = 0; k < 3; k++) {
@@ -2030,7 +2036,8 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     if (!last) {
       // policy: TimeSpline::Sample + Clamp (SamplingPolicy::Action)
       int up = 0;
-      while (up < P && a.node_times[up] <= S.time) up++;
+      const double now = QUNIFORM_TIME(S.time);
+      while (up < P && a.node_times[up] <= now) up++;
       QUNROLL for (int e = 0; e < 3; e++) {
         double u;
         if (up == P || up == 0) u = QNODE(up == 0 ? 0 : P - 1, e);
@@ -2075,18 +2082,18 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     // ---- record step t: the quad's four lanes share the row
     {
       double* st = a.states + ((size_t)cand * H + t) * ds;
-      if (leg == 0) QUNROLL for (int k = 0; k < 7; k++) st[k] = S.tq[k];
-      if (leg == 1) QUNROLL for (int k = 0; k < 6; k++) st[19 + k] = S.tv[k];
-      QUNROLL for (int j = 0; j < 3; j++) { st[7 + 3 * leg + j] = S.lq[j]; st[25 + 3 * leg + j] = S.lv[j]; }
+      if (leg == 0) QUNROLL for (int k = 0; k < 7; k++) QREC(st[k], S.tq[k]);
+      if (leg == 1) QUNROLL for (int k = 0; k < 6; k++) QREC(st[19 + k], S.tv[k]);
+      QUNROLL for (int j = 0; j < 3; j++) { QREC(st[7 + 3 * leg + j], S.lq[j]); QREC(st[25 + 3 * leg + j], S.lv[j]); }
       double* ac = a.actions + ((size_t)cand * H + t) * nu;
-      QUNROLL for (int j = 0; j < 3; j++) ac[3 * leg + j] = ctrl[j];
+      QUNROLL for (int j = 0; j < 3; j++) QREC(ac[3 * leg + j], ctrl[j]);
       double* rs = a.residual + ((size_t)cand * H + t) * nr;
-      if (leg == 2) { QUNROLL for (int i = 0; i < 7; i++) rs[i] = r.shared[i]; }
-      if (leg == 3) { rs[11] = r.shared[7]; rs[12] = r.shared[8]; QUNROLL for (int i = 0; i < 5; i++) rs[37 + i] = r.shared[9 + i]; }
-      rs[7 + L.foot_index] = r.gait;
-      QUNROLL for (int j = 0; j < 3; j++) { rs[13 + 3 * leg + j] = r.effort[j]; rs[25 + 3 * leg + j] = r.posture[j]; }
-      if (leg == 0) { a.times[(size_t)cand * H + t] = S.time; a.costs[(size_t)cand * H + t] = cost; }
-      if (leg == 1) for (int q = 0; q < m.ntrace; q++) QUNROLL for (int k = 0; k < 3; k++) a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k] = f.trace[q][k];
+      if (leg == 2) { QUNROLL for (int i = 0; i < 7; i++) QREC(rs[i], r.shared[i]); }
+      if (leg == 3) { QREC(rs[11], r.shared[7]); QREC(rs[12], r.shared[8]); QUNROLL for (int i = 0; i < 5; i++) QREC(rs[37 + i], r.shared[9 + i]); }
+      QREC(rs[7 + L.foot_index], r.gait);
+      QUNROLL for (int j = 0; j < 3; j++) { QREC(rs[13 + 3 * leg + j], r.effort[j]); QREC(rs[25 + 3 * leg + j], r.posture[j]); }
+      if (leg == 0) { QREC(a.times[(size_t)cand * H + t], S.time); QREC(a.costs[(size_t)cand * H + t], cost); }
+      if (leg == 1) for (int q = 0; q < m.ntrace; q++) QUNROLL for (int k = 0; k < 3; k++) QREC(a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k], f.trace[q][k]);
     }
     total += cost;
     if (a.con_cap > 0 && qd_or(D.ncon > a.con_cap ? 1 : 0)) { flags = kFlagOverflow; break; }
