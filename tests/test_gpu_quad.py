@@ -136,3 +136,31 @@ def test_determinism_and_sharding(quad):
     ctx.rollout_noise(N // 2, H, 0, times, nominal, half)
     assert np.array_equal(ctx.returns()[0], r1[N // 2:])
     ctx.close()
+
+
+def test_ragged_batches_and_short_horizons(quad):
+    """Batches that do not fill a wavefront (16 candidates each) or end inside one, and horizons of one and two steps: a candidate's
+    rollout does not depend on its neighbours in the wavefront or on the batch size (bit for bit), and the short horizons agree with the
+    oracle (H = 1 is one sensor stage: the return is that step's cost)."""
+    pm, pt = quad.packed_model(), quad.packed()
+    P = 3
+    state = np.concatenate([quad.model.keyframes["home"]["qpos"], np.zeros(18)])
+    ctx = context(quad)
+    for H in (1, 2, 30):
+        times = np.arange(P) * (max(H - 1, 1) * 0.01 / (P - 1))
+        nominal = np.clip(np.random.default_rng(5).normal(0, 0.05, (P, 12)), -1, 1)
+        ns = capi.make_noise_spec(seed=9, iteration=2, mode=capi.NOISE_SAMPLING, std0=0.05)
+        ctx.rollout_noise(64, H, capi.SPLINE_LINEAR, times, nominal, ns)
+        full, fail = ctx.returns()
+        full = full.copy()
+        assert not fail.any() and ctx.quad_stats()["handed_on"] == 0
+        nodes = np.stack([ctx.fetch_spline(i) for i in range(64)])
+        for N in (1, 3, 17, 49):
+            ctx.rollout_noise(N, H, capi.SPLINE_LINEAR, times, nominal, ns)
+            r, f = ctx.returns()
+            assert r.shape == (N,) and not f.any() and np.array_equal(r, full[:N]), (H, N)
+        ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, 8, H, P, capi.SPLINE_LINEAR, times, nodes[:8], num_threads=2)
+        assert close(full[:8], ref["total_return"], 1e-9), (H, float(np.abs(full[:8] - ref["total_return"]).max()))
+        if H == 1:
+            assert close(full[:8], ref["costs"][:, 0], 1e-9)
+    ctx.close()
