@@ -1592,22 +1592,8 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
   const bool tree = c->wh.tree_ok && !c->no_tree;
   const int Ppolicy = tree ? (int)(ndx + 2 * ds) : (int)((ndx + 2 * ds + nu - 1) / nu + 1);
   const size_t lds = wave_lds_bytes(c, Ppolicy, tree);
-  const bool rk4 = c->wh.m.integrator == MJPCX_INT_RK4;  // (one NMAX = 32 instantiation per family carries mj_RungeKutta)
-  auto kern = rk4 ? (tree ? w64::rollout_feedback_wave_kernel<32, true, true> : w64::rollout_feedback_wave_kernel<32, false, true>)
-            : tree ? (c->wh.m.nv <= 18 ? w64::rollout_feedback_wave_kernel<18, true> : w64::rollout_feedback_wave_kernel<32, true>)
-            : c->wh.m.nv <= 20 ? w64::rollout_feedback_wave_kernel<20> : w64::rollout_feedback_wave_kernel<32>;
-  const size_t fixed = LdsLayout<TreeCfgA1, double>::kBytes + c->wh.blob_bytes;
-  if (c->wh.registered == 0 && tree && !rk4 && c->wh.dev_image && fixed + lds <= 160 * 1024) {
-    // registered model: image + blob + one arena per workgroup (the launch is a handful of wavefronts: nothing to share an image between)
-    auto reg = w64::rollout_feedback_tree_kernel<TreeCfgA1>;
-    HIPCHK(c, hipFuncSetAttribute((const void*)reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fixed + lds)));
-    hipLaunchKernelGGL(reg, dim3(N), dim3(64), fixed + lds, c->stream, c->wh.m, wt, a, fb, (const unsigned char*)c->wh.dev_image,
-                       (unsigned)c->wh.blob_bytes);
-  } else {
-    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, c->wh.m, wt, a, fb);
-  }
-  HIPCHK(c, hipGetLastError());
+  const bool rk4 = c->wh.m.integrator == MJPCX_INT_RK4;
+  HIPCHK(c, launch_feedback_wave(c->wh.m, wt, a, fb, N, lds, tree, rk4, c->wh.registered == 0 ? c->wh.dev_image : nullptr, c->wh.blob_bytes, c->stream));
   c->N = N; c->H = H; c->P = 1;
   c->have_rollout = true;
   c->traj_candidate_major = true;
@@ -1639,15 +1625,8 @@ int do_transition_fd_wave(mjpcx_ctx* c, int Tn, const double* times, const doubl
   const bool tree = c->wh.tree_ok && !c->no_tree;
   const size_t lds = wave_lds_bytes(c, 1, tree);
   const bool rk4 = c->wh.m.integrator == MJPCX_INT_RK4;
-  auto kern = rk4 ? (tree ? w64::transition_fd_wave_kernel<32, true, true> : w64::transition_fd_wave_kernel<32, false, true>)
-            : tree ? (c->wh.m.nv <= 18 ? w64::transition_fd_wave_kernel<18, true> : w64::transition_fd_wave_kernel<32, true>)
-            : c->wh.m.nv <= 20 ? w64::transition_fd_wave_kernel<20> : w64::transition_fd_wave_kernel<32>;
-  HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)(Tn * nc)), dim3(64), lds, c->stream, c->wh.m, wt, f);
-  HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(w64::fd_tangent_kernel, dim3((unsigned)std::min<size_t>((Tn * nc + 63) / 64, 1024)), dim3(64), 0, c->stream, c->wh.m,
-                     (const double*)base, (double*)(base + off_tan), Tn, (int)nc);
-  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, launch_transition_fd_wave(c->wh.m, wt, f, (unsigned)(Tn * nc), lds, tree, rk4, c->stream));
+  HIPCHK(c, launch_fd_tangent(c->wh.m, (const double*)base, (double*)(base + off_tan), Tn, (int)nc, c->stream));
   double* dA = (double*)(base + off_A);
   double *dB = dA + nA, *dC = dB + nB, *dD = dC + nC;
   const int total = (int)(Tn * (ndx + nr) * (ndx + nu));
@@ -1705,9 +1684,7 @@ int mjpcx_kinematics(mjpcx_ctx* c, double* xpos, double* xquat, double* xmat, do
   HIPCHK(c, c->d_ilqg_out.reserve(total * 8));
   HIPCHK(c, hipMemsetAsync(c->d_ilqg_out.p, 0, total * 8, c->stream));
   const size_t lds = wave_lds_bytes(c, 1);
-  HIPCHK(c, hipFuncSetAttribute((const void*)w64::kinematics_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(w64::kinematics_wave_kernel, dim3(1), dim3(64), lds, c->stream, c->wh.m, wt, (double*)c->d_ilqg_out.p, (int)nb, (int)ns);
-  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, launch_kinematics_wave(c->wh.m, wt, (double*)c->d_ilqg_out.p, (int)nb, (int)ns, lds, c->stream));
   std::vector<double> h(total);
   HIPCHK(c, hipMemcpyAsync(h.data(), c->d_ilqg_out.p, total * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

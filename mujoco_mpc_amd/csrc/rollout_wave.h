@@ -22,6 +22,7 @@
 #include "tree_registry.h"
 #include "quad_abi.h"  // kQFallback
 #include "ilqg_kernels.h"  // find_interval, fd_assemble_kernel
+#include "wave_ilqg_launch.h"  // FdWaveArgs, FeedbackWaveArgs
 
 // The device code below is instantiated twice, textually: namespace mjpcx::w64 with wreal = double (the parity path, also
 // the finite-difference and feedback-rollout kernels of iLQG) and mjpcx::w32 with wreal = float (BASELINE configs[3]'s
@@ -66,7 +67,9 @@ __device__ __forceinline__ float dpp_move(float v) {
 #include "wave_residual.h"
 #include "wave_kernel.h"
 #include "tree_kernel.h"
+#ifdef MJPCX_WITH_ILQG_WAVE_KERNELS  // (ilqg_wave.hip: the iLQG kernels are instantiated in that translation unit only)
 #include "wave_ilqg.h"
+#endif
 #undef MJPCX_WAVE_ILQG
 #undef WAVE_KERNEL_ATTR
 #undef wreal

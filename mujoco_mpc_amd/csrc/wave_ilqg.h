@@ -51,13 +51,6 @@ __device__ __forceinline__ void w_state_diff(const MODEL& m, wreal* dx, const wr
   if (lane < nv) dx[nv + lane] = s2[nq + lane] - s1[nq + lane];
 }
 
-struct FdWaveArgs {
-  const wreal *times, *states, *actions;  // [Tn], [Tn][nq+nv], [Tn][nu]
-  int Tn, ncol;                            // ncol = 1 + 2 (2 nv + nu): 0 nominal | +x_j | -x_j | +u_k | -u_k
-  wreal eps;
-  wreal* next;    // [Tn][ncol][nq+nv] raw next states
-  wreal* sensor;  // [Tn][ncol][nr]
-};
 
 // TREE: the Jacobian-free forward pass of wave_tree.h (its LDS layout, its contact lists at the large capacities) instead of the
 // row-table one -- the same step function the rollout kernels of such a model use
@@ -180,10 +173,6 @@ __global__ void fd_tangent_kernel(const WModel m, const wreal* __restrict__ next
   }
 }
 
-struct FeedbackWaveArgs {
-  const wreal *times, *states, *actions, *gains, *improvement, *alpha;  // as FeedbackArgs (ilqg_kernels.h)
-  int Tn, mode, representation, use_state;
-};
 
 // one candidate's rollout under the feedback policy, by one wavefront; MODEL / TASK: the generic structs (arrays behind global pointers)
 // or a registered model's LDS image (lds_model.h)
