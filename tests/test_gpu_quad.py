@@ -164,3 +164,15 @@ def test_ragged_batches_and_short_horizons(quad):
         if H == 1:
             assert close(full[:8], ref["costs"][:, 0], 1e-9)
     ctx.close()
+
+
+def test_random_states_against_the_oracle():
+    """tools/fuzz_quad.py: 60 random plan states (trunk poses and heights, legs far from home, fast initial velocities), horizons, spline
+    representations and noise levels, 32 candidates each, against the oracle at 1e-9 (returns) / 1e-7 (states after the horizon);
+    candidates the quad kernel hands on are included (they come back from the other kernel). 1050 such cases: profiles/r03_fuzz_quad.log"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_quad.py"), "60", "7"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "60 cases x 32 candidates" in out.stdout.splitlines()[-1]
