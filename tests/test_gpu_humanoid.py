@@ -179,3 +179,17 @@ def test_a_folded_body_with_more_contacts_than_the_first_pass_stages():
         tr = ctx.fetch_trajectory(c)
         assert close(tr.states, ref["states"][c], 1e-6)
     ctx.close()
+
+
+def test_random_states_against_the_oracle():
+    """tools/fuzz_humanoid.py: 30 random cases -- every motion of the clip set at a random time, joints / orientation / velocities
+    perturbed around the clip's pose (every third case far: folded limbs, self-collision, tendon limits), all three spline
+    representations -- 8 candidates x 40 steps each on rollout_tree_kernel<Humanoid> (fp64) against the oracle: failure flags equal,
+    states and residuals of the first steps within 1e-9. 90 such cases: profiles/r03_fuzz_humanoid.log (2e-11 over 40 steps)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_humanoid.py"), "30", "3"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "30 cases x 8 candidates" in out.stdout.splitlines()[-1]

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Random-state parity sweep of the Humanoid tracking task's kernel (rollout_tree_kernel<Humanoid>, fp64) against the oracle (run on
+the GPU box): every motion of the clip set at a random time, joints and velocities perturbed around the clip's pose (every third case
+far: folded limbs, self-collision, tendon limits), controls of every size. Agreement is judged over the first steps at 1e-9 -- the
+chaotic humanoid amplifies rounding differences by orders of magnitude over 40 steps, which is reported but not asserted -- and on the
+failure flags."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.task import load_task
+from oracle import pyoracle
+
+
+def mocap7(mpos):
+    return np.concatenate([np.concatenate([p, [1, 0, 0, 0]]) for p in np.asarray(mpos).reshape(-1, 3)])
+
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t = load_task("HumanoidTrack")
+worst_first = worst_all = 0.0
+flagged = 0
+for case in range(cases):
+    mode = int(rng.integers(0, 10))
+    time = float(rng.uniform(0, 1.5))
+    e0 = t.transition(0.0, mode=mode)     # the motion's first keyframe: the pose the perturbations start from
+    e = t.transition(time, mode=mode)     # the reference at `time`: mocap targets between two keyframes
+    pm, pt = t.packed_model(), t.packed()
+    ctx = capi.Context(pm, pt, 0, 64)   # (the task's per-mode residual state is part of the context)
+    assert "rollout_tree_kernel<Humanoid>" in ctx.kernel_name
+    q = np.array(e0["qpos"], float)
+    far = case % 3 == 2
+    q[7:] += rng.normal(0, 0.6 if far else 0.1, q.size - 7)
+    quat = q[3:7] + rng.normal(0, 0.4 if far else 0.05, 4)
+    q[3:7] = quat / np.linalg.norm(quat)
+    q[2] += rng.uniform(-0.3, 0.3) if far else 0.0
+    v = np.array(e0["qvel"], float) + rng.normal(0, 2.0 if far else 0.3, 27)
+    state = np.concatenate([q, v])
+    mocap = mocap7(e["mocap_pos"])
+    N, H, P = 8, 40, int(rng.integers(2, 6))
+    interp = int(rng.integers(0, 3))
+    dt = t.model.get_number("agent_timestep", t.model.timestep)
+    times = time + np.arange(P) * ((H - 1) * dt / (P - 1))
+    nodes = np.clip(rng.normal(0, float(rng.choice([0.1, 0.4, 1.0])), (N, P, t.model.nu)), -1, 1)
+    ctx.set_state(state, time, mocap)
+    ctx.rollout_splines(H, interp, times, nodes)
+    ret, fail = ctx.returns()
+    ref = pyoracle.rollout_batch(pm, pt, state, time, mocap, N, H, P, interp, times, nodes, num_threads=8)
+    assert np.array_equal(np.asarray(fail, bool), np.asarray(ref["failure"], bool)), (case, fail, ref["failure"])
+    flagged += int(np.asarray(fail, bool).sum())
+    e_first = e_all = 0.0
+    for c in range(N):
+        if fail[c]:
+            continue
+        tr = ctx.fetch_trajectory(c)
+        d = np.abs(tr.states - ref["states"][c]) / (1 + np.abs(ref["states"][c]))
+        dr = np.abs(tr.residual - ref["residual"][c]) / (1 + np.abs(ref["residual"][c]))
+        e_first = max(e_first, float(d[:4].max()), float(dr[:4].max()))
+        e_all = max(e_all, float(d.max()))
+    worst_first, worst_all = max(worst_first, e_first), max(worst_all, e_all)
+    ctx.close()
+    bad = e_first >= 1e-9
+    if bad or case % 5 == 0:
+        print(f"case {case:3d}: mode {mode:2d} t = {time:.2f} {'far ' if far else 'near'} interp {interp} P = {P} flagged {int(np.asarray(fail, bool).sum())}  first 4 steps {e_first:.2e}  40 steps {e_all:.2e}{'   <-- beyond tolerance' if bad else ''}", flush=True)
+print(f"{cases} cases x 8 candidates: worst over the first 4 steps {worst_first:.3e}, over 40 steps {worst_all:.3e}, flagged rollouts (same on both sides) {flagged}")
+assert worst_first < 1e-9

@@ -2,10 +2,12 @@
 """Random-state parity sweep of rollout_quad_kernel against the oracle (run on the GPU box): random trunk poses / heights / velocities,
 joint angles around the home pose, goals, gait modes of the residual, spline representations and noise levels. Prints the worst
 relative error of the returns and of the final states per case, how many candidates were handed to the other kernel, and fails loudly
-beyond 1e-9 (returns) / 1e-7 (states after the horizon: contact switching amplifies the 1e-13 per-step agreement)."""
+beyond 1e-9 (returns) / 1e-7 (states after the horizon: contact switching amplifies the 1e-13 per-step agreement).
+  python tools/fuzz_quad.py [cases] [seed] [tree]      tree: the same sweep on rollout_tree_kernel<A1> (MJPCX_NO_QUAD=1), at 1e-7 / 1e-5"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["MJPCX_QUAD_MIN_N"] = "0"
+TREE = len(sys.argv) > 3 and sys.argv[3] == "tree"   # the same sweep on the wavefront-per-candidate kernel of the A1 (rollout_tree_kernel<A1>)
+os.environ["MJPCX_NO_QUAD" if TREE else "MJPCX_QUAD_MIN_N"] = "1" if TREE else "0"
 import numpy as np
 from mujoco_mpc_amd import capi
 from mujoco_mpc_amd.task import load_task
@@ -18,7 +20,7 @@ t.transition(0.0)
 pm, pt = t.packed_model(), t.packed()
 home = t.model.keyframes["home"]["qpos"]
 ctx = capi.Context(pm, pt, 0, 64)
-assert ctx.kernel_name.startswith("rollout_quad_kernel")
+assert ctx.kernel_name.startswith("rollout_tree_kernel<A1>" if TREE else "rollout_quad_kernel")
 worst_r = worst_s = 0.0
 handed = failed = 0
 for case in range(cases):
@@ -39,7 +41,7 @@ for case in range(cases):
     ctx.set_state(state, 0.01 * case, mocap)
     ctx.rollout_noise(N, H, interp, times, nominal, ns)
     ret, fail = ctx.returns()
-    st = ctx.quad_stats()
+    st = {"handed_on": 0} if TREE else ctx.quad_stats()
     handed += st["handed_on"]
     nodes = np.stack([ctx.fetch_spline(i) for i in range(N)])
     ref = pyoracle.rollout_batch(pm, pt, state, 0.01 * case, mocap, N, H, P, interp, times, nodes, num_threads=8)
@@ -53,8 +55,8 @@ for case in range(cases):
             tr = ctx.fetch_trajectory(int(c))
             es = max(es, float(np.max(np.abs(tr.states - ref["states"][c]) / (1 + np.abs(ref["states"][c])))))
         worst_r, worst_s = max(worst_r, er), max(worst_s, es)
-        flag = "" if er < 1e-9 and es < 1e-7 else "   <-- beyond tolerance"
+        flag = "" if er < (1e-7 if TREE else 1e-9) and es < (1e-5 if TREE else 1e-7) else "   <-- beyond tolerance"
         if flag or case % 10 == 0:
             print(f"case {case:3d}: H = {H:2d} P = {P} interp {interp} handed on {st['handed_on']:2d} failed {int((~ok).sum()):2d}  returns {er:.2e} states {es:.2e}{flag}", flush=True)
 print(f"{cases} cases x 32 candidates: worst returns {worst_r:.3e}, worst states {worst_s:.3e}, handed on {handed}, failed rollouts (both sides) {failed}")
-assert worst_r < 1e-9 and worst_s < 1e-7
+assert worst_r < (1e-7 if TREE else 1e-9) and worst_s < (1e-5 if TREE else 1e-7)   # (the other kernel's sums run in another order: its suite's tolerance)
