@@ -17,8 +17,10 @@ def mocap7(mpos):
 
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+PREC = int(sys.argv[3]) if len(sys.argv) > 3 else 64   # 32: the fp32 kernel of configs[3] against the fp64 oracle (first steps at 2e-4, returns reported)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t = load_task("HumanoidTrack")
+TOL = 1e-9 if PREC == 64 else 2e-4
 worst_first = worst_all = 0.0
 flagged = 0
 for case in range(cases):
@@ -27,7 +29,7 @@ for case in range(cases):
     e0 = t.transition(0.0, mode=mode)     # the motion's first keyframe: the pose the perturbations start from
     e = t.transition(time, mode=mode)     # the reference at `time`: mocap targets between two keyframes
     pm, pt = t.packed_model(), t.packed()
-    ctx = capi.Context(pm, pt, 0, 64)   # (the task's per-mode residual state is part of the context)
+    ctx = capi.Context(pm, pt, 0, PREC)   # (the task's per-mode residual state is part of the context)
     assert "rollout_tree_kernel<Humanoid>" in ctx.kernel_name
     q = np.array(e0["qpos"], float)
     far = case % 3 == 2
@@ -47,7 +49,9 @@ for case in range(cases):
     ctx.rollout_splines(H, interp, times, nodes)
     ret, fail = ctx.returns()
     ref = pyoracle.rollout_batch(pm, pt, state, time, mocap, N, H, P, interp, times, nodes, num_threads=8)
-    assert np.array_equal(np.asarray(fail, bool), np.asarray(ref["failure"], bool)), (case, fail, ref["failure"])
+    if PREC == 64:
+        assert np.array_equal(np.asarray(fail, bool), np.asarray(ref["failure"], bool)), (case, fail, ref["failure"])
+    fail = np.asarray(fail, bool) | np.asarray(ref["failure"], bool)
     flagged += int(np.asarray(fail, bool).sum())
     e_first = e_all = 0.0
     for c in range(N):
@@ -60,8 +64,11 @@ for case in range(cases):
         e_all = max(e_all, float(d.max()))
     worst_first, worst_all = max(worst_first, e_first), max(worst_all, e_all)
     ctx.close()
-    bad = e_first >= 1e-9
+    bad = e_first >= TOL
+    if PREC == 32 and e_all > 0.1:   # a chaotic case: show how far the returns are apart
+        okc = ~fail
+        print(f"case {case:3d}: 40-step state error {e_all:.2e}; returns device / oracle: " + " ".join(f"{a:.4g}/{b:.4g}" for a, b in zip(ret[okc], ref["total_return"][okc])), flush=True)
     if bad or case % 5 == 0:
         print(f"case {case:3d}: mode {mode:2d} t = {time:.2f} {'far ' if far else 'near'} interp {interp} P = {P} flagged {int(np.asarray(fail, bool).sum())}  first 4 steps {e_first:.2e}  40 steps {e_all:.2e}{'   <-- beyond tolerance' if bad else ''}", flush=True)
 print(f"{cases} cases x 8 candidates: worst over the first 4 steps {worst_first:.3e}, over 40 steps {worst_all:.3e}, flagged rollouts (same on both sides) {flagged}")
-assert worst_first < 1e-9
+assert worst_first < TOL
