@@ -463,3 +463,15 @@ def test_kinematics_query(name):
         assert close(k[key][first:live], ref[first:live], 1e-12), key
         assert np.all(k[key][live:] == 0)
     ctx.close()
+
+
+def test_ilqg_kernels_on_random_states():
+    """tools/fuzz_ilqg.py: 12 random A1 states -- a nominal trajectory each, feedback rollouts in both policy modes and all three
+    representations with random gains (1e-7), forward and centred derivative sweeps (5e-5). 40 such cases: profiles/r03_fuzz_ilqg.log"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_ilqg.py"), "12", "5"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.stdout.splitlines()[-1].startswith("12 cases")

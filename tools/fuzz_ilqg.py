@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Random-state parity sweep of the iLQG device kernels of the A1 (run on the GPU box): a nominal trajectory from a random state under
+a random spline, then (a) the feedback rollouts -- RolloutDiscrete with the index policy and iLQGPolicy::Action in its three
+representations, random gains, ten line-search scalings -- against oracle/ilqg.c at 1e-7, and (b) the finite-difference sweep
+(forward and centred) against the oracle's at 5e-5 (the quotient amplifies the step functions' 1e-13 agreement by 1 / eps = 1e6, and a
+contact that switches inside the perturbation is a genuinely large entry on both sides)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mujoco_mpc_amd import capi
+from mujoco_mpc_amd.task import load_task
+from oracle import pyoracle
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t = load_task("QuadrupedFlat")
+t.transition(0.0)
+pm, pt = t.packed_model(), t.packed()
+home = t.model.keyframes["home"]["qpos"]
+ctx = capi.Context(pm, pt, 0, 64)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / (1 + np.abs(b))))
+
+
+worst_fb = worst_fd = 0.0
+for case in range(cases):
+    H = int(rng.integers(8, 30))
+    q = home.copy()
+    q[0:2] += rng.normal(0, 0.2, 2)
+    q[2] += rng.uniform(-0.08, 0.1)
+    quat = np.array([1.0, 0, 0, 0]) + rng.normal(0, 0.15, 4)
+    q[3:7] = quat / np.linalg.norm(quat)
+    q[7:] += rng.normal(0, 0.25, 12)
+    state = np.concatenate([q, rng.normal(0, 0.4, 18)])
+    mocap = np.array([rng.normal(0, 1.0), rng.normal(0, 1.0), 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0.0])
+    times = np.arange(4) * (H - 1) * 0.01 / 3
+    nodes = np.clip(rng.normal(0, 0.2, (1, 4, 12)), -1, 1)
+    nom = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, 1, H, 4, 1, times, nodes, num_threads=1)
+    nom = {k: v[0] for k, v in nom.items() if k not in ("total_return", "failure")}
+    gains = float(rng.choice([0.01, 0.05, 0.2])) * rng.normal(size=(H, 12, 36))
+    improvement = 0.05 * rng.normal(size=(H, 12))
+    alpha = np.concatenate([np.exp(np.linspace(0, np.log(1e-3), 9)), [0.0]])
+    start = state.copy()
+    start[0:3] += rng.normal(0, 0.01, 3)
+    qq = start[3:7] + rng.normal(0, 0.02, 4)
+    start[3:7] = qq / np.linalg.norm(qq)
+    start[19:] += 0.05 * rng.normal(size=18)
+    e_fb = 0.0
+    for mode, rep in ((0, 0), (1, 0), (1, 1), (1, 2)):
+        ctx.set_state(start, 0.0, mocap)
+        ctx.rollout_feedback(H, mode, rep, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+        ret, fail = ctx.returns()
+        ref = pyoracle.rollout_feedback(pm, pt, start, 0.0, mocap, H, mode, rep, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+        assert np.array_equal(np.asarray(fail, bool), np.asarray(ref["failure"], bool)), (case, mode, rep, fail, ref["failure"])
+        ok = ~np.asarray(fail, bool)
+        if ok.any():
+            e_fb = max(e_fb, rel(ret[ok], ref["total_return"][ok]))
+            c = int(np.flatnonzero(ok)[0])
+            e_fb = max(e_fb, rel(ctx.fetch_trajectory(c).states, ref["states"][c]))
+    e_fd = 0.0
+    Hd = min(H, 8)
+    for centered in (0, 1):
+        ctx.set_state(state, 0.0, mocap)
+        A, B, C, D = ctx.transition_fd(nom["times"][:Hd], nom["states"][:Hd], nom["actions"][:Hd], 1e-6, centered)
+        Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"][:Hd], nom["times"][:Hd], nom["actions"][:Hd], 1e-6, centered, mocap=mocap)
+        e_fd = max(e_fd, rel(A, Ao), rel(B, Bo), rel(C, Co), rel(D, Do))
+    worst_fb, worst_fd = max(worst_fb, e_fb), max(worst_fd, e_fd)
+    bad = e_fb >= 1e-7 or e_fd >= 5e-5
+    if bad or case % 5 == 0:
+        print(f"case {case:3d}: H = {H:2d}  feedback rollouts {e_fb:.2e}  derivative sweep {e_fd:.2e}{'   <-- beyond tolerance' if bad else ''}", flush=True)
+print(f"{cases} cases: worst feedback rollouts {worst_fb:.3e}, worst derivative sweep {worst_fd:.3e}")
+assert worst_fb < 1e-7 and worst_fd < 5e-5
