@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libmjpcx.so")
 # (source, extra flags). lane_static.hip holds the instantiations specialised for compile-time model
 # constants; its flags let exact-zero arithmetic fold (see the file header).
-SOURCES = [("mjpcx.hip", []), ("ilqg_wave.hip", []), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]), ("quad_kernel.hip", [])]
+SOURCES = [("mjpcx.hip", []), ("ilqg_wave.hip", []), ("wave32.hip", []), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]), ("quad_kernel.hip", [])]
 # headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
 # re-compile the wavefront-per-candidate kernels, and vice versa)
 QUAD_ONLY = ["quad_step.h", "quad_kernel.h", "quad_model.h"]

@@ -20,6 +20,8 @@
 #include "ilqg_dense.h"
 #include "rollout_wave.h"
 #include "quad_launch.h"
+#include "wave32_launch.h"
+#include <type_traits>
 #include <dlfcn.h>
 #include <mutex>
 #include <chrono>
@@ -588,13 +590,11 @@ hipError_t launch_tree_pass(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTas
     if ((e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, c->stream, wm, wt, a, (const unsigned char*)image, (unsigned)blob_bytes, (unsigned)arena,
                        (int*)c->d_work.p, mode, (T*)slabs);
-  } else {
-    auto kern = w32::rollout_tree_kernel<C, BIG>;
-    if ((e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, c->stream, wm, wt, a, (const unsigned char*)image, (unsigned)blob_bytes, (unsigned)arena,
-                       (int*)c->d_work.p, mode, (T*)slabs);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  } else {  // (the fp32 kernels live in wave32.hip)
+    if ((e = launch_tree_kernel_f32(std::is_same<C, TreeCfgA1>::value ? 0 : 1, BIG, grid, 64 * W, lds, wm, wt, a, (const unsigned char*)image,
+                                    (unsigned)blob_bytes, (unsigned)arena, (int*)c->d_work.p, mode, (float*)slabs, c->stream)) != hipSuccess) return e;
   }
-  if ((e = hipGetLastError()) != hipSuccess) return e;
   if (c->stamp_step >= 0) std::fprintf(stderr, "rollout_tree_kernel%s: %d wavefronts per workgroup, grid %d, LDS %zu B (arena %zu B)\n", BIG ? " (second pass)" : "", W, grid, lds, arena);
   if (mode & 2) {  // self-check launch: report the mismatch count
     int h[2] = {0, 0};
@@ -834,27 +834,15 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
                                 : (4 * w32::wave_lds_elems(wm.nq, wm.nv, wm.nu, wm.nbody, wm.njnt, wm.nsite, wt.nr, wt.nterm, P, wm.cone, /*nodes_in_lds=*/false, a.xfrc_scale > 0) + 15) & ~(size_t)15;
     const size_t lds = two_pass ? tree_lds(w32::kTreeMaxSimple, w32::kTreeMaxCone) : lds_big;
     if (lds_big > 160 * 1024) return fail(c, MJPCX_EUNSUPPORTED, "model state does not fit the 160 KB LDS of a CU");
-    auto kern_big = wm.integrator == MJPCX_INT_RK4 ? w32::rollout_wave_kernel<32, false, true>
-              : tree ? w32::rollout_wave_kernel<32, true>
-              : wm.nv <= 18 ? w32::rollout_wave_kernel<18> : wm.nv <= 20 ? w32::rollout_wave_kernel<20>
-              : wm.nv <= 28 ? w32::rollout_wave_kernel<28> : w32::rollout_wave_kernel<32>;
-    auto kern = !two_pass ? kern_big
-              : w32::rollout_wave_kernel<32, true, false, true>;
-    le = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (le == hipSuccess) {
-      hipLaunchKernelGGL(kern, dim3(N), dim3(64), lds, c->stream, wm, wt, a);
-      le = hipGetLastError();
-    }
+    const int kern_big = wm.integrator == MJPCX_INT_RK4 ? kW32Rk4 : tree ? kW32Tree
+                       : wm.nv <= 18 ? kW32Rows18 : wm.nv <= 20 ? kW32Rows20 : wm.nv <= 28 ? kW32Rows28 : kW32Rows32;
+    le = launch_wave_kernel_f32(two_pass ? kW32TreeSmall : kern_big, N, lds, wm, wt, a, c->stream);  // (the fp32 kernels live in wave32.hip)
     if (two_pass && le == hipSuccess) {
       if (c->timing && c->cur_main) { if ((le = hipEventRecord(c->cur_main, c->stream)) == hipSuccess) c->cur_main = nullptr; }
       RolloutArgs<float> a2 = a;
       a2.noise.mode = -1;
       a2.only_overflowed = 1;
-      if (le == hipSuccess) le = hipFuncSetAttribute((const void*)kern_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
-      if (le == hipSuccess) {
-        hipLaunchKernelGGL(kern_big, dim3(N), dim3(64), lds_big, c->stream, wm, wt, a2);
-        le = hipGetLastError();
-      }
+      if (le == hipSuccess) le = launch_wave_kernel_f32(kern_big, N, lds_big, wm, wt, a2, c->stream);
     }
     if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, lds, tree);
     }
