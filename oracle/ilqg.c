@@ -9,6 +9,7 @@
  *     RolloutDiscrete (mjpc/trajectory.cc:92-309)
  * TEST INFRASTRUCTURE ONLY (see oracle.h). */
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
@@ -287,21 +288,36 @@ static void fb_action(const FbPolicy* p, double* action, const double* state, do
   clamp_ctrl(m, action);
 }
 
-/* N rollouts sharing the nominal trajectory, differing by alpha[i]; outputs candidate-major like orollout_batch */
-int orollout_feedback(const mjpcx_model* m, const mjpcx_task* task, const double* state, double time, const double* mocap,
-                      int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
-                      const double* states, const double* actions, const double* gains, const double* improvement,
-                      const double* alpha, OBatchOut* out) {
-  const int nu = m->nu, ds = m->nq + m->nv, nr = task->num_residual, ntr = task->num_trace;
+/* N rollouts sharing the nominal trajectory, differing by alpha[i]; outputs candidate-major like orollout_batch. The candidates are
+ * fanned over num_threads workers, one physics arena each, as iLQGPlanner::ActionRollouts schedules them on the ThreadPool
+ * (ilqg/planner.cc:630-692); a candidate's numbers do not depend on the worker that rolls it out. */
+typedef struct {
+  const mjpcx_model* m; const mjpcx_task* task;
+  const double *state, *mocap, *times, *states, *actions, *gains, *improvement, *alpha;
+  double time;
+  int N, H, mode, representation, use_state, Tn;
+  OBatchOut* out;
+  int next, failed;
+} FbBatch;
+
+static void* fb_worker(void* arg) {
+  FbBatch* b = (FbBatch*)arg;
+  const mjpcx_model* m = b->m;
+  const mjpcx_task* task = b->task;
+  OBatchOut* out = b->out;
+  const int nu = m->nu, ds = m->nq + m->nv, nr = task->num_residual, ntr = task->num_trace, H = b->H;
   OData* d = odata_new(m);
-  if (!d) return -1;
   double* r = (double*)malloc(sizeof(double) * (size_t)(nr + nu + ds));
+  if (!d || !r) { __atomic_store_n(&b->failed, 1, __ATOMIC_RELAXED); free(r); if (d) odata_free(d); return NULL; }
   double *act = r + nr, *st = act + nu;
-  for (int i = 0; i < N; i++) {
-    FbPolicy p = {m, Tn, mode, representation, use_state, times, states, actions, gains, improvement, alpha[i]};
-    odata_set_state(d, state, time, mocap, NULL);
-    memcpy(st, state, sizeof(double) * ds);
-    double cur = time, total = 0;
+  for (;;) {
+    const int i = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
+    if (i >= b->N) break;
+    FbPolicy p = {m, b->Tn, b->mode, b->representation, b->use_state, b->times, b->states, b->actions, b->gains, b->improvement, b->alpha[i]};
+    odata_set_state(d, b->state, b->time, b->mocap, NULL);
+    memcpy(st, b->state, sizeof(double) * ds);
+    memset(act, 0, sizeof(double) * nu);
+    double cur = b->time, total = 0;
     int failure = 0;
     for (int t = 0; t < H; t++) {
       const int last = t == H - 1;
@@ -324,5 +340,71 @@ int orollout_feedback(const mjpcx_model* m, const mjpcx_task* task, const double
   }
   free(r);
   odata_free(d);
-  return 0;
+  return NULL;
+}
+
+int orollout_feedback_mt(const mjpcx_model* m, const mjpcx_task* task, const double* state, double time, const double* mocap,
+                         int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
+                         const double* states, const double* actions, const double* gains, const double* improvement,
+                         const double* alpha, int num_threads, OBatchOut* out) {
+  FbBatch b = {m, task, state, mocap, times, states, actions, gains, improvement, alpha, time, N, H, mode, representation, use_state, Tn, out, 0, 0};
+  if (num_threads < 1) num_threads = 1;
+  if (num_threads > N) num_threads = N > 0 ? N : 1;
+  if (num_threads == 1) { fb_worker(&b); return b.failed ? -1 : 0; }
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * num_threads);
+  for (int t = 0; t < num_threads; t++) pthread_create(&th[t], NULL, fb_worker, &b);
+  for (int t = 0; t < num_threads; t++) pthread_join(th[t], NULL);
+  free(th);
+  return b.failed ? -1 : 0;
+}
+
+int orollout_feedback(const mjpcx_model* m, const mjpcx_task* task, const double* state, double time, const double* mocap,
+                      int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
+                      const double* states, const double* actions, const double* gains, const double* improvement,
+                      const double* alpha, OBatchOut* out) {
+  return orollout_feedback_mt(m, task, state, time, mocap, N, H, mode, representation, use_state, Tn, times, states, actions, gains,
+                              improvement, alpha, 1, out);
+}
+
+/* ModelDerivatives::Compute (model_derivatives.cc:45-106): the T calls of mjd_transitionFD fanned over num_threads workers, one
+ * physics arena each (the reference schedules one task per time step on the ThreadPool). A, B, C, D time-major. */
+typedef struct {
+  const mjpcx_model* m; const mjpcx_task* task;
+  const double *mocap, *states, *times, *actions;
+  double eps;
+  int T, centered;
+  double *A, *B, *C, *D;
+  int next, failed;
+} FdBatch;
+
+static void* fd_worker(void* arg) {
+  FdBatch* b = (FdBatch*)arg;
+  const mjpcx_model* m = b->m;
+  const size_t ds = (size_t)(m->nq + m->nv), ndx = 2 * (size_t)m->nv, nu = (size_t)m->nu, nr = (size_t)b->task->num_residual;
+  OData* d = odata_new(m);
+  if (!d) { __atomic_store_n(&b->failed, 1, __ATOMIC_RELAXED); return NULL; }
+  for (;;) {
+    const int t = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
+    if (t >= b->T) break;
+    odata_set_state(d, b->states + t * ds, b->times[t], b->mocap, NULL);  /* (the mocap poses: otransition_fd sets the rest itself) */
+    if (otransition_fd(m, b->task, d, b->states + t * ds, b->times[t], b->actions + t * nu, b->eps, b->centered, b->A + t * ndx * ndx,
+                       b->B + t * ndx * nu, b->C + t * nr * ndx, b->D + t * nr * nu) != 0)
+      __atomic_store_n(&b->failed, 1, __ATOMIC_RELAXED);
+  }
+  odata_free(d);
+  return NULL;
+}
+
+int otransition_fd_batch(const mjpcx_model* m, const mjpcx_task* task, const double* mocap, int T, const double* states,
+                         const double* times, const double* actions, double eps, int centered, double* A, double* B, double* C,
+                         double* D, int num_threads) {
+  FdBatch b = {m, task, mocap, states, times, actions, eps, T, centered, A, B, C, D, 0, 0};
+  if (num_threads < 1) num_threads = 1;
+  if (num_threads > T) num_threads = T > 0 ? T : 1;
+  if (num_threads == 1) { fd_worker(&b); return b.failed ? -1 : 0; }
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * num_threads);
+  for (int t = 0; t < num_threads; t++) pthread_create(&th[t], NULL, fd_worker, &b);
+  for (int t = 0; t < num_threads; t++) pthread_join(th[t], NULL);
+  free(th);
+  return b.failed ? -1 : 0;
 }

@@ -140,6 +140,15 @@ int orollout_feedback(const mjpcx_model* m, const mjpcx_task* task, const double
                       int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
                       const double* states, const double* actions, const double* gains, const double* improvement,
                       const double* alpha, OBatchOut* out);
+/* the same fanned over worker threads (one physics arena each), as the reference schedules them on its ThreadPool: the candidates of
+ * the line search (ilqg/planner.cc:630-692) and the time steps of ModelDerivatives::Compute (model_derivatives.cc:45-106) */
+int orollout_feedback_mt(const mjpcx_model* m, const mjpcx_task* task, const double* state, double time, const double* mocap,
+                         int N, int H, int mode, int representation, int use_state, int Tn, const double* times,
+                         const double* states, const double* actions, const double* gains, const double* improvement,
+                         const double* alpha, int num_threads, OBatchOut* out);
+int otransition_fd_batch(const mjpcx_model* m, const mjpcx_task* task, const double* mocap, int T, const double* states,
+                         const double* times, const double* actions, double eps, int centered, double* A, double* B, double* C,
+                         double* D, int num_threads);
 
 /* ---------------- iLQG backward pass (mjpc/planners/ilqg/backward_pass.cc) ---------------- */
 /* box-constrained QP (MuJoCo mju_boxQP): returns the number of free dimensions, -1 if not PD */

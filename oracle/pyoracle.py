@@ -58,7 +58,30 @@ class OBatchOut(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        _LIB = _load(build())
+    return _LIB
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def timing_build():
+    """Inside the block every call of this module goes to the -O3 -march=native -flto build of the same sources (the way the reference
+    builds its release binaries): bench.py's cpu_baseline legs only, never the parity checker. Handles (Physics) made inside the
+    block belong to that library and must not outlive it."""
+    global _LIB
+    saved = _LIB
+    _LIB = _load(build(fast=True))
+    try:
+        yield
+    finally:
+        _LIB = saved
+
+
+def _load(path):
+    if True:
+        L = C.CDLL(path)
         L.odata_new.restype = C.c_void_p
         L.odata_new.argtypes = [C.POINTER(MjpcxModel)]
         L.odata_free.argtypes = [C.c_void_p]
@@ -105,10 +128,13 @@ def lib():
         L.ocost_derivatives.argtypes = [C.POINTER(MjpcxTask), C.c_int, C.c_int, C.c_int] + [c_f64p] * 8
         L.orollout_feedback.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [c_f64p] * 6 + [C.POINTER(OBatchOut)]
+        L.orollout_feedback_mt.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [c_f64p] * 6 + [C.c_int, C.POINTER(OBatchOut)]
+        L.otransition_fd_batch.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_int, c_f64p, c_f64p, c_f64p,
+                                           C.c_double, C.c_int, c_f64p, c_f64p, c_f64p, c_f64p, C.c_int]
         L.oriccati.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int] + [c_f64p] * 14
         L.oboxqp.argtypes = [c_f64p, c_f64p, c_i32p, c_f64p, c_f64p, C.c_int, c_f64p, c_f64p]
-        _LIB = L
-    return _LIB
+    return L
 
 
 def _f(a):
@@ -354,19 +380,17 @@ def boxqp(H, g, lower, upper, x0=None):
     return nfree, res, idx[:max(nfree, 0)]
 
 
-def transition_fd(pm, pt, states, times, actions, eps=1e-6, centered=0, mocap=None):
-    """ModelDerivatives::Compute: A (T,ndx,ndx), B (T,ndx,nu), C (T,nr,ndx), D (T,nr,nu)."""
+def transition_fd(pm, pt, states, times, actions, eps=1e-6, centered=0, mocap=None, num_threads=1):
+    """ModelDerivatives::Compute: A (T,ndx,ndx), B (T,ndx,nu), C (T,nr,ndx), D (T,nr,nu); the time steps fanned over num_threads
+    workers as the reference schedules them on its ThreadPool (the numbers do not depend on the thread count)."""
     m = pm.struct
     T, ndx, nu, nr = len(times), 2 * m.nv, m.nu, pt.struct.num_residual
-    ph = Physics(pm)
-    if mocap is not None:
-        ph.set_state(np.zeros(m.nq), np.zeros(m.nv), 0.0, mocap)
     A, B, Cm, D = np.zeros((T, ndx, ndx)), np.zeros((T, ndx, nu)), np.zeros((T, nr, ndx)), np.zeros((T, nr, nu))
-    states, actions = _f(states).reshape(T, -1), _f(actions).reshape(T, -1)
-    for t in range(T):
-        rc = lib().otransition_fd(pm.ptr, pt.ptr, ph.d, as_f64p(states[t]), float(times[t]), as_f64p(actions[t]), float(eps),
-                                  int(centered), as_f64p(A[t]), as_f64p(B[t]), as_f64p(Cm[t]), as_f64p(D[t]))
-        assert rc == 0
+    states, actions, times = _f(states).reshape(T, -1), _f(actions).reshape(T, -1), _f(times).reshape(-1)
+    mc = None if mocap is None else as_f64p(_f(mocap))
+    rc = lib().otransition_fd_batch(pm.ptr, pt.ptr, mc, T, as_f64p(states), as_f64p(times), as_f64p(actions), float(eps), int(centered),
+                                    as_f64p(A), as_f64p(B), as_f64p(Cm), as_f64p(D), int(num_threads))
+    assert rc == 0
     return A, B, Cm, D
 
 
@@ -382,7 +406,7 @@ def cost_derivatives(pt, residual, Cm, D):
 
 
 def rollout_feedback(pm, pt, state, time, mocap, H, mode, representation, use_state, times, states, actions, gains,
-                     improvement, alpha):
+                     improvement, alpha, num_threads=1):
     m = pm.struct
     N, Tn = len(alpha), len(times)
     ds, nu, nr, ntr = m.nq + m.nv, m.nu, pt.struct.num_residual, pt.struct.num_trace
@@ -394,7 +418,7 @@ def rollout_feedback(pm, pt, state, time, mocap, H, mode, representation, use_st
     o.residual, o.costs, o.trace = as_f64p(out["residual"]), as_f64p(out["costs"]), as_f64p(out["trace"])
     mc = None if mocap is None else as_f64p(_f(mocap))
     arrs = [_f(x).reshape(-1) for x in (times, states, actions, gains, improvement, alpha)]
-    rc = lib().orollout_feedback(pm.ptr, pt.ptr, as_f64p(_f(state)), float(time), mc, N, H, int(mode), int(representation),
-                                 int(use_state), Tn, *[as_f64p(a) for a in arrs], C.byref(o))
+    rc = lib().orollout_feedback_mt(pm.ptr, pt.ptr, as_f64p(_f(state)), float(time), mc, N, H, int(mode), int(representation),
+                                    int(use_state), Tn, *[as_f64p(a) for a in arrs], int(num_threads), C.byref(o))
     assert rc == 0
     return out

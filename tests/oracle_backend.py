@@ -69,10 +69,10 @@ class OracleContext:
     def rollout_feedback(self, horizon, mode, representation, use_state, times, states, actions, gains, improvement, alpha):
         self.N, self.H, self.P = len(alpha), horizon, 0
         self.out = pyoracle.rollout_feedback(self.pm, self.pt, self.state, self.time, self.mocap, horizon, mode, representation,
-                                             use_state, times, states, actions, gains, improvement, alpha)
+                                             use_state, times, states, actions, gains, improvement, alpha, num_threads=self.threads)
 
     def transition_fd(self, times, states, actions, eps=1e-6, centered=0):
-        return pyoracle.transition_fd(self.pm, self.pt, states, times, actions, eps, centered, mocap=self.mocap)
+        return pyoracle.transition_fd(self.pm, self.pt, states, times, actions, eps, centered, mocap=self.mocap, num_threads=self.threads)
 
     def cost_derivatives(self, residual, Cm, D):
         return pyoracle.cost_derivatives(self.pt, np.asarray(residual), np.asarray(Cm), np.asarray(D))

@@ -113,3 +113,31 @@ def test_oracle_time_policy_matches_the_python_policy(representation):
         x = np.concatenate([ph.get("qpos"), ph.get("qvel")])
         t += dt
         assert np.allclose(ref["states"][0][k + 1], x, rtol=0, atol=1e-12)
+
+
+def test_oracle_ilqg_sweeps_do_not_depend_on_the_thread_count():
+    """oracle/ilqg.c fans the derivative sweep over time steps and the feedback rollouts over candidates (bench.py's CPU leg of
+    configs[4] uses 16 workers, as the reference's ThreadPool would); every item has its own physics arena, so the numbers are
+    the single-thread ones bit for bit. On the A1: free joint, contacts."""
+    from mujoco_mpc_amd.task import load_task
+    from oracle import pyoracle
+    t = load_task("QuadrupedFlat")
+    t.transition(0.0)
+    pm, pt = t.packed_model(), t.packed()
+    rng = np.random.default_rng(4)
+    H = 10
+    state = np.concatenate([t.model.keyframes["home"]["qpos"], 0.1 * rng.normal(size=18)])
+    mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0.0])
+    times = np.arange(3) * (H - 1) * 0.01 / 2
+    nodes = np.clip(rng.normal(0, 0.1, (1, 3, 12)), -1, 1)
+    nom = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, 1, H, 3, 1, times, nodes, num_threads=1)
+    nom = {k: v[0] for k, v in nom.items() if k not in ("total_return", "failure")}
+    one = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], 1e-6, 0, mocap=mocap, num_threads=1)
+    four = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], 1e-6, 0, mocap=mocap, num_threads=4)
+    assert all(np.array_equal(a, b) for a, b in zip(one, four)) and np.abs(one[0]).max() > 0.5
+    gains = 0.05 * rng.normal(size=(H, 12, 36))
+    improvement = 0.05 * rng.normal(size=(H, 12))
+    alpha = np.exp(np.linspace(0, np.log(1e-3), 7))
+    args = (pm, pt, state, 0.0, mocap, H, 0, 0, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
+    a, b = pyoracle.rollout_feedback(*args, num_threads=1), pyoracle.rollout_feedback(*args, num_threads=3)
+    assert all(np.array_equal(a[k], b[k]) for k in a) and np.ptp(a["total_return"]) > 0
