@@ -1,6 +1,7 @@
 #include "trajectory.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -15,16 +16,56 @@ namespace mjpc {
 namespace {
 constexpr double kMaxReturnValue = 1.0e6;  // trajectory.cc:29
 
-// One device context per (model, task) the host-policy rollouts are asked for; created on first use, kept for the process.
-gpu::Context* RolloutContext(const mjModel* model, const Task* task) {
-  static std::mutex mtx;
-  static std::map<std::pair<const mjModel*, const Task*>, std::unique_ptr<gpu::Context>> contexts;
-  const std::lock_guard<std::mutex> lock(mtx);
-  auto& slot = contexts[{model, task}];
-  if (!slot) slot = std::make_unique<gpu::Context>(model, *task, /*device=*/0, /*precision=*/64);
-  return slot.get();
+// One device context per (model, task) the host-policy rollouts are asked for, created on first use. The key is the pair of
+// addresses; a model deleted and another loaded at the same address (or a task re-created there) is told apart by a fingerprint of
+// what the context was built from, and gets a fresh context. The table is never destroyed (a static destructor would call into the
+// HIP runtime after it may have shut down); ReleaseRolloutContexts() frees the contexts while the runtime is alive.
+struct RolloutSlot {
+  std::uint64_t fingerprint = 0;
+  std::unique_ptr<gpu::Context> ctx;
+};
+using RolloutTable = std::map<std::pair<const mjModel*, const Task*>, RolloutSlot>;
+std::mutex& RolloutMutex() { static std::mutex* m = new std::mutex; return *m; }
+RolloutTable& RolloutContexts() { static RolloutTable* t = new RolloutTable; return *t; }
+
+std::uint64_t Fingerprint(const mjModel* m, const Task* task) {
+  std::uint64_t h = 1469598103934665603ull;  // FNV-1a over the dimensions and the arrays a re-authored model would change
+  auto mix = [&h](const void* p, size_t bytes) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  };
+  const int dims[] = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nsensor, m->ntendon, task->num_residual, task->num_term, task->num_trace};
+  mix(dims, sizeof dims);
+  const mjtNum opt[] = {m->opt.timestep, m->opt.gravity[0], m->opt.gravity[1], m->opt.gravity[2], m->opt.tolerance, m->opt.impratio,
+                        (mjtNum)m->opt.integrator, (mjtNum)m->opt.iterations, (mjtNum)m->opt.cone, (mjtNum)m->opt.disableflags};
+  mix(opt, sizeof opt);
+  if (m->body_mass) mix(m->body_mass, sizeof(mjtNum) * m->nbody);
+  if (m->body_pos) mix(m->body_pos, sizeof(mjtNum) * 3 * m->nbody);
+  if (m->geom_size) mix(m->geom_size, sizeof(mjtNum) * 3 * m->ngeom);
+  if (m->geom_pos) mix(m->geom_pos, sizeof(mjtNum) * 3 * m->ngeom);
+  if (m->dof_damping) mix(m->dof_damping, sizeof(mjtNum) * m->nv);
+  if (m->actuator_gainprm) mix(m->actuator_gainprm, sizeof(mjtNum) * m->nu);
+  return h;
 }
 
+gpu::Context* RolloutContext(const mjModel* model, const Task* task) {
+  const std::lock_guard<std::mutex> lock(RolloutMutex());
+  RolloutSlot& slot = RolloutContexts()[{model, task}];
+  const std::uint64_t fp = Fingerprint(model, task);
+  if (!slot.ctx || slot.fingerprint != fp) {
+    slot.ctx = std::make_unique<gpu::Context>(model, *task, /*device=*/0, /*precision=*/64);
+    slot.fingerprint = fp;
+  }
+  return slot.ctx.get();
+}
+}  // namespace
+
+void ReleaseRolloutContexts() {
+  const std::lock_guard<std::mutex> lock(RolloutMutex());
+  RolloutContexts().clear();
+}
+
+namespace {
 // The body shared by Rollout and RolloutDiscrete: `policy(action, state, t)` with t the step index.
 template <class Policy>
 void HostPolicyRollout(Trajectory* tr, Policy policy, const Task* task, const mjModel* model, mjData* data, const double* state, double time,

@@ -42,4 +42,9 @@ class Trajectory {
   bool failure = false;
 };
 
+// The host-policy rollouts (Rollout / RolloutDiscrete) keep one device context per (model, task) they were asked for; this frees them
+// (they are re-created on the next use). Call it before unloading the library or the HIP runtime; a model re-loaded at the same
+// address is detected on its own.
+void ReleaseRolloutContexts();
+
 }  // namespace mjpc

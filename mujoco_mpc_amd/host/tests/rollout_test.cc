@@ -83,6 +83,26 @@ int main(int argc, char** argv) {
   single.Rollout(feedback_policy, &task, model, data, s1, 0.5, mocap, nullptr, 1);
   for (int i = 0; i < nx; i++) CHECK_NEAR(single.residual[i], s1[i], 1e-12);
 
+  // the host-policy rollouts keep a device context per (model, task) address pair: a different model at the same address (here the
+  // same struct with a heavier particle, as after mj_deleteModel + a reload) must not be served by the stale context, and the
+  // contexts can be released and come back
+  {
+    const double mass = model->body_mass[model->nbody - 1];
+    model->body_mass[model->nbody - 1] = 3.0 * mass;
+    Trajectory heavy;
+    heavy.Initialize(nx, model->nu, task.num_residual, 1, horizon);
+    heavy.Allocate(horizon);
+    heavy.Rollout(feedback_policy, &task, model, data, state, 0.0, mocap, nullptr, horizon);
+    CHECK(!heavy.failure && std::fabs(heavy.total_return - trajectory.total_return) > 1e-6);
+    model->body_mass[model->nbody - 1] = mass;
+    ReleaseRolloutContexts();
+    Trajectory again;
+    again.Initialize(nx, model->nu, task.num_residual, 1, horizon);
+    again.Allocate(horizon);
+    again.Rollout(feedback_policy, &task, model, data, state, 0.0, mocap, nullptr, horizon);
+    CHECK_NEAR(again.total_return, trajectory.total_return, 1e-12);
+  }
+
   // Planner::data_ / ResizeMjData (planners/planner.cc:23-33)
   GpuSamplingPlanner planner(0, 64, 1);
   planner.ResizeMjData(model, 3);
