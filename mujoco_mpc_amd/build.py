@@ -10,7 +10,16 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libmjpcx.so")
 # (source, extra flags). lane_static.hip holds the instantiations specialised for compile-time model
 # constants; its flags let exact-zero arithmetic fold (see the file header).
-SOURCES = [("mjpcx.hip", []), ("ilqg_wave.hip", []), ("wave32.hip", []), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]), ("quad_kernel.hip", [])]
+# Register-pressure switches for the two units whose kernels live at the edge of the register file (the quad kernel: 512 registers and
+# 68 GB of spill traffic per launch; the fp32 tree kernels: 256). None of them changes what is computed, only what the optimiser hoists,
+# merges or if-converts -- each of those moves lengthens live ranges: loop-invariant code motion (machine level and promotion), sinking
+# of common code out of branches, speculation of branch bodies into selects, SLP pairing of scalar loads -- and the scheduler is told to
+# weigh occupancy / pressure over latency. Measured on MI355X, same box, back to back: quad kernel 67.5 -> 62.1 ms,
+# Humanoid fp32 143.4 -> 155.9 k rollouts/s; the iLQG unit got slower with them (19.2 -> 20.0 ms) and keeps the defaults.
+PRESSURE = ["-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-licm-promotion", "-mllvm", "-simplifycfg-sink-common=false",
+            "-mllvm", "-phi-node-folding-threshold=0", "-mllvm", "-amdgpu-schedule-metric-bias=100"]
+SOURCES = [("mjpcx.hip", []), ("ilqg_wave.hip", []), ("wave32.hip", PRESSURE), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]),
+           ("quad_kernel.hip", PRESSURE)]
 # headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
 # re-compile the wavefront-per-candidate kernels, and vice versa)
 QUAD_ONLY = ["quad_step.h", "quad_kernel.h", "quad_model.h"]
@@ -40,6 +49,7 @@ def build_native(force=False, verbose=False):
     # every header of csrc/ is a dependency of both translation units (the wave_*.h / ilqg_*.h files are included by mjpcx.hip)
     deps = sorted(set([os.path.join(CSRC, s) for s, _ in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS] +
                       glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "generated", "*.h"))))
+    deps.append(os.path.abspath(__file__))
     if not force and not _stale(LIB, deps):
         return LIB
     objdir = os.path.join(PKG_DIR, "build")
@@ -53,6 +63,7 @@ def build_native(force=False, verbose=False):
             mine = [os.path.join(CSRC, h) for h in QUAD_DEPS]
         else:
             mine = [d for d in deps if os.path.basename(d) not in QUAD_ONLY and os.path.basename(d) != "quad_kernel.hip"]
+        mine = mine + [os.path.abspath(__file__)]  # (the flags are in this file)
         if force or _stale(obj, mine):
             cmd = common + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:

@@ -168,7 +168,7 @@ def test_ragged_batches_and_short_horizons(quad):
 
 def test_random_states_against_the_oracle():
     """tools/fuzz_quad.py: 60 random plan states (trunk poses and heights, legs far from home, fast initial velocities), horizons, spline
-    representations and noise levels, 32 candidates each, against the oracle at 1e-9 (returns) / 1e-7 (states after the horizon);
+    representations and noise levels, 32 candidates each, against the oracle at 1e-8 (returns) / 1e-7 (states after the horizon);
     candidates the quad kernel hands on are included (they come back from the other kernel). 1050 such cases: profiles/r03_fuzz_quad.log"""
     import subprocess
     import sys
