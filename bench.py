@@ -70,14 +70,14 @@ BASELINE_SIZE = {
 
 
 def kernel_source_sha16():
-    """identity of the device code being benchmarked: sha256 over the kernel sources (csrc/*.h, *.hip, generated/*, include/mjpcx.h),
+    """identity of the device code being benchmarked: sha256 over the kernel sources (csrc/*.h, *.hip, generated/*, include/mjpcx.h) and build.py (the compiler switches),
     so that a PMC summary is tied to the code it profiled and survives a rebuild of the same sources"""
     import glob
     from mujoco_mpc_amd import capi
     capi.lib()  # (the library must exist: the product path fails loudly without it)
     csrc = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
     files = sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "generated", "*.h"))
-                   + [os.path.join(ROOT, "include", "mjpcx.h")])
+                   + [os.path.join(ROOT, "include", "mjpcx.h"), os.path.join(ROOT, "mujoco_mpc_amd", "build.py")])   # (build.py: the compiler switches)
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())

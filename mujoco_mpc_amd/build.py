@@ -10,15 +10,16 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libmjpcx.so")
 # (source, extra flags). lane_static.hip holds the instantiations specialised for compile-time model
 # constants; its flags let exact-zero arithmetic fold (see the file header).
-# Register-pressure switches for the two units whose kernels live at the edge of the register file (the quad kernel: 512 registers and
-# 68 GB of spill traffic per launch; the fp32 tree kernels: 256). None of them changes what is computed, only what the optimiser hoists,
+# Register-pressure switches for the units whose kernels live at the edge of the register file (the quad kernel: 512 registers and
+# 68 GB of spill traffic per launch; the tree kernels in fp32 and fp64: 256). None of them changes what is computed, only what the optimiser hoists,
 # merges or if-converts -- each of those moves lengthens live ranges: loop-invariant code motion (machine level and promotion), sinking
 # of common code out of branches, speculation of branch bodies into selects, SLP pairing of scalar loads -- and the scheduler is told to
 # weigh occupancy / pressure over latency. Measured on MI355X, same box, back to back: quad kernel 67.5 -> 62.1 ms,
-# Humanoid fp32 143.4 -> 155.9 k rollouts/s; the iLQG unit got slower with them (19.2 -> 20.0 ms) and keeps the defaults.
+# Humanoid fp32 143.4 -> 155.9 k rollouts/s, the fp64 tree kernels of mjpcx.hip +5 % (A1 at N = 2048: 35.7 -> 33.9 ms; Humanoid fp64 65 -> 69 k;
+# its lane kernels and the Riccati pass unchanged); the iLQG unit got slower with them (19.2 -> 20.0 ms) and keeps the defaults.
 PRESSURE = ["-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-licm-promotion", "-mllvm", "-simplifycfg-sink-common=false",
             "-mllvm", "-phi-node-folding-threshold=0", "-mllvm", "-amdgpu-schedule-metric-bias=100"]
-SOURCES = [("mjpcx.hip", []), ("ilqg_wave.hip", []), ("wave32.hip", PRESSURE), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]),
+SOURCES = [("mjpcx.hip", PRESSURE), ("ilqg_wave.hip", []), ("wave32.hip", PRESSURE), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]),
            ("quad_kernel.hip", PRESSURE)]
 # headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
 # re-compile the wavefront-per-candidate kernels, and vice versa)
