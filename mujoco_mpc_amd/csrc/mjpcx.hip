@@ -349,7 +349,7 @@ struct mjpcx_ctx {
   int stamp_step = -1;
   bool no_tree = false;  // MJPCX_NO_TREE=1: keep the row-table constraint path (A/B runs)
   bool no_lds_model = false;  // MJPCX_NO_LDS_MODEL=1: generic kernel even for a registered model (A/B runs)
-  int max_waves = 8;          // MJPCX_TREE_WAVES=<1..8>: wavefronts per workgroup of the registered-model kernel
+  int max_waves = 8;          // MJPCX_TREE_WAVES=<1..8, fp32: 1..12>: wavefronts per workgroup of the registered-model kernel (fp32 default 12: wave32.hip)
   int tree_mode = 16;         // tree_kernel.h mode bits: 16 dynamic candidate hand-out (default), 8 arena poison, 2 image self-check (MJPCX_TREE_MODE)
   bool no_second_pass = false;  // MJPCX_TREE_ONE_PASS=1: leave list overflows as failures (tuning: counts them)
   // multi-GPU (mjpcx_comm_*): the RCCL communicator of this context's rank and its staging buffers
@@ -936,7 +936,8 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     mjpcx_ctx* c = new (std::nothrow) mjpcx_ctx();
     if (!c) return bad(MJPCX_ENOMEM, "host allocation failed");
     c->device = device; c->precision = precision; c->stamp_step = env_stamp_step(); c->no_tree = getenv("MJPCX_NO_TREE") != nullptr; c->no_lds_model = getenv("MJPCX_NO_LDS_MODEL") != nullptr;
-    if (const char* e = getenv("MJPCX_TREE_WAVES")) c->max_waves = std::max(1, std::min(8, std::atoi(e)));
+    if (precision == 32) c->max_waves = 12;
+    if (const char* e = getenv("MJPCX_TREE_WAVES")) c->max_waves = std::max(1, std::min(precision == 32 ? 12 : 8, std::atoi(e)));
     if (const char* e = getenv("MJPCX_TREE_MODE")) c->tree_mode = std::atoi(e);
     c->no_second_pass = getenv("MJPCX_TREE_ONE_PASS") != nullptr;
     c->no_cone_slabs = getenv("MJPCX_TREE_NO_SLABS") != nullptr;

@@ -13,8 +13,11 @@ namespace mjpcx { namespace WAVE_NS {
 // mode bit 1: self-check -- compare the staged image with the generic model's arrays, mismatches are counted in work[1]
 //             and the launch rolls nothing out (tuning / bring-up aid, MJPCX_TREE_CHECK=1)
 // BIG: second pass -- only the candidates the first pass flagged "contact list full" (failure bits, mjpcx.h), with the large lists
+#ifndef TREE_KERNEL_THREADS
+#define TREE_KERNEL_THREADS 512  // 8 wavefronts of 256 registers
+#endif
 template <class C, bool BIG = false>
-__global__ __launch_bounds__(512) void rollout_tree_kernel(const WModel m_in, const WTask tk_in, const RolloutArgs<wreal> a,
+__global__ __launch_bounds__(TREE_KERNEL_THREADS) void rollout_tree_kernel(const WModel m_in, const WTask tk_in, const RolloutArgs<wreal> a,
                                                            const unsigned char* __restrict__ image, unsigned blob_bytes, unsigned arena_bytes,
                                                            int* work, int mode, wreal* __restrict__ cone_slabs) {
   typedef LdsLayout<C, wreal> L;

@@ -2,6 +2,9 @@
 // precision) as a translation unit of their own; mjpcx.hip reaches them through wave32_launch.h.
 #include <hip/hip_runtime.h>
 
+// twelve wavefronts of 170 registers per workgroup instead of eight of 256: once the build switches of build.py had taken the spills
+// away (12.3 -> 1.5 GB per launch), the third wavefront per SIMD pays (Humanoid: 155.7 -> 162.0 k rollouts/s; LDS admits eleven arenas)
+#define TREE_KERNEL_THREADS 768
 #include "rollout_wave.h"
 #include "wave32_launch.h"
 
