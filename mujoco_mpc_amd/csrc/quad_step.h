@@ -478,10 +478,7 @@ QD void contact_line(const QContact& c, const double* fr, const double* jv, doub
 // The same along a fixed search direction, for the first kQLineSlots contacts of a lane: alpha enters a contact's penalty only through
 // jn = jn0 + alpha vn and the quadratic T^2 = A + 2 B alpha + C alpha^2 (B = UV at 0, C = VV, which does not depend on alpha), so a
 // trial costs a dozen flops per contact instead of a pass over its record. D0 carries the half weight of a leg-leg contact.
-#ifndef QLINE_SLOTS
-#define QLINE_SLOTS 4
-#endif
-constexpr int kQLineSlots = QLINE_SLOTS;
+constexpr int kQLineSlots = 4;
 #ifndef QREC
 #define QREC(dst, v) (dst) = (v)   // a trajectory-buffer store (the device build streams them past the caches: quad_kernel.h)
 #endif
@@ -703,13 +700,7 @@ QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, 
 // rtsafe safeguard). Out of line on the device, like the solver itself: the loop's working set (the contacts' coefficients, the diagonal
 // rows) then has the register file to itself instead of competing with everything the iteration keeps alive around it.
 template <bool MULTI, class CS, class QProfT>
-// (out of line until the build switches of build.py lowered the register pressure; inlined since: 64.5 -> 62.9 ms. QEXP_LS_NOINLINE for A/B runs)
-#ifdef QEXP_LS_NOINLINE
-QNOINLINE
-#else
-QD
-#endif
-double line_search(const QuadModel& m, const QuadLeg& L, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs)[6], int pmask,
+QNOINLINE double line_search(const QuadModel& m, const QuadLeg& L, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs)[6], int pmask,
                              double q1, double q2, double gtol, QProfT& pf) {
   // (everything small arrives by value: an argument passed by reference pins the caller's copy in memory for the whole iteration)
   const double hl[3] = {hl0, hl1, hl2};
