@@ -550,14 +550,57 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start one copy of this command per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR = 127.0.0.1 / a free MASTER_PORT in the environment, as torch.distributed.run would set them), pass rank 0's
+    standard output through (the one JSON line), and exit non-zero -- after stopping the others -- as soon as any rank dies.
+    MJPC_BENCH_LAUNCH_TIMEOUT_S bounds the whole run (default 1800 s)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + float(os.environ.get("MJPC_BENCH_LAUNCH_TIMEOUT_S", "1800"))
+    rc = 0
+    live = list(range(n))
+    while live and rc == 0:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.remove(r)
+                if code != 0:
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                    rc = code if code > 0 else 1
+        if time.monotonic() > deadline:
+            print("bench.py: launch timed out", file=sys.stderr)
+            rc = 124
+        time.sleep(0.05)
+    for r in live:                      # a rank died or the deadline passed: stop the ranks this process started (exact PIDs)
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    sys.exit(rc)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)      # plain `python bench.py --gpus N`: one child per GPU, this process only supervises
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry_run:
         return dry_run(args, rank, world)
     import torch

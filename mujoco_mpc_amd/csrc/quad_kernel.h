@@ -42,6 +42,13 @@ __device__ __forceinline__ double qd_partner(double v, int p) {
 }
 // true in every lane of the wavefront if pred holds in any (the four-lane quads of a wavefront share its instruction stream)
 __device__ __forceinline__ bool qw_any(bool pred) { return __ballot(pred) != 0; }
+// the largest value of v (0..4) over the ACTIVE lanes of the wavefront, as a scalar (ballots: lanes that left a loop earlier do not take
+// part, and a butterfly of shuffles would lose values behind them)
+__device__ __forceinline__ int qw_max(int v) {
+  int r = 0;
+  for (int k = 1; k <= 4; k++) r += __ballot(v >= k) != 0 ? 1 : 0;
+  return r;
+}
 __device__ __forceinline__ int qd_or(int v) {
   v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
   v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
@@ -56,7 +63,8 @@ namespace mjpcx { namespace quad {
 struct QContact;
 constexpr int kQLdsSlots = 3;
 typedef __attribute__((address_space(3))) double qlds_f64;  // a typed LDS pointer: ds_read / ds_write instead of FLAT accesses
-struct LdsStore { qlds_f64* lds; double* ovf; };
+typedef __attribute__((address_space(5))) double qprv_f64;  // a typed private pointer: scratch_load / scratch_store
+struct LdsStore { qlds_f64* lds; qprv_f64* ovf; };
 struct LdsM { qlds_f64* ml; qlds_f64* mt; };
 struct QProf { long long* buf; long long last; };
 } }
@@ -91,6 +99,10 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
 #define QNOINLINE __device__ __noinline__
 #define QD __device__ __forceinline__
 #define QFAST_MATH 1
+// what an out-of-line function of the step gets by reference: the model image lives in LDS, the caller's locals in its private segment.
+// Saying so turns the FLAT loads of a generic pointer (LDS and vector-memory path, both counters) into ds_read / scratch_load.
+#define QREBIND_LDS(T, ref) (*(const T*)(const __attribute__((address_space(3))) T*)(&(ref)))
+#define QREBIND_PRIVATE(T, ptr) ((__attribute__((address_space(5))) T*)(ptr))
 #ifndef QEXP_NO_NT
 // trajectory buffers are written once and read by the host or a later kernel: stream them past the caches the spill traffic lives in
 #define QREC(dst, v) __builtin_nontemporal_store((v), &(dst))
@@ -126,7 +138,7 @@ __device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int sl
   using namespace mjpcx::quad;
   double v[kQConRec];
   if (slot < kQLdsSlots) { const qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f * 64]; }
-  else { const double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f]; }
+  else { const qprv_f64* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f]; }
   QUNROLL for (int k = 0; k < 3; k++) { c.n[k] = v[k]; c.off[k] = v[3 + k]; }
   c.D0 = v[6];
   QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = v[7 + k];
@@ -141,12 +153,12 @@ __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, c
   QUNROLL for (int k = 0; k < 6; k++) v[7 + k] = c.jar[k];
   v[13] = (double)(c.depth | (c.fid << 2) | (c.rel << 5) | (c.sgn > 0 ? 64 : 0) | (c.pd << 7) | (c.px << 9));
   if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) p[f * 64] = v[f]; }
-  else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) p[f] = v[f]; }
+  else { qprv_f64* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) p[f] = v[f]; }
 }
 __device__ __forceinline__ void qcs_store_jar(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
   using namespace mjpcx::quad;
   if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int k = 0; k < 6; k++) p[(7 + k) * 64] = c.jar[k]; }
-  else { double* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int k = 0; k < 6; k++) p[7 + k] = c.jar[k]; }
+  else { qprv_f64* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int k = 0; k < 6; k++) p[7 + k] = c.jar[k]; }
 }
 
 namespace mjpcx { namespace quad {
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __re
   tk.param = blob + bo.off_param; tk.re = blob + bo.off_rreal; tk.ri = reinterpret_cast<const int*>(blob + bo.off_rint); tk.risk = blob[bo.off_risk];
   double ovf[(kQMaxCon - kQLdsSlots) * kQConRec];
   qlds_f64* wave_lds = (qlds_f64*)con_lds + (threadIdx.x >> 6) * (kQWaveLds / sizeof(double));
-  LdsStore cs{wave_lds + (threadIdx.x & 63), ovf};
+  LdsStore cs{wave_lds + (threadIdx.x & 63), (qprv_f64*)ovf};
   LdsM ms{wave_lds + kQWaveCon + (threadIdx.x & 63), wave_lds + kQWaveCon + kQWaveMl + ((threadIdx.x & 63) >> 2)};
   QProf pf{nullptr, 0};
   if (a.stamps && blockIdx.x == 0 && threadIdx.x < 64) { pf.buf = a.stamps; pf.last = __builtin_readcyclecounter(); }

@@ -34,6 +34,12 @@
 #ifndef QUNROLL
 #define QUNROLL
 #endif
+// An out-of-line function receives the model image and its caller's locals through plain references; the device build says where they
+// live (LDS / the private segment) so that they are read with ds_read / scratch_load instead of FLAT loads (quad_kernel.h).
+#ifndef QREBIND_LDS
+#define QREBIND_LDS(T, ref) (ref)
+#define QREBIND_PRIVATE(T, ptr) (ptr)
+#endif
 #ifndef QNOINLINE
 #define QNOINLINE QD
 #endif
@@ -652,13 +658,15 @@ QD void rows_line_prepare(const QuadModel& m, CS& cs, int ncon, const double Vp[
     if (MULTI) x = next_x(pmask, x);
   }
 }
-template <bool MULTI, class CS>
-QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, int ncon, double alpha, const double* xl, const double Vp[4][6], int pmask,
-                  bool beyond_slots, const QRel& rq, const QLine* ql, double& d1, double& d2) {
+// the lane's friction-loss parameters, read from the model once per line search
+struct QDiag { double fl[3], flR[3], flD[3]; };
+template <bool MULTI, bool BEYOND, class CS>
+QD void rows_line(const QuadModel& m, const QDiag& dg, const QRows& R, CS& cs, int ncon, double alpha, const double* xl, const double Vp[4][6], int pmask,
+                  bool beyond_slots, int nslot_wave, const QRel& rq, const QLine* ql, double& d1, double& d2) {
   double g = 0, h = 0;
   QUNROLL for (int j = 0; j < 3; j++) {
     {
-      const double jv = xl[j], x = R.fl_jar[j] + alpha * jv, fl = L.floss[j], Rr = L.floss_R[j], D = L.floss_D[j];
+      const double jv = xl[j], x = R.fl_jar[j] + alpha * jv, fl = dg.fl[j], Rr = dg.flR[j], D = dg.flD[j];
       const bool on = fl > 0, low = x <= -Rr * fl, high = x >= Rr * fl;
       const double gq = low ? -fl * jv : (high ? fl * jv : D * x * jv), hq = (low || high) ? 0.0 : D * jv * jv;
       g += on ? gq : 0.0; h += on ? hq : 0.0;
@@ -669,8 +677,9 @@ QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, 
       g += on ? R.lm_D[j] * x * jv : 0.0; h += on ? R.lm_D[j] * jv * jv : 0.0;
     }
   }
-  QUNROLL for (int i = 0; i < kQLineSlots; i++) line_eval(ql[i], alpha, g, h);
-  if (beyond_slots) {  // (quad-uniform: a lane of the quad holds more contacts than slots -- from the records; rq is the first pass's exchange)
+  // (slots no lane of the wavefront fills are skipped by a scalar branch: an empty slot adds exactly zero)
+  QUNROLL for (int i = 0; i < kQLineSlots; i++) if (i < nslot_wave) line_eval(ql[i], alpha, g, h);
+  if (BEYOND && beyond_slots) {  // (quad-uniform: a lane of the quad holds more contacts than slots -- from the records; rq is the first pass's exchange)
     int x = next_x(pmask, 0);
     for (int pass = 0; pass == 0 || (MULTI && x < 4); pass++) {
       QRel rx;
@@ -699,22 +708,35 @@ QD void rows_line(const QuadModel& m, const QuadLeg& L, const QRows& R, CS& cs, 
 // The exact line search of one Newton iteration (oracle constraint_newton's inner loop: Newton on the derivative, bracketed, with the
 // rtsafe safeguard). Out of line on the device, like the solver itself: the loop's working set (the contacts' coefficients, the diagonal
 // rows) then has the register file to itself instead of competing with everything the iteration keeps alive around it.
-template <bool MULTI, class CS, class QProfT>
-QNOINLINE double line_search(const QuadModel& m, const QuadLeg& L, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs)[6], int pmask,
+// BEYOND = false: no lane of the wavefront holds more contacts than slots (the common case) -- the trial loop then lives on the slots'
+// coefficients and the diagonal rows alone; the records, the chain velocities and the partner exchange are dead after the preparation.
+template <bool MULTI, bool BEYOND, class CS, class QProfT>
+QNOINLINE double line_search(const QuadModel& m_in, int leg, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs_in)[6], int pmask,
                              double q1, double q2, double gtol, QProfT& pf) {
   // (everything small arrives by value: an argument passed by reference pins the caller's copy in memory for the whole iteration)
+  const QuadModel& m = QREBIND_LDS(QuadModel, m_in);
+  const QuadLeg& L = m.leg[leg];
   const double hl[3] = {hl0, hl1, hl2};
+  double Vs[4][6];
+  {
+    const auto* vp = QREBIND_PRIVATE(double, &Vs_in[0][0]);
+    QUNROLL for (int d = 0; d < 4; d++) QUNROLL for (int k = 0; k < 6; k++) Vs[d][k] = vp[6 * d + k];
+  }
+  QDiag dg;
+  QUNROLL for (int j = 0; j < 3; j++) { dg.fl[j] = L.floss[j]; dg.flR[j] = L.floss_R[j]; dg.flD[j] = L.floss_D[j]; }
   QLine ql[kQLineSlots];
   QRel rq;
   QPROF(pf, 40);
   rows_line_prepare<MULTI>(m, cs, ncon, Vs, pmask, rq, ql);
-  const bool beyond = qd_or(ncon > kQLineSlots ? 1 : 0) != 0;
+  const bool beyond = BEYOND && qd_or(ncon > kQLineSlots ? 1 : 0) != 0;
+  const int nslot_wave = qw_max(ncon < kQLineSlots ? ncon : kQLineSlots);
   QPROF(pf, 41);
   double lo = 0, hi = -1, alpha = 0, d1, d2;
-  rows_line<MULTI>(m, L, R, cs, ncon, 0.0, hl, Vs, pmask, beyond, rq, ql, d1, d2);
+  rows_line<MULTI, BEYOND>(m, dg, R, cs, ncon, 0.0, hl, Vs, pmask, beyond, nslot_wave, rq, ql, d1, d2);
   d1 += q1; d2 += q2;
   const double d10 = fabs(d1);
   double step1 = 1e300, step2 = 1e300;  // the last step and the one before (rtsafe safeguard, oracle/contact.inc)
+  int trials = 0;
 #ifdef QEXP_MAXLS
   for (int ls = 0; ls < QEXP_MAXLS && d10 >= gtol; ls++) {
 #else
@@ -726,12 +748,13 @@ QNOINLINE double line_search(const QuadModel& m, const QuadLeg& L, const QRows R
     if (an == alpha) break;
     step2 = step1; step1 = fabs(an - alpha);
     alpha = an;
-    rows_line<MULTI>(m, L, R, cs, ncon, alpha, hl, Vs, pmask, beyond, rq, ql, d1, d2);
+    rows_line<MULTI, BEYOND>(m, dg, R, cs, ncon, alpha, hl, Vs, pmask, beyond, nslot_wave, rq, ql, d1, d2);
     d1 += q1 + alpha * q2; d2 += q2;
     if (fabs(d1) < gtol) break;
     if (d1 < 0) lo = alpha; else hi = alpha;
-    QPROF_COUNT(pf, 17, 1);
+    trials++;
   }
+  QPROF_COUNT(pf, 17, trials);
   QPROF(pf, 42);
   return alpha;
 }
@@ -1048,7 +1071,8 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       double Vs[4][6];
       chain_velocity(kin, hl, ht, Vs);
       const double gtol = m.tolerance * kQLsTol * sqrt(snorm) / scale;
-      const double alpha = line_search<GENERAL>(m, L, R, cs, ncon, hl[0], hl[1], hl[2], Vs, pmask, q1, q2, gtol, pf);
+      const double alpha = qw_any(ncon > kQLineSlots) ? line_search<GENERAL, true>(m, leg, R, cs, ncon, hl[0], hl[1], hl[2], Vs, pmask, q1, q2, gtol, pf)
+                                                      : line_search<GENERAL, false>(m, leg, R, cs, ncon, hl[0], hl[1], hl[2], Vs, pmask, q1, q2, gtol, pf);
       QPROF(pf, 11);
       QUNROLL for (int j = 0; j < 3; j++) al[j] += alpha * hl[j];
       QUNROLL for (int k = 0; k < 6; k++) at[k] += alpha * ht[k];
@@ -1071,23 +1095,39 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
 }
 
 template <bool GENERAL, class CS, class MS, class QProfT>
-QNOINLINE int constraint_newton(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmask, bool have_rel,
+QNOINLINE int constraint_newton(const QuadModel& m_in, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmask, bool have_rel,
                          const double* sl_in, const double* st_in, const double* wl_in, const double* wt_in, bool have_warm,
                          double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf) {
   // (an out-of-line function on the device: its register allocation starts afresh, so the rollout's state is parked once per step instead
   // of being spilled around inside the iteration. Everything that arrives by reference is copied to locals first: a by-reference operand
-  // is re-read from the caller's stack at every use.)
-  const QKin kin = kin_in;
+  // is re-read from the caller's stack at every use. The model image is in LDS, the caller's locals in its private segment.)
+  const QuadModel& m = QREBIND_LDS(QuadModel, m_in);
+  const QuadLeg& L = m.leg[leg];
+  QKin kin;
+  {
+    const auto* kp = QREBIND_PRIVATE(double, &kin_in.cdof[0][0]);
+    static_assert(sizeof(QKin) == 36 * sizeof(double), "QKin is 36 doubles: cdof, ca, cl");
+    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) kin.cdof[j][k] = kp[6 * j + k];
+    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 3; k++) { kin.ca[j][k] = kp[18 + 3 * j + k]; kin.cl[j][k] = kp[27 + 3 * j + k]; }
+  }
   const MS ms = ms_in;
   QRows R = R_in;
   CS cs = cs_in;
   double sl[3], st[6], wl[3], wt[6], al[3], at[6], fc_l[3], fc_t[6];
-  QUNROLL for (int j = 0; j < 3; j++) { sl[j] = sl_in[j]; wl[j] = wl_in[j]; }
-  QUNROLL for (int k = 0; k < 6; k++) { st[k] = st_in[k]; wt[k] = wt_in[k]; }
+  {
+    const auto* slp = QREBIND_PRIVATE(double, sl_in); const auto* stp = QREBIND_PRIVATE(double, st_in);
+    const auto* wlp = QREBIND_PRIVATE(double, wl_in); const auto* wtp = QREBIND_PRIVATE(double, wt_in);
+    QUNROLL for (int j = 0; j < 3; j++) { sl[j] = slp[j]; wl[j] = wlp[j]; }
+    QUNROLL for (int k = 0; k < 6; k++) { st[k] = stp[k]; wt[k] = wtp[k]; }
+  }
   int iters = 0;
   const int rc = newton_body<GENERAL>(m, L, kin, ms, R, cs, ncon, leg, pmask, have_rel, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
-  QUNROLL for (int j = 0; j < 3; j++) { al_out[j] = al[j]; fc_l_out[j] = fc_l[j]; }
-  QUNROLL for (int k = 0; k < 6; k++) { at_out[k] = at[k]; fc_t_out[k] = fc_t[k]; }
+  {
+    auto* alp = QREBIND_PRIVATE(double, al_out); auto* atp = QREBIND_PRIVATE(double, at_out);
+    auto* flp = QREBIND_PRIVATE(double, fc_l_out); auto* ftp = QREBIND_PRIVATE(double, fc_t_out);
+    QUNROLL for (int j = 0; j < 3; j++) { alp[j] = al[j]; flp[j] = fc_l[j]; }
+    QUNROLL for (int k = 0; k < 6; k++) { atp[k] = at[k]; ftp[k] = fc_t[k]; }
+  }
   iters_out = iters;
   return rc;
 }
@@ -2105,9 +2145,9 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     // every candidate of the wavefront then (it covers the other cases too, and the wavefront runs one solver instead of both in turn)
     const bool wave_general = qw_any(((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom);
     if (wave_general)
-      flags = constraint_newton<true>(m, L, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+      flags = constraint_newton<true>(m, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     else
-      flags = constraint_newton<false>(m, L, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+      flags = constraint_newton<false>(m, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     if (flags) break;
     QWAVE_TIMES(a, iters, wave_general, D.ncon);
     QPROF(pf, 6);

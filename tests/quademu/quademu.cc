@@ -58,12 +58,19 @@ static inline double qd_partner(double x, int p) {  // lane (l xor p)'s value
   g_ctx->bar.wait(g_sense);
   return g_ctx->dbuf[s][g_lane ^ p];
 }
-static inline bool qw_any(bool pred) { return pred; }  // (the emulator's wavefront is one quad)
+static inline int qd_or(int x);
+static inline int qw_max(int v);
+static inline bool qw_any(bool pred) { return qd_or(pred ? 1 : 0) != 0; }  // (the emulator's wavefront is one quad)
 static inline int qd_or(int x) {
   const int s = g_phase++ & 1;
   g_ctx->ibuf[s][g_lane] = x;
   g_ctx->bar.wait(g_sense);
   return g_ctx->ibuf[s][0] | g_ctx->ibuf[s][1] | g_ctx->ibuf[s][2] | g_ctx->ibuf[s][3];
+}
+
+static inline int qw_max(int v) {  // the largest value in the wavefront (= the quad here), for v in 0..4
+  const int m = qd_or(1 << v);
+  return 31 - __builtin_clz(m);
 }
 
 #define QD static inline
@@ -189,9 +196,9 @@ int quademu_forward(const mjpcx_model* model, const mjpcx_task* task, const doub
     double al[3], at[6], fc_l[3], fc_t[6];
     int iters;
     if (((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom)
-      fl = constraint_newton<true>(b->qm, b->qm.leg[leg], D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
+      fl = constraint_newton<true>(b->qm, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
     else
-      fl = constraint_newton<false>(b->qm, b->qm.leg[leg], D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
+      fl = constraint_newton<false>(b->qm, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
     flags_out[leg] = fl;
     if (fl) return;
     for (int j = 0; j < 3; j++) {
