@@ -199,6 +199,75 @@ def pmc_summary(task_name, candidates, horizon, precision):
     return s
 
 
+class ClockSampler:
+    """sclk / socket power of the GPU sampled at about 10 Hz from sysfs (hwmon freq1_input, power1_average | power1_input; no
+    subprocess on the timed path) while the timed region runs: the headline carries the clock it was measured at. A box without the
+    files yields None."""
+
+    def __init__(self, device_index=0):
+        import ctypes
+        import glob
+        # the HIP device's PCI address names its sysfs node (a node shows every GPU of the box, whatever this process may use)
+        self.freq = self.power = self.pci = None
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+                self.pci = buf.value.decode().lower()
+        except OSError:
+            pass
+        for card in glob.glob("/sys/class/drm/card[0-9]*/device"):
+            if self.pci is None or os.path.basename(os.path.realpath(card)).lower() != self.pci:
+                continue
+            for h in sorted(glob.glob(os.path.join(card, "hwmon", "hwmon*"))):
+                f = os.path.join(h, "freq1_input")
+                if os.path.exists(f):
+                    self.freq = f
+                for name in ("power1_average", "power1_input"):
+                    q = os.path.join(h, name)
+                    if self.power is None and os.path.exists(q):
+                        self.power = q
+        self.samples = []
+        self._stop = False
+        self._thread = None
+
+    def _read(self, path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop:
+            self.samples.append((self._read(self.freq) if self.freq else None, self._read(self.power) if self.power else None))
+            time.sleep(0.1)
+
+    def __enter__(self):
+        if self.freq or self.power:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        f = [a * 1e-6 for a, _ in self.samples if a]
+        p = [b * 1e-6 for _, b in self.samples if b]
+        if not f and not p:
+            return None
+        out = {"samples": len(self.samples), "pci": self.pci, "source": "sysfs hwmon of the HIP device's PCI address, 10 Hz over the timed region"}
+        if f:
+            out.update({"sclk_mhz_min": min(f), "sclk_mhz_mean": sum(f) / len(f), "sclk_mhz_max": max(f)})
+        if p:
+            out.update({"power_w_mean": sum(p) / len(p), "power_w_max": max(p)})
+        return out
+
+
 def run_config(args, task_name, kind, candidates, horizon, precision, steps, warmup, world, local_rank, group, want_cpu, rank, native=None,
                total=None):
     """one BASELINE config through the C++ planner over the C ABI; returns the fields of a bench line. candidates: this rank's share;
@@ -230,6 +299,7 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
         planner = HostPlanner(task, device=local_rank, precision=precision, seed=0,
                               num_trajectory=total,  # lifts kMaxTrajectory = 128
                               group=group, kind=kind)
+    physics_notes = capi.lib().mjpcx_create_error().decode()   # "" or what of the model the device does not reproduce (skipped geom pairs)
     qpos, qvel, mocap_pos, mocap_quat = initial_condition(task_name, task, planner)
     planner.reset(H)
     P = planner.num_spline_points
@@ -246,11 +316,12 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
         planner.optimize_policy(H)
     fence()
     planner.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        planner.optimize_policy(H)
-    fence()
-    elapsed = time.perf_counter() - t0
+    with ClockSampler(local_rank) as clocks:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            planner.optimize_policy(H)
+        fence()
+        elapsed = time.perf_counter() - t0
     main_ms, _ = planner.timing_read_main()
     kernel_ms, launches = planner.timing_read()
     handed_on = planner.quad_stats()
@@ -275,6 +346,8 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
                    "candidates_per_gpu": candidates, "horizon": H, "spline_points": P,
                    "parallelism": f"candidates sharded over {world} rank(s)" + (", exchange over RCCL inside libmjpcx.so" if native is not None else (f", exchange over {transport}" if world > 1 else "")),
                    "kernel": planner.kernel_name,
+                   "physics_not_reproduced": physics_notes or None,
+                   "rccl_world": planner.comm_info()[1],   # ranks of the library's own RCCL communicator (1: none was created)
                    "host": ("C++ mjpc::GpuSamplingPlanner" if kind == "sampling" else "C++ mjpc::GpuCrossEntropyPlanner") + " over the C ABI"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -287,6 +360,7 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
                              "wavefront-per-candidate kernel. The contact models are latency / issue-bound, not HBM-bound (DESIGN.md 4): see `valu`"},
     }
     del interp
+    out["gpu_clock"] = clocks.summary()
     pmc = pmc_summary(task_name, candidates, H, precision)
     if pmc is not None:
         out["roofline"]["traffic"] = pmc.get("hbm_bytes_per_launch")
@@ -512,6 +586,8 @@ def dry_run(args, rank, world):
     import torch.distributed as dist
     from mujoco_mpc_amd.distributed import RankGroup
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("MJPC_BENCH_DRY_RUN_FAIL_RANK") == str(rank):   # (tests: a rank that dies before the rendezvous)
+        sys.exit(3)
     if world > 1:
         dist.init_process_group(backend="gloo")
     group = RankGroup(dist, torch.device("cpu")) if world > 1 else None
@@ -641,7 +717,7 @@ def main():
         out = {"metric": "candidate-trajectory rollouts/sec (fixed horizon)", "value": main_line["value"], "unit": "rollouts/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_line["ms_per_step"],
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_line["dtype"], "data": "synthetic",
-               "config": main_line["config"], "roofline": main_line["roofline"]}
+               "config": main_line["config"], "roofline": main_line["roofline"], "gpu_clock": main_line.get("gpu_clock")}
         if "cpu_baseline" in main_line:
             out["cpu_baseline"] = main_line["cpu_baseline"]
             cb = main_line["cpu_baseline"]

@@ -608,6 +608,8 @@ template <class C, typename T>
 hipError_t launch_tree(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>& wt, const RolloutArgs<T>& a, const void* image, size_t blob_bytes,
                        int N, int P, bool only_flagged = false) {
   hipError_t e = launch_tree_pass<C, T, false>(c, wm, wt, a, image, blob_bytes, N, P, only_flagged);
+  // (mjpcx_timing_read_main: the first pass is the kernel that rolls the batch out; the pass over the quad kernel's hand-ons does not own the stamp)
+  if (e == hipSuccess && !only_flagged && c->timing && c->cur_main) { if ((e = hipEventRecord(c->cur_main, c->stream)) == hipSuccess) c->cur_main = nullptr; }
   if (e != hipSuccess || (c->tree_mode & 2) || c->no_second_pass) return e;
   RolloutArgs<T> a2 = a;
   a2.noise.mode = -1;  // the first pass left every candidate's spline nodes in a.nodes
@@ -762,6 +764,7 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
       if (c->wh.registered == 0 && c->quad_ok && a.xfrc_scale == 0 && !wt.stamps && N >= c->quad_min_n) {
         le = launch_quad(c, wm, wt, a, N, P);
       } else if (c->wh.registered == 0) {
+        if (c->quad_ok) (void)hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream);  // (mjpcx_quad_stats reports the LAST rollout: nothing was handed on in this one)
         le = launch_tree<TreeCfgA1, double>(c, wm, wt, a, c->wh.dev_image, c->wh.blob_bytes, N, P);
         if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
       } else if (c->wh.registered == 1 && wm.integrator != MJPCX_INT_RK4) {
@@ -973,7 +976,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
         c->quad_why = quad::build_images(m, t, hq, ht);
         if (c->quad_why.empty()) {
           if (c->d_qmodel.reserve(hq.size()) != hipSuccess || c->d_qtab.reserve(ht.size()) != hipSuccess || c->d_qstats.reserve(32) != hipSuccess ||
-              c->d_qstamps.reserve(512) != hipSuccess ||
+              c->d_qstamps.reserve(512) != hipSuccess || hipMemset(c->d_qstats.p, 0, 32) != hipSuccess ||
               hipMemcpy(c->d_qmodel.p, hq.data(), hq.size(), hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(c->d_qtab.p, ht.data(), ht.size(), hipMemcpyHostToDevice) != hipSuccess) {
             mjpcx_destroy(c);
@@ -1000,6 +1003,11 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     set_norm_params(c, t->norm_parameter);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
     g_create_error = c->wh.warning;  // (empty, or what this context does NOT model of the caller's mjModel)
+    if (!c->wh.warning.empty() && getenv("MJPCX_STRICT_PAIRS")) {  // strict callers (tests, parity runs) refuse a model whose physics is not fully reproduced
+      const std::string why = c->wh.warning;
+      mjpcx_destroy(c);
+      return bad(MJPCX_EUNSUPPORTED, why.c_str());
+    }
     // a model the Jacobian-free path could serve, but with no registered configuration (dimensions in tree_registry.h): it runs -- on the
     // generic kernel, at a fraction of the registered kernel's rate. Say so instead of leaving the caller to find out from the clock.
     if (c->wh.tree_ok && c->wh.registered < 0 && !c->no_tree && !c->no_lds_model)
@@ -1856,23 +1864,37 @@ int mjpcx_comm_init(mjpcx_ctx* c, const void* unique_id, int rank, int world) {
   // ncclCommInitRank blocks until every rank of the world has joined: a rank that never arrives (a crashed peer, a mismatched id) would
   // hang the planner for good. The call runs on a helper thread with a deadline (MJPCX_COMM_TIMEOUT_S, default 120 s); past it the
   // context stays without a communicator, the caller gets MJPCX_EDEVICE and can fall back to its own transport (bench.py does).
-  struct InitState { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t rc = ncclSuccess; ncclComm_t comm = nullptr; };
+  // A communicator that arrives AFTER the deadline is destroyed by the helper thread itself (the peers' next collective then fails
+  // instead of waiting for a rank that has moved on); callers must agree on the fallback collectively, as bench.py does.
+  struct InitState { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; ncclResult_t rc = ncclSuccess; ncclComm_t comm = nullptr; };
   auto st = std::make_shared<InitState>();
   const int device = c->device;
   std::thread([st, R, world, id, rank, device]() {
     (void)hipSetDevice(device);
     ncclComm_t comm = nullptr;
     const ncclResult_t rc = R->CommInitRank(&comm, world, id, rank);
-    std::lock_guard<std::mutex> lk(st->m);
-    st->rc = rc; st->comm = comm; st->done = true;
-    st->cv.notify_all();
+    bool late;
+    {
+      std::lock_guard<std::mutex> lk(st->m);
+      st->rc = rc; st->comm = comm; st->done = true;
+      late = st->abandoned;
+      st->cv.notify_all();
+    }
+    if (late && rc == ncclSuccess && comm) (void)R->CommDestroy(comm);
   }).detach();
   double deadline = 120.0;
-  if (const char* e = getenv("MJPCX_COMM_TIMEOUT_S")) deadline = std::atof(e);
+  if (const char* e = getenv("MJPCX_COMM_TIMEOUT_S")) {
+    char* end = nullptr;
+    const double v = std::strtod(e, &end);
+    if (end == e || !(v > 0)) return fail(c, MJPCX_EINVAL, "MJPCX_COMM_TIMEOUT_S must be a positive number of seconds");
+    deadline = v;
+  }
   {
     std::unique_lock<std::mutex> lk(st->m);
-    if (!st->cv.wait_for(lk, std::chrono::duration<double>(deadline), [&] { return st->done; }))
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(deadline), [&] { return st->done; })) {
+      st->abandoned = true;
       return fail(c, MJPCX_EDEVICE, "ncclCommInitRank did not complete within MJPCX_COMM_TIMEOUT_S: a rank of the world is missing");
+    }
   }
   NCCLCHK(c, st->rc);
   ncclComm_t comm = st->comm;

@@ -14,12 +14,9 @@ hipError_t launch_rollout_quad(const void* model_, const void* tables_, const do
   // four wavefronts (64 candidates) per workgroup once every CU has one; single-wavefront workgroups for smaller batches
   const int W = a.N >= 64 * 128 ? 4 : 1;
   const size_t lds = W * kQWaveLds;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)rollout_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kQWaveLds));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  // (the opt-in to more than 64 KB of dynamic LDS is per device and costs nothing next to a 60 ms launch: set on every launch, like the other launchers)
+  hipError_t e = hipFuncSetAttribute((const void*)rollout_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kQWaveLds));
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(rollout_quad_kernel, dim3((a.N + 16 * W - 1) / (16 * W)), dim3(64 * W), lds, stream, model, tables, blob, bo, a, stats);
   return hipGetLastError();
 }

@@ -72,6 +72,12 @@ void Agent::Allocate() {
 }
 
 void Agent::Reset(const double* initial_repeated_action) {
+  // every planner that holds a device context is reset, as the reference resets every planner (agent.cc Reset): a planner the caller
+  // switches back to after a simulation reset must not resume the policy it had before it
+  for (size_t i = 0; i < planners_.size(); i++) {
+    if ((int)i == planner_ || !planners_[i]) continue;
+    if (i < allocated_.size() && allocated_[i]) planners_[i]->Reset(kMaxTrajectoryHorizon, initial_repeated_action);
+  }
   ActivePlanner().Reset(kMaxTrajectoryHorizon, initial_repeated_action);
   state.Reset();
   count_ = 0;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -17,46 +18,71 @@ namespace {
 constexpr double kMaxReturnValue = 1.0e6;  // trajectory.cc:29
 
 // One device context per (model, task) the host-policy rollouts are asked for, created on first use. The key is the pair of
-// addresses; a model deleted and another loaded at the same address (or a task re-created there) is told apart by a fingerprint of
-// what the context was built from, and gets a fresh context. The table is never destroyed (a static destructor would call into the
-// HIP runtime after it may have shut down); ReleaseRolloutContexts() frees the contexts while the runtime is alive.
+// addresses; a model deleted and another loaded at the same address (or a task re-created there, or the model edited in place) is
+// told apart by a fingerprint of every numeric array the context is built from, and gets a fresh context. The reference calls
+// Trajectory::Rollout from ThreadPool workers concurrently: a slot's context is shared (shared_ptr: a replacement or
+// ReleaseRolloutContexts() cannot destroy it under a running rollout) and a rollout holds the slot's own mutex from set_state to the
+// last fetch, so two threads rolling out the same (model, task) take turns on its one stream instead of interleaving. The table is
+// never destroyed (a static destructor would call into the HIP runtime after it may have shut down); ReleaseRolloutContexts() drops
+// the contexts while the runtime is alive.
 struct RolloutSlot {
   std::uint64_t fingerprint = 0;
-  std::unique_ptr<gpu::Context> ctx;
+  std::shared_ptr<gpu::Context> ctx;
+  std::shared_ptr<std::mutex> busy;
+};
+struct RolloutLease {
+  std::shared_ptr<gpu::Context> ctx;
+  std::shared_ptr<std::mutex> busy;
 };
 using RolloutTable = std::map<std::pair<const mjModel*, const Task*>, RolloutSlot>;
 std::mutex& RolloutMutex() { static std::mutex* m = new std::mutex; return *m; }
 RolloutTable& RolloutContexts() { static RolloutTable* t = new RolloutTable; return *t; }
 
 std::uint64_t Fingerprint(const mjModel* m, const Task* task) {
-  std::uint64_t h = 1469598103934665603ull;  // FNV-1a over the dimensions and the arrays a re-authored model would change
+  std::uint64_t h = 1469598103934665603ull;  // FNV-1a, eight bytes at a time, over the dimensions, the options and every numeric model array
   auto mix = [&h](const void* p, size_t bytes) {
+    if (!p) return;
     const unsigned char* b = static_cast<const unsigned char*>(p);
-    for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { std::uint64_t w; std::memcpy(&w, b + i, 8); h ^= w; h *= 1099511628211ull; }
+    for (; i < bytes; i++) { h ^= b[i]; h *= 1099511628211ull; }
   };
-  const int dims[] = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nsensor, m->ntendon, task->num_residual, task->num_term, task->num_trace};
+  const int dims[] = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->nsite, m->nmocap, m->nsensor, m->ntendon, m->nwrap, m->nexclude,
+                      task->num_residual, task->num_term, task->num_trace};
   mix(dims, sizeof dims);
   const mjtNum opt[] = {m->opt.timestep, m->opt.gravity[0], m->opt.gravity[1], m->opt.gravity[2], m->opt.tolerance, m->opt.impratio,
                         (mjtNum)m->opt.integrator, (mjtNum)m->opt.iterations, (mjtNum)m->opt.cone, (mjtNum)m->opt.disableflags};
   mix(opt, sizeof opt);
-  if (m->body_mass) mix(m->body_mass, sizeof(mjtNum) * m->nbody);
-  if (m->body_pos) mix(m->body_pos, sizeof(mjtNum) * 3 * m->nbody);
-  if (m->geom_size) mix(m->geom_size, sizeof(mjtNum) * 3 * m->ngeom);
-  if (m->geom_pos) mix(m->geom_pos, sizeof(mjtNum) * 3 * m->ngeom);
-  if (m->dof_damping) mix(m->dof_damping, sizeof(mjtNum) * m->nv);
-  if (m->actuator_gainprm) mix(m->actuator_gainprm, sizeof(mjtNum) * m->nu);
+  const size_t N = sizeof(mjtNum), nb = (size_t)m->nbody, nj = (size_t)m->njnt, nv = (size_t)m->nv, ng = (size_t)m->ngeom, nu = (size_t)m->nu;
+  mix(m->body_mass, N * nb); mix(m->body_pos, N * 3 * nb); mix(m->body_quat, N * 4 * nb); mix(m->body_ipos, N * 3 * nb);
+  mix(m->body_iquat, N * 4 * nb); mix(m->body_inertia, N * 3 * nb);
+  mix(m->jnt_pos, N * 3 * nj); mix(m->jnt_axis, N * 3 * nj); mix(m->jnt_stiffness, N * nj); mix(m->jnt_range, N * 2 * nj);
+  mix(m->jnt_margin, N * nj); mix(m->jnt_solref, N * 2 * nj); mix(m->jnt_solimp, N * 5 * nj); mix(m->jnt_limited, nj);
+  mix(m->dof_armature, N * nv); mix(m->dof_damping, N * nv); mix(m->dof_frictionloss, N * nv); mix(m->dof_solref, N * 2 * nv);
+  mix(m->dof_solimp, N * 5 * nv);
+  mix(m->geom_size, N * 3 * ng); mix(m->geom_pos, N * 3 * ng); mix(m->geom_quat, N * 4 * ng); mix(m->geom_friction, N * 3 * ng);
+  mix(m->geom_solref, N * 2 * ng); mix(m->geom_solimp, N * 5 * ng); mix(m->geom_margin, N * ng); mix(m->geom_gap, N * ng);
+  mix(m->geom_solmix, N * ng); mix(m->geom_type, sizeof(int) * ng); mix(m->geom_contype, sizeof(int) * ng);
+  mix(m->geom_conaffinity, sizeof(int) * ng); mix(m->geom_condim, sizeof(int) * ng); mix(m->geom_priority, sizeof(int) * ng);
+  mix(m->qpos0, N * (size_t)m->nq); mix(m->qpos_spring, N * (size_t)m->nq);
+  mix(m->site_pos, N * 3 * (size_t)m->nsite); mix(m->site_quat, N * 4 * (size_t)m->nsite);
+  mix(m->actuator_gear, N * 6 * nu); mix(m->actuator_gainprm, N * mjNGAIN * nu); mix(m->actuator_biasprm, N * mjNBIAS * nu);
+  mix(m->actuator_ctrlrange, N * 2 * nu); mix(m->actuator_forcerange, N * 2 * nu); mix(m->actuator_ctrllimited, nu);
+  mix(m->actuator_forcelimited, nu);
+  mix(m->tendon_range, N * 2 * (size_t)m->ntendon); mix(m->wrap_prm, N * (size_t)m->nwrap);
   return h;
 }
 
-gpu::Context* RolloutContext(const mjModel* model, const Task* task) {
+RolloutLease RolloutContext(const mjModel* model, const Task* task) {
+  const std::uint64_t fp = Fingerprint(model, task);   // (hashed outside the table's lock: other (model, task) pairs are not held up)
   const std::lock_guard<std::mutex> lock(RolloutMutex());
   RolloutSlot& slot = RolloutContexts()[{model, task}];
-  const std::uint64_t fp = Fingerprint(model, task);
   if (!slot.ctx || slot.fingerprint != fp) {
-    slot.ctx = std::make_unique<gpu::Context>(model, *task, /*device=*/0, /*precision=*/64);
+    slot.ctx = std::make_shared<gpu::Context>(model, *task, /*device=*/0, /*precision=*/64);
+    slot.busy = std::make_shared<std::mutex>();
     slot.fingerprint = fp;
   }
-  return slot.ctx.get();
+  return {slot.ctx, slot.busy};
 }
 }  // namespace
 
@@ -73,7 +99,9 @@ void HostPolicyRollout(Trajectory* tr, Policy policy, const Task* task, const mj
   tr->failure = false;
   tr->horizon = steps;
   const int nx = tr->dim_state, nu = tr->dim_action, nr = tr->dim_residual, ntr = tr->dim_trace;
-  gpu::Context* ctx = RolloutContext(model, task);
+  const RolloutLease lease = RolloutContext(model, task);
+  const std::lock_guard<std::mutex> turn(*lease.busy);  // one rollout at a time on this (model, task)'s context and stream
+  gpu::Context* ctx = lease.ctx.get();
   ctx->SyncTask(*task);
   Trajectory one;  // the two rows a single mj_step produces
   one.Initialize(nx, nu, nr, ntr / 3, 2);

@@ -83,6 +83,19 @@ int main(int argc, char** argv) {
     ThreadPool pool(1);
     agent.PlanIteration(&pool);  // would dereference an unallocated planner without the lazy Allocate
     CHECK(agent.ActivePlanner().BestTrajectory() != nullptr);
+    // switch -> Reset -> switch back: Agent::Reset resets EVERY planner that holds a context (the reference's Agent::Reset does), so
+    // the planner the caller returns to starts from the zero policy, not from the one it had before the simulation was reset
+    std::vector<double> action(m->nu, 0.0), zero(m->nu, 0.0);
+    for (int k = 0; k < 3; k++) agent.PlanIteration(&pool);
+    agent.ActivePlanner().ActionFromPolicy(action.data(), agent.state.state().data(), 0.05);
+    bool moved = false;
+    for (int i = 0; i < m->nu; i++) moved |= action[i] != 0.0;
+    CHECK(moved);                               // the cross-entropy planner holds a non-trivial policy now
+    agent.SetPlanner(kSamplingPlanner);         // away ...
+    agent.Reset();                              // ... the simulation is reset while another planner is active ...
+    agent.SetPlanner(kCrossEntropyPlanner);     // ... and back
+    agent.ActivePlanner().ActionFromPolicy(action.data(), agent.state.state().data(), 0.05);
+    for (int i = 0; i < m->nu; i++) CHECK(action[i] == 0.0);
   }
   TEST_MAIN_END();
 }

@@ -181,6 +181,16 @@ class HostPlanner:
         except Exception:
             pass
 
+    def comm_info(self):
+        """(rank, world) of the library's own RCCL communicator (mjpcx_comm_info); (0, 1) before mjpcx_comm_init"""
+        ctx = lib().mjpc_planner_ctx(self.h)
+        r, w = C.c_int(0), C.c_int(1)
+        if ctx:
+            L = capi.lib()
+            L.mjpcx_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            L.mjpcx_comm_info(ctx, C.byref(r), C.byref(w))
+        return r.value, w.value
+
     def comm_barrier(self):
         self._chk(lib().mjpc_planner_comm_barrier(self.h))
 

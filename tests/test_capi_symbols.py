@@ -104,6 +104,14 @@ def test_moving_geom_pairs_the_kernels_cannot_collide_are_reported():
     ctx = capi.Context(quad.packed_model(), quad.packed(), 0, 64)
     assert "NOT collided" in ctx.create_warning and "neither sphere nor capsule" in ctx.create_warning
     ctx.close()
+    # a strict caller gets an error instead of a context whose physics differs from the model's
+    os.environ["MJPCX_STRICT_PAIRS"] = "1"
+    try:
+        with pytest.raises(capi.MjpcxError) as err:
+            capi.Context(quad.packed_model(), quad.packed(), 0, 64)
+        assert "NOT collided" in str(err.value)
+    finally:
+        os.environ.pop("MJPCX_STRICT_PAIRS", None)
     hum = load_task("HumanoidTrack")
     ctx = capi.Context(hum.packed_model(), hum.packed(), 0, 64)
     assert ctx.create_warning == ""   # nothing left uncollided, and the model has a registered kernel configuration (tree_registry.h)

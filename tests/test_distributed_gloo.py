@@ -128,6 +128,31 @@ def test_bench_launcher_dry_run_at_world_size_two(scaling):
     assert line["ms_per_step"] >= 20.0          # the slower rank (2 x 10 ms per step), not rank 0's own 10 ms
 
 
+def test_bench_launches_its_own_ranks_when_called_plainly():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (how the driver's BENCH record invokes it): bench.py starts one copy
+    of itself per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), rank 0's JSON line comes out
+    once, the exit code is 0 -- and non-zero when a rank dies."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--candidates", "4097"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["dry_run"] is True
+    assert line["ms_per_step"] >= 20.0
+    # a rank that dies takes the launch down with a non-zero exit code instead of leaving the others at a barrier
+    env["MJPC_BENCH_DRY_RUN_FAIL_RANK"] = "1"
+    env["MJPC_BENCH_LAUNCH_TIMEOUT_S"] = "120"
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 # ---------------------------------------------------------------- the C++ planners (what bench.py ships), on a CPU stand-in for the device
 CPP_WORKER = r'''
 import os, sys, json
