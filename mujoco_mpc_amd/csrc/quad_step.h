@@ -710,8 +710,15 @@ QD void rows_line(const QuadModel& m, const QDiag& dg, const QRows& R, CS& cs, i
 // rows) then has the register file to itself instead of competing with everything the iteration keeps alive around it.
 // BEYOND = false: no lane of the wavefront holds more contacts than slots (the common case) -- the trial loop then lives on the slots'
 // coefficients and the diagonal rows alone; the records, the chain velocities and the partner exchange are dead after the preparation.
+// (inlined into the Newton iteration since the split: the common variant is small, and the call -- arguments through the stack, the
+// chain velocities re-read from memory -- cost 7 % of the launch)
+#if defined(QEXP_LS_NOINLINE)
+#define QLS_ATTR QNOINLINE
+#else
+#define QLS_ATTR QD
+#endif
 template <bool MULTI, bool BEYOND, class CS, class QProfT>
-QNOINLINE double line_search(const QuadModel& m_in, int leg, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs_in)[6], int pmask,
+QLS_ATTR double line_search(const QuadModel& m_in, int leg, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs_in)[6], int pmask,
                              double q1, double q2, double gtol, QProfT& pf) {
   // (everything small arrives by value: an argument passed by reference pins the caller's copy in memory for the whole iteration)
   const QuadModel& m = QREBIND_LDS(QuadModel, m_in);
@@ -758,6 +765,19 @@ QNOINLINE double line_search(const QuadModel& m_in, int leg, const QRows R, CS c
   QPROF(pf, 42);
   return alpha;
 }
+#ifdef QEXP_LS_SLOW_NOINLINE
+template <bool MULTI, class CS, class QProfT>
+QNOINLINE double line_search_beyond(const QuadModel& m_in, int leg, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs_in)[6], int pmask,
+                                    double q1, double q2, double gtol, QProfT& pf) {
+  return line_search<MULTI, true>(m_in, leg, R, cs, ncon, hl0, hl1, hl2, Vs_in, pmask, q1, q2, gtol, pf);
+}
+#else
+template <bool MULTI, class CS, class QProfT>
+QD double line_search_beyond(const QuadModel& m_in, int leg, const QRows R, CS cs, int ncon, double hl0, double hl1, double hl2, const double (*Vs_in)[6], int pmask,
+                             double q1, double q2, double gtol, QProfT& pf) {
+  return line_search<MULTI, true>(m_in, leg, R, cs, ncon, hl0, hl1, hl2, Vs_in, pmask, q1, q2, gtol, pf);
+}
+#endif
 // H += J' (d2s) J of the contacts: the lane's leg block and coupling from its own contacts' blocks (X, from rows_eval), the trunk block
 // from the quad sum of X. Contacts whose body is not the last link were counted for dofs below their body: taken out again.
 template <class CS>
@@ -1071,7 +1091,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       double Vs[4][6];
       chain_velocity(kin, hl, ht, Vs);
       const double gtol = m.tolerance * kQLsTol * sqrt(snorm) / scale;
-      const double alpha = qw_any(ncon > kQLineSlots) ? line_search<GENERAL, true>(m, leg, R, cs, ncon, hl[0], hl[1], hl[2], Vs, pmask, q1, q2, gtol, pf)
+      const double alpha = qw_any(ncon > kQLineSlots) ? line_search_beyond<GENERAL>(m, leg, R, cs, ncon, hl[0], hl[1], hl[2], Vs, pmask, q1, q2, gtol, pf)
                                                       : line_search<GENERAL, false>(m, leg, R, cs, ncon, hl[0], hl[1], hl[2], Vs, pmask, q1, q2, gtol, pf);
       QPROF(pf, 11);
       QUNROLL for (int j = 0; j < 3; j++) al[j] += alpha * hl[j];
@@ -1082,9 +1102,13 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       QUNROLL for (int k = 0; k < 6; k++) dt[k] = at[k] - st[k];
       arrow_mul_s(ms, dl, dt, Mal, Mat);
       const double gauss = 0.5 * arrow_dot(dl, dt, Mal, Mat);
-      double Ve[4][6];  // (the chain velocities again: Vs was handed to the line search by address, which pins it in memory)
+#ifdef QEXP_VE
+      double Ve[4][6];  // (the chain velocities again)
       chain_velocity(kin, hl, ht, Ve);
       const double newcost = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, hl, Ve, alpha, fc_l, fc_t, pmask);
+#else
+      const double newcost = gauss + rows_eval<GENERAL>(m, L, kin, R, cs, ncon, kEvalStep, hl, Vs, alpha, fc_l, fc_t, pmask);
+#endif
       improvement = cost - newcost;
       cost = newcost;
     }
@@ -1094,8 +1118,13 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
   return 0;
 }
 
+#ifdef QEXP_NEWTON_INLINE
+#define QNEWTON_ATTR QD
+#else
+#define QNEWTON_ATTR QNOINLINE
+#endif
 template <bool GENERAL, class CS, class MS, class QProfT>
-QNOINLINE int constraint_newton(const QuadModel& m_in, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmask, bool have_rel,
+QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmask, bool have_rel,
                          const double* sl_in, const double* st_in, const double* wl_in, const double* wt_in, bool have_warm,
                          double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf) {
   // (an out-of-line function on the device: its register allocation starts afresh, so the rollout's state is parked once per step instead
