@@ -40,6 +40,14 @@ __device__ __forceinline__ double qd_partner(double v, int p) {
   const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// lane (l + d) mod 4 of the quad, d in {1, 2, 3} at run time (quad-uniform): the LDS crossbar again
+__device__ __forceinline__ double qd_rotv(double v, int d) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int src = ((lane & ~3) | ((lane + d) & 3)) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 // true in every lane of the wavefront if pred holds in any (the four-lane quads of a wavefront share its instruction stream)
 __device__ __forceinline__ bool qw_any(bool pred) { return __ballot(pred) != 0; }
 // the largest value of v (0..4) over the ACTIVE lanes of the wavefront, as a scalar (ballots: lanes that left a loop earlier do not take

@@ -4,6 +4,7 @@
 //     qd_sum(x)        sum over the four lanes of the quad, bit-identical in all four
 //     qd_bcast<k>(x)   lane k's value
 //     qd_or(i)         bitwise or over the quad
+//     qd_rotv(x, d)    lane (l + d) mod 4's value, d at run time (quad-uniform)
 // which the including translation unit provides (DPP quad permutes on gfx950: quad_kernel.h; a four-thread lock-step
 // emulator on the CPU: tests/quademu, test infrastructure). Control flow around a primitive is quad-uniform by
 // construction: every loop bound and branch condition on such a path derives from quad-summed or trunk (replicated) values.
@@ -1455,12 +1456,12 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
     }
   }
   // the other three legs
-  QUNROLL for (int d = 1; d <= 3; d++) {
+  for (int d = 1; d <= 3; d++) {  // (a rolled loop: ONE instance of the tests below; the partner's values come through qd_rotv, a run-time rotation)
     const int o = (leg + d) & 3;
     const QuadLeg& O = m.leg[o];
     double oc[kQPairGeom][3];
     QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++)
-      oc[j][k] = d == 1 ? qd_rot<1>(pg.c[j][k]) : (d == 2 ? qd_rot<2>(pg.c[j][k]) : qd_rot<3>(pg.c[j][k]));
+      oc[j][k] = qd_rotv(pg.c[j][k], d);
     unsigned long long mask = near_mask(oc, O.npg, O.pg_reach);
 #ifdef QEXP_PAIRS_NOLOOP
     mask = mask > (1ull << 62) ? 1 : 0;  // (tuning: the tests run, no pair reaches the exact stage)
@@ -1468,8 +1469,8 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
     if (qd_or(mask != 0 ? 1 : 0) == 0) continue;  // (quad-uniform: the axes and velocities are only fetched for a partner that is near)
     double oa[kQPairGeom][3], ov[3][6];
     QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++)
-      oa[j][k] = d == 1 ? qd_rot<1>(pg.a[j][k]) : (d == 2 ? qd_rot<2>(pg.a[j][k]) : qd_rot<3>(pg.a[j][k]));
-    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) ov[j][k] = d == 1 ? qd_rot<1>(cvel[j][k]) : (d == 2 ? qd_rot<2>(cvel[j][k]) : qd_rot<3>(cvel[j][k]));
+      oa[j][k] = qd_rotv(pg.a[j][k], d);
+    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) ov[j][k] = qd_rotv(cvel[j][k], d);
     QPROF_COUNT(pf, 45, 1);
     while (mask) {
       QPROF_COUNT(pf, 44, 1);

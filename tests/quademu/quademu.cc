@@ -52,6 +52,12 @@ template <int D> static inline double qd_rot(double x) {  // lane (l + D) % 4's 
   g_ctx->bar.wait(g_sense);
   return g_ctx->dbuf[s][(g_lane + D) & 3];
 }
+static inline double qd_rotv(double x, int d) {  // lane (l + d) % 4's value, d at run time
+  const int s = g_phase++ & 1;
+  g_ctx->dbuf[s][g_lane] = x;
+  g_ctx->bar.wait(g_sense);
+  return g_ctx->dbuf[s][(g_lane + d) & 3];
+}
 static inline double qd_partner(double x, int p) {  // lane (l xor p)'s value
   const int s = g_phase++ & 1;
   g_ctx->dbuf[s][g_lane] = x;
