@@ -451,47 +451,67 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {  // src must b
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
-// in-place Cholesky; on exit row[k], k <= lane, holds L[lane][k]. Same operation order as the left-looking serial
-// algorithm (each entry has its products subtracted for k = 0, 1, ...). Returns false on a non-positive pivot.
-__device__ __forceinline__ bool reg_chol16(double (&row)[16], int m, int lane) {
+// 1 / sqrt(x) and sqrt(x) for x > 0 from the hardware estimate (v_rsq_f64, ~2^-26) refined by two Newton steps and one correction of the
+// root: an ulp or two from the correctly rounded values, a fifth of the instructions of sqrt() followed by a division -- the pivots of
+// a 12 x 12 factorisation are a chain of sixteen of these with nothing to overlap them
+__device__ __forceinline__ void bp_sqrt_rsqrt(double x, double& s, double& r) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  y = fma(y, fma(-hx * y, y, 0.5), y);
+  double g = x * y;
+  g = fma(fma(-g, g, x), 0.5 * y, g);
+  s = g; r = y;
+}
+// sum over lanes 0..15 (the others contribute nothing), the same value in every lane: four DPP row shifts instead of five LDS-crossbar
+// shuffles (the box-QP evaluates two to four of these per iteration on its critical path)
+__device__ __forceinline__ double row_sum16(double v, int lane) {
+  v = lane < 16 ? v : 0.0;
+  // row_shr:1,2,4,8 (bound_ctrl: lanes shifted in from outside the row read 0): after the four steps lane 15 of the row holds the total
+#define MJPCX_ROW_SHR(ctrl) do { const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true); \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true); v += __hiloint2double(hi_, lo_); } while (0)
+  MJPCX_ROW_SHR(0x111); MJPCX_ROW_SHR(0x112); MJPCX_ROW_SHR(0x114); MJPCX_ROW_SHR(0x118);
+#undef MJPCX_ROW_SHR
+  return bcast_lane(v, 15);
+}
+// in-place Cholesky of the M x M matrix (M = 12 or 16 at compile time: the run-time m <= M, rows / columns beyond m are the identity); on
+// exit row[k], k <= lane, holds L[lane][k] and inv[j] = 1 / L[j][j] (the same in every lane). Same operation order as the left-looking
+// serial algorithm (each entry has its products subtracted for k = 0, 1, ...), with the division by the pivot a multiplication by its
+// reciprocal. Returns false on a non-positive pivot.
+template <int M>
+__device__ __forceinline__ bool reg_chol16(double (&row)[16], double (&inv)[16], int lane) {
   bool ok = true;
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    if (j < m && ok) {
-      const double djj = bcast_lane(row[j], j);
-      if (!(djj > 1e-15)) {
-        ok = false;
-      } else {
-        const double d = sqrt(djj);
-        const double lij = lane == j ? d : row[j] / d;
-        row[j] = lij;
+  for (int j = 0; j < M; j++) {
+    const double djj = bcast_lane(row[j], j);
+    ok = ok && djj > 1e-15;
+    double d, id;
+    bp_sqrt_rsqrt(ok ? djj : 1.0, d, id);
+    inv[j] = id;
+    const double lij = lane == j ? d : row[j] * id;
+    row[j] = lij;
 #pragma unroll
-        for (int k = j + 1; k < 16; k++) {
-          if (k < m) {
-            const double lkj = bcast_lane(lij, k);
-            if (lane >= k) row[k] -= lij * lkj;
-          }
-        }
-      }
+    for (int k = j + 1; k < M; k++) {
+      const double lkj = bcast_lane(lij, k);
+      row[k] = lane >= k ? row[k] - lij * lkj : row[k];
     }
   }
+#pragma unroll
+  for (int j = M; j < 16; j++) inv[j] = 1.0;
   return ok;
 }
-// x = (L L')^-1 b; row[k] = L[lane][k], col[k] = L[k][lane]; b is this lane's right-hand side entry
-__device__ __forceinline__ double reg_solve16(const double (&row)[16], const double (&col)[16], double b, int m, int lane) {
+// x = (L L')^-1 b; row[k] = L[lane][k], col[k] = L[k][lane], inv[j] = 1 / L[j][j]; b is this lane's right-hand side entry
+template <int M>
+__device__ __forceinline__ double reg_solve16(const double (&row)[16], const double (&col)[16], const double (&inv)[16], double b, int lane) {
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    if (j < m) {
-      const double yj = bcast_lane(b, j) / bcast_lane(row[j], j);
-      b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
-    }
+  for (int j = 0; j < M; j++) {
+    const double yj = bcast_lane(b, j) * inv[j];
+    b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
   }
 #pragma unroll
-  for (int j = 15; j >= 0; j--) {
-    if (j < m) {
-      const double xj = bcast_lane(b, j) / bcast_lane(row[j], j);
-      b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
-    }
+  for (int j = M - 1; j >= 0; j--) {
+    const double xj = bcast_lane(b, j) * inv[j];
+    b = lane == j ? xj : (lane < j ? b - col[j] * xj : b);
   }
   return b;
 }
@@ -505,31 +525,35 @@ __device__ __forceinline__ void reg_transpose16(double (&col)[16], const double 
 #pragma unroll
   for (int k = 0; k < 16; k++) col[k] = lane < 16 ? lds[k * 16 + lane] : 0.0;
 }
+template <int M>
 __device__ __forceinline__ double reg_matvec16(const double (&row)[16], double x, int m, int lane) {
   double s = 0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) if (k < m) s += row[k] * bcast_lane(x, k);
+  for (int k = 0; k < M; k++) s += row[k] * bcast_lane(x, k);
   return lane < m ? s : 0.0;
 }
 // mju_boxQP (projected Newton) with everything in registers. res: this lane's coordinate (in/out, warm start);
-// Hrow: row of H; on return Lrow/Lcol hold the factor of the masked Hessian of the last evaluated free set (also left
-// in Llds, ld 16) and fmask that free set. Returns nfree or -1 (factorisation failed).
+// Hrow: row of H (zero beyond m); on return Lrow/Lcol hold the factor of the masked Hessian of the last evaluated free set (also left
+// in Llds, ld 16, its reciprocal pivots in Linvlds) and fmask that free set. Returns nfree or -1 (factorisation failed).
 // boxed == false is the unconstrained branch of the backward pass (one factorisation, res = -H^-1 g): it shares this
 // body so that the unrolled Cholesky and triangular solves exist ONCE in the instruction stream.
+template <int M>
 __device__ __forceinline__ int reg_boxqp16(double& res, double (&Lrow)[16], unsigned& fmask, const double (&Hrow)[16], double gi,
-                                            int m, double lower, double upper, double* Llds, int lane, bool boxed) {
+                                            int m, double lower, double upper, double* Llds, double* Linvlds, int lane, bool boxed) {
   int nfree = 0;
   if (boxed) res = lane < m ? fmin(fmax(res, lower), upper) : 0.0;
   double oldvalue = 0;
-  double Lcol[16];
+  double Lcol[16], Linv[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) Linv[k] = 1.0;
   unsigned long long prev_fm = 0;
   for (int iter = 0; iter < 100; iter++) {
     const double xi = res;
     double value = 0, grad = 0;
     bool is_free = lane < m;
     if (boxed) {
-      const double hx = reg_matvec16(Hrow, xi, m, lane);
-      value = wave_sum16(0.5 * xi * hx + gi * xi, lane);
+      const double hx = reg_matvec16<M>(Hrow, xi, m, lane);
+      value = row_sum16(0.5 * xi * hx + gi * xi, lane);
       grad = hx + gi;
       const bool clamped = lane < m && ((xi <= lower && grad > 0) || (xi >= upper && grad < 0));
       is_free = lane < m && !clamped;
@@ -541,34 +565,38 @@ __device__ __forceinline__ int reg_boxqp16(double& res, double (&Lrow)[16], unsi
     if (iter == 0 || fm != prev_fm) {  // re-factorise only when the clamped set changed
 #pragma unroll
       for (int k = 0; k < 16; k++) Lrow[k] = (is_free && ((fm >> k) & 1)) ? Hrow[k] : (lane == k ? 1.0 : 0.0);
-      if (!reg_chol16(Lrow, m, lane)) return -1;
+      if (!reg_chol16<M>(Lrow, Linv, lane)) return -1;
       wave_sync();
       reg_transpose16(Lcol, Lrow, Llds, lane);
+      if (lane == 0) {  // the reciprocal pivots for the K columns (backward_pass_kernel)
+#pragma unroll
+        for (int k = 0; k < 16; k++) Linvlds[k] = Linv[k];
+      }
       prev_fm = fm;
     }
     double rhs = -gi;
     if (boxed) {
       if (iter > 0 && (oldvalue - value) < 1e-8 * fabs(oldvalue)) break;  // no further relative improvement
       oldvalue = value;
-      const double gn = wave_sum16(is_free ? grad * grad : 0.0, lane);
+      const double gn = row_sum16(is_free ? grad * grad : 0.0, lane);
       if (sqrt(gn) < 1e-16) break;
       // Newton step in the free subspace: rhs = -(g + H x_clamped) on free rows, 0 on clamped rows
       double sc = 0;
 #pragma unroll
-      for (int k = 0; k < 16; k++) if (k < m && !((fm >> k) & 1)) sc += Hrow[k] * bcast_lane(xi, k);
+      for (int k = 0; k < M; k++) sc += ((fm >> k) & 1) ? 0.0 : Hrow[k] * bcast_lane(xi, k);
       rhs = is_free ? -(gi + sc) : 0.0;
     }
-    const double search = reg_solve16(Lrow, Lcol, rhs, m, lane);
+    const double search = reg_solve16<M>(Lrow, Lcol, Linv, rhs, lane);
     if (!boxed) { res = search; break; }
     const double sd = is_free ? search - xi : 0.0;
-    const double sdotg = wave_sum16(sd * grad, lane);
+    const double sdotg = row_sum16(sd * grad, lane);
     if (sdotg >= 0) break;
     double step = 1, ci = 0;
     bool ok = false;
     while (step > 1e-22) {
       ci = lane < m ? fmin(fmax(xi + step * sd, lower), upper) : 0.0;
-      const double hc = reg_matvec16(Hrow, ci, m, lane);
-      const double vc = wave_sum16(0.5 * ci * hc + gi * ci, lane);
+      const double hc = reg_matvec16<M>(Hrow, ci, m, lane);
+      const double vc = row_sum16(0.5 * ci * hc + gi * ci, lane);
       if ((vc - value) / (step * sdotg) >= 0.1) { ok = true; break; }
       step *= 0.5;
     }
@@ -649,6 +677,7 @@ __device__ __forceinline__ void flat_store(double* l, const double (&v)[K], int 
 // All LDS matrices are DENSE (leading dimension = their column count), which makes every staging copy flat:
 //   W[n*n] Wx[n] At[n*n] Bt[n*m] tmp[n*n] tmp2[m*n] Qxx[n*n] Qxu[n*m] Quu[m*m] Quur[m*m] Qx[n] Qu[m]
 //   Kt[m*n] KQ[m*n] dut[m] qsum[m] L[16*16] cxl[n] cul[m] actl[m] lim[2m]      (carved with NP = 16*ceil(n/16), 16)
+template <int M>
 __global__ __launch_bounds__(kBackwardThreads) void backward_pass_kernel(const BackwardArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n = a.n, m = a.m, T = a.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -662,6 +691,7 @@ __global__ __launch_bounds__(kBackwardThreads) void backward_pass_kernel(const B
   double* Kt = Qu + MP; double* KQ = Kt + MP * NP; double* dut = KQ + MP * NP; double* qsum = dut + MP;
   double* Llds = qsum + MP; double* cxl = Llds + MP * MP; double* cul = cxl + NP; double* actl = cul + MP;
   double* lim = actl + MP;  // 2*MP
+  double* Linvl = lim + 2 * MP;  // MP: reciprocal pivots of the factor in Llds
   __shared__ unsigned fmask_s;
   __shared__ int ok_s;
   __shared__ double dV0, dV1;
@@ -760,7 +790,7 @@ __global__ __launch_bounds__(kBackwardThreads) void backward_pass_kernel(const B
       const double act = (boxed && lane < m) ? actl[lane] : 0.0;
       const double lo = (boxed && lane < m) ? lim[2 * lane] - act : 0.0, hi = (boxed && lane < m) ? lim[2 * lane + 1] - act : 0.0;
       double x0 = boxed ? boxres : 0.0;
-      const int mf = reg_boxqp16(x0, Lrow, fmask, Hrow, qu, m, lo, hi, Llds, lane, boxed);
+      const int mf = reg_boxqp16<M>(x0, Lrow, fmask, Hrow, qu, m, lo, hi, Llds, Linvl, lane, boxed);
       if (boxed) boxres = x0;
       const bool ok = mf >= 0;
       const double du_i = lane < m ? x0 : 0.0;
@@ -768,15 +798,16 @@ __global__ __launch_bounds__(kBackwardThreads) void backward_pass_kernel(const B
         if (mf == 0 && lane < 16) {  // everything clamped: identity factor, K = 0
 #pragma unroll
           for (int k = 0; k < 16; k++) Llds[lane * 16 + k] = lane == k ? 1.0 : 0.0;
+          Linvl[lane] = 1.0;
         }
         if (lane < m) dut[lane] = du_i;
         // dV and Quu du + Qu
         double quu_row[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) quu_row[k] = (lane < m && k < m) ? Quu[(lane < m ? lane : 0) * m + (k < m ? k : 0)] : 0.0;
-        const double qd = reg_matvec16(quu_row, du_i, m, lane);
+        const double qd = reg_matvec16<M>(quu_row, du_i, m, lane);
         if (lane < m) qsum[lane] = qd + qu;
-        const double d0 = wave_sum16(lane < m ? du_i * qu : 0.0, lane), d1 = wave_sum16(lane < m ? 0.5 * du_i * qd : 0.0, lane);
+        const double d0 = row_sum16(lane < m ? du_i * qu : 0.0, lane), d1 = row_sum16(lane < m ? 0.5 * du_i * qd : 0.0, lane);
         if (lane == 0) { dV0 += d0; dV1 += d1; }
       }
       if (lane == 0) { fmask_s = fmask; if (!ok) ok_s = 0; }
@@ -790,29 +821,26 @@ __global__ __launch_bounds__(kBackwardThreads) void backward_pass_kernel(const B
       // that the per-thread solution vector stays in registers; L is read from LDS (broadcast across lanes)
       const unsigned fmask = fmask_s;
       for (int j = tid; j < n; j += NT) {
-        double x[16];
+        // (rows / columns m .. M-1 of the factor are the identity and their right-hand sides zero: no run-time guards in the unrolled loops)
+        double x[M];
 #pragma unroll
-        for (int i = 0; i < 16; i++) x[i] = (i < m && ((fmask >> i) & 1)) ? Qxu[j * m + i] : 0.0;
+        for (int i = 0; i < M; i++) x[i] = (i < m && ((fmask >> i) & 1)) ? Qxu[j * m + (i < m ? i : 0)] : 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          if (i < m) {
-            double v = x[i];
+        for (int i = 0; i < M; i++) {
+          double v = x[i];
 #pragma unroll
-            for (int k = 0; k < i; k++) v -= Llds[i * 16 + k] * x[k];
-            x[i] = v / Llds[i * 16 + i];
-          }
+          for (int k = 0; k < i; k++) v -= Llds[i * 16 + k] * x[k];
+          x[i] = v * Linvl[i];
         }
 #pragma unroll
-        for (int i = 15; i >= 0; i--) {
-          if (i < m) {
-            double v = x[i];
+        for (int i = M - 1; i >= 0; i--) {
+          double v = x[i];
 #pragma unroll
-            for (int k = i + 1; k < 16; k++) if (k < m) v -= Llds[k * 16 + i] * x[k];
-            x[i] = v / Llds[i * 16 + i];
-          }
+          for (int k = i + 1; k < M; k++) v -= Llds[k * 16 + i] * x[k];
+          x[i] = v * Linvl[i];
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++) if (i < m) Kt[i * n + j] = -x[i];
+        for (int i = 0; i < M; i++) if (i < m) Kt[i * n + j] = -x[i];
       }
     }
     __syncthreads();

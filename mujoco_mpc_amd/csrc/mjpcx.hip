@@ -1752,13 +1752,20 @@ int mjpcx_backward_pass(mjpcx_ctx* c, int n, int m, int T, double mu, int reg_ty
   a.status = (int*)(a.dV + 2);
   a.stamps = c->stamp_step >= 0 ? (long long*)(a.dV + 4) : nullptr;
   const int NP = (n + 15) & ~15;
-  const size_t lds = (size_t)(5 * NP * NP + 2 * NP + 6 * NP * 16 + 5 * 256 + 16 * 23 + 16 * 12) * 8;
+  const size_t lds = (size_t)(5 * NP * NP + 3 * NP + 6 * NP * 16 + 5 * 256 + 16 * 23 + 16 * 13) * 8;  // (the carve of backward_pass_kernel, with slack)
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
-  HIPCHK(c, hipFuncSetAttribute((const void*)backward_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  HIPCHK(c, hipEventRecord(e0, c->stream));
-  hipLaunchKernelGGL(backward_pass_kernel, dim3(1), dim3(64 * kBackwardWaves), lds, c->stream, a);
+  // the m x m factorisation / box-QP of a step is unrolled to 12 or 16 columns at compile time (the A1 has 12 controls)
+  if (m <= 12) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)backward_pass_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(backward_pass_kernel<12>, dim3(1), dim3(64 * kBackwardWaves), lds, c->stream, a);
+  } else {
+    HIPCHK(c, hipFuncSetAttribute((const void*)backward_pass_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(backward_pass_kernel<16>, dim3(1), dim3(64 * kBackwardWaves), lds, c->stream, a);
+  }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipMemcpyAsync(Vx, a.Vx, sT * sn * 8, hipMemcpyDeviceToHost, c->stream));
