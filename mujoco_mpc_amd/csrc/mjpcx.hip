@@ -364,7 +364,8 @@ struct mjpcx_ctx {
   // quad kernel (quad_kernel.h): four lanes per candidate; fp64 contexts of a model quad_build accepts
   bool quad_ok = false;       // MJPCX_NO_QUAD=1 keeps the wavefront-per-candidate kernels (A/B runs)
   bool quad_stamps = false;   // MJPCX_QUAD_STAMPS=1: phase cycle stamps of wavefront 0 (tuning aid; synchronises every rollout)
-  int quad_min_n = 4096;          // batches below this go to rollout_tree_kernel<A1> (MJPCX_QUAD_MIN_N)
+  int quad_min_n = 4096;          // batches below this go to rollout_tree_kernel<A1> (MJPCX_QUAD_MIN_N): measured cross-over, tools/quad_n_sweep.py (N = 2048: 34 ms there, 46 ms here)
+  int quad_cpw = 0;               // candidates per wavefront of the quad kernel (0: chosen from the batch size; MJPCX_QUAD_CPW)
   int quad_con_cap = 0;           // MJPCX_QUAD_CON_CAP=<n>: hand on candidates with more than n contacts in a lane (tests of the hand-on path)
   bool quad_no_fallback = false;  // MJPCX_QUAD_NO_FALLBACK=1: leave the handed-on candidates flagged (tuning: failure[] then carries reason and step)
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
@@ -626,14 +627,14 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
   q.nominal_candidate = a.noise.nominal_candidate; q.explore_count = a.noise.explore_count; q.std0 = a.noise.std0; q.std1 = a.noise.std1;
   q.param_variance = a.noise.param_variance;
   q.states = a.states; q.actions = a.actions; q.times = a.times; q.residual = a.residual; q.costs = a.costs; q.trace = a.trace;
-  q.total_return = a.total_return; q.failure = a.failure; q.con_cap = c->quad_con_cap;
+  q.total_return = a.total_return; q.failure = a.failure; q.con_cap = c->quad_con_cap; q.cpw = c->quad_cpw;
   const quad::QBlob bo{wt.off_time, wt.off_mocap, wt.off_weight, wt.off_normp, wt.off_normq, wt.off_param, wt.off_risk, wt.off_rreal, wt.off_rint};
   hipError_t e;
   if ((e = hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream)) != hipSuccess) return e;  // (how many candidates are handed on, by reason: mjpcx_quad_stats)
   if (c->quad_stamps) {
     if ((e = hipMemsetAsync(c->d_qstamps.p, 0, 512, c->stream)) != hipSuccess) return e;
     q.stamps = (long long*)c->d_qstamps.p;
-    const size_t wb = (size_t)((N + 15) / 16) * 32;
+    const size_t wb = (size_t)N * 32;  // (one wavefront per candidate at most)
     if ((e = c->d_qwave.reserve(wb)) != hipSuccess || (e = hipMemsetAsync(c->d_qwave.p, 0, wb, c->stream)) != hipSuccess) return e;
     q.wave_times = (long long*)c->d_qwave.p;
   }
@@ -654,7 +655,8 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
     std::fprintf(stderr, "\n");
     std::fprintf(stderr, "  newton: entry %lld, first pass %lld, warm start %lld; line search: entry %lld, coefficients %lld, trials %lld\n", h[13], h[14], h[15], h[40], h[41], h[42]);
     {
-      const int W = (N + 15) / 16;
+      int cpw_ = c->quad_cpw; if (cpw_ <= 0) { cpw_ = 16; while (cpw_ > 1 && (N + cpw_ - 1) / cpw_ < 1024) cpw_ >>= 1; }
+      const int W = (N + cpw_ - 1) / cpw_;
       std::vector<long long> w((size_t)W * 4);
       (void)hipMemcpy(w.data(), c->d_qwave.p, w.size() * 8, hipMemcpyDeviceToHost);
       std::vector<int> order(W);
@@ -970,6 +972,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       c->quad_no_fallback = getenv("MJPCX_QUAD_NO_FALLBACK") != nullptr;
       if (const char* e = getenv("MJPCX_QUAD_CON_CAP")) c->quad_con_cap = std::atoi(e);
       if (const char* e = getenv("MJPCX_QUAD_MIN_N")) c->quad_min_n = std::atoi(e);
+      if (const char* e = getenv("MJPCX_QUAD_CPW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->quad_cpw = v; }
       if (precision == 64 && !getenv("MJPCX_NO_QUAD")) {
         // the quad kernel family (four lanes per candidate): models of the legged class quad_build accepts
         std::vector<unsigned char> hq, ht;

@@ -23,6 +23,7 @@ struct QArgs {
   int* failure;
   long long* stamps;  // nullptr, or 64 counters: phase cycles of wavefront 0 (tuning aid, MJPCX_QUAD_STAMPS=1)
   long long* wave_times;  // nullptr, or [wavefront][4] (tuning aid, with stamps): cycles; Newton iterations run (each step the slowest candidate's); steps through the general solver; the largest per-lane contact count, summed over the steps
+  int cpw;            // candidates per wavefront (1, 2, 4, 8 or 16: the first 4 * cpw lanes of a wavefront work; 0 = 16). Small batches spread over more wavefronts: the lock-step is over fewer candidates and every SIMD gets one
   int con_cap;        // a lane that collects more contacts than this hands its candidate on (0: kQMaxCon, the store's capacity; MJPCX_QUAD_CON_CAP lowers it, for tests of the hand-on)
 };
 

@@ -190,8 +190,12 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __re
   __syncthreads();
   if ((int)threadIdx.x < sm.nstatic) static_pose(sm, blob + bo.off_mocap, threadIdx.x, sp[threadIdx.x]);
   __syncthreads();
-  const int cand = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, leg = threadIdx.x & 3;
-  if (cand >= a.N) return;  // (whole quads leave together)
+  // candidates per wavefront: 16 fills the chip at N = 16384; a smaller batch is dealt over more wavefronts (a.cpw of them per wavefront, in
+  // its first lanes), so that its lock-step is over fewer candidates and it still uses every SIMD
+  const int cpw = a.cpw > 0 ? a.cpw : 16;
+  const int quad = (threadIdx.x & 63) >> 2, leg = threadIdx.x & 3;
+  const int cand = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * cpw + quad;
+  if (quad >= cpw || cand >= a.N) return;  // (whole quads leave together)
   QTask tk;
   tk.mocap = blob + bo.off_mocap; tk.weight = blob + bo.off_weight; tk.norm_p = blob + bo.off_normp; tk.norm_q = blob + bo.off_normq;
   tk.param = blob + bo.off_param; tk.re = blob + bo.off_rreal; tk.ri = reinterpret_cast<const int*>(blob + bo.off_rint); tk.risk = blob[bo.off_risk];

@@ -11,13 +11,17 @@ std::string build_images(const mjpcx_model* m, const mjpcx_task* t, std::vector<
 hipError_t launch_rollout_quad(const void* model_, const void* tables_, const double* blob, const QBlob& bo, const QArgs& a, int* stats, hipStream_t stream) {
   const QuadModel* model = static_cast<const QuadModel*>(model_);
   const QuadTables* tables = static_cast<const QuadTables*>(tables_);
-  // four wavefronts (64 candidates) per workgroup once every CU has one; single-wavefront workgroups for smaller batches
-  const int W = a.N >= 64 * 128 ? 4 : 1;
+  // candidates per wavefront: as many as it takes to give every SIMD of the 256 CUs one wavefront, 16 at most (a.cpw > 0: the caller's choice);
+  // four wavefronts per workgroup (one per SIMD of a CU, sharing one model image) once every CU has one
+  QArgs q = a;
+  if (q.cpw <= 0) { q.cpw = 16; while (q.cpw > 1 && (a.N + q.cpw - 1) / q.cpw < 1024) q.cpw >>= 1; }
+  const int waves = (a.N + q.cpw - 1) / q.cpw;
+  const int W = waves >= 512 ? 4 : 1;
   const size_t lds = W * kQWaveLds;
   // (the opt-in to more than 64 KB of dynamic LDS is per device and costs nothing next to a 60 ms launch: set on every launch, like the other launchers)
   hipError_t e = hipFuncSetAttribute((const void*)rollout_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kQWaveLds));
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(rollout_quad_kernel, dim3((a.N + 16 * W - 1) / (16 * W)), dim3(64 * W), lds, stream, model, tables, blob, bo, a, stats);
+  hipLaunchKernelGGL(rollout_quad_kernel, dim3((waves + W - 1) / W), dim3(64 * W), lds, stream, model, tables, blob, bo, q, stats);
   return hipGetLastError();
 }
 } }

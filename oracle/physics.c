@@ -12,12 +12,14 @@
  *               comVel, passive, rne, actuation, acceleration, constraint solve (PGS),
  *               [sensorAcc -> task residual via mjcb_sensor, mjpc/app.cc:110-126]
  *
- * Feature subset: free/ball/slide/hinge joints in an arbitrary tree, joint
- * springs/dampers/armature, gravity, joint-transmission actuators (fixed gain,
- * none/affine bias, ctrl/force clamps), slide/hinge joint limits as soft
- * constraints (solref/solimp), Euler integrator. No contacts, tendons,
- * friction loss or equality constraints yet (models that need them are
- * rejected by odata_new).
+ * Feature subset (this file + contact.inc, humanoid.inc, quadruped.inc): free/ball/slide/hinge joints in an arbitrary tree, joint
+ * springs/dampers/armature, gravity, joint-transmission actuators (fixed gain, none/affine bias, ctrl/force clamps), friction loss,
+ * slide/hinge joint limits and limits of fixed tendons as soft constraints (solref/solimp), contacts with elliptic and pyramidal
+ * friction cones (condim 1/3/4/6) between spheres / capsules / boxes / cylinders and planes, spheres and static spheres / boxes,
+ * spheres / capsules of two moving bodies behind MuJoCo's body-pair filters, primal Newton solver with an exact line search (a PGS
+ * solver of the dual for cross-checks), Euler (implicit joint damping) and RK4 integrators, xfrc_applied. NOT restated: pairs of
+ * moving geoms that MuJoCo hands to its general convex collider (boxes, cylinders: reported by odata_new's caller and by
+ * mjpcx_create), spatial tendons, equality constraints, implicit integrators (models that need them are rejected).
  */
 #include <math.h>
 #include <stdio.h>

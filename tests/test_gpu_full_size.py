@@ -22,7 +22,7 @@ def mocap7(mpos):
     return np.concatenate([np.concatenate([p, [1, 0, 0, 0]]) for p in np.asarray(mpos).reshape(-1, 3)])
 
 
-def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, tol, sample_stride):
+def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, tol, sample_stride, expect_quad=False):
     pm, pt = task.packed_model(), task.packed()
     nu = task.model.nu
     dt = task.model.get_number("agent_timestep", task.model.timestep)
@@ -39,6 +39,14 @@ def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, t
     # produces a genuine warning (the sample in (e) pins the failure flags to the oracle's one by one)
     assert not fail.any(), (int(fail.sum()), [hex(int(x)) for x in ctx.failure_raw[fail != 0][:8]])
     assert np.all(np.isfinite(ret)) and np.all(ret > 0)
+    if expect_quad:
+        # the four-lanes-per-candidate kernel rolled the batch out; what it handed to the wavefront-per-candidate kernel is accounted for
+        # reason by reason (every hand-on carries at least one reason; this workload has none that fills a contact list or goes non-finite)
+        assert ctx.kernel_name.startswith("rollout_quad_kernel")
+        st = ctx.quad_stats()
+        reasons = ("contact_list_full", "leg_leg_contact", "indefinite_hessian", "non_finite", "both_limits", "trunk_leg_contact")
+        assert 0 <= st["handed_on"] <= sum(st[r] for r in reasons) and st["handed_on"] <= N // 100
+        assert st["contact_list_full"] == 0 and st["non_finite"] == 0 and st["leg_leg_contact"] == 0 and st["trunk_leg_contact"] == 0
     # (a) determinism
     ctx.rollout_noise(N, H, interp, times, nominal, ns)
     assert np.array_equal(ctx.returns()[0], ret)
@@ -79,13 +87,13 @@ def test_config3_quadruped_cross_entropy_n16384_h100():
 
 def test_north_star_quadruped_predictive_sampling_n16384_h100():
     """the workload bench.py times: Predictive-Sampling noise (task_flat.xml's sampling_exploration), zero-order splines, 16384 x 100,
-    with the oracle on 64 candidates of the batch"""
+    with the oracle on 256 candidates of the batch at 1e-8 and the quad kernel's hand-on statistics asserted per reason"""
     quad = load_task("QuadrupedFlat")
     quad.transition(0.0)
     state = np.concatenate([quad.model.keyframes["home"]["qpos"], np.zeros(18)])
     mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
-    full_size_properties(quad, state, mocap, N=16384, H=100, P=3, interp=0, mode=capi.NOISE_SAMPLING, precision=64, tol=1e-6,
-                         sample_stride=256)
+    full_size_properties(quad, state, mocap, N=16384, H=100, P=3, interp=0, mode=capi.NOISE_SAMPLING, precision=64, tol=1e-8,
+                         sample_stride=64, expect_quad=True)
 
 
 @pytest.mark.parametrize("precision,tol", [(64, 1e-6), (32, 2e-3)])

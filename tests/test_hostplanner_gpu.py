@@ -93,6 +93,36 @@ def test_cpp_cross_entropy_on_the_quadruped_equals_python_planner():
     assert "rollout_wave_kernel" in cpp.kernel_name or "rollout_tree_kernel" in cpp.kernel_name
 
 
+def test_cpp_cross_entropy_at_full_size_equals_python_planner():
+    """BASELINE configs[2] at FULL size through the C++ host: 16384 candidates x horizon 100, n_elite = 1638, three plan iterations of
+    mjpc::GpuCrossEntropyPlanner on rollout_quad_kernel == the Python mirror bit for bit (elite order, policy, improvement)."""
+    from mujoco_mpc_amd.hostplanner import HostPlanner
+    from mujoco_mpc_amd.planners import GpuCrossEntropyPlanner, State
+    from mujoco_mpc_amd.task import load_task
+    t = load_task("QuadrupedFlat")
+    t.transition(0.0)
+    H, N = 100, 16384
+    cpp = HostPlanner(load_task("QuadrupedFlat"), seed=3, num_trajectory=N, kind="cross_entropy")
+    cpp.task_transition(0.0)
+    cpp.reset(H)
+    py = GpuCrossEntropyPlanner(seed=3)
+    py.initialize(t.model, t); py.num_trajectory_ = N; py.n_elite_ = N // 10; py.allocate(); py.reset(H)
+    assert py.n_elite_ == 1638
+    st = State(t.model)
+    home = t.model.keyframes["home"]["qpos"]
+    mp = np.array([[0.3, 0, 0.26], [-2.5, 0, 0]]); mq = np.array([[1.0, 0, 0, 0], [1.0, 0, 0, 0]])
+    for k in range(3):
+        tm = 0.01 * k
+        st.set(home, np.zeros(18), mocap_pos=mp, mocap_quat=mq, time=tm); py.set_state(st); py.optimize_policy(H)
+        cpp.set_state(home, np.zeros(18), tm, mocap_pos=mp, mocap_quat=mq); cpp.optimize_policy(H)
+        elites = list(cpp.ce_elites())
+        assert len(elites) == 1638 and elites == py.trajectory_order
+        ct, cv = cpp.policy()
+        assert np.array_equal(ct, py.policy.plan.times()) and np.array_equal(cv, py.policy.plan.values())
+        assert cpp.improvement == py.improvement
+    assert cpp.kernel_name.startswith("rollout_quad_kernel")
+
+
 def test_cpp_predictive_sampling_replans_on_the_quadruped():
     """several plan iterations through mjpcx_best on a wave-kernel context (regression: the model allocation must
     outlive the first policy update) -- the return of the winner keeps improving from a standing start"""
