@@ -457,6 +457,58 @@ QD double contact_eval(const QContact& c, const double* fr, double* Fs, double* 
   QUNROLL for (int k = 0; k < 3; k++) { Fs[k] += w[k] + Fa[k]; Fs[3 + k] += Fl[k]; }
   return cost;
 }
+// The contact's Hessian block X = A' (d2s / djar2) A APPLIED to a spatial vector, without forming its 21 entries: what the rare passes over
+// single contacts need (self-collision, shallow contacts) -- a dense block per contact there lives in memory, not in registers.
+//   bottom zone:  X v = D0 et (et . v) + Dq Qt v
+//   middle zone:  X v = Dm at (at . v) - sT Qt v + sT rt (rt . v)
+// with Qt v = A' Qd A v evaluated through the point: u = [w; vl + w x off], Qd u = [f3^2 n (n . w) + f4^2 (w - n (n . w)); f1^2 (ul - n (n . ul))],
+// A' [qa; ql] = [qa + off x ql; ql].
+struct QHessOp { int zone; double et[6], rt[6], at[6], ca, cq, cr, f1s, f3s, f4s; };
+QD void contact_hess_prepare(const QContact& c, const double* fr, QHessOp& h) {
+  const double* n = c.n;
+  const double jn = dot3(n, c.jar + 3), an = dot3(n, c.jar);
+  double tl[3], ar[3];
+  QUNROLL for (int k = 0; k < 3; k++) { tl[k] = c.jar[3 + k] - jn * n[k]; ar[k] = c.jar[k] - an * n[k]; }
+  const double mu = fr[0];
+  h.f1s = fr[1] * fr[1]; h.f3s = fr[2] * fr[2]; h.f4s = fr[3] * fr[3];
+  const double T2 = h.f1s * dot3(tl, tl) + h.f3s * an * an + h.f4s * dot3(ar, ar), N = mu * jn;
+  double T = 0, iT = 0;
+  if (T2 > 1e-200) q_sqrt_rsqrt(T2, T, iT);
+  QUNROLL for (int k = 0; k < 6; k++) { h.et[k] = 0; h.rt[k] = 0; h.at[k] = 0; }
+  h.ca = 0; h.cq = 0; h.cr = 0;
+  if (N >= mu * T || (T <= 0 && N >= 0)) { h.zone = 0; return; }
+  double g[3];
+  cr3(g, c.off, n);
+  QUNROLL for (int k = 0; k < 3; k++) { h.et[k] = g[k]; h.et[3 + k] = n[k]; }
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    h.zone = 2; h.ca = c.D0; h.cq = c.D0 * fr[4];
+    QUNROLL for (int k = 0; k < 6; k++) h.at[k] = h.et[k];
+    return;
+  }
+  const double Dm = c.D0 * fr[5], NT = N - mu * T, sT = Dm * NT * mu * iT;
+  double ra[3], rl[3], w[3];
+  QUNROLL for (int k = 0; k < 3; k++) { ra[k] = h.f3s * an * n[k] + h.f4s * ar[k]; rl[k] = h.f1s * tl[k]; }
+  cr3(w, c.off, rl);
+  QUNROLL for (int k = 0; k < 3; k++) { h.rt[k] = (ra[k] + w[k]) * iT; h.rt[3 + k] = rl[k] * iT; }
+  QUNROLL for (int k = 0; k < 6; k++) h.at[k] = mu * (h.et[k] - h.rt[k]);
+  h.zone = 1; h.ca = Dm; h.cq = -sT; h.cr = sT;
+}
+QD void contact_hess_apply(const QContact& c, const QHessOp& h, const double* v, double* Y) {
+  const double* n = c.n;
+  // Qt v through the point
+  double wxo[3], ul[3];
+  cr3(wxo, v, c.off);
+  QUNROLL for (int k = 0; k < 3; k++) ul[k] = v[3 + k] + wxo[k];
+  const double nw = dot3(n, v), nu = dot3(n, ul);
+  double qa[3], ql[3], oxq[3];
+  QUNROLL for (int k = 0; k < 3; k++) { qa[k] = h.f3s * n[k] * nw + h.f4s * (v[k] - n[k] * nw); ql[k] = h.f1s * (ul[k] - n[k] * nu); }
+  cr3(oxq, c.off, ql);
+  const double av = h.ca * dot6(h.at, v), rv = h.cr * dot6(h.rt, v);
+  QUNROLL for (int k = 0; k < 3; k++) {
+    Y[k] = av * h.at[k] + h.cq * (qa[k] + oxq[k]) + rv * h.rt[k];
+    Y[3 + k] = av * h.at[3 + k] + h.cq * ql[k] + rv * h.rt[3 + k];
+  }
+}
 // first and second derivative of the contact's penalty along jv at jar + alpha jv (oracle constraint_line, in point space)
 QD void contact_line(const QContact& c, const double* fr, const double* jv, double alpha, double& g, double& h) {
   const double* n = c.n;
@@ -783,31 +835,29 @@ QD double line_search_beyond(const QuadModel& m_in, int leg, const QRows R, CS c
 // from the quad sum of X. Contacts whose body is not the last link were counted for dofs below their body: taken out again.
 template <class CS>
 QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H);
+// Self-collision contacts: the own leg's block (Hl, packed 3 x 3) and, for the lower leg of a pair, the cross block (Hab; rows: own dofs,
+// columns: the partner's). Called BEFORE the iteration's X and H exist (QEXP_REL_LATE: after, as until round 4), so that their 75
+// numbers are not alive around this loop.
 template <class CS>
-QD void hessian_blocks(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H, int leg, int pmode, bool have_rel) {
-  if (have_rel) {  // (quad-uniform) self-collision contacts: the own leg's block, and for the lower leg of a pair the cross block
-    double cq[3][6];  // the partner leg's dof axes
-    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) cq[j][k] = qd_partner(kin.cdof[j][k], pmode);
-    const bool isA = leg < (leg ^ pmode);
-    for (int i = 0; i < ncon; i++) {
-      QContact c;
-      qcs_load(cs, i, c);
-      if (!c.rel) continue;
-      double Fs[6] = {0, 0, 0, 0, 0, 0}, Xc[21];
-      QUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
-      int zone;
-      (void)contact_eval(c, m.fric[c.fid], Fs, Xc, zone);
-      if (zone == 0) continue;
-      QUNROLL for (int j = 0; j < 3; j++) {
-        if (j >= c.depth) continue;
-        double Y[6];
-        QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += Xc[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
-        QUNROLL for (int ii = 0; ii <= j; ii++) H.l[tri(j, ii)] += dot6(kin.cdof[ii], Y);
-        if (isA) { QUNROLL for (int ii = 0; ii < 3; ii++) if (ii < c.pd) H.ab[j][ii] -= dot6(cq[ii], Y); }
-      }
+QD void hessian_rel(const QuadModel& m, const QKin& kin, CS& cs, int ncon, int leg, int pmode, double* Hl, double (*Hab)[3]) {
+  double cq[3][6];  // the partner leg's dof axes
+  QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) cq[j][k] = qd_partner(kin.cdof[j][k], pmode);
+  const bool isA = leg < (leg ^ pmode);
+  for (int i = 0; i < ncon; i++) {
+    QContact c;
+    qcs_load(cs, i, c);
+    if (!c.rel) continue;
+    QHessOp h;
+    contact_hess_prepare(c, m.fric[c.fid], h);
+    if (h.zone == 0) continue;
+    QUNROLL for (int j = 0; j < 3; j++) {
+      if (j >= c.depth) continue;
+      double Y[6];
+      contact_hess_apply(c, h, kin.cdof[j], Y);
+      QUNROLL for (int ii = 0; ii <= j; ii++) Hl[tri(j, ii)] += dot6(kin.cdof[ii], Y);
+      if (isA) { QUNROLL for (int ii = 0; ii < 3; ii++) if (ii < c.pd) Hab[j][ii] -= dot6(cq[ii], Y); }
     }
   }
-  hessian_common(m, kin, cs, ncon, X, nshallow, H);
 }
 template <class CS>
 QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H) {
@@ -822,15 +872,13 @@ QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int ncon, do
       QContact c;
       qcs_load(cs, i, c);
       if (c.depth >= 3 || c.rel) continue;
-      double Fs[6] = {0, 0, 0, 0, 0, 0}, Xc[21];
-      QUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
-      int zone;
-      (void)contact_eval(c, m.fric[c.fid], Fs, Xc, zone);
-      if (zone == 0) continue;
+      QHessOp h;
+      contact_hess_prepare(c, m.fric[c.fid], h);
+      if (h.zone == 0) continue;
       QUNROLL for (int j = 0; j < 3; j++) {
         if (j < c.depth) continue;
         double Y[6];
-        QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += Xc[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
+        contact_hess_apply(c, h, kin.cdof[j], Y);
         QUNROLL for (int ii = 0; ii <= j; ii++) H.l[tri(j, ii)] -= dot6(kin.cdof[ii], Y);
         QUNROLL for (int k = 0; k < 6; k++) H.b[j][k] -= trunk_dot(kin, k, Y);
       }
@@ -1064,18 +1112,29 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
     QPROF(pf, 8);
     double X[21];
     int nshallow;
-    rows_X(m, cs, ncon, X, nshallow);
     if constexpr (GENERAL) {
+      rows_X(m, cs, ncon, X, nshallow);
       if (!newton_direction_general(m, L, kin, ms, R, cs, ncon, X, nshallow, leg, pmask, hl, ht)) return kFlagNotPD;
     } else {
-      // H = M + J' (d2s) J: diagonal rows, then the contacts through their 6 x 6 spatial blocks; factored in place
+      // H = M + J' (d2s) J: the self-collision contacts' blocks first (into small accumulators, nothing else of the Hessian alive yet),
+      // then the diagonal rows and the other contacts through their 6 x 6 spatial blocks; factored in place
+      double Hl_rel[6] = {0, 0, 0, 0, 0, 0}, Hab_rel[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#ifndef QEXP_REL_LATE
+      if (have_rel) hessian_rel(m, kin, cs, ncon, leg, pmode, Hl_rel, Hab_rel);  // (quad-uniform)
+#endif
+      rows_X(m, cs, ncon, X, nshallow);
       Arrow H;
       load_arrow(ms, H);
+#ifdef QEXP_REL_LATE
+      if (have_rel) hessian_rel(m, kin, cs, ncon, leg, pmode, Hl_rel, Hab_rel);
+#endif
+      QUNROLL for (int i = 0; i < 6; i++) H.l[i] += Hl_rel[i];
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) H.ab[r][c] = Hab_rel[r][c];
       QUNROLL for (int j = 0; j < 3; j++) {
         if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.l[tri(j, j)] += L.floss_D[j]; }
         if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.l[tri(j, j)] += R.lm_D[j];
       }
-      hessian_blocks(m, kin, cs, ncon, X, nshallow, H, leg, pmode, have_rel);
+      hessian_common(m, kin, cs, ncon, X, nshallow, H);
       QPROF(pf, 9);
       if (!arrow_factor(H, leg, pmode)) return kFlagNotPD;
       QUNROLL for (int j = 0; j < 3; j++) hl[j] = -hl[j];  // search direction
@@ -1127,12 +1186,13 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
 template <bool GENERAL, class CS, class MS, class QProfT>
 QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmask, bool have_rel,
                          const double* sl_in, const double* st_in, const double* wl_in, const double* wt_in, bool have_warm,
-                         double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf) {
+                         double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf_in) {
   // (an out-of-line function on the device: its register allocation starts afresh, so the rollout's state is parked once per step instead
   // of being spilled around inside the iteration. Everything that arrives by reference is copied to locals first: a by-reference operand
   // is re-read from the caller's stack at every use. The model image is in LDS, the caller's locals in its private segment.)
   const QuadModel& m = QREBIND_LDS(QuadModel, m_in);
   const QuadLeg& L = m.leg[leg];
+  QProfT pf = pf_in;  // (a local copy: through the reference every stamp would start with a load of pf.buf from the caller's stack and wait for it)
   QKin kin;
   {
     const auto* kp = QREBIND_PRIVATE(double, &kin_in.cdof[0][0]);
@@ -1159,6 +1219,7 @@ QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, co
     QUNROLL for (int k = 0; k < 6; k++) { atp[k] = at[k]; ftp[k] = fc_t[k]; }
   }
   iters_out = iters;
+  pf_in = pf;
   return rc;
 }
 
