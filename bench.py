@@ -186,10 +186,10 @@ def initial_condition(task_name, task, planner):
 
 
 def pmc_summary(task_name, candidates, horizon, precision):
-    """Counter-derived figures of the rollout kernel for THIS build: profiles/r03_pmc_<task>.json is written by
+    """Counter-derived figures of the rollout kernel for THIS build: profiles/r04_pmc_<task>.json is written by
     tools/pmc_rollout.sh (separate --pmc passes, as MI355X_MICROARCH.md prescribes) and records the sha256 of the
     kernel sources it profiled; a summary of any other source state is ignored (never a stale lookup)."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_{task_name.lower()}_fp{precision}.json")
+    path = os.path.join(ROOT, "profiles", f"r04_pmc_{task_name.lower()}_fp{precision}.json")
     try:
         s = json.load(open(path))
     except (OSError, ValueError):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gpurun_out/pmc/summary.json (tools/pmc_rollout.sh, tools/summarize_pmc.py) -> the per-build counter summary bench.py reads
-(profiles/r03_pmc_<task>_fp<prec>.json): python tools/derive_pmc.py <summary.json> <task> <candidates> <horizon> <precision> <out.json>
+(profiles/r04_pmc_<task>_fp<prec>.json): python tools/derive_pmc.py <summary.json> <task> <candidates> <horizon> <precision> <out.json>
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB per dispatch; the x2 is MI355X_MICROARCH.md's gfx950 correction for wide reads).
 The summary is tied to the code it profiled by the sha256 of the kernel sources (bench.kernel_source_sha16); bench.py ignores it
 for any other source state."""

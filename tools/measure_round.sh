@@ -1,12 +1,12 @@
 #!/bin/bash
-# One GPU-box call that collects everything profiles/r03_* is made of: the PMC summaries of the current build first (bench.py picks
+# One GPU-box call that collects everything profiles/r04_* is made of: the PMC summaries of the current build first (bench.py picks
 # them up as roofline.traffic / .valu of each line), the default bench line with its extras, and the kernel-trace summary of the same
-# command. The files land in gpurun_out/r03/ (merged back by gpurun); copy them to profiles/ and commit.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+# command. The files land in gpurun_out/r04/ (merged back by gpurun); copy them to profiles/ and commit.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
 bash $R/tools/pmc_rollout.sh QuadrupedFlat 16384 100 64 0 0.04 > $O/pmc_quadrupedflat.log 2>&1
 bash $R/tools/pmc_rollout.sh Cartpole 4096 128 64 2 0.5 > $O/pmc_cartpole.log 2>&1
 bash $R/tools/pmc_rollout.sh HumanoidTrack 8192 64 32 2 0.1 > $O/pmc_humanoidtrack.log 2>&1
-for f in $R/gpurun_out/pmc_*/r03_pmc_*.json; do cp $f $R/profiles/; cp $f $O/; done   # (the profiles/ copy lives on the box only; $O is merged back)
+for f in $R/gpurun_out/pmc_*/r04_pmc_*.json; do cp $f $R/profiles/; cp $f $O/; done   # (the profiles/ copy lives on the box only; $O is merged back)
 cd $R
 timeout 900 python bench.py > $O/bench_line.json 2> $O/bench.err
 tail -c 1500 $O/bench_line.json
