@@ -19,8 +19,12 @@ LIB = os.path.join(PKG_DIR, "libmjpcx.so")
 # its lane kernels and the Riccati pass unchanged); the iLQG unit got slower with them (19.2 -> 20.0 ms) and keeps the defaults.
 PRESSURE = ["-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-licm-promotion", "-mllvm", "-simplifycfg-sink-common=false",
             "-mllvm", "-phi-node-folding-threshold=0", "-mllvm", "-amdgpu-schedule-metric-bias=100"]
+# the quad unit after round 4's restructuring (line search inlined, no memory-resident Hessian blocks): the scheduler bias and the SLP switch
+# no longer pay there (same box, back to back: 58.0 ms with all six, 57.5 with these four; without the LICM pair 59.4, without the CFG pair 59.1)
+PRESSURE_QUAD = ["-mllvm", "-disable-machine-licm", "-mllvm", "-disable-licm-promotion", "-mllvm", "-simplifycfg-sink-common=false",
+                 "-mllvm", "-phi-node-folding-threshold=0"]
 SOURCES = [("mjpcx.hip", PRESSURE), ("ilqg_wave.hip", []), ("wave32.hip", PRESSURE), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]),
-           ("quad_kernel.hip", PRESSURE)]
+           ("quad_kernel.hip", PRESSURE_QUAD)]
 # headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
 # re-compile the wavefront-per-candidate kernels, and vice versa)
 QUAD_ONLY = ["quad_step.h", "quad_kernel.h", "quad_model.h"]

@@ -1389,8 +1389,10 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
     const double r0 = g.size[0], h0 = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
     double ci[3], ai[3];  // the own geom, picked from the register arrays (i is a run-time index here)
     QUNROLL for (int k = 0; k < 3; k++) {
-      double vc = pg.c[0][k], va = pg.a[0][k];
-      QUNROLL for (int q = 1; q < kQPairGeom; q++) { vc = i == q ? pg.c[q][k] : vc; va = i == q ? pg.a[q][k] : va; }
+      // (0 / 1 weights, not a chain of selects: the optimiser folds `i == q ? arr[q] : ...` over the elements of one array into a load at a
+      // run-time index, and an array indexed at run time lives in scratch -- 72 doubles written and re-read every step before this)
+      double vc = 0, va = 0;
+      QUNROLL for (int q = 0; q < kQPairGeom; q++) { const double wq = i == q ? 1.0 : 0.0; vc += wq * pg.c[q][k]; va += wq * pg.a[q][k]; }
       ci[k] = vc; ai[k] = va;
     }
     const bool own_first = ((L.pg_first[o] >> (8 * i + j)) & 1) != 0;
@@ -1470,8 +1472,8 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
   // partner instead of one per (i, j).
   auto pick3 = [](const double (*arr)[3], int idx, double* out) {
     QUNROLL for (int k = 0; k < 3; k++) {
-      double v = arr[0][k];
-      QUNROLL for (int q = 1; q < kQPairGeom; q++) v = idx == q ? arr[q][k] : v;
+      double v = 0;
+      QUNROLL for (int q = 0; q < kQPairGeom; q++) v += (idx == q ? 1.0 : 0.0) * arr[q][k];  // (weights, not selects: see `one`)
       out[k] = v;
     }
   };
@@ -1636,7 +1638,8 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     }
   }
   // (from here on the stages are ordered so that the big per-link arrays die early: velocities and the bias-acceleration recursion, the
-  // sensor values, collision (the last reader of the link frames), then inertias -> bias forces -> M)
+  // sensor values, inertias -> bias forces -> M (the last readers of the inertias and bias accelerations), then collision, which only
+  // needs the link frames and velocities: measured 58.4 -> 57.9 ms against collision first)
   // ================= velocities (o_comvel) and the acceleration recursion of o_rne (cdof_dot q-dot terms), link by link
   double cvel[3][6], cvelT[6], cacc[3][6], caccT[6];
   {
@@ -1662,7 +1665,7 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
   QUNROLL for (int k = 0; k < 3; k++) { out.txipos[k] = txipos[k]; out.com[k] = com[k]; }
   mv3(tmp3, txm, m.head_pos);
   QUNROLL for (int k = 0; k < 3; k++) out.head[k] = txpos[k] + tmp3[k];
-  for (int t = 0; t < m.ntrace; t++) { mv3(tmp3, txm, m.trace_pos[t]); QUNROLL for (int k = 0; k < 3; k++) out.trace[t][k] = txpos[k] + tmp3[k]; }
+  QUNROLL for (int t = 0; t < kQMaxTrace; t++) { mv3(tmp3, txm, m.trace_pos[t]); QUNROLL for (int k = 0; k < 3; k++) out.trace[t][k] = txpos[k] + tmp3[k]; }  // (a fixed trip count: a run-time one would index out.trace at run time and put QSense in scratch)
   {  // subtree linear velocity of the trunk (o_subtree_linvel)
     double mom[3] = {0, 0, 0};
     QUNROLL for (int j = 0; j < 3; j++) {
@@ -1677,50 +1680,6 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     QUNROLL for (int k = 0; k < 3; k++) out.comvel[k] = (qd_sum(mom[k]) + m.trunk_mass * (cvelT[3 + k] + lin[k])) / m.total_mass;
   }
   QPROF(pf, 1);
-  // ================= collision (o_collision): the leg's geoms and the lane's share of the trunk geoms; the self-collision test
-  int ncon = 0;
-  {
-    QPairGeoms pg;
-    QUNROLL for (int i = 0; i < kQPairGeom; i++) QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = 0; pg.a[i][k] = 0; }
-    for (int gi = 0; gi < L.ngeom; gi++) {
-      const QuadGeom& g = L.geom[gi];
-      double gp[3], gR[9];
-      const int lk = g.link;
-      double bm[9], bp[3], bv[6];
-      QUNROLL for (int k = 0; k < 9; k++) bm[k] = lk == 0 ? xmat[0][k] : (lk == 1 ? xmat[1][k] : xmat[2][k]);
-      QUNROLL for (int k = 0; k < 3; k++) bp[k] = lk == 0 ? xpos[0][k] : (lk == 1 ? xpos[1][k] : xpos[2][k]);
-      QUNROLL for (int k = 0; k < 6; k++) bv[k] = lk == 0 ? cvel[0][k] : (lk == 1 ? cvel[1][k] : cvel[2][k]);
-      mv3(gp, bm, g.pos);
-      QUNROLL for (int k = 0; k < 3; k++) gp[k] += bp[k];
-      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = bm[3 * r] * g.rot[c] + bm[3 * r + 1] * g.rot[3 + c] + bm[3 * r + 2] * g.rot[6 + c];
-      if (gi == L.foot_slot) { QUNROLL for (int k = 0; k < 3; k++) out.foot[k] = gp[k]; }
-      QUNROLL for (int i = 0; i < kQPairGeom; i++) {  // (compile-time slots: a run-time index would put the array in scratch)
-        const bool hit = i < L.npg && L.pg_slot[i] == gi;
-        QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = hit ? gp[k] : pg.c[i][k]; pg.a[i][k] = hit ? gR[3 * k + 2] : pg.a[i][k]; }
-      }
-      collide_geom(m, sp, g, &tab.leg[leg][0][gi], kQLegGeom, com, bv, lk + 1, gp, gR, cs, ncon, flags);
-    }
-    for (int gi = leg; gi < m.ntrunk_geom; gi += kQLegs) {
-      const QuadGeom& g = m.trunk_geom[gi];
-      double gp[3], gR[9];
-      mv3(gp, txm, g.pos);
-      QUNROLL for (int k = 0; k < 3; k++) gp[k] += txpos[k];
-      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
-      collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, com, cvelT, 0, gp, gR, cs, ncon, flags);
-    }
-    QPROF(pf, 2);
-    int pmask = 0, nrel = 0;
-#ifndef QEXP_NOPAIRS
-    pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, cs, ncon, flags, pmask, nrel, pf);
-#endif
-    D.ncon = ncon;
-    // bit x of pmask: some leg A touches leg A xor x. One bit set (the common case of self-collision) means disjoint pairs, which the
-    // arrowhead factorisation takes as super-legs; two or three (a leg touching two others) go through the dense elimination of the
-    // leg blocks (newton_direction_general)
-    D.pmask = qd_or(pmask);
-    D.have_rel = qd_or(nrel > 0 ? 1 : 0);
-    QPROF(pf, 3);
-  }
   // ================= spatial inertias about the centre of mass (o_compos); bias forces (o_rne), passive, actuation -> qfrc_smooth
   double cin[3][10], cinT[10];
   QUNROLL for (int j = 0; j < 3; j++) {
@@ -1777,6 +1736,50 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     QUNROLL for (int j = 0; j < 3; j++) D.sl[j] = D.fs_l[j];
     QUNROLL for (int k = 0; k < 6; k++) D.st[k] = D.fs_t[k];
     arrow_solve(M, D.sl, D.st, leg, 0);
+  }
+  // ================= collision (o_collision): the leg's geoms and the lane's share of the trunk geoms; the self-collision test
+  int ncon = 0;
+  {
+    QPairGeoms pg;
+    QUNROLL for (int i = 0; i < kQPairGeom; i++) QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = 0; pg.a[i][k] = 0; }
+    for (int gi = 0; gi < L.ngeom; gi++) {
+      const QuadGeom& g = L.geom[gi];
+      double gp[3], gR[9];
+      const int lk = g.link;
+      double bm[9], bp[3], bv[6];
+      QUNROLL for (int k = 0; k < 9; k++) bm[k] = lk == 0 ? xmat[0][k] : (lk == 1 ? xmat[1][k] : xmat[2][k]);
+      QUNROLL for (int k = 0; k < 3; k++) bp[k] = lk == 0 ? xpos[0][k] : (lk == 1 ? xpos[1][k] : xpos[2][k]);
+      QUNROLL for (int k = 0; k < 6; k++) bv[k] = lk == 0 ? cvel[0][k] : (lk == 1 ? cvel[1][k] : cvel[2][k]);
+      mv3(gp, bm, g.pos);
+      QUNROLL for (int k = 0; k < 3; k++) gp[k] += bp[k];
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = bm[3 * r] * g.rot[c] + bm[3 * r + 1] * g.rot[3 + c] + bm[3 * r + 2] * g.rot[6 + c];
+      if (gi == L.foot_slot) { QUNROLL for (int k = 0; k < 3; k++) out.foot[k] = gp[k]; }
+      QUNROLL for (int i = 0; i < kQPairGeom; i++) {  // (compile-time slots: a run-time index would put the array in scratch)
+        const bool hit = i < L.npg && L.pg_slot[i] == gi;
+        QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = hit ? gp[k] : pg.c[i][k]; pg.a[i][k] = hit ? gR[3 * k + 2] : pg.a[i][k]; }
+      }
+      collide_geom(m, sp, g, &tab.leg[leg][0][gi], kQLegGeom, com, bv, lk + 1, gp, gR, cs, ncon, flags);
+    }
+    for (int gi = leg; gi < m.ntrunk_geom; gi += kQLegs) {
+      const QuadGeom& g = m.trunk_geom[gi];
+      double gp[3], gR[9];
+      mv3(gp, txm, g.pos);
+      QUNROLL for (int k = 0; k < 3; k++) gp[k] += txpos[k];
+      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
+      collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, com, cvelT, 0, gp, gR, cs, ncon, flags);
+    }
+    QPROF(pf, 2);
+    int pmask = 0, nrel = 0;
+#ifndef QEXP_NOPAIRS
+    pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, cs, ncon, flags, pmask, nrel, pf);
+#endif
+    D.ncon = ncon;
+    // bit x of pmask: some leg A touches leg A xor x. One bit set (the common case of self-collision) means disjoint pairs, which the
+    // arrowhead factorisation takes as super-legs; two or three (a leg touching two others) go through the dense elimination of the
+    // leg blocks (newton_direction_general)
+    D.pmask = qd_or(pmask);
+    D.have_rel = qd_or(nrel > 0 ? 1 : 0);
+    QPROF(pf, 3);
   }
   // ================= constraint rows of the lane: friction loss, joint limits (o_make_constraint_full); contacts are in the store
   QRows& R = D.R;
@@ -2059,27 +2062,29 @@ QD double residual_cost(const QuadModel& m, const QTask& tk, const QStaticPose* 
   R[10] = th[1] - sin(heading_goal);
   QUNROLL for (int k = 0; k < 3; k++) R[11 + k] = f.comvel[k];
   // ---- cost: terms Upright(3) Height(1) Position(3) Gait(4) Balance(2) Effort(12) Posture(12) Yaw(2) Angmom(3)
-  auto term_shared = [&](int term, const double* x, int cnt) {
-    double c = 0;
-    for (int i = 0; i < cnt; i++) c += norm_elem(x[i], m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
-    return tk.weight[term] * norm_finish(c, m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+  // (the entries by value, at most three per term: a pointer + run-time count would index the residual at run time and put it in scratch)
+  auto term_sum = [&](int term, int cnt, double x0, double x1, double x2) {
+    double c = norm_elem(x0, m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+    if (cnt > 1) c += norm_elem(x1, m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+    if (cnt > 2) c += norm_elem(x2, m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+    return c;
   };
-  auto term_dealt = [&](int term, const double* x, int cnt) {
-    double c = 0;
-    for (int i = 0; i < cnt; i++) c += norm_elem(x[i], m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
-    c = qd_sum(c);
-    return tk.weight[term] * norm_finish(c, m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+  auto term_shared = [&](int term, int cnt, double x0, double x1, double x2) {
+    return tk.weight[term] * norm_finish(term_sum(term, cnt, x0, x1, x2), m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
+  };
+  auto term_dealt = [&](int term, int cnt, double x0, double x1, double x2) {
+    return tk.weight[term] * norm_finish(qd_sum(term_sum(term, cnt, x0, x1, x2)), m.term_norm[term], tk.norm_p[term], tk.norm_q[term]);
   };
   double cost = 0;
-  cost += term_shared(0, R + 0, 3);
-  cost += term_shared(1, R + 3, 1);
-  cost += term_shared(2, R + 4, 3);
-  cost += term_dealt(3, &r.gait, 1);
-  cost += term_shared(4, R + 7, 2);
-  cost += term_dealt(5, r.effort, 3);
-  cost += term_dealt(6, r.posture, 3);
-  cost += term_shared(7, R + 9, 2);
-  cost += term_shared(8, R + 11, 3);
+  cost += term_shared(0, 3, R[0], R[1], R[2]);
+  cost += term_shared(1, 1, R[3], 0, 0);
+  cost += term_shared(2, 3, R[4], R[5], R[6]);
+  cost += term_dealt(3, 1, r.gait, 0, 0);
+  cost += term_shared(4, 2, R[7], R[8], 0);
+  cost += term_dealt(5, 3, r.effort[0], r.effort[1], r.effort[2]);
+  cost += term_dealt(6, 3, r.posture[0], r.posture[1], r.posture[2]);
+  cost += term_shared(7, 2, R[9], R[10], 0);
+  cost += term_shared(8, 3, R[11], R[12], R[13]);
   if (!(fabs(tk.risk) < 1.0e-6)) cost = (exp(tk.risk * cost) - 1.0) / tk.risk;
   return cost;
 }
@@ -2145,7 +2150,7 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
             const double sd = sqrt(a.param_variance[j]);
             sigma = sd > fl ? sd : fl;
           }
-          v = clampd(v + sigma * z[j & 1], lo, hi);
+          v = clampd(v + sigma * ((j & 1) ? z[1] : z[0]), lo, hi);
         }
         a.nodes[(size_t)j * N + cand] = v;
       }
@@ -2224,7 +2229,7 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
       QREC(rs[7 + L.foot_index], r.gait);
       QUNROLL for (int j = 0; j < 3; j++) { QREC(rs[13 + 3 * leg + j], r.effort[j]); QREC(rs[25 + 3 * leg + j], r.posture[j]); }
       if (leg == 0) { QREC(a.times[(size_t)cand * H + t], S.time); QREC(a.costs[(size_t)cand * H + t], cost); }
-      if (leg == 1) for (int q = 0; q < m.ntrace; q++) QUNROLL for (int k = 0; k < 3; k++) QREC(a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k], f.trace[q][k]);
+      if (leg == 1) { QUNROLL for (int q = 0; q < kQMaxTrace; q++) if (q < m.ntrace) QUNROLL for (int k = 0; k < 3; k++) QREC(a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k], f.trace[q][k]); }
     }
     total += cost;
     if (a.con_cap > 0 && qd_or(D.ncon > a.con_cap ? 1 : 0)) { flags = kFlagOverflow; break; }
@@ -2235,6 +2240,8 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     // one pair pattern of legs in contact (or none): the super-leg solver; a leg touching two others (rare): the general one -- for
     // every candidate of the wavefront then (it covers the other cases too, and the wavefront runs one solver instead of both in turn)
     const bool wave_general = qw_any(((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom);
+    // (the solver's inputs are handed over as pointers into S and D, which pins those two structs in memory -- measured the better
+    // trade: copying them into a block of their own so that S and D stay in registers costs 2 ms of 57 in register pressure)
     if (wave_general)
       flags = constraint_newton<true>(m, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     else
