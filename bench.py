@@ -208,7 +208,7 @@ class ClockSampler:
         import ctypes
         import glob
         # the HIP device's PCI address names its sysfs node (a node shows every GPU of the box, whatever this process may use)
-        self.freq = self.power = self.pci = None
+        self.freq = self.power = self.pci = self.mfreq = None
         try:
             hip = ctypes.CDLL("libamdhip64.so")
             buf = ctypes.create_string_buffer(64)
@@ -223,11 +223,15 @@ class ClockSampler:
                 f = os.path.join(h, "freq1_input")
                 if os.path.exists(f):
                     self.freq = f
+                f2 = os.path.join(h, "freq2_input")     # (mclk: the boxes of the pool differ by up to 35 % on the same build; memory-side state is the suspect)
+                if os.path.exists(f2):
+                    self.mfreq = f2
                 for name in ("power1_average", "power1_input"):
                     q = os.path.join(h, name)
                     if self.power is None and os.path.exists(q):
                         self.power = q
         self.samples = []
+        self.msamples = []
         self._stop = False
         self._thread = None
 
@@ -241,6 +245,8 @@ class ClockSampler:
     def _run(self):
         while not self._stop:
             self.samples.append((self._read(self.freq) if self.freq else None, self._read(self.power) if self.power else None))
+            if self.mfreq:
+                self.msamples.append(self._read(self.mfreq))
             time.sleep(0.1)
 
     def __enter__(self):
@@ -265,6 +271,9 @@ class ClockSampler:
             out.update({"sclk_mhz_min": min(f), "sclk_mhz_mean": sum(f) / len(f), "sclk_mhz_max": max(f)})
         if p:
             out.update({"power_w_mean": sum(p) / len(p), "power_w_max": max(p)})
+        mm = [x * 1e-6 for x in self.msamples if x]
+        if mm:
+            out["mclk_mhz_mean"] = sum(mm) / len(mm)
         return out
 
 

@@ -44,7 +44,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mjpcx_lds[];
   X(R, geom_size, 3 * C::NG) X(R, geom_pos, 3 * C::NG) X(R, geom_quat, 4 * C::NG) X(R, geom_margin, C::NG)                       \
   X(R, key_qpos, C::NKEY * C::NQ)                                                                                               \
   X(L, body_subtree_mask, C::NB) X(U, body_dofmask, C::NB)                                                                       \
-  X(I, level_body, C::NB) X(I, static_geom, C::NSG) X(I, dynamic_geom, C::NDG) X(I, ray_geom, C::NRAY)                           \
+  X(I, level_body, C::NB) X(I, level_start, kWaveMaxLevel + 1) X(I, static_geom, C::NSG) X(I, dynamic_geom, C::NDG) X(I, ray_geom, C::NRAY) \
   X(I, task_dim_norm_residual, C::NTERM) X(I, task_norm, C::NTERM) X(I, task_trace_site, C::NTRACE) X(I, task_term_off, C::NTERM) \
   X(I, task_res_term, C::NR)
 
@@ -105,7 +105,8 @@ struct LdsModelT {
   // run-time scalars
   int cone, disableflags, solver_iterations, any_damping, nlevel, npair, full;
   double timestep, gravity[3], solver_tolerance, meaninertia, impratio;
-  int level_start[kWaveMaxLevel + 1];
+  // (level_start is an array of the image: as a member it would be indexed at run time, and an aggregate indexed at run time lives in
+  // scratch -- the whole struct with it, every scalar and pointer below a scratch load)
   // cold arrays (global memory)
   const T *geom_friction, *geom_solref, *geom_solimp, *geom_gap, *geom_solmix, *key_mpos;
   const int *pair_g1, *pair_g2;
@@ -122,7 +123,6 @@ struct LdsModelT {
         wrap_objid(m.wrap_objid), wrap_prm(m.wrap_prm), tendon_range(m.tendon_range), tendon_margin(m.tendon_margin), tendon_solref_lim(m.tendon_solref_lim),
         tendon_solimp_lim(m.tendon_solimp_lim), tendon_invweight0(m.tendon_invweight0), tendon_dofmask(m.tendon_dofmask) {
     for (int k = 0; k < 3; k++) gravity[k] = m.gravity[k];
-    for (int k = 0; k <= kWaveMaxLevel; k++) level_start[k] = m.level_start[k];
   }
 };
 
@@ -186,6 +186,7 @@ inline std::vector<unsigned char> lds_model_image(const mjpcx_model* src, const 
   std::memcpy(img.data() + L::offset(kLdsF_body_subtree_mask), wh.h_subtree_mask.data(), wh.h_subtree_mask.size() * 8);
   std::memcpy(img.data() + L::offset(kLdsF_body_dofmask), wh.h_dofmask.data(), wh.h_dofmask.size() * 4);
   put_i(kLdsF_level_body, wh.h_level_body.data(), wh.h_level_body.size());
+  put_i(kLdsF_level_start, wh.m.level_start, (size_t)kWaveMaxLevel + 1);
   put_i(kLdsF_static_geom, wh.h_static_geom.data(), wh.h_static_geom.size());
   put_i(kLdsF_dynamic_geom, wh.h_dynamic_geom.data(), wh.h_dynamic_geom.size());
   put_i(kLdsF_ray_geom, wh.h_ray_geom.data(), wh.h_ray_geom.size());

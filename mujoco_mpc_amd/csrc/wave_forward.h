@@ -237,7 +237,11 @@ __device__ __forceinline__ void wf_smooth_forces(const MODEL& m, WaveData& d, in
   }
   // RNE forward: cacc level by level, cfrc per body
   if (lane < 6) {
-    d.cacc[lane] = (lane >= 3 && !(m.disableflags & MJPCX_DSBL_GRAVITY)) ? -m.gravity[lane - 3] : WL(0.0);
+    // (0 / 1 weights over the three components: `m.gravity[lane - 3]` indexes a member of the model struct at run time, which puts the
+    // whole struct -- every scalar and pointer of a registered model -- in scratch)
+    const wreal gl = (lane == 3 ? WL(1.0) : WL(0.0)) * (wreal)m.gravity[0] + (lane == 4 ? WL(1.0) : WL(0.0)) * (wreal)m.gravity[1] +
+                     (lane == 5 ? WL(1.0) : WL(0.0)) * (wreal)m.gravity[2];
+    d.cacc[lane] = (lane >= 3 && !(m.disableflags & MJPCX_DSBL_GRAVITY)) ? -gl : WL(0.0);
     d.cfrc[lane] = 0;
   }
   WSYNC();
