@@ -176,3 +176,27 @@ def test_random_states_against_the_oracle():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_quad.py"), "60", "7"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "60 cases x 32 candidates" in out.stdout.splitlines()[-1]
+
+
+def test_results_do_not_depend_on_the_candidates_per_wavefront(quad):
+    """The launch deals 1, 2, 4, 8 or 16 candidates to a wavefront (small batches spread over every SIMD: quad_kernel.hip); a candidate's
+    rollout is its own four lanes' work whatever the others in the wavefront do, so returns, failure flags and a whole trajectory are
+    bit-identical across the five shapes -- and with them across world sizes that leave a rank different batch sizes."""
+    N, H, P = 200, 60, 3
+    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+    nominal = np.clip(np.random.default_rng(4).normal(0, 0.05, (P, 12)), -1, 1)
+    ns = capi.make_noise_spec(seed=5, iteration=1, mode=capi.NOISE_SAMPLING, std0=0.1)
+    ref = None
+    for cpw in (16, 8, 4, 2, 1):
+        ctx = context(quad, {"MJPCX_QUAD_CPW": str(cpw)})
+        ctx.rollout_noise(N, H, 0, times, nominal, ns)
+        ret, fail = ctx.returns()
+        tr = ctx.fetch_trajectory(137)
+        got = (ret.copy(), fail.copy(), tr.states.copy(), tr.residual.copy(), tr.costs.copy())
+        ctx.close()
+        if ref is None:
+            ref = got
+            assert np.all(np.isfinite(ret)) and not fail.any()
+        else:
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b), cpw
