@@ -43,8 +43,11 @@ enum {
 /* ---- enums shared with the reference ------------------------------------ */
 /* mjtJoint (MuJoCo) */
 enum { MJPCX_JNT_FREE = 0, MJPCX_JNT_BALL = 1, MJPCX_JNT_SLIDE = 2, MJPCX_JNT_HINGE = 3 };
-/* mjtIntegrator (MuJoCo): only Euler (with implicit joint damping) and RK4 */
-enum { MJPCX_INT_EULER = 0, MJPCX_INT_RK4 = 1 };
+/* mjtIntegrator (MuJoCo). Euler (with implicit joint damping) and RK4 are integrated as such. IMPLICITFAST is accepted for models whose
+ * only velocity-dependent smooth force is joint damping (no actuator with a velocity term in its bias, which is all this ABI carries
+ * besides damping): there MuJoCo's M - h dqfrc_smooth/dqvel is M + h diag(damping), i.e. mj_implicit's update IS mj_Euler's -- the
+ * context integrates with the Euler path. IMPLICIT (Coriolis derivatives) and other IMPLICITFAST models are refused by mjpcx_create. */
+enum { MJPCX_INT_EULER = 0, MJPCX_INT_RK4 = 1, MJPCX_INT_IMPLICIT = 2, MJPCX_INT_IMPLICITFAST = 3 };
 /* mjpc::spline::SplineInterpolation, mjpc/spline/spline.h:29-33 */
 enum { MJPCX_SPLINE_ZERO = 0, MJPCX_SPLINE_LINEAR = 1, MJPCX_SPLINE_CUBIC = 2 };
 /* mjpc::NormType, mjpc/norm.h:24-35 */

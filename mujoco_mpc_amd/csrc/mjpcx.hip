@@ -910,8 +910,20 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
   if (precision != 64 && precision != 32) return bad(MJPCX_EINVAL, "precision must be 64 or 32");
   // ---- features the device kernels cover today
   if (m->na != 0) return bad(MJPCX_EUNSUPPORTED, "actuator activations (na > 0) unsupported");
+  mjpcx_model m_euler;
+  if (m->integrator == MJPCX_INT_IMPLICITFAST) {
+    // mj_implicit with qDeriv = d qfrc_smooth / d qvel restricted to passive damping + actuator velocity terms: without the latter the
+    // matrix is M + h diag(damping), mj_Euler's own (include/mjpcx.h). The context then runs the Euler path on a copy of the header.
+    for (int i = 0; i < m->nu; i++)
+      if (m->actuator_biasprm && m->actuator_biasprm[3 * i + 2] != 0)
+        return bad(MJPCX_EUNSUPPORTED, "implicitfast with a velocity-dependent actuator (biasprm[2] != 0): only models whose velocity-dependent smooth force "
+                                       "is joint damping are integrated (as mj_Euler, which is the same update there)");
+    m_euler = *m;
+    m_euler.integrator = MJPCX_INT_EULER;
+    m = &m_euler;
+  }
   if (m->integrator != MJPCX_INT_EULER && m->integrator != MJPCX_INT_RK4)
-    return bad(MJPCX_EUNSUPPORTED, "integrators: Euler and RK4 (implicit / implicitfast are not implemented)");
+    return bad(MJPCX_EUNSUPPORTED, "integrators: Euler, RK4 and (damping-only models) implicitfast; implicit is not implemented");
   // ---- wavefront-per-candidate family: free/ball joints, friction loss, contacts
   bool needs_wave = false;
   for (int j = 0; j < m->njnt; j++) needs_wave |= m->jnt_type[j] == MJPCX_JNT_FREE || m->jnt_type[j] == MJPCX_JNT_BALL;

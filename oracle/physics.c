@@ -189,7 +189,13 @@ OData* odata_new(const mjpcx_model* m) {
   for (int j = 0; j < m->njnt; j++)
     if (m->jnt_limited[j] && (m->jnt_type[j] == MJPCX_JNT_BALL || m->jnt_type[j] == MJPCX_JNT_FREE))
       return NULL;
-  if ((m->integrator != MJPCX_INT_EULER && m->integrator != MJPCX_INT_RK4) || m->na != 0) return NULL;
+  if (m->integrator == MJPCX_INT_IMPLICITFAST) {
+    /* mj_implicit's matrix M - h dqfrc_smooth/dqvel is mj_Euler's M + h diag(damping) when no actuator force depends on velocity
+     * (include/mjpcx.h): such a model steps through o_euler; any other is rejected */
+    for (int i = 0; i < m->nu; i++)
+      if (m->actuator_biasprm && m->actuator_biasprm[3 * i + 2] != 0) return NULL;
+  } else if (m->integrator != MJPCX_INT_EULER && m->integrator != MJPCX_INT_RK4) return NULL;
+  if (m->na != 0) return NULL;
 
   OData* d = (OData*)calloc(1, sizeof(OData));
   d->m = m;

@@ -385,3 +385,34 @@ def test_rk4_integrator_on_the_lane_kernels(cartpole, particle, N, H, interp):
     pm = particle.packed_model(); pm.struct.integrator = 1
     mocap = [0.2, -0.1, 0.01, 1, 0, 0, 0]
     compare_batch(particle, [0.05, -0.1, 0.3, 0.2], 0.0, mocap, N, H, P, interp, np.arange(P) * 0.1 * max(H - 1, 1) / (P - 1) , random_nodes(N, N, P, 2), pm=pm)
+
+
+def test_implicitfast_is_the_euler_update_on_damping_only_models(cartpole):
+    """<option integrator="implicitfast"> (mjpc tasks that ask for it through agent_integrator): for a model whose only velocity-dependent
+    smooth force is joint damping, MuJoCo's M - h dqfrc_smooth/dqvel is M + h diag(damping) -- mj_implicit's update is mj_Euler's. The
+    context accepts such a model and its rollouts are bit-identical to the Euler context's; with a velocity term in an actuator's bias
+    (position actuator with kv) it is refused, as plain `implicit` is."""
+    N, H, P = 64, 32, 4
+    times = np.arange(P) * 0.01 * (H - 1) / (P - 1)
+    nodes = random_nodes(3, N, P, 1)
+    state = [0.3, 2.7, -0.4, 0.9]
+    rets = []
+    for integ in (0, 3):
+        pm = cartpole.packed_model(); pm.struct.integrator = integ
+        ctx = capi.Context(pm, cartpole.packed(), 0, 64)
+        ctx.set_state(np.asarray(state, float), 0.0)
+        ctx.rollout_splines(H, 2, times, nodes)
+        rets.append(ctx.returns()[0].copy())
+        ctx.close()
+        ref = pyoracle.rollout_batch(pm, cartpole.packed(), state, 0.0, None, N, H, P, 2, times, nodes, num_threads=4)
+        assert close(rets[-1], ref["total_return"], 1e-9)
+    assert np.array_equal(rets[0], rets[1])
+    pm = cartpole.packed_model(); pm.struct.integrator = 2
+    with pytest.raises(capi.MjpcxError):
+        capi.Context(pm, cartpole.packed(), 0, 64)
+    pm = cartpole.packed_model(); pm.struct.integrator = 3
+    bias = np.ctypeslib.as_array(pm.struct.actuator_biasprm, (3 * cartpole.model.nu,))
+    bias[2] = -0.5
+    with pytest.raises(capi.MjpcxError) as err:
+        capi.Context(pm, cartpole.packed(), 0, 64)
+    assert "velocity-dependent actuator" in str(err.value)

@@ -142,3 +142,28 @@ def test_unsupported_features_are_rejected():
       <geom type="sphere" size="0.1"/></body></worldbody></mujoco>""")
     with pytest.raises(NotImplementedError):
         pyoracle.Physics(PackedModel(fm))
+
+
+def test_implicitfast_steps_like_euler_on_a_damping_only_model_and_is_refused_otherwise():
+    """include/mjpcx.h: MJPCX_INT_IMPLICITFAST is accepted where MuJoCo's implicit-in-velocity update equals mj_Euler's (joint damping is
+    the only velocity-dependent smooth force); an actuator with a velocity term in its bias, or MJPCX_INT_IMPLICIT, is rejected"""
+    import numpy as np
+    from mujoco_mpc_amd.task import load_task
+    from oracle import pyoracle
+    t = load_task("Cartpole")
+    N, H, P = 3, 12, 3
+    times = np.arange(P) * 0.01 * (H - 1) / (P - 1)
+    nodes = np.random.default_rng(0).normal(0, 0.3, (N, P, 1))
+    out = []
+    for integ in (0, 3):
+        pm = t.packed_model(); pm.struct.integrator = integ
+        out.append(pyoracle.rollout_batch(pm, t.packed(), [0.3, 2.7, -0.4, 0.9], 0.0, None, N, H, P, 2, times, nodes, num_threads=1))
+    assert np.array_equal(out[0]["states"], out[1]["states"]) and np.array_equal(out[0]["total_return"], out[1]["total_return"])
+    for integ, kv in ((2, 0.0), (3, -0.5)):
+        pm = t.packed_model(); pm.struct.integrator = integ
+        np.ctypeslib.as_array(pm.struct.actuator_biasprm, (3 * t.model.nu,))[2] = kv
+        try:
+            pyoracle.Physics(pm)
+        except NotImplementedError:
+            continue
+        raise AssertionError("accepted")
