@@ -230,6 +230,11 @@ class ClockSampler:
                     q = os.path.join(h, name)
                     if self.power is None and os.path.exists(q):
                         self.power = q
+        self.dpm = {}     # fabric / SoC clock levels (pp_dpm_fclk, pp_dpm_socclk: the line marked '*'), read when the sampling stops
+        self._card = None
+        for card in glob.glob("/sys/class/drm/card[0-9]*/device"):
+            if self.pci is not None and os.path.basename(os.path.realpath(card)).lower() == self.pci:
+                self._card = card
         self.samples = []
         self.msamples = []
         self._stop = False
@@ -257,6 +262,14 @@ class ClockSampler:
         return self
 
     def __exit__(self, *exc):
+        if self._card:
+            for name in ("pp_dpm_fclk", "pp_dpm_socclk"):
+                try:
+                    for line in open(os.path.join(self._card, name)):
+                        if "*" in line:
+                            self.dpm[name[7:] + "_mhz"] = float("".join(ch for ch in line.split(":")[1] if ch.isdigit() or ch == "."))
+                except (OSError, ValueError, IndexError):
+                    pass
         self._stop = True
         if self._thread is not None:
             self._thread.join(timeout=1.0)
@@ -274,6 +287,7 @@ class ClockSampler:
         mm = [x * 1e-6 for x in self.msamples if x]
         if mm:
             out["mclk_mhz_mean"] = sum(mm) / len(mm)
+        out.update(self.dpm)
         return out
 
 
