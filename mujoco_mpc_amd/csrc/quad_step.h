@@ -548,8 +548,10 @@ constexpr int kQLineSlots = 4;
 #define QGENERAL_FROM 2  // (tests build the emulator with 1: single pairs through the dense elimination as well)
 #endif
 constexpr int kQGeneralFrom = QGENERAL_FROM;
-struct QLine { double jn0, vn, A, B, C, D0, mu, Dq, Dm; };
-QD void line_empty(QLine& q) { q.jn0 = 1; q.vn = 0; q.A = 0; q.B = 0; q.C = 0; q.D0 = 0; q.mu = 1; q.Dq = 0; q.Dm = 0; }  // (top zone at every alpha)
+// (what a trial needs of a contact, products of the direction-only factors taken once per line search: D0vn = D0 vn, muvn = mu vn,
+// hb = D0 vn^2 + Dq C, the bottom zone's second derivative, which does not depend on alpha)
+struct QLine { double jn0, vn, A, B, C, mu, Dq, Dm, D0vn, muvn, hb; };
+QD void line_empty(QLine& q) { q.jn0 = 1; q.vn = 0; q.A = 0; q.B = 0; q.C = 0; q.mu = 1; q.Dq = 0; q.Dm = 0; q.D0vn = 0; q.muvn = 0; q.hb = 0; }  // (top zone at every alpha)
 QD void line_coeffs(const QContact& c, const double* fr, const double* jv, double w, QLine& q) {
   const double* n = c.n;
   const double jn = dot3(n, c.jar + 3), an = dot3(n, c.jar), vn = dot3(n, jv + 3), wn = dot3(n, jv);
@@ -560,23 +562,27 @@ QD void line_coeffs(const QContact& c, const double* fr, const double* jv, doubl
   q.A = f1s * dot3(tl, tl) + f3s * an * an + f4s * dot3(ar, ar);
   q.B = f1s * dot3(tl, jv + 3) + f3s * an * wn + f4s * dot3(ar, jv);
   q.C = f1s * (dot3(jv + 3, jv + 3) - vn * vn) + f3s * wn * wn + f4s * (dot3(jv, jv) - wn * wn);
-  q.D0 = w * c.D0; q.mu = fr[0]; q.Dq = q.D0 * fr[4]; q.Dm = q.D0 * fr[5];
+  const double D0 = w * c.D0;
+  q.mu = fr[0]; q.Dq = D0 * fr[4]; q.Dm = D0 * fr[5];
+  q.D0vn = D0 * vn; q.muvn = q.mu * vn; q.hb = q.D0vn * vn + q.Dq * q.C;
 }
-// (no branches: the slots of a lane are independent chains the scheduler can interleave -- with one wavefront per SIMD nothing else hides
-// the latency of dependent fp64 instructions -- and the three zones differ by a handful of flops)
+// One trial of one slot: about 35 fp64 operations and a dozen selects (this loop is two thirds of the kernel's instructions: a wavefront
+// runs ~12 trials in each of ~10 Newton iterations per step). No branches: the slots of a lane are independent chains the scheduler can
+// interleave, and the three zones differ by a handful of flops. Where T^2 is not positive (the cone's axis) the root and its reciprocal
+// are garbage and are replaced by zeros, which makes the zone tests those of the sign of N alone.
 QD void line_eval(const QLine& q, double alpha, double& g, double& h) {
-  const double mu = q.mu, jn = q.jn0 + alpha * q.vn, T2 = q.A + alpha * (2 * q.B + alpha * q.C);
-  const bool pos = T2 > 1e-200;  // (below: the cone's axis, where the zones are told apart by the sign of N alone)
+  const double jn = fma(alpha, q.vn, q.jn0), UV = fma(alpha, q.C, q.B), T2 = fma(alpha, q.B + UV, q.A);  // T^2 = A + 2 B alpha + C alpha^2
+  const bool pos = T2 > 1e-200;
   double Ts, iTs;
-  q_sqrt_rsqrt(pos ? T2 : 1.0, Ts, iTs);
-  const double T = pos ? Ts : 0.0, iT = pos ? iTs : 0.0, N = mu * jn;
-  const bool top = N >= mu * T || (!pos && N >= 0), bottom = mu * N + T <= 0 || (!pos && N < 0);
-  const double UV = q.B + alpha * q.C;
-  const double gb = q.D0 * jn * q.vn + q.Dq * UV, hb = q.D0 * q.vn * q.vn + q.Dq * q.C;
-  const double NT = N - mu * T, dNT = mu * q.vn - mu * UV * iT, d2NT = -mu * (q.C * iT - UV * UV * (iT * iT * iT));
-  const double gm = q.Dm * NT * dNT, hm = q.Dm * (dNT * dNT + NT * d2NT);
+  q_sqrt_rsqrt(T2, Ts, iTs);
+  const double T = pos ? Ts : 0.0, iT = pos ? iTs : 0.0, N = q.mu * jn;
+  const bool top = N >= q.mu * T, bottom = fma(q.mu, N, T) <= 0;
+  const double gb = fma(q.D0vn, jn, q.Dq * UV);
+  const double NT = fma(-q.mu, T, N), u = UV * iT, dNT = fma(-q.mu, u, q.muvn);
+  const double d2NT = -(q.mu * iT) * fma(-u, u, q.C);  // -mu (C / T - UV^2 / T^3)
+  const double gm = q.Dm * NT * dNT, hm = q.Dm * fma(NT, d2NT, dNT * dNT);
   g += top ? 0.0 : (bottom ? gb : gm);
-  h += top ? 0.0 : (bottom ? hb : hm);
+  h += top ? 0.0 : (bottom ? q.hb : hm);
 }
 
 // ---------------------------------------------------------------- constraint solve (oracle o_constraint_newton)
@@ -711,23 +717,40 @@ QD void rows_line_prepare(const QuadModel& m, CS& cs, int ncon, const double Vp[
     if (MULTI) x = next_x(pmask, x);
   }
 }
-// the lane's friction-loss parameters, read from the model once per line search
-struct QDiag { double fl[3], flR[3], flD[3]; };
+// the lane's diagonal rows along the search direction, prepared once per line search: friction loss (x0 = jar, jv = the dof's component of
+// the direction; Rfl = R fl, fljv = fl jv, Djv = D jv, Djv2 = D jv^2; a dof without friction loss: Rfl = inf, the rest 0) and the active
+// joint limit (lx0, ljv = -side component; lDjv, lDjv2 zero when no limit is active)
+struct QDiag { double x0[3], jv[3], Rfl[3], fljv[3], Djv[3], Djv2[3], lx0[3], ljv[3], lDjv[3], lDjv2[3]; };
+QD void diag_prepare(const QuadLeg& L, const QRows& R, const double* xl, QDiag& dg) {
+  QUNROLL for (int j = 0; j < 3; j++) {
+    const double fl = L.floss[j], jv = xl[j];
+    const bool on = fl > 0;
+    dg.x0[j] = R.fl_jar[j]; dg.jv[j] = jv;
+    dg.Rfl[j] = on ? L.floss_R[j] * fl : 1e300;
+    dg.fljv[j] = on ? fl * jv : 0.0;
+    dg.Djv[j] = on ? L.floss_D[j] * jv : 0.0;
+    dg.Djv2[j] = on ? L.floss_D[j] * jv * jv : 0.0;
+    const double lj = -R.lm_side[j] * xl[j];
+    dg.lx0[j] = R.lm_jar[j]; dg.ljv[j] = lj;
+    dg.lDjv[j] = R.lm_side[j] != 0 ? R.lm_D[j] * lj : 0.0;
+    dg.lDjv2[j] = R.lm_side[j] != 0 ? R.lm_D[j] * lj * lj : 0.0;
+  }
+}
 template <bool MULTI, bool BEYOND, class CS>
-QD void rows_line(const QuadModel& m, const QDiag& dg, const QRows& R, CS& cs, int ncon, double alpha, const double* xl, const double Vp[4][6], int pmask,
+QD void rows_line(const QuadModel& m, const QDiag& dg, bool any_limit, CS& cs, int ncon, double alpha, const double Vp[4][6], int pmask,
                   bool beyond_slots, int nslot_wave, const QRel& rq, const QLine* ql, double& d1, double& d2) {
   double g = 0, h = 0;
   QUNROLL for (int j = 0; j < 3; j++) {
-    {
-      const double jv = xl[j], x = R.fl_jar[j] + alpha * jv, fl = dg.fl[j], Rr = dg.flR[j], D = dg.flD[j];
-      const bool on = fl > 0, low = x <= -Rr * fl, high = x >= Rr * fl;
-      const double gq = low ? -fl * jv : (high ? fl * jv : D * x * jv), hq = (low || high) ? 0.0 : D * jv * jv;
-      g += on ? gq : 0.0; h += on ? hq : 0.0;
-    }
-    {
-      const double jv = -R.lm_side[j] * xl[j], x = R.lm_jar[j] + alpha * jv;
-      const bool on = R.lm_side[j] != 0 && x < 0;
-      g += on ? R.lm_D[j] * x * jv : 0.0; h += on ? R.lm_D[j] * jv * jv : 0.0;
+    const double x = fma(alpha, dg.jv[j], dg.x0[j]);
+    const bool low = x <= -dg.Rfl[j], high = x >= dg.Rfl[j];
+    g += low ? -dg.fljv[j] : (high ? dg.fljv[j] : dg.Djv[j] * x);
+    h += (low || high) ? 0.0 : dg.Djv2[j];
+  }
+  if (any_limit) {  // (wavefront-uniform: joint limits are rarely active)
+    QUNROLL for (int j = 0; j < 3; j++) {
+      const double x = fma(alpha, dg.ljv[j], dg.lx0[j]);
+      const bool on = x < 0;
+      g += on ? dg.lDjv[j] * x : 0.0; h += on ? dg.lDjv2[j] : 0.0;
     }
   }
   // (slots no lane of the wavefront fills are skipped by a scalar branch: an empty slot adds exactly zero)
@@ -783,7 +806,8 @@ QLS_ATTR double line_search(const QuadModel& m_in, int leg, const QRows R, CS cs
     QUNROLL for (int d = 0; d < 4; d++) QUNROLL for (int k = 0; k < 6; k++) Vs[d][k] = vp[6 * d + k];
   }
   QDiag dg;
-  QUNROLL for (int j = 0; j < 3; j++) { dg.fl[j] = L.floss[j]; dg.flR[j] = L.floss_R[j]; dg.flD[j] = L.floss_D[j]; }
+  diag_prepare(L, R, hl, dg);
+  const bool any_limit = qw_any(R.lm_side[0] != 0 || R.lm_side[1] != 0 || R.lm_side[2] != 0);
   QLine ql[kQLineSlots];
   QRel rq;
   QPROF(pf, 40);
@@ -792,7 +816,7 @@ QLS_ATTR double line_search(const QuadModel& m_in, int leg, const QRows R, CS cs
   const int nslot_wave = qw_max(ncon < kQLineSlots ? ncon : kQLineSlots);
   QPROF(pf, 41);
   double lo = 0, hi = -1, alpha = 0, d1, d2;
-  rows_line<MULTI, BEYOND>(m, dg, R, cs, ncon, 0.0, hl, Vs, pmask, beyond, nslot_wave, rq, ql, d1, d2);
+  rows_line<MULTI, BEYOND>(m, dg, any_limit, cs, ncon, 0.0, Vs, pmask, beyond, nslot_wave, rq, ql, d1, d2);
   d1 += q1; d2 += q2;
   const double d10 = fabs(d1);
   double step1 = 1e300, step2 = 1e300;  // the last step and the one before (rtsafe safeguard, oracle/contact.inc)
@@ -808,7 +832,7 @@ QLS_ATTR double line_search(const QuadModel& m_in, int leg, const QRows R, CS cs
     if (an == alpha) break;
     step2 = step1; step1 = fabs(an - alpha);
     alpha = an;
-    rows_line<MULTI, BEYOND>(m, dg, R, cs, ncon, alpha, hl, Vs, pmask, beyond, nslot_wave, rq, ql, d1, d2);
+    rows_line<MULTI, BEYOND>(m, dg, any_limit, cs, ncon, alpha, Vs, pmask, beyond, nslot_wave, rq, ql, d1, d2);
     d1 += q1 + alpha * q2; d2 += q2;
     if (fabs(d1) < gtol) break;
     if (d1 < 0) lo = alpha; else hi = alpha;
