@@ -372,6 +372,7 @@ struct mjpcx_ctx {
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
   int quad_ids[7] = {0, 0, 0, 0, 0, 0, 0};  // residual_int[1..7] the quad model was built for (torso, head site, goal mocap, feet)
   DevBuf d_qmodel, d_qtab, d_qstats, d_qstamps, d_qwave;
+  void* h_qstats = nullptr;       // pinned copy of d_qstats (whether the hand-on pass has anything to do)
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -672,6 +673,16 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
                  (double)h[26] / (64.0 * a.H), (double)h[36] / (64.0 * a.H), (double)h[37] / a.H);
   }
   if (c->quad_no_fallback) return hipSuccess;
+  // the pass over the candidates the quad kernel handed on is 16384 wavefronts that each find their candidate unflagged (0.24 ms) when
+  // nothing was handed on -- the usual case: the count comes back first (32 bytes, one synchronisation the plan step pays anyway a moment later)
+  if (!c->quad_stats) {
+    if (!c->h_qstats && hipHostMalloc(&c->h_qstats, 32, hipHostMallocDefault) != hipSuccess) c->h_qstats = nullptr;
+    if (c->h_qstats) {
+      if ((e = hipMemcpyAsync(c->h_qstats, c->d_qstats.p, 32, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+      if (static_cast<const int*>(c->h_qstats)[0] == 0) return hipSuccess;
+    }
+  }
   RolloutArgs<double> a2 = a;
   a2.noise.mode = -1;  // the quad kernel left every candidate's spline nodes in a.nodes
   e = launch_tree<TreeCfgA1, double>(c, wm, wt, a2, c->wh.dev_image, c->wh.blob_bytes, N, P, /*only_flagged=*/true);
@@ -1136,6 +1147,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
     sl.dev.release();
   }
   if (c->best_host) (void)hipHostFree(c->best_host);
+  if (c->h_qstats) (void)hipHostFree(c->h_qstats);
   (void)mjpcx_comm_destroy(c);
   c->wh.release();
   DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_qmodel, &c->d_qtab, &c->d_qstats, &c->d_qstamps, &c->d_qwave, &c->d_comm_send, &c->d_comm_recv,
