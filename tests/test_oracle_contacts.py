@@ -42,6 +42,41 @@ def test_resting_contacts_carry_the_weight():
     assert ph.get("solver_iter")[0] <= 6
 
 
+def _resting_depth(share, g=9.81, solref=(0.02, 1.0), solimp=(0.9, 0.95, 0.001, 0.5, 2.0)):
+    """Penetration at which a soft contact carries `share` of a free body's weight, from MuJoCo's published constraint model alone
+    (no oracle code): at rest J qacc = 0, so f = aref / R with aref = -k d(r) r, R = (1 - d) / d * (1 / m) and f = share * m g, i.e.
+    k d(r)^2 |r| = (1 - d(r)) g share; k = 1 / (dmax^2 timeconst^2 dampratio^2); d(r) the solimp sigmoid (power p, midpoint)."""
+    d0, dmax, width, mid, p = solimp
+    k = 1.0 / (dmax * dmax * solref[0] ** 2 * solref[1] ** 2)
+
+    def imp(r):
+        x = abs(r) / width
+        if x >= 1:
+            return dmax
+        y = x ** p / mid ** (p - 1) if x <= mid else 1 - (1 - x) ** p / (1 - mid) ** (p - 1)
+        return d0 + y * (dmax - d0)
+
+    lo, hi = 0.0, 10 * width
+    for _ in range(200):
+        r = 0.5 * (lo + hi)
+        d = imp(r)
+        lo, hi = (r, hi) if k * d * d * r < (1 - d) * g * share else (lo, r)
+    return 0.5 * (lo + hi)
+
+
+def test_resting_penetration_is_the_closed_form_of_the_published_soft_contact_model():
+    """solref -> (k, b), solimp -> d(r), R = (1 - d) / d * body_invweight0 and the reference acceleration, all at once: the depth at
+    which the ball (one contact) and the box (four corners, a quarter of the weight each) come to rest"""
+    fm, pm, ph = scene()
+    for _ in range(3000):
+        ph.step()
+    ph.forward()
+    c = ph.get("contact").reshape(-1, 11)
+    assert np.abs(ph.get("qvel")).max() < 1e-10
+    assert abs(-c[0, 0] - _resting_depth(1.0)) < 1e-9
+    assert np.allclose(-c[1:, 0], _resting_depth(0.25), rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize("deg,slides", [(20, False), (35, True)])
 def test_coulomb_threshold_and_rolling(deg, slides):
     th = np.radians(deg)
