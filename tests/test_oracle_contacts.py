@@ -64,17 +64,27 @@ def _resting_depth(share, g=9.81, solref=(0.02, 1.0), solimp=(0.9, 0.95, 0.001, 
     return 0.5 * (lo + hi)
 
 
-def test_resting_penetration_is_the_closed_form_of_the_published_soft_contact_model():
+@pytest.mark.parametrize("cone", ["elliptic", "pyramidal"])
+def test_resting_penetration_is_the_closed_form_of_the_published_soft_contact_model(cone):
     """solref -> (k, b), solimp -> d(r), R = (1 - d) / d * body_invweight0 and the reference acceleration, all at once: the depth at
-    which the ball (one contact) and the box (four corners, a quarter of the weight each) come to rest"""
-    fm, pm, ph = scene()
+    which the ball (one contact) and the box (four corners, a quarter of the weight each) come to rest. Pyramidal cones: the four
+    edges n +- mu t of a condim-3 contact carry a quarter of the normal force each, with Rpy = 2 mu^2 R and the diagonal
+    approximation (1 + mu^2) / m of an edge row, so the same equation holds with the weight scaled by 2 mu^2 (1 + mu^2) / 4."""
+    fm = mjcf.load_xml(os.path.join(HERE, "models", "ball_plane.xml"))
+    fm.scalars["cone"] = {"pyramidal": 0, "elliptic": 1}[cone]
+    ph = pyoracle.Physics(PackedModel(fm))
+    ph.set_state(fm.arrays["qpos0"].copy(), np.zeros(fm.nv))
+    ph.set_ctrl(np.zeros(0))
     for _ in range(3000):
         ph.step()
     ph.forward()
     c = ph.get("contact").reshape(-1, 11)
+    mu = 0.5
+    scale = 1.0 if cone == "elliptic" else 2 * mu * mu * (1 + mu * mu) / 4
+    assert len(c) == 5 and int(ph.get("nefc")[0]) == (15 if cone == "elliptic" else 20)
     assert np.abs(ph.get("qvel")).max() < 1e-10
-    assert abs(-c[0, 0] - _resting_depth(1.0)) < 1e-9
-    assert np.allclose(-c[1:, 0], _resting_depth(0.25), rtol=0, atol=1e-9)
+    assert abs(-c[0, 0] - _resting_depth(scale)) < 1e-9
+    assert np.allclose(-c[1:, 0], _resting_depth(0.25 * scale), rtol=0, atol=1e-9)
 
 
 @pytest.mark.parametrize("deg,slides", [(20, False), (35, True)])
