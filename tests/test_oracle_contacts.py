@@ -87,6 +87,37 @@ def test_resting_penetration_is_the_closed_form_of_the_published_soft_contact_mo
     assert np.allclose(-c[1:, 0], _resting_depth(0.25 * scale), rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("cone", ["elliptic", "pyramidal"])
+def test_one_contact_accelerates_a_free_ball_by_the_impedance_times_the_reference_acceleration(cone):
+    """No gravity, the ball 0.3 mm inside the floor and moving into it at 1 cm/s: with A = 1 / m for the normal row and
+    R = (1 - d) / d / m the published model gives qacc_z = d aref, aref = -b v - k d r (elliptic). Pyramidal: the four edge rows sum
+    to 4 / m (the tangential parts cancel by symmetry) and each carries Rpy = 2 mu^2 (1 + mu^2) (1 - d) / d / m, so
+    qacc_z = 4 aref / (4 + m Rpy)."""
+    fm = mjcf.load_xml(os.path.join(HERE, "models", "ball_plane.xml"))
+    fm.scalars["gravity"] = np.zeros(3)
+    fm.scalars["cone"] = {"pyramidal": 0, "elliptic": 1}[cone]
+    ph = pyoracle.Physics(PackedModel(fm))
+    q = fm.arrays["qpos0"].copy()
+    r, v = -3e-4, -0.01
+    q[2] = 0.1 + r
+    q[9] = 1.0  # the box: out of the way
+    qvel = np.zeros(fm.nv)
+    qvel[2] = v
+    ph.set_state(q, qvel)
+    ph.set_ctrl(np.zeros(0))
+    ph.forward()
+    assert int(ph.get("ncon")[0]) == 1
+    d0, dmax, width, mid, p = 0.9, 0.95, 0.001, 0.5, 2.0
+    x = abs(r) / width
+    d = d0 + (x ** p / mid ** (p - 1)) * (dmax - d0)  # x <= midpoint
+    k, b = 1 / (dmax ** 2 * 0.02 ** 2), 2 / (dmax * 0.02)
+    aref = -b * v - k * d * r
+    mu = 0.5
+    want = d * aref if cone == "elliptic" else 4 * aref / (4 + 2 * mu * mu * (1 + mu * mu) * (1 - d) / d)
+    a = ph.get("qacc")
+    assert abs(a[2] - want) < 1e-9 and np.abs(np.delete(a[:6], 2)).max() < 1e-12
+
+
 @pytest.mark.parametrize("deg,slides", [(20, False), (35, True)])
 def test_coulomb_threshold_and_rolling(deg, slides):
     th = np.radians(deg)
