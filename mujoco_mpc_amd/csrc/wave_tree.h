@@ -413,14 +413,16 @@ __device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeDa
 
 // ---- packed symmetric matrices (lower triangle, row-major: (i, j), i >= j, at i (i + 1) / 2 + j)
 __device__ __forceinline__ int wt_tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
-// (M v)[lane] for a packed symmetric M; lane < nv
+// (M v)[lane] for a packed symmetric M; called by the lanes < nv (all of them: entry b of v is lane b's own value, handed round by
+// v_readlane instead of nv broadcast reads of LDS)
 template <int NMAX>
 __device__ __forceinline__ wreal wt_sym_mulvec(const wreal* Mp, const wreal* v, int nv, int lane) {
   wreal s = 0;
   const int rowadr = lane * (lane + 1) / 2;
+  const wreal mine = v[lane];
 #pragma unroll
   for (int b = 0; b < NMAX; b++)
-    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * v[b];
+    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * wbcast(mine, b);
   return s;
 }
 // same with v = x - y
@@ -428,9 +430,10 @@ template <int NMAX>
 __device__ __forceinline__ wreal wt_sym_mulvec_diff(const wreal* Mp, const wreal* x, const wreal* y, int nv, int lane) {
   wreal s = 0;
   const int rowadr = lane * (lane + 1) / 2;
+  const wreal mine = x[lane] - y[lane];
 #pragma unroll
   for (int b = 0; b < NMAX; b++)
-    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * (x[b] - y[b]);
+    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * wbcast(mine, b);
   return s;
 }
 
@@ -978,11 +981,13 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
   };
   set_jar(d.qacc);
   wreal cost = wt_cost(d, t, q, lane, pyr);
+  bool factor_valid = false, have_Ma = false, have_jtf = false;
+  wreal improvement = 0, Ma_kept = 0, jtf_kept = 0;
   if (have_warm) {  // warm start (mj_fwdConstraint): begin at the previous step's qacc if its cost is lower
-    wreal gauss = 0;
+    wreal gauss = 0, Mw = 0;
     if (lane < nv) {
-      const wreal s = wt_sym_mulvec_diff<NMAX>(d.M, d.qacc_warm, d.qacc_smooth, nv, lane);
-      gauss = WL(0.5) * s * (d.qacc_warm[lane] - d.qacc_smooth[lane]);
+      Mw = wt_sym_mulvec_diff<NMAX>(d.M, d.qacc_warm, d.qacc_smooth, nv, lane);
+      gauss = WL(0.5) * Mw * (d.qacc_warm[lane] - d.qacc_smooth[lane]);
     }
     gauss = wave_sum(gauss);
     set_jar(d.qacc_warm);
@@ -990,6 +995,7 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     if (cw < cost) {
       cost = cw;
       if (lane < nv) d.qacc[lane] = d.qacc_warm[lane];
+      Ma_kept = Mw; have_Ma = true;  // (the first gradient's M (qacc - qacc_smooth))
       WSYNC();
     } else {
       set_jar(d.qacc);
@@ -997,8 +1003,6 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     }
   }
   const wreal scale = WL(1.0) / (m.meaninertia * (nv > 1 ? nv : 1));
-  bool factor_valid = false;
-  wreal improvement = 0;
   int zf_prev = -2, zl0_prev = -2, zl1_prev = -2, zs_prev = -2, zc_prev = -2, zt0_prev = -2, zt1_prev = -2;
   long long tacc = 0;
 #define WACC(k) do { if (stamp && lane == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); stamp[k] += now_ - tacc; tacc = now_; } } while (0)
@@ -1007,8 +1011,10 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     // gradient = M (qacc - qacc_smooth) - J' force
     wreal g = 0;
     const wreal jtf = wt_jt_force(m, d, t, q, ns, nc, lane);
+    jtf_kept = jtf; have_jtf = true;
     if (lane < nv) {
-      const wreal s = wt_sym_mulvec_diff<NMAX>(d.M, d.qacc, d.qacc_smooth, nv, lane);
+      // (after the first iteration: the product the previous one formed for its cost, at the same qacc)
+      const wreal s = have_Ma ? Ma_kept : wt_sym_mulvec_diff<NMAX>(d.M, d.qacc, d.qacc_smooth, nv, lane);
       d.Ma[lane] = s;
       g = s - jtf;
       d.search[lane] = -g;
@@ -1255,16 +1261,20 @@ __device__ __forceinline__ void wt_constraint_newton(const MODEL& m, WaveData& d
     if (lane < nv) {
       const wreal s = wt_sym_mulvec_diff<NMAX>(d.M, d.qacc, d.qacc_smooth, nv, lane);
       gauss = WL(0.5) * s * (d.qacc[lane] - d.qacc_smooth[lane]);
+      Ma_kept = s;
     }
+    have_Ma = true;
     gauss = wave_sum(gauss);
     const wreal newcost = gauss + wt_cost(d, t, q, lane, pyr);
+    have_jtf = false;  // (the forces moved)
     improvement = cost - newcost;
     cost = newcost;
     WACC(38);
     if (stamp && lane == 0) stamp[20] = iter + 1;
   }
 #undef WACC
-  const wreal jtf = wt_jt_force(m, d, t, q, ns, nc, lane);
+  // (a loop left at its convergence test has J' force of the final forces in hand)
+  const wreal jtf = have_jtf ? jtf_kept : wt_jt_force(m, d, t, q, ns, nc, lane);
   if (lane < nv) d.qfrc_constraint[lane] = jtf;
   WSYNC();
 }
