@@ -413,16 +413,16 @@ __device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeDa
 
 // ---- packed symmetric matrices (lower triangle, row-major: (i, j), i >= j, at i (i + 1) / 2 + j)
 __device__ __forceinline__ int wt_tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
-// (M v)[lane] for a packed symmetric M; called by the lanes < nv (all of them: entry b of v is lane b's own value, handed round by
-// v_readlane instead of nv broadcast reads of LDS)
+// (M v)[lane] for a packed symmetric M; lane < nv. (Entry b of v as a broadcast read of LDS: handing it round with v_readlane from the
+// owning lane saves 2 nv LDS reads and is 1 % faster on the Humanoid, but the allocator then spills loop-carried solver state inside
+// the Newton loop -- scratch traffic 12.6 -> 27 GB per launch, measured -- so the reads stay.)
 template <int NMAX>
 __device__ __forceinline__ wreal wt_sym_mulvec(const wreal* Mp, const wreal* v, int nv, int lane) {
   wreal s = 0;
   const int rowadr = lane * (lane + 1) / 2;
-  const wreal mine = v[lane];
 #pragma unroll
   for (int b = 0; b < NMAX; b++)
-    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * wbcast(mine, b);
+    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * v[b];
   return s;
 }
 // same with v = x - y
@@ -430,10 +430,9 @@ template <int NMAX>
 __device__ __forceinline__ wreal wt_sym_mulvec_diff(const wreal* Mp, const wreal* x, const wreal* y, int nv, int lane) {
   wreal s = 0;
   const int rowadr = lane * (lane + 1) / 2;
-  const wreal mine = x[lane] - y[lane];
 #pragma unroll
   for (int b = 0; b < NMAX; b++)
-    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * wbcast(mine, b);
+    if (b < nv) s += Mp[b <= lane ? rowadr + b : b * (b + 1) / 2 + lane] * (x[b] - y[b]);
   return s;
 }
 
