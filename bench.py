@@ -377,7 +377,7 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
                      "kernel_ms": avg_kernel_s * 1e3, "all_rollout_kernels_ms": avg_rollout_s * 1e3, "bytes_per_launch": bytes_per_launch,
                      "handed_on_last_step": {"candidates": handed_on[0], "contact_list_full": handed_on[1], "leg_leg_contact": handed_on[2],
                                              "indefinite_hessian": handed_on[3], "non_finite": handed_on[4], "both_limits": handed_on[5],
-                                             "trunk_leg_contact": handed_on[6]},
+                                             "trunk_leg_contact": handed_on[6], "out_of_proof_range": handed_on[7]},
                      "note": "algorithmic bytes (SURVEY 8d) / HIP-event time of the kernel that rolls the batch out (mjpcx_timing_read_main), on "
                              "the context's stream; all_rollout_kernels_ms adds the pass over the candidates it handed to the "
                              "wavefront-per-candidate kernel. The contact models are latency / issue-bound, not HBM-bound (DESIGN.md 4): see `valu`"},

@@ -409,7 +409,8 @@ int mjpcx_timing_read(mjpcx_ctx* ctx, double* kernel_ms, int64_t* launches);
 int mjpcx_timing_read_main(mjpcx_ctx* ctx, double* main_kernel_ms, int64_t* launches);
 /* rollout_quad_kernel only (zeros otherwise): of the last rollout, [0] candidates handed to the wavefront-per-candidate kernel, then by
  * reason: [1] contact list full [2] contact between two legs [3] indefinite Hessian [4] non-finite value [5] both limits of a joint
- * [6] contact between the trunk and a leg. Synchronises. */
+ * [6] contact between the trunk and a leg [7] a joint beyond the range over which the geom pairs the kernel leaves out are proven
+ * apart (csrc/pair_cull.h). Synchronises. */
 int mjpcx_quad_stats(mjpcx_ctx* ctx, int32_t* handed_on /* 8 */);
 
 /* Algorithmic bytes of one candidate rollout:

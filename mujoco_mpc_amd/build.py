@@ -28,7 +28,8 @@ SOURCES = [("mjpcx.hip", PRESSURE), ("ilqg_wave.hip", []), ("wave32.hip", PRESSU
 # headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
 # re-compile the wavefront-per-candidate kernels, and vice versa)
 QUAD_ONLY = ["quad_step.h", "quad_kernel.h", "quad_model.h"]
-QUAD_DEPS = ["quad_step.h", "quad_kernel.h", "quad_model.h", "quad_abi.h", "quad_launch.h", "quad_kernel.hip", os.path.join("..", "..", "include", "mjpcx.h")]
+QUAD_DEPS = ["quad_step.h", "quad_kernel.h", "quad_model.h", "quad_abi.h", "quad_launch.h", "quad_kernel.hip", "solid_pairs.h", "pair_cull.h",
+             os.path.join("..", "..", "include", "mjpcx.h")]
 HEADERS = ["device_common.h", "rollout_lane.h", "lane_registry.h", os.path.join("generated", "static_models.h"),
            os.path.join("..", "..", "include", "mjpcx.h")]
 

@@ -331,7 +331,7 @@ class Context:
         h = np.zeros(8, np.int32)
         self._chk(lib().mjpcx_quad_stats(self.handle, as_i32p(h)))
         return dict(handed_on=int(h[0]), contact_list_full=int(h[1]), leg_leg_contact=int(h[2]), indefinite_hessian=int(h[3]), non_finite=int(h[4]),
-                    both_limits=int(h[5]), trunk_leg_contact=int(h[6]))
+                    both_limits=int(h[5]), trunk_leg_contact=int(h[6]), out_of_proof_range=int(h[7]))
 
     def algorithmic_bytes(self, horizon, num_nodes):
         return lib().mjpcx_algorithmic_bytes(self.handle, int(horizon), int(num_nodes))

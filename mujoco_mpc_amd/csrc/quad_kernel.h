@@ -151,7 +151,7 @@ __device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int sl
   c.D0 = v[6];
   QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = v[7 + k];
   const int meta = (int)v[13];
-  c.depth = meta & 3; c.fid = (meta >> 2) & 7; c.rel = (meta >> 5) & 1; c.sgn = (meta & 64) ? 1 : -1; c.pd = (meta >> 7) & 3; c.px = (meta >> 9) & 3;
+  c.depth = meta & 3; c.fid = (meta >> 2) & 7; c.rel = (meta >> 5) & 1; c.sgn = (meta & 64) ? 1 : -1; c.pd = (meta >> 7) & 3; c.px = (meta >> 9) & 3; c.self = (meta >> 11) & 1;
 }
 __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
   using namespace mjpcx::quad;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, c
   QUNROLL for (int k = 0; k < 3; k++) { v[k] = c.n[k]; v[3 + k] = c.off[k]; }
   v[6] = c.D0;
   QUNROLL for (int k = 0; k < 6; k++) v[7 + k] = c.jar[k];
-  v[13] = (double)(c.depth | (c.fid << 2) | (c.rel << 5) | (c.sgn > 0 ? 64 : 0) | (c.pd << 7) | (c.px << 9));
+  v[13] = (double)(c.depth | (c.fid << 2) | (c.rel << 5) | (c.sgn > 0 ? 64 : 0) | (c.pd << 7) | (c.px << 9) | (c.self << 11));
   if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) p[f * 64] = v[f]; }
   else { qprv_f64* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) p[f] = v[f]; }
 }

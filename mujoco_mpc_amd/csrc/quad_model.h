@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "../../include/mjpcx.h"
+#include "pair_cull.h"
 #include "quad_abi.h"
 
 namespace mjpcx {
@@ -28,7 +29,7 @@ constexpr int kQLegs = 4, kQLinks = 3;
 constexpr int kQLegGeom = 8;     // collidable geoms per leg
 constexpr int kQTrunkGeom = 8;   // collidable geoms on the trunk (dealt over the four lanes: lane l tests geoms l, l + 4)
 constexpr int kQStatic = 4;      // collidable static geoms (world / mocap bodies)
-constexpr int kQPairGeom = 6;    // sphere | capsule geoms per leg in moving-geom pairs; kQTrunkPairGeom on the trunk
+constexpr int kQPairGeom = 8;    // geoms per leg in moving-geom pairs (sphere | capsule; cylinder: against the sphere | capsule geoms of other legs); kQTrunkPairGeom on the trunk (sphere | capsule)
 constexpr int kQTrunkPairGeom = 2;
 constexpr int kQMaxFric = 8;     // distinct friction sets (mu, tangential, torsional, rolling) over the contact pairs
 constexpr int kQMaxKey = 4, kQMaxTrace = 2, kQMaxTerm = 16, kQMaxRay = 4;
@@ -62,15 +63,17 @@ struct QuadLeg {
   double jnt_pos[kQLinks][3], jnt_axis[kQLinks][3];
   double qpos0[kQLinks], qpos_spring[kQLinks], stiffness[kQLinks], armature[kQLinks], damping[kQLinks];
   double range[kQLinks][2], margin[kQLinks];
+  double guard[kQLinks][2];  // joint values outside [guard[j][0], guard[j][1]] leave the box the bake-time proofs of the dropped pairs cover (pair_cull.h)
   double lim_k[kQLinks], lim_b[kQLinks], lim_imp[kQLinks][5], lim_diag[kQLinks];
   double floss[kQLinks], floss_R[kQLinks], floss_D[kQLinks], floss_b[kQLinks];
   double act_gear[kQLinks], act_gain[kQLinks], act_bias[kQLinks][3], ctrlrange[kQLinks][2], forcerange[kQLinks][2];
   double key_q[kQMaxKey][kQLinks];  // keyframe joint values of this leg (Posture residual)
   int limited[kQLinks], act_biastype[kQLinks], ctrllimited[kQLinks], forcelimited[kQLinks];
   int ngeom, foot_slot, foot_index, npg;  // foot_slot: the leg's geom the residual reads; foot_index: its place in foot_geom_id_ (FL HL FR HR)
-  int pg_slot[kQPairGeom];                // the leg's sphere | capsule geoms that can touch another leg or the trunk (self-collision test)
+  int pg_slot[kQPairGeom];                // the leg's geoms that can touch another leg or the trunk (self-collision test)
   double pg_reach[kQPairGeom];              // radius of the pair geom's bounding sphere about its centre (capsule: radius + half length)
   unsigned long long pg_first[kQLegs + 1];  // per other leg (kQLegs: the trunk), bit 8 i + j: the own pair geom i is geom1 of the pair with the other's j
+  unsigned long long pg_active[kQLegs + 1]; // bit 8 i + j: (own pair geom i, the other's j) is a pair MuJoCo's filters leave and pair_cull.h did not prove apart
   QuadGeom geom[kQLegGeom];
 };
 
@@ -338,62 +341,76 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
       { const std::string err = pair_params(g1, g2, p); if (!err.empty()) return err; }
     }
   }
-  // moving-geom pairs (oracle/contact.inc bake_pairs): tested only. The kernel walks them as a cross product, so the set must be one.
+  // moving-geom pairs (pair_cull.h: MuJoCo's filters, each pair's class, the proofs). The kernel walks (own pair geom, pair geom of another
+  // leg | of the trunk) by the bits of pg_active: sphere | capsule pairs and (sphere | capsule, cylinder) pairs between two legs.
   {
-    std::vector<char> in_pair(m->ngeom, 0);
-    int npair = 0;
+    std::vector<char> in_pair(m->ngeom, 0), moving(m->nbody, 0);
+    for (int b = 1; b < m->nbody; b++) moving[b] = moving[m->body_parentid[b]] || m->body_dofnum[b] > 0;
     double pmargin = 0;
-    std::vector<std::pair<int, int>> plist;
-    if (m->body_weldid)
-      for (int a = 0; a < m->ngeom; a++)
-        for (int b = a + 1; b < m->ngeom; b++) {
-          if (slot_leg[a] == -2 || slot_leg[b] == -2) continue;
-          const int ta = m->geom_type[a], tb = m->geom_type[b];
-          if ((ta != MJPCX_GEOM_SPHERE && ta != MJPCX_GEOM_CAPSULE) || (tb != MJPCX_GEOM_SPHERE && tb != MJPCX_GEOM_CAPSULE)) continue;
-          if (!((m->geom_contype[a] & m->geom_conaffinity[b]) || (m->geom_contype[b] & m->geom_conaffinity[a]))) continue;
-          const int b1 = m->geom_bodyid[a], b2 = m->geom_bodyid[b];
-          const int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
-          if (w1 == w2) continue;
-          const int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
-          if (w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
-          const int sig = ((b1 < b2 ? b1 : b2) << 16) + (b1 < b2 ? b2 : b1);
-          bool excluded = false;
-          for (int e = 0; e < m->nexclude; e++) excluded |= m->exclude_signature[e] == sig;
-          if (excluded) continue;
-          in_pair[a] = in_pair[b] = 1;
-          plist.emplace_back(a, b);
-          pmargin = std::max(pmargin, std::max(m->geom_margin[a], m->geom_margin[b]));
-          npair++;
-        }
+    std::vector<MovingPair> mp, plist;
+    if (m->body_weldid) moving_pairs(m, moving, true, mp);
+    bool proofs = false;
+    std::vector<double> pad_lo(m->njnt, kPairCullPad), pad_hi(m->njnt, kPairCullPad);
+    for (const MovingPair& q : mp) {
+      if (q.kind == kPairOther) continue;                                 // (no narrow phase anywhere: left out and reported by WaveHost::build)
+      if (q.kind == kPairSolids && !(q.apart && q.tight_jnt < 0)) continue;  // (the same; the wave kernels drop two solids on the plain proof only)
+      // what the layout can walk: sphere | capsule pairs between two legs or a leg and the trunk; a leg's sphere | capsule against a cylinder of
+      // another leg, or of its own leg on a link above it
+      const char* why = nullptr;
+      if (slot_leg[q.g1] == -2 || slot_leg[q.g2] == -2) why = "a moving-geom pair with a geom outside the trunk and the legs";
+      else if (slot_leg[q.g1] == slot_leg[q.g2] && (q.kind != kPairThinSolid || m->geom_bodyid[q.g1] <= m->geom_bodyid[q.g2]))
+        why = "a self-collision pair inside one leg other than (sphere | capsule on a lower link, cylinder on a higher one)";
+      else if (q.kind == kPairThinSolid && (m->geom_type[q.g2] != MJPCX_GEOM_CYLINDER || slot_leg[q.g1] < 0 || slot_leg[q.g2] < 0))
+        why = "a (sphere | capsule, box | cylinder) pair other than between legs' geoms with a cylinder";
+      else if (q.kind == kPairSolids) why = "two solids";
+      // dropped on the strength of its proof (the step function checks the joint ranges the proofs cover: kFlagRange) -- unless the proof
+      // needed the tight pad and the pair can be walked instead
+      if (q.apart && (q.tight_jnt < 0 || why)) {
+        proofs = true;
+        if (q.tight_jnt >= 0) (q.tight_side == 0 ? pad_lo : pad_hi)[q.tight_jnt] = kPairCullPadTight;
+        continue;
+      }
+      if (why) return why;
+      in_pair[q.g1] = in_pair[q.g2] = 1;
+      plist.push_back(q);
+      pmargin = std::max(pmargin, std::max(m->geom_margin[q.g1], m->geom_margin[q.g2]));
+    }
     for (int g = 0; g < m->ngeom; g++) {
       if (!in_pair[g]) continue;
       if (slot_leg[g] < 0) { if (qm->ntpg == kQTrunkPairGeom) return "more trunk geoms in self-collision pairs than staged"; qm->tpg_slot[qm->ntpg++] = slot_idx[g]; }
       else { QuadLeg& L = qm->leg[slot_leg[g]]; if (L.npg == kQPairGeom) return "more leg geoms in self-collision pairs than staged"; L.pg_slot[L.npg++] = slot_idx[g]; }
     }
-    int expect = 0;
-    for (int l = 0; l < kQLegs; l++) { expect += qm->leg[l].npg * qm->ntpg; for (int l2 = l + 1; l2 < kQLegs; l2++) expect += qm->leg[l].npg * qm->leg[l2].npg; }
-    for (auto& pr : plist) if (slot_leg[pr.first] == slot_leg[pr.second]) return "a self-collision pair inside one leg";
-    if (npair != expect) return "self-collision pairs are not the cross product of the legs' pair geoms";
-    qt->npair = npair;
+    qt->npair = (int)plist.size();
     qm->pair_margin = pmargin;
+    // the joint box the proofs of the dropped pairs cover (qpos units); without proofs, or for a joint without a range, everything
+    for (int l = 0; l < kQLegs; l++)
+      for (int j = 0; j < kQLinks; j++) {
+        const int jid = m->body_jntadr[trunk + 1 + kQLinks * l + j];
+        const bool on = proofs && m->jnt_limited[jid];
+        qm->leg[l].guard[j][0] = on ? m->jnt_range[2 * jid] - pad_lo[jid] : -1e30;
+        qm->leg[l].guard[j][1] = on ? m->jnt_range[2 * jid + 1] + pad_hi[jid] : 1e30;
+      }
     auto pg_index = [&](int g) { const int l = slot_leg[g]; const int* sl = l < 0 ? qm->tpg_slot : qm->leg[l].pg_slot; const int n = l < 0 ? qm->ntpg : qm->leg[l].npg;
                                  for (int i = 0; i < n; i++) if (sl[i] == slot_idx[g]) return i; return -1; };
-    for (auto& pr : plist) {
-      const int ta = m->geom_type[pr.first], tb = m->geom_type[pr.second];
-      const int g1 = ta > tb ? pr.second : pr.first, g2 = ta > tb ? pr.first : pr.second;  // MuJoCo's order: lower geom type first, then lower index
+    for (const MovingPair& pr : plist) {
+      const int g1 = pr.g1, g2 = pr.g2;  // MuJoCo's order: lower geom type first, then lower index
       for (int side = 0; side < 2; side++) {
         const int own = side == 0 ? g1 : g2, other = side == 0 ? g2 : g1;
         if (slot_leg[own] < 0) continue;  // (the trunk has no lane of its own: the leg's lane handles a trunk-leg pair)
-        QuadPair& p = qt->mm[slot_leg[own]][pg_index(own)][slot_leg[other] < 0 ? kQLegs : slot_leg[other]][pg_index(other)];
+        if (side == 1 && slot_leg[own] == slot_leg[other]) continue;  // (a pair inside one leg is walked once, from its geom1)
+        const int o = slot_leg[other] < 0 ? kQLegs : slot_leg[other];
+        QuadPair& p = qt->mm[slot_leg[own]][pg_index(own)][o][pg_index(other)];
         const std::string err = pair_params(g1, g2, p);
         if (!err.empty()) return err;
         p.collide = 1; p.pad = own == g1;
-        if (own == g1) qm->leg[slot_leg[own]].pg_first[slot_leg[other] < 0 ? kQLegs : slot_leg[other]] |= 1ull << (8 * pg_index(own) + pg_index(other));
+        const unsigned long long bit = 1ull << (8 * pg_index(own) + pg_index(other));
+        qm->leg[slot_leg[own]].pg_active[o] |= bit;
+        if (own == g1) qm->leg[slot_leg[own]].pg_first[o] |= bit;
       }
     }
   }
   {
-    auto reach = [](const QuadGeom& g) { return g.size[0] + (g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0); };
+    auto reach = [](const QuadGeom& g) { return g.type == MJPCX_GEOM_CAPSULE ? g.size[0] + g.size[1] : (g.type == MJPCX_GEOM_CYLINDER ? std::sqrt(g.size[0] * g.size[0] + g.size[1] * g.size[1]) : g.size[0]); };
     for (int l = 0; l < kQLegs; l++) for (int i = 0; i < qm->leg[l].npg; i++) qm->leg[l].pg_reach[i] = reach(qm->leg[l].geom[qm->leg[l].pg_slot[i]]);
     for (int j = 0; j < qm->ntpg; j++) qm->tpg_reach[j] = reach(qm->trunk_geom[qm->tpg_slot[j]]);
   }

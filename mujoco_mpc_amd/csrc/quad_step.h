@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "quad_model.h"
+#include "solid_pairs.h"
 
 #ifndef QPROF
 #define QPROF(pf, idx)
@@ -53,7 +54,7 @@ namespace mjpcx { namespace quad {
 constexpr double kQMinVal = 1e-15, kQMaxVal = 1e10, kQPi = 3.14159265358979323846;
 constexpr double kQLsTol = 0.01;
 
-enum { kFlagOverflow = 1, kFlagPair = 2, kFlagNotPD = 4, kFlagBad = 8, kFlagLimits = 16, kFlagPairTrunk = 32 };
+enum { kFlagOverflow = 1, kFlagPair = 2, kFlagNotPD = 4, kFlagBad = 8, kFlagLimits = 16, kFlagPairTrunk = 32, kFlagRange = 64 };
 
 // ---------------------------------------------------------------- small algebra
 // square root with its reciprocal, and a reciprocal, for the line search's inner loop: the includer may supply faster ones (the device
@@ -326,7 +327,12 @@ struct QContact {
   // side of the force). sgn = +1 if the own body carries geom2 (J = jac(body2) - jac(body1)).
   int rel, sgn, pd;
   int px;  // leg-leg contact: own leg index xor the partner's (1..3); 0 otherwise
+  // A contact between two bodies of the SAME leg (a calf or foot on the leg's own hip; self = 1, px = 0): pd is the depth of the shallower
+  // body, the rows act on the leg's dofs pd <= j < depth alone, and no other lane holds a copy.
+  int self;
 };
+// whether leg dof j is in the rows of the self-collision contact c
+QD bool rel_dof(const QContact& c, int j) { return j < c.depth && !(c.self != 0 && j < c.pd); }
 constexpr int kQConRec = 14;  // doubles per stored contact (quad_kernel.h / the emulator provide the store: qcs_load, qcs_store, qcs_store_jar)
 
 // world poses of the static geoms, computed once per rollout (mocap bodies do not move during a rollout)
@@ -378,11 +384,15 @@ QD void rel_exchange(const double Vp[4][6], int pmode, QRel& q) {
 // the point-space relative velocity of a self-collision contact: sgn ((V_own_body - V_trunk) - (V_partner_body - V_trunk))
 QD void point_vel_rel(const QContact& c, const double Vp[4][6], const QRel& q, double* out) {
   const double w2 = c.depth < 3 ? 1.0 : 0.0, w1 = c.depth < 2 ? 1.0 : 0.0;
-  const double u3 = c.pd == 3 ? 1.0 : 0.0, u2 = c.pd == 2 ? 1.0 : 0.0, u1 = c.pd == 1 ? 1.0 : 0.0, sg = c.sgn;
+  const double ws = c.self != 0 ? 1.0 : 0.0, wp = 1.0 - ws;  // (the other body: on the own chain | the partner's)
+  const double u3 = c.pd == 3 ? wp : 0.0, u2 = c.pd == 2 ? wp : 0.0, u1 = c.pd == 1 ? wp : 0.0, sg = c.sgn;
+  const double s2 = c.pd == 2 ? ws : 0.0, s1 = c.pd == 1 ? ws : 0.0;
   double V[6];
   QUNROLL for (int k = 0; k < 6; k++) {
     const double own = (Vp[3][k] - Vp[0][k]) - w2 * (Vp[3][k] - Vp[2][k]) - w1 * (Vp[2][k] - Vp[1][k]);  // (depth >= 1 for a moving geom of a leg)
-    V[k] = sg * (own - (u3 * q.dq[2][k] + u2 * q.dq[1][k] + u1 * q.dq[0][k]));
+    double other = s2 * (Vp[2][k] - Vp[0][k]) + s1 * (Vp[1][k] - Vp[0][k]);
+    if (c.self == 0) other = u3 * q.dq[2][k] + u2 * q.dq[1][k] + u1 * q.dq[0][k];
+    V[k] = sg * (own - other);
   }
   double w[3];
   cr3(w, V, c.off);
@@ -639,8 +649,8 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
       int zone;
       if (c.rel) {  // self-collision: own leg's dofs only, the own side of the force; a leg-leg contact is counted half here, half in its partner's lane
         const double cc = contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
-        cost += c.pd > 0 ? 0.5 * cc : cc;
-        if (zone != 0) { QUNROLL for (int j = 0; j < 3; j++) if (j < c.depth) jl[j] += c.sgn * dot6(kin.cdof[j], Fs); }
+        cost += c.px != 0 ? 0.5 * cc : cc;
+        if (zone != 0) { QUNROLL for (int j = 0; j < 3; j++) if (rel_dof(c, j)) jl[j] += c.sgn * dot6(kin.cdof[j], Fs); }
         continue;
       }
       cost += contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
@@ -712,7 +722,7 @@ QD void rows_line_prepare(const QuadModel& m, CS& cs, int ncon, const double Vp[
       if (MULTI && !in_pass(c, pass, x)) continue;
       double jv[6];
       if (c.rel) point_vel_rel(c, Vp, rx, jv); else point_vel(c, Vp, jv);
-      line_coeffs(c, m.fric[c.fid], jv, c.rel && c.pd > 0 ? 0.5 : 1.0, ql[i]);
+      line_coeffs(c, m.fric[c.fid], jv, c.rel && c.px != 0 ? 0.5 : 1.0, ql[i]);
     }
     if (MULTI) x = next_x(pmask, x);
   }
@@ -769,7 +779,7 @@ QD void rows_line(const QuadModel& m, const QDiag& dg, bool any_limit, CS& cs, i
           point_vel_rel(c, Vp, rx, jv);
           double gr = 0, hr = 0;
           contact_line(c, m.fric[c.fid], jv, alpha, gr, hr);
-          const double w = c.pd > 0 ? 0.5 : 1.0;
+          const double w = c.px != 0 ? 0.5 : 1.0;
           g += w * gr; h += w * hr;
         } else {
           point_vel(c, Vp, jv);
@@ -875,11 +885,11 @@ QD void hessian_rel(const QuadModel& m, const QKin& kin, CS& cs, int ncon, int l
     contact_hess_prepare(c, m.fric[c.fid], h);
     if (h.zone == 0) continue;
     QUNROLL for (int j = 0; j < 3; j++) {
-      if (j >= c.depth) continue;
+      if (!rel_dof(c, j)) continue;
       double Y[6];
       contact_hess_apply(c, h, kin.cdof[j], Y);
-      QUNROLL for (int ii = 0; ii <= j; ii++) Hl[tri(j, ii)] += dot6(kin.cdof[ii], Y);
-      if (isA) { QUNROLL for (int ii = 0; ii < 3; ii++) if (ii < c.pd) Hab[j][ii] -= dot6(cq[ii], Y); }
+      QUNROLL for (int ii = 0; ii <= j; ii++) if (rel_dof(c, ii)) Hl[tri(j, ii)] += dot6(kin.cdof[ii], Y);
+      if (isA && c.self == 0) { QUNROLL for (int ii = 0; ii < 3; ii++) if (ii < c.pd) Hab[j][ii] -= dot6(cq[ii], Y); }
     }
   }
 }
@@ -946,11 +956,11 @@ QD void hessian_rel_general(const QuadModel& m, const QKin& kin, CS& cs, int nco
       (void)contact_eval(c, m.fric[c.fid], Fs, Xc, zone);
       if (zone == 0) continue;
       QUNROLL for (int j = 0; j < 3; j++) {
-        if (j >= c.depth) continue;
+        if (!rel_dof(c, j)) continue;
         double Y[6];
         QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += Xc[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
-        QUNROLL for (int ii = 0; ii <= j; ii++) H.a.l[tri(j, ii)] += dot6(kin.cdof[ii], Y);
-        if (upper && c.pd > 0) {
+        QUNROLL for (int ii = 0; ii <= j; ii++) if (rel_dof(c, ii)) H.a.l[tri(j, ii)] += dot6(kin.cdof[ii], Y);
+        if (upper && c.px != 0) {
           QUNROLL for (int ii = 0; ii < 3; ii++) {
             if (ii >= c.pd) continue;
             const double v = dot6(cq[ii], Y);
@@ -1251,11 +1261,11 @@ QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, co
 // a contact found: its record (mj_instantiateContact + mj_makeImpedance for its rows, in point space) goes to the lane's store
 template <class CS>
 QD void add_contact(const QuadPair& p, const double* com, const double* cvel, int depth, double dist, const double* pos, const double* normal,
-                    CS& cs, int& ncon, int& flags, int rel = 0, int sgn = 1, int pd = 0, int px = 0) {
+                    CS& cs, int& ncon, int& flags, int rel = 0, int sgn = 1, int pd = 0, int px = 0, int self = 0) {
   if (!(dist < p.margin)) return;
   if (ncon >= kQMaxCon) { flags |= kFlagOverflow; return; }
   QContact c;
-  c.depth = depth; c.rel = rel; c.sgn = sgn; c.pd = pd; c.px = px;
+  c.depth = depth; c.rel = rel; c.sgn = sgn; c.pd = pd; c.px = px; c.self = self;
   QUNROLL for (int k = 0; k < 3; k++) { c.n[k] = normal[k]; c.off[k] = pos[k] - com[k]; }
   c.fid = p.fid;
   const double x = dist - p.includemargin;
@@ -1410,7 +1420,7 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
   auto one = [&](int i, int o, int j, const double* oc, const double* oa, int otype, double orad, double ohalf, const double* ov0, const double* ov1, const double* ov2,
                  int olink, int odepth) {
     const QuadGeom& g = L.geom[L.pg_slot[i]];
-    const double r0 = g.size[0], h0 = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
+    const double r0 = g.size[0], h0 = g.type != MJPCX_GEOM_SPHERE ? g.size[1] : 0.0;  // (capsule, cylinder: half length)
     double ci[3], ai[3];  // the own geom, picked from the register arrays (i is a run-time index here)
     QUNROLL for (int k = 0; k < 3; k++) {
       // (0 / 1 weights, not a chain of selects: the optimiser folds `i == q ? arr[q] : ...` over the elements of one array into a load at a
@@ -1455,6 +1465,43 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
       return x < -h ? -h : (x > h ? h : x);
     };
     double c1[3], c2[3];
+    if (t2 == MJPCX_GEOM_CYLINDER) {
+      // (sphere | capsule, cylinder) -- a calf or foot against another leg's hip: solid_pairs.h in a frame built on the cylinder's axis
+      // (the solid is one of revolution: any frame about its axis gives the same contact; oracle pair_thin_solid uses the geom's own)
+      if (t1 == MJPCX_GEOM_CYLINDER) return;  // (two solids: proven apart at bake time or reported, never walked)
+      double e1[3], e2[3];
+      { const bool yy = a2[1] < 0.5 && a2[1] > -0.5;
+        e1[0] = 0; e1[1] = yy ? 1.0 : 0.0; e1[2] = yy ? 0.0 : 1.0;
+        const double dt = a2[0] * e1[0] + a2[1] * e1[1] + a2[2] * e1[2];
+        QUNROLL for (int k = 0; k < 3; k++) e1[k] -= dt * a2[k];
+        const double nn = 1.0 / sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+        QUNROLL for (int k = 0; k < 3; k++) e1[k] *= nn;
+        cr3(e2, a2, e1); }
+      const double rel[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+      const double pl[3] = {rel[0] * e1[0] + rel[1] * e1[1] + rel[2] * e1[2], rel[0] * e2[0] + rel[1] * e2[1] + rel[2] * e2[2], rel[0] * a2[0] + rel[1] * a2[1] + rel[2] * a2[2]};
+      const double al[3] = {a1[0] * e1[0] + a1[1] * e1[1] + a1[2] * e1[2], a1[0] * e2[0] + a1[1] * e2[1] + a1[2] * e2[2], a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]};
+      const double size[3] = {r2, h2, 0.0};
+      double nl[3], cl[3];
+      const double dist = solid::thin_vs_solid<double>(solid::kSolidCylinder, size, pl, al, t1 == MJPCX_GEOM_CAPSULE ? h1 : 0.0, r1, nl, cl);
+      if (!(dist < mg)) return;
+      const QuadPair& P = tab.mm[leg][i][o][j];
+      if (!P.collide || !(dist < P.margin)) return;
+      double n[3], pos[3], vrel[6];
+      QUNROLL for (int k = 0; k < 3; k++) {
+        n[k] = nl[0] * e1[k] + nl[1] * e2[k] + nl[2] * a2[k];
+        const double s = r1 + 0.5 * dist;
+        pos[k] = p2[k] + (cl[0] + nl[0] * s) * e1[k] + (cl[1] + nl[1] * s) * e2[k] + (cl[2] + nl[2] * s) * a2[k];
+      }
+      QUNROLL for (int k = 0; k < 6; k++) {
+        const double vo = g.link == 0 ? cvel[0][k] : (g.link == 1 ? cvel[1][k] : cvel[2][k]);
+        const double vp = olink == 0 ? ov0[k] : (olink == 1 ? ov1[k] : ov2[k]);
+        vrel[k] = own_first ? vp - vo : vo - vp;
+      }
+      const int before = ncon;
+      add_contact(P, com, vrel, depth, dist, pos, n, cs, ncon, flags, 1, sgn, odepth, o < kQLegs ? (leg ^ o) : 0, o == leg ? 1 : 0);
+      if (ncon > before) { nrel++; if (o < kQLegs && o != leg) pmask |= 1 << (leg ^ o); }
+      return;
+    }
     if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) { (void)spheres(p1, p2); return; }
     if (t1 == MJPCX_GEOM_SPHERE) {  // (sphere, capsule): spheres come first in MuJoCo's order
       const double x = seg(p2, a2, h2, p1);
@@ -1503,7 +1550,7 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
   };
   double own_reach[kQPairGeom];
   QUNROLL for (int i = 0; i < kQPairGeom; i++) own_reach[i] = L.pg_reach[i] + mg;
-  auto near_mask = [&](const double (*oc)[3], int on, const double* oreach) {  // bit 8 * i + j: pair (own i, other j) may touch
+  auto near_mask = [&](const double (*oc)[3], int on, const double* oreach) {  // bit 8 * i + j: pair (own i, other j) may touch (the caller keeps the pairs that exist)
     unsigned long long mask = 0;
     QUNROLL for (int j = 0; j < kQPairGeom; j++) {
       if (j >= on) continue;
@@ -1528,9 +1575,10 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
       mv3(c, txm, g.pos);
       QUNROLL for (int k = 0; k < 3; k++) { tc[j][k] = c[k] + txpos[k]; ta[j][k] = txm[3 * k] * g.rot[2] + txm[3 * k + 1] * g.rot[5] + txm[3 * k + 2] * g.rot[8]; }
     }
-    double treach[kQPairGeom] = {0, 0, 0, 0, 0, 0};
+    double treach[kQPairGeom];
+    QUNROLL for (int j = 0; j < kQPairGeom; j++) treach[j] = 0;
     QUNROLL for (int j = 0; j < kQTrunkPairGeom; j++) treach[j] = m.tpg_reach[j];
-    unsigned long long mask = near_mask(tc, m.ntpg, treach);
+    unsigned long long mask = near_mask(tc, m.ntpg, treach) & L.pg_active[kQLegs];
     while (mask) {
       QPROF_COUNT(pf, 43, 1);
       const int bit = __builtin_ctzll(mask);
@@ -1539,7 +1587,20 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
       const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
       double c[3], a[3];
       pick3(tc, j, c); pick3(ta, j, a);
-      one(i, kQLegs, j, c, a, g.type, g.size[0], g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, cvelT, cvelT, cvelT, 0, 0);
+      one(i, kQLegs, j, c, a, g.type, g.size[0], g.type != MJPCX_GEOM_SPHERE ? g.size[1] : 0.0, cvelT, cvelT, cvelT, 0, 0);
+    }
+  }
+  // the own leg's cylinders (a calf or the foot against the leg's own hip: a contact inside the lane, QContact::self)
+  if (L.pg_active[leg] != 0) {
+    unsigned long long mask = near_mask(pg.c, L.npg, L.pg_reach) & L.pg_active[leg];
+    while (mask) {
+      const int bit = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int i = bit >> 3, j = bit & 7;
+      const QuadGeom& g2 = L.geom[L.pg_slot[j]];
+      double c2[3], a2[3];
+      pick3(pg.c, j, c2); pick3(pg.a, j, a2);
+      one(i, leg, j, c2, a2, g2.type, g2.size[0], g2.type != MJPCX_GEOM_SPHERE ? g2.size[1] : 0.0, cvel[0], cvel[1], cvel[2], g2.link, g2.link + 1);
     }
   }
   // the other three legs
@@ -1549,7 +1610,7 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
     double oc[kQPairGeom][3];
     QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++)
       oc[j][k] = qd_rotv(pg.c[j][k], d);
-    unsigned long long mask = near_mask(oc, O.npg, O.pg_reach);
+    unsigned long long mask = near_mask(oc, O.npg, O.pg_reach) & L.pg_active[o];
 #ifdef QEXP_PAIRS_NOLOOP
     mask = mask > (1ull << 62) ? 1 : 0;  // (tuning: the tests run, no pair reaches the exact stage)
 #endif
@@ -1567,7 +1628,7 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
       const QuadGeom& g2 = O.geom[O.pg_slot[j]];
       double c2[3], a2[3];
       pick3(oc, j, c2); pick3(oa, j, a2);
-      one(i, o, j, c2, a2, g2.type, g2.size[0], g2.type == MJPCX_GEOM_CAPSULE ? g2.size[1] : 0.0, ov[0], ov[1], ov[2], g2.link, g2.link + 1);
+      one(i, o, j, c2, a2, g2.type, g2.size[0], g2.type != MJPCX_GEOM_SPHERE ? g2.size[1] : 0.0, ov[0], ov[1], ov[2], g2.link, g2.link + 1);
     }
   }
 }
@@ -1810,6 +1871,8 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
   QUNROLL for (int j = 0; j < 3; j++) {
     R.fl_jar[j] = L.floss_b[j] * S.lv[j];  // -aref
     R.lm_side[j] = 0; R.lm_D[j] = 0; R.lm_jar[j] = 0;
+    // (geom pairs this kernel does not walk were proven apart for joints inside `guard`: beyond it the candidate goes to the kernel that walks them)
+    if (S.lq[j] < L.guard[j][0] || S.lq[j] > L.guard[j][1]) flags |= kFlagRange;
     if (L.limited[j]) {
       const double dlo = S.lq[j] - L.range[j][0], dhi = L.range[j][1] - S.lq[j];
       int side = 0; double dist = 0;

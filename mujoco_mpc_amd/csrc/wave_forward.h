@@ -87,6 +87,38 @@ __device__ __forceinline__ void wf_geom_pose(const MODEL& m, const WaveData& d, 
   q_mul(q, d.xquat + 4 * b, m.geom_quat + 4 * g);
   q2mat(mat, q);
 }
+// radius of a pair geom's bounding sphere about its centre (the pretest of the moving-geom pairs)
+template <class MODEL>
+__device__ __forceinline__ wreal wf_pair_bound(const MODEL& m, int g) {
+  const int t = m.geom_type[g];
+  const wreal s0 = m.geom_size[3 * g], s1 = m.geom_size[3 * g + 1], s2 = m.geom_size[3 * g + 2];
+  if (t == MJPCX_GEOM_CAPSULE) return s0 + s1;
+  if (t == MJPCX_GEOM_CYLINDER) return sqrt(s0 * s0 + s1 * s1);
+  if (t == MJPCX_GEOM_BOX) return sqrt(s0 * s0 + s1 * s1 + s2 * s2);
+  return s0;
+}
+// (sphere | capsule) g1 against the (box | cylinder) g2 at world poses (p1, R1), (p2, R2): oracle pair_thin_solid; one contact at most
+template <class MODEL>
+__device__ __forceinline__ int wf_thin_vs_solid(const MODEL& m, int g1, int g2, const wreal* p1, const wreal* R1, const wreal* p2, const wreal* R2, wreal margin,
+                                                wreal* cd, wreal* cp, wreal* cn) {
+  const wreal h = m.geom_type[g1] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g1 + 1] : WL(0.0), r = m.geom_size[3 * g1];
+  const wreal rel[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  wreal pl[3], al[3], n[3], c[3];
+  for (int k = 0; k < 3; k++) {
+    pl[k] = R2[k] * rel[0] + R2[3 + k] * rel[1] + R2[6 + k] * rel[2];
+    al[k] = R2[k] * R1[2] + R2[3 + k] * R1[5] + R2[6 + k] * R1[8];
+  }
+  const wreal size[3] = {m.geom_size[3 * g2], m.geom_size[3 * g2 + 1], m.geom_size[3 * g2 + 2]};
+  const wreal dist = solid::thin_vs_solid<wreal>(m.geom_type[g2] == MJPCX_GEOM_CYLINDER ? solid::kSolidCylinder : solid::kSolidBox, size, pl, al, h, r, n, c);
+  if (!(dist < margin)) return 0;
+  wreal loc[3], w[3];
+  for (int k = 0; k < 3; k++) loc[k] = c[k] + n[k] * (r + WL(0.5) * dist);
+  mv3(w, R2, loc);
+  for (int k = 0; k < 3; k++) cp[k] = p2[k] + w[k];
+  mv3(cn, R2, n);
+  cd[0] = dist;
+  return 1;
+}
 
 // ---- o_compos: subtree centres of mass, cinert, cdof
 template <class MODEL>
@@ -510,7 +542,7 @@ __device__ __forceinline__ void wf_collision(const MODEL& m, WaveData& d, int la
     }
     WSYNC();
   }
-  // moving-geom pairs (sphere | capsule; oracle: pair_collide): one lane per baked pair, up to two contacts each
+  // moving-geom pairs (sphere | capsule pairs, sphere | capsule against box | cylinder; oracle: pair_collide): one lane per baked pair, up to two contacts each
   for (int p0 = 0; p0 < m.npair; p0 += 64) {
     const bool on = p0 + lane < m.npair;
     const int g1 = on ? m.pair_g1[p0 + lane] : 0, g2 = on ? m.pair_g2[p0 + lane] : 0;
@@ -528,9 +560,7 @@ __device__ __forceinline__ void wf_collision(const MODEL& m, WaveData& d, int la
       mv3(v2, d.xmat + 9 * b2, m.geom_pos + 3 * g2);
       wreal dd = 0;
       for (int k = 0; k < 3; k++) { p1[k] = d.xpos[3 * b1 + k] + v1[k]; p2[k] = d.xpos[3 * b2 + k] + v2[k]; dd += (p1[k] - p2[k]) * (p1[k] - p2[k]); }
-      const wreal reach = m.geom_size[3 * g1] + m.geom_size[3 * g2] + margin + WL(1e-6) +
-                           (m.geom_type[g1] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g1 + 1] : WL(0.0)) +
-                           (m.geom_type[g2] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g2 + 1] : WL(0.0));
+      const wreal reach = wf_pair_bound(m, g1) + wf_pair_bound(m, g2) + margin + WL(1e-6);
       near = dd <= reach * reach;
     }
     if (__ballot(near) == 0ull) continue;
@@ -556,7 +586,9 @@ __device__ __forceinline__ void wf_collision(const MODEL& m, WaveData& d, int la
         const wreal x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
         return x < -h ? -h : (x > h ? h : x);
       };
-      if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
+      if (t2 == MJPCX_GEOM_CYLINDER || t2 == MJPCX_GEOM_BOX) {  // (sphere | capsule, box | cylinder): solid_pairs.h
+        cnt = wf_thin_vs_solid(m, g1, g2, p1, R1, p2, R2, margin, cd, cp[0], cn[0]);
+      } else if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
         spheres(p1, p2);
       } else if (t1 == MJPCX_GEOM_SPHERE) {
         const wreal a2[3] = {R2[2], R2[5], R2[8]};

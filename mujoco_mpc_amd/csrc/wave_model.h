@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/mjpcx.h"
+#include "pair_cull.h"
 
 namespace mjpcx {
 
@@ -115,6 +116,7 @@ struct WaveHost {
   std::vector<int> h_level_body, h_static_geom, h_dynamic_geom, h_ray_geom, h_term_off, h_res_term;
   void* dev_image = nullptr; void* dev_image32 = nullptr;  // LDS images of a registered model (fp64 / fp32)
   std::string warning;                                     // non-fatal findings of build() (reported through mjpcx_create_error after MJPCX_OK)
+  int pairs_apart = 0;                                     // moving-geom pairs dropped because they are proven never to touch (pair_cull.h)
   int registered = -1;                                     // index into the registered configurations, -1: generic kernels
   std::vector<double> state, mocap, weight, norm_p, norm_q, parameters, residual_real;
   std::vector<int32_t> residual_int, norm_types;
@@ -244,43 +246,34 @@ struct WaveHost {
       for (int w = src->tendon_adr[t]; w < src->tendon_adr[t] + src->tendon_num[t]; w++) tmask[t] |= 1u << src->jnt_dofadr[src->wrap_objid[w]];
     }
     reg(&m.tendon_dofmask, tmask.data(), sizeof(unsigned) * (size_t)nt);
-    // moving-geom pairs (sphere | capsule) after MuJoCo's body filters; canonical order = lower geom type first
+    // moving-geom pairs after MuJoCo's body filters (pair_cull.h: the list, each pair's class, the proofs); canonical order = lower geom
+    // type first. The kernels collide sphere | capsule pairs and (sphere | capsule) x (box | cylinder) pairs (solid_pairs.h).
     std::vector<int> pg1, pg2;
     int skipped_pairs = 0, skipped_a = -1, skipped_b = -1;
+    pairs_apart = 0;
     {
-      std::vector<int> weld(nb);  // (a caller that passes no body_weldid: every body is its own weld, as for a model without welds)
-      for (int b = 0; b < nb; b++) weld[b] = src->body_weldid ? src->body_weldid[b] : b;
       const bool contacts_on = !(src->disableflags & (MJPCX_DSBL_CONTACT | MJPCX_DSBL_CONSTRAINT));
-      for (int a = 0; a < ng; a++)
-        for (int b = a + 1; b < ng; b++) {
-          if (dofmask[src->geom_bodyid[a]] == 0 || dofmask[src->geom_bodyid[b]] == 0) continue;
-          if (!((src->geom_contype[a] & src->geom_conaffinity[b]) || (src->geom_contype[b] & src->geom_conaffinity[a]))) continue;
-          const int b1 = src->geom_bodyid[a], b2 = src->geom_bodyid[b];
-          const int w1 = weld[b1], w2 = weld[b2];
-          if (w1 == w2) continue;
-          const int pw1 = weld[src->body_parentid[w1]], pw2 = weld[src->body_parentid[w2]];
-          if (w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
-          const int sig = ((b1 < b2 ? b1 : b2) << 16) + (b1 < b2 ? b2 : b1);
-          bool excluded = false;
-          for (int e = 0; e < src->nexclude; e++) excluded |= src->exclude_signature[e] == sig;
-          if (excluded) continue;
-          // the pair passes MuJoCo's filters: it must be one the kernels collide, or the rollouts would silently run other physics
-          const int ta = src->geom_type[a], tb = src->geom_type[b];
-          if ((ta != MJPCX_GEOM_SPHERE && ta != MJPCX_GEOM_CAPSULE) || (tb != MJPCX_GEOM_SPHERE && tb != MJPCX_GEOM_CAPSULE)) {
-            // MuJoCo would hand this pair to its general convex collider (boxes, cylinders, ellipsoids, meshes). There is no device
-            // (or oracle) counterpart: the pair is left out, and create says so (mjpcx_create_error() after MJPCX_OK).
-            if (contacts_on && skipped_pairs++ == 0) { skipped_a = a; skipped_b = b; }
-            continue;
-          }
-          pg1.push_back(ta > tb ? b : a);
-          pg2.push_back(ta > tb ? a : b);
+      std::vector<char> moving(nb);
+      for (int b = 0; b < nb; b++) moving[b] = dofmask[b] != 0;
+      std::vector<MovingPair> mp;
+      moving_pairs(src, moving, contacts_on, mp);
+      for (const MovingPair& q : mp) {
+        if (q.kind == kPairThin || q.kind == kPairThinSolid) {  // (collided whether proven apart or not: these kernels have the narrow phase)
+          pg1.push_back(q.g1);
+          pg2.push_back(q.g2);
+          continue;
         }
+        if (q.kind == kPairSolids && q.apart && q.tight_jnt < 0) { pairs_apart++; continue; }
+        // two solids (or a geom type MuJoCo hands to its convex collider) that could not be proven apart: there is no device (or
+        // oracle) narrow phase; the pair is left out, and create says so (mjpcx_create_error() after MJPCX_OK).
+        if (contacts_on && skipped_pairs++ == 0) { skipped_a = q.g1; skipped_b = q.g2; }
+      }
     }
     warning.clear();
     if (skipped_pairs > 0)
-      warning = std::to_string(skipped_pairs) + " collidable geom pair(s) between two moving bodies involve a geom that is neither sphere nor capsule "
-                "(first: geoms " + std::to_string(skipped_a) + ", " + std::to_string(skipped_b) + ") and are NOT collided: MuJoCo's general convex collider has no "
-                "device counterpart (contacts with static geoms are unaffected)";
+      warning = std::to_string(skipped_pairs) + " collidable geom pair(s) between two moving bodies have no narrow phase here (two box | cylinder geoms that could not be "
+                "proven apart over the joint ranges, or a geom type other than sphere | capsule | cylinder | box; first: geoms " + std::to_string(skipped_a) + ", " +
+                std::to_string(skipped_b) + ") and are NOT collided (contacts with static geoms are unaffected)";
     m.npair = (int)pg1.size();
     reg(&m.pair_g1, pg1.data(), sizeof(int) * pg1.size());
     reg(&m.pair_g2, pg2.data(), sizeof(int) * pg2.size());

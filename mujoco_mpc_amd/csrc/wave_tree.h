@@ -320,7 +320,7 @@ __device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeDa
     for (int k = 0; k < 4; k++) for (int e = 0; e < 3; e++) cnk[k][e] = cn[e];
     wt_emit<4>(m, d, t, lane, cnt, cd, cp, cnk, g1, g2, m.geom_bodyid[g1], b2, com);
   }
-  // moving-geom pairs (sphere | capsule; oracle pair_collide): one lane per baked pair, up to two contacts each
+  // moving-geom pairs (sphere | capsule pairs, sphere | capsule against box | cylinder; oracle pair_collide): one lane per baked pair, up to two contacts each
   for (int p0 = 0; p0 < m.npair; p0 += 64) {
     const bool on = p0 + lane < m.npair;
     const int g1 = on ? m.pair_g1[p0 + lane] : 0, g2p = on ? m.pair_g2[p0 + lane] : 0;
@@ -336,9 +336,7 @@ __device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeDa
       mv3(v2, d.xmat + 9 * pb2, m.geom_pos + 3 * g2p);
       wreal dd = 0;
       for (int k = 0; k < 3; k++) { p1[k] = d.xpos[3 * pb1 + k] + v1[k]; q2[k] = d.xpos[3 * pb2 + k] + v2[k]; dd += (p1[k] - q2[k]) * (p1[k] - q2[k]); }
-      const wreal reach = m.geom_size[3 * g1] + m.geom_size[3 * g2p] + margin + WL(1e-6) +
-                           (m.geom_type[g1] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g1 + 1] : WL(0.0)) +
-                           (m.geom_type[g2p] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g2p + 1] : WL(0.0));
+      const wreal reach = wf_pair_bound(m, g1) + wf_pair_bound(m, g2p) + margin + WL(1e-6);
       near = dd <= reach * reach;
     }
     if (__ballot(near) == 0ull) continue;
@@ -365,7 +363,9 @@ __device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeDa
         return x < -h ? -h : (x > h ? h : x);
       };
       const int t2p = m.geom_type[g2p];
-      if (t1 == MJPCX_GEOM_SPHERE && t2p == MJPCX_GEOM_SPHERE) {
+      if (t2p == MJPCX_GEOM_CYLINDER || t2p == MJPCX_GEOM_BOX) {  // (sphere | capsule, box | cylinder): solid_pairs.h
+        cnt = wf_thin_vs_solid(m, g1, g2p, p1, R1, q2, R2p, margin, cd, cp[0], cn[0]);
+      } else if (t1 == MJPCX_GEOM_SPHERE && t2p == MJPCX_GEOM_SPHERE) {
         spheres(p1, q2);
       } else if (t1 == MJPCX_GEOM_SPHERE) {
         const wreal a2[3] = {R2p[2], R2p[5], R2p[8]};

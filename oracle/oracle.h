@@ -87,6 +87,9 @@ int odata_get(const OData* d, const char* name, double* out, int cap);
  * force_out[nefc] (may be NULL); returns the sweeps taken */
 int o_solve_pgs(OData* d, int max_sweeps, double tol, double* qacc_out, double* force_out);
 
+/* tests only: the narrow phase of a thin geom (sphere | capsule) against a solid (box | cylinder), in the solid's frame (contact.inc) */
+double thin_vs_solid(int is_cylinder, const double* size, const double* p, const double* a, double h, double r, double* n, double* c);
+
 /* residual dispatch (the ResidualFn::Residual overrides) */
 void oresidual(const mjpcx_task* task, const OData* d, double* residual);
 

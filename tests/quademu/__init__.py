@@ -17,7 +17,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_DIR, "libquademu.so")
-        srcs = [os.path.join(_DIR, "quademu.cc")] + [os.path.join(_DIR, "..", "..", "mujoco_mpc_amd", "csrc", f) for f in ("quad_step.h", "quad_model.h")]
+        srcs = [os.path.join(_DIR, "quademu.cc")] + [os.path.join(_DIR, "..", "..", "mujoco_mpc_amd", "csrc", f) for f in ("quad_step.h", "quad_model.h", "solid_pairs.h", "pair_cull.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-o", so, srcs[0]])
         L = C.CDLL(so)

@@ -96,27 +96,60 @@ def test_no_cpu_fallback_in_product():
 
 @pytest.mark.gpu
 def test_moving_geom_pairs_the_kernels_cannot_collide_are_reported():
-    """pairs MuJoCo would hand to its general convex collider (box / cylinder between two moving bodies) have no device or oracle
-    counterpart: they are left out and mjpcx_create says so instead of staying silent. The A1 has such pairs (trunk box and
-    cylinders against the legs' capsules); a model of spheres and capsules only (the humanoid) reports no such pair."""
-    from mujoco_mpc_amd.task import load_task
+    """Between two moving bodies the kernels (and the oracle) collide sphere | capsule pairs and (sphere | capsule) x (box | cylinder) pairs.
+    Two solids have no narrow phase: such a pair is dropped only if it is proven apart over the joint ranges (csrc/pair_cull.h), otherwise
+    it is left out and mjpcx_create says so instead of staying silent. The A1's 210 pairs with a box or a cylinder (the trunk's and the
+    hips' against the legs') are all collided or proven apart: no warning, and a strict caller gets its context. Two free boxes can
+    touch: reported, and refused under MJPCX_STRICT_PAIRS."""
+    from mujoco_mpc_amd import mjcf
+    from mujoco_mpc_amd.task import Task, load_task
     quad = load_task("QuadrupedFlat")
-    ctx = capi.Context(quad.packed_model(), quad.packed(), 0, 64)
-    assert "NOT collided" in ctx.create_warning and "neither sphere nor capsule" in ctx.create_warning
-    ctx.close()
-    # a strict caller gets an error instead of a context whose physics differs from the model's
     os.environ["MJPCX_STRICT_PAIRS"] = "1"
     try:
+        ctx = capi.Context(quad.packed_model(), quad.packed(), 0, 64)
+        assert ctx.create_warning == ""
+        ctx.close()
+        fm = mjcf.load_xml(os.path.join(ROOT, "tests", "models", "two_boxes.xml"))
+        task = Task(name="scene", residual_id=0, model=fm).reset()
         with pytest.raises(capi.MjpcxError) as err:
-            capi.Context(quad.packed_model(), quad.packed(), 0, 64)
+            capi.Context(task.packed_model(), task.packed(), 0, 64)
         assert "NOT collided" in str(err.value)
     finally:
         os.environ.pop("MJPCX_STRICT_PAIRS", None)
+    ctx = capi.Context(task.packed_model(), task.packed(), 0, 64)
+    assert "NOT collided" in ctx.create_warning and "no narrow phase" in ctx.create_warning
+    ctx.close()
     hum = load_task("HumanoidTrack")
     ctx = capi.Context(hum.packed_model(), hum.packed(), 0, 64)
     assert ctx.create_warning == ""   # nothing left uncollided, and the model has a registered kernel configuration (tree_registry.h)
     assert "rollout_tree_kernel<Humanoid>" in ctx.kernel_name
     ctx.close()
+
+
+def test_the_a1s_solid_pairs_are_collided_or_proven_apart():
+    """csrc/pair_cull.h on the north-star model (CPU build, tests/solidpairs): of the 474 geom pairs MuJoCo's filters leave between moving
+    bodies, 264 are sphere | capsule pairs, 201 pair a sphere | capsule with a box or a cylinder (146 proven apart with every joint 0.2 rad past
+    its range, 10 -- a calf or foot against the leg's own hip -- only with the knee held to 0.1 rad past its fold limit, 45 -- calves and feet
+    against other legs' hips -- not at all: those can touch) and 9 are two cylinders, all proven apart."""
+    import ctypes as C
+    from collections import Counter
+    from mujoco_mpc_amd.task import load_task
+    from tests import solidpairs
+    quad = load_task("QuadrupedFlat")
+    pm = quad.packed_model()
+    out = (C.c_int * (6 * 1024))()
+    n = solidpairs.lib().sp_moving_pairs(C.cast(pm.ptr, C.c_void_p), out, 1024)
+    rows = [tuple(out[6 * i:6 * i + 6]) for i in range(n)]
+    kinds = Counter((r[2], r[3], r[4] >= 0) for r in rows)
+    assert n == 474 and kinds == {(0, 0, False): 264, (1, 1, False): 146, (1, 1, True): 10, (1, 0, False): 45, (2, 1, False): 9}
+    a = quad.model.arrays
+    for g1, g2, kind, apart, tj, ts in rows:
+        if tj >= 0:   # the tight proofs: same leg, the knee's lower (fold) side
+            b1, b2 = int(a["geom_bodyid"][g1]), int(a["geom_bodyid"][g2])
+            assert (b1 - 4) // 3 == (b2 - 4) // 3 and ts == 0 and (tj - 1) % 3 == 2
+        if kind == 1 and not apart:
+            b1, b2 = int(a["geom_bodyid"][g1]), int(a["geom_bodyid"][g2])
+            assert (b1 - 4) // 3 != (b2 - 4) // 3 and (b1 - 4) % 3 == 2 and (b2 - 4) % 3 == 0   # a calf body's geom, another leg's hip
 
 
 def test_registered_tree_configs_match_the_shipped_models():

@@ -44,7 +44,7 @@ def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, t
         # reason by reason (every hand-on carries at least one reason; this workload has none that fills a contact list or goes non-finite)
         assert ctx.kernel_name.startswith("rollout_quad_kernel")
         st = ctx.quad_stats()
-        reasons = ("contact_list_full", "leg_leg_contact", "indefinite_hessian", "non_finite", "both_limits", "trunk_leg_contact")
+        reasons = ("contact_list_full", "leg_leg_contact", "indefinite_hessian", "non_finite", "both_limits", "trunk_leg_contact", "out_of_proof_range")
         assert 0 <= st["handed_on"] <= sum(st[r] for r in reasons) and st["handed_on"] <= N // 100
         assert st["contact_list_full"] == 0 and st["non_finite"] == 0 and st["leg_leg_contact"] == 0 and st["trunk_leg_contact"] == 0
     # (a) determinism

@@ -122,6 +122,9 @@ def test_one_contact_accelerates_a_free_ball_by_the_impedance_times_the_referenc
 def test_coulomb_threshold_and_rolling(deg, slides):
     th = np.radians(deg)
     fm, pm, ph = scene([9.81 * np.sin(th), 0, -9.81 * np.cos(th)])
+    q = fm.arrays["qpos0"].copy()
+    q[8] = 1.0  # the box: out of the rolling ball's way (the two collide since the sphere-box pair between moving bodies exists)
+    ph.set_state(q, np.zeros(fm.nv))
     for _ in range(500):  # 1 s
         ph.step()
     v = ph.get("qvel")
