@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __re
   if (a.wave_times && (threadIdx.x & 63) == 0) a.wave_times[4 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)] = __builtin_readcyclecounter() - wave_t0;
   if (flags && leg == 0 && stats) {
     atomicAdd(stats, 1);
-    QUNROLL for (int b = 0; b < 6; b++) if (flags & (1 << b)) atomicAdd(stats + 1 + b, 1);
+    QUNROLL for (int b = 0; b < 7; b++) if (flags & (1 << b)) atomicAdd(stats + 1 + b, 1);
   }
 }
 

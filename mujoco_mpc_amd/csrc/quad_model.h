@@ -63,6 +63,7 @@ struct QuadLeg {
   double jnt_pos[kQLinks][3], jnt_axis[kQLinks][3];
   double qpos0[kQLinks], qpos_spring[kQLinks], stiffness[kQLinks], armature[kQLinks], damping[kQLinks];
   double range[kQLinks][2], margin[kQLinks];
+  double self_box[kQLinks][2];  // joint values inside: the leg's own pairs (pg_active[own leg]) are proven apart and need no test (empty box: no proof)
   double guard[kQLinks][2];  // joint values outside [guard[j][0], guard[j][1]] leave the box the bake-time proofs of the dropped pairs cover (pair_cull.h)
   double lim_k[kQLinks], lim_b[kQLinks], lim_imp[kQLinks][5], lim_diag[kQLinks];
   double floss[kQLinks], floss_R[kQLinks], floss_D[kQLinks], floss_b[kQLinks];
@@ -72,6 +73,7 @@ struct QuadLeg {
   int ngeom, foot_slot, foot_index, npg;  // foot_slot: the leg's geom the residual reads; foot_index: its place in foot_geom_id_ (FL HL FR HR)
   int pg_slot[kQPairGeom];                // the leg's geoms that can touch another leg or the trunk (self-collision test)
   double pg_reach[kQPairGeom];              // radius of the pair geom's bounding sphere about its centre (capsule: radius + half length)
+  double pg_half[kQPairGeom], pg_rad[kQPairGeom];  // the leg-level cull's end spheres: half length along the axis, radius about each end (cylinder: 0, its bounding radius)
   unsigned long long pg_first[kQLegs + 1];  // per other leg (kQLegs: the trunk), bit 8 i + j: the own pair geom i is geom1 of the pair with the other's j
   unsigned long long pg_active[kQLegs + 1]; // bit 8 i + j: (own pair geom i, the other's j) is a pair MuJoCo's filters leave and pair_cull.h did not prove apart
   QuadGeom geom[kQLegGeom];
@@ -95,6 +97,7 @@ struct QuadModel {
   // over these sets (checked by quad_build); the kernel only tests them -- a pair within pair_margin hands the candidate on
   int ntpg, tpg_slot[kQTrunkPairGeom];
   double tpg_reach[kQTrunkPairGeom];  // bounding-sphere radii of the trunk's pair geoms (as QuadLeg::pg_reach)
+  double tpg_box[2][3];               // box of the trunk's pair geoms' bounding spheres in the trunk frame (lower, upper corner)
   double pair_margin;
   // friction sets of the contact pairs: regularised mu, then the tangential / torsional / rolling coefficient, ZERO for rows the pair's
   // condim does not have (the cone formulas then reduce to the lower condim's)
@@ -349,8 +352,9 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
     double pmargin = 0;
     std::vector<MovingPair> mp, plist;
     if (m->body_weldid) moving_pairs(m, moving, true, mp);
-    bool proofs = false;
+    bool proofs = false, self_unproven = false;
     std::vector<double> pad_lo(m->njnt, kPairCullPad), pad_hi(m->njnt, kPairCullPad);
+    std::vector<double> self_lo(m->njnt, kPairCullPad), self_hi(m->njnt, kPairCullPad);  // pads of the proofs of the WALKED pairs inside one leg
     for (const MovingPair& q : mp) {
       if (q.kind == kPairOther) continue;                                 // (no narrow phase anywhere: left out and reported by WaveHost::build)
       if (q.kind == kPairSolids && !(q.apart && q.tight_jnt < 0)) continue;  // (the same; the wave kernels drop two solids on the plain proof only)
@@ -371,6 +375,10 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
         continue;
       }
       if (why) return why;
+      if (slot_leg[q.g1] == slot_leg[q.g2]) {  // walked, yet proven apart inside some joint box: there the step function skips the test
+        if (!q.apart) self_unproven = true;
+        else if (q.tight_jnt >= 0) (q.tight_side == 0 ? self_lo : self_hi)[q.tight_jnt] = kPairCullPadTight;
+      }
       in_pair[q.g1] = in_pair[q.g2] = 1;
       plist.push_back(q);
       pmargin = std::max(pmargin, std::max(m->geom_margin[q.g1], m->geom_margin[q.g2]));
@@ -389,6 +397,9 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
         const bool on = proofs && m->jnt_limited[jid];
         qm->leg[l].guard[j][0] = on ? m->jnt_range[2 * jid] - pad_lo[jid] : -1e30;
         qm->leg[l].guard[j][1] = on ? m->jnt_range[2 * jid + 1] + pad_hi[jid] : 1e30;
+        const bool box = !self_unproven && m->jnt_limited[jid];
+        qm->leg[l].self_box[j][0] = box ? m->jnt_range[2 * jid] - self_lo[jid] : 1e30;
+        qm->leg[l].self_box[j][1] = box ? m->jnt_range[2 * jid + 1] + self_hi[jid] : -1e30;
       }
     auto pg_index = [&](int g) { const int l = slot_leg[g]; const int* sl = l < 0 ? qm->tpg_slot : qm->leg[l].pg_slot; const int n = l < 0 ? qm->ntpg : qm->leg[l].npg;
                                  for (int i = 0; i < n; i++) if (sl[i] == slot_idx[g]) return i; return -1; };
@@ -411,8 +422,23 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
   }
   {
     auto reach = [](const QuadGeom& g) { return g.type == MJPCX_GEOM_CAPSULE ? g.size[0] + g.size[1] : (g.type == MJPCX_GEOM_CYLINDER ? std::sqrt(g.size[0] * g.size[0] + g.size[1] * g.size[1]) : g.size[0]); };
-    for (int l = 0; l < kQLegs; l++) for (int i = 0; i < qm->leg[l].npg; i++) qm->leg[l].pg_reach[i] = reach(qm->leg[l].geom[qm->leg[l].pg_slot[i]]);
+    for (int l = 0; l < kQLegs; l++) for (int i = 0; i < qm->leg[l].npg; i++) {
+      const QuadGeom& g = qm->leg[l].geom[qm->leg[l].pg_slot[i]];
+      qm->leg[l].pg_reach[i] = reach(g);
+      qm->leg[l].pg_half[i] = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0;
+      qm->leg[l].pg_rad[i] = g.type == MJPCX_GEOM_CAPSULE ? g.size[0] : reach(g);
+    }
     for (int j = 0; j < qm->ntpg; j++) qm->tpg_reach[j] = reach(qm->trunk_geom[qm->tpg_slot[j]]);
+    for (int k = 0; k < 3; k++) { qm->tpg_box[0][k] = 1e30; qm->tpg_box[1][k] = -1e30; }
+    for (int j = 0; j < qm->ntpg; j++) {
+      const QuadGeom& g = qm->trunk_geom[qm->tpg_slot[j]];
+      const double half = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, rad = g.type == MJPCX_GEOM_CAPSULE ? g.size[0] : qm->tpg_reach[j];
+      for (int k = 0; k < 3; k++) {  // (the geom's axis in the trunk frame: the third column of its rotation)
+        const double ext = half * std::fabs(g.rot[3 * k + 2]) + rad;
+        qm->tpg_box[0][k] = std::min(qm->tpg_box[0][k], g.pos[k] - ext);
+        qm->tpg_box[1][k] = std::max(qm->tpg_box[1][k], g.pos[k] + ext);
+      }
+    }
   }
   qm->npair = qt->npair;
 

@@ -1404,233 +1404,299 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
   }
 }
 
+// (sphere | capsule, cylinder): solid_pairs.h in a frame built on the cylinder's axis (the solid is one of revolution: any frame about its
+// axis gives the same contact; oracle pair_thin_solid uses the geom's own). geo: thin geom's centre, axis; cylinder's centre, axis; the thin
+// geom's half length, radius. Returns the distance; res: world normal (thin geom -> cylinder), contact position.
+QNOINLINE double cylinder_contact(const double* geo_in, double r2, double h2, double* res_out) {
+  const auto* geo = QREBIND_PRIVATE(double, geo_in);
+  auto* res = QREBIND_PRIVATE(double, res_out);
+  const double p1[3] = {geo[0], geo[1], geo[2]}, a1[3] = {geo[3], geo[4], geo[5]}, p2[3] = {geo[6], geo[7], geo[8]}, a2[3] = {geo[9], geo[10], geo[11]};
+  const double h1 = geo[12], r1 = geo[13];
+  double e1[3], e2[3];
+  const bool yy = a2[1] < 0.5 && a2[1] > -0.5;
+  e1[0] = 0; e1[1] = yy ? 1.0 : 0.0; e1[2] = yy ? 0.0 : 1.0;
+  const double dt = a2[0] * e1[0] + a2[1] * e1[1] + a2[2] * e1[2];
+  for (int k = 0; k < 3; k++) e1[k] -= dt * a2[k];
+  const double nn = 1.0 / sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+  for (int k = 0; k < 3; k++) e1[k] *= nn;
+  cr3(e2, a2, e1);
+  const double rel[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const double pl[3] = {rel[0] * e1[0] + rel[1] * e1[1] + rel[2] * e1[2], rel[0] * e2[0] + rel[1] * e2[1] + rel[2] * e2[2], rel[0] * a2[0] + rel[1] * a2[1] + rel[2] * a2[2]};
+  const double al[3] = {a1[0] * e1[0] + a1[1] * e1[1] + a1[2] * e1[2], a1[0] * e2[0] + a1[1] * e2[1] + a1[2] * e2[2], a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]};
+  const double size[3] = {r2, h2, 0.0};
+  double nl[3], cl[3];
+  const double dist = solid::thin_vs_solid<double>(solid::kSolidCylinder, size, pl, al, h1, r1, nl, cl);
+  const double s = r1 + 0.5 * dist;
+  for (int k = 0; k < 3; k++) {
+    res[k] = nl[0] * e1[k] + nl[1] * e2[k] + nl[2] * a2[k];
+    res[3 + k] = p2[k] + (cl[0] + nl[0] * s) * e1[k] + (cl[1] + nl[1] * s) * e2[k] + (cl[2] + nl[2] * s) * a2[k];
+  }
+  return dist;
+}
+
 // Self-collision (oracle pair_collide over the baked moving-geom pairs): the cross product of the own leg's pair geoms with the trunk's
 // and with every other leg's (their centres / axes / link velocities arrive through quad rotations). Bounding spheres first, the exact
 // nearest points for the pairs that pass; a pair within its margin becomes a RELATIVE contact (QContact::rel) in the own lane's list --
 // and, for a leg-leg pair, identically in the partner's lane, which walks the same pair from its side with the same arithmetic (the two
 // geoms are always taken in MuJoCo's order: geom1 first). pmask collects 1 << (own leg xor partner leg) of the leg-leg contacts.
+// what the tests need of the lane's state: handed over in memory (the function is out of line: below)
+struct QPairArgs {
+  QPairGeoms pg;
+  double txpos[3], txm[9], com[3], cvel[3][6], cvelT[6];
+  int need;                      // bit 0: the trunk's pair geoms, bit 1: the own leg's pairs, bit 1 + d: the leg d lanes on (quad-uniform)
+  int ncon, flags, pmask, nrel;  // in / out
+};
+// Out of line and COMPACT: one instance of the bounding-sphere test, of the exact tests and of the contact's creation, in rolled loops over
+// arrays that live in memory and are indexed at run time. (Inlined into the forward pass and unrolled over the 8 x 8 grid of a partner the
+// stage was 30 % of the launch -- 52.7 -> 37.1 ms with the stage skipped at run time, same box -- although the north-star batch never
+// has a pair within reach: tens of kilobytes of cold straight-line code per step.) Called only at the steps at which the leg-level cull
+// (pair_contacts) leaves something to test for some candidate of the wavefront.
 template <class CS, class QProfT>
-QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const QPairGeoms& pg, const double* txpos, const double* txm, const double* com,
-                      const double cvel[3][6], const double* cvelT, CS& cs, int& ncon, int& flags, int& pmask, int& nrel, QProfT& pf) {
+QNOINLINE void pair_contacts_tests(const QuadModel& m_in, const QuadTables& tab, int leg, QPairArgs* args_in, CS cs, QProfT& pf_in) {
+  const QuadModel& m = QREBIND_LDS(QuadModel, m_in);
+  auto* args = QREBIND_PRIVATE(QPairArgs, args_in);
+  QProfT pf = pf_in;
+#ifdef QEXP_NEED_MASK
+  const int need = args->need & (QEXP_NEED_MASK);  // (tuning: which of the sources below the time goes to)
+#else
+  const int need = args->need;
+#endif
+  int ncon = args->ncon, flags = args->flags, pmask = args->pmask, nrel = args->nrel;
   const QuadLeg& L = m.leg[leg];
   const double mg = m.pair_margin;
-  // one pair: own geom (index i of the leg's pair geoms) against (other leg o or kQLegs = trunk, index j)
-  // (nothing of the pair's table record -- global memory -- is touched before a distance is below the largest margin: the order of the two
-  // geoms comes from the leg's bit mask, the record is read when a contact is created)
-  auto one = [&](int i, int o, int j, const double* oc, const double* oa, int otype, double orad, double ohalf, const double* ov0, const double* ov1, const double* ov2,
-                 int olink, int odepth) {
-    const QuadGeom& g = L.geom[L.pg_slot[i]];
-    const double r0 = g.size[0], h0 = g.type != MJPCX_GEOM_SPHERE ? g.size[1] : 0.0;  // (capsule, cylinder: half length)
-    double ci[3], ai[3];  // the own geom, picked from the register arrays (i is a run-time index here)
+  const double com[3] = {args->com[0], args->com[1], args->com[2]};
+  // The pretest of a pair: bounding spheres AND the boxes of the two geoms in the trunk's axes (a capsule's: half length along the axis plus
+  // the radius). In a gait the legs work close to each other and the bounding spheres of their long capsules overlap all the time -- 1.7
+  // exact tests per lane and step on the bench's batch, run in lock-step by the wavefront: that was the 14 ms of this stage -- while the
+  // boxes of two near-vertical capsules a hand apart do not. The own geoms' centres and half extents (trunk axes) in registers
+  // (compile-time indices only); everything indexed at run time lives in memory: the other side of the source being walked
+  // (world centres, axes, link velocities), fetched when a pair passes the pretest.
+  double xs[kQPairGeom][3], es[kQPairGeom][3], own_reach[kQPairGeom];
+  QUNROLL for (int i = 0; i < kQPairGeom; i++) {
+    const double rel[3] = {args->pg.c[i][0] - args->txpos[0], args->pg.c[i][1] - args->txpos[1], args->pg.c[i][2] - args->txpos[2]};
     QUNROLL for (int k = 0; k < 3; k++) {
-      // (0 / 1 weights, not a chain of selects: the optimiser folds `i == q ? arr[q] : ...` over the elements of one array into a load at a
-      // run-time index, and an array indexed at run time lives in scratch -- 72 doubles written and re-read every step before this)
-      double vc = 0, va = 0;
-      QUNROLL for (int q = 0; q < kQPairGeom; q++) { const double wq = i == q ? 1.0 : 0.0; vc += wq * pg.c[q][k]; va += wq * pg.a[q][k]; }
-      ci[k] = vc; ai[k] = va;
+      xs[i][k] = args->txm[k] * rel[0] + args->txm[3 + k] * rel[1] + args->txm[6 + k] * rel[2];  // (txm' rel)
+      es[i][k] = L.pg_half[i] * fabs(args->txm[k] * args->pg.a[i][0] + args->txm[3 + k] * args->pg.a[i][1] + args->txm[6 + k] * args->pg.a[i][2]) + L.pg_rad[i];
     }
-    const bool own_first = ((L.pg_first[o] >> (8 * i + j)) & 1) != 0;
-    // geom1 / geom2 in MuJoCo's order
-    const double* p1 = own_first ? ci : oc; const double* p2 = own_first ? oc : ci;
-    const double* a1 = own_first ? ai : oa; const double* a2 = own_first ? oa : ai;
-    const int t1 = own_first ? g.type : otype, t2 = own_first ? otype : g.type;
-    const double r1 = own_first ? r0 : orad, r2 = own_first ? orad : r0, h1 = own_first ? h0 : ohalf, h2 = own_first ? ohalf : h0;
-    const int sgn = own_first ? -1 : 1, depth = g.link + 1;
-    auto spheres = [&](const double* c1, const double* c2) {  // oracle sphere_vs_sphere -> add_contact; returns whether a contact was added
-      double n[3], len = 0, pos[3];
-      QUNROLL for (int k = 0; k < 3; k++) { n[k] = c2[k] - c1[k]; len += n[k] * n[k]; }
-      len = sqrt(len);
-      const double dist = len - r1 - r2;
-      if (!(dist < mg)) return false;
-      const QuadPair& P = tab.mm[leg][i][o][j];
-      if (!P.collide || !(dist < P.margin)) return false;
-      if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else { QUNROLL for (int k = 0; k < 3; k++) n[k] /= len; }
-      double vrel[6];  // J qvel of J = jac(body2) - jac(body1), about the centre of mass
-      QUNROLL for (int k = 0; k < 6; k++) {
-        const double vo = g.link == 0 ? cvel[0][k] : (g.link == 1 ? cvel[1][k] : cvel[2][k]);
-        const double vp = olink == 0 ? ov0[k] : (olink == 1 ? ov1[k] : ov2[k]);
-        vrel[k] = own_first ? vp - vo : vo - vp;
-      }
-      QUNROLL for (int k = 0; k < 3; k++) pos[k] = c1[k] + n[k] * (r1 + 0.5 * dist);
-      const int before = ncon;
-#ifdef QEXP_PAIRS_DRY
-      if (dist > -1e30) return false;
-#endif
-      add_contact(P, com, vrel, depth, dist, pos, n, cs, ncon, flags, 1, sgn, odepth, o < kQLegs ? (leg ^ o) : 0);
-      if (ncon > before) { nrel++; if (o < kQLegs) pmask |= 1 << (leg ^ o); }
-      return true;
-    };
-    auto seg = [](const double* p, const double* a, double h, const double* c) {
-      const double x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
-      return x < -h ? -h : (x > h ? h : x);
-    };
-    double c1[3], c2[3];
-    if (t2 == MJPCX_GEOM_CYLINDER) {
-      // (sphere | capsule, cylinder) -- a calf or foot against another leg's hip: solid_pairs.h in a frame built on the cylinder's axis
-      // (the solid is one of revolution: any frame about its axis gives the same contact; oracle pair_thin_solid uses the geom's own)
-      if (t1 == MJPCX_GEOM_CYLINDER) return;  // (two solids: proven apart at bake time or reported, never walked)
-      double e1[3], e2[3];
-      { const bool yy = a2[1] < 0.5 && a2[1] > -0.5;
-        e1[0] = 0; e1[1] = yy ? 1.0 : 0.0; e1[2] = yy ? 0.0 : 1.0;
-        const double dt = a2[0] * e1[0] + a2[1] * e1[1] + a2[2] * e1[2];
-        QUNROLL for (int k = 0; k < 3; k++) e1[k] -= dt * a2[k];
-        const double nn = 1.0 / sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
-        QUNROLL for (int k = 0; k < 3; k++) e1[k] *= nn;
-        cr3(e2, a2, e1); }
-      const double rel[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-      const double pl[3] = {rel[0] * e1[0] + rel[1] * e1[1] + rel[2] * e1[2], rel[0] * e2[0] + rel[1] * e2[1] + rel[2] * e2[2], rel[0] * a2[0] + rel[1] * a2[1] + rel[2] * a2[2]};
-      const double al[3] = {a1[0] * e1[0] + a1[1] * e1[1] + a1[2] * e1[2], a1[0] * e2[0] + a1[1] * e2[1] + a1[2] * e2[2], a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]};
-      const double size[3] = {r2, h2, 0.0};
-      double nl[3], cl[3];
-      const double dist = solid::thin_vs_solid<double>(solid::kSolidCylinder, size, pl, al, t1 == MJPCX_GEOM_CAPSULE ? h1 : 0.0, r1, nl, cl);
-      if (!(dist < mg)) return;
-      const QuadPair& P = tab.mm[leg][i][o][j];
-      if (!P.collide || !(dist < P.margin)) return;
-      double n[3], pos[3], vrel[6];
-      QUNROLL for (int k = 0; k < 3; k++) {
-        n[k] = nl[0] * e1[k] + nl[1] * e2[k] + nl[2] * a2[k];
-        const double s = r1 + 0.5 * dist;
-        pos[k] = p2[k] + (cl[0] + nl[0] * s) * e1[k] + (cl[1] + nl[1] * s) * e2[k] + (cl[2] + nl[2] * s) * a2[k];
-      }
-      QUNROLL for (int k = 0; k < 6; k++) {
-        const double vo = g.link == 0 ? cvel[0][k] : (g.link == 1 ? cvel[1][k] : cvel[2][k]);
-        const double vp = olink == 0 ? ov0[k] : (olink == 1 ? ov1[k] : ov2[k]);
-        vrel[k] = own_first ? vp - vo : vo - vp;
-      }
-      const int before = ncon;
-      add_contact(P, com, vrel, depth, dist, pos, n, cs, ncon, flags, 1, sgn, odepth, o < kQLegs ? (leg ^ o) : 0, o == leg ? 1 : 0);
-      if (ncon > before) { nrel++; if (o < kQLegs && o != leg) pmask |= 1 << (leg ^ o); }
-      return;
-    }
-    if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) { (void)spheres(p1, p2); return; }
-    if (t1 == MJPCX_GEOM_SPHERE) {  // (sphere, capsule): spheres come first in MuJoCo's order
-      const double x = seg(p2, a2, h2, p1);
-      QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + x * a2[k];
-      (void)spheres(p1, c2);
-      return;
-    }
-    const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    const double mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
-    const double u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
-    const double v = a2[0] * dif[0] + a2[1] * dif[1] + a2[2] * dif[2];
-    const double det = 1.0 - mb * mb;
-    if (fabs(det) >= kQMinVal) {
-      double x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
-      if (x1 > h1) { x1 = h1; x2 = v - mb * x1; } else if (x1 < -h1) { x1 = -h1; x2 = v - mb * x1; }
-      if (x2 > h2) { x2 = h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
-      else if (x2 < -h2) { x2 = -h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
-      QUNROLL for (int k = 0; k < 3; k++) { c1[k] = p1[k] + x1 * a1[k]; c2[k] = p2[k] + x2 * a2[k]; }
-      (void)spheres(c1, c2);
-    } else {  // parallel: the ends of capsule 1 against axis 2, then the ends of capsule 2 against axis 1, two contacts at most
-      int added = 0;
-      for (int e = 0; e < 4 && added < 2; e++) {
-        const double sg = (e & 1) ? -1.0 : 1.0;
-        if (e < 2) {
-          QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + sg * h1 * a1[k];
-          const double x2 = seg(p2, a2, h2, c1);
-          QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + x2 * a2[k];
-        } else {
-          QUNROLL for (int k = 0; k < 3; k++) c2[k] = p2[k] + sg * h2 * a2[k];
-          const double x1 = seg(p1, a1, h1, c2);
-          QUNROLL for (int k = 0; k < 3; k++) c1[k] = p1[k] + x1 * a1[k];
-        }
-        if (spheres(c1, c2)) added++;
-      }
-    }
-  };
-  // Bounding-sphere tests are straight-line code over the compile-time (i, j) grid and only set bits; the pairs that pass (rare) are then
-  // walked in a run-time loop, their geoms picked from the register arrays by select chains -- ONE instance of the exact test per
-  // partner instead of one per (i, j).
-  auto pick3 = [](const double (*arr)[3], int idx, double* out) {
-    QUNROLL for (int k = 0; k < 3; k++) {
-      double v = 0;
-      QUNROLL for (int q = 0; q < kQPairGeom; q++) v += (idx == q ? 1.0 : 0.0) * arr[q][k];  // (weights, not selects: see `one`)
-      out[k] = v;
-    }
-  };
-  double own_reach[kQPairGeom];
-  QUNROLL for (int i = 0; i < kQPairGeom; i++) own_reach[i] = L.pg_reach[i] + mg;
-  auto near_mask = [&](const double (*oc)[3], int on, const double* oreach) {  // bit 8 * i + j: pair (own i, other j) may touch (the caller keeps the pairs that exist)
+    own_reach[i] = L.pg_reach[i] + mg;
+  }
+  const double bmg = mg + 1e-9;
+  double oc[kQPairGeom][3], oa[kQPairGeom][3], ov[3][6];
+  for (int src = 0; src < 5; src++) {  // 0: the trunk's pair geoms, 1: the own leg (its cylinders), 2..4: the leg d = src - 1 lanes on
+    const bool mine = ((need >> src) & 1) != 0;
+    if (qd_or(mine ? 1 : 0) == 0) continue;  // (quad-uniform; the bits of the other legs are quad-uniform themselves)
+    const int d = src - 1, o = src == 0 ? kQLegs : (src == 1 ? leg : ((leg + d) & 3));
+    const int on = !mine ? 0 : (src == 0 ? m.ntpg : m.leg[o & 3].npg);
+    // the pretest: a ROLLED loop over the other side's geoms (centre and half extents of geom j arrive -- through the quad rotation for
+    // another leg -- and meet the eight own geoms in registers): a hundred instructions instead of the 8 x 8 grid unrolled
     unsigned long long mask = 0;
-    QUNROLL for (int j = 0; j < kQPairGeom; j++) {
+    for (int j = 0; j < (src == 0 ? kQTrunkPairGeom : kQPairGeom); j++) {
+      double xj[3], ej[3];
+      if (src == 0) {  // (a trunk geom: constant in the trunk's axes)
+        const QuadGeom& g = m.trunk_geom[m.tpg_slot[j < m.ntpg ? j : 0]];
+        const double half = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, rad = g.type == MJPCX_GEOM_CAPSULE ? g.size[0] : g.bound;
+        QUNROLL for (int k = 0; k < 3; k++) { xj[k] = g.pos[k]; ej[k] = half * fabs(g.rot[3 * k + 2]) + rad; }
+      } else {
+        QUNROLL for (int k = 0; k < 3; k++) {  // (the own geom j by 0 / 1 weights: a run-time index would put the arrays in memory)
+          double vx = 0, ve = 0;
+          QUNROLL for (int q = 0; q < kQPairGeom; q++) { const double w = j == q ? 1.0 : 0.0; vx += w * xs[q][k]; ve += w * es[q][k]; }
+          xj[k] = src == 1 ? vx : qd_rotv(vx, d);
+          ej[k] = src == 1 ? ve : qd_rotv(ve, d);
+        }
+      }
       if (j >= on) continue;
-      const double reach2 = oreach[j];
+      const double oreach = src == 0 ? m.tpg_reach[j] : m.leg[o & 3].pg_reach[j];
       QUNROLL for (int i = 0; i < kQPairGeom; i++) {
-        if (i >= L.npg) continue;
-        const double reach = own_reach[i] + reach2;
-        const double dx = pg.c[i][0] - oc[j][0], dy = pg.c[i][1] - oc[j][1], dz = pg.c[i][2] - oc[j][2];
-        if (dx * dx + dy * dy + dz * dz < reach * reach) mask |= 1ull << (8 * i + j);
+        const double reach = own_reach[i] + oreach;
+        const double dx = xs[i][0] - xj[0], dy = xs[i][1] - xj[1], dz = xs[i][2] - xj[2];
+        const bool boxes = fabs(dx) < es[i][0] + ej[0] + bmg && fabs(dy) < es[i][1] + ej[1] + bmg && fabs(dz) < es[i][2] + ej[2] + bmg;
+        if (i < L.npg && boxes && dx * dx + dy * dy + dz * dz < reach * reach) mask |= 1ull << (8 * i + j);
       }
     }
-    return mask;
-  };
-  // the trunk's pair geoms
-  {
-    double tc[kQPairGeom][3], ta[kQPairGeom][3];
-    QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++) { tc[j][k] = 0; ta[j][k] = 0; }
-    QUNROLL for (int j = 0; j < kQTrunkPairGeom; j++) {
-      if (j >= m.ntpg) continue;
-      const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
-      double c[3];
-      mv3(c, txm, g.pos);
-      QUNROLL for (int k = 0; k < 3; k++) { tc[j][k] = c[k] + txpos[k]; ta[j][k] = txm[3 * k] * g.rot[2] + txm[3 * k + 1] * g.rot[5] + txm[3 * k + 2] * g.rot[8]; }
+    mask &= L.pg_active[o];
+    if (src >= 2) {
+      if (qd_or(mask != 0 ? 1 : 0) == 0) continue;  // (quad-uniform: the axes and velocities are only fetched for a partner that is near)
+      for (int j = 0; j < kQPairGeom; j++) for (int k = 0; k < 3; k++) { oc[j][k] = qd_rotv(args->pg.c[j][k], d); oa[j][k] = qd_rotv(args->pg.a[j][k], d); }
+      for (int j = 0; j < 3; j++) for (int k = 0; k < 6; k++) ov[j][k] = qd_rotv(args->cvel[j][k], d);
+      QPROF_COUNT(pf, 45, 1);
+    } else if (mask != 0) {
+      if (src == 0) {
+        for (int j = 0; j < m.ntpg; j++) {
+          const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
+          for (int k = 0; k < 3; k++) {
+            oc[j][k] = args->txm[3 * k] * g.pos[0] + args->txm[3 * k + 1] * g.pos[1] + args->txm[3 * k + 2] * g.pos[2] + args->txpos[k];
+            oa[j][k] = args->txm[3 * k] * g.rot[2] + args->txm[3 * k + 1] * g.rot[5] + args->txm[3 * k + 2] * g.rot[8];
+          }
+        }
+        for (int j = 0; j < 3; j++) for (int k = 0; k < 6; k++) ov[j][k] = args->cvelT[k];
+      } else {
+        for (int j = 0; j < kQPairGeom; j++) for (int k = 0; k < 3; k++) { oc[j][k] = args->pg.c[j][k]; oa[j][k] = args->pg.a[j][k]; }
+        for (int j = 0; j < 3; j++) for (int k = 0; k < 6; k++) ov[j][k] = args->cvel[j][k];
+      }
     }
-    double treach[kQPairGeom];
-    QUNROLL for (int j = 0; j < kQPairGeom; j++) treach[j] = 0;
-    QUNROLL for (int j = 0; j < kQTrunkPairGeom; j++) treach[j] = m.tpg_reach[j];
-    unsigned long long mask = near_mask(tc, m.ntpg, treach) & L.pg_active[kQLegs];
-    while (mask) {
-      QPROF_COUNT(pf, 43, 1);
+    while (mask) {  // (ascending bits: own geom first, then the other's -- the order contacts are created in)
       const int bit = __builtin_ctzll(mask);
       mask &= mask - 1;
       const int i = bit >> 3, j = bit & 7;
-      const QuadGeom& g = m.trunk_geom[m.tpg_slot[j]];
-      double c[3], a[3];
-      pick3(tc, j, c); pick3(ta, j, a);
-      one(i, kQLegs, j, c, a, g.type, g.size[0], g.type != MJPCX_GEOM_SPHERE ? g.size[1] : 0.0, cvelT, cvelT, cvelT, 0, 0);
-    }
-  }
-  // the own leg's cylinders (a calf or the foot against the leg's own hip: a contact inside the lane, QContact::self)
-  if (L.pg_active[leg] != 0) {
-    unsigned long long mask = near_mask(pg.c, L.npg, L.pg_reach) & L.pg_active[leg];
-    while (mask) {
-      const int bit = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const int i = bit >> 3, j = bit & 7;
-      const QuadGeom& g2 = L.geom[L.pg_slot[j]];
-      double c2[3], a2[3];
-      pick3(pg.c, j, c2); pick3(pg.a, j, a2);
-      one(i, leg, j, c2, a2, g2.type, g2.size[0], g2.type != MJPCX_GEOM_SPHERE ? g2.size[1] : 0.0, cvel[0], cvel[1], cvel[2], g2.link, g2.link + 1);
-    }
-  }
-  // the other three legs
-  for (int d = 1; d <= 3; d++) {  // (a rolled loop: ONE instance of the tests below; the partner's values come through qd_rotv, a run-time rotation)
-    const int o = (leg + d) & 3;
-    const QuadLeg& O = m.leg[o];
-    double oc[kQPairGeom][3];
-    QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++)
-      oc[j][k] = qd_rotv(pg.c[j][k], d);
-    unsigned long long mask = near_mask(oc, O.npg, O.pg_reach) & L.pg_active[o];
-#ifdef QEXP_PAIRS_NOLOOP
-    mask = mask > (1ull << 62) ? 1 : 0;  // (tuning: the tests run, no pair reaches the exact stage)
+      {
+        const QuadGeom& g = L.geom[L.pg_slot[i]];
+        const double ci[3] = {args->pg.c[i][0], args->pg.c[i][1], args->pg.c[i][2]}, ai[3] = {args->pg.a[i][0], args->pg.a[i][1], args->pg.a[i][2]};
+        const double r0 = g.size[0], h0 = g.type != MJPCX_GEOM_SPHERE ? g.size[1] : 0.0;  // (capsule, cylinder: half length)
+        const QuadGeom& g2 = o == kQLegs ? m.trunk_geom[m.tpg_slot[j]] : m.leg[o & 3].geom[m.leg[o & 3].pg_slot[j]];
+        QPROF_COUNT(pf, src == 0 ? 43 : 44, 1);
+        // ---- the exact test of one pair: own geom (index i of the leg's pair geoms) against (other leg o or kQLegs = trunk, index j).
+        // (Nothing of the pair's table record -- global memory -- is touched before a distance is below the largest margin: the order of the
+        // two geoms comes from the leg's bit mask, the record is read when a contact is created.)
+        const int otype = g2.type, olink = o == kQLegs ? 0 : g2.link, odepth = o == kQLegs ? 0 : g2.link + 1;
+        const double orad = g2.size[0], ohalf = g2.type != MJPCX_GEOM_SPHERE ? g2.size[1] : 0.0;
+        const bool own_first = ((L.pg_first[o] >> (8 * i + j)) & 1) != 0;
+        // geom1 / geom2 in MuJoCo's order
+        double p1[3], p2[3], a1[3], a2[3];
+        for (int k = 0; k < 3; k++) { p1[k] = own_first ? ci[k] : oc[j][k]; p2[k] = own_first ? oc[j][k] : ci[k]; a1[k] = own_first ? ai[k] : oa[j][k]; a2[k] = own_first ? oa[j][k] : ai[k]; }
+        const int t1 = own_first ? g.type : otype, t2 = own_first ? otype : g.type;
+        const double r1 = own_first ? r0 : orad, r2 = own_first ? orad : r0, h1 = own_first ? h0 : ohalf, h2 = own_first ? ohalf : h0;
+        const int sgn = own_first ? -1 : 1, depth = g.link + 1;
+        // up to four candidate point pairs (centres of the two balls the contact reduces to), of which at most `limit` become contacts
+        double q1[4][3], q2[4][3], qn[3] = {0, 0, 0}, qpos[3] = {0, 0, 0}, qdist = 0;
+        int nq = 0, limit = 1;
+        bool direct = false;  // (a cylinder: the contact comes whole from solid_pairs.h)
+        auto seg = [](const double* p, const double* a, double h, const double* c) {
+          const double x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
+          return x < -h ? -h : (x > h ? h : x);
+        };
+        if (t2 == MJPCX_GEOM_CYLINDER) {
+          // (sphere | capsule, cylinder) -- a calf or foot against a hip (two solids: proven apart at bake time or reported, never walked)
+          if (t1 == MJPCX_GEOM_CYLINDER) continue;
+          double geo[14] = {p1[0], p1[1], p1[2], a1[0], a1[1], a1[2], p2[0], p2[1], p2[2], a2[0], a2[1], a2[2], t1 == MJPCX_GEOM_CAPSULE ? h1 : 0.0, r1};
+          double res[6];
+          qdist = cylinder_contact(geo, r2, h2, res);
+          for (int k = 0; k < 3; k++) { qn[k] = res[k]; qpos[k] = res[3 + k]; }
+          direct = true; nq = 1;
+        } else if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
+          for (int k = 0; k < 3; k++) { q1[0][k] = p1[k]; q2[0][k] = p2[k]; }
+          nq = 1;
+        } else if (t1 == MJPCX_GEOM_SPHERE) {  // (sphere, capsule): spheres come first in MuJoCo's order
+          const double x = seg(p2, a2, h2, p1);
+          for (int k = 0; k < 3; k++) { q1[0][k] = p1[k]; q2[0][k] = p2[k] + x * a2[k]; }
+          nq = 1;
+        } else {
+          const double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+          const double mb = -(a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2]);
+          const double u = -(a1[0] * dif[0] + a1[1] * dif[1] + a1[2] * dif[2]);
+          const double v = a2[0] * dif[0] + a2[1] * dif[1] + a2[2] * dif[2];
+          const double det = 1.0 - mb * mb;
+          if (fabs(det) >= kQMinVal) {
+            double x1 = (u - mb * v) / det, x2 = (v - mb * u) / det;
+            if (x1 > h1) { x1 = h1; x2 = v - mb * x1; } else if (x1 < -h1) { x1 = -h1; x2 = v - mb * x1; }
+            if (x2 > h2) { x2 = h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
+            else if (x2 < -h2) { x2 = -h2; x1 = u - mb * x2; x1 = x1 > h1 ? h1 : (x1 < -h1 ? -h1 : x1); }
+            for (int k = 0; k < 3; k++) { q1[0][k] = p1[k] + x1 * a1[k]; q2[0][k] = p2[k] + x2 * a2[k]; }
+            nq = 1;
+          } else {  // parallel: the ends of capsule 1 against axis 2, then the ends of capsule 2 against axis 1, two contacts at most
+            for (int e = 0; e < 4; e++) {
+              const double sg = (e & 1) ? -1.0 : 1.0;
+              if (e < 2) {
+                for (int k = 0; k < 3; k++) q1[e][k] = p1[k] + sg * h1 * a1[k];
+                const double x2 = seg(p2, a2, h2, q1[e]);
+                for (int k = 0; k < 3; k++) q2[e][k] = p2[k] + x2 * a2[k];
+              } else {
+                for (int k = 0; k < 3; k++) q2[e][k] = p2[k] + sg * h2 * a2[k];
+                const double x1 = seg(p1, a1, h1, q2[e]);
+                for (int k = 0; k < 3; k++) q1[e][k] = p1[k] + x1 * a1[k];
+              }
+            }
+            nq = 4; limit = 2;
+          }
+        }
+        int added = 0;
+        for (int e = 0; e < nq && added < limit; e++) {  // oracle sphere_vs_sphere -> add_contact
+          double n[3], pos[3], dist;
+          double len = 0;
+          if (direct) { dist = qdist; for (int k = 0; k < 3; k++) { n[k] = qn[k]; pos[k] = qpos[k]; } }
+          else {
+            for (int k = 0; k < 3; k++) { n[k] = q2[e][k] - q1[e][k]; len += n[k] * n[k]; }
+            len = sqrt(len);
+            dist = len - r1 - r2;
+          }
+          if (!(dist < mg)) continue;
+          const QuadPair& P = tab.mm[leg][i][o][j];
+          if (!P.collide || !(dist < P.margin)) continue;
+          if (!direct) {
+            if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else { for (int k = 0; k < 3; k++) n[k] /= len; }
+            for (int k = 0; k < 3; k++) pos[k] = q1[e][k] + n[k] * (r1 + 0.5 * dist);
+          }
+          double vrel[6];  // J qvel of J = jac(body2) - jac(body1), about the centre of mass
+          for (int k = 0; k < 6; k++) {
+            const double vo = args->cvel[g.link][k], vp = ov[olink][k];
+            vrel[k] = own_first ? vp - vo : vo - vp;
+          }
+          const int before = ncon;
+#ifdef QEXP_PAIRS_DRY
+          if (dist > -1e30) continue;
 #endif
-    if (qd_or(mask != 0 ? 1 : 0) == 0) continue;  // (quad-uniform: the axes and velocities are only fetched for a partner that is near)
-    double oa[kQPairGeom][3], ov[3][6];
-    QUNROLL for (int j = 0; j < kQPairGeom; j++) QUNROLL for (int k = 0; k < 3; k++)
-      oa[j][k] = qd_rotv(pg.a[j][k], d);
-    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) ov[j][k] = qd_rotv(cvel[j][k], d);
-    QPROF_COUNT(pf, 45, 1);
-    while (mask) {
-      QPROF_COUNT(pf, 44, 1);
-      const int bit = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const int i = bit >> 3, j = bit & 7;
-      const QuadGeom& g2 = O.geom[O.pg_slot[j]];
-      double c2[3], a2[3];
-      pick3(oc, j, c2); pick3(oa, j, a2);
-      one(i, o, j, c2, a2, g2.type, g2.size[0], g2.type != MJPCX_GEOM_SPHERE ? g2.size[1] : 0.0, ov[0], ov[1], ov[2], g2.link, g2.link + 1);
+          add_contact(P, com, vrel, depth, dist, pos, n, cs, ncon, flags, 1, sgn, odepth, o < kQLegs ? (leg ^ o) : 0, o == leg ? 1 : 0);
+          if (ncon > before) { nrel++; if (o < kQLegs && o != leg) pmask |= 1 << (leg ^ o); }
+          added++;
+        }
+      }
     }
   }
+  args->ncon = ncon; args->flags = flags; args->pmask = pmask; args->nrel = nrel;
+  pf_in = pf;
+}
+
+// The leg-level cull, exact: the box of the leg's pair geoms in the trunk's axes -- of their end spheres (a capsule's or cylinder's two ends,
+// the radius about each; a cylinder's rim lies within its bounding sphere's radius of the axis ends' midpoint, so it takes the bounding
+// sphere). Two geoms whose bounding volumes come within the margin have boxes that overlap (by more than -margin) on every axis, so a
+// partner (another leg; the trunk's pair geoms: a constant box; the own leg: a joint box, pair_cull.h) whose box is clear on some axis
+// needs no test. In a gait that is every partner at nearly every step; the tests themselves are out of line (pair_contacts_tests).
+template <class CS, class QProfT>
+QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const QPairGeoms& pg, const double* txpos, const double* txm, const double* com,
+                      const double cvel[3][6], const double* cvelT, bool self_walk, CS& cs, int& ncon, int& flags, int& pmask, int& nrel, QProfT& pf) {
+  const QuadLeg& L = m.leg[leg];
+  const double mg = m.pair_margin;
+#ifdef QEXP_PAIRS_SKIP
+  if (mg > -1.0) return;  // (tuning: what a perfect cull of the self-collision stage would save; the solver keeps its self-collision paths)
+#endif
+  double blo[3], bhi[3], tlo[3], thi[3];  // the box of all the leg's pair geoms; of those that pair with a trunk geom (not the hip's)
+  QUNROLL for (int k = 0; k < 3; k++) { blo[k] = tlo[k] = 1e30; bhi[k] = thi[k] = -1e30; }
+  QUNROLL for (int i = 0; i < kQPairGeom; i++) {
+    const double rel[3] = {pg.c[i][0] - txpos[0], pg.c[i][1] - txpos[1], pg.c[i][2] - txpos[2]};
+    const double out = i < L.npg ? 0.0 : 1e30;  // (an empty slot stays out of the box)
+    const double outT = ((L.pg_active[kQLegs] >> (8 * i)) & 0xffull) != 0 ? 0.0 : 1e30;
+    QUNROLL for (int k = 0; k < 3; k++) {
+      const double x = txm[k] * rel[0] + txm[3 + k] * rel[1] + txm[6 + k] * rel[2];        // (txm' rel)
+      const double ax = txm[k] * pg.a[i][0] + txm[3 + k] * pg.a[i][1] + txm[6 + k] * pg.a[i][2];
+      const double ext = L.pg_half[i] * fabs(ax) + L.pg_rad[i];                                  // half length along the axis, then the end sphere
+      blo[k] = fmin(blo[k], x - ext + out); bhi[k] = fmax(bhi[k], x + ext - out);
+      tlo[k] = fmin(tlo[k], x - ext + outT); thi[k] = fmax(thi[k], x + ext - outT);
+    }
+  }
+  const double bmg = mg + 1e-9;
+  bool trunk_near = L.pg_active[kQLegs] != 0;
+  QUNROLL for (int k = 0; k < 3; k++) trunk_near = trunk_near && !(tlo[k] > m.tpg_box[1][k] + bmg) && !(m.tpg_box[0][k] > thi[k] + bmg);
+  int need = (trunk_near ? 1 : 0) | ((L.pg_active[leg] != 0 && self_walk) ? 2 : 0);
+  QUNROLL for (int d = 1; d <= 3; d++) {
+    bool apart = false;
+    QUNROLL for (int k = 0; k < 3; k++) {
+      const double olo = qd_rotv(blo[k], d), ohi = qd_rotv(bhi[k], d);
+      apart = apart || blo[k] > ohi + bmg || olo > bhi[k] + bmg;
+    }
+    need |= qd_or(apart ? 0 : 1) << (1 + d);  // (quad-uniform: clear only if all four (leg, leg + d) pairs are)
+  }
+  if (qd_or(need) == 0) return;
+#ifdef QEXP_PAIRS_SKIP2
+  if (mg > -1.0) return;  // (tuning: the leg-level cull runs, the tests never do)
+#endif
+  QPairArgs args;
+  QUNROLL for (int i = 0; i < kQPairGeom; i++) QUNROLL for (int k = 0; k < 3; k++) { args.pg.c[i][k] = pg.c[i][k]; args.pg.a[i][k] = pg.a[i][k]; }
+  QUNROLL for (int k = 0; k < 3; k++) { args.txpos[k] = txpos[k]; args.com[k] = com[k]; }
+  QUNROLL for (int k = 0; k < 9; k++) args.txm[k] = txm[k];
+  QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) args.cvel[j][k] = cvel[j][k];
+  QUNROLL for (int k = 0; k < 6; k++) args.cvelT[k] = cvelT[k];
+  args.need = need; args.ncon = ncon; args.flags = flags; args.pmask = pmask; args.nrel = nrel;
+  pair_contacts_tests(m, tab, leg, &args, cs, pf);
+  ncon = args.ncon; flags = args.flags; pmask = args.pmask; nrel = args.nrel;
 }
 
 // ---------------------------------------------------------------- mj_forward (oracle o_forward) for the lane's share of one candidate
@@ -1856,7 +1922,10 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     QPROF(pf, 2);
     int pmask = 0, nrel = 0;
 #ifndef QEXP_NOPAIRS
-    pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, cs, ncon, flags, pmask, nrel, pf);
+    // (the leg's own pairs -- a calf or foot on its hip -- are proven apart inside a joint box: pair_cull.h)
+    const bool self_walk = !(S.lq[0] >= L.self_box[0][0] && S.lq[0] <= L.self_box[0][1] && S.lq[1] >= L.self_box[1][0] && S.lq[1] <= L.self_box[1][1] &&
+                             S.lq[2] >= L.self_box[2][0] && S.lq[2] <= L.self_box[2][1]);
+    pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, self_walk, cs, ncon, flags, pmask, nrel, pf);
 #endif
     D.ncon = ncon;
     // bit x of pmask: some leg A touches leg A xor x. One bit set (the common case of self-collision) means disjoint pairs, which the
