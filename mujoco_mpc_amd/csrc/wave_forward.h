@@ -97,11 +97,18 @@ __device__ __forceinline__ wreal wf_pair_bound(const MODEL& m, int g) {
   if (t == MJPCX_GEOM_BOX) return sqrt(s0 * s0 + s1 * s1 + s2 * s2);
   return s0;
 }
-// (sphere | capsule) g1 against the (box | cylinder) g2 at world poses (p1, R1), (p2, R2): oracle pair_thin_solid; one contact at most
+// (sphere | capsule) g1 against the (box | cylinder) g2 at world poses (p1, R1), (p2, R2): oracle pair_thin_solid; one contact at most.
+// g1 a solid too (`watch`): no contact is made -- there is no narrow phase for two solids -- but -1 is returned if the thin geom that contains
+// g1 (cylinder: its capsule, box: the ball about its centre) is within the margin of g2, as the oracle raises warning bit 128 then
 template <class MODEL>
 __device__ __forceinline__ int wf_thin_vs_solid(const MODEL& m, int g1, int g2, const wreal* p1, const wreal* R1, const wreal* p2, const wreal* R2, wreal margin,
-                                                wreal* cd, wreal* cp, wreal* cn) {
-  const wreal h = m.geom_type[g1] == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g1 + 1] : WL(0.0), r = m.geom_size[3 * g1];
+                                                wreal* cd, wreal* cp, wreal* cn, bool watch = false) {
+  const int t1 = m.geom_type[g1];
+  wreal h = t1 == MJPCX_GEOM_CAPSULE ? m.geom_size[3 * g1 + 1] : WL(0.0), r = m.geom_size[3 * g1];
+  if (watch) {
+    const wreal s0 = m.geom_size[3 * g1], s1 = m.geom_size[3 * g1 + 1], s2 = m.geom_size[3 * g1 + 2];
+    if (t1 == MJPCX_GEOM_CYLINDER) { h = s1; r = s0; } else { h = WL(0.0); r = sqrt(s0 * s0 + s1 * s1 + s2 * s2); }
+  }
   const wreal rel[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
   wreal pl[3], al[3], n[3], c[3];
   for (int k = 0; k < 3; k++) {
@@ -111,6 +118,7 @@ __device__ __forceinline__ int wf_thin_vs_solid(const MODEL& m, int g1, int g2, 
   const wreal size[3] = {m.geom_size[3 * g2], m.geom_size[3 * g2 + 1], m.geom_size[3 * g2 + 2]};
   const wreal dist = solid::thin_vs_solid<wreal>(m.geom_type[g2] == MJPCX_GEOM_CYLINDER ? solid::kSolidCylinder : solid::kSolidBox, size, pl, al, h, r, n, c);
   if (!(dist < margin)) return 0;
+  if (watch) return -1;
   wreal loc[3], w[3];
   for (int k = 0; k < 3; k++) loc[k] = c[k] + n[k] * (r + WL(0.5) * dist);
   mv3(w, R2, loc);
@@ -550,7 +558,7 @@ __device__ __forceinline__ void wf_collision(const MODEL& m, WaveData& d, int la
     int cnt = 0;
     // conservative bounding-sphere pretest on the geom centres (never rejects a pair the narrow phase would accept):
     // most steps have no self-contact and skip the poses, the narrow phase and the compaction altogether
-    bool near = false;
+    bool near = false, solids_touch = false;
     wreal p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
     const wreal margin = on ? fmax(m.geom_margin[g1], m.geom_margin[g2]) : WL(0.0);
     if (on) {
@@ -586,8 +594,9 @@ __device__ __forceinline__ void wf_collision(const MODEL& m, WaveData& d, int la
         const wreal x = (c[0] - p[0]) * a[0] + (c[1] - p[1]) * a[1] + (c[2] - p[2]) * a[2];
         return x < -h ? -h : (x > h ? h : x);
       };
-      if (t2 == MJPCX_GEOM_CYLINDER || t2 == MJPCX_GEOM_BOX) {  // (sphere | capsule, box | cylinder): solid_pairs.h
-        cnt = wf_thin_vs_solid(m, g1, g2, p1, R1, p2, R2, margin, cd, cp[0], cn[0]);
+      if (t2 == MJPCX_GEOM_CYLINDER || t2 == MJPCX_GEOM_BOX) {  // (sphere | capsule, box | cylinder): solid_pairs.h; two solids are only watched
+        cnt = wf_thin_vs_solid(m, g1, g2, p1, R1, p2, R2, margin, cd, cp[0], cn[0], t1 == MJPCX_GEOM_CYLINDER || t1 == MJPCX_GEOM_BOX);
+        if (cnt < 0) { cnt = 0; solids_touch = true; }
       } else if (t1 == MJPCX_GEOM_SPHERE && t2 == MJPCX_GEOM_SPHERE) {
         spheres(p1, p2);
       } else if (t1 == MJPCX_GEOM_SPHERE) {
@@ -628,6 +637,7 @@ __device__ __forceinline__ void wf_collision(const MODEL& m, WaveData& d, int la
         }
       }
     }
+    if (__ballot(solids_touch) != 0ull && lane == 0) d.counters[2] |= 128;  // (two solids within reach: no narrow phase -- the rollout fails, as the oracle's does)
     int below = 0, total = 0;
     for (int k = 0; k < 2; k++) {
       const unsigned long long b = __ballot(cnt > k);

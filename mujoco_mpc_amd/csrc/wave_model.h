@@ -263,9 +263,15 @@ struct WaveHost {
           pg2.push_back(q.g2);
           continue;
         }
-        if (q.kind == kPairSolids && q.apart && q.tight_jnt < 0) { pairs_apart++; continue; }
-        // two solids (or a geom type MuJoCo hands to its convex collider) that could not be proven apart: there is no device (or
-        // oracle) narrow phase; the pair is left out, and create says so (mjpcx_create_error() after MJPCX_OK).
+        // two solids: no narrow phase anywhere. The pair stays in the list and is WATCHED (a thin geom that contains one of them within the
+        // margin of the other raises warning bit 128: the rollout fails, as the oracle's does) -- proven apart or not: a proof holds for
+        // joints inside their ranges + pad, and a caller may start a rollout anywhere. One that cannot be proven apart is REPORTED too
+        // (mjpcx_create_error() after MJPCX_OK; MJPCX_STRICT_PAIRS refuses the model).
+        if (q.kind == kPairSolids) {
+          pg1.push_back(q.g1);
+          pg2.push_back(q.g2);
+          if (q.apart && q.tight_jnt < 0) { pairs_apart++; continue; }
+        }
         if (contacts_on && skipped_pairs++ == 0) { skipped_a = q.g1; skipped_b = q.g2; }
       }
     }
@@ -273,7 +279,7 @@ struct WaveHost {
     if (skipped_pairs > 0)
       warning = std::to_string(skipped_pairs) + " collidable geom pair(s) between two moving bodies have no narrow phase here (two box | cylinder geoms that could not be "
                 "proven apart over the joint ranges, or a geom type other than sphere | capsule | cylinder | box; first: geoms " + std::to_string(skipped_a) + ", " +
-                std::to_string(skipped_b) + ") and are NOT collided (contacts with static geoms are unaffected)";
+                std::to_string(skipped_b) + ") and are NOT collided: a rollout in which two such solids come within reach FAILS (contacts with static geoms are unaffected)";
     m.npair = (int)pg1.size();
     reg(&m.pair_g1, pg1.data(), sizeof(int) * pg1.size());
     reg(&m.pair_g2, pg2.data(), sizeof(int) * pg2.size());

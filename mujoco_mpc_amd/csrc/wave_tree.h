@@ -326,7 +326,7 @@ __device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeDa
     const int g1 = on ? m.pair_g1[p0 + lane] : 0, g2p = on ? m.pair_g2[p0 + lane] : 0;
     wreal cd[2] = {0, 0}, cp[2][3] = {{0, 0, 0}, {0, 0, 0}}, cn[2][3] = {{1, 0, 0}, {1, 0, 0}};
     int cnt = 0;
-    bool near = false;
+    bool near = false, solids_touch = false;
     wreal p1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
     const wreal margin = on ? fmax(m.geom_margin[g1], m.geom_margin[g2p]) : WL(0.0);
     const int pb1 = on ? m.geom_bodyid[g1] : 0, pb2 = on ? m.geom_bodyid[g2p] : 0;
@@ -363,8 +363,9 @@ __device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeDa
         return x < -h ? -h : (x > h ? h : x);
       };
       const int t2p = m.geom_type[g2p];
-      if (t2p == MJPCX_GEOM_CYLINDER || t2p == MJPCX_GEOM_BOX) {  // (sphere | capsule, box | cylinder): solid_pairs.h
-        cnt = wf_thin_vs_solid(m, g1, g2p, p1, R1, q2, R2p, margin, cd, cp[0], cn[0]);
+      if (t2p == MJPCX_GEOM_CYLINDER || t2p == MJPCX_GEOM_BOX) {  // (sphere | capsule, box | cylinder): solid_pairs.h; two solids are only watched
+        cnt = wf_thin_vs_solid(m, g1, g2p, p1, R1, q2, R2p, margin, cd, cp[0], cn[0], t1 == MJPCX_GEOM_CYLINDER || t1 == MJPCX_GEOM_BOX);
+        if (cnt < 0) { cnt = 0; solids_touch = true; }
       } else if (t1 == MJPCX_GEOM_SPHERE && t2p == MJPCX_GEOM_SPHERE) {
         spheres(p1, q2);
       } else if (t1 == MJPCX_GEOM_SPHERE) {
@@ -407,6 +408,7 @@ __device__ __forceinline__ void wt_collision(const MODEL& m, WaveData& d, TreeDa
     }
     wreal pcom[3] = {0, 0, 0};
     if (on) for (int k = 0; k < 3; k++) pcom[k] = d.subtree_com[3 * m.body_rootid[pb2] + k];
+    if (__ballot(solids_touch) != 0ull && lane == 0) d.counters[2] |= 128;  // (two solids within reach: no narrow phase -- the rollout fails, as the oracle's does)
     wt_emit<2>(m, d, t, lane, cnt, cd, cp, cn, g1, g2p, pb1, pb2, pcom);
   }
 }

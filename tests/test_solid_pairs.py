@@ -175,3 +175,49 @@ def test_thin_geoms_rest_on_moving_solids_and_carry_their_weight(scene):
         assert abs(f[int(r[10])] - 2 * 9.81) < 1e-5            # the upper body's weight
     floor = np.array([f[int(r[10])] for r in con if gb[int(r[7])] == 0])
     assert abs(floor.sum() - 2 * 3 * 9.81) < 1e-4
+
+
+def test_pairs_proven_apart_are_apart_on_random_joint_samples():
+    """csrc/pair_cull.h's proofs on the A1, checked the other way round: 2500 random joint configurations inside the box a proof covers
+    (every hinge up to 0.2 rad past its range; the knee's fold side 0.1 rad for the ten pairs whose proof needed that) -- none of the 165
+    pairs proven apart (146 + 10 thin-solid, 9 cylinder-cylinder) comes within its margin; the smallest distance seen stays positive.
+    Distances from the oracle's geom poses and narrow phase (two cylinders: one taken as its enclosing capsule, as the proof does)."""
+    import ctypes as C
+    from mujoco_mpc_amd.task import load_task
+    quad = load_task("QuadrupedFlat")
+    quad.transition(0.0)
+    pm = quad.packed_model()
+    a = quad.model.arrays
+    out = (C.c_int * (6 * 1024))()
+    n = solidpairs.lib().sp_moving_pairs(C.cast(pm.ptr, C.c_void_p), out, 1024)
+    rows = [tuple(out[6 * i:6 * i + 6]) for i in range(n)]
+    proven = [r for r in rows if r[3]]
+    assert len(proven) == 165
+    ph = pyoracle.Physics(pm)
+    rng = np.random.default_rng(0)
+    lo, hi = a["jnt_range"][1:13, 0], a["jnt_range"][1:13, 1]
+    ng = quad.model.scalars["ngeom"]
+    mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0.0])
+    worst = np.inf
+    for it in range(2500):
+        pad_lo, pad_hi = np.full(12, 0.2), np.full(12, 0.2)
+        pad_lo[2::3] = 0.1   # the knees' fold side: the tight pad of the same-leg proofs (valid for every other proof too)
+        q = rng.uniform(lo - pad_lo, hi + pad_hi)
+        if it % 4 == 0:      # corners of the box are where proofs fail first
+            q = np.where(rng.random(12) < 0.5, lo - pad_lo, hi + pad_hi)
+        qpos = np.concatenate([[0, 0, 0.5, 1, 0, 0, 0], q])
+        ph.set_state(qpos, np.zeros(18), 0.0, mocap)
+        ph.forward()
+        gx = np.array(ph.get("geom_xpos", 3 * ng)).reshape(ng, 3)
+        gm = np.array(ph.get("geom_xmat", 9 * ng)).reshape(ng, 3, 3)
+        for g1, g2, kind, apart, tj, ts in proven:
+            t1, t2 = int(a["geom_type"][g1]), int(a["geom_type"][g2])
+            s1 = a["geom_size"][g1]
+            h, r = (s1[1] if t1 in (3, 5) else 0.0), s1[0]
+            R2 = gm[g2]
+            pl = R2.T @ (gx[g1] - gx[g2])
+            al = R2.T @ gm[g1][:, 2]
+            d, _, _ = oracle_tvs(t2 == 5, a["geom_size"][g2], pl, al, h, r)
+            worst = min(worst, d)
+            assert d > 0.001, (g1, g2, d, it)
+    assert worst > 0.001

@@ -31,6 +31,7 @@ out = dict(c)
 out.update({
     "kernel": name, "task": task, "candidates": N, "horizon": H, "precision": prec,
     "src_sha16": __import__("bench").kernel_source_sha16(),
+    "unit_src_sha16": __import__("bench").kernel_source_sha16("quad") if "rollout_quad_kernel" in name else None,
     "hbm_bytes_per_launch": (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024.0,
     "algorithmic_bytes_per_launch": per_rollout * N,
     "valu": {
