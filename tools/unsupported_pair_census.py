@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""How often do the geom pairs the kernels (and the oracle) do NOT collide come within their margin on the north-star batch?
+"""HISTORICAL (round 4, first session): the pairs this tool counts -- a box or a cylinder against a sphere | capsule between two moving bodies -- are collided
+since the round's second session (csrc/solid_pairs.h, oracle/contact.inc pair_thin_solid); it measured what leaving them out was worth.
+
+How often do the geom pairs the kernels (and the oracle) do NOT collide come within their margin on the north-star batch?
 
 `mjpcx_create` leaves out every pair of geoms on two moving bodies in which a geom is neither a sphere nor a capsule (the A1: the trunk's
 boxes and cylinders and the hips' cylinders against thigh / calf / foot geoms; csrc/wave_model.h, oracle/contact.inc bake_pairs) and says
