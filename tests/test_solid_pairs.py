@@ -221,3 +221,38 @@ def test_pairs_proven_apart_are_apart_on_random_joint_samples():
             worst = min(worst, d)
             assert d > 0.001, (g1, g2, d, it)
     assert worst > 0.001
+
+
+@pytest.mark.parametrize("rng_,provable", [(0.3, True), (0.9, False)])
+def test_the_proof_depends_on_the_joint_ranges(rng_, provable):
+    """tests/models/two_arms.xml: a box and a cylinder at the ends of two arms 0.6 m apart on a base that turns freely (an unlimited hinge ABOVE
+    both bodies: not between them, so it does not enter the proof). With the arms' hinges limited to +-0.3 rad the ends stay 0.26 m apart
+    even 0.2 rad past the limits: proven; with +-0.9 rad they can meet: no proof, and a sampled configuration inside the ranges has them in touch."""
+    import ctypes as C
+    import os
+    from mujoco_mpc_amd import mjcf
+    from mujoco_mpc_amd.task import PackedModel
+    fm = mjcf.load_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "two_arms.xml"))
+    fm.arrays["jnt_range"][1] = [-rng_, rng_]
+    fm.arrays["jnt_range"][2] = [-rng_, rng_]
+    pm = PackedModel(fm)
+    out = (C.c_int * (6 * 16))()
+    n = solidpairs.lib().sp_moving_pairs(C.cast(pm.ptr, C.c_void_p), out, 16)
+    rows = [tuple(out[6 * i:6 * i + 6]) for i in range(n)]
+    assert len(rows) == 1 and rows[0][2] == 2          # one pair: (cylinder, box) = two solids
+    g1, g2 = rows[0][0], rows[0][1]
+    assert fm.arrays["geom_type"][g1] == 5 and fm.arrays["geom_type"][g2] == 6
+    assert bool(rows[0][3]) == provable
+    # the other way round: distances of the cylinder's enclosing capsule to the box over the joint box
+    ph = pyoracle.Physics(pm)
+    best = np.inf
+    for ql in np.linspace(-rng_, rng_, 25):
+        for qr in np.linspace(-rng_, rng_, 25):
+            ph.set_state(np.array([0.7, ql, qr]), np.zeros(3))
+            ph.forward()
+            gx = np.array(ph.get("geom_xpos", 3 * fm.scalars["ngeom"])).reshape(-1, 3)
+            gm = np.array(ph.get("geom_xmat", 9 * fm.scalars["ngeom"])).reshape(-1, 3, 3)
+            s1 = fm.arrays["geom_size"][g1]
+            d, _, _ = oracle_tvs(0, fm.arrays["geom_size"][g2], gm[g2].T @ (gx[g1] - gx[g2]), gm[g2].T @ gm[g1][:, 2], s1[1], s1[0])
+            best = min(best, d)
+    assert (best > 0.1) if provable else (best < 0.0)
