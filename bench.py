@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TF = 78.6   # MI355X vector FP64 (not in the local guide)
+FP32_VALU_PEAK_TF = 157.3  # MI355X vector FP32 (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -134,6 +135,17 @@ def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=Non
     ns = capi.make_noise_spec(seed=0, iteration=1, mode=capi.NOISE_SAMPLING, std0=sigma)
     nodes = pyoracle.noise_candidates(pm, ns, num_nodes, nom, np.arange(1, n_per_call + 1))
     ip = capi.SPLINE_CUBIC if interp is None else interp
+    # floating-point operations of the reference algorithm per candidate-step, counted on the first candidates of this very batch by the
+    # oracle's operation-counting build (oracle/flopcount.h): the numerator of roofline.fp64 / .fp32
+    flops = {}
+    n_fl = min(32, n_per_call)
+    try:
+        with pyoracle.counting_flops(flops):
+            pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, n_fl, horizon, num_nodes, ip, times, nodes[:n_fl], num_threads=min(8, max(1, cores)))
+        flops["candidates"] = n_fl
+        flops["per_candidate_step"] = flops["flop"] / (n_fl * horizon)
+    except Exception as ex:  # noqa: BLE001  (the counter must never take the line down)
+        flops = {"error": repr(ex)}
 
     def run(n, threads):
         t0 = time.perf_counter()
@@ -162,7 +174,7 @@ def cpu_baseline(task, state, horizon, num_nodes, seconds, n_per_call, mocap=Non
                 sample=f"{done} rollouts of H={horizon} ({el:.1f} s) through the C oracle's ThreadPool-style fan-out on candidates drawn like the "
                        f"device's (noise {sigma} around the planner's nominal), {best_threads} threads; gcc -O3 -march=native -flto; CPU restatement, "
                        f"not MuJoCo",
-                host=budget, single_thread=single, parallel_efficiency=value / (best_threads * single),
+                host=budget, single_thread=single, parallel_efficiency=value / (best_threads * single), flops=flops,
                 probe={str(k): v for k, v in probe.items()},
                 reference_default_threads={"threads": ref_threads, "value": ref_rate,
                                            "note": "testspeed's default: hardware threads - 5 (mjpc/testspeed_app.cc:24)"})
@@ -191,10 +203,11 @@ def initial_condition(task_name, task, planner):
 
 
 def pmc_summary(task_name, candidates, horizon, precision):
-    """Counter-derived figures of the rollout kernel for THIS build: profiles/r04_pmc_<task>.json is written by
-    tools/pmc_rollout.sh (separate --pmc passes, as MI355X_MICROARCH.md prescribes) and records the sha256 of the
-    kernel sources it profiled; a summary of any other source state is ignored (never a stale lookup)."""
-    path = os.path.join(ROOT, "profiles", f"r04_pmc_{task_name.lower()}_fp{precision}.json")
+    """Counter-derived figures of the rollout kernel for THIS build: profiles/r05_pmc_<task>.json is written by
+    tools/pmc_bench.sh (separate --pmc passes over bench.py's own command, as MI355X_MICROARCH.md prescribes: the counters are of the
+    launches this file times) and records the sha256 of the kernel sources it profiled; a summary of any other source state is
+    ignored (never a stale lookup)."""
+    path = os.path.join(ROOT, "profiles", f"r05_pmc_{task_name.lower()}_fp{precision}.json")
     try:
         s = json.load(open(path))
     except (OSError, ValueError):
@@ -395,6 +408,10 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
     pmc = pmc_summary(task_name, candidates, H, precision)
     if pmc is not None:
         out["roofline"]["traffic"] = pmc.get("hbm_bytes_per_launch")
+        t = pmc.get("timed") or {}
+        out["roofline"]["traffic_collected_on"] = {
+            "launches": f"the {pmc.get('launches', 0) - pmc.get('warmup_launches', 0)} timed launches of `{pmc.get('command')}` (tools/pmc_bench.sh)",
+            "kernel_ms_under_kernel_trace": t.get("kernel_ms_under_kernel_trace"), "hbm_bytes_min_max": t.get("hbm_bytes_min_max")}
         if "valu" in pmc:
             out["roofline"]["valu"] = pmc["valu"]
     if want_cpu:
@@ -405,6 +422,18 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
                                            mocap=None if mocap_pos is None else np.hstack([mocap_pos, mocap_quat]).reshape(-1),
                                            interp=capi.SPLINE_ZERO if task_name == "QuadrupedFlat" or kind == "cross_entropy" else capi.SPLINE_CUBIC,
                                            nominal=nominal_nodes if nominal_nodes.shape[0] == P else None)
+        fl = out["cpu_baseline"].get("flops") or {}
+        if "per_candidate_step" in fl:
+            # the roofline that binds the contact models: the reference algorithm's floating-point operations (as the oracle restates it:
+            # dense Jacobian rows, dense Cholesky of the nv x nv Hessian) / the rollout kernel's time, against the vector peak of the dtype
+            peak = FP64_VALU_PEAK_TF if precision == 64 else FP32_VALU_PEAK_TF
+            tf = fl["per_candidate_step"] * candidates * H / avg_kernel_s / 1e12
+            out["roofline"]["fp64" if precision == 64 else "fp32"] = {
+                "flop_per_candidate_step": fl["per_candidate_step"], "achieved_tflops": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                "counted": {k: fl[k] for k in ("add", "mul", "div", "sqrt", "libm", "candidates")},
+                "note": "flop = additions + multiplications + divisions + square roots + other libm calls (one each) executed by the CPU "
+                        "oracle's operation-counting build (oracle/flopcount.h) on the first candidates of the batch the device rolls; the "
+                        "device's own formulation (no Jacobian, arrowhead factorisation) executes fewer"}
     planner.close()
     return out
 

@@ -79,6 +79,30 @@ def timing_build():
         _LIB = saved
 
 
+def flops_build():
+    """liboracle_flops.so: the oracle's sources compiled with an operation-counting `double` (oracle/flopcount.h)."""
+    subprocess.check_call(["make", "-C", _DIR, "-s", "liboracle_flops.so"], stdout=subprocess.DEVNULL)
+    return os.path.join(_DIR, "liboracle_flops.so")
+
+
+@contextlib.contextmanager
+def counting_flops(out):
+    """Inside the block every call of this module goes to the operation-counting build; on exit `out` (a dict) holds the operations
+    executed inside it: add (additions and subtractions), mul, div, sqrt, libm (other math-library calls, one each), flop (their sum).
+    The flop count of the REFERENCE ALGORITHM as the oracle restates it -- bench.py's roofline.fp64 numerator; never a checker, never timed."""
+    global _LIB
+    saved = _LIB
+    _LIB = _load(flops_build())
+    _LIB.oracle_flops_reset()
+    try:
+        yield
+    finally:
+        v = (C.c_ulonglong * 5)()
+        _LIB.oracle_flops_read(v)
+        out.update(add=int(v[0]), mul=int(v[1]), div=int(v[2]), sqrt=int(v[3]), libm=int(v[4]), flop=int(sum(v)))
+        _LIB = saved
+
+
 def _load(path):
     if True:
         L = C.CDLL(path)

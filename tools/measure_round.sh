@@ -1,22 +1,36 @@
 #!/bin/bash
-# One GPU-box call that collects everything profiles/r04_* is made of: the GPU test suite, the PMC summary of the north-star kernel
-# (bench.py picks it up as roofline.traffic / .valu of the line), the default bench line with its extras, the kernel-trace summary of the
-# same command, then the PMC summaries of the other two configurations. The files land in gpurun_out/r04/ (merged back by gpurun);
-# copy them to profiles/ and commit.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
+# One GPU-box call that collects what profiles/r05_* is made of; the sections run in this order and are picked by WHAT (default: all):
+#   tests   the GPU test suite
+#   pmc     counters + kernel trace of the launches bench.py times, north star and Humanoid (tools/pmc_bench.sh); bench.py picks the
+#           summaries up from profiles/ as roofline.traffic / .valu of its line
+#   stamps  phase stamps of wavefront 0 of the quad kernel over the first plan steps of the bench (MJPCX_QUAD_STAMPS)
+#   bench   the default bench line with its extras
+#   trace   rocprofv3 --kernel-trace --stats of the bench command
+#   ilqg    kernel trace of the iLQG iteration
+# Files land in gpurun_out/r05/ (merged back by gpurun); copy them to profiles/ and commit.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05; mkdir -p $O
+WHAT=${WHAT:-tests pmc stamps bench trace ilqg}
+has() { [[ " $WHAT " == *" $1 "* ]]; }
 cd $R
-timeout 300 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; tail -3 $O/gputests.log
-[ -z "$SKIP_PMC" ] && bash $R/tools/pmc_rollout.sh QuadrupedFlat 16384 100 64 0 0.04 > $O/pmc_quadrupedflat.log 2>&1   # (SKIP_PMC=1: the committed profiles/r04_pmc_*.json are of this build)
-for f in $R/gpurun_out/pmc_*/r04_pmc_*.json; do [ -f $f ] && cp $f $R/profiles/ && cp $f $O/; done   # (the profiles/ copy lives on the box only; $O is merged back)
+if has tests; then timeout 900 python -m pytest tests -m gpu -q -x > $O/gputests.log 2>&1; tail -3 $O/gputests.log; fi
+if has pmc; then
+  bash $R/tools/pmc_bench.sh QuadrupedFlat 64 > $O/pmc_quadrupedflat.log 2>&1; tail -3 $O/pmc_quadrupedflat.log
+  bash $R/tools/pmc_bench.sh HumanoidTrack 32 10 2 > $O/pmc_humanoidtrack.log 2>&1; tail -3 $O/pmc_humanoidtrack.log
+  for f in $R/gpurun_out/pmc_*/r05_pmc_*.json; do [ -f $f ] && cp $f $R/profiles/ && cp $f $O/; done   # (the profiles/ copy lives on the box only; $O is merged back)
+  for t in quadrupedflat humanoidtrack; do find $R/gpurun_out/pmc_$t/p0 -name "*kernel_trace.csv" -exec cp {} $O/pmc_${t}_kernel_trace.csv \; ; done
+fi
 cd $R
-timeout 600 python bench.py > $O/bench_line.json 2> $O/bench.err
-tail -c 1500 $O/bench_line.json
+if has stamps; then MJPCX_QUAD_STAMPS=1 timeout 300 python bench.py --steps 10 --warmup 0 --no-extra --no-cpu-baseline > $O/stamps_line.json 2> $O/quad_stamps.log; grep -c "cycles of wavefront" $O/quad_stamps.log; fi
+if has bench; then timeout 900 python bench.py > $O/bench_line.json 2> $O/bench.err; tail -c 1500 $O/bench_line.json; fi
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --no-extra --no-cpu-baseline > $O/trace.log 2>&1
-find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
-head -6 $O/bench_kernel_stats.csv
-[ -n "$SKIP_PMC" ] && exit 0
-tail -3 $O/pmc_quadrupedflat.log
-bash $R/tools/pmc_rollout.sh HumanoidTrack 8192 64 32 2 0.1 > $O/pmc_humanoidtrack.log 2>&1
-bash $R/tools/pmc_rollout.sh Cartpole 4096 128 64 2 0.5 > $O/pmc_cartpole.log 2>&1
-for f in $R/gpurun_out/pmc_*/r04_pmc_*.json; do cp $f $O/; done
+if has trace; then
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --no-extra --no-cpu-baseline > $O/trace.log 2>&1
+  find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
+  head -6 $O/bench_kernel_stats.csv
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_h -o bench -- python $R/bench.py --task HumanoidTrack --precision 32 --steps 10 --no-extra --no-cpu-baseline > $O/trace_h.log 2>&1
+  find $O/trace_h -name "*kernel_stats.csv" -exec cp {} $O/humanoid_kernel_stats.csv \;
+  head -4 $O/humanoid_kernel_stats.csv
+  rm -rf $O/trace $O/trace_h
+fi
+if has ilqg; then bash $R/tools/measure_ilqg.sh > $O/ilqg.log 2>&1; tail -5 $O/ilqg.log; fi
+true
