@@ -371,7 +371,7 @@ struct mjpcx_ctx {
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
   int quad_ids[7] = {0, 0, 0, 0, 0, 0, 0};  // residual_int[1..7] the quad model was built for (torso, head site, goal mocap, feet)
-  DevBuf d_qmodel, d_qtab, d_qstats, d_qstamps, d_qwave;
+  DevBuf d_qmodel, d_qtab, d_qstats, d_qstamps, d_qwave, d_qovf, d_qclass;
   void* h_qstats = nullptr;       // pinned copy of d_qstats (whether the hand-on pass has anything to do)
   // timing
   bool timing = false;
@@ -631,6 +631,10 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
   q.total_return = a.total_return; q.failure = a.failure; q.con_cap = c->quad_con_cap; q.cpw = c->quad_cpw;
   const quad::QBlob bo{wt.off_time, wt.off_mocap, wt.off_weight, wt.off_normp, wt.off_normq, wt.off_param, wt.off_risk, wt.off_rreal, wt.off_rint};
   hipError_t e;
+  if (quad::quad_uses_ovf_slab()) {  // (a build with QEXP_OVF_SLAB: contacts beyond a lane's LDS slots in global memory, 150 KB per wavefront)
+    if ((e = c->d_qovf.reserve((size_t)quad::quad_waves(N, c->quad_cpw) * quad::quad_ovf_doubles_per_wave() * sizeof(double))) != hipSuccess) return e;
+    q.ovf_slab = (double*)c->d_qovf.p;
+  }
   if ((e = hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream)) != hipSuccess) return e;  // (how many candidates are handed on, by reason: mjpcx_quad_stats)
   if (c->quad_stamps) {
     if ((e = hipMemsetAsync(c->d_qstamps.p, 0, 512, c->stream)) != hipSuccess) return e;
@@ -639,8 +643,31 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
     if ((e = c->d_qwave.reserve(wb)) != hipSuccess || (e = hipMemsetAsync(c->d_qwave.p, 0, wb, c->stream)) != hipSuccess) return e;
     q.wave_times = (long long*)c->d_qwave.p;
   }
+  static const bool classes = getenv("MJPCX_QUAD_CLASSES") != nullptr;  // (tuning aid: cycles by class of wavefront-step, printed after every launch)
+  const int nwave = quad::quad_waves(N, c->quad_cpw);
+  if (classes) {
+    const size_t wb = (size_t)nwave * 64 * 8;
+    if ((e = c->d_qclass.reserve(wb)) != hipSuccess || (e = hipMemsetAsync(c->d_qclass.p, 0, wb, c->stream)) != hipSuccess) return e;
+    q.wave_class = (long long*)c->d_qclass.p;
+  }
   if ((e = quad::launch_rollout_quad(c->d_qmodel.p, c->d_qtab.p, wt.blob, bo, q, (int*)c->d_qstats.p,
                                      c->stream)) != hipSuccess) return e;
+  if (classes) {
+    std::vector<long long> w((size_t)nwave * 64), tot(64, 0);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(w.data(), c->d_qclass.p, w.size() * 8, hipMemcpyDeviceToHost);
+    for (int i = 0; i < nwave; i++) for (int k = 0; k < 64; k++) tot[k] += w[(size_t)i * 64 + k];
+    long long steps = 0, cyc = 0, scyc = 0;
+    for (int k = 0; k < 16; k++) { steps += tot[32 + 2 * k]; cyc += tot[32 + 2 * k + 1]; scyc += tot[2 * k + 1]; }
+    std::fprintf(stderr, "rollout_quad_kernel wavefront-steps by class (rel = a contact between two moving geoms in some candidate, leg = a leg-leg one, ovf = a lane beyond its "
+                         "LDS slots, bey = beyond the line-search slots): %lld steps, %.0f cycles per step, %.0f of them in the solve\n", steps, steps ? (double)cyc / steps : 0.0,
+                 steps ? (double)scyc / steps : 0.0);
+    for (int k = 0; k < 16; k++)
+      if (tot[32 + 2 * k] > 0)
+        std::fprintf(stderr, "  %s%s%s%s%s: %5.1f %% of the steps, %5.1f %% of the cycles; per step %.0f cycles, solve %.0f\n", k == 0 ? "plain" : "", (k & 1) ? "rel " : "", (k & 2) ? "leg " : "",
+                     (k & 4) ? "ovf " : "", (k & 8) ? "bey " : "", 100.0 * tot[32 + 2 * k] / steps, 100.0 * tot[32 + 2 * k + 1] / cyc, (double)tot[32 + 2 * k + 1] / tot[32 + 2 * k],
+                     tot[2 * k] ? (double)tot[2 * k + 1] / tot[2 * k] : 0.0);
+  }
   if (c->timing && c->cur_main) { if ((e = hipEventRecord(c->cur_main, c->stream)) != hipSuccess) return e; c->cur_main = nullptr; }
   if (c->quad_stamps) {
     long long h[64];
@@ -656,8 +683,7 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
     std::fprintf(stderr, "\n");
     std::fprintf(stderr, "  newton: entry %lld, first pass %lld, warm start %lld; line search: entry %lld, coefficients %lld, trials %lld\n", h[13], h[14], h[15], h[40], h[41], h[42]);
     {
-      int cpw_ = c->quad_cpw; if (cpw_ <= 0) { cpw_ = 16; while (cpw_ > 1 && (N + cpw_ - 1) / cpw_ < 1024) cpw_ >>= 1; }
-      const int W = (N + cpw_ - 1) / cpw_;
+      const int W = quad::quad_waves(N, c->quad_cpw);
       std::vector<long long> w((size_t)W * 4);
       (void)hipMemcpy(w.data(), c->d_qwave.p, w.size() * 8, hipMemcpyDeviceToHost);
       std::vector<int> order(W);
@@ -926,9 +952,12 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
     // mj_implicit with qDeriv = d qfrc_smooth / d qvel restricted to passive damping + actuator velocity terms: without the latter the
     // matrix is M + h diag(damping), mj_Euler's own (include/mjpcx.h). The context then runs the Euler path on a copy of the header.
     for (int i = 0; i < m->nu; i++)
-      if (m->actuator_biasprm && m->actuator_biasprm[3 * i + 2] != 0)
-        return bad(MJPCX_EUNSUPPORTED, "implicitfast with a velocity-dependent actuator (biasprm[2] != 0): only models whose velocity-dependent smooth force "
-                                       "is joint damping are integrated (as mj_Euler, which is the same update there)");
+      if (m->actuator_biasprm && m->actuator_biastype && m->actuator_biastype[i] == MJPCX_BIAS_AFFINE && m->actuator_biasprm[3 * i + 2] != 0)
+        return bad(MJPCX_EUNSUPPORTED, "implicitfast with a velocity-dependent actuator (affine bias, biasprm[2] != 0): only models whose velocity-dependent smooth "
+                                       "force is joint damping are integrated (as mj_Euler, which is the same update there)");
+    // mj_implicit ignores mjDSBL_EULERDAMP, mj_Euler switches to explicit damping under it: the two updates differ then
+    if (m->disableflags & MJPCX_DSBL_EULERDAMP)
+      return bad(MJPCX_EUNSUPPORTED, "implicitfast with eulerdamp disabled: mj_implicit keeps the damping implicit, the Euler path this context would run does not");
     m_euler = *m;
     m_euler.integrator = MJPCX_INT_EULER;
     m = &m_euler;
@@ -1150,7 +1179,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   if (c->h_qstats) (void)hipHostFree(c->h_qstats);
   (void)mjpcx_comm_destroy(c);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_qmodel, &c->d_qtab, &c->d_qstats, &c->d_qstamps, &c->d_qwave, &c->d_comm_send, &c->d_comm_recv,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_qmodel, &c->d_qtab, &c->d_qstats, &c->d_qstamps, &c->d_qwave, &c->d_qovf, &c->d_qclass, &c->d_comm_send, &c->d_comm_recv,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();
@@ -1900,6 +1929,13 @@ int mjpcx_comm_init(mjpcx_ctx* c, const void* unique_id, int rank, int world) {
   // context stays without a communicator, the caller gets MJPCX_EDEVICE and can fall back to its own transport (bench.py does).
   // A communicator that arrives AFTER the deadline is destroyed by the helper thread itself (the peers' next collective then fails
   // instead of waiting for a rank that has moved on); callers must agree on the fallback collectively, as bench.py does.
+  double deadline = 120.0;
+  if (const char* e = getenv("MJPCX_COMM_TIMEOUT_S")) {  // (validated BEFORE the helper thread exists: nothing to abandon on a bad value)
+    char* end = nullptr;
+    const double v = std::strtod(e, &end);
+    if (end == e || !(v > 0)) return fail(c, MJPCX_EINVAL, "MJPCX_COMM_TIMEOUT_S must be a positive number of seconds");
+    deadline = v;
+  }
   struct InitState { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; ncclResult_t rc = ncclSuccess; ncclComm_t comm = nullptr; };
   auto st = std::make_shared<InitState>();
   const int device = c->device;
@@ -1916,13 +1952,6 @@ int mjpcx_comm_init(mjpcx_ctx* c, const void* unique_id, int rank, int world) {
     }
     if (late && rc == ncclSuccess && comm) (void)R->CommDestroy(comm);
   }).detach();
-  double deadline = 120.0;
-  if (const char* e = getenv("MJPCX_COMM_TIMEOUT_S")) {
-    char* end = nullptr;
-    const double v = std::strtod(e, &end);
-    if (end == e || !(v > 0)) return fail(c, MJPCX_EINVAL, "MJPCX_COMM_TIMEOUT_S must be a positive number of seconds");
-    deadline = v;
-  }
   {
     std::unique_lock<std::mutex> lk(st->m);
     if (!st->cv.wait_for(lk, std::chrono::duration<double>(deadline), [&] { return st->done; })) {

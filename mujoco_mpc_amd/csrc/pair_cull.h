@@ -12,9 +12,12 @@
 // bounding radius), delta_j the cell's half width. The distance is exact for thin-solid pairs (solid_pairs.h) and a lower bound for two
 // solids (one replaced by a thin geom that contains it).
 //   * wave / tree kernels (wave_model.h): every sphere | capsule pair and every thin-solid pair is collided, proven apart or not; two solids
-//     are dropped if proven apart and REPORTED otherwise (the warning / MJPCX_STRICT_PAIRS refusal).
-//   * quad kernel (quad_model.h): pairs outside its layout must be proven apart or the model is declined; a candidate one of whose joints
-//     leaves the range the proofs cover (range + pad) is handed to the wavefront-per-candidate kernel at that step (kFlagRange).
+//     are kept in the list and WATCHED, proven apart or not (a thin geom containing one of them within the margin of the other raises
+//     warning bit 128 and the rollout fails, as the oracle's does); the ones that cannot be proven apart are REPORTED at create time (the
+//     warning / MJPCX_STRICT_PAIRS refusal), and a model in which two of them already touch at qpos0 or a keyframe is refused outright.
+//   * quad kernel (quad_model.h): pairs outside its layout must be proven apart or the model is declined -- two solids with the wide pad
+//     only; a candidate one of whose joints leaves the range the proofs cover (range + pad) is handed to the wavefront-per-candidate
+//     kernel at that step (kFlagRange).
 // The oracle keeps every pair and raises a warning should two solids come within reach: the parity suites check the proofs at run time.
 #pragma once
 #include <math.h>
@@ -205,6 +208,49 @@ inline bool pair_never_touches(const mjpcx_model* m, int g1, int g2, double marg
   if (evals) *evals = P.evals;
   if (closest) *closest = P.closest;
   return ok;
+}
+
+// Two solids at the model's reference pose qpos0: the kernels' watch (the thin geom that contains g1 against the solid g2; oracle
+// pair_thin_solid with as_thin) evaluated on the host. true: the pair is within its margin there -- every rollout that starts near
+// qpos0 would fail with warning bit 128 at its first step, so mjpcx_create refuses such a model with one clear message instead.
+inline bool solids_touch_at_qpos0(const mjpcx_model* m, int g1, int g2) {
+  using namespace cull_detail;
+  if (!is_solid(m->geom_type[g1]) || !is_solid(m->geom_type[g2])) return false;
+  double gp[2][3], gR[2][9];
+  for (int s = 0; s < 2; s++) {
+    const int g = s == 0 ? g1 : g2;
+    std::vector<int> chain;
+    for (int b = m->geom_bodyid[g]; b > 0; b = m->body_parentid[b]) chain.push_back(b);
+    double p[3] = {0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (auto it = chain.rbegin(); it != chain.rend(); ++it) {
+      const int b = *it;
+      const double* bp = m->body_pos + 3 * b; const double* bq = m->body_quat + 4 * b;
+      // (a free joint's qpos0 IS the body's pose; hinges and slides are at zero displacement at qpos0, a ball joint at its reference quaternion)
+      if (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == MJPCX_JNT_FREE) { bp = m->qpos0 + m->jnt_qposadr[m->body_jntadr[b]]; bq = bp + 3; }
+      double v[3], Rb[9];
+      mv(v, R, bp);
+      for (int k = 0; k < 3; k++) p[k] += v[k];
+      q2m(Rb, bq);
+      mm(R, R, Rb);
+    }
+    double v[3], Rg[9];
+    mv(v, R, m->geom_pos + 3 * g);
+    for (int k = 0; k < 3; k++) gp[s][k] = p[k] + v[k];
+    q2m(Rg, m->geom_quat + 4 * g);
+    mm(gR[s], R, Rg);
+  }
+  const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  double h = 0, r = 0;
+  solid::solid_as_thin<double>(t1 == MJPCX_GEOM_CYLINDER ? solid::kSolidCylinder : solid::kSolidBox, m->geom_size + 3 * g1, h, r);
+  double rel[3], pl[3], al[3], n[3], cc[3];
+  for (int k = 0; k < 3; k++) rel[k] = gp[0][k] - gp[1][k];
+  for (int k = 0; k < 3; k++) {
+    pl[k] = gR[1][k] * rel[0] + gR[1][3 + k] * rel[1] + gR[1][6 + k] * rel[2];
+    al[k] = gR[1][k] * gR[0][2] + gR[1][3 + k] * gR[0][5] + gR[1][6 + k] * gR[0][8];
+  }
+  const double d = solid::thin_vs_solid<double>(t2 == MJPCX_GEOM_CYLINDER ? solid::kSolidCylinder : solid::kSolidBox, m->geom_size + 3 * g2, pl, al, h, r, n, cc);
+  const double margin = m->geom_margin[g1] > m->geom_margin[g2] ? m->geom_margin[g1] : m->geom_margin[g2];
+  return d < margin;
 }
 
 // the moving-geom pairs of a model in MuJoCo's order (lower geom type first, then lower index)

@@ -23,7 +23,12 @@ struct QArgs {
   int* failure;
   long long* stamps;  // nullptr, or 64 counters: phase cycles of wavefront 0 (tuning aid, MJPCX_QUAD_STAMPS=1)
   long long* wave_times;  // nullptr, or [wavefront][4] (tuning aid, with stamps): cycles; Newton iterations run (each step the slowest candidate's); steps through the general solver; the largest per-lane contact count, summed over the steps
+  long long* wave_class;  // nullptr, or [wavefront][64] (tuning aid, MJPCX_QUAD_CLASSES=1): per class of wavefront-step -- bit 0 some candidate has a contact between
+                          // two moving geoms, bit 1 a leg-leg one, bit 2 some lane holds more contacts than LDS slots, bit 3 more than line-search slots --
+                          // [2 c] steps, [2 c + 1] cycles in the constraint solve, [32 + 2 c] steps, [32 + 2 c + 1] cycles of the whole step
   int cpw;            // candidates per wavefront (1, 2, 4, 8 or 16: the first 4 * cpw lanes of a wavefront work; 0 = 16). Small batches spread over more wavefronts: the lock-step is over fewer candidates and every SIMD gets one
+  double* ovf_slab;   // builds with QEXP_OVF_SLAB only (nullptr otherwise): per wavefront, (kQMaxCon - kQLdsSlots) x kQConRec x 64 doubles ([slot][field][lane], as the
+                      // LDS store): a lane's contacts beyond the LDS slots (quad_ovf_doubles_per_wave / quad_waves: quad_launch.h)
   int con_cap;        // a lane that collects more contacts than this hands its candidate on (0: kQMaxCon, the store's capacity; MJPCX_QUAD_CON_CAP lowers it, for tests of the hand-on)
 };
 

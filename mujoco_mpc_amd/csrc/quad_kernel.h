@@ -50,11 +50,11 @@ __device__ __forceinline__ double qd_rotv(double v, int d) {
 }
 // true in every lane of the wavefront if pred holds in any (the four-lane quads of a wavefront share its instruction stream)
 __device__ __forceinline__ bool qw_any(bool pred) { return __ballot(pred) != 0; }
-// the largest value of v (0..4) over the ACTIVE lanes of the wavefront, as a scalar (ballots: lanes that left a loop earlier do not take
+// the largest value of v (0..8) over the ACTIVE lanes of the wavefront, as a scalar (ballots: lanes that left a loop earlier do not take
 // part, and a butterfly of shuffles would lose values behind them)
 __device__ __forceinline__ int qw_max(int v) {
   int r = 0;
-  for (int k = 1; k <= 4; k++) r += __ballot(v >= k) != 0 ? 1 : 0;
+  for (int k = 1; k <= 8; k++) r += __ballot(v >= k) != 0 ? 1 : 0;
   return r;
 }
 __device__ __forceinline__ int qd_or(int v) {
@@ -64,7 +64,10 @@ __device__ __forceinline__ int qd_or(int v) {
 }
 
 // ---- the lane's contact store: the first kQLdsSlots records in LDS ([slot][field][lane]: a wavefront's access to one field is one
-// conflict-free ds_read_b64 / ds_write_b64), further ones in a private overflow array (scratch; touched by the rare lane with more contacts).
+// conflict-free ds_read_b64 / ds_write_b64), further ones in a private array (scratch: touched only by a lane with that many contacts -- 40 % of
+// the wavefront-steps of the bench's gait). QEXP_OVF_SLAB moves that array to a per-wavefront slab in global memory (QArgs::ovf_slab, the LDS
+// store's layout): measured 1.6 ms of 63 SLOWER on the gait (same box, back to back: 64.2 against 62.6 ms -- 64-bit address arithmetic per
+// access where scratch has an immediate offset), so the private array stays although it is 2.3 KB of the 5.4 KB private segment.
 // ---- the store of M while the solver runs: leg block + coupling per lane ([entry][lane]), the trunk block once per QUAD ([entry][quad]:
 // its four lanes write the same value and read it back as an LDS broadcast).
 namespace mjpcx { namespace quad {
@@ -72,7 +75,13 @@ struct QContact;
 constexpr int kQLdsSlots = 3;
 typedef __attribute__((address_space(3))) double qlds_f64;  // a typed LDS pointer: ds_read / ds_write instead of FLAT accesses
 typedef __attribute__((address_space(5))) double qprv_f64;  // a typed private pointer: scratch_load / scratch_store
+#ifndef QEXP_OVF_SLAB
 struct LdsStore { qlds_f64* lds; qprv_f64* ovf; };
+#define QOVF_STRIDE 1
+#else
+struct LdsStore { qlds_f64* lds; double* ovf; };
+#define QOVF_STRIDE 64
+#endif
 struct LdsM { qlds_f64* ml; qlds_f64* mt; };
 struct QProf { long long* buf; long long last; };
 } }
@@ -100,6 +109,13 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
     for (int o_ = 32; o_ > 0; o_ >>= 1) { const int t_ = __shfl_xor(mi_, o_); mi_ = t_ > mi_ ? t_ : mi_; const int u_ = __shfl_xor(mc_, o_); mc_ = u_ > mc_ ? u_ : mc_; } \
     long long* w_ = (a).wave_times + 4 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6); \
     if ((threadIdx.x & 63) == 0) { w_[1] += mi_; w_[2] += (general) ? 1 : 0; w_[3] += mc_; } } } while (0)
+
+// per-class cycle totals of the wavefront (a.wave_class, quad_abi.h): written by the wavefront's first lane
+#define QCLASS_NOW(a) ((a).wave_class ? (long long)__builtin_readcyclecounter() : 0ll)
+#define QCLASS_ADD(a, base, have_rel, pmask, ncon, t0) do { if ((a).wave_class) { \
+    const int c_ = (__ballot((have_rel) != 0) ? 1 : 0) | (__ballot((pmask) != 0) ? 2 : 0) | (__ballot((ncon) > mjpcx::quad::kQLdsSlots) ? 4 : 0) | (__ballot((ncon) > mjpcx::quad::kQLineSlots) ? 8 : 0); \
+    if ((threadIdx.x & 63) == 0) { long long* w_ = (a).wave_class + 64 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) + (base) + 2 * c_; \
+      w_[0] += 1; w_[1] += (long long)__builtin_readcyclecounter() - (t0); } } } while (0)
 
 // every fixed-trip loop over a small array is unrolled: a loop the compiler keeps rolled indexes its array at run time, and a private array
 // indexed at run time lives in scratch
@@ -146,7 +162,7 @@ __device__ __forceinline__ void qcs_load(const mjpcx::quad::LdsStore& cs, int sl
   using namespace mjpcx::quad;
   double v[kQConRec];
   if (slot < kQLdsSlots) { const qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f * 64]; }
-  else { const qprv_f64* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f]; }
+  else { const auto* p = cs.ovf + (size_t)(slot - kQLdsSlots) * kQConRec * QOVF_STRIDE; QUNROLL for (int f = 0; f < kQConRec; f++) v[f] = p[f * QOVF_STRIDE]; }
   QUNROLL for (int k = 0; k < 3; k++) { c.n[k] = v[k]; c.off[k] = v[3 + k]; }
   c.D0 = v[6];
   QUNROLL for (int k = 0; k < 6; k++) c.jar[k] = v[7 + k];
@@ -161,12 +177,12 @@ __device__ __forceinline__ void qcs_store(mjpcx::quad::LdsStore& cs, int slot, c
   QUNROLL for (int k = 0; k < 6; k++) v[7 + k] = c.jar[k];
   v[13] = (double)(c.depth | (c.fid << 2) | (c.rel << 5) | (c.sgn > 0 ? 64 : 0) | (c.pd << 7) | (c.px << 9) | (c.self << 11));
   if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int f = 0; f < kQConRec; f++) p[f * 64] = v[f]; }
-  else { qprv_f64* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int f = 0; f < kQConRec; f++) p[f] = v[f]; }
+  else { auto* p = cs.ovf + (size_t)(slot - kQLdsSlots) * kQConRec * QOVF_STRIDE; QUNROLL for (int f = 0; f < kQConRec; f++) p[f * QOVF_STRIDE] = v[f]; }
 }
 __device__ __forceinline__ void qcs_store_jar(mjpcx::quad::LdsStore& cs, int slot, const mjpcx::quad::QContact& c) {
   using namespace mjpcx::quad;
   if (slot < kQLdsSlots) { qlds_f64* p = cs.lds + slot * kQConRec * 64; QUNROLL for (int k = 0; k < 6; k++) p[(7 + k) * 64] = c.jar[k]; }
-  else { qprv_f64* p = cs.ovf + (slot - kQLdsSlots) * kQConRec; QUNROLL for (int k = 0; k < 6; k++) p[7 + k] = c.jar[k]; }
+  else { auto* p = cs.ovf + (size_t)(slot - kQLdsSlots) * kQConRec * QOVF_STRIDE; QUNROLL for (int k = 0; k < 6; k++) p[(7 + k) * QOVF_STRIDE] = c.jar[k]; }
 }
 
 namespace mjpcx { namespace quad {
@@ -199,9 +215,14 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __re
   QTask tk;
   tk.mocap = blob + bo.off_mocap; tk.weight = blob + bo.off_weight; tk.norm_p = blob + bo.off_normp; tk.norm_q = blob + bo.off_normq;
   tk.param = blob + bo.off_param; tk.re = blob + bo.off_rreal; tk.ri = reinterpret_cast<const int*>(blob + bo.off_rint); tk.risk = blob[bo.off_risk];
-  double ovf[(kQMaxCon - kQLdsSlots) * kQConRec];
   qlds_f64* wave_lds = (qlds_f64*)con_lds + (threadIdx.x >> 6) * (kQWaveLds / sizeof(double));
-  LdsStore cs{wave_lds + (threadIdx.x & 63), (qprv_f64*)ovf};
+#ifndef QEXP_OVF_SLAB
+  double ovf_prv[(kQMaxCon - kQLdsSlots) * kQConRec];
+  LdsStore cs{wave_lds + (threadIdx.x & 63), (qprv_f64*)ovf_prv};
+#else
+  double* ovf = a.ovf_slab + (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * ((kQMaxCon - kQLdsSlots) * kQConRec * 64) + (threadIdx.x & 63);
+  LdsStore cs{wave_lds + (threadIdx.x & 63), ovf};
+#endif
   LdsM ms{wave_lds + kQWaveCon + (threadIdx.x & 63), wave_lds + kQWaveCon + kQWaveMl + ((threadIdx.x & 63) >> 2)};
   QProf pf{nullptr, 0};
   if (a.stamps && blockIdx.x == 0 && threadIdx.x < 64) { pf.buf = a.stamps; pf.last = __builtin_readcyclecounter(); }

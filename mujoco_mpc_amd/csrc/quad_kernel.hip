@@ -8,13 +8,24 @@ std::string build_images(const mjpcx_model* m, const mjpcx_task* t, std::vector<
   tables.assign(sizeof(QuadTables), 0);
   return quad_build(m, t, reinterpret_cast<QuadModel*>(model.data()), reinterpret_cast<QuadTables*>(tables.data()));
 }
+static int pick_cpw(int N, int cpw) {
+  // candidates per wavefront: as many as it takes to give every SIMD of the 256 CUs one wavefront, 16 at most (cpw > 0: the caller's choice)
+  if (cpw <= 0) { cpw = 16; while (cpw > 1 && (N + cpw - 1) / cpw < 1024) cpw >>= 1; }
+  return cpw;
+}
+int quad_waves(int N, int cpw) { cpw = pick_cpw(N, cpw); return (N + cpw - 1) / cpw; }
+#ifdef QEXP_OVF_SLAB
+bool quad_uses_ovf_slab() { return true; }
+#else
+bool quad_uses_ovf_slab() { return false; }
+#endif
+size_t quad_ovf_doubles_per_wave() { return (size_t)(kQMaxCon - kQLdsSlots) * kQConRec * 64; }
 hipError_t launch_rollout_quad(const void* model_, const void* tables_, const double* blob, const QBlob& bo, const QArgs& a, int* stats, hipStream_t stream) {
   const QuadModel* model = static_cast<const QuadModel*>(model_);
   const QuadTables* tables = static_cast<const QuadTables*>(tables_);
-  // candidates per wavefront: as many as it takes to give every SIMD of the 256 CUs one wavefront, 16 at most (a.cpw > 0: the caller's choice);
   // four wavefronts per workgroup (one per SIMD of a CU, sharing one model image) once every CU has one
   QArgs q = a;
-  if (q.cpw <= 0) { q.cpw = 16; while (q.cpw > 1 && (a.N + q.cpw - 1) / q.cpw < 1024) q.cpw >>= 1; }
+  q.cpw = pick_cpw(a.N, a.cpw);
   const int waves = (a.N + q.cpw - 1) / q.cpw;
   const int W = waves >= 512 ? 4 : 1;
   const size_t lds = W * kQWaveLds;

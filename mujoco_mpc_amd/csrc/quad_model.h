@@ -45,8 +45,18 @@ struct QuadPair {
   double diag;                                            // mj_diagApprox: translational body_invweight0 of the two bodies
 };
 
+// the part of a (static geom, moving geom) pair's record that instantiating a contact reads, de-duplicated over the pairs (the A1's 160
+// pairs share a dozen): staged in LDS with the model, so that the collision stage -- which tests every capsule end near the floor against
+// the pair's margin -- never waits for global memory (measured: that stage was 11 of 79 M cycles per wavefront and rollout)
+struct QuadSPair {
+  double margin, includemargin, k, b, imp[5], diag;
+  int dim, fid;
+};
+constexpr int kQMaxSPair = 20;
+
 struct QuadGeom {
   int type, link, model_id, static_mask;  // link: -1 trunk, 0..2 link of the lane's leg; static_mask: bit s = collides with static geom s
+  int spair, pad3;                // byte s: index of the pair (static geom s, this geom) in QuadModel::spair
   double pos[3], rot[9], size[3]; // pose in the body frame (rotation matrix of geom_quat)
   double bound;                   // radius of its bounding sphere
 };
@@ -101,8 +111,9 @@ struct QuadModel {
   double pair_margin;
   // friction sets of the contact pairs: regularised mu, then the tangential / torsional / rolling coefficient, ZERO for rows the pair's
   // condim does not have (the cone formulas then reduce to the lower condim's)
-  int nfric, pad2;
+  int nfric, nspair;
   double fric[kQMaxFric][6];   // mu, tangential, torsional, rolling, 1 / mu^2, 1 / (mu^2 (1 + mu^2))
+  QuadSPair spair[kQMaxSPair]; // distinct contact-parameter sets of the (static geom, moving geom) pairs
 };
 
 // everything the kernel needs that is too rarely read to deserve LDS: the pair table [static][trunk geoms | leg geoms]
@@ -340,8 +351,21 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
       else ok = false;
       p.collide = ok;
       if (!ok) continue;
-      (slot_leg[g2] < 0 ? qm->trunk_geom[slot_idx[g2]] : qm->leg[slot_leg[g2]].geom[slot_idx[g2]]).static_mask |= 1 << s;
+      QuadGeom& qg = slot_leg[g2] < 0 ? qm->trunk_geom[slot_idx[g2]] : qm->leg[slot_leg[g2]].geom[slot_idx[g2]];
+      qg.static_mask |= 1 << s;
       { const std::string err = pair_params(g1, g2, p); if (!err.empty()) return err; }
+      QuadSPair sp;
+      std::memset(&sp, 0, sizeof sp);
+      sp.margin = p.margin; sp.includemargin = p.includemargin; sp.k = p.k; sp.b = p.b; sp.diag = p.diag; sp.dim = p.dim; sp.fid = p.fid;
+      std::memcpy(sp.imp, p.imp, sizeof sp.imp);
+      int si = -1;
+      for (int f = 0; f < qm->nspair; f++) if (std::memcmp(&qm->spair[f], &sp, sizeof sp) == 0) si = f;
+      if (si < 0) {
+        if (qm->nspair == kQMaxSPair) return std::string("more distinct contact-parameter sets over the (static geom, moving geom) pairs than the quad kernel stages");
+        qm->spair[qm->nspair] = sp;
+        si = qm->nspair++;
+      }
+      qg.spair |= si << (8 * s);
     }
   }
   // moving-geom pairs (pair_cull.h: MuJoCo's filters, each pair's class, the proofs). The kernel walks (own pair geom, pair geom of another
@@ -357,7 +381,11 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
     std::vector<double> self_lo(m->njnt, kPairCullPad), self_hi(m->njnt, kPairCullPad);  // pads of the proofs of the WALKED pairs inside one leg
     for (const MovingPair& q : mp) {
       if (q.kind == kPairOther) continue;                                 // (no narrow phase anywhere: left out and reported by WaveHost::build)
-      if (q.kind == kPairSolids && !(q.apart && q.tight_jnt < 0)) continue;  // (the same; the wave kernels drop two solids on the plain proof only)
+      // two solids have no narrow phase: the wavefront-per-candidate kernels and the oracle WATCH every such pair (warning bit 128 should a
+      // thin geom containing one come within the margin of the other) -- this layout cannot, so only a plain proof lets it drop one; with a
+      // tight-pad proof or none the model is declined (pair_cull.h's contract) and keeps the kernels that watch
+      if (q.kind == kPairSolids && !(q.apart && q.tight_jnt < 0))
+        return "two solids (box | cylinder) of moving bodies that are not proven apart with the wide pad: only the wavefront-per-candidate kernels watch such a pair";
       // what the layout can walk: sphere | capsule pairs between two legs or a leg and the trunk; a leg's sphere | capsule against a cylinder of
       // another leg, or of its own leg on a link above it
       const char* why = nullptr;

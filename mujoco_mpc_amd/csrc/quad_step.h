@@ -33,6 +33,10 @@
 #define QPROF_WAVE_HIST(pf, idx, v)
 #define QWAVE_TIMES(a, iters, general, ncon)
 #endif
+#ifndef QCLASS_NOW
+#define QCLASS_NOW(a) 0ll
+#define QCLASS_ADD(a, base, have_rel, pmask, ncon, t0)
+#endif
 #ifndef QUNROLL
 #define QUNROLL
 #endif
@@ -519,35 +523,13 @@ QD void contact_hess_apply(const QContact& c, const QHessOp& h, const double* v,
     Y[3 + k] = av * h.at[3 + k] + h.cq * ql[k] + rv * h.rt[3 + k];
   }
 }
-// first and second derivative of the contact's penalty along jv at jar + alpha jv (oracle constraint_line, in point space)
-QD void contact_line(const QContact& c, const double* fr, const double* jv, double alpha, double& g, double& h) {
-  const double* n = c.n;
-  double x[6];
-  QUNROLL for (int k = 0; k < 6; k++) x[k] = c.jar[k] + alpha * jv[k];
-  const double jn = dot3(n, x + 3), an = dot3(n, x), vn = dot3(n, jv + 3), wn = dot3(n, jv);
-  double tl[3], ar[3];
-  QUNROLL for (int k = 0; k < 3; k++) { tl[k] = x[3 + k] - jn * n[k]; ar[k] = x[k] - an * n[k]; }
-  const double mu = fr[0], f1s = fr[1] * fr[1], f3s = fr[2] * fr[2], f4s = fr[3] * fr[3];
-  const double T = sqrt(f1s * dot3(tl, tl) + f3s * an * an + f4s * dot3(ar, ar)), N = mu * jn;
-  if (N >= mu * T || (T <= 0 && N >= 0)) return;
-  const double UV = f1s * dot3(tl, jv + 3) + f3s * an * wn + f4s * dot3(ar, jv);
-  const double VV = f1s * (dot3(jv + 3, jv + 3) - vn * vn) + f3s * wn * wn + f4s * (dot3(jv, jv) - wn * wn);
-  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
-    const double Dq = c.D0 * fr[4];
-    g += c.D0 * jn * vn + Dq * UV;
-    h += c.D0 * vn * vn + Dq * VV;
-    return;
-  }
-  const double Dm = c.D0 * fr[5], NT = N - mu * T, iT = 1.0 / T;
-  const double dNT = mu * vn - mu * UV * iT, d2NT = -mu * (VV * iT - UV * UV * (iT * iT * iT));
-  g += Dm * NT * dNT;
-  h += Dm * (dNT * dNT + NT * d2NT);
-}
-
-// The same along a fixed search direction, for the first kQLineSlots contacts of a lane: alpha enters a contact's penalty only through
+// First and second derivative of a contact's penalty along a fixed search direction (oracle constraint_line, in point space): alpha enters a contact's penalty only through
 // jn = jn0 + alpha vn and the quadratic T^2 = A + 2 B alpha + C alpha^2 (B = UV at 0, C = VV, which does not depend on alpha), so a
 // trial costs a dozen flops per contact instead of a pass over its record. D0 carries the half weight of a leg-leg contact.
-constexpr int kQLineSlots = 4;
+#ifndef QEXP_LINE_SLOTS
+#define QEXP_LINE_SLOTS 4
+#endif
+constexpr int kQLineSlots = QEXP_LINE_SLOTS;
 #ifndef QREC
 #define QREC(dst, v) (dst) = (v)   // a trajectory-buffer store (the device build streams them past the caches: quad_kernel.h)
 #endif
@@ -647,14 +629,15 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
       }
       double Fs[6] = {0, 0, 0, 0, 0, 0};
       int zone;
-      if (c.rel) {  // self-collision: own leg's dofs only, the own side of the force; a leg-leg contact is counted half here, half in its partner's lane
-        const double cc = contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
-        cost += c.px != 0 ? 0.5 * cc : cc;
-        if (zone != 0) { QUNROLL for (int j = 0; j < 3; j++) if (rel_dof(c, j)) jl[j] += c.sgn * dot6(kin.cdof[j], Fs); }
+      // (ONE instance of the penalty for both kinds of contact: lanes of a wavefront that hold different kinds at the same index would
+      // otherwise run two copies of it one after the other)
+      const double cc = contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
+      cost += (c.rel && c.px != 0) ? 0.5 * cc : cc;  // (a leg-leg contact is counted half here, half in its partner's lane)
+      if (zone == 0) continue;
+      if (c.rel) {  // self-collision: own leg's dofs only, the own side of the force
+        QUNROLL for (int j = 0; j < 3; j++) if (rel_dof(c, j)) jl[j] += c.sgn * dot6(kin.cdof[j], Fs);
         continue;
       }
-      cost += contact_eval(c, m.fric[c.fid], Fs, nullptr, zone);
-      if (zone == 0) continue;
       QUNROLL for (int k = 0; k < 6; k++) Fown[k] += Fs[k];
       if (c.depth < 3) {  // rare: a contact on the trunk (this lane's share), the hip or the thigh link does not act on the dofs below it
         QUNROLL for (int j = 0; j < 3; j++) if (j >= c.depth) jl[j] -= dot6(kin.cdof[j], Fs);
@@ -672,13 +655,12 @@ QD double rows_eval(const QuadModel& m, const QuadLeg& L, const QKin& kin, QRows
 // factorisations, and the line search between them) do not carry 21 accumulators. nshallow counts the lane's contacts in a penalty
 // zone whose body is not the last link (their blocks need the correction of hessian_common).
 template <class CS>
-QD void rows_X(const QuadModel& m, CS& cs, int ncon, double* X, int& nshallow) {
+QD void rows_X(const QuadModel& m, CS& cs, int nstat, double* X, int& nshallow) {
   QUNROLL for (int e = 0; e < 21; e++) X[e] = 0;
   nshallow = 0;
-  for (int i = 0; i < ncon; i++) {
+  for (int i = 0; i < nstat; i++) {  // (the contacts with static geoms: the self-collision contacts behind them are hessian_rel's)
     QContact c;
     qcs_load(cs, i, c);
-    if (c.rel) continue;  // (self-collision contacts: hessian_blocks walks them itself)
     double Fs[6] = {0, 0, 0, 0, 0, 0};
     int zone;
     (void)contact_eval(c, m.fric[c.fid], Fs, X, zone);
@@ -707,14 +689,17 @@ QD void rows_step_only(const QuadLeg& L, QRows& R, CS& cs, int ncon, const doubl
 }
 // derivatives of the row penalties along the search direction at step alpha (quad sums)
 // (xl: the search direction's leg part, Vp: its chain_velocity; J search is recomputed per row: 9 flops per contact)
-template <bool MULTI, class CS>
-QD void rows_line_prepare(const QuadModel& m, CS& cs, int ncon, const double Vp[4][6], int pmask, QRel& rq, QLine* ql) {
+// qx (BEYOND): the coefficients of the lane's contacts beyond the slots, in an array that lives in memory (written once per line search,
+// read by every trial: the trial loop touches no other memory, so these reads stay in the vector L1) -- until round 5 a trial walked those
+// contacts' RECORDS (point velocity, square root, division per contact and trial): wavefront-steps with such a lane, a fifth of the bench's
+// gait, took 1.54 M cycles against 1.11 M
+template <bool MULTI, bool BEYOND, class CS>
+QD void rows_line_prepare(const QuadModel& m, CS& cs, int ncon, const double Vp[4][6], int pmask, bool beyond_slots, QLine* ql, QLine* qx) {
   QUNROLL for (int i = 0; i < kQLineSlots; i++) line_empty(ql[i]);
   int x = next_x(pmask, 0);
   for (int pass = 0; pass == 0 || (MULTI && x < 4); pass++) {
     QRel rx;
     if (x < 4) rel_exchange(Vp, x, rx);
-    if (pass == 0) rq = rx;  // (kept for the contacts beyond the slots: rows_line)
     QUNROLL for (int i = 0; i < kQLineSlots; i++) {
       if (i >= ncon) continue;
       QContact c;
@@ -723,6 +708,18 @@ QD void rows_line_prepare(const QuadModel& m, CS& cs, int ncon, const double Vp[
       double jv[6];
       if (c.rel) point_vel_rel(c, Vp, rx, jv); else point_vel(c, Vp, jv);
       line_coeffs(c, m.fric[c.fid], jv, c.rel && c.px != 0 ? 0.5 : 1.0, ql[i]);
+    }
+    if (BEYOND && beyond_slots) {  // (quad-uniform)
+      for (int i = kQLineSlots; i < ncon; i++) {
+        QContact c;
+        qcs_load(cs, i, c);
+        if (MULTI && !in_pass(c, pass, x)) continue;
+        double jv[6];
+        if (c.rel) point_vel_rel(c, Vp, rx, jv); else point_vel(c, Vp, jv);
+        QLine t;
+        line_coeffs(c, m.fric[c.fid], jv, c.rel && c.px != 0 ? 0.5 : 1.0, t);
+        qx[i - kQLineSlots] = t;
+      }
     }
     if (MULTI) x = next_x(pmask, x);
   }
@@ -746,9 +743,8 @@ QD void diag_prepare(const QuadLeg& L, const QRows& R, const double* xl, QDiag& 
     dg.lDjv2[j] = R.lm_side[j] != 0 ? R.lm_D[j] * lj * lj : 0.0;
   }
 }
-template <bool MULTI, bool BEYOND, class CS>
-QD void rows_line(const QuadModel& m, const QDiag& dg, bool any_limit, CS& cs, int ncon, double alpha, const double Vp[4][6], int pmask,
-                  bool beyond_slots, int nslot_wave, const QRel& rq, const QLine* ql, double& d1, double& d2) {
+template <bool BEYOND>
+QD void rows_line(const QDiag& dg, bool any_limit, int ncon, double alpha, bool beyond_slots, int nslot_wave, const QLine* ql, const QLine* qx, double& d1, double& d2) {
   double g = 0, h = 0;
   QUNROLL for (int j = 0; j < 3; j++) {
     const double x = fma(alpha, dg.jv[j], dg.x0[j]);
@@ -765,29 +761,8 @@ QD void rows_line(const QuadModel& m, const QDiag& dg, bool any_limit, CS& cs, i
   }
   // (slots no lane of the wavefront fills are skipped by a scalar branch: an empty slot adds exactly zero)
   QUNROLL for (int i = 0; i < kQLineSlots; i++) if (i < nslot_wave) line_eval(ql[i], alpha, g, h);
-  if (BEYOND && beyond_slots) {  // (quad-uniform: a lane of the quad holds more contacts than slots -- from the records; rq is the first pass's exchange)
-    int x = next_x(pmask, 0);
-    for (int pass = 0; pass == 0 || (MULTI && x < 4); pass++) {
-      QRel rx;
-      if (pass > 0) rel_exchange(Vp, x, rx); else rx = rq;
-      for (int i = kQLineSlots; i < ncon; i++) {
-        QContact c;
-        qcs_load(cs, i, c);
-        if (MULTI && !in_pass(c, pass, x)) continue;
-        double jv[6];
-        if (c.rel) {
-          point_vel_rel(c, Vp, rx, jv);
-          double gr = 0, hr = 0;
-          contact_line(c, m.fric[c.fid], jv, alpha, gr, hr);
-          const double w = c.px != 0 ? 0.5 : 1.0;
-          g += w * gr; h += w * hr;
-        } else {
-          point_vel(c, Vp, jv);
-          contact_line(c, m.fric[c.fid], jv, alpha, g, h);
-        }
-      }
-      if (MULTI) x = next_x(pmask, x);
-    }
+  if (BEYOND && beyond_slots) {  // (quad-uniform: a lane of the quad holds more contacts than slots)
+    for (int i = kQLineSlots; i < ncon; i++) { const QLine t = qx[i - kQLineSlots]; line_eval(t, alpha, g, h); }
   }
   d1 = qd_sum(g); d2 = qd_sum(h);
 }
@@ -819,14 +794,14 @@ QLS_ATTR double line_search(const QuadModel& m_in, int leg, const QRows R, CS cs
   diag_prepare(L, R, hl, dg);
   const bool any_limit = qw_any(R.lm_side[0] != 0 || R.lm_side[1] != 0 || R.lm_side[2] != 0);
   QLine ql[kQLineSlots];
-  QRel rq;
+  QLine qx[BEYOND ? kQMaxCon - kQLineSlots : 1];
   QPROF(pf, 40);
-  rows_line_prepare<MULTI>(m, cs, ncon, Vs, pmask, rq, ql);
   const bool beyond = BEYOND && qd_or(ncon > kQLineSlots ? 1 : 0) != 0;
+  rows_line_prepare<MULTI, BEYOND>(m, cs, ncon, Vs, pmask, beyond, ql, qx);
   const int nslot_wave = qw_max(ncon < kQLineSlots ? ncon : kQLineSlots);
   QPROF(pf, 41);
   double lo = 0, hi = -1, alpha = 0, d1, d2;
-  rows_line<MULTI, BEYOND>(m, dg, any_limit, cs, ncon, 0.0, Vs, pmask, beyond, nslot_wave, rq, ql, d1, d2);
+  rows_line<BEYOND>(dg, any_limit, ncon, 0.0, beyond, nslot_wave, ql, qx, d1, d2);
   d1 += q1; d2 += q2;
   const double d10 = fabs(d1);
   double step1 = 1e300, step2 = 1e300;  // the last step and the one before (rtsafe safeguard, oracle/contact.inc)
@@ -842,7 +817,7 @@ QLS_ATTR double line_search(const QuadModel& m_in, int leg, const QRows R, CS cs
     if (an == alpha) break;
     step2 = step1; step1 = fabs(an - alpha);
     alpha = an;
-    rows_line<MULTI, BEYOND>(m, dg, any_limit, cs, ncon, alpha, Vs, pmask, beyond, nslot_wave, rq, ql, d1, d2);
+    rows_line<BEYOND>(dg, any_limit, ncon, alpha, beyond, nslot_wave, ql, qx, d1, d2);
     d1 += q1 + alpha * q2; d2 += q2;
     if (fabs(d1) < gtol) break;
     if (d1 < 0) lo = alpha; else hi = alpha;
@@ -868,19 +843,18 @@ QD double line_search_beyond(const QuadModel& m_in, int leg, const QRows R, CS c
 // H += J' (d2s) J of the contacts: the lane's leg block and coupling from its own contacts' blocks (X, from rows_eval), the trunk block
 // from the quad sum of X. Contacts whose body is not the last link were counted for dofs below their body: taken out again.
 template <class CS>
-QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H);
+QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int nstat, double* X, int nshallow, Arrow& H);
 // Self-collision contacts: the own leg's block (Hl, packed 3 x 3) and, for the lower leg of a pair, the cross block (Hab; rows: own dofs,
 // columns: the partner's). Called BEFORE the iteration's X and H exist (QEXP_REL_LATE: after, as until round 4), so that their 75
 // numbers are not alive around this loop.
 template <class CS>
-QD void hessian_rel(const QuadModel& m, const QKin& kin, CS& cs, int ncon, int leg, int pmode, double* Hl, double (*Hab)[3]) {
+QD void hessian_rel(const QuadModel& m, const QKin& kin, CS& cs, int nstat, int ncon, int leg, int pmode, double* Hl, double (*Hab)[3]) {
   double cq[3][6];  // the partner leg's dof axes
   QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) cq[j][k] = qd_partner(kin.cdof[j][k], pmode);
   const bool isA = leg < (leg ^ pmode);
-  for (int i = 0; i < ncon; i++) {
+  for (int i = nstat; i < ncon; i++) {  // (the self-collision contacts are the last of the lane's list)
     QContact c;
     qcs_load(cs, i, c);
-    if (!c.rel) continue;
     QHessOp h;
     contact_hess_prepare(c, m.fric[c.fid], h);
     if (h.zone == 0) continue;
@@ -894,7 +868,7 @@ QD void hessian_rel(const QuadModel& m, const QKin& kin, CS& cs, int ncon, int l
   }
 }
 template <class CS>
-QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int ncon, double* X, int nshallow, Arrow& H) {
+QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int nstat, double* X, int nshallow, Arrow& H) {
   QUNROLL for (int j = 0; j < 3; j++) {
     double Y[6];
     QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += X[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
@@ -902,10 +876,10 @@ QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int ncon, do
     QUNROLL for (int k = 0; k < 6; k++) H.b[j][k] += trunk_dot(kin, k, Y);
   }
   if (nshallow > 0) {
-    for (int i = 0; i < ncon; i++) {
+    for (int i = 0; i < nstat; i++) {
       QContact c;
       qcs_load(cs, i, c);
-      if (c.depth >= 3 || c.rel) continue;
+      if (c.depth >= 3) continue;
       QHessOp h;
       contact_hess_prepare(c, m.fric[c.fid], h);
       if (h.zone == 0) continue;
@@ -940,16 +914,16 @@ QD void pick_block(const double B[3][3][3], int idx, double out[3][3]) {
   QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) out[r][c] = idx == 0 ? B[0][r][c] : (idx == 1 ? B[1][r][c] : B[2][r][c]);
 }
 template <class CS>
-QD void hessian_rel_general(const QuadModel& m, const QKin& kin, CS& cs, int ncon, ArrowG& H, int leg, int pmask) {
+QD void hessian_rel_general(const QuadModel& m, const QKin& kin, CS& cs, int nstat, int ncon, ArrowG& H, int leg, int pmask) {
   int x = next_x(pmask, 0);
   for (int pass = 0; pass == 0 || x < 4; pass++) {
     double cq[3][6];  // the partner leg's dof axes
     QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) cq[j][k] = qd_partner(kin.cdof[j][k], x & 3);
     const bool upper = x < 4 && (leg ^ x) > leg;
-    for (int i = 0; i < ncon; i++) {
+    for (int i = nstat; i < ncon; i++) {
       QContact c;
       qcs_load(cs, i, c);
-      if (!c.rel || !in_pass(c, pass, x)) continue;
+      if (!in_pass(c, pass, x)) continue;
       double Fs[6] = {0, 0, 0, 0, 0, 0}, Xc[21];
       QUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
       int zone;
@@ -1065,7 +1039,7 @@ QD void arrow_mul_s(const MS& ms, const double* xl, const double* xt, double* yl
 
 // search direction -H^-1 gradient in the general case of self-collision (out of line: rare, and it needs room for three cross blocks)
 template <class CS, class MS>
-QD bool newton_direction_general(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, const QRows& R_in, CS& cs_in, int ncon,
+QD bool newton_direction_general(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, const QRows& R_in, CS& cs_in, int nstat, int ncon,
                                         const double* X_in, int nshallow, int leg, int pmask, double* hl_io, double* ht_io) {
   const QKin kin = kin_in;
   const MS ms = ms_in;
@@ -1082,8 +1056,8 @@ QD bool newton_direction_general(const QuadModel& m, const QuadLeg& L, const QKi
     if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.a.l[tri(j, j)] += L.floss_D[j]; }
     if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.a.l[tri(j, j)] += R.lm_D[j];
   }
-  hessian_rel_general(m, kin, cs, ncon, H, leg, pmask);
-  hessian_common(m, kin, cs, ncon, X, nshallow, H.a);
+  hessian_rel_general(m, kin, cs, nstat, ncon, H, leg, pmask);
+  hessian_common(m, kin, cs, nstat, X, nshallow, H.a);
   if (!arrow_factor_general(H, leg)) return false;
   arrow_solve_general(H, hl, ht, leg);
   QUNROLL for (int j = 0; j < 3; j++) hl_io[j] = hl[j];
@@ -1094,10 +1068,11 @@ QD bool newton_direction_general(const QuadModel& m, const QuadLeg& L, const QKi
 // Newton solver. (sl, st) = qacc_smooth, (wl, wt) = warm start, M in the store `ms`; leaves qacc in (al, at) and J' force in
 // (fc_l, fc_t). Returns the flag bits (quad-uniform).
 template <bool GENERAL, class CS, class MS, class QProfT>
-QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon, int leg, int pmask, bool have_rel,
+QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon, int nrel, int leg, int pmask, bool have_rel,
                    const double* sl, const double* st, const double* wl, const double* wt, bool have_warm,
                    double* al, double* at, double* fc_l, double* fc_t, int& iters, QProfT& pf) {
   iters = 0;
+  const int nstat = ncon - nrel;  // the lane's contacts with static geoms come first, its nrel self-collision contacts after them
   // !GENERAL: one pair pattern (or none), the super-leg factorisation; GENERAL: the dense elimination of the leg blocks
   const int pmode = GENERAL ? 0 : (next_x(pmask, 0) & 3);
   QUNROLL for (int j = 0; j < 3; j++) al[j] = sl[j];
@@ -1147,20 +1122,20 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
     double X[21];
     int nshallow;
     if constexpr (GENERAL) {
-      rows_X(m, cs, ncon, X, nshallow);
-      if (!newton_direction_general(m, L, kin, ms, R, cs, ncon, X, nshallow, leg, pmask, hl, ht)) return kFlagNotPD;
+      rows_X(m, cs, nstat, X, nshallow);
+      if (!newton_direction_general(m, L, kin, ms, R, cs, nstat, ncon, X, nshallow, leg, pmask, hl, ht)) return kFlagNotPD;
     } else {
       // H = M + J' (d2s) J: the self-collision contacts' blocks first (into small accumulators, nothing else of the Hessian alive yet),
       // then the diagonal rows and the other contacts through their 6 x 6 spatial blocks; factored in place
       double Hl_rel[6] = {0, 0, 0, 0, 0, 0}, Hab_rel[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #ifndef QEXP_REL_LATE
-      if (have_rel) hessian_rel(m, kin, cs, ncon, leg, pmode, Hl_rel, Hab_rel);  // (quad-uniform)
+      if (have_rel) hessian_rel(m, kin, cs, nstat, ncon, leg, pmode, Hl_rel, Hab_rel);  // (quad-uniform)
 #endif
-      rows_X(m, cs, ncon, X, nshallow);
+      rows_X(m, cs, nstat, X, nshallow);
       Arrow H;
       load_arrow(ms, H);
 #ifdef QEXP_REL_LATE
-      if (have_rel) hessian_rel(m, kin, cs, ncon, leg, pmode, Hl_rel, Hab_rel);
+      if (have_rel) hessian_rel(m, kin, cs, nstat, ncon, leg, pmode, Hl_rel, Hab_rel);
 #endif
       QUNROLL for (int i = 0; i < 6; i++) H.l[i] += Hl_rel[i];
       QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) H.ab[r][c] = Hab_rel[r][c];
@@ -1168,7 +1143,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
         if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.l[tri(j, j)] += L.floss_D[j]; }
         if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.l[tri(j, j)] += R.lm_D[j];
       }
-      hessian_common(m, kin, cs, ncon, X, nshallow, H);
+      hessian_common(m, kin, cs, nstat, X, nshallow, H);
       QPROF(pf, 9);
       if (!arrow_factor(H, leg, pmode)) return kFlagNotPD;
       QUNROLL for (int j = 0; j < 3; j++) hl[j] = -hl[j];  // search direction
@@ -1218,7 +1193,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
 #define QNEWTON_ATTR QNOINLINE
 #endif
 template <bool GENERAL, class CS, class MS, class QProfT>
-QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int leg, int pmask, bool have_rel,
+QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int nrel, int leg, int pmask, bool have_rel,
                          const double* sl_in, const double* st_in, const double* wl_in, const double* wt_in, bool have_warm,
                          double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf_in) {
   // (an out-of-line function on the device: its register allocation starts afresh, so the rollout's state is parked once per step instead
@@ -1245,7 +1220,7 @@ QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, co
     QUNROLL for (int k = 0; k < 6; k++) { st[k] = stp[k]; wt[k] = wtp[k]; }
   }
   int iters = 0;
-  const int rc = newton_body<GENERAL>(m, L, kin, ms, R, cs, ncon, leg, pmask, have_rel, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
+  const int rc = newton_body<GENERAL>(m, L, kin, ms, R, cs, ncon, nrel, leg, pmask, have_rel, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
   {
     auto* alp = QREBIND_PRIVATE(double, al_out); auto* atp = QREBIND_PRIVATE(double, at_out);
     auto* flp = QREBIND_PRIVATE(double, fc_l_out); auto* ftp = QREBIND_PRIVATE(double, fc_t_out);
@@ -1259,8 +1234,8 @@ QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, co
 
 // ---------------------------------------------------------------- collision of the lane's geoms with the static geoms
 // a contact found: its record (mj_instantiateContact + mj_makeImpedance for its rows, in point space) goes to the lane's store
-template <class CS>
-QD void add_contact(const QuadPair& p, const double* com, const double* cvel, int depth, double dist, const double* pos, const double* normal,
+template <class PAIR, class CS>
+QD void add_contact(const PAIR& p, const double* com, const double* cvel, int depth, double dist, const double* pos, const double* normal,
                     CS& cs, int& ncon, int& flags, int rel = 0, int sgn = 1, int pd = 0, int px = 0, int self = 0) {
   if (!(dist < p.margin)) return;
   if (ncon >= kQMaxCon) { flags |= kFlagOverflow; return; }
@@ -1284,8 +1259,15 @@ QD void add_contact(const QuadPair& p, const double* com, const double* cvel, in
   qcs_store(cs, ncon, c);
   ncon++;
 }
+#ifdef QEXP_SPAIR_GLOBAL
+#define QSPAIR_T QuadPair
+#define QSPAIR(m, g, s) pairs[(s) * pair_stride]
+#else
+#define QSPAIR_T QuadSPair
+#define QSPAIR(m, g, s) (m).spair[((g).spair >> (8 * (s))) & 255]
+#endif
 template <class CS>
-QD void sphere_plane(const QuadPair& p, const double* com, const double* cvel, int depth, const double* pp, const double* pn,
+QD void sphere_plane(const QSPAIR_T& p, const double* com, const double* cvel, int depth, const double* pp, const double* pn,
                      const double* c, double r, CS& cs, int& ncon, int& flags) {
   const double dist = (c[0] - pp[0]) * pn[0] + (c[1] - pp[1]) * pn[1] + (c[2] - pp[2]) * pn[2] - r;
   double pos[3];
@@ -1294,8 +1276,7 @@ QD void sphere_plane(const QuadPair& p, const double* com, const double* cvel, i
 }
 // one moving geom (world pose gp / gR) against every static geom; oracle o_collision's pair table
 template <class CS>
-QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& g, const QuadPair* pairs /* [kQStatic] stride */, int pair_stride,
-                     const double* com, const double* cvel, int depth, const double* gp, const double* gR, CS& cs, int& ncon, int& flags) {
+QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& g, const QuadPair* pairs /* [kQStatic] stride: QEXP_SPAIR_GLOBAL only */, int pair_stride, const double* com, const double* cvel, int depth, const double* gp, const double* gR, CS& cs, int& ncon, int& flags) {
   for (int s = 0; s < m.nstatic; s++) {
     const QuadStatic& S = m.stat[s];
     if (S.type < 0) continue;
@@ -1305,8 +1286,8 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
       // bounding-sphere rejection: nothing of the geom within the margin of the plane (margins are far below this slack)
       const double cd = (gp[0] - p1[0]) * n[0] + (gp[1] - p1[1]) * n[1] + (gp[2] - p1[2]) * n[2];
       if (cd - g.bound >= 0.01) continue;
-      if (!((g.static_mask >> s) & 1)) continue;  // (QuadPair::collide, kept with the geom: the pair table is global memory)
-      const QuadPair& p = pairs[s * pair_stride];
+      if (!((g.static_mask >> s) & 1)) continue;
+      const QSPAIR_T& p = QSPAIR(m, g, s);  // (LDS: quad_model.h)
       if (g.type == MJPCX_GEOM_SPHERE) {
         sphere_plane(p, com, cvel, depth, p1, n, gp, g.size[0], cs, ncon, flags);
       } else if (g.type == MJPCX_GEOM_CAPSULE) {
@@ -1360,7 +1341,7 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
       const double reach = S.size[0] + g.size[0] + 0.01;
       if (len >= reach * reach) continue;
       if (!((g.static_mask >> s) & 1)) continue;
-      const QuadPair& p = pairs[s * pair_stride];
+      const QSPAIR_T& p = QSPAIR(m, g, s);
       len = sqrt(len);
       const double r1 = S.size[0], dist = len - r1 - g.size[0];
       if (!(dist < p.margin)) continue;
@@ -1375,7 +1356,7 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
       const double br = S.bound + g.size[0] + 0.01;
       if (rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] >= br * br) continue;
       if (!((g.static_mask >> s) & 1)) continue;
-      const QuadPair& p = pairs[s * pair_stride];
+      const QSPAIR_T& p = QSPAIR(m, g, s);
       QUNROLL for (int k = 0; k < 3; k++) loc[k] = R1[k] * rel[0] + R1[3 + k] * rel[1] + R1[6 + k] * rel[2];
       bool inside = true;
       QUNROLL for (int k = 0; k < 3; k++) {
@@ -1464,6 +1445,9 @@ QNOINLINE void pair_contacts_tests(const QuadModel& m_in, const QuadTables& tab,
   int ncon = args->ncon, flags = args->flags, pmask = args->pmask, nrel = args->nrel;
   const QuadLeg& L = m.leg[leg];
   const double mg = m.pair_margin;
+#ifdef QEXP_PAIRS_ENTRY
+  if (mg > -1.0 && need >= 0) { pf_in = pf; return; }  // (tuning: the cost of the call and of handing the arguments over, without any test)
+#endif
   const double com[3] = {args->com[0], args->com[1], args->com[2]};
   // The pretest of a pair: bounding spheres AND the boxes of the two geoms in the trunk's axes (a capsule's: half length along the axis plus
   // the radius). In a gait the legs work close to each other and the bounding spheres of their long capsules overlap all the time -- 1.7
@@ -1712,7 +1696,7 @@ struct QDyn {
   QRows R;
   double sl[3], st[6];      // qacc_smooth
   double fs_l[3], fs_t[6];  // qfrc_smooth
-  int ncon;
+  int ncon, nrel;           // the lane's contacts; the last nrel of them are between two moving geoms
   int pmask, have_rel;      // self-collision: bit x set if some leg A touches leg A xor x; whether the candidate has such contacts at all (quad-uniform)
 };
 // Position and velocity stages, collision, smooth dynamics, constraint rows: everything of mj_forward before the constraint solve.
@@ -1927,7 +1911,7 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
                              S.lq[2] >= L.self_box[2][0] && S.lq[2] <= L.self_box[2][1]);
     pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, self_walk, cs, ncon, flags, pmask, nrel, pf);
 #endif
-    D.ncon = ncon;
+    D.ncon = ncon; D.nrel = nrel;
     // bit x of pmask: some leg A touches leg A xor x. One bit set (the common case of self-collision) means disjoint pairs, which the
     // arrowhead factorisation takes as super-legs; two or three (a leg touching two others) go through the dense elimination of the
     // leg blocks (newton_direction_general)
@@ -2323,6 +2307,7 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
   int flags = 0, flag_step = 0;
   for (int t = 0; t < H; t++) {
     flag_step = t;
+    const long long step_t0 = QCLASS_NOW(a);
     const bool last = t == H - 1;
     bool bad = false;
     if (!last) {
@@ -2395,14 +2380,16 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     int iters;
     // one pair pattern of legs in contact (or none): the super-leg solver; a leg touching two others (rare): the general one -- for
     // every candidate of the wavefront then (it covers the other cases too, and the wavefront runs one solver instead of both in turn)
+    const long long solve_t0 = QCLASS_NOW(a);
     const bool wave_general = qw_any(((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom);
     // (the solver's inputs are handed over as pointers into S and D, which pins those two structs in memory -- measured the better
     // trade: copying them into a block of their own so that S and D stay in registers costs 2 ms of 57 in register pressure)
     if (wave_general)
-      flags = constraint_newton<true>(m, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+      flags = constraint_newton<true>(m, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     else
-      flags = constraint_newton<false>(m, D.kin, ms, D.R, cs, D.ncon, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+      flags = constraint_newton<false>(m, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     if (flags) break;
+    QCLASS_ADD(a, 0, D.have_rel, D.pmask, D.ncon, solve_t0);
     QWAVE_TIMES(a, iters, wave_general, D.ncon);
     QPROF(pf, 6);
     QPROF_COUNT(pf, 16, iters);
@@ -2412,6 +2399,7 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     QUNROLL for (int k = 0; k < 6; k++) bad |= qbad(at[k]);
     if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
     euler(m, leg, S, D, ms, al, at, fc_l, fc_t);
+    QCLASS_ADD(a, 32, D.have_rel, D.pmask, D.ncon, step_t0);
     QPROF(pf, 7);
   }
 #undef QNODE

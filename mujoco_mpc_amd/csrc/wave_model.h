@@ -268,6 +268,12 @@ struct WaveHost {
         // joints inside their ranges + pad, and a caller may start a rollout anywhere. One that cannot be proven apart is REPORTED too
         // (mjpcx_create_error() after MJPCX_OK; MJPCX_STRICT_PAIRS refuses the model).
         if (q.kind == kPairSolids) {
+          // (already within reach at the reference pose -- boxes resting on each other, say: every rollout from there would fail at its
+          // first step; one clear refusal instead)
+          if (contacts_on && solids_touch_at_qpos0(src, q.g1, q.g2)) {
+            return "geoms " + std::to_string(q.g1) + " and " + std::to_string(q.g2) + " (box | cylinder both, on two moving bodies) are within their contact margin at "
+                       "qpos0, and a pair of two such solids has no narrow phase here: every rollout from there would fail (warning bit 128)";
+          }
           pg1.push_back(q.g1);
           pg2.push_back(q.g2);
           if (q.apart && q.tight_jnt < 0) { pairs_apart++; continue; }

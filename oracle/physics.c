@@ -193,7 +193,8 @@ OData* odata_new(const mjpcx_model* m) {
     /* mj_implicit's matrix M - h dqfrc_smooth/dqvel is mj_Euler's M + h diag(damping) when no actuator force depends on velocity
      * (include/mjpcx.h): such a model steps through o_euler; any other is rejected */
     for (int i = 0; i < m->nu; i++)
-      if (m->actuator_biasprm && m->actuator_biasprm[3 * i + 2] != 0) return NULL;
+      if (m->actuator_biasprm && m->actuator_biastype && m->actuator_biastype[i] == MJPCX_BIAS_AFFINE && m->actuator_biasprm[3 * i + 2] != 0) return NULL;
+    if (m->disableflags & MJPCX_DSBL_EULERDAMP) return NULL; /* mj_implicit ignores the flag, o_euler honours it: not the same update */
   } else if (m->integrator != MJPCX_INT_EULER && m->integrator != MJPCX_INT_RK4) return NULL;
   if (m->na != 0) return NULL;
 
