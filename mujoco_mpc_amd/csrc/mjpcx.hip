@@ -368,6 +368,7 @@ struct mjpcx_ctx {
   int quad_cpw = 0;               // candidates per wavefront of the quad kernel (0: chosen from the batch size; MJPCX_QUAD_CPW)
   int quad_con_cap = 0;           // MJPCX_QUAD_CON_CAP=<n>: hand on candidates with more than n contacts in a lane (tests of the hand-on path)
   bool quad_no_fallback = false;  // MJPCX_QUAD_NO_FALLBACK=1: leave the handed-on candidates flagged (tuning: failure[] then carries reason and step)
+  bool no_quad_feedback = false;  // MJPCX_NO_QUAD_FEEDBACK=1: the iLQG rollouts stay on the wavefront-per-candidate kernel (A/B runs, tests)
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
   int quad_ids[7] = {0, 0, 0, 0, 0, 0, 0};  // residual_int[1..7] the quad model was built for (torso, head site, goal mocap, feet)
@@ -1022,6 +1023,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       c->quad_stats = getenv("MJPCX_QUAD_STATS") != nullptr;
       c->quad_stamps = getenv("MJPCX_QUAD_STAMPS") != nullptr;
       c->quad_no_fallback = getenv("MJPCX_QUAD_NO_FALLBACK") != nullptr;
+      c->no_quad_feedback = getenv("MJPCX_NO_QUAD_FEEDBACK") != nullptr;
       if (const char* e = getenv("MJPCX_QUAD_CON_CAP")) c->quad_con_cap = std::atoi(e);
       if (const char* e = getenv("MJPCX_QUAD_MIN_N")) c->quad_min_n = std::atoi(e);
       if (const char* e = getenv("MJPCX_QUAD_CPW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->quad_cpw = v; }
@@ -1641,8 +1643,35 @@ int do_feedback_wave(mjpcx_ctx* c, int N, int H, int mode, int representation, i
   a.states = (double*)c->d_states.p; a.actions = (double*)c->d_actions.p; a.times = (double*)c->d_times.p;
   a.residual = (double*)c->d_residual.p; a.costs = (double*)c->d_costs.p; a.trace = (double*)c->d_trace.p;
   a.total_return = (double*)c->d_ret.p; a.failure = (int*)c->d_fail.p;
-  w64::FeedbackWaveArgs fb{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state};
+  w64::FeedbackWaveArgs fb{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state, 0};
   const bool tree = c->wh.tree_ok && !c->no_tree;
+  // a model of the quad kernel's class: the iLQG rollouts are one or ten candidates of pure per-step latency, and the quad form's step is the
+  // shortest (one candidate per wavefront; MJPCX_NO_QUAD_FEEDBACK=1 keeps the wavefront-per-candidate kernel for A/B runs). Candidates it
+  // hands on are rolled out by that kernel afterwards, as for the sampling rollouts.
+  if (c->quad_ok && !c->no_quad_feedback && c->wh.m.integrator == MJPCX_INT_EULER) {
+    quad::QArgs q{};
+    q.N = N; q.H = H; q.P = 1; q.noise_mode = -1; q.nodes = (double*)c->d_nodes.p;
+    q.states = a.states; q.actions = a.actions; q.times = a.times; q.residual = a.residual; q.costs = a.costs; q.trace = a.trace;
+    q.total_return = a.total_return; q.failure = a.failure; q.con_cap = c->quad_con_cap; q.cpw = 1;
+    const quad::QBlob bo{wt.off_time, wt.off_mocap, wt.off_weight, wt.off_normp, wt.off_normq, wt.off_param, wt.off_risk, wt.off_rreal, wt.off_rint};
+    const quad::QFeedback qf{d[0], d[1], d[2], d[3], d[4], d[5], Tn, mode, representation, use_state};
+    HIPCHK(c, hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream));
+    HIPCHK(c, quad::launch_feedback_quad(c->d_qmodel.p, c->d_qtab.p, wt.blob, bo, q, qf, (int*)c->d_qstats.p, c->stream));
+    if (!c->h_qstats && hipHostMalloc(&c->h_qstats, 32, hipHostMallocDefault) != hipSuccess) c->h_qstats = nullptr;
+    bool handed_on = true;
+    if (c->h_qstats) {
+      HIPCHK(c, hipMemcpyAsync(c->h_qstats, c->d_qstats.p, 32, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      handed_on = static_cast<const int*>(c->h_qstats)[0] != 0;
+    }
+    if (!handed_on) {
+      c->N = N; c->H = H; c->P = 1;
+      c->have_rollout = true;
+      c->traj_candidate_major = true;
+      return MJPCX_OK;
+    }
+    fb.only_flagged = 1;
+  }
   const int Ppolicy = tree ? (int)(ndx + 2 * ds) : (int)((ndx + 2 * ds + nu - 1) / nu + 1);
   const size_t lds = wave_lds_bytes(c, Ppolicy, tree);
   const bool rk4 = c->wh.m.integrator == MJPCX_INT_RK4;

@@ -32,6 +32,12 @@ struct QArgs {
   int con_cap;        // a lane that collects more contacts than this hands its candidate on (0: kQMaxCon, the store's capacity; MJPCX_QUAD_CON_CAP lowers it, for tests of the hand-on)
 };
 
+// the feedback policy of the iLQG rollouts (FeedbackArgs of ilqg_kernels.h): nullptr members = the spline policy of QArgs
+struct QFeedback {
+  const double *times, *states, *actions, *gains, *improvement, *alpha;  // [Tn], [Tn][nq + nv], [Tn][nu], [Tn][nu][2 nv], [Tn][nu], [N]
+  int Tn, mode, representation, use_state;  // mode 0: index policy (RolloutDiscrete, planner.cc:630-692); 1: iLQGPolicy::Action at the time (policy.cc:82-161)
+};
+
 // offsets into the per-plan blob (WaveTaskT: wave_model.h)
 struct QBlob { int off_time, off_mocap, off_weight, off_normp, off_normq, off_param, off_risk, off_rreal, off_rint; };
 }  // namespace quad

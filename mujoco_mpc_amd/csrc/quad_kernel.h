@@ -192,8 +192,9 @@ constexpr size_t kQWaveLds = (kQWaveCon + kQWaveMl + kQWaveMt) * sizeof(double);
 
 // Workgroup = W wavefronts (W = 4 for the large batches: one per SIMD of a CU, sharing one model image; W = 1 spreads small batches
 // over the CUs). stats[0]: candidates handed to the fallback kernel, stats[1 + log2(flag)]: by reason.
-__global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __restrict__ gm, const QuadTables* __restrict__ tab, const double* __restrict__ blob,
-                                                           const QBlob bo, const QArgs a, int* __restrict__ stats) {
+template <bool FEEDBACK>
+__device__ __forceinline__ void quad_kernel_body(const QuadModel* __restrict__ gm, const QuadTables* __restrict__ tab, const double* __restrict__ blob,
+                                                 const QBlob& bo, const QArgs& a, const QFeedback& fb, int* __restrict__ stats) {
   __shared__ QuadModel sm;
   __shared__ QStaticPose sp[kQStatic];
   extern __shared__ __attribute__((aligned(16))) double con_lds[];
@@ -227,12 +228,24 @@ __global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __re
   QProf pf{nullptr, 0};
   if (a.stamps && blockIdx.x == 0 && threadIdx.x < 64) { pf.buf = a.stamps; pf.last = __builtin_readcyclecounter(); }
   const long long wave_t0 = a.wave_times ? __builtin_readcyclecounter() : 0;
-  const int flags = rollout(sm, *tab, sp, tk, blob, blob[bo.off_time], a, cand, leg, cs, ms, pf);
+  const int flags = rollout<FEEDBACK>(sm, *tab, sp, tk, blob, blob[bo.off_time], a, fb, cand, leg, cs, ms, pf);
   if (a.wave_times && (threadIdx.x & 63) == 0) a.wave_times[4 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6)] = __builtin_readcyclecounter() - wave_t0;
   if (flags && leg == 0 && stats) {
     atomicAdd(stats, 1);
     QUNROLL for (int b = 0; b < 7; b++) if (flags & (1 << b)) atomicAdd(stats + 1 + b, 1);
   }
+}
+__global__ __launch_bounds__(256) void rollout_quad_kernel(const QuadModel* __restrict__ gm, const QuadTables* __restrict__ tab, const double* __restrict__ blob,
+                                                           const QBlob bo, const QArgs a, int* __restrict__ stats) {
+  quad_kernel_body<false>(gm, tab, blob, bo, a, QFeedback{}, stats);
+}
+// The iLQG rollouts (the nominal under iLQGPolicy::Action, the line search's under the index policy) on the same step function: one or ten
+// candidates, ONE per wavefront (QArgs::cpw = 1) -- pure per-step latency, and the quad form's step is the shortest of the kernels' (0.145 ms
+// against 0.2 of the wavefront-per-candidate form: tools/latency_probe.py). A candidate it does not cover is flagged as in rollout_quad_kernel
+// and rolled out by rollout_feedback_tree_kernel.
+__global__ __launch_bounds__(256) void rollout_feedback_quad_kernel(const QuadModel* __restrict__ gm, const QuadTables* __restrict__ tab, const double* __restrict__ blob,
+                                                                    const QBlob bo, const QArgs a, const QFeedback fb, int* __restrict__ stats) {
+  quad_kernel_body<true>(gm, tab, blob, bo, a, fb, stats);
 }
 
 } }  // namespace mjpcx::quad

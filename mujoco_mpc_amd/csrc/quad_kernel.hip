@@ -20,6 +20,17 @@ bool quad_uses_ovf_slab() { return true; }
 bool quad_uses_ovf_slab() { return false; }
 #endif
 size_t quad_ovf_doubles_per_wave() { return (size_t)(kQMaxCon - kQLdsSlots) * kQConRec * 64; }
+hipError_t launch_feedback_quad(const void* model_, const void* tables_, const double* blob, const QBlob& bo, const QArgs& a, const QFeedback& fb, int* stats,
+                                hipStream_t stream) {
+  const QuadModel* model = static_cast<const QuadModel*>(model_);
+  const QuadTables* tables = static_cast<const QuadTables*>(tables_);
+  QArgs q = a;
+  q.cpw = 1;  // one candidate per wavefront, one wavefront per workgroup: the rollouts of an iLQG iteration are latency, not throughput
+  hipError_t e = hipFuncSetAttribute((const void*)rollout_feedback_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kQWaveLds));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(rollout_feedback_quad_kernel, dim3(a.N), dim3(64), kQWaveLds, stream, model, tables, blob, bo, q, fb, stats);
+  return hipGetLastError();
+}
 hipError_t launch_rollout_quad(const void* model_, const void* tables_, const double* blob, const QBlob& bo, const QArgs& a, int* stats, hipStream_t stream) {
   const QuadModel* model = static_cast<const QuadModel*>(model_);
   const QuadTables* tables = static_cast<const QuadTables*>(tables_);

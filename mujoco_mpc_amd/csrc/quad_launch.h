@@ -18,5 +18,8 @@ std::string build_images(const mjpcx_model* m, const mjpcx_task* t, std::vector<
 int quad_waves(int N, int cpw);
 size_t quad_ovf_doubles_per_wave();
 bool quad_uses_ovf_slab();  // (whether this build keeps a lane's contacts beyond the LDS slots in QArgs::ovf_slab: QEXP_OVF_SLAB)
+// the iLQG feedback rollouts of a.N candidates (one per wavefront); outputs and hand-on as launch_rollout_quad
+hipError_t launch_feedback_quad(const void* model, const void* tables, const double* blob, const QBlob& bo, const QArgs& a, const QFeedback& fb, int* stats,
+                                hipStream_t stream);
 hipError_t launch_rollout_quad(const void* model, const void* tables, const double* blob, const QBlob& bo, const QArgs& a, int* stats, hipStream_t stream);
 } }

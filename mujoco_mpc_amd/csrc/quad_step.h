@@ -2260,17 +2260,120 @@ QD double bernoulli_uniform(uint64_t seed, uint32_t cand, uint32_t iter) {
   return u53(o[0], o[1]);
 }
 
+// ---------------------------------------------------------------- the iLQG feedback policy in quad form
+// FindInterval / the interpolation weights of Zero / Linear / CubicInterpolation (mjpc/utilities.h:124-144, utilities.cc:304-422) on a
+// quad-uniform query: the arithmetic of ilqg_kernels.h interp_weights (the wavefront-per-candidate kernels' and the oracle's)
+struct QInterp { int i[4]; double w[4]; };
+QD void q_find_interval(const double* xs, double value, int length, int& b0, int& b1) {
+  int up = 0;
+  while (up < length && xs[up] <= value) up++;
+  const int lo = up - 1;
+  if (lo < 0) { b0 = b1 = 0; }
+  else if (lo > length - 1) { b0 = b1 = length - 1; }
+  else { b0 = lo; b1 = up < length - 1 ? up : length - 1; }
+}
+QD QInterp q_interp_weights(const double* xs, double value, int length, int representation) {
+  QInterp r;
+  int b0, b1;
+  q_find_interval(xs, value, length, b0, b1);
+  const int last = length - 1;
+  r.i[0] = b0 > 0 ? b0 - 1 : 0; r.i[1] = b0; r.i[2] = b0 < last ? b0 + 1 : last; r.i[3] = b0 + 2 <= last ? b0 + 2 : last;
+  r.w[0] = r.w[2] = r.w[3] = 0; r.w[1] = 1;
+  if (b0 == b1 || representation == 0) return r;
+  const double span = xs[b1] - xs[b0], t = (value - xs[b0]) / span;
+  if (representation != 2) { r.w[1] = 1.0 - t; r.w[2] = t; return r; }
+  const double t2 = t * t, t3 = t2 * t;
+  const double c0 = 2.0 * t3 - 3.0 * t2 + 1.0, c1 = (t3 - 2.0 * t2 + t) * span, c2 = -2.0 * t3 + 3.0 * t2, c3 = (t3 - t2) * span;
+  double m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
+  const double is1 = 1.0 / span;
+  if (b0 == 0) { m0[1] = -is1; m0[2] = is1; }
+  else { const double isl = 1.0 / (xs[b0] - xs[b0 - 1]); m0[0] = -0.5 * isl; m0[1] = 0.5 * isl - 0.5 * is1; m0[2] = 0.5 * is1; }
+  if (b1 == last) { if (length > 2) { m1[1] = -is1; m1[2] = is1; } }
+  else { const double isr = 1.0 / (xs[b1 + 1] - xs[b1]); m1[1] = -0.5 * is1; m1[2] = 0.5 * is1 - 0.5 * isr; m1[3] = 0.5 * isr; }
+  r.w[0] = c1 * m0[0];
+  r.w[1] = c0 + c1 * m0[1] + c3 * m1[1];
+  r.w[2] = c2 + c1 * m0[2] + c3 * m1[2];
+  r.w[3] = c3 * m1[3];
+  return r;
+}
+// StateDiff(ref, x) in the tangent space (mj_differentiatePos, utilities.cc:543-553; wave_ilqg.h w_state_diff): all 36 entries in every
+// lane -- [trunk position 3, rotation 3, the legs' joints 12 | trunk velocity 6, the legs' 12] -- the trunk's computed redundantly, a
+// leg's six broadcast from its lane. ref: a state row [qpos 19 | qvel 18]; its quaternion is used as it is (the caller normalises an
+// interpolated one).
+QD void q_state_diff(const double* ref, const double* rquat, const QState& S, int leg, double* dx) {
+  QUNROLL for (int k = 0; k < 3; k++) dx[k] = S.tq[k] - ref[k];
+  sub_quat(dx + 3, S.tq + 3, rquat);
+  QUNROLL for (int k = 0; k < 6; k++) dx[18 + k] = S.tv[k] - ref[19 + k];
+  double mine[6];
+  QUNROLL for (int j = 0; j < 3; j++) { mine[j] = S.lq[j] - ref[7 + 3 * leg + j]; mine[3 + j] = S.lv[j] - ref[19 + 6 + 3 * leg + j]; }
+  QUNROLL for (int j = 0; j < 3; j++) {
+    dx[6 + j] = qd_bcast<0>(mine[j]); dx[9 + j] = qd_bcast<1>(mine[j]); dx[12 + j] = qd_bcast<2>(mine[j]); dx[15 + j] = qd_bcast<3>(mine[j]);
+    dx[24 + j] = qd_bcast<0>(mine[3 + j]); dx[27 + j] = qd_bcast<1>(mine[3 + j]); dx[30 + j] = qd_bcast<2>(mine[3 + j]); dx[33 + j] = qd_bcast<3>(mine[3 + j]);
+  }
+}
+// the lane's three controls under the feedback policy at step t / time S.time (before the clamp)
+QD void feedback_ctrl(const QFeedback& fb, double alpha, int t, const QState& S, int leg, double* u) {
+  constexpr int nu = kQLegs * kQLinks, ds = 37, ndx = 36;
+  double dx[ndx];
+  if (fb.mode == 0) {  // index policy: u = actions[t] + alpha improvement[t] + K[t] StateDiff(states[t], x)
+    const int tt = t < fb.Tn ? t : fb.Tn - 1;
+    const double* ref = fb.states + (size_t)tt * ds;
+    q_state_diff(ref, ref + 3, S, leg, dx);
+    QUNROLL for (int e = 0; e < 3; e++) {
+      const int row = tt * nu + 3 * leg + e;
+      const double* K = fb.gains + (size_t)row * ndx;
+      double s = 0;
+      for (int j = 0; j < ndx; j++) s += K[j] * dx[j];
+      u[e] = fb.actions[row] + alpha * fb.improvement[row] + s;
+    }
+    return;
+  }
+  // iLQGPolicy::Action at the rollout's time: actions / gains over the Tn - 1 entries the reference passes, states over Tn
+  const double now = QUNIFORM_TIME(S.time);
+  int b0, b1;
+  q_find_interval(fb.times, now, fb.Tn, b0, b1);
+  const int rep = (b0 == b1) ? 0 : fb.representation;
+  const QInterp wa = q_interp_weights(fb.times, now, fb.Tn - 1, rep);
+  QUNROLL for (int e = 0; e < 3; e++) {
+    double v = 0;
+    QUNROLL for (int p = 0; p < 4; p++) v += wa.w[p] * fb.actions[(size_t)wa.i[p] * nu + 3 * leg + e];
+    u[e] = v;
+  }
+  if (!fb.use_state) return;
+  const QInterp ws = q_interp_weights(fb.times, now, fb.Tn, rep);
+  double xi[ds];
+  for (int i = 0; i < ds; i++) {
+    double v = 0;
+    QUNROLL for (int p = 0; p < 4; p++) v += ws.w[p] * fb.states[(size_t)ws.i[p] * ds + i];
+    xi[i] = v;
+  }
+  double qi[4] = {xi[3], xi[4], xi[5], xi[6]};
+  q_norm(qi);  // (policy.cc:118-125: interpolated quaternions are renormalised)
+  q_state_diff(xi, qi, S, leg, dx);
+  QUNROLL for (int e = 0; e < 3; e++) {
+    double s = 0;
+    for (int j = 0; j < ndx; j++) {
+      double kj = 0;
+      QUNROLL for (int p = 0; p < 4; p++) kj += wa.w[p] * fb.gains[((size_t)wa.i[p] * nu + 3 * leg + e) * ndx + j];
+      s += kj * dx[j];
+    }
+    u[e] += alpha * s;
+  }
+}
+
 // One lane's share of one candidate's rollout. `state0` = qpos[19] qvel[18] of the plan (Planner::SetState), `con` the lane's contact
 // list storage (kQMaxCon records). Returns the flag bits (0: rolled out; otherwise failure[cand] carries kQFallback and the
 // wavefront-per-candidate kernel takes the candidate over).
-template <class CS, class MS, class QProfT>
+// FEEDBACK: the candidate follows the iLQG feedback policy `fb` (Trajectory::RolloutDiscrete / Rollout with iLQGPolicy::Action) instead of a spline
+template <bool FEEDBACK, class CS, class MS, class QProfT>
 QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp, const QTask& tk, const double* state0, double time0, const QArgs& a,
-               int cand, int leg, CS& cs, MS& ms, QProfT& pf) {
+               const QFeedback& fb, int cand, int leg, CS& cs, MS& ms, QProfT& pf) {
   const QuadLeg& L = m.leg[leg];
   const int nu = kQLegs * kQLinks, P = a.P, H = a.H, nr = m.nr;
   const size_t N = (size_t)a.N;
+  const double fb_alpha = FEEDBACK ? fb.alpha[cand] : 0.0;
   // ---- the candidate's spline nodes of this leg's three actuators (AddNoiseToPolicy)
-  if (a.noise_mode >= 0) {
+  if (!FEEDBACK && a.noise_mode >= 0) {
     const int gi = a.candidate_offset + cand;
     double std = a.std0;
     if (a.noise_mode == 0 && a.std1 > 0) { if (bernoulli_uniform(a.seed, (uint32_t)gi, a.iteration) < 0.2) std = a.std1; }
@@ -2311,13 +2414,16 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     const bool last = t == H - 1;
     bool bad = false;
     if (!last) {
+      double ufb[3] = {0, 0, 0};
+      if (FEEDBACK) feedback_ctrl(fb, fb_alpha, t, S, leg, ufb);
       // policy: TimeSpline::Sample + Clamp (SamplingPolicy::Action)
       int up = 0;
       const double now = QUNIFORM_TIME(S.time);
-      while (up < P && a.node_times[up] <= now) up++;
+      while (!FEEDBACK && up < P && a.node_times[up] <= now) up++;
       QUNROLL for (int e = 0; e < 3; e++) {
         double u;
-        if (up == P || up == 0) u = QNODE(up == 0 ? 0 : P - 1, e);
+        if (FEEDBACK) u = ufb[e];
+        else if (up == P || up == 0) u = QNODE(up == 0 ? 0 : P - 1, e);
         else {
           const int lo = up - 1;
           const double tl = a.node_times[lo], tu = a.node_times[up];

@@ -329,6 +329,7 @@ template <int NMAX, bool TREE = false, bool RK4 = false>
 __global__ __launch_bounds__(64) void rollout_feedback_wave_kernel(const WModel m, const WTask tk, const RolloutArgs<wreal> a,
                                                                     const FeedbackWaveArgs fb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (fb.only_flagged && !(a.failure[blockIdx.x] & kQFallback)) return;  // (workgroup-uniform)
   feedback_rollout_body<NMAX, TREE, RK4>(m, tk, a, fb, smem_raw, blockIdx.x, threadIdx.x);
 }
 
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(64) void rollout_feedback_tree_kernel(const WModel 
                                                                     unsigned blob_bytes) {
   typedef LdsLayout<C, wreal> L;
   const int lane = threadIdx.x;
+  if (fb.only_flagged && !(a.failure[blockIdx.x] & kQFallback)) return;  // (workgroup-uniform)
   {
     const uint4* src = reinterpret_cast<const uint4*>(image);
     uint4* dst = reinterpret_cast<uint4*>(mjpcx_lds);

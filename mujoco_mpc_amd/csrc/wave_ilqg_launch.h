@@ -19,6 +19,7 @@ struct FdWaveArgs {
 struct FeedbackWaveArgs {
   const double *times, *states, *actions, *gains, *improvement, *alpha;  // as FeedbackArgs (ilqg_kernels.h)
   int Tn, mode, representation, use_state;
+  int only_flagged;  // roll out only the candidates whose failure[] carries kQFallback: the ones rollout_feedback_quad_kernel handed on
 };
 }  // namespace w64
 

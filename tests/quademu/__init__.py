@@ -26,6 +26,8 @@ def lib():
         L.quademu_forward.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, c_f64p, c_f64p, c_f64p]
         L.quademu_rollout.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       c_f64p, c_f64p, C.POINTER(MjpcxNoiseSpec), c_f64p] + [c_f64p] * 7 + [c_i32p, c_f64p, c_i32p]
+        L.quademu_rollout_feedback.argtypes = [C.POINTER(MjpcxModel), C.POINTER(MjpcxTask), c_f64p, C.c_double, c_f64p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int] + [c_f64p] * 6 + [c_f64p] * 7 + [c_i32p, c_i32p]
         _LIB = L
     return _LIB
 
@@ -58,6 +60,23 @@ def rollout(pm, pt, state, time, mocap, N, H, P, interp, node_times, node_values
                                None if noise is None else C.byref(noise), nom,
                                as_f64p(out["states"]), as_f64p(out["actions"]), as_f64p(out["times"]), as_f64p(out["residual"]), as_f64p(out["costs"]),
                                as_f64p(out["trace"]), as_f64p(out["total_return"]), as_i32p(out["failure"]), as_f64p(out["nodes"]), as_i32p(out["flags"]))
+    if rc != 0:
+        raise RuntimeError("quad kernel does not cover this model / task: " + check(pm, pt))
+    return out
+
+
+def rollout_feedback(pm, pt, state, time, mocap, N, H, mode, representation, use_state, times, states, actions, gains, improvement, alpha):
+    """N rollouts under the iLQG feedback policy (the arguments of capi.Context.rollout_feedback / pyoracle.rollout_feedback)"""
+    m = pm.struct
+    ds, nu, nr, ntr = m.nq + m.nv, m.nu, pt.struct.num_residual, pt.struct.num_trace
+    Tn = len(times)
+    out = dict(states=np.zeros((N, H, ds)), actions=np.zeros((N, H, nu)), times=np.zeros((N, H)), residual=np.zeros((N, H, nr)),
+               costs=np.zeros((N, H)), trace=np.zeros((N, H, 3 * ntr)), total_return=np.zeros(N), failure=np.zeros(N, np.int32), flags=np.zeros(N, np.int32))
+    keep = [_f(times), _f(states), _f(actions), _f(gains), _f(improvement), _f(alpha)]
+    rc = lib().quademu_rollout_feedback(pm.ptr, pt.ptr, as_f64p(_f(state)), float(time), as_f64p(_f(mocap)), N, H, mode, representation, int(use_state), Tn,
+                                        *[as_f64p(k) for k in keep],
+                                        as_f64p(out["states"]), as_f64p(out["actions"]), as_f64p(out["times"]), as_f64p(out["residual"]), as_f64p(out["costs"]),
+                                        as_f64p(out["trace"]), as_f64p(out["total_return"]), as_i32p(out["failure"]), as_i32p(out["flags"]))
     if rc != 0:
         raise RuntimeError("quad kernel does not cover this model / task: " + check(pm, pt))
     return out

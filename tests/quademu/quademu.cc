@@ -232,10 +232,10 @@ int quademu_forward(const mjpcx_model* model, const mjpcx_task* task, const doub
 
 // N rollouts. node_values: candidate-major [N][P][nu] or NULL (then `ns` generates them); outputs candidate-major [N][H][field];
 // nodes_out [N][P][nu] (the candidates rolled out); flags[N]
-int quademu_rollout(const mjpcx_model* model, const mjpcx_task* task, const double* state, double time, const double* mocap, int N, int H, int P,
-                    int interp, const double* node_times, const double* node_values, const mjpcx_noise_spec* ns, const double* nominal,
-                    double* states, double* actions, double* times, double* residual, double* costs, double* trace, double* total_return,
-                    int* failure, double* nodes_out, int* flags) {
+static int run_rollouts(const mjpcx_model* model, const mjpcx_task* task, const double* state, double time, const double* mocap, int N, int H, int P,
+                        int interp, const double* node_times, const double* node_values, const mjpcx_noise_spec* ns, const double* nominal,
+                        double* states, double* actions, double* times, double* residual, double* costs, double* trace, double* total_return,
+                        int* failure, double* nodes_out, int* flags, const QFeedback* fb) {
   Built* b = new Built;
   if (!build(model, task, mocap, *b).empty()) { delete b; return -1; }
   const int nu = model->nu;
@@ -265,7 +265,8 @@ int quademu_rollout(const mjpcx_model* model, const mjpcx_task* task, const doub
           EmuStore cs{con};
           EmuProf pf;
           EmuM ms;
-          const int fl = rollout(b->qm, b->qt, b->sp, b->tk, state, time, a, cand, leg, cs, ms, pf);
+          const int fl = fb ? rollout<true>(b->qm, b->qt, b->sp, b->tk, state, time, a, *fb, cand, leg, cs, ms, pf)
+                            : rollout<false>(b->qm, b->qt, b->sp, b->tk, state, time, a, QFeedback{}, cand, leg, cs, ms, pf);
           if (leg == 0 && flags) flags[cand] = fl;
         });
       }
@@ -275,6 +276,26 @@ int quademu_rollout(const mjpcx_model* model, const mjpcx_task* task, const doub
     for (int c = 0; c < N; c++) for (int j = 0; j < P * nu; j++) nodes_out[(size_t)c * P * nu + j] = nodes[(size_t)j * N + c];
   delete b;
   return 0;
+}
+
+int quademu_rollout(const mjpcx_model* model, const mjpcx_task* task, const double* state, double time, const double* mocap, int N, int H, int P,
+                    int interp, const double* node_times, const double* node_values, const mjpcx_noise_spec* ns, const double* nominal,
+                    double* states, double* actions, double* times, double* residual, double* costs, double* trace, double* total_return,
+                    int* failure, double* nodes_out, int* flags) {
+  return run_rollouts(model, task, state, time, mocap, N, H, P, interp, node_times, node_values, ns, nominal, states, actions, times, residual, costs, trace,
+                      total_return, failure, nodes_out, flags, nullptr);
+}
+
+// N rollouts under the iLQG feedback policy (mjpcx_rollout_feedback's arguments: mode 0 the index policy, 1 iLQGPolicy::Action)
+int quademu_rollout_feedback(const mjpcx_model* model, const mjpcx_task* task, const double* state, double time, const double* mocap, int N, int H, int mode,
+                             int representation, int use_state, int Tn, const double* fb_times, const double* fb_states, const double* fb_actions,
+                             const double* fb_gains, const double* fb_improvement, const double* alpha,
+                             double* states, double* actions, double* times, double* residual, double* costs, double* trace, double* total_return,
+                             int* failure, int* flags) {
+  QFeedback fb{fb_times, fb_states, fb_actions, fb_gains, fb_improvement, alpha, Tn, mode, representation, use_state};
+  const double t0[1] = {0.0};
+  return run_rollouts(model, task, state, time, mocap, N, H, 1, 0, t0, nullptr, nullptr, nullptr, states, actions, times, residual, costs, trace,
+                      total_return, failure, nullptr, flags, &fb);
 }
 
 }  // extern "C"

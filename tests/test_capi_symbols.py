@@ -119,6 +119,19 @@ def test_moving_geom_pairs_the_kernels_cannot_collide_are_reported():
     ctx = capi.Context(task.packed_model(), task.packed(), 0, 64)
     assert "NOT collided" in ctx.create_warning and "no narrow phase" in ctx.create_warning
     ctx.close()
+    # two solids that already touch at qpos0 (one box resting on the other): every rollout would fail at its first step (warning bit 128), so
+    # the model is refused outright with one clear message, strict or not
+    import tempfile
+    xml = open(os.path.join(ROOT, "tests", "models", "two_boxes.xml")).read().replace('pos="0.5 0 0.05"', 'pos="0.05 0 0.15"')
+    with tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False) as f:
+        f.write(xml)
+    try:
+        stacked = Task(name="scene", residual_id=0, model=mjcf.load_xml(f.name)).reset()
+    finally:
+        os.unlink(f.name)
+    with pytest.raises(capi.MjpcxError) as err:
+        capi.Context(stacked.packed_model(), stacked.packed(), 0, 64)
+    assert "within their contact margin at qpos0" in str(err.value)
     hum = load_task("HumanoidTrack")
     ctx = capi.Context(hum.packed_model(), hum.packed(), 0, 64)
     assert ctx.create_warning == ""   # nothing left uncollided, and the model has a registered kernel configuration (tree_registry.h)

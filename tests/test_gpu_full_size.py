@@ -22,7 +22,42 @@ def mocap7(mpos):
     return np.concatenate([np.concatenate([p, [1, 0, 0, 0]]) for p in np.asarray(mpos).reshape(-1, 3)])
 
 
-def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, tol, sample_stride, expect_quad=False):
+def contact_census(task, mocap, states):
+    """Which kinds of contact the oracle sees along recorded rollouts (states [n, H, nq + nv]): per candidate, whether some step carries a
+    contact between geoms of two different LEGS, and whether one involves a hip CYLINDER and a geom of another moving body -- the cases
+    the quad kernel's solver pays most for (super-leg elimination, the thin-solid narrow phase). Legs: the chains below the free-joint body."""
+    m = task.model
+    gb, gt, parent = m.arrays["geom_bodyid"], m.arrays["geom_type"], m.arrays["body_parentid"]
+    trunk = next(b for b in range(m.nbody) if m.arrays["body_dofnum"][b] == 6)
+
+    def leg_of(b):  # the child of the trunk the body hangs under (-1: the trunk itself or a body outside the robot)
+        while b > 0 and parent[b] != trunk:
+            b = parent[b]
+        return int(b) if b > 0 else -1
+    legs = [leg_of(int(b)) for b in gb]
+    ph = pyoracle.Physics(task.packed_model())
+    leg_leg, hip_cyl = set(), set()
+    nq = m.nq
+    for k in range(states.shape[0]):
+        for t in range(states.shape[1]):
+            s = states[k, t]
+            ph.set_state(s[:nq], s[nq:], 0.0, mocap)
+            ph.forward()
+            nc = int(ph.get("ncon")[0])
+            if nc == 0:
+                continue
+            for r in ph.get("contact").reshape(-1, 11)[:nc]:
+                g1, g2 = int(r[7]), int(r[8])
+                if legs[g1] < 0 or legs[g2] < 0:
+                    continue  # (a static geom or the trunk on one side)
+                if legs[g1] != legs[g2]:
+                    leg_leg.add(k)
+                if 5 in (gt[g1], gt[g2]):  # MJPCX_GEOM_CYLINDER: the A1's hips (against another leg's geom, or the own calf / foot)
+                    hip_cyl.add(k)
+    return leg_leg, hip_cyl
+
+
+def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, tol, sample_stride, expect_quad=False, census=False):
     pm, pt = task.packed_model(), task.packed()
     nu = task.model.nu
     dt = task.model.get_number("agent_timestep", task.model.timestep)
@@ -74,6 +109,10 @@ def full_size_properties(task, state, mocap, N, H, P, interp, mode, precision, t
     nodes = pyoracle.noise_candidates(pm, ns, P, nominal, sample)
     ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, len(sample), H, P, interp, times, nodes, num_threads=16)
     assert np.array_equal(ref["failure"], fail[sample]) and close(ret[sample], ref["total_return"], tol)
+    if census:
+        # the expensive paths are provably IN the sample: candidates whose legs touch each other, and ones with a hip cylinder in contact
+        leg_leg, hip_cyl = contact_census(task, mocap, ref["states"])
+        assert len(leg_leg) >= 1 and len(hip_cyl) >= 1, (len(leg_leg), len(hip_cyl))
     ctx.close()
 
 
@@ -83,8 +122,10 @@ def test_config3_quadruped_cross_entropy_n16384_h100():
     state = np.concatenate([quad.model.keyframes["home"]["qpos"], np.zeros(18)])
     mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
     # zero-order splines (the Cross-Entropy planner's default, cross_entropy/planner.h:141-142), 3 points
-    full_size_properties(quad, state, mocap, N=16384, H=100, P=3, interp=0, mode=capi.NOISE_CROSS_ENTROPY, precision=64, tol=1e-5,
-                         sample_stride=1024)
+    # as the Predictive-Sampling variant below: the oracle on 256 candidates of the batch at 1e-8, the quad kernel's hand-on statistics per
+    # reason, and the oracle's contact census of the sample (leg-leg and hip-cylinder contacts are in it)
+    full_size_properties(quad, state, mocap, N=16384, H=100, P=3, interp=0, mode=capi.NOISE_CROSS_ENTROPY, precision=64, tol=1e-8,
+                         sample_stride=64, expect_quad=True, census=True)
 
 
 def test_north_star_quadruped_predictive_sampling_n16384_h100():
@@ -95,7 +136,7 @@ def test_north_star_quadruped_predictive_sampling_n16384_h100():
     state = np.concatenate([quad.model.keyframes["home"]["qpos"], np.zeros(18)])
     mocap = np.array([0.3, 0, 0.26, 1, 0, 0, 0, -2.5, 0, 0, 1, 0, 0, 0])
     full_size_properties(quad, state, mocap, N=16384, H=100, P=3, interp=0, mode=capi.NOISE_SAMPLING, precision=64, tol=1e-8,
-                         sample_stride=64, expect_quad=True)
+                         sample_stride=64, expect_quad=True, census=True)
 
 
 @pytest.mark.parametrize("precision,tol", [(64, 1e-6), (32, 2e-3)])

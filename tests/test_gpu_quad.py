@@ -52,6 +52,35 @@ def test_the_quad_kernel_serves_the_a1(quad):
     ctx.close()
 
 
+def test_a_model_with_unproven_solid_pairs_keeps_the_kernel_that_watches_them(quad):
+    """quad_build declines a model in which two solids (box | cylinder) of moving bodies are not plainly proven apart: the quad layout
+    cannot watch such a pair, so at ANY batch size the model is served by the wavefront-per-candidate kernel, which does -- the outcome of
+    a rollout no longer depends on whether the batch is above the quad kernel's threshold. The A1 with hip cylinders long
+    enough to defeat the proof, 4096 candidates: not the quad kernel, and the oracle's returns and failure flags on a sample."""
+    m = quad.model
+    gt, gb = m.arrays["geom_type"], m.arrays["geom_bodyid"]
+    trunk = next(b for b in range(m.nbody) if m.arrays["body_dofnum"][b] == 6)
+    pm, pt = quad.packed_model(), quad.packed()
+    size = np.ctypeslib.as_array(pm.struct.geom_size, (m.ngeom * 3,)).reshape(-1, 3)
+    for g in range(m.ngeom):
+        if gt[g] == 5 and m.arrays["body_parentid"][gb[g]] == trunk:
+            size[g, 1] = 0.07
+    ctx = capi.Context(pm, pt, 0, 64)
+    assert "rollout_quad_kernel" not in ctx.kernel_name
+    N, H, P = 4096, 20, 3
+    state = np.concatenate([m.keyframes["home"]["qpos"], np.zeros(18)])
+    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+    ns = capi.make_noise_spec(seed=3, iteration=1, mode=capi.NOISE_SAMPLING, std0=0.1)
+    ctx.set_state(state, 0.0, MOCAP)
+    ctx.rollout_noise(N, H, 0, times, np.zeros((P, 12)), ns)
+    ret, fail = ctx.returns()
+    ctx.close()
+    sample = np.arange(1, N, 128)
+    nodes = pyoracle.noise_candidates(pm, ns, P, np.zeros((P, 12)), sample)
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, len(sample), H, P, 0, times, nodes, num_threads=8)
+    assert np.array_equal(ref["failure"] != 0, fail[sample] != 0) and close(ret[sample], ref["total_return"], 1e-8)
+
+
 @pytest.mark.parametrize("interp,std", [(capi.SPLINE_ZERO, 0.04), (capi.SPLINE_CUBIC, 0.08)])
 def test_all_six_buffers_against_the_oracle(quad, interp, std):
     pm, pt = quad.packed_model(), quad.packed()

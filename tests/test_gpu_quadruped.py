@@ -78,9 +78,11 @@ def test_falling_and_tumbling(quad):
     run(quad, np.concatenate([q, v]), N=4, H=60, P=3, interp=0, seed=5, tol=1e-5)
 
 
-def test_rollout_feedback_registered_and_generic_kernels_agree(quad, monkeypatch):
-    """The A1's feedback rollouts run on rollout_feedback_tree_kernel<A1> (model image and plan blob in LDS); MJPCX_NO_LDS_MODEL=1
-    keeps the context on the generic kernel (model behind global pointers). One step function, two sources of the same numbers."""
+def test_rollout_feedback_on_the_three_kernels_agree(quad, monkeypatch):
+    """The A1's feedback rollouts run on rollout_feedback_quad_kernel (four lanes per candidate, one candidate per wavefront: the shortest
+    step of the three); MJPCX_NO_QUAD_FEEDBACK=1 keeps them on rollout_feedback_tree_kernel<A1> (model image and plan blob in LDS),
+    MJPCX_NO_LDS_MODEL=1 on the generic kernel (model behind global pointers). Three kernels, the same numbers; and a candidate the quad
+    form hands on (MJPCX_QUAD_CON_CAP=1: every lane with two contacts) comes back from the wavefront-per-candidate kernel."""
     H = 24
     pm, pt, nom, state = nominal_quad(quad, H, 21)
     rng = np.random.default_rng(22)
@@ -90,22 +92,30 @@ def test_rollout_feedback_registered_and_generic_kernels_agree(quad, monkeypatch
     start = state.copy()
     start[19:] = 0.05 * rng.normal(size=18)
     got = []
-    for generic in (False, True):
-        if generic:
-            monkeypatch.setenv("MJPCX_NO_LDS_MODEL", "1")
+    for env in ({}, {"MJPCX_NO_QUAD_FEEDBACK": "1"}, {"MJPCX_NO_LDS_MODEL": "1"}, {"MJPCX_QUAD_CON_CAP": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         ctx = capi.Context(pm, pt, 0, 64)
-        assert ctx.kernel_name.startswith("rollout_wave_kernel" if generic else "rollout_quad_kernel")   # (the latter: a registered A1)
+        assert ctx.kernel_name.startswith("rollout_wave_kernel" if "MJPCX_NO_LDS_MODEL" in env else "rollout_quad_kernel")   # (the latter: a registered A1)
         ctx.set_state(start, 0.0, MOCAP)
         for mode, rep in ((0, 0), (1, 2)):
             ctx.rollout_feedback(H, mode, rep, 1, nom["times"], nom["states"], nom["actions"], gains, improvement, alpha)
             ret, fail = ctx.returns()
             tr = ctx.fetch_trajectory(3)
             got.append((ret.copy(), fail.copy(), tr.states.copy(), tr.actions.copy(), tr.residual.copy(), tr.costs.copy()))
+            if "MJPCX_QUAD_CON_CAP" in env:
+                assert ctx.quad_stats()["handed_on"] == len(alpha)   # (every candidate has a lane with two contacts at some step)
+            elif not env:   # (random gains of 0.05 push a joint of the wilder candidates out of the range the pair proofs cover: handed on, legitimately)
+                st = ctx.quad_stats()
+                assert st["handed_on"] < len(alpha) // 2 and st["handed_on"] == st["out_of_proof_range"], st
         ctx.close()
-    for a, b in zip(got[:2], got[2:]):
-        assert not a[1].any() and not b[1].any()
-        for x, y in zip(a, b):
-            assert close(x, y, 1e-12), float(np.abs(x - y).max())
+        for k in env:
+            monkeypatch.delenv(k)
+    for variant in (got[2:4], got[4:6], got[6:8]):
+        for a, b in zip(got[:2], variant):
+            assert not a[1].any() and not b[1].any()
+            for x, y in zip(a, b):
+                assert close(x, y, 1e-11), float(np.abs(x - y).max())
 
 
 @pytest.mark.parametrize("tree", [True, False])

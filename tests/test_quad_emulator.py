@@ -40,6 +40,24 @@ def test_other_models_are_declined_with_a_reason():
     assert why != ""  # (the humanoid has tendons, 27 dofs, no legged arrowhead)
 
 
+def test_two_solids_without_a_plain_proof_decline_the_model(quad):
+    """pair_cull.h's contract: a pair outside the quad layout must be proven apart or the model is declined. Two solids (box | cylinder) have
+    no narrow phase; the wavefront-per-candidate kernels WATCH them, this layout cannot -- so hip cylinders long enough that the proof over
+    the joint ranges no longer holds with the wide pad hand the model to the kernels that watch (until round 5 such pairs were silently
+    skipped and the batch size decided whether a rollout could fail on them)."""
+    m = quad.model
+    gt, gb = m.arrays["geom_type"], m.arrays["geom_bodyid"]
+    trunk = next(b for b in range(m.nbody) if m.arrays["body_dofnum"][b] == 6)
+    hips = [g for g in range(m.ngeom) if gt[g] == 5 and m.arrays["body_parentid"][gb[g]] == trunk]
+    assert len(hips) >= 4
+    pm = quad.packed_model()
+    size = np.ctypeslib.as_array(pm.struct.geom_size, (m.ngeom * 3,)).reshape(-1, 3)
+    for g in hips:
+        size[g, 1] = 0.07  # (half length 4 cm in the model)
+    why = quademu.check(pm, quad.packed())
+    assert "two solids" in why and "proven apart" in why
+
+
 def test_forward_pass_matches_the_oracle(quad):
     """mj_forward + residual at the home pose (no contact yet) and 30 steps later (feet and calves on the floor, Newton solver active)"""
     pm, pt = quad.packed_model(), quad.packed()
@@ -210,3 +228,36 @@ def test_random_states_through_the_emulator(quad):
             checked += int(ok.sum())
     assert worst < 1e-8, worst
     assert checked >= 48 and flagged <= 16, (checked, flagged)
+
+
+@pytest.mark.parametrize("mode,representation,use_state", [(0, 0, 1), (1, 1, 1), (1, 0, 0), (1, 2, 1)])
+def test_feedback_rollouts_match_the_oracle(quad, mode, representation, use_state):
+    """The iLQG rollouts on the quad step function (rollout_feedback_quad_kernel on the device): RolloutDiscrete with the index policy and
+    Trajectory::Rollout with iLQGPolicy::Action in its three representations, StateDiff on the free joint's quaternion, from an off-nominal
+    start -- all buffers against oracle/ilqg.c (1e-9 over 20 steps)."""
+    pm, pt = quad.packed_model(), quad.packed()
+    H = 20
+    rng = np.random.default_rng(12)
+    state = home_state(quad)
+    times4 = np.arange(4) * (H - 1) * 0.01 / 3
+    nodes = np.clip(rng.normal(0, 0.15, (1, 4, 12)), -1, 1)
+    nomr = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, 1, H, 4, 1, times4, nodes, num_threads=1)
+    nom = {k: v[0] for k, v in nomr.items() if k not in ("total_return", "failure")}
+    rng = np.random.default_rng(13)
+    gains = 0.05 * rng.normal(size=(H, 12, 36))
+    improvement = 0.05 * rng.normal(size=(H, 12))
+    alpha = np.concatenate([np.exp(np.linspace(0, np.log(1e-3), 5)), [0.0]])
+    start = state.copy()
+    start[0:3] += [0.01, -0.005, 0.004]
+    q = start[3:7] + [0.0, 0.02, -0.01, 0.015]
+    start[3:7] = q / np.linalg.norm(q)
+    start[19:] = 0.05 * rng.normal(size=18)
+    ref = pyoracle.rollout_feedback(pm, pt, start, 0.0, MOCAP, H, mode, representation, use_state, nom["times"], nom["states"], nom["actions"], gains,
+                                    improvement, alpha)
+    emu = quademu.rollout_feedback(pm, pt, start, 0.0, MOCAP, len(alpha), H, mode, representation, use_state, nom["times"], nom["states"], nom["actions"],
+                                   gains, improvement, alpha)
+    assert not emu["flags"].any() and not ref["failure"].any()
+    for k in ("states", "actions", "times", "residual", "costs", "trace", "total_return"):
+        assert close(emu[k], ref[k], 1e-9), (k, float(np.abs(emu[k] - ref[k]).max()))
+    if use_state:
+        assert np.ptp(emu["total_return"]) > 1e-7
