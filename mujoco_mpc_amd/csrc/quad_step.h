@@ -286,6 +286,108 @@ QD void arrow_solve(const Arrow& f, double* xl, double* xt, int leg, int pmode) 
     if (isA) { QUNROLL for (int r = 0; r < 3; r++) xl[r] -= f.ab[r][0] * ya[0] + f.ab[r][1] * ya[1] + f.ab[r][2] * ya[2]; }
   }
 }
+// ---- self-collision, a leg in contact with TWO OR THREE others: leaf elimination.
+// The legs' contact graph (an edge per pair of legs with a contact between them) of a tangled robot is nearly always a FOREST: a chain
+// A-B-C or a star. A leaf -- a leg with one partner -- is eliminated into that partner exactly as the lower leg of a pair is (Y = Haa^-1 Hab
+// replaces its cross block; the partner's block and trunk coupling receive the Schur updates), whether or not the partner has other partners,
+// and no fill appears between legs; what remains after at most three such slots is the arrowhead of independent legs. Every step is the pair
+// step at one xor value, so the state is an Arrow as for pairs -- until round 5 these candidates took a dense block elimination with fill
+// (ArrowG: 81 + 96 doubles in flight, 434 spill reloads in the solver's loop) and, rare as they are (17 of 16384), set the time of the
+// launch through the wavefronts that held them (57.9 -> 49.5 ms with them taken out). A graph with a CYCLE (three legs touching one another)
+// is not eliminated here: the candidate is handed to the wavefront-per-candidate kernel (kFlagPair), as anything else the quad form does not
+// cover -- a call to a dense elimination inside the solver's loop, however rarely taken, costs every step of every candidate (the values
+// live across the call leave the registers: 145 -> 1103 spill reloads in the loop).
+struct QPlan {
+  int nslots, x[3];  // slot s eliminates the leaves whose edge is the xor value x[s]
+  int eslot[4];      // the slot in which leg k is eliminated into leg k ^ x[eslot], or -1
+  bool cyclic;
+};
+QD int q_popc3(int m) { return ((m >> 1) & 1) + ((m >> 2) & 1) + ((m >> 3) & 1); }
+// mymask: bit x (1..3) set if the lane's leg touches leg ^ x. Computed identically in the four lanes from the four masks.
+QD QPlan make_plan(int mymask, int leg) {
+  int mk[4];
+  QUNROLL for (int k = 0; k < 4; k++) mk[k] = qd_or(leg == k ? (mymask & 14) : 0);
+  QPlan p;
+  p.nslots = 0; p.cyclic = false;
+  QUNROLL for (int k = 0; k < 4; k++) p.eslot[k] = -1;
+  QUNROLL for (int s = 0; s < 3; s++) {
+    p.x[s] = 0;
+    if ((mk[0] | mk[1] | mk[2] | mk[3]) != 0 && !p.cyclic) {
+      int x = 0;
+      QUNROLL for (int k = 3; k >= 0; k--) if (q_popc3(mk[k]) == 1) x = __builtin_ctz(mk[k]);  // the lowest leaf's edge
+      if (x == 0) p.cyclic = true;
+      else {
+        bool el[4];
+        QUNROLL for (int k = 0; k < 4; k++) el[k] = q_popc3(mk[k]) == 1 && __builtin_ctz(mk[k]) == x;
+        bool el2[4];  // (an isolated pair: both are leaves of each other -- the lower leg eliminates)
+        QUNROLL for (int k = 0; k < 4; k++) el2[k] = el[k] && !(el[k ^ x] && (k ^ x) < k);
+        p.x[s] = x;
+        p.nslots = s + 1;
+        QUNROLL for (int k = 0; k < 4; k++) if (el2[k]) p.eslot[k] = s;
+        QUNROLL for (int k = 0; k < 4; k++) if (el2[k] || el2[k ^ x]) mk[k] &= ~(1 << x);
+      }
+    }
+  }
+  if ((mk[0] | mk[1] | mk[2] | mk[3]) != 0) p.cyclic = true;
+  return p;
+}
+QD int plan_eslot(const QPlan& p, int k) { return k == 0 ? p.eslot[0] : (k == 1 ? p.eslot[1] : (k == 2 ? p.eslot[2] : p.eslot[3])); }
+// the xor value of the lane's own elimination edge, 0 if it is never a leaf
+QD int plan_my_x(const QPlan& p, int leg) {
+  const int s = plan_eslot(p, leg);
+  return s == 0 ? p.x[0] : (s == 1 ? p.x[1] : (s == 2 ? p.x[2] : 0));
+}
+// the leaves' eliminations, slot by slot (a.ab: the lane's cross block to the leg it is eliminated into -- rows: own dofs); then the
+// arrowhead of independent legs. Returns false (quad-uniform) if a pivot is not positive.
+QD bool arrow_factor_plan(Arrow& a, int leg, const QPlan& p) {
+  const int my_slot = plan_eslot(p, leg);
+  QUNROLL for (int s = 0; s < 3; s++) {
+    if (s >= p.nslots) continue;  // (quad-uniform)
+    const int x = p.x[s];
+    const bool elim = my_slot == s, recv = plan_eslot(p, leg ^ x) == s;
+    double lf[6];
+    QUNROLL for (int i = 0; i < 6; i++) lf[i] = a.l[i];
+    (void)leg_ldl(lf);  // (the pivots are checked by the common pass below, which factors the block again)
+    double G[6], W[3][6], Y[3][3];
+    QUNROLL for (int c = 0; c < 3; c++) {
+      double col[3] = {a.ab[0][c], a.ab[1][c], a.ab[2][c]};
+      leg_solve_l(lf, col);
+      Y[0][c] = col[0]; Y[1][c] = col[1]; Y[2][c] = col[2];
+    }
+    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c <= r; c++) G[tri(r, c)] = a.ab[0][r] * Y[0][c] + a.ab[1][r] * Y[1][c] + a.ab[2][r] * Y[2][c];
+    QUNROLL for (int k = 0; k < 6; k++) {
+      double col[3] = {a.b[0][k], a.b[1][k], a.b[2][k]};
+      leg_solve_l(lf, col);
+      QUNROLL for (int r = 0; r < 3; r++) W[r][k] = a.ab[0][r] * col[0] + a.ab[1][r] * col[1] + a.ab[2][r] * col[2];
+    }
+    if (elim) { QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) a.ab[r][c] = Y[r][c]; }
+    QUNROLL for (int i = 0; i < 6; i++) { const double g = qd_partner(G[i], x); if (recv) a.l[i] -= g; }
+    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int k = 0; k < 6; k++) { const double w = qd_partner(W[r][k], x); if (recv) a.b[r][k] -= w; }
+  }
+  return arrow_factor(a, leg, 0);
+}
+QD void arrow_solve_plan(const Arrow& f, double* xl, double* xt, int leg, const QPlan& p) {
+  const int my_slot = plan_eslot(p, leg);
+  QUNROLL for (int s = 0; s < 3; s++) {  // forward: the partner's right-hand side loses Y' g of the leaf
+    if (s >= p.nslots) continue;
+    const int x = p.x[s];
+    const bool recv = plan_eslot(p, leg ^ x) == s;
+    QUNROLL for (int c = 0; c < 3; c++) {
+      const double w = qd_partner(f.ab[0][c] * xl[0] + f.ab[1][c] * xl[1] + f.ab[2][c] * xl[2], x);
+      if (recv) xl[c] -= w;
+    }
+  }
+  arrow_solve(f, xl, xt, leg, 0);
+  QUNROLL for (int s = 2; s >= 0; s--) {  // backward: the leaf's solution loses Y x of its partner
+    if (s >= p.nslots) continue;
+    const int x = p.x[s];
+    const bool elim = my_slot == s;
+    double ya[3];
+    QUNROLL for (int c = 0; c < 3; c++) ya[c] = qd_partner(xl[c], x);
+    if (elim) { QUNROLL for (int r = 0; r < 3; r++) xl[r] -= f.ab[r][0] * ya[0] + f.ab[r][1] * ya[1] + f.ab[r][2] * ya[2]; }
+  }
+}
+
 // y = A x; yt needs the quad sum of the coupling term
 QD void arrow_mul(const Arrow& a, const double* xl, const double* xt, double* yl, double* yt) {
   QUNROLL for (int j = 0; j < 3; j++) {
@@ -867,6 +969,34 @@ QD void hessian_rel(const QuadModel& m, const QKin& kin, CS& cs, int nstat, int 
     }
   }
 }
+// The same for a leg with several partners (leaf elimination, QPlan): one pass per xor value present; the lane accumulates its own block
+// from all its self-collision contacts and the cross block of the ONE edge it is eliminated along (rows: own dofs, columns: that partner's).
+template <class CS>
+QD void hessian_rel_plan(const QuadModel& m, const QKin& kin, CS& cs, int nstat, int ncon, int leg, int pmask, const QPlan& plan, double* Hl, double (*Hab)[3]) {
+  const int myx = plan_my_x(plan, leg);
+  int x = next_x(pmask, 0);
+  for (int pass = 0; pass == 0 || x < 4; pass++) {  // (quad-uniform)
+    double cq[3][6];  // the dof axes of the leg x lanes across
+    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) cq[j][k] = qd_partner(kin.cdof[j][k], x & 3);
+    const bool holder = x < 4 && x == myx;
+    for (int i = nstat; i < ncon; i++) {
+      QContact c;
+      qcs_load(cs, i, c);
+      if (!in_pass(c, pass, x)) continue;
+      QHessOp h;
+      contact_hess_prepare(c, m.fric[c.fid], h);
+      if (h.zone == 0) continue;
+      QUNROLL for (int j = 0; j < 3; j++) {
+        if (!rel_dof(c, j)) continue;
+        double Y[6];
+        contact_hess_apply(c, h, kin.cdof[j], Y);
+        QUNROLL for (int ii = 0; ii <= j; ii++) if (rel_dof(c, ii)) Hl[tri(j, ii)] += dot6(kin.cdof[ii], Y);
+        if (holder && c.px != 0) { QUNROLL for (int ii = 0; ii < 3; ii++) if (ii < c.pd) Hab[j][ii] -= dot6(cq[ii], Y); }
+      }
+    }
+    x = next_x(pmask, x);
+  }
+}
 template <class CS>
 QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int nstat, double* X, int nshallow, Arrow& H) {
   QUNROLL for (int j = 0; j < 3; j++) {
@@ -903,108 +1033,6 @@ QD void hessian_common(const QuadModel& m, const QKin& kin, CS& cs, int nstat, d
   }
 }
 
-// ---------------------------------------------------------------- self-collision, the general case: a leg in contact with two others
-// The leg blocks no longer decouple into pairs: dense block elimination of the four leg blocks in leg order (0, 1, 2, 3) with fill, then
-// the trunk as for independent legs. Lane A holds, per xor value x, the block between A and A xor x if A xor x > A (rows: A's dofs,
-// columns: the other leg's) and, once A is eliminated, Y = Haa^-1 of it. A few candidates in ten thousand come here, so everything is
-// exchanged by broadcast and computed redundantly in the four lanes; the pair case above is this elimination restricted to one block.
-struct ArrowG { Arrow a; double x[3][3][3]; };
-QD double bcast_k(double v, int k) { return k == 0 ? qd_bcast<0>(v) : (k == 1 ? qd_bcast<1>(v) : (k == 2 ? qd_bcast<2>(v) : qd_bcast<3>(v))); }
-QD void pick_block(const double B[3][3][3], int idx, double out[3][3]) {
-  QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) out[r][c] = idx == 0 ? B[0][r][c] : (idx == 1 ? B[1][r][c] : B[2][r][c]);
-}
-template <class CS>
-QD void hessian_rel_general(const QuadModel& m, const QKin& kin, CS& cs, int nstat, int ncon, ArrowG& H, int leg, int pmask) {
-  int x = next_x(pmask, 0);
-  for (int pass = 0; pass == 0 || x < 4; pass++) {
-    double cq[3][6];  // the partner leg's dof axes
-    QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) cq[j][k] = qd_partner(kin.cdof[j][k], x & 3);
-    const bool upper = x < 4 && (leg ^ x) > leg;
-    for (int i = nstat; i < ncon; i++) {
-      QContact c;
-      qcs_load(cs, i, c);
-      if (!in_pass(c, pass, x)) continue;
-      double Fs[6] = {0, 0, 0, 0, 0, 0}, Xc[21];
-      QUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
-      int zone;
-      (void)contact_eval(c, m.fric[c.fid], Fs, Xc, zone);
-      if (zone == 0) continue;
-      QUNROLL for (int j = 0; j < 3; j++) {
-        if (!rel_dof(c, j)) continue;
-        double Y[6];
-        QUNROLL for (int p = 0; p < 6; p++) { double v = 0; QUNROLL for (int q = 0; q < 6; q++) v += Xc[tri(p, q)] * kin.cdof[j][q]; Y[p] = v; }
-        QUNROLL for (int ii = 0; ii <= j; ii++) if (rel_dof(c, ii)) H.a.l[tri(j, ii)] += dot6(kin.cdof[ii], Y);
-        if (upper && c.px != 0) {
-          QUNROLL for (int ii = 0; ii < 3; ii++) {
-            if (ii >= c.pd) continue;
-            const double v = dot6(cq[ii], Y);
-            QUNROLL for (int xx = 0; xx < 3; xx++) if (xx == x - 1) H.x[xx][j][ii] -= v;
-          }
-        }
-      }
-    }
-    x = next_x(pmask, x);
-  }
-}
-// returns false (quad-uniform) if a pivot is not positive
-QD bool arrow_factor_general(ArrowG& g, int leg) {
-  QUNROLL for (int k = 0; k < 3; k++) {  // eliminate leg k: its lane's blocks to everybody, the arithmetic in every lane
-    double lk[6], bk[3][6], xk[3][3][3];
-    QUNROLL for (int i = 0; i < 6; i++) lk[i] = bcast_k(g.a.l[i], k);
-    QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 6; c++) bk[r][c] = bcast_k(g.a.b[r][c], k);
-    QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) xk[x][r][c] = bcast_k(g.x[x][r][c], k);
-    (void)leg_ldl(lk);  // (the pivots are checked by the common pass, which factors the block again)
-    double Y[3][3][3], Z[3][6];
-    QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int c = 0; c < 3; c++) {
-      double col[3] = {xk[x][0][c], xk[x][1][c], xk[x][2][c]};
-      leg_solve_l(lk, col);
-      Y[x][0][c] = col[0]; Y[x][1][c] = col[1]; Y[x][2][c] = col[2];
-    }
-    QUNROLL for (int c = 0; c < 6; c++) {
-      double col[3] = {bk[0][c], bk[1][c], bk[2][c]};
-      leg_solve_l(lk, col);
-      Z[0][c] = col[0]; Z[1][c] = col[1]; Z[2][c] = col[2];
-    }
-    if (leg == k) {
-      QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) g.x[x][r][c] = Y[x][r][c];
-    } else if (leg > k) {
-      double Hkm[3][3], Ym[3][3];  // leg k's block to this leg (rows: k's dofs) and Hkk^-1 of it
-      pick_block(xk, (leg ^ k) - 1, Hkm);
-      pick_block(Y, (leg ^ k) - 1, Ym);
-      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c <= r; c++) g.a.l[tri(r, c)] -= Hkm[0][r] * Ym[0][c] + Hkm[1][r] * Ym[1][c] + Hkm[2][r] * Ym[2][c];
-      QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 6; c++) g.a.b[r][c] -= Hkm[0][r] * Z[0][c] + Hkm[1][r] * Z[1][c] + Hkm[2][r] * Z[2][c];
-      QUNROLL for (int xp = 1; xp <= 3; xp++) {  // this leg's blocks to the legs above it: fill from k's blocks to both
-        const int p = leg ^ xp;
-        if (p <= leg) continue;
-        double Yp[3][3];
-        pick_block(Y, (k ^ p) - 1, Yp);
-        QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) g.x[xp - 1][r][c] -= Hkm[0][r] * Yp[0][c] + Hkm[1][r] * Yp[1][c] + Hkm[2][r] * Yp[2][c];
-      }
-    }
-  }
-  return arrow_factor(g.a, leg, 0);
-}
-QD void arrow_solve_general(const ArrowG& g, double* xl, double* xt, int leg) {
-  QUNROLL for (int k = 0; k < 3; k++) {  // forward: x_o -= Y_ko' x_k
-    double vb[3][3];  // per xor value: Y' x_k of leg k
-    QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int c = 0; c < 3; c++)
-      vb[x][c] = bcast_k(g.x[x][0][c] * xl[0] + g.x[x][1][c] * xl[1] + g.x[x][2][c] * xl[2], k);
-    if (leg > k) {
-      const int xo = (leg ^ k) - 1;
-      QUNROLL for (int c = 0; c < 3; c++) xl[c] -= xo == 0 ? vb[0][c] : (xo == 1 ? vb[1][c] : vb[2][c]);
-    }
-  }
-  arrow_solve(g.a, xl, xt, leg, 0);
-  QUNROLL for (int k = 2; k >= 0; k--) {  // backward: x_k -= Y_ko x_o over the legs o above k (final by now)
-    QUNROLL for (int x = 1; x <= 3; x++) {
-      const int o = k ^ x;
-      if (o <= k) continue;
-      const double xo[3] = {bcast_k(xl[0], o), bcast_k(xl[1], o), bcast_k(xl[2], o)};
-      if (leg == k) { QUNROLL for (int r = 0; r < 3; r++) xl[r] -= g.x[x - 1][r][0] * xo[0] + g.x[x - 1][r][1] * xo[1] + g.x[x - 1][r][2] * xo[2]; }
-    }
-  }
-}
-
 // M lives in the includer's store while the solver runs (LDS on the device: the leg block and the coupling per lane, the trunk block
 // once per quad): element accessors qms_l / qms_b / qms_t, setters qms_set_*.
 template <class MS>
@@ -1037,43 +1065,20 @@ QD void arrow_mul_s(const MS& ms, const double* xl, const double* xt, double* yl
   }
 }
 
-// search direction -H^-1 gradient in the general case of self-collision (out of line: rare, and it needs room for three cross blocks)
-template <class CS, class MS>
-QD bool newton_direction_general(const QuadModel& m, const QuadLeg& L, const QKin& kin_in, const MS& ms_in, const QRows& R_in, CS& cs_in, int nstat, int ncon,
-                                        const double* X_in, int nshallow, int leg, int pmask, double* hl_io, double* ht_io) {
-  const QKin kin = kin_in;
-  const MS ms = ms_in;
-  const QRows R = R_in;
-  CS cs = cs_in;
-  double X[21], hl[3], ht[6];
-  QUNROLL for (int e = 0; e < 21; e++) X[e] = X_in[e];
-  QUNROLL for (int j = 0; j < 3; j++) hl[j] = -hl_io[j];
-  QUNROLL for (int k = 0; k < 6; k++) ht[k] = -ht_io[k];
-  ArrowG H;
-  load_arrow(ms, H.a);
-  QUNROLL for (int x = 0; x < 3; x++) QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) H.x[x][r][c] = 0;
-  QUNROLL for (int j = 0; j < 3; j++) {
-    if (L.floss[j] > 0) { const double x = R.fl_jar[j]; if (x > -L.floss_R[j] * L.floss[j] && x < L.floss_R[j] * L.floss[j]) H.a.l[tri(j, j)] += L.floss_D[j]; }
-    if (R.lm_side[j] != 0 && R.lm_jar[j] < 0) H.a.l[tri(j, j)] += R.lm_D[j];
-  }
-  hessian_rel_general(m, kin, cs, nstat, ncon, H, leg, pmask);
-  hessian_common(m, kin, cs, nstat, X, nshallow, H.a);
-  if (!arrow_factor_general(H, leg)) return false;
-  arrow_solve_general(H, hl, ht, leg);
-  QUNROLL for (int j = 0; j < 3; j++) hl_io[j] = hl[j];
-  QUNROLL for (int k = 0; k < 6; k++) ht_io[k] = ht[k];
-  return true;
-}
-
 // Newton solver. (sl, st) = qacc_smooth, (wl, wt) = warm start, M in the store `ms`; leaves qacc in (al, at) and J' force in
 // (fc_l, fc_t). Returns the flag bits (quad-uniform).
 template <bool GENERAL, class CS, class MS, class QProfT>
-QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon, int nrel, int leg, int pmask, bool have_rel,
+QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const MS& ms, QRows& R, CS& cs, int ncon, int nrel, int leg, int pmask, int mymask, bool have_rel,
                    const double* sl, const double* st, const double* wl, const double* wt, bool have_warm,
                    double* al, double* at, double* fc_l, double* fc_t, int& iters, QProfT& pf) {
   iters = 0;
   const int nstat = ncon - nrel;  // the lane's contacts with static geoms come first, its nrel self-collision contacts after them
-  // !GENERAL: one pair pattern (or none), the super-leg factorisation; GENERAL: the dense elimination of the leg blocks
+  QPlan plan;
+  if constexpr (GENERAL) {
+    plan = make_plan(mymask, leg);
+    if (plan.cyclic) return kFlagPair;  // (quad-uniform) three legs touching one another: handed to the wavefront-per-candidate kernel
+  }
+  // !GENERAL: one pair pattern (or none), the super-leg factorisation; GENERAL: leaf elimination over several patterns (QPlan)
   const int pmode = GENERAL ? 0 : (next_x(pmask, 0) & 3);
   QUNROLL for (int j = 0; j < 3; j++) al[j] = sl[j];
   QUNROLL for (int k = 0; k < 6; k++) at[k] = st[k];
@@ -1121,22 +1126,18 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
     QPROF(pf, 8);
     double X[21];
     int nshallow;
-    if constexpr (GENERAL) {
-      rows_X(m, cs, nstat, X, nshallow);
-      if (!newton_direction_general(m, L, kin, ms, R, cs, nstat, ncon, X, nshallow, leg, pmask, hl, ht)) return kFlagNotPD;
-    } else {
+    {
       // H = M + J' (d2s) J: the self-collision contacts' blocks first (into small accumulators, nothing else of the Hessian alive yet),
       // then the diagonal rows and the other contacts through their 6 x 6 spatial blocks; factored in place
       double Hl_rel[6] = {0, 0, 0, 0, 0, 0}, Hab_rel[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#ifndef QEXP_REL_LATE
-      if (have_rel) hessian_rel(m, kin, cs, nstat, ncon, leg, pmode, Hl_rel, Hab_rel);  // (quad-uniform)
-#endif
+      if (have_rel) {  // (quad-uniform)
+        if constexpr (GENERAL) hessian_rel_plan(m, kin, cs, nstat, ncon, leg, pmask, plan, Hl_rel, Hab_rel);
+        else hessian_rel(m, kin, cs, nstat, ncon, leg, pmode, Hl_rel, Hab_rel);
+      }
       rows_X(m, cs, nstat, X, nshallow);
       Arrow H;
       load_arrow(ms, H);
-#ifdef QEXP_REL_LATE
-      if (have_rel) hessian_rel(m, kin, cs, nstat, ncon, leg, pmode, Hl_rel, Hab_rel);
-#endif
+
       QUNROLL for (int i = 0; i < 6; i++) H.l[i] += Hl_rel[i];
       QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) H.ab[r][c] = Hab_rel[r][c];
       QUNROLL for (int j = 0; j < 3; j++) {
@@ -1145,10 +1146,12 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
       }
       hessian_common(m, kin, cs, nstat, X, nshallow, H);
       QPROF(pf, 9);
-      if (!arrow_factor(H, leg, pmode)) return kFlagNotPD;
+      bool pd;
+      if constexpr (GENERAL) pd = arrow_factor_plan(H, leg, plan); else pd = arrow_factor(H, leg, pmode);
+      if (!pd) return kFlagNotPD;
       QUNROLL for (int j = 0; j < 3; j++) hl[j] = -hl[j];  // search direction
       QUNROLL for (int k = 0; k < 6; k++) ht[k] = -ht[k];
-      arrow_solve(H, hl, ht, leg, pmode);
+      if constexpr (GENERAL) arrow_solve_plan(H, hl, ht, leg, plan); else arrow_solve(H, hl, ht, leg, pmode);
     }
     QPROF(pf, 10);
     double q1, q2, snorm;
@@ -1193,7 +1196,7 @@ QD int newton_body(const QuadModel& m, const QuadLeg& L, const QKin& kin, const 
 #define QNEWTON_ATTR QNOINLINE
 #endif
 template <bool GENERAL, class CS, class MS, class QProfT>
-QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int nrel, int leg, int pmask, bool have_rel,
+QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, const MS& ms_in, QRows& R_in, CS& cs_in, int ncon, int nrel, int leg, int pmask, int mymask, bool have_rel,
                          const double* sl_in, const double* st_in, const double* wl_in, const double* wt_in, bool have_warm,
                          double* al_out, double* at_out, double* fc_l_out, double* fc_t_out, int& iters_out, QProfT& pf_in) {
   // (an out-of-line function on the device: its register allocation starts afresh, so the rollout's state is parked once per step instead
@@ -1220,7 +1223,7 @@ QNEWTON_ATTR int constraint_newton(const QuadModel& m_in, const QKin& kin_in, co
     QUNROLL for (int k = 0; k < 6; k++) { st[k] = stp[k]; wt[k] = wtp[k]; }
   }
   int iters = 0;
-  const int rc = newton_body<GENERAL>(m, L, kin, ms, R, cs, ncon, nrel, leg, pmask, have_rel, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
+  const int rc = newton_body<GENERAL>(m, L, kin, ms, R, cs, ncon, nrel, leg, pmask, mymask, have_rel, sl, st, wl, wt, have_warm, al, at, fc_l, fc_t, iters, pf);
   {
     auto* alp = QREBIND_PRIVATE(double, al_out); auto* atp = QREBIND_PRIVATE(double, at_out);
     auto* flp = QREBIND_PRIVATE(double, fc_l_out); auto* ftp = QREBIND_PRIVATE(double, fc_t_out);
@@ -1698,6 +1701,7 @@ struct QDyn {
   double fs_l[3], fs_t[6];  // qfrc_smooth
   int ncon, nrel;           // the lane's contacts; the last nrel of them are between two moving geoms
   int pmask, have_rel;      // self-collision: bit x set if some leg A touches leg A xor x; whether the candidate has such contacts at all (quad-uniform)
+  int mymask;               // bit x set if THIS leg touches leg ^ x
 };
 // Position and velocity stages, collision, smooth dynamics, constraint rows: everything of mj_forward before the constraint solve.
 // ctrl: the leg's three controls. Returns flag bits (quad-uniform; 0: fine).
@@ -1916,6 +1920,7 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     // arrowhead factorisation takes as super-legs; two or three (a leg touching two others) go through the dense elimination of the
     // leg blocks (newton_direction_general)
     D.pmask = qd_or(pmask);
+    D.mymask = pmask;
     D.have_rel = qd_or(nrel > 0 ? 1 : 0);
     QPROF(pf, 3);
   }
@@ -2298,14 +2303,15 @@ QD QInterp q_interp_weights(const double* xs, double value, int length, int repr
 }
 // StateDiff(ref, x) in the tangent space (mj_differentiatePos, utilities.cc:543-553; wave_ilqg.h w_state_diff): all 36 entries in every
 // lane -- [trunk position 3, rotation 3, the legs' joints 12 | trunk velocity 6, the legs' 12] -- the trunk's computed redundantly, a
-// leg's six broadcast from its lane. ref: a state row [qpos 19 | qvel 18]; its quaternion is used as it is (the caller normalises an
-// interpolated one).
-QD void q_state_diff(const double* ref, const double* rquat, const QState& S, int leg, double* dx) {
-  QUNROLL for (int k = 0; k < 3; k++) dx[k] = S.tq[k] - ref[k];
-  sub_quat(dx + 3, S.tq + 3, rquat);
-  QUNROLL for (int k = 0; k < 6; k++) dx[18 + k] = S.tv[k] - ref[19 + k];
+// leg's six broadcast from its lane. The reference's quaternion is used as it is (the caller normalises an interpolated one).
+// the entries of a state row a lane reads: the trunk's 13 and its own leg's 6
+struct QRefState { double tpos[3], tquat[4], tvel[6], lq[3], lv[3]; };
+QD void q_state_diff(const QRefState& ref, const QState& S, double* dx) {
+  QUNROLL for (int k = 0; k < 3; k++) dx[k] = S.tq[k] - ref.tpos[k];
+  sub_quat(dx + 3, S.tq + 3, ref.tquat);
+  QUNROLL for (int k = 0; k < 6; k++) dx[18 + k] = S.tv[k] - ref.tvel[k];
   double mine[6];
-  QUNROLL for (int j = 0; j < 3; j++) { mine[j] = S.lq[j] - ref[7 + 3 * leg + j]; mine[3 + j] = S.lv[j] - ref[19 + 6 + 3 * leg + j]; }
+  QUNROLL for (int j = 0; j < 3; j++) { mine[j] = S.lq[j] - ref.lq[j]; mine[3 + j] = S.lv[j] - ref.lv[j]; }
   QUNROLL for (int j = 0; j < 3; j++) {
     dx[6 + j] = qd_bcast<0>(mine[j]); dx[9 + j] = qd_bcast<1>(mine[j]); dx[12 + j] = qd_bcast<2>(mine[j]); dx[15 + j] = qd_bcast<3>(mine[j]);
     dx[24 + j] = qd_bcast<0>(mine[3 + j]); dx[27 + j] = qd_bcast<1>(mine[3 + j]); dx[30 + j] = qd_bcast<2>(mine[3 + j]); dx[33 + j] = qd_bcast<3>(mine[3 + j]);
@@ -2315,16 +2321,23 @@ QD void q_state_diff(const double* ref, const double* rquat, const QState& S, in
 QD void feedback_ctrl(const QFeedback& fb, double alpha, int t, const QState& S, int leg, double* u) {
   constexpr int nu = kQLegs * kQLinks, ds = 37, ndx = 36;
   double dx[ndx];
+  // (every loop over the 36 gains of a row is unrolled: its loads are then all in flight together -- one memory latency per row instead of
+  // one per entry on a path that is nothing but latency)
   if (fb.mode == 0) {  // index policy: u = actions[t] + alpha improvement[t] + K[t] StateDiff(states[t], x)
     const int tt = t < fb.Tn ? t : fb.Tn - 1;
-    const double* ref = fb.states + (size_t)tt * ds;
-    q_state_diff(ref, ref + 3, S, leg, dx);
+    const double* row = fb.states + (size_t)tt * ds;
+    QRefState ref;
+    QUNROLL for (int k = 0; k < 3; k++) ref.tpos[k] = row[k];
+    QUNROLL for (int k = 0; k < 4; k++) ref.tquat[k] = row[3 + k];
+    QUNROLL for (int k = 0; k < 6; k++) ref.tvel[k] = row[19 + k];
+    QUNROLL for (int j = 0; j < 3; j++) { ref.lq[j] = row[7 + 3 * leg + j]; ref.lv[j] = row[25 + 3 * leg + j]; }
+    q_state_diff(ref, S, dx);
     QUNROLL for (int e = 0; e < 3; e++) {
-      const int row = tt * nu + 3 * leg + e;
-      const double* K = fb.gains + (size_t)row * ndx;
+      const int r = tt * nu + 3 * leg + e;
+      const double* K = fb.gains + (size_t)r * ndx;
       double s = 0;
-      for (int j = 0; j < ndx; j++) s += K[j] * dx[j];
-      u[e] = fb.actions[row] + alpha * fb.improvement[row] + s;
+      QUNROLL for (int j = 0; j < ndx; j++) s += K[j] * dx[j];
+      u[e] = fb.actions[r] + alpha * fb.improvement[r] + s;
     }
     return;
   }
@@ -2341,21 +2354,26 @@ QD void feedback_ctrl(const QFeedback& fb, double alpha, int t, const QState& S,
   }
   if (!fb.use_state) return;
   const QInterp ws = q_interp_weights(fb.times, now, fb.Tn, rep);
-  double xi[ds];
-  for (int i = 0; i < ds; i++) {
+  auto interp_state = [&](int i) {
     double v = 0;
     QUNROLL for (int p = 0; p < 4; p++) v += ws.w[p] * fb.states[(size_t)ws.i[p] * ds + i];
-    xi[i] = v;
-  }
-  double qi[4] = {xi[3], xi[4], xi[5], xi[6]};
-  q_norm(qi);  // (policy.cc:118-125: interpolated quaternions are renormalised)
-  q_state_diff(xi, qi, S, leg, dx);
+    return v;
+  };
+  QRefState ref;
+  QUNROLL for (int k = 0; k < 3; k++) ref.tpos[k] = interp_state(k);
+  QUNROLL for (int k = 0; k < 4; k++) ref.tquat[k] = interp_state(3 + k);
+  QUNROLL for (int k = 0; k < 6; k++) ref.tvel[k] = interp_state(19 + k);
+  QUNROLL for (int j = 0; j < 3; j++) { ref.lq[j] = interp_state(7 + 3 * leg + j); ref.lv[j] = interp_state(25 + 3 * leg + j); }
+  q_norm(ref.tquat);  // (policy.cc:118-125: interpolated quaternions are renormalised)
+  q_state_diff(ref, S, dx);
   QUNROLL for (int e = 0; e < 3; e++) {
     double s = 0;
-    for (int j = 0; j < ndx; j++) {
-      double kj = 0;
-      QUNROLL for (int p = 0; p < 4; p++) kj += wa.w[p] * fb.gains[((size_t)wa.i[p] * nu + 3 * leg + e) * ndx + j];
-      s += kj * dx[j];
+    QUNROLL for (int p = 0; p < 4; p++) {
+      if (wa.w[p] == 0) continue;  // (quad-uniform: zero-order and linear policies read one or two gain rows, not four)
+      const double* K = fb.gains + ((size_t)wa.i[p] * nu + 3 * leg + e) * ndx;
+      double sp = 0;
+      QUNROLL for (int j = 0; j < ndx; j++) sp += K[j] * dx[j];
+      s += wa.w[p] * sp;
     }
     u[e] += alpha * s;
   }
@@ -2487,13 +2505,17 @@ QD int rollout(const QuadModel& m, const QuadTables& tab, const QStaticPose* sp,
     // one pair pattern of legs in contact (or none): the super-leg solver; a leg touching two others (rare): the general one -- for
     // every candidate of the wavefront then (it covers the other cases too, and the wavefront runs one solver instead of both in turn)
     const long long solve_t0 = QCLASS_NOW(a);
+#ifdef QEXP_NO_GENERAL
+    // (tuning: what the launch would take if no candidate ever needed the general solver -- such candidates stop here, flagged)
+    if (((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom) { flags = kFlagPair; break; }
+#endif
     const bool wave_general = qw_any(((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom);
     // (the solver's inputs are handed over as pointers into S and D, which pins those two structs in memory -- measured the better
     // trade: copying them into a block of their own so that S and D stay in registers costs 2 ms of 57 in register pressure)
     if (wave_general)
-      flags = constraint_newton<true>(m, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+      flags = constraint_newton<true>(m, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.mymask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     else
-      flags = constraint_newton<false>(m, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
+      flags = constraint_newton<false>(m, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.mymask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, t > 0, al, at, fc_l, fc_t, iters, pf);
     if (flags) break;
     QCLASS_ADD(a, 0, D.have_rel, D.pmask, D.ncon, solve_t0);
     QWAVE_TIMES(a, iters, wave_general, D.ncon);

@@ -202,9 +202,9 @@ int quademu_forward(const mjpcx_model* model, const mjpcx_task* task, const doub
     double al[3], at[6], fc_l[3], fc_t[6];
     int iters;
     if (((D.pmask >> 1) & 1) + ((D.pmask >> 2) & 1) + ((D.pmask >> 3) & 1) >= kQGeneralFrom)
-      fl = constraint_newton<true>(b->qm, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
+      fl = constraint_newton<true>(b->qm, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.mymask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
     else
-      fl = constraint_newton<false>(b->qm, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
+      fl = constraint_newton<false>(b->qm, D.kin, ms, D.R, cs, D.ncon, D.nrel, leg, D.pmask, D.mymask, D.have_rel != 0, D.sl, D.st, S.wl, S.wt, warm != nullptr, al, at, fc_l, fc_t, iters, pf);
     flags_out[leg] = fl;
     if (fl) return;
     for (int j = 0; j < 3; j++) {
