@@ -364,7 +364,9 @@ struct mjpcx_ctx {
   // quad kernel (quad_kernel.h): four lanes per candidate; fp64 contexts of a model quad_build accepts
   bool quad_ok = false;       // MJPCX_NO_QUAD=1 keeps the wavefront-per-candidate kernels (A/B runs)
   bool quad_stamps = false;   // MJPCX_QUAD_STAMPS=1: phase cycle stamps of wavefront 0 (tuning aid; synchronises every rollout)
-  int quad_min_n = 4096;          // batches below this go to rollout_tree_kernel<A1> (MJPCX_QUAD_MIN_N): measured cross-over, tools/quad_n_sweep.py (N = 2048: 34 ms there, 46 ms here)
+  int quad_min_n = 2048;          // batches below this go to rollout_tree_kernel<A1> (MJPCX_QUAD_MIN_N). 2048 = a rank's share of configs[2]'s 16384 candidates over 8 GPUs: there the
+                                  // two kernels are level (gait steps, same box: 39.7 ms here at 4 candidates per wavefront, 37.8 there), and a sharded run then executes the
+                                  // SAME kernel as one rank -- equal results bit for bit, not to a tolerance
   int quad_cpw = 0;               // candidates per wavefront of the quad kernel (0: chosen from the batch size; MJPCX_QUAD_CPW)
   int quad_con_cap = 0;           // MJPCX_QUAD_CON_CAP=<n>: hand on candidates with more than n contacts in a lane (tests of the hand-on path)
   bool quad_no_fallback = false;  // MJPCX_QUAD_NO_FALLBACK=1: leave the handed-on candidates flagged (tuning: failure[] then carries reason and step)

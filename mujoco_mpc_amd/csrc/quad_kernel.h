@@ -111,9 +111,14 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
     if ((threadIdx.x & 63) == 0) { w_[1] += mi_; w_[2] += (general) ? 1 : 0; w_[3] += mc_; } } } while (0)
 
 // per-class cycle totals of the wavefront (a.wave_class, quad_abi.h): written by the wavefront's first lane
+#ifdef QEXP_CLASS_GENERAL   // (tuning: the histogram's "ovf" bit counts the steps through the multi-pattern solver instead)
+#define QCLASS_BIT2(pmask, ncon) ((((pmask) >> 1) & 1) + (((pmask) >> 2) & 1) + (((pmask) >> 3) & 1) >= 2)
+#else
+#define QCLASS_BIT2(pmask, ncon) ((ncon) > mjpcx::quad::kQLdsSlots)
+#endif
 #define QCLASS_NOW(a) ((a).wave_class ? (long long)__builtin_readcyclecounter() : 0ll)
 #define QCLASS_ADD(a, base, have_rel, pmask, ncon, t0) do { if ((a).wave_class) { \
-    const int c_ = (__ballot((have_rel) != 0) ? 1 : 0) | (__ballot((pmask) != 0) ? 2 : 0) | (__ballot((ncon) > mjpcx::quad::kQLdsSlots) ? 4 : 0) | (__ballot((ncon) > mjpcx::quad::kQLineSlots) ? 8 : 0); \
+    const int c_ = (__ballot((have_rel) != 0) ? 1 : 0) | (__ballot((pmask) != 0) ? 2 : 0) | (__ballot(QCLASS_BIT2(pmask, ncon)) ? 4 : 0) | (__ballot((ncon) > mjpcx::quad::kQLineSlots) ? 8 : 0); \
     if ((threadIdx.x & 63) == 0) { long long* w_ = (a).wave_class + 64 * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) + (base) + 2 * c_; \
       w_[0] += 1; w_[1] += (long long)__builtin_readcyclecounter() - (t0); } } } while (0)
 

@@ -28,7 +28,7 @@ def quad():
 
 
 def context(t, env=None):
-    env = dict({"MJPCX_QUAD_MIN_N": "0"}, **(env or {}))  # (batches below 4096 go to the wavefront-per-candidate kernel otherwise)
+    env = dict({"MJPCX_QUAD_MIN_N": "0"}, **(env or {}))  # (batches below 2048 go to the wavefront-per-candidate kernel otherwise)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
