@@ -26,7 +26,10 @@ PRESSURE = ["-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-mllvm", "
 # WAVEFRONT) then round alike, so a candidate's result does not depend on its wavefront's other candidates (tests/test_gpu_quad.py::
 # test_results_do_not_depend_on_the_candidates_per_wavefront saw 5e-16 otherwise), and the launch is 2 % faster (57.3 -> 56.1 ms, same box)
 PRESSURE_QUAD = ["-mllvm", "-disable-machine-licm", "-mllvm", "-disable-licm-promotion", "-mllvm", "-simplifycfg-sink-common=false",
-                 "-mllvm", "-phi-node-folding-threshold=0", "-ffp-contract=on"]
+                 "-mllvm", "-phi-node-folding-threshold=0", "-ffp-contract=on", "-fno-slp-vectorize"]
+# what each group is worth on the round-5 kernel (gait steps of the bench, same box, back to back; 51.1 ms with the set): without the LICM pair 53.5,
+# without the CFG pair 51.9, without both (-ffp-contract=on alone) 53.3; + -fno-slp-vectorize 50.8 (twice); + the scheduler bias 51.1 (none);
+# -amdgpu-sched-strategy=max-ilp 51.4
 SOURCES = [("mjpcx.hip", PRESSURE), ("ilqg_wave.hip", []), ("wave32.hip", PRESSURE), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]),
            ("quad_kernel.hip", PRESSURE_QUAD)]
 # headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
