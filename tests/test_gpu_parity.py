@@ -413,13 +413,17 @@ def test_implicitfast_is_the_euler_update_on_damping_only_models(cartpole):
     pm = cartpole.packed_model(); pm.struct.integrator = 3
     bias = np.ctypeslib.as_array(pm.struct.actuator_biasprm, (3 * cartpole.model.nu,))
     btype = np.ctypeslib.as_array(pm.struct.actuator_biastype, (cartpole.model.nu,))
-    bias[2] = -0.5
-    if btype[0] != 1:  # (biastype none: biasprm is not read by MuJoCo, so the velocity coefficient does not count)
-        capi.Context(pm, cartpole.packed(), 0, 64).close()
-        btype[0] = 1   # affine
-    with pytest.raises(capi.MjpcxError) as err:
-        capi.Context(pm, cartpole.packed(), 0, 64)
-    assert "velocity-dependent actuator" in str(err.value)
+    saved = (float(bias[2]), int(btype[0]))  # (the packed arrays are the fixture model's own: put them back)
+    try:
+        bias[2] = -0.5
+        if btype[0] != 1:  # (biastype none: biasprm is not read by MuJoCo, so the velocity coefficient does not count)
+            capi.Context(pm, cartpole.packed(), 0, 64).close()
+            btype[0] = 1   # affine
+        with pytest.raises(capi.MjpcxError) as err:
+            capi.Context(pm, cartpole.packed(), 0, 64)
+        assert "velocity-dependent actuator" in str(err.value)
+    finally:
+        bias[2], btype[0] = saved
     # mj_implicit ignores mjDSBL_EULERDAMP, mj_Euler honours it: with the flag set the two updates differ and the model is refused
     pm = cartpole.packed_model(); pm.struct.integrator = 3
     pm.struct.disableflags |= 1 << 14

@@ -62,22 +62,26 @@ def test_a_model_with_unproven_solid_pairs_keeps_the_kernel_that_watches_them(qu
     trunk = next(b for b in range(m.nbody) if m.arrays["body_dofnum"][b] == 6)
     pm, pt = quad.packed_model(), quad.packed()
     size = np.ctypeslib.as_array(pm.struct.geom_size, (m.ngeom * 3,)).reshape(-1, 3)
-    for g in range(m.ngeom):
-        if gt[g] == 5 and m.arrays["body_parentid"][gb[g]] == trunk:
-            size[g, 1] = 0.07
-    ctx = capi.Context(pm, pt, 0, 64)
-    assert "rollout_quad_kernel" not in ctx.kernel_name
-    N, H, P = 4096, 20, 3
-    state = np.concatenate([m.keyframes["home"]["qpos"], np.zeros(18)])
-    times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
-    ns = capi.make_noise_spec(seed=3, iteration=1, mode=capi.NOISE_SAMPLING, std0=0.1)
-    ctx.set_state(state, 0.0, MOCAP)
-    ctx.rollout_noise(N, H, 0, times, np.zeros((P, 12)), ns)
-    ret, fail = ctx.returns()
-    ctx.close()
-    sample = np.arange(1, N, 128)
-    nodes = pyoracle.noise_candidates(pm, ns, P, np.zeros((P, 12)), sample)
-    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, len(sample), H, P, 0, times, nodes, num_threads=8)
+    saved = size.copy()  # (the packed arrays may be the fixture model's own: put them back)
+    try:
+        for g in range(m.ngeom):
+            if gt[g] == 5 and m.arrays["body_parentid"][gb[g]] == trunk:
+                size[g, 1] = 0.07
+        ctx = capi.Context(pm, pt, 0, 64)
+        assert "rollout_quad_kernel" not in ctx.kernel_name
+        N, H, P = 4096, 20, 3
+        state = np.concatenate([m.keyframes["home"]["qpos"], np.zeros(18)])
+        times = np.arange(P) * ((H - 1) * 0.01 / (P - 1))
+        ns = capi.make_noise_spec(seed=3, iteration=1, mode=capi.NOISE_SAMPLING, std0=0.1)
+        ctx.set_state(state, 0.0, MOCAP)
+        ctx.rollout_noise(N, H, 0, times, np.zeros((P, 12)), ns)
+        ret, fail = ctx.returns()
+        ctx.close()
+        sample = np.arange(1, N, 128)
+        nodes = pyoracle.noise_candidates(pm, ns, P, np.zeros((P, 12)), sample)
+        ref = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, len(sample), H, P, 0, times, nodes, num_threads=8)
+    finally:
+        size[:] = saved
     assert np.array_equal(ref["failure"] != 0, fail[sample] != 0) and close(ret[sample], ref["total_return"], 1e-8)
 
 

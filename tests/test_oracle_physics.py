@@ -159,11 +159,19 @@ def test_implicitfast_steps_like_euler_on_a_damping_only_model_and_is_refused_ot
         pm = t.packed_model(); pm.struct.integrator = integ
         out.append(pyoracle.rollout_batch(pm, t.packed(), [0.3, 2.7, -0.4, 0.9], 0.0, None, N, H, P, 2, times, nodes, num_threads=1))
     assert np.array_equal(out[0]["states"], out[1]["states"]) and np.array_equal(out[0]["total_return"], out[1]["total_return"])
-    for integ, kv in ((2, 0.0), (3, -0.5)):
+    # refused: plain `implicit`; implicitfast with an AFFINE bias that has a velocity term; implicitfast with eulerdamp disabled (mj_implicit
+    # ignores that flag, o_euler honours it). A velocity coefficient under biastype none is not read by MuJoCo and does not count.
+    for integ, kv, affine, flags in ((2, 0.0, 0, 0), (3, -0.5, 1, 0), (3, 0.0, 0, 1 << 14)):
         pm = t.packed_model(); pm.struct.integrator = integ
+        pm.struct.disableflags |= flags
         np.ctypeslib.as_array(pm.struct.actuator_biasprm, (3 * t.model.nu,))[2] = kv
+        np.ctypeslib.as_array(pm.struct.actuator_biastype, (t.model.nu,))[0] = affine
         try:
             pyoracle.Physics(pm)
         except NotImplementedError:
             continue
         raise AssertionError("accepted")
+    pm = t.packed_model(); pm.struct.integrator = 3
+    np.ctypeslib.as_array(pm.struct.actuator_biasprm, (3 * t.model.nu,))[2] = -0.5
+    np.ctypeslib.as_array(pm.struct.actuator_biastype, (t.model.nu,))[0] = 0
+    pyoracle.Physics(pm)   # accepted

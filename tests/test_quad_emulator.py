@@ -52,9 +52,13 @@ def test_two_solids_without_a_plain_proof_decline_the_model(quad):
     assert len(hips) >= 4
     pm = quad.packed_model()
     size = np.ctypeslib.as_array(pm.struct.geom_size, (m.ngeom * 3,)).reshape(-1, 3)
-    for g in hips:
-        size[g, 1] = 0.07  # (half length 4 cm in the model)
-    why = quademu.check(pm, quad.packed())
+    saved = size.copy()  # (the packed arrays may be the fixture model's own: put them back)
+    try:
+        for g in hips:
+            size[g, 1] = 0.07  # (half length 4 cm in the model)
+        why = quademu.check(pm, quad.packed())
+    finally:
+        size[:] = saved
     assert "two solids" in why and "proven apart" in why
 
 
