@@ -9,8 +9,10 @@ std::string build_images(const mjpcx_model* m, const mjpcx_task* t, std::vector<
   return quad_build(m, t, reinterpret_cast<QuadModel*>(model.data()), reinterpret_cast<QuadTables*>(tables.data()));
 }
 static int pick_cpw(int N, int cpw) {
-  // candidates per wavefront: as many as it takes to give every SIMD of the 256 CUs one wavefront, 16 at most (cpw > 0: the caller's choice)
-  if (cpw <= 0) { cpw = 16; while (cpw > 1 && (N + cpw - 1) / cpw < 1024) cpw >>= 1; }
+  // candidates per wavefront: as many as it takes to give every SIMD of the 256 CUs one wavefront, 16 at most and 4 at least (cpw > 0: the
+  // caller's choice). Below four the lock-step no longer shrinks but the wavefronts multiply, and co-resident wavefronts cost each other more
+  // than that buys (a rank's 2048-candidate share of configs[2], gait steps, same box: 39.7 ms at 4 per wavefront = 512 wavefronts, 58.3 ms at 2 = 1024)
+  if (cpw <= 0) { cpw = 16; while (cpw > 4 && (N + cpw - 1) / cpw < 1024) cpw >>= 1; }
   return cpw;
 }
 int quad_waves(int N, int cpw) { cpw = pick_cpw(N, cpw); return (N + cpw - 1) / cpw; }
