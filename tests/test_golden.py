@@ -130,3 +130,22 @@ def test_oracle_against_mujoco_goldens(path):
         ph.step()
         assert np.allclose(ph.get("qacc"), g["qacc"][k], rtol=1e-5, atol=1e-6), k
         assert np.allclose(ph.get("qpos"), g["qpos"][k + 1], rtol=0, atol=1e-7), k
+
+
+def test_the_mujoco_golden_dump_stays_runnable():
+    """tools/dump_mujoco_golden.py is what turns 'parity unpinned' into a pin on the day a MuJoCo wheel is at hand: it must keep compiling,
+    say what is missing when the wheel is not there (this image), and name model files that exist."""
+    import py_compile
+    import subprocess
+    import sys
+    from mujoco_mpc_amd.task import _REGISTRY, MODELS_DIR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "dump_mujoco_golden.py")
+    py_compile.compile(tool, doraise=True)
+    for name, (rel, _) in _REGISTRY.items():
+        assert os.path.exists(os.path.join(MODELS_DIR, rel)), name
+    try:
+        import mujoco  # noqa: F401
+    except ImportError:
+        out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and "mujoco" in (out.stderr + out.stdout)
