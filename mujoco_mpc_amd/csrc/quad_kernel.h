@@ -125,6 +125,7 @@ __device__ __forceinline__ void qms_set_t(mjpcx::quad::LdsM& m, int i, double v)
 // every fixed-trip loop over a small array is unrolled: a loop the compiler keeps rolled indexes its array at run time, and a private array
 // indexed at run time lives in scratch
 #define QUNROLL _Pragma("unroll")
+#define QNOUNROLL _Pragma("nounroll")
 #define QNOINLINE __device__ __noinline__
 #define QD __device__ __forceinline__
 #define QFAST_MATH 1

@@ -56,7 +56,7 @@ constexpr int kQMaxSPair = 20;
 
 struct QuadGeom {
   int type, link, model_id, static_mask;  // link: -1 trunk, 0..2 link of the lane's leg; static_mask: bit s = collides with static geom s
-  int spair, pad3;                // byte s: index of the pair (static geom s, this geom) in QuadModel::spair
+  int spair, pgi;                 // byte s: index of the pair (static geom s, this geom) in QuadModel::spair; pgi: the geom's place among its leg's pair geoms (QuadLeg::pg_slot) or -1
   double pos[3], rot[9], size[3]; // pose in the body frame (rotation matrix of geom_quat)
   double bound;                   // radius of its bounding sphere
 };
@@ -80,6 +80,7 @@ struct QuadLeg {
   double act_gear[kQLinks], act_gain[kQLinks], act_bias[kQLinks][3], ctrlrange[kQLinks][2], forcerange[kQLinks][2];
   double key_q[kQMaxKey][kQLinks];  // keyframe joint values of this leg (Posture residual)
   int limited[kQLinks], act_biastype[kQLinks], ctrllimited[kQLinks], forcelimited[kQLinks];
+  double reach;                           // no point of the leg's geoms is farther than this from the origin of its first link (its geoms' bounds along the chain)
   int ngeom, foot_slot, foot_index, npg;  // foot_slot: the leg's geom the residual reads; foot_index: its place in foot_geom_id_ (FL HL FR HR)
   int pg_slot[kQPairGeom];                // the leg's geoms that can touch another leg or the trunk (self-collision test)
   double pg_reach[kQPairGeom];              // radius of the pair geom's bounding sphere about its centre (capsule: radius + half length)
@@ -94,6 +95,7 @@ struct QuadModel {
   int iterations, gravity_on, nstatic, ntrunk_geom, ntrace, nterm, nr, nray;
   // trunk
   double trunk_ipos[3], trunk_iquat[4], trunk_mass, trunk_inertia[3];
+  double trunk_reach;               // no point of the trunk's geoms is farther than this from the trunk's origin
   double head_pos[3];               // the site the Position residual reads (trunk frame)
   double trace_pos[kQMaxTrace][3];  // traced points (trunk frame)
   QuadGeom trunk_geom[kQTrunkGeom];
@@ -167,6 +169,8 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
   using namespace quad_detail;
   std::memset(qm, 0, sizeof *qm);
   std::memset(qt, 0, sizeof *qt);
+  for (int l = 0; l < kQLegs; l++) for (int g = 0; g < kQLegGeom; g++) qm->leg[l].geom[g].pgi = -1;  // (not a pair geom until the pair list says so)
+  for (int g = 0; g < kQTrunkGeom; g++) qm->trunk_geom[g].pgi = -1;
   if (m->integrator != MJPCX_INT_EULER) return "integrator is not Euler";
   if (m->disableflags != 0) return "non-default disable flags";
   if (m->ntendon != 0 || m->na != 0) return "tendons / activations";
@@ -296,6 +300,17 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
     const double* sz = dst->size;
     dst->bound = dst->type == MJPCX_GEOM_CAPSULE ? sz[0] + sz[1] : dst->type == MJPCX_GEOM_CYLINDER ? std::sqrt(sz[0] * sz[0] + sz[1] * sz[1])
                : dst->type == MJPCX_GEOM_BOX ? std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]) : sz[0];
+    {  // how far from the origin of the leg's first link (of the trunk) a point of this geom can be: the links' offsets down to its body + its own
+      double far = std::sqrt(dst->pos[0] * dst->pos[0] + dst->pos[1] * dst->pos[1] + dst->pos[2] * dst->pos[2]) + dst->bound;
+      if (b == trunk) qm->trunk_reach = std::max(qm->trunk_reach, far);
+      else {
+        QuadLeg& L = qm->leg[(b - trunk - 1) / kQLinks];
+        for (int j = 1; j <= dst->link; j++)  // (a hinge off its body's origin moves that origin by up to twice the offset)
+          far += std::sqrt(L.body_pos[j][0] * L.body_pos[j][0] + L.body_pos[j][1] * L.body_pos[j][1] + L.body_pos[j][2] * L.body_pos[j][2]) +
+                 2 * std::sqrt(L.jnt_pos[j][0] * L.jnt_pos[j][0] + L.jnt_pos[j][1] * L.jnt_pos[j][1] + L.jnt_pos[j][2] * L.jnt_pos[j][2]);
+        L.reach = std::max(L.reach, far);
+      }
+    }
   }
   // pair parameters (oracle/contact.inc contact_param; o_collision's type table)
   const double impratio = m->impratio > 1e-15 ? m->impratio : 1.0;
@@ -414,7 +429,7 @@ inline std::string quad_build(const mjpcx_model* m, const mjpcx_task* task, Quad
     for (int g = 0; g < m->ngeom; g++) {
       if (!in_pair[g]) continue;
       if (slot_leg[g] < 0) { if (qm->ntpg == kQTrunkPairGeom) return "more trunk geoms in self-collision pairs than staged"; qm->tpg_slot[qm->ntpg++] = slot_idx[g]; }
-      else { QuadLeg& L = qm->leg[slot_leg[g]]; if (L.npg == kQPairGeom) return "more leg geoms in self-collision pairs than staged"; L.pg_slot[L.npg++] = slot_idx[g]; }
+      else { QuadLeg& L = qm->leg[slot_leg[g]]; if (L.npg == kQPairGeom) return "more leg geoms in self-collision pairs than staged"; L.geom[slot_idx[g]].pgi = L.npg; L.pg_slot[L.npg++] = slot_idx[g]; }
     }
     qt->npair = (int)plist.size();
     qm->pair_margin = pmargin;

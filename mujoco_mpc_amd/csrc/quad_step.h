@@ -40,6 +40,9 @@
 #ifndef QUNROLL
 #define QUNROLL
 #endif
+#ifndef QNOUNROLL
+#define QNOUNROLL   // (the device build keeps a loop so marked ROLLED: code size against the 64 KB instruction cache)
+#endif
 // An out-of-line function receives the model image and its caller's locals through plain references; the device build says where they
 // live (LDS / the private segment) so that they are read with ds_read / scratch_load instead of FLAT loads (quad_kernel.h).
 #ifndef QREBIND_LDS
@@ -1269,50 +1272,72 @@ QD void add_contact(const PAIR& p, const double* com, const double* cvel, int de
 #define QSPAIR_T QuadSPair
 #define QSPAIR(m, g, s) (m).spair[((g).spair >> (8 * (s))) & 255]
 #endif
-template <class CS>
-QD void sphere_plane(const QSPAIR_T& p, const double* com, const double* cvel, int depth, const double* pp, const double* pn,
-                     const double* c, double r, CS& cs, int& ncon, int& flags) {
-  const double dist = (c[0] - pp[0]) * pn[0] + (c[1] - pp[1]) * pn[1] + (c[2] - pp[2]) * pn[2] - r;
-  double pos[3];
-  QUNROLL for (int k = 0; k < 3; k++) pos[k] = c[k] - pn[k] * (r + 0.5 * dist);
-  add_contact(p, com, cvel, depth, dist, pos, pn, cs, ncon, flags);
-}
-// one moving geom (world pose gp / gR) against every static geom; oracle o_collision's pair table
-template <class CS>
-QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& g, const QuadPair* pairs /* [kQStatic] stride: QEXP_SPAIR_GLOBAL only */, int pair_stride, const double* com, const double* cvel, int depth, const double* gp, const double* gR, CS& cs, int& ncon, int& flags) {
-  for (int s = 0; s < m.nstatic; s++) {
+// one moving geom (world pose gp / gR) against every static geom; oracle o_collision's pair table.
+// COMPACT on purpose (round 5): a ROLLED loop over the static geoms that first collects the pair's candidate points -- at most four: a sphere's
+// one, a capsule's two ends, a box's first four corners within the margin, a cylinder's four rim points -- and then creates the contacts in ONE
+// instance of add_contact. With the static loop unrolled and add_contact inlined at every shape's site the body of the caller's geom loop was
+// 12.8 k instructions (77 KB against 64 KB of instruction cache): the stage took 79 k cycles per step for ~2 k executed instructions.
+// `near`: bit s set if static geom s can be within the margin of anything `reach` from `origin` (static_near_mask, once per step and leg):
+// the other static geoms of a scene -- props metres away -- then cost a register test per geom instead of a chain of LDS reads
+QD int static_near_mask(const QuadModel& m, const QStaticPose* sp, const double* origin, double reach) {
+  int near = 0;
+  QNOUNROLL for (int s = 0; s < m.nstatic; s++) {
     const QuadStatic& S = m.stat[s];
     if (S.type < 0) continue;
     const double* p1 = sp[s].pos; const double* R1 = sp[s].mat;
+    const double rel[3] = {origin[0] - p1[0], origin[1] - p1[1], origin[2] - p1[2]};
+    double clear;  // a lower bound of the distance between the static geom and anything within `reach` of the origin
+    if (S.type == MJPCX_GEOM_PLANE) clear = rel[0] * R1[2] + rel[1] * R1[5] + rel[2] * R1[8] - reach;
+    else clear = sqrt(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) - (S.type == MJPCX_GEOM_SPHERE ? S.size[0] : S.bound) - reach;
+    if (clear < 0.01) near |= 1 << s;  // (the slack of collide_geom's own bounding tests; contact margins are below 9 mm: quad_build)
+  }
+  return near;
+}
+template <class CS>
+QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& g, int near, const QuadPair* pairs /* [kQStatic] stride: QEXP_SPAIR_GLOBAL only */, int pair_stride, const double* com, const double* cvel, int depth, const double* gp, const double* gR, CS& cs, int& ncon, int& flags) {
+  QNOUNROLL for (int s = 0; s < m.nstatic; s++) {
+    if (((near >> s) & 1) == 0) continue;
+    const QuadStatic& S = m.stat[s];
+    if (S.type < 0) continue;
+    const double* p1 = sp[s].pos; const double* R1 = sp[s].mat;
+    double cp[4][3], cd[4], cn[3] = {0, 0, 0};  // the pair's candidate points: contact position, distance; one normal
+    QUNROLL for (int k = 0; k < 4; k++) { cd[k] = 0; QUNROLL for (int c = 0; c < 3; c++) cp[k][c] = 0; }
+    int nc = 0;
     if (S.type == MJPCX_GEOM_PLANE) {
       const double n[3] = {R1[2], R1[5], R1[8]};
       // bounding-sphere rejection: nothing of the geom within the margin of the plane (margins are far below this slack)
-      const double cd = (gp[0] - p1[0]) * n[0] + (gp[1] - p1[1]) * n[1] + (gp[2] - p1[2]) * n[2];
-      if (cd - g.bound >= 0.01) continue;
+      const double cdist = (gp[0] - p1[0]) * n[0] + (gp[1] - p1[1]) * n[1] + (gp[2] - p1[2]) * n[2];
+      if (cdist - g.bound >= 0.01) continue;
       if (!((g.static_mask >> s) & 1)) continue;
-      const QSPAIR_T& p = QSPAIR(m, g, s);  // (LDS: quad_model.h)
-      if (g.type == MJPCX_GEOM_SPHERE) {
-        sphere_plane(p, com, cvel, depth, p1, n, gp, g.size[0], cs, ncon, flags);
-      } else if (g.type == MJPCX_GEOM_CAPSULE) {
-        for (int sgn = -1; sgn <= 1; sgn += 2) {
+      QUNROLL for (int k = 0; k < 3; k++) cn[k] = n[k];
+      if (g.type == MJPCX_GEOM_SPHERE || g.type == MJPCX_GEOM_CAPSULE) {
+        // (a capsule: its two end spheres; a sphere: one of zero half length -- the second point is then not counted)
+        const double half = g.type == MJPCX_GEOM_CAPSULE ? g.size[1] : 0.0, r = g.size[0];
+        QUNROLL for (int e = 0; e < 2; e++) {
+          const double sg = e == 0 ? -1.0 : 1.0;
           double c[3];
-          QUNROLL for (int k = 0; k < 3; k++) c[k] = gp[k] + sgn * g.size[1] * gR[3 * k + 2];
-          sphere_plane(p, com, cvel, depth, p1, n, c, g.size[0], cs, ncon, flags);
+          QUNROLL for (int k = 0; k < 3; k++) c[k] = gp[k] + sg * half * gR[3 * k + 2];
+          const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2] - r;
+          QUNROLL for (int k = 0; k < 3; k++) cp[e][k] = c[k] - n[k] * (r + 0.5 * dist);
+          cd[e] = dist;
         }
+        nc = g.type == MJPCX_GEOM_CAPSULE ? 2 : 1;
+        if (g.type == MJPCX_GEOM_SPHERE) { QUNROLL for (int k = 0; k < 3; k++) cp[0][k] = gp[k] - n[k] * (r + 0.5 * cd[0]); }  // (exactly the sphere's own formula: half = 0 adds -0.0 * axis)
       } else if (g.type == MJPCX_GEOM_BOX) {
-        int cnt = 0;
-        for (int i = 0; i < 8 && cnt < 4; i++) {
+        const QSPAIR_T& pb = QSPAIR(m, g, s);
+        QNOUNROLL for (int i = 0; i < 8; i++) {
           const double loc[3] = {(i & 1 ? g.size[0] : -g.size[0]), (i & 2 ? g.size[1] : -g.size[1]), (i & 4 ? g.size[2] : -g.size[2])};
           double c[3];
           mv3(c, gR, loc);
           QUNROLL for (int k = 0; k < 3; k++) c[k] += gp[k];
           const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
-          if (dist < p.margin) {
-            double pos[3];
-            QUNROLL for (int k = 0; k < 3; k++) pos[k] = c[k] - 0.5 * dist * n[k];
-            add_contact(p, com, cvel, depth, dist, pos, n, cs, ncon, flags);
-            cnt++;
+          const bool hit = dist < pb.margin && nc < 4;
+          QUNROLL for (int q4 = 0; q4 < 4; q4++) {
+            const bool put = hit && nc == q4;
+            cd[q4] = put ? dist : cd[q4];
+            QUNROLL for (int k = 0; k < 3; k++) cp[q4][k] = put ? c[k] - 0.5 * dist * n[k] : cp[q4][k];
           }
+          nc += hit ? 1 : 0;
         }
       } else if (g.type == MJPCX_GEOM_CYLINDER) {
         const double a[3] = {gR[2], gR[5], gR[8]};
@@ -1331,10 +1356,10 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
           const double side = i < 3 ? sgn : -sgn, cc = i < 3 ? cs3[i] : 1.0, ss = i < 3 ? sn3[i] : 0.0;
           QUNROLL for (int k = 0; k < 3; k++) c[k] = gp[k] + side * g.size[1] * a[k] + g.size[0] * (cc * v[k] + ss * w[k]);
           const double dist = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2];
-          double pos[3];
-          QUNROLL for (int k = 0; k < 3; k++) pos[k] = c[k] - 0.5 * dist * n[k];
-          add_contact(p, com, cvel, depth, dist, pos, n, cs, ncon, flags);
+          QUNROLL for (int k = 0; k < 3; k++) cp[i][k] = c[k] - 0.5 * dist * n[k];
+          cd[i] = dist;
         }
+        nc = 4;
       }
     } else if (g.type != MJPCX_GEOM_SPHERE) {
       continue;  // static spheres and boxes collide with moving spheres only
@@ -1344,14 +1369,11 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
       const double reach = S.size[0] + g.size[0] + 0.01;
       if (len >= reach * reach) continue;
       if (!((g.static_mask >> s) & 1)) continue;
-      const QSPAIR_T& p = QSPAIR(m, g, s);
       len = sqrt(len);
       const double r1 = S.size[0], dist = len - r1 - g.size[0];
-      if (!(dist < p.margin)) continue;
       if (len < kQMinVal) { n[0] = 1; n[1] = n[2] = 0; } else QUNROLL for (int k = 0; k < 3; k++) n[k] /= len;
-      double pos[3];
-      QUNROLL for (int k = 0; k < 3; k++) pos[k] = p1[k] + n[k] * (r1 + 0.5 * dist);
-      add_contact(p, com, cvel, depth, dist, pos, n, cs, ncon, flags);
+      QUNROLL for (int k = 0; k < 3; k++) { cn[k] = n[k]; cp[0][k] = p1[k] + n[k] * (r1 + 0.5 * dist); }
+      cd[0] = dist; nc = 1;
     } else if (S.type == MJPCX_GEOM_BOX) {
       const double* s1 = S.size;
       double rel[3], loc[3], clamped[3];
@@ -1359,7 +1381,6 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
       const double br = S.bound + g.size[0] + 0.01;
       if (rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2] >= br * br) continue;
       if (!((g.static_mask >> s) & 1)) continue;
-      const QSPAIR_T& p = QSPAIR(m, g, s);
       QUNROLL for (int k = 0; k < 3; k++) loc[k] = R1[k] * rel[0] + R1[3 + k] * rel[1] + R1[6 + k] * rel[2];
       bool inside = true;
       QUNROLL for (int k = 0; k < 3; k++) {
@@ -1379,11 +1400,18 @@ QD void collide_geom(const QuadModel& m, const QStaticPose* sp, const QuadGeom& 
         QUNROLL for (int k = 0; k < 3; k++) if (k == best) { nl[k] = loc[k] >= 0 ? 1 : -1; clamped[k] = nl[k] * s1[k]; }
         dist = -bd - g.size[0];
       }
-      double n[3], surf[3], pos[3];
+      double n[3], surf[3];
       mv3(n, R1, nl);
       mv3(surf, R1, clamped);
-      QUNROLL for (int k = 0; k < 3; k++) pos[k] = p1[k] + surf[k] + 0.5 * dist * n[k];
-      add_contact(p, com, cvel, depth, dist, pos, n, cs, ncon, flags);
+      QUNROLL for (int k = 0; k < 3; k++) { cn[k] = n[k]; cp[0][k] = p1[k] + surf[k] + 0.5 * dist * n[k]; }
+      cd[0] = dist; nc = 1;
+    }
+    if (nc == 0) continue;
+    // the pair's contacts, in the candidates' order: one instance of the contact's creation, the candidates shifted through slot 0
+    const QSPAIR_T& p = QSPAIR(m, g, s);
+    QNOUNROLL for (int k = 0; k < nc; k++) {
+      add_contact(p, com, cvel, depth, cd[0], cp[0], cn, cs, ncon, flags);
+      QUNROLL for (int j = 0; j < 3; j++) { cd[j] = cd[j + 1]; QUNROLL for (int c = 0; c < 3; c++) cp[j][c] = cp[j + 1][c]; }
     }
   }
 }
@@ -1637,28 +1665,32 @@ QNOINLINE void pair_contacts_tests(const QuadModel& m_in, const QuadTables& tab,
 // sphere). Two geoms whose bounding volumes come within the margin have boxes that overlap (by more than -margin) on every axis, so a
 // partner (another leg; the trunk's pair geoms: a constant box; the own leg: a joint box, pair_cull.h) whose box is clear on some axis
 // needs no test. In a gait that is every partner at nearly every step; the tests themselves are out of line (pair_contacts_tests).
+// The boxes of the cull, grown geom by geom inside the collision loop (QPairBoxes; until round 5 the loop kept the 48 doubles of the pair geoms'
+// poses alive -- selects into compile-time slots, 96 v_cndmask per geom -- and spilled the link frames around them: 9 scratch round trips per
+// geom, 76 k cycles per step). The poses themselves go straight into the argument block of the tests, which lives in memory anyway.
+struct QPairBoxes { double blo[3], bhi[3], tlo[3], thi[3]; };  // the box of all the leg's pair geoms; of those that pair with a trunk geom (not the hip's)
+QD void pair_boxes_init(QPairBoxes& b) { QUNROLL for (int k = 0; k < 3; k++) { b.blo[k] = b.tlo[k] = 1e30; b.bhi[k] = b.thi[k] = -1e30; } }
+QD void pair_boxes_add(const QuadLeg& L, int i, const double* gp, const double* ga, const double* txpos, const double* txm, QPairBoxes& b) {
+  const double rel[3] = {gp[0] - txpos[0], gp[1] - txpos[1], gp[2] - txpos[2]};
+  const double outT = ((L.pg_active[kQLegs] >> (8 * i)) & 0xffull) != 0 ? 0.0 : 1e30;
+  const double half = L.pg_half[i], rad = L.pg_rad[i];
+  QUNROLL for (int k = 0; k < 3; k++) {
+    const double x = txm[k] * rel[0] + txm[3 + k] * rel[1] + txm[6 + k] * rel[2];        // (txm' rel)
+    const double ax = txm[k] * ga[0] + txm[3 + k] * ga[1] + txm[6 + k] * ga[2];
+    const double ext = half * fabs(ax) + rad;                                            // half length along the axis, then the end sphere
+    b.blo[k] = fmin(b.blo[k], x - ext); b.bhi[k] = fmax(b.bhi[k], x + ext);
+    b.tlo[k] = fmin(b.tlo[k], x - ext + outT); b.thi[k] = fmax(b.thi[k], x + ext - outT);
+  }
+}
 template <class CS, class QProfT>
-QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const QPairGeoms& pg, const double* txpos, const double* txm, const double* com,
+QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, QPairArgs& args, const QPairBoxes& bx, const double* txpos, const double* txm, const double* com,
                       const double cvel[3][6], const double* cvelT, bool self_walk, CS& cs, int& ncon, int& flags, int& pmask, int& nrel, QProfT& pf) {
   const QuadLeg& L = m.leg[leg];
   const double mg = m.pair_margin;
 #ifdef QEXP_PAIRS_SKIP
   if (mg > -1.0) return;  // (tuning: what a perfect cull of the self-collision stage would save; the solver keeps its self-collision paths)
 #endif
-  double blo[3], bhi[3], tlo[3], thi[3];  // the box of all the leg's pair geoms; of those that pair with a trunk geom (not the hip's)
-  QUNROLL for (int k = 0; k < 3; k++) { blo[k] = tlo[k] = 1e30; bhi[k] = thi[k] = -1e30; }
-  QUNROLL for (int i = 0; i < kQPairGeom; i++) {
-    const double rel[3] = {pg.c[i][0] - txpos[0], pg.c[i][1] - txpos[1], pg.c[i][2] - txpos[2]};
-    const double out = i < L.npg ? 0.0 : 1e30;  // (an empty slot stays out of the box)
-    const double outT = ((L.pg_active[kQLegs] >> (8 * i)) & 0xffull) != 0 ? 0.0 : 1e30;
-    QUNROLL for (int k = 0; k < 3; k++) {
-      const double x = txm[k] * rel[0] + txm[3 + k] * rel[1] + txm[6 + k] * rel[2];        // (txm' rel)
-      const double ax = txm[k] * pg.a[i][0] + txm[3 + k] * pg.a[i][1] + txm[6 + k] * pg.a[i][2];
-      const double ext = L.pg_half[i] * fabs(ax) + L.pg_rad[i];                                  // half length along the axis, then the end sphere
-      blo[k] = fmin(blo[k], x - ext + out); bhi[k] = fmax(bhi[k], x + ext - out);
-      tlo[k] = fmin(tlo[k], x - ext + outT); thi[k] = fmax(thi[k], x + ext - outT);
-    }
-  }
+  const double* blo = bx.blo; const double* bhi = bx.bhi; const double* tlo = bx.tlo; const double* thi = bx.thi;
   const double bmg = mg + 1e-9;
   bool trunk_near = L.pg_active[kQLegs] != 0;
   QUNROLL for (int k = 0; k < 3; k++) trunk_near = trunk_near && !(tlo[k] > m.tpg_box[1][k] + bmg) && !(m.tpg_box[0][k] > thi[k] + bmg);
@@ -1675,8 +1707,6 @@ QD void pair_contacts(const QuadModel& m, const QuadTables& tab, int leg, const 
 #ifdef QEXP_PAIRS_SKIP2
   if (mg > -1.0) return;  // (tuning: the leg-level cull runs, the tests never do)
 #endif
-  QPairArgs args;
-  QUNROLL for (int i = 0; i < kQPairGeom; i++) QUNROLL for (int k = 0; k < 3; k++) { args.pg.c[i][k] = pg.c[i][k]; args.pg.a[i][k] = pg.a[i][k]; }
   QUNROLL for (int k = 0; k < 3; k++) { args.txpos[k] = txpos[k]; args.com[k] = com[k]; }
   QUNROLL for (int k = 0; k < 9; k++) args.txm[k] = txm[k];
   QUNROLL for (int j = 0; j < 3; j++) QUNROLL for (int k = 0; k < 6; k++) args.cvel[j][k] = cvel[j][k];
@@ -1879,8 +1909,11 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
   // ================= collision (o_collision): the leg's geoms and the lane's share of the trunk geoms; the self-collision test
   int ncon = 0;
   {
-    QPairGeoms pg;
-    QUNROLL for (int i = 0; i < kQPairGeom; i++) QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = 0; pg.a[i][k] = 0; }
+    const int near_leg = static_near_mask(m, sp, xpos[0], L.reach), near_trunk = static_near_mask(m, sp, txpos, m.trunk_reach);
+    QPairArgs pargs;  // (the self-collision tests' argument block: in memory -- they are out of line; the loop below writes the pair geoms' poses into it)
+    QPairBoxes pbox;
+    pair_boxes_init(pbox);
+    for (int i = 0; i < kQPairGeom; i++) for (int k = 0; k < 3; k++) { pargs.pg.c[i][k] = 0; pargs.pg.a[i][k] = 0; }
     for (int gi = 0; gi < L.ngeom; gi++) {
       const QuadGeom& g = L.geom[gi];
       double gp[3], gR[9];
@@ -1893,11 +1926,12 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
       QUNROLL for (int k = 0; k < 3; k++) gp[k] += bp[k];
       QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = bm[3 * r] * g.rot[c] + bm[3 * r + 1] * g.rot[3 + c] + bm[3 * r + 2] * g.rot[6 + c];
       if (gi == L.foot_slot) { QUNROLL for (int k = 0; k < 3; k++) out.foot[k] = gp[k]; }
-      QUNROLL for (int i = 0; i < kQPairGeom; i++) {  // (compile-time slots: a run-time index would put the array in scratch)
-        const bool hit = i < L.npg && L.pg_slot[i] == gi;
-        QUNROLL for (int k = 0; k < 3; k++) { pg.c[i][k] = hit ? gp[k] : pg.c[i][k]; pg.a[i][k] = hit ? gR[3 * k + 2] : pg.a[i][k]; }
+      if (g.pgi >= 0) {  // a pair geom: its pose to the tests' argument block (memory, run-time slot), its box into the cull's
+        const double ga[3] = {gR[2], gR[5], gR[8]};
+        for (int k = 0; k < 3; k++) { pargs.pg.c[g.pgi][k] = gp[k]; pargs.pg.a[g.pgi][k] = ga[k]; }
+        pair_boxes_add(L, g.pgi, gp, ga, txpos, txm, pbox);
       }
-      collide_geom(m, sp, g, &tab.leg[leg][0][gi], kQLegGeom, com, bv, lk + 1, gp, gR, cs, ncon, flags);
+      collide_geom(m, sp, g, near_leg, &tab.leg[leg][0][gi], kQLegGeom, com, bv, lk + 1, gp, gR, cs, ncon, flags);
     }
     for (int gi = leg; gi < m.ntrunk_geom; gi += kQLegs) {
       const QuadGeom& g = m.trunk_geom[gi];
@@ -1905,7 +1939,7 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
       mv3(gp, txm, g.pos);
       QUNROLL for (int k = 0; k < 3; k++) gp[k] += txpos[k];
       QUNROLL for (int r = 0; r < 3; r++) QUNROLL for (int c = 0; c < 3; c++) gR[3 * r + c] = txm[3 * r] * g.rot[c] + txm[3 * r + 1] * g.rot[3 + c] + txm[3 * r + 2] * g.rot[6 + c];
-      collide_geom(m, sp, g, &tab.trunk[0][gi], kQTrunkGeom, com, cvelT, 0, gp, gR, cs, ncon, flags);
+      collide_geom(m, sp, g, near_trunk, &tab.trunk[0][gi], kQTrunkGeom, com, cvelT, 0, gp, gR, cs, ncon, flags);
     }
     QPROF(pf, 2);
     int pmask = 0, nrel = 0;
@@ -1913,7 +1947,7 @@ QD int forward_smooth(const QuadModel& m, const QuadTables& tab, const QStaticPo
     // (the leg's own pairs -- a calf or foot on its hip -- are proven apart inside a joint box: pair_cull.h)
     const bool self_walk = !(S.lq[0] >= L.self_box[0][0] && S.lq[0] <= L.self_box[0][1] && S.lq[1] >= L.self_box[1][0] && S.lq[1] <= L.self_box[1][1] &&
                              S.lq[2] >= L.self_box[2][0] && S.lq[2] <= L.self_box[2][1]);
-    pair_contacts(m, tab, leg, pg, txpos, txm, com, cvel, cvelT, self_walk, cs, ncon, flags, pmask, nrel, pf);
+    pair_contacts(m, tab, leg, pargs, pbox, txpos, txm, com, cvel, cvelT, self_walk, cs, ncon, flags, pmask, nrel, pf);
 #endif
     D.ncon = ncon; D.nrel = nrel;
     // bit x of pmask: some leg A touches leg A xor x. One bit set (the common case of self-collision) means disjoint pairs, which the
