@@ -438,7 +438,7 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
     return out
 
 
-def run_ilqg(local_rank, iterations=6, warmup=2):
+def run_ilqg(local_rank, iterations=6, warmup=2, cpu=True):
     """BASELINE configs[4]: one iLQG iteration on the Quadruped (T = 36, 10 line-search rollouts, forward differences,
     MakeDifferentiable on) through the C++ mjpc::GpuILQGPlanner; beside it the same iteration by the Python mirror of the
     planner on the CPU oracle (tests/oracle_backend.py: oracle/{ilqg,riccati}.c) on the host cores."""
@@ -492,6 +492,8 @@ def run_ilqg(local_rank, iterations=6, warmup=2):
                                                      "products: latency-bound by construction (DESIGN.md 4.4)"}}
     except Exception as e:  # noqa: BLE001
         out["backward_pass"] = {"error": repr(e)}
+    if not cpu:   # (A/B runs of device builds: tools/ab_ilqg.sh)
+        return out
     # CPU port of the same iteration
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -72,7 +72,10 @@ __device__ __forceinline__ int qd_or(int v) {
 // its four lanes write the same value and read it back as an LDS broadcast).
 namespace mjpcx { namespace quad {
 struct QContact;
-constexpr int kQLdsSlots = 3;
+#ifndef QEXP_LDS_SLOTS
+#define QEXP_LDS_SLOTS 3   // (a fourth slot would need 28.7 KB more of the CU's LDS; 0.8 KB are free)
+#endif
+constexpr int kQLdsSlots = QEXP_LDS_SLOTS;
 typedef __attribute__((address_space(3))) double qlds_f64;  // a typed LDS pointer: ds_read / ds_write instead of FLAT accesses
 typedef __attribute__((address_space(5))) double qprv_f64;  // a typed private pointer: scratch_load / scratch_store
 #ifndef QEXP_OVF_SLAB
