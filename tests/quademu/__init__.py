@@ -36,6 +36,16 @@ def _f(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def plan(masks):
+    """quad_step.h make_plan on the four legs' contact masks -> (nslots, x[3], eslot[4], cyclic), the same in the four lanes"""
+    import numpy as np
+    out = np.zeros((4, 9), np.int32)
+    m = np.ascontiguousarray(masks, np.int32)
+    lib().quademu_plan(m.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.POINTER(C.c_int)))
+    assert (out == out[0]).all(), out
+    return int(out[0, 0]), out[0, 1:4].tolist(), out[0, 4:8].tolist(), bool(out[0, 8])
+
+
 def check(pm, pt):
     return lib().quademu_check(pm.ptr, pt.ptr).decode()
 

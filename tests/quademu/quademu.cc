@@ -149,6 +149,19 @@ const char* quademu_check(const mjpcx_model* model, const mjpcx_task* task) {
   return msg.c_str();
 }
 
+// the elimination plan of a leg-contact graph (quad_step.h make_plan): masks[k] bit x (1..3) = leg k touches leg k ^ x. out, per lane
+// (4 x 9 ints): nslots, x[3], eslot[4], cyclic -- the four lanes must agree
+void quademu_plan(const int* masks, int* out) {
+  run_quad([&](int leg) {
+    const QPlan p = make_plan(masks[leg], leg);
+    int* o = out + 9 * leg;
+    o[0] = p.nslots;
+    for (int s = 0; s < 3; s++) o[1 + s] = p.x[s];
+    for (int k = 0; k < 4; k++) o[4 + k] = p.eslot[k];
+    o[8] = p.cyclic ? 1 : 0;
+  });
+}
+
 // prints the self-collision tables of the model (bring-up aid)
 void quademu_dump_pairs(const mjpcx_model* model, const mjpcx_task* task) {
   Built* b = new Built;

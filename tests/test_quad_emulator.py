@@ -265,3 +265,55 @@ def test_feedback_rollouts_match_the_oracle(quad, mode, representation, use_stat
         assert close(emu[k], ref[k], 1e-9), (k, float(np.abs(emu[k] - ref[k]).max()))
     if use_state:
         assert np.ptp(emu["total_return"]) > 1e-7
+
+
+def test_elimination_plan_on_every_leg_contact_graph():
+    """quad_step.h make_plan over all 64 graphs on the four legs: a forest gets an order in which every edge is eliminated exactly once, each
+    time from a leg that is a LEAF at that moment into the leg on the other end, at most one elimination per leg, the lower leg of an isolated
+    pair; a graph with a cycle is reported cyclic (the kernel hands such a candidate on, kFlagPair)"""
+    import itertools
+    from tests import quademu
+    edges_all = [(a, b) for a in range(4) for b in range(a + 1, 4)]
+    seen_cyclic = seen_forest = 0
+    for bits in range(64):
+        edges = {e for i, e in enumerate(edges_all) if bits >> i & 1}
+        masks = [0] * 4
+        for a, b in edges:
+            masks[a] |= 1 << (a ^ b); masks[b] |= 1 << (a ^ b)
+        # a cycle: union-find over the edges
+        root = list(range(4))
+
+        def find(k):
+            while root[k] != k:
+                k = root[k]
+            return k
+        has_cycle = False
+        for a, b in sorted(edges):
+            ra, rb = find(a), find(b)
+            if ra == rb:
+                has_cycle = True
+            root[ra] = rb
+        nslots, x, eslot, cyclic = quademu.plan(masks)
+        assert cyclic == has_cycle, (sorted(edges), cyclic)
+        if cyclic:
+            seen_cyclic += 1
+            continue
+        seen_forest += 1
+        left = set(edges)
+        assert nslots <= 3 and all(0 < x[s] < 4 for s in range(nslots)) and all(-1 <= s < nslots for s in eslot)
+        for s in range(nslots):
+            gone = set()
+            for k in range(4):
+                if eslot[k] != s:
+                    continue
+                e = (min(k, k ^ x[s]), max(k, k ^ x[s]))
+                assert e in left and e not in gone, (sorted(edges), s, k)
+                assert sum(1 for f in left if k in f) == 1, (sorted(edges), s, k)       # a leaf when its slot comes
+                if sum(1 for f in left if (k ^ x[s]) in f) == 1:                          # an isolated pair: the lower leg eliminates
+                    assert k < (k ^ x[s])
+                assert eslot[k ^ x[s]] != s                                                # the receiver is not eliminated in the same slot
+                gone.add(e)
+            assert gone, (sorted(edges), s)
+            left -= gone
+        assert not left, (sorted(edges), sorted(left))
+    assert seen_forest == 38 and seen_cyclic == 26   # the labelled forests on four vertices (OEIS A001858: 38)
