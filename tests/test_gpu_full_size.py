@@ -144,4 +144,4 @@ def test_config4_humanoid_tracking_n8192_h64(precision, tol):
     t = load_task("HumanoidTrack")
     e = t.transition(0.0, mode=9)
     full_size_properties(t, np.concatenate([e["qpos"], e["qvel"]]), mocap7(e["mocap_pos"]), N=8192, H=64, P=16, interp=2,
-                         mode=capi.NOISE_SAMPLING, precision=precision, tol=tol, sample_stride=512)
+                         mode=capi.NOISE_SAMPLING, precision=precision, tol=tol, sample_stride=64)
