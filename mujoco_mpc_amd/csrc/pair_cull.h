@@ -14,7 +14,7 @@
 //   * wave / tree kernels (wave_model.h): every sphere | capsule pair and every thin-solid pair is collided, proven apart or not; two solids
 //     are kept in the list and WATCHED, proven apart or not (a thin geom containing one of them within the margin of the other raises
 //     warning bit 128 and the rollout fails, as the oracle's does); the ones that cannot be proven apart are REPORTED at create time (the
-//     warning / MJPCX_STRICT_PAIRS refusal), and a model in which two of them already touch at qpos0 or a keyframe is refused outright.
+//     warning / MJPCX_STRICT_PAIRS refusal), and a model in which two of them already touch at qpos0 is refused outright (qpos0 only: keyframes are not examined -- a model whose solids overlap in a keyframe alone fails its rollouts at run time with warning bit 128).
 //   * quad kernel (quad_model.h): pairs outside its layout must be proven apart or the model is declined -- two solids with the wide pad
 //     only; a candidate one of whose joints leaves the range the proofs cover (range + pad) is handed to the wavefront-per-candidate
 //     kernel at that step (kFlagRange).

@@ -40,7 +40,9 @@ hipError_t launch_rollout_quad(const void* model_, const void* tables_, const do
   QArgs q = a;
   q.cpw = pick_cpw(a.N, a.cpw);
   const int waves = (a.N + q.cpw - 1) / q.cpw;
-  const int W = waves >= 512 ? 4 : 1;
+  // (below 1024 wavefronts W = 4 would leave CUs without a workgroup: 512 waves in 128 workgroups on 256 CUs -- ADVICE r05; one wavefront
+  // per workgroup spreads a 2048-candidate share over 512 CUs' worth of slots instead)
+  const int W = waves >= 4 * 256 ? 4 : 1;
   const size_t lds = W * kQWaveLds;
   // (the opt-in to more than 64 KB of dynamic LDS is per device and costs nothing next to a 60 ms launch: set on every launch, like the other launchers)
   hipError_t e = hipFuncSetAttribute((const void*)rollout_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kQWaveLds));

@@ -293,6 +293,38 @@ def test_ilqg_kernels_with_the_rk4_integrator(quad, tree, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("risk", [0.0, 0.7])
+def test_cost_derivatives_at_the_a1s_shape(quad, risk):
+    """cost_derivatives_kernel against oracle ocost_derivatives (mjpc/planners/cost_derivatives.cc:112-230) at the shape of
+    BASELINE configs[4]: nr = 42 residuals in 9 terms with the task's own norm mix, ndx = 36, nu = 12, T = 36, risk-neutral and
+    risk-sensitive. C, D are the ORACLE's finite differences, so both sides contract the same Jacobians: 1e-10 relative."""
+    import copy
+    t2 = copy.copy(quad); t2.risk = risk
+    pm, pt = t2.packed_model(), t2.packed()
+    H = 36
+    home = quad.model.keyframes["home"]["qpos"]
+    rng = np.random.default_rng(11)
+    state = np.concatenate([home, 0.3 * rng.normal(size=18)])
+    state[7:19] += 0.15 * rng.normal(size=12)
+    times = np.arange(4) * (H - 1) * 0.01 / 3
+    nodes = np.clip(rng.normal(0, 0.3, (1, 4, 12)), -1, 1)
+    nom = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, 1, H, 4, 1, times, nodes, num_threads=1)
+    nom = {k: v[0] for k, v in nom.items() if k not in ("total_return", "failure")}
+    assert nom["residual"].shape == (H, 42) and pt.struct.num_term == 9
+    norms = sorted(set(int(pt.struct.norm[i]) for i in range(9)))
+    assert len(norms) >= 3, norms                      # the A1's norm mix (quadratic, L2, smooth-abs ...), not one type
+    _, _, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], 1e-6, 0, mocap=MOCAP)
+    assert Co.shape == (H, 42, 36) and Do.shape == (H, 42, 12)
+    ctx = capi.Context(pm, pt, 0, 64)
+    got = ctx.cost_derivatives(nom["residual"], Co, Do)
+    ref = pyoracle.cost_derivatives(pt, nom["residual"], Co, Do)
+    for name, g, o in zip(("cx", "cu", "cxx", "cxu", "cuu"), got, ref):
+        scale = 1 + np.abs(o).max()
+        assert np.abs(g - o).max() <= 1e-10 * scale, (name, float(np.abs(g - o).max()), scale)
+    assert np.abs(got[2]).max() > 0 and np.abs(got[3]).max() > 0 and np.abs(got[4]).max() > 0
+    ctx.close()
+
+
 def test_ilqg_planner_on_the_quadruped():
     """BASELINE configs[4] in miniature: iLQG on the A1 (T = 36, 10 line-search rollouts, forward differences) -- the
     device sweep (49 perturbed steps per time step), cost derivatives, the MFMA Riccati pass at n = 36, m = 12 and the

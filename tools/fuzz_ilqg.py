@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Random-state parity sweep of the iLQG device kernels of the A1 (run on the GPU box): a nominal trajectory from a random state under
 a random spline, then (a) the feedback rollouts -- RolloutDiscrete with the index policy and iLQGPolicy::Action in its three
-representations, random gains, ten line-search scalings -- against oracle/ilqg.c at 1e-7, and (b) the finite-difference sweep
+representations, random gains, ten line-search scalings -- against oracle/ilqg.c at 1e-7, (b) the finite-difference sweep
 (forward and centred) against the oracle's at 5e-5 (the quotient amplifies the step functions' 1e-13 agreement by 1 / eps = 1e6, and a
-contact that switches inside the perturbation is a genuinely large entry on both sides)."""
+contact that switches inside the perturbation is a genuinely large entry on both sides), and (c) cost_derivatives_kernel at the A1's shape (nr 42, ndx 36, nu 12; risk 0 and 0.7) on the
+oracle's C, D against oracle ocost_derivatives at 1e-10."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -25,7 +26,7 @@ def rel(a, b):
     return float(np.max(np.abs(a - b) / (1 + np.abs(b))))
 
 
-worst_fb = worst_fd = 0.0
+worst_fb = worst_fd = worst_cd = 0.0
 for case in range(cases):
     H = int(rng.integers(8, 30))
     q = home.copy()
@@ -67,9 +68,21 @@ for case in range(cases):
         A, B, C, D = ctx.transition_fd(nom["times"][:Hd], nom["states"][:Hd], nom["actions"][:Hd], 1e-6, centered)
         Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"][:Hd], nom["times"][:Hd], nom["actions"][:Hd], 1e-6, centered, mocap=mocap)
         e_fd = max(e_fd, rel(A, Ao), rel(B, Bo), rel(C, Co), rel(D, Do))
+    # (c) cost_derivatives_kernel on the oracle's C, D of this trajectory (both sides contract the same Jacobians): risk-neutral and not
+    e_cd = 0.0
+    for risk in (0.0, 0.7):
+        pt.struct.risk = risk
+        cctx = capi.Context(pm, pt, 0, 64)
+        got = cctx.cost_derivatives(nom["residual"][:Hd], Co, Do)
+        ref = pyoracle.cost_derivatives(pt, nom["residual"][:Hd], Co, Do)
+        for g, o in zip(got, ref):
+            e_cd = max(e_cd, float(np.abs(g - o).max() / (1 + np.abs(o).max())))
+        cctx.close()
+    pt.struct.risk = 0.0
+    worst_cd = max(worst_cd, e_cd)
     worst_fb, worst_fd = max(worst_fb, e_fb), max(worst_fd, e_fd)
-    bad = e_fb >= 1e-7 or e_fd >= 5e-5
+    bad = e_fb >= 1e-7 or e_fd >= 5e-5 or e_cd >= 1e-10
     if bad or case % 5 == 0:
-        print(f"case {case:3d}: H = {H:2d}  feedback rollouts {e_fb:.2e}  derivative sweep {e_fd:.2e}{'   <-- beyond tolerance' if bad else ''}", flush=True)
-print(f"{cases} cases: worst feedback rollouts {worst_fb:.3e}, worst derivative sweep {worst_fd:.3e}")
-assert worst_fb < 1e-7 and worst_fd < 5e-5
+        print(f"case {case:3d}: H = {H:2d}  feedback rollouts {e_fb:.2e}  derivative sweep {e_fd:.2e}  cost derivatives {e_cd:.2e}{'   <-- beyond tolerance' if bad else ''}", flush=True)
+print(f"{cases} cases: worst feedback rollouts {worst_fb:.3e}, worst derivative sweep {worst_fd:.3e}, worst cost derivatives {worst_cd:.3e}")
+assert worst_fb < 1e-7 and worst_fd < 5e-5 and worst_cd < 1e-10

@@ -1,6 +1,6 @@
 #!/bin/bash
-# kernel trace of one Quadruped iLQG planning run (configs[4]) -> gpurun_out/r05/ilqg_kernel_stats.csv (copy to profiles/r05_ilqg_kernel_stats.csv)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05; mkdir -p $O
+# kernel trace of one Quadruped iLQG planning run (configs[4]) -> gpurun_out/$ROUND/ilqg_kernel_stats.csv (copy to profiles/${ROUND}_ilqg_kernel_stats.csv)
+ROUND=${ROUND:-r06}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$ROUND; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ilqg_trace -o ilqg -- python -c "
 import sys; sys.path.insert(0, '$R')

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box call that collects what profiles/r05_* is made of; the sections run in this order and are picked by WHAT (default: all):
+# One GPU-box call that collects what profiles/${ROUND}_* is made of; the sections run in this order and are picked by WHAT (default: all):
 #   tests   the GPU test suite
 #   pmc     counters + kernel trace of the launches bench.py times, north star and Humanoid (tools/pmc_bench.sh); bench.py picks the
 #           summaries up from profiles/ as roofline.traffic / .valu of its line
@@ -7,8 +7,9 @@
 #   bench   the default bench line with its extras
 #   trace   rocprofv3 --kernel-trace --stats of the bench command
 #   ilqg    kernel trace of the iLQG iteration
-# Files land in gpurun_out/r05/ (merged back by gpurun); copy them to profiles/ and commit.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05; mkdir -p $O
+# Files land in gpurun_out/$ROUND/ (merged back by gpurun); copy them to profiles/ and commit.
+export ROUND=${ROUND:-r06}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$ROUND; mkdir -p $O
 WHAT=${WHAT:-tests pmc stamps bench trace ilqg}
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 cd $R
@@ -16,7 +17,7 @@ if has tests; then timeout 900 python -m pytest tests -m gpu -q -x > $O/gputests
 if has pmc; then
   bash $R/tools/pmc_bench.sh QuadrupedFlat 64 > $O/pmc_quadrupedflat.log 2>&1; tail -3 $O/pmc_quadrupedflat.log
   bash $R/tools/pmc_bench.sh HumanoidTrack 32 10 2 > $O/pmc_humanoidtrack.log 2>&1; tail -3 $O/pmc_humanoidtrack.log
-  for f in $R/gpurun_out/pmc_*/r05_pmc_*.json; do [ -f $f ] && cp $f $R/profiles/ && cp $f $O/; done   # (the profiles/ copy lives on the box only; $O is merged back)
+  for f in $R/gpurun_out/pmc_*/${ROUND}_pmc_*.json; do [ -f $f ] && cp $f $R/profiles/ && cp $f $O/; done   # (the profiles/ copy lives on the box only; $O is merged back)
   for t in quadrupedflat humanoidtrack; do find $R/gpurun_out/pmc_$t/p0 -name "*kernel_trace.csv" -exec cp {} $O/pmc_${t}_kernel_trace.csv \; ; done
 fi
 cd $R

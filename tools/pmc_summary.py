@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc_<task>/p0..p5 (tools/pmc_bench.sh: one --kernel-trace pass and five --pmc passes over bench.py's own command) ->
-the per-build counter summary bench.py reads (profiles/r05_pmc_<task>_fp<prec>.json):
+"""gpurun_out/pmc_<task>/p0..p7 (tools/pmc_bench.sh: one --kernel-trace pass and seven --pmc passes over bench.py's own command) ->
+the per-build counter summary bench.py reads (profiles/rNN_pmc_<task>_fp<prec>.json):
     python tools/pmc_summary.py <dir> <task> <precision> <steps> <warmup> <out.json>
 Every figure is kept PER LAUNCH of the task's rollout kernel, in launch order (warm-up launches first), so that the easy first
 launches and the timed ones are separable; `timed` averages the launches bench.py times (index >= warmup).
@@ -44,9 +44,9 @@ cut = 0.1 * max(launch_ms)
 keep = [i for i, ms in enumerate(launch_ms) if ms > cut]
 launch_ms = [launch_ms[i] for i in keep]
 
-# ---- passes 1..5: counters per launch
+# ---- passes 1..7: counters per launch
 per = {}
-for p in range(1, 6):
+for p in range(1, 8):
     for f in glob.glob(os.path.join(d, f"p{p}", "**", "*counter_collection.csv"), recursive=True):
         acc, dur = {}, {}
         for row in csv.DictReader(open(f)):
@@ -116,5 +116,23 @@ out = {
         "candidates_per_wavefront": per_wave,
     },
 }
+# ---- what the kernel executes in floating point (pass 6 / 7): wave-level instruction counts by class of the working precision. A
+# wave-instruction is credited with all 64 lanes, so flop_per_launch is an UPPER bound of the useful work (lanes masked off by EXEC, the
+# trunk's arithmetic replicated in the lanes of a candidate, selects and moves are not separated); lane_activity says how full the VALU
+# instructions were (SQ_THREAD_CYCLES_VALU: active lanes summed over the VALU cycles, against 64 x the wave-level VALU cycles)
+F = f"F{prec}"
+if f"SQ_INSTS_VALU_FMA_{F}" in c:
+    fma, add, mul, tr = (c.get(f"SQ_INSTS_VALU_{k}_{F}", 0.0) for k in ("FMA", "ADD", "MUL", "TRANS"))
+    out["executed_flops"] = {
+        "wave_instructions": {"fma": fma, "add": add, "mul": mul, "trans": tr, "all_valu": c.get("SQ_INSTS_VALU"),
+                              "int32": c.get("SQ_INSTS_VALU_INT32"), "cvt": c.get("SQ_INSTS_VALU_CVT")},
+        "flop_per_launch": (2 * fma + add + mul + tr) * 64,
+        "fp_share_of_valu": (fma + add + mul + tr) / c["SQ_INSTS_VALU"] if c.get("SQ_INSTS_VALU") else None,
+        "hardware_flops_counter": c.get(f"SQ_INSTS_VALU_FLOPS_FP{prec}"), "hardware_flops_trans_counter": c.get(f"SQ_INSTS_VALU_FLOPS_FP{prec}_TRANS"),
+        "thread_cycles_valu": c.get("SQ_THREAD_CYCLES_VALU"),
+        "lane_activity": (c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])) if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None,
+        "note": "flop_per_launch = (2 FMA + ADD + MUL + TRANS wave-instructions of the working precision) x 64 lanes, mean of the timed launches: "
+                "an upper bound of the useful floating-point work (every lane credited; see lane_activity). Counters: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_" + F,
+    }
 json.dump(out, open(dst, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("kernel", "src_sha16", "launches", "launch_ms_under_kernel_trace", "hbm_bytes_by_launch", "timed", "valu")}, indent=1))
+print(json.dumps({k: out[k] for k in ("kernel", "src_sha16", "launches", "launch_ms_under_kernel_trace", "hbm_bytes_by_launch", "timed", "valu", "executed_flops") if k in out}, indent=1))
