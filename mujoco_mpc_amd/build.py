@@ -31,10 +31,13 @@ PRESSURE_QUAD = ["-mllvm", "-disable-machine-licm", "-mllvm", "-disable-licm-pro
 # without the CFG pair 51.9, without both (-ffp-contract=on alone) 53.3; + -fno-slp-vectorize 50.8 (twice); + the scheduler bias 51.1 (none);
 # -amdgpu-sched-strategy=max-ilp 51.4
 SOURCES = [("mjpcx.hip", PRESSURE), ("ilqg_wave.hip", []), ("wave32.hip", PRESSURE), ("lane_static.hip", ["-fno-signed-zeros", "-ffinite-math-only"]),
-           ("quad_kernel.hip", PRESSURE_QUAD)]
+           ("quad_kernel.hip", PRESSURE_QUAD), ("limb_kernel.hip", [])]
 # headers only the quad kernel's translation unit includes / the headers that unit needs (so that a change of the quad step does not
 # re-compile the wavefront-per-candidate kernels, and vice versa)
-QUAD_ONLY = ["quad_step.h", "quad_kernel.h", "quad_model.h"]
+QUAD_ONLY = ["quad_step.h", "quad_kernel.h", "quad_model.h", "limb_step.h", "limb_kernel.h", "limb_model.h"]
+# likewise the limb kernel's unit (the Humanoid of configs[3])
+LIMB_DEPS = ["limb_step.h", "limb_kernel.h", "limb_model.h", "limb_abi.h", "limb_launch.h", "limb_kernel.hip", "pair_cull.h", "solid_pairs.h",
+             os.path.join("..", "..", "include", "mjpcx.h")]
 QUAD_DEPS = ["quad_step.h", "quad_kernel.h", "quad_model.h", "quad_abi.h", "quad_launch.h", "quad_kernel.hip", "solid_pairs.h", "pair_cull.h",
              os.path.join("..", "..", "include", "mjpcx.h")]
 HEADERS = ["device_common.h", "rollout_lane.h", "lane_registry.h", os.path.join("generated", "static_models.h"),
@@ -74,8 +77,10 @@ def build_native(force=False, verbose=False):
         objs.append(obj)
         if src == "quad_kernel.hip":
             mine = [os.path.join(CSRC, h) for h in QUAD_DEPS]
+        elif src == "limb_kernel.hip":
+            mine = [os.path.join(CSRC, h) for h in LIMB_DEPS]
         else:
-            mine = [d for d in deps if os.path.basename(d) not in QUAD_ONLY and os.path.basename(d) != "quad_kernel.hip"]
+            mine = [d for d in deps if os.path.basename(d) not in QUAD_ONLY and os.path.basename(d) not in ("quad_kernel.hip", "limb_kernel.hip")]
         mine = mine + [os.path.abspath(__file__)]  # (the flags are in this file)
         if force or _stale(obj, mine):
             cmd = common + flags + ["-c", os.path.join(CSRC, src), "-o", obj]

@@ -34,7 +34,7 @@ constexpr int kTGL = 2;             // trunk geoms dealt to a lane for the test 
 constexpr int kLS = 4;              // tracking sites per lane (the limb's own and the trunk's, dealt)
 constexpr int kNG = 24;             // moving geoms in the candidate's shared pose table
 constexpr int kMaxPC = 8;           // contacts with the floor per lane and step
-constexpr int kMaxX = 4;            // contacts between two moving geoms per candidate and step
+constexpr int kMaxX = 8;            // contacts between two moving geoms per candidate and step
 constexpr int kMaxPair = 192, kMaxPSet = 8, kMaxResid = 160, kMaxTerm = 32, kMaxTrace = 2;
 constexpr int kPairsPerLane = kMaxPair / kLimbs;
 inline constexpr int slot_body(int j) { return j < 3 ? 0 : (j < 4 ? 1 : 2); }

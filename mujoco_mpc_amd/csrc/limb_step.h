@@ -27,6 +27,7 @@
 #pragma once
 #include <stdint.h>
 
+#include "limb_abi.h"
 #include "limb_model.h"
 
 #ifndef LD
@@ -40,6 +41,32 @@
 #endif
 #ifndef LNOINLINE
 #define LNOINLINE LD
+#endif
+// An out-of-line function of the step receives the model image and its caller's locals through plain references / pointers; the device build
+// says where they live (LDS / the private segment) so that they are read with ds_read / scratch_load instead of FLAT accesses, and copies
+// the locals in and out once per call (limb_kernel.h).
+#ifndef LREBIND_LDS
+#define LREBIND_LDS(T, ref) (ref)
+#endif
+#ifndef LPRV_LOAD
+#define LPRV_LOAD(dst, src) (dst) = *(src)
+#define LPRV_STORE(dst, src) *(dst) = (src)
+#define LPRV_LOADN(dst, src, n) do { for (int i_ = 0; i_ < (n); i_++) (dst)[i_] = (src)[i_]; } while (0)
+#define LPRV_STOREN(dst, src, n) do { for (int i_ = 0; i_ < (n); i_++) (dst)[i_] = (src)[i_]; } while (0)
+#endif
+#ifndef LEXP_COPY_MASK
+#define LEXP_COPY_MASK 0   // (which out-of-line stages copy their arguments in and out: 1 forward, 2 newton, 4 euler, 8 residual. The forward stage works on the caller's structs directly: with the copies its device build produced wrong states -- the emulator did not -- and they save nothing there, 300 accesses in a 30 k-instruction stage)
+#endif
+#ifndef LPOISON
+#define LPOISON(x)   // (the emulator fills fresh locals with NaN patterns: a read before a write shows)
+#endif
+#ifndef LEXP_GFLOOR
+#define LEXP_GFLOOR 16   // (multiples of the working precision's epsilon: see the Newton loop's floors)
+#define LEXP_CFLOOR 8
+#endif
+#ifndef LPROF
+#define LPROF(a, last, idx)   // phase cycle stamps of wavefront 0 (the device build: limb_kernel.h)
+#define LPROF_COUNT(a, idx)
 #endif
 
 namespace mjpcx { namespace limb {
@@ -125,6 +152,11 @@ template <typename R> LD void cross_force(R* res, const R* vel, const R* f) {
 }
 template <typename R> LD R clampr(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
 // solimp (digested: limb_model.h) -> impedance at violation `dist` (oracle impedance())
+// (the general exponent needs pow(): ONE out-of-line instance for all the call sites -- inlined it was four pow() bodies per site, and the
+// step function's code has to stay near the 64 KB of the instruction cache)
+template <typename R> LNOINLINE R impedance_pow(R x, R mid, R power) {
+  return x <= mid ? R(pow(x, power) / pow(mid, power - 1)) : R(1 - pow(1 - x, power) / pow(1 - mid, power - 1));
+}
 template <typename R> LD R impedance(const R* d, R dist) {
   const R dmin = d[0], dmax = d[1], width = d[2], mid = d[3], power = d[4];
   if (dmin == dmax || width <= R(1e-15)) return R(0.5) * (dmin + dmax);
@@ -134,9 +166,10 @@ template <typename R> LD R impedance(const R* d, R dist) {
   R y;
   if (power == 1) y = x;
   else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
-  else y = x <= mid ? R(pow(x, power) / pow(mid, power - 1)) : R(1 - pow(1 - x, power) / pow(1 - mid, power - 1));
+  else y = impedance_pow(x, mid, power);
   return dmin + y * (dmax - dmin);
 }
+template <typename R> LD constexpr R kEps() { return sizeof(R) == 4 ? R(1.1920929e-7) : R(2.220446049250313e-16); }
 LD constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
 template <typename R> LD void sym6_add_outer(R* X, R w, const R* v) {
   LUNROLL for (int p = 0; p < 6; p++) { const R wp = w * v[p]; LUNROLL for (int q = 0; q <= p; q++) X[tri(p, q)] += wp * v[q]; }
@@ -281,16 +314,20 @@ constexpr int kLConRec = 10;  // reals per stored contact: off 0-2, D 3, mu 4, j
 // A contact between two moving geoms, in the candidate's SHARED block: the row's generator et = [off x n; n] about the centre of mass,
 // what the row's instantiation needs, and which chains it acts on (body 1: minus, body 2: plus)
 template <typename R> struct LCross { R et[6], D, b, kimpx; int la, sa, lb, sb; };
-constexpr int kLCrossRec = 10;  // et 0-5, D 6, b 7, kimpx 8, meta 9
+constexpr int kLCrossRec = 12;  // et 0-5, D 6, b 7, kimpx 8, meta 9; the solver's: jar 10, its rate along the search direction 11 (lsh_xget / lsh_xset)
 
+template <typename R> LD R xsel(const R* v, int r) {  // v[r], r at run time, without indexing registers
+  R o = 0;
+  LUNROLL for (int i = 0; i < kMaxX; i++) o = i == r ? v[i] : o;
+  return o;
+}
 // the lane's diagonal rows: the active limit of each joint (side 0: none; J = -side on the dof) and of the limb's tendon; the trunk's three
 // hinges' (replicated)
 template <typename R> struct LRows {
   R lm_D[kLD], lm_jar[kLD]; int lm_side[kLD];
   R tn_D, tn_jar; int tn_side;
   R tl_D[3], tl_jar[3]; int tl_side[3];
-  R xD[kMaxX], xjar[kMaxX];  // the contacts between moving geoms (replicated): D, jar
-};
+};  // (the rows of the contacts between moving geoms live in the quad's shared block: LCross, lsh_xget / lsh_xset)
 
 // what the sensor stage reads
 template <typename R> struct LSense { R spos[kLS][3], svel[kLS][3], trace[kMaxTrace][3]; };
@@ -318,7 +355,7 @@ template <typename R> LD void limit_row(R dist, R margin, R vel, R invw, R k, R 
 
 // ---------------------------------------------------------------- mj_forward before the constraint solve
 template <typename R, class CS, class MS, class SH>
-LD int forward_smooth(const LimbModelT<R>& m, int lane, const LState<R>& S, const R* ctrl, const R* tctrl, CS& cs, MS& ms, SH& sh, LDyn<R>& D, LSense<R>& out) {
+LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S, const R* ctrl, const R* tctrl, CS& cs, MS& ms, SH& sh, LDyn<R>& D, LSense<R>& out) {
   const LimbT<R>& L = m.limb[lane];
   LKin<R>& kin = D.kin;
   int flags = 0;
@@ -745,8 +782,23 @@ LD int forward_smooth(const LimbModelT<R>& m, int lane, const LState<R>& S, cons
   }
   if (nx > kMaxX) nx = 0;
   D.nx = nx;
-  LUNROLL for (int r = 0; r < kMaxX; r++) { Rw.xD[r] = 0; Rw.xjar[r] = 0; }
   flags = qd_or(flags);
+  return flags;
+}
+
+template <typename R, class CS, class MS, class SH>
+LNOINLINE int forward_smooth(const LimbModelT<R>& m_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, CS cs, MS ms, SH sh, LDyn<R>* D_out, LSense<R>* out_out) {
+  const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
+  if (!(LEXP_COPY_MASK & 1)) return forward_smooth_body(m, lane, *S_in, ctrl_in, tctrl_in, cs, ms, sh, *D_out, *out_out);
+  LState<R> S;
+  LPRV_LOAD(S, S_in);
+  R ctrl[kLD], tctrl[3];
+  LPRV_LOADN(ctrl, ctrl_in, kLD); LPRV_LOADN(tctrl, tctrl_in, 3);
+  LDyn<R> D;
+  LSense<R> out;
+  LPOISON(D); LPOISON(out);
+  const int flags = forward_smooth_body(m, lane, S, ctrl, tctrl, cs, ms, sh, D, out);
+  LPRV_STORE(D_out, D); LPRV_STORE(out_out, out);
   return flags;
 }
 
@@ -832,20 +884,18 @@ LD R rows_eval(const LimbModelT<R>& m, const LimbT<R>& L, int lane, const LKin<R
     }
     LUNROLL for (int k = 0; k < 3; k++) { Fp[k] += Fa[k]; Fp[3 + k] += Fl[k]; }
   }
-  if (nx > 0) {  // (quad-uniform)
-    LUNROLL for (int r = 0; r < kMaxX; r++) {
-      if (r >= nx) continue;
-      LCross<R> C;
-      lsh_get_cross(sh, r, C);
-      if (step) Rw.xjar[r] += alpha * cross_value(m, kin, C, lane, VR, xt);
-      R f = 0;
-      row_pen(Rw.xjar[r], Rw.xD[r], costT, f);
-      const int na = C.la < 4 ? m.limb[C.la & 3].nanc : (C.sa == 0 ? 6 : (C.sa == 1 ? 8 : 9)), nb = C.lb < 4 ? m.limb[C.lb & 3].nanc : (C.sb == 0 ? 6 : (C.sb == 1 ? 8 : 9));
-      LUNROLL for (int k = 6; k < kTD; k++) { const int coef = (k < nb ? 1 : 0) - (k < na ? 1 : 0); if (coef != 0) jt[k] += R(coef) * f * dot6(C.et, kin.cdofT[k]); }
-      LUNROLL for (int b = 0; b < kLB; b++) {
-        const R w = (C.lb == lane && C.sb == b ? f : R(0)) - (C.la == lane && C.sa == b ? f : R(0));
-        LUNROLL for (int c = 0; c < 6; c++) Fb[b][c] += w * C.et[c];
-      }
+  for (int r = 0; r < nx; r++) {  // (quad-uniform trip count; a rolled loop: one instance of the row's code for the eight slots)
+    LCross<R> C;
+    lsh_get_cross(sh, r, C);
+    R jar = lsh_xget(sh, r, 10);
+    if (step) { jar += alpha * cross_value(m, kin, C, lane, VR, xt); lsh_xset(sh, r, 10, jar); }
+    R f = 0;
+    row_pen(jar, C.D, costT, f);
+    const int na = C.la < 4 ? m.limb[C.la & 3].nanc : (C.sa == 0 ? 6 : (C.sa == 1 ? 8 : 9)), nb = C.lb < 4 ? m.limb[C.lb & 3].nanc : (C.sb == 0 ? 6 : (C.sb == 1 ? 8 : 9));
+    LUNROLL for (int k = 6; k < kTD; k++) { const int coef = (k < nb ? 1 : 0) - (k < na ? 1 : 0); jt[k] += R(coef) * f * dot6(C.et, kin.cdofT[k]); }
+    LUNROLL for (int b = 0; b < kLB; b++) {
+      const R w = (C.lb == lane && C.sb == b ? f : R(0)) - (C.la == lane && C.sa == b ? f : R(0));
+      LUNROLL for (int c = 0; c < 6; c++) Fb[b][c] += w * C.et[c];
     }
   }
   // limb dofs: the forces on the bodies at or below the dof's
@@ -871,23 +921,24 @@ template <typename R> struct LLine { R x0[4], v[4], D; };
 // Newton solver. (sl, st) = qacc_smooth, (wl, wt) = warm start, M in the store `ms`; leaves qacc in (al, at) and J' force in (fc_l, fc_t).
 // Returns the flag bits (quad-uniform).
 template <typename R, class CS, class MS, class SH>
-LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms, LRows<R>& Rw, CS& cs, int ncon, SH& sh, int nx,
+LD int newton_body(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms, LRows<R>& Rw, CS& cs, int ncon, SH& sh, int nx,
               const R* sl, const R* st, const R* wl, const R* wt, bool have_warm, const R* qvl, const R* qvt,
-              R* al, R* at, R* fc_l, R* fc_t, int& iters) {
+              R* al, R* at, R* fc_l, R* fc_t, int& iters, long long* stamps) {
   const LimbT<R>& L = m.limb[lane];
   iters = 0;
+  struct { long long* stamps; } pa{stamps};
+  long long prof_last = 0;
+  LPROF(pa, prof_last, -1);
   LUNROLL for (int j = 0; j < kLD; j++) al[j] = sl[j];
   LUNROLL for (int k = 0; k < kTD; k++) at[k] = st[k];
   // the contacts between moving geoms: D and -aref of their rows (aref needs J qvel: a quad sum per row)
   if (nx > 0) {
     R VT[kTB][6], VL[kLB][6], VR[kLB][6];
     chain_velocity(kin, L.attach, qvl, qvt, VT, VL, VR);
-    LUNROLL for (int r = 0; r < kMaxX; r++) {
-      if (r >= nx) continue;
+    for (int r = 0; r < nx; r++) {
       LCross<R> C;
       lsh_get_cross(sh, r, C);
-      Rw.xD[r] = C.D;
-      Rw.xjar[r] = C.b * cross_value(m, kin, C, lane, VR, qvt) + C.kimpx;
+      lsh_xset(sh, r, 10, C.b * cross_value(m, kin, C, lane, VR, qvt) + C.kimpx);
     }
   }
   R Mal[kLD], Mat[kTD];
@@ -911,6 +962,7 @@ LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms
   }
   const R scale = R(1) / (m.meaninertia * R(m.nv > 1 ? m.nv : 1));
   R improvement = 0;
+  LPROF(pa, prof_last, 8);
   for (int iter = 0; iter < m.iterations; iter++) {
     R hl[kLD], ht[kTD];
     LUNROLL for (int j = 0; j < kLD; j++) hl[j] = Mal[j] - fc_l[j];
@@ -918,6 +970,14 @@ LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms
     const R gnorm = sqrt(arrow_dot(hl, ht, hl, ht));
     if (gnorm == 0) break;
     if (iter > 0 && (scale * improvement < m.tolerance || scale * gnorm < m.tolerance)) break;
+    // The working precision's floor under the two tests: a gradient that is the rounding residue of its two parts (M (a - a_smooth) and
+    // J' force cancel at the minimum), or a cost that no longer moves by more than its own rounding, cannot be improved on. In double both
+    // floors lie far below the tolerance and never fire first (the iterates are the oracle's); in float the tolerance of 1e-8 is below the
+    // noise, and without the floors every solve would run a confirming iteration or two on noise.
+    if (iter > 0) {
+      const R gref = sqrt(arrow_dot(Mal, Mat, Mal, Mat) + arrow_dot(fc_l, fc_t, fc_l, fc_t));
+      if (gnorm <= LEXP_GFLOOR * kEps<R>() * gref || improvement <= LEXP_CFLOOR * kEps<R>() * fabs(cost)) break;
+    }
     {
       // A = M + J' D J of the rows that keep the arrowhead: limits, the tendon, the floor's contacts through 6 x 6 blocks on the limb's
       // bodies (the composite-rigid-body recursion with the contacts' curvature in place of inertias)
@@ -932,13 +992,12 @@ LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms
         }
       }
       if (qw_any(ncon > 0)) {
+        // the contacts' 6 x 6 blocks by body: nearly every contact is on the limb's LAST body (a foot, a hand), so one block is accumulated in
+        // the pass over the contacts and the other two bodies get a pass of their own only when some lane of the wavefront holds such a contact
         R X[kLB][21];
         LUNROLL for (int b = 0; b < kLB; b++) LUNROLL for (int e = 0; e < 21; e++) X[b][e] = 0;
-        for (int i = 0; i < ncon; i++) {
-          LContact<R> C;
-          lcs_load(cs, i, C);
-          R Xc[21];
-          LUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
+        bool shallow = false;
+        auto contact_block = [&](const LContact<R>& C, R* Xc) {
           LUNROLL for (int e = 0; e < 4; e++) {
             if (e >= C.nrow || !(C.jar[e] < 0)) continue;
             const R s1 = C.nrow == 1 ? R(0) : (e == 0 ? C.mu : (e == 1 ? -C.mu : R(0))), s2 = C.nrow == 1 ? R(0) : (e == 2 ? C.mu : (e == 3 ? -C.mu : R(0)));
@@ -947,9 +1006,27 @@ LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms
             cr3(a, C.off, a + 3);
             sym6_add_outer(Xc, C.D, a);
           }
-          LUNROLL for (int b = 0; b < kLB; b++) { const R w = C.body == b ? R(1) : R(0); LUNROLL for (int e = 0; e < 21; e++) X[b][e] += w * Xc[e]; }
+        };
+        for (int i = 0; i < ncon; i++) {
+          LContact<R> C;
+          lcs_load(cs, i, C);
+          if (C.body != kLB - 1) { shallow = true; continue; }
+          contact_block(C, X[kLB - 1]);
         }
-        LUNROLL for (int e = 0; e < 21; e++) { X[1][e] += X[2][e]; X[0][e] += X[1][e]; }
+        if (qw_any(shallow)) {
+          for (int i = 0; i < ncon; i++) {
+            LContact<R> C;
+            lcs_load(cs, i, C);
+            if (C.body == kLB - 1) continue;
+            R Xc[21];
+            LUNROLL for (int e = 0; e < 21; e++) Xc[e] = 0;
+            contact_block(C, Xc);
+            LUNROLL for (int b = 0; b < kLB - 1; b++) { const R w = C.body == b ? R(1) : R(0); LUNROLL for (int e = 0; e < 21; e++) X[b][e] += w * Xc[e]; }
+          }
+          LUNROLL for (int e = 0; e < 21; e++) { X[1][e] += X[2][e]; X[0][e] += X[1][e]; }
+        } else {
+          LUNROLL for (int e = 0; e < 21; e++) { X[1][e] = X[2][e]; X[0][e] = X[2][e]; }
+        }
         LUNROLL for (int i = 0; i < kLD; i++) {
           R Y[6];
           sym6_mul(Y, X[slot_body(i)], kin.cdof[i]);
@@ -969,61 +1046,72 @@ LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms
         }
       }
       LUNROLL for (int h = 0; h < 3; h++) if (Rw.tl_side[h] != 0 && Rw.tl_jar[h] < 0) H.t[tri(6 + h, 6 + h)] += Rw.tl_D[h];
+      LPROF(pa, prof_last, 9);
       if (!arrow_factor(H)) return kFlagNotPD;
       LUNROLL for (int j = 0; j < kLD; j++) hl[j] = -hl[j];
       LUNROLL for (int k = 0; k < kTD; k++) ht[k] = -ht[k];
       arrow_solve(H, hl, ht);
+      LPROF(pa, prof_last, 10);
       // the contacts between moving geoms: H = A + sum_r D_r u_r u_r' -> (Woodbury) s = y - Z (D^-1 + U' Z)^-1 U' y, Z = A^-1 U
       if (nx > 0) {
+        // (rolled loops over the rows, their vectors in arrays indexed at run time -- private memory: touched only by candidates that have such
+        // contacts, one wavefront-step in two; unrolled over the eight slots this block was a quarter of the solver's code and 200 registers)
         R zl[kMaxX][kLD], zt[kMaxX][kTD], Sm[kMaxX][kMaxX], rhs[kMaxX];
-        bool act[kMaxX];
-        LUNROLL for (int r = 0; r < kMaxX; r++) {
-          act[r] = r < nx && Rw.xjar[r] < 0;
-          LUNROLL for (int j = 0; j < kLD; j++) zl[r][j] = 0;
-          LUNROLL for (int k = 0; k < kTD; k++) zt[r][k] = 0;
-          if (!(r < nx)) continue;  // (quad-uniform)
-          LCross<R> C;
-          lsh_get_cross(sh, r, C);
-          if (act[r]) { cross_vector(m, kin, C, lane, zl[r], zt[r]); arrow_solve(H, zl[r], zt[r]); }
-        }
-        LUNROLL for (int r = 0; r < kMaxX; r++) {
-          rhs[r] = 0;
-          LUNROLL for (int s = 0; s < kMaxX; s++) Sm[r][s] = r == s ? R(1) : R(0);
-          if (!(r < nx) || !act[r]) continue;
-          LCross<R> C;
-          lsh_get_cross(sh, r, C);
+        int act = 0;
+        for (int r = 0; r < nx; r++) {
           R ul[kLD], ut[kTD];
-          cross_vector(m, kin, C, lane, ul, ut);
-          LUNROLL for (int s = 0; s < kMaxX; s++) {
-            if (!(s < nx) || !act[s]) continue;
-            Sm[r][s] = arrow_dot(ul, ut, zl[s], zt[s]) + (r == s ? R(1) / Rw.xD[r] : R(0));
+          LUNROLL for (int j = 0; j < kLD; j++) ul[j] = 0;
+          LUNROLL for (int k = 0; k < kTD; k++) ut[k] = 0;
+          if (lsh_xget(sh, r, 10) < 0) {  // (quad-uniform: the row's jar is the quad's)
+            act |= 1 << r;
+            LCross<R> C;
+            lsh_get_cross(sh, r, C);
+            cross_vector(m, kin, C, lane, ul, ut);
+            rhs[r] = arrow_dot(ul, ut, hl, ht);
+            // row r of U' Z needs the earlier rows' z: S_rs = u_r . z_s (s < r), S_sr by symmetry; the diagonal after the solve
+            for (int q = 0; q < r; q++) { const R v = (act >> q) & 1 ? arrow_dot(ul, ut, zl[q], zt[q]) : R(0); Sm[r][q] = v; Sm[q][r] = v; }
+            R dl[kLD], dt[kTD];
+            LUNROLL for (int j = 0; j < kLD; j++) dl[j] = ul[j];
+            LUNROLL for (int k = 0; k < kTD; k++) dt[k] = ut[k];
+            arrow_solve(H, dl, dt);
+            Sm[r][r] = arrow_dot(ul, ut, dl, dt) + R(1) / C.D;
+            LUNROLL for (int j = 0; j < kLD; j++) zl[r][j] = dl[j];
+            LUNROLL for (int k = 0; k < kTD; k++) zt[r][k] = dt[k];
+          } else {
+            rhs[r] = 0;
+            for (int q = 0; q < r; q++) { Sm[r][q] = 0; Sm[q][r] = 0; }
+            Sm[r][r] = 1;
+            LUNROLL for (int j = 0; j < kLD; j++) zl[r][j] = 0;
+            LUNROLL for (int k = 0; k < kTD; k++) zt[r][k] = 0;
           }
-          rhs[r] = arrow_dot(ul, ut, hl, ht);
         }
-        // the small symmetric positive-definite system, in place (inactive rows: identity)
-        LUNROLL for (int j = 0; j < kMaxX; j++) {
+        // the small symmetric positive-definite system (inactive rows: identity), Gaussian elimination in place
+        for (int j = 0; j < nx; j++) {
           const R inv = R(1) / Sm[j][j];
-          LUNROLL for (int i = j + 1; i < kMaxX; i++) {
+          for (int i = j + 1; i < nx; i++) {
             const R f = Sm[i][j] * inv;
-            LUNROLL for (int k = j; k < kMaxX; k++) Sm[i][k] -= f * Sm[j][k];
+            for (int k = j; k < nx; k++) Sm[i][k] -= f * Sm[j][k];
             rhs[i] -= f * rhs[j];
           }
         }
-        LUNROLL for (int i = kMaxX - 1; i >= 0; i--) {
+        for (int i = nx - 1; i >= 0; i--) {
           R v = rhs[i];
-          LUNROLL for (int k = i + 1; k < kMaxX; k++) v -= Sm[i][k] * rhs[k];
+          for (int k = i + 1; k < nx; k++) v -= Sm[i][k] * rhs[k];
           rhs[i] = v / Sm[i][i];
         }
-        LUNROLL for (int r = 0; r < kMaxX; r++) {
-          LUNROLL for (int j = 0; j < kLD; j++) hl[j] -= rhs[r] * zl[r][j];
-          LUNROLL for (int k = 0; k < kTD; k++) ht[k] -= rhs[r] * zt[r][k];
+        for (int r = 0; r < nx; r++) {
+          const R c = rhs[r];
+          LUNROLL for (int j = 0; j < kLD; j++) hl[j] -= c * zl[r][j];
+          LUNROLL for (int k = 0; k < kTD; k++) ht[k] -= c * zt[r][k];
         }
       }
     }
+    LPROF(pa, prof_last, 11);
     R q1, q2, snorm, Msl[kLD], Mst[kTD];
     arrow_mul_s(ms, hl, ht, Msl, Mst);
     q1 = arrow_dot(hl, ht, Mal, Mat); q2 = arrow_dot(hl, ht, Msl, Mst); snorm = arrow_dot(hl, ht, hl, ht);
     const R gtol = m.tolerance * R(0.01) * sqrt(snorm) / scale;
+    LPROF(pa, prof_last, 12);
     // ---- exact line search (oracle: Newton on the derivative in a bracket, rtsafe safeguard)
     R alpha = 0;
     {
@@ -1038,14 +1126,12 @@ LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms
       LUNROLL for (int h = 0; h < 3; h++) { tx0[h] = Rw.tl_jar[h]; tv[h] = -Rw.tl_side[h] * ht[6 + h]; tD[h] = Rw.tl_side[h] != 0 ? Rw.tl_D[h] : R(0); }
       R xx0[kMaxX], xv[kMaxX], xDv[kMaxX];
       LUNROLL for (int r = 0; r < kMaxX; r++) { xx0[r] = 0; xv[r] = 0; xDv[r] = 0; }
-      if (nx > 0) {
-        LUNROLL for (int r = 0; r < kMaxX; r++) {
-          if (r >= nx) continue;
-          LCross<R> C;
-          lsh_get_cross(sh, r, C);
-          xx0[r] = Rw.xjar[r]; xv[r] = cross_value(m, kin, C, lane, VR, ht); xDv[r] = Rw.xD[r];
-        }
+      for (int r = 0; r < nx; r++) {  // (rolled: the rate of each row along the direction goes through the shared block)
+        LCross<R> C;
+        lsh_get_cross(sh, r, C);
+        lsh_xset(sh, r, 11, cross_value(m, kin, C, lane, VR, ht));
       }
+      if (nx > 0) { LUNROLL for (int r = 0; r < kMaxX; r++) if (r < nx) { xx0[r] = lsh_xget(sh, r, 10); xv[r] = lsh_xget(sh, r, 11); xDv[r] = lsh_xget(sh, r, 6); } }
       auto contact_rates = [&](const LContact<R>& C, LLine<R>& q) {
         R V[6], w[3], pv[3];
         pick3(VL, C.body, V);
@@ -1080,24 +1166,27 @@ LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms
         LUNROLL for (int r = 0; r < kMaxX; r++) { const R x = xx0[r] + a * xv[r]; const bool on = x < 0; gT += on ? xDv[r] * x * xv[r] : R(0); hT += on ? xDv[r] * xv[r] * xv[r] : R(0); }
         d1 = qd_sum(g) + gT; d2 = qd_sum(h) + hT;
       };
-      R lo = 0, hi = -1, d1, d2;
-      derivs(R(0), d1, d2);
-      d1 += q1; d2 += q2;
-      const R d10 = fabs(d1);
+      // (one call site of the derivative evaluation: the first pass is the evaluation at alpha = 0)
+      R lo = 0, hi = -1, d1 = 0, d2 = 1, d10 = 0;
       R step1 = R(1e30), step2 = R(1e30);
-      for (int ls = 0; ls < 50 && d10 >= gtol; ls++) {
-        R an = alpha - d1 / d2;
-        if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? R(0.5) * (lo + hi) : 2 * alpha + 1;
-        else if (hi >= 0 && fabs(an - alpha) > R(0.5) * step2) an = R(0.5) * (lo + hi);
-        if (an == alpha) break;
-        step2 = step1; step1 = fabs(an - alpha);
-        alpha = an;
+      for (int ls = -1; ls < 50; ls++) {
+        if (ls >= 0) {
+          R an = alpha - d1 / d2;
+          if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? R(0.5) * (lo + hi) : 2 * alpha + 1;
+          else if (hi >= 0 && fabs(an - alpha) > R(0.5) * step2) an = R(0.5) * (lo + hi);
+          if (an == alpha) break;
+          step2 = step1; step1 = fabs(an - alpha);
+          alpha = an;
+        }
         derivs(alpha, d1, d2);
+        if (pa.stamps) LPROF_COUNT(pa, 16);
         d1 += q1 + alpha * q2; d2 += q2;
+        if (ls < 0) { d10 = fabs(d1); if (!(d10 >= gtol)) break; continue; }
         if (fabs(d1) < gtol) break;
         if (d1 < 0) lo = alpha; else hi = alpha;
       }
     }
+    LPROF(pa, prof_last, 13);
     LUNROLL for (int j = 0; j < kLD; j++) al[j] += alpha * hl[j];
     LUNROLL for (int k = 0; k < kTD; k++) at[k] += alpha * ht[k];
     R dl[kLD], dt[kTD];
@@ -1109,18 +1198,48 @@ LD int newton(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms
     improvement = cost - newcost;
     cost = newcost;
     iters = iter + 1;
+    LPROF(pa, prof_last, 14);
+    if (pa.stamps) LPROF_COUNT(pa, 15);
   }
   return 0;
 }
 
+// what the solver reads of the step, and what it leaves
+template <typename R> struct LNewtonIO { R sl[kLD], st[kTD], wl[kLD], wt[kTD], qvl[kLD], qvt[kTD], al[kLD], at[kTD], fc_l[kLD], fc_t[kTD]; int iters; };
+template <typename R, class CS, class MS, class SH>
+LNOINLINE int newton(const LimbModelT<R>& m_in, int lane, const LKin<R>* kin_in, MS ms, LRows<R>* Rw_io, CS cs, int ncon, SH sh, int nx, bool have_warm,
+                     LNewtonIO<R>* io_ptr, long long* stamps) {
+  const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
+  if (!(LEXP_COPY_MASK & 2)) {
+    LNewtonIO<R>& o = *io_ptr;
+    return newton_body(m, lane, *kin_in, ms, *Rw_io, cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, o.al, o.at, o.fc_l, o.fc_t, o.iters, stamps);
+  }
+  LKin<R> kin;
+  LPRV_LOAD(kin, kin_in);
+  LRows<R> Rw;
+  LPRV_LOAD(Rw, Rw_io);
+  LNewtonIO<R> io;
+  LPRV_LOAD(io, io_ptr);
+  const int rc = newton_body(m, lane, kin, ms, Rw, cs, ncon, sh, nx, io.sl, io.st, io.wl, io.wt, have_warm, io.qvl, io.qvt, io.al, io.at, io.fc_l, io.fc_t, io.iters, stamps);
+  LPRV_STORE(io_ptr, io);
+  return rc;
+}
+
 // ---------------------------------------------------------------- mj_Euler with implicit joint damping, then mj_advance (oracle o_euler)
+template <typename R> struct LEulerIn { R fs_l[kLD], fs_t[kTD], al[kLD], at[kTD], fc_l[kLD], fc_t[kTD]; };
 template <typename R, class MS>
-LD void euler(const LimbModelT<R>& m, int lane, LState<R>& S, const LDyn<R>& D, const MS& ms, const R* al, const R* at, const R* fc_l, const R* fc_t) {
+LNOINLINE void euler(const LimbModelT<R>& m_in, int lane, LState<R>* S_io, const LEulerIn<R>* in_ptr, MS ms) {
+  const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
   const LimbT<R>& L = m.limb[lane];
+  LState<R> S;
+  LPRV_LOAD(S, S_io);
+  LEulerIn<R> in;
+  LPRV_LOAD(in, in_ptr);
+  const R* al = in.al; const R* at = in.at;
   const R h = m.timestep;
   R ql[kLD], qt[kTD];
-  LUNROLL for (int j = 0; j < kLD; j++) ql[j] = D.fs_l[j] + fc_l[j];
-  LUNROLL for (int k = 0; k < kTD; k++) qt[k] = D.fs_t[k] + fc_t[k];
+  LUNROLL for (int j = 0; j < kLD; j++) ql[j] = in.fs_l[j] + in.fc_l[j];
+  LUNROLL for (int k = 0; k < kTD; k++) qt[k] = in.fs_t[k] + in.fc_t[k];
   Arrow<R> A;
   load_arrow(ms, A);
   LUNROLL for (int j = 0; j < kLD; j++) A.l[tri(j, j)] += h * L.jnt[j].damping;
@@ -1144,12 +1263,13 @@ LD void euler(const LimbModelT<R>& m, int lane, LState<R>& S, const LDyn<R>& D, 
   }
   LUNROLL for (int hh = 0; hh < 3; hh++) S.tq[7 + hh] += h * S.tv[6 + hh];
   S.time += h;
+  LPRV_STORE(S_io, S);
 }
 
 // ---------------------------------------------------------------- the tracking residual and its cost (oracle humanoid_track_residual, ocost_value)
 // mjpc::Norm value per entry (every norm of this task class is a sum over entries: limb_model.h checks): quadratic, cosh, power loss,
 // smooth abs, smooth abs 2, rectify
-template <typename R> LD R norm_entry(R x, int type, R p, R q) {
+template <typename R> LNOINLINE R norm_entry(R x, int type, R p, R q) {
   switch (type) {
     case 0: return R(0.5) * x * x;
     case 3: return p * p * (cosh(x / p) - R(1));
@@ -1162,8 +1282,17 @@ template <typename R> LD R norm_entry(R x, int type, R p, R q) {
 }
 // writes the lane's entries of residual row `rs` (nullptr: cost only) and returns the step's cost (the same in the four lanes)
 template <typename R, class T>
-LD R residual_cost(const LimbModelT<R>& m, const LTask<R>& tk, int lane, const LState<R>& S, const R* ctrl, const R* tctrl, const LSense<R>& f, T* rs) {
+LNOINLINE R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, const LSense<R>* f_in, T* rs) {
+  const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
   const LimbT<R>& L = m.limb[lane];
+  LTask<R> tk;
+  LPRV_LOAD(tk, tk_in);
+  LState<R> S;
+  LPRV_LOAD(S, S_in);
+  LSense<R> f;
+  LPRV_LOAD(f, f_in);
+  R ctrl[kLD], tctrl[3];
+  LPRV_LOADN(ctrl, ctrl_in, kLD); LPRV_LOADN(tctrl, tctrl_in, 3);
   const int nj = m.nv - 6, nu = m.nu, c0 = nj + nu;
   R cost = 0;
   auto entry = [&](int idx, R x) {
@@ -1248,26 +1377,6 @@ LD double bernoulli_uniform(uint64_t seed, uint32_t cand, uint32_t iter) {
   return u53(o[0], o[1]);
 }
 
-// the rollout request (RolloutArgs<T> of rollout_lane.h, flattened so that the CPU emulator can fill it too)
-template <typename R> struct LArgs {
-  int N, H, P, interp;
-  const R* node_times;  // P
-  R* nodes;             // [P][nu][N]
-  const R* nominal;     // [P][nu]
-  int noise_mode;       // -1: candidates given in `nodes`
-  uint64_t seed; uint32_t iteration;
-  int candidate_offset, nominal_candidate, explore_count;
-  double std0, std1;
-  const double* param_variance;
-  R *states, *actions, *times, *residual, *costs, *trace;  // [candidate][step][field]
-  double* total_return;
-  int* failure;
-  int cpw;              // candidates per wavefront (1, 2, 4, 8, 16; 0 = 16)
-  long long* stamps;    // nullptr, or 32 counters: phase cycles of wavefront 0 (tuning aid)
-  int* iters;           // nullptr, or [N]: Newton iterations summed over the steps (tuning aid)
-};
-constexpr int kLFallback = 0x40000000;  // failure[] marker of a candidate handed on (= kQFallback of quad_abi.h: tree_kernel.h's mode bit 32 reads it)
-
 // One lane's share of one candidate's rollout. `state0` = qpos[nq] qvel[nv] of the plan (Planner::SetState). Returns the flag bits (0:
 // rolled out; otherwise failure[cand] carries kLFallback and the wavefront-per-candidate kernel takes the candidate over).
 template <typename R, class CS, class MS, class SH>
@@ -1321,6 +1430,8 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
   LUNROLL for (int j = 0; j < kLD; j++) ctrl[j] = 0;
   LUNROLL for (int h = 0; h < 3; h++) tctrl[h] = 0;
   int flags = 0, flag_step = 0, iters_total = 0;
+  long long prof_last = 0;
+  LPROF(a, prof_last, -1);
   for (int t = 0; t < H; t++) {
     flag_step = t;
     const bool last = t == H - 1;
@@ -1369,13 +1480,16 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
       LUNROLL for (int j = 0; j < kLD; j++) bad |= lbad(S.lq[j]) || lbad(S.lv[j]);
     }
     if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
+    LPROF(a, prof_last, 0);
     LDyn<R> D;
     LSense<R> f;
-    flags = forward_smooth(m, lane, S, ctrl, tctrl, cs, ms, sh, D, f);
+    LPOISON(D); LPOISON(f);
+    flags = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, &D, &f);
     if (flags) break;
+    LPROF(a, prof_last, 1);
     // the sensor stage (residual, cost, traces) does not depend on the constraint solve: evaluated and recorded first
     R* rs = a.residual + ((size_t)cand * H + t) * m.nr;
-    const R cost = residual_cost(m, tk, lane, S, ctrl, tctrl, f, rs);
+    const R cost = residual_cost(m, &tk, lane, &S, ctrl, tctrl, &f, rs);
     {
       R* st = a.states + ((size_t)cand * H + t) * ds;
       R* ac = a.actions + ((size_t)cand * H + t) * nu;
@@ -1391,16 +1505,26 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
           LUNROLL for (int k = 0; k < 3; k++) LREC(a.trace[((size_t)cand * H + t) * 3 * m.ntrace + 3 * q + k], f.trace[q][k]);
     }
     total += (double)cost;
+    LPROF(a, prof_last, 2);
     if (last) break;  // (the last step's mj_forward only feeds the sensor stage)
-    R al[kLD], at[kTD], fc_l[kLD], fc_t[kTD];
-    int iters = 0;
-    flags = newton(m, lane, D.kin, ms, D.rows, cs, D.ncon, sh, D.nx, D.sl, D.st, S.wl, S.wt, t > 0, S.lv, S.tv, al, at, fc_l, fc_t, iters);
+    LNewtonIO<R> io;
+    LPOISON(io);
+    LUNROLL for (int j = 0; j < kLD; j++) { io.sl[j] = D.sl[j]; io.wl[j] = S.wl[j]; io.qvl[j] = S.lv[j]; io.al[j] = 0; io.fc_l[j] = 0; }
+    LUNROLL for (int k = 0; k < kTD; k++) { io.st[k] = D.st[k]; io.wt[k] = S.wt[k]; io.qvt[k] = S.tv[k]; io.at[k] = 0; io.fc_t[k] = 0; }
+    io.iters = 0;
+    flags = newton(m, lane, &D.kin, ms, &D.rows, cs, D.ncon, sh, D.nx, t > 0, &io, a.stamps);
     if (flags) break;
-    iters_total += iters;
-    LUNROLL for (int j = 0; j < kLD; j++) bad |= lbad(al[j]);
-    LUNROLL for (int k = 0; k < kTD; k++) bad |= lbad(at[k]);
+    LPROF(a, prof_last, 3);
+    iters_total += io.iters;
+    LUNROLL for (int j = 0; j < kLD; j++) bad |= lbad(io.al[j]);
+    LUNROLL for (int k = 0; k < kTD; k++) bad |= lbad(io.at[k]);
     if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
-    euler(m, lane, S, D, ms, al, at, fc_l, fc_t);
+    LEulerIn<R> ei;
+    LPOISON(ei);
+    LUNROLL for (int j = 0; j < kLD; j++) { ei.fs_l[j] = D.fs_l[j]; ei.al[j] = io.al[j]; ei.fc_l[j] = io.fc_l[j]; }
+    LUNROLL for (int k = 0; k < kTD; k++) { ei.fs_t[k] = D.fs_t[k]; ei.at[k] = io.at[k]; ei.fc_t[k] = io.fc_t[k]; }
+    euler(m, lane, &S, &ei, ms);
+    LPROF(a, prof_last, 4);
   }
 #undef LNODE
   if (lane == 0) {

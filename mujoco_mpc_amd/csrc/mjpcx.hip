@@ -20,6 +20,7 @@
 #include "ilqg_dense.h"
 #include "rollout_wave.h"
 #include "quad_launch.h"
+#include "limb_launch.h"
 #include "wave32_launch.h"
 #include <type_traits>
 #include <dlfcn.h>
@@ -111,6 +112,9 @@ const KernelEntry kTreeEntryHumanoid = {"rollout_tree_kernel<Humanoid> (register
                                          "Jacobian-free Newton contact solver: pyramidal cones, tendon limits)", TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 const KernelEntry kQuadEntryA1 = {"rollout_quad_kernel (four lanes per candidate, one per leg: 16 candidates per wavefront, arrowhead Newton contact solver; "
                                    "candidates it hands on run rollout_tree_kernel<A1>)", TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+const KernelEntry kLimbEntryHumanoid = {"rollout_limb_kernel (four lanes per candidate, one per limb: up to 16 candidates per wavefront, arrowhead Newton contact solver with "
+                                         "Woodbury terms for contacts between moving geoms; candidates it hands on run rollout_tree_kernel<Humanoid>)",
+                                         TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 const KernelEntry kWaveEntry = {"rollout_wave_kernel (wavefront per candidate, model in LDS/L1; Newton contact solver)",
                                 TopoKey{}, TaskKey{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -373,6 +377,15 @@ struct mjpcx_ctx {
   bool no_quad_feedback = false;  // MJPCX_NO_QUAD_FEEDBACK=1: the iLQG rollouts stay on the wavefront-per-candidate kernel (A/B runs, tests)
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
+  // limb kernel (limb_kernel.h): four lanes per candidate, one per limb of the Humanoid class limb_build accepts. fp32 contexts (the precision
+  // configs[3] is quoted in) by default; fp64 contexts with MJPCX_LIMB_F64=1 (parity tests at the oracle's precision)
+  bool limb_ok = false;       // MJPCX_NO_LIMB=1 keeps the wavefront-per-candidate kernel (A/B runs)
+  int limb_min_n = 512;       // batches below this go to rollout_tree_kernel<Humanoid> (MJPCX_LIMB_MIN_N)
+  int limb_cpw = 0;           // candidates per wavefront (0: chosen from the batch size; MJPCX_LIMB_CPW)
+  bool limb_no_fallback = false;  // MJPCX_LIMB_NO_FALLBACK=1: leave the handed-on candidates flagged (tuning)
+  std::string limb_why;       // why limb_build declined
+  int limb_ids[32];           // residual_int[2..33] the limb model was built for (tracking sites, mocap bodies)
+  DevBuf d_limb;              // the model image in the context's precision
   int quad_ids[7] = {0, 0, 0, 0, 0, 0, 0};  // residual_int[1..7] the quad model was built for (torso, head site, goal mocap, feet)
   DevBuf d_qmodel, d_qtab, d_qstats, d_qstamps, d_qwave, d_qovf, d_qclass;
   void* h_qstats = nullptr;       // pinned copy of d_qstats (whether the hand-on pass has anything to do)
@@ -725,6 +738,64 @@ hipError_t launch_quad(mjpcx_ctx* c, const WaveModel& wm, const WaveTask& wt, co
   return e;
 }
 
+// limb kernel (limb_kernel.h), then the wavefront-per-candidate kernel for the candidates it handed on
+template <typename T>
+hipError_t launch_limb(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>& wt, const RolloutArgs<T>& a, int N, int P) {
+  limb::LArgs<T> q{};
+  q.N = a.N; q.H = a.H; q.P = a.P; q.interp = a.interp; q.node_times = a.node_times; q.nodes = a.nodes; q.nominal = a.nominal;
+  q.noise_mode = a.noise.mode; q.seed = a.noise.seed; q.iteration = a.noise.iteration; q.candidate_offset = a.noise.candidate_offset;
+  q.nominal_candidate = a.noise.nominal_candidate; q.explore_count = a.noise.explore_count; q.std0 = a.noise.std0; q.std1 = a.noise.std1;
+  q.param_variance = a.noise.param_variance;
+  q.states = a.states; q.actions = a.actions; q.times = a.times; q.residual = a.residual; q.costs = a.costs; q.trace = a.trace;
+  q.total_return = a.total_return; q.failure = a.failure; q.cpw = c->limb_cpw;
+  const limb::LBlob bo{wt.off_time, wt.off_mocap, wt.off_weight, wt.off_normp, wt.off_normq, wt.off_param, wt.off_risk, wt.off_rreal, wt.off_rint};
+  hipError_t e;
+  if ((e = hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream)) != hipSuccess) return e;  // (how many candidates are handed on, by reason: mjpcx_quad_stats)
+  static const bool stamps = getenv("MJPCX_LIMB_STAMPS") != nullptr;  // (tuning aid: phase cycles of wavefront 0, Newton iterations; synchronises every rollout)
+  if (stamps) {
+    if ((e = c->d_qstamps.reserve(512)) != hipSuccess || (e = hipMemsetAsync(c->d_qstamps.p, 0, 512, c->stream)) != hipSuccess) return e;
+    q.stamps = (long long*)c->d_qstamps.p;
+    if ((e = c->d_qwave.reserve((size_t)N * 4)) != hipSuccess) return e;
+    q.iters = (int*)c->d_qwave.p;
+  }
+  if ((e = limb::launch_rollout_limb(c->d_limb.p, wt.blob, bo, q, wm.key_mpos, (int*)c->d_qstats.p, c->stream)) != hipSuccess) return e;
+  if (stamps) {
+    long long h[32];
+    std::vector<int> it((size_t)N);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h, c->d_qstamps.p, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(it.data(), c->d_qwave.p, (size_t)N * 4, hipMemcpyDeviceToHost);
+    long long sum = 0; int mx = 0;
+    for (int v : it) { sum += v; mx = v > mx ? v : mx; }
+    std::fprintf(stderr, "rollout_limb_kernel cycles of wavefront 0 (H = %d): policy %lld forward %lld residual+record %lld newton %lld euler %lld | Newton iterations per candidate-step %.2f (most over a rollout: %d)\n",
+                 a.H, h[0], h[1], h[2], h[3], h[4], (double)sum / ((double)N * (a.H > 1 ? a.H - 1 : 1)), mx);
+    std::fprintf(stderr, "  newton: setup %lld | per iteration (the wavefront ran %lld): hessian %lld factor+solve %lld woodbury %lld mul+dots %lld linesearch %lld update+eval %lld\n",
+                 h[8], h[15], h[9], h[10], h[11], h[12], h[13], h[14]);
+    std::fprintf(stderr, "  line-search derivative evaluations of candidate 0: %lld\n", h[16]);
+  }
+  if (c->timing && c->cur_main) { if ((e = hipEventRecord(c->cur_main, c->stream)) == hipSuccess) c->cur_main = nullptr; else return e; }
+  if (c->limb_no_fallback) return hipSuccess;
+  if (!c->quad_stats) {  // the count of hand-ons comes back first: nothing handed on (the usual case) -> no second launch
+    if (!c->h_qstats && hipHostMalloc(&c->h_qstats, 32, hipHostMallocDefault) != hipSuccess) c->h_qstats = nullptr;
+    if (c->h_qstats) {
+      if ((e = hipMemcpyAsync(c->h_qstats, c->d_qstats.p, 32, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+      if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+      if (static_cast<const int*>(c->h_qstats)[0] == 0) return hipSuccess;
+    }
+  }
+  RolloutArgs<T> a2 = a;
+  a2.noise.mode = -1;  // the limb kernel left every candidate's spline nodes in a.nodes
+  e = launch_tree<TreeCfgHumanoid, T>(c, wm, wt, a2, sizeof(T) == 8 ? c->wh.dev_image : c->wh.dev_image32, sizeof(T) == 8 ? c->wh.blob_bytes : c->wh.blob_bytes32, N, P, /*only_flagged=*/true);
+  if (e == hipSuccess && c->quad_stats) {
+    int h[8] = {0};
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h, c->d_qstats.p, 32, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "rollout_limb_kernel: %d of %d candidates handed to rollout_tree_kernel (floor contact list full %d, more moving-geom contacts than slots %d, "
+                 "indefinite matrix %d, non-finite %d, both limits %d, trunk on the floor %d)\n", h[0], N, h[1], h[2], h[3], h[4], h[5], h[6]);
+  }
+  return e;
+}
+
 template <typename T>
 int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node_times,
                const double* node_values, const double* nominal, const mjpcx_noise_spec* ns) {
@@ -809,7 +880,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
         if (c->quad_ok) (void)hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream);  // (mjpcx_quad_stats reports the LAST rollout: nothing was handed on in this one)
         le = launch_tree<TreeCfgA1, double>(c, wm, wt, a, c->wh.dev_image, c->wh.blob_bytes, N, P);
         if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
+      } else if (c->wh.registered == 1 && c->limb_ok && a.xfrc_scale == 0 && !wt.stamps && N >= c->limb_min_n) {
+        le = launch_limb<double>(c, wm, wt, a, N, P);
       } else if (c->wh.registered == 1 && wm.integrator != MJPCX_INT_RK4) {
+        if (c->limb_ok) (void)hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream);
         le = launch_tree<TreeCfgHumanoid, double>(c, wm, wt, a, c->wh.dev_image, c->wh.blob_bytes, N, P);
         if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
       } else {
@@ -866,7 +940,10 @@ int do_rollout(mjpcx_ctx* c, int N, int H, int P, int interp, const double* node
     if (c->wh.registered == 0) {
       le = launch_tree<TreeCfgA1, float>(c, wm, wt, a, c->wh.dev_image32, c->wh.blob_bytes32, N, P);
       if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
+    } else if (c->wh.registered == 1 && c->limb_ok && a.xfrc_scale == 0 && !wt.stamps && N >= c->limb_min_n) {
+      le = launch_limb<float>(c, wm, wt, a, N, P);
     } else if (c->wh.registered == 1 && wm.integrator != MJPCX_INT_RK4) {
+      if (c->limb_ok) (void)hipMemsetAsync(c->d_qstats.p, 0, 32, c->stream);
       le = launch_tree<TreeCfgHumanoid, float>(c, wm, wt, a, c->wh.dev_image32, c->wh.blob_bytes32, N, P);
       if (wt.stamps && le == hipSuccess) print_wave_stamps(c, wt.stamps, wt.stamp_step, 0, true);
     } else {
@@ -1058,6 +1135,26 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       c->kernel = &kTreeEntryHumanoid;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
+      c->quad_stats = getenv("MJPCX_QUAD_STATS") != nullptr;
+      c->limb_no_fallback = getenv("MJPCX_LIMB_NO_FALLBACK") != nullptr;
+      if (const char* e = getenv("MJPCX_LIMB_MIN_N")) c->limb_min_n = std::atoi(e);
+      if (const char* e = getenv("MJPCX_LIMB_CPW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->limb_cpw = v; }
+      if (!getenv("MJPCX_NO_LIMB") && (precision == 32 || getenv("MJPCX_LIMB_F64"))) {
+        // the limb kernel family (four lanes per candidate, one per limb): models of the class limb_build accepts
+        std::vector<unsigned char> h32, h64;
+        c->limb_why = limb::build_images(m, t, h32, h64);
+        if (c->limb_why.empty()) {
+          const std::vector<unsigned char>& img = precision == 64 ? h64 : h32;
+          if (c->d_limb.reserve(img.size()) != hipSuccess || c->d_qstats.reserve(32) != hipSuccess || hipMemset(c->d_qstats.p, 0, 32) != hipSuccess ||
+              hipMemcpy(c->d_limb.p, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            mjpcx_destroy(c);
+            return bad(MJPCX_ENOMEM, "upload of the limb kernel's model failed");
+          }
+          c->limb_ok = true;
+          c->kernel = &kLimbEntryHumanoid;
+          for (int k = 0; k < 32; k++) c->limb_ids[k] = t->residual_int[2 + k];
+        }
+      }
     }
     set_norm_params(c, t->norm_parameter);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { mjpcx_destroy(c); return bad(MJPCX_EDEVICE, "hipStreamCreate failed"); }
@@ -1183,7 +1280,7 @@ void mjpcx_destroy(mjpcx_ctx* c) {
   if (c->h_qstats) (void)hipHostFree(c->h_qstats);
   (void)mjpcx_comm_destroy(c);
   c->wh.release();
-  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_qmodel, &c->d_qtab, &c->d_qstats, &c->d_qstamps, &c->d_qwave, &c->d_qovf, &c->d_qclass, &c->d_comm_send, &c->d_comm_recv,
+  DevBuf* bufs[] = {&c->d_nodes, &c->d_in_nodes, &c->d_ilqg, &c->d_ilqg_out, &c->d_wblob, &c->d_work, &c->d_ovf, &c->d_qmodel, &c->d_qtab, &c->d_qstats, &c->d_qstamps, &c->d_qwave, &c->d_qovf, &c->d_qclass, &c->d_limb, &c->d_comm_send, &c->d_comm_recv,
                     &c->d_states, &c->d_actions, &c->d_times, &c->d_residual, &c->d_costs, &c->d_trace, &c->d_ret,
                     &c->d_fail, &c->d_sort, &c->d_stage};
   for (DevBuf* b : bufs) b->release();
@@ -1234,6 +1331,8 @@ int mjpcx_set_residual_state(mjpcx_ctx* c, const int32_t* residual_int, const do
   if (residual_int) c->wh.residual_int.assign(residual_int, residual_int + c->wh.t.nri);
   if (residual_int && c->quad_ok)  // the quad model bakes the ids Task::Reset resolves; a caller that changes them gets the generic path
     for (int k = 0; k < 7; k++) if (residual_int[1 + k] != c->quad_ids[k]) { c->quad_ok = false; c->kernel = &kTreeEntryA1; }
+  if (residual_int && c->limb_ok)  // likewise the limb model: the tracking sites and mocap bodies (the motion's first / last key may change)
+    for (int k = 0; k < 32; k++) if (residual_int[2 + k] != c->limb_ids[k]) { c->limb_ok = false; c->kernel = &kTreeEntryHumanoid; }
   if (residual_real) c->wh.residual_real.assign(residual_real, residual_real + c->wh.t.nrr);
   return MJPCX_OK;
 }
@@ -1493,7 +1592,7 @@ int mjpcx_timing_read_main(mjpcx_ctx* c, double* main_kernel_ms, int64_t* launch
 int mjpcx_quad_stats(mjpcx_ctx* c, int32_t* handed_on) {
   if (!c || !handed_on) return MJPCX_EINVAL;
   for (int k = 0; k < 8; k++) handed_on[k] = 0;
-  if (!c->quad_ok) return MJPCX_OK;
+  if (!c->quad_ok && !c->limb_ok) return MJPCX_OK;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(handed_on, c->d_qstats.p, 32, hipMemcpyDeviceToHost));

@@ -63,28 +63,34 @@ static inline bool qw_any(bool pred) { return qd_or(pred ? 1 : 0) != 0; }  // (t
 static inline void ld_sync() { (void)qd_or(0); }
 
 #define LD static inline
+#define LPOISON(x) std::memset((void*)&(x), 0xFF, sizeof(x))
 #include "../../mujoco_mpc_amd/csrc/limb_model.h"
 namespace mjpcx { namespace limb { template <typename R> struct LContact; template <typename R> struct LCross; } }
 // the lane's stores: plain arrays here (LDS on the device, limb_kernel.h)
 template <typename R> struct EmuCS { mjpcx::limb::LContact<R>* p; };
-template <typename R> struct EmuM { R l[21], b[mjpcx::limb::kLD][mjpcx::limb::kTD], t[45]; };
+template <typename R> struct EmuMData { R l[21], b[mjpcx::limb::kLD][mjpcx::limb::kTD], t[45]; };
+template <typename R> struct EmuM { EmuMData<R>* p; };  // (the stores are handles passed by value, as the device's LDS pointers are)
 template <typename R> struct EmuShared;
 template <typename R> struct EmuSH { EmuShared<R>* p; };
 template <typename R> static inline void lcs_load(const EmuCS<R>& cs, int i, mjpcx::limb::LContact<R>& c);
 template <typename R> static inline void lcs_store(EmuCS<R>& cs, int i, const mjpcx::limb::LContact<R>& c);
 template <typename R> static inline void lcs_store_jar(EmuCS<R>& cs, int i, const mjpcx::limb::LContact<R>& c);
-template <typename R> static inline R lms_l(const EmuM<R>& m, int i) { return m.l[i]; }
-template <typename R> static inline R lms_b(const EmuM<R>& m, int j, int k) { return m.b[j][k]; }
-template <typename R> static inline R lms_t(const EmuM<R>& m, int i) { return m.t[i]; }
-template <typename R> static inline void lms_set_l(EmuM<R>& m, int i, R v) { m.l[i] = v; }
-template <typename R> static inline void lms_set_b(EmuM<R>& m, int j, int k, R v) { m.b[j][k] = v; }
-template <typename R> static inline void lms_set_t(EmuM<R>& m, int i, R v) { m.t[i] = v; }
+template <typename R> static inline R lms_l(const EmuM<R>& m, int i) { return m.p->l[i]; }
+template <typename R> static inline R lms_b(const EmuM<R>& m, int j, int k) { return m.p->b[j][k]; }
+template <typename R> static inline R lms_t(const EmuM<R>& m, int i) { return m.p->t[i]; }
+template <typename R> static inline void lms_set_l(EmuM<R>& m, int i, R v) { m.p->l[i] = v; }
+template <typename R> static inline void lms_set_b(EmuM<R>& m, int j, int k, R v) { m.p->b[j][k] = v; }
+template <typename R> static inline void lms_set_t(EmuM<R>& m, int i, R v) { m.p->t[i] = v; }
 template <typename R> static inline void lsh_set_geom(EmuSH<R>& sh, int g, const R* pos, const R* axis);
 template <typename R> static inline void lsh_get_geom(const EmuSH<R>& sh, int g, R* pos, R* axis);
 template <typename R> static inline void lsh_set_cross(EmuSH<R>& sh, int r, const mjpcx::limb::LCross<R>& c);
 template <typename R> static inline void lsh_get_cross(const EmuSH<R>& sh, int r, mjpcx::limb::LCross<R>& c);
+template <typename R> static inline R lsh_xget(const EmuSH<R>& sh, int r, int f);
+template <typename R> static inline void lsh_xset(EmuSH<R>& sh, int r, int f, R v);
 #include "../../mujoco_mpc_amd/csrc/limb_step.h"
-template <typename R> struct EmuShared { R gpos[mjpcx::limb::kNG][3], gax[mjpcx::limb::kNG][3]; mjpcx::limb::LCross<R> cross[mjpcx::limb::kMaxX]; };
+template <typename R> struct EmuShared { R gpos[mjpcx::limb::kNG][3], gax[mjpcx::limb::kNG][3]; mjpcx::limb::LCross<R> cross[mjpcx::limb::kMaxX]; R xrow[mjpcx::limb::kMaxX][2]; };
+template <typename R> static inline R lsh_xget(const EmuSH<R>& sh, int r, int f) { return f == 6 ? sh.p->cross[r].D : sh.p->xrow[r][f - 10]; }
+template <typename R> static inline void lsh_xset(EmuSH<R>& sh, int r, int f, R v) { sh.p->xrow[r][f - 10] = v; }
 template <typename R> static inline void lcs_load(const EmuCS<R>& cs, int i, mjpcx::limb::LContact<R>& c) { c = cs.p[i]; }
 template <typename R> static inline void lcs_store(EmuCS<R>& cs, int i, const mjpcx::limb::LContact<R>& c) { cs.p[i] = c; }
 template <typename R> static inline void lcs_store_jar(EmuCS<R>& cs, int i, const mjpcx::limb::LContact<R>& c) { for (int k = 0; k < 4; k++) cs.p[i].jar[k] = c.jar[k]; }
@@ -167,28 +173,33 @@ int forward_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
     S.time = (R)time;
     LContact<R> con[kMaxPC];
     EmuCS<R> cs{con};
-    EmuM<R> ms;
+    EmuMData<R> msd;
+    EmuM<R> ms{&msd};
     EmuSH<R> sh{&shared};
     LDyn<R> D;
     LSense<R> f;
-    int fl = forward_smooth(m, lane, S, ctrl, tctrl, cs, ms, sh, D, f);
+    int fl = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, &D, &f);
     flags_out[lane] = fl;
     if (fl) return;
-    const R cost = residual_cost(m, b->tk, lane, S, ctrl, tctrl, f, res.data());
-    R al[kLD], at[kTD], fc_l[kLD], fc_t[kTD];
-    int iters = 0;
-    fl = newton(m, lane, D.kin, ms, D.rows, cs, D.ncon, sh, D.nx, D.sl, D.st, S.wl, S.wt, warm != nullptr, S.lv, S.tv, al, at, fc_l, fc_t, iters);
+    const R cost = residual_cost(m, &b->tk, lane, &S, ctrl, tctrl, &f, res.data());
+    LNewtonIO<R> io;
+    for (int j = 0; j < kLD; j++) { io.sl[j] = D.sl[j]; io.wl[j] = S.wl[j]; io.qvl[j] = S.lv[j]; io.al[j] = 0; io.fc_l[j] = 0; }
+    for (int k = 0; k < kTD; k++) { io.st[k] = D.st[k]; io.wt[k] = S.wt[k]; io.qvt[k] = S.tv[k]; io.at[k] = 0; io.fc_t[k] = 0; }
+    io.iters = 0;
+    fl = newton(m, lane, &D.kin, ms, &D.rows, cs, D.ncon, sh, D.nx, warm != nullptr, &io, (long long*)nullptr);
     flags_out[lane] = fl;
     if (fl) return;
+    const R* al = io.al; const R* at = io.at; const R* fc_l = io.fc_l; const R* fc_t = io.fc_t;
+    const int iters = io.iters;
     for (int j = 0; j < kLD; j++) {
       const LJointT<R>& J = L.jnt[j];
       if (!J.on) continue;
       out[J.dof] = al[j]; out[nv + J.dof] = D.fs_l[j]; out[2 * nv + J.dof] = fc_l[j];
       out[3 * nv + (size_t)nv * nv + 3 + nr + 4 + J.dof] = D.sl[j];
-      for (int i = 0; i < kLD; i++) if (L.jnt[i].on) M[(size_t)J.dof * nv + L.jnt[i].dof] = ms.l[tri(j, i)];
+      for (int i = 0; i < kLD; i++) if (L.jnt[i].on) M[(size_t)J.dof * nv + L.jnt[i].dof] = msd.l[tri(j, i)];
       for (int k = 0; k < kTD; k++) {
         const int dk = k < 6 ? k : (m.tjnt[k - 6].on ? m.tjnt[k - 6].dof : -1);
-        if (dk >= 0) M[(size_t)J.dof * nv + dk] = M[(size_t)dk * nv + J.dof] = ms.b[j][k];
+        if (dk >= 0) M[(size_t)J.dof * nv + dk] = M[(size_t)dk * nv + J.dof] = msd.b[j][k];
       }
     }
     if (lane == 0) {
@@ -197,7 +208,7 @@ int forward_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
         if (dk < 0) continue;
         out[dk] = at[k]; out[nv + dk] = D.fs_t[k]; out[2 * nv + dk] = fc_t[k];
         out[3 * nv + (size_t)nv * nv + 3 + nr + 4 + dk] = D.st[k];
-        for (int i = 0; i < kTD; i++) { const int di = i < 6 ? i : (m.tjnt[i - 6].on ? m.tjnt[i - 6].dof : -1); if (di >= 0) M[(size_t)dk * nv + di] = ms.t[tri(k, i)]; }
+        for (int i = 0; i < kTD; i++) { const int di = i < 6 ? i : (m.tjnt[i - 6].on ? m.tjnt[i - 6].dof : -1); if (di >= 0) M[(size_t)dk * nv + di] = msd.t[tri(k, i)]; }
       }
       double* o = out + 3 * nv + (size_t)nv * nv;
       for (int k = 0; k < 3; k++) o[k] = D.com[k];
@@ -252,7 +263,8 @@ int rollout_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
         run_quad([&](int lane) {
           LContact<R> con[kMaxPC];
           EmuCS<R> cs{con};
-          EmuM<R> ms;
+          EmuMData<R> msd;
+          EmuM<R> ms{&msd};
           EmuSH<R> sh{&shared};
           const int fl = rollout(b->lm, b->tk, st0.data(), (R)time, a, cand, lane, cs, ms, sh);
           if (lane == 0 && flags) flags[cand] = fl;
