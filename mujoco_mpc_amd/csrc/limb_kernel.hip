@@ -45,6 +45,7 @@ static hipError_t launch(const void* image, const R* blob, const LBlob& bo, cons
   LArgs<R> q = a;
   q.cpw = pick_cpw(a.N, a.cpw);
   // up to eight candidates per wavefront: the half-width layout (half the LDS per wavefront: four wavefronts per CU)
+  if (q.cpw <= 4) return launch_ls<R, 16>(image, blob, bo, q, key_mpos, stats, stream);
   if (q.cpw <= 8) return launch_ls<R, 32>(image, blob, bo, q, key_mpos, stats, stream);
   return launch_ls<R, 64>(image, blob, bo, q, key_mpos, stats, stream);
 }

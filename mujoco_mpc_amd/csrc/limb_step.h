@@ -64,6 +64,9 @@
 #define LEXP_GFLOOR 16   // (multiples of the working precision's epsilon: see the Newton loop's floors)
 #define LEXP_CFLOOR 8
 #endif
+#ifndef LEXP_LFLOOR
+#define LEXP_LFLOOR 16
+#endif
 #ifndef LPROF
 #define LPROF(a, last, idx)   // phase cycle stamps of wavefront 0 (the device build: limb_kernel.h)
 #define LPROF_COUNT(a, idx)
@@ -1182,7 +1185,10 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const M
         if (pa.stamps) LPROF_COUNT(pa, 16);
         d1 += q1 + alpha * q2; d2 += q2;
         if (ls < 0) { d10 = fabs(d1); if (!(d10 >= gtol)) break; continue; }
-        if (fabs(d1) < gtol) break;
+        // (the tolerance, or the working precision's floor under it: a derivative that is the rounding residue of its start value -- its terms
+        // cancel at the minimum -- cannot be reduced further. In float the tolerance lies below that floor and the search would otherwise run
+        // until its steps stop moving alpha: nine evaluations per search instead of three)
+        if (fabs(d1) < gtol || fabs(d1) <= LEXP_LFLOOR * kEps<R>() * d10) break;
         if (d1 < 0) lo = alpha; else hi = alpha;
       }
     }

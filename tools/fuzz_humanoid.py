@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Random-state parity sweep of the Humanoid tracking task's kernel (rollout_tree_kernel<Humanoid>, fp64) against the oracle (run on
-the GPU box): every motion of the clip set at a random time, joints and velocities perturbed around the clip's pose (every third case
+"""Random-state parity sweep of the Humanoid tracking task's kernels against the oracle (run on the GPU box) --
+    python tools/fuzz_humanoid.py [cases] [seed] [precision] [kernel]      kernel: tree (rollout_tree_kernel<Humanoid>, the default) | limb
+(rollout_limb_kernel, four lanes per candidate: candidates it does not cover are handed to the tree kernel, so every rollout is compared) --: every motion of the clip set at a random time, joints and velocities perturbed around the clip's pose (every third case
 far: folded limbs, self-collision, tendon limits), controls of every size. Agreement is judged over the first steps at 1e-9 -- the
 chaotic humanoid amplifies rounding differences by orders of magnitude over 40 steps, which is reported but not asserted -- and on the
 failure flags."""
@@ -17,6 +18,12 @@ def mocap7(mpos):
 
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "tree"
+if KERNEL == "limb":
+    os.environ["MJPCX_LIMB_MIN_N"] = "0"
+    os.environ["MJPCX_LIMB_F64"] = "1"
+else:
+    os.environ["MJPCX_NO_LIMB"] = "1"
 PREC = int(sys.argv[3]) if len(sys.argv) > 3 else 64   # 32: the fp32 kernel of configs[3] against the fp64 oracle (first steps at 1e-3, returns reported)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t = load_task("HumanoidTrack")
@@ -31,7 +38,8 @@ for case in range(cases):
     e = t.transition(time, mode=mode)     # the reference at `time`: mocap targets between two keyframes
     pm, pt = t.packed_model(), t.packed()
     ctx = capi.Context(pm, pt, 0, PREC)   # (the task's per-mode residual state is part of the context)
-    assert "rollout_tree_kernel<Humanoid>" in ctx.kernel_name
+    assert ("rollout_limb_kernel" if KERNEL == "limb" else "rollout_tree_kernel<Humanoid>") in ctx.kernel_name
+    handed = 0
     q = np.array(e0["qpos"], float)
     far = case % 3 == 2
     q[7:] += rng.normal(0, 0.6 if far else 0.1, q.size - 7)
@@ -49,6 +57,9 @@ for case in range(cases):
     ctx.set_state(state, time, mocap)
     ctx.rollout_splines(H, interp, times, nodes)
     ret, fail = ctx.returns()
+    if KERNEL == "limb":
+        handed = ctx.quad_stats()["handed_on"]
+        handed_total = globals().get("handed_total", 0) + handed
     ref = pyoracle.rollout_batch(pm, pt, state, time, mocap, N, H, P, interp, times, nodes, num_threads=8)
     if PREC == 64:
         assert np.array_equal(np.asarray(fail, bool), np.asarray(ref["failure"], bool)), (case, fail, ref["failure"])
@@ -71,6 +82,8 @@ for case in range(cases):
         okc = ~fail
         print(f"case {case:3d}: 40-step state error {e_all:.2e}; returns device / oracle: " + " ".join(f"{a:.4g}/{b:.4g}" for a, b in zip(ret[okc], ref["total_return"][okc])), flush=True)
     if bad or case % 5 == 0:
-        print(f"case {case:3d}: mode {mode:2d} t = {time:.2f} {'far ' if far else 'near'} interp {interp} P = {P} flagged {int(np.asarray(fail, bool).sum())}  first 4 steps {e_first:.2e}  40 steps {e_all:.2e}{'   <-- beyond tolerance' if bad else ''}", flush=True)
-print(f"{cases} cases x 8 candidates: worst over the first 4 steps {worst_first:.3e} (median {np.median(all_first):.2e}), over 40 steps {worst_all:.3e}, flagged rollouts (same on both sides) {flagged}")
+        print(f"case {case:3d}: mode {mode:2d} t = {time:.2f} {'far ' if far else 'near'} interp {interp} P = {P} flagged {int(np.asarray(fail, bool).sum())} handed on {handed}  first 4 steps {e_first:.2e}  40 steps {e_all:.2e}{'   <-- beyond tolerance' if bad else ''}", flush=True)
+if KERNEL == "limb":
+    print(f"rollout_limb_kernel handed {globals().get('handed_total', 0)} of {8 * cases} rollouts to rollout_tree_kernel<Humanoid>")
+print(f"{cases} cases x 8 candidates ({KERNEL} kernel, fp{PREC}): worst over the first 4 steps {worst_first:.3e} (median {np.median(all_first):.2e}), over 40 steps {worst_all:.3e}, flagged rollouts (same on both sides) {flagged}")
 assert worst_first < TOL
