@@ -1306,14 +1306,16 @@ LNOINLINE R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, int 
     cost += tk.weight[t] * norm_entry(x, m.term_norm[t], tk.norm_p[t], tk.norm_q[t]);
     if (rs) LREC(rs[idx], (T)x);
   };
-  LUNROLL for (int j = 0; j < kLD; j++) {
+  // (ROLLED loops over the joints and the sites, their data read from memory at run time: one instance of an entry's code per kind instead
+  // of forty-five)
+  for (int j = 0; j < kLD; j++) {
     const LJointT<R>& J = L.jnt[j];
     if (!J.on) continue;
     entry(J.dof - 6, S.lv[j]);
     if (J.act >= 0) entry(nj + J.act, ctrl[j]);
   }
   if (L.owns_trunk_rows) {
-    LUNROLL for (int h = 0; h < 3; h++) {
+    for (int h = 0; h < 3; h++) {
       const LJointT<R>& J = m.tjnt[h];
       if (!J.on) continue;
       entry(J.dof - 6, S.tv[6 + h]);
@@ -1328,29 +1330,31 @@ LNOINLINE R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, int 
   const int k0 = (int)floor(clamped);
   const int k1 = k0 + 1 < last ? k0 + 1 : last;
   const R w1 = clamped - R(k0), w0 = R(1) - w1;
-  R mp[kLS][3], dv[kLS][3], am[3] = {0, 0, 0}, as[3] = {0, 0, 0};
-  LUNROLL for (int s = 0; s < kLS; s++) {
+  R am[3] = {0, 0, 0}, as[3] = {0, 0, 0};
+  for (int s = 0; s < kLS; s++) {
     const LSiteT<R>& St = L.site[s];
-    LUNROLL for (int k = 0; k < 3; k++) { mp[s][k] = 0; dv[s][k] = 0; }
     if (!St.on) continue;
     const R* key0 = tk.key_mpos + ((size_t)m.nmocap * k0 + St.mocap) * 3;
     const R* key1 = tk.key_mpos + ((size_t)m.nmocap * k1 + St.mocap) * 3;
     LUNROLL for (int k = 0; k < 3; k++) {
       R v = key0[k] * w0;
       v += key1[k] * w1;
-      mp[s][k] = v;
-      dv[s][k] = (key1[k] - key0[k]) * kFps - f.svel[s][k];
       am[k] += v; as[k] += f.spos[s][k];
     }
   }
   LUNROLL for (int k = 0; k < 3; k++) { am[k] = qd_sum(am[k]) * (R(1) / 16); as[k] = qd_sum(as[k]) * (R(1) / 16); }
-  if (L.owns_trunk_rows) { LUNROLL for (int k = 0; k < 3; k++) entry(c0 + k, am[k] - as[k]); }
-  LUNROLL for (int s = 0; s < kLS; s++) {
+  if (L.owns_trunk_rows) { for (int k = 0; k < 3; k++) entry(c0 + k, k == 0 ? am[0] - as[0] : (k == 1 ? am[1] - as[1] : am[2] - as[2])); }
+  for (int s = 0; s < kLS; s++) {
     const LSiteT<R>& St = L.site[s];
     if (!St.on) continue;
-    LUNROLL for (int k = 0; k < 3; k++) {
-      entry(c0 + 3 + 3 * St.marker + k, (mp[s][k] - am[k]) - (f.spos[s][k] - as[k]));
-      entry(c0 + 51 + 3 * St.marker + k, dv[s][k]);
+    const R* key0 = tk.key_mpos + ((size_t)m.nmocap * k0 + St.mocap) * 3;
+    const R* key1 = tk.key_mpos + ((size_t)m.nmocap * k1 + St.mocap) * 3;
+    for (int k = 0; k < 3; k++) {
+      R v = key0[k] * w0;
+      v += key1[k] * w1;
+      const R amk = k == 0 ? am[0] : (k == 1 ? am[1] : am[2]), ask = k == 0 ? as[0] : (k == 1 ? as[1] : as[2]);
+      entry(c0 + 3 + 3 * St.marker + k, (v - amk) - (f.spos[s][k] - ask));
+      entry(c0 + 51 + 3 * St.marker + k, (key1[k] - key0[k]) * kFps - f.svel[s][k]);
     }
   }
   cost = qd_sum(cost);
@@ -1435,7 +1439,7 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
   R ctrl[kLD], tctrl[3];
   LUNROLL for (int j = 0; j < kLD; j++) ctrl[j] = 0;
   LUNROLL for (int h = 0; h < 3; h++) tctrl[h] = 0;
-  int flags = 0, flag_step = 0, iters_total = 0;
+  int flags = 0, flag_step = 0, iters_total = 0, up = 0;
   long long prof_last = 0;
   LPROF(a, prof_last, -1);
   for (int t = 0; t < H; t++) {
@@ -1444,9 +1448,8 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
     bool bad = false;
     if (!last) {
       // policy: TimeSpline::Sample + Clamp (SamplingPolicy::Action, sampling/policy.cc:52-59)
-      int up = 0;
       const R now = S.time;
-      while (up < P && a.node_times[up] <= now) up++;
+      while (up < P && a.node_times[up] <= now) up++;  // (time only moves forward: the search resumes where the last step's ended)
       R mine[kLD + 3];
       LUNROLL for (int e = 0; e < kLD + 3; e++) {
         const int ua = act_of(e);

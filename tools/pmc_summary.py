@@ -79,7 +79,14 @@ m = t.packed_model().struct
 nr, ntr = t.packed().struct.num_residual, t.packed().struct.num_trace
 wsz = 8 if prec == 64 else 4
 per_rollout = wsz * (H * (m.nq + m.nv + m.nu + 1 + nr + 3 * ntr + 1) + P * m.nu + P + 2)  # == mjpcx_algorithmic_bytes
-per_wave = 16 if "rollout_quad" in name else (64 if "lane" in name else 1)
+def limb_cpw(n):   # (limb_kernel.hip pick_cpw: one wavefront per SIMD first, sixteen candidates per wavefront from 16384 on)
+    c = 1
+    while c < 16 and (n + c - 1) // c > 1024:
+        c *= 2
+    return c
+
+
+per_wave = 16 if "rollout_quad" in name else (limb_cpw(N) if "rollout_limb" in name else (64 if "lane" in name else 1))
 waves_steps = (N + per_wave - 1) // per_wave * H
 c = {k: timed(v) for k, v in per.items() if not k.startswith("_")}
 hbm = [(2 * f + w) * 1024.0 for f, w in zip(per.get("FETCH_SIZE", []), per.get("WRITE_SIZE", []))]
