@@ -82,6 +82,9 @@ template <typename R> __device__ __forceinline__ void lsh_get_cross(const mjpcx:
 #ifndef LEXP_NO_REBIND
 #define LREBIND_LDS(T, ref) (*(const T*)(const __attribute__((address_space(3))) T*)(&(ref)))
 #endif
+#ifndef LEXP_NO_REBIND_PRV
+#define LREBIND_PRV(T, ptr) ((T*)(__attribute__((address_space(5))) T*)(ptr))
+#endif
 #ifndef LEXP_NO_PRV
 #define LPRV_LOAD(dst, src) __builtin_memcpy(&(dst), (const __attribute__((address_space(5))) decltype(dst)*)(src), sizeof(dst))
 #define LPRV_STORE(dst, src) __builtin_memcpy((__attribute__((address_space(5))) decltype(src)*)(dst), &(src), sizeof(src))

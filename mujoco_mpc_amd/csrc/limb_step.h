@@ -48,6 +48,9 @@
 #ifndef LREBIND_LDS
 #define LREBIND_LDS(T, ref) (ref)
 #endif
+#ifndef LREBIND_PRV
+#define LREBIND_PRV(T, ptr) (ptr)   // a pointer to a caller's local: the device build says it is private memory (scratch_ instead of FLAT accesses)
+#endif
 #ifndef LPRV_LOAD
 #define LPRV_LOAD(dst, src) (dst) = *(src)
 #define LPRV_STORE(dst, src) *(dst) = (src)
@@ -55,7 +58,13 @@
 #define LPRV_STOREN(dst, src, n) do { for (int i_ = 0; i_ < (n); i_++) (dst)[i_] = (src)[i_]; } while (0)
 #endif
 #ifndef LEXP_COPY_MASK
-#define LEXP_COPY_MASK 0   // (which out-of-line stages copy their arguments in and out: 1 forward, 2 newton, 4 euler, 8 residual. The forward stage works on the caller's structs directly: with the copies its device build produced wrong states -- the emulator did not -- and they save nothing there, 300 accesses in a 30 k-instruction stage)
+#define LEXP_COPY_MASK 16
+// Which out-of-line stages copy what they get by pointer into locals (bits: 1 forward, 2 newton: everything, 4 euler, 8 residual, 16 newton: only
+// what it WRITES -- the rows' jar, the iterate, J' force: a read-modify-write through the caller's memory waits for its own store every time,
+// while what is only read (dof axes, qacc_smooth) is served by the vector L1). Measured on MI355X, Humanoid 8192 x 64 fp32, same box: no
+// copies 23.7 ms; 16: 23.1; 2 | 4 | 8: 44.2 (164 spilled registers instead of 38). The forward stage always works on the caller's structs:
+// with copies its DEVICE build produced wrong states (the emulator's did not; not understood), and they would save 300 accesses in 30 k
+// instructions.
 #endif
 #ifndef LPOISON
 #define LPOISON(x)   // (the emulator fills fresh locals with NaN patterns: a read before a write shows)
@@ -790,9 +799,12 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
 }
 
 template <typename R, class CS, class MS, class SH>
-LNOINLINE int forward_smooth(const LimbModelT<R>& m_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, CS cs, MS ms, SH sh, LDyn<R>* D_out, LSense<R>* out_out) {
+LNOINLINE int forward_smooth(const LimbModelT<R>& m_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, CS cs, MS ms, SH sh,
+                             LDyn<R>* D_out, LSense<R>* out_out) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
-  if (!(LEXP_COPY_MASK & 1)) return forward_smooth_body(m, lane, *S_in, ctrl_in, tctrl_in, cs, ms, sh, *D_out, *out_out);
+  if (!(LEXP_COPY_MASK & 1))
+    return forward_smooth_body(m, lane, *LREBIND_PRV(const LState<R>, S_in), LREBIND_PRV(const R, ctrl_in), LREBIND_PRV(const R, tctrl_in), cs, ms, sh,
+                               *LREBIND_PRV(LDyn<R>, D_out), *LREBIND_PRV(LSense<R>, out_out));
   LState<R> S;
   LPRV_LOAD(S, S_in);
   R ctrl[kLD], tctrl[3];
@@ -1212,13 +1224,31 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const M
 
 // what the solver reads of the step, and what it leaves
 template <typename R> struct LNewtonIO { R sl[kLD], st[kTD], wl[kLD], wt[kTD], qvl[kLD], qvt[kTD], al[kLD], at[kTD], fc_l[kLD], fc_t[kTD]; int iters; };
+#ifndef LNEWTON_ATTR
+#define LNEWTON_ATTR LNOINLINE
+#define LEULER_ATTR LNOINLINE
+#define LRESID_ATTR LNOINLINE
+#endif
 template <typename R, class CS, class MS, class SH>
-LNOINLINE int newton(const LimbModelT<R>& m_in, int lane, const LKin<R>* kin_in, MS ms, LRows<R>* Rw_io, CS cs, int ncon, SH sh, int nx, bool have_warm,
+LNEWTON_ATTR int newton(const LimbModelT<R>& m_in, int lane, const LKin<R>* kin_in, MS ms, LRows<R>* Rw_io, CS cs, int ncon, SH sh, int nx, bool have_warm,
                      LNewtonIO<R>* io_ptr, long long* stamps) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
-  if (!(LEXP_COPY_MASK & 2)) {
-    LNewtonIO<R>& o = *io_ptr;
-    return newton_body(m, lane, *kin_in, ms, *Rw_io, cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, o.al, o.at, o.fc_l, o.fc_t, o.iters, stamps);
+  if (!(LEXP_COPY_MASK & (2 | 16))) {
+    LNewtonIO<R>& o = *LREBIND_PRV(LNewtonIO<R>, io_ptr);
+    return newton_body(m, lane, *LREBIND_PRV(const LKin<R>, kin_in), ms, *LREBIND_PRV(LRows<R>, Rw_io), cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, o.al, o.at, o.fc_l, o.fc_t, o.iters, stamps);
+  }
+  if (LEXP_COPY_MASK & 16) {
+    // what the solver WRITES lives in registers for the call (the rows' jar, the iterate, J' force: a read-modify-write through the caller's
+    // memory waits for its own store every time); what it only reads (the dof axes, qacc_smooth, the warm start) stays where it is
+    LRows<R> Rw;
+    LPRV_LOAD(Rw, Rw_io);
+    const LNewtonIO<R>& o = *io_ptr;
+    R al[kLD], at[kTD], fc_l[kLD], fc_t[kTD];
+    int iters = 0;
+    const int rc = newton_body(m, lane, *kin_in, ms, Rw, cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, al, at, fc_l, fc_t, iters, stamps);
+    LPRV_STOREN(io_ptr->al, al, kLD); LPRV_STOREN(io_ptr->at, at, kTD); LPRV_STOREN(io_ptr->fc_l, fc_l, kLD); LPRV_STOREN(io_ptr->fc_t, fc_t, kTD);
+    io_ptr->iters = iters;
+    return rc;
   }
   LKin<R> kin;
   LPRV_LOAD(kin, kin_in);
@@ -1234,7 +1264,7 @@ LNOINLINE int newton(const LimbModelT<R>& m_in, int lane, const LKin<R>* kin_in,
 // ---------------------------------------------------------------- mj_Euler with implicit joint damping, then mj_advance (oracle o_euler)
 template <typename R> struct LEulerIn { R fs_l[kLD], fs_t[kTD], al[kLD], at[kTD], fc_l[kLD], fc_t[kTD]; };
 template <typename R, class MS>
-LNOINLINE void euler(const LimbModelT<R>& m_in, int lane, LState<R>* S_io, const LEulerIn<R>* in_ptr, MS ms) {
+LEULER_ATTR void euler(const LimbModelT<R>& m_in, int lane, LState<R>* S_io, const LEulerIn<R>* in_ptr, MS ms) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
   const LimbT<R>& L = m.limb[lane];
   LState<R> S;
@@ -1288,7 +1318,7 @@ template <typename R> LNOINLINE R norm_entry(R x, int type, R p, R q) {
 }
 // writes the lane's entries of residual row `rs` (nullptr: cost only) and returns the step's cost (the same in the four lanes)
 template <typename R, class T>
-LNOINLINE R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, const LSense<R>* f_in, T* rs) {
+LRESID_ATTR R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, const LSense<R>* f_in, T* rs) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
   const LimbT<R>& L = m.limb[lane];
   LTask<R> tk;
