@@ -41,6 +41,7 @@ __device__ __forceinline__ void ld_sync() {
 namespace mjpcx { namespace limb {
 template <typename R> struct LContact;
 template <typename R> struct LCross;
+template <typename R> struct LKin;
 // LS: lanes of a wavefront that work (4 x candidates per wavefront: 64, or 32 for batches that fill the chip at eight candidates per
 // wavefront) = the stride of the per-lane arrays -- a half-filled wavefront takes half the LDS, so four of them fit a CU
 // (typed LDS pointers: ds_read / ds_write instead of FLAT accesses -- a third of the solver's memory instructions were FLAT before)
@@ -52,6 +53,12 @@ template <typename R> using lds_ptr = __attribute__((address_space(3))) R*;
 template <typename R, int LS> struct LdsCS { lds_ptr<R> p; };   // + lane
 template <typename R, int LS> struct LdsMS { lds_ptr<R> ml; lds_ptr<R> mt; };  // + lane / + quad
 template <typename R> struct LdsSH { lds_ptr<R> p; };   // the candidate's shared block
+// the dof axes about the centre of mass (limb_step.h LKin), in LDS: the limb's six per lane ([axis][component][lane]), the trunk's nine once
+// per quad. The solver reads them element by element through these proxies (kin.cdof[j][c]): until round 6 they travelled from the
+// forward stage to the solver through the private segment -- 90 stores and ~1500 FLAT loads per wavefront-step
+template <typename R, int ST> struct LdsVec { lds_ptr<R> p; __device__ __forceinline__ R operator[](int c) const { return p[c * ST]; } };
+template <typename R, int ST> struct LdsRows { lds_ptr<R> base; __device__ __forceinline__ LdsVec<R, ST> operator[](int j) const { return LdsVec<R, ST>{base + 6 * j * ST}; } };
+template <typename R, int LS> struct LdsKin { LdsRows<R, LS> cdof; LdsRows<R, LS / 4> cdofT; };
 constexpr int kShGeom = kNG * 6, kShCross = kMaxX * 12;
 constexpr int kShStride = ((kShGeom + kShCross) | 1) + 2;  // (odd: the sixteen candidates' blocks start in different banks)
 } }
@@ -64,6 +71,7 @@ template <typename R, int LS> __device__ __forceinline__ R lms_t(const mjpcx::li
 template <typename R, int LS> __device__ __forceinline__ void lms_set_l(mjpcx::limb::LdsMS<R, LS>& m, int i, R v) { m.ml[i * LS] = v; }
 template <typename R, int LS> __device__ __forceinline__ void lms_set_b(mjpcx::limb::LdsMS<R, LS>& m, int j, int k, R v) { m.ml[(21 + mjpcx::limb::kTD * j + k) * LS] = v; }
 template <typename R, int LS> __device__ __forceinline__ void lms_set_t(mjpcx::limb::LdsMS<R, LS>& m, int i, R v) { m.mt[i * (LS / 4)] = v; }
+template <typename R, int LS> __device__ __forceinline__ void lkin_store(mjpcx::limb::LdsKin<R, LS>& ks, const mjpcx::limb::LKin<R>& k);
 template <typename R> __device__ __forceinline__ void lsh_set_geom(mjpcx::limb::LdsSH<R>& sh, int g, const R* pos, const R* axis) {
 #pragma unroll
   for (int k = 0; k < 3; k++) { sh.p[6 * g + k] = pos[k]; sh.p[6 * g + 3 + k] = axis[k]; }
@@ -143,12 +151,20 @@ template <typename R> __device__ __forceinline__ void lsh_get_cross(const mjpcx:
   c.la = meta & 7; c.sa = (meta >> 3) & 3; c.lb = (meta >> 5) & 7; c.sb = (meta >> 8) & 3;
 }
 
+template <typename R, int LS> __device__ __forceinline__ void lkin_store(mjpcx::limb::LdsKin<R, LS>& ks, const mjpcx::limb::LKin<R>& k) {
+  using namespace mjpcx::limb;
+  LUNROLL for (int j = 0; j < kLD; j++) LUNROLL for (int c = 0; c < 6; c++) ks.cdof.base[(6 * j + c) * LS] = k.cdof[j][c];
+  LUNROLL for (int j = 0; j < kTD; j++) LUNROLL for (int c = 0; c < 6; c++) ks.cdofT.base[(6 * j + c) * (LS / 4)] = k.cdofT[j][c];  // (the quad's four lanes write the same values)
+}
+
 namespace mjpcx { namespace limb {
 // reals of LDS per wavefront of LS working lanes: contacts, M (limb part per lane, trunk block per quad), the candidates' shared blocks
 constexpr size_t wave_con(int LS) { return (size_t)kMaxPC * kLConRec * LS; }
 constexpr size_t wave_ml(int LS) { return (size_t)(21 + kLD * kTD) * LS; }
 constexpr size_t wave_mt(int LS) { return (size_t)45 * (LS / 4); }
-constexpr size_t wave_reals(int LS) { return wave_con(LS) + wave_ml(LS) + wave_mt(LS) + (size_t)kShStride * (LS / 4); }
+constexpr size_t wave_sh(int LS) { return (size_t)kShStride * (LS / 4); }
+constexpr size_t wave_kin(int LS) { return (size_t)6 * kLD * LS + (size_t)6 * kTD * (LS / 4); }
+constexpr size_t wave_reals(int LS) { return wave_con(LS) + wave_ml(LS) + wave_mt(LS) + wave_sh(LS) + wave_kin(LS); }
 
 // Workgroup = W wavefronts sharing one model image. stats[0]: candidates handed to the fallback kernel, stats[1 + b]: by reason bit b.
 template <typename R, int LS>
@@ -174,7 +190,9 @@ __global__ __launch_bounds__(256) void rollout_limb_kernel(const LimbModelT<R>* 
   LdsCS<R, LS> cs{wave_lds + wl};
   LdsMS<R, LS> ms{wave_lds + wave_con(LS) + wl, wave_lds + wave_con(LS) + wave_ml(LS) + quad};
   LdsSH<R> sh{wave_lds + wave_con(LS) + wave_ml(LS) + wave_mt(LS) + (size_t)quad * kShStride};
-  const int flags = rollout(sm, tk, blob, blob[bo.off_time], a, cand, lane, cs, ms, sh);
+  const lds_ptr<R> kin_lds = wave_lds + wave_con(LS) + wave_ml(LS) + wave_mt(LS) + wave_sh(LS);
+  LdsKin<R, LS> ks{LdsRows<R, LS>{kin_lds + wl}, LdsRows<R, LS / 4>{kin_lds + (size_t)6 * kLD * LS + quad}};
+  const int flags = rollout(sm, tk, blob, blob[bo.off_time], a, cand, lane, cs, ms, sh, ks);
   if (flags && lane == 0 && stats) {
     atomicAdd(stats, 1);
     LUNROLL for (int b = 0; b < 6; b++) if (flags & (1 << b)) atomicAdd(stats + 1 + b, 1);

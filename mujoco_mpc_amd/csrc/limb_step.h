@@ -115,7 +115,8 @@ template <typename R> LD void cr3(R* r, const R* a, const R* b) {
   r[0] = x; r[1] = y; r[2] = z;
 }
 template <typename R> LD R dot3(const R* a, const R* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-template <typename R> LD R dot6(const R* a, const R* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+// (generic over anything indexable: the dof axes live in the includer's store -- LDS on the device, read element by element through a proxy)
+template <class A, class B> LD auto dot6(const A& a, const B& b) -> decltype(a[0] * b[0]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
 // R I R' of a symmetric I (xx yy zz xy xz yz) -> the same six
 template <typename R> LD void rot_sym(R* res, const R* I, const R* m) {
   R t[9];  // t = m I
@@ -186,7 +187,9 @@ LD constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (
 template <typename R> LD void sym6_add_outer(R* X, R w, const R* v) {
   LUNROLL for (int p = 0; p < 6; p++) { const R wp = w * v[p]; LUNROLL for (int q = 0; q <= p; q++) X[tri(p, q)] += wp * v[q]; }
 }
-template <typename R> LD void sym6_mul(R* y, const R* X, const R* v) {
+template <typename R, class V> LD void sym6_mul(R* y, const R* X, const V& vv) {
+  R v[6];
+  LUNROLL for (int q = 0; q < 6; q++) v[q] = vv[q];
   LUNROLL for (int p = 0; p < 6; p++) { R s = 0; LUNROLL for (int q = 0; q < 6; q++) s += X[tri(p, q)] * v[q]; y[p] = s; }
 }
 
@@ -299,7 +302,7 @@ template <typename R> struct LKin { R cdof[kLD][6], cdofT[kTD][6]; };
 // spatial velocities [angular; linear about the centre of mass] of the bodies for the dof vector (xl, xt): VT the trunk bodies, VL the
 // limb's, VR the limb's relative to the trunk body it hangs on (what a contact between two moving geoms needs: the common motion never
 // enters, so nothing cancels)
-template <typename R> LD void chain_velocity(const LKin<R>& k, int attach, const R* xl, const R* xt, R VT[kTB][6], R VL[kLB][6], R VR[kLB][6]) {
+template <typename R, class KIN> LD void chain_velocity(const KIN& k, int attach, const R* xl, const R* xt, R VT[kTB][6], R VL[kLB][6], R VR[kLB][6]) {
   LUNROLL for (int c = 0; c < 6; c++) {
     R v = 0;
     LUNROLL for (int d = 0; d < 6; d++) v += k.cdofT[d][c] * xt[d];
@@ -343,8 +346,7 @@ template <typename R> struct LRows {
 
 // what the sensor stage reads
 template <typename R> struct LSense { R spos[kLS][3], svel[kLS][3], trace[kMaxTrace][3]; };
-template <typename R> struct LDyn {
-  LKin<R> kin;
+template <typename R> struct LDyn {   // (the dof axes go to the includer's store: lkin_store)
   LRows<R> rows;
   R sl[kLD], st[kTD];        // qacc_smooth
   R fs_l[kLD], fs_t[kTD];    // qfrc_smooth
@@ -366,10 +368,10 @@ template <typename R> LD void limit_row(R dist, R margin, R vel, R invw, R k, R 
 }
 
 // ---------------------------------------------------------------- mj_forward before the constraint solve
-template <typename R, class CS, class MS, class SH>
-LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S, const R* ctrl, const R* tctrl, CS& cs, MS& ms, SH& sh, LDyn<R>& D, LSense<R>& out) {
+template <typename R, class CS, class MS, class SH, class KS>
+LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S, const R* ctrl, const R* tctrl, CS& cs, MS& ms, SH& sh, KS& ks, LDyn<R>& D, LSense<R>& out) {
   const LimbT<R>& L = m.limb[lane];
-  LKin<R>& kin = D.kin;
+  LKin<R> kin;
   int flags = 0;
   // ================= kinematics (o_kinematics): the trunk chain, then the limb's chain
   R tpos[kTB][3], tmat[kTB][9], tipos[kTB][3], tanchor[3][3], taxis[3][3];
@@ -483,6 +485,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
       } else { LUNROLL for (int c = 0; c < 6; c++) kin.cdofT[6 + h][c] = 0; }
     }
   }
+  lkin_store(ks, kin);
   // ================= composite inertias -> M as an arrowhead (o_crb)
   {
     Arrow<R> M;
@@ -798,12 +801,12 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
   return flags;
 }
 
-template <typename R, class CS, class MS, class SH>
-LNOINLINE int forward_smooth(const LimbModelT<R>& m_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, CS cs, MS ms, SH sh,
+template <typename R, class CS, class MS, class SH, class KS>
+LNOINLINE int forward_smooth(const LimbModelT<R>& m_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, CS cs, MS ms, SH sh, KS ks,
                              LDyn<R>* D_out, LSense<R>* out_out) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
   if (!(LEXP_COPY_MASK & 1))
-    return forward_smooth_body(m, lane, *LREBIND_PRV(const LState<R>, S_in), LREBIND_PRV(const R, ctrl_in), LREBIND_PRV(const R, tctrl_in), cs, ms, sh,
+    return forward_smooth_body(m, lane, *LREBIND_PRV(const LState<R>, S_in), LREBIND_PRV(const R, ctrl_in), LREBIND_PRV(const R, tctrl_in), cs, ms, sh, ks,
                                *LREBIND_PRV(LDyn<R>, D_out), *LREBIND_PRV(LSense<R>, out_out));
   LState<R> S;
   LPRV_LOAD(S, S_in);
@@ -812,13 +815,13 @@ LNOINLINE int forward_smooth(const LimbModelT<R>& m_in, int lane, const LState<R
   LDyn<R> D;
   LSense<R> out;
   LPOISON(D); LPOISON(out);
-  const int flags = forward_smooth_body(m, lane, S, ctrl, tctrl, cs, ms, sh, D, out);
+  const int flags = forward_smooth_body(m, lane, S, ctrl, tctrl, cs, ms, sh, ks, D, out);
   LPRV_STORE(D_out, D); LPRV_STORE(out_out, out);
   return flags;
 }
 
 // the value J_r x of the contact between moving geoms `C` for a dof vector with relative chain velocities VR and trunk part xt
-template <typename R> LD R cross_value(const LimbModelT<R>& m, const LKin<R>& kin, const LCross<R>& C, int lane, const R VR[kLB][6], const R* xt) {
+template <typename R, class KIN> LD R cross_value(const LimbModelT<R>& m, const KIN& kin, const LCross<R>& C, int lane, const R VR[kLB][6], const R* xt) {
   R own = 0, v[6];
   if (C.la == lane) { pick3(VR, C.sa, v); own -= dot6(C.et, v); }
   if (C.lb == lane) { pick3(VR, C.sb, v); own += dot6(C.et, v); }
@@ -828,7 +831,7 @@ template <typename R> LD R cross_value(const LimbModelT<R>& m, const LKin<R>& ki
   return qd_sum(own) + tr;
 }
 // the row as a distributed vector u (ul: the lane's limb part, ut: the trunk part, replicated)
-template <typename R> LD void cross_vector(const LimbModelT<R>& m, const LKin<R>& kin, const LCross<R>& C, int lane, R* ul, R* ut) {
+template <typename R, class KIN> LD void cross_vector(const LimbModelT<R>& m, const KIN& kin, const LCross<R>& C, int lane, R* ul, R* ut) {
   LUNROLL for (int j = 0; j < kLD; j++) {
     R s = 0;
     if (C.la == lane && slot_body(j) <= C.sa) s -= dot6(C.et, kin.cdof[j]);
@@ -842,8 +845,8 @@ template <typename R> LD void cross_vector(const LimbModelT<R>& m, const LKin<R>
 // ---------------------------------------------------------------- constraint solve (oracle o_constraint_newton)
 // One pass over the candidate's rows: jar += alpha J x (x = (xl, xt)), then the penalty at jar: returns the cost of ALL rows (the same in
 // the four lanes), J' force in jl (the lane's limb dofs) / jt (trunk dofs, replicated).
-template <typename R, class CS, class SH>
-LD R rows_eval(const LimbModelT<R>& m, const LimbT<R>& L, int lane, const LKin<R>& kin, LRows<R>& Rw, CS& cs, int ncon, SH& sh, int nx, bool step,
+template <typename R, class CS, class SH, class KIN>
+LD R rows_eval(const LimbModelT<R>& m, const LimbT<R>& L, int lane, const KIN& kin, LRows<R>& Rw, CS& cs, int ncon, SH& sh, int nx, bool step,
                const R* xl, const R* xt, R alpha, R* jl, R* jt) {
   R VT[kTB][6], VL[kLB][6], VR[kLB][6];
   if (step) chain_velocity(kin, L.attach, xl, xt, VT, VL, VR);
@@ -935,8 +938,8 @@ template <typename R> struct LLine { R x0[4], v[4], D; };
 
 // Newton solver. (sl, st) = qacc_smooth, (wl, wt) = warm start, M in the store `ms`; leaves qacc in (al, at) and J' force in (fc_l, fc_t).
 // Returns the flag bits (quad-uniform).
-template <typename R, class CS, class MS, class SH>
-LD int newton_body(const LimbModelT<R>& m, int lane, const LKin<R>& kin, const MS& ms, LRows<R>& Rw, CS& cs, int ncon, SH& sh, int nx,
+template <typename R, class CS, class MS, class SH, class KIN>
+LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& ms, LRows<R>& Rw, CS& cs, int ncon, SH& sh, int nx,
               const R* sl, const R* st, const R* wl, const R* wt, bool have_warm, const R* qvl, const R* qvt,
               R* al, R* at, R* fc_l, R* fc_t, int& iters, long long* stamps) {
   const LimbT<R>& L = m.limb[lane];
@@ -1229,35 +1232,25 @@ template <typename R> struct LNewtonIO { R sl[kLD], st[kTD], wl[kLD], wt[kTD], q
 #define LEULER_ATTR LNOINLINE
 #define LRESID_ATTR LNOINLINE
 #endif
-template <typename R, class CS, class MS, class SH>
-LNEWTON_ATTR int newton(const LimbModelT<R>& m_in, int lane, const LKin<R>* kin_in, MS ms, LRows<R>* Rw_io, CS cs, int ncon, SH sh, int nx, bool have_warm,
+template <typename R, class CS, class MS, class SH, class KS>
+LNEWTON_ATTR int newton(const LimbModelT<R>& m_in, int lane, KS ks, MS ms, LRows<R>* Rw_io, CS cs, int ncon, SH sh, int nx, bool have_warm,
                      LNewtonIO<R>* io_ptr, long long* stamps) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
-  if (!(LEXP_COPY_MASK & (2 | 16))) {
+  if (!(LEXP_COPY_MASK & 16)) {
     LNewtonIO<R>& o = *LREBIND_PRV(LNewtonIO<R>, io_ptr);
-    return newton_body(m, lane, *LREBIND_PRV(const LKin<R>, kin_in), ms, *LREBIND_PRV(LRows<R>, Rw_io), cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, o.al, o.at, o.fc_l, o.fc_t, o.iters, stamps);
+    return newton_body(m, lane, ks, ms, *LREBIND_PRV(LRows<R>, Rw_io), cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, o.al, o.at, o.fc_l, o.fc_t, o.iters, stamps);
   }
-  if (LEXP_COPY_MASK & 16) {
-    // what the solver WRITES lives in registers for the call (the rows' jar, the iterate, J' force: a read-modify-write through the caller's
-    // memory waits for its own store every time); what it only reads (the dof axes, qacc_smooth, the warm start) stays where it is
-    LRows<R> Rw;
-    LPRV_LOAD(Rw, Rw_io);
-    const LNewtonIO<R>& o = *io_ptr;
-    R al[kLD], at[kTD], fc_l[kLD], fc_t[kTD];
-    int iters = 0;
-    const int rc = newton_body(m, lane, *kin_in, ms, Rw, cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, al, at, fc_l, fc_t, iters, stamps);
-    LPRV_STOREN(io_ptr->al, al, kLD); LPRV_STOREN(io_ptr->at, at, kTD); LPRV_STOREN(io_ptr->fc_l, fc_l, kLD); LPRV_STOREN(io_ptr->fc_t, fc_t, kTD);
-    io_ptr->iters = iters;
-    return rc;
-  }
-  LKin<R> kin;
-  LPRV_LOAD(kin, kin_in);
+  // what the solver WRITES lives in registers for the call (the rows' jar, the iterate, J' force: a read-modify-write through the caller's
+  // memory waits for its own store every time); what it only reads (qacc_smooth, the warm start) stays where it is; the dof axes are in the
+  // includer's store (LDS)
   LRows<R> Rw;
   LPRV_LOAD(Rw, Rw_io);
-  LNewtonIO<R> io;
-  LPRV_LOAD(io, io_ptr);
-  const int rc = newton_body(m, lane, kin, ms, Rw, cs, ncon, sh, nx, io.sl, io.st, io.wl, io.wt, have_warm, io.qvl, io.qvt, io.al, io.at, io.fc_l, io.fc_t, io.iters, stamps);
-  LPRV_STORE(io_ptr, io);
+  const LNewtonIO<R>& o = *io_ptr;
+  R al[kLD], at[kTD], fc_l[kLD], fc_t[kTD];
+  int iters = 0;
+  const int rc = newton_body(m, lane, ks, ms, Rw, cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, al, at, fc_l, fc_t, iters, stamps);
+  LPRV_STOREN(io_ptr->al, al, kLD); LPRV_STOREN(io_ptr->at, at, kTD); LPRV_STOREN(io_ptr->fc_l, fc_l, kLD); LPRV_STOREN(io_ptr->fc_t, fc_t, kTD);
+  io_ptr->iters = iters;
   return rc;
 }
 
@@ -1419,8 +1412,8 @@ LD double bernoulli_uniform(uint64_t seed, uint32_t cand, uint32_t iter) {
 
 // One lane's share of one candidate's rollout. `state0` = qpos[nq] qvel[nv] of the plan (Planner::SetState). Returns the flag bits (0:
 // rolled out; otherwise failure[cand] carries kLFallback and the wavefront-per-candidate kernel takes the candidate over).
-template <typename R, class CS, class MS, class SH>
-LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R time0, const LArgs<R>& a, int cand, int lane, CS& cs, MS& ms, SH& sh) {
+template <typename R, class CS, class MS, class SH, class KS>
+LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R time0, const LArgs<R>& a, int cand, int lane, CS& cs, MS& ms, SH& sh, KS& ks) {
   const LimbT<R>& L = m.limb[lane];
   const int nu = m.nu, P = a.P, H = a.H, nq = m.nq;
   const size_t N = (size_t)a.N;
@@ -1523,7 +1516,7 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
     LDyn<R> D;
     LSense<R> f;
     LPOISON(D); LPOISON(f);
-    flags = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, &D, &f);
+    flags = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, ks, &D, &f);
     if (flags) break;
     LPROF(a, prof_last, 1);
     // the sensor stage (residual, cost, traces) does not depend on the constraint solve: evaluated and recorded first
@@ -1551,7 +1544,7 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
     LUNROLL for (int j = 0; j < kLD; j++) { io.sl[j] = D.sl[j]; io.wl[j] = S.wl[j]; io.qvl[j] = S.lv[j]; io.al[j] = 0; io.fc_l[j] = 0; }
     LUNROLL for (int k = 0; k < kTD; k++) { io.st[k] = D.st[k]; io.wt[k] = S.wt[k]; io.qvt[k] = S.tv[k]; io.at[k] = 0; io.fc_t[k] = 0; }
     io.iters = 0;
-    flags = newton(m, lane, &D.kin, ms, &D.rows, cs, D.ncon, sh, D.nx, t > 0, &io, a.stamps);
+    flags = newton(m, lane, ks, ms, &D.rows, cs, D.ncon, sh, D.nx, t > 0, &io, a.stamps);
     if (flags) break;
     LPROF(a, prof_last, 3);
     iters_total += io.iters;

@@ -70,6 +70,9 @@ namespace mjpcx { namespace limb { template <typename R> struct LContact; templa
 template <typename R> struct EmuCS { mjpcx::limb::LContact<R>* p; };
 template <typename R> struct EmuMData { R l[21], b[mjpcx::limb::kLD][mjpcx::limb::kTD], t[45]; };
 template <typename R> struct EmuM { EmuMData<R>* p; };  // (the stores are handles passed by value, as the device's LDS pointers are)
+namespace mjpcx { namespace limb { template <typename R> struct LKin; } }
+template <typename R> struct EmuKin { R (*cdof)[6]; R (*cdofT)[6]; };  // a view of an LKin held by the caller (the device keeps the axes in LDS)
+template <typename R> static inline void lkin_store(EmuKin<R>& ks, const mjpcx::limb::LKin<R>& k);
 template <typename R> struct EmuShared;
 template <typename R> struct EmuSH { EmuShared<R>* p; };
 template <typename R> static inline void lcs_load(const EmuCS<R>& cs, int i, mjpcx::limb::LContact<R>& c);
@@ -91,6 +94,10 @@ template <typename R> static inline void lsh_xset(EmuSH<R>& sh, int r, int f, R 
 template <typename R> struct EmuShared { R gpos[mjpcx::limb::kNG][3], gax[mjpcx::limb::kNG][3]; mjpcx::limb::LCross<R> cross[mjpcx::limb::kMaxX]; R xrow[mjpcx::limb::kMaxX][2]; };
 template <typename R> static inline R lsh_xget(const EmuSH<R>& sh, int r, int f) { return f == 6 ? sh.p->cross[r].D : sh.p->xrow[r][f - 10]; }
 template <typename R> static inline void lsh_xset(EmuSH<R>& sh, int r, int f, R v) { sh.p->xrow[r][f - 10] = v; }
+template <typename R> static inline void lkin_store(EmuKin<R>& ks, const mjpcx::limb::LKin<R>& k) {
+  for (int j = 0; j < mjpcx::limb::kLD; j++) for (int c = 0; c < 6; c++) ks.cdof[j][c] = k.cdof[j][c];
+  for (int j = 0; j < mjpcx::limb::kTD; j++) for (int c = 0; c < 6; c++) ks.cdofT[j][c] = k.cdofT[j][c];
+}
 template <typename R> static inline void lcs_load(const EmuCS<R>& cs, int i, mjpcx::limb::LContact<R>& c) { c = cs.p[i]; }
 template <typename R> static inline void lcs_store(EmuCS<R>& cs, int i, const mjpcx::limb::LContact<R>& c) { cs.p[i] = c; }
 template <typename R> static inline void lcs_store_jar(EmuCS<R>& cs, int i, const mjpcx::limb::LContact<R>& c) { for (int k = 0; k < 4; k++) cs.p[i].jar[k] = c.jar[k]; }
@@ -176,9 +183,11 @@ int forward_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
     EmuMData<R> msd;
     EmuM<R> ms{&msd};
     EmuSH<R> sh{&shared};
+    LKin<R> kind;
+    EmuKin<R> ks{kind.cdof, kind.cdofT};
     LDyn<R> D;
     LSense<R> f;
-    int fl = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, &D, &f);
+    int fl = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, ks, &D, &f);
     flags_out[lane] = fl;
     if (fl) return;
     const R cost = residual_cost(m, &b->tk, lane, &S, ctrl, tctrl, &f, res.data());
@@ -186,7 +195,7 @@ int forward_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
     for (int j = 0; j < kLD; j++) { io.sl[j] = D.sl[j]; io.wl[j] = S.wl[j]; io.qvl[j] = S.lv[j]; io.al[j] = 0; io.fc_l[j] = 0; }
     for (int k = 0; k < kTD; k++) { io.st[k] = D.st[k]; io.wt[k] = S.wt[k]; io.qvt[k] = S.tv[k]; io.at[k] = 0; io.fc_t[k] = 0; }
     io.iters = 0;
-    fl = newton(m, lane, &D.kin, ms, &D.rows, cs, D.ncon, sh, D.nx, warm != nullptr, &io, (long long*)nullptr);
+    fl = newton(m, lane, ks, ms, &D.rows, cs, D.ncon, sh, D.nx, warm != nullptr, &io, (long long*)nullptr);
     flags_out[lane] = fl;
     if (fl) return;
     const R* al = io.al; const R* at = io.at; const R* fc_l = io.fc_l; const R* fc_t = io.fc_t;
@@ -266,7 +275,9 @@ int rollout_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
           EmuMData<R> msd;
           EmuM<R> ms{&msd};
           EmuSH<R> sh{&shared};
-          const int fl = rollout(b->lm, b->tk, st0.data(), (R)time, a, cand, lane, cs, ms, sh);
+          LKin<R> kind;
+          EmuKin<R> ks{kind.cdof, kind.cdofT};
+          const int fl = rollout(b->lm, b->tk, st0.data(), (R)time, a, cand, lane, cs, ms, sh, ks);
           if (lane == 0 && flags) flags[cand] = fl;
         });
       }
