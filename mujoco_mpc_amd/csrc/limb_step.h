@@ -1225,50 +1225,45 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
   return 0;
 }
 
-// what the solver reads of the step, and what it leaves
-template <typename R> struct LNewtonIO { R sl[kLD], st[kTD], wl[kLD], wt[kTD], qvl[kLD], qvt[kTD], al[kLD], at[kTD], fc_l[kLD], fc_t[kTD]; int iters; };
+// what the solver leaves (what it reads -- qacc_smooth, the warm start, qvel -- it takes from the step's own structs: no copies through
+// the private segment)
+template <typename R> struct LNewtonOut { R al[kLD], at[kTD], fc_l[kLD], fc_t[kTD]; int iters; };
 #ifndef LNEWTON_ATTR
 #define LNEWTON_ATTR LNOINLINE
 #define LEULER_ATTR LNOINLINE
 #define LRESID_ATTR LNOINLINE
 #endif
 template <typename R, class CS, class MS, class SH, class KS>
-LNEWTON_ATTR int newton(const LimbModelT<R>& m_in, int lane, KS ks, MS ms, LRows<R>* Rw_io, CS cs, int ncon, SH sh, int nx, bool have_warm,
-                     LNewtonIO<R>* io_ptr, long long* stamps) {
+LNEWTON_ATTR int newton(const LimbModelT<R>& m_in, int lane, KS ks, MS ms, const LDyn<R>* D_in, const LState<R>* S_in, CS cs, SH sh, bool have_warm,
+                     LNewtonOut<R>* out_ptr, long long* stamps) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
-  if (!(LEXP_COPY_MASK & 16)) {
-    LNewtonIO<R>& o = *LREBIND_PRV(LNewtonIO<R>, io_ptr);
-    return newton_body(m, lane, ks, ms, *LREBIND_PRV(LRows<R>, Rw_io), cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, o.al, o.at, o.fc_l, o.fc_t, o.iters, stamps);
-  }
   // what the solver WRITES lives in registers for the call (the rows' jar, the iterate, J' force: a read-modify-write through the caller's
   // memory waits for its own store every time); what it only reads (qacc_smooth, the warm start) stays where it is; the dof axes are in the
   // includer's store (LDS)
   LRows<R> Rw;
-  LPRV_LOAD(Rw, Rw_io);
-  const LNewtonIO<R>& o = *io_ptr;
+  LPRV_LOAD(Rw, &D_in->rows);
   R al[kLD], at[kTD], fc_l[kLD], fc_t[kTD];
   int iters = 0;
-  const int rc = newton_body(m, lane, ks, ms, Rw, cs, ncon, sh, nx, o.sl, o.st, o.wl, o.wt, have_warm, o.qvl, o.qvt, al, at, fc_l, fc_t, iters, stamps);
-  LPRV_STOREN(io_ptr->al, al, kLD); LPRV_STOREN(io_ptr->at, at, kTD); LPRV_STOREN(io_ptr->fc_l, fc_l, kLD); LPRV_STOREN(io_ptr->fc_t, fc_t, kTD);
-  io_ptr->iters = iters;
+  const int rc = newton_body(m, lane, ks, ms, Rw, cs, D_in->ncon, sh, D_in->nx, D_in->sl, D_in->st, S_in->wl, S_in->wt, have_warm, S_in->lv, S_in->tv, al, at, fc_l, fc_t, iters, stamps);
+  LPRV_STOREN(out_ptr->al, al, kLD); LPRV_STOREN(out_ptr->at, at, kTD); LPRV_STOREN(out_ptr->fc_l, fc_l, kLD); LPRV_STOREN(out_ptr->fc_t, fc_t, kTD);
+  out_ptr->iters = iters;
   return rc;
 }
 
 // ---------------------------------------------------------------- mj_Euler with implicit joint damping, then mj_advance (oracle o_euler)
-template <typename R> struct LEulerIn { R fs_l[kLD], fs_t[kTD], al[kLD], at[kTD], fc_l[kLD], fc_t[kTD]; };
 template <typename R, class MS>
-LEULER_ATTR void euler(const LimbModelT<R>& m_in, int lane, LState<R>* S_io, const LEulerIn<R>* in_ptr, MS ms) {
+LEULER_ATTR void euler(const LimbModelT<R>& m_in, int lane, LState<R>* S_io, const LDyn<R>* D_in, const LNewtonOut<R>* in_ptr, MS ms) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
   const LimbT<R>& L = m.limb[lane];
   LState<R> S;
   LPRV_LOAD(S, S_io);
-  LEulerIn<R> in;
+  LNewtonOut<R> in;
   LPRV_LOAD(in, in_ptr);
   const R* al = in.al; const R* at = in.at;
   const R h = m.timestep;
   R ql[kLD], qt[kTD];
-  LUNROLL for (int j = 0; j < kLD; j++) ql[j] = in.fs_l[j] + in.fc_l[j];
-  LUNROLL for (int k = 0; k < kTD; k++) qt[k] = in.fs_t[k] + in.fc_t[k];
+  LUNROLL for (int j = 0; j < kLD; j++) ql[j] = D_in->fs_l[j] + in.fc_l[j];
+  LUNROLL for (int k = 0; k < kTD; k++) qt[k] = D_in->fs_t[k] + in.fc_t[k];
   Arrow<R> A;
   load_arrow(ms, A);
   LUNROLL for (int j = 0; j < kLD; j++) A.l[tri(j, j)] += h * L.jnt[j].damping;
@@ -1539,23 +1534,16 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
     total += (double)cost;
     LPROF(a, prof_last, 2);
     if (last) break;  // (the last step's mj_forward only feeds the sensor stage)
-    LNewtonIO<R> io;
+    LNewtonOut<R> io;
     LPOISON(io);
-    LUNROLL for (int j = 0; j < kLD; j++) { io.sl[j] = D.sl[j]; io.wl[j] = S.wl[j]; io.qvl[j] = S.lv[j]; io.al[j] = 0; io.fc_l[j] = 0; }
-    LUNROLL for (int k = 0; k < kTD; k++) { io.st[k] = D.st[k]; io.wt[k] = S.wt[k]; io.qvt[k] = S.tv[k]; io.at[k] = 0; io.fc_t[k] = 0; }
-    io.iters = 0;
-    flags = newton(m, lane, ks, ms, &D.rows, cs, D.ncon, sh, D.nx, t > 0, &io, a.stamps);
+    flags = newton(m, lane, ks, ms, &D, &S, cs, sh, t > 0, &io, a.stamps);
     if (flags) break;
     LPROF(a, prof_last, 3);
     iters_total += io.iters;
     LUNROLL for (int j = 0; j < kLD; j++) bad |= lbad(io.al[j]);
     LUNROLL for (int k = 0; k < kTD; k++) bad |= lbad(io.at[k]);
     if (qd_or(bad ? 1 : 0)) { flags = kFlagBad; break; }
-    LEulerIn<R> ei;
-    LPOISON(ei);
-    LUNROLL for (int j = 0; j < kLD; j++) { ei.fs_l[j] = D.fs_l[j]; ei.al[j] = io.al[j]; ei.fc_l[j] = io.fc_l[j]; }
-    LUNROLL for (int k = 0; k < kTD; k++) { ei.fs_t[k] = D.fs_t[k]; ei.at[k] = io.at[k]; ei.fc_t[k] = io.fc_t[k]; }
-    euler(m, lane, &S, &ei, ms);
+    euler(m, lane, &S, &D, &io, ms);
     LPROF(a, prof_last, 4);
   }
 #undef LNODE

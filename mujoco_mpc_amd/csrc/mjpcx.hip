@@ -377,8 +377,7 @@ struct mjpcx_ctx {
   bool no_quad_feedback = false;  // MJPCX_NO_QUAD_FEEDBACK=1: the iLQG rollouts stay on the wavefront-per-candidate kernel (A/B runs, tests)
   bool quad_stats = false;    // MJPCX_QUAD_STATS=1: print how many candidates each rollout handed to the fallback kernel, by reason
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
-  // limb kernel (limb_kernel.h): four lanes per candidate, one per limb of the Humanoid class limb_build accepts. fp32 contexts (the precision
-  // configs[3] is quoted in) by default; fp64 contexts with MJPCX_LIMB_F64=1 (parity tests at the oracle's precision)
+  // limb kernel (limb_kernel.h): four lanes per candidate, one per limb of the Humanoid class limb_build accepts; both precisions
   bool limb_ok = false;       // MJPCX_NO_LIMB=1 keeps the wavefront-per-candidate kernel (A/B runs)
   int limb_min_n = 512;       // batches below this go to rollout_tree_kernel<Humanoid> (MJPCX_LIMB_MIN_N)
   int limb_cpw = 0;           // candidates per wavefront (0: chosen from the batch size; MJPCX_LIMB_CPW)
@@ -1139,7 +1138,7 @@ int mjpcx_create(const mjpcx_model* m, const mjpcx_task* t, int device, int prec
       c->limb_no_fallback = getenv("MJPCX_LIMB_NO_FALLBACK") != nullptr;
       if (const char* e = getenv("MJPCX_LIMB_MIN_N")) c->limb_min_n = std::atoi(e);
       if (const char* e = getenv("MJPCX_LIMB_CPW")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->limb_cpw = v; }
-      if (!getenv("MJPCX_NO_LIMB") && (precision == 32 || getenv("MJPCX_LIMB_F64"))) {
+      if (!getenv("MJPCX_NO_LIMB")) {   // (both precisions: the fp64 instantiation spills more but is still ahead of the tree kernel, 78 against 95 ms on configs[3]'s share)
         // the limb kernel family (four lanes per candidate, one per limb): models of the class limb_build accepts
         std::vector<unsigned char> h32, h64;
         c->limb_why = limb::build_images(m, t, h32, h64);

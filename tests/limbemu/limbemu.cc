@@ -191,11 +191,8 @@ int forward_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
     flags_out[lane] = fl;
     if (fl) return;
     const R cost = residual_cost(m, &b->tk, lane, &S, ctrl, tctrl, &f, res.data());
-    LNewtonIO<R> io;
-    for (int j = 0; j < kLD; j++) { io.sl[j] = D.sl[j]; io.wl[j] = S.wl[j]; io.qvl[j] = S.lv[j]; io.al[j] = 0; io.fc_l[j] = 0; }
-    for (int k = 0; k < kTD; k++) { io.st[k] = D.st[k]; io.wt[k] = S.wt[k]; io.qvt[k] = S.tv[k]; io.at[k] = 0; io.fc_t[k] = 0; }
-    io.iters = 0;
-    fl = newton(m, lane, ks, ms, &D.rows, cs, D.ncon, sh, D.nx, warm != nullptr, &io, (long long*)nullptr);
+    LNewtonOut<R> io;
+    fl = newton(m, lane, ks, ms, &D, &S, cs, sh, warm != nullptr, &io, (long long*)nullptr);
     flags_out[lane] = fl;
     if (fl) return;
     const R* al = io.al; const R* at = io.at; const R* fc_l = io.fc_l; const R* fc_t = io.fc_t;

@@ -11,6 +11,13 @@ from oracle import pyoracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def tree_kernel_only(monkeypatch):
+    """this suite is the wavefront-per-candidate kernel's (the hand-on target of the limb kernel, the kernel of small batches and NoisyRollout):
+    contexts are created without the limb kernel, whose own suite is tests/test_gpu_limb.py"""
+    monkeypatch.setenv("MJPCX_NO_LIMB", "1")
+
+
 def mocap7(mpos):
     return np.concatenate([np.concatenate([p, [1, 0, 0, 0]]) for p in np.asarray(mpos).reshape(-1, 3)])
 

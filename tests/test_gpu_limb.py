@@ -1,5 +1,5 @@
 """-m gpu: the limb kernel (csrc/limb_step.h: four lanes per candidate, one per limb of the Humanoid of BASELINE configs[3]) against the CPU
-oracle through the C ABI. fp64 (MJPCX_LIMB_F64=1: the kernel at the oracle's precision) at 1e-9 (1 + |x|) on every Trajectory buffer over short
+oracle through the C ABI. fp64 (the kernel at the oracle's precision) at 1e-9 (1 + |x|) on every Trajectory buffer over short
 horizons and 1e-7 over the config's 64 steps; fp32 -- the precision configs[3] is quoted in and the kernel's default -- at 2e-3 on returns.
 A candidate the limb form does not cover is handed to rollout_tree_kernel<Humanoid>: results never depend on which kernel ran."""
 import os
@@ -32,8 +32,6 @@ def walk():
 
 def limb_context(pm, pt, precision, min_n=0):
     env = {"MJPCX_LIMB_MIN_N": str(min_n)}
-    if precision == 64:
-        env["MJPCX_LIMB_F64"] = "1"
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:

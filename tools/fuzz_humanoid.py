@@ -21,7 +21,6 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 KERNEL = sys.argv[4] if len(sys.argv) > 4 else "tree"
 if KERNEL == "limb":
     os.environ["MJPCX_LIMB_MIN_N"] = "0"
-    os.environ["MJPCX_LIMB_F64"] = "1"
 else:
     os.environ["MJPCX_NO_LIMB"] = "1"
 PREC = int(sys.argv[3]) if len(sys.argv) > 3 else 64   # 32: the fp32 kernel of configs[3] against the fp64 oracle (first steps at 1e-3, returns reported)
