@@ -55,6 +55,7 @@ def parse():
                          "candidate offset) -- what the per-rank time of --scaling strong will be before the hardware shows up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` configs (they only run at --gpus 1)")
+    ap.add_argument("--no-box-probe", action="store_true", help="skip gpu_clock.box_probe (three library-kernel figures that tell the pool's kinds of box apart)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test without a device: rendezvous over gloo, the unique-id broadcast, the candidate split, the "
@@ -225,6 +226,42 @@ def pmc_summary(task_name, candidates, horizon, precision):
     if not same and "rollout_quad_kernel" in s.get("kernel", ""):  # (its translation unit's own sources decide for the quad kernel)
         same = s.get("unit_src_sha16") == kernel_source_sha16("quad")
     return s if same else None
+
+
+def box_probe(device_index=0):
+    """Which kind of box this is, in three numbers taken AFTER the timed region (half a second; library kernels, none of this repository's):
+    fp64 GEMM rate (rocBLAS, 4096^3), device-to-device copy rate (256 MiB) and the round trip of a one-element kernel with a synchronisation.
+    The pool's boxes run the fp64 contact kernels 48-51 ms or 60-77 ms at the same reported clocks: a reader of the line can
+    tell from these which kind produced it -- the slow kind shows in the copy rate and the round trip, not in sclk."""
+    try:
+        import torch
+        dev = torch.device("cuda", device_index)
+        x = torch.randn(4096, 4096, dtype=torch.float64, device=dev)
+        y = torch.randn(4096, 4096, dtype=torch.float64, device=dev)
+        torch.mm(x, y); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            torch.mm(x, y)
+        torch.cuda.synchronize(dev)
+        gemm = 4 * 2 * 4096 ** 3 / (time.perf_counter() - t0) / 1e12
+        a = torch.empty(32 * 2 ** 20, dtype=torch.float64, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(8):
+            b.copy_(a)
+        torch.cuda.synchronize(dev)
+        copy = 8 * 2 * a.numel() * 8 / (time.perf_counter() - t0) / 1e9
+        one = torch.zeros(1, device=dev)
+        one.add_(1); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            one.add_(1)
+            torch.cuda.synchronize(dev)
+        rt = (time.perf_counter() - t0) / 200 * 1e6
+        return {"dgemm_4096_tflops": gemm, "copy_256mib_gbs": copy, "launch_sync_round_trip_us": rt}
+    except Exception as e:  # noqa: BLE001 -- a probe must never take the line down
+        return {"error": str(e)}
 
 
 class ClockSampler:
@@ -412,6 +449,8 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
     }
     del interp
     out["gpu_clock"] = clocks.summary()
+    if out["gpu_clock"] is not None and not getattr(args, "no_box_probe", False):
+        out["gpu_clock"]["box_probe"] = box_probe(local_rank)
     pmc = pmc_summary(task_name, candidates, H, precision)
     if pmc is not None:
         out["roofline"]["traffic"] = pmc.get("hbm_bytes_per_launch")

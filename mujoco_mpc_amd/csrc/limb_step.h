@@ -1311,12 +1311,11 @@ LRESID_ATTR R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, in
   const LimbT<R>& L = m.limb[lane];
   LTask<R> tk;
   LPRV_LOAD(tk, tk_in);
-  LState<R> S;
-  LPRV_LOAD(S, S_in);
-  LSense<R> f;
-  LPRV_LOAD(f, f_in);
-  R ctrl[kLD], tctrl[3];
-  LPRV_LOADN(ctrl, ctrl_in, kLD); LPRV_LOADN(tctrl, tctrl_in, 3);
+  // (the loops below index these at run time: read where they are -- local copies would only be written back to the private segment)
+  const LState<R>& S = *LREBIND_PRV(const LState<R>, S_in);
+  const LSense<R>& f = *LREBIND_PRV(const LSense<R>, f_in);
+  const R* ctrl = LREBIND_PRV(const R, ctrl_in);
+  const R* tctrl = LREBIND_PRV(const R, tctrl_in);
   const int nj = m.nv - 6, nu = m.nu, c0 = nj + nu;
   R cost = 0;
   auto entry = [&](int idx, R x) {

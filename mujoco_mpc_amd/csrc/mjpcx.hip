@@ -379,7 +379,8 @@ struct mjpcx_ctx {
   std::string quad_why;       // why quad_build declined (mjpcx_create_error after MJPCX_OK carries it when MJPCX_QUAD_STATS is set)
   // limb kernel (limb_kernel.h): four lanes per candidate, one per limb of the Humanoid class limb_build accepts; both precisions
   bool limb_ok = false;       // MJPCX_NO_LIMB=1 keeps the wavefront-per-candidate kernel (A/B runs)
-  int limb_min_n = 512;       // batches below this go to rollout_tree_kernel<Humanoid> (MJPCX_LIMB_MIN_N)
+  int limb_min_n = 2560;      // batches below this go to rollout_tree_kernel<Humanoid> (MJPCX_LIMB_MIN_N). The limb kernel's launch is one wavefront's latency, ~20 ms for
+                              // any batch up to 8192; the tree kernel takes 13.2 / 13.9 / 15.5 ms at 512 / 1024 / 2048 candidates and 27.1 at 3072 (limb: 18.9), fp32 on MI355X
   int limb_cpw = 0;           // candidates per wavefront (0: chosen from the batch size; MJPCX_LIMB_CPW)
   bool limb_no_fallback = false;  // MJPCX_LIMB_NO_FALLBACK=1: leave the handed-on candidates flagged (tuning)
   std::string limb_why;       // why limb_build declined

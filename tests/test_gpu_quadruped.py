@@ -326,6 +326,54 @@ def test_cost_derivatives_at_the_a1s_shape(quad, risk):
     ctx.close()
 
 
+def test_one_ilqg_iteration_on_the_a1_against_the_oracle(quad):
+    """BASELINE configs[4]'s iteration, device against oracle, with the ORACLE's finite differences fed to both sides so that the 1 / eps
+    amplification of the sweep drops out (ilqg/planner.cc:377-627): cost derivatives -> Riccati pass at the planner's regularisation (state-
+    control regularisation, action limits: n = 36, m = 12, T = 36) -> the ten line-search rollouts under the index policy. The gains, the
+    improvement and the expected decrease at 1e-8, the rollouts' returns at 1e-7, and the SAME line-search step wins."""
+    pm, pt = quad.packed_model(), quad.packed()
+    H = 36
+    home = quad.model.keyframes["home"]["qpos"]
+    rng = np.random.default_rng(21)
+    state = np.concatenate([home, 0.2 * rng.normal(size=18)])
+    times = np.arange(4) * (H - 1) * 0.01 / 3
+    nodes = np.clip(rng.normal(0, 0.2, (1, 4, 12)), -1, 1)
+    nom = pyoracle.rollout_batch(pm, pt, state, 0.0, MOCAP, 1, H, 4, 1, times, nodes, num_threads=1)
+    nom = {k: v[0] for k, v in nom.items() if k not in ("total_return", "failure")}
+    Ao, Bo, Co, Do = pyoracle.transition_fd(pm, pt, nom["states"], nom["times"], nom["actions"], 1e-6, 0, mocap=MOCAP)
+    Ao[-1] = 0; Bo[-1] = 0; Do[-1] = 0                       # (the last step has no transition: model_derivatives.cc:88-92)
+    limits = np.tile([-1.0, 1.0], (12, 1))
+    ctx = capi.Context(pm, pt, 0, 64)
+    cd_dev = ctx.cost_derivatives(nom["residual"], Co, Do)
+    cd_ref = pyoracle.cost_derivatives(pt, nom["residual"], Co, Do)
+    mu, reg_type = 1.0, 1
+    dev = ref = None
+    for _ in range(8):                                        # the planner's regularisation retries: both sides must agree on success
+        dev = ctx.backward_pass(mu, reg_type, 1, Ao, Bo, *cd_dev, nom["actions"], limits)
+        ref = pyoracle.riccati(36, 12, H, mu, reg_type, 1, Ao, Bo, *cd_ref, nom["actions"], limits)
+        assert dev["ok"] == ref["ok"]
+        if ref["ok"]:
+            break
+        mu *= 1.6
+    assert ref["ok"]
+    for name in ("K", "du", "Vx", "Vxx"):
+        scale = 1 + np.abs(ref[name]).max()
+        assert np.abs(dev[name] - ref[name]).max() <= 1e-8 * scale, (name, float(np.abs(dev[name] - ref[name]).max()), scale)
+    assert np.allclose(dev["dV"], ref["dV"], rtol=1e-8, atol=1e-10)
+    alpha = np.concatenate([np.exp(np.linspace(0, np.log(1e-3), 9)), [0.0]])
+    ctx.set_state(state, 0.0, MOCAP)
+    ctx.rollout_feedback(H, 0, 0, 1, nom["times"], nom["states"], nom["actions"], dev["K"], dev["du"], alpha)
+    ret, fail = ctx.returns()
+    refb = pyoracle.rollout_feedback(pm, pt, state, 0.0, MOCAP, H, 0, 0, 1, nom["times"], nom["states"], nom["actions"], ref["K"], ref["du"], alpha)
+    assert np.array_equal(np.asarray(fail, bool), np.asarray(refb["failure"], bool))
+    ok = ~np.asarray(fail, bool)
+    assert ok.any() and close(ret[ok], refb["total_return"][ok], 1e-7)
+    best = lambda r, f: min((j for j in range(len(r)) if not f[j]), key=lambda j: (r[j], -j))   # BestRollout: last index wins ties
+    assert best(ret, fail) == best(refb["total_return"], refb["failure"])
+    assert close(ret[-1], nom["costs"].mean(), 1e-7)          # step 0 reproduces the nominal trajectory
+    ctx.close()
+
+
 def test_ilqg_planner_on_the_quadruped():
     """BASELINE configs[4] in miniature: iLQG on the A1 (T = 36, 10 line-search rollouts, forward differences) -- the
     device sweep (49 perturbed steps per time step), cost derivatives, the MFMA Riccati pass at n = 36, m = 12 and the
