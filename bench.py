@@ -80,8 +80,8 @@ def kernel_source_sha16(unit=None):
     from mujoco_mpc_amd import build, capi
     capi.lib()  # (the library must exist: the product path fails loudly without it)
     csrc = os.path.join(ROOT, "mujoco_mpc_amd", "csrc")
-    if unit == "quad":
-        files = sorted(os.path.normpath(os.path.join(csrc, f)) for f in build.QUAD_DEPS) + [os.path.join(ROOT, "mujoco_mpc_amd", "build.py")]
+    if unit in ("quad", "limb"):   # (likewise the limb kernel's unit: build.LIMB_DEPS)
+        files = sorted(os.path.normpath(os.path.join(csrc, f)) for f in (build.QUAD_DEPS if unit == "quad" else build.LIMB_DEPS)) + [os.path.join(ROOT, "mujoco_mpc_amd", "build.py")]
     else:
         files = sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "generated", "*.h"))
                        + [os.path.join(ROOT, "include", "mjpcx.h"), os.path.join(ROOT, "mujoco_mpc_amd", "build.py")])   # (build.py: the compiler switches)
@@ -225,6 +225,8 @@ def pmc_summary(task_name, candidates, horizon, precision):
     same = s.get("src_sha16") == kernel_source_sha16()
     if not same and "rollout_quad_kernel" in s.get("kernel", ""):  # (its translation unit's own sources decide for the quad kernel)
         same = s.get("unit_src_sha16") == kernel_source_sha16("quad")
+    if not same and "rollout_limb_kernel" in s.get("kernel", ""):
+        same = s.get("unit_src_sha16") == kernel_source_sha16("limb")
     return s if same else None
 
 

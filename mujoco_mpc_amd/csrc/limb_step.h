@@ -369,8 +369,11 @@ template <typename R> LD void limit_row(R dist, R margin, R vel, R invw, R k, R 
 
 // ---------------------------------------------------------------- mj_forward before the constraint solve
 template <typename R, class CS, class MS, class SH, class KS>
-LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S, const R* ctrl, const R* tctrl, CS& cs, MS& ms, SH& sh, KS& ks, LDyn<R>& D, LSense<R>& out) {
+LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S, const R* ctrl, const R* tctrl, CS& cs, MS& ms, SH& sh, KS& ks, LDyn<R>& D, LSense<R>& out, long long* stamps) {
   const LimbT<R>& L = m.limb[lane];
+  struct { long long* stamps; } pa{stamps};
+  long long prof_last = 0;
+  LPROF(pa, prof_last, -1);
   LKin<R> kin;
   int flags = 0;
   // ================= kinematics (o_kinematics): the trunk chain, then the limb's chain
@@ -485,6 +488,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
       } else { LUNROLL for (int c = 0; c < 6; c++) kin.cdofT[6 + h][c] = 0; }
     }
   }
+  LPROF(pa, prof_last, 20);
   lkin_store(ks, kin);
   // ================= composite inertias -> M as an arrowhead (o_crb)
   {
@@ -513,6 +517,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
     }
     store_arrow(ms, M);
   }
+  LPROF(pa, prof_last, 21);
   // ================= velocity stage (o_comvel): body velocities, cdof_dot; bias forces (o_rne); passive and actuator forces
   R fs_l[kLD], fs_t[kTD];
   R VTq[kTB][6], VLq[kLB][6];
@@ -575,6 +580,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
       }
     }
   }
+  LPROF(pa, prof_last, 22);
   LUNROLL for (int j = 0; j < kLD; j++) { D.fs_l[j] = fs_l[j]; D.sl[j] = fs_l[j]; }
   LUNROLL for (int k = 0; k < kTD; k++) { D.fs_t[k] = fs_t[k]; D.st[k] = fs_t[k]; }
   {
@@ -583,6 +589,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
     if (!arrow_factor(F)) return kFlagNotPD;
     arrow_solve(F, D.sl, D.st);
   }
+  LPROF(pa, prof_last, 23);
   // ================= sites (tracking markers), traces
   LUNROLL for (int s = 0; s < kLS; s++) {
     const LSiteT<R>& St = L.site[s];
@@ -606,6 +613,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
     mv3(v, bm, T.pos);
     LUNROLL for (int k = 0; k < 3; k++) out.trace[q][k] = bp[k] + v[k];
   }
+  LPROF(pa, prof_last, 24);
   // ================= constraint rows: limits of the lane's joints, of its tendon, of the trunk's hinges
   LRows<R>& Rw = D.rows;
   LUNROLL for (int j = 0; j < kLD; j++) {
@@ -639,6 +647,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
     if (lo < T.margin) { Rw.tn_side = -1; limit_row(lo, T.margin, vel, T.invw, T.k, T.b, T.imp, Rw.tn_D, Rw.tn_jar); }
     else if (hi < T.margin) { Rw.tn_side = 1; limit_row(hi, T.margin, -vel, T.invw, T.k, T.b, T.imp, Rw.tn_D, Rw.tn_jar); }
   }
+  LPROF(pa, prof_last, 25);
   // ================= collision: the lane's geoms against the floor; their poses into the quad's shared table
   int ncon = 0;
   auto floor_test = [&](const LGeomT<R>& G, bool trunk_geom, const R* bp, const R* bm, const R* bvel) {
@@ -702,6 +711,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
   }
   D.ncon = ncon;
   ld_sync();
+  LPROF(pa, prof_last, 26);
   // ================= self-collision (oracle pair_collide over the baked moving-geom pairs): the lane's share of the pairs
   int nmine = 0;
   R xb_n[kMaxX][3], xb_p[kMaxX][3], xb_d[kMaxX]; int xb_i[kMaxX];
@@ -767,6 +777,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
       }
     }
   }
+  LPROF(pa, prof_last, 27);
   // the quad's list: lane by lane, each lane's contacts in its pairs' order
   int nx = 0;
   {
@@ -795,6 +806,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
       ld_sync();
     }
   }
+  LPROF(pa, prof_last, 28);
   if (nx > kMaxX) nx = 0;
   D.nx = nx;
   flags = qd_or(flags);
@@ -803,11 +815,11 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
 
 template <typename R, class CS, class MS, class SH, class KS>
 LNOINLINE int forward_smooth(const LimbModelT<R>& m_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, CS cs, MS ms, SH sh, KS ks,
-                             LDyn<R>* D_out, LSense<R>* out_out) {
+                             LDyn<R>* D_out, LSense<R>* out_out, long long* stamps) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
   if (!(LEXP_COPY_MASK & 1))
     return forward_smooth_body(m, lane, *LREBIND_PRV(const LState<R>, S_in), LREBIND_PRV(const R, ctrl_in), LREBIND_PRV(const R, tctrl_in), cs, ms, sh, ks,
-                               *LREBIND_PRV(LDyn<R>, D_out), *LREBIND_PRV(LSense<R>, out_out));
+                               *LREBIND_PRV(LDyn<R>, D_out), *LREBIND_PRV(LSense<R>, out_out), stamps);
   LState<R> S;
   LPRV_LOAD(S, S_in);
   R ctrl[kLD], tctrl[3];
@@ -815,7 +827,7 @@ LNOINLINE int forward_smooth(const LimbModelT<R>& m_in, int lane, const LState<R
   LDyn<R> D;
   LSense<R> out;
   LPOISON(D); LPOISON(out);
-  const int flags = forward_smooth_body(m, lane, S, ctrl, tctrl, cs, ms, sh, ks, D, out);
+  const int flags = forward_smooth_body(m, lane, S, ctrl, tctrl, cs, ms, sh, ks, D, out, stamps);
   LPRV_STORE(D_out, D); LPRV_STORE(out_out, out);
   return flags;
 }
@@ -1510,7 +1522,7 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
     LDyn<R> D;
     LSense<R> f;
     LPOISON(D); LPOISON(f);
-    flags = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, ks, &D, &f);
+    flags = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, ks, &D, &f, a.stamps);
     if (flags) break;
     LPROF(a, prof_last, 1);
     // the sensor stage (residual, cost, traces) does not depend on the constraint solve: evaluated and recorded first

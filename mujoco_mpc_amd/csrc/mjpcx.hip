@@ -772,6 +772,8 @@ hipError_t launch_limb(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>
     std::fprintf(stderr, "  newton: setup %lld | per iteration (the wavefront ran %lld): hessian %lld factor+solve %lld woodbury %lld mul+dots %lld linesearch %lld update+eval %lld\n",
                  h[8], h[15], h[9], h[10], h[11], h[12], h[13], h[14]);
     std::fprintf(stderr, "  line-search derivative evaluations of candidate 0: %lld\n", h[16]);
+    std::fprintf(stderr, "  forward: kinematics+inertias %lld M %lld velocity+bias %lld factor+solve %lld sites %lld rows %lld floor %lld pairs %lld pair list %lld\n",
+                 h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27], h[28]);
   }
   if (c->timing && c->cur_main) { if ((e = hipEventRecord(c->cur_main, c->stream)) == hipSuccess) c->cur_main = nullptr; else return e; }
   if (c->limb_no_fallback) return hipSuccess;

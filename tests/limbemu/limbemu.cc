@@ -187,7 +187,7 @@ int forward_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
     EmuKin<R> ks{kind.cdof, kind.cdofT};
     LDyn<R> D;
     LSense<R> f;
-    int fl = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, ks, &D, &f);
+    int fl = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, ks, &D, &f, (long long*)nullptr);
     flags_out[lane] = fl;
     if (fl) return;
     const R cost = residual_cost(m, &b->tk, lane, &S, ctrl, tctrl, &f, res.data());

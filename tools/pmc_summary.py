@@ -94,7 +94,7 @@ out = {
     "kernel": name, "task": task, "candidates": N, "horizon": H, "precision": prec,
     "command": f"bench.py --task {task} --precision {prec} --steps {steps} --warmup {warm} --no-extra --no-cpu-baseline",
     "src_sha16": bench.kernel_source_sha16(),
-    "unit_src_sha16": bench.kernel_source_sha16("quad") if "rollout_quad_kernel" in name else None,
+    "unit_src_sha16": bench.kernel_source_sha16("quad") if "rollout_quad_kernel" in name else (bench.kernel_source_sha16("limb") if "rollout_limb_kernel" in name else None),
     "launches": n, "warmup_launches": warm,
     "launch_ms_under_kernel_trace": launch_ms,
     "launch_ms_under_counters": {k[1:]: v for k, v in per.items() if k.startswith("_")},
