@@ -493,14 +493,18 @@ def run_config(args, task_name, kind, candidates, horizon, precision, steps, war
                         "divided by the device kernel's time: the rate a processor running the REFERENCE's dense algorithm would need to "
                         "match this kernel. The device's own formulation (no Jacobian, arrowhead factorisation) executes fewer operations; "
                         "its executed rate is `executed` (from SQ_INSTS_VALU_*_F64 / F32 counters), not this figure"}
-            if pmc is not None and pmc.get("executed_flops"):
-                ex = dict(pmc["executed_flops"])
-                if ex.get("flop_per_launch"):
-                    ex["achieved_tflops"] = ex["flop_per_launch"] / avg_kernel_s / 1e12
-                    ex["peak"] = peak
-                    ex["frac"] = ex["achieved_tflops"] / peak
-                ex["replayed_from"] = os.path.relpath(pmc_path(task_name, precision), ROOT)
-                out["roofline"]["fp64_executed" if precision == 64 else "fp32_executed"] = ex
+
+    if pmc is not None and pmc.get("executed_flops"):
+        # what the device EXECUTES in floating point (hardware counters of the timed launches, replayed like `traffic`): an upper bound of
+        # the useful work -- every lane of a wave-instruction is credited (`lane_activity` says how full they were)
+        peak = FP64_VALU_PEAK_TF if precision == 64 else FP32_VALU_PEAK_TF
+        ex = dict(pmc["executed_flops"])
+        if ex.get("flop_per_launch"):
+            ex["achieved_tflops"] = ex["flop_per_launch"] / avg_kernel_s / 1e12
+            ex["peak"] = peak
+            ex["frac"] = ex["achieved_tflops"] / peak
+        ex["replayed_from"] = os.path.relpath(pmc_path(task_name, precision), ROOT)
+        out["roofline"]["fp64_executed" if precision == 64 else "fp32_executed"] = ex
     planner.close()
     return out
 
