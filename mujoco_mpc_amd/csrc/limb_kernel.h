@@ -178,14 +178,23 @@ __global__ __launch_bounds__(256) void rollout_limb_kernel(const LimbModelT<R>* 
     for (unsigned i = threadIdx.x; i < sizeof(LimbModelT<R>) / 4; i += blockDim.x) dst[i] = src[i];
   }
   __syncthreads();
+  // the cost terms' weights and norm parameters (per-plan data in the blob): staged behind the model image -- every residual entry reads three of
+  // them, and from global memory that was 2 k cycles an entry (97 k of a step's 770 k)
+  constexpr size_t image_only = (sizeof(LimbModelT<R>) + 15) & ~(size_t)15;
+  R* terms = reinterpret_cast<R*>(lds_raw + image_only);
+  for (unsigned i = threadIdx.x; i < 3u * kMaxTerm; i += blockDim.x) {
+    const unsigned t = i % kMaxTerm, which = i / kMaxTerm;
+    terms[i] = (int)t < sm.nterm ? blob[(which == 0 ? bo.off_weight : (which == 1 ? bo.off_normp : bo.off_normq)) + t] : R(0);
+  }
+  __syncthreads();
   const int cpw = a.cpw > 0 && a.cpw <= LS / 4 ? a.cpw : LS / 4;
   const int wl = threadIdx.x & 63, quad = wl >> 2, lane = wl & 3;
   const int cand = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * cpw + quad;
   if (quad >= cpw || cand >= a.N) return;  // (whole quads leave together)
   LTask<R> tk;
-  tk.mocap = blob + bo.off_mocap; tk.weight = blob + bo.off_weight; tk.norm_p = blob + bo.off_normp; tk.norm_q = blob + bo.off_normq;
+  tk.mocap = blob + bo.off_mocap; tk.weight = terms; tk.norm_p = terms + kMaxTerm; tk.norm_q = terms + 2 * kMaxTerm;
   tk.re = blob + bo.off_rreal; tk.ri = reinterpret_cast<const int*>(blob + bo.off_rint); tk.risk = blob[bo.off_risk]; tk.key_mpos = key_mpos;
-  constexpr size_t image = (sizeof(LimbModelT<R>) + 15) & ~(size_t)15;
+  constexpr size_t image = image_only + ((3 * kMaxTerm * sizeof(R) + 15) & ~(size_t)15);
   const lds_ptr<R> wave_lds = (lds_ptr<R>)reinterpret_cast<R*>(lds_raw + image) + (threadIdx.x >> 6) * wave_reals(LS);
   LdsCS<R, LS> cs{wave_lds + wl};
   LdsMS<R, LS> ms{wave_lds + wave_con(LS) + wl, wave_lds + wave_con(LS) + wave_ml(LS) + quad};

@@ -27,7 +27,7 @@ int limb_waves(int N, int cpw) { const int c = pick_cpw(N, cpw); return (N + c -
 template <typename R, int LS>
 static hipError_t launch_ls(const void* image, const R* blob, const LBlob& bo, const LArgs<R>& q, const R* key_mpos, int* stats, hipStream_t stream) {
   const int waves = (q.N + q.cpw - 1) / q.cpw;
-  constexpr size_t img = (sizeof(LimbModelT<R>) + 15) & ~(size_t)15, per_wave = wave_reals(LS) * sizeof(R);
+  constexpr size_t img = ((sizeof(LimbModelT<R>) + 15) & ~(size_t)15) + ((3 * kMaxTerm * sizeof(R) + 15) & ~(size_t)15), per_wave = wave_reals(LS) * sizeof(R);
   int W = (int)((160 * 1024 - img) / per_wave);
   if (W < 1) return hipErrorInvalidValue;
   if (W > 4) W = 4;

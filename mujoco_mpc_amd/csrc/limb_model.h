@@ -55,7 +55,7 @@ template <typename R> struct LGeomT {
   int on, body, gslot, pset, pdim;  // body: limb body slot 0..2 (a limb's geom) | trunk body 0..2 (a dealt trunk geom); pset: LPSetT index, pdim: condim (0: no pair)
 };
 template <typename R> struct LPSetT { R margin, includemargin, k, b, imp[5]; };
-template <typename R> struct LSiteT { R pos[3]; int on, body, marker, mocap; };  // body: 0..2 limb body, 3..5 trunk body
+template <typename R> struct LSiteT { R pos[3]; int on, body, marker, mocap, tpos, tvel; };  // tpos / tvel: the cost terms of the marker's position / velocity entries  // body: 0..2 limb body, 3..5 trunk body
 template <typename R> struct LTendonT { R coef[2], range[2], margin, invw, k, b, imp[5]; int on, slot[2]; };
 template <typename R> struct LPairT { R diag, reach; unsigned char ga, gb, pset, pad; };
 template <typename R> struct LTraceT { R pos[3]; int lane, body; };  // lane 0..3 + limb body slot, or lane 4 + trunk body
@@ -87,6 +87,7 @@ template <typename R> struct LimbModelT {
   unsigned char term_of[kMaxResid];
   int term_norm[kMaxTerm];
   int iterations, nv, nq, nu, nr, nterm, ntrace, nmocap, ngeom, npair;
+  int t_qvel, t_ctrl, t_avg;        // the cost terms of the joint-velocity, control and marker-average entries
   int key_start, key_last;          // residual_int[0..1] at build time (the kernel reads the current ones from the plan blob)
   int nattach[kTB];                 // limbs hanging on each trunk body
 };
@@ -491,6 +492,20 @@ inline std::string limb_build(const mjpcx_model* m, const mjpcx_task* task, Limb
     for (int i = 0; i < task->dim_norm_residual[t]; i++) L.term_of[off + i] = (unsigned char)t;
     off += task->dim_norm_residual[t];
   }
+  {  // the residual's layout fixes the term of every entry group: one term each for the joint velocities, the controls and the average, one
+     // position and one velocity term per marker (three entries each)
+    const int nj = m->nv - 6, c0 = nj + m->nu;
+    auto same = [&](int lo, int n) { for (int i = 1; i < n; i++) if (L.term_of[lo + i] != L.term_of[lo]) return false; return true; };
+    if (!same(0, nj) || !same(nj, m->nu) || !same(c0, 3)) return "the joint-velocity, control or average entries span several cost terms";
+    L.t_qvel = L.term_of[0]; L.t_ctrl = L.term_of[nj]; L.t_avg = L.term_of[c0];
+    for (int l = 0; l < kLimbs; l++)
+      for (int i = 0; i < kLS; i++) {
+        LSiteT<double>& St = L.limb[l].site[i];
+        if (!St.on) continue;
+        if (!same(c0 + 3 + 3 * St.marker, 3) || !same(c0 + 51 + 3 * St.marker, 3)) return "a marker's three entries span several cost terms";
+        St.tpos = L.term_of[c0 + 3 + 3 * St.marker]; St.tvel = L.term_of[c0 + 51 + 3 * St.marker];
+      }
+  }
   if (task->num_trace > kMaxTrace) return "more traces than staged";
   L.ntrace = task->num_trace;
   for (int q = 0; q < task->num_trace; q++) {
@@ -534,7 +549,7 @@ inline void limb_cast(const LimbModelD& s, LimbModelT<R>& d) {
     for (int i = 0; i < kLD; i++) cj(a.jnt[i], b.jnt[i]);
     for (int i = 0; i < kLG; i++) cg(a.geom[i], b.geom[i]);
     for (int i = 0; i < kTGL; i++) cg(a.tgeom[i], b.tgeom[i]);
-    for (int i = 0; i < kLS; i++) { for (int k = 0; k < 3; k++) b.site[i].pos[k] = (R)a.site[i].pos[k]; b.site[i].on = a.site[i].on; b.site[i].body = a.site[i].body; b.site[i].marker = a.site[i].marker; b.site[i].mocap = a.site[i].mocap; }
+    for (int i = 0; i < kLS; i++) { for (int k = 0; k < 3; k++) b.site[i].pos[k] = (R)a.site[i].pos[k]; b.site[i].on = a.site[i].on; b.site[i].body = a.site[i].body; b.site[i].marker = a.site[i].marker; b.site[i].mocap = a.site[i].mocap; b.site[i].tpos = a.site[i].tpos; b.site[i].tvel = a.site[i].tvel; }
     const LTendonT<double>& t = a.tendon; LTendonT<R>& u = b.tendon;
     u.coef[0] = (R)t.coef[0]; u.coef[1] = (R)t.coef[1]; u.range[0] = (R)t.range[0]; u.range[1] = (R)t.range[1]; u.margin = (R)t.margin; u.invw = (R)t.invw; u.k = (R)t.k; u.b = (R)t.b;
     for (int k = 0; k < 5; k++) u.imp[k] = (R)t.imp[k];
@@ -553,7 +568,7 @@ inline void limb_cast(const LimbModelD& s, LimbModelT<R>& d) {
   for (int q = 0; q < kMaxTrace; q++) { for (int k = 0; k < 3; k++) d.trace[q].pos[k] = (R)s.trace[q].pos[k]; d.trace[q].lane = s.trace[q].lane; d.trace[q].body = s.trace[q].body; }
   memcpy(d.term_of, s.term_of, sizeof d.term_of); memcpy(d.term_norm, s.term_norm, sizeof d.term_norm);
   d.iterations = s.iterations; d.nv = s.nv; d.nq = s.nq; d.nu = s.nu; d.nr = s.nr; d.nterm = s.nterm; d.ntrace = s.ntrace; d.nmocap = s.nmocap; d.ngeom = s.ngeom; d.npair = s.npair;
-  d.key_start = s.key_start; d.key_last = s.key_last;
+  d.key_start = s.key_start; d.key_last = s.key_last; d.t_qvel = s.t_qvel; d.t_ctrl = s.t_ctrl; d.t_avg = s.t_avg;
   for (int i = 0; i < kTB; i++) d.nattach[i] = s.nattach[i];
 }
 

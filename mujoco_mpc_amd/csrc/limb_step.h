@@ -730,15 +730,29 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
     }
     nmine++;
   };
-  for (int q = 0; q < kPairsPerLane; q++) {
-    if (q >= L.npair) break;
-    const int pi = L.pair0 + q;
+  // (the bounding-sphere filter of mj_collideGeoms for FOUR pairs at a time -- their centres' loads in flight together; one pair per pass had
+  // every pass wait for its own LDS round trip, 940 cycles a pair -- then the narrow phase, one instance, for the pairs that passed)
+  for (int q0 = 0; q0 < kPairsPerLane; q0 += 4) {
+    if (q0 >= L.npair) break;
+    int hits = 0;
+    LUNROLL for (int u = 0; u < 4; u++) {
+      const int qq = q0 + u < L.npair ? q0 + u : L.npair - 1;
+      const LPairT<R>& Pq = m.pair[L.pair0 + qq];
+      R c1[3], c2[3], ax[3];
+      lsh_get_geom(sh, Pq.ga, c1, ax);
+      lsh_get_geom(sh, Pq.gb, c2, ax);
+      const R ex = c1[0] - c2[0], ey = c1[1] - c2[1], ez = c1[2] - c2[2];
+      if (q0 + u < L.npair && !(ex * ex + ey * ey + ez * ez > Pq.reach * Pq.reach)) hits |= 1 << u;
+    }
+  while (hits) {
+    const int u = __builtin_ctz(hits);
+    hits &= hits - 1;
+    const int pi = L.pair0 + q0 + u;
     const LPairT<R>& P = m.pair[pi];
     R p1[3], a1[3], p2[3], a2[3];
     lsh_get_geom(sh, P.ga, p1, a1);
     lsh_get_geom(sh, P.gb, p2, a2);
     const R dx = p1[0] - p2[0], dy = p1[1] - p2[1], dz = p1[2] - p2[2];
-    if (dx * dx + dy * dy + dz * dz > P.reach * P.reach) continue;  // (mj_collideGeoms' bounding-sphere filter)
     const R r1 = m.grad[P.ga], r2 = m.grad[P.gb], h1 = m.ghalf[P.ga], h2 = m.ghalf[P.gb], margin = m.pset[P.pset].margin;
     if (h1 == 0 && h2 == 0) ball_pair(pi, p1, r1, p2, r2, margin);
     else if (h1 == 0) {
@@ -776,6 +790,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
         }
       }
     }
+  }
   }
   LPROF(pa, prof_last, 27);
   // the quad's list: lane by lane, each lane's contacts in its pairs' order
@@ -1305,52 +1320,67 @@ LEULER_ATTR void euler(const LimbModelT<R>& m_in, int lane, LState<R>* S_io, con
 // ---------------------------------------------------------------- the tracking residual and its cost (oracle humanoid_track_residual, ocost_value)
 // mjpc::Norm value per entry (every norm of this task class is a sum over entries: limb_model.h checks): quadratic, cosh, power loss,
 // smooth abs, smooth abs 2, rectify
-template <typename R> LNOINLINE R norm_entry(R x, int type, R p, R q) {
+#ifndef LNORM_ATTR
+#define LNORM_ATTR LNOINLINE
+#endif
+template <typename R> LNORM_ATTR R norm_entry(R x, int type, R p, R q) {
   switch (type) {
     case 0: return R(0.5) * x * x;
     case 3: return p * p * (cosh(x / p) - R(1));
     case 5: return R(pow(fabs(x), p));
     case 6: return sqrt(x * x + p * p) - p;
-    case 7: return R(pow(pow(fabs(x), q) + pow(p, q), 1 / q)) - p;
+    case 7:  // (q = 2 and q = 4 -- the tracking task's -- by products and square roots: the same function without three pow() calls)
+      if (q == 2) return sqrt(x * x + p * p) - p;
+      if (q == 4) { const R x2 = x * x, p2 = p * p; return sqrt(sqrt(x2 * x2 + p2 * p2)) - p; }
+      return R(pow(pow(fabs(x), q) + pow(p, q), 1 / q)) - p;
     case 8: return p > 0 ? p * R(log(1 + exp(x / p))) : (x > 0 ? x : R(0));
     default: return 0;
   }
 }
 // writes the lane's entries of residual row `rs` (nullptr: cost only) and returns the step's cost (the same in the four lanes)
+// (one term's parameters, read once for all the entries of the term that a lane holds: weight, norm type, its two parameters)
+template <typename R> struct LTerm { R w, p, q; int type; };
+template <typename R> LD LTerm<R> term_of(const LimbModelT<R>& m, const LTask<R>& tk, int t) { return LTerm<R>{tk.weight[t], tk.norm_p[t], tk.norm_q[t], m.term_norm[t]}; }
 template <typename R, class T>
-LRESID_ATTR R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, const LSense<R>* f_in, T* rs) {
+LRESID_ATTR R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, const LSense<R>* f_in, T* rs, long long* stamps) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
   const LimbT<R>& L = m.limb[lane];
+  struct { long long* stamps; } pa{stamps};
+  long long prof_last = 0;
+  LPROF(pa, prof_last, -1);
   LTask<R> tk;
   LPRV_LOAD(tk, tk_in);
-  // (the loops below index these at run time: read where they are -- local copies would only be written back to the private segment)
-  const LState<R>& S = *LREBIND_PRV(const LState<R>, S_in);
-  const LSense<R>& f = *LREBIND_PRV(const LSense<R>, f_in);
-  const R* ctrl = LREBIND_PRV(const R, ctrl_in);
-  const R* tctrl = LREBIND_PRV(const R, tctrl_in);
+  LState<R> S;
+  LPRV_LOAD(S, S_in);
+  LSense<R> f;
+  LPRV_LOAD(f, f_in);
+  R ctrl[kLD], tctrl[3];
+  LPRV_LOADN(ctrl, ctrl_in, kLD); LPRV_LOADN(tctrl, tctrl_in, 3);
   const int nj = m.nv - 6, nu = m.nu, c0 = nj + nu;
   R cost = 0;
-  auto entry = [&](int idx, R x) {
-    const int t = m.term_of[idx];
-    cost += tk.weight[t] * norm_entry(x, m.term_norm[t], tk.norm_p[t], tk.norm_q[t]);
+  // Entries are evaluated term by term: the residual's layout fixes which term an entry belongs to (joint velocities, controls, the marker
+  // average, one position and one velocity term per marker: limb_model.h bakes the marker terms into the sites), so a term's weight and norm
+  // parameters are read once for its entries instead of through a chain of look-ups per entry (that chain was 2 k cycles an entry).
+  auto entry = [&](const LTerm<R>& t, int idx, R x) {
+    cost += t.w * norm_entry(x, t.type, t.p, t.q);
     if (rs) LREC(rs[idx], (T)x);
   };
-  // (ROLLED loops over the joints and the sites, their data read from memory at run time: one instance of an entry's code per kind instead
-  // of forty-five)
-  for (int j = 0; j < kLD; j++) {
+  const LTerm<R> tv = term_of(m, tk, m.t_qvel), tc = term_of(m, tk, m.t_ctrl);
+  LUNROLL for (int j = 0; j < kLD; j++) {
     const LJointT<R>& J = L.jnt[j];
     if (!J.on) continue;
-    entry(J.dof - 6, S.lv[j]);
-    if (J.act >= 0) entry(nj + J.act, ctrl[j]);
+    entry(tv, J.dof - 6, S.lv[j]);
+    if (J.act >= 0) entry(tc, nj + J.act, ctrl[j]);
   }
   if (L.owns_trunk_rows) {
-    for (int h = 0; h < 3; h++) {
+    LUNROLL for (int h = 0; h < 3; h++) {
       const LJointT<R>& J = m.tjnt[h];
       if (!J.on) continue;
-      entry(J.dof - 6, S.tv[6 + h]);
-      if (J.act >= 0) entry(nj + J.act, tctrl[h]);
+      entry(tv, J.dof - 6, S.tv[6 + h]);
+      if (J.act >= 0) entry(tc, nj + J.act, tctrl[h]);
     }
   }
+  LPROF(pa, prof_last, 29);
   // ComputeInterpolationValues (tracking.cc:29-38)
   const int start = tk.ri[0], last = tk.ri[1];
   const R kFps = 30;
@@ -1359,33 +1389,34 @@ LRESID_ATTR R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, in
   const int k0 = (int)floor(clamped);
   const int k1 = k0 + 1 < last ? k0 + 1 : last;
   const R w1 = clamped - R(k0), w0 = R(1) - w1;
-  R am[3] = {0, 0, 0}, as[3] = {0, 0, 0};
-  for (int s = 0; s < kLS; s++) {
+  R mp[kLS][3], dv[kLS][3], am[3] = {0, 0, 0}, as[3] = {0, 0, 0};
+  LUNROLL for (int s = 0; s < kLS; s++) {   // (unrolled: the four sites' twenty-four key loads are in flight together)
     const LSiteT<R>& St = L.site[s];
-    if (!St.on) continue;
-    const R* key0 = tk.key_mpos + ((size_t)m.nmocap * k0 + St.mocap) * 3;
-    const R* key1 = tk.key_mpos + ((size_t)m.nmocap * k1 + St.mocap) * 3;
+    const int mc = St.on ? St.mocap : 0;
+    const R* key0 = tk.key_mpos + ((size_t)m.nmocap * k0 + mc) * 3;
+    const R* key1 = tk.key_mpos + ((size_t)m.nmocap * k1 + mc) * 3;
     LUNROLL for (int k = 0; k < 3; k++) {
-      R v = key0[k] * w0;
-      v += key1[k] * w1;
-      am[k] += v; as[k] += f.spos[s][k];
+      const R a0 = key0[k], a1 = key1[k];
+      R v = a0 * w0;
+      v += a1 * w1;
+      mp[s][k] = v;
+      dv[s][k] = (a1 - a0) * kFps - f.svel[s][k];
+      am[k] += St.on ? v : R(0); as[k] += St.on ? f.spos[s][k] : R(0);
     }
   }
   LUNROLL for (int k = 0; k < 3; k++) { am[k] = qd_sum(am[k]) * (R(1) / 16); as[k] = qd_sum(as[k]) * (R(1) / 16); }
-  if (L.owns_trunk_rows) { for (int k = 0; k < 3; k++) entry(c0 + k, k == 0 ? am[0] - as[0] : (k == 1 ? am[1] - as[1] : am[2] - as[2])); }
-  for (int s = 0; s < kLS; s++) {
+  LPROF(pa, prof_last, 30);
+  if (L.owns_trunk_rows) { const LTerm<R> ta = term_of(m, tk, m.t_avg); LUNROLL for (int k = 0; k < 3; k++) entry(ta, c0 + k, am[k] - as[k]); }
+  LUNROLL for (int s = 0; s < kLS; s++) {
     const LSiteT<R>& St = L.site[s];
     if (!St.on) continue;
-    const R* key0 = tk.key_mpos + ((size_t)m.nmocap * k0 + St.mocap) * 3;
-    const R* key1 = tk.key_mpos + ((size_t)m.nmocap * k1 + St.mocap) * 3;
-    for (int k = 0; k < 3; k++) {
-      R v = key0[k] * w0;
-      v += key1[k] * w1;
-      const R amk = k == 0 ? am[0] : (k == 1 ? am[1] : am[2]), ask = k == 0 ? as[0] : (k == 1 ? as[1] : as[2]);
-      entry(c0 + 3 + 3 * St.marker + k, (v - amk) - (f.spos[s][k] - ask));
-      entry(c0 + 51 + 3 * St.marker + k, (key1[k] - key0[k]) * kFps - f.svel[s][k]);
+    const LTerm<R> tp = term_of(m, tk, St.tpos), tw = term_of(m, tk, St.tvel);
+    LUNROLL for (int k = 0; k < 3; k++) {
+      entry(tp, c0 + 3 + 3 * St.marker + k, (mp[s][k] - am[k]) - (f.spos[s][k] - as[k]));
+      entry(tw, c0 + 51 + 3 * St.marker + k, dv[s][k]);
     }
   }
+  LPROF(pa, prof_last, 31);
   cost = qd_sum(cost);
   if (!(fabs(tk.risk) < R(1.0e-6))) cost = (exp(tk.risk * cost) - R(1)) / tk.risk;
   return cost;
@@ -1527,7 +1558,10 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
     LPROF(a, prof_last, 1);
     // the sensor stage (residual, cost, traces) does not depend on the constraint solve: evaluated and recorded first
     R* rs = a.residual + ((size_t)cand * H + t) * m.nr;
-    const R cost = residual_cost(m, &tk, lane, &S, ctrl, tctrl, &f, rs);
+#ifdef LEXP_NO_RESID_STORE
+    rs = nullptr;
+#endif
+    const R cost = residual_cost(m, &tk, lane, &S, ctrl, tctrl, &f, rs, a.stamps);
     {
       R* st = a.states + ((size_t)cand * H + t) * ds;
       R* ac = a.actions + ((size_t)cand * H + t) * nu;

@@ -774,6 +774,7 @@ hipError_t launch_limb(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>
     std::fprintf(stderr, "  line-search derivative evaluations of candidate 0: %lld\n", h[16]);
     std::fprintf(stderr, "  forward: kinematics+inertias %lld M %lld velocity+bias %lld factor+solve %lld sites %lld rows %lld floor %lld pairs %lld pair list %lld\n",
                  h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27], h[28]);
+    std::fprintf(stderr, "  residual: joint entries %lld marker averages %lld marker entries %lld\n", h[29], h[30], h[31]);
   }
   if (c->timing && c->cur_main) { if ((e = hipEventRecord(c->cur_main, c->stream)) == hipSuccess) c->cur_main = nullptr; else return e; }
   if (c->limb_no_fallback) return hipSuccess;

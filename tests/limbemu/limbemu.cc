@@ -190,7 +190,7 @@ int forward_impl(const mjpcx_model* model, const mjpcx_task* task, const double*
     int fl = forward_smooth(m, lane, &S, ctrl, tctrl, cs, ms, sh, ks, &D, &f, (long long*)nullptr);
     flags_out[lane] = fl;
     if (fl) return;
-    const R cost = residual_cost(m, &b->tk, lane, &S, ctrl, tctrl, &f, res.data());
+    const R cost = residual_cost(m, &b->tk, lane, &S, ctrl, tctrl, &f, res.data(), (long long*)nullptr);
     LNewtonOut<R> io;
     fl = newton(m, lane, ks, ms, &D, &S, cs, sh, warm != nullptr, &io, (long long*)nullptr);
     flags_out[lane] = fl;
