@@ -106,6 +106,7 @@ template <typename R> __device__ __forceinline__ void lsh_get_cross(const mjpcx:
 #define LNOINLINE __device__ __noinline__
 #endif
 #define LREC(dst, v) __builtin_nontemporal_store((v), &(dst))
+#define LUNIFORM(i) __builtin_amdgcn_readfirstlane(i)
 // phase cycle stamps of wavefront 0 (a.stamps != nullptr: MJPCX_LIMB_STAMPS=1): [idx] += cycles since the previous stamp; idx -1 starts the clock
 #define LPROF(a, last, idx) do { if ((a).stamps && blockIdx.x == 0 && threadIdx.x < 64) { const long long now_ = __builtin_readcyclecounter(); \
     if ((idx) >= 0 && (threadIdx.x & 63) == 0) (a).stamps[(idx) < 0 ? 0 : (idx)] += now_ - (last); (last) = now_; } } while (0)

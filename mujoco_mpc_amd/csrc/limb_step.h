@@ -66,6 +66,9 @@
 // with copies its DEVICE build produced wrong states (the emulator's did not; not understood), and they would save 300 accesses in 30 k
 // instructions.
 #endif
+#ifndef LUNIFORM
+#define LUNIFORM(i) (i)   // (the device build: an int known to be the same in every lane, moved to a scalar register)
+#endif
 #ifndef LPOISON
 #define LPOISON(x)   // (the emulator fills fresh locals with NaN patterns: a read before a write shows)
 #endif
@@ -75,6 +78,11 @@
 #endif
 #ifndef LEXP_LFLOOR
 #define LEXP_LFLOOR 16
+#endif
+#ifdef LEXP_XSTAMPS
+#define LXPROF(a, last, idx) LPROF(a, last, idx)
+#else
+#define LXPROF(a, last, idx)
 #endif
 #ifndef LPROF
 #define LPROF(a, last, idx)   // phase cycle stamps of wavefront 0 (the device build: limb_kernel.h)
@@ -87,6 +95,8 @@ enum { kFlagOverflow = 1, kFlagCross = 2, kFlagNotPD = 4, kFlagBad = 8, kFlagLim
 constexpr int kLsTolInv = 100;  // mjOption.ls_tolerance = 0.01
 
 // ---------------------------------------------------------------- small algebra
+LD void lsincos(double x, double& s, double& c) { sincos(x, &s, &c); }   // (one range reduction for the pair)
+LD void lsincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
 template <typename R> LD bool lbad(R x) { return !(x <= R(1e10) && x >= R(-1e10)); }
 template <typename R> LD void q_mul(R* r, const R* a, const R* b) {
   const R w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
@@ -316,6 +326,10 @@ template <typename R, class KIN> LD void chain_velocity(const KIN& k, int attach
     LUNROLL for (int b = 0; b < kLB; b++) VL[b][c] = base + VR[b][c];
   }
 }
+// one of six bodies' values (the limb's three, the trunk's three) by 0 / 1 weights: a five-deep chain of ?: on a lane's own index is compiled
+// into BRANCHES (the four sites and two traces of a step were 970 of them, 22 k cycles), the weights into a multiply-add per source
+template <typename R> LD void pick6_weights(int d, R* w) { LUNROLL for (int i = 0; i < 6; i++) w[i] = d == i ? R(1) : R(0); }
+template <typename R> LD R pick6(const R* w, R a0, R a1, R a2, R a3, R a4, R a5) { return w[0] * a0 + w[1] * a1 + w[2] * a2 + w[3] * a3 + w[4] * a4 + w[5] * a5; }
 template <typename R> LD void pick3(const R V[3][6], int d, R* out) {  // V[d] by 0 / 1 weights (no run-time index into registers)
   const R w0 = d == 0 ? R(1) : R(0), w1 = d == 1 ? R(1) : R(0), w2 = d == 2 ? R(1) : R(0);
   LUNROLL for (int c = 0; c < 6; c++) out[c] = w0 * V[0][c] + w1 * V[1][c] + w2 * V[2][c];
@@ -401,7 +415,7 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
     q_rot(axis, J.axis, xquat);
     const R ang = q - J.qpos0;
     R ql[4] = {1, 0, 0, 0};
-    if (ang != 0) { const R s = sin(R(0.5) * ang), c = cos(R(0.5) * ang); ql[0] = c; ql[1] = J.axis[0] * s; ql[2] = J.axis[1] * s; ql[3] = J.axis[2] * s; }
+    if (ang != 0) { R s, c; lsincos(R(0.5) * ang, s, c); ql[0] = c; ql[1] = J.axis[0] * s; ql[2] = J.axis[1] * s; ql[3] = J.axis[2] * s; }
     R nq[4];
     q_mul(nq, xquat, ql);
     LUNROLL for (int k = 0; k < 4; k++) xquat[k] = nq[k];
@@ -583,33 +597,31 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
   LPROF(pa, prof_last, 22);
   LUNROLL for (int j = 0; j < kLD; j++) { D.fs_l[j] = fs_l[j]; D.sl[j] = fs_l[j]; }
   LUNROLL for (int k = 0; k < kTD; k++) { D.fs_t[k] = fs_t[k]; D.st[k] = fs_t[k]; }
-  {
-    Arrow<R> F;
-    load_arrow(ms, F);
-    if (!arrow_factor(F)) return kFlagNotPD;
-    arrow_solve(F, D.sl, D.st);
-  }
-  LPROF(pa, prof_last, 23);
   // ================= sites (tracking markers), traces
   LUNROLL for (int s = 0; s < kLS; s++) {
     const LSiteT<R>& St = L.site[s];
     const int b = St.body;
     R bp[3], bm[9], cv[6];
-    LUNROLL for (int k = 0; k < 3; k++) bp[k] = b == 0 ? xpos[0][k] : (b == 1 ? xpos[1][k] : (b == 2 ? xpos[2][k] : (b == 3 ? tpos[0][k] : (b == 4 ? tpos[1][k] : tpos[2][k]))));
-    LUNROLL for (int k = 0; k < 9; k++) bm[k] = b == 0 ? xmat[0][k] : (b == 1 ? xmat[1][k] : (b == 2 ? xmat[2][k] : (b == 3 ? tmat[0][k] : (b == 4 ? tmat[1][k] : tmat[2][k]))));
-    LUNROLL for (int k = 0; k < 6; k++) cv[k] = b == 0 ? VLq[0][k] : (b == 1 ? VLq[1][k] : (b == 2 ? VLq[2][k] : (b == 3 ? VTq[0][k] : (b == 4 ? VTq[1][k] : VTq[2][k]))));
-    R v[3], off[3], lin[3];
+    R pw[6];
+    pick6_weights(b, pw);
+    LUNROLL for (int k = 0; k < 3; k++) bp[k] = pick6(pw, xpos[0][k], xpos[1][k], xpos[2][k], tpos[0][k], tpos[1][k], tpos[2][k]);
+    LUNROLL for (int k = 0; k < 9; k++) bm[k] = pick6(pw, xmat[0][k], xmat[1][k], xmat[2][k], tmat[0][k], tmat[1][k], tmat[2][k]);
+    LUNROLL for (int k = 0; k < 6; k++) cv[k] = pick6(pw, VLq[0][k], VLq[1][k], VLq[2][k], VTq[0][k], VTq[1][k], VTq[2][k]);
+    R v[3], off[3], lin[3], sp[3];
     mv3(v, bm, St.pos);
-    LUNROLL for (int k = 0; k < 3; k++) { out.spos[s][k] = bp[k] + v[k]; off[k] = out.spos[s][k] - com[k]; }
+    LUNROLL for (int k = 0; k < 3; k++) { sp[k] = bp[k] + v[k]; off[k] = sp[k] - com[k]; out.spos[s][k] = sp[k]; }
     cr3(lin, cv, off);
     LUNROLL for (int k = 0; k < 3; k++) out.svel[s][k] = cv[3 + k] + lin[k];
   }
+  LXPROF(pa, prof_last, 35);
   LUNROLL for (int q = 0; q < kMaxTrace; q++) {
     const LTraceT<R>& T = m.trace[q];
     const int b = T.lane == 4 ? 3 + T.body : T.body;
     R bp[3], bm[9], v[3];
-    LUNROLL for (int k = 0; k < 3; k++) bp[k] = b == 0 ? xpos[0][k] : (b == 1 ? xpos[1][k] : (b == 2 ? xpos[2][k] : (b == 3 ? tpos[0][k] : (b == 4 ? tpos[1][k] : tpos[2][k]))));
-    LUNROLL for (int k = 0; k < 9; k++) bm[k] = b == 0 ? xmat[0][k] : (b == 1 ? xmat[1][k] : (b == 2 ? xmat[2][k] : (b == 3 ? tmat[0][k] : (b == 4 ? tmat[1][k] : tmat[2][k]))));
+    R pw[6];
+    pick6_weights(b, pw);
+    LUNROLL for (int k = 0; k < 3; k++) bp[k] = pick6(pw, xpos[0][k], xpos[1][k], xpos[2][k], tpos[0][k], tpos[1][k], tpos[2][k]);
+    LUNROLL for (int k = 0; k < 9; k++) bm[k] = pick6(pw, xmat[0][k], xmat[1][k], xmat[2][k], tmat[0][k], tmat[1][k], tmat[2][k]);
     mv3(v, bm, T.pos);
     LUNROLL for (int k = 0; k < 3; k++) out.trace[q][k] = bp[k] + v[k];
   }
@@ -824,6 +836,16 @@ LD int forward_smooth_body(const LimbModelT<R>& m, int lane, const LState<R>& S,
   LPROF(pa, prof_last, 28);
   if (nx > kMaxX) nx = 0;
   D.nx = nx;
+  // ================= qacc_smooth = M^-1 qfrc_smooth: LAST -- the factor's hundred and twenty numbers push whatever else is alive out of the
+  // registers, and the sites, rows and collision stages above all read the body frames (with the factor in its place after the bias forces
+  // the four sites alone took 22 k cycles a step re-fetching them)
+  {
+    Arrow<R> F;
+    load_arrow(ms, F);
+    if (!arrow_factor(F)) flags |= kFlagNotPD;
+    arrow_solve(F, D.sl, D.st);
+  }
+  LPROF(pa, prof_last, 23);
   flags = qd_or(flags);
   return flags;
 }
@@ -1036,6 +1058,7 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
           H.l[tri(i, j)] += Rw.tn_D * ci * cj;
         }
       }
+      LXPROF(pa, prof_last, 32);
       if (qw_any(ncon > 0)) {
         // the contacts' 6 x 6 blocks by body: nearly every contact is on the limb's LAST body (a foot, a hand), so one block is accumulated in
         // the pass over the contacts and the other two bodies get a pass of their own only when some lane of the wavefront holds such a contact
@@ -1043,13 +1066,14 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
         LUNROLL for (int b = 0; b < kLB; b++) LUNROLL for (int e = 0; e < 21; e++) X[b][e] = 0;
         bool shallow = false;
         auto contact_block = [&](const LContact<R>& C, R* Xc) {
+          // (no branch per row: the wavefront runs the union of its lanes' rows anyway, and an inactive row enters with weight zero)
           LUNROLL for (int e = 0; e < 4; e++) {
-            if (e >= C.nrow || !(C.jar[e] < 0)) continue;
+            const R d = (e < C.nrow && C.jar[e] < 0) ? C.D : R(0);
             const R s1 = C.nrow == 1 ? R(0) : (e == 0 ? C.mu : (e == 1 ? -C.mu : R(0))), s2 = C.nrow == 1 ? R(0) : (e == 2 ? C.mu : (e == 3 ? -C.mu : R(0)));
             R a[6];
             LUNROLL for (int k = 0; k < 3; k++) a[3 + k] = m.plane_n[k] + s1 * m.plane_t1[k] + s2 * m.plane_t2[k];
             cr3(a, C.off, a + 3);
-            sym6_add_outer(Xc, C.D, a);
+            sym6_add_outer(Xc, d, a);
           }
         };
         for (int i = 0; i < ncon; i++) {
@@ -1072,12 +1096,17 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
         } else {
           LUNROLL for (int e = 0; e < 21; e++) { X[1][e] = X[2][e]; X[0][e] = X[2][e]; }
         }
+        LXPROF(pa, prof_last, 33);
+        // (the trunk dofs below the limb's attachment do not move it: weight zero instead of a branch per entry; the free joint's six always do)
+        R wanc[kTD];
+        LUNROLL for (int k = 0; k < kTD; k++) wanc[k] = (k < 6 || k < L.nanc) ? R(1) : R(0);
         LUNROLL for (int i = 0; i < kLD; i++) {
           R Y[6];
           sym6_mul(Y, X[slot_body(i)], kin.cdof[i]);
           LUNROLL for (int j = 0; j <= i; j++) H.l[tri(i, j)] += dot6(kin.cdof[j], Y);
-          LUNROLL for (int k = 0; k < kTD; k++) if (k < L.nanc) H.b[i][k] += dot6(kin.cdofT[k], Y);
+          LUNROLL for (int k = 0; k < kTD; k++) H.b[i][k] += wanc[k] * dot6(kin.cdofT[k], Y);
         }
+        LXPROF(pa, prof_last, 34);
         R XT[21];
         LUNROLL for (int e = 0; e < 21; e++) XT[e] = 0;
         LUNROLL for (int i = kTB - 1; i >= 0; i--) {
@@ -1211,27 +1240,37 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
         LUNROLL for (int r = 0; r < kMaxX; r++) { const R x = xx0[r] + a * xv[r]; const bool on = x < 0; gT += on ? xDv[r] * x * xv[r] : R(0); hT += on ? xDv[r] * xv[r] * xv[r] : R(0); }
         d1 = qd_sum(g) + gT; d2 = qd_sum(h) + hT;
       };
-      // (one call site of the derivative evaluation: the first pass is the evaluation at alpha = 0)
+      // (one call site of the derivative evaluation: the first pass is the evaluation at alpha = 0.) The loop runs until no candidate of the
+      // WAVEFRONT is still searching -- one uniform branch per pass; what a candidate's own exits were (its step stopped moving alpha, the
+      // derivative below the tolerance or its floor) freezes its alpha through selects. The wavefront ran the longest search before, too.
       R lo = 0, hi = -1, d1 = 0, d2 = 1, d10 = 0;
       R step1 = R(1e30), step2 = R(1e30);
+      bool done = false;
       for (int ls = -1; ls < 50; ls++) {
+        if (!qw_any(!done)) break;
         if (ls >= 0) {
           R an = alpha - d1 / d2;
-          if (!(an > lo) || (hi >= 0 && !(an < hi))) an = hi >= 0 ? R(0.5) * (lo + hi) : 2 * alpha + 1;
-          else if (hi >= 0 && fabs(an - alpha) > R(0.5) * step2) an = R(0.5) * (lo + hi);
-          if (an == alpha) break;
-          step2 = step1; step1 = fabs(an - alpha);
-          alpha = an;
+          const bool outside = !(an > lo) || (hi >= 0 && !(an < hi));
+          const R mid = R(0.5) * (lo + hi);
+          an = outside ? (hi >= 0 ? mid : 2 * alpha + 1) : ((hi >= 0 && fabs(an - alpha) > R(0.5) * step2) ? mid : an);
+          done = done || an == alpha;
+          step2 = done ? step2 : step1; step1 = done ? step1 : fabs(an - alpha);
+          alpha = done ? alpha : an;
         }
-        derivs(alpha, d1, d2);
-        if (pa.stamps) LPROF_COUNT(pa, 16);
-        d1 += q1 + alpha * q2; d2 += q2;
-        if (ls < 0) { d10 = fabs(d1); if (!(d10 >= gtol)) break; continue; }
+        R e1, e2;
+        derivs(alpha, e1, e2);
+        if (pa.stamps && !done) LPROF_COUNT(pa, 16);
+        e1 += q1 + alpha * q2; e2 += q2;
+        if (ls < 0) { d1 = e1; d2 = e2; d10 = fabs(d1); done = !(d10 >= gtol); continue; }
         // (the tolerance, or the working precision's floor under it: a derivative that is the rounding residue of its start value -- its terms
         // cancel at the minimum -- cannot be reduced further. In float the tolerance lies below that floor and the search would otherwise run
         // until its steps stop moving alpha: nine evaluations per search instead of three)
-        if (fabs(d1) < gtol || fabs(d1) <= LEXP_LFLOOR * kEps<R>() * d10) break;
-        if (d1 < 0) lo = alpha; else hi = alpha;
+        const bool live = !done;
+        d1 = live ? e1 : d1; d2 = live ? e2 : d2;
+        const bool conv = fabs(e1) < gtol || fabs(e1) <= LEXP_LFLOOR * kEps<R>() * d10;
+        lo = (live && !conv && e1 < 0) ? alpha : lo;
+        hi = (live && !conv && !(e1 < 0)) ? alpha : hi;
+        done = done || conv;
       }
     }
     LPROF(pa, prof_last, 13);
@@ -1511,35 +1550,44 @@ LD int rollout(const LimbModelT<R>& m, const LTask<R>& tk, const R* state0, R ti
       const R now = S.time;
       while (up < P && a.node_times[up] <= now) up++;  // (time only moves forward: the search resumes where the last step's ended)
       R mine[kLD + 3];
-      LUNROLL for (int e = 0; e < kLD + 3; e++) {
-        const int ua = act_of(e);
-        mine[e] = 0;
-        if (ua < 0) continue;
-        R u;
-        if (up == P || up == 0) u = LNODE(up == 0 ? 0 : P - 1, ua);
-        else {
-          const int lo = up - 1;
-          const R tl = a.node_times[lo], tu = a.node_times[up];
-          const R p0 = LNODE(lo, ua), p1 = LNODE(up, ua);
-          if (a.interp == 0) u = p0;
-          else {
-            const R s = (S.time - tl) / (tu - tl);
-            if (a.interp == 1) u = p0 * (1 - s) + p1 * s;
-            else {
-              const R dt_mid = tu - tl, fwd = (p1 - p0) / dt_mid;
-              R m0, m1;
-              if (lo == 0) m0 = fwd;
-              else m0 = R(0.5) * (p1 - p0) / dt_mid + R(0.5) * (p0 - LNODE(lo - 1, ua)) / (tl - a.node_times[lo - 1]);
-              if (up == P - 1) m1 = fwd;
-              else m1 = R(0.5) * (LNODE(up + 1, ua) - p1) / (a.node_times[up + 1] - tu) + R(0.5) * (p1 - p0) / dt_mid;
-              const R s2 = s * s, s3 = s * s * s;
-              const R c0 = 2 * s3 - 3 * s2 + 1, c1 = (s3 - 2 * s2 + s) * (tu - tl), c2 = -2 * s3 + 3 * s2, c3 = (s3 - s2) * (tu - tl);
-              u = c0 * p0 + c1 * m0 + c2 * p1 + c3 * m1;
-            }
-          }
+      {
+        // every candidate of a launch runs on the same clock (state0's time + t steps), so the interval is the same in all lanes: its index
+        // goes to a scalar register, the node times are read once, and the lane's node values -- up to four per actuator for the cubic --
+        // are fetched together before anything waits for them (fetched inside the per-actuator arithmetic they were 40 k cycles a step)
+        const int upu = LUNIFORM(up);
+        const bool edge = upu == P || upu == 0;
+        const int lo = edge ? (upu == 0 ? 0 : P - 1) : upu - 1, hi = edge ? lo : upu;
+        const int im = lo > 0 ? lo - 1 : 0, ip = hi + 1 < P ? hi + 1 : P - 1;
+        R pm[kLD + 3], p0[kLD + 3], p1[kLD + 3], p2[kLD + 3];
+        LUNROLL for (int e = 0; e < kLD + 3; e++) {
+          const int ua = act_of(e), uu = ua < 0 ? 0 : ua;
+          p0[e] = LNODE(lo, uu); p1[e] = LNODE(hi, uu);
+          pm[e] = p0[e]; p2[e] = p1[e];
+          if (a.interp >= 2 && !edge) { pm[e] = LNODE(im, uu); p2[e] = LNODE(ip, uu); }
         }
-        bad |= lbad(u);
-        mine[e] = clampr(u, lo_of(e), hi_of(e));
+        const R tl = a.node_times[lo], tu = a.node_times[hi], tp = a.node_times[im], tn = a.node_times[ip];
+        const R s = edge ? R(0) : (S.time - tl) / (tu - tl), dt_mid = tu - tl;
+        const R s2 = s * s, s3 = s * s * s;
+        const R c0 = 2 * s3 - 3 * s2 + 1, c1 = (s3 - 2 * s2 + s) * (tu - tl), c2 = -2 * s3 + 3 * s2, c3 = (s3 - s2) * (tu - tl);
+        LUNROLL for (int e = 0; e < kLD + 3; e++) {
+          const int ua = act_of(e);
+          mine[e] = 0;
+          if (ua < 0) continue;
+          R u;
+          if (edge || a.interp == 0) u = p0[e];
+          else if (a.interp == 1) u = p0[e] * (1 - s) + p1[e] * s;
+          else {
+            const R fwd = (p1[e] - p0[e]) / dt_mid;
+            R m0, m1;
+            if (lo == 0) m0 = fwd;
+            else m0 = R(0.5) * (p1[e] - p0[e]) / dt_mid + R(0.5) * (p0[e] - pm[e]) / (tl - tp);
+            if (hi == P - 1) m1 = fwd;
+            else m1 = R(0.5) * (p2[e] - p1[e]) / (tn - tu) + R(0.5) * (p1[e] - p0[e]) / dt_mid;
+            u = c0 * p0[e] + c1 * m0 + c2 * p1[e] + c3 * m1;
+          }
+          bad |= lbad(u);
+          mine[e] = clampr(u, lo_of(e), hi_of(e));
+        }
       }
       LUNROLL for (int j = 0; j < kLD; j++) ctrl[j] = mine[j];
       // the trunk's controls reach every lane from the one that evaluated their splines

@@ -760,7 +760,7 @@ hipError_t launch_limb(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>
   }
   if ((e = limb::launch_rollout_limb(c->d_limb.p, wt.blob, bo, q, wm.key_mpos, (int*)c->d_qstats.p, c->stream)) != hipSuccess) return e;
   if (stamps) {
-    long long h[32];
+    long long h[64];
     std::vector<int> it((size_t)N);
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemcpy(h, c->d_qstamps.p, sizeof h, hipMemcpyDeviceToHost);
@@ -775,6 +775,8 @@ hipError_t launch_limb(mjpcx_ctx* c, const WaveModelT<T>& wm, const WaveTaskT<T>
     std::fprintf(stderr, "  forward: kinematics+inertias %lld M %lld velocity+bias %lld factor+solve %lld sites %lld rows %lld floor %lld pairs %lld pair list %lld\n",
                  h[20], h[21], h[22], h[23], h[24], h[25], h[26], h[27], h[28]);
     std::fprintf(stderr, "  residual: joint entries %lld marker averages %lld marker entries %lld\n", h[29], h[30], h[31]);
+    if (h[32] | h[33] | h[34] | h[35] | h[36] | h[37] | h[38] | h[39])  // (stamps a tuning build adds: -DLEXP_XSTAMPS)
+      std::fprintf(stderr, "  raw 32..39: %lld %lld %lld %lld %lld %lld %lld %lld\n", h[32], h[33], h[34], h[35], h[36], h[37], h[38], h[39]);
   }
   if (c->timing && c->cur_main) { if ((e = hipEventRecord(c->cur_main, c->stream)) == hipSuccess) c->cur_main = nullptr; else return e; }
   if (c->limb_no_fallback) return hipSuccess;
