@@ -1378,8 +1378,19 @@ template <typename R> LNORM_ATTR R norm_entry(R x, int type, R p, R q) {
 }
 // writes the lane's entries of residual row `rs` (nullptr: cost only) and returns the step's cost (the same in the four lanes)
 // (one term's parameters, read once for all the entries of the term that a lane holds: weight, norm type, its two parameters)
-template <typename R> struct LTerm { R w, p, q; int type; };
-template <typename R> LD LTerm<R> term_of(const LimbModelT<R>& m, const LTask<R>& tk, int t) { return LTerm<R>{tk.weight[t], tk.norm_p[t], tk.norm_q[t], m.term_norm[t]}; }
+// kind: 0 quadratic, 1 the smooth-abs family -- sqrt(x^2 + p^2) - p, or (x^4 + p^4)^(1/4) - p (`four`) --, 2 anything else. The first two are
+// evaluated in line when every lane of the wavefront holds such a term at the call site (the tracking task: all but the controls' cosh):
+// thirty of a lane's thirty-six entries then cost a handful of instructions instead of a call into the switch over the norm types
+// (term_of is called where all four lanes of a candidate are: it asks the wavefront)
+template <typename R> struct LTerm { R w, p, q; int type, mode; bool four; };
+template <typename R> LD LTerm<R> term_of(const LimbModelT<R>& m, const LTask<R>& tk, int t, bool on = true) {  // (on: does this lane use the term)
+  LTerm<R> r{tk.weight[t], tk.norm_p[t], tk.norm_q[t], m.term_norm[t], 2, false};
+  r.four = r.type == 7 && r.q == 4;
+  const int kind = r.type == 0 ? 0 : ((r.type == 6 || (r.type == 7 && (r.q == 2 || r.q == 4))) ? 1 : 2);
+  const bool all0 = !qw_any(on && kind != 0), all1 = !qw_any(on && kind != 1);
+  r.mode = all0 ? 0 : (all1 ? 1 : 2);
+  return r;
+}
 template <typename R, class T>
 LRESID_ATTR R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, int lane, const LState<R>* S_in, const R* ctrl_in, const R* tctrl_in, const LSense<R>* f_in, T* rs, long long* stamps) {
   const LimbModelT<R>& m = LREBIND_LDS(LimbModelT<R>, m_in);
@@ -1401,7 +1412,14 @@ LRESID_ATTR R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, in
   // average, one position and one velocity term per marker: limb_model.h bakes the marker terms into the sites), so a term's weight and norm
   // parameters are read once for its entries instead of through a chain of look-ups per entry (that chain was 2 k cycles an entry).
   auto entry = [&](const LTerm<R>& t, int idx, R x) {
-    cost += t.w * norm_entry(x, t.type, t.p, t.q);
+    R v;
+    if (t.mode == 0) v = R(0.5) * x * x;
+    else if (t.mode == 1) {
+      const R x2 = x * x, p2 = t.p * t.p;
+      const R r2 = sqrt(x2 + p2), r4 = sqrt(sqrt(x2 * x2 + p2 * p2));
+      v = (t.four ? r4 : r2) - t.p;
+    } else v = norm_entry(x, t.type, t.p, t.q);
+    cost += t.w * v;
     if (rs) LREC(rs[idx], (T)x);
   };
   const LTerm<R> tv = term_of(m, tk, m.t_qvel), tc = term_of(m, tk, m.t_ctrl);
@@ -1445,11 +1463,12 @@ LRESID_ATTR R residual_cost(const LimbModelT<R>& m_in, const LTask<R>* tk_in, in
   }
   LUNROLL for (int k = 0; k < 3; k++) { am[k] = qd_sum(am[k]) * (R(1) / 16); as[k] = qd_sum(as[k]) * (R(1) / 16); }
   LPROF(pa, prof_last, 30);
-  if (L.owns_trunk_rows) { const LTerm<R> ta = term_of(m, tk, m.t_avg); LUNROLL for (int k = 0; k < 3; k++) entry(ta, c0 + k, am[k] - as[k]); }
+  const LTerm<R> ta = term_of(m, tk, m.t_avg);
+  if (L.owns_trunk_rows) { LUNROLL for (int k = 0; k < 3; k++) entry(ta, c0 + k, am[k] - as[k]); }
   LUNROLL for (int s = 0; s < kLS; s++) {
     const LSiteT<R>& St = L.site[s];
+    const LTerm<R> tp = term_of(m, tk, St.on ? St.tpos : 0, St.on), tw = term_of(m, tk, St.on ? St.tvel : 0, St.on);
     if (!St.on) continue;
-    const LTerm<R> tp = term_of(m, tk, St.tpos), tw = term_of(m, tk, St.tvel);
     LUNROLL for (int k = 0; k < 3; k++) {
       entry(tp, c0 + 3 + 3 * St.marker + k, (mp[s][k] - am[k]) - (f.spos[s][k] - as[k]));
       entry(tw, c0 + 51 + 3 * St.marker + k, dv[s][k]);
