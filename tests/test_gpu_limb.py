@@ -46,12 +46,14 @@ def limb_context(pm, pt, precision, min_n=0):
     return ctx
 
 
-def run(walk, N, H, P, interp, seed, precision, tol, std=0.3, time=0.0):
+def run(walk, N, H, P, interp, seed, precision, tol, std=0.3, time=0.0, node_span=None):
     t, state, mocap = walk
     pm, pt = t.packed_model(), t.packed()
     rng = np.random.default_rng(seed)
     dt = t.model.get_number("agent_timestep", t.model.timestep)
     times = time + np.arange(P) * max((H - 1) * dt / max(P - 1, 1), 1e-3)
+    if node_span is not None:   # (first node, last node) in steps after the rollout's start: the spline's two constant ends are exercised
+        times = time + dt * np.linspace(node_span[0], node_span[1], P)
     nodes = np.clip(rng.normal(0, std, (N, P, t.model.nu)), -1, 1)
     ctx = limb_context(pm, pt, precision)
     ctx.set_state(state, time, mocap)
@@ -82,6 +84,15 @@ def test_walk_first_steps_fp64(walk):
 def test_walk_sixty_four_steps_fp64(walk, interp):
     worst, st = run(walk, N=32, H=64, P=16, interp=interp, seed=2 + interp, precision=64, tol=1e-7)
     assert st["handed_on"] <= 2   # (noise of std 0.3 on every node: a candidate or two may end up outside the limb form)
+
+
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_rollout_longer_than_the_spline_on_both_sides(walk, interp):
+    """TimeSpline::Sample before the first node and after the last one returns the end nodes (spline.cc): the rollout starts 6.5 steps before
+    the first node and runs 10 steps past the last -- the limb kernel takes the interval index from one lane for the whole wavefront and
+    fetches the interval's nodes unconditionally, so both ends and the one-sided cubic slopes next to them are worth their own case"""
+    worst, st = run(walk, N=16, H=40, P=6, interp=interp, seed=11 + interp, precision=64, tol=1e-8, std=0.2, node_span=(6.5, 29.0))
+    assert st["handed_on"] == 0
 
 
 def test_walk_fp32_returns(walk):

@@ -94,6 +94,26 @@ def test_rollouts_against_the_oracle(walk, precision, tol_traj, tol_ret):
         assert out["iters"].mean() <= ref64["iters"].mean() + (H - 1)
 
 
+@pytest.mark.parametrize("interp", [0, 1, 2])
+def test_rollout_longer_than_the_spline_on_both_sides(walk, interp):
+    """the rollout starts 6.5 steps before the first spline node and runs 10 past the last: the constant ends of TimeSpline::Sample and the
+    one-sided cubic slopes next to them, in every interpolation"""
+    t, state, mocap = walk
+    pm, pt = t.packed_model(), t.packed()
+    m = t.model
+    N, H, P = 8, 40, 6
+    dt = m.get_number("agent_timestep", m.timestep)
+    times = dt * np.linspace(6.5, 29.0, P)
+    nominal = np.clip(np.random.default_rng(21 + interp).normal(0, 0.2, (P, m.nu)), -1, 1)
+    ns = capi.make_noise_spec(seed=5, iteration=1, mode=capi.NOISE_SAMPLING, std0=0.1)
+    nodes = pyoracle.noise_candidates(pm, ns, P, nominal, np.arange(N))
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, N, H, P, interp, times, nodes, num_threads=8)
+    out = limbemu.rollout(pm, pt, state, 0.0, mocap, N, H, P, interp, times, noise=ns, nominal=nominal, precision=64)
+    assert not out["flags"].any() and not ref["failure"].any()
+    for name in ("states", "actions", "residual", "costs"):
+        assert rel(out[name], ref[name]) < 1e-9, name
+
+
 def test_wild_candidates_are_flagged_not_approximated(walk):
     """noise of std 1 on four nodes: some candidates leave the limb form (the trunk on the floor, more contacts than slots); the emulator flags
     them (the device hands them to rollout_tree_kernel<Humanoid>) and every unflagged one still equals the oracle"""
