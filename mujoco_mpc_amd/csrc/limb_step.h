@@ -308,6 +308,13 @@ template <typename R> struct LState {
 };
 // the position-dependent part of a forward pass that the constraint solve needs: dof axes about the centre of mass
 template <typename R> struct LKin { R cdof[kLD][6], cdofT[kTD][6]; };
+// The free joint's three translations are unit vectors in world axes -- cdofT[k] = e_(3+k) for k < 3 --, which the solver, reading the axes from
+// the includer's store, cannot know: products with them are picked, not computed (k is a compile-time index wherever these are used)
+template <typename R, class KIN> LD R trunk_dot(const KIN& kin, int k, const R* F) { return k < 3 ? F[3 + k] : dot6(kin.cdofT[k], F); }
+template <typename R, class KIN> LD void trunk_sym6_mul(R* y, const R* X, const KIN& kin, int k) {
+  if (k < 3) { LUNROLL for (int p = 0; p < 6; p++) y[p] = p >= 3 + k ? X[tri(p, 3 + k)] : X[tri(3 + k, p)]; }
+  else sym6_mul(y, X, kin.cdofT[k]);
+}
 
 // spatial velocities [angular; linear about the centre of mass] of the bodies for the dof vector (xl, xt): VT the trunk bodies, VL the
 // limb's, VR the limb's relative to the trunk body it hangs on (what a contact between two moving geoms needs: the common motion never
@@ -315,7 +322,8 @@ template <typename R> struct LKin { R cdof[kLD][6], cdofT[kTD][6]; };
 template <typename R, class KIN> LD void chain_velocity(const KIN& k, int attach, const R* xl, const R* xt, R VT[kTB][6], R VL[kLB][6], R VR[kLB][6]) {
   LUNROLL for (int c = 0; c < 6; c++) {
     R v = 0;
-    LUNROLL for (int d = 0; d < 6; d++) v += k.cdofT[d][c] * xt[d];
+    if (c >= 3) v = xt[c - 3];  // (the translations: see trunk_dot)
+    LUNROLL for (int d = 3; d < 6; d++) v += k.cdofT[d][c] * xt[d];
     VT[0][c] = v;
     VT[1][c] = v + k.cdofT[6][c] * xt[6] + k.cdofT[7][c] * xt[7];
     VT[2][c] = VT[1][c] + k.cdofT[8][c] * xt[8];
@@ -896,9 +904,11 @@ template <typename R, class KIN> LD void cross_vector(const LimbModelT<R>& m, co
 // the four lanes), J' force in jl (the lane's limb dofs) / jt (trunk dofs, replicated).
 template <typename R, class CS, class SH, class KIN>
 LD R rows_eval(const LimbModelT<R>& m, const LimbT<R>& L, int lane, const KIN& kin, LRows<R>& Rw, CS& cs, int ncon, SH& sh, int nx, bool step,
-               const R* xl, const R* xt, R alpha, R* jl, R* jt) {
+               const R* xl, const R* xt, R alpha, R* jl, R* jt, const R (*VLin)[6] = nullptr, const R (*VRin)[6] = nullptr) {
+  // (VLin / VRin: the bodies' velocities along (xl, xt) where the caller has them already -- the line search's, for the step that follows it)
   R VT[kTB][6], VL[kLB][6], VR[kLB][6];
-  if (step) chain_velocity(kin, L.attach, xl, xt, VT, VL, VR);
+  if (VLin) { LUNROLL for (int b = 0; b < kLB; b++) LUNROLL for (int c = 0; c < 6; c++) { VL[b][c] = VLin[b][c]; VR[b][c] = VRin[b][c]; } }
+  else if (step) chain_velocity(kin, L.attach, xl, xt, VT, VL, VR);
   R cost = 0, costT = 0;
   R Fb[kLB][6], Fp[6];
   LUNROLL for (int b = 0; b < kLB; b++) LUNROLL for (int c = 0; c < 6; c++) Fb[b][c] = 0;
@@ -977,7 +987,7 @@ LD R rows_eval(const LimbModelT<R>& m, const LimbT<R>& L, int lane, const KIN& k
         if (m.nattach[i] > 0) v += qd_sum(L.attach == i ? Fp[c] : R(0));
         FT[i][c] = v;
       }
-    LUNROLL for (int k = 0; k < kTD; k++) jt[k] += dot6(kin.cdofT[k], FT[trunk_dof_body(k)]);
+    LUNROLL for (int k = 0; k < kTD; k++) jt[k] += trunk_dot(kin, k, FT[trunk_dof_body(k)]);
   }
   return qd_sum(cost) + costT;
 }
@@ -1104,7 +1114,7 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
           R Y[6];
           sym6_mul(Y, X[slot_body(i)], kin.cdof[i]);
           LUNROLL for (int j = 0; j <= i; j++) H.l[tri(i, j)] += dot6(kin.cdof[j], Y);
-          LUNROLL for (int k = 0; k < kTD; k++) H.b[i][k] += wanc[k] * dot6(kin.cdofT[k], Y);
+          LUNROLL for (int k = 0; k < kTD; k++) H.b[i][k] += wanc[k] * trunk_dot(kin, k, Y);
         }
         LXPROF(pa, prof_last, 34);
         R XT[21];
@@ -1114,8 +1124,8 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
           LUNROLL for (int k = 0; k < kTD; k++) {
             if (trunk_dof_body(k) != i) continue;
             R Y[6];
-            sym6_mul(Y, XT, kin.cdofT[k]);
-            LUNROLL for (int l = 0; l <= k; l++) H.t[tri(k, l)] += dot6(kin.cdofT[l], Y);
+            trunk_sym6_mul(Y, XT, kin, k);
+            LUNROLL for (int l = 0; l <= k; l++) H.t[tri(k, l)] += trunk_dot(kin, l, Y);
           }
         }
       }
@@ -1188,9 +1198,9 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
     LPROF(pa, prof_last, 12);
     // ---- exact line search (oracle: Newton on the derivative in a bracket, rtsafe safeguard)
     R alpha = 0;
+    R VT[kTB][6], VL[kLB][6], VR[kLB][6];  // the bodies' velocities along the direction: the search's and the step's after it
+    chain_velocity(kin, L.attach, hl, ht, VT, VL, VR);
     {
-      R VT[kTB][6], VL[kLB][6], VR[kLB][6];
-      chain_velocity(kin, L.attach, hl, ht, VT, VL, VR);
       // the rows' values and rates: the lane's diagonal rows, its first four floor contacts in registers (further ones from the store)
       R lx0[kLD], lv[kLD], lD[kLD];
       LUNROLL for (int j = 0; j < kLD; j++) { lx0[j] = Rw.lm_jar[j]; lv[j] = -Rw.lm_side[j] * hl[j]; lD[j] = Rw.lm_side[j] != 0 ? Rw.lm_D[j] : R(0); }
@@ -1281,7 +1291,7 @@ LD int newton_body(const LimbModelT<R>& m, int lane, const KIN& kin, const MS& m
     LUNROLL for (int k = 0; k < kTD; k++) dt[k] = at[k] - st[k];
     arrow_mul_s(ms, dl, dt, Mal, Mat);
     const R gauss = R(0.5) * arrow_dot(dl, dt, Mal, Mat);
-    const R newcost = gauss + rows_eval(m, L, lane, kin, Rw, cs, ncon, sh, nx, true, hl, ht, alpha, fc_l, fc_t);
+    const R newcost = gauss + rows_eval(m, L, lane, kin, Rw, cs, ncon, sh, nx, true, hl, ht, alpha, fc_l, fc_t, VL, VR);
     improvement = cost - newcost;
     cost = newcost;
     iters = iter + 1;
