@@ -129,3 +129,37 @@ def test_device_noise_and_sharding(walk):
     ctx.rollout_noise(N // 2, H, 2, times, nominal, half)
     assert np.array_equal(ctx.returns()[0], ret[N // 2:])
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["cross_entropy", "sampling_two_scales"])
+def test_the_other_noise_streams_through_the_limb_kernel(walk, mode):
+    """CrossEntropyPlanner::AddNoiseToPolicy (per-parameter variance with the explore / exploit floors, the nominal candidate left clean:
+    cross_entropy/planner.cc:351-385) and the sampling planner's second noise scale (a fifth of the candidates: sampling/planner.cc:326-352),
+    drawn by the limb kernel itself: the nodes it leaves and the returns are the oracle's"""
+    t, state, mocap = walk
+    pm, pt = t.packed_model(), t.packed()
+    N, H, P = 128, 24, 6
+    nu = t.model.nu
+    dt = t.model.get_number("agent_timestep", t.model.timestep)
+    times = np.arange(P) * ((H - 1) * dt / (P - 1))
+    rng = np.random.default_rng(17)
+    nominal = np.clip(rng.normal(0, 0.2, (P, nu)), -1, 1)
+    if mode == "cross_entropy":
+        var = rng.uniform(0.0, 0.05, P * nu) ** 2   # some below the floors, some above
+        ns = capi.make_noise_spec(seed=5, iteration=2, mode=capi.NOISE_CROSS_ENTROPY, std0=0.08, std1=0.01, explore_count=N // 4,
+                                  nominal_candidate=N - 1, param_variance=var)
+    else:
+        ns = capi.make_noise_spec(seed=5, iteration=2, mode=capi.NOISE_SAMPLING, std0=0.05, std1=0.2)
+    ctx = limb_context(pm, pt, 64)
+    ctx.set_state(state, 0.0, mocap)
+    ctx.rollout_noise(N, H, 2, times, nominal, ns)
+    ret, fail = ctx.returns()
+    sample = np.arange(N)
+    nodes = pyoracle.noise_candidates(pm, ns, P, nominal, sample)
+    for c in (0, 1, N // 4 - 1, N // 4, N - 2, N - 1):
+        assert np.max(np.abs(ctx.fetch_spline(c) - nodes[c])) < 1e-13, c   # (device log / cos against libm's: an ulp)
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, N, H, P, 2, times, nodes, num_threads=8)
+    assert np.array_equal(fail, ref["failure"])
+    ok = fail == 0
+    assert ok.sum() >= N - 4 and close(ret[ok], ref["total_return"][ok], 1e-8)
+    ctx.close()
