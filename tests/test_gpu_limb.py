@@ -163,3 +163,39 @@ def test_the_other_noise_streams_through_the_limb_kernel(walk, mode):
     ok = fail == 0
     assert ok.sum() >= N - 4 and close(ret[ok], ref["total_return"][ok], 1e-8)
     ctx.close()
+
+
+def test_collapse_keeps_tendon_limit_rows_in_the_limb_kernel():
+    """From a spinning crouch with near-random controls the body folds: arms and legs touch, the hamstring tendons reach their limits. Candidates
+    the limb form covers stay in the limb kernel, the others are handed on -- and the oracle's census of the rollouts says that candidates with
+    an active tendon-limit row and with contacts between moving geoms are among those the limb kernel KEPT (its tendon row and its Woodbury
+    terms are exercised on the device, not only in the emulator)"""
+    from test_gpu_full_size import humanoid_census
+    t = load_task("HumanoidTrack")
+    e = t.transition(0.0, mode=4)   # Crouch Flip
+    v = np.zeros(27)
+    v[3:6] = [1.5, -1.0, 0.5]
+    state, mocap = np.concatenate([e["qpos"], v]), mocap7(e["mocap_pos"])
+    pm, pt = t.packed_model(), t.packed()
+    N, H, P = 16, 60, 4
+    dt = t.model.get_number("agent_timestep", t.model.timestep)
+    times = np.arange(P) * ((H - 1) * dt / (P - 1))
+    nodes = np.clip(np.random.default_rng(9).normal(0, 0.8, (N, P, t.model.nu)), -1, 1)
+    os.environ["MJPCX_LIMB_NO_FALLBACK"] = "1"   # which candidates the limb kernel kept: the others stay flagged in this context
+    try:
+        ctx = limb_context(pm, pt, 64)
+    finally:
+        os.environ.pop("MJPCX_LIMB_NO_FALLBACK", None)
+    ctx.set_state(state, 0.0, mocap)
+    ctx.rollout_splines(H, 0, times, nodes)
+    ret, _ = ctx.returns()
+    kept = (np.asarray(ctx.failure_raw) & 0x40000000) == 0
+    ref = pyoracle.rollout_batch(pm, pt, state, 0.0, mocap, N, H, P, 0, times, nodes, num_threads=8)
+    ok = kept & (ref["failure"] == 0)
+    assert ok.sum() >= 4, (int(kept.sum()), int((ref["failure"] == 0).sum()))
+    assert close(ret[ok], ref["total_return"][ok], 1e-6)
+    idx = np.flatnonzero(ok)
+    selfc, tendon, _ = humanoid_census(t, mocap, ref["states"][idx], ref["times"][idx])
+    print(f"kept {int(kept.sum())} of {N}; of the {len(idx)} compared: tendon-limit rows in {len(tendon)}, contacts between moving geoms in {len(selfc)}")
+    assert len(tendon) >= 1 and len(selfc) >= 1
+    ctx.close()
